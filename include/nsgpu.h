@@ -1,0 +1,140 @@
+/*
+ * nsgpu.h -- C-ABI of libnsgpu.so, the MI355X (gfx950) implementation of
+ * NanoSpring's read-clustering + reference-encode hot path.
+ *
+ * Every entry point replaces one seam of the reference (paths relative to the
+ * NanoSpring tree); INTEGRATION.md shows the C++ adaptor a maintainer adds on the
+ * reference side.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative nsgpu_status on error;
+ *     nsgpu_last_error() returns a thread-local message (the adaptor rethrows it
+ *     as std::runtime_error, as the reference does, src/main.cpp:161-176).
+ *   - inputs are borrowed for the duration of the call; outputs named *_out are
+ *     caller-allocated; outputs returned through T** are library-allocated and
+ *     released with nsgpu_free().
+ *   - all device work of a context is issued on ONE HIP stream (nsgpu_set_stream,
+ *     default: a stream created by the context).  Calls whose name ends in
+ *     _async only enqueue; everything else synchronises that stream before
+ *     returning host-visible results.
+ *   - base alphabet is the reference's: code(c) = (c & 2) | ((c & 4) >> 2), i.e.
+ *     A0 T1 C2 G3, N (and anything else) folds through the same bits
+ *     (src/dnaToBits.cpp:6-8); 2-bit packing is MSB-first, 4 bases per byte
+ *     (src/dnaToBits.cpp:10-36).
+ */
+#ifndef NSGPU_H_
+#define NSGPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nsgpu_ctx nsgpu_ctx;
+
+typedef enum {
+    NSGPU_OK = 0,
+    NSGPU_ERR_ARG = -1,      /* bad argument / call order */
+    NSGPU_ERR_HIP = -2,      /* HIP runtime error (message has hipGetErrorString) */
+    NSGPU_ERR_NOMEM = -3,
+    NSGPU_ERR_RANGE = -4,    /* value exceeds a format limit (e.g. > 2^32-1 reads, "Too many reads for read_t", src/ReadData.cpp:194-196) */
+    NSGPU_ERR_NODEV = -5     /* no gfx950 device visible: the product path never falls back to the CPU */
+} nsgpu_status;
+
+/* The public fields of Compressor / MinHashReadFilter / Consensus that reach the
+ * hot path (include/Compressor.h:10-35, include/ReadFilter.h:36-44,
+ * include/Consensus.h:37-63). */
+typedef struct {
+    uint32_t k;                  /* MinHash k-mer size, -k (default 23); 1 <= k <= 31 */
+    uint32_t n;                  /* sketch size, -n / --num-hash (default 60); 1 <= n <= 256 */
+    uint32_t overlap_sketch_thr; /* --overlap-sketch-thr (default 6) */
+    uint32_t m_k;                /* --minimap-k (default 20), <= 28 */
+    uint32_t m_w;                /* --minimap-w (default 50), < 256 */
+    uint32_t max_chain_iter;     /* --max-chain-iter (default 400) */
+    uint64_t edge_threshold;     /* --edge-thr (default 4000000) */
+    int32_t  device;             /* HIP device ordinal */
+    int32_t  reserved;
+} nsgpu_params;
+
+void nsgpu_default_params(nsgpu_params *p);
+
+/* ---- life cycle ---------------------------------------------------------- */
+int  nsgpu_create(const nsgpu_params *p, nsgpu_ctx **ctx_out);
+void nsgpu_destroy(nsgpu_ctx *ctx);
+void nsgpu_free(void *p);
+const char *nsgpu_last_error(void);
+/* hipStream_t as void*; NULL restores the context's own stream. */
+int  nsgpu_set_stream(nsgpu_ctx *ctx, void *hip_stream);
+int  nsgpu_sync(nsgpu_ctx *ctx);
+/* library build id + "gfx950"; never NULL */
+const char *nsgpu_version(void);
+
+/* ---- read store: replaces ReadData::loadFromFastqFile_lowmem's DnaBitset temp
+ *      file + ReadData::getRead (src/ReadData.cpp:156-235) ----------------------
+ * Reads become 2-bit packed rows resident in HBM (each row 16-byte aligned). */
+/* ASCII in: bases = concatenation of N reads, off[N+1] byte offsets. Packing runs on the GPU. */
+int nsgpu_load_reads_ascii(nsgpu_ctx *ctx, const char *bases, const uint64_t *off, uint32_t n_reads);
+/* Already-packed in (the bytes DnaBitset::to_file writes, src/dnaToBits.cpp:100-103):
+ * read r occupies packed[byte_off[r] .. byte_off[r] + (len[r]+3)/4). */
+int nsgpu_load_reads_packed(nsgpu_ctx *ctx, const uint8_t *packed, const uint64_t *byte_off,
+                            const uint32_t *len, uint32_t n_reads);
+uint32_t nsgpu_num_reads(const nsgpu_ctx *ctx);
+uint64_t nsgpu_num_bases(const nsgpu_ctx *ctx);
+/* ReadData::getRead (src/ReadData.cpp:225-235): read r as ASCII (A/T/C/G), out must hold len[r] bytes. */
+int nsgpu_get_read(nsgpu_ctx *ctx, uint32_t r, char *out, uint32_t *len_out);
+/* DnaBitset bytes of read r (checker for a1); out must hold (len+3)/4 bytes. */
+int nsgpu_get_read_packed(nsgpu_ctx *ctx, uint32_t r, uint8_t *out, uint32_t *len_out);
+
+/* ---- MinHash sketch + bucket tables: replaces MinHashReadFilter::initialize
+ *      (src/ReadFilter.cpp:11-47).  The n salts are an explicit input (the
+ *      reference draws them from std::random_device, src/ReadFilter.cpp:49-63). */
+/* string2Sketch for every read (src/ReadFilter.cpp:117-136). sketches_out: N*n u64 row-major by read, or NULL. */
+int nsgpu_sketch(nsgpu_ctx *ctx, const uint64_t *salts, uint64_t *sketches_out);
+/* populateHashTables (src/ReadFilter.cpp:159-172; BBHashMap::initialize, src/BBHashMap.cpp:10-99). */
+int nsgpu_build_index(nsgpu_ctx *ctx);
+/* Table j as (distinct keys ascending, CSR start, ascending read ids) -- checker for a7.
+ * keys_out: N u64, start_out: N+1 u32, ids_out: N u32; *nkeys_out distinct keys. */
+int nsgpu_index_export(nsgpu_ctx *ctx, uint32_t j, uint64_t *keys_out, uint32_t *start_out,
+                       uint32_t *ids_out, uint32_t *nkeys_out);
+
+/* ---- overlap candidates: replaces ReadFilter::getFilteredReads
+ *      (include/ReadFilter.h:24, src/ReadFilter.cpp:65-97) ------------------- */
+/* One query string; *ids is library-allocated (nsgpu_free), ascending read ids. */
+int nsgpu_filter(nsgpu_ctx *ctx, const char *s, size_t len, uint32_t **ids, size_t *n_ids);
+/* Q query strings (strs + qoff[Q+1]); results as CSR: (*out_off)[Q+1], (*out_ids)[(*out_off)[Q]]. */
+int nsgpu_filter_batch(nsgpu_ctx *ctx, const char *strs, const uint64_t *qoff, uint32_t n_queries,
+                       uint64_t **out_off, uint32_t **out_ids);
+/* Whole-read queries for every loaded read, forward (query 2r) and reverse-complement
+ * (query 2r+1) -- the first window of every contig in Consensus::addRelatedReads
+ * (src/Consensus.cpp:170-189).  Device resident; returns the total candidate count. */
+int nsgpu_filter_all_reads(nsgpu_ctx *ctx, uint64_t *n_candidates_out);
+/* copy the result of nsgpu_filter_all_reads to the host: off_out 2N+1 u64, ids_out n_candidates u32 */
+int nsgpu_filter_all_fetch(nsgpu_ctx *ctx, uint64_t *off_out, uint32_t *ids_out);
+
+/* ---- Consensus::checkRepetitive for every read (src/Consensus.cpp:405-442) -- */
+int nsgpu_check_repetitive(nsgpu_ctx *ctx, uint8_t *flags_out);
+
+/* ---- timing of the last call of each stage, in ms, measured with HIP events on
+ *      the context's stream (for bench.py's roofline object) ------------------ */
+typedef struct {
+    float pack_ms, sketch_ms, index_ms, filter_ms, repetitive_ms;
+    float sketch_kernel_ms;   /* the xor-min kernel alone */
+    float filter_kernel_ms;
+    uint64_t filter_matches;  /* sum of M over queries of the last filter call */
+} nsgpu_timing;
+int nsgpu_get_timing(const nsgpu_ctx *ctx, nsgpu_timing *t);
+
+/* ---- synthetic reads (SURVEY 8d model; host side, deterministic per seed):
+ *      iid genome of length G, reads start uniform, strand 50/50, length
+ *      max(500, Gamma(2, mean/2)), per-base sub/ins/del at the given rates.
+ *      Allocates *bases_out (ASCII, concatenated) and *off_out (n_reads+1). ---- */
+int nsgpu_synth_reads(uint64_t seed, uint64_t genome_len, uint32_t n_reads, double mean_len,
+                      double p_sub, double p_ins, double p_del,
+                      char **bases_out, uint64_t **off_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSGPU_H_ */

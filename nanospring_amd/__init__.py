@@ -1,0 +1,13 @@
+"""nanospring_amd -- MI355X (gfx950) implementation of NanoSpring's read-clustering
++ reference-encode hot path.
+
+The product is libnsgpu.so (hand-written HIP behind the C-ABI of include/nsgpu.h).
+This package is the thin host-side mirror used by the tests and bench.py; it has
+no CPU fallback: importing works anywhere, but every operator raises
+NsGpuError when the library or a gfx950 device is missing.
+"""
+from ._lib import NsGpuError, lib_path, load_library, Params, Timing  # noqa: F401
+from .filter import NsGpu, MinHashReadFilter, mt19937_64_salts, synth_reads  # noqa: F401
+
+__all__ = ["NsGpuError", "lib_path", "load_library", "Params", "Timing", "NsGpu", "MinHashReadFilter",
+           "mt19937_64_salts", "synth_reads"]

@@ -1,0 +1,352 @@
+// api.hip -- the C-ABI of libnsgpu.so (include/nsgpu.h): context life cycle, the
+// HBM read store and the MinHash stages.  No CPU fallback exists: without a
+// gfx950 device nsgpu_create fails with NSGPU_ERR_NODEV.
+#include "common.hpp"
+#include <cstdarg>
+#include <algorithm>
+
+namespace nsgpu {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static uint64_t row_bytes_h(uint32_t len) { return ((((uint64_t)len + 3) / 4 + 15) & ~(uint64_t)15) + 16; }
+
+// decide the HBM layout of a set of sequences and upload offsets/lengths
+static int store_prepare(nsgpu_ctx *c, SeqStore &st, const uint32_t *len, uint32_t n)
+{
+    st.n = n;
+    st.h_len.assign(len, len + n);
+    st.h_poff.resize((size_t)n + 1);
+    uint64_t off = 0, nb = 0;
+    uint32_t mx = 0;
+    for (uint32_t r = 0; r < n; ++r) {
+        st.h_poff[r] = off;
+        off += row_bytes_h(len[r]);
+        nb += len[r];
+        mx = std::max(mx, len[r]);
+    }
+    st.h_poff[n] = off;
+    st.packed_bytes = off;
+    st.n_bases = nb;
+    st.max_len = mx;
+    NS_TRY(st.packed.reserve(off + 64));
+    NS_TRY(st.poff.reserve(((size_t)n + 1) * 8));
+    NS_TRY(st.len.reserve(((size_t)n + 1) * 4));
+    NS_HIP(hipMemcpyAsync(st.poff.p, st.h_poff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (n) NS_HIP(hipMemcpyAsync(st.len.p, st.h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    return NSGPU_OK;
+}
+
+static int store_from_ascii(nsgpu_ctx *c, SeqStore &st, const char *bases, const uint64_t *off, uint32_t n)
+{
+    std::vector<uint32_t> len(n);
+    for (uint32_t r = 0; r < n; ++r) {
+        NS_CHECK(off[r + 1] >= off[r], NSGPU_ERR_ARG, "offsets must be non-decreasing (read %u)", r);
+        NS_CHECK(off[r + 1] - off[r] <= 0xFFFFFFF0ull, NSGPU_ERR_RANGE, "read %u longer than 2^32-16 bases", r);
+        len[r] = (uint32_t)(off[r + 1] - off[r]);
+    }
+    NS_TRY(store_prepare(c, st, len.data(), n));
+    const uint64_t total = n ? off[n] - off[0] : 0;
+    NS_TRY(c->ascii.reserve(total + 64));
+    NS_TRY(c->aoff.reserve(((size_t)n + 1) * 8));
+    std::vector<uint64_t> rel((size_t)n + 1);
+    for (uint32_t r = 0; r <= n; ++r) rel[r] = off[r] - off[0];
+    if (total) NS_HIP(hipMemcpyAsync(c->ascii.p, bases + off[0], total, hipMemcpyHostToDevice, c->stream));
+    NS_HIP(hipMemcpyAsync(c->aoff.p, rel.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    NS_HIP(hipEventRecord(c->t_kernel.a, c->stream));
+    NS_TRY(launch_pack_ascii(c, c->ascii.as<char>(), c->aoff.as<uint64_t>(), st));
+    NS_HIP(hipEventRecord(c->t_kernel.b, c->stream));
+    NS_HIP(hipStreamSynchronize(c->stream));   // rel / len vectors go out of scope
+    NS_HIP(hipEventElapsedTime(&c->timing.pack_ms, c->t_kernel.a, c->t_kernel.b));
+    return NSGPU_OK;
+}
+
+}  // namespace nsgpu
+
+using namespace nsgpu;
+
+extern "C" {
+
+const char *nsgpu_last_error(void) { return g_err; }
+const char *nsgpu_version(void) { return "nsgpu 0.1 (gfx950, hipcc " __VERSION__ ")"; }
+void nsgpu_free(void *p) { free(p); }
+
+void nsgpu_default_params(nsgpu_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->k = 23; p->n = 60; p->overlap_sketch_thr = 6;          // src/main.cpp:52-60
+    p->m_k = 20; p->m_w = 50; p->max_chain_iter = 400;        // src/main.cpp:62-70
+    p->edge_threshold = 4000000;                              // src/main.cpp:72
+    p->device = 0;
+}
+
+int nsgpu_create(const nsgpu_params *p, nsgpu_ctx **ctx_out)
+{
+    NS_CHECK(p && ctx_out, NSGPU_ERR_ARG, "nsgpu_create: null argument");
+    NS_CHECK(p->k >= 1 && p->k <= 31, NSGPU_ERR_ARG, "k must be in 1..31 (2k-bit k-mers in a u64; k=32 is UB in the reference too, src/ReadFilter.cpp:145)");
+    NS_CHECK(p->n >= 1 && p->n <= 256, NSGPU_ERR_ARG, "n (sketch size) must be in 1..256");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        set_error("no HIP device visible (%s); libnsgpu has no CPU fallback", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return NSGPU_ERR_NODEV;
+    }
+    NS_CHECK(p->device >= 0 && p->device < ndev, NSGPU_ERR_ARG, "device %d out of range (have %d)", p->device, ndev);
+    NS_HIP(hipSetDevice(p->device));
+    hipDeviceProp_t prop;
+    NS_HIP(hipGetDeviceProperties(&prop, p->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libnsgpu is built for gfx950 only", p->device, prop.gcnArchName);
+        return NSGPU_ERR_NODEV;
+    }
+    nsgpu_ctx *c = new nsgpu_ctx();
+    c->prm = *p;
+    c->n_cu = prop.multiProcessorCount;
+    memset(&c->timing, 0, sizeof(c->timing));
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; set_error("hipStreamCreate failed"); return NSGPU_ERR_HIP; }
+    c->stream = c->own_stream;
+    if (c->t_stage.init() != NSGPU_OK || c->t_kernel.init() != NSGPU_OK) { delete c; return NSGPU_ERR_HIP; }
+    *ctx_out = c;
+    return NSGPU_OK;
+}
+
+void nsgpu_destroy(nsgpu_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->prm.device);
+    (void)hipStreamSynchronize(c->stream);
+    c->reads.release(); c->queries.release();
+    DevBuf *bufs[] = {&c->ascii, &c->aoff, &c->salts, &c->sketch, &c->sketch_rc, &c->qsketch, &c->idx_keys, &c->idx_ids, &c->idx_tmp_k,
+                      &c->idx_tmp_v, &c->idx_tmp_e, &c->idx_tmp_e2, &c->idx_sort_ws, &c->f_pool, &c->f_qstart, &c->f_qcnt, &c->f_qm, &c->f_off,
+                      &c->f_ids, &c->f_ctrl, &c->f_ovf_list, &c->f_ovf_cnt, &c->f_scan_ws, &c->rep_flags};
+    for (DevBuf *b : bufs) b->release();
+    c->t_stage.destroy(); c->t_kernel.destroy();
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int nsgpu_set_stream(nsgpu_ctx *c, void *s)
+{
+    NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
+    NS_HIP(hipStreamSynchronize(c->stream));
+    c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+    return NSGPU_OK;
+}
+
+int nsgpu_sync(nsgpu_ctx *c)
+{
+    NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
+    NS_HIP(hipStreamSynchronize(c->stream));
+    return NSGPU_OK;
+}
+
+int nsgpu_load_reads_ascii(nsgpu_ctx *c, const char *bases, const uint64_t *off, uint32_t n)
+{
+    NS_CHECK(c && off && (bases || n == 0 || off[n] == off[0]), NSGPU_ERR_ARG, "nsgpu_load_reads_ascii: null argument");
+    NS_HIP(hipSetDevice(c->prm.device));
+    c->have_sketch = c->have_index = c->have_filter_all = false;
+    return store_from_ascii(c, c->reads, bases, off, n);
+}
+
+int nsgpu_load_reads_packed(nsgpu_ctx *c, const uint8_t *packed, const uint64_t *byte_off, const uint32_t *len, uint32_t n)
+{
+    NS_CHECK(c && (n == 0 || (packed && byte_off && len)), NSGPU_ERR_ARG, "nsgpu_load_reads_packed: null argument");
+    NS_HIP(hipSetDevice(c->prm.device));
+    c->have_sketch = c->have_index = c->have_filter_all = false;
+    NS_TRY(store_prepare(c, c->reads, len, n));
+    SeqStore &st = c->reads;
+    // DnaBitset bytes are already in the row format; rows only need re-basing to
+    // 16-byte aligned, zero padded slots.
+    std::vector<uint8_t> stage(st.packed_bytes + 64, 0);
+    for (uint32_t r = 0; r < n; ++r) memcpy(stage.data() + st.h_poff[r], packed + byte_off[r], ((size_t)len[r] + 3) / 4);
+    NS_HIP(hipMemcpyAsync(st.packed.p, stage.data(), st.packed_bytes, hipMemcpyHostToDevice, c->stream));
+    NS_HIP(hipStreamSynchronize(c->stream));
+    return NSGPU_OK;
+}
+
+uint32_t nsgpu_num_reads(const nsgpu_ctx *c) { return c ? c->reads.n : 0; }
+uint64_t nsgpu_num_bases(const nsgpu_ctx *c) { return c ? c->reads.n_bases : 0; }
+
+int nsgpu_get_read_packed(nsgpu_ctx *c, uint32_t r, uint8_t *out, uint32_t *len_out)
+{
+    NS_CHECK(c && out, NSGPU_ERR_ARG, "null argument");
+    NS_CHECK(r < c->reads.n, NSGPU_ERR_ARG, "read id %u out of range (%u reads)", r, c->reads.n);
+    const uint32_t L = c->reads.h_len[r];
+    if (len_out) *len_out = L;
+    const size_t nb = ((size_t)L + 3) / 4;
+    if (nb) NS_HIP(hipMemcpyAsync(out, c->reads.packed.as<uint8_t>() + c->reads.h_poff[r], nb, hipMemcpyDeviceToHost, c->stream));
+    NS_HIP(hipStreamSynchronize(c->stream));
+    return NSGPU_OK;
+}
+
+int nsgpu_get_read(nsgpu_ctx *c, uint32_t r, char *out, uint32_t *len_out)
+{
+    NS_CHECK(c && out, NSGPU_ERR_ARG, "null argument");
+    NS_CHECK(r < c->reads.n, NSGPU_ERR_ARG, "read id %u out of range (%u reads)", r, c->reads.n);
+    const uint32_t L = c->reads.h_len[r];
+    std::vector<uint8_t> pk(((size_t)L + 3) / 4 + 1);
+    NS_TRY(nsgpu_get_read_packed(c, r, pk.data(), len_out));
+    static const char dna[4] = {'A', 'T', 'C', 'G'};          // DnaBitset::to_string, src/dnaToBits.cpp:81-98
+    for (uint32_t i = 0; i < L; ++i) out[i] = dna[(pk[i >> 2] >> (6 - 2 * (i & 3))) & 3];
+    return NSGPU_OK;
+}
+
+int nsgpu_sketch(nsgpu_ctx *c, const uint64_t *salts, uint64_t *sketches_out)
+{
+    NS_CHECK(c && salts, NSGPU_ERR_ARG, "nsgpu_sketch: null argument");
+    NS_HIP(hipSetDevice(c->prm.device));
+    const uint32_t N = c->reads.n, n = c->prm.n;
+    NS_TRY(c->salts.reserve((size_t)n * 8));
+    NS_HIP(hipMemcpyAsync(c->salts.p, salts, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    c->have_salts = true;
+    NS_TRY(c->sketch.reserve(((size_t)N * n + 1) * 8));
+    NS_HIP(hipEventRecord(c->t_stage.a, c->stream));
+    NS_TRY(launch_sketch(c, c->reads, c->sketch.as<uint64_t>(), nullptr));
+    NS_HIP(hipEventRecord(c->t_stage.b, c->stream));
+    if (sketches_out && N) NS_HIP(hipMemcpyAsync(sketches_out, c->sketch.p, (size_t)N * n * 8, hipMemcpyDeviceToHost, c->stream));
+    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(hipEventElapsedTime(&c->timing.sketch_kernel_ms, c->t_stage.a, c->t_stage.b));
+    c->timing.sketch_ms = c->timing.sketch_kernel_ms;
+    c->have_sketch = true;
+    c->have_index = c->have_filter_all = false;
+    return NSGPU_OK;
+}
+
+int nsgpu_build_index(nsgpu_ctx *c)
+{
+    NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
+    NS_CHECK(c->have_sketch, NSGPU_ERR_ARG, "nsgpu_build_index: call nsgpu_sketch first");
+    NS_HIP(hipSetDevice(c->prm.device));
+    NS_HIP(hipEventRecord(c->t_stage.a, c->stream));
+    NS_TRY(build_index(c));
+    NS_HIP(hipEventRecord(c->t_stage.b, c->stream));
+    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(hipEventElapsedTime(&c->timing.index_ms, c->t_stage.a, c->t_stage.b));
+    c->have_index = true;
+    c->have_filter_all = false;
+    return NSGPU_OK;
+}
+
+int nsgpu_index_export(nsgpu_ctx *c, uint32_t j, uint64_t *keys_out, uint32_t *start_out, uint32_t *ids_out, uint32_t *nkeys_out)
+{
+    NS_CHECK(c && keys_out && start_out && ids_out && nkeys_out, NSGPU_ERR_ARG, "null argument");
+    NS_CHECK(c->have_index, NSGPU_ERR_ARG, "nsgpu_index_export: no index");
+    NS_CHECK(j < c->prm.n, NSGPU_ERR_ARG, "table %u out of range", j);
+    const uint32_t N = c->reads.n;
+    std::vector<uint64_t> k(N);
+    if (N) {
+        NS_HIP(hipMemcpyAsync(k.data(), c->idx_keys.as<uint64_t>() + (size_t)j * N, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
+        NS_HIP(hipMemcpyAsync(ids_out, c->idx_ids.as<uint32_t>() + (size_t)j * N, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    NS_HIP(hipStreamSynchronize(c->stream));
+    uint32_t u = 0;
+    for (uint32_t i = 0; i < N; ++i)
+        if (i == 0 || k[i] != k[i - 1]) { keys_out[u] = k[i]; start_out[u] = i; ++u; }
+    start_out[u] = N;
+    *nkeys_out = u;
+    return NSGPU_OK;
+}
+
+static int filter_strings(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq)
+{
+    NS_CHECK(c->have_index && c->have_salts, NSGPU_ERR_ARG, "filter: build the index first");
+    NS_HIP(hipSetDevice(c->prm.device));
+    NS_HIP(hipEventRecord(c->t_stage.a, c->stream));
+    NS_TRY(store_from_ascii(c, c->queries, strs, qoff, nq));
+    NS_TRY(c->qsketch.reserve(((size_t)nq * c->prm.n + 1) * 8));
+    NS_TRY(launch_sketch(c, c->queries, c->qsketch.as<uint64_t>(), nullptr));
+    NS_TRY(run_filter(c, c->qsketch.as<uint64_t>(), nullptr, nq, false));
+    NS_HIP(hipEventRecord(c->t_stage.b, c->stream));
+    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(hipEventElapsedTime(&c->timing.filter_ms, c->t_stage.a, c->t_stage.b));
+    c->have_filter_all = false;
+    return NSGPU_OK;
+}
+
+int nsgpu_filter_batch(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq, uint64_t **out_off, uint32_t **out_ids)
+{
+    NS_CHECK(c && qoff && out_off && out_ids, NSGPU_ERR_ARG, "nsgpu_filter_batch: null argument");
+    NS_TRY(filter_strings(c, strs, qoff, nq));
+    uint64_t *off = (uint64_t *)malloc(((size_t)nq + 1) * 8);
+    uint32_t *ids = (uint32_t *)malloc((c->f_total + 1) * 4);
+    NS_CHECK(off && ids, NSGPU_ERR_NOMEM, "malloc failed");
+    NS_HIP(hipMemcpyAsync(off, c->f_off.p, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (c->f_total) NS_HIP(hipMemcpyAsync(ids, c->f_ids.p, c->f_total * 4, hipMemcpyDeviceToHost, c->stream));
+    NS_HIP(hipStreamSynchronize(c->stream));
+    *out_off = off;
+    *out_ids = ids;
+    return NSGPU_OK;
+}
+
+int nsgpu_filter(nsgpu_ctx *c, const char *s, size_t len, uint32_t **ids, size_t *n_ids)
+{
+    NS_CHECK(c && ids && n_ids && (s || len == 0), NSGPU_ERR_ARG, "nsgpu_filter: null argument");
+    uint64_t qoff[2] = {0, (uint64_t)len};
+    uint64_t *off = nullptr;
+    NS_TRY(nsgpu_filter_batch(c, s, qoff, 1, &off, ids));
+    *n_ids = (size_t)off[1];
+    free(off);
+    return NSGPU_OK;
+}
+
+int nsgpu_filter_all_reads(nsgpu_ctx *c, uint64_t *n_candidates_out)
+{
+    NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
+    NS_CHECK(c->have_index && c->have_sketch, NSGPU_ERR_ARG, "nsgpu_filter_all_reads: build the index first");
+    NS_HIP(hipSetDevice(c->prm.device));
+    const uint32_t N = c->reads.n, n = c->prm.n;
+    NS_CHECK((uint64_t)N * 2 < (1ull << 32), NSGPU_ERR_RANGE, "too many reads for 2N queries");
+    NS_TRY(c->sketch_rc.reserve(((size_t)N * n + 1) * 8));
+    NS_HIP(hipEventRecord(c->t_stage.a, c->stream));
+    NS_TRY(launch_sketch(c, c->reads, nullptr, c->sketch_rc.as<uint64_t>()));
+    NS_TRY(run_filter(c, c->sketch.as<uint64_t>(), c->sketch_rc.as<uint64_t>(), 2 * N, true));
+    NS_HIP(hipEventRecord(c->t_stage.b, c->stream));
+    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(hipEventElapsedTime(&c->timing.filter_ms, c->t_stage.a, c->t_stage.b));
+    c->have_filter_all = true;
+    if (n_candidates_out) *n_candidates_out = c->f_total;
+    return NSGPU_OK;
+}
+
+int nsgpu_filter_all_fetch(nsgpu_ctx *c, uint64_t *off_out, uint32_t *ids_out)
+{
+    NS_CHECK(c && off_out, NSGPU_ERR_ARG, "null argument");
+    NS_CHECK(c->have_filter_all, NSGPU_ERR_ARG, "nsgpu_filter_all_fetch: call nsgpu_filter_all_reads first");
+    NS_HIP(hipMemcpyAsync(off_out, c->f_off.p, ((size_t)c->f_nq + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (c->f_total && ids_out) NS_HIP(hipMemcpyAsync(ids_out, c->f_ids.p, c->f_total * 4, hipMemcpyDeviceToHost, c->stream));
+    NS_HIP(hipStreamSynchronize(c->stream));
+    return NSGPU_OK;
+}
+
+int nsgpu_check_repetitive(nsgpu_ctx *c, uint8_t *flags_out)
+{
+    NS_CHECK(c && flags_out, NSGPU_ERR_ARG, "null argument");
+    NS_HIP(hipSetDevice(c->prm.device));
+    const uint32_t N = c->reads.n;
+    NS_TRY(c->rep_flags.reserve((size_t)N + 16));
+    NS_HIP(hipEventRecord(c->t_stage.a, c->stream));
+    NS_TRY(launch_repetitive(c, c->reads, c->rep_flags.as<uint8_t>()));
+    NS_HIP(hipEventRecord(c->t_stage.b, c->stream));
+    if (N) NS_HIP(hipMemcpyAsync(flags_out, c->rep_flags.p, N, hipMemcpyDeviceToHost, c->stream));
+    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(hipEventElapsedTime(&c->timing.repetitive_ms, c->t_stage.a, c->t_stage.b));
+    return NSGPU_OK;
+}
+
+int nsgpu_get_timing(const nsgpu_ctx *c, nsgpu_timing *t)
+{
+    NS_CHECK(c && t, NSGPU_ERR_ARG, "null argument");
+    *t = c->timing;
+    return NSGPU_OK;
+}
+
+}  // extern "C"

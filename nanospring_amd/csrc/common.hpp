@@ -1,0 +1,122 @@
+// common.hpp -- context, error handling and device-buffer helpers shared by the
+// translation units of libnsgpu.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/nsgpu.h"
+
+namespace nsgpu {
+
+void set_error(const char *fmt, ...);
+
+#define NS_HIP(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            nsgpu::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return NSGPU_ERR_HIP;                                                          \
+        }                                                                                  \
+    } while (0)
+
+#define NS_CHECK(cond, code, ...)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            nsgpu::set_error(__VA_ARGS__);        \
+            return (code);                        \
+        }                                         \
+    } while (0)
+
+#define NS_TRY(expr)                 \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != NSGPU_OK) return rc_; \
+    } while (0)
+
+// Growable device allocation (never shrinks). No hipMalloc happens inside a
+// stage once the buffers have reached their steady-state size.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return NSGPU_OK;
+        if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
+        size_t want = bytes + (bytes >> 3) + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            p = nullptr;
+            return NSGPU_ERR_NOMEM;
+        }
+        cap = want;
+        return NSGPU_OK;
+    }
+    void release() { if (p) { hipError_t e = hipFree(p); (void)e; } p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// A set of 2-bit packed sequences in HBM.  Row r starts at byte poff[r]
+// (16-byte aligned, zero padded to the next 16 bytes plus 16 more so that
+// kernels may over-read two dwords) and holds len[r] bases, MSB-first.
+struct SeqStore {
+    DevBuf packed, poff, len;
+    uint32_t n = 0;
+    uint64_t packed_bytes = 0;
+    uint64_t n_bases = 0;
+    uint32_t max_len = 0;
+    std::vector<uint64_t> h_poff;   // host mirrors (needed by get_read and job planning)
+    std::vector<uint32_t> h_len;
+    void release() { packed.release(); poff.release(); len.release(); n = 0; }
+};
+
+struct Timer {
+    hipEvent_t a = nullptr, b = nullptr;
+    int init() { NS_HIP(hipEventCreate(&a)); NS_HIP(hipEventCreate(&b)); return NSGPU_OK; }
+    void destroy() { if (a) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } a = b = nullptr; }
+};
+
+}  // namespace nsgpu
+
+struct nsgpu_ctx {
+    nsgpu_params prm;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    int n_cu = 256;
+    nsgpu::SeqStore reads;       // the loaded reads
+    nsgpu::SeqStore queries;     // scratch store for window/query strings
+    nsgpu::DevBuf ascii, aoff;   // staging for ASCII uploads
+    nsgpu::DevBuf salts;         // n u64
+    bool have_salts = false, have_sketch = false, have_index = false, have_filter_all = false;
+    nsgpu::DevBuf sketch;        // N*n u64, row-major by read (fwd)
+    nsgpu::DevBuf sketch_rc;     // N*n u64 (whole-read RC queries)
+    nsgpu::DevBuf qsketch;       // Q*n u64 (string queries)
+    // bucket index: per slot j, keys sorted ascending (idx_keys[j*N+i]) with the
+    // read ids in the same order (idx_ids[j*N+i], ascending within equal keys)
+    nsgpu::DevBuf idx_keys, idx_ids, idx_tmp_k, idx_tmp_v, idx_tmp_e, idx_tmp_e2, idx_sort_ws;
+    // filter results
+    nsgpu::DevBuf f_pool, f_qstart, f_qcnt, f_qm, f_off, f_ids, f_ctrl, f_ovf_list, f_ovf_cnt, f_scan_ws;
+    size_t f_pool_cap = 0;       // ids
+    uint64_t f_total = 0;        // candidates of the last filter call
+    uint32_t f_nq = 0;
+    nsgpu::DevBuf rep_flags;
+    nsgpu::Timer t_stage, t_kernel;
+    nsgpu_timing timing;
+};
+
+namespace nsgpu {
+
+// kernels_minhash.hip
+int launch_pack_ascii(nsgpu_ctx *c, const char *d_ascii, const uint64_t *d_aoff, SeqStore &st);
+int launch_sketch(nsgpu_ctx *c, const SeqStore &st, uint64_t *d_out_fwd, uint64_t *d_out_rc);
+int launch_repetitive(nsgpu_ctx *c, const SeqStore &st, uint8_t *d_flags);
+int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, uint32_t nq, bool interleave);
+// index.hip
+int build_index(nsgpu_ctx *c);
+int scan_u32_to_u64(nsgpu_ctx *c, const uint32_t *d_in, uint64_t *d_out, uint32_t n);  // exclusive, n+1 outputs
+
+int store_layout(SeqStore &st, const uint32_t *len, uint32_t n);   // fills h_poff/h_len, allocs
+}  // namespace nsgpu

@@ -1,0 +1,220 @@
+"""Host-side mirror of the reference's operator interface for the MinHash half of
+the path: `MinHashReadFilter` has the reference's public fields and methods
+(include/ReadFilter.h:15-30, 33-111) and forwards to libnsgpu.so."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import NsGpuError, Params, Timing, check, load_library
+
+
+def mt19937_64_salts(n, seed=12345):
+    """First n outputs of std::mt19937_64(seed): what generateRandomNumbers
+    (src/ReadFilter.cpp:49-63) yields once its random_device seed is pinned
+    (uniform_int_distribution<unsigned long long> over the full range is the
+    identity map in libstdc++)."""
+    nn, mm = 312, 156
+    mask = (1 << 64) - 1
+    mt = [0] * nn
+    mt[0] = seed & mask
+    for i in range(1, nn):
+        mt[i] = (6364136223846793005 * (mt[i - 1] ^ (mt[i - 1] >> 62)) + i) & mask
+    out = []
+    idx = nn
+    um, lm = 0xFFFFFFFF80000000, 0x7FFFFFFF
+    while len(out) < n:
+        if idx >= nn:
+            for i in range(nn):
+                x = (mt[i] & um) | (mt[(i + 1) % nn] & lm)
+                xa = x >> 1
+                if x & 1:
+                    xa ^= 0xB5026F5AA96619E9
+                mt[i] = mt[(i + mm) % nn] ^ xa
+            idx = 0
+        x = mt[idx]
+        idx += 1
+        x ^= (x >> 29) & 0x5555555555555555
+        x ^= (x << 17) & 0x71D67FFFEDA60000
+        x ^= (x << 37) & 0xFFF7EEE000000000
+        x ^= x >> 43
+        out.append(x & mask)
+    return np.array(out, dtype=np.uint64)
+
+
+def synth_reads(seed, genome_len, n_reads, mean_len=8000.0, p_sub=0.01, p_ins=0.01, p_del=0.01):
+    """SURVEY 8d synthetic reads.  Returns (bases: np.uint8 array of ASCII, off: np.uint64[n+1])."""
+    lib = load_library()
+    pb, po = C.c_void_p(), C.c_void_p()
+    rc = lib.nsgpu_synth_reads(seed, genome_len, n_reads, mean_len, p_sub, p_ins, p_del, C.byref(pb), C.byref(po))
+    if rc != 0:
+        raise NsGpuError(f"nsgpu_synth_reads failed ({rc})")
+    off = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), shape=(n_reads + 1,)).copy()
+    total = int(off[-1])
+    bases = np.ctypeslib.as_array(C.cast(pb, C.POINTER(C.c_uint8)), shape=(max(total, 1),))[:total].copy()
+    lib.nsgpu_free(pb)
+    lib.nsgpu_free(po)
+    return bases, off
+
+
+def _concat(strings):
+    off = np.zeros(len(strings) + 1, dtype=np.uint64)
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in strings]
+    if bs:
+        off[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    buf = np.frombuffer(b"".join(bs), dtype=np.uint8) if bs and off[-1] else np.zeros(0, dtype=np.uint8)
+    return np.ascontiguousarray(buf), off
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+class NsGpu:
+    """One nsgpu_ctx (one GPU, one stream)."""
+
+    def __init__(self, k=23, n=60, overlap_sketch_thr=6, m_k=20, m_w=50, max_chain_iter=400, edge_threshold=4000000,
+                 device=0, stream=None):
+        self.lib = load_library()
+        p = Params()
+        self.lib.nsgpu_default_params(C.byref(p))
+        p.k, p.n, p.overlap_sketch_thr = k, n, overlap_sketch_thr
+        p.m_k, p.m_w, p.max_chain_iter, p.edge_threshold, p.device = m_k, m_w, max_chain_iter, edge_threshold, device
+        self.params = p
+        self.ctx = C.c_void_p()
+        check(self.lib, self.lib.nsgpu_create(C.byref(p), C.byref(self.ctx)))
+        if stream is not None:
+            check(self.lib, self.lib.nsgpu_set_stream(self.ctx, C.c_void_p(stream)))
+        self.k, self.n = k, n
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.nsgpu_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- read store ----
+    def load_reads(self, reads):
+        """reads: list of str/bytes, or (bases uint8 array, off uint64 array)."""
+        if isinstance(reads, tuple):
+            bases, off = reads
+        else:
+            bases, off = _concat(reads)
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        self._keep = (bases, off)
+        check(self.lib, self.lib.nsgpu_load_reads_ascii(self.ctx, _ptr(bases), _ptr(off), len(off) - 1))
+
+    def load_reads_packed(self, packed, byte_off, lens):
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        byte_off = np.ascontiguousarray(byte_off, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        check(self.lib, self.lib.nsgpu_load_reads_packed(self.ctx, _ptr(packed), _ptr(byte_off), _ptr(lens), len(lens)))
+
+    @property
+    def num_reads(self):
+        return int(self.lib.nsgpu_num_reads(self.ctx))
+
+    @property
+    def num_bases(self):
+        return int(self.lib.nsgpu_num_bases(self.ctx))
+
+    def get_read(self, r, maxlen=1 << 24):
+        ln = C.c_uint32()
+        buf = np.zeros(maxlen, dtype=np.uint8)
+        check(self.lib, self.lib.nsgpu_get_read(self.ctx, r, _ptr(buf), C.byref(ln)))
+        return buf[:ln.value].tobytes().decode()
+
+    def get_read_packed(self, r, maxlen=1 << 24):
+        ln = C.c_uint32()
+        buf = np.zeros(maxlen // 4 + 4, dtype=np.uint8)
+        check(self.lib, self.lib.nsgpu_get_read_packed(self.ctx, r, _ptr(buf), C.byref(ln)))
+        return buf[:(ln.value + 3) // 4].copy(), ln.value
+
+    # ---- sketch / index / filter ----
+    def sketch(self, salts, fetch=True):
+        salts = np.ascontiguousarray(salts, dtype=np.uint64)
+        assert salts.size == self.n
+        out = np.zeros((self.num_reads, self.n), dtype=np.uint64) if fetch else None
+        check(self.lib, self.lib.nsgpu_sketch(self.ctx, _ptr(salts), _ptr(out) if fetch else None))
+        return out
+
+    def build_index(self):
+        check(self.lib, self.lib.nsgpu_build_index(self.ctx))
+
+    def index_export(self, j):
+        N = self.num_reads
+        keys = np.zeros(max(N, 1), dtype=np.uint64)
+        start = np.zeros(N + 1, dtype=np.uint32)
+        ids = np.zeros(max(N, 1), dtype=np.uint32)
+        nk = C.c_uint32()
+        check(self.lib, self.lib.nsgpu_index_export(self.ctx, j, _ptr(keys), _ptr(start), _ptr(ids), C.byref(nk)))
+        u = nk.value
+        return keys[:u].copy(), start[:u + 1].copy(), ids[:N].copy()
+
+    def filter(self, s):
+        b = s.encode() if isinstance(s, str) else bytes(s)
+        ids, n = C.c_void_p(), C.c_size_t()
+        check(self.lib, self.lib.nsgpu_filter(self.ctx, b, len(b), C.byref(ids), C.byref(n)))
+        out = np.ctypeslib.as_array(C.cast(ids, C.POINTER(C.c_uint32)), shape=(max(n.value, 1),))[:n.value].copy()
+        self.lib.nsgpu_free(ids)
+        return out
+
+    def filter_batch(self, strings):
+        bases, off = _concat(strings)
+        po, pi = C.c_void_p(), C.c_void_p()
+        check(self.lib, self.lib.nsgpu_filter_batch(self.ctx, _ptr(bases), _ptr(off), len(strings), C.byref(po), C.byref(pi)))
+        q = len(strings)
+        o = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), shape=(q + 1,)).copy()
+        tot = int(o[-1])
+        ids = np.ctypeslib.as_array(C.cast(pi, C.POINTER(C.c_uint32)), shape=(max(tot, 1),))[:tot].copy()
+        self.lib.nsgpu_free(po)
+        self.lib.nsgpu_free(pi)
+        return o, ids
+
+    def filter_all_reads(self, fetch=True):
+        tot = C.c_uint64()
+        check(self.lib, self.lib.nsgpu_filter_all_reads(self.ctx, C.byref(tot)))
+        if not fetch:
+            return int(tot.value)
+        off = np.zeros(2 * self.num_reads + 1, dtype=np.uint64)
+        ids = np.zeros(max(int(tot.value), 1), dtype=np.uint32)
+        check(self.lib, self.lib.nsgpu_filter_all_fetch(self.ctx, _ptr(off), _ptr(ids)))
+        return off, ids[:int(tot.value)]
+
+    def check_repetitive(self):
+        f = np.zeros(max(self.num_reads, 1), dtype=np.uint8)
+        check(self.lib, self.lib.nsgpu_check_repetitive(self.ctx, _ptr(f)))
+        return f[:self.num_reads]
+
+    def timing(self):
+        t = Timing()
+        check(self.lib, self.lib.nsgpu_get_timing(self.ctx, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    def sync(self):
+        check(self.lib, self.lib.nsgpu_sync(self.ctx))
+
+
+class MinHashReadFilter:
+    """Same surface as the reference's MinHashReadFilter (include/ReadFilter.h:33-111):
+    public fields k, n, overlapSketchThreshold; initialize(reads); getFilteredReads(s).
+    The salts are explicit (`randNumbers`) instead of std::random_device."""
+
+    def __init__(self, k=23, n=60, overlapSketchThreshold=6, randNumbers=None, device=0):
+        self.k, self.n, self.overlapSketchThreshold = k, n, overlapSketchThreshold
+        self.randNumbers = mt19937_64_salts(n) if randNumbers is None else np.asarray(randNumbers, dtype=np.uint64)
+        self.gpu = NsGpu(k=k, n=n, overlap_sketch_thr=overlapSketchThreshold, device=device)
+        self.sketches = None
+
+    def initialize(self, reads, keep_sketches=False):
+        self.gpu.load_reads(reads)
+        self.sketches = self.gpu.sketch(self.randNumbers, fetch=keep_sketches)
+        self.gpu.build_index()
+
+    def getFilteredReads(self, s):
+        return self.gpu.filter(s)

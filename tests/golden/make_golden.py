@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Generates the committed golden vectors from the REFERENCE's own objects
+(oracle/_ref, built by oracle/Makefile from /root/reference where it lies).
+
+    python tests/golden/make_golden.py            # needs /root/reference (this container)
+
+Outputs (data only: inputs + the reference's outputs):
+    minhash_small.npz   reads, salts, queries -> sketches, DnaBitset bytes, per-table
+                        id lists, getFilteredReads results     (P1, P2, P3 of SURVEY 8c)
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from tests import oracle_lib  # noqa: E402
+from nanospring_amd.filter import mt19937_64_salts  # noqa: E402
+
+COMP = {"A": "T", "T": "A", "C": "G", "G": "C"}
+
+
+def revcomp(s):
+    return "".join(COMP.get(c, c) for c in reversed(s))
+
+
+def mutate(rng, s, p):
+    out = []
+    for c in s:
+        u = rng.random_sample()
+        if u < p:
+            out.append("ACGT"[rng.randint(4)])
+        elif u < 2 * p:
+            out.append("ACGT"[rng.randint(4)])
+            out.append(c)
+        elif u < 3 * p:
+            continue
+        else:
+            out.append(c)
+    return "".join(out)
+
+
+def minhash_reads(seed=1234, k=23):
+    """~70 reads: overlapping noisy reads of a 40 kb genome with a planted tandem
+    repeat, plus the edge cases of SURVEY A2 (len < k-1, == k-1, == k, 31, 32),
+    N / lowercase bytes (folded by baseToInt), exact duplicates and a homopolymer."""
+    rng = np.random.RandomState(seed)
+    g = "".join("ACGT"[i] for i in rng.randint(0, 4, size=40000))
+    unit = "".join("ACGT"[i] for i in rng.randint(0, 4, size=37))
+    g = g[:15000] + unit * 60 + g[15000:]
+    reads = []
+    for _ in range(56):
+        ln = int(max(300, rng.gamma(2.0, 1500.0)))
+        st = rng.randint(0, len(g) - ln)
+        s = g[st:st + ln]
+        if rng.randint(2):
+            s = revcomp(s)
+        reads.append(mutate(rng, s, 0.01))
+    reads += ["", "A", g[:k - 3], g[:k - 2], g[100:100 + k - 1], g[200:200 + k], g[300:300 + k + 1], g[400:431], g[500:532]]
+    reads += [g[1000:1400].replace("A", "N", 3), g[2000:2300].lower(), reads[0], reads[0], "A" * 500, "AC" * 300]
+    return g, reads
+
+
+def minhash_case():
+    k, n, thr = 23, 60, 6
+    g, reads = minhash_reads(k=k)
+    salts = mt19937_64_salts(n, 12345)
+    queries = []
+    for r in (0, 1, 2, 3, 10, 20, 30):
+        queries += [reads[r], revcomp(reads[r])]
+    queries += [g[15000:17000], g[14000:16000], revcomp(g[5000:9000]), g[0:32], g[40:40 + k - 1], g[40:40 + k - 2], "", "ACGT" * 10,
+                reads[0][:500], "A" * 200]
+    ref = oracle_lib.run_nsref(reads, queries, k, n, thr, salts)
+    assert ref["unpack_ok"].all()
+    rb, roff = oracle_lib.concat(reads)
+    qb, qoff = oracle_lib.concat(queries)
+    fl_off = np.zeros(len(queries) + 1, dtype=np.uint64)
+    fl_off[1:] = np.cumsum([len(x) for x in ref["filter"]])
+    fl_ids = np.concatenate(ref["filter"]) if fl_off[-1] else np.zeros(0, np.uint32)
+    # tables: per (j, r) the id list of sketch[r][j]; store as CSR
+    tl = [x for row in ref["tables"] for x in row]
+    t_off = np.zeros(len(tl) + 1, dtype=np.uint64)
+    t_off[1:] = np.cumsum([len(x) for x in tl])
+    t_ids = np.concatenate(tl)
+    np.savez_compressed(os.path.join(HERE, "minhash_small.npz"), k=k, n=n, thr=thr, salts=salts,
+                        read_bases=rb[:int(roff[-1])], read_off=roff, query_bases=qb[:int(qoff[-1])], query_off=qoff,
+                        sketches=ref["sketches"], packed=ref["packed"], qsketch=ref["qsketch"],
+                        filter_off=fl_off, filter_ids=fl_ids, table_off=t_off, table_ids=t_ids.astype(np.uint32))
+    print("minhash_small.npz:", len(reads), "reads,", len(queries), "queries,",
+          int(fl_off[-1]), "filter ids, max list", max(len(x) for x in tl))
+
+
+if __name__ == "__main__":
+    if not oracle_lib.have_nsref():
+        sys.exit("oracle/_ref/nsref missing: run `make -C oracle` where /root/reference exists")
+    minhash_case()

@@ -1,0 +1,157 @@
+"""ctypes wrappers around the checkers: oracle/libnsoracle.so (our CPU
+restatement) and, when present, oracle/_ref (the reference's own objects).
+Test infrastructure only -- never imported by nanospring_amd."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libnsoracle.so")
+NSREF = os.path.join(ORACLE_DIR, "_ref", "nsref")
+MM2REF = os.path.join(ORACLE_DIR, "_ref", "libmm2ref.so")
+
+
+def build_oracle():
+    subprocess.run(["make", "-C", ORACLE_DIR, "libnsoracle.so"], check=True, capture_output=True)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def concat(strings):
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in strings]
+    off = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        off[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    buf = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if off[-1] else np.zeros(1, dtype=np.uint8)
+    return buf, off
+
+
+class Oracle:
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(
+                os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in os.listdir(ORACLE_DIR) if f.endswith("_oracle.c")):
+            build_oracle()
+        self.lib = C.CDLL(ORACLE_SO)
+        L = self.lib
+        L.oracle_filter_sketch.restype = C.c_uint64
+        L.oracle_filter_string.restype = C.c_uint64
+        L.oracle_check_repetitive.restype = C.c_int
+        L.oracle_num_threads.restype = C.c_int
+
+    def pack2bit(self, s):
+        b = s.encode() if isinstance(s, str) else bytes(s)
+        out = np.zeros((len(b) + 3) // 4 + 1, dtype=np.uint8)
+        self.lib.oracle_pack2bit(b, C.c_uint64(len(b)), _p(out))
+        return out[:(len(b) + 3) // 4]
+
+    def unpack2bit(self, packed, n):
+        out = np.zeros(n + 1, dtype=np.uint8)
+        packed = np.ascontiguousarray(packed)
+        self.lib.oracle_unpack2bit(_p(packed), C.c_uint64(n), _p(out))
+        return out[:n].tobytes().decode()
+
+    def revcomp(self, s):
+        b = s.encode() if isinstance(s, str) else bytes(s)
+        out = np.zeros(len(b) + 1, dtype=np.uint8)
+        self.lib.oracle_revcomp(b, C.c_uint64(len(b)), _p(out))
+        return out[:len(b)].tobytes().decode()
+
+    def sketch(self, s, k, n, salts):
+        b = s.encode() if isinstance(s, str) else bytes(s)
+        out = np.zeros(n, dtype=np.uint64)
+        salts = np.ascontiguousarray(salts, dtype=np.uint64)
+        self.lib.oracle_sketch(b, C.c_uint64(len(b)), C.c_uint32(k), C.c_uint32(n), _p(salts), _p(out))
+        return out
+
+    def sketch_reads(self, bases, off, k, n, salts):
+        N = len(off) - 1
+        out = np.zeros((N, n), dtype=np.uint64)
+        salts = np.ascontiguousarray(salts, dtype=np.uint64)
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        self.lib.oracle_sketch_reads(_p(bases), _p(off), C.c_uint32(N), C.c_uint32(k), C.c_uint32(n), _p(salts), _p(out))
+        return out
+
+    def index_build(self, sketches):
+        N, n = sketches.shape
+        sk = np.ascontiguousarray(sketches, dtype=np.uint64)
+        keys = np.zeros((n, max(N, 1)), dtype=np.uint64)
+        start = np.zeros((n, N + 1), dtype=np.uint32)
+        ids = np.zeros((n, max(N, 1)), dtype=np.uint32)
+        nkeys = np.zeros(n, dtype=np.uint32)
+        self.lib.oracle_index_build(_p(sk), C.c_uint32(N), C.c_uint32(n), _p(keys), _p(start), _p(ids), _p(nkeys))
+        return {"keys": keys, "start": start, "ids": ids, "nkeys": nkeys, "N": N, "n": n}
+
+    def filter_sketch(self, q, idx, thr):
+        N, n = idx["N"], idx["n"]
+        q = np.ascontiguousarray(q, dtype=np.uint64)
+        out = np.zeros(max(N, 1), dtype=np.uint32)
+        m = C.c_uint64()
+        c = self.lib.oracle_filter_sketch(_p(q), C.c_uint32(N), C.c_uint32(n), C.c_uint32(thr), _p(idx["keys"]), _p(idx["start"]),
+                                          _p(idx["ids"]), _p(idx["nkeys"]), _p(out), C.c_uint64(N), C.byref(m))
+        return out[:c].copy(), int(m.value)
+
+    def filter_string(self, s, k, salts, idx, thr):
+        return self.filter_sketch(self.sketch(s, k, idx["n"], salts), idx, thr)
+
+    def check_repetitive(self, s):
+        b = s.encode() if isinstance(s, str) else bytes(s)
+        return int(self.lib.oracle_check_repetitive(b, C.c_uint64(len(b))))
+
+    def num_threads(self):
+        return int(self.lib.oracle_num_threads())
+
+
+def have_nsref():
+    return os.path.exists(NSREF)
+
+
+def run_nsref(reads, queries, k, n, thr, salts):
+    """Runs the reference's own MinHashReadFilter objects (oracle/_ref/nsref)."""
+    rb, roff = concat(reads)
+    qb, qoff = concat(queries)
+    N, Q = len(reads), len(queries)
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(np.array([k, n, thr, N, Q], dtype=np.uint32).tobytes())
+            f.write(np.ascontiguousarray(salts, dtype=np.uint64).tobytes())
+            f.write(roff.tobytes())
+            f.write(rb[:int(roff[-1])].tobytes())
+            f.write(qoff.tobytes())
+            f.write(qb[:int(qoff[-1])].tobytes())
+        subprocess.run([NSREF, fin, fout, td], check=True, capture_output=True)
+        raw = open(fout, "rb").read()
+    p = 0
+
+    def take(dtype, cnt):
+        nonlocal p
+        a = np.frombuffer(raw, dtype=dtype, count=cnt, offset=p).copy()
+        p += a.nbytes
+        return a
+    res = {}
+    res["sketches"] = take(np.uint64, N * n).reshape(N, n)
+    tot = int(take(np.uint64, 1)[0])
+    res["packed"] = take(np.uint8, tot)
+    res["qsketch"] = take(np.uint64, Q * n).reshape(Q, n)
+    fl = []
+    for _ in range(Q):
+        c = int(take(np.uint64, 1)[0])
+        fl.append(take(np.uint32, c))
+    res["filter"] = fl
+    tabs = []
+    for j in range(n):
+        row = []
+        for r in range(N):
+            c = int(take(np.uint64, 1)[0])
+            row.append(take(np.uint32, c))
+        tabs.append(row)
+    res["tables"] = tabs
+    res["unpack_ok"] = take(np.uint8, N)
+    return res
