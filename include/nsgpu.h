@@ -116,6 +116,23 @@ int nsgpu_filter_all_fetch(nsgpu_ctx *ctx, uint64_t *off_out, uint32_t *ids_out)
 /* ---- Consensus::checkRepetitive for every read (src/Consensus.cpp:405-442) -- */
 int nsgpu_check_repetitive(nsgpu_ctx *ctx, uint8_t *flags_out);
 
+/* ---- a14h: batched ksw_extd2 (minimap2/ksw2_extd2_sse.c:34-401 behind mm_align_pair,
+ *      minimap2/align.c:313-339).  Problem i aligns query seqs[qoff[i] .. +qlen[i]) to target
+ *      seqs[toff[i] .. +tlen[i]); bases are minimap2's codes 0..3, 4 = ambiguous
+ *      (minimap2/sketch.c:9-26).  Scoring is ksw_gen_simple_mat(a, b, sc_ambi)
+ *      (align.c:9-22) with gap costs (q,e)/(q2,e2).  flag takes the KSW_EZ_* bits of
+ *      minimap2/ksw2.h:8-18 except KSW_EZ_GENERIC_SC / splice bits (unreachable from
+ *      NanoSpring).  ez_out[i] = ksw_extz_t fields; CIGARs come back as a CSR. ---- */
+typedef struct { int32_t a, b, sc_ambi, q, e, q2, e2; } nsgpu_ksw_params;
+typedef struct {
+    uint32_t max; int32_t zdropped;
+    int32_t max_q, max_t, mqe, mqe_t, mte, mte_q, score, n_cigar, reach_end;
+} nsgpu_ksw_ez;
+int nsgpu_ksw_extd2_batch(nsgpu_ctx *ctx, uint32_t n, const uint8_t *seqs, const uint64_t *qoff, const int32_t *qlen,
+                          const uint64_t *toff, const int32_t *tlen, const int32_t *w, const int32_t *zdrop,
+                          const int32_t *end_bonus, const int32_t *flag, const nsgpu_ksw_params *prm, nsgpu_ksw_ez *ez_out,
+                          uint64_t **cigar_off_out, uint32_t **cigar_out);
+
 /* ---- timing of the last call of each stage, in ms, measured with HIP events on
  *      the context's stream (for bench.py's roofline object) ------------------ */
 typedef struct {

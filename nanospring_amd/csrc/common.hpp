@@ -8,6 +8,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include "../../include/nsgpu.h"
 
 namespace nsgpu {
@@ -103,6 +104,9 @@ struct nsgpu_ctx {
     uint64_t f_total = 0;        // candidates of the last filter call
     uint32_t f_nq = 0;
     nsgpu::DevBuf rep_flags;
+    // ksw2 batches
+    nsgpu::DevBuf k_tasks, k_order, k_seqs, k_p, k_cig, k_res, k_slab;
+    double ksw_kernel_ms = 0, ksw_cells = 0;
     nsgpu::Timer t_stage, t_kernel;
     nsgpu_timing timing;
 };

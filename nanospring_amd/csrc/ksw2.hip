@@ -1,0 +1,513 @@
+// ksw2.hip -- a14h: banded dual-affine-gap extension / global alignment with
+// traceback, bit-identical to minimap2's ksw_extd2_sse
+// (minimap2/ksw2_extd2_sse.c:34-401, ksw2.h:103-176; v2.17-r974-dirty).
+//
+// Integer anti-diagonal wavefront kernel, no MFMA.  One 64-lane wave owns one DP
+// problem; lanes run along the anti-diagonal (index t = target position), the
+// (t-1) neighbour of the previous anti-diagonal arrives by a lane shuffle with a
+// carried value across 64-cell chunks -- the wave64 counterpart of the
+// reference's _mm_slli_si128 / x1_ carry.
+//
+// "Lane-exact" like the oracle (oracle/ksw2_oracle.c): the reference computes
+// 16-cell blocks, so out-of-band cells inside the first/last block exist, hold
+// stale-derived values and feed in-band cells once the band binds.  The kernel
+// therefore sweeps the same 16-aligned [st, en] ranges, keeps the score row s,
+// the target copy sf and the reversed query qr contiguous (16-byte score stores
+// may spill from s into sf, exactly as in the reference's memory picture) and
+// does int8 wrap-around arithmetic.
+//
+// Per-problem working set: 8 B of DP state per target cell + 2 B (s, sf) + the
+// reversed query -- held in LDS (classes of 4/16/64 KiB per wave) or, for huge
+// problems (LONG_JOIN gap fills up to 20 kb), in an HBM scratch slab.  The
+// traceback matrix p (1 B per computed cell) is scratch in HBM; it is written
+// once with coalesced 64-byte stores and read sparsely by the backtrack.
+#include "common.hpp"
+#include "ksw2.hpp"
+
+namespace nsgpu {
+
+#define KSW_NEG_INF (-0x40000000)
+#define KSW_EZ_SCORE_ONLY 0x01
+#define KSW_EZ_RIGHT 0x02
+#define KSW_EZ_GENERIC_SC 0x04
+#define KSW_EZ_APPROX_MAX 0x08
+#define KSW_EZ_APPROX_DROP 0x10
+#define KSW_EZ_EXTZ_ONLY 0x40
+#define KSW_EZ_REV_CIGAR 0x80
+
+__device__ __forceinline__ int sx8(int v) { return (int)(int8_t)(v & 0xff); }
+
+struct RowRange { int st0, en0, st, en; bool empty; };
+
+__device__ __forceinline__ RowRange row_range(int r, int qlen, int tlen, int w)
+{
+    RowRange o;
+    int st = 0, en = tlen - 1;
+    if (st < r - qlen + 1) st = r - qlen + 1;
+    if (en > r) en = r;
+    if (st < ((r - w + 1) >> 1)) st = (r - w + 1) >> 1;
+    if (en > ((r + w) >> 1)) en = (r + w) >> 1;
+    o.empty = st > en;
+    o.st0 = st, o.en0 = en;
+    o.st = st / 16 * 16, o.en = (en + 16) / 16 * 16 - 1;
+    return o;
+}
+
+__device__ __forceinline__ unsigned long long shfl_max_u64(unsigned long long k)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(k, o, 64);
+        k = other > k ? other : k;
+    }
+    return k;
+}
+
+// BP: byte pointer, SP: uint2 (8-byte state) pointer, HP: int32 pointer -- LDS or HBM.
+template <class BP, class SP, class HP>
+__device__ void ksw_extd2_wave(const KswTask &tk, const KswParams &pr, const uint8_t *__restrict__ seqs, uint8_t *__restrict__ p_pool,
+                               uint32_t *__restrict__ cig_pool, KswResult *__restrict__ res_out, SP S, BP bytes, HP H)
+{
+    const int lane = threadIdx.x & 63;
+    const int qlen = tk.qlen, tlen = tk.tlen, flag = tk.flag, zdrop = tk.zdrop;
+    int q = pr.q, e = pr.e, q2 = pr.q2, e2 = pr.e2;
+    if (q2 + e2 < q + e) { int t_ = q; q = q2; q2 = t_; t_ = e; e = e2; e2 = t_; }
+    const int qe = q + e, qe2 = q2 + e2;
+    const int sc_mch = pr.sc_mch, sc_mis = pr.sc_mis;
+    const int sc_N = pr.sc_ambi == 0 ? -e2 : pr.sc_ambi;
+    const bool approx_max = (flag & KSW_EZ_APPROX_MAX) != 0, right = (flag & KSW_EZ_RIGHT) != 0;
+
+    // ksw_reset_extz
+    int ez_max = 0, ez_zdropped = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1, ez_mte = KSW_NEG_INF, ez_mte_q = -1;
+    int ez_score = KSW_NEG_INF, ez_reach_end = 0;
+    uint32_t n_cigar = 0;
+
+    int w = tk.w;
+    if (w < 0) w = tlen > qlen ? tlen : qlen;
+    const int tlen_ = (tlen + 15) / 16, T16 = tlen_ * 16;
+    int n_col_ = qlen < tlen ? qlen : tlen;
+    n_col_ = ((n_col_ < w + 1 ? n_col_ : w + 1) + 15) / 16 + 1;
+    const int ncol16 = n_col_ * 16;
+    int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+    if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+    const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+
+    BP s = bytes, sf = bytes + T16, qr = bytes + 2 * T16;
+    const int qr_bytes = ((qlen + 15) / 16 + 1) * 16;
+    // init: state = {u,v,x,y = -q-e ; x2,y2 = -q2-e2}; s, sf, qr zero then filled
+    {
+        const uint32_t b0 = (uint32_t)(-q - e) & 0xff, b1 = (uint32_t)(-q2 - e2) & 0xff;
+        const uint2 init = make_uint2(b0 | b0 << 8 | b0 << 16 | b0 << 24, b1 | b1 << 8);
+        for (int t = lane; t < T16; t += 64) S[t] = init;
+        for (int i = lane; i < 2 * T16 + qr_bytes; i += 64) bytes[i] = 0;
+        if (!approx_max) for (int t = lane; t < T16; t += 64) H[t] = KSW_NEG_INF;
+    }
+    __syncthreads();
+    {
+        const uint8_t *query = seqs + tk.qoff, *target = seqs + tk.toff;
+        for (int t = lane; t < qlen; t += 64) qr[t] = query[qlen - 1 - t];
+        for (int t = lane; t < tlen; t += 64) sf[t] = target[t];
+    }
+    __syncthreads();
+
+    uint8_t *p = p_pool + tk.p_off;
+    int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0;
+    const int n_rows = qlen + tlen - 1;
+
+    for (int r = 0; r < n_rows; ++r) {
+        const RowRange rr = row_range(r, qlen, tlen, w);
+        if (rr.empty) { ez_zdropped = 1; break; }
+        const int st0 = rr.st0, en0 = rr.en0, st = rr.st, en = rr.en;
+        int x1, x21, v1;
+        if (st > 0) {
+            if (st - 1 >= last_st && st - 1 <= last_en) {
+                const uint2 sv = S[st - 1];
+                x1 = sx8(sv.x >> 16), x21 = sx8(sv.y), v1 = sx8(sv.x >> 8);
+            } else x1 = sx8(-q - e), x21 = sx8(-q2 - e2), v1 = sx8(-q - e);
+        } else {
+            x1 = sx8(-q - e), x21 = sx8(-q2 - e2);
+            v1 = r == 0 ? sx8(-q - e) : r < long_thres ? sx8(-e) : r == long_thres ? sx8(long_diff) : sx8(-e2);
+        }
+        if (en >= r && lane == 0) {
+            uint2 sv = S[r];
+            const uint32_t ur = (uint32_t)(r == 0 ? (-q - e) : r < long_thres ? (-e) : r == long_thres ? long_diff : (-e2)) & 0xff;
+            sv.x = (sv.x & 0x00ffff00u) | ur | (((uint32_t)(-q - e) & 0xff) << 24);       // u[r], y[r]
+            sv.y = (sv.y & 0xffff00ffu) | (((uint32_t)(-q2 - e2) & 0xff) << 8);           // y2[r]
+            S[r] = sv;
+        }
+        // score row: 16-byte blocks from st0; may run past en0 and from s into sf
+        {
+            const int nsc = ((en0 - st0) / 16 + 1) * 16;
+            const int qoff = qlen - 1 - r;      // qrr = qr + qoff, may be negative (reads sf's tail)
+            for (int i = lane; i < nsc; i += 64) {
+                const int t = st0 + i;
+                const int sq = sf[t], sq2 = qr[qoff + t];
+                int z = sq == sq2 ? sc_mch : sc_mis;
+                if (sq == 4 || sq2 == 4) z = sc_N;
+                s[t] = (uint8_t)z;
+            }
+        }
+        __syncthreads();
+        // core loop over the 16-aligned range
+        {
+            int cx = x1, cx2 = x21, cv = v1;
+            uint8_t *prow = p + (size_t)r * ncol16 - st;
+            for (int c = st; c <= en; c += 64) {
+                const int t = c + lane;
+                const bool on = t <= en;
+                uint2 sv = make_uint2(0, 0);
+                int z = 0;
+                if (on) { sv = S[t]; z = sx8(s[t]); }
+                const int ut = sx8(sv.x), vo = sx8(sv.x >> 8), xo = sx8(sv.x >> 16), yo = sx8(sv.x >> 24);
+                const int x2o = sx8(sv.y), y2o = sx8(sv.y >> 8);
+                int xt1 = __shfl_up(xo, 1, 64), vt1 = __shfl_up(vo, 1, 64), x2t1 = __shfl_up(x2o, 1, 64);
+                if (lane == 0) xt1 = cx, vt1 = cv, x2t1 = cx2;
+                cx = __shfl(xo, 63, 64), cv = __shfl(vo, 63, 64), cx2 = __shfl(x2o, 63, 64);
+                int a = sx8(xt1 + vt1), b = sx8(yo + ut), a2 = sx8(x2t1 + vt1), b2 = sx8(y2o + ut), d;
+                if (!right) {
+                    d = a > z ? 1 : 0;  z = z > a ? z : a;
+                    d = b > z ? 2 : d;  z = z > b ? z : b;
+                    d = a2 > z ? 3 : d; z = z > a2 ? z : a2;
+                    d = b2 > z ? 4 : d; z = z > b2 ? z : b2;
+                } else {
+                    d = z > a ? 0 : 1;  z = z > a ? z : a;
+                    d = z > b ? d : 2;  z = z > b ? z : b;
+                    d = z > a2 ? d : 3; z = z > a2 ? z : a2;
+                    d = z > b2 ? d : 4; z = z > b2 ? z : b2;
+                }
+                z = z < sc_mch ? z : sc_mch;
+                const int un = sx8(z - vt1), vn = sx8(z - ut);
+                int tmp = sx8(z - q);
+                a = sx8(a - tmp), b = sx8(b - tmp);
+                tmp = sx8(z - q2);
+                a2 = sx8(a2 - tmp), b2 = sx8(b2 - tmp);
+                int xn, yn, x2n, y2n;
+                if (!right) {
+                    xn = sx8((a > 0 ? a : 0) - qe);    d |= a > 0 ? 0x08 : 0;
+                    yn = sx8((b > 0 ? b : 0) - qe);    d |= b > 0 ? 0x10 : 0;
+                    x2n = sx8((a2 > 0 ? a2 : 0) - qe2); d |= a2 > 0 ? 0x20 : 0;
+                    y2n = sx8((b2 > 0 ? b2 : 0) - qe2); d |= b2 > 0 ? 0x40 : 0;
+                } else {
+                    xn = sx8((0 > a ? 0 : a) - qe);    d |= 0 > a ? 0 : 0x08;
+                    yn = sx8((0 > b ? 0 : b) - qe);    d |= 0 > b ? 0 : 0x10;
+                    x2n = sx8((0 > a2 ? 0 : a2) - qe2); d |= 0 > a2 ? 0 : 0x20;
+                    y2n = sx8((0 > b2 ? 0 : b2) - qe2); d |= 0 > b2 ? 0 : 0x40;
+                }
+                if (on) {
+                    S[t] = make_uint2((uint32_t)(un & 0xff) | (uint32_t)(vn & 0xff) << 8 | (uint32_t)(xn & 0xff) << 16 | (uint32_t)(yn & 0xff) << 24,
+                                      (uint32_t)(x2n & 0xff) | (uint32_t)(y2n & 0xff) << 8);
+                    prow[t] = (uint8_t)d;
+                }
+            }
+        }
+        __syncthreads();
+        bool brk = false;
+        if (!approx_max) {
+            int max_H, max_t;
+            if (r > 0) {
+                // H[en0] first (from the OLD H[en0-1]), then H[t] += v[t] for st0 <= t < en0
+                int h_en0;
+                {
+                    const uint2 se = S[en0];
+                    h_en0 = en0 > 0 ? H[en0 - 1] + sx8(se.x) : H[en0] + sx8(se.x >> 8);
+                }
+                __syncthreads();
+                const int en1 = st0 + (en0 - st0) / 4 * 4;
+                unsigned long long best = ((unsigned long long)((long long)h_en0 + 0x80000000ll) << 32) | 0xFFFFFFFFull;  // rank -1: wins ties
+                for (int t = st0 + lane; t < en0; t += 64) {
+                    const int h = H[t] + sx8(S[t].x >> 8);
+                    H[t] = h;
+                    const uint32_t rank = t < en1 ? (uint32_t)((t - st0) & 3) * 0x100000u + (uint32_t)t : 4u * 0x100000u + (uint32_t)t;
+                    const unsigned long long key = ((unsigned long long)((long long)h + 0x80000000ll) << 32) | (0xFFFFFFFEull - rank);
+                    best = key > best ? key : best;
+                }
+                if (lane == 0) H[en0] = h_en0;
+                best = shfl_max_u64(best);
+                max_H = (int)((long long)(best >> 32) - 0x80000000ll);
+                const uint32_t lo = (uint32_t)best;
+                max_t = lo == 0xFFFFFFFFu ? en0 : (int)((0xFFFFFFFEu - lo) & 0xFFFFFu);
+                __syncthreads();
+            } else {
+                const int h = sx8(S[0].x >> 8) - qe;
+                __syncthreads();
+                if (lane == 0) H[0] = h;
+                max_H = h, max_t = 0;
+                __syncthreads();
+            }
+            const int h_en0 = H[en0], h_st0 = H[st0];
+            if (en0 == tlen - 1 && h_en0 > ez_mte) ez_mte = h_en0, ez_mte_q = r - en;
+            if (r - st0 == qlen - 1 && h_st0 > ez_mqe) ez_mqe = h_st0, ez_mqe_t = st0;
+            // ksw_apply_zdrop(ez, 1, max_H, r, max_t, zdrop, e2)
+            if (max_H > ez_max) {
+                ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
+            } else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
+                const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+                if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; brk = true; }
+            }
+            if (!brk && r == qlen + tlen - 2 && en0 == tlen - 1) ez_score = H[tlen - 1];
+        } else {
+            if (r > 0) {
+                if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+                    const int d0 = sx8(S[last_H0_t].x >> 8), d1 = sx8(S[last_H0_t + 1].x);
+                    if (d0 > d1) H0 += d0;
+                    else H0 += d1, ++last_H0_t;
+                } else if (last_H0_t >= st0 && last_H0_t <= en0) {
+                    H0 += sx8(S[last_H0_t].x >> 8);
+                } else {
+                    ++last_H0_t, H0 += sx8(S[last_H0_t].x);
+                }
+            } else H0 = sx8(S[0].x >> 8) - qe, last_H0_t = 0;
+            if (flag & KSW_EZ_APPROX_DROP) {
+                if (H0 > ez_max) {
+                    ez_max = H0, ez_max_t = last_H0_t, ez_max_q = r - last_H0_t;
+                } else if (last_H0_t >= ez_max_t && r - last_H0_t >= ez_max_q) {
+                    const int tl = last_H0_t - ez_max_t, ql = (r - last_H0_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+                    if (zdrop >= 0 && ez_max - H0 > zdrop + l * e2) { ez_zdropped = 1; brk = true; }
+                }
+            }
+            if (!brk && r == qlen + tlen - 2 && en0 == tlen - 1) ez_score = H0;
+        }
+        if (brk) break;
+        last_st = st, last_en = en;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // backtrack (ksw2.h:119-151, is_rot = 1) by lane 0
+    if (!(flag & KSW_EZ_SCORE_ONLY)) {
+        int i0 = -1, j0 = -1;
+        if (!ez_zdropped && !(flag & KSW_EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
+        else if (!ez_zdropped && (flag & KSW_EZ_EXTZ_ONLY) && ez_mqe + tk.end_bonus > ez_max) ez_reach_end = 1, i0 = ez_mqe_t, j0 = qlen - 1;
+        else if (ez_max_t >= 0 && ez_max_q >= 0) i0 = ez_max_t, j0 = ez_max_q;
+        if (lane == 0 && i0 >= 0 && j0 >= 0) {
+            uint32_t *cig = cig_pool + tk.cig_off;
+            int i = i0, j = j0, state = 0;
+            uint32_t cur_op = 0xffffffffu, cur_len = 0;
+            while (i >= 0 && j >= 0) {
+                const int r = i + j;
+                const RowRange rr = row_range(r, qlen, tlen, w);
+                int force_state = -1;
+                if (i < rr.st) force_state = 2;
+                if (i > rr.en) force_state = 1;
+                const uint32_t tmp = force_state < 0 ? p[(size_t)r * ncol16 + i - rr.st] : 0u;
+                if (state == 0) state = tmp & 7;
+                else if (!(tmp >> (state + 2) & 1)) state = 0;
+                if (state == 0) state = tmp & 7;
+                if (force_state >= 0) state = force_state;
+                uint32_t op;
+                if (state == 0) op = 0, --i, --j;
+                else if (state == 1 || state == 3) op = 2, --i;
+                else op = 1, --j;
+                if (op == cur_op) ++cur_len;
+                else { if (cur_len) cig[n_cigar++] = cur_len << 4 | cur_op; cur_op = op, cur_len = 1; }
+            }
+            if (i >= 0) { if (cur_op == 2) cur_len += i + 1; else { if (cur_len) cig[n_cigar++] = cur_len << 4 | cur_op; cur_op = 2, cur_len = i + 1; } }
+            if (j >= 0) { if (cur_op == 1) cur_len += j + 1; else { if (cur_len) cig[n_cigar++] = cur_len << 4 | cur_op; cur_op = 1, cur_len = j + 1; } }
+            if (cur_len) cig[n_cigar++] = cur_len << 4 | cur_op;
+            if (!(flag & KSW_EZ_REV_CIGAR))
+                for (uint32_t a = 0; a < n_cigar >> 1; ++a) { const uint32_t t_ = cig[a]; cig[a] = cig[n_cigar - 1 - a]; cig[n_cigar - 1 - a] = t_; }
+        }
+    }
+    if (lane == 0) {
+        KswResult o;
+        o.max = (uint32_t)ez_max; o.zdropped = ez_zdropped; o.max_q = ez_max_q; o.max_t = ez_max_t; o.mqe = ez_mqe; o.mqe_t = ez_mqe_t;
+        o.mte = ez_mte; o.mte_q = ez_mte_q; o.score = ez_score; o.n_cigar = (int)n_cigar; o.reach_end = ez_reach_end;
+        res_out[tk.out_idx] = o;
+    }
+}
+
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+
+__global__ __launch_bounds__(64) void ksw_extd2_lds_kernel(const KswTask *__restrict__ tasks, const uint32_t *__restrict__ order, uint32_t n,
+                                                           KswParams pr, const uint8_t *__restrict__ seqs, uint8_t *__restrict__ p_pool,
+                                                           uint32_t *__restrict__ cig_pool, KswResult *__restrict__ res)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t i = blockIdx.x;
+    if (i >= n) return;
+    const KswTask tk = tasks[order[i]];
+    const int T16 = (tk.tlen + 15) / 16 * 16;
+    uint2 *S = reinterpret_cast<uint2 *>(lds);
+    int *H = reinterpret_cast<int *>(lds + (size_t)T16 * 8);
+    const bool exact = !(tk.flag & KSW_EZ_APPROX_MAX);
+    uint8_t *bytes = lds + (size_t)T16 * 8 + (exact ? (size_t)T16 * 4 : 0);
+    ksw_extd2_wave<uint8_t *, uint2 *, int *>(tk, pr, seqs, p_pool, cig_pool, res, S, bytes, H);
+}
+
+__global__ __launch_bounds__(64) void ksw_extd2_hbm_kernel(const KswTask *__restrict__ tasks, const uint32_t *__restrict__ order, uint32_t n,
+                                                           KswParams pr, const uint8_t *__restrict__ seqs, uint8_t *__restrict__ p_pool,
+                                                           uint32_t *__restrict__ cig_pool, KswResult *__restrict__ res,
+                                                           uint8_t *__restrict__ slab, size_t slab_stride)
+{
+    // persistent-style: each workgroup owns one slab and walks the task list
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const KswTask tk = tasks[order[i]];
+        const int T16 = (tk.tlen + 15) / 16 * 16;
+        uint8_t *base = slab + (size_t)blockIdx.x * slab_stride;
+        uint2 *S = reinterpret_cast<uint2 *>(base);
+        int *H = reinterpret_cast<int *>(base + (size_t)T16 * 8);
+        uint8_t *bytes = base + (size_t)T16 * 12;
+        ksw_extd2_wave<uint8_t *, uint2 *, int *>(tk, pr, seqs, p_pool, cig_pool, res, S, bytes, H);
+        __syncthreads();
+    }
+}
+
+size_t ksw_lds_bytes(int qlen, int tlen, int flag)
+{
+    const size_t T16 = (size_t)(tlen + 15) / 16 * 16;
+    const size_t qrb = ((size_t)(qlen + 15) / 16 + 1) * 16;
+    return T16 * 8 + ((flag & KSW_EZ_APPROX_MAX) ? 0 : T16 * 4) + 2 * T16 + qrb + 16;
+}
+
+size_t ksw_p_bytes(int qlen, int tlen, int w)
+{
+    if (qlen <= 0 || tlen <= 0) return 0;
+    if (w < 0) w = tlen > qlen ? tlen : qlen;
+    int n_col_ = qlen < tlen ? qlen : tlen;
+    n_col_ = ((n_col_ < w + 1 ? n_col_ : w + 1) + 15) / 16 + 1;
+    return ((size_t)(qlen + tlen - 1) * n_col_ + 1) * 16;
+}
+
+// Runs a batch.  tasks/seqs are host arrays; results and CIGARs come back to the host.
+// Task fields p_off / cig_off / out_idx are filled here.
+int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs, size_t seq_bytes, const KswParams &pr,
+                  std::vector<KswResult> &results, std::vector<uint32_t> &cigars, std::vector<uint64_t> &cig_off)
+{
+    const size_t n = tasks.size();
+    results.assign(n, KswResult());
+    cig_off.assign(n + 1, 0);
+    cigars.clear();
+    if (n == 0) return NSGPU_OK;
+    static const size_t kClass[3] = {4096, 16384, 65536};
+    std::vector<uint32_t> order[4];
+    size_t p_total = 0, cig_total = 0, hbm_stride = 0;
+    for (size_t i = 0; i < n; ++i) {
+        KswTask &t = tasks[i];
+        NS_CHECK(t.qlen >= 0 && t.tlen >= 0, NSGPU_ERR_ARG, "ksw: negative length");
+        NS_CHECK(!(t.flag & KSW_EZ_GENERIC_SC), NSGPU_ERR_ARG, "ksw: KSW_EZ_GENERIC_SC is not on NanoSpring's path");
+        t.out_idx = (uint32_t)i;
+        t.p_off = p_total;
+        t.cig_off = (uint32_t)cig_total;
+        cig_off[i] = cig_total;
+        if (t.qlen <= 0 || t.tlen <= 0) continue;    // result stays "reset" (ksw_reset_extz), as the reference returns early
+        p_total += (ksw_p_bytes(t.qlen, t.tlen, t.w) + 63) & ~(size_t)63;
+        cig_total += (size_t)t.qlen + t.tlen + 2;
+        NS_CHECK(cig_total < (1ull << 32), NSGPU_ERR_RANGE, "ksw batch too large (cigar pool)");
+        const size_t need = ksw_lds_bytes(t.qlen, t.tlen, t.flag);
+        int cls = need <= kClass[0] ? 0 : need <= kClass[1] ? 1 : need <= kClass[2] ? 2 : 3;
+        if (cls == 3) { const size_t hn = ksw_lds_bytes(t.qlen, t.tlen, 0); if (hn > hbm_stride) hbm_stride = hn; }
+        order[cls].push_back((uint32_t)i);
+    }
+    cig_off[n] = cig_total;
+    // reset-state results for empty problems
+    for (size_t i = 0; i < n; ++i) {
+        KswResult &o = results[i];
+        o.max = 0; o.zdropped = 0; o.max_q = o.max_t = o.mqe_t = o.mte_q = -1; o.mqe = o.mte = o.score = KSW_NEG_INF; o.n_cigar = 0; o.reach_end = 0;
+    }
+    NS_TRY(c->k_tasks.reserve(n * sizeof(KswTask)));
+    NS_TRY(c->k_order.reserve(n * 4 + 16));
+    NS_TRY(c->k_seqs.reserve(seq_bytes + 64));
+    NS_TRY(c->k_p.reserve(p_total + 256));
+    NS_TRY(c->k_cig.reserve((cig_total + 16) * 4));
+    NS_TRY(c->k_res.reserve(n * sizeof(KswResult)));
+    NS_HIP(hipMemcpyAsync(c->k_tasks.p, tasks.data(), n * sizeof(KswTask), hipMemcpyHostToDevice, c->stream));
+    NS_HIP(hipMemcpyAsync(c->k_seqs.p, seqs, seq_bytes, hipMemcpyHostToDevice, c->stream));
+    NS_HIP(hipMemcpyAsync(c->k_res.p, results.data(), n * sizeof(KswResult), hipMemcpyHostToDevice, c->stream));
+    std::vector<uint32_t> flat;
+    size_t start[5] = {0, 0, 0, 0, 0};
+    for (int k = 0; k < 4; ++k) {
+        // big problems first inside a class (longest-processing-time-first)
+        std::stable_sort(order[k].begin(), order[k].end(), [&](uint32_t a, uint32_t b) {
+            return (size_t)tasks[a].qlen * tasks[a].tlen > (size_t)tasks[b].qlen * tasks[b].tlen; });
+        start[k] = flat.size();
+        flat.insert(flat.end(), order[k].begin(), order[k].end());
+    }
+    start[4] = flat.size();
+    if (!flat.empty()) NS_HIP(hipMemcpyAsync(c->k_order.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, c->stream));
+    NS_HIP(hipEventRecord(c->t_kernel.a, c->stream));
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t m = (uint32_t)order[k].size();
+        if (!m) continue;
+        if (kClass[k] > 49152) NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClass[k]));
+        hipLaunchKernelGGL(ksw_extd2_lds_kernel, dim3(m), dim3(64), kClass[k], c->stream, c->k_tasks.as<KswTask>(),
+                           c->k_order.as<uint32_t>() + start[k], m, pr, c->k_seqs.as<uint8_t>(), c->k_p.as<uint8_t>(), c->k_cig.as<uint32_t>(),
+                           c->k_res.as<KswResult>());
+        NS_HIP(hipGetLastError());
+    }
+    if (!order[3].empty()) {
+        const uint32_t m = (uint32_t)order[3].size();
+        const uint32_t wgs = m < 512u ? m : 512u;
+        hbm_stride = (hbm_stride + 255) & ~(size_t)255;
+        NS_TRY(c->k_slab.reserve((size_t)wgs * hbm_stride));
+        hipLaunchKernelGGL(ksw_extd2_hbm_kernel, dim3(wgs), dim3(64), 0, c->stream, c->k_tasks.as<KswTask>(), c->k_order.as<uint32_t>() + start[3], m, pr,
+                           c->k_seqs.as<uint8_t>(), c->k_p.as<uint8_t>(), c->k_cig.as<uint32_t>(), c->k_res.as<KswResult>(), c->k_slab.as<uint8_t>(),
+                           hbm_stride);
+        NS_HIP(hipGetLastError());
+    }
+    NS_HIP(hipEventRecord(c->t_kernel.b, c->stream));
+    NS_HIP(hipMemcpyAsync(results.data(), c->k_res.p, n * sizeof(KswResult), hipMemcpyDeviceToHost, c->stream));
+    cigars.resize(cig_total + 1);
+    if (cig_total) NS_HIP(hipMemcpyAsync(cigars.data(), c->k_cig.p, cig_total * 4, hipMemcpyDeviceToHost, c->stream));
+    NS_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    NS_HIP(hipEventElapsedTime(&ms, c->t_kernel.a, c->t_kernel.b));
+    c->ksw_kernel_ms += ms;
+    c->ksw_cells += [&] { double s = 0; for (auto &t : tasks) s += (double)t.qlen * t.tlen; return s; }();
+    return NSGPU_OK;
+}
+
+}  // namespace nsgpu
+
+using namespace nsgpu;
+
+extern "C" int nsgpu_ksw_extd2_batch(nsgpu_ctx *c, uint32_t n, const uint8_t *seqs, const uint64_t *qoff, const int32_t *qlen,
+                                     const uint64_t *toff, const int32_t *tlen, const int32_t *w, const int32_t *zdrop,
+                                     const int32_t *end_bonus, const int32_t *flag, const nsgpu_ksw_params *prm, nsgpu_ksw_ez *ez_out,
+                                     uint64_t **cigar_off_out, uint32_t **cigar_out)
+{
+    NS_CHECK(c && (n == 0 || (seqs && qoff && qlen && toff && tlen && w && zdrop && end_bonus && flag)) && prm && ez_out && cigar_off_out && cigar_out,
+             NSGPU_ERR_ARG, "nsgpu_ksw_extd2_batch: null argument");
+    NS_HIP(hipSetDevice(c->prm.device));
+    std::vector<KswTask> tasks(n);
+    size_t seq_bytes = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        KswTask &t = tasks[i];
+        NS_CHECK(qoff[i] + (uint64_t)(qlen[i] > 0 ? qlen[i] : 0) < (1ull << 32) && toff[i] + (uint64_t)(tlen[i] > 0 ? tlen[i] : 0) < (1ull << 32),
+                 NSGPU_ERR_RANGE, "sequence pool larger than 4 GiB");
+        t.qoff = (uint32_t)qoff[i]; t.toff = (uint32_t)toff[i]; t.qlen = qlen[i]; t.tlen = tlen[i]; t.w = w[i]; t.zdrop = zdrop[i];
+        t.end_bonus = end_bonus[i]; t.flag = flag[i];
+        seq_bytes = std::max<size_t>(seq_bytes, std::max<size_t>(qoff[i] + (qlen[i] > 0 ? qlen[i] : 0), toff[i] + (tlen[i] > 0 ? tlen[i] : 0)));
+    }
+    KswParams pr;
+    pr.sc_mch = prm->a < 0 ? -prm->a : prm->a;               // ksw_gen_simple_mat, align.c:9-22
+    pr.sc_mis = prm->b > 0 ? -prm->b : prm->b;
+    pr.sc_ambi = prm->sc_ambi > 0 ? -prm->sc_ambi : prm->sc_ambi;
+    pr.q = prm->q; pr.e = prm->e; pr.q2 = prm->q2; pr.e2 = prm->e2;
+    {
+        int mn = pr.sc_mis < pr.sc_ambi ? pr.sc_mis : pr.sc_ambi;
+        if (pr.sc_mch < mn) mn = pr.sc_mch;
+        int qq = pr.q, ee = pr.e;
+        if (pr.q2 + pr.e2 < pr.q + pr.e) qq = pr.q2, ee = pr.e2;
+        NS_CHECK(-mn <= 2 * (qq + ee), NSGPU_ERR_ARG, "ksw: -min_sc > 2*(q+e): the reference returns without aligning (ksw2_extd2_sse.c:99)");
+    }
+    std::vector<KswResult> res;
+    std::vector<uint32_t> cig;
+    std::vector<uint64_t> coff;
+    NS_TRY(ksw_run_batch(c, tasks, seqs, seq_bytes, pr, res, cig, coff));
+    uint64_t *oo = (uint64_t *)malloc(((size_t)n + 1) * 8);
+    uint64_t tot = 0;
+    for (uint32_t i = 0; i < n; ++i) tot += res[i].n_cigar;
+    uint32_t *oc = (uint32_t *)malloc((tot + 1) * 4);
+    NS_CHECK(oo && oc, NSGPU_ERR_NOMEM, "malloc failed");
+    tot = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        oo[i] = tot;
+        memcpy(oc + tot, cig.data() + coff[i], (size_t)res[i].n_cigar * 4);
+        tot += res[i].n_cigar;
+        memcpy(&ez_out[i], &res[i], sizeof(KswResult));
+    }
+    oo[n] = tot;
+    *cigar_off_out = oo;
+    *cigar_out = oc;
+    return NSGPU_OK;
+}

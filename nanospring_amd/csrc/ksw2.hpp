@@ -1,0 +1,31 @@
+// ksw2.hpp -- batch interface of the ksw_extd2 wavefront kernel (ksw2.hip).
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <vector>
+
+struct nsgpu_ctx;
+
+namespace nsgpu {
+
+struct KswTask {
+    uint32_t qoff, toff;      // byte offsets of the 0..4 coded query / target in the sequence pool
+    int32_t qlen, tlen;
+    int32_t w, zdrop, end_bonus, flag;
+    uint64_t p_off;           // traceback scratch offset (filled by ksw_run_batch)
+    uint32_t cig_off, out_idx;
+};
+
+struct KswParams { int32_t sc_mch, sc_mis, sc_ambi, q, e, q2, e2; };   // sc_* as in the 5x5 matrix (mis, ambi negative)
+
+struct KswResult {            // ksw_extz_t (minimap2/ksw2.h:23-32) without the pointer
+    uint32_t max; int32_t zdropped;
+    int32_t max_q, max_t, mqe, mqe_t, mte, mte_q, score, n_cigar, reach_end;
+};
+
+size_t ksw_lds_bytes(int qlen, int tlen, int flag);
+size_t ksw_p_bytes(int qlen, int tlen, int w);
+int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs, size_t seq_bytes, const KswParams &pr,
+                  std::vector<KswResult> &results, std::vector<uint32_t> &cigars, std::vector<uint64_t> &cig_off);
+
+}  // namespace nsgpu

@@ -218,3 +218,47 @@ class MinHashReadFilter:
 
     def getFilteredReads(self, s):
         return self.gpu.filter(s)
+
+
+class KswParams(C.Structure):
+    _fields_ = [("a", C.c_int32), ("b", C.c_int32), ("sc_ambi", C.c_int32), ("q", C.c_int32), ("e", C.c_int32),
+                ("q2", C.c_int32), ("e2", C.c_int32)]
+
+
+class KswEz(C.Structure):
+    _fields_ = [("max", C.c_uint32), ("zdropped", C.c_int32), ("max_q", C.c_int32), ("max_t", C.c_int32), ("mqe", C.c_int32),
+                ("mqe_t", C.c_int32), ("mte", C.c_int32), ("mte_q", C.c_int32), ("score", C.c_int32), ("n_cigar", C.c_int32),
+                ("reach_end", C.c_int32)]
+
+
+def ksw_extd2_batch(gpu, problems, a=2, b=4, sc_ambi=1, q=4, e=2, q2=24, e2=1):
+    """problems: list of (query codes uint8, target codes uint8, w, zdrop, end_bonus, flag).
+    Returns (list of ez tuples, list of CIGAR uint32 arrays) -- ksw_extd2_sse semantics."""
+    n = len(problems)
+    parts, qoff, toff, ql, tl = [], [], [], [], []
+    pos = 0
+    for (qq, tt, *_r) in problems:
+        qq = np.ascontiguousarray(qq, dtype=np.uint8)
+        tt = np.ascontiguousarray(tt, dtype=np.uint8)
+        qoff.append(pos); pos += len(qq); toff.append(pos); pos += len(tt)
+        ql.append(len(qq)); tl.append(len(tt))
+        parts += [qq, tt]
+    seqs = np.concatenate(parts) if parts else np.zeros(1, np.uint8)
+    if seqs.size == 0:
+        seqs = np.zeros(1, np.uint8)
+    arr = lambda v, dt: np.ascontiguousarray(np.array(v, dtype=dt))
+    qoff, toff = arr(qoff, np.uint64), arr(toff, np.uint64)
+    ql, tl = arr(ql, np.int32), arr(tl, np.int32)
+    w, zd, eb, fl = (arr([p[i] for p in problems], np.int32) for i in (2, 3, 4, 5))
+    prm = KswParams(a, b, sc_ambi, q, e, q2, e2)
+    ez = (KswEz * max(n, 1))()
+    po, pc = C.c_void_p(), C.c_void_p()
+    check(gpu.lib, gpu.lib.nsgpu_ksw_extd2_batch(gpu.ctx, n, _ptr(seqs), _ptr(qoff), _ptr(ql), _ptr(toff), _ptr(tl), _ptr(w), _ptr(zd),
+                                                 _ptr(eb), _ptr(fl), C.byref(prm), ez, C.byref(po), C.byref(pc)))
+    off = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+    tot = int(off[-1])
+    cig = np.ctypeslib.as_array(C.cast(pc, C.POINTER(C.c_uint32)), shape=(max(tot, 1),))[:tot].copy()
+    gpu.lib.nsgpu_free(po)
+    gpu.lib.nsgpu_free(pc)
+    ezs = [tuple(getattr(ez[i], f) for f, _ in KswEz._fields_) for i in range(n)]
+    return ezs, [cig[int(off[i]):int(off[i + 1])] for i in range(n)]

@@ -93,7 +93,31 @@ def minhash_case():
           int(fl_off[-1]), "filter ids, max list", max(len(x) for x in tl))
 
 
+
+
+def ksw2_case():
+    """Raw ksw_extd2_sse calls (P4k of SURVEY 8c): inputs -> ez fields + CIGAR from the reference kernel."""
+    from tests.test_ksw2_oracle import cases
+    cs = cases(77, 120)
+    seqs, so, prm, ezs, cig, co = [], [0], [], [], [], [0]
+    for q, t, w, zdrop, eb, flag in cs:
+        ez, c = oracle_lib.ref_ksw(q, t, w, zdrop, eb, flag)
+        seqs += [q, t]
+        so += [so[-1] + len(q), so[-1] + len(q) + len(t)]
+        prm.append([w, zdrop, eb, flag])
+        ezs.append(list(ez))
+        cig.append(c)
+        co.append(co[-1] + len(c))
+    np.savez_compressed(os.path.join(HERE, "ksw2_cases.npz"), n=len(cs), seqs=np.concatenate(seqs).astype(np.uint8),
+                        seq_off=np.array(so, dtype=np.int64), params=np.array(prm, dtype=np.int32), ez=np.array(ezs, dtype=np.int64),
+                        cigar=np.concatenate(cig).astype(np.uint32), cigar_off=np.array(co, dtype=np.int64))
+    print("ksw2_cases.npz:", len(cs), "calls,", sum(e[1] for e in ezs), "z-dropped")
+
 if __name__ == "__main__":
     if not oracle_lib.have_nsref():
         sys.exit("oracle/_ref/nsref missing: run `make -C oracle` where /root/reference exists")
-    minhash_case()
+    which = sys.argv[1:] or ["minhash", "ksw2"]
+    if "minhash" in which:
+        minhash_case()
+    if "ksw2" in which:
+        ksw2_case()

@@ -155,3 +155,82 @@ def run_nsref(reads, queries, k, n, thr, salts):
     res["tables"] = tabs
     res["unpack_ok"] = take(np.uint8, N)
     return res
+
+
+# ---------------------------------------------------------------------------
+# ksw2 (dual-affine banded DP): oracle restatement and the reference's own SSE kernel
+# ---------------------------------------------------------------------------
+class EzT(C.Structure):
+    _fields_ = [("max", C.c_uint32), ("zdropped", C.c_int32), ("max_q", C.c_int32), ("max_t", C.c_int32), ("mqe", C.c_int32),
+                ("mqe_t", C.c_int32), ("mte", C.c_int32), ("mte_q", C.c_int32), ("score", C.c_int32), ("n_cigar", C.c_int32),
+                ("reach_end", C.c_int32)]
+
+    def astuple(self):
+        return tuple(getattr(self, f) for f, _ in self._fields_)
+
+
+KSW_DEFAULT = dict(a=2, b=4, sc_ambi=1, q=4, e=2, q2=24, e2=1)   # minimap2/options.c:43-44
+
+
+def oracle_ksw(orc, query, target, w, zdrop, end_bonus, flag, prm=KSW_DEFAULT):
+    q = np.ascontiguousarray(query, dtype=np.uint8)
+    t = np.ascontiguousarray(target, dtype=np.uint8)
+    ez = EzT()
+    cap = len(q) + len(t) + 4
+    cig = np.zeros(cap, dtype=np.uint32)
+    f = orc.lib.oracle_ksw_extd2
+    f.restype = C.c_int
+    n = f(C.c_int(len(q)), _p(q), C.c_int(len(t)), _p(t), C.c_int8(prm["a"]), C.c_int8(-prm["b"]), C.c_int8(-prm["sc_ambi"]),
+          C.c_int8(prm["q"]), C.c_int8(prm["e"]), C.c_int8(prm["q2"]), C.c_int8(prm["e2"]), C.c_int(w), C.c_int(zdrop),
+          C.c_int(end_bonus), C.c_int(flag), C.byref(ez), _p(cig), C.c_int(cap))
+    return ez.astuple(), cig[:max(n, 0)].copy()
+
+
+_MM2 = None
+
+
+def mm2ref():
+    global _MM2
+    if _MM2 is None:
+        if not os.path.exists(MM2REF):
+            return None
+        _MM2 = C.CDLL(MM2REF)
+    return _MM2
+
+
+def ref_ksw(query, target, w, zdrop, end_bonus, flag, prm=KSW_DEFAULT):
+    lib = mm2ref()
+    q = np.ascontiguousarray(query, dtype=np.uint8)
+    t = np.ascontiguousarray(target, dtype=np.uint8)
+    ez = EzT()
+    cap = len(q) + len(t) + 4
+    cig = np.zeros(cap, dtype=np.uint32)
+    lib.ref_ksw_extd2(C.c_int(len(q)), _p(q), C.c_int(len(t)), _p(t), C.c_int(prm["a"]), C.c_int(prm["b"]), C.c_int(prm["sc_ambi"]),
+                      C.c_int(prm["q"]), C.c_int(prm["e"]), C.c_int(prm["q2"]), C.c_int(prm["e2"]), C.c_int(w), C.c_int(zdrop),
+                      C.c_int(end_bonus), C.c_int(flag), C.byref(ez), _p(cig), C.c_int(cap))
+    return ez.astuple(), cig[:max(ez.n_cigar, 0)].copy()
+
+
+def ksw_random_problem(rng, qlen, tlen, err=0.06, n_frac=0.0, diverge_at=None):
+    """target = random; query = noisy copy (sub/ins/del), cut/padded to qlen; codes 0..3 (4 = N)."""
+    tgt = rng.randint(0, 4, size=tlen).astype(np.uint8)
+    out = []
+    i = 0
+    while len(out) < qlen:
+        if i >= tlen or (diverge_at is not None and len(out) >= diverge_at):
+            out.append(rng.randint(0, 4))
+            continue
+        u = rng.random_sample()
+        if u < err / 3:
+            out.append((int(tgt[i]) + 1 + rng.randint(3)) % 4); i += 1
+        elif u < 2 * err / 3:
+            out.append(rng.randint(0, 4))
+        elif u < err:
+            i += 1
+        else:
+            out.append(int(tgt[i])); i += 1
+    qry = np.array(out[:qlen], dtype=np.uint8)
+    if n_frac > 0:
+        qry[rng.random_sample(qlen) < n_frac] = 4
+        tgt[rng.random_sample(tlen) < n_frac] = 4
+    return qry, tgt

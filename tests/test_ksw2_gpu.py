@@ -1,0 +1,104 @@
+"""GPU parity of the ksw_extd2 wavefront kernel through the C-ABI:
+bit-exact ez fields + CIGAR versus the golden vectors emitted by the reference's own
+ksw_extd2_sse and versus oracle/ksw2_oracle.c on seeded random problems, for every flag
+combination NanoSpring reaches, band-limited / Z-dropped / empty problems, and the
+HBM-state variant used for very long problems."""
+import os
+
+import numpy as np
+import pytest
+
+import nanospring_amd as ns
+from tests import oracle_lib
+from tests.test_ksw2_oracle import cases, GOLD
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    g = ns.NsGpu()
+    yield g
+    g.close()
+
+
+def test_golden_calls(gpu):
+    z = np.load(GOLD)
+    n = int(z["n"])
+    seqs, so = z["seqs"], z["seq_off"]
+    probs = []
+    for i in range(n):
+        q = seqs[int(so[2 * i]):int(so[2 * i + 1])]
+        t = seqs[int(so[2 * i + 1]):int(so[2 * i + 2])]
+        w, zdrop, eb, flag = map(int, z["params"][i])
+        probs.append((q, t, w, zdrop, eb, flag))
+    ezs, cigs = ns.ksw_extd2_batch(gpu, probs)
+    co = z["cigar_off"]
+    for i in range(n):
+        assert ezs[i] == tuple(int(v) for v in z["ez"][i]), (i, probs[i][2:], ezs[i], tuple(z["ez"][i]))
+        assert np.array_equal(cigs[i], z["cigar"][int(co[i]):int(co[i + 1])]), i
+
+
+def test_random_vs_oracle(gpu, oracle):
+    probs = cases(31337, 400)
+    ezs, cigs = ns.ksw_extd2_batch(gpu, probs)
+    nzd = 0
+    for i, (q, t, w, zdrop, eb, flag) in enumerate(probs):
+        we, wc = oracle_lib.oracle_ksw(oracle, q, t, w, zdrop, eb, flag)
+        assert ezs[i] == we, (i, len(q), len(t), w, zdrop, eb, hex(flag), ezs[i], we)
+        assert np.array_equal(cigs[i], wc), i
+        nzd += we[1]
+    assert nzd > 5
+
+
+def test_empty_and_degenerate(gpu, oracle):
+    q = np.array([0, 1, 2, 3], dtype=np.uint8)
+    e = np.zeros(0, dtype=np.uint8)
+    probs = [(e, q, 751, 400, -1, 0x08), (q, e, 751, 400, -1, 0x40), (q, q, 0, 400, -1, 0x08), (q[:1], q[:1], 751, 400, -1, 0x00)]
+    ezs, cigs = ns.ksw_extd2_batch(gpu, probs)
+    for i, (qq, tt, w, zd, eb, fl) in enumerate(probs):
+        we, wc = oracle_lib.oracle_ksw(oracle, qq, tt, w, zd, eb, fl)
+        assert ezs[i] == we and np.array_equal(cigs[i], wc), i
+    assert ns.ksw_extd2_batch(gpu, []) == ([], [])
+
+
+def test_long_problems_use_hbm_state(gpu, oracle):
+    """LONG_JOIN-sized gap fills (bw = max(len)) do not fit the 64 KiB LDS class."""
+    rng = np.random.RandomState(9)
+    probs = []
+    for ql, tl, flag, w in [(7000, 6900, 0x08, 7000), (6800, 7100, 0x00, 7100), (5000, 9000, 0x40, 751), (9000, 6000, 0xC2, 751)]:
+        q, t = oracle_lib.ksw_random_problem(rng, ql, tl, err=0.05)
+        probs.append((q, t, w, 400, -1 if flag < 0x40 else 0, flag))
+    ezs, cigs = ns.ksw_extd2_batch(gpu, probs)
+    for i, (q, t, w, zd, eb, fl) in enumerate(probs):
+        we, wc = oracle_lib.oracle_ksw(oracle, q, t, w, zd, eb, fl)
+        assert ezs[i] == we, (i, ezs[i], we)
+        assert np.array_equal(cigs[i], wc), i
+
+
+def test_cigar_consumes_both_sequences_at_scale(gpu):
+    """Size-independent property on a production-sized batch (typical 240 x 240 gap fills):
+    a global (non-extension) alignment that is not Z-dropped consumes exactly qlen / tlen
+    bases, and its score equals the score recomputed from the CIGAR."""
+    rng = np.random.RandomState(4)
+    probs = []
+    for i in range(4000):
+        ql = int(rng.randint(200, 330))
+        q, t = oracle_lib.ksw_random_problem(rng, ql, ql + int(rng.randint(-8, 9)), err=0.04)
+        probs.append((q, t, 751, 400, -1, 0x08))
+    ezs, cigs = ns.ksw_extd2_batch(gpu, probs)
+    for (q, t, *_), ez, c in zip(probs, ezs, cigs):
+        assert not ez[1]
+        ops, lens = c & 0xf, c >> 4
+        assert int(lens[ops != 2].sum()) == len(q) and int(lens[ops != 1].sum()) == len(t)
+        sc, i, j = 0, 0, 0
+        for op, ln in zip(ops, lens):
+            ln = int(ln)
+            if op == 0:
+                eq = q[j:j + ln] == t[i:i + ln]
+                sc += 2 * int(eq.sum()) - 4 * int((~eq).sum()); i += ln; j += ln
+            else:
+                sc -= min(4 + 2 * ln, 24 + ln)
+                if op == 1: j += ln
+                else: i += ln
+        assert sc == ez[8]
