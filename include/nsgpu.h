@@ -133,6 +133,34 @@ int nsgpu_ksw_extd2_batch(nsgpu_ctx *ctx, uint32_t n, const uint8_t *seqs, const
                           const int32_t *end_bonus, const int32_t *flag, const nsgpu_ksw_params *prm, nsgpu_ksw_ez *ez_out,
                           uint64_t **cigar_off_out, uint32_t **cigar_out);
 
+/* ---- a13: batched ConsensusGraph::alignRead (include/ConsensusGraph.h:245-247,
+ *      src/ConsensusGraph.cpp:161-398): align query i (qrys[qry_off[i]..qry_off[i+1])) to reference
+ *      pair_ref[i] (refs[ref_off[r]..ref_off[r+1])) with minimap2's defaults + MM_F_CIGAR|MM_F_FOR_ONLY,
+ *      k = params.m_k, w = params.m_w, max_chain_iter = params.max_chain_iter, and convert reg[0] to
+ *      the reference's Edit list.  Many queries may share one reference string (its minimizer index
+ *      is built once per batch).  out[i].ok is alignRead's bool; hits == 0 means mm_map found nothing.
+ *      Edit types: 0 SAME(num) 1 INSERT(base) 2 DELETE(base)  (include/Edits.h:8). ---- */
+typedef struct { uint8_t type; uint8_t base; uint16_t reserved; uint32_t num; } nsgpu_edit;
+typedef struct {
+    int32_t ok, hits;
+    int64_t rel_pos, begin_offset, end_offset;          /* relPos, beginOffset, endOffset */
+    int32_t rs, re, qs, qe, blen, mlen, n_ambi, dp_max; /* mm_reg1_t / mm_extra_t fields of reg[0] */
+    uint32_t n_cigar, n_edits;
+    uint64_t cigar_off, edit_off;                       /* into *cigars_out / *edits_out */
+} nsgpu_aln;
+int nsgpu_align_batch(nsgpu_ctx *ctx, const char *refs, const uint64_t *ref_off, uint32_t n_refs, const char *qrys,
+                      const uint64_t *qry_off, const uint32_t *pair_ref, uint32_t n_pairs, nsgpu_aln *out,
+                      uint32_t **cigars_out, nsgpu_edit **edits_out);
+/* cumulative counters of the align path since nsgpu_reset_align_stats (for bench.py) */
+typedef struct {
+    uint64_t pairs, dp_tasks, dp_rounds;
+    double dp_cells;          /* sum of qlen*tlen over all DP problems */
+    double index_ms, host_ms, dp_ms, dp_kernel_ms;   /* host wall / host wall / wall around the DP launches / HIP-event kernel time */
+    uint32_t host_threads, reserved;
+} nsgpu_align_stats;
+int nsgpu_get_align_stats(const nsgpu_ctx *ctx, nsgpu_align_stats *s);
+int nsgpu_reset_align_stats(nsgpu_ctx *ctx);
+
 /* ---- timing of the last call of each stage, in ms, measured with HIP events on
  *      the context's stream (for bench.py's roofline object) ------------------ */
 typedef struct {

@@ -1,0 +1,208 @@
+// align_batch.hip -- a13: batched ConsensusGraph::alignRead (src/ConsensusGraph.cpp:161-398).
+//
+// The reference aligns ONE candidate at a time and rebuilds the minimizer index of the whole
+// consensus for each of them.  Here a batch of (reference, query) pairs is processed together:
+//   * one index per distinct reference string of the batch (host threads),
+//   * seeds / chaining / region bookkeeping per pair on host threads (mm2.cpp),
+//   * every banded DP of every pair gathered into ONE launch of the ksw_extd2 wavefront
+//     kernel per round (ksw2.hip); a pair needs 1-3 rounds (first pass, Z-drop second pass,
+//     split regions),
+//   * CIGAR -> edit script conversion per pair.
+#include "common.hpp"
+#include "ksw2.hpp"
+#include "mm2.hpp"
+#include <atomic>
+#include <thread>
+#include <chrono>
+
+namespace nsgpu {
+
+unsigned host_threads()
+{
+    static unsigned n = [] {
+        unsigned v = std::thread::hardware_concurrency();
+        if (const char *e = getenv("NSGPU_THREADS")) { int x = atoi(e); if (x > 0) v = (unsigned)x; }
+        if (v == 0) v = 8;
+        if (v > 256) v = 256;
+        return v;
+    }();
+    return n;
+}
+
+template <class F>
+static void parallel_for(size_t n, F fn)
+{
+    if (n == 0) return;
+    unsigned nt = host_threads();
+    if (nt > n) nt = (unsigned)n;
+    if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<size_t> next(0);
+    const size_t chunk = n / (nt * 8) ? n / (nt * 8) : 1;
+    std::vector<std::thread> th;
+    th.reserve(nt);
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&]() {
+            for (;;) {
+                const size_t b = next.fetch_add(chunk);
+                if (b >= n) break;
+                const size_t e = b + chunk < n ? b + chunk : n;
+                for (size_t i = b; i < e; ++i) fn(i);
+            }
+        });
+    for (auto &x : th) x.join();
+}
+
+static double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int align_batch(nsgpu_ctx *c, const char *refs, const uint64_t *roff, uint32_t n_refs, const char *qrys, const uint64_t *qoff,
+                const uint32_t *pair_ref, uint32_t n_pairs, std::vector<mm2::AlnOut> &outs)
+{
+    using namespace mm2;
+    outs.assign(n_pairs, AlnOut());
+    if (n_pairs == 0) return NSGPU_OK;
+    for (uint32_t i = 0; i < n_pairs; ++i) NS_CHECK(pair_ref[i] < n_refs, NSGPU_ERR_ARG, "pair %u refers to reference %u of %u", i, pair_ref[i], n_refs);
+    for (uint32_t i = 0; i < n_refs; ++i) NS_CHECK(roff[i + 1] - roff[i] < (1ull << 31), NSGPU_ERR_RANGE, "reference %u longer than 2^31", i);
+    Opt opt;
+    opt.k = (int)c->prm.m_k, opt.w = (int)c->prm.m_w, opt.max_chain_iter = (int)c->prm.max_chain_iter;
+    NS_CHECK(opt.k > 0 && opt.k <= 28 && opt.w > 0 && opt.w < 256, NSGPU_ERR_ARG, "minimap k must be in 1..28 and w in 1..255 (sketch.c:84)");
+    double t0 = now_ms();
+    std::vector<RefIndex> idx(n_refs);
+    parallel_for(n_refs, [&](size_t i) { idx[i].build(refs + roff[i], (uint32_t)(roff[i + 1] - roff[i]), opt.w, opt.k, opt.mid_occ_frac); });
+    double t1 = now_ms();
+    c->aln_index_ms += t1 - t0;
+    std::vector<AlignJob> jobs(n_pairs);
+    for (uint32_t i = 0; i < n_pairs; ++i) jobs[i].start(&idx[pair_ref[i]], qrys + qoff[i], (int)(qoff[i + 1] - qoff[i]), opt);
+    KswParams kp;
+    kp.sc_mch = opt.a; kp.sc_mis = -opt.b; kp.sc_ambi = -opt.sc_ambi; kp.q = opt.q; kp.e = opt.e; kp.q2 = opt.q2; kp.e2 = opt.e2;
+    std::vector<uint32_t> live(n_pairs);
+    for (uint32_t i = 0; i < n_pairs; ++i) live[i] = i;
+    std::vector<KswTask> tasks;
+    std::vector<uint8_t> pool;
+    std::vector<KswResult> res;
+    std::vector<uint32_t> cig;
+    std::vector<uint64_t> coff;
+    for (int round = 0; !live.empty(); ++round) {
+        NS_CHECK(round < 64, NSGPU_ERR_ARG, "align_batch: no convergence after 64 DP rounds (internal error)");
+        double a0 = now_ms();
+        parallel_for(live.size(), [&](size_t i) { jobs[live[i]].step(); });
+        double a1 = now_ms();
+        c->aln_host_ms += a1 - a0;
+        std::vector<uint32_t> still;
+        std::vector<size_t> t_off, b_off;
+        size_t nt = 0, nb = 0;
+        for (uint32_t j : live) {
+            AlignJob &J = jobs[j];
+            if (J.finished) continue;
+            still.push_back(j);
+            t_off.push_back(nt), b_off.push_back(nb);
+            nt += J.cache.missing.size();
+            for (const DpKey &k : J.cache.missing) nb += (size_t)(k.qe - k.qs) + (size_t)(k.re - k.rs);
+        }
+        live.swap(still);
+        if (live.empty()) break;
+        NS_CHECK(nb < (1ull << 32), NSGPU_ERR_RANGE, "align_batch: DP sequence pool exceeds 4 GiB; use smaller batches");
+        tasks.resize(nt);
+        pool.resize(nb + 16);
+        parallel_for(live.size(), [&](size_t li) {
+            AlignJob &J = jobs[live[li]];
+            size_t ti = t_off[li], bo = b_off[li];
+            for (const DpKey &k : J.cache.missing) {
+                KswTask &t = tasks[ti++];
+                const int ql = k.qe - k.qs, tl = k.re - k.rs;
+                t.qoff = (uint32_t)bo; t.toff = (uint32_t)(bo + ql); t.qlen = ql; t.tlen = tl;
+                t.w = k.w; t.zdrop = k.zdrop; t.end_bonus = k.end_bonus; t.flag = k.flag;
+                uint8_t *q = pool.data() + bo, *tt = q + ql;
+                const uint8_t *qs = J.qseq.data() + k.qs, *ts = J.ref->seq.data() + k.rs;
+                if (k.flag & 0x02) {            // left extension: both sequences reversed (align.c:693-696)
+                    for (int x = 0; x < ql; ++x) q[x] = qs[ql - 1 - x];
+                    for (int x = 0; x < tl; ++x) tt[x] = ts[tl - 1 - x];
+                } else { memcpy(q, qs, ql); memcpy(tt, ts, tl); }
+                bo += (size_t)ql + tl;
+            }
+        });
+        double a2 = now_ms();
+        c->aln_host_ms += a2 - a1;
+        NS_TRY(ksw_run_batch(c, tasks, pool.data(), nb, kp, res, cig, coff));
+        double a3 = now_ms();
+        c->aln_dp_ms += a3 - a2;
+        c->aln_dp_tasks += nt;
+        ++c->aln_rounds;
+        parallel_for(live.size(), [&](size_t li) {
+            AlignJob &J = jobs[live[li]];
+            size_t ti = t_off[li];
+            for (const DpKey &k : J.cache.missing) {
+                const KswResult &r = res[ti];
+                DpResult d;
+                d.max = r.max; d.zdropped = r.zdropped; d.max_q = r.max_q; d.max_t = r.max_t; d.mqe = r.mqe; d.mqe_t = r.mqe_t; d.mte = r.mte;
+                d.mte_q = r.mte_q; d.score = r.score; d.reach_end = r.reach_end;
+                d.cigar.assign(cig.begin() + coff[ti], cig.begin() + coff[ti] + r.n_cigar);
+                J.cache.done.emplace(k, std::move(d));
+                ++ti;
+            }
+        });
+        c->aln_host_ms += now_ms() - a3;
+    }
+    double b0 = now_ms();
+    parallel_for(n_pairs, [&](size_t i) {
+        const uint32_t rf = pair_ref[i];
+        align_read_result(jobs[i], refs + roff[rf], (size_t)(roff[rf + 1] - roff[rf]), outs[i]);
+    });
+    c->aln_host_ms += now_ms() - b0;
+    c->aln_pairs += n_pairs;
+    return NSGPU_OK;
+}
+
+}  // namespace nsgpu
+
+using namespace nsgpu;
+
+extern "C" int nsgpu_align_batch(nsgpu_ctx *c, const char *refs, const uint64_t *ref_off, uint32_t n_refs, const char *qrys,
+                                 const uint64_t *qry_off, const uint32_t *pair_ref, uint32_t n_pairs, nsgpu_aln *out,
+                                 uint32_t **cigars_out, nsgpu_edit **edits_out)
+{
+    NS_CHECK(c && ref_off && qry_off && (n_pairs == 0 || (refs && qrys && pair_ref && out)) && cigars_out && edits_out, NSGPU_ERR_ARG,
+             "nsgpu_align_batch: null argument");
+    NS_HIP(hipSetDevice(c->prm.device));
+    std::vector<mm2::AlnOut> outs;
+    NS_TRY(align_batch(c, refs, ref_off, n_refs, qrys, qry_off, pair_ref, n_pairs, outs));
+    uint64_t nc = 0, ne = 0;
+    for (auto &o : outs) nc += o.cigar.size(), ne += o.edits.size();
+    uint32_t *cg = (uint32_t *)malloc((nc + 1) * 4);
+    nsgpu_edit *ed = (nsgpu_edit *)malloc((ne + 1) * sizeof(nsgpu_edit));
+    NS_CHECK(cg && ed, NSGPU_ERR_NOMEM, "malloc failed");
+    nc = ne = 0;
+    for (uint32_t i = 0; i < n_pairs; ++i) {
+        const mm2::AlnOut &o = outs[i];
+        nsgpu_aln &a = out[i];
+        a.ok = o.ok; a.hits = o.hits; a.rel_pos = o.rel_pos; a.begin_offset = o.begin_offset; a.end_offset = o.end_offset;
+        a.rs = o.rs; a.re = o.re; a.qs = o.qs; a.qe = o.qe; a.blen = o.blen; a.mlen = o.mlen; a.n_ambi = o.n_ambi; a.dp_max = o.dp_max;
+        a.n_cigar = (uint32_t)o.cigar.size(); a.n_edits = (uint32_t)o.edits.size(); a.cigar_off = nc; a.edit_off = ne;
+        memcpy(cg + nc, o.cigar.data(), o.cigar.size() * 4);
+        for (const mm2::EditOp &e : o.edits) { nsgpu_edit &x = ed[ne++]; x.type = e.type; x.base = e.base; x.reserved = 0; x.num = e.num; }
+        nc += o.cigar.size();
+    }
+    *cigars_out = cg;
+    *edits_out = ed;
+    return NSGPU_OK;
+}
+
+extern "C" int nsgpu_get_align_stats(const nsgpu_ctx *c, nsgpu_align_stats *s)
+{
+    NS_CHECK(c && s, NSGPU_ERR_ARG, "null argument");
+    s->pairs = c->aln_pairs; s->dp_tasks = c->aln_dp_tasks; s->dp_rounds = c->aln_rounds; s->dp_cells = c->ksw_cells;
+    s->index_ms = c->aln_index_ms; s->host_ms = c->aln_host_ms; s->dp_ms = c->aln_dp_ms; s->dp_kernel_ms = c->ksw_kernel_ms;
+    s->host_threads = host_threads();
+    return NSGPU_OK;
+}
+
+extern "C" int nsgpu_reset_align_stats(nsgpu_ctx *c)
+{
+    NS_CHECK(c, NSGPU_ERR_ARG, "null argument");
+    c->aln_pairs = c->aln_dp_tasks = c->aln_rounds = 0;
+    c->aln_index_ms = c->aln_host_ms = c->aln_dp_ms = 0;
+    c->ksw_kernel_ms = c->ksw_cells = 0;
+    return NSGPU_OK;
+}

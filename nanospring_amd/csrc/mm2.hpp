@@ -1,0 +1,128 @@
+// mm2.hpp -- host side of the "ReadAligner" half of the hot path: the decision
+// chain of minimap2 v2.17 as NanoSpring drives it (ConsensusGraph::alignRead,
+// src/ConsensusGraph.cpp:161-398): minimizer sketch, single-sequence index,
+// seeds, chaining, region bookkeeping and the alignment skeleton.  Every banded
+// DP (ksw_extd2) is NOT computed here: the skeleton asks for it through DpCache
+// and the batch driver runs all outstanding requests of all pairs in one launch
+// of the HIP wavefront kernel (ksw2.hip).
+//
+// Written from scratch against the behaviour of the reference (cited per
+// function, paths relative to the NanoSpring tree); bit-exactness is tested
+// against the reference's own minimap2 build (tests/test_align_gpu.py,
+// tests/golden/align_*.npz).
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <vector>
+#include <map>
+#include <string>
+#include <memory>
+
+namespace nsgpu {
+namespace mm2 {
+
+struct Anchor { uint64_t x, y; };            // mm128_t (minimap2/minimap.h:53)
+
+// seed flags (minimap2/mmpriv.h:17-23)
+constexpr uint64_t SEED_LONG_JOIN = 1ull << 40, SEED_IGNORE = 1ull << 41, SEED_TANDEM = 1ull << 42;
+constexpr int PARENT_UNSET = -1, PARENT_TMP_PRI = -2;
+
+// mm_mapopt_t after mm_set_opt(0,...) + NanoSpring's overrides (minimap2/options.c:14-54,
+// src/ConsensusGraph.cpp:200-203); SURVEY appendix A5.
+struct Opt {
+    int k = 20, w = 50, bucket_bits = 14;
+    int seed = 11;
+    float mid_occ_frac = 2e-4f;
+    int min_cnt = 3, min_chain_score = 40, bw = 500, max_gap = 5000, max_chain_skip = 25, max_chain_iter = 400;
+    float chain_gap_scale = 1.0f, mask_level = 0.5f;
+    int mask_len = 0x7fffffff;
+    float pri_ratio = 0.8f;
+    int best_n = 5, max_join_long = 20000, max_join_short = 2000, min_join_flank_sc = 1000;
+    float min_join_flank_ratio = 0.5f, alt_drop = 0.15f;
+    int a = 2, b = 4, q = 4, e = 2, q2 = 24, e2 = 1, sc_ambi = 1, zdrop = 400, zdrop_inv = 200, end_bonus = -1;
+    int min_dp_max = 80, min_ksw_len = 200;
+    float max_clip_ratio = 1.0f;
+};
+
+void mm_sketch(const char *str, int len, int w, int k, uint32_t rid, std::vector<Anchor> &out);   // minimap2/sketch.c:77-143
+void radix_sort_128x(Anchor *beg, Anchor *end);                                                  // minimap2/ksort.h:98-151 via misc.c:153-156
+void radix_sort_64(uint64_t *beg, uint64_t *end);                                                // misc.c:158-159
+
+// mm_idx_str for ONE sequence + mm_mapopt_update (index.c:386-434, 164-185; options.c:56-66)
+struct RefIndex {
+    int k = 0, w = 0;
+    uint32_t len = 0;
+    std::vector<uint8_t> seq;          // nt4 codes (mm_idx_getseq source; mmpriv.h:29-30)
+    std::vector<uint64_t> keys;        // distinct minimizer hashes, ascending
+    std::vector<uint32_t> start;       // CSR into pos
+    std::vector<uint64_t> pos;         // per key: y values ascending (index.c:230)
+    int32_t mid_occ = 0;
+    void build(const char *s, uint32_t n, int w_, int k_, float mid_occ_frac);
+    const uint64_t *get(uint64_t minier, int *n) const;   // mm_idx_get (index.c:81-98)
+};
+
+struct Extra {                         // mm_extra_t (minimap.h:77-84)
+    int32_t dp_score = 0, dp_max = 0, dp_max2 = 0;
+    uint32_t n_ambi = 0;
+    std::vector<uint32_t> cigar;
+};
+
+struct Reg {                           // mm_reg1_t (minimap.h:86-103)
+    int32_t id = 0, cnt = 0, rid = 0, score = 0, qs = 0, qe = 0, rs = 0, re = 0, parent = 0, subsc = 0, as = 0, mlen = 0, blen = 0,
+            n_sub = 0, score0 = 0;
+    uint8_t split = 0, rev = 0, inv = 0, sam_pri = 0, split_inv = 0;
+    uint32_t hash = 0;
+    bool has_p = false;
+    Extra p;
+};
+
+// One banded-DP request of the skeleton (mm_align_pair, align.c:313-339).  Coordinates
+// are on the forward query / reference; `left` = the left extension, whose two
+// sequences are reversed before the DP (align.c:693-696).
+struct DpKey {
+    int32_t qs, qe, rs, re, w, zdrop, end_bonus, flag;
+    bool operator<(const DpKey &o) const;
+};
+struct DpResult {                      // ksw_extz_t
+    uint32_t max = 0; int32_t zdropped = 0, max_q = -1, max_t = -1, mqe = 0, mqe_t = -1, mte = 0, mte_q = -1, score = 0, reach_end = 0;
+    std::vector<uint32_t> cigar;
+};
+struct DpCache {
+    std::map<DpKey, DpResult> done;
+    std::vector<DpKey> missing;        // requests discovered by the last step()
+    const DpResult *get(const DpKey &k);
+};
+
+// The alignment of one (reference, query) pair as a resumable job.
+struct AlignJob {
+    const RefIndex *ref = nullptr;
+    const char *qstr = nullptr;
+    int qlen = 0;
+    Opt opt;
+    // results
+    bool finished = false;
+    std::vector<Reg> regs;             // final hits (mm_map output order)
+    // internals
+    std::vector<uint8_t> qseq;         // nt4 codes, forward strand only (MM_F_FOR_ONLY)
+    std::vector<Anchor> a;
+    int32_t n_a = 0;
+    int cur = 0;                       // region being aligned in the skeleton loop
+    bool seeded = false;
+    DpCache cache;
+    void start(const RefIndex *r, const char *q, int ql, const Opt &o);
+    bool step();                       // true when finished; otherwise cache.missing is non-empty
+};
+
+// ConsensusGraph::alignRead's conversion of reg[0] (src/ConsensusGraph.cpp:219-397)
+struct EditOp { uint8_t type; uint8_t base; uint32_t num; };   // type: 0 SAME(num) 1 INSERT(base) 2 DELETE(base)
+struct AlnOut {
+    int32_t ok = 0, hits = 0;
+    int64_t rel_pos = 0, begin_offset = 0, end_offset = 0;
+    int32_t rs = 0, re = 0, qs = 0, qe = 0, blen = 0, mlen = 0, n_ambi = 0, dp_max = 0, n_cigar = 0;
+    std::vector<uint32_t> cigar;
+    std::vector<EditOp> edits;
+};
+void align_read_result(const AlignJob &job, const char *ref, size_t ref_len, AlnOut &out);
+
+}  // namespace mm2
+}  // namespace nsgpu

@@ -262,3 +262,56 @@ def ksw_extd2_batch(gpu, problems, a=2, b=4, sc_ambi=1, q=4, e=2, q2=24, e2=1):
     gpu.lib.nsgpu_free(pc)
     ezs = [tuple(getattr(ez[i], f) for f, _ in KswEz._fields_) for i in range(n)]
     return ezs, [cig[int(off[i]):int(off[i + 1])] for i in range(n)]
+
+
+class Aln(C.Structure):
+    _fields_ = [("ok", C.c_int32), ("hits", C.c_int32), ("rel_pos", C.c_int64), ("begin_offset", C.c_int64), ("end_offset", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("rs", "re", "qs", "qe", "blen", "mlen", "n_ambi", "dp_max")] + \
+               [("n_cigar", C.c_uint32), ("n_edits", C.c_uint32), ("cigar_off", C.c_uint64), ("edit_off", C.c_uint64)]
+
+
+class AlignStats(C.Structure):
+    _fields_ = [("pairs", C.c_uint64), ("dp_tasks", C.c_uint64), ("dp_rounds", C.c_uint64), ("dp_cells", C.c_double),
+                ("index_ms", C.c_double), ("host_ms", C.c_double), ("dp_ms", C.c_double), ("dp_kernel_ms", C.c_double),
+                ("host_threads", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+EDIT_DT = np.dtype([("type", np.uint8), ("base", np.uint8), ("reserved", np.uint16), ("num", np.uint32)])
+
+
+def align_batch(gpu, refs, queries, pair_ref):
+    """ConsensusGraph::alignRead for a batch: refs/queries are lists of str (or (bases, off) tuples),
+    pair_ref[i] = index of the reference of query i.  Returns a list of dicts with alignRead's outputs
+    (ok, rel_pos, begin_offset, end_offset, edits) plus reg[0]'s coordinates and CIGAR."""
+    rb, ro = refs if isinstance(refs, tuple) else _concat(refs)
+    qb, qo = queries if isinstance(queries, tuple) else _concat(queries)
+    pr = np.ascontiguousarray(pair_ref, dtype=np.uint32)
+    n = len(qo) - 1
+    assert len(pr) == n
+    out = (Aln * max(n, 1))()
+    pc, pe = C.c_void_p(), C.c_void_p()
+    check(gpu.lib, gpu.lib.nsgpu_align_batch(gpu.ctx, _ptr(rb), _ptr(ro), len(ro) - 1, _ptr(qb), _ptr(qo), _ptr(pr), n, out,
+                                             C.byref(pc), C.byref(pe)))
+    nc = sum(out[i].n_cigar for i in range(n))
+    ne = sum(out[i].n_edits for i in range(n))
+    cig = np.ctypeslib.as_array(C.cast(pc, C.POINTER(C.c_uint32)), shape=(max(nc, 1),))[:nc].copy()
+    raw = np.ctypeslib.as_array(C.cast(pe, C.POINTER(C.c_uint8)), shape=(max(ne, 1) * 8,))[:ne * 8].copy()
+    ed = raw.view(EDIT_DT)
+    gpu.lib.nsgpu_free(pc)
+    gpu.lib.nsgpu_free(pe)
+    res = []
+    for i in range(n):
+        a = out[i]
+        d = {f: getattr(a, f) for f, _ in Aln._fields_}
+        d["cigar"] = cig[a.cigar_off:a.cigar_off + a.n_cigar]
+        d["edits"] = ed[a.edit_off:a.edit_off + a.n_edits]
+        res.append(d)
+    return res
+
+
+def align_stats(gpu, reset=False):
+    s = AlignStats()
+    check(gpu.lib, gpu.lib.nsgpu_get_align_stats(gpu.ctx, C.byref(s)))
+    if reset:
+        check(gpu.lib, gpu.lib.nsgpu_reset_align_stats(gpu.ctx))
+    return {k: getattr(s, k) for k, _ in AlignStats._fields_}

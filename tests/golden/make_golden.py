@@ -113,11 +113,46 @@ def ksw2_case():
                         cigar=np.concatenate(cig).astype(np.uint32), cigar_off=np.array(co, dtype=np.int64))
     print("ksw2_cases.npz:", len(cs), "calls,", sum(e[1] for e in ezs), "z-dropped")
 
+
+def align_case():
+    """(reference string, query) pairs -> what the reference's minimap2 returns for reg[0] under NanoSpring's
+    call sequence (src/ConsensusGraph.cpp:195-217): P4 of SURVEY 8c, minus alignRead's own Edit list (its
+    translation unit needs Boost and cannot be built here; that conversion is pinned by the reference's
+    CHECKS invariant applyEdits(ref, script) == read instead)."""
+    from tests.align_cases import pairs, make_genome, mutate as mut2
+    ps = [(r[:15000], q) for r, q in pairs(4242, 72, big=False)]
+    rng = np.random.RandomState(99)
+    gg = make_genome(rng, 140000)
+    for _ in range(3):
+        a = rng.randint(0, len(gg) - 9000)
+        ps.append((gg, mut2(rng, gg[a:a + rng.randint(3000, 9000)], 0.03)))
+    refs, ref_id = [], []
+    for r, _ in ps:
+        if r not in refs:
+            refs.append(r)
+        ref_id.append(refs.index(r))
+    rb, ro = oracle_lib.concat(refs)
+    qb, qo = oracle_lib.concat([q for _, q in ps])
+    fields = ["hits", "rs", "re", "qs", "qe", "blen", "mlen", "n_ambi", "dp_max", "n_cigar", "mid_occ"]
+    vals, cig, co = [], [], [0]
+    for r, q in ps:
+        d = oracle_lib.ref_mm2_align(r, q)
+        vals.append([d[f] for f in fields])
+        cig.append(d["cigar"])
+        co.append(co[-1] + len(d["cigar"]))
+    np.savez_compressed(os.path.join(HERE, "align_pairs.npz"), ref_bases=rb[:int(ro[-1])], ref_off=ro, qry_bases=qb[:int(qo[-1])], qry_off=qo,
+                        pair_ref=np.array(ref_id, dtype=np.uint32), fields=np.array(fields), values=np.array(vals, dtype=np.int64),
+                        cigar=np.concatenate(cig).astype(np.uint32), cigar_off=np.array(co, dtype=np.int64))
+    v = np.array(vals)
+    print("align_pairs.npz:", len(ps), "pairs,", int((v[:, 0] > 0).sum()), "with hits,", int((v[:, 0] > 1).sum()), "multi-hit")
+
 if __name__ == "__main__":
     if not oracle_lib.have_nsref():
         sys.exit("oracle/_ref/nsref missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["minhash", "ksw2"]
+    which = sys.argv[1:] or ["minhash", "ksw2", "align"]
     if "minhash" in which:
         minhash_case()
     if "ksw2" in which:
         ksw2_case()
+    if "align" in which:
+        align_case()

@@ -234,3 +234,31 @@ def ksw_random_problem(rng, qlen, tlen, err=0.06, n_frac=0.0, diverge_at=None):
         qry[rng.random_sample(qlen) < n_frac] = 4
         tgt[rng.random_sample(tlen) < n_frac] = 4
     return qry, tgt
+
+
+# ---------------------------------------------------------------------------
+# the reference's minimap2 (oracle/_ref/libmm2ref.so)
+# ---------------------------------------------------------------------------
+class RefAln(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("hits", "rs", "re", "qs", "qe", "blen", "mlen", "n_ambi", "dp_max", "dp_score", "score", "cnt",
+                                         "rev", "mid_occ", "n_cigar")]
+
+
+def ref_mm2_align(ref, qry, k=20, w=50, max_chain_iter=400):
+    lib = mm2ref()
+    rb, qb = ref.encode(), qry.encode()
+    out = RefAln()
+    cap = len(rb) + len(qb) + 8
+    cig = np.zeros(cap, dtype=np.uint32)
+    lib.ref_mm2_align(rb, len(rb), qb, len(qb), k, w, max_chain_iter, C.byref(out), _p(cig), cap)
+    d = {f: getattr(out, f) for f, _ in RefAln._fields_}
+    d["cigar"] = cig[:max(out.n_cigar, 0)].copy()
+    return d
+
+
+def ref_mm_sketch(s, w, k):
+    lib = mm2ref()
+    b = s.encode()
+    xy = np.zeros(2 * (len(b) + 8), dtype=np.uint64)
+    n = lib.ref_mm_sketch(b, len(b), w, k, 0, 0, _p(xy), len(b) + 8)
+    return xy[:2 * n].reshape(n, 2).copy()
