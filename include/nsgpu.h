@@ -161,6 +161,30 @@ typedef struct {
 int nsgpu_get_align_stats(const nsgpu_ctx *ctx, nsgpu_align_stats *s);
 int nsgpu_reset_align_stats(nsgpu_ctx *ctx);
 
+/* ---- a11/a12/a16/a17: the contig stage, replaces Consensus::generateAndWriteConsensus
+ *      (src/Consensus.cpp:21-166) and everything below it.  Needs loaded reads, nsgpu_sketch and
+ *      nsgpu_build_index.  n_builders virtual contig builders advance in lock-step rounds (all their
+ *      window queries and alignments of a round are batched on the GPU); n_builders = 1 is the
+ *      reference's deterministic `-t 1` schedule.  The builders' outputs are merged into
+ *      n_threads_out stream sets, i.e. exactly the files Compressor::compress expects for numThr =
+ *      n_threads_out (src/Compressor.cpp:111-143) plus metaData (src/Consensus.cpp:370-386). ---- */
+typedef struct {
+    uint32_t n_builders, reserved;
+    uint64_t n_rounds, n_filter_rounds, n_align_rounds, n_windows, n_contigs, n_lone;
+    uint64_t count_minhash, count_minhash_not_in_graph, count_aligner, n_align_calls;   /* CountStats, include/Consensus.h:19-35 */
+    double total_ms, graph_ms, filter_ms, index_ms, align_ms;
+} nsgpu_consensus_stats;
+int nsgpu_consensus_run(nsgpu_ctx *ctx, uint32_t n_builders, uint32_t n_threads_out, nsgpu_consensus_stats *stats_out);
+/* stream `which` of output thread `thread`: 0 .genome 1 .lone 2 .id 3 .pos 4 .type 5 .base 6 .complement, 7 = metaData
+ * (thread ignored).  *data_out is library-allocated (nsgpu_free). */
+int nsgpu_consensus_stream(nsgpu_ctx *ctx, uint32_t thread, uint32_t which, uint8_t **data_out, size_t *len_out);
+/* writes temp_dir + temp_file_name + ".tid.<t>" + ext for every thread/extension and temp_dir + "metaData",
+ * the names Consensus / ConsensusGraphWriter use (temp_dir must end in '/'). */
+int nsgpu_consensus_write(nsgpu_ctx *ctx, const char *temp_dir, const char *temp_file_name);
+/* decodes the produced streams with the logic of Decompressor::generateRead (src/Decompressor.cpp:252-314)
+ * and counts the reads that do not come back identical (0 = lossless). */
+int nsgpu_consensus_verify(nsgpu_ctx *ctx, uint64_t *n_bad_out);
+
 /* ---- timing of the last call of each stage, in ms, measured with HIP events on
  *      the context's stream (for bench.py's roofline object) ------------------ */
 typedef struct {

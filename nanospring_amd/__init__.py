@@ -7,7 +7,7 @@ no CPU fallback: importing works anywhere, but every operator raises
 NsGpuError when the library or a gfx950 device is missing.
 """
 from ._lib import NsGpuError, lib_path, load_library, Params, Timing  # noqa: F401
-from .filter import NsGpu, MinHashReadFilter, mt19937_64_salts, synth_reads, ksw_extd2_batch, align_batch, align_stats  # noqa: F401
+from .filter import NsGpu, MinHashReadFilter, mt19937_64_salts, synth_reads, ksw_extd2_batch, align_batch, align_stats, consensus_run, consensus_stream, consensus_verify, consensus_write  # noqa: F401
 
 __all__ = ["NsGpuError", "lib_path", "load_library", "Params", "Timing", "NsGpu", "MinHashReadFilter",
-           "mt19937_64_salts", "synth_reads", "ksw_extd2_batch", "align_batch", "align_stats"]
+           "mt19937_64_salts", "synth_reads", "ksw_extd2_batch", "align_batch", "align_stats", "consensus_run", "consensus_stream", "consensus_verify", "consensus_write"]

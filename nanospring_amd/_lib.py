@@ -56,6 +56,10 @@ SIGNATURES = {
     "nsgpu_align_batch": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, C.c_uint32, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "nsgpu_get_align_stats": (C.c_int, [_vp, _vp]),
     "nsgpu_reset_align_stats": (C.c_int, [_vp]),
+    "nsgpu_consensus_run": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
+    "nsgpu_consensus_stream": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "nsgpu_consensus_write": (C.c_int, [_vp, C.c_char_p, C.c_char_p]),
+    "nsgpu_consensus_verify": (C.c_int, [_vp, _u64p]),
     "nsgpu_get_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
     "nsgpu_synth_reads": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_double,
                                     C.POINTER(_vp), C.POINTER(_vp)]),

@@ -14,6 +14,8 @@
 #include <atomic>
 #include <thread>
 #include <chrono>
+#include <functional>
+#include "host_util.hpp"
 
 namespace nsgpu {
 
@@ -29,8 +31,11 @@ unsigned host_threads()
     return n;
 }
 
+void parallel_for_impl(size_t n, const std::function<void(size_t)> &fn);
 template <class F>
-static void parallel_for(size_t n, F fn)
+static void parallel_for(size_t n, F fn) { parallel_for_impl(n, std::function<void(size_t)>(fn)); }
+
+void parallel_for_impl(size_t n, const std::function<void(size_t)> &fn)
 {
     if (n == 0) return;
     unsigned nt = host_threads();
@@ -52,40 +57,33 @@ static void parallel_for(size_t n, F fn)
     for (auto &x : th) x.join();
 }
 
-static double now_ms()
+double now_ms()
 {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-int align_batch(nsgpu_ctx *c, const char *refs, const uint64_t *roff, uint32_t n_refs, const char *qrys, const uint64_t *qoff,
-                const uint32_t *pair_ref, uint32_t n_pairs, std::vector<mm2::AlnOut> &outs)
+// One alignment request: query against a reference whose index the caller owns.
+int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::AlnOut> &outs)
 {
     using namespace mm2;
+    const size_t n_pairs = reqs.size();
     outs.assign(n_pairs, AlnOut());
     if (n_pairs == 0) return NSGPU_OK;
-    for (uint32_t i = 0; i < n_pairs; ++i) NS_CHECK(pair_ref[i] < n_refs, NSGPU_ERR_ARG, "pair %u refers to reference %u of %u", i, pair_ref[i], n_refs);
-    for (uint32_t i = 0; i < n_refs; ++i) NS_CHECK(roff[i + 1] - roff[i] < (1ull << 31), NSGPU_ERR_RANGE, "reference %u longer than 2^31", i);
     Opt opt;
     opt.k = (int)c->prm.m_k, opt.w = (int)c->prm.m_w, opt.max_chain_iter = (int)c->prm.max_chain_iter;
-    NS_CHECK(opt.k > 0 && opt.k <= 28 && opt.w > 0 && opt.w < 256, NSGPU_ERR_ARG, "minimap k must be in 1..28 and w in 1..255 (sketch.c:84)");
-    double t0 = now_ms();
-    std::vector<RefIndex> idx(n_refs);
-    parallel_for(n_refs, [&](size_t i) { idx[i].build(refs + roff[i], (uint32_t)(roff[i + 1] - roff[i]), opt.w, opt.k, opt.mid_occ_frac); });
-    double t1 = now_ms();
-    c->aln_index_ms += t1 - t0;
     std::vector<AlignJob> jobs(n_pairs);
-    for (uint32_t i = 0; i < n_pairs; ++i) jobs[i].start(&idx[pair_ref[i]], qrys + qoff[i], (int)(qoff[i + 1] - qoff[i]), opt);
+    for (size_t i = 0; i < n_pairs; ++i) jobs[i].start(reqs[i].idx, reqs[i].qry, (int)reqs[i].qry_len, opt);
     KswParams kp;
     kp.sc_mch = opt.a; kp.sc_mis = -opt.b; kp.sc_ambi = -opt.sc_ambi; kp.q = opt.q; kp.e = opt.e; kp.q2 = opt.q2; kp.e2 = opt.e2;
     std::vector<uint32_t> live(n_pairs);
-    for (uint32_t i = 0; i < n_pairs; ++i) live[i] = i;
+    for (size_t i = 0; i < n_pairs; ++i) live[i] = (uint32_t)i;
     std::vector<KswTask> tasks;
     std::vector<uint8_t> pool;
     std::vector<KswResult> res;
     std::vector<uint32_t> cig;
     std::vector<uint64_t> coff;
     for (int round = 0; !live.empty(); ++round) {
-        NS_CHECK(round < 64, NSGPU_ERR_ARG, "align_batch: no convergence after 64 DP rounds (internal error)");
+        NS_CHECK(round < 64, NSGPU_ERR_ARG, "align: no convergence after 64 DP rounds (internal error)");
         double a0 = now_ms();
         parallel_for(live.size(), [&](size_t i) { jobs[live[i]].step(); });
         double a1 = now_ms();
@@ -103,7 +101,7 @@ int align_batch(nsgpu_ctx *c, const char *refs, const uint64_t *roff, uint32_t n
         }
         live.swap(still);
         if (live.empty()) break;
-        NS_CHECK(nb < (1ull << 32), NSGPU_ERR_RANGE, "align_batch: DP sequence pool exceeds 4 GiB; use smaller batches");
+        NS_CHECK(nb < (1ull << 32), NSGPU_ERR_RANGE, "align: DP sequence pool exceeds 4 GiB; use smaller batches");
         tasks.resize(nt);
         pool.resize(nb + 16);
         parallel_for(live.size(), [&](size_t li) {
@@ -146,13 +144,31 @@ int align_batch(nsgpu_ctx *c, const char *refs, const uint64_t *roff, uint32_t n
         c->aln_host_ms += now_ms() - a3;
     }
     double b0 = now_ms();
-    parallel_for(n_pairs, [&](size_t i) {
-        const uint32_t rf = pair_ref[i];
-        align_read_result(jobs[i], refs + roff[rf], (size_t)(roff[rf + 1] - roff[rf]), outs[i]);
-    });
+    parallel_for(n_pairs, [&](size_t i) { align_read_result(jobs[i], reqs[i].ref, reqs[i].ref_len, outs[i]); });
     c->aln_host_ms += now_ms() - b0;
     c->aln_pairs += n_pairs;
     return NSGPU_OK;
+}
+
+int align_batch(nsgpu_ctx *c, const char *refs, const uint64_t *roff, uint32_t n_refs, const char *qrys, const uint64_t *qoff,
+                const uint32_t *pair_ref, uint32_t n_pairs, std::vector<mm2::AlnOut> &outs)
+{
+    using namespace mm2;
+    outs.assign(n_pairs, AlnOut());
+    if (n_pairs == 0) return NSGPU_OK;
+    for (uint32_t i = 0; i < n_pairs; ++i) NS_CHECK(pair_ref[i] < n_refs, NSGPU_ERR_ARG, "pair %u refers to reference %u of %u", i, pair_ref[i], n_refs);
+    for (uint32_t i = 0; i < n_refs; ++i) NS_CHECK(roff[i + 1] - roff[i] < (1ull << 31), NSGPU_ERR_RANGE, "reference %u longer than 2^31", i);
+    NS_CHECK(c->prm.m_k > 0 && c->prm.m_k <= 28 && c->prm.m_w > 0 && c->prm.m_w < 256, NSGPU_ERR_ARG, "minimap k must be in 1..28 and w in 1..255 (sketch.c:84)");
+    const double t0 = now_ms();
+    std::vector<RefIndex> idx(n_refs);
+    parallel_for(n_refs, [&](size_t i) { idx[i].build(refs + roff[i], (uint32_t)(roff[i + 1] - roff[i]), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f); });
+    c->aln_index_ms += now_ms() - t0;
+    std::vector<AlignReq> reqs(n_pairs);
+    for (uint32_t i = 0; i < n_pairs; ++i) {
+        const uint32_t rf = pair_ref[i];
+        reqs[i] = AlignReq{&idx[rf], refs + roff[rf], (size_t)(roff[rf + 1] - roff[rf]), qrys + qoff[i], (size_t)(qoff[i + 1] - qoff[i])};
+    }
+    return align_requests(c, reqs, outs);
 }
 
 }  // namespace nsgpu

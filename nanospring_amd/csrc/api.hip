@@ -154,8 +154,17 @@ int nsgpu_load_reads_ascii(nsgpu_ctx *c, const char *bases, const uint64_t *off,
 {
     NS_CHECK(c && off && (bases || n == 0 || off[n] == off[0]), NSGPU_ERR_ARG, "nsgpu_load_reads_ascii: null argument");
     NS_HIP(hipSetDevice(c->prm.device));
-    c->have_sketch = c->have_index = c->have_filter_all = false;
-    return store_from_ascii(c, c->reads, bases, off, n);
+    c->have_sketch = c->have_index = c->have_filter_all = c->have_cons = false;
+    NS_TRY(store_from_ascii(c, c->reads, bases, off, n));
+    // host mirror, folded exactly like DnaBitset (src/dnaToBits.cpp:6-8, 81-98)
+    static const char dna[4] = {'A', 'T', 'C', 'G'};
+    const uint64_t total = n ? off[n] - off[0] : 0;
+    c->h_bases.resize(total + 1);
+    c->h_off.resize((size_t)n + 1);
+    for (uint32_t r = 0; r <= n; ++r) c->h_off[r] = off[r] - off[0];
+    const char *src = bases + (n ? off[0] : 0);
+    for (uint64_t i = 0; i < total; ++i) c->h_bases[i] = dna[(src[i] & 2) | ((src[i] & 4) >> 2)];
+    return NSGPU_OK;
 }
 
 int nsgpu_load_reads_packed(nsgpu_ctx *c, const uint8_t *packed, const uint64_t *byte_off, const uint32_t *len, uint32_t n)
@@ -171,6 +180,20 @@ int nsgpu_load_reads_packed(nsgpu_ctx *c, const uint8_t *packed, const uint64_t 
     for (uint32_t r = 0; r < n; ++r) memcpy(stage.data() + st.h_poff[r], packed + byte_off[r], ((size_t)len[r] + 3) / 4);
     NS_HIP(hipMemcpyAsync(st.packed.p, stage.data(), st.packed_bytes, hipMemcpyHostToDevice, c->stream));
     NS_HIP(hipStreamSynchronize(c->stream));
+    {
+        static const char dna[4] = {'A', 'T', 'C', 'G'};
+        c->h_off.resize((size_t)n + 1);
+        uint64_t tot = 0;
+        for (uint32_t r = 0; r < n; ++r) { c->h_off[r] = tot; tot += len[r]; }
+        c->h_off[n] = tot;
+        c->h_bases.resize(tot + 1);
+        for (uint32_t r = 0; r < n; ++r) {
+            const uint8_t *pk = packed + byte_off[r];
+            char *dst = c->h_bases.data() + c->h_off[r];
+            for (uint32_t i = 0; i < len[r]; ++i) dst[i] = dna[(pk[i >> 2] >> (6 - 2 * (i & 3))) & 3];
+        }
+        c->have_cons = false;
+    }
     return NSGPU_OK;
 }
 
@@ -257,7 +280,7 @@ int nsgpu_index_export(nsgpu_ctx *c, uint32_t j, uint64_t *keys_out, uint32_t *s
     return NSGPU_OK;
 }
 
-static int filter_strings(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq)
+int nsgpu_filter_strings_impl(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq)
 {
     NS_CHECK(c->have_index && c->have_salts, NSGPU_ERR_ARG, "filter: build the index first");
     NS_HIP(hipSetDevice(c->prm.device));
@@ -276,7 +299,7 @@ static int filter_strings(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, 
 int nsgpu_filter_batch(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq, uint64_t **out_off, uint32_t **out_ids)
 {
     NS_CHECK(c && qoff && out_off && out_ids, NSGPU_ERR_ARG, "nsgpu_filter_batch: null argument");
-    NS_TRY(filter_strings(c, strs, qoff, nq));
+    NS_TRY(nsgpu_filter_strings_impl(c, strs, qoff, nq));
     uint64_t *off = (uint64_t *)malloc(((size_t)nq + 1) * 8);
     uint32_t *ids = (uint32_t *)malloc((c->f_total + 1) * 4);
     NS_CHECK(off && ids, NSGPU_ERR_NOMEM, "malloc failed");
@@ -351,3 +374,8 @@ int nsgpu_get_timing(const nsgpu_ctx *c, nsgpu_timing *t)
 }
 
 }  // extern "C"
+
+namespace nsgpu {
+int filter_strings_device(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq) { return nsgpu_filter_strings_impl(c, strs, qoff, nq); }
+}
+

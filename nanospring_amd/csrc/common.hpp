@@ -10,6 +10,7 @@
 #include <vector>
 #include <algorithm>
 #include "../../include/nsgpu.h"
+#include "consensus.hpp"
 
 namespace nsgpu {
 
@@ -110,6 +111,13 @@ struct nsgpu_ctx {
     // align batches
     uint64_t aln_pairs = 0, aln_dp_tasks = 0, aln_rounds = 0;
     double aln_index_ms = 0, aln_host_ms = 0, aln_dp_ms = 0;
+    // host copy of the reads as ReadData::getRead returns them (A/T/C/G after the 2-bit folding)
+    std::vector<char> h_bases;
+    std::vector<uint64_t> h_off;
+    // consensus run
+    bool have_cons = false;
+    nsgpu_consensus_stats cons_stats;
+    std::vector<nsgpu::cons::StreamSet> cons_out;
     nsgpu::Timer t_stage, t_kernel;
     nsgpu_timing timing;
 };

@@ -1,0 +1,590 @@
+// consensus.cpp -- see consensus.hpp.
+#include "consensus.hpp"
+#include <algorithm>
+#include <cassert>
+#include <cstring>
+#include <iterator>
+#include <new>
+#include <set>
+
+namespace nsgpu {
+namespace cons {
+
+using mm2::EditOp;
+
+// ---------------------------------------------------------------------------
+// pool
+// ---------------------------------------------------------------------------
+template <class T> Pool<T>::~Pool()
+{
+    // objects still alive own std::vectors: run their destructors
+    std::set<T *> dead(free_.begin(), free_.end());
+    size_t slab_i = 0;
+    for (auto &slab : slabs_) {
+        const size_t n = (slab_i + 1 == slabs_.size()) ? used_in_last_ : kPerSlab;
+        T *base = reinterpret_cast<T *>(slab.data());
+        for (size_t i = 0; i < n; ++i)
+            if (!dead.count(base + i)) (base + i)->~T();
+        ++slab_i;
+    }
+}
+template <class T> template <class... A> T *Pool<T>::make(A &&...a)
+{
+    T *p;
+    if (!free_.empty()) { p = free_.back(); free_.pop_back(); }
+    else {
+        if (slabs_.empty() || used_in_last_ == kPerSlab) { slabs_.emplace_back(sizeof(T) * kPerSlab + alignof(T)); used_in_last_ = 0; }
+        p = reinterpret_cast<T *>(slabs_.back().data()) + used_in_last_++;
+    }
+    ++live;
+    return new (p) T(std::forward<A>(a)...);
+}
+template <class T> void Pool<T>::free(T *p) { p->~T(); free_.push_back(p); --live; }
+template class Pool<Node>;
+template class Pool<Edge>;
+
+// ---------------------------------------------------------------------------
+// nodes and edges
+// ---------------------------------------------------------------------------
+void Edge::add_read(read_t r) { ++count; reads.insert(std::lower_bound(reads.begin(), reads.end(), r), r); }
+
+Edge *Node::edge_to(Node *n) const { for (Edge *e : out) if (e->sink == n) return e; return nullptr; }
+Edge *Node::edge_to_side(char b) const { for (Edge *e : out) if (!e->sink->on_main && e->sink->base == b) return e; return nullptr; }
+Edge *Node::best_out() const { Edge *best = nullptr; read_t c = 0; for (Edge *e : out) if (e->count > c) c = e->count, best = e; return best; }
+Edge *Node::best_in() const { Edge *best = nullptr; read_t c = 0; for (Edge *e : in) if (e->count > c) c = e->count, best = e; return best; }
+Edge *Node::edge_in_read(read_t r) const { for (Edge *e : out) if (std::binary_search(e->reads.begin(), e->reads.end(), r)) return e; return nullptr; }
+
+Node *ContigGraph::create_node(char b) { ++n_nodes_; return nodes_.make(b); }
+Edge *ContigGraph::create_edge(Node *s, Node *t, read_t r)
+{
+    Edge *e = edges_.make();
+    e->source = s, e->sink = t, e->count = 1, e->reads.push_back(r);
+    s->out.push_back(e), t->in.push_back(e);
+    ++n_edges_;
+    return e;
+}
+Edge *ContigGraph::create_edge(Node *s, Node *t, const std::vector<read_t> &rs)
+{
+    Edge *e = edges_.make();
+    e->source = s, e->sink = t, e->reads = rs, e->count = (read_t)rs.size();
+    s->out.push_back(e), t->in.push_back(e);
+    ++n_edges_;
+    return e;
+}
+// removeEdge (:861-876): the source side drops the FIRST out-edge that leads to the same sink
+void ContigGraph::remove_edge(Edge *e, bool keep_in_source, bool keep_in_sink)
+{
+    if (!keep_in_source) {
+        auto &v = e->source->out;
+        v.erase(std::find_if(v.begin(), v.end(), [&](const Edge *p) { return p->sink == e->sink; }));
+    }
+    if (!keep_in_sink) {
+        auto &v = e->sink->in;
+        v.erase(std::find(v.begin(), v.end(), e));
+    }
+    edges_.free(e);
+    --n_edges_;
+}
+void ContigGraph::remove_node(Node *n)
+{
+    for (Edge *e : std::vector<Edge *>(n->in)) remove_edge(e, false, true);
+    for (Edge *e : std::vector<Edge *>(n->out)) remove_edge(e, true, false);
+    nodes_.free(n);
+    --n_nodes_;
+}
+void ContigGraph::remove_reads_from_edge(Edge *e, const std::vector<read_t> &rs)
+{
+    std::vector<read_t> left;
+    std::set_difference(e->reads.begin(), e->reads.end(), rs.begin(), rs.end(), std::back_inserter(left));
+    e->reads.swap(left);
+    e->count = (read_t)e->reads.size();
+    if (e->count == 0) remove_edge(e);
+}
+
+// ---------------------------------------------------------------------------
+// graph construction
+// ---------------------------------------------------------------------------
+void ContigGraph::initialize(const std::string &seed, read_t id, long pos)
+{
+    Node *cur = create_node(seed[0]);
+    reads.insert(std::make_pair(id, GraphRead{pos, cur, seed.length(), false}));
+    right_unchanged_ = left_unchanged_ = cur;
+    right_off_ = left_off_ = 0;
+    main_path.push_back(cur->base);
+    cur->on_main = true;
+    cur->cum_weight = 0;
+    for (size_t i = 1; i < seed.length(); ++i) {
+        Node *nx = create_node(seed[i]);
+        create_edge(cur, nx, id);
+        cur = nx;
+    }
+    start_pos = pos;
+    end_pos = pos + 1;     // only one base is on the main path until calculate_main_path_greedy runs
+}
+
+void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &script, ssize_t begin_offset, ssize_t end_offset, read_t id,
+                               long pos, bool rc)
+{
+    const size_t n_path_edges = main_edges.size();
+    size_t ei = 0;                                   // edgeInPath
+    Node *node_in_path = main_edges[0]->source;
+    Node *cur = nullptr, *initial = nullptr;
+
+    if (begin_offset >= 0 || end_offset >= 0) {
+        right_off_ = (size_t)std::max((ssize_t)left_off_, std::min((ssize_t)right_off_, begin_offset));
+        right_unchanged_ = right_off_ > 0 ? main_edges[right_off_ - 1]->sink : main_edges[0]->source;
+    } else {
+        left_off_ = std::min(right_off_, std::max(left_off_, main_path.size() - 1 + (size_t)end_offset));
+        left_unchanged_ = left_off_ > 0 ? main_edges[left_off_ - 1]->sink : main_edges[0]->source;
+    }
+    auto advance = [&]() {
+        if (ei == n_path_edges) return;
+        node_in_path = main_edges[ei]->sink;
+        ++ei;
+    };
+    if (begin_offset >= 1) {
+        ei += (size_t)begin_offset - 1;
+        node_in_path = main_edges[ei]->sink;
+        ++ei;
+    } else if (begin_offset <= -1) {
+        const size_t n_ins = (size_t)(-begin_offset);
+        size_t i = 0;
+        cur = create_node(s[i++]);
+        initial = cur;
+        for (; i < n_ins; ++i) {
+            Node *nx = create_node(s[i]);
+            create_edge(cur, nx, id);
+            cur = nx;
+        }
+    }
+    auto insert_node = [&](char base) {
+        if (!cur) {
+            cur = create_node(base);
+            initial = cur;
+        } else {
+            Edge *e = cur->edge_to_side(base);
+            if (e) e->add_read(id);
+            else e = create_edge(cur, create_node(base), id);
+            cur = e->sink;
+        }
+    };
+    for (const EditOp &op : script) {
+        if (op.type == 0) {                          // SAME
+            if (!cur) initial = cur = node_in_path;
+            else {
+                Edge *e = cur->edge_to(node_in_path);
+                if (e) e->add_read(id);
+                else e = create_edge(cur, node_in_path, id);
+                cur = node_in_path;
+            }
+            advance();
+            for (size_t i = 1; i < op.num; ++i) {
+                cur->edge_to(node_in_path)->add_read(id);
+                cur = node_in_path;
+                advance();
+            }
+        } else if (op.type == 2) advance();          // DELETE
+        else if (op.type == 1) insert_node((char)op.base);
+    }
+    if (end_offset > 0)
+        for (size_t i = s.size() - (size_t)end_offset; i < s.size(); ++i) insert_node(s[i]);
+    reads.insert(std::make_pair(id, GraphRead{pos, initial, s.length(), rc}));
+}
+
+void ContigGraph::clear_main_path()
+{
+    const size_t l = main_edges.size();
+    for (size_t i = right_off_; i < l; ++i) main_edges[i]->sink->on_main = false;
+    if (right_off_ < main_edges.size()) main_edges.erase(main_edges.begin() + right_off_, main_edges.end());
+    if (main_path.size() > right_off_ + 1) main_path.erase(main_path.begin() + right_off_ + 1, main_path.end());
+    for (size_t i = 0; i < left_off_; ++i) main_edges[i]->source->on_main = false;
+    if (left_off_ > 0) {
+        main_edges.erase(main_edges.begin(), main_edges.begin() + left_off_);
+        main_path.erase(main_path.begin(), main_path.begin() + left_off_);
+        right_off_ -= left_off_;
+    }
+    left_off_ = 0;
+}
+
+void ContigGraph::calculate_main_path_greedy()
+{
+    clear_main_path();
+    {
+        Node *cur = right_unchanged_;
+        Edge *e;
+        while ((e = cur->best_out())) {
+            main_edges.push_back(e);
+            cur = e->sink;
+            cur->on_main = true;
+            main_path.push_back(cur->base);
+        }
+        const read_t ending = *main_edges.back()->reads.begin();
+        const GraphRead &er = reads.at(ending);
+        end_pos = er.pos + (long)er.len;
+    }
+    {
+        Node *cur = left_unchanged_;
+        Edge *e;
+        std::string prefix;                          // collected back to front, prepended once
+        while ((e = cur->best_in())) {
+            main_edges.push_front(e);
+            cur = e->source;
+            cur->on_main = true;
+            prefix.push_back(cur->base);
+            ++left_off_;
+            ++right_off_;
+        }
+        if (!prefix.empty()) {
+            std::reverse(prefix.begin(), prefix.end());
+            main_path.insert(0, prefix);
+        }
+        const read_t starting = *main_edges.front()->reads.begin();
+        start_pos = reads.at(starting).pos;
+    }
+    remove_cycles();
+    right_unchanged_ = main_edges.back()->sink;
+    right_off_ = main_edges.size();
+    left_unchanged_ = main_edges.front()->source;
+    left_off_ = 0;
+}
+
+void ContigGraph::remove_cycles()
+{
+    std::vector<Edge *> stack;
+    {
+        size_t ei = right_off_;
+        const size_t end = main_edges.size();
+        Node *n = ei < end ? main_edges[ei]->source : main_edges[ei - 1]->sink;
+        for (;;) {
+            const std::vector<Edge *> copy = n->out;      // the walk edits n->out
+            for (Edge *e : copy) walk_and_prune(e, stack);
+            if (ei == end) break;
+            n = main_edges[ei]->sink;
+            ++ei;
+        }
+    }
+    {
+        size_t ei = left_off_ < main_edges.size() ? left_off_ : main_edges.size() - 1;
+        for (;;) {
+            Node *n = main_edges[ei]->source;
+            const std::vector<Edge *> copy = n->out;
+            for (Edge *e : copy) walk_and_prune(e, stack);
+            if (ei == 0) break;
+            --ei;
+        }
+    }
+}
+
+void ContigGraph::walk_and_prune(Edge *e, std::vector<Edge *> &stack)
+{
+    stack.push_back(e);
+    while (!stack.empty()) {
+        Edge *curr = stack.back();
+        stack.pop_back();
+        Node *sink = curr->sink, *source = curr->source;
+        if (sink->on_main) continue;
+        if (sink->in.size() > 1) split_path(source, curr, curr->reads);
+        for (Edge *o : sink->out) stack.push_back(o);
+    }
+}
+
+// Give the reads of edge e (a side branch entering a node that has other ways in) a private copy
+// of everything downstream until the main path is reached again; every side node then has
+// in-degree one.  Iterative form of the reference's two-visit context stack.
+void ContigGraph::split_path(Node *new_pre0, Edge *e0, const std::vector<read_t> &reads0)
+{
+    struct Ctx {
+        Node *new_pre; Edge *e;
+        const std::vector<read_t> *in_reads;       // borrowed from the parent context (or the caller)
+        std::vector<read_t> own;                   // intersection computed at the first visit
+        bool visited = false;
+        Node *old_cur = nullptr;
+    };
+    std::deque<Ctx> st;                               // deque: stable addresses while children are pushed
+    const std::vector<read_t> first_copy = reads0;    // e0->reads dies with e0 during the first visit
+    st.push_back(Ctx{new_pre0, e0, &first_copy, {}, false, nullptr});
+    while (!st.empty()) {
+        Ctx &c = st.back();
+        if (c.visited) {
+            Node *oc = c.old_cur;
+            st.pop_back();
+            if (oc && oc->in.empty() && oc->out.empty()) remove_node(oc);
+            continue;
+        }
+        std::set_intersection(c.in_reads->begin(), c.in_reads->end(), c.e->reads.begin(), c.e->reads.end(), std::back_inserter(c.own));
+        c.visited = true;
+        if (c.own.empty()) continue;
+        Node *old_cur = c.e->sink;
+        c.old_cur = old_cur;
+        remove_reads_from_edge(c.e, c.own);
+        if (old_cur->on_main) { create_edge(c.new_pre, old_cur, c.own); continue; }
+        Node *new_cur = create_node(old_cur->base);
+        create_edge(c.new_pre, new_cur, c.own);
+        const std::vector<read_t> *mine = &c.own;
+        const std::vector<Edge *> outs = old_cur->out;
+        for (Edge *o : outs) st.push_back(Ctx{new_cur, o, mine, {}, false, nullptr});
+    }
+}
+
+// ---------------------------------------------------------------------------
+// emission
+// ---------------------------------------------------------------------------
+void write_var_uint32(uint32_t v, std::string &out)
+{
+    while (v > 127) { out.push_back((char)((v & 0x7f) | 0x80)); v >>= 7; }
+    out.push_back((char)(v & 0x7f));
+}
+
+size_t optimize_edit_script(const std::vector<EditOp> &in, std::vector<EditOp> &out)
+{
+    size_t dis = 0;
+    out.clear();
+    size_t i = 0;
+    const size_t n = in.size();
+    while (i < n) {
+        while (i < n && in[i].type == 0) out.push_back(in[i++]);
+        std::string ins;
+        size_t n_del = 0;
+        while (i < n && in[i].type != 0) {
+            if (in[i].type == 1) ins.push_back((char)in[i].base); else ++n_del;
+            ++i;
+        }
+        const size_t n_ins = ins.size(), n_sub = std::min(n_ins, n_del);
+        dis += std::max(n_del, n_ins);
+        size_t k;
+        for (k = 0; k < n_sub; ++k) out.push_back(EditOp{3, (uint8_t)ins[k], 0});
+        if (n_ins > n_del) for (; k < n_ins; ++k) out.push_back(EditOp{1, (uint8_t)ins[k], 0});
+        else for (; k < n_del; ++k) out.push_back(EditOp{2, (uint8_t)'-', 0});
+    }
+    return dis;
+}
+
+size_t ContigGraph::read_to_edits(const GraphRead &r, read_t id, std::vector<EditOp> &script, uint32_t &pos) const
+{
+    script.clear();
+    auto next = [&](const Node *n) -> Node * { Edge *e = n->edge_in_read(id); return e ? e->sink : nullptr; };
+    Node *cur = r.start;
+    bool meets = true;
+    while (!cur->on_main) {
+        cur = next(cur);
+        if (!cur) { meets = false; break; }
+    }
+    if (!meets) {                                    // never touches the consensus: all inserts
+        pos = 0;
+        size_t dis = 0;
+        Node *c = r.start;
+        do { script.push_back(EditOp{1, (uint8_t)c->base, 0}); ++dis; } while ((c = next(c)));
+        return dis;
+    }
+    pos = (uint32_t)cur->cum_weight;
+    size_t dis = 0, at = cur->cum_weight, same = 0;
+    auto flush = [&]() { if (same > 0) { script.push_back(EditOp{0, 0, (uint32_t)same}); same = 0; } };
+    cur = r.start;
+    do {
+        if (cur->on_main) {
+            const size_t p = cur->cum_weight;
+            if (p > at) flush();
+            for (; at < p; ++at) { script.push_back(EditOp{2, (uint8_t)'-', 0}); ++dis; }
+            ++same;
+            ++at;
+        } else {
+            flush();
+            script.push_back(EditOp{1, (uint8_t)cur->base, 0});
+            ++dis;
+        }
+    } while ((cur = next(cur)));
+    flush();
+    return dis;
+}
+
+size_t ContigGraph::write_read(StreamSet &o, const GraphRead &r, read_t id) const
+{
+    uint32_t offset;
+    std::vector<EditOp> raw, es;
+    read_to_edits(r, id, raw, offset);
+    write_var_uint32(offset, o.pos);
+    const size_t dis = optimize_edit_script(raw, es);
+    uint32_t ins_start = 0, ins_end = 0;
+    for (size_t i = 0; i != es.size(); ++i) {
+        if (es[i].type != 1) break;
+        ++ins_start;
+        o.base.push_back((char)es[i].base);
+    }
+    if (ins_start != es.size())
+        for (int64_t i = (int64_t)es.size() - 1; i >= 0; --i) {
+            if (es[i].type != 1) break;
+            ++ins_end;
+        }
+    write_var_uint32(ins_start, o.pos);
+    uint32_t same = 0;
+    for (size_t i = ins_start; i < es.size() - ins_end; ++i) {
+        switch (es[i].type) {
+        case 0: same += es[i].num; break;
+        case 1: write_var_uint32(same, o.pos); same = 0; o.type.push_back('i'); o.base.push_back((char)es[i].base); break;
+        case 2: write_var_uint32(same, o.pos); same = 0; o.type.push_back('d'); break;
+        case 3: write_var_uint32(same, o.pos); same = 0; o.type.push_back('s'); o.base.push_back((char)es[i].base); break;
+        }
+    }
+    write_var_uint32(same, o.pos);
+    write_var_uint32(ins_end, o.pos);
+    for (size_t i = es.size() - ins_end; i != es.size(); ++i) o.base.push_back((char)es[i].base);
+    o.type.push_back('\n');
+    return dis;
+}
+
+void ContigGraph::write_main_path(StreamSet &o) const { o.genome += main_path; o.genome.push_back('\n'); }
+void ContigGraph::write_read_lone(StreamSet &o) const { o.lone += main_path; o.lone.push_back('\n'); }
+
+void ContigGraph::write_reads(StreamSet &o)
+{
+    main_edges.front()->source->cum_weight = 0;
+    size_t i = 0;
+    for (Edge *e : main_edges) e->sink->cum_weight = ++i;
+    read_t prev = 0;
+    for (auto &it : reads) {
+        const read_t diff = it.first - prev;
+        o.id_contigs.append(reinterpret_cast<const char *>(&diff), 4);     // 4 bytes: std::ios::binary == 4 is passed as the count (:998)
+        o.complement.push_back(it.second.rc ? 'c' : 'n');
+        prev = it.first;
+        write_read(o, it.second, it.first);
+    }
+    o.complement.push_back('\n');
+}
+
+bool ContigGraph::read_string(read_t id, std::string &out) const
+{
+    out.clear();
+    auto it = reads.find(id);
+    if (it == reads.end()) return false;
+    const Node *cur = it->second.start;
+    while (cur) {
+        out.push_back(cur->base);
+        Edge *e = cur->edge_in_read(id);
+        cur = e ? e->sink : nullptr;
+        if (out.size() > it->second.len + 8) return false;
+    }
+    return out.size() == it->second.len;
+}
+
+bool ContigGraph::has_cycle() const
+{
+    // every read must thread a simple path: a cycle shows up as a read walk longer than the read
+    std::string tmp;
+    for (auto &it : reads) if (!read_string(it.first, tmp)) return true;
+    return false;
+}
+
+// ---------------------------------------------------------------------------
+// stream sets
+// ---------------------------------------------------------------------------
+void StreamSet::append(const StreamSet &o)
+{
+    genome += o.genome; lone += o.lone; pos += o.pos; type += o.type; base += o.base; complement += o.complement; id_contigs += o.id_contigs;
+    lone_ids.insert(lone_ids.end(), o.lone_ids.begin(), o.lone_ids.end());
+    reads_in_contig.insert(reads_in_contig.end(), o.reads_in_contig.begin(), o.reads_in_contig.end());
+}
+
+std::string StreamSet::id_bytes() const
+{
+    std::string s = id_contigs;
+    read_t prev = 0;
+    for (read_t r : lone_ids) {
+        const read_t diff = r - prev;
+        s.append(reinterpret_cast<const char *>(&diff), 4);
+        prev = r;
+    }
+    return s;
+}
+
+std::string meta_data(uint64_t n_reads, const std::vector<StreamSet> &threads)
+{
+    size_t n_contigs = 0;
+    for (auto &t : threads) n_contigs += t.reads_in_contig.size();
+    std::string s = "numReads=" + std::to_string(n_reads) + "\nnumContigs=" + std::to_string(n_contigs) + "\nnumThr=" +
+                    std::to_string(threads.size()) + "\nnumReadsInContig=";
+    for (auto &t : threads) for (read_t c : t.reads_in_contig) s += std::to_string(c) + ":";
+    s.push_back('\n');
+    return s;
+}
+
+void reverse_complement(const std::string &s, std::string &out)
+{
+    out.resize(s.size());
+    for (size_t i = 0; i < s.size(); ++i) {
+        const char c = s[s.size() - 1 - i];
+        out[i] = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// decoder
+// ---------------------------------------------------------------------------
+namespace {
+struct Cursor {
+    const std::string &s; size_t p = 0;
+    explicit Cursor(const std::string &x) : s(x) {}
+    bool eof() const { return p >= s.size(); }
+    bool get(char &c) { if (p >= s.size()) return false; c = s[p++]; return true; }
+    bool var(uint32_t &v) {
+        v = 0; uint8_t b, shift = 0;
+        do { if (p >= s.size()) return false; b = (uint8_t)s[p++]; v |= (uint32_t)(b & 0x7f) << shift; shift += 7; } while (b & 0x80);
+        return true;
+    }
+    bool u32(uint32_t &v) { if (p + 4 > s.size()) return false; memcpy(&v, s.data() + p, 4); p += 4; return true; }
+    bool line(std::string &o) { if (p >= s.size()) return false; size_t e = s.find('\n', p); if (e == std::string::npos) e = s.size(); o.assign(s, p, e - p); p = e + 1; return true; }
+};
+}  // namespace
+
+bool decode_streams(const StreamSet &ss, std::vector<std::pair<read_t, std::string>> &out, std::string &err)
+{
+    const std::string idb = ss.id_bytes();
+    Cursor genome(ss.genome), id(idb), pos(ss.pos), type(ss.type), base(ss.base), comp(ss.complement), lone(ss.lone);
+    std::string g, read;
+    auto fail = [&](const char *m) { err = m; return false; };
+    while (genome.line(g)) {
+        read_t rid = 0;
+        for (;;) {
+            char c;
+            if (!comp.get(c)) return fail(".complement ended early");
+            if (c == '\n') break;
+            uint32_t inc;
+            if (!id.u32(inc)) return fail(".id ended early");
+            rid += inc;
+            // generateRead
+            read.clear();
+            uint32_t cur, n_start, n_end, same;
+            if (!pos.var(cur) || !pos.var(n_start)) return fail(".pos ended early");
+            for (uint32_t i = 0; i < n_start; ++i) { char b; if (!base.get(b)) return fail(".base ended early"); read.push_back(b); }
+            for (;;) {
+                if (!pos.var(same)) return fail(".pos ended early");
+                if ((size_t)cur + same > g.size()) return fail("run past the consensus end");
+                read.append(g, cur, same);
+                cur += same;
+                char t;
+                if (!type.get(t)) return fail(".type ended early");
+                if (t == '\n') break;
+                if (t == 'd') ++cur;
+                else if (t == 'i') { char b; if (!base.get(b)) return fail(".base ended early"); read.push_back(b); }
+                else if (t == 's') { ++cur; char b; if (!base.get(b)) return fail(".base ended early"); read.push_back(b); }
+                else return fail("bad edit type");
+            }
+            if (!pos.var(n_end)) return fail(".pos ended early");
+            for (uint32_t i = 0; i < n_end; ++i) { char b; if (!base.get(b)) return fail(".base ended early"); read.push_back(b); }
+            if (c == 'c') { std::string t2; reverse_complement(read, t2); read.swap(t2); }
+            out.emplace_back(rid, read);
+        }
+    }
+    read_t rid = 0;
+    std::string l;
+    while (lone.line(l)) {
+        uint32_t inc;
+        if (!id.u32(inc)) return fail(".id ended early (lone)");
+        rid += inc;
+        out.emplace_back(rid, l);
+    }
+    if (!id.eof() || !pos.eof() || !type.eof() || !base.eof() || !comp.eof()) return fail("trailing bytes in a stream");
+    return true;
+}
+
+}  // namespace cons
+}  // namespace nsgpu

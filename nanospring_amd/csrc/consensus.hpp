@@ -1,0 +1,128 @@
+// consensus.hpp -- host side of the contig builder: the per-base consensus DAG
+// (ConsensusGraph, src/ConsensusGraph.cpp:135-159, 400-897), consensus-edit emission and the
+// seven output streams (src/ConsensusGraph.cpp:979-1178, src/Edits.cpp:23-60,
+// src/DirectoryUtils.cpp:18-28), and the decoder that is the executable spec of the stream
+// layout (Decompressor::generateRead, src/Decompressor.cpp:252-314).
+//
+// Pure host C++ (no HIP): the graph is pointer-chasing, per-contig sequential work; it runs on
+// host threads, one contig builder per task, while sketching, candidate lookup and all
+// alignment DP run on the GPU (consensus_driver.hip).
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <deque>
+#include <map>
+#include <string>
+#include <vector>
+#include "mm2.hpp"
+
+namespace nsgpu {
+namespace cons {
+
+typedef uint32_t read_t;
+
+struct Edge;
+struct Node {
+    char base;
+    bool on_main = false;
+    std::vector<Edge *> out, in;
+    size_t cum_weight = 0;
+    explicit Node(char b) : base(b) {}
+    Edge *edge_to(Node *n) const;             // Node::getEdgeTo          (:33-43)
+    Edge *edge_to_side(char b) const;         // Node::getEdgeToSide      (:45-53)
+    Edge *best_out() const;                   // Node::getBestEdgeOut     (:55-67) first max wins
+    Edge *best_in() const;                    // Node::getBestEdgeIn      (:69-81)
+    Edge *edge_in_read(read_t r) const;       // Node::getEdgeInRead      (:83-91)
+};
+struct Edge {
+    Node *source, *sink;
+    read_t count;
+    std::vector<read_t> reads;                // ascending
+    void add_read(read_t r);                  // Edge::addRead            (:24-28)
+};
+
+template <class T>
+class Pool {                                   // slab allocator with a free list; everything dies with the graph
+public:
+    ~Pool();
+    template <class... A> T *make(A &&...a);
+    void free(T *p);
+    size_t live = 0;
+private:
+    std::deque<std::vector<unsigned char>> slabs_;
+    std::vector<T *> free_;
+    size_t used_in_last_ = 0;
+    static constexpr size_t kPerSlab = 4096;
+};
+
+// The seven per-"thread" streams (ConsensusGraphWriter, src/ConsensusGraph.cpp:118-133).  .id keeps
+// the contig part (4-byte LE deltas, restarting at 0 per contig) apart from the lone-read ids, which
+// the reference appends at the very end of the thread's file (src/Consensus.cpp:129).
+struct StreamSet {
+    std::string genome, lone, pos, type, base, complement, id_contigs;
+    std::vector<read_t> lone_ids;
+    std::vector<read_t> reads_in_contig;      // metaData numReadsInContig
+    void append(const StreamSet &o);
+    std::string id_bytes() const;             // contig deltas + lone deltas (src/ConsensusGraph.cpp:1018-1025)
+};
+
+void write_var_uint32(uint32_t v, std::string &out);   // src/DirectoryUtils.cpp:18-28
+
+struct GraphRead { long pos; Node *start; size_t len; bool rc; };
+
+class ContigGraph {
+public:
+    ContigGraph() = default;
+    ContigGraph(const ContigGraph &) = delete;
+    ssize_t start_pos = 0, end_pos = 0;
+    std::string main_path;                     // mainPath.path
+    std::deque<Edge *> main_edges;             // mainPath.edges
+    read_t first_read = 0;
+    std::map<read_t, GraphRead> reads;         // readsInGraph (ascending id = output order)
+
+    void initialize(const std::string &seed, read_t id, long pos);                         // :135-159
+    void update_graph(const std::string &s, const std::vector<mm2::EditOp> &script, ssize_t begin_offset, ssize_t end_offset,
+                      read_t id, long pos, bool rc);                                        // :400-557
+    void calculate_main_path_greedy();                                                      // :559-615
+    size_t num_reads() const { return reads.size(); }
+    size_t num_edges() const { return n_edges_; }
+    size_t num_nodes() const { return n_nodes_; }
+    void write_main_path(StreamSet &o) const;                                               // :979-982
+    void write_reads(StreamSet &o);                                                         // :984-1012
+    void write_read_lone(StreamSet &o) const;                                               // :1014-1016
+    // checker used by the tests (Consensus::checkRead, src/Consensus.cpp:342-368)
+    bool read_string(read_t id, std::string &out) const;
+    bool has_cycle() const;
+
+private:
+    Node *right_unchanged_ = nullptr, *left_unchanged_ = nullptr;
+    size_t right_off_ = 0, left_off_ = 0;
+    size_t n_nodes_ = 0, n_edges_ = 0;
+    Pool<Node> nodes_;
+    Pool<Edge> edges_;
+    Node *create_node(char b);
+    Edge *create_edge(Node *s, Node *t, read_t r);
+    Edge *create_edge(Node *s, Node *t, const std::vector<read_t> &rs);
+    void remove_reads_from_edge(Edge *e, const std::vector<read_t> &rs);
+    void remove_edge(Edge *e, bool keep_in_source = false, bool keep_in_sink = false);
+    void remove_node(Node *n);
+    void clear_main_path();                                                                 // :617-651
+    void remove_cycles();                                                                   // :653-691
+    void walk_and_prune(Edge *e, std::vector<Edge *> &stack);                               // :693-714
+    void split_path(Node *new_pre, Edge *e, const std::vector<read_t> &reads2split);        // :716-807
+    size_t read_to_edits(const GraphRead &r, read_t id, std::vector<mm2::EditOp> &script, uint32_t &pos) const;   // :1031-1096
+    size_t write_read(StreamSet &o, const GraphRead &r, read_t id) const;                   // :1098-1178
+};
+
+// Edit::optimizeEditScript (src/Edits.cpp:23-60): types 0 SAME 1 INSERT 2 DELETE 3 SUBSTITUTION
+size_t optimize_edit_script(const std::vector<mm2::EditOp> &in, std::vector<mm2::EditOp> &out);
+
+// Decoder of one stream set (Decompressor::decompress inner loop + generateRead,
+// src/Decompressor.cpp:105-172, 252-314).  Returns (id, read) pairs in file order.
+bool decode_streams(const StreamSet &s, std::vector<std::pair<read_t, std::string>> &out, std::string &err);
+std::string meta_data(uint64_t n_reads, const std::vector<StreamSet> &threads);            // finishWriteConsensus, src/Consensus.cpp:370-386
+
+void reverse_complement(const std::string &s, std::string &out);                            // include/ReadData.h:163-172
+
+}  // namespace cons
+}  // namespace nsgpu

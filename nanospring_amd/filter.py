@@ -315,3 +315,38 @@ def align_stats(gpu, reset=False):
     if reset:
         check(gpu.lib, gpu.lib.nsgpu_reset_align_stats(gpu.ctx))
     return {k: getattr(s, k) for k, _ in AlignStats._fields_}
+
+
+class ConsensusStats(C.Structure):
+    _fields_ = [("n_builders", C.c_uint32), ("reserved", C.c_uint32)] + \
+               [(n, C.c_uint64) for n in ("n_rounds", "n_filter_rounds", "n_align_rounds", "n_windows", "n_contigs", "n_lone", "count_minhash",
+                                          "count_minhash_not_in_graph", "count_aligner", "n_align_calls")] + \
+               [(n, C.c_double) for n in ("total_ms", "graph_ms", "filter_ms", "index_ms", "align_ms")]
+
+
+STREAMS = ["genome", "lone", "id", "pos", "type", "base", "complement"]
+
+
+def consensus_run(gpu, n_builders=256, n_threads_out=1):
+    s = ConsensusStats()
+    check(gpu.lib, gpu.lib.nsgpu_consensus_run(gpu.ctx, n_builders, n_threads_out, C.byref(s)))
+    return {k: getattr(s, k) for k, _ in ConsensusStats._fields_}
+
+
+def consensus_stream(gpu, thread, which):
+    idx = 7 if which == "metaData" else STREAMS.index(which)
+    p, n = C.c_void_p(), C.c_size_t()
+    check(gpu.lib, gpu.lib.nsgpu_consensus_stream(gpu.ctx, thread, idx, C.byref(p), C.byref(n)))
+    b = C.string_at(p, n.value)
+    gpu.lib.nsgpu_free(p)
+    return b
+
+
+def consensus_verify(gpu):
+    bad = C.c_uint64()
+    check(gpu.lib, gpu.lib.nsgpu_consensus_verify(gpu.ctx, C.byref(bad)))
+    return int(bad.value)
+
+
+def consensus_write(gpu, temp_dir, temp_file_name="Stream"):
+    check(gpu.lib, gpu.lib.nsgpu_consensus_write(gpu.ctx, temp_dir.encode(), temp_file_name.encode()))

@@ -83,3 +83,171 @@ void harness_radix_sort_128x(uint64_t *xy, int64_t n) { radix_sort_128x((Anchor 
 void harness_radix_sort_64(uint64_t *x, int64_t n) { radix_sort_64(x, x + n); }
 
 }
+
+// ---------------------------------------------------------------------------
+// Sequential restatement of the reference's `-t 1` contig loop (src/Consensus.cpp:21-340) as plain
+// nested loops, with candidates from the CPU oracle filter and DP from the CPU oracle.  It is the
+// checker for the GPU batch engine (consensus_driver.hip) run with ONE builder, and it exercises the
+// product's host-side graph / emission / decoder code on the CPU.
+// ---------------------------------------------------------------------------
+#include <string>
+#include "../nanospring_amd/csrc/consensus.hpp"
+
+extern "C" {
+void oracle_sketch_reads(const char *bases, const uint64_t *off, uint32_t N, uint32_t k, uint32_t n, const uint64_t *salts, uint64_t *sketches);
+void oracle_index_build(const uint64_t *sketches, uint32_t N, uint32_t n, uint64_t *keys, uint32_t *start, uint32_t *ids, uint32_t *nkeys);
+uint64_t oracle_filter_string(const char *s, uint64_t len, uint32_t k, uint32_t N, uint32_t n, uint32_t thr, const uint64_t *salts,
+                              const uint64_t *keys, const uint32_t *start, const uint32_t *ids, const uint32_t *nkeys, uint32_t *out,
+                              uint64_t cap, uint64_t *n_matches);
+int oracle_check_repetitive(const char *s, uint64_t len);
+}
+
+using namespace nsgpu::cons;
+
+static bool harness_align1(const std::string &ref, const std::string &q, int k, int w, int mci, AlnOut &ao)
+{
+    RefIndex ri;
+    ri.build(ref.data(), (uint32_t)ref.size(), w, k, 2e-4f);
+    Opt o;
+    o.k = k, o.w = w, o.max_chain_iter = mci;
+    AlignJob J;
+    J.start(&ri, q.data(), (int)q.size(), o);
+    while (!J.step()) answer(J);
+    align_read_result(J, ref.data(), ref.size(), ao);
+    return ao.ok != 0;
+}
+
+extern "C" {
+
+typedef struct { uint64_t n_contigs, n_lone, count_minhash, count_minhash_not_in_graph, count_aligner, n_align_calls, n_bad_roundtrip, n_graph_check_fail; } harness_cons_stats;
+
+// streams_out[0..6] = genome, lone, id, pos, type, base, complement; streams_out[7] = metaData (malloc'ed)
+int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32_t k, uint32_t n, uint32_t thr, const uint64_t *salts,
+                      int m_k, int m_w, int mci, uint64_t edge_thr, int run_checks, uint8_t **streams_out, uint64_t *lens_out,
+                      harness_cons_stats *st)
+{
+    std::vector<std::string> reads(N);
+    static const char dna[4] = {'A', 'T', 'C', 'G'};
+    std::string folded(bases + off[0], bases + off[N]);
+    for (auto &c : folded) c = dna[(c & 2) | ((c & 4) >> 2)];
+    uint64_t total = 0;
+    for (uint32_t r = 0; r < N; ++r) { reads[r] = folded.substr(off[r] - off[0], off[r + 1] - off[r]); total += reads[r].size(); }
+    std::vector<uint64_t> sk((size_t)N * n), keys((size_t)N * n);
+    std::vector<uint32_t> start((size_t)(N + 1) * n), ids((size_t)N * n), nkeys(n);
+    std::vector<uint64_t> foff(N + 1);
+    for (uint32_t r = 0; r <= N; ++r) foff[r] = off[r] - off[0];
+    oracle_sketch_reads(folded.data(), foff.data(), N, k, n, salts, sk.data());
+    oracle_index_build(sk.data(), N, n, keys.data(), start.data(), ids.data(), nkeys.data());
+    std::vector<uint8_t> in_graph(N, 0), rep(N, 0);
+    for (uint32_t r = 0; r < N; ++r) rep[r] = reads[r].empty() ? 0 : (uint8_t)oracle_check_repetitive(reads[r].data(), reads[r].size());
+    const size_t offset = N ? std::max<size_t>(1, (total / N) / 4) : 1;
+    StreamSet out;
+    memset(st, 0, sizeof(*st));
+    std::vector<uint32_t> cand(N + 1);
+    read_t cursor = 0;
+    for (;;) {
+        read_t first = cursor;
+        while (first < N && in_graph[first]) ++first;
+        if (first >= N) break;
+        in_graph[first] = 1;
+        cursor = first + 1;
+        ContigGraph g;
+        g.main_path = reads[first];
+        g.start_pos = 0, g.end_pos = (ssize_t)reads[first].size(), g.first_read = first;
+        const ssize_t init_start = g.start_pos, len = g.end_pos - g.start_pos;
+        auto add_related = [&](ssize_t cur_pos) {
+            const ssize_t o = cur_pos - g.start_pos;
+            if (len == 0 || o < 0 || o >= (ssize_t)g.main_path.size()) return;
+            const std::string fwd = g.main_path.substr((size_t)o, (size_t)len);
+            std::string rcs;
+            reverse_complement(fwd, rcs);
+            for (int strand = 0; strand < 2; ++strand) {
+                const std::string &w = strand ? rcs : fwd;
+                uint64_t m;
+                const uint64_t nc = oracle_filter_string(w.data(), w.size(), k, N, n, thr, salts, keys.data(), start.data(), ids.data(), nkeys.data(),
+                                                         cand.data(), N, &m);
+                st->count_minhash += nc;
+                for (uint64_t ci = 0; ci < nc; ++ci) {
+                    const read_t r = cand[ci];
+                    if (g.num_edges() >= edge_thr) return;
+                    if (rep[r] || in_graph[r]) continue;
+                    ++st->count_minhash_not_in_graph;
+                    if (reads[r].size() < 32) continue;
+                    std::string q;
+                    if (strand) reverse_complement(reads[r], q); else q = reads[r];
+                    AlnOut ao;
+                    ++st->n_align_calls;
+                    if (!harness_align1(g.main_path, q, m_k, m_w, mci, ao)) continue;
+                    in_graph[r] = 1;
+                    ++st->count_aligner;
+                    if (g.num_reads() == 0) {
+                        const std::string seed = g.main_path;
+                        g.main_path.clear();
+                        g.initialize(seed, g.first_read, 0);
+                        g.calculate_main_path_greedy();
+                    }
+                    g.update_graph(q, ao.edits, (ssize_t)ao.begin_offset, (ssize_t)ao.end_offset, r, (long)ao.rel_pos, strand == 1);
+                    if (run_checks) {            // Consensus::checkRead / checkNoCycle under -DCHECKS (src/Consensus.cpp:328-337)
+                        std::string back;
+                        if (!g.read_string(r, back) || back != q) ++st->n_graph_check_fail;
+                    }
+                    g.calculate_main_path_greedy();
+                    if (run_checks) {
+                        std::string back;
+                        if (!g.read_string(r, back) || back != q || g.has_cycle()) ++st->n_graph_check_fail;
+                    }
+                }
+            }
+        };
+        bool too_many = false;
+        const bool usable = len >= 32 && !rep[first];
+        ssize_t cur_pos = g.start_pos;
+        while (usable) {
+            add_related(cur_pos);
+            cur_pos += (ssize_t)offset;
+            if (cur_pos + len > g.end_pos) break;
+            else if (g.num_edges() >= edge_thr) { too_many = true; break; }
+        }
+        cur_pos = init_start - (ssize_t)offset;
+        while (usable && !too_many) {
+            if (cur_pos < g.start_pos) break;
+            else if (g.num_edges() >= edge_thr) { too_many = true; break; }
+            add_related(cur_pos);
+            cur_pos -= (ssize_t)offset;
+        }
+        if (g.num_reads() == 0) {
+            g.write_read_lone(out);
+            out.lone_ids.push_back(first);
+            out.reads_in_contig.push_back(1);
+            ++st->n_lone;
+        } else {
+            g.write_main_path(out);
+            g.write_reads(out);
+            out.reads_in_contig.push_back((read_t)g.num_reads());
+        }
+        ++st->n_contigs;
+    }
+    // round trip through the decoder
+    {
+        std::vector<std::pair<read_t, std::string>> rd;
+        std::string err;
+        std::vector<uint8_t> seen(N, 0);
+        if (!decode_streams(out, rd, err)) st->n_bad_roundtrip = N + 1;
+        else {
+            for (auto &p : rd) { if (p.first >= N || seen[p.first] || p.second != reads[p.first]) ++st->n_bad_roundtrip; else seen[p.first] = 1; }
+            for (uint32_t r = 0; r < N; ++r) st->n_bad_roundtrip += !seen[r];
+        }
+    }
+    const std::string parts[8] = {out.genome, out.lone, out.id_bytes(), out.pos, out.type, out.base, out.complement,
+                                  meta_data(N, std::vector<StreamSet>(1, out))};
+    for (int i = 0; i < 8; ++i) {
+        streams_out[i] = (uint8_t *)malloc(parts[i].size() + 1);
+        memcpy(streams_out[i], parts[i].data(), parts[i].size());
+        lens_out[i] = parts[i].size();
+    }
+    return 0;
+}
+
+void harness_free(void *p) { free(p); }
+
+}

@@ -8,9 +8,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tests", "_build", "libhostharness.so")
-SRCS = [os.path.join(ROOT, "tests", "host_harness.cpp"), os.path.join(ROOT, "nanospring_amd", "csrc", "mm2.cpp")]
-CSRC = [os.path.join(ROOT, "oracle", "ksw2_oracle.c")]
-DEPS = SRCS + CSRC + [os.path.join(ROOT, "nanospring_amd", "csrc", "mm2.hpp")]
+SRCS = [os.path.join(ROOT, "tests", "host_harness.cpp"), os.path.join(ROOT, "nanospring_amd", "csrc", "mm2.cpp"),
+        os.path.join(ROOT, "nanospring_amd", "csrc", "consensus.cpp")]
+CSRC = [os.path.join(ROOT, "oracle", "ksw2_oracle.c"), os.path.join(ROOT, "oracle", "ns_oracle.c")]
+DEPS = SRCS + CSRC + [os.path.join(ROOT, "nanospring_amd", "csrc", "mm2.hpp"), os.path.join(ROOT, "nanospring_amd", "csrc", "consensus.hpp")]
 
 
 class HarnessAln(C.Structure):
@@ -22,9 +23,12 @@ def build():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     if os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
-    obj = os.path.join(os.path.dirname(OUT), "ksw2_oracle.o")
-    subprocess.run(["gcc", "-O2", "-fPIC", "-c", CSRC[0], "-o", obj], check=True)
-    subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-Wall"] + SRCS + [obj, "-o", OUT], check=True)
+    objs = []
+    for c in CSRC:
+        obj = os.path.join(os.path.dirname(OUT), os.path.basename(c) + ".o")
+        subprocess.run(["gcc", "-O2", "-fPIC", "-fopenmp", "-c", c, "-o", obj], check=True)
+        objs.append(obj)
+    subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fopenmp", "-Wall"] + SRCS + objs + ["-o", OUT], check=True)
     return OUT
 
 
@@ -62,3 +66,29 @@ def sketch(s, w, k):
     xy = np.zeros(2 * (len(b) + 8), dtype=np.uint64)
     n = L.harness_sketch(b, len(b), w, k, _p(xy), len(b) + 8)
     return xy[:2 * n].reshape(n, 2).copy()
+
+
+class HarnessConsStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_contigs", "n_lone", "count_minhash", "count_minhash_not_in_graph", "count_aligner", "n_align_calls",
+                                          "n_bad_roundtrip", "n_graph_check_fail")]
+
+
+STREAMS = ["genome", "lone", "id", "pos", "type", "base", "complement", "metaData"]
+
+
+def consensus(bases, off, salts, k=23, n=60, thr=6, m_k=20, m_w=50, mci=400, edge_thr=4000000, checks=True):
+    """The reference's -t 1 contig loop as plain nested loops over the product's host graph code, CPU oracle filter and DP."""
+    L = lib()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    salts = np.ascontiguousarray(salts, dtype=np.uint64)
+    ptrs = (C.c_void_p * 8)()
+    lens = (C.c_uint64 * 8)()
+    st = HarnessConsStats()
+    L.harness_consensus(_p(bases), _p(off), C.c_uint32(len(off) - 1), C.c_uint32(k), C.c_uint32(n), C.c_uint32(thr), _p(salts), m_k, m_w, mci,
+                        C.c_uint64(edge_thr), int(checks), ptrs, lens, C.byref(st))
+    out = {}
+    for i, name in enumerate(STREAMS):
+        out[name] = C.string_at(ptrs[i], lens[i])
+        L.harness_free(C.c_void_p(ptrs[i]))
+    return out, {f: getattr(st, f) for f, _ in HarnessConsStats._fields_}

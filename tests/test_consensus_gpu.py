@@ -1,0 +1,94 @@
+"""GPU tests of the contig stage: nsgpu_consensus_run (virtual
+builders in lock-step, window queries and alignments batched on the GPU).
+  - ONE builder must produce byte-identical streams to the plain sequential restatement of the
+    reference's -t 1 loop over the CPU oracles (tests/host_harness.cpp);
+  - any number of builders: lossless (library decoder and the independent Python decoder), deterministic;
+  - file names / metaData as Compressor::compress expects them."""
+import os
+
+import numpy as np
+import pytest
+
+import nanospring_amd as ns
+from tests import host_lib
+from tests.stream_decode import decode, fold
+from nanospring_amd.filter import STREAMS
+
+pytestmark = pytest.mark.gpu
+
+
+def run(bases, off, n_builders, n_out=1, **kw):
+    g = ns.NsGpu(**kw)
+    g.load_reads((bases, off))
+    g.sketch(ns.mt19937_64_salts(60), fetch=False)
+    g.build_index()
+    st = ns.consensus_run(g, n_builders, n_out)
+    streams = [{k: ns.consensus_stream(g, t, k) for k in STREAMS} for t in range(n_out)]
+    md = ns.consensus_stream(g, 0, "metaData")
+    return g, st, streams, md
+
+
+def test_one_builder_equals_sequential_reference_loop():
+    bases, off = ns.synth_reads(5, 40000, 160, 2500.0)
+    want, wst = host_lib.consensus(bases, off, ns.mt19937_64_salts(60), checks=False)
+    g, st, streams, md = run(bases, off, 1)
+    for k in STREAMS:
+        assert streams[0][k] == want[k], k
+    assert md == want["metaData"]
+    for a, b in (("count_minhash", "count_minhash"), ("count_minhash_not_in_graph", "count_minhash_not_in_graph"), ("count_aligner", "count_aligner"),
+                 ("n_contigs", "n_contigs"), ("n_lone", "n_lone"), ("n_align_calls", "n_align_calls")):
+        assert st[a] == wst[b], a
+    assert ns.consensus_verify(g) == 0
+    g.close()
+
+
+@pytest.mark.parametrize("n_builders,n_out", [(16, 1), (64, 3)])
+def test_many_builders_lossless_and_deterministic(n_builders, n_out):
+    bases, off = ns.synth_reads(31, 150000, 600, 4000.0)
+    g, st, streams, md = run(bases, off, n_builders, n_out)
+    assert ns.consensus_verify(g) == 0
+    b = bytes(bases)
+    got = {}
+    for s in streams:
+        d = decode(s)
+        assert not (set(d) & set(got))
+        got.update(d)
+    assert len(got) == 600
+    for i in range(600):
+        assert got[i] == b[int(off[i]):int(off[i + 1])]
+    assert st["count_aligner"] > 400 and st["n_rounds"] < 400
+    lines = md.decode().splitlines()
+    assert lines[0] == "numReads=600" and lines[2] == "numThr=%d" % n_out
+    assert sum(int(x) for x in lines[3].split("=")[1].split(":") if x) == 600
+    g.close()
+    g2, st2, streams2, md2 = run(bases, off, n_builders, n_out)
+    assert streams2 == streams and md2 == md
+    g2.close()
+
+
+def test_edge_cases_and_files(tmp_path):
+    rng = np.random.RandomState(2)
+    gs = "".join("ACGT"[i] for i in rng.randint(0, 4, size=6000))
+    reads = [gs[0:3000], gs[1000:4000], gs[2000:5500], gs[500:2500], "A" * 400, "ACGT", "", gs[100:131], gs[100:132], gs[0:3000],
+             gs[1500:3500].replace("A", "N", 5), "AC" * 300, gs[4000:6000]]
+    bases = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    want, _ = host_lib.consensus(bases, off, ns.mt19937_64_salts(60), checks=False)
+    g, st, streams, md = run(bases, off, 1)
+    for k in STREAMS:
+        assert streams[0][k] == want[k], k
+    assert ns.consensus_verify(g) == 0
+    d = str(tmp_path) + "/"
+    ns.consensus_write(g, d, "Stream")
+    for ext in STREAMS:
+        assert open(d + "Stream.tid.0." + ext, "rb").read() == streams[0][ext]
+    assert open(d + "metaData", "rb").read() == md
+    g.close()
+    g4, st4, streams4, _ = run(bases, off, 4, 2)
+    assert ns.consensus_verify(g4) == 0
+    got = {}
+    for s in streams4:
+        got.update(decode(s))
+    assert [got[i] for i in range(len(reads))] == [fold(r.encode()) for r in reads]
+    g4.close()
