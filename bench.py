@@ -1,23 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- Mbases/s through the NanoSpring hot path on MI355X.
+"""bench.py -- Mbases/s through the NanoSpring hot path (sketch + overlap + align + consensus edits) on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch of synthetic reads that is
-already resident (2-bit packed) in HBM: MinHash sketch of every read -> the n
-bucket tables -> overlap candidates for every read (forward + reverse-complement
-whole-read queries) [-> alignment stages as they land; config.stages lists what
-the timed region contains].  Workload = BASELINE.json configs[1]: 100 000
-synthetic ONT-like reads, mean 8 kb, k=23, n=60 per GPU.
+One "step" = one pass of the whole hot path over one batch of synthetic reads that is already
+resident (2-bit packed) in HBM:
+    MinHash sketch of every read -> n bucket tables                      (MinHashReadFilter::initialize)
+    -> contig stage: window queries against the tables, batched alignRead of every candidate
+       against its contig's consensus (all banded DP on the GPU), consensus-DAG update,
+       consensus-edit emission into the seven streams                    (Consensus::generateAndWriteConsensus)
+Workload = BASELINE.json configs[1]: 100 000 synthetic ONT-like reads, mean 8 kb, 20x of an iid
+genome, 1% sub + 1% ins + 1% del, k=23 n=60 thr=6, minimap k=20 w=50, per GPU.
 
-Multi-GPU: reads shard by id, one process per GPU, no data-path collective in the
-stages timed so far (weak scaling: every rank holds its own 100 k reads).
+Multi-GPU: reads shard by id, one process per GPU; every rank runs the whole path on its shard
+(contigs are built inside a shard), no data-path collective -> weak scaling.
 
-Prints ONE JSON line on rank 0 (contract in the task description), including
-  roofline     : dominant kernel's algorithmic bytes / its HIP-event duration vs HBM peak
-  cpu_baseline : the CPU oracle (bit-exact restatement, oracle/ns_oracle.c) timed on
-                 this host's cores on a bounded sample of the same workload.
+Prints ONE JSON line on rank 0, including
+  roofline     : dominant kernel (ksw_extd2 wavefront DP) algorithmic bytes / HIP-event kernel time vs HBM peak
+  cpu_baseline : the sequential CPU restatement of the same path (reference's -t 1 schedule; the
+                 reference's own minimap2 does the alignments when oracle/_ref is present), timed on
+                 this host on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -33,42 +36,34 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(bases, off, k, n, thr, salts, sample_reads):
-    """Oracle (kind "port") on the host cores, bounded sample, same stages as the GPU step."""
-    from tests import oracle_lib
-    orc = oracle_lib.Oracle()
-    ns_ = min(sample_reads, len(off) - 1)
-    sb = bases[:int(off[ns_])]
-    so = off[:ns_ + 1]
+def cpu_baseline(n_reads, mean_len, k, n, thr, salts):
+    """CPU checker path (kind "port": our sequential restatement of the -t 1 loop; the alignments are
+    answered by the reference's minimap2 when oracle/_ref/libmm2ref.so travelled with the repo)."""
+    import nanospring_amd as ns
+    from tests import host_lib, oracle_lib
+    bases, off = ns.synth_reads(11, int(n_reads * mean_len / 20), n_reads, mean_len)
+    use_ref = oracle_lib.mm2ref() is not None
     t0 = time.perf_counter()
-    sk = orc.sketch_reads(sb, so, k, n, salts)
-    t1 = time.perf_counter()
-    idx = orc.index_build(sk)
-    t2 = time.perf_counter()
-    # overlap queries: forward sketches are the reads' own; RC sketches need the RC strings
-    b = bytes(sb)
-    comp = bytes.maketrans(b"ATCG", b"TAGC")
-    nq = 0
-    for r in range(ns_):
-        s = b[int(so[r]):int(so[r + 1])]
-        orc.filter_sketch(sk[r], idx, thr)
-        orc.filter_string(s[::-1].translate(comp), k, salts, idx, thr)
-        nq += 2
-    t3 = time.perf_counter()
-    nb = int(so[-1])
-    return {"value": round(nb / 1e6 / (t3 - t0), 3), "unit": "Mbases/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": f"{ns_} reads / {nb / 1e6:.1f} Mbases of the same workload; sketch {t1 - t0:.2f}s (OpenMP), "
-                      f"tables {t2 - t1:.2f}s (OpenMP), overlap queries {t3 - t2:.2f}s (1 thread)"}
+    _, st = host_lib.consensus(bases, off, salts, k=k, n=n, thr=thr, checks=False, ref_aligner=use_ref)
+    dt = time.perf_counter() - t0
+    nb = int(off[-1])
+    assert st["n_bad_roundtrip"] == 0
+    return {"value": round(nb / 1e6 / dt, 3), "unit": "Mbases/s", "cores": 1, "kind": "port",
+            "sample": f"{n_reads} reads / {nb / 1e6:.1f} Mbases, same generator and parameters (20x of a {n_reads * mean_len / 20 / 1e6:.2f} Mb genome), "
+                      f"sequential -t 1 schedule in {dt:.1f} s: oracle MinHash filter + "
+                      f"{'the reference minimap2 (SSE ksw2, oracle/_ref)' if use_ref else 'oracle scalar DP'} + host consensus graph; "
+                      f"{st['count_aligner']} reads aligned into {st['n_contigs']} contigs"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU (cfg2: 100000)")
     ap.add_argument("--mean-len", type=float, default=8000.0)
-    ap.add_argument("--cpu-sample", type=int, default=3000, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--builders", type=int, default=1024, help="virtual contig builders per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=1500, help="reads in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -78,7 +73,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (no CPU fallback)")
+        sys.exit("bench.py needs a GPU (the product has no CPU fallback)")
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
@@ -88,8 +83,7 @@ def main():
     k, n, thr = 23, 60, 6
     salts = ns.mt19937_64_salts(n, 12345)
     genome_len = int(args.reads * args.mean_len / 20)          # 20x depth
-    # shard = its own slice of the read-id space: rank r draws reads with seed 11 + r
-    bases, off = ns.synth_reads(11 + rank, genome_len, args.reads, args.mean_len)
+    bases, off = ns.synth_reads(11 + rank, genome_len, args.reads, args.mean_len)   # rank r = read-id shard r
     n_bases = int(off[-1])
 
     stream = torch.cuda.Stream()
@@ -99,7 +93,7 @@ def main():
     def step():
         g.sketch(salts, fetch=False)
         g.build_index()
-        return g.filter_all_reads(fetch=False)
+        return ns.consensus_run(g, args.builders, 8)
 
     def barrier():
         torch.cuda.synchronize()
@@ -110,15 +104,15 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    ns.align_stats(g, reset=True)
+    sk_ms = idx_ms = 0.0
+    st = None
     t0 = time.perf_counter()
-    k_sketch = k_filter = k_index = 0.0
-    cands = 0
     for _ in range(args.steps):
-        cands = step()
+        st = step()
         tm = g.timing()
-        k_sketch += tm["sketch_kernel_ms"]
-        k_index += tm["index_ms"]
-        k_filter += tm["filter_ms"]
+        sk_ms += tm["sketch_kernel_ms"]
+        idx_ms += tm["index_ms"]
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -132,34 +126,46 @@ def main():
         total_bases = n_bases
 
     if rank == 0:
-        tm = g.timing()
         steps = max(args.steps, 1)
-        sk_ms = k_sketch / steps
-        # dominant kernel so far: the xor-min sketch kernel.  Algorithmic bytes per launch
-        # (SURVEY 8d): 0.25 B/base (2-bit read) + 8n B per read (sketch row).
-        alg_bytes = 0.25 * n_bases + 8.0 * n * args.reads
-        achieved = alg_bytes / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else 0.0
+        a = ns.align_stats(g)
+        bad = ns.consensus_verify(g)
+        stream_bytes = sum(len(ns.consensus_stream(g, t, kk)) for t in range(8) for kk in ns.filter.STREAMS)
+        # dominant kernel: the ksw_extd2 wavefront DP.  Algorithmic bytes per DP problem = its two
+        # sequences (1 B/base as coded) + its CIGAR (4 B/op) + the 44-byte result; the traceback matrix
+        # is scratch.  Launches = DP rounds; both figures are per launch.
+        launches = max(a["dp_rounds"], 1)
+        dp_ms = a["dp_kernel_ms"] / launches
+        alg = a.get("dp_alg_bytes", 0.0) / launches
+        achieved = alg / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
         out = {
             "metric": "Mbases/sec sketch+overlap+align, 8kb ONT reads",
             "value": round(total_bases * steps / 1e6 / dt, 2),
             "unit": "Mbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / steps * 1e3, 3),
+            "ms_per_step": round(dt / steps * 1e3, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
+            "dtype": "i8/i32 DP, u64 sketch", "data": "synthetic",
             "config": {"workload": f"cfg2: {args.reads} synthetic ONT reads/GPU, mean {args.mean_len:.0f} b, 20x of an iid genome, "
-                                   f"1% sub + 1% ins + 1% del, k=23 n=60 thr=6, salts mt19937_64(12345)",
-                       "stages": ["sketch", "bucket-tables", "overlap(fwd+rc whole-read queries)"],
-                       "stages_missing": ["align", "consensus-edit"],
-                       "bases_per_gpu": n_bases, "candidates_per_step": int(cands),
-                       "stage_ms": {"sketch": round(sk_ms, 3), "tables": round(k_index / steps, 3), "overlap": round(k_filter / steps, 3)},
-                       "parallelism": f"reads sharded by id x{world}"},
-            "roofline": {"kernel": "sketch_kernel<1>", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "note": "integer-ALU bound by construction: %.1f G xor-min/s" % (n * n_bases / (sk_ms * 1e-3) / 1e9 if sk_ms else 0)},
+                                   f"1% sub + 1% ins + 1% del, k=23 n=60 thr=6, minimap k=20 w=50 max_chain_iter=400, salts mt19937_64(12345)",
+                       "stages": ["sketch", "bucket-tables", "overlap (window queries)", "align (batched alignRead, DP on GPU)",
+                                  "consensus graph + edit emission (host)"],
+                       "bases_per_gpu": n_bases, "builders": st["n_builders"], "host_threads": a["host_threads"],
+                       "lossless_roundtrip_bad_reads": bad, "stream_bytes_per_base": round(stream_bytes / n_bases, 4),
+                       "contigs": st["n_contigs"], "lone_reads": st["n_lone"], "reads_aligned": st["count_aligner"], "align_calls": st["n_align_calls"],
+                       "rounds": st["n_rounds"],
+                       "stage_ms_per_step": {"sketch": round(sk_ms / steps, 2), "tables": round(idx_ms / steps, 2),
+                                             "contig_stage_total": round(st["total_ms"], 1), "window_queries": round(st["filter_ms"], 1),
+                                             "consensus_index": round(st["index_ms"], 1), "align_total": round(st["align_ms"], 1),
+                                             "align_dp_kernel": round(a["dp_kernel_ms"] / steps, 1), "graph_host_wall": round(st["graph_ms"], 1)},
+                       "parallelism": f"reads sharded by id x{world}, no collective"},
+            "roofline": {"kernel": "ksw_extd2_lds_kernel", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": None,
+                         "launches": int(a["dp_rounds"]), "avg_launch_ms": round(dp_ms, 3),
+                         "note": "integer DP, LDS/ALU bound by construction: %.1f GCUPS over %.3g cells" % (
+                             a["dp_cells"] / (a["dp_kernel_ms"] * 1e-3) / 1e9 if a["dp_kernel_ms"] else 0, a["dp_cells"])},
         }
         if args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(bases, off, k, n, thr, salts, args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.mean_len, k, n, thr, salts)
         print(json.dumps(out), flush=True)
     g.close()
     if dist is not None:

@@ -156,6 +156,7 @@ typedef struct {
     uint64_t pairs, dp_tasks, dp_rounds;
     double dp_cells;          /* sum of qlen*tlen over all DP problems */
     double index_ms, host_ms, dp_ms, dp_kernel_ms;   /* host wall / host wall / wall around the DP launches / HIP-event kernel time */
+    double dp_alg_bytes;      /* sum over DP problems of qlen + tlen + 4 * n_cigar + sizeof(result) */
     uint32_t host_threads, reserved;
 } nsgpu_align_stats;
 int nsgpu_get_align_stats(const nsgpu_ctx *ctx, nsgpu_align_stats *s);
@@ -172,7 +173,8 @@ typedef struct {
     uint32_t n_builders, reserved;
     uint64_t n_rounds, n_filter_rounds, n_align_rounds, n_windows, n_contigs, n_lone;
     uint64_t count_minhash, count_minhash_not_in_graph, count_aligner, n_align_calls;   /* CountStats, include/Consensus.h:19-35 */
-    double total_ms, graph_ms, filter_ms, index_ms, align_ms;
+    double total_ms, graph_ms, filter_ms, index_ms, align_ms;   /* wall per phase */
+    double graph_cpu_ms, graph_max_ms;                          /* summed / longest single builder step in the graph phase */
 } nsgpu_consensus_stats;
 int nsgpu_consensus_run(nsgpu_ctx *ctx, uint32_t n_builders, uint32_t n_threads_out, nsgpu_consensus_stats *stats_out);
 /* stream `which` of output thread `thread`: 0 .genome 1 .lone 2 .id 3 .pos 4 .type 5 .base 6 .complement, 7 = metaData

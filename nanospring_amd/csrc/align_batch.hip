@@ -15,6 +15,8 @@
 #include <thread>
 #include <chrono>
 #include <functional>
+#include <mutex>
+#include <condition_variable>
 #include "host_util.hpp"
 
 namespace nsgpu {
@@ -23,6 +25,16 @@ unsigned host_threads()
 {
     static unsigned n = [] {
         unsigned v = std::thread::hardware_concurrency();
+        // honour a cgroup CPU quota (containers): more runnable threads than quota only adds throttling
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64]; long long period = 0;
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+                const long long quota = atoll(q);
+                const unsigned lim = (unsigned)((quota + period - 1) / period);
+                if (lim >= 1 && lim < v) v = lim;
+            }
+            fclose(f);
+        }
         if (const char *e = getenv("NSGPU_THREADS")) { int x = atoi(e); if (x > 0) v = (unsigned)x; }
         if (v == 0) v = 8;
         if (v > 256) v = 256;
@@ -35,26 +47,89 @@ void parallel_for_impl(size_t n, const std::function<void(size_t)> &fn);
 template <class F>
 static void parallel_for(size_t n, F fn) { parallel_for_impl(n, std::function<void(size_t)>(fn)); }
 
+// Persistent host thread pool: workers sleep on a condition variable between jobs; a job is an
+// index range handed out in chunks through an atomic cursor.  (Spawning ~256 std::threads per
+// parallel loop cost more than the loops themselves.)
+namespace {
+class HostPool {
+public:
+    explicit HostPool(unsigned n) : n_(n) { for (unsigned i = 1; i < n_; ++i) th_.emplace_back([this, i] { worker(i); }); }
+    ~HostPool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    // pinned = true: index i always runs on thread i % n_threads (keeps a builder's heap traffic in one malloc arena)
+    void run(size_t n, const std::function<void(size_t)> &fn, bool pinned = false)
+    {
+        std::lock_guard<std::mutex> serial(run_m_);       // one job at a time
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn; total_ = n; next_.store(0); pinned_ = pinned;
+            chunk_ = n / ((size_t)n_ * 8) ? n / ((size_t)n_ * 8) : 1;
+            pending_ = (unsigned)th_.size();
+            ++gen_;
+        }
+        cv_.notify_all();
+        work(0);
+        std::unique_lock<std::mutex> lk(m_);
+        done_cv_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void work(unsigned me)
+    {
+        if (pinned_) { for (size_t i = me; i < total_; i += n_) (*fn_)(i); return; }
+        for (;;) {
+            const size_t b = next_.fetch_add(chunk_);
+            if (b >= total_) break;
+            const size_t e = b + chunk_ < total_ ? b + chunk_ : total_;
+            for (size_t i = b; i < e; ++i) (*fn_)(i);
+        }
+    }
+    void worker(unsigned me)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+            }
+            work(me);
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0) done_cv_.notify_one();
+        }
+    }
+    unsigned n_;
+    std::vector<std::thread> th_;
+    std::mutex m_, run_m_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    size_t total_ = 0, chunk_ = 1;
+    std::atomic<size_t> next_{0};
+    unsigned pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false, pinned_ = false;
+};
+}  // namespace
+
+static HostPool &the_pool() { static HostPool pool(host_threads()); return pool; }
+
 void parallel_for_impl(size_t n, const std::function<void(size_t)> &fn)
 {
     if (n == 0) return;
-    unsigned nt = host_threads();
-    if (nt > n) nt = (unsigned)n;
-    if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
-    std::atomic<size_t> next(0);
-    const size_t chunk = n / (nt * 8) ? n / (nt * 8) : 1;
-    std::vector<std::thread> th;
-    th.reserve(nt);
-    for (unsigned t = 0; t < nt; ++t)
-        th.emplace_back([&]() {
-            for (;;) {
-                const size_t b = next.fetch_add(chunk);
-                if (b >= n) break;
-                const size_t e = b + chunk < n ? b + chunk : n;
-                for (size_t i = b; i < e; ++i) fn(i);
-            }
-        });
-    for (auto &x : th) x.join();
+    if (n == 1 || host_threads() <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    the_pool().run(n, fn);
+}
+
+void parallel_for_pinned_impl(size_t n, const std::function<void(size_t)> &fn)
+{
+    if (n == 0) return;
+    if (host_threads() <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    the_pool().run(n, fn, true);
 }
 
 double now_ms()
@@ -210,6 +285,7 @@ extern "C" int nsgpu_get_align_stats(const nsgpu_ctx *c, nsgpu_align_stats *s)
     NS_CHECK(c && s, NSGPU_ERR_ARG, "null argument");
     s->pairs = c->aln_pairs; s->dp_tasks = c->aln_dp_tasks; s->dp_rounds = c->aln_rounds; s->dp_cells = c->ksw_cells;
     s->index_ms = c->aln_index_ms; s->host_ms = c->aln_host_ms; s->dp_ms = c->aln_dp_ms; s->dp_kernel_ms = c->ksw_kernel_ms;
+    s->dp_alg_bytes = c->ksw_alg_bytes;
     s->host_threads = host_threads();
     return NSGPU_OK;
 }
@@ -219,6 +295,6 @@ extern "C" int nsgpu_reset_align_stats(nsgpu_ctx *c)
     NS_CHECK(c, NSGPU_ERR_ARG, "null argument");
     c->aln_pairs = c->aln_dp_tasks = c->aln_rounds = 0;
     c->aln_index_ms = c->aln_host_ms = c->aln_dp_ms = 0;
-    c->ksw_kernel_ms = c->ksw_cells = 0;
+    c->ksw_kernel_ms = c->ksw_cells = c->ksw_alg_bytes = 0;
     return NSGPU_OK;
 }

@@ -255,9 +255,16 @@ void ContigGraph::remove_cycles()
         size_t ei = right_off_;
         const size_t end = main_edges.size();
         Node *n = ei < end ? main_edges[ei]->source : main_edges[ei - 1]->sink;
+        std::vector<Edge *> copy;
         for (;;) {
-            const std::vector<Edge *> copy = n->out;      // the walk edits n->out
-            for (Edge *e : copy) walk_and_prune(e, stack);
+            // walk_and_prune returns at once for edges into main-path nodes; only side branches need the
+            // (copied, because the walk edits n->out) edge list
+            bool side = false;
+            for (Edge *e : n->out) if (!e->sink->on_main) { side = true; break; }
+            if (side) {
+                copy = n->out;
+                for (Edge *e : copy) walk_and_prune(e, stack);
+            }
             if (ei == end) break;
             n = main_edges[ei]->sink;
             ++ei;
@@ -265,10 +272,15 @@ void ContigGraph::remove_cycles()
     }
     {
         size_t ei = left_off_ < main_edges.size() ? left_off_ : main_edges.size() - 1;
+        std::vector<Edge *> copy;
         for (;;) {
             Node *n = main_edges[ei]->source;
-            const std::vector<Edge *> copy = n->out;
-            for (Edge *e : copy) walk_and_prune(e, stack);
+            bool side = false;
+            for (Edge *e : n->out) if (!e->sink->on_main) { side = true; break; }
+            if (side) {
+                copy = n->out;
+                for (Edge *e : copy) walk_and_prune(e, stack);
+            }
             if (ei == 0) break;
             --ei;
         }

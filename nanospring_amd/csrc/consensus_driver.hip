@@ -48,6 +48,7 @@ struct Builder {
     bool idx_valid = false;
     cons::StreamSet out;
     uint64_t n_minhash = 0, n_minhash_new = 0, n_aligner = 0, n_align_calls = 0, n_contigs = 0, n_lone = 0;
+    double cpu_ms = 0, max_ms = 0;
 };
 
 struct Driver {
@@ -172,6 +173,15 @@ struct Driver {
     // parallel phase: consume what the last round delivered and run to the next request
     void advance(Builder &b)
     {
+        if (b.st != Builder::ADVANCE && b.st != Builder::GOT_FILTER && b.st != Builder::GOT_ALIGN) return;
+        const double t0 = now_ms();
+        advance_inner(b);
+        const double dt = now_ms() - t0;
+        b.cpu_ms += dt;
+        if (dt > b.max_ms) b.max_ms = dt;
+    }
+    void advance_inner(Builder &b)
+    {
         if (b.st == Builder::ADVANCE) walk(b, false);
         else if (b.st == Builder::GOT_FILTER) next_candidate(b);
         else if (b.st == Builder::GOT_ALIGN) {
@@ -225,17 +235,17 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
     for (;;) {
         // 1. parallel: consume deliveries, run to the next request
         double a0 = now_ms();
-        par_for(D.B.size(), [&](size_t i) { D.advance(D.B[i]); });
+        par_for_pinned(D.B.size(), [&](size_t i) { D.advance(D.B[i]); });
         // 2. sequential seed claims, then 3. parallel: open their first window
         bool any_new = false;
         for (Builder &b : D.B) if (b.st == Builder::NEED_CONTIG) { D.claim_seed(b); any_new |= b.st == Builder::ADVANCE; }
-        if (any_new) par_for(D.B.size(), [&](size_t i) { if (D.B[i].st == Builder::ADVANCE) D.advance(D.B[i]); });
+        if (any_new) par_for_pinned(D.B.size(), [&](size_t i) { if (D.B[i].st == Builder::ADVANCE) D.advance(D.B[i]); });
         // builders whose fresh contig finished at once (lone, repetitive or short seeds) claim again
         for (int guard = 0; guard < 1 << 30; ++guard) {
             bool again = false;
             for (Builder &b : D.B) if (b.st == Builder::NEED_CONTIG) { D.claim_seed(b); again |= b.st == Builder::ADVANCE; }
             if (!again) break;
-            par_for(D.B.size(), [&](size_t i) { if (D.B[i].st == Builder::ADVANCE) D.advance(D.B[i]); });
+            par_for_pinned(D.B.size(), [&](size_t i) { if (D.B[i].st == Builder::ADVANCE) D.advance(D.B[i]); });
         }
         S.graph_ms += now_ms() - a0;
         // 4. window queries of this round
@@ -305,6 +315,7 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
     for (Builder &b : D.B) {
         S.n_contigs += b.n_contigs; S.n_lone += b.n_lone; S.count_minhash += b.n_minhash; S.count_minhash_not_in_graph += b.n_minhash_new;
         S.count_aligner += b.n_aligner; S.n_align_calls += b.n_align_calls;
+        S.graph_cpu_ms += b.cpu_ms; if (b.max_ms > S.graph_max_ms) S.graph_max_ms = b.max_ms;
     }
     S.total_ms = now_ms() - t0;
     c->have_cons = true;

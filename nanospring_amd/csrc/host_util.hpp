@@ -14,6 +14,8 @@ unsigned host_threads();
 double now_ms();
 void parallel_for_impl(size_t n, const std::function<void(size_t)> &fn);
 template <class F> inline void par_for(size_t n, F fn) { parallel_for_impl(n, std::function<void(size_t)>(fn)); }
+void parallel_for_pinned_impl(size_t n, const std::function<void(size_t)> &fn);
+template <class F> inline void par_for_pinned(size_t n, F fn) { parallel_for_pinned_impl(n, std::function<void(size_t)>(fn)); }
 
 struct AlignReq {
     const mm2::RefIndex *idx;     // index of `ref` (owned by the caller, reusable across batches)

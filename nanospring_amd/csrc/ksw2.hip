@@ -453,6 +453,8 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
     NS_HIP(hipEventElapsedTime(&ms, c->t_kernel.a, c->t_kernel.b));
     c->ksw_kernel_ms += ms;
     c->ksw_cells += [&] { double s = 0; for (auto &t : tasks) s += (double)t.qlen * t.tlen; return s; }();
+    // algorithmic HBM bytes of a DP problem: both sequences in, CIGAR + result out (the traceback matrix is scratch)
+    for (size_t i = 0; i < n; ++i) c->ksw_alg_bytes += (double)tasks[i].qlen + tasks[i].tlen + 4.0 * results[i].n_cigar + sizeof(KswResult);
     return NSGPU_OK;
 }
 

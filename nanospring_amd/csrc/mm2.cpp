@@ -1148,31 +1148,29 @@ bool AlignJob::step()
     return true;
 }
 
-// ConsensusGraph::alignRead after mm_map (src/ConsensusGraph.cpp:219-397)
-void align_read_result(const AlignJob &job, const char *ref, size_t ref_len, AlnOut &out)
+// ConsensusGraph::alignRead after mm_map (src/ConsensusGraph.cpp:219-397): reg[0] -> Edit list + offsets
+void edits_from_hit(int hits, int rs, int re, int qs, int qe, int blen, int mlen, int n_ambi, int dp_max, bool has_p,
+                    const std::vector<uint32_t> &cigar, const char *ref, size_t ref_len, const char *s, size_t slen, AlnOut &out)
 {
     out = AlnOut();
-    out.hits = (int32_t)job.regs.size();
-    if (out.hits <= 0) return;
-    const Reg &r = job.regs[0];
-    const char *s = job.qstr;
-    const size_t slen = (size_t)job.qlen;
-    out.rs = r.rs, out.re = r.re, out.qs = r.qs, out.qe = r.qe, out.blen = r.blen, out.mlen = r.mlen;
-    out.n_ambi = (int32_t)r.p.n_ambi, out.dp_max = r.p.dp_max;
-    out.cigar = r.p.cigar;
-    out.n_cigar = r.has_p ? (int32_t)r.p.cigar.size() : -1;
-    const size_t edit_dis = (size_t)(r.blen - r.mlen + (int)r.p.n_ambi);
-    const int aligned_len = r.qe - r.qs;
-    if (r.rs > 0 && r.re < (int64_t)ref_len)
+    out.hits = hits;
+    if (hits <= 0) return;
+    out.rs = rs, out.re = re, out.qs = qs, out.qe = qe, out.blen = blen, out.mlen = mlen;
+    out.n_ambi = n_ambi, out.dp_max = dp_max;
+    out.cigar = cigar;
+    out.n_cigar = has_p ? (int32_t)cigar.size() : -1;
+    const size_t edit_dis = (size_t)(blen - mlen + n_ambi);
+    const int aligned_len = qe - qs;
+    if (rs > 0 && re < (int64_t)ref_len)
         if (edit_dis / (double)aligned_len >= 1.0 || (double)aligned_len / slen <= 0.0) return;   // ok stays 0
     std::vector<EditOp> &ed = out.edits;
-    int qpos = r.qs, rpos = r.rs;
-    out.rel_pos = (int64_t)r.rs - (int64_t)r.qs;
-    if (r.rs > 0) {
-        out.begin_offset = r.rs;
-        for (int i = 0; i < r.qs; ++i) ed.push_back({1, (uint8_t)s[i], 0});
-    } else out.begin_offset = -(int64_t)r.qs;
-    for (uint32_t c : r.p.cigar) {
+    int qpos = qs, rpos = rs;
+    out.rel_pos = (int64_t)rs - (int64_t)qs;
+    if (rs > 0) {
+        out.begin_offset = rs;
+        for (int i = 0; i < qs; ++i) ed.push_back({1, (uint8_t)s[i], 0});
+    } else out.begin_offset = -(int64_t)qs;
+    for (uint32_t c : cigar) {
         const uint32_t op = c & 0xf, len = c >> 4;
         if (op == 0) {
             uint32_t same = 0;
@@ -1193,13 +1191,21 @@ void align_read_result(const AlignJob &job, const char *ref, size_t ref_len, Aln
             for (uint32_t k = 0; k < len; ++k) ed.push_back({2, (uint8_t)ref[rpos++], 0});
         }
     }
-    if (r.re < (int64_t)ref_len) {
-        out.end_offset = (int64_t)r.re - (int64_t)ref_len;
-        for (size_t i = (size_t)r.qe; i < slen; ++i) ed.push_back({1, (uint8_t)s[i], 0});
-    } else out.end_offset = (int64_t)slen - r.qe;
+    if (re < (int64_t)ref_len) {
+        out.end_offset = (int64_t)re - (int64_t)ref_len;
+        for (size_t i = (size_t)qe; i < slen; ++i) ed.push_back({1, (uint8_t)s[i], 0});
+    } else out.end_offset = (int64_t)slen - qe;
     size_t unchanged = 0;
     for (const EditOp &e : ed) if (e.type == 0) unchanged += e.num;
     out.ok = unchanged != 0;
+}
+
+void align_read_result(const AlignJob &job, const char *ref, size_t ref_len, AlnOut &out)
+{
+    if (job.regs.empty()) { out = AlnOut(); return; }
+    const Reg &r = job.regs[0];
+    edits_from_hit((int)job.regs.size(), r.rs, r.re, r.qs, r.qe, r.blen, r.mlen, (int)r.p.n_ambi, r.p.dp_max, r.has_p, r.p.cigar, ref, ref_len,
+                   job.qstr, (size_t)job.qlen, out);
 }
 
 }  // namespace mm2

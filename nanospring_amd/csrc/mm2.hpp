@@ -123,6 +123,8 @@ struct AlnOut {
     std::vector<EditOp> edits;
 };
 void align_read_result(const AlignJob &job, const char *ref, size_t ref_len, AlnOut &out);
+void edits_from_hit(int hits, int rs, int re, int qs, int qe, int blen, int mlen, int n_ambi, int dp_max, bool has_p,
+                    const std::vector<uint32_t> &cigar, const char *ref, size_t ref_len, const char *qry, size_t qry_len, AlnOut &out);
 
 }  // namespace mm2
 }  // namespace nsgpu

@@ -273,7 +273,7 @@ class Aln(C.Structure):
 class AlignStats(C.Structure):
     _fields_ = [("pairs", C.c_uint64), ("dp_tasks", C.c_uint64), ("dp_rounds", C.c_uint64), ("dp_cells", C.c_double),
                 ("index_ms", C.c_double), ("host_ms", C.c_double), ("dp_ms", C.c_double), ("dp_kernel_ms", C.c_double),
-                ("host_threads", C.c_uint32), ("reserved", C.c_uint32)]
+                ("dp_alg_bytes", C.c_double), ("host_threads", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 EDIT_DT = np.dtype([("type", np.uint8), ("base", np.uint8), ("reserved", np.uint16), ("num", np.uint32)])
@@ -321,7 +321,7 @@ class ConsensusStats(C.Structure):
     _fields_ = [("n_builders", C.c_uint32), ("reserved", C.c_uint32)] + \
                [(n, C.c_uint64) for n in ("n_rounds", "n_filter_rounds", "n_align_rounds", "n_windows", "n_contigs", "n_lone", "count_minhash",
                                           "count_minhash_not_in_graph", "count_aligner", "n_align_calls")] + \
-               [(n, C.c_double) for n in ("total_ms", "graph_ms", "filter_ms", "index_ms", "align_ms")]
+               [(n, C.c_double) for n in ("total_ms", "graph_ms", "filter_ms", "index_ms", "align_ms", "graph_cpu_ms", "graph_max_ms")]
 
 
 STREAMS = ["genome", "lone", "id", "pos", "type", "base", "complement"]

@@ -91,7 +91,9 @@ void harness_radix_sort_64(uint64_t *x, int64_t n) { radix_sort_64(x, x + n); }
 // product's host-side graph / emission / decoder code on the CPU.
 // ---------------------------------------------------------------------------
 #include <string>
+#include <chrono>
 #include "../nanospring_amd/csrc/consensus.hpp"
+static double hnow() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 extern "C" {
 void oracle_sketch_reads(const char *bases, const uint64_t *off, uint32_t N, uint32_t k, uint32_t n, const uint64_t *salts, uint64_t *sketches);
@@ -104,8 +106,24 @@ int oracle_check_repetitive(const char *s, uint64_t len);
 
 using namespace nsgpu::cons;
 
+// optional: answer alignments with the REFERENCE's minimap2 (ref_mm2_align of oracle/_ref/libmm2ref.so);
+// used for the CPU baseline of bench.py (the reference's own aligner at SSE speed)
+typedef struct { int32_t hits, rs, re, qs, qe, blen, mlen, n_ambi, dp_max, dp_score, score, cnt, rev, mid_occ, n_cigar; } ref_aln_t;
+typedef int (*ref_align_fn)(const char *, int, const char *, int, int, int, int, ref_aln_t *, uint32_t *, int);
+static ref_align_fn g_ref_align = nullptr;
+extern "C" void harness_set_ref_align(void *fn) { g_ref_align = (ref_align_fn)fn; }
+
 static bool harness_align1(const std::string &ref, const std::string &q, int k, int w, int mci, AlnOut &ao)
 {
+    if (g_ref_align) {
+        ref_aln_t ra;
+        std::vector<uint32_t> cig(ref.size() + q.size() + 8);
+        g_ref_align(ref.c_str(), (int)ref.size(), q.c_str(), (int)q.size(), k, w, mci, &ra, cig.data(), (int)cig.size());
+        cig.resize(ra.n_cigar > 0 ? ra.n_cigar : 0);
+        edits_from_hit(ra.hits, ra.rs, ra.re, ra.qs, ra.qe, ra.blen, ra.mlen, ra.n_ambi, ra.dp_max, ra.n_cigar >= 0, cig, ref.data(), ref.size(), q.data(),
+                       q.size(), ao);
+        return ao.ok != 0;
+    }
     RefIndex ri;
     ri.build(ref.data(), (uint32_t)ref.size(), w, k, 2e-4f);
     Opt o;
@@ -119,7 +137,7 @@ static bool harness_align1(const std::string &ref, const std::string &q, int k, 
 
 extern "C" {
 
-typedef struct { uint64_t n_contigs, n_lone, count_minhash, count_minhash_not_in_graph, count_aligner, n_align_calls, n_bad_roundtrip, n_graph_check_fail; } harness_cons_stats;
+typedef struct { uint64_t n_contigs, n_lone, count_minhash, count_minhash_not_in_graph, count_aligner, n_align_calls, n_bad_roundtrip, n_graph_check_fail; double update_ms, mainpath_ms, write_ms; } harness_cons_stats;
 
 // streams_out[0..6] = genome, lone, id, pos, type, base, complement; streams_out[7] = metaData (malloc'ed)
 int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32_t k, uint32_t n, uint32_t thr, const uint64_t *salts,
@@ -186,12 +204,16 @@ int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32
                         g.initialize(seed, g.first_read, 0);
                         g.calculate_main_path_greedy();
                     }
+                    double t0 = hnow();
                     g.update_graph(q, ao.edits, (ssize_t)ao.begin_offset, (ssize_t)ao.end_offset, r, (long)ao.rel_pos, strand == 1);
+                    st->update_ms += hnow() - t0;
                     if (run_checks) {            // Consensus::checkRead / checkNoCycle under -DCHECKS (src/Consensus.cpp:328-337)
                         std::string back;
                         if (!g.read_string(r, back) || back != q) ++st->n_graph_check_fail;
                     }
+                    t0 = hnow();
                     g.calculate_main_path_greedy();
+                    st->mainpath_ms += hnow() - t0;
                     if (run_checks) {
                         std::string back;
                         if (!g.read_string(r, back) || back != q || g.has_cycle()) ++st->n_graph_check_fail;
@@ -221,8 +243,10 @@ int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32
             out.reads_in_contig.push_back(1);
             ++st->n_lone;
         } else {
+            double t0 = hnow();
             g.write_main_path(out);
             g.write_reads(out);
+            st->write_ms += hnow() - t0;
             out.reads_in_contig.push_back((read_t)g.num_reads());
         }
         ++st->n_contigs;

@@ -70,15 +70,23 @@ def sketch(s, w, k):
 
 class HarnessConsStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_contigs", "n_lone", "count_minhash", "count_minhash_not_in_graph", "count_aligner", "n_align_calls",
-                                          "n_bad_roundtrip", "n_graph_check_fail")]
+                                          "n_bad_roundtrip", "n_graph_check_fail")] + \
+               [(n, C.c_double) for n in ("update_ms", "mainpath_ms", "write_ms")]
 
 
 STREAMS = ["genome", "lone", "id", "pos", "type", "base", "complement", "metaData"]
 
 
-def consensus(bases, off, salts, k=23, n=60, thr=6, m_k=20, m_w=50, mci=400, edge_thr=4000000, checks=True):
-    """The reference's -t 1 contig loop as plain nested loops over the product's host graph code, CPU oracle filter and DP."""
+def consensus(bases, off, salts, k=23, n=60, thr=6, m_k=20, m_w=50, mci=400, edge_thr=4000000, checks=True, ref_aligner=False):
+    """The reference's -t 1 contig loop as plain nested loops over the product's host graph code, CPU oracle filter and DP.
+    ref_aligner=True answers every alignment with the reference's own minimap2 (oracle/_ref/libmm2ref.so) instead."""
     L = lib()
+    if ref_aligner:
+        from tests import oracle_lib
+        fn = C.cast(oracle_lib.mm2ref().ref_mm2_align, C.c_void_p)
+        L.harness_set_ref_align(fn)
+    else:
+        L.harness_set_ref_align(None)
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     off = np.ascontiguousarray(off, dtype=np.uint64)
     salts = np.ascontiguousarray(salts, dtype=np.uint64)
