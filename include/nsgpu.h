@@ -157,6 +157,7 @@ typedef struct {
     double dp_cells;          /* sum of qlen*tlen over all DP problems */
     double index_ms, host_ms, dp_ms, dp_kernel_ms;   /* host wall / host wall / wall around the DP launches / HIP-event kernel time */
     double dp_alg_bytes;      /* sum over DP problems of qlen + tlen + 4 * n_cigar + sizeof(result) */
+    uint64_t dp_launches;     /* ksw_extd2 kernel launches (one per LDS size class per DP round) */
     uint32_t host_threads, reserved;
 } nsgpu_align_stats;
 int nsgpu_get_align_stats(const nsgpu_ctx *ctx, nsgpu_align_stats *s);

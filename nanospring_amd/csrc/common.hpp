@@ -108,6 +108,7 @@ struct nsgpu_ctx {
     // ksw2 batches
     nsgpu::DevBuf k_tasks, k_order, k_seqs, k_p, k_cig, k_res, k_slab;
     double ksw_kernel_ms = 0, ksw_cells = 0, ksw_alg_bytes = 0;
+    uint64_t ksw_launches = 0;
     // align batches
     uint64_t aln_pairs = 0, aln_dp_tasks = 0, aln_rounds = 0;
     double aln_index_ms = 0, aln_host_ms = 0, aln_dp_ms = 0;

@@ -3,9 +3,20 @@
 #include <algorithm>
 #include <cassert>
 #include <cstring>
+#include <cstdlib>
 #include <iterator>
 #include <new>
 #include <set>
+
+#ifdef NSGPU_PROF
+#include <chrono>
+double g_prof[8];
+#define PROF_T(x) const double x = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count()
+#define PROF_ADD(i, v) g_prof[i] += (v)
+#else
+#define PROF_T(x)
+#define PROF_ADD(i, v)
+#endif
 
 namespace nsgpu {
 namespace cons {
@@ -59,7 +70,9 @@ Edge *ContigGraph::create_edge(Node *s, Node *t, read_t r)
 {
     Edge *e = edges_.make();
     e->source = s, e->sink = t, e->count = 1, e->reads.push_back(r);
+    n_multi_in_side_ -= multi_in_side(t);
     s->out.push_back(e), t->in.push_back(e);
+    n_multi_in_side_ += multi_in_side(t);
     ++n_edges_;
     return e;
 }
@@ -67,7 +80,9 @@ Edge *ContigGraph::create_edge(Node *s, Node *t, const std::vector<read_t> &rs)
 {
     Edge *e = edges_.make();
     e->source = s, e->sink = t, e->reads = rs, e->count = (read_t)rs.size();
+    n_multi_in_side_ -= multi_in_side(t);
     s->out.push_back(e), t->in.push_back(e);
+    n_multi_in_side_ += multi_in_side(t);
     ++n_edges_;
     return e;
 }
@@ -80,13 +95,17 @@ void ContigGraph::remove_edge(Edge *e, bool keep_in_source, bool keep_in_sink)
     }
     if (!keep_in_sink) {
         auto &v = e->sink->in;
+        n_multi_in_side_ -= multi_in_side(e->sink);
         v.erase(std::find(v.begin(), v.end(), e));
+        n_multi_in_side_ += multi_in_side(e->sink);
     }
     edges_.free(e);
     --n_edges_;
 }
 void ContigGraph::remove_node(Node *n)
 {
+    n_multi_in_side_ -= multi_in_side(n);
+    n->on_main = true;      // keeps the counter untouched while the node's edges go away
     for (Edge *e : std::vector<Edge *>(n->in)) remove_edge(e, false, true);
     for (Edge *e : std::vector<Edge *>(n->out)) remove_edge(e, true, false);
     nodes_.free(n);
@@ -111,7 +130,7 @@ void ContigGraph::initialize(const std::string &seed, read_t id, long pos)
     right_unchanged_ = left_unchanged_ = cur;
     right_off_ = left_off_ = 0;
     main_path.push_back(cur->base);
-    cur->on_main = true;
+    set_on_main(cur, true);
     cur->cum_weight = 0;
     for (size_t i = 1; i < seed.length(); ++i) {
         Node *nx = create_node(seed[i]);
@@ -194,10 +213,10 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
 void ContigGraph::clear_main_path()
 {
     const size_t l = main_edges.size();
-    for (size_t i = right_off_; i < l; ++i) main_edges[i]->sink->on_main = false;
+    for (size_t i = right_off_; i < l; ++i) set_on_main(main_edges[i]->sink, false);
     if (right_off_ < main_edges.size()) main_edges.erase(main_edges.begin() + right_off_, main_edges.end());
     if (main_path.size() > right_off_ + 1) main_path.erase(main_path.begin() + right_off_ + 1, main_path.end());
-    for (size_t i = 0; i < left_off_; ++i) main_edges[i]->source->on_main = false;
+    for (size_t i = 0; i < left_off_; ++i) set_on_main(main_edges[i]->source, false);
     if (left_off_ > 0) {
         main_edges.erase(main_edges.begin(), main_edges.begin() + left_off_);
         main_path.erase(main_path.begin(), main_path.begin() + left_off_);
@@ -208,20 +227,23 @@ void ContigGraph::clear_main_path()
 
 void ContigGraph::calculate_main_path_greedy()
 {
+    PROF_T(t0);
     clear_main_path();
+    PROF_T(t1);
     {
         Node *cur = right_unchanged_;
         Edge *e;
         while ((e = cur->best_out())) {
             main_edges.push_back(e);
             cur = e->sink;
-            cur->on_main = true;
+            set_on_main(cur, true);
             main_path.push_back(cur->base);
         }
         const read_t ending = *main_edges.back()->reads.begin();
         const GraphRead &er = reads.at(ending);
         end_pos = er.pos + (long)er.len;
     }
+    PROF_T(t2);
     {
         Node *cur = left_unchanged_;
         Edge *e;
@@ -229,7 +251,7 @@ void ContigGraph::calculate_main_path_greedy()
         while ((e = cur->best_in())) {
             main_edges.push_front(e);
             cur = e->source;
-            cur->on_main = true;
+            set_on_main(cur, true);
             prefix.push_back(cur->base);
             ++left_off_;
             ++right_off_;
@@ -241,7 +263,10 @@ void ContigGraph::calculate_main_path_greedy()
         const read_t starting = *main_edges.front()->reads.begin();
         start_pos = reads.at(starting).pos;
     }
+    PROF_T(t3);
     remove_cycles();
+    PROF_T(t4);
+    PROF_ADD(0, t1 - t0); PROF_ADD(1, t2 - t1); PROF_ADD(2, t3 - t2); PROF_ADD(3, t4 - t3);
     right_unchanged_ = main_edges.back()->sink;
     right_off_ = main_edges.size();
     left_unchanged_ = main_edges.front()->source;
@@ -250,6 +275,9 @@ void ContigGraph::calculate_main_path_greedy()
 
 void ContigGraph::remove_cycles()
 {
+    ++dbg_cycles_calls;
+    static const bool no_skip = getenv("NSGPU_NO_CYCLE_SKIP") != nullptr;       // debugging aid: always walk, as the reference does
+    if (n_multi_in_side_ == 0 && !no_skip) { ++dbg_cycles_skipped; return; }   // exact: walk_and_prune only ever acts on side nodes with in-degree > 1
     std::vector<Edge *> stack;
     {
         size_t ei = right_off_;
@@ -374,6 +402,7 @@ size_t optimize_edit_script(const std::vector<EditOp> &in, std::vector<EditOp> &
 size_t ContigGraph::read_to_edits(const GraphRead &r, read_t id, std::vector<EditOp> &script, uint32_t &pos) const
 {
     script.clear();
+    script.reserve(r.len / 8 + 16);
     auto next = [&](const Node *n) -> Node * { Edge *e = n->edge_in_read(id); return e ? e->sink : nullptr; };
     Node *cur = r.start;
     bool meets = true;

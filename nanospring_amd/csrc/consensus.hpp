@@ -98,6 +98,14 @@ private:
     Node *right_unchanged_ = nullptr, *left_unchanged_ = nullptr;
     size_t right_off_ = 0, left_off_ = 0;
     size_t n_nodes_ = 0, n_edges_ = 0;
+    // number of side nodes (not on the main path) with more than one edge in: remove_cycles has work to do
+    // only while this is non-zero (walk_and_prune acts on nothing else)
+    size_t n_multi_in_side_ = 0;
+    static bool multi_in_side(const Node *n) { return !n->on_main && n->in.size() > 1; }
+    void set_on_main(Node *n, bool v) { n_multi_in_side_ -= multi_in_side(n); n->on_main = v; n_multi_in_side_ += multi_in_side(n); }
+public:
+    uint64_t dbg_cycles_calls = 0, dbg_cycles_skipped = 0;
+private:
     Pool<Node> nodes_;
     Pool<Edge> edges_;
     Node *create_node(char b);

@@ -433,6 +433,7 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
                            c->k_order.as<uint32_t>() + start[k], m, pr, c->k_seqs.as<uint8_t>(), c->k_p.as<uint8_t>(), c->k_cig.as<uint32_t>(),
                            c->k_res.as<KswResult>());
         NS_HIP(hipGetLastError());
+        ++c->ksw_launches;
     }
     if (!order[3].empty()) {
         const uint32_t m = (uint32_t)order[3].size();
@@ -443,6 +444,7 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
                            c->k_seqs.as<uint8_t>(), c->k_p.as<uint8_t>(), c->k_cig.as<uint32_t>(), c->k_res.as<KswResult>(), c->k_slab.as<uint8_t>(),
                            hbm_stride);
         NS_HIP(hipGetLastError());
+        ++c->ksw_launches;
     }
     NS_HIP(hipEventRecord(c->t_kernel.b, c->stream));
     NS_HIP(hipMemcpyAsync(results.data(), c->k_res.p, n * sizeof(KswResult), hipMemcpyDeviceToHost, c->stream));

@@ -1164,6 +1164,7 @@ void edits_from_hit(int hits, int rs, int re, int qs, int qe, int blen, int mlen
     if (rs > 0 && re < (int64_t)ref_len)
         if (edit_dis / (double)aligned_len >= 1.0 || (double)aligned_len / slen <= 0.0) return;   // ok stays 0
     std::vector<EditOp> &ed = out.edits;
+    ed.reserve(cigar.size() * 2 + (size_t)(blen - mlen) * 2 + 64);
     int qpos = qs, rpos = rs;
     out.rel_pos = (int64_t)rs - (int64_t)qs;
     if (rs > 0) {
