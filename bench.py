@@ -89,6 +89,7 @@ def main():
     stream = torch.cuda.Stream()
     g = ns.NsGpu(k=k, n=n, overlap_sketch_thr=thr, device=local, stream=stream.cuda_stream)
     g.load_reads((bases, off))          # host -> HBM + 2-bit pack: outside the timed region
+    ns.filter.check(g.lib, g.lib.nsgpu_set_read_id_base(g.ctx, rank * args.reads))   # global read ids of this shard
 
     def step():
         g.sketch(salts, fetch=False)
@@ -145,7 +146,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / steps * 1e3, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "i8/i32 DP, u64 sketch", "data": "synthetic",
+            "dtype": "i8", "data": "synthetic",
             "config": {"workload": f"cfg2: {args.reads} synthetic ONT reads/GPU, mean {args.mean_len:.0f} b, 20x of an iid genome, "
                                    f"1% sub + 1% ins + 1% del, k=23 n=60 thr=6, minimap k=20 w=50 max_chain_iter=400, salts mt19937_64(12345)",
                        "stages": ["sketch", "bucket-tables", "overlap (window queries)", "align (batched alignRead, DP on GPU)",

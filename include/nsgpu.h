@@ -177,6 +177,9 @@ typedef struct {
     double total_ms, graph_ms, filter_ms, index_ms, align_ms;   /* wall per phase */
     double graph_cpu_ms, graph_max_ms;                          /* summed / longest single builder step in the graph phase */
 } nsgpu_consensus_stats;
+/* Multi-GPU shards: global id of this context's read 0; the .id streams then carry global read ids so that the
+ * stream sets of all shards can sit side by side as additional "threads" of one archive (default 0). */
+int nsgpu_set_read_id_base(nsgpu_ctx *ctx, uint32_t base);
 int nsgpu_consensus_run(nsgpu_ctx *ctx, uint32_t n_builders, uint32_t n_threads_out, nsgpu_consensus_stats *stats_out);
 /* stream `which` of output thread `thread`: 0 .genome 1 .lone 2 .id 3 .pos 4 .type 5 .base 6 .complement, 7 = metaData
  * (thread ignored).  *data_out is library-allocated (nsgpu_free). */

@@ -56,6 +56,7 @@ SIGNATURES = {
     "nsgpu_align_batch": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, C.c_uint32, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "nsgpu_get_align_stats": (C.c_int, [_vp, _vp]),
     "nsgpu_reset_align_stats": (C.c_int, [_vp]),
+    "nsgpu_set_read_id_base": (C.c_int, [_vp, C.c_uint32]),
     "nsgpu_consensus_run": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
     "nsgpu_consensus_stream": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "nsgpu_consensus_write": (C.c_int, [_vp, C.c_char_p, C.c_char_p]),

@@ -117,6 +117,7 @@ struct nsgpu_ctx {
     std::vector<uint64_t> h_off;
     // consensus run
     bool have_cons = false;
+    uint32_t read_id_base = 0;   // global id of local read 0 (multi-GPU shards)
     nsgpu_consensus_stats cons_stats;
     std::vector<nsgpu::cons::StreamSet> cons_out;
     nsgpu::Timer t_stage, t_kernel;

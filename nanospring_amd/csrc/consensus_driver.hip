@@ -53,7 +53,7 @@ struct Builder {
 
 struct Driver {
     nsgpu_ctx *c;
-    uint32_t N;
+    uint32_t N, id_base = 0;
     uint64_t edge_thr;
     size_t offset;                     // avgReadLen / 4 (src/Consensus.cpp:54)
     std::vector<uint8_t> in_graph, rep;
@@ -73,7 +73,7 @@ struct Driver {
         b.g->main_path.assign(read_ptr(r), read_len(r));
         b.g->start_pos = 0;
         b.g->end_pos = (ssize_t)read_len(r);
-        b.g->first_read = r;
+        b.g->first_read = r + id_base;       // graph / stream ids are global, array indices local
         b.cursor = r + 1;
         b.init_start = 0;
         b.len = b.g->end_pos - b.g->start_pos;
@@ -121,7 +121,7 @@ struct Driver {
     void walk(Builder &b, bool window_just_done)
     {
         cons::ContigGraph &g = *b.g;
-        const bool usable = b.len >= 32 && !rep[g.first_read];
+        const bool usable = b.len >= 32 && !rep[g.first_read - id_base];
         for (;;) {
             if (b.right_phase) {
                 if (window_just_done) {
@@ -193,7 +193,7 @@ struct Driver {
                     g.initialize(seed, g.first_read, 0);
                     g.calculate_main_path_greedy();
                 }
-                g.update_graph(b.query, b.aln.edits, (ssize_t)b.aln.begin_offset, (ssize_t)b.aln.end_offset, b.pend, (long)b.aln.rel_pos, b.strand == 1);
+                g.update_graph(b.query, b.aln.edits, (ssize_t)b.aln.begin_offset, (ssize_t)b.aln.end_offset, b.pend + id_base, (long)b.aln.rel_pos, b.strand == 1);
                 g.calculate_main_path_greedy();
                 b.idx_valid = false;
                 b.accepted = false;
@@ -212,6 +212,8 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
     D.c = c;
     D.N = c->reads.n;
     D.edge_thr = c->prm.edge_threshold;
+    D.id_base = c->read_id_base;
+    NS_CHECK((uint64_t)D.id_base + D.N <= 0xFFFFFFFFull, NSGPU_ERR_RANGE, "read id base + reads exceeds read_t");
     D.offset = D.N ? (size_t)(c->reads.n_bases / D.N) / 4 : 0;      // avgReadLen is integer-truncated (src/ReadData.cpp:207)
     if (D.offset == 0) D.offset = 1;                                  // the reference would never terminate with a zero stride
     D.in_graph.assign(D.N, 0);
@@ -328,6 +330,13 @@ using namespace nsgpu;
 
 extern "C" {
 
+int nsgpu_set_read_id_base(nsgpu_ctx *c, uint32_t base)
+{
+    NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
+    c->read_id_base = base;
+    return NSGPU_OK;
+}
+
 int nsgpu_consensus_run(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_out, nsgpu_consensus_stats *stats_out)
 {
     NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
@@ -392,10 +401,11 @@ int nsgpu_consensus_verify(nsgpu_ctx *c, uint64_t *n_bad_out)
         std::string err;
         if (!cons::decode_streams(s, rd, err)) { set_error("stream set does not decode: %s", err.c_str()); return NSGPU_ERR_ARG; }
         for (auto &pr : rd) {
-            if (pr.first >= N || seen[pr.first]) { ++bad; continue; }
-            seen[pr.first] = 1;
-            const size_t L = (size_t)(c->h_off[pr.first + 1] - c->h_off[pr.first]);
-            if (pr.second.size() != L || memcmp(pr.second.data(), c->h_bases.data() + c->h_off[pr.first], L) != 0) ++bad;
+            const uint32_t r = pr.first - c->read_id_base;      // streams carry global ids
+            if (pr.first < c->read_id_base || r >= N || seen[r]) { ++bad; continue; }
+            seen[r] = 1;
+            const size_t L = (size_t)(c->h_off[r + 1] - c->h_off[r]);
+            if (pr.second.size() != L || memcmp(pr.second.data(), c->h_bases.data() + c->h_off[r], L) != 0) ++bad;
         }
     }
     for (uint32_t r = 0; r < N; ++r) bad += !seen[r];

@@ -144,7 +144,7 @@ typedef struct { uint64_t n_contigs, n_lone, count_minhash, count_minhash_not_in
 // streams_out[0..6] = genome, lone, id, pos, type, base, complement; streams_out[7] = metaData (malloc'ed)
 int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32_t k, uint32_t n, uint32_t thr, const uint64_t *salts,
                       int m_k, int m_w, int mci, uint64_t edge_thr, int run_checks, uint8_t **streams_out, uint64_t *lens_out,
-                      harness_cons_stats *st)
+                      harness_cons_stats *st, uint32_t id_base)
 {
     std::vector<std::string> reads(N);
     static const char dna[4] = {'A', 'T', 'C', 'G'};
@@ -173,7 +173,7 @@ int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32
         cursor = first + 1;
         ContigGraph g;
         g.main_path = reads[first];
-        g.start_pos = 0, g.end_pos = (ssize_t)reads[first].size(), g.first_read = first;
+        g.start_pos = 0, g.end_pos = (ssize_t)reads[first].size(), g.first_read = first + id_base;
         const ssize_t init_start = g.start_pos, len = g.end_pos - g.start_pos;
         auto add_related = [&](ssize_t cur_pos) {
             const ssize_t o = cur_pos - g.start_pos;
@@ -207,18 +207,18 @@ int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32
                         g.calculate_main_path_greedy();
                     }
                     double t0 = hnow();
-                    g.update_graph(q, ao.edits, (ssize_t)ao.begin_offset, (ssize_t)ao.end_offset, r, (long)ao.rel_pos, strand == 1);
+                    g.update_graph(q, ao.edits, (ssize_t)ao.begin_offset, (ssize_t)ao.end_offset, r + id_base, (long)ao.rel_pos, strand == 1);
                     st->update_ms += hnow() - t0;
                     if (run_checks) {            // Consensus::checkRead / checkNoCycle under -DCHECKS (src/Consensus.cpp:328-337)
                         std::string back;
-                        if (!g.read_string(r, back) || back != q) ++st->n_graph_check_fail;
+                        if (!g.read_string(r + id_base, back) || back != q) ++st->n_graph_check_fail;
                     }
                     t0 = hnow();
                     g.calculate_main_path_greedy();
                     st->mainpath_ms += hnow() - t0;
                     if (run_checks) {
                         std::string back;
-                        if (!g.read_string(r, back) || back != q || g.has_cycle()) ++st->n_graph_check_fail;
+                        if (!g.read_string(r + id_base, back) || back != q || g.has_cycle()) ++st->n_graph_check_fail;
                     }
                 }
             }
@@ -241,7 +241,7 @@ int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32
         }
         if (g.num_reads() == 0) {
             g.write_read_lone(out);
-            out.lone_ids.push_back(first);
+            out.lone_ids.push_back(first + id_base);
             out.reads_in_contig.push_back(1);
             ++st->n_lone;
         } else {
@@ -261,7 +261,7 @@ int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32
         std::vector<uint8_t> seen(N, 0);
         if (!decode_streams(out, rd, err)) st->n_bad_roundtrip = N + 1;
         else {
-            for (auto &p : rd) { if (p.first >= N || seen[p.first] || p.second != reads[p.first]) ++st->n_bad_roundtrip; else seen[p.first] = 1; }
+            for (auto &p : rd) { const uint32_t r = p.first - id_base; if (p.first < id_base || r >= N || seen[r] || p.second != reads[r]) ++st->n_bad_roundtrip; else seen[r] = 1; }
             for (uint32_t r = 0; r < N; ++r) st->n_bad_roundtrip += !seen[r];
         }
     }

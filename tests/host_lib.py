@@ -77,7 +77,7 @@ class HarnessConsStats(C.Structure):
 STREAMS = ["genome", "lone", "id", "pos", "type", "base", "complement", "metaData"]
 
 
-def consensus(bases, off, salts, k=23, n=60, thr=6, m_k=20, m_w=50, mci=400, edge_thr=4000000, checks=True, ref_aligner=False):
+def consensus(bases, off, salts, k=23, n=60, thr=6, m_k=20, m_w=50, mci=400, edge_thr=4000000, checks=True, ref_aligner=False, id_base=0):
     """The reference's -t 1 contig loop as plain nested loops over the product's host graph code, CPU oracle filter and DP.
     ref_aligner=True answers every alignment with the reference's own minimap2 (oracle/_ref/libmm2ref.so) instead."""
     L = lib()
@@ -94,7 +94,7 @@ def consensus(bases, off, salts, k=23, n=60, thr=6, m_k=20, m_w=50, mci=400, edg
     lens = (C.c_uint64 * 8)()
     st = HarnessConsStats()
     L.harness_consensus(_p(bases), _p(off), C.c_uint32(len(off) - 1), C.c_uint32(k), C.c_uint32(n), C.c_uint32(thr), _p(salts), m_k, m_w, mci,
-                        C.c_uint64(edge_thr), int(checks), ptrs, lens, C.byref(st))
+                        C.c_uint64(edge_thr), int(checks), ptrs, lens, C.byref(st), C.c_uint32(id_base))
     out = {}
     for i, name in enumerate(STREAMS):
         out[name] = C.string_at(ptrs[i], lens[i])

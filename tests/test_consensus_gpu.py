@@ -92,3 +92,21 @@ def test_edge_cases_and_files(tmp_path):
         got.update(decode(s))
     assert [got[i] for i in range(len(reads))] == [fold(r.encode()) for r in reads]
     g4.close()
+
+
+def test_shard_engine_with_global_id_base():
+    """The per-rank engine of nanospring_amd/dist.py: stream ids are global (id base of the shard)."""
+    from nanospring_amd import dist as nd
+    bases, off = ns.synth_reads(8, 60000, 240, 3000.0)
+    lo, hi = nd.shard_bounds(off, 2)[1]
+    sb, so = nd.take_shard(bases, off, lo, hi)
+    streams, md, st = nd.gpu_engine(n_builders=8)(sb, so, lo, 2)
+    assert st["bad"] == 0
+    got = {}
+    for s in streams:
+        got.update(decode(s))
+    assert sorted(got) == list(range(lo, hi))
+    b = bytes(bases)
+    for i in range(lo, hi):
+        assert got[i] == b[int(off[i]):int(off[i + 1])]
+    assert nd.parse_meta(md)["numReads"] == hi - lo
