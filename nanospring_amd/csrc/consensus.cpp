@@ -4,6 +4,7 @@
 #include <cassert>
 #include <cstring>
 #include <cstdlib>
+#include <cstdio>
 #include <iterator>
 #include <new>
 #include <set>
@@ -145,6 +146,10 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
                                long pos, bool rc)
 {
     const size_t n_path_edges = main_edges.size();
+    std::vector<uint64_t> dbg_before;
+    static const bool dbg = getenv("NSGPU_SPLICE_CHECK") != nullptr;      // debugging aid for the tail re-use shortcut
+    auto out_sig = [](const Node *n) { uint64_t h = n->out.size(); for (Edge *e : n->out) h = h * 1000003u + e->count; return h; };
+    if (dbg) for (size_t i = 0; i < n_path_edges; ++i) dbg_before.push_back(out_sig(main_edges[i]->sink));
     size_t ei = 0;                                   // edgeInPath
     Node *node_in_path = main_edges[0]->source;
     Node *cur = nullptr, *initial = nullptr;
@@ -208,6 +213,8 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
     if (end_offset > 0)
         for (size_t i = s.size() - (size_t)end_offset; i < s.size(); ++i) insert_node(s[i]);
     reads.insert(std::make_pair(id, GraphRead{pos, initial, s.length(), rc}));
+    touch_idx_ = ei, have_touch_ = true;         // main-path nodes beyond index ei were not modified
+    if (dbg) for (size_t i = ei; i < n_path_edges; ++i) if (dbg_before[i] != out_sig(main_edges[i]->sink)) { fprintf(stderr, "UPDATE touched node %zu beyond ei=%zu (begin %zd end %zd)\n", i + 1, ei, begin_offset, end_offset); break; }
 }
 
 void ContigGraph::clear_main_path()
@@ -227,10 +234,58 @@ void ContigGraph::clear_main_path()
 
 void ContigGraph::calculate_main_path_greedy()
 {
-    PROF_T(t0);
-    clear_main_path();
-    PROF_T(t1);
-    {
+    static const bool no_splice = getenv("NSGPU_NO_TAIL_SPLICE") != nullptr;     // debugging aid: always re-walk the tail
+    const size_t m = main_edges.size();
+    const bool try_splice = !no_splice && have_touch_ && left_off_ == 0 && m > 0 && touch_idx_ < m && right_off_ <= touch_idx_ &&
+                            consistent_from_ != (size_t)-1 && consistent_from_ <= touch_idx_ + 1;
+    have_touch_ = false;
+    if (try_splice) {
+        // ---- exact shortcut: keep the untouched part of the old tail aside, re-walk only up to where the walk re-joins it ----
+        const size_t R = right_off_, T = touch_idx_;          // node j (j >= 1) = main_edges[j-1]->sink
+        std::vector<Edge *> saved(main_edges.begin() + T, main_edges.end());     // saved[i]->sink = node T+1+i
+        const std::string saved_str = main_path.substr(T + 1);
+        for (size_t i = 0; i < saved.size(); ++i) saved[i]->sink->mark = (uint32_t)i;
+        for (size_t i = R; i < T; ++i) set_on_main(main_edges[i]->sink, false);          // nodes R+1 .. T
+        main_edges.erase(main_edges.begin() + R, main_edges.end());
+        main_path.erase(main_path.begin() + R + 1, main_path.end());
+        Node *cur = right_unchanged_;
+        Edge *e;
+        bool joined = false;
+        while ((e = cur->best_out())) {
+            Node *nx = e->sink;
+            main_edges.push_back(e);
+            main_path.push_back(nx->base);
+            if (nx->on_main) {                                  // a node of the kept tail (everything else was cleared)
+                const size_t j = nx->mark;
+                for (size_t i = 0; i < j; ++i) set_on_main(saved[i]->sink, false);       // by-passed tail nodes
+                main_edges.insert(main_edges.end(), saved.begin() + j + 1, saved.end());
+                main_path.append(saved_str, j + 1, std::string::npos);
+                ++dbg_spliced; dbg_spliced_nodes += saved.size() - j - 1;
+                static const bool dbg_chk = getenv("NSGPU_SPLICE_CHECK") != nullptr;
+                if (dbg_chk) {
+                    Node *c2 = nx;
+                    for (size_t i = j + 1; i < saved.size(); ++i) {
+                        Edge *b = c2->best_out();
+                        if (b != saved[i]) { fprintf(stderr, "SPLICE MISMATCH at tail pos %zu of %zu (j=%zu T=%zu R=%zu m=%zu): best count %u saved count %u nout %zu\n", i, saved.size(), j, T, R, m, b ? b->count : 0, saved[i]->count, c2->out.size()); break; }
+                        c2 = saved[i]->sink;
+                    }
+                    if (c2->best_out() && c2 == saved.back()->sink) fprintf(stderr, "SPLICE: tail end has a best_out now\n");
+                }
+                joined = true;
+                break;
+            }
+            cur = nx;
+            set_on_main(cur, true);
+        }
+        if (!joined) for (Edge *se : saved) set_on_main(se->sink, false);
+        const read_t ending = *main_edges.back()->reads.begin();
+        const GraphRead &er = reads.at(ending);
+        end_pos = er.pos + (long)er.len;
+        if (R < consistent_from_) consistent_from_ = R;
+    } else {
+        if (consistent_from_ != (size_t)-1) consistent_from_ = consistent_from_ > left_off_ ? consistent_from_ - left_off_ : 0;
+        clear_main_path();                            // right_off_ is now the index of right_unchanged_
+        if (right_off_ < consistent_from_) consistent_from_ = right_off_;
         Node *cur = right_unchanged_;
         Edge *e;
         while ((e = cur->best_out())) {
@@ -243,7 +298,6 @@ void ContigGraph::calculate_main_path_greedy()
         const GraphRead &er = reads.at(ending);
         end_pos = er.pos + (long)er.len;
     }
-    PROF_T(t2);
     {
         Node *cur = left_unchanged_;
         Edge *e;
@@ -255,6 +309,7 @@ void ContigGraph::calculate_main_path_greedy()
             prefix.push_back(cur->base);
             ++left_off_;
             ++right_off_;
+            if (consistent_from_ != (size_t)-1) ++consistent_from_;      // nodes chosen by best_in are not trusted
         }
         if (!prefix.empty()) {
             std::reverse(prefix.begin(), prefix.end());
@@ -263,10 +318,9 @@ void ContigGraph::calculate_main_path_greedy()
         const read_t starting = *main_edges.front()->reads.begin();
         start_pos = reads.at(starting).pos;
     }
-    PROF_T(t3);
+    const uint64_t splits_before = n_splits_;
     remove_cycles();
-    PROF_T(t4);
-    PROF_ADD(0, t1 - t0); PROF_ADD(1, t2 - t1); PROF_ADD(2, t3 - t2); PROF_ADD(3, t4 - t3);
+    if (n_splits_ != splits_before) consistent_from_ = (size_t)-1;   // a re-routing may change greedy choices anywhere on the path
     right_unchanged_ = main_edges.back()->sink;
     right_off_ = main_edges.size();
     left_unchanged_ = main_edges.front()->source;
@@ -333,6 +387,7 @@ void ContigGraph::walk_and_prune(Edge *e, std::vector<Edge *> &stack)
 // in-degree one.  Iterative form of the reference's two-visit context stack.
 void ContigGraph::split_path(Node *new_pre0, Edge *e0, const std::vector<read_t> &reads0)
 {
+    ++n_splits_;
     struct Ctx {
         Node *new_pre; Edge *e;
         const std::vector<read_t> *in_reads;       // borrowed from the parent context (or the caller)

@@ -25,6 +25,7 @@ struct Edge;
 struct Node {
     char base;
     bool on_main = false;
+    uint32_t mark = 0;                        // scratch: old main-path index while a tail is being re-used
     std::vector<Edge *> out, in;
     size_t cum_weight = 0;
     explicit Node(char b) : base(b) {}
@@ -101,10 +102,17 @@ private:
     // number of side nodes (not on the main path) with more than one edge in: remove_cycles has work to do
     // only while this is non-zero (walk_and_prune acts on nothing else)
     size_t n_multi_in_side_ = 0;
+    // tail re-use (exact shortcut of calculate_main_path_greedy): node indices > touch_idx_ were not modified by the
+    // last update_graph; if in addition the previous remove_cycles re-routed nothing, the old path beyond the point
+    // where the greedy walk re-joins it is what the walk would produce again
+    size_t touch_idx_ = 0;
+    bool have_touch_ = false;
+    size_t consistent_from_ = (size_t)-1;     // main-path nodes with index >= this were chosen by best_out on the current counts
+    uint64_t n_splits_ = 0;
     static bool multi_in_side(const Node *n) { return !n->on_main && n->in.size() > 1; }
     void set_on_main(Node *n, bool v) { n_multi_in_side_ -= multi_in_side(n); n->on_main = v; n_multi_in_side_ += multi_in_side(n); }
 public:
-    uint64_t dbg_cycles_calls = 0, dbg_cycles_skipped = 0;
+    uint64_t dbg_cycles_calls = 0, dbg_cycles_skipped = 0, dbg_spliced = 0, dbg_spliced_nodes = 0;
 private:
     Pool<Node> nodes_;
     Pool<Edge> edges_;

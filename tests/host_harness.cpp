@@ -135,8 +135,8 @@ static bool harness_align1(const std::string &ref, const std::string &q, int k, 
     return ao.ok != 0;
 }
 
-uint64_t g_dbg_calls = 0, g_dbg_skipped = 0;
-extern "C" uint64_t harness_dbg(int which) { return which ? g_dbg_skipped : g_dbg_calls; }
+uint64_t g_dbg_calls = 0, g_dbg_skipped = 0, g_dbg_spliced = 0, g_dbg_spliced_nodes = 0;
+extern "C" uint64_t harness_dbg(int which) { return which == 0 ? g_dbg_calls : which == 1 ? g_dbg_skipped : which == 2 ? g_dbg_spliced : g_dbg_spliced_nodes; }
 extern "C" {
 
 typedef struct { uint64_t n_contigs, n_lone, count_minhash, count_minhash_not_in_graph, count_aligner, n_align_calls, n_bad_roundtrip, n_graph_check_fail; double update_ms, mainpath_ms, write_ms; } harness_cons_stats;
@@ -252,7 +252,7 @@ int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32
             out.reads_in_contig.push_back((read_t)g.num_reads());
         }
         ++st->n_contigs;
-        g_dbg_calls += g.dbg_cycles_calls; g_dbg_skipped += g.dbg_cycles_skipped;
+        g_dbg_calls += g.dbg_cycles_calls; g_dbg_skipped += g.dbg_cycles_skipped; g_dbg_spliced += g.dbg_spliced; g_dbg_spliced_nodes += g.dbg_spliced_nodes;
     }
     // round trip through the decoder
     {

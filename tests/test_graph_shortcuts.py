@@ -1,0 +1,58 @@
+"""The two exact shortcuts in the consensus DAG maintenance (skip of no-op cycle pruning, re-use of the
+untouched main-path tail) must not change a single output byte: run the sequential contig loop with and
+without them (NSGPU_NO_CYCLE_SKIP / NSGPU_NO_TAIL_SPLICE make the code take the reference's literal route)
+on iid and on repeat-rich genomes and compare all streams."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import sys, hashlib
+sys.path.insert(0, %(root)r)
+import numpy as np
+import nanospring_amd as ns
+from tests import host_lib, oracle_lib
+from tests.align_cases import make_genome, mutate, revcomp
+kind, seed = sys.argv[1], int(sys.argv[2])
+rng = np.random.RandomState(seed)
+if kind == "iid":
+    bases, off = ns.synth_reads(seed, 60000, 260, 3500.0)
+else:
+    g = make_genome(rng, 30000)
+    g = g + g[5000:9000] + make_genome(rng, 15000)          # a 4 kb exact duplication and more repeats
+    reads = []
+    for _ in range(220):
+        ln = int(max(400, rng.gamma(2.0, 1500.0)))
+        st = rng.randint(0, max(1, len(g) - ln))
+        s = mutate(rng, g[st:st + ln], 0.04)
+        reads.append(revcomp(s) if rng.randint(2) else s)
+    bases = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    off = np.zeros(len(reads) + 1, dtype=np.uint64); off[1:] = np.cumsum([len(r) for r in reads])
+out, st = host_lib.consensus(bases, off, ns.mt19937_64_salts(60), checks=False, ref_aligner=oracle_lib.mm2ref() is not None)
+assert st["n_bad_roundtrip"] == 0
+h = hashlib.sha256()
+for k in sorted(out):
+    h.update(out[k])
+print("HASH", h.hexdigest(), st["count_aligner"], st["n_contigs"])
+'''
+
+
+def run(kind, seed, **env):
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT}, kind, str(seed)], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0].split()
+    return line[1], int(line[2]), int(line[3])
+
+
+@pytest.mark.parametrize("kind,seed", [("iid", 3), ("repeats", 4), ("repeats", 5)])
+def test_shortcuts_change_nothing(kind, seed):
+    fast = run(kind, seed)
+    literal = run(kind, seed, NSGPU_NO_CYCLE_SKIP="1", NSGPU_NO_TAIL_SPLICE="1")
+    assert fast == literal
+    assert fast[1] > 100
