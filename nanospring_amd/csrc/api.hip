@@ -128,9 +128,11 @@ void nsgpu_destroy(nsgpu_ctx *c)
     DevBuf *bufs[] = {&c->ascii, &c->aoff, &c->salts, &c->sketch, &c->sketch_rc, &c->qsketch, &c->idx_keys, &c->idx_ids, &c->idx_tmp_k,
                       &c->idx_tmp_v, &c->idx_tmp_e, &c->idx_tmp_e2, &c->idx_sort_ws, &c->f_pool, &c->f_qstart, &c->f_qcnt, &c->f_qm, &c->f_off,
                       &c->f_ids, &c->f_ctrl, &c->f_ovf_list, &c->f_ovf_cnt, &c->f_scan_ws, &c->rep_flags,
-                      &c->k_tasks, &c->k_order, &c->k_seqs, &c->k_p, &c->k_cig, &c->k_res, &c->k_slab};
+                      &c->k_tasks, &c->k_order, &c->k_seqs, &c->k_p, &c->k_cig, &c->k_res, &c->k_slab, &c->k_ncig, &c->k_coff, &c->k_cig2};
     for (DevBuf *b : bufs) b->release();
     c->t_stage.destroy(); c->t_kernel.destroy();
+    for (int i = 0; i < 3; ++i) { if (c->side_stream[i]) (void)hipStreamDestroy(c->side_stream[i]); if (c->side_done[i]) (void)hipEventDestroy(c->side_done[i]); }
+    if (c->side_fork) (void)hipEventDestroy(c->side_fork);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

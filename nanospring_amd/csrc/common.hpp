@@ -106,9 +106,11 @@ struct nsgpu_ctx {
     uint32_t f_nq = 0;
     nsgpu::DevBuf rep_flags;
     // ksw2 batches
-    nsgpu::DevBuf k_tasks, k_order, k_seqs, k_p, k_cig, k_res, k_slab;
+    nsgpu::DevBuf k_tasks, k_order, k_seqs, k_p, k_cig, k_res, k_slab, k_ncig, k_coff, k_cig2;
     double ksw_kernel_ms = 0, ksw_cells = 0, ksw_alg_bytes = 0;
     uint64_t ksw_launches = 0;
+    hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t side_done[3] = {nullptr, nullptr, nullptr}, side_fork = nullptr;
     // align batches
     uint64_t aln_pairs = 0, aln_dp_tasks = 0, aln_rounds = 0;
     double aln_index_ms = 0, aln_host_ms = 0, aln_dp_ms = 0;

@@ -23,6 +23,7 @@
 // once with coalesced 64-byte stores and read sparsely by the backtrack.
 #include "common.hpp"
 #include "ksw2.hpp"
+#include "host_util.hpp"
 
 namespace nsgpu {
 
@@ -63,8 +64,18 @@ __device__ __forceinline__ unsigned long long shfl_max_u64(unsigned long long k)
     return k;
 }
 
+// Ordering between the lanes of the ONE wave that owns a problem.  LDS operations of a wave execute in issue
+// order, so for LDS-resident state it is enough to drain the LDS queue (and stop the compiler from moving
+// memory operations across): no s_barrier and, above all, no wait for the traceback stores still in flight
+// to HBM (a __syncthreads() implies vmcnt(0), i.e. a full HBM store round trip on every anti-diagonal).
+template <bool LDS_STATE> __device__ __forceinline__ void wave_sync()
+{
+    if (LDS_STATE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else __syncthreads();
+}
+
 // BP: byte pointer, SP: uint2 (8-byte state) pointer, HP: int32 pointer -- LDS or HBM.
-template <class BP, class SP, class HP>
+template <bool LDS_STATE, class BP, class SP, class HP>
 __device__ void ksw_extd2_wave(const KswTask &tk, const KswParams &pr, const uint8_t *__restrict__ seqs, uint8_t *__restrict__ p_pool,
                                uint32_t *__restrict__ cig_pool, KswResult *__restrict__ res_out, SP S, BP bytes, HP H)
 {
@@ -102,13 +113,13 @@ __device__ void ksw_extd2_wave(const KswTask &tk, const KswParams &pr, const uin
         for (int i = lane; i < 2 * T16 + qr_bytes; i += 64) bytes[i] = 0;
         if (!approx_max) for (int t = lane; t < T16; t += 64) H[t] = KSW_NEG_INF;
     }
-    __syncthreads();
+    wave_sync<LDS_STATE>();
     {
         const uint8_t *query = seqs + tk.qoff, *target = seqs + tk.toff;
         for (int t = lane; t < qlen; t += 64) qr[t] = query[qlen - 1 - t];
         for (int t = lane; t < tlen; t += 64) sf[t] = target[t];
     }
-    __syncthreads();
+    wave_sync<LDS_STATE>();
 
     uint8_t *p = p_pool + tk.p_off;
     int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0;
@@ -147,7 +158,7 @@ __device__ void ksw_extd2_wave(const KswTask &tk, const KswParams &pr, const uin
                 s[t] = (uint8_t)z;
             }
         }
-        __syncthreads();
+        wave_sync<LDS_STATE>();
         // core loop over the 16-aligned range
         {
             int cx = x1, cx2 = x21, cv = v1;
@@ -200,7 +211,7 @@ __device__ void ksw_extd2_wave(const KswTask &tk, const KswParams &pr, const uin
                 }
             }
         }
-        __syncthreads();
+        wave_sync<LDS_STATE>();
         bool brk = false;
         if (!approx_max) {
             int max_H, max_t;
@@ -211,7 +222,7 @@ __device__ void ksw_extd2_wave(const KswTask &tk, const KswParams &pr, const uin
                     const uint2 se = S[en0];
                     h_en0 = en0 > 0 ? H[en0 - 1] + sx8(se.x) : H[en0] + sx8(se.x >> 8);
                 }
-                __syncthreads();
+                wave_sync<LDS_STATE>();
                 const int en1 = st0 + (en0 - st0) / 4 * 4;
                 unsigned long long best = ((unsigned long long)((long long)h_en0 + 0x80000000ll) << 32) | 0xFFFFFFFFull;  // rank -1: wins ties
                 for (int t = st0 + lane; t < en0; t += 64) {
@@ -226,13 +237,13 @@ __device__ void ksw_extd2_wave(const KswTask &tk, const KswParams &pr, const uin
                 max_H = (int)((long long)(best >> 32) - 0x80000000ll);
                 const uint32_t lo = (uint32_t)best;
                 max_t = lo == 0xFFFFFFFFu ? en0 : (int)((0xFFFFFFFEu - lo) & 0xFFFFFu);
-                __syncthreads();
+                wave_sync<LDS_STATE>();
             } else {
                 const int h = sx8(S[0].x >> 8) - qe;
-                __syncthreads();
+                wave_sync<LDS_STATE>();
                 if (lane == 0) H[0] = h;
                 max_H = h, max_t = 0;
-                __syncthreads();
+                wave_sync<LDS_STATE>();
             }
             const int h_en0 = H[en0], h_st0 = H[st0];
             if (en0 == tlen - 1 && h_en0 > ez_mte) ez_mte = h_en0, ez_mte_q = r - en;
@@ -271,7 +282,7 @@ __device__ void ksw_extd2_wave(const KswTask &tk, const KswParams &pr, const uin
         last_st = st, last_en = en;
     }
     __threadfence_block();
-    __syncthreads();
+    __syncthreads();        // every traceback byte must have landed before lane 0 walks it
 
     // backtrack (ksw2.h:119-151, is_rot = 1) by lane 0
     if (!(flag & KSW_EZ_SCORE_ONLY)) {
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(64) void ksw_extd2_lds_kernel(const KswTask *__rest
     int *H = reinterpret_cast<int *>(lds + (size_t)T16 * 8);
     const bool exact = !(tk.flag & KSW_EZ_APPROX_MAX);
     uint8_t *bytes = lds + (size_t)T16 * 8 + (exact ? (size_t)T16 * 4 : 0);
-    ksw_extd2_wave<uint8_t *, uint2 *, int *>(tk, pr, seqs, p_pool, cig_pool, res, S, bytes, H);
+    ksw_extd2_wave<true, uint8_t *, uint2 *, int *>(tk, pr, seqs, p_pool, cig_pool, res, S, bytes, H);
 }
 
 __global__ __launch_bounds__(64) void ksw_extd2_hbm_kernel(const KswTask *__restrict__ tasks, const uint32_t *__restrict__ order, uint32_t n,
@@ -347,8 +358,30 @@ __global__ __launch_bounds__(64) void ksw_extd2_hbm_kernel(const KswTask *__rest
         uint2 *S = reinterpret_cast<uint2 *>(base);
         int *H = reinterpret_cast<int *>(base + (size_t)T16 * 8);
         uint8_t *bytes = base + (size_t)T16 * 12;
-        ksw_extd2_wave<uint8_t *, uint2 *, int *>(tk, pr, seqs, p_pool, cig_pool, res, S, bytes, H);
+        ksw_extd2_wave<false, uint8_t *, uint2 *, int *>(tk, pr, seqs, p_pool, cig_pool, res, S, bytes, H);
         __syncthreads();
+    }
+}
+
+// CIGAR compaction: every problem owns a worst-case slice (qlen + tlen + 2 entries) of the CIGAR pool, of which it
+// uses a handful; only the used entries travel back over PCIe.
+__global__ __launch_bounds__(256) void ksw_ncigar_kernel(const KswResult *__restrict__ res, uint32_t n, uint32_t *__restrict__ ncig)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) ncig[i] = i < n ? (uint32_t)res[i].n_cigar : 0u;
+}
+
+__global__ __launch_bounds__(256) void ksw_cigar_gather_kernel(const KswTask *__restrict__ tasks, const KswResult *__restrict__ res, uint32_t n,
+                                                               const uint64_t *__restrict__ off, const uint32_t *__restrict__ pool,
+                                                               uint32_t *__restrict__ out)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = w; i < n; i += nw) {
+        const uint32_t c = (uint32_t)res[i].n_cigar;
+        const uint32_t *src = pool + tasks[i].cig_off;
+        uint32_t *dst = out + off[i];
+        for (uint32_t k = lane; k < c; k += 64) dst[k] = src[k];
     }
 }
 
@@ -424,32 +457,72 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
     }
     start[4] = flat.size();
     if (!flat.empty()) NS_HIP(hipMemcpyAsync(c->k_order.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, c->stream));
+    static const bool dbg = getenv("NSGPU_KSW_DEBUG") != nullptr;     // per-launch log (adds a sync per launch)
     NS_HIP(hipEventRecord(c->t_kernel.a, c->stream));
-    for (int k = 0; k < 3; ++k) {
+    // The few long problems (extensions up to 5000 x 5000) are latency-bound on one wave each and leave the chip
+    // idle: they run on side streams, concurrently with the bulk of small gap fills on the main stream.
+    if (!c->side_stream[0]) {
+        for (int i = 0; i < 3; ++i) { NS_HIP(hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking)); NS_HIP(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming)); }
+        NS_HIP(hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming));
+    }
+    NS_HIP(hipEventRecord(c->side_fork, c->stream));
+    bool side_used[3] = {false, false, false};
+    for (int k = 2; k >= 0; --k) {
         const uint32_t m = (uint32_t)order[k].size();
         if (!m) continue;
+        hipStream_t st = c->stream;
+        if (k > 0 && !dbg) { st = c->side_stream[k]; NS_HIP(hipStreamWaitEvent(st, c->side_fork, 0)); side_used[k] = true; }
+        double dbg_t0 = 0;
+        if (dbg) { NS_HIP(hipStreamSynchronize(c->stream)); dbg_t0 = now_ms(); }
         if (kClass[k] > 49152) NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClass[k]));
-        hipLaunchKernelGGL(ksw_extd2_lds_kernel, dim3(m), dim3(64), kClass[k], c->stream, c->k_tasks.as<KswTask>(),
+        hipLaunchKernelGGL(ksw_extd2_lds_kernel, dim3(m), dim3(64), kClass[k], st, c->k_tasks.as<KswTask>(),
                            c->k_order.as<uint32_t>() + start[k], m, pr, c->k_seqs.as<uint8_t>(), c->k_p.as<uint8_t>(), c->k_cig.as<uint32_t>(),
                            c->k_res.as<KswResult>());
         NS_HIP(hipGetLastError());
         ++c->ksw_launches;
+        if (dbg) {
+            NS_HIP(hipStreamSynchronize(c->stream));
+            double cells = 0, mx = 0;
+            for (uint32_t i : order[k]) { const double x = (double)tasks[i].qlen * tasks[i].tlen; cells += x; if (x > mx) mx = x; }
+            fprintf(stderr, "KSW class %d tasks %u cells %.3g max %.3g (q %d t %d) ms %.3f\n", k, m, cells, mx, tasks[order[k][0]].qlen, tasks[order[k][0]].tlen, now_ms() - dbg_t0);
+        }
     }
     if (!order[3].empty()) {
+        NS_HIP(hipStreamWaitEvent(c->side_stream[0], c->side_fork, 0));
+        side_used[0] = true;
         const uint32_t m = (uint32_t)order[3].size();
         const uint32_t wgs = m < 512u ? m : 512u;
         hbm_stride = (hbm_stride + 255) & ~(size_t)255;
         NS_TRY(c->k_slab.reserve((size_t)wgs * hbm_stride));
-        hipLaunchKernelGGL(ksw_extd2_hbm_kernel, dim3(wgs), dim3(64), 0, c->stream, c->k_tasks.as<KswTask>(), c->k_order.as<uint32_t>() + start[3], m, pr,
+        hipLaunchKernelGGL(ksw_extd2_hbm_kernel, dim3(wgs), dim3(64), 0, c->side_stream[0], c->k_tasks.as<KswTask>(), c->k_order.as<uint32_t>() + start[3], m, pr,
                            c->k_seqs.as<uint8_t>(), c->k_p.as<uint8_t>(), c->k_cig.as<uint32_t>(), c->k_res.as<KswResult>(), c->k_slab.as<uint8_t>(),
                            hbm_stride);
         NS_HIP(hipGetLastError());
         ++c->ksw_launches;
     }
+    for (int i = 0; i < 3; ++i)
+        if (side_used[i]) { NS_HIP(hipEventRecord(c->side_done[i], c->side_stream[i])); NS_HIP(hipStreamWaitEvent(c->stream, c->side_done[i], 0)); }
     NS_HIP(hipEventRecord(c->t_kernel.b, c->stream));
+    // compact the CIGARs on the device, then fetch results + used CIGAR entries only
+    NS_TRY(c->k_ncig.reserve((n + 2) * 4));
+    NS_TRY(c->k_coff.reserve((n + 2) * 8));
+    hipLaunchKernelGGL(ksw_ncigar_kernel, dim3((uint32_t)((n + 256) / 256)), dim3(256), 0, c->stream, c->k_res.as<KswResult>(), (uint32_t)n, c->k_ncig.as<uint32_t>());
+    NS_HIP(hipGetLastError());
+    NS_TRY(scan_u32_to_u64(c, c->k_ncig.as<uint32_t>(), c->k_coff.as<uint64_t>(), (uint32_t)n));
     NS_HIP(hipMemcpyAsync(results.data(), c->k_res.p, n * sizeof(KswResult), hipMemcpyDeviceToHost, c->stream));
-    cigars.resize(cig_total + 1);
-    if (cig_total) NS_HIP(hipMemcpyAsync(cigars.data(), c->k_cig.p, cig_total * 4, hipMemcpyDeviceToHost, c->stream));
+    NS_HIP(hipMemcpyAsync(cig_off.data(), c->k_coff.p, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    NS_HIP(hipStreamSynchronize(c->stream));
+    const uint64_t used = cig_off[n];
+    NS_TRY(c->k_cig2.reserve((used + 16) * 4));
+    if (used) {
+        uint32_t grid = (uint32_t)((n + 3) / 4);
+        if (grid > 16384u) grid = 16384u;
+        hipLaunchKernelGGL(ksw_cigar_gather_kernel, dim3(grid), dim3(256), 0, c->stream, c->k_tasks.as<KswTask>(), c->k_res.as<KswResult>(), (uint32_t)n,
+                           c->k_coff.as<uint64_t>(), c->k_cig.as<uint32_t>(), c->k_cig2.as<uint32_t>());
+        NS_HIP(hipGetLastError());
+    }
+    cigars.resize(used + 1);
+    if (used) NS_HIP(hipMemcpyAsync(cigars.data(), c->k_cig2.p, used * 4, hipMemcpyDeviceToHost, c->stream));
     NS_HIP(hipStreamSynchronize(c->stream));
     float ms = 0;
     NS_HIP(hipEventElapsedTime(&ms, c->t_kernel.a, c->t_kernel.b));
