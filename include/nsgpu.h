@@ -92,6 +92,13 @@ int nsgpu_get_read_packed(nsgpu_ctx *ctx, uint32_t r, uint8_t *out, uint32_t *le
  *      reference draws them from std::random_device, src/ReadFilter.cpp:49-63). */
 /* string2Sketch for every read (src/ReadFilter.cpp:117-136). sketches_out: N*n u64 row-major by read, or NULL. */
 int nsgpu_sketch(nsgpu_ctx *ctx, const uint64_t *salts, uint64_t *sketches_out);
+/* Multi-GPU: sketch only reads lo..hi (this rank's id range); rows of the sketch table can be read out / written
+ * in place (host or device buffers, e.g. the buffers of an RCCL all-gather); nsgpu_sketch_mark_complete declares the
+ * table complete once every row has been sketched or imported. */
+int nsgpu_sketch_range(nsgpu_ctx *ctx, const uint64_t *salts, uint32_t lo, uint32_t hi);
+int nsgpu_sketch_rows_get(nsgpu_ctx *ctx, uint32_t lo, uint32_t hi, void *dst, int dst_on_device);
+int nsgpu_sketch_rows_set(nsgpu_ctx *ctx, uint32_t lo, uint32_t hi, const void *src, int src_on_device);
+int nsgpu_sketch_mark_complete(nsgpu_ctx *ctx);
 /* populateHashTables (src/ReadFilter.cpp:159-172; BBHashMap::initialize, src/BBHashMap.cpp:10-99). */
 int nsgpu_build_index(nsgpu_ctx *ctx);
 /* Table j as (distinct keys ascending, CSR start, ascending read ids) -- checker for a7.
@@ -184,6 +191,21 @@ int nsgpu_consensus_run(nsgpu_ctx *ctx, uint32_t n_builders, uint32_t n_threads_
 /* stream `which` of output thread `thread`: 0 .genome 1 .lone 2 .id 3 .pos 4 .type 5 .base 6 .complement, 7 = metaData
  * (thread ignored).  *data_out is library-allocated (nsgpu_free). */
 int nsgpu_consensus_stream(nsgpu_ctx *ctx, uint32_t thread, uint32_t which, uint8_t **data_out, size_t *len_out);
+/* The same engine phase by phase, for multi-GPU jobs (one process per GPU, every rank holds all reads and the whole
+ * bucket index; rank r owns the builders with gid % world == r).  Per round:
+ *   advance(0) -> { seed_requests -> [all-gather] -> seed_resolve -> advance(1) } until nothing starts
+ *   -> batches -> claim_requests -> [all-gather] -> claim_resolve.
+ * The *_resolve calls take the request lists of ALL ranks (any order) and apply them to a replicated claim table in
+ * global builder order, so every rank stays in step and the result does not depend on the number of ranks.
+ * nsgpu_consensus_run is exactly this loop with world = 1.  Lists returned through T** are library-allocated. */
+int nsgpu_cons_begin(nsgpu_ctx *ctx, uint32_t n_builders_total, uint32_t rank, uint32_t world);
+int nsgpu_cons_advance(nsgpu_ctx *ctx, int only_fresh);
+int nsgpu_cons_seed_requests(nsgpu_ctx *ctx, uint32_t **gids_out, uint32_t **cursors_out, uint32_t *n_out);
+int nsgpu_cons_seed_resolve(nsgpu_ctx *ctx, const uint32_t *gids, const uint32_t *cursors, uint32_t n, uint32_t *n_started_out);
+int nsgpu_cons_batches(nsgpu_ctx *ctx);
+int nsgpu_cons_claim_requests(nsgpu_ctx *ctx, uint32_t **gids_out, uint32_t **reads_out, uint32_t *n_out);
+int nsgpu_cons_claim_resolve(nsgpu_ctx *ctx, const uint32_t *gids, const uint32_t *reads, uint32_t n, uint32_t *all_done_out);
+int nsgpu_cons_finish(nsgpu_ctx *ctx, uint32_t n_threads_out, nsgpu_consensus_stats *stats_out);
 /* writes temp_dir + temp_file_name + ".tid.<t>" + ext for every thread/extension and temp_dir + "metaData",
  * the names Consensus / ConsensusGraphWriter use (temp_dir must end in '/'). */
 int nsgpu_consensus_write(nsgpu_ctx *ctx, const char *temp_dir, const char *temp_file_name);

@@ -129,7 +129,8 @@ void parallel_for_pinned_impl(size_t n, const std::function<void(size_t)> &fn)
 {
     if (n == 0) return;
     if (host_threads() <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
-    the_pool().run(n, fn, true);
+    static const bool dyn = getenv("NSGPU_DYNAMIC_BUILDERS") != nullptr;
+    the_pool().run(n, fn, !dyn);
 }
 
 double now_ms()

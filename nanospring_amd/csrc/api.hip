@@ -133,6 +133,7 @@ void nsgpu_destroy(nsgpu_ctx *c)
     c->t_stage.destroy(); c->t_kernel.destroy();
     for (int i = 0; i < 3; ++i) { if (c->side_stream[i]) (void)hipStreamDestroy(c->side_stream[i]); if (c->side_done[i]) (void)hipEventDestroy(c->side_done[i]); }
     if (c->side_fork) (void)hipEventDestroy(c->side_fork);
+    if (c->cons_engine) c->cons_engine_free(c->cons_engine);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -242,6 +243,57 @@ int nsgpu_sketch(nsgpu_ctx *c, const uint64_t *salts, uint64_t *sketches_out)
     NS_HIP(hipStreamSynchronize(c->stream));
     NS_HIP(hipEventElapsedTime(&c->timing.sketch_kernel_ms, c->t_stage.a, c->t_stage.b));
     c->timing.sketch_ms = c->timing.sketch_kernel_ms;
+    c->have_sketch = true;
+    c->have_index = c->have_filter_all = false;
+    return NSGPU_OK;
+}
+
+int nsgpu_sketch_range(nsgpu_ctx *c, const uint64_t *salts, uint32_t lo, uint32_t hi)
+{
+    NS_CHECK(c && salts, NSGPU_ERR_ARG, "nsgpu_sketch_range: null argument");
+    NS_CHECK(lo <= hi && hi <= c->reads.n, NSGPU_ERR_ARG, "nsgpu_sketch_range: bad range");
+    NS_HIP(hipSetDevice(c->prm.device));
+    const uint32_t N = c->reads.n, n = c->prm.n;
+    NS_TRY(c->salts.reserve((size_t)n * 8));
+    NS_HIP(hipMemcpyAsync(c->salts.p, salts, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    c->have_salts = true;
+    NS_TRY(c->sketch.reserve(((size_t)N * n + 1) * 8));
+    NS_HIP(hipEventRecord(c->t_stage.a, c->stream));
+    NS_TRY(launch_sketch_range(c, c->reads, lo, hi, c->sketch.as<uint64_t>()));
+    NS_HIP(hipEventRecord(c->t_stage.b, c->stream));
+    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(hipEventElapsedTime(&c->timing.sketch_kernel_ms, c->t_stage.a, c->t_stage.b));
+    c->timing.sketch_ms = c->timing.sketch_kernel_ms;
+    c->have_index = c->have_filter_all = false;
+    return NSGPU_OK;
+}
+
+static int sketch_rows_copy(nsgpu_ctx *c, uint32_t lo, uint32_t hi, void *buf, int buf_on_device, bool to_buf)
+{
+    NS_CHECK(c && buf, NSGPU_ERR_ARG, "sketch rows: null argument");
+    NS_CHECK(lo <= hi && hi <= c->reads.n, NSGPU_ERR_ARG, "sketch rows: bad range");
+    NS_HIP(hipSetDevice(c->prm.device));
+    const size_t n = c->prm.n, bytes = (size_t)(hi - lo) * n * 8;
+    NS_TRY(c->sketch.reserve(((size_t)c->reads.n * n + 1) * 8));
+    uint8_t *rows = c->sketch.as<uint8_t>() + (size_t)lo * n * 8;
+    const hipMemcpyKind kind = buf_on_device ? hipMemcpyDeviceToDevice : (to_buf ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice);
+    if (bytes) NS_HIP(hipMemcpyAsync(to_buf ? buf : (void *)rows, to_buf ? (const void *)rows : buf, bytes, kind, c->stream));
+    NS_HIP(hipStreamSynchronize(c->stream));
+    return NSGPU_OK;
+}
+
+int nsgpu_sketch_rows_get(nsgpu_ctx *c, uint32_t lo, uint32_t hi, void *dst, int dst_on_device) { return sketch_rows_copy(c, lo, hi, dst, dst_on_device, true); }
+
+int nsgpu_sketch_rows_set(nsgpu_ctx *c, uint32_t lo, uint32_t hi, const void *src, int src_on_device)
+{
+    NS_TRY(sketch_rows_copy(c, lo, hi, const_cast<void *>(src), src_on_device, false));
+    if (lo == 0 && hi == c->reads.n) c->have_sketch = true;
+    return NSGPU_OK;
+}
+
+int nsgpu_sketch_mark_complete(nsgpu_ctx *c)
+{
+    NS_CHECK(c && c->have_salts, NSGPU_ERR_ARG, "nsgpu_sketch_mark_complete: no salts / sketch rows yet");
     c->have_sketch = true;
     c->have_index = c->have_filter_all = false;
     return NSGPU_OK;

@@ -120,6 +120,9 @@ struct nsgpu_ctx {
     // consensus run
     bool have_cons = false;
     uint32_t read_id_base = 0;   // global id of local read 0 (multi-GPU shards)
+    void *cons_engine = nullptr;                 // resumable contig engine (consensus_driver.hip)
+    void (*cons_engine_free)(void *) = nullptr;
+    uint64_t cons_n_reads_out = 0;               // reads covered by this context's output streams
     nsgpu_consensus_stats cons_stats;
     std::vector<nsgpu::cons::StreamSet> cons_out;
     nsgpu::Timer t_stage, t_kernel;
@@ -131,6 +134,7 @@ namespace nsgpu {
 // kernels_minhash.hip
 int launch_pack_ascii(nsgpu_ctx *c, const char *d_ascii, const uint64_t *d_aoff, SeqStore &st);
 int launch_sketch(nsgpu_ctx *c, const SeqStore &st, uint64_t *d_out_fwd, uint64_t *d_out_rc);
+int launch_sketch_range(nsgpu_ctx *c, const SeqStore &st, uint32_t lo, uint32_t hi, uint64_t *d_out_fwd);   // rows lo..hi only
 int launch_repetitive(nsgpu_ctx *c, const SeqStore &st, uint8_t *d_flags);
 int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, uint32_t nq, bool interleave);
 // index.hip

@@ -24,9 +24,9 @@ namespace nsgpu {
 using cons::read_t;
 
 struct Builder {
-    enum State { NEED_CONTIG, ADVANCE, WAIT_FILTER, WAIT_ALIGN, GOT_FILTER, GOT_ALIGN, DONE };
+    enum State { NEED_CONTIG, ADVANCE, WAIT_FILTER, WAIT_ALIGN, GOT_FILTER, ALIGNED, GOT_ALIGN, DONE };
     State st = NEED_CONTIG;
-    uint32_t id = 0;
+    uint32_t id = 0, gid = 0;                 // local index / global builder id
     std::unique_ptr<cons::ContigGraph> g;
     read_t cursor = 0;
     // contig walk (src/Consensus.cpp:51-95)
@@ -62,13 +62,9 @@ struct Driver {
     const char *read_ptr(read_t r) const { return c->h_bases.data() + c->h_off[r]; }
     size_t read_len(read_t r) const { return (size_t)(c->h_off[r + 1] - c->h_off[r]); }
 
-    // Consensus::getRead + createGraph (src/Consensus.cpp:388-403, 444-468); sequential
-    void claim_seed(Builder &b)
+    // createGraph (src/Consensus.cpp:388-403) for the seed read r the builder was granted
+    void start_contig(Builder &b, read_t r)
     {
-        read_t r = b.cursor;
-        while (r < N && in_graph[r]) ++r;
-        if (r >= N) { b.st = Builder::DONE; return; }
-        in_graph[r] = 1;
         b.g.reset(new cons::ContigGraph());
         b.g->main_path.assign(read_ptr(r), read_len(r));
         b.g->start_pos = 0;
@@ -204,11 +200,39 @@ struct Driver {
     }
 };
 
-static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_out)
-{
-    NS_CHECK(c->have_index && c->have_salts, NSGPU_ERR_ARG, "nsgpu_consensus_run: call nsgpu_sketch and nsgpu_build_index first");
-    NS_CHECK(n_builders >= 1 && n_threads_out >= 1, NSGPU_ERR_ARG, "n_builders and n_threads_out must be >= 1");
+// ---------------------------------------------------------------------------
+// The engine as resumable phases.  A single process (nsgpu_consensus_run) and a multi-GPU job
+// (one process per GPU, nanospring_amd/dist.py) run the SAME phases; in the multi-GPU job every rank
+// holds all reads and the whole bucket index (replicated by all-gather), owns the builders with
+// gid % world == rank, and the two kinds of claims are resolved on a replicated in_graph[] from
+// all-gathered request lists, strictly in global builder order -- so the result does not depend on
+// the number of ranks.
+// ---------------------------------------------------------------------------
+struct Engine {
     Driver D;
+    uint32_t rank = 0, world = 1, n_total = 0;     // global builder count
+    uint64_t n_done_global = 0;
+    double t0 = 0;
+    std::vector<uint32_t> who;
+    std::string qbuf;
+    std::vector<uint64_t> qoff, foff;
+    std::vector<uint32_t> fids;
+    std::vector<AlignReq> reqs;
+    std::vector<mm2::AlnOut> outs;
+    Builder *local(uint32_t gid) { return gid % world == rank ? &D.B[gid / world] : nullptr; }
+};
+
+static void engine_free(void *p) { delete static_cast<Engine *>(p); }
+
+static int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, uint32_t world)
+{
+    NS_CHECK(c->have_index && c->have_salts, NSGPU_ERR_ARG, "consensus: call nsgpu_sketch and nsgpu_build_index first");
+    NS_CHECK(n_builders_total >= 1 && world >= 1 && rank < world, NSGPU_ERR_ARG, "consensus: bad builder / rank arguments");
+    NS_CHECK(c->h_off.size() == (size_t)c->reads.n + 1, NSGPU_ERR_ARG, "consensus: reads must be loaded first");
+    if (c->cons_engine) { c->cons_engine_free(c->cons_engine); c->cons_engine = nullptr; }
+    Engine *E = new Engine();
+    c->cons_engine = E, c->cons_engine_free = engine_free;
+    Driver &D = E->D;
     D.c = c;
     D.N = c->reads.n;
     D.edge_thr = c->prm.edge_threshold;
@@ -218,117 +242,278 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
     if (D.offset == 0) D.offset = 1;                                  // the reference would never terminate with a zero stride
     D.in_graph.assign(D.N, 0);
     D.rep.assign((size_t)D.N + 1, 0);
-    const double t0 = now_ms();
+    E->t0 = now_ms();
     if (D.N) NS_TRY(nsgpu_check_repetitive(c, D.rep.data()));
-    if (n_builders > D.N && D.N > 0) n_builders = D.N;
-    if (D.N == 0) n_builders = 1;
-    D.B.resize(n_builders);
-    for (uint32_t i = 0; i < n_builders; ++i) D.B[i].id = i;
-    nsgpu_consensus_stats &S = c->cons_stats;
-    memset(&S, 0, sizeof(S));
-    S.n_builders = n_builders;
-    std::vector<uint32_t> who;
-    std::string qbuf;
-    std::vector<uint64_t> qoff;
-    std::vector<uint64_t> foff;
-    std::vector<uint32_t> fids;
-    std::vector<AlignReq> reqs;
-    std::vector<mm2::AlnOut> outs;
-    for (;;) {
-        // 1. parallel: consume deliveries, run to the next request
-        double a0 = now_ms();
-        par_for_pinned(D.B.size(), [&](size_t i) { D.advance(D.B[i]); });
-        // 2. sequential seed claims, then 3. parallel: open their first window
-        bool any_new = false;
-        for (Builder &b : D.B) if (b.st == Builder::NEED_CONTIG) { D.claim_seed(b); any_new |= b.st == Builder::ADVANCE; }
-        if (any_new) par_for_pinned(D.B.size(), [&](size_t i) { if (D.B[i].st == Builder::ADVANCE) D.advance(D.B[i]); });
-        // builders whose fresh contig finished at once (lone, repetitive or short seeds) claim again
-        for (int guard = 0; guard < 1 << 30; ++guard) {
-            bool again = false;
-            for (Builder &b : D.B) if (b.st == Builder::NEED_CONTIG) { D.claim_seed(b); again |= b.st == Builder::ADVANCE; }
-            if (!again) break;
-            par_for_pinned(D.B.size(), [&](size_t i) { if (D.B[i].st == Builder::ADVANCE) D.advance(D.B[i]); });
-        }
-        S.graph_ms += now_ms() - a0;
-        // 4. window queries of this round
-        who.clear();
-        for (Builder &b : D.B) if (b.st == Builder::WAIT_FILTER) who.push_back(b.id);
-        if (!who.empty()) {
-            double f0 = now_ms();
-            qbuf.clear(); qoff.assign(1, 0);
-            for (uint32_t bi : who) for (int s = 0; s < 2; ++s) { qbuf += D.B[bi].win[s]; qoff.push_back(qbuf.size()); }
-            const uint32_t nq = (uint32_t)(2 * who.size());
-            NS_TRY(filter_strings_device(c, qbuf.data(), qoff.data(), nq));
-            foff.resize((size_t)nq + 1);
-            fids.resize(c->f_total + 1);
-            NS_HIP(hipMemcpyAsync(foff.data(), c->f_off.p, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-            if (c->f_total) NS_HIP(hipMemcpyAsync(fids.data(), c->f_ids.p, c->f_total * 4, hipMemcpyDeviceToHost, c->stream));
-            NS_HIP(hipStreamSynchronize(c->stream));
-            for (size_t w = 0; w < who.size(); ++w) {
-                Builder &b = D.B[who[w]];
-                for (int s = 0; s < 2; ++s) b.cand[s].assign(fids.begin() + foff[2 * w + s], fids.begin() + foff[2 * w + s + 1]);
-                b.st = Builder::GOT_FILTER;
-            }
-            S.filter_ms += now_ms() - f0;
-            S.n_windows += who.size();
-            ++S.n_filter_rounds;
-        }
-        // 5. alignments of this round
-        who.clear();
-        for (Builder &b : D.B) if (b.st == Builder::WAIT_ALIGN) who.push_back(b.id);
-        if (!who.empty()) {
-            double g0 = now_ms();
-            par_for(who.size(), [&](size_t w) {
-                Builder &b = D.B[who[w]];
-                if (!b.idx_valid) {
-                    b.idx.build(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f);
-                    b.idx_valid = true;
-                }
-            });
-            const double g1 = now_ms();
-            S.index_ms += g1 - g0;
-            reqs.resize(who.size());
-            for (size_t w = 0; w < who.size(); ++w) {
-                Builder &b = D.B[who[w]];
-                reqs[w] = AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size()};
-            }
-            NS_TRY(align_requests(c, reqs, outs));
-            // 6. claims, strictly in builder order (src/Consensus.cpp:256-277 without lock contention)
-            for (size_t w = 0; w < who.size(); ++w) {
-                Builder &b = D.B[who[w]];
-                b.aln = std::move(outs[w]);
-                ++b.n_align_calls;
-                b.accepted = false;
-                if (b.aln.ok && !D.in_graph[b.pend]) { D.in_graph[b.pend] = 1; b.accepted = true; ++b.n_aligner; }
-                b.st = Builder::GOT_ALIGN;
-            }
-            S.align_ms += now_ms() - g1;
-            ++S.n_align_rounds;
-        }
-        bool active = false;
-        for (Builder &b : D.B) active |= b.st != Builder::DONE;
-        if (!active) break;
-        ++S.n_rounds;
+    if (n_builders_total > D.N && D.N > 0) n_builders_total = D.N;
+    if (D.N == 0) n_builders_total = 1;
+    E->rank = rank, E->world = world, E->n_total = n_builders_total;
+    const uint32_t n_local = n_builders_total > rank ? (n_builders_total - rank + world - 1) / world : 0;
+    D.B.resize(n_local);
+    for (uint32_t i = 0; i < n_local; ++i) D.B[i].id = i, D.B[i].gid = rank + i * world;
+    memset(&c->cons_stats, 0, sizeof(c->cons_stats));
+    c->cons_stats.n_builders = n_builders_total;
+    c->have_cons = false;
+    return NSGPU_OK;
+}
+
+// phase 1/3: consume deliveries and run every local builder to its next request
+static void engine_advance(nsgpu_ctx *c, bool only_fresh)
+{
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    Driver &D = E->D;
+    const double a0 = now_ms();
+    if (only_fresh) par_for_pinned(D.B.size(), [&](size_t i) { if (D.B[i].st == Builder::ADVANCE) D.advance(D.B[i]); });
+    else par_for_pinned(D.B.size(), [&](size_t i) { D.advance(D.B[i]); });
+    c->cons_stats.graph_ms += now_ms() - a0;
+}
+
+// phase 2: (gid, cursor) of every local builder that needs a new contig
+static void engine_seed_requests(nsgpu_ctx *c, std::vector<uint32_t> &gids, std::vector<uint32_t> &cursors)
+{
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    gids.clear(); cursors.clear();
+    for (Builder &b : E->D.B) if (b.st == Builder::NEED_CONTIG) { gids.push_back(b.gid); cursors.push_back(b.cursor); }
+}
+
+// resolve the seed requests of ALL ranks on the replicated in_graph[], in global builder order
+// (Consensus::getRead + createGraph, src/Consensus.cpp:388-403, 444-468); returns how many builders started a contig
+static uint32_t engine_seed_resolve(nsgpu_ctx *c, const uint32_t *gids, const uint32_t *cursors, uint32_t n)
+{
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    Driver &D = E->D;
+    std::vector<uint32_t> ord(n);
+    for (uint32_t i = 0; i < n; ++i) ord[i] = i;
+    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return gids[a] < gids[b]; });
+    uint32_t started = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t gid = gids[ord[k]];
+        read_t r = cursors[ord[k]];
+        while (r < D.N && D.in_graph[r]) ++r;
+        Builder *b = E->local(gid);
+        if (r >= D.N) { ++E->n_done_global; if (b) b->st = Builder::DONE; continue; }
+        D.in_graph[r] = 1;
+        ++started;
+        if (b) D.start_contig(*b, r);
     }
+    return started;
+}
+
+// phases 4+5: window queries and alignments of the local builders (GPU batches); no claims yet
+static int engine_batches(nsgpu_ctx *c)
+{
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    Driver &D = E->D;
+    nsgpu_consensus_stats &S = c->cons_stats;
+    std::vector<uint32_t> &who = E->who;
+    who.clear();
+    for (Builder &b : D.B) if (b.st == Builder::WAIT_FILTER) who.push_back(b.id);
+    if (!who.empty()) {
+        const double f0 = now_ms();
+        E->qbuf.clear(); E->qoff.assign(1, 0);
+        for (uint32_t bi : who) for (int s = 0; s < 2; ++s) { E->qbuf += D.B[bi].win[s]; E->qoff.push_back(E->qbuf.size()); }
+        const uint32_t nq = (uint32_t)(2 * who.size());
+        NS_TRY(filter_strings_device(c, E->qbuf.data(), E->qoff.data(), nq));
+        E->foff.resize((size_t)nq + 1);
+        E->fids.resize(c->f_total + 1);
+        NS_HIP(hipMemcpyAsync(E->foff.data(), c->f_off.p, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        if (c->f_total) NS_HIP(hipMemcpyAsync(E->fids.data(), c->f_ids.p, c->f_total * 4, hipMemcpyDeviceToHost, c->stream));
+        NS_HIP(hipStreamSynchronize(c->stream));
+        for (size_t w = 0; w < who.size(); ++w) {
+            Builder &b = D.B[who[w]];
+            for (int s = 0; s < 2; ++s) b.cand[s].assign(E->fids.begin() + E->foff[2 * w + s], E->fids.begin() + E->foff[2 * w + s + 1]);
+            b.st = Builder::GOT_FILTER;
+        }
+        S.filter_ms += now_ms() - f0;
+        S.n_windows += who.size();
+        ++S.n_filter_rounds;
+    }
+    who.clear();
+    for (Builder &b : D.B) if (b.st == Builder::WAIT_ALIGN) who.push_back(b.id);
+    if (!who.empty()) {
+        const double g0 = now_ms();
+        par_for(who.size(), [&](size_t w) {
+            Builder &b = D.B[who[w]];
+            if (!b.idx_valid) {
+                b.idx.build(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f);
+                b.idx_valid = true;
+            }
+        });
+        const double g1 = now_ms();
+        S.index_ms += g1 - g0;
+        E->reqs.resize(who.size());
+        for (size_t w = 0; w < who.size(); ++w) {
+            Builder &b = D.B[who[w]];
+            E->reqs[w] = AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size()};
+        }
+        NS_TRY(align_requests(c, E->reqs, E->outs));
+        for (size_t w = 0; w < who.size(); ++w) {
+            Builder &b = D.B[who[w]];
+            b.aln = std::move(E->outs[w]);
+            ++b.n_align_calls;
+            b.accepted = false;
+            b.st = Builder::ALIGNED;
+        }
+        S.align_ms += now_ms() - g1;
+        ++S.n_align_rounds;
+    }
+    return NSGPU_OK;
+}
+
+// phase 6a: (gid, read) of every local builder whose alignment succeeded
+static void engine_claim_requests(nsgpu_ctx *c, std::vector<uint32_t> &gids, std::vector<uint32_t> &reads)
+{
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    gids.clear(); reads.clear();
+    for (Builder &b : E->D.B) if (b.st == Builder::ALIGNED && b.aln.ok) { gids.push_back(b.gid); reads.push_back(b.pend); }
+}
+
+// phase 6b: claims of ALL ranks, strictly in global builder order (src/Consensus.cpp:256-277 without lock contention)
+static void engine_claim_resolve(nsgpu_ctx *c, const uint32_t *gids, const uint32_t *reads, uint32_t n)
+{
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    Driver &D = E->D;
+    std::vector<uint32_t> ord(n);
+    for (uint32_t i = 0; i < n; ++i) ord[i] = i;
+    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return gids[a] < gids[b]; });
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t gid = gids[ord[k]], r = reads[ord[k]];
+        if (r >= D.N || D.in_graph[r]) continue;
+        D.in_graph[r] = 1;
+        if (Builder *b = E->local(gid)) { b->accepted = true; ++b->n_aligner; }
+    }
+    for (Builder &b : D.B) if (b.st == Builder::ALIGNED) b.st = Builder::GOT_ALIGN;
+    ++c->cons_stats.n_rounds;
+}
+
+static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
+{
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    NS_CHECK(E && n_threads_out >= 1, NSGPU_ERR_ARG, "consensus: nothing to finish");
+    Driver &D = E->D;
+    nsgpu_consensus_stats &S = c->cons_stats;
     // merge builders into the requested number of output "threads" (Compressor expects exactly numThr
     // file sets, src/Compressor.cpp:123-124; Decompressor reads numThr from metaData)
     c->cons_out.assign(n_threads_out, cons::StreamSet());
-    for (size_t i = 0; i < D.B.size(); ++i) c->cons_out[i * n_threads_out / D.B.size()].append(D.B[i].out);
+    for (size_t i = 0; i < D.B.size(); ++i) c->cons_out[i * n_threads_out / (D.B.empty() ? 1 : D.B.size())].append(D.B[i].out);
     for (Builder &b : D.B) {
         S.n_contigs += b.n_contigs; S.n_lone += b.n_lone; S.count_minhash += b.n_minhash; S.count_minhash_not_in_graph += b.n_minhash_new;
         S.count_aligner += b.n_aligner; S.n_align_calls += b.n_align_calls;
         S.graph_cpu_ms += b.cpu_ms; if (b.max_ms > S.graph_max_ms) S.graph_max_ms = b.max_ms;
     }
-    S.total_ms = now_ms() - t0;
+    S.total_ms = now_ms() - E->t0;
+    c->cons_n_reads_out = 0;
+    for (auto &t : c->cons_out) for (read_t x : t.reads_in_contig) c->cons_n_reads_out += x;
     c->have_cons = true;
+    c->cons_engine_free(c->cons_engine);
+    c->cons_engine = nullptr;
     return NSGPU_OK;
+}
+
+static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_out)
+{
+    NS_CHECK(n_threads_out >= 1, NSGPU_ERR_ARG, "n_threads_out must be >= 1");
+    NS_TRY(engine_begin(c, n_builders, 0, 1));
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    std::vector<uint32_t> ga, gb;
+    for (;;) {
+        engine_advance(c, false);
+        for (;;) {
+            engine_seed_requests(c, ga, gb);
+            if (ga.empty()) break;
+            if (engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) == 0) break;
+            engine_advance(c, true);
+        }
+        NS_TRY(engine_batches(c));
+        engine_claim_requests(c, ga, gb);
+        engine_claim_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size());
+        if (E->n_done_global >= E->n_total) break;
+    }
+    return engine_finish(c, n_threads_out);
 }
 
 }  // namespace nsgpu
 
 using namespace nsgpu;
 
+static int give_u32(const std::vector<uint32_t> &v, uint32_t **out)
+{
+    uint32_t *p = (uint32_t *)malloc((v.size() + 1) * 4);
+    NS_CHECK(p, NSGPU_ERR_NOMEM, "malloc failed");
+    if (!v.empty()) memcpy(p, v.data(), v.size() * 4);
+    *out = p;
+    return NSGPU_OK;
+}
+
 extern "C" {
+
+// ---- the contig engine phase by phase (multi-GPU jobs drive these and put a collective between the
+//      *_requests and *_resolve calls; see nanospring_amd/dist.py) ----
+int nsgpu_cons_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, uint32_t world)
+{
+    NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
+    NS_HIP(hipSetDevice(c->prm.device));
+    return engine_begin(c, n_builders_total, rank, world);
+}
+
+int nsgpu_cons_advance(nsgpu_ctx *c, int only_fresh)
+{
+    NS_CHECK(c && c->cons_engine, NSGPU_ERR_ARG, "nsgpu_cons_advance: call nsgpu_cons_begin first");
+    engine_advance(c, only_fresh != 0);
+    return NSGPU_OK;
+}
+
+int nsgpu_cons_seed_requests(nsgpu_ctx *c, uint32_t **gids_out, uint32_t **cursors_out, uint32_t *n_out)
+{
+    NS_CHECK(c && c->cons_engine && gids_out && cursors_out && n_out, NSGPU_ERR_ARG, "nsgpu_cons_seed_requests: bad argument");
+    std::vector<uint32_t> a, b;
+    engine_seed_requests(c, a, b);
+    NS_TRY(give_u32(a, gids_out));
+    NS_TRY(give_u32(b, cursors_out));
+    *n_out = (uint32_t)a.size();
+    return NSGPU_OK;
+}
+
+int nsgpu_cons_seed_resolve(nsgpu_ctx *c, const uint32_t *gids, const uint32_t *cursors, uint32_t n, uint32_t *n_started_out)
+{
+    NS_CHECK(c && c->cons_engine && (n == 0 || (gids && cursors)) && n_started_out, NSGPU_ERR_ARG, "nsgpu_cons_seed_resolve: bad argument");
+    *n_started_out = engine_seed_resolve(c, gids, cursors, n);
+    return NSGPU_OK;
+}
+
+int nsgpu_cons_batches(nsgpu_ctx *c)
+{
+    NS_CHECK(c && c->cons_engine, NSGPU_ERR_ARG, "nsgpu_cons_batches: call nsgpu_cons_begin first");
+    NS_HIP(hipSetDevice(c->prm.device));
+    return engine_batches(c);
+}
+
+int nsgpu_cons_claim_requests(nsgpu_ctx *c, uint32_t **gids_out, uint32_t **reads_out, uint32_t *n_out)
+{
+    NS_CHECK(c && c->cons_engine && gids_out && reads_out && n_out, NSGPU_ERR_ARG, "nsgpu_cons_claim_requests: bad argument");
+    std::vector<uint32_t> a, b;
+    engine_claim_requests(c, a, b);
+    NS_TRY(give_u32(a, gids_out));
+    NS_TRY(give_u32(b, reads_out));
+    *n_out = (uint32_t)a.size();
+    return NSGPU_OK;
+}
+
+int nsgpu_cons_claim_resolve(nsgpu_ctx *c, const uint32_t *gids, const uint32_t *reads, uint32_t n, uint32_t *all_done_out)
+{
+    NS_CHECK(c && c->cons_engine && (n == 0 || (gids && reads)) && all_done_out, NSGPU_ERR_ARG, "nsgpu_cons_claim_resolve: bad argument");
+    engine_claim_resolve(c, gids, reads, n);
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    *all_done_out = E->n_done_global >= E->n_total;
+    return NSGPU_OK;
+}
+
+int nsgpu_cons_finish(nsgpu_ctx *c, uint32_t n_threads_out, nsgpu_consensus_stats *stats_out)
+{
+    NS_CHECK(c && c->cons_engine, NSGPU_ERR_ARG, "nsgpu_cons_finish: call nsgpu_cons_begin first");
+    NS_TRY(engine_finish(c, n_threads_out));
+    if (stats_out) *stats_out = c->cons_stats;
+    return NSGPU_OK;
+}
 
 int nsgpu_set_read_id_base(nsgpu_ctx *c, uint32_t base)
 {
@@ -362,7 +547,7 @@ int nsgpu_consensus_stream(nsgpu_ctx *c, uint32_t thread, uint32_t which, uint8_
     NS_CHECK(c && data_out && len_out, NSGPU_ERR_ARG, "null argument");
     NS_CHECK(c->have_cons, NSGPU_ERR_ARG, "nsgpu_consensus_stream: run nsgpu_consensus_run first");
     NS_CHECK(which <= 7 && (which == 7 || thread < c->cons_out.size()), NSGPU_ERR_ARG, "no such stream");
-    const std::string s = which == 7 ? cons::meta_data(c->reads.n, c->cons_out) : stream_of(c->cons_out[thread], (int)which);
+    const std::string s = which == 7 ? cons::meta_data(c->cons_n_reads_out, c->cons_out) : stream_of(c->cons_out[thread], (int)which);
     uint8_t *p = (uint8_t *)malloc(s.size() + 1);
     NS_CHECK(p, NSGPU_ERR_NOMEM, "malloc failed");
     memcpy(p, s.data(), s.size());
@@ -386,7 +571,7 @@ int nsgpu_consensus_write(nsgpu_ctx *c, const char *temp_dir, const char *temp_f
     for (size_t t = 0; t < c->cons_out.size(); ++t)
         for (int k = 0; k < 7; ++k)       // same names as Consensus.cpp:36 + ConsensusGraphWriter
             NS_TRY(put(std::string(temp_dir) + temp_file_name + ".tid." + std::to_string(t) + kExt[k], stream_of(c->cons_out[t], k)));
-    return put(std::string(temp_dir) + "metaData", cons::meta_data(c->reads.n, c->cons_out));
+    return put(std::string(temp_dir) + "metaData", cons::meta_data(c->cons_n_reads_out, c->cons_out));
 }
 
 int nsgpu_consensus_verify(nsgpu_ctx *c, uint64_t *n_bad_out)
@@ -408,7 +593,8 @@ int nsgpu_consensus_verify(nsgpu_ctx *c, uint64_t *n_bad_out)
             if (pr.second.size() != L || memcmp(pr.second.data(), c->h_bases.data() + c->h_off[r], L) != 0) ++bad;
         }
     }
-    for (uint32_t r = 0; r < N; ++r) bad += !seen[r];
+    if (c->cons_n_reads_out == N)                       // a multi-GPU rank only holds its builders' share of the reads
+        for (uint32_t r = 0; r < N; ++r) bad += !seen[r];
     *n_bad_out = bad;
     return NSGPU_OK;
 }

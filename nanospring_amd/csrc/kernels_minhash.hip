@@ -198,6 +198,19 @@ int launch_sketch(nsgpu_ctx *c, const SeqStore &st, uint64_t *d_out_fwd, uint64_
     return NSGPU_OK;
 }
 
+// forward sketches of reads lo..hi only (multi-GPU: every rank sketches its own id range, the rows of the
+// other ranks arrive by all-gather)
+int launch_sketch_range(nsgpu_ctx *c, const SeqStore &st, uint32_t lo, uint32_t hi, uint64_t *d_out_fwd)
+{
+    if (hi <= lo) return NSGPU_OK;
+    const uint32_t cnt = hi - lo, n = c->prm.n;
+    const uint32_t grid = cnt < 262144u ? cnt : 262144u;
+    hipLaunchKernelGGL(sketch_kernel<1>, dim3(grid), dim3(256), 0, c->stream, st.packed.as<uint8_t>(), st.poff.as<uint64_t>() + lo, st.len.as<uint32_t>() + lo, cnt,
+                       c->prm.k, n, c->salts.as<uint64_t>(), d_out_fwd + (size_t)lo * n, (uint64_t *)nullptr);
+    NS_HIP(hipGetLastError());
+    return NSGPU_OK;
+}
+
 // ----------------------------------------------------------------------------
 // a10: checkRepetitive.  One workgroup per read; for shift 1..6 count the
 // positions j with read[j] == read[(j+shift) % L]; flag if any count exceeds

@@ -84,3 +84,153 @@ def gpu_engine(device=0, n_builders=1024, k=23, n=60, thr=6, salts=None, **kw):
         g.close()
         return streams, md, st
     return engine
+
+
+# ---------------------------------------------------------------------------
+# Exchange mode: every rank ends up with ALL reads and the WHOLE bucket index, so contigs
+# recruit reads across shards; claims are resolved on a replicated table from all-gathered request
+# lists in global builder order, which makes the result independent of the number of ranks.
+#   bulk data   : all-gather of the read shards (at load time) and, every step, of the sketch rows each
+#                 rank computed for its own id range  (RCCL when the backend is "nccl")
+#   per round   : two small all-gathers of (builder, read) request lists
+# ---------------------------------------------------------------------------
+def _torch():
+    import torch
+    return torch
+
+
+def _dev(dist):
+    torch = _torch()
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def all_gather_bytes(arr, dist):
+    """arr: 1-D uint8 numpy array (different length per rank) -> list of numpy arrays in rank order."""
+    torch = _torch()
+    dev = _dev(dist)
+    world = dist.get_world_size()
+    n = torch.tensor([arr.size], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(max(sizes), 1)
+    buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
+    if arr.size:
+        buf[:arr.size] = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+    out = torch.empty(mx * world, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, buf)
+    out = out.cpu().numpy()
+    return [out[r * mx:r * mx + sizes[r]].copy() for r in range(world)]
+
+
+def all_gather_u32_lists(a, b, dist):
+    """Two equally long uint32 lists per rank -> the concatenation over all ranks (rank order)."""
+    world = dist.get_world_size()
+    if world == 1:
+        return np.asarray(a, dtype=np.uint32), np.asarray(b, dtype=np.uint32)
+    packed = np.concatenate([np.asarray(a, dtype=np.uint32), np.asarray(b, dtype=np.uint32)]).view(np.uint8)
+    parts = all_gather_bytes(packed, dist)
+    aa, bb = [], []
+    for p in parts:
+        v = p.view(np.uint32)
+        h = v.size // 2
+        aa.append(v[:h]); bb.append(v[h:])
+    return np.concatenate(aa), np.concatenate(bb)
+
+
+def replicate_reads(bases, off, dist):
+    """Each rank passes its own shard (reads in global id order across ranks).  Returns (all_bases, all_off, lo, hi)
+    with [lo, hi) = this rank's id range in the replicated set."""
+    off = np.asarray(off, dtype=np.uint64)
+    lens = np.diff(off).astype(np.uint32)
+    shards = all_gather_bytes(np.ascontiguousarray(bases[int(off[0]):int(off[-1])]), dist)
+    lens_all = [p.view(np.uint32) for p in all_gather_bytes(lens.view(np.uint8), dist)]
+    rank = dist.get_rank()
+    lo = int(sum(len(x) for x in lens_all[:rank]))
+    hi = lo + len(lens_all[rank])
+    all_lens = np.concatenate(lens_all) if lens_all else np.zeros(0, np.uint32)
+    all_off = np.zeros(all_lens.size + 1, dtype=np.uint64)
+    all_off[1:] = np.cumsum(all_lens, dtype=np.uint64)
+    return np.concatenate(shards), all_off, lo, hi
+
+
+def exchange_sketch_rows(gpu, salts, lo, hi, dist):
+    """Sketch the own id range, all-gather the rows, import the other ranks' rows (device buffers with nccl)."""
+    import ctypes as C
+    from . import filter as F
+    torch = _torch()
+    lib, ctx = gpu.lib, gpu.ctx
+    n = gpu.n
+    salts = np.ascontiguousarray(salts, dtype=np.uint64)
+    F.check(lib, lib.nsgpu_sketch_range(ctx, salts.ctypes.data_as(C.c_void_p), lo, hi))
+    world = dist.get_world_size()
+    if world > 1:
+        dev = _dev(dist)
+        on_dev = int(dev.type == "cuda")
+        rows = torch.tensor([hi - lo], dtype=torch.int64, device=dev)
+        cnts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(cnts, rows)
+        cnts = [int(x.item()) for x in cnts]
+        mx = max(max(cnts), 1)
+        mine = torch.zeros(mx * n, dtype=torch.int64, device=dev)
+        if hi > lo:
+            F.check(lib, lib.nsgpu_sketch_rows_get(ctx, lo, hi, C.c_void_p(mine.data_ptr()), on_dev))
+        allrows = torch.empty(mx * n * world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allrows, mine)
+        if on_dev:
+            torch.cuda.synchronize()
+        start = 0
+        for r in range(world):
+            if r != dist.get_rank() and cnts[r]:
+                ptr = allrows.data_ptr() + r * mx * n * 8
+                F.check(lib, lib.nsgpu_sketch_rows_set(ctx, start, start + cnts[r], C.c_void_p(ptr), on_dev))
+            start += cnts[r]
+    F.check(lib, lib.nsgpu_sketch_mark_complete(ctx))
+
+
+def consensus_exchange(gpu, n_builders_total, dist, n_threads_out=1):
+    """The contig stage over all ranks (nsgpu_cons_* phases with an all-gather between requests and resolve)."""
+    import ctypes as C
+    from . import filter as F
+    lib, ctx = gpu.lib, gpu.ctx
+    rank, world = dist.get_rank(), dist.get_world_size()
+    F.check(lib, lib.nsgpu_cons_begin(ctx, n_builders_total, rank, world))
+
+    def take(fn):
+        pa, pb, n = C.c_void_p(), C.c_void_p(), C.c_uint32()
+        F.check(lib, fn(ctx, C.byref(pa), C.byref(pb), C.byref(n)))
+        a = np.ctypeslib.as_array(C.cast(pa, C.POINTER(C.c_uint32)), shape=(max(n.value, 1),))[:n.value].copy()
+        b = np.ctypeslib.as_array(C.cast(pb, C.POINTER(C.c_uint32)), shape=(max(n.value, 1),))[:n.value].copy()
+        lib.nsgpu_free(pa); lib.nsgpu_free(pb)
+        return a, b
+
+    def ptr(a):
+        return a.ctypes.data_as(C.c_void_p) if a.size else None
+
+    n_coll = 0
+    while True:
+        F.check(lib, lib.nsgpu_cons_advance(ctx, 0))
+        while True:
+            ga, gb = all_gather_u32_lists(*take(lib.nsgpu_cons_seed_requests), dist)
+            n_coll += 1
+            if ga.size == 0:
+                break
+            started = C.c_uint32()
+            ga, gb = np.ascontiguousarray(ga), np.ascontiguousarray(gb)
+            F.check(lib, lib.nsgpu_cons_seed_resolve(ctx, ptr(ga), ptr(gb), ga.size, C.byref(started)))
+            if started.value == 0:
+                break
+            F.check(lib, lib.nsgpu_cons_advance(ctx, 1))
+        F.check(lib, lib.nsgpu_cons_batches(ctx))
+        ga, gb = all_gather_u32_lists(*take(lib.nsgpu_cons_claim_requests), dist)
+        n_coll += 1
+        ga, gb = np.ascontiguousarray(ga), np.ascontiguousarray(gb)
+        done = C.c_uint32()
+        F.check(lib, lib.nsgpu_cons_claim_resolve(ctx, ptr(ga), ptr(gb), ga.size, C.byref(done)))
+        if done.value:
+            break
+    st = F.ConsensusStats()
+    F.check(lib, lib.nsgpu_cons_finish(ctx, n_threads_out, C.byref(st)))
+    out = {k: getattr(st, k) for k, _ in F.ConsensusStats._fields_}
+    out["n_collectives"] = n_coll
+    return out

@@ -1,0 +1,35 @@
+"""Worker of tests/test_dist_gpu.py: one rank of the exchange-mode contig stage (all ranks share cuda:0 here; the
+collectives run over gloo so that the test needs only one GPU)."""
+import os
+import pickle
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch.distributed as dist
+
+import nanospring_amd as ns
+from nanospring_amd import dist as nd
+from nanospring_amd.filter import STREAMS
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n_reads, n_builders, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+bases, off = ns.synth_reads(41, 120000, n_reads, 3000.0)
+lo, hi = nd.shard_bounds(off, world)[rank]
+sb, so = nd.take_shard(bases, off, lo, hi)                  # what this rank "owns" before the exchange
+all_b, all_o, lo2, hi2 = nd.replicate_reads(sb, so, dist)
+assert (lo2, hi2) == (lo, hi) and np.array_equal(all_o, off) and np.array_equal(all_b, bases)
+g = ns.NsGpu()
+g.load_reads((all_b, all_o))
+salts = ns.mt19937_64_salts(60)
+nd.exchange_sketch_rows(g, salts, lo, hi, dist)
+g.build_index()
+st = nd.consensus_exchange(g, n_builders, dist, 1)
+streams = {k: ns.consensus_stream(g, 0, k) for k in STREAMS}
+res = nd.gather_to_rank0((streams, ns.consensus_stream(g, 0, "metaData"), st, ns.consensus_verify(g)), dist)
+if rank == 0:
+    pickle.dump(res, open(out, "wb"))
+dist.barrier()
+g.close()
+dist.destroy_process_group()

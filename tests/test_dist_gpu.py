@@ -1,0 +1,67 @@
+"""Exchange-mode multi-GPU contig stage (nanospring_amd/dist.py) with 2 and 3 ranks sharing the one GPU of the
+test box (collectives over gloo): the result must not depend on the number of ranks -- same contigs, same
+counters as the single-process run with the same total number of builders -- and be lossless."""
+import os
+import pickle
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import nanospring_amd as ns
+from nanospring_amd import dist as nd
+from nanospring_amd.filter import STREAMS
+from tests.stream_decode import decode
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_READS, N_BUILDERS = 500, 24
+
+
+def single():
+    bases, off = ns.synth_reads(41, 120000, N_READS, 3000.0)
+    g = ns.NsGpu()
+    g.load_reads((bases, off))
+    g.sketch(ns.mt19937_64_salts(60), fetch=False)
+    g.build_index()
+    st = ns.consensus_run(g, N_BUILDERS, 1)
+    s = {k: ns.consensus_stream(g, 0, k) for k in STREAMS}
+    assert ns.consensus_verify(g) == 0
+    g.close()
+    return bases, off, st, s
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_result_is_independent_of_rank_count(world):
+    bases, off, st1, s1 = single()
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "o.pkl")
+        port = str(29600 + world)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, NSGPU_THREADS="4")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                            "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(N_READS),
+                            str(N_BUILDERS), out], env=env, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        res = pickle.load(open(out, "rb"))
+    assert len(res) == world
+    got, genomes, lones = {}, [], []
+    for streams, md, st, bad in res:
+        assert bad == 0
+        d = decode(streams)
+        assert not set(d) & set(got)
+        got.update(d)
+        genomes += streams["genome"].split(b"\n")[:-1]
+        lones += streams["lone"].split(b"\n")[:-1]
+    b = bytes(bases)
+    assert sorted(got) == list(range(N_READS))
+    for i in range(N_READS):
+        assert got[i] == b[int(off[i]):int(off[i + 1])]
+    # same contigs and counters as one process with the same number of builders
+    assert sorted(genomes) == sorted(s1["genome"].split(b"\n")[:-1])
+    assert sorted(lones) == sorted(s1["lone"].split(b"\n")[:-1])
+    for k in ("n_contigs", "n_lone", "count_minhash", "count_minhash_not_in_graph", "count_aligner", "n_align_calls"):
+        assert sum(x[2][k] for x in res) == st1[k], k
+    m = nd.parse_meta(nd.merge_meta([x[1] for x in res]))
+    assert m["numReads"] == N_READS and m["numThr"] == world and sum(m["numReadsInContig"]) == N_READS
