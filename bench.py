@@ -13,8 +13,11 @@ resident (2-bit packed) in HBM:
 Workload = BASELINE.json configs[1]: 100 000 synthetic ONT-like reads, mean 8 kb, 20x of an iid
 genome, 1% sub + 1% ins + 1% del, k=23 n=60 thr=6, minimap k=20 w=50, per GPU.
 
-Multi-GPU: reads shard by id, one process per GPU; every rank runs the whole path on its shard
-(contigs are built inside a shard), no data-path collective -> weak scaling.
+Multi-GPU (one process per GPU, RCCL): reads shard by id (rank r generates reads [r*R, (r+1)*R) of ONE read set over
+a genome N times larger: weak scaling).  Exchange mode (default): the read shards are replicated by all-gather at load
+time; every step each rank sketches its own id range, the sketch rows are all-gathered, every rank builds the whole
+bucket index and owns the contig builders with gid % N == rank; claims are resolved from all-gathered request lists
+in global builder order (nanospring_amd/dist.py).  --no-exchange: independent shards, no collective.
 
 Prints ONE JSON line on rank 0, including
   roofline     : dominant kernel (ksw_extd2 wavefront DP) algorithmic bytes / HIP-event kernel time vs HBM peak
@@ -64,6 +67,7 @@ def main():
     ap.add_argument("--mean-len", type=float, default=8000.0)
     ap.add_argument("--builders", type=int, default=1024, help="virtual contig builders per GPU")
     ap.add_argument("--cpu-sample", type=int, default=1500, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-exchange", action="store_true", help="multi-GPU: independent shards, no collective")
     args = ap.parse_args()
 
     import torch
@@ -74,24 +78,40 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU fallback)")
+    local %= max(torch.cuda.device_count(), 1)      # (test rigs with fewer GPUs than ranks share devices; needs the gloo override)
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("NSGPU_BENCH_BACKEND", "nccl")      # "nccl" = RCCL; "gloo" only for single-GPU test rigs
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     k, n, thr = 23, 60, 6
     salts = ns.mt19937_64_salts(n, 12345)
-    genome_len = int(args.reads * args.mean_len / 20)          # 20x depth
-    bases, off = ns.synth_reads(11 + rank, genome_len, args.reads, args.mean_len)   # rank r = read-id shard r
+    exchange = world > 1 and not args.no_exchange
+    genome_len = int(world * args.reads * args.mean_len / 20)  # 20x depth; one genome for the whole job
+    # rank r owns read ids [r*R, (r+1)*R) of one read set
+    bases, off = ns.synth_reads(11, genome_len, args.reads, args.mean_len, first=rank * args.reads)
     n_bases = int(off[-1])
 
     stream = torch.cuda.Stream()
     g = ns.NsGpu(k=k, n=n, overlap_sketch_thr=thr, device=local, stream=stream.cuda_stream)
-    g.load_reads((bases, off))          # host -> HBM + 2-bit pack: outside the timed region
-    ns.filter.check(g.lib, g.lib.nsgpu_set_read_id_base(g.ctx, rank * args.reads))   # global read ids of this shard
+    if exchange:
+        from nanospring_amd import dist as nd
+        all_b, all_o, lo, hi = nd.replicate_reads(bases, off, dist)     # RCCL all-gather of the shards (load time)
+        g.load_reads((all_b, all_o))
+    else:
+        g.load_reads((bases, off))      # host -> HBM + 2-bit pack: outside the timed region
+        ns.filter.check(g.lib, g.lib.nsgpu_set_read_id_base(g.ctx, rank * args.reads))   # global read ids of this shard
 
     def step():
+        if exchange:
+            nd.exchange_sketch_rows(g, salts, lo, hi, dist)    # own rows + RCCL all-gather of everybody's
+            g.build_index()
+            return nd.consensus_exchange(g, args.builders * world, dist, 8)
         g.sketch(salts, fetch=False)
         g.build_index()
         return ns.consensus_run(g, args.builders, 8)
@@ -117,10 +137,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        cdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tb = torch.tensor([n_bases], device="cuda", dtype=torch.int64)
+        tb = torch.tensor([n_bases], device=cdev, dtype=torch.int64)
         dist.all_reduce(tb)
         total_bases = int(tb.item())
     else:
@@ -129,7 +150,7 @@ def main():
     if rank == 0:
         steps = max(args.steps, 1)
         a = ns.align_stats(g)
-        bad = ns.consensus_verify(g)
+        bad = ns.consensus_verify(g)         # rank 0's share of the reads (all of them when n_gpus == 1)
         stream_bytes = sum(len(ns.consensus_stream(g, t, kk)) for t in range(8) for kk in ns.filter.STREAMS)
         # dominant kernel: the ksw_extd2 wavefront DP.  Algorithmic bytes per DP problem = its two
         # sequences (1 B/base as coded) + its CIGAR (4 B/op) + the 44-byte result; the traceback matrix
@@ -159,7 +180,9 @@ def main():
                                              "contig_stage_total": round(st["total_ms"], 1), "window_queries": round(st["filter_ms"], 1),
                                              "consensus_index": round(st["index_ms"], 1), "align_total": round(st["align_ms"], 1),
                                              "align_dp_kernel": round(a["dp_kernel_ms"] / steps, 1), "graph_host_wall": round(st["graph_ms"], 1)},
-                       "parallelism": f"reads sharded by id x{world}, no collective"},
+                       "parallelism": (f"x{world}: reads sharded by id, replicated by all-gather; per step all-gather of sketch rows + "
+                                       f"{st.get('n_collectives', 0)} small all-gathers of claim lists (global builder order)") if exchange
+                       else f"reads sharded by id x{world}, no collective"},
             "roofline": {"kernel": "ksw_extd2_lds_kernel", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": None,
                          "launches": int(a["dp_launches"]), "avg_launch_ms": round(dp_ms, 3),

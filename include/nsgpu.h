@@ -230,6 +230,9 @@ int nsgpu_get_timing(const nsgpu_ctx *ctx, nsgpu_timing *t);
 int nsgpu_synth_reads(uint64_t seed, uint64_t genome_len, uint32_t n_reads, double mean_len,
                       double p_sub, double p_ins, double p_del,
                       char **bases_out, uint64_t **off_out);
+/* reads [first, first + n_reads) of the same read set (multi-GPU ranks generate only their id range) */
+int nsgpu_synth_reads_range(uint64_t seed, uint64_t genome_len, uint32_t first, uint32_t n_reads, double mean_len,
+                            double p_sub, double p_ins, double p_del, char **bases_out, uint64_t **off_out);
 
 #ifdef __cplusplus
 }

@@ -66,8 +66,24 @@ uint64_t emit_read(const std::vector<char> &genome, const Plan &pl, uint64_t see
 
 }  // namespace
 
+static int synth_impl(uint64_t seed, uint64_t genome_len, uint32_t first, uint32_t n_reads, double mean_len, double p_sub, double p_ins,
+                      double p_del, char **bases_out, uint64_t **off_out);
+
 extern "C" int nsgpu_synth_reads(uint64_t seed, uint64_t genome_len, uint32_t n_reads, double mean_len, double p_sub, double p_ins,
                                  double p_del, char **bases_out, uint64_t **off_out)
+{
+    return synth_impl(seed, genome_len, 0, n_reads, mean_len, p_sub, p_ins, p_del, bases_out, off_out);
+}
+
+// reads [first, first + n_reads) of the read set that nsgpu_synth_reads(seed, genome_len, ...) defines
+extern "C" int nsgpu_synth_reads_range(uint64_t seed, uint64_t genome_len, uint32_t first, uint32_t n_reads, double mean_len, double p_sub,
+                                       double p_ins, double p_del, char **bases_out, uint64_t **off_out)
+{
+    return synth_impl(seed, genome_len, first, n_reads, mean_len, p_sub, p_ins, p_del, bases_out, off_out);
+}
+
+static int synth_impl(uint64_t seed, uint64_t genome_len, uint32_t first, uint32_t n_reads, double mean_len, double p_sub, double p_ins,
+                      double p_del, char **bases_out, uint64_t **off_out)
 {
     if (!bases_out || !off_out || genome_len < 1000) return NSGPU_ERR_ARG;
     unsigned nt = std::thread::hardware_concurrency();
@@ -92,7 +108,7 @@ extern "C" int nsgpu_synth_reads(uint64_t seed, uint64_t genome_len, uint32_t n_
     }
     std::vector<Plan> plan(n_reads);
     for (uint32_t r = 0; r < n_reads; ++r) {
-        Rng rng(mix(seed ^ 0x5151515151ull, r));
+        Rng rng(mix(seed ^ 0x5151515151ull, (uint64_t)first + r));
         double l = -(mean_len / 2.0) * (std::log(1.0 - rng.uni()) + std::log(1.0 - rng.uni()));
         if (l < 500.0) l = 500.0;
         uint64_t len = (uint64_t)l;
@@ -110,7 +126,7 @@ extern "C" int nsgpu_synth_reads(uint64_t seed, uint64_t genome_len, uint32_t n_
         for (unsigned t = 0; t < nt; ++t)
             th.emplace_back([&, t]() {
                 for (uint32_t r = t; r < n_reads; r += nt) {
-                    const uint64_t l = emit_read(genome, plan[r], seed, r, p_sub, p_ins, p_del, base ? base + off[r] : nullptr);
+                    const uint64_t l = emit_read(genome, plan[r], seed, first + r, p_sub, p_ins, p_del, base ? base + off[r] : nullptr);
                     if (!base) lens[r] = l;
                 }
             });
