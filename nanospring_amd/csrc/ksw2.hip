@@ -363,6 +363,289 @@ __global__ __launch_bounds__(64) void ksw_extd2_hbm_kernel(const KswTask *__rest
     }
 }
 
+
+// ----------------------------------------------------------------------------
+// v2: workgroup-per-problem kernel (NT = 64 ... 256 threads).  Every anti-diagonal is swept in two phases:
+//   read   : each thread loads the state of its (up to MAXPOS) cells, the (x, v, x2) of the left neighbour
+//            straight from LDS (no cross-lane shuffles, no carried values), and its score -- recomputed when the
+//            cell lies in the reference's 16-byte score-store range of this row, the stale s[t] otherwise;
+//   write  : after a barrier, the recurrences, the new state, s[t] and the traceback byte.
+// Same lane-exact semantics as ksw_extd2_wave (16-aligned sweep, stale scores, s|sf|qr contiguity, int8 wrap).
+// Long problems get 256 threads, i.e. 4 waves per anti-diagonal instead of 1: they are latency-bound.
+// ----------------------------------------------------------------------------
+template <int NT, int MAXPOS>
+__global__ __launch_bounds__(NT) void ksw_extd2_wg_kernel(const KswTask *__restrict__ tasks, const uint32_t *__restrict__ order, uint32_t n_tasks,
+                                                          KswParams pr, const uint8_t *__restrict__ seqs, uint8_t *__restrict__ p_pool,
+                                                          uint32_t *__restrict__ cig_pool, KswResult *__restrict__ res_out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ unsigned long long s_best[NT / 64];
+    if (blockIdx.x >= n_tasks) return;
+    const KswTask tk = tasks[order[blockIdx.x]];
+    const int tid = threadIdx.x;
+    const int qlen = tk.qlen, tlen = tk.tlen, flag = tk.flag, zdrop = tk.zdrop;
+    int q = pr.q, e = pr.e, q2 = pr.q2, e2 = pr.e2;
+    if (q2 + e2 < q + e) { int t_ = q; q = q2; q2 = t_; t_ = e; e = e2; e2 = t_; }
+    const int qe = q + e, qe2 = q2 + e2;
+    const int sc_mch = pr.sc_mch, sc_mis = pr.sc_mis;
+    const int sc_N = pr.sc_ambi == 0 ? -e2 : pr.sc_ambi;
+    const bool approx_max = (flag & KSW_EZ_APPROX_MAX) != 0, right = (flag & KSW_EZ_RIGHT) != 0;
+    int ez_max = 0, ez_zdropped = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1, ez_mte = KSW_NEG_INF, ez_mte_q = -1;
+    int ez_score = KSW_NEG_INF, ez_reach_end = 0;
+    uint32_t n_cigar = 0;
+    int w = tk.w;
+    if (w < 0) w = tlen > qlen ? tlen : qlen;
+    const int T16 = (tlen + 15) / 16 * 16;
+    int n_col_ = qlen < tlen ? qlen : tlen;
+    n_col_ = ((n_col_ < w + 1 ? n_col_ : w + 1) + 15) / 16 + 1;
+    const int ncol16 = n_col_ * 16;
+    int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+    if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+    const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+
+    uint2 *S = reinterpret_cast<uint2 *>(lds);
+    int *H = reinterpret_cast<int *>(lds + (size_t)T16 * 8);
+    uint8_t *bytes = lds + (size_t)T16 * 8 + (approx_max ? 0 : (size_t)T16 * 4);
+    uint8_t *s = bytes, *sf = bytes + T16, *qr = bytes + 2 * T16;
+    const int qr_bytes = ((qlen + 15) / 16 + 1) * 16;
+    const uint32_t b0 = (uint32_t)(-q - e) & 0xff, b1 = (uint32_t)(-q2 - e2) & 0xff;
+    {
+        const uint2 init = make_uint2(b0 | b0 << 8 | b0 << 16 | b0 << 24, b1 | b1 << 8);
+        for (int t = tid; t < T16; t += NT) S[t] = init;
+        for (int i = tid; i < 2 * T16 + qr_bytes; i += NT) bytes[i] = 0;
+        if (!approx_max) for (int t = tid; t < T16; t += NT) H[t] = KSW_NEG_INF;
+    }
+    __syncthreads();
+    {
+        const uint8_t *query = seqs + tk.qoff, *target = seqs + tk.toff;
+        for (int t = tid; t < qlen; t += NT) qr[t] = query[qlen - 1 - t];
+        for (int t = tid; t < tlen; t += NT) sf[t] = target[t];
+    }
+    __syncthreads();
+
+    uint8_t *p = p_pool + tk.p_off;
+    int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0;
+    const int n_rows = qlen + tlen - 1;
+    for (int r = 0; r < n_rows; ++r) {
+        const RowRange rr = row_range(r, qlen, tlen, w);
+        if (rr.empty) { ez_zdropped = 1; break; }
+        const int st0 = rr.st0, en0 = rr.en0, st = rr.st, en = rr.en;
+        // ---- read phase ----
+        uint32_t nb_first;                                         // (x, v, x2) seen by the first cell of the sweep
+        if (st > 0) {
+            if (st - 1 >= last_st && st - 1 <= last_en) { const uint2 sv = S[st - 1]; nb_first = ((sv.x >> 16) & 0xff) << 16 | ((sv.x >> 8) & 0xff) << 8 | (sv.y & 0xff); }
+            else nb_first = b0 << 16 | b0 << 8 | b1;
+        } else {
+            const uint32_t v1 = (uint32_t)(r == 0 ? (-q - e) : r < long_thres ? (-e) : r == long_thres ? long_diff : (-e2)) & 0xff;
+            nb_first = b0 << 16 | v1 << 8 | b1;
+        }
+        const int sc_end = st0 + ((en0 - st0) / 16 + 1) * 16;    // exclusive end of this row's score stores
+        const int qoff = qlen - 1 - r;
+        uint2 sv[MAXPOS];
+        uint32_t nb[MAXPOS];
+        int zz[MAXPOS];
+#pragma unroll
+        for (int k = 0; k < MAXPOS; ++k) {
+            const int t = st + tid + k * NT;
+            sv[k] = make_uint2(0, 0), nb[k] = 0, zz[k] = 0;
+            if (t <= en) {
+                uint2 a = S[t];
+                if (t == r) {                                      // u[r], y[r], y2[r] boundary of this row (en >= r holds: r is inside [st, en])
+                    const uint32_t ur = (uint32_t)(r == 0 ? (-q - e) : r < long_thres ? (-e) : r == long_thres ? long_diff : (-e2)) & 0xff;
+                    a.x = (a.x & 0x00ffff00u) | ur | (b0 << 24);
+                    a.y = (a.y & 0xffff00ffu) | (b1 << 8);
+                }
+                sv[k] = a;
+                if (t == st) nb[k] = nb_first;
+                else { const uint2 l = S[t - 1]; nb[k] = ((l.x >> 16) & 0xff) << 16 | ((l.x >> 8) & 0xff) << 8 | (l.y & 0xff); }
+                if (t >= st0 && t < sc_end) {
+                    const int sq = sf[t], sq2 = qr[qoff + t];
+                    int z = sq == sq2 ? sc_mch : sc_mis;
+                    if (sq == 4 || sq2 == 4) z = sc_N;
+                    zz[k] = z;
+                } else zz[k] = sx8(s[t]);
+            }
+        }
+        // score stores that run past the aligned end of the sweep (at most 15 cells; they may spill from s into sf)
+        int t_extra = en + 1 + tid, z_extra = 0;
+        const bool has_extra = tid < 16 && t_extra < sc_end;
+        if (has_extra) {
+            const int sq = sf[t_extra], sq2 = qr[qoff + t_extra];
+            z_extra = sq == sq2 ? sc_mch : sc_mis;
+            if (sq == 4 || sq2 == 4) z_extra = sc_N;
+        }
+        __syncthreads();
+        // ---- write phase ----
+        uint8_t *prow = p + (size_t)r * ncol16 - st;
+#pragma unroll
+        for (int k = 0; k < MAXPOS; ++k) {
+            const int t = st + tid + k * NT;
+            if (t <= en) {
+                int z = zz[k];
+                const int ut = sx8(sv[k].x), yo = sx8(sv[k].x >> 24), y2o = sx8(sv[k].y >> 8);
+                const int xt1 = sx8(nb[k] >> 16), vt1 = sx8(nb[k] >> 8), x2t1 = sx8(nb[k]);
+                int a = sx8(xt1 + vt1), b = sx8(yo + ut), a2 = sx8(x2t1 + vt1), b2 = sx8(y2o + ut), d;
+                if (!right) {
+                    d = a > z ? 1 : 0;  z = z > a ? z : a;
+                    d = b > z ? 2 : d;  z = z > b ? z : b;
+                    d = a2 > z ? 3 : d; z = z > a2 ? z : a2;
+                    d = b2 > z ? 4 : d; z = z > b2 ? z : b2;
+                } else {
+                    d = z > a ? 0 : 1;  z = z > a ? z : a;
+                    d = z > b ? d : 2;  z = z > b ? z : b;
+                    d = z > a2 ? d : 3; z = z > a2 ? z : a2;
+                    d = z > b2 ? d : 4; z = z > b2 ? z : b2;
+                }
+                z = z < sc_mch ? z : sc_mch;
+                const int un = sx8(z - vt1), vn = sx8(z - ut);
+                int tmp = sx8(z - q);
+                a = sx8(a - tmp), b = sx8(b - tmp);
+                tmp = sx8(z - q2);
+                a2 = sx8(a2 - tmp), b2 = sx8(b2 - tmp);
+                int xn, yn, x2n, y2n;
+                if (!right) {
+                    xn = sx8((a > 0 ? a : 0) - qe);    d |= a > 0 ? 0x08 : 0;
+                    yn = sx8((b > 0 ? b : 0) - qe);    d |= b > 0 ? 0x10 : 0;
+                    x2n = sx8((a2 > 0 ? a2 : 0) - qe2); d |= a2 > 0 ? 0x20 : 0;
+                    y2n = sx8((b2 > 0 ? b2 : 0) - qe2); d |= b2 > 0 ? 0x40 : 0;
+                } else {
+                    xn = sx8((0 > a ? 0 : a) - qe);    d |= 0 > a ? 0 : 0x08;
+                    yn = sx8((0 > b ? 0 : b) - qe);    d |= 0 > b ? 0 : 0x10;
+                    x2n = sx8((0 > a2 ? 0 : a2) - qe2); d |= 0 > a2 ? 0 : 0x20;
+                    y2n = sx8((0 > b2 ? 0 : b2) - qe2); d |= 0 > b2 ? 0 : 0x40;
+                }
+                S[t] = make_uint2((uint32_t)(un & 0xff) | (uint32_t)(vn & 0xff) << 8 | (uint32_t)(xn & 0xff) << 16 | (uint32_t)(yn & 0xff) << 24,
+                                  (uint32_t)(x2n & 0xff) | (uint32_t)(y2n & 0xff) << 8);
+                if (t >= st0 && t < sc_end) s[t] = (uint8_t)zz[k];
+                prow[t] = (uint8_t)d;
+            }
+        }
+        if (has_extra) s[t_extra] = (uint8_t)z_extra;
+        __syncthreads();
+        // ---- score bookkeeping (uniform) ----
+        bool brk = false;
+        if (!approx_max) {
+            int max_H, max_t;
+            if (r > 0) {
+                int h_en0;
+                { const uint2 se = S[en0]; h_en0 = en0 > 0 ? H[en0 - 1] + sx8(se.x) : H[en0] + sx8(se.x >> 8); }
+                __syncthreads();
+                const int en1 = st0 + (en0 - st0) / 4 * 4;
+                unsigned long long best = ((unsigned long long)((long long)h_en0 + 0x80000000ll) << 32) | 0xFFFFFFFFull;
+                for (int t = st0 + tid; t < en0; t += NT) {
+                    const int h = H[t] + sx8(S[t].x >> 8);
+                    H[t] = h;
+                    const uint32_t rank = t < en1 ? (uint32_t)((t - st0) & 3) * 0x100000u + (uint32_t)t : 4u * 0x100000u + (uint32_t)t;
+                    const unsigned long long key = ((unsigned long long)((long long)h + 0x80000000ll) << 32) | (0xFFFFFFFEull - rank);
+                    best = key > best ? key : best;
+                }
+                if (tid == 0) H[en0] = h_en0;
+                best = shfl_max_u64(best);
+                if (NT > 64) {
+                    if ((tid & 63) == 0) s_best[tid >> 6] = best;
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < NT / 64; ++i) best = s_best[i] > best ? s_best[i] : best;
+                }
+                max_H = (int)((long long)(best >> 32) - 0x80000000ll);
+                const uint32_t lo = (uint32_t)best;
+                max_t = lo == 0xFFFFFFFFu ? en0 : (int)((0xFFFFFFFEu - lo) & 0xFFFFFu);
+                __syncthreads();
+            } else {
+                const int h = sx8(S[0].x >> 8) - qe;
+                __syncthreads();
+                if (tid == 0) H[0] = h;
+                max_H = h, max_t = 0;
+                __syncthreads();
+            }
+            const int h_en0 = H[en0], h_st0 = H[st0];
+            if (en0 == tlen - 1 && h_en0 > ez_mte) ez_mte = h_en0, ez_mte_q = r - en;
+            if (r - st0 == qlen - 1 && h_st0 > ez_mqe) ez_mqe = h_st0, ez_mqe_t = st0;
+            if (max_H > ez_max) {
+                ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
+            } else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
+                const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+                if (zdrop >= 0 && ez_max - max_H > zdrop + l * e2) { ez_zdropped = 1; brk = true; }
+            }
+            if (!brk && r == qlen + tlen - 2 && en0 == tlen - 1) ez_score = H[tlen - 1];
+        } else {
+            if (r > 0) {
+                if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+                    const int d0 = sx8(S[last_H0_t].x >> 8), d1 = sx8(S[last_H0_t + 1].x);
+                    if (d0 > d1) H0 += d0;
+                    else H0 += d1, ++last_H0_t;
+                } else if (last_H0_t >= st0 && last_H0_t <= en0) {
+                    H0 += sx8(S[last_H0_t].x >> 8);
+                } else {
+                    ++last_H0_t, H0 += sx8(S[last_H0_t].x);
+                }
+            } else H0 = sx8(S[0].x >> 8) - qe, last_H0_t = 0;
+            if (flag & KSW_EZ_APPROX_DROP) {
+                if (H0 > ez_max) {
+                    ez_max = H0, ez_max_t = last_H0_t, ez_max_q = r - last_H0_t;
+                } else if (last_H0_t >= ez_max_t && r - last_H0_t >= ez_max_q) {
+                    const int tl = last_H0_t - ez_max_t, ql = (r - last_H0_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+                    if (zdrop >= 0 && ez_max - H0 > zdrop + l * e2) { ez_zdropped = 1; brk = true; }
+                }
+            }
+            if (!brk && r == qlen + tlen - 2 && en0 == tlen - 1) ez_score = H0;
+        }
+        if (brk) break;
+        last_st = st, last_en = en;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (!(flag & KSW_EZ_SCORE_ONLY)) {
+        int i0 = -1, j0 = -1;
+        if (!ez_zdropped && !(flag & KSW_EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
+        else if (!ez_zdropped && (flag & KSW_EZ_EXTZ_ONLY) && ez_mqe + tk.end_bonus > ez_max) ez_reach_end = 1, i0 = ez_mqe_t, j0 = qlen - 1;
+        else if (ez_max_t >= 0 && ez_max_q >= 0) i0 = ez_max_t, j0 = ez_max_q;
+        if (tid == 0 && i0 >= 0 && j0 >= 0) {
+            uint32_t *cig = cig_pool + tk.cig_off;
+            int i = i0, j = j0, state = 0;
+            uint32_t cur_op = 0xffffffffu, cur_len = 0;
+            while (i >= 0 && j >= 0) {
+                const int r = i + j;
+                const RowRange rr = row_range(r, qlen, tlen, w);
+                int force_state = -1;
+                if (i < rr.st) force_state = 2;
+                if (i > rr.en) force_state = 1;
+                const uint32_t tmp = force_state < 0 ? p[(size_t)r * ncol16 + i - rr.st] : 0u;
+                if (state == 0) state = tmp & 7;
+                else if (!(tmp >> (state + 2) & 1)) state = 0;
+                if (state == 0) state = tmp & 7;
+                if (force_state >= 0) state = force_state;
+                uint32_t op;
+                if (state == 0) op = 0, --i, --j;
+                else if (state == 1 || state == 3) op = 2, --i;
+                else op = 1, --j;
+                if (op == cur_op) ++cur_len;
+                else { if (cur_len) cig[n_cigar++] = cur_len << 4 | cur_op; cur_op = op, cur_len = 1; }
+            }
+            if (i >= 0) { if (cur_op == 2) cur_len += i + 1; else { if (cur_len) cig[n_cigar++] = cur_len << 4 | cur_op; cur_op = 2, cur_len = i + 1; } }
+            if (j >= 0) { if (cur_op == 1) cur_len += j + 1; else { if (cur_len) cig[n_cigar++] = cur_len << 4 | cur_op; cur_op = 1, cur_len = j + 1; } }
+            if (cur_len) cig[n_cigar++] = cur_len << 4 | cur_op;
+            if (!(flag & KSW_EZ_REV_CIGAR))
+                for (uint32_t a = 0; a < n_cigar >> 1; ++a) { const uint32_t t_ = cig[a]; cig[a] = cig[n_cigar - 1 - a]; cig[n_cigar - 1 - a] = t_; }
+        }
+    }
+    if (tid == 0) {
+        KswResult o;
+        o.max = (uint32_t)ez_max; o.zdropped = ez_zdropped; o.max_q = ez_max_q; o.max_t = ez_max_t; o.mqe = ez_mqe; o.mqe_t = ez_mqe_t;
+        o.mte = ez_mte; o.mte_q = ez_mte_q; o.score = ez_score; o.n_cigar = (int)n_cigar; o.reach_end = ez_reach_end;
+        res_out[tk.out_idx] = o;
+    }
+}
+
+// widest 16-aligned sweep of a problem (cells per anti-diagonal)
+static int ksw_max_width(int qlen, int tlen, int w)
+{
+    if (w < 0) w = tlen > qlen ? tlen : qlen;
+    const int T16 = (tlen + 15) / 16 * 16;
+    const long long band = (long long)w + 1 + 32;
+    return (int)(band < T16 ? band : T16);
+}
+
 // CIGAR compaction: every problem owns a worst-case slice (qlen + tlen + 2 entries) of the CIGAR pool, of which it
 // uses a handful; only the used entries travel back over PCIe.
 __global__ __launch_bounds__(256) void ksw_ncigar_kernel(const KswResult *__restrict__ res, uint32_t n, uint32_t *__restrict__ ncig)
@@ -412,7 +695,12 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
     cigars.clear();
     if (n == 0) return NSGPU_OK;
     static const size_t kClass[3] = {4096, 16384, 65536};
-    std::vector<uint32_t> order[4];
+    std::vector<uint32_t> order[4];          // fallback: one wave per problem (LDS classes 0..2, HBM slab 3)
+    // workgroup kernel for the long, latency-bound problems of LDS classes 1 and 2: 256 threads (more waves only add barrier cost), up to 5 / 8 cells per
+    // thread and row; the bulk of small gap fills (class 0) is throughput-bound and stays on one wave per problem
+    std::vector<uint32_t> wg[3];
+    static const int kWgThreads[3] = {0, 256, 256}, kWgMaxPos[3] = {0, 5, 8};
+    static const bool no_wg = getenv("NSGPU_KSW_NO_WG") != nullptr;      // debugging aid: fallback kernels only
     size_t p_total = 0, cig_total = 0, hbm_stride = 0;
     for (size_t i = 0; i < n; ++i) {
         KswTask &t = tasks[i];
@@ -429,7 +717,8 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
         const size_t need = ksw_lds_bytes(t.qlen, t.tlen, t.flag);
         int cls = need <= kClass[0] ? 0 : need <= kClass[1] ? 1 : need <= kClass[2] ? 2 : 3;
         if (cls == 3) { const size_t hn = ksw_lds_bytes(t.qlen, t.tlen, 0); if (hn > hbm_stride) hbm_stride = hn; }
-        order[cls].push_back((uint32_t)i);
+        if (cls >= 1 && cls < 3 && !no_wg && ksw_max_width(t.qlen, t.tlen, t.w) <= kWgThreads[cls] * kWgMaxPos[cls]) wg[cls].push_back((uint32_t)i);
+        else order[cls].push_back((uint32_t)i);
     }
     cig_off[n] = cig_total;
     // reset-state results for empty problems
@@ -447,26 +736,58 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
     NS_HIP(hipMemcpyAsync(c->k_seqs.p, seqs, seq_bytes, hipMemcpyHostToDevice, c->stream));
     NS_HIP(hipMemcpyAsync(c->k_res.p, results.data(), n * sizeof(KswResult), hipMemcpyHostToDevice, c->stream));
     std::vector<uint32_t> flat;
-    size_t start[5] = {0, 0, 0, 0, 0};
+    size_t start[5] = {0, 0, 0, 0, 0}, wg_start[3] = {0, 0, 0};
+    auto by_size = [&](uint32_t a, uint32_t b) { return (size_t)tasks[a].qlen * tasks[a].tlen > (size_t)tasks[b].qlen * tasks[b].tlen; };
     for (int k = 0; k < 4; ++k) {
         // big problems first inside a class (longest-processing-time-first)
-        std::stable_sort(order[k].begin(), order[k].end(), [&](uint32_t a, uint32_t b) {
-            return (size_t)tasks[a].qlen * tasks[a].tlen > (size_t)tasks[b].qlen * tasks[b].tlen; });
+        std::stable_sort(order[k].begin(), order[k].end(), by_size);
         start[k] = flat.size();
         flat.insert(flat.end(), order[k].begin(), order[k].end());
     }
     start[4] = flat.size();
+    for (int k = 0; k < 3; ++k) {
+        std::stable_sort(wg[k].begin(), wg[k].end(), by_size);
+        wg_start[k] = flat.size();
+        flat.insert(flat.end(), wg[k].begin(), wg[k].end());
+    }
     if (!flat.empty()) NS_HIP(hipMemcpyAsync(c->k_order.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, c->stream));
     static const bool dbg = getenv("NSGPU_KSW_DEBUG") != nullptr;     // per-launch log (adds a sync per launch)
     NS_HIP(hipEventRecord(c->t_kernel.a, c->stream));
     // The few long problems (extensions up to 5000 x 5000) are latency-bound on one wave each and leave the chip
     // idle: they run on side streams, concurrently with the bulk of small gap fills on the main stream.
     if (!c->side_stream[0]) {
-        for (int i = 0; i < 3; ++i) { NS_HIP(hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking)); NS_HIP(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming)); }
+        int prio_lo = 0, prio_hi = 0;
+        NS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));      // the long problems must be dispatched first: highest priority
+        for (int i = 0; i < 3; ++i) { NS_HIP(hipStreamCreateWithPriority(&c->side_stream[i], hipStreamNonBlocking, prio_hi)); NS_HIP(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming)); }
         NS_HIP(hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming));
     }
     NS_HIP(hipEventRecord(c->side_fork, c->stream));
     bool side_used[3] = {false, false, false};
+    for (int k = 2; k >= 0; --k) {
+        const uint32_t m = (uint32_t)wg[k].size();
+        if (!m) continue;
+        hipStream_t st = c->stream;
+        if (k > 0 && !dbg) { st = c->side_stream[k]; NS_HIP(hipStreamWaitEvent(st, c->side_fork, 0)); side_used[k] = true; }
+        double dbg_t0 = 0;
+        if (dbg) { NS_HIP(hipStreamSynchronize(c->stream)); dbg_t0 = now_ms(); }
+        const uint32_t *ord = c->k_order.as<uint32_t>() + wg_start[k];
+        if (k == 1)
+            hipLaunchKernelGGL((ksw_extd2_wg_kernel<256, 5>), dim3(m), dim3(256), kClass[1], st, c->k_tasks.as<KswTask>(), ord, m, pr, c->k_seqs.as<uint8_t>(),
+                               c->k_p.as<uint8_t>(), c->k_cig.as<uint32_t>(), c->k_res.as<KswResult>());
+        else {
+            NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_wg_kernel<256, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClass[2]));
+            hipLaunchKernelGGL((ksw_extd2_wg_kernel<256, 8>), dim3(m), dim3(256), kClass[2], st, c->k_tasks.as<KswTask>(), ord, m, pr, c->k_seqs.as<uint8_t>(),
+                               c->k_p.as<uint8_t>(), c->k_cig.as<uint32_t>(), c->k_res.as<KswResult>());
+        }
+        NS_HIP(hipGetLastError());
+        ++c->ksw_launches;
+        if (dbg) {
+            NS_HIP(hipStreamSynchronize(c->stream));
+            double cells = 0, mx = 0;
+            for (uint32_t i : wg[k]) { const double x = (double)tasks[i].qlen * tasks[i].tlen; cells += x; if (x > mx) mx = x; }
+            fprintf(stderr, "KSW class %d tasks %u cells %.3g max %.3g (q %d t %d) ms %.3f\n", k + 4, m, cells, mx, tasks[wg[k][0]].qlen, tasks[wg[k][0]].tlen, now_ms() - dbg_t0);
+        }
+    }
     for (int k = 2; k >= 0; --k) {
         const uint32_t m = (uint32_t)order[k].size();
         if (!m) continue;
