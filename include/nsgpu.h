@@ -162,7 +162,8 @@ int nsgpu_align_batch(nsgpu_ctx *ctx, const char *refs, const uint64_t *ref_off,
 typedef struct {
     uint64_t pairs, dp_tasks, dp_rounds;
     double dp_cells;          /* sum of qlen*tlen over all DP problems */
-    double index_ms, host_ms, dp_ms, dp_kernel_ms;   /* host wall / host wall / wall around the DP launches / HIP-event kernel time */
+    double index_ms, host_ms, dp_ms, dp_kernel_ms;   /* host wall / host wall / wall around the DP batches / HIP-event wall of the launches of a batch */
+    double dp_kernel_sum_ms;  /* sum of the individual ksw_extd2 kernel durations (launches overlap on side streams) */
     double dp_alg_bytes;      /* sum over DP problems of qlen + tlen + 4 * n_cigar + sizeof(result) */
     uint64_t dp_launches;     /* ksw_extd2 kernel launches (one per LDS size class per DP round) */
     uint32_t host_threads, reserved;

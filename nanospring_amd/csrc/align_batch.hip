@@ -285,7 +285,7 @@ extern "C" int nsgpu_get_align_stats(const nsgpu_ctx *c, nsgpu_align_stats *s)
 {
     NS_CHECK(c && s, NSGPU_ERR_ARG, "null argument");
     s->pairs = c->aln_pairs; s->dp_tasks = c->aln_dp_tasks; s->dp_rounds = c->aln_rounds; s->dp_cells = c->ksw_cells;
-    s->index_ms = c->aln_index_ms; s->host_ms = c->aln_host_ms; s->dp_ms = c->aln_dp_ms; s->dp_kernel_ms = c->ksw_kernel_ms;
+    s->index_ms = c->aln_index_ms; s->host_ms = c->aln_host_ms; s->dp_ms = c->aln_dp_ms; s->dp_kernel_ms = c->ksw_kernel_ms; s->dp_kernel_sum_ms = c->ksw_kernel_sum_ms;
     s->dp_alg_bytes = c->ksw_alg_bytes;
     s->dp_launches = c->ksw_launches;
     s->host_threads = host_threads();
@@ -297,7 +297,7 @@ extern "C" int nsgpu_reset_align_stats(nsgpu_ctx *c)
     NS_CHECK(c, NSGPU_ERR_ARG, "null argument");
     c->aln_pairs = c->aln_dp_tasks = c->aln_rounds = 0;
     c->aln_index_ms = c->aln_host_ms = c->aln_dp_ms = 0;
-    c->ksw_kernel_ms = c->ksw_cells = c->ksw_alg_bytes = 0;
+    c->ksw_kernel_ms = c->ksw_cells = c->ksw_alg_bytes = c->ksw_kernel_sum_ms = 0;
     c->ksw_launches = 0;
     return NSGPU_OK;
 }

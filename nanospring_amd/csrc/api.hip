@@ -134,6 +134,7 @@ void nsgpu_destroy(nsgpu_ctx *c)
     for (int i = 0; i < 3; ++i) { if (c->side_stream[i]) (void)hipStreamDestroy(c->side_stream[i]); if (c->side_done[i]) (void)hipEventDestroy(c->side_done[i]); }
     if (c->side_fork) (void)hipEventDestroy(c->side_fork);
     if (c->cons_engine) c->cons_engine_free(c->cons_engine);
+    for (hipEvent_t e : c->ksw_ev) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

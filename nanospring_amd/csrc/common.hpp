@@ -107,7 +107,9 @@ struct nsgpu_ctx {
     nsgpu::DevBuf rep_flags;
     // ksw2 batches
     nsgpu::DevBuf k_tasks, k_order, k_seqs, k_p, k_cig, k_res, k_slab, k_ncig, k_coff, k_cig2;
-    double ksw_kernel_ms = 0, ksw_cells = 0, ksw_alg_bytes = 0;
+    double ksw_kernel_ms = 0, ksw_cells = 0, ksw_alg_bytes = 0;     // kernel_ms: wall of the (overlapping) DP launches per batch
+    double ksw_kernel_sum_ms = 0;                                    // sum of the individual kernel durations (what rocprof reports)
+    std::vector<hipEvent_t> ksw_ev;                                  // start/end event pairs, one pair per launch of a batch
     uint64_t ksw_launches = 0;
     hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t side_done[3] = {nullptr, nullptr, nullptr}, side_fork = nullptr;

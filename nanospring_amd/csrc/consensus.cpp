@@ -62,9 +62,25 @@ void Edge::add_read(read_t r) { ++count; reads.insert(std::lower_bound(reads.beg
 
 Edge *Node::edge_to(Node *n) const { for (Edge *e : out) if (e->sink == n) return e; return nullptr; }
 Edge *Node::edge_to_side(char b) const { for (Edge *e : out) if (!e->sink->on_main && e->sink->base == b) return e; return nullptr; }
-Edge *Node::best_out() const { Edge *best = nullptr; read_t c = 0; for (Edge *e : out) if (e->count > c) c = e->count, best = e; return best; }
+Edge *Node::best_out() const
+{
+    if (out.size() == 1) return out[0]->count ? out[0] : nullptr;
+    Edge *best = nullptr; read_t c = 0;
+    for (Edge *e : out) if (e->count > c) c = e->count, best = e;
+    return best;
+}
 Edge *Node::best_in() const { Edge *best = nullptr; read_t c = 0; for (Edge *e : in) if (e->count > c) c = e->count, best = e; return best; }
-Edge *Node::edge_in_read(read_t r) const { for (Edge *e : out) if (std::binary_search(e->reads.begin(), e->reads.end(), r)) return e; return nullptr; }
+Edge *Node::edge_in_read(read_t r) const
+{
+    for (Edge *e : out) {
+        const read_t *b = e->reads.data();
+        size_t n = e->reads.size();
+        if (n == 0 || r < b[0] || r > b[n - 1]) continue;
+        while (n > 1) { const size_t h = n >> 1; b = b[h] <= r ? b + h : b; n -= h; }   // branch-free lower bound on a short sorted list
+        if (*b == r) return e;
+    }
+    return nullptr;
+}
 
 Node *ContigGraph::create_node(char b) { ++n_nodes_; return nodes_.make(b); }
 Edge *ContigGraph::create_edge(Node *s, Node *t, read_t r)
@@ -203,7 +219,12 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
             }
             advance();
             for (size_t i = 1; i < op.num; ++i) {
-                cur->edge_to(node_in_path)->add_read(id);
+                // cur and node_in_path are consecutive main-path nodes here, and edges are unique per (source, sink)
+                // (update_graph looks before it creates; split_path only adds edges out of fresh nodes), so the edge
+                // getEdgeTo() would find is the main-path edge itself
+                Edge *e = ei >= 1 && ei <= n_path_edges && main_edges[ei - 1]->source == cur && main_edges[ei - 1]->sink == node_in_path
+                              ? main_edges[ei - 1] : cur->edge_to(node_in_path);
+                e->add_read(id);
                 cur = node_in_path;
                 advance();
             }

@@ -763,6 +763,8 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
     }
     NS_HIP(hipEventRecord(c->side_fork, c->stream));
     bool side_used[3] = {false, false, false};
+    size_t n_ev = 0;
+    auto ev_at = [&](size_t i) -> hipEvent_t { while (c->ksw_ev.size() <= i) { hipEvent_t e = nullptr; (void)hipEventCreate(&e); c->ksw_ev.push_back(e); } return c->ksw_ev[i]; };
     for (int k = 2; k >= 0; --k) {
         const uint32_t m = (uint32_t)wg[k].size();
         if (!m) continue;
@@ -771,6 +773,7 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
         double dbg_t0 = 0;
         if (dbg) { NS_HIP(hipStreamSynchronize(c->stream)); dbg_t0 = now_ms(); }
         const uint32_t *ord = c->k_order.as<uint32_t>() + wg_start[k];
+        NS_HIP(hipEventRecord(ev_at(n_ev++), st));
         if (k == 1)
             hipLaunchKernelGGL((ksw_extd2_wg_kernel<256, 5>), dim3(m), dim3(256), kClass[1], st, c->k_tasks.as<KswTask>(), ord, m, pr, c->k_seqs.as<uint8_t>(),
                                c->k_p.as<uint8_t>(), c->k_cig.as<uint32_t>(), c->k_res.as<KswResult>());
@@ -780,6 +783,7 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
                                c->k_p.as<uint8_t>(), c->k_cig.as<uint32_t>(), c->k_res.as<KswResult>());
         }
         NS_HIP(hipGetLastError());
+        NS_HIP(hipEventRecord(ev_at(n_ev++), st));
         ++c->ksw_launches;
         if (dbg) {
             NS_HIP(hipStreamSynchronize(c->stream));
@@ -796,10 +800,12 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
         double dbg_t0 = 0;
         if (dbg) { NS_HIP(hipStreamSynchronize(c->stream)); dbg_t0 = now_ms(); }
         if (kClass[k] > 49152) NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClass[k]));
+        NS_HIP(hipEventRecord(ev_at(n_ev++), st));
         hipLaunchKernelGGL(ksw_extd2_lds_kernel, dim3(m), dim3(64), kClass[k], st, c->k_tasks.as<KswTask>(),
                            c->k_order.as<uint32_t>() + start[k], m, pr, c->k_seqs.as<uint8_t>(), c->k_p.as<uint8_t>(), c->k_cig.as<uint32_t>(),
                            c->k_res.as<KswResult>());
         NS_HIP(hipGetLastError());
+        NS_HIP(hipEventRecord(ev_at(n_ev++), st));
         ++c->ksw_launches;
         if (dbg) {
             NS_HIP(hipStreamSynchronize(c->stream));
@@ -815,10 +821,12 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
         const uint32_t wgs = m < 512u ? m : 512u;
         hbm_stride = (hbm_stride + 255) & ~(size_t)255;
         NS_TRY(c->k_slab.reserve((size_t)wgs * hbm_stride));
+        NS_HIP(hipEventRecord(ev_at(n_ev++), c->side_stream[0]));
         hipLaunchKernelGGL(ksw_extd2_hbm_kernel, dim3(wgs), dim3(64), 0, c->side_stream[0], c->k_tasks.as<KswTask>(), c->k_order.as<uint32_t>() + start[3], m, pr,
                            c->k_seqs.as<uint8_t>(), c->k_p.as<uint8_t>(), c->k_cig.as<uint32_t>(), c->k_res.as<KswResult>(), c->k_slab.as<uint8_t>(),
                            hbm_stride);
         NS_HIP(hipGetLastError());
+        NS_HIP(hipEventRecord(ev_at(n_ev++), c->side_stream[0]));
         ++c->ksw_launches;
     }
     for (int i = 0; i < 3; ++i)
@@ -848,6 +856,7 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
     float ms = 0;
     NS_HIP(hipEventElapsedTime(&ms, c->t_kernel.a, c->t_kernel.b));
     c->ksw_kernel_ms += ms;
+    for (size_t i = 0; i + 1 < n_ev; i += 2) { float d = 0; if (hipEventElapsedTime(&d, c->ksw_ev[i], c->ksw_ev[i + 1]) == hipSuccess) c->ksw_kernel_sum_ms += d; }
     c->ksw_cells += [&] { double s = 0; for (auto &t : tasks) s += (double)t.qlen * t.tlen; return s; }();
     // algorithmic HBM bytes of a DP problem: both sequences in, CIGAR + result out (the traceback matrix is scratch)
     for (size_t i = 0; i < n; ++i) c->ksw_alg_bytes += (double)tasks[i].qlen + tasks[i].tlen + 4.0 * results[i].n_cigar + sizeof(KswResult);
