@@ -129,8 +129,11 @@ def main():
     sk_ms = idx_ms = 0.0
     st = None
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        ts = time.perf_counter()
         st = step()
+        if rank == 0:
+            print("step %d: %.2f s (graph %.1f s, align %.1f s)" % (i, time.perf_counter() - ts, st["graph_ms"] / 1e3, st["align_ms"] / 1e3), file=sys.stderr, flush=True)
         tm = g.timing()
         sk_ms += tm["sketch_kernel_ms"]
         idx_ms += tm["index_ms"]

@@ -67,6 +67,7 @@ public:
         {
             std::lock_guard<std::mutex> lk(m_);
             fn_ = &fn; total_ = n; next_.store(0); pinned_ = pinned;
+            if (pinned) { if (pos_.size() != n_) pos_ = std::vector<std::atomic<size_t>>(n_); for (auto &x : pos_) x.store(0); }
             chunk_ = n / ((size_t)n_ * 8) ? n / ((size_t)n_ * 8) : 1;
             pending_ = (unsigned)th_.size();
             ++gen_;
@@ -80,7 +81,20 @@ public:
 private:
     void work(unsigned me)
     {
-        if (pinned_) { for (size_t i = me; i < total_; i += n_) (*fn_)(i); return; }
+        if (pinned_) {
+            // index i belongs to thread i % n_ (keeps a builder's heap traffic in one malloc arena and its graph in one
+            // core's caches); a thread that runs out of its own items steals from the others
+            for (unsigned k = 0; k < n_; ++k) {
+                const unsigned v = (me + k) % n_;
+                for (;;) {
+                    const size_t j = pos_[v].fetch_add(1, std::memory_order_relaxed);
+                    const size_t i = (size_t)v + j * n_;
+                    if (i >= total_) break;
+                    (*fn_)(i);
+                }
+            }
+            return;
+        }
         for (;;) {
             const size_t b = next_.fetch_add(chunk_);
             if (b >= total_) break;
@@ -110,6 +124,7 @@ private:
     const std::function<void(size_t)> *fn_ = nullptr;
     size_t total_ = 0, chunk_ = 1;
     std::atomic<size_t> next_{0};
+    std::vector<std::atomic<size_t>> pos_;
     unsigned pending_ = 0;
     uint64_t gen_ = 0;
     bool stop_ = false, pinned_ = false;

@@ -27,17 +27,45 @@ using mm2::EditOp;
 // ---------------------------------------------------------------------------
 // pool
 // ---------------------------------------------------------------------------
+namespace {
+struct SlabCache {
+    std::vector<unsigned char *> free;
+    ~SlabCache() { for (unsigned char *p : free) ::free(p); }
+};
+thread_local SlabCache t_slabs;
+constexpr size_t kMaxCachedSlabsPerThread = 16384;      // x 512 KiB = 8 GiB
+}  // namespace
+
+static const bool g_no_slab_cache = getenv("NSGPU_NO_SLAB_CACHE") != nullptr;
+
+unsigned char *slab_acquire(size_t bytes)
+{
+    if (g_no_slab_cache) return static_cast<unsigned char *>(calloc(1, bytes));
+    if (!t_slabs.free.empty()) { unsigned char *p = t_slabs.free.back(); t_slabs.free.pop_back(); return p; }
+    void *p = nullptr;
+    if (posix_memalign(&p, 64, bytes) != 0) throw std::bad_alloc();
+    return static_cast<unsigned char *>(p);
+}
+
+void slab_release(unsigned char *p, size_t)
+{
+    if (g_no_slab_cache) { ::free(p); return; }
+    if (t_slabs.free.size() < kMaxCachedSlabsPerThread) t_slabs.free.push_back(p);
+    else ::free(p);
+}
+
 template <class T> Pool<T>::~Pool()
 {
     // objects still alive own std::vectors: run their destructors
-    std::set<T *> dead(free_.begin(), free_.end());
+    std::sort(free_.begin(), free_.end());
     size_t slab_i = 0;
-    for (auto &slab : slabs_) {
+    for (unsigned char *slab : slabs_) {
         const size_t n = (slab_i + 1 == slabs_.size()) ? used_in_last_ : kPerSlab;
-        T *base = reinterpret_cast<T *>(slab.data());
+        T *base = reinterpret_cast<T *>(slab);
         for (size_t i = 0; i < n; ++i)
-            if (!dead.count(base + i)) (base + i)->~T();
+            if (!std::binary_search(free_.begin(), free_.end(), base + i)) (base + i)->~T();
         ++slab_i;
+        slab_release(slab, kSlabBytes);
     }
 }
 template <class T> template <class... A> T *Pool<T>::make(A &&...a)
@@ -45,8 +73,8 @@ template <class T> template <class... A> T *Pool<T>::make(A &&...a)
     T *p;
     if (!free_.empty()) { p = free_.back(); free_.pop_back(); }
     else {
-        if (slabs_.empty() || used_in_last_ == kPerSlab) { slabs_.emplace_back(sizeof(T) * kPerSlab + alignof(T)); used_in_last_ = 0; }
-        p = reinterpret_cast<T *>(slabs_.back().data()) + used_in_last_++;
+        if (slabs_.empty() || used_in_last_ == kPerSlab) { slabs_.push_back(slab_acquire(kSlabBytes)); used_in_last_ = 0; }
+        p = reinterpret_cast<T *>(slabs_.back()) + used_in_last_++;
     }
     ++live;
     return new (p) T(std::forward<A>(a)...);

@@ -50,11 +50,17 @@ public:
     void free(T *p);
     size_t live = 0;
 private:
-    std::deque<std::vector<unsigned char>> slabs_;
+    std::vector<unsigned char *> slabs_;      // fixed-size slabs, recycled through a per-thread cache (SlabCache)
     std::vector<T *> free_;
     size_t used_in_last_ = 0;
-    static constexpr size_t kPerSlab = 4096;
+    static constexpr size_t kSlabBytes = 512 * 1024;
+    static constexpr size_t kPerSlab = kSlabBytes / sizeof(T);
 };
+
+// Slabs of finished graphs are kept per host thread and handed to the next graph built on that thread (contig
+// builders are pinned to threads): no mmap/munmap and no first-touch page faults per contig.
+unsigned char *slab_acquire(size_t bytes);
+void slab_release(unsigned char *p, size_t bytes);
 
 // The seven per-"thread" streams (ConsensusGraphWriter, src/ConsensusGraph.cpp:118-133).  .id keeps
 // the contig part (4-byte LE deltas, restarting at 0 per contig) apart from the lone-read ids, which
