@@ -163,6 +163,14 @@ def main():
         dp_ms = a["dp_kernel_sum_ms"] / launches          # mean duration of one ksw_extd2 launch (launches of a batch overlap on streams)
         alg = a.get("dp_alg_bytes", 0.0) / launches
         achieved = alg / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
+        # HBM traffic of the same kernel: PMC counters cannot be read from inside this process; the committed figure
+        # comes from rocprofv3 --pmc passes over this very command (profiles/r01_pmc_ksw_traffic.json) and is only
+        # reported for the workload it was measured on.
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_ksw_traffic.json")
+        if os.path.exists(pmc) and args.reads == 100000 and args.builders == 1024 and world == 1:
+            pj = json.load(open(pmc))
+            traffic, traffic_src = round(pj["traffic_bytes_per_launch"]), "profiles/r01_pmc_ksw_traffic.json (2*FETCH_SIZE + WRITE_SIZE per launch; traceback scratch dominates)"
         out = {
             "metric": "Mbases/sec sketch+overlap+align, 8kb ONT reads",
             "value": round(total_bases * steps / 1e6 / dt, 2),
@@ -187,7 +195,7 @@ def main():
                                        f"{st.get('n_collectives', 0)} small all-gathers of claim lists (global builder order)") if exchange
                        else f"reads sharded by id x{world}, no collective"},
             "roofline": {"kernel": "ksw_extd2 (ksw_extd2_lds_kernel + ksw_extd2_wg_kernel<256,*>)", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": traffic, "traffic_source": traffic_src,
                          "launches": int(a["dp_launches"]), "avg_launch_ms": round(dp_ms, 3),
                          "note": "integer DP, LDS/ALU bound by construction: %.1f GCUPS over %.3g cells" % (
                              a["dp_cells"] / (a["dp_kernel_ms"] * 1e-3) / 1e9 if a["dp_kernel_ms"] else 0, a["dp_cells"]) +
