@@ -184,6 +184,7 @@ typedef struct {
     uint64_t count_minhash, count_minhash_not_in_graph, count_aligner, n_align_calls;   /* CountStats, include/Consensus.h:19-35 */
     double total_ms, graph_ms, filter_ms, index_ms, align_ms;   /* wall per phase */
     double graph_cpu_ms, graph_max_ms;                          /* summed / longest single builder step in the graph phase */
+    double graph_crit_ms, write_cpu_ms;                         /* sum over phases of the slowest builder step / CPU time in contig finalisation */
 } nsgpu_consensus_stats;
 /* Multi-GPU shards: global id of this context's read 0; the .id streams then carry global read ids so that the
  * stream sets of all shards can sit side by side as additional "threads" of one archive (default 0). */

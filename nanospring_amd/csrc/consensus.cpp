@@ -56,17 +56,8 @@ void slab_release(unsigned char *p, size_t)
 
 template <class T> Pool<T>::~Pool()
 {
-    // objects still alive own std::vectors: run their destructors
-    std::sort(free_.begin(), free_.end());
-    size_t slab_i = 0;
-    for (unsigned char *slab : slabs_) {
-        const size_t n = (slab_i + 1 == slabs_.size()) ? used_in_last_ : kPerSlab;
-        T *base = reinterpret_cast<T *>(slab);
-        for (size_t i = 0; i < n; ++i)
-            if (!std::binary_search(free_.begin(), free_.end(), base + i)) (base + i)->~T();
-        ++slab_i;
-        slab_release(slab, kSlabBytes);
-    }
+    // the objects own nothing outside the graph's Arena: only the slabs go back
+    for (unsigned char *slab : slabs_) slab_release(slab, kSlabBytes);
 }
 template <class T> template <class... A> T *Pool<T>::make(A &&...a)
 {
@@ -79,14 +70,50 @@ template <class T> template <class... A> T *Pool<T>::make(A &&...a)
     ++live;
     return new (p) T(std::forward<A>(a)...);
 }
-template <class T> void Pool<T>::free(T *p) { p->~T(); free_.push_back(p); --live; }
+template <class T> void Pool<T>::free(T *p) { free_.push_back(p); --live; }
 template class Pool<Node>;
 template class Pool<Edge>;
+
+Arena::~Arena()
+{
+    for (unsigned char *slab : slabs_) slab_release(slab, kSlabBytes);
+    for (void *p : big_) ::free(p);
+}
+void *Arena::alloc(unsigned cls)
+{
+    const size_t bytes = (size_t)32 << cls;
+    if (cls >= kClasses) {
+        void *p = malloc(bytes);
+        if (!p) throw std::bad_alloc();
+        big_.push_back(p);
+        return p;
+    }
+    if (void *p = free_[cls]) { memcpy(&free_[cls], p, sizeof(void *)); return p; }
+    if (used_ + bytes > kSlabBytes) {
+        // the unused rest of the slab is wasted (at most one block of the largest class per slab)
+        slabs_.push_back(slab_acquire(kSlabBytes));
+        used_ = 0;
+    }
+    void *p = slabs_.back() + used_;
+    used_ += bytes;
+    return p;
+}
+void Arena::release(void *p, unsigned cls)
+{
+    if (cls >= kClasses) {
+        auto it = std::find(big_.begin(), big_.end(), p);
+        if (it != big_.end()) { *it = big_.back(); big_.pop_back(); }
+        ::free(p);
+        return;
+    }
+    memcpy(p, &free_[cls], sizeof(void *));
+    free_[cls] = p;
+}
 
 // ---------------------------------------------------------------------------
 // nodes and edges
 // ---------------------------------------------------------------------------
-void Edge::add_read(read_t r) { ++count; reads.insert(std::lower_bound(reads.begin(), reads.end(), r), r); }
+void Edge::add_read(Arena &a, read_t r) { ++count; reads.insert_at(a, (size_t)(std::lower_bound(reads.begin(), reads.end(), r) - reads.begin()), r); }
 
 Edge *Node::edge_to(Node *n) const { for (Edge *e : out) if (e->sink == n) return e; return nullptr; }
 Edge *Node::edge_to_side(char b) const { for (Edge *e : out) if (!e->sink->on_main && e->sink->base == b) return e; return nullptr; }
@@ -114,9 +141,9 @@ Node *ContigGraph::create_node(char b) { ++n_nodes_; return nodes_.make(b); }
 Edge *ContigGraph::create_edge(Node *s, Node *t, read_t r)
 {
     Edge *e = edges_.make();
-    e->source = s, e->sink = t, e->count = 1, e->reads.push_back(r);
+    e->source = s, e->sink = t, e->count = 1, e->reads.push_back(arena_, r);
     n_multi_in_side_ -= multi_in_side(t);
-    s->out.push_back(e), t->in.push_back(e);
+    s->out.push_back(arena_, e), t->in.push_back(arena_, e);
     n_multi_in_side_ += multi_in_side(t);
     ++n_edges_;
     return e;
@@ -124,9 +151,9 @@ Edge *ContigGraph::create_edge(Node *s, Node *t, read_t r)
 Edge *ContigGraph::create_edge(Node *s, Node *t, const std::vector<read_t> &rs)
 {
     Edge *e = edges_.make();
-    e->source = s, e->sink = t, e->reads = rs, e->count = (read_t)rs.size();
+    e->source = s, e->sink = t, e->reads.assign(arena_, rs.data(), rs.size()), e->count = (read_t)rs.size();
     n_multi_in_side_ -= multi_in_side(t);
-    s->out.push_back(e), t->in.push_back(e);
+    s->out.push_back(arena_, e), t->in.push_back(arena_, e);
     n_multi_in_side_ += multi_in_side(t);
     ++n_edges_;
     return e;
@@ -136,14 +163,15 @@ void ContigGraph::remove_edge(Edge *e, bool keep_in_source, bool keep_in_sink)
 {
     if (!keep_in_source) {
         auto &v = e->source->out;
-        v.erase(std::find_if(v.begin(), v.end(), [&](const Edge *p) { return p->sink == e->sink; }));
+        v.erase_at((size_t)(std::find_if(v.begin(), v.end(), [&](const Edge *p) { return p->sink == e->sink; }) - v.begin()));
     }
     if (!keep_in_sink) {
         auto &v = e->sink->in;
         n_multi_in_side_ -= multi_in_side(e->sink);
-        v.erase(std::find(v.begin(), v.end(), e));
+        v.erase_at((size_t)(std::find(v.begin(), v.end(), e) - v.begin()));
         n_multi_in_side_ += multi_in_side(e->sink);
     }
+    e->reads.release(arena_);
     edges_.free(e);
     --n_edges_;
 }
@@ -151,16 +179,17 @@ void ContigGraph::remove_node(Node *n)
 {
     n_multi_in_side_ -= multi_in_side(n);
     n->on_main = true;      // keeps the counter untouched while the node's edges go away
-    for (Edge *e : std::vector<Edge *>(n->in)) remove_edge(e, false, true);
-    for (Edge *e : std::vector<Edge *>(n->out)) remove_edge(e, true, false);
+    for (Edge *e : std::vector<Edge *>(n->in.begin(), n->in.end())) remove_edge(e, false, true);
+    for (Edge *e : std::vector<Edge *>(n->out.begin(), n->out.end())) remove_edge(e, true, false);
+    n->in.release(arena_), n->out.release(arena_);
     nodes_.free(n);
     --n_nodes_;
 }
 void ContigGraph::remove_reads_from_edge(Edge *e, const std::vector<read_t> &rs)
 {
-    std::vector<read_t> left;
-    std::set_difference(e->reads.begin(), e->reads.end(), rs.begin(), rs.end(), std::back_inserter(left));
-    e->reads.swap(left);
+    // in place: the output never overtakes the input of a set difference
+    read_t *w = std::set_difference(e->reads.begin(), e->reads.end(), rs.begin(), rs.end(), e->reads.begin());
+    e->reads.n = (uint32_t)(w - e->reads.begin());
     e->count = (read_t)e->reads.size();
     if (e->count == 0) remove_edge(e);
 }
@@ -231,7 +260,7 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
             initial = cur;
         } else {
             Edge *e = cur->edge_to_side(base);
-            if (e) e->add_read(id);
+            if (e) e->add_read(arena_, id);
             else e = create_edge(cur, create_node(base), id);
             cur = e->sink;
         }
@@ -241,7 +270,7 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
             if (!cur) initial = cur = node_in_path;
             else {
                 Edge *e = cur->edge_to(node_in_path);
-                if (e) e->add_read(id);
+                if (e) e->add_read(arena_, id);
                 else e = create_edge(cur, node_in_path, id);
                 cur = node_in_path;
             }
@@ -252,7 +281,7 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
                 // getEdgeTo() would find is the main-path edge itself
                 Edge *e = ei >= 1 && ei <= n_path_edges && main_edges[ei - 1]->source == cur && main_edges[ei - 1]->sink == node_in_path
                               ? main_edges[ei - 1] : cur->edge_to(node_in_path);
-                e->add_read(id);
+                e->add_read(arena_, id);
                 cur = node_in_path;
                 advance();
             }
@@ -393,7 +422,7 @@ void ContigGraph::remove_cycles()
             bool side = false;
             for (Edge *e : n->out) if (!e->sink->on_main) { side = true; break; }
             if (side) {
-                copy = n->out;
+                copy.assign(n->out.begin(), n->out.end());
                 for (Edge *e : copy) walk_and_prune(e, stack);
             }
             if (ei == end) break;
@@ -409,7 +438,7 @@ void ContigGraph::remove_cycles()
             bool side = false;
             for (Edge *e : n->out) if (!e->sink->on_main) { side = true; break; }
             if (side) {
-                copy = n->out;
+                copy.assign(n->out.begin(), n->out.end());
                 for (Edge *e : copy) walk_and_prune(e, stack);
             }
             if (ei == 0) break;
@@ -426,7 +455,7 @@ void ContigGraph::walk_and_prune(Edge *e, std::vector<Edge *> &stack)
         stack.pop_back();
         Node *sink = curr->sink, *source = curr->source;
         if (sink->on_main) continue;
-        if (sink->in.size() > 1) split_path(source, curr, curr->reads);
+        if (sink->in.size() > 1) split_path(source, curr, std::vector<read_t>(curr->reads.begin(), curr->reads.end()));
         for (Edge *o : sink->out) stack.push_back(o);
     }
 }
@@ -445,7 +474,7 @@ void ContigGraph::split_path(Node *new_pre0, Edge *e0, const std::vector<read_t>
         Node *old_cur = nullptr;
     };
     std::deque<Ctx> st;                               // deque: stable addresses while children are pushed
-    const std::vector<read_t> first_copy = reads0;    // e0->reads dies with e0 during the first visit
+    const std::vector<read_t> &first_copy = reads0;   // a copy owned by the caller: e0->reads dies with e0 during the first visit
     st.push_back(Ctx{new_pre0, e0, &first_copy, {}, false, nullptr});
     while (!st.empty()) {
         Ctx &c = st.back();
@@ -465,7 +494,7 @@ void ContigGraph::split_path(Node *new_pre0, Edge *e0, const std::vector<read_t>
         Node *new_cur = create_node(old_cur->base);
         create_edge(c.new_pre, new_cur, c.own);
         const std::vector<read_t> *mine = &c.own;
-        const std::vector<Edge *> outs = old_cur->out;
+        const std::vector<Edge *> outs(old_cur->out.begin(), old_cur->out.end());
         for (Edge *o : outs) st.push_back(Ctx{new_cur, o, mine, {}, false, nullptr});
     }
 }
@@ -503,29 +532,57 @@ size_t optimize_edit_script(const std::vector<EditOp> &in, std::vector<EditOp> &
     return dis;
 }
 
-size_t ContigGraph::read_to_edits(const GraphRead &r, read_t id, std::vector<EditOp> &script, uint32_t &pos) const
+// The nodes a read threads, in order.  Without a base source this is the reference's walk (the out-edge whose read
+// list holds the id, Node::getNextNodeInRead).  With the read's own bases at hand the walk is guided by them: a node
+// with one out-edge needs no test at all, and among several out-edges the one whose sink carries the read's next base
+// is the read's edge whenever it is the only such edge -- the list lookup is only needed to break ties.
+void ContigGraph::collect_path(const GraphRead &r, read_t id, const ReadBases *src, std::vector<const Node *> &path) const
+{
+    path.clear();
+    path.reserve(r.len);
+    const Node *cur = r.start;
+    if (!src) {
+        while (cur) { path.push_back(cur); const Edge *e = cur->edge_in_read(id); cur = e ? e->sink : nullptr; }
+        return;
+    }
+    const char *fw = src->bases;
+    const size_t L = src->len;
+    auto base_at = [&](size_t i) -> char {
+        if (!r.rc) return fw[i];
+        const char c = fw[L - 1 - i];
+        return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
+    };
+    for (size_t i = 0; i < L; ++i) {
+        path.push_back(cur);
+        if (i + 1 == L) break;
+        const auto &out = cur->out;
+        if (out.size() == 1) { cur = out[0]->sink; continue; }
+        const char nb = base_at(i + 1);
+        const Edge *pick = nullptr;
+        int cnt = 0;
+        for (const Edge *e : out) if (e->sink->base == nb) { pick = e; ++cnt; }
+        if (cnt != 1) pick = cur->edge_in_read(id);
+        cur = pick->sink;
+    }
+}
+
+size_t ContigGraph::read_to_edits(const GraphRead &r, read_t id, const ReadBases *src, std::vector<EditOp> &script, uint32_t &pos) const
 {
     script.clear();
     script.reserve(r.len / 8 + 16);
-    auto next = [&](const Node *n) -> Node * { Edge *e = n->edge_in_read(id); return e ? e->sink : nullptr; };
-    Node *cur = r.start;
-    bool meets = true;
-    while (!cur->on_main) {
-        cur = next(cur);
-        if (!cur) { meets = false; break; }
-    }
-    if (!meets) {                                    // never touches the consensus: all inserts
+    static thread_local std::vector<const Node *> path;
+    collect_path(r, id, src, path);
+    size_t first_main = 0;
+    while (first_main < path.size() && !path[first_main]->on_main) ++first_main;
+    if (first_main == path.size()) {                 // never touches the consensus: all inserts
         pos = 0;
-        size_t dis = 0;
-        Node *c = r.start;
-        do { script.push_back(EditOp{1, (uint8_t)c->base, 0}); ++dis; } while ((c = next(c)));
-        return dis;
+        for (const Node *c : path) script.push_back(EditOp{1, (uint8_t)c->base, 0});
+        return path.size();
     }
-    pos = (uint32_t)cur->cum_weight;
-    size_t dis = 0, at = cur->cum_weight, same = 0;
+    pos = (uint32_t)path[first_main]->cum_weight;
+    size_t dis = 0, at = path[first_main]->cum_weight, same = 0;
     auto flush = [&]() { if (same > 0) { script.push_back(EditOp{0, 0, (uint32_t)same}); same = 0; } };
-    cur = r.start;
-    do {
+    for (const Node *cur : path) {
         if (cur->on_main) {
             const size_t p = cur->cum_weight;
             if (p > at) flush();
@@ -537,16 +594,16 @@ size_t ContigGraph::read_to_edits(const GraphRead &r, read_t id, std::vector<Edi
             script.push_back(EditOp{1, (uint8_t)cur->base, 0});
             ++dis;
         }
-    } while ((cur = next(cur)));
+    }
     flush();
     return dis;
 }
 
-size_t ContigGraph::write_read(StreamSet &o, const GraphRead &r, read_t id) const
+size_t ContigGraph::write_read(StreamSet &o, const GraphRead &r, read_t id, const ReadBases *src) const
 {
     uint32_t offset;
-    std::vector<EditOp> raw, es;
-    read_to_edits(r, id, raw, offset);
+    static thread_local std::vector<EditOp> raw, es;
+    read_to_edits(r, id, src, raw, offset);
     write_var_uint32(offset, o.pos);
     const size_t dis = optimize_edit_script(raw, es);
     uint32_t ins_start = 0, ins_end = 0;
@@ -580,7 +637,7 @@ size_t ContigGraph::write_read(StreamSet &o, const GraphRead &r, read_t id) cons
 void ContigGraph::write_main_path(StreamSet &o) const { o.genome += main_path; o.genome.push_back('\n'); }
 void ContigGraph::write_read_lone(StreamSet &o) const { o.lone += main_path; o.lone.push_back('\n'); }
 
-void ContigGraph::write_reads(StreamSet &o)
+void ContigGraph::write_reads(StreamSet &o, const std::function<ReadBases(read_t)> *source)
 {
     main_edges.front()->source->cum_weight = 0;
     size_t i = 0;
@@ -591,7 +648,8 @@ void ContigGraph::write_reads(StreamSet &o)
         o.id_contigs.append(reinterpret_cast<const char *>(&diff), 4);     // 4 bytes: std::ios::binary == 4 is passed as the count (:998)
         o.complement.push_back(it.second.rc ? 'c' : 'n');
         prev = it.first;
-        write_read(o, it.second, it.first);
+        if (source) { const ReadBases rb = (*source)(it.first); write_read(o, it.second, it.first, &rb); }
+        else write_read(o, it.second, it.first, nullptr);
     }
     o.complement.push_back('\n');
 }

@@ -10,7 +10,9 @@
 #pragma once
 #include <cstdint>
 #include <cstddef>
+#include <cstring>
 #include <deque>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -21,12 +23,80 @@ namespace cons {
 
 typedef uint32_t read_t;
 
+unsigned char *slab_acquire(size_t bytes);
+void slab_release(unsigned char *p, size_t bytes);
+constexpr size_t kSlabBytes = 512 * 1024;
+
+// Per-graph bump allocator for the overflow storage of the small vectors below: power-of-two blocks (32 B << cls)
+// carved out of recycled slabs, with one free list per class.  Nothing is freed one by one when a graph dies -- the
+// slabs go back to the thread's slab cache.
+class Arena {
+public:
+    Arena() = default;
+    Arena(const Arena &) = delete;
+    ~Arena();
+    void *alloc(unsigned cls);
+    void release(void *p, unsigned cls);
+private:
+    static constexpr unsigned kClasses = 13;   // 32 B .. 128 KiB from slabs; larger blocks come from malloc
+    void *free_[kClasses] = {};
+    std::vector<unsigned char *> slabs_;
+    size_t used_ = kSlabBytes;
+    std::vector<void *> big_;
+};
+
+// Vector with N inline slots (a graph node has one or two edges each way, a side edge carries one read): no heap
+// block, no extra cache line in the common case.  sizeof == 8 + N * sizeof(T); growth doubles into the graph's Arena.
+template <class T, unsigned N>
+struct SmallVec {
+    static_assert(sizeof(T) * N >= sizeof(T *) && (sizeof(T) * N * 2) % 32 == 0 && ((sizeof(T) * N * 2 / 32) & (sizeof(T) * N * 2 / 32 - 1)) == 0,
+                  "overflow blocks must be 32 B << cls");
+    uint32_t n = 0, cap = N;
+    union { T inl[N]; T *heap; };
+    SmallVec() {}
+    SmallVec(const SmallVec &) = delete;
+    SmallVec &operator=(const SmallVec &) = delete;
+    T *data() { return cap == N ? inl : heap; }
+    const T *data() const { return cap == N ? inl : heap; }
+    T *begin() { return data(); }
+    T *end() { return data() + n; }
+    const T *begin() const { return data(); }
+    const T *end() const { return data() + n; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T &operator[](size_t i) { return data()[i]; }
+    const T &operator[](size_t i) const { return data()[i]; }
+    static unsigned cls_of(uint32_t c) { unsigned k = 0; for (size_t b = sizeof(T) * c / 32; b > 1; b >>= 1) ++k; return k; }
+    void reserve(Arena &a, size_t want)
+    {
+        if (want <= cap) return;
+        uint32_t nc = cap;
+        while (nc < want) nc *= 2;
+        T *nb = static_cast<T *>(a.alloc(cls_of(nc)));
+        memcpy(nb, data(), n * sizeof(T));
+        if (cap != N) a.release(heap, cls_of(cap));
+        heap = nb, cap = nc;
+    }
+    void push_back(Arena &a, const T &v) { if (n == cap) reserve(a, n + 1); data()[n++] = v; }
+    void insert_at(Arena &a, size_t i, const T &v)
+    {
+        if (n == cap) reserve(a, n + 1);
+        T *d = data();
+        memmove(d + i + 1, d + i, (n - i) * sizeof(T));
+        d[i] = v;
+        ++n;
+    }
+    void erase_at(size_t i) { T *d = data(); memmove(d + i, d + i + 1, (n - i - 1) * sizeof(T)); --n; }
+    void assign(Arena &a, const T *p, size_t cnt) { n = 0; reserve(a, cnt); memcpy(data(), p, cnt * sizeof(T)); n = (uint32_t)cnt; }
+    void release(Arena &a) { if (cap != N) { a.release(heap, cls_of(cap)); cap = N; } n = 0; }
+};
+
 struct Edge;
-struct Node {
+struct Node {                                 // 64 bytes, slab-aligned: one cache line
     char base;
     bool on_main = false;
     uint32_t mark = 0;                        // scratch: old main-path index while a tail is being re-used
-    std::vector<Edge *> out, in;
+    SmallVec<Edge *, 2> out, in;
     size_t cum_weight = 0;
     explicit Node(char b) : base(b) {}
     Edge *edge_to(Node *n) const;             // Node::getEdgeTo          (:33-43)
@@ -35,12 +105,13 @@ struct Node {
     Edge *best_in() const;                    // Node::getBestEdgeIn      (:69-81)
     Edge *edge_in_read(read_t r) const;       // Node::getEdgeInRead      (:83-91)
 };
-struct Edge {
+struct Edge {                                 // 64 bytes
     Node *source, *sink;
     read_t count;
-    std::vector<read_t> reads;                // ascending
-    void add_read(read_t r);                  // Edge::addRead            (:24-28)
+    SmallVec<read_t, 8> reads;                // ascending
+    void add_read(Arena &a, read_t r);        // Edge::addRead            (:24-28)
 };
+static_assert(sizeof(Node) == 64 && sizeof(Edge) == 64, "graph objects are one cache line each");
 
 template <class T>
 class Pool {                                   // slab allocator with a free list; everything dies with the graph
@@ -53,14 +124,11 @@ private:
     std::vector<unsigned char *> slabs_;      // fixed-size slabs, recycled through a per-thread cache (SlabCache)
     std::vector<T *> free_;
     size_t used_in_last_ = 0;
-    static constexpr size_t kSlabBytes = 512 * 1024;
     static constexpr size_t kPerSlab = kSlabBytes / sizeof(T);
 };
 
 // Slabs of finished graphs are kept per host thread and handed to the next graph built on that thread (contig
 // builders are pinned to threads): no mmap/munmap and no first-touch page faults per contig.
-unsigned char *slab_acquire(size_t bytes);
-void slab_release(unsigned char *p, size_t bytes);
 
 // The seven per-"thread" streams (ConsensusGraphWriter, src/ConsensusGraph.cpp:118-133).  .id keeps
 // the contig part (4-byte LE deltas, restarting at 0 per contig) apart from the lone-read ids, which
@@ -76,6 +144,7 @@ struct StreamSet {
 void write_var_uint32(uint32_t v, std::string &out);   // src/DirectoryUtils.cpp:18-28
 
 struct GraphRead { long pos; Node *start; size_t len; bool rc; };
+struct ReadBases { const char *bases; size_t len; };   // a read as stored (forward orientation)
 
 class ContigGraph {
 public:
@@ -95,7 +164,9 @@ public:
     size_t num_edges() const { return n_edges_; }
     size_t num_nodes() const { return n_nodes_; }
     void write_main_path(StreamSet &o) const;                                               // :979-982
-    void write_reads(StreamSet &o);                                                         // :984-1012
+    // :984-1012; `source` (optional) hands out the stored bases of a read id: emission then walks each read guided by
+    // its own bases instead of searching edge read lists (same result, see collect_path)
+    void write_reads(StreamSet &o, const std::function<ReadBases(read_t)> *source = nullptr);
     void write_read_lone(StreamSet &o) const;                                               // :1014-1016
     // checker used by the tests (Consensus::checkRead, src/Consensus.cpp:342-368)
     bool read_string(read_t id, std::string &out) const;
@@ -120,6 +191,7 @@ private:
 public:
     uint64_t dbg_cycles_calls = 0, dbg_cycles_skipped = 0, dbg_spliced = 0, dbg_spliced_nodes = 0;
 private:
+    Arena arena_;
     Pool<Node> nodes_;
     Pool<Edge> edges_;
     Node *create_node(char b);
@@ -132,8 +204,9 @@ private:
     void remove_cycles();                                                                   // :653-691
     void walk_and_prune(Edge *e, std::vector<Edge *> &stack);                               // :693-714
     void split_path(Node *new_pre, Edge *e, const std::vector<read_t> &reads2split);        // :716-807
-    size_t read_to_edits(const GraphRead &r, read_t id, std::vector<mm2::EditOp> &script, uint32_t &pos) const;   // :1031-1096
-    size_t write_read(StreamSet &o, const GraphRead &r, read_t id) const;                   // :1098-1178
+    void collect_path(const GraphRead &r, read_t id, const ReadBases *src, std::vector<const Node *> &path) const;
+    size_t read_to_edits(const GraphRead &r, read_t id, const ReadBases *src, std::vector<mm2::EditOp> &script, uint32_t &pos) const;   // :1031-1096
+    size_t write_read(StreamSet &o, const GraphRead &r, read_t id, const ReadBases *src) const;   // :1098-1178
 };
 
 // Edit::optimizeEditScript (src/Edits.cpp:23-60): types 0 SAME 1 INSERT 2 DELETE 3 SUBSTITUTION

@@ -48,7 +48,7 @@ struct Builder {
     bool idx_valid = false;
     cons::StreamSet out;
     uint64_t n_minhash = 0, n_minhash_new = 0, n_aligner = 0, n_align_calls = 0, n_contigs = 0, n_lone = 0;
-    double cpu_ms = 0, max_ms = 0;
+    double cpu_ms = 0, max_ms = 0, last_ms = 0, write_ms = 0, dbg_w1 = 0, dbg_w2 = 0, dbg_w3 = 0, dbg_u = 0, dbg_m = 0;
 };
 
 struct Driver {
@@ -81,6 +81,12 @@ struct Driver {
 
     void finish_contig(Builder &b)
     {
+        const double tw = now_ms();
+        finish_contig_inner(b);
+        b.write_ms += now_ms() - tw;
+    }
+    void finish_contig_inner(Builder &b)
+    {
         cons::ContigGraph &g = *b.g;
         if (g.num_reads() == 0) {
             g.write_read_lone(b.out);
@@ -88,12 +94,22 @@ struct Driver {
             b.out.reads_in_contig.push_back(1);
             ++b.n_lone;
         } else {
+            const double t0 = now_ms();
             g.write_main_path(b.out);
-            g.write_reads(b.out);
+            const std::function<cons::ReadBases(cons::read_t)> src = [this](cons::read_t id) {
+                const read_t r = id - id_base;
+                return cons::ReadBases{read_ptr(r), read_len(r)};
+            };
+            const double t1 = now_ms();
+            g.write_reads(b.out, &src);
+            const double t2 = now_ms();
+            b.dbg_w1 += t1 - t0, b.dbg_w2 += t2 - t1;
             b.out.reads_in_contig.push_back((read_t)g.num_reads());
         }
         ++b.n_contigs;
+        const double t3 = now_ms();
         b.g.reset();
+        b.dbg_w3 += now_ms() - t3;
         b.st = Builder::NEED_CONTIG;
     }
 
@@ -174,6 +190,7 @@ struct Driver {
         advance_inner(b);
         const double dt = now_ms() - t0;
         b.cpu_ms += dt;
+        b.last_ms = dt;
         if (dt > b.max_ms) b.max_ms = dt;
     }
     void advance_inner(Builder &b)
@@ -189,8 +206,11 @@ struct Driver {
                     g.initialize(seed, g.first_read, 0);
                     g.calculate_main_path_greedy();
                 }
+                const double u0 = now_ms();
                 g.update_graph(b.query, b.aln.edits, (ssize_t)b.aln.begin_offset, (ssize_t)b.aln.end_offset, b.pend + id_base, (long)b.aln.rel_pos, b.strand == 1);
+                const double u1 = now_ms();
                 g.calculate_main_path_greedy();
+                b.dbg_u += u1 - u0, b.dbg_m += now_ms() - u1;
                 b.idx_valid = false;
                 b.accepted = false;
             }
@@ -265,6 +285,9 @@ static void engine_advance(nsgpu_ctx *c, bool only_fresh)
     if (only_fresh) par_for_pinned(D.B.size(), [&](size_t i) { if (D.B[i].st == Builder::ADVANCE) D.advance(D.B[i]); });
     else par_for_pinned(D.B.size(), [&](size_t i) { D.advance(D.B[i]); });
     c->cons_stats.graph_ms += now_ms() - a0;
+    double mx = 0;
+    for (Builder &b : D.B) { if (b.last_ms > mx) mx = b.last_ms; b.last_ms = 0; }
+    c->cons_stats.graph_crit_ms += mx;       // sum over phases of the slowest builder step: the floor of the phase wall
 }
 
 // phase 2: (gid, cursor) of every local builder that needs a new contig
@@ -395,11 +418,16 @@ static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
     // file sets, src/Compressor.cpp:123-124; Decompressor reads numThr from metaData)
     c->cons_out.assign(n_threads_out, cons::StreamSet());
     for (size_t i = 0; i < D.B.size(); ++i) c->cons_out[i * n_threads_out / (D.B.empty() ? 1 : D.B.size())].append(D.B[i].out);
+    double dbg_w[5] = {0, 0, 0, 0, 0};
     for (Builder &b : D.B) {
         S.n_contigs += b.n_contigs; S.n_lone += b.n_lone; S.count_minhash += b.n_minhash; S.count_minhash_not_in_graph += b.n_minhash_new;
         S.count_aligner += b.n_aligner; S.n_align_calls += b.n_align_calls;
         S.graph_cpu_ms += b.cpu_ms; if (b.max_ms > S.graph_max_ms) S.graph_max_ms = b.max_ms;
+        S.write_cpu_ms += b.write_ms;
+        dbg_w[0] += b.dbg_w1, dbg_w[1] += b.dbg_w2, dbg_w[2] += b.dbg_w3, dbg_w[3] += b.dbg_u, dbg_w[4] += b.dbg_m;
     }
+    if (getenv("NSGPU_CONS_DEBUG"))
+        fprintf(stderr, "[cons] cpu-ms: update_graph %.0f main_path %.0f write_main %.0f write_reads %.0f graph_free %.0f\n", dbg_w[3], dbg_w[4], dbg_w[0], dbg_w[1], dbg_w[2]);
     S.total_ms = now_ms() - E->t0;
     c->cons_n_reads_out = 0;
     for (auto &t : c->cons_out) for (read_t x : t.reads_in_contig) c->cons_n_reads_out += x;

@@ -322,7 +322,7 @@ class ConsensusStats(C.Structure):
     _fields_ = [("n_builders", C.c_uint32), ("reserved", C.c_uint32)] + \
                [(n, C.c_uint64) for n in ("n_rounds", "n_filter_rounds", "n_align_rounds", "n_windows", "n_contigs", "n_lone", "count_minhash",
                                           "count_minhash_not_in_graph", "count_aligner", "n_align_calls")] + \
-               [(n, C.c_double) for n in ("total_ms", "graph_ms", "filter_ms", "index_ms", "align_ms", "graph_cpu_ms", "graph_max_ms")]
+               [(n, C.c_double) for n in ("total_ms", "graph_ms", "filter_ms", "index_ms", "align_ms", "graph_cpu_ms", "graph_max_ms", "graph_crit_ms", "write_cpu_ms")]
 
 
 STREAMS = ["genome", "lone", "id", "pos", "type", "base", "complement"]
