@@ -158,6 +158,8 @@ int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::A
 {
     using namespace mm2;
     const size_t n_pairs = reqs.size();
+    static const bool dbg_t = getenv("NSGPU_ALIGN_DEBUG") != nullptr;
+    const double d0 = now_ms();
     outs.assign(n_pairs, AlnOut());
     if (n_pairs == 0) return NSGPU_OK;
     Opt opt;
@@ -173,6 +175,8 @@ int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::A
     std::vector<KswResult> res;
     std::vector<uint32_t> cig;
     std::vector<uint64_t> coff;
+    const double d1 = now_ms();
+    double d_serial = 0;
     for (int round = 0; !live.empty(); ++round) {
         NS_CHECK(round < 64, NSGPU_ERR_ARG, "align: no convergence after 64 DP rounds (internal error)");
         double a0 = now_ms();
@@ -191,6 +195,7 @@ int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::A
             for (const DpKey &k : J.cache.missing) nb += (size_t)(k.qe - k.qs) + (size_t)(k.re - k.rs);
         }
         live.swap(still);
+        d_serial += now_ms() - a1;
         if (live.empty()) break;
         NS_CHECK(nb < (1ull << 32), NSGPU_ERR_RANGE, "align: DP sequence pool exceeds 4 GiB; use smaller batches");
         tasks.resize(nt);
@@ -238,6 +243,9 @@ int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::A
     parallel_for(n_pairs, [&](size_t i) { align_read_result(jobs[i], reqs[i].ref, reqs[i].ref_len, outs[i]); });
     c->aln_host_ms += now_ms() - b0;
     c->aln_pairs += n_pairs;
+    const double d2 = now_ms();
+    parallel_for(n_pairs, [&](size_t i) { AlignJob().swap_storage(jobs[i]); });      // free the jobs' heap blocks on all threads
+    if (dbg_t) fprintf(stderr, "[align] pairs %zu setup %.2f serial-in-rounds %.2f result %.2f free %.2f ms\n", n_pairs, d1 - d0, d_serial, d2 - b0, now_ms() - d2);
     return NSGPU_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <cstdio>
+#include <chrono>
 #include <iterator>
 #include <new>
 #include <set>
@@ -354,6 +355,7 @@ void ContigGraph::calculate_main_path_greedy()
             }
             cur = nx;
             set_on_main(cur, true);
+            ++dbg_walked_nodes;
         }
         if (!joined) for (Edge *se : saved) set_on_main(se->sink, false);
         const read_t ending = *main_edges.back()->reads.begin();
@@ -371,6 +373,7 @@ void ContigGraph::calculate_main_path_greedy()
             cur = e->sink;
             set_on_main(cur, true);
             main_path.push_back(cur->base);
+            ++dbg_walked_nodes;
         }
         const read_t ending = *main_edges.back()->reads.begin();
         const GraphRead &er = reads.at(ending);
@@ -397,7 +400,9 @@ void ContigGraph::calculate_main_path_greedy()
         start_pos = reads.at(starting).pos;
     }
     const uint64_t splits_before = n_splits_;
+    const auto tc0 = std::chrono::steady_clock::now();
     remove_cycles();
+    dbg_cycles_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
     if (n_splits_ != splits_before) consistent_from_ = (size_t)-1;   // a re-routing may change greedy choices anywhere on the path
     right_unchanged_ = main_edges.back()->sink;
     right_off_ = main_edges.size();

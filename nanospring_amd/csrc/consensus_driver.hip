@@ -48,7 +48,8 @@ struct Builder {
     bool idx_valid = false;
     cons::StreamSet out;
     uint64_t n_minhash = 0, n_minhash_new = 0, n_aligner = 0, n_align_calls = 0, n_contigs = 0, n_lone = 0;
-    double cpu_ms = 0, max_ms = 0, last_ms = 0, write_ms = 0, dbg_w1 = 0, dbg_w2 = 0, dbg_w3 = 0, dbg_u = 0, dbg_m = 0;
+    double cpu_ms = 0, max_ms = 0, last_ms = 0, write_ms = 0, dbg_w1 = 0, dbg_w2 = 0, dbg_w3 = 0, dbg_u = 0, dbg_m = 0, dbg_cyc = 0;
+    uint64_t dbg_c[5] = {0, 0, 0, 0, 0};
 };
 
 struct Driver {
@@ -107,6 +108,8 @@ struct Driver {
             b.out.reads_in_contig.push_back((read_t)g.num_reads());
         }
         ++b.n_contigs;
+        b.dbg_cyc += g.dbg_cycles_ms;
+        b.dbg_c[0] += g.dbg_cycles_calls, b.dbg_c[1] += g.dbg_cycles_skipped, b.dbg_c[2] += g.dbg_spliced, b.dbg_c[3] += g.dbg_spliced_nodes, b.dbg_c[4] += g.dbg_walked_nodes;
         const double t3 = now_ms();
         b.g.reset();
         b.dbg_w3 += now_ms() - t3;
@@ -418,16 +421,19 @@ static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
     // file sets, src/Compressor.cpp:123-124; Decompressor reads numThr from metaData)
     c->cons_out.assign(n_threads_out, cons::StreamSet());
     for (size_t i = 0; i < D.B.size(); ++i) c->cons_out[i * n_threads_out / (D.B.empty() ? 1 : D.B.size())].append(D.B[i].out);
-    double dbg_w[5] = {0, 0, 0, 0, 0};
+    double dbg_w[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t dbg_c[5] = {0, 0, 0, 0, 0};
     for (Builder &b : D.B) {
         S.n_contigs += b.n_contigs; S.n_lone += b.n_lone; S.count_minhash += b.n_minhash; S.count_minhash_not_in_graph += b.n_minhash_new;
         S.count_aligner += b.n_aligner; S.n_align_calls += b.n_align_calls;
         S.graph_cpu_ms += b.cpu_ms; if (b.max_ms > S.graph_max_ms) S.graph_max_ms = b.max_ms;
         S.write_cpu_ms += b.write_ms;
-        dbg_w[0] += b.dbg_w1, dbg_w[1] += b.dbg_w2, dbg_w[2] += b.dbg_w3, dbg_w[3] += b.dbg_u, dbg_w[4] += b.dbg_m;
+        dbg_w[0] += b.dbg_w1, dbg_w[1] += b.dbg_w2, dbg_w[2] += b.dbg_w3, dbg_w[3] += b.dbg_u, dbg_w[4] += b.dbg_m, dbg_w[5] += b.dbg_cyc;
+        for (int k = 0; k < 5; ++k) dbg_c[k] += b.dbg_c[k];
     }
     if (getenv("NSGPU_CONS_DEBUG"))
-        fprintf(stderr, "[cons] cpu-ms: update_graph %.0f main_path %.0f write_main %.0f write_reads %.0f graph_free %.0f\n", dbg_w[3], dbg_w[4], dbg_w[0], dbg_w[1], dbg_w[2]);
+        fprintf(stderr, "[cons] cpu-ms: update_graph %.0f main_path %.0f (remove_cycles %.0f) write_main %.0f write_reads %.0f graph_free %.0f; main-path calls %llu cycles-skipped %llu spliced %llu spliced-nodes %llu walked-nodes %llu\n",
+                dbg_w[3], dbg_w[4], dbg_w[5], dbg_w[0], dbg_w[1], dbg_w[2], (unsigned long long)dbg_c[0], (unsigned long long)dbg_c[1], (unsigned long long)dbg_c[2], (unsigned long long)dbg_c[3], (unsigned long long)dbg_c[4]);
     S.total_ms = now_ms() - E->t0;
     c->cons_n_reads_out = 0;
     for (auto &t : c->cons_out) for (read_t x : t.reads_in_contig) c->cons_n_reads_out += x;
@@ -443,20 +449,38 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
     NS_TRY(engine_begin(c, n_builders, 0, 1));
     Engine *E = static_cast<Engine *>(c->cons_engine);
     std::vector<uint32_t> ga, gb;
+    double w_adv = 0, w_seed = 0, w_batch = 0, w_claim = 0;
+    const double w_begin = now_ms() - E->t0;
     for (;;) {
+        double t = now_ms();
         engine_advance(c, false);
+        w_adv += now_ms() - t;
         for (;;) {
+            t = now_ms();
             engine_seed_requests(c, ga, gb);
             if (ga.empty()) break;
-            if (engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) == 0) break;
+            const uint32_t started = engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size());
+            w_seed += now_ms() - t;
+            if (started == 0) break;
+            t = now_ms();
             engine_advance(c, true);
+            w_adv += now_ms() - t;
         }
+        t = now_ms();
         NS_TRY(engine_batches(c));
+        w_batch += now_ms() - t;
+        t = now_ms();
         engine_claim_requests(c, ga, gb);
         engine_claim_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size());
+        w_claim += now_ms() - t;
         if (E->n_done_global >= E->n_total) break;
     }
-    return engine_finish(c, n_threads_out);
+    const double tf = now_ms();
+    const int rc = engine_finish(c, n_threads_out);
+    if (getenv("NSGPU_CONS_DEBUG"))
+        fprintf(stderr, "[cons] wall-ms: begin %.0f advance %.0f seed %.0f batches %.0f claim %.0f finish %.0f\n", w_begin, w_adv, w_seed, w_batch, w_claim,
+                now_ms() - tf);
+    return rc;
 }
 
 }  // namespace nsgpu

@@ -111,6 +111,7 @@ struct AlignJob {
     DpCache cache;
     void start(const RefIndex *r, const char *q, int ql, const Opt &o);
     bool step();                       // true when finished; otherwise cache.missing is non-empty
+    void swap_storage(AlignJob &o) { regs.swap(o.regs); qseq.swap(o.qseq); a.swap(o.a); cache.done.swap(o.cache.done); cache.missing.swap(o.cache.missing); }
 };
 
 // ConsensusGraph::alignRead's conversion of reg[0] (src/ConsensusGraph.cpp:219-397)
