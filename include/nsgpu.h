@@ -140,6 +140,15 @@ int nsgpu_ksw_extd2_batch(nsgpu_ctx *ctx, uint32_t n, const uint8_t *seqs, const
                           const int32_t *end_bonus, const int32_t *flag, const nsgpu_ksw_params *prm, nsgpu_ksw_ez *ez_out,
                           uint64_t **cigar_off_out, uint32_t **cigar_out);
 
+/* ---- a14c: mm_sketch (minimap2/sketch.c:77-143; called by mm_idx_str -> mm_idx_add and by mm_map's
+ *      collect_minimizers, minimap2/map.c:55-67) for a batch of sequences, rid = 0: the (w,k)-minimizers of
+ *      sequence i (seqs[seq_off[i]..seq_off[i+1]), ASCII) are the mm128_t pairs
+ *      (*xy_out)[2*j], (*xy_out)[2*j+1] = x, y for j in (*off_out)[i] .. (*off_out)[i+1], in the
+ *      reference's output order (x = hash<<8 | span, y = pos<<1 | strand).  Both arrays are
+ *      malloc'ed; release with nsgpu_free. ---- */
+int nsgpu_mm_sketch_batch(nsgpu_ctx *ctx, const char *seqs, const uint64_t *seq_off, uint32_t n, uint32_t w, uint32_t k,
+                          uint64_t **xy_out, uint64_t **off_out);
+
 /* ---- a13: batched ConsensusGraph::alignRead (include/ConsensusGraph.h:245-247,
  *      src/ConsensusGraph.cpp:161-398): align query i (qrys[qry_off[i]..qry_off[i+1])) to reference
  *      pair_ref[i] (refs[ref_off[r]..ref_off[r+1])) with minimap2's defaults + MM_F_CIGAR|MM_F_FOR_ONLY,

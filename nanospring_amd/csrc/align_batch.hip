@@ -154,8 +154,10 @@ double now_ms()
 }
 
 // One alignment request: query against a reference whose index the caller owns.
-int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::AlnOut> &outs)
+int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::AlnOut> &outs, int ws_index)
 {
+    double host_ms = 0, dp_ms = 0;
+    uint64_t dp_tasks = 0, rounds = 0;
     using namespace mm2;
     const size_t n_pairs = reqs.size();
     static const bool dbg_t = getenv("NSGPU_ALIGN_DEBUG") != nullptr;
@@ -165,7 +167,11 @@ int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::A
     Opt opt;
     opt.k = (int)c->prm.m_k, opt.w = (int)c->prm.m_w, opt.max_chain_iter = (int)c->prm.max_chain_iter;
     std::vector<AlignJob> jobs(n_pairs);
-    for (size_t i = 0; i < n_pairs; ++i) jobs[i].start(reqs[i].idx, reqs[i].qry, (int)reqs[i].qry_len, opt);
+    for (size_t i = 0; i < n_pairs; ++i) {
+        jobs[i].start(reqs[i].idx, reqs[i].qry, (int)reqs[i].qry_len, opt);
+        // a query of length 0 has no sketch either way; pre_mz must be non-null to count as "given"
+        if (reqs[i].qry_mz) jobs[i].pre_mz = reqs[i].qry_mz, jobs[i].n_pre_mz = reqs[i].n_qry_mz;
+    }
     KswParams kp;
     kp.sc_mch = opt.a; kp.sc_mis = -opt.b; kp.sc_ambi = -opt.sc_ambi; kp.q = opt.q; kp.e = opt.e; kp.q2 = opt.q2; kp.e2 = opt.e2;
     std::vector<uint32_t> live(n_pairs);
@@ -182,7 +188,7 @@ int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::A
         double a0 = now_ms();
         parallel_for(live.size(), [&](size_t i) { jobs[live[i]].step(); });
         double a1 = now_ms();
-        c->aln_host_ms += a1 - a0;
+        host_ms += a1 - a0;
         std::vector<uint32_t> still;
         std::vector<size_t> t_off, b_off;
         size_t nt = 0, nb = 0;
@@ -218,12 +224,12 @@ int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::A
             }
         });
         double a2 = now_ms();
-        c->aln_host_ms += a2 - a1;
-        NS_TRY(ksw_run_batch(c, tasks, pool.data(), nb, kp, res, cig, coff));
+        host_ms += a2 - a1;
+        NS_TRY(ksw_run_batch(c, tasks, pool.data(), nb, kp, res, cig, coff, ws_index));
         double a3 = now_ms();
-        c->aln_dp_ms += a3 - a2;
-        c->aln_dp_tasks += nt;
-        ++c->aln_rounds;
+        dp_ms += a3 - a2;
+        dp_tasks += nt;
+        ++rounds;
         parallel_for(live.size(), [&](size_t li) {
             AlignJob &J = jobs[live[li]];
             size_t ti = t_off[li];
@@ -237,12 +243,15 @@ int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::A
                 ++ti;
             }
         });
-        c->aln_host_ms += now_ms() - a3;
+        host_ms += now_ms() - a3;
     }
     double b0 = now_ms();
     parallel_for(n_pairs, [&](size_t i) { align_read_result(jobs[i], reqs[i].ref, reqs[i].ref_len, outs[i]); });
-    c->aln_host_ms += now_ms() - b0;
-    c->aln_pairs += n_pairs;
+    host_ms += now_ms() - b0;
+    {
+        std::lock_guard<std::mutex> lk(c->stat_m);
+        c->aln_host_ms += host_ms, c->aln_dp_ms += dp_ms, c->aln_dp_tasks += dp_tasks, c->aln_rounds += rounds, c->aln_pairs += n_pairs;
+    }
     const double d2 = now_ms();
     parallel_for(n_pairs, [&](size_t i) { AlignJob().swap_storage(jobs[i]); });      // free the jobs' heap blocks on all threads
     if (dbg_t) fprintf(stderr, "[align] pairs %zu setup %.2f serial-in-rounds %.2f result %.2f free %.2f ms\n", n_pairs, d1 - d0, d_serial, d2 - b0, now_ms() - d2);
@@ -259,13 +268,23 @@ int align_batch(nsgpu_ctx *c, const char *refs, const uint64_t *roff, uint32_t n
     for (uint32_t i = 0; i < n_refs; ++i) NS_CHECK(roff[i + 1] - roff[i] < (1ull << 31), NSGPU_ERR_RANGE, "reference %u longer than 2^31", i);
     NS_CHECK(c->prm.m_k > 0 && c->prm.m_k <= 28 && c->prm.m_w > 0 && c->prm.m_w < 256, NSGPU_ERR_ARG, "minimap k must be in 1..28 and w in 1..255 (sketch.c:84)");
     const double t0 = now_ms();
+    // minimizers of every reference and every query in one GPU batch (mm_sketch.hip)
+    std::vector<SketchReq> sk(n_refs + (size_t)n_pairs);
+    for (uint32_t i = 0; i < n_refs; ++i) sk[i] = SketchReq{refs + roff[i], (size_t)(roff[i + 1] - roff[i])};
+    for (uint32_t i = 0; i < n_pairs; ++i) sk[n_refs + i] = SketchReq{qrys + qoff[i], (size_t)(qoff[i + 1] - qoff[i])};
+    const Anchor *mz = nullptr;
+    std::vector<uint64_t> mz_off;
+    NS_TRY(gpu_mm_sketch(c, sk, (int)c->prm.m_w, (int)c->prm.m_k, mz, mz_off));
     std::vector<RefIndex> idx(n_refs);
-    parallel_for(n_refs, [&](size_t i) { idx[i].build(refs + roff[i], (uint32_t)(roff[i + 1] - roff[i]), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f); });
+    parallel_for(n_refs, [&](size_t i) {
+        idx[i].build_from_sketch(refs + roff[i], (uint32_t)(roff[i + 1] - roff[i]), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f, mz + mz_off[i], (size_t)(mz_off[i + 1] - mz_off[i]));
+    });
     c->aln_index_ms += now_ms() - t0;
     std::vector<AlignReq> reqs(n_pairs);
     for (uint32_t i = 0; i < n_pairs; ++i) {
         const uint32_t rf = pair_ref[i];
-        reqs[i] = AlignReq{&idx[rf], refs + roff[rf], (size_t)(roff[rf + 1] - roff[rf]), qrys + qoff[i], (size_t)(qoff[i + 1] - qoff[i])};
+        reqs[i] = AlignReq{&idx[rf], refs + roff[rf], (size_t)(roff[rf + 1] - roff[rf]), qrys + qoff[i], (size_t)(qoff[i + 1] - qoff[i]),
+                           mz + mz_off[n_refs + i], (size_t)(mz_off[n_refs + i + 1] - mz_off[n_refs + i])};
     }
     return align_requests(c, reqs, outs);
 }
@@ -273,6 +292,29 @@ int align_batch(nsgpu_ctx *c, const char *refs, const uint64_t *roff, uint32_t n
 }  // namespace nsgpu
 
 using namespace nsgpu;
+
+// mm_sketch (minimap2/sketch.c:77-143, rid 0) of a batch of sequences on the GPU: minimizers of sequence i are the
+// (x, y) pairs xy_out[2 * off_out[i]] .. xy_out[2 * off_out[i + 1]) in the reference's output order.
+extern "C" int nsgpu_mm_sketch_batch(nsgpu_ctx *c, const char *seqs, const uint64_t *seq_off, uint32_t n, uint32_t w, uint32_t k, uint64_t **xy_out,
+                                     uint64_t **off_out)
+{
+    NS_CHECK(c && seq_off && (n == 0 || seqs) && xy_out && off_out, NSGPU_ERR_ARG, "nsgpu_mm_sketch_batch: null argument");
+    NS_HIP(hipSetDevice(c->prm.device));
+    std::vector<SketchReq> sk(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        NS_CHECK(seq_off[i + 1] >= seq_off[i], NSGPU_ERR_ARG, "offsets must be non-decreasing");
+        sk[i] = SketchReq{seqs + seq_off[i], (size_t)(seq_off[i + 1] - seq_off[i])};
+    }
+    const mm2::Anchor *mz = nullptr;
+    std::vector<uint64_t> off;
+    NS_TRY(gpu_mm_sketch(c, sk, (int)w, (int)k, mz, off));
+    uint64_t *xy = (uint64_t *)malloc((off[n] * 2 + 1) * 8), *of = (uint64_t *)malloc(((size_t)n + 1) * 8);
+    NS_CHECK(xy && of, NSGPU_ERR_NOMEM, "malloc failed");
+    if (off[n]) memcpy(xy, mz, off[n] * 16);
+    memcpy(of, off.data(), ((size_t)n + 1) * 8);
+    *xy_out = xy, *off_out = of;
+    return NSGPU_OK;
+}
 
 extern "C" int nsgpu_align_batch(nsgpu_ctx *c, const char *refs, const uint64_t *ref_off, uint32_t n_refs, const char *qrys,
                                  const uint64_t *qry_off, const uint32_t *pair_ref, uint32_t n_pairs, nsgpu_aln *out,

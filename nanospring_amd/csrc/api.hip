@@ -127,14 +127,29 @@ void nsgpu_destroy(nsgpu_ctx *c)
     c->reads.release(); c->queries.release();
     DevBuf *bufs[] = {&c->ascii, &c->aoff, &c->salts, &c->sketch, &c->sketch_rc, &c->qsketch, &c->idx_keys, &c->idx_ids, &c->idx_tmp_k,
                       &c->idx_tmp_v, &c->idx_tmp_e, &c->idx_tmp_e2, &c->idx_sort_ws, &c->f_pool, &c->f_qstart, &c->f_qcnt, &c->f_qm, &c->f_off,
-                      &c->f_ids, &c->f_ctrl, &c->f_ovf_list, &c->f_ovf_cnt, &c->f_scan_ws, &c->rep_flags,
-                      &c->k_tasks, &c->k_order, &c->k_seqs, &c->k_p, &c->k_cig, &c->k_res, &c->k_slab, &c->k_ncig, &c->k_coff, &c->k_cig2};
+                      &c->f_ids, &c->f_ctrl, &c->f_ovf_list, &c->f_ovf_cnt, &c->f_scan_ws, &c->rep_flags};
     for (DevBuf *b : bufs) b->release();
     c->t_stage.destroy(); c->t_kernel.destroy();
-    for (int i = 0; i < 3; ++i) { if (c->side_stream[i]) (void)hipStreamDestroy(c->side_stream[i]); if (c->side_done[i]) (void)hipEventDestroy(c->side_done[i]); }
-    if (c->side_fork) (void)hipEventDestroy(c->side_fork);
     if (c->cons_engine) c->cons_engine_free(c->cons_engine);
-    for (hipEvent_t e : c->ksw_ev) if (e) (void)hipEventDestroy(e);
+    {
+        nsgpu_ctx::SketchWs &w = c->sws;
+        DevBuf *sb[] = {&w.seqs, &w.soff, &w.len, &w.sob, &w.vf, &w.mk, &w.vr, &w.linv, &w.npf, &w.pushf, &w.npr, &w.pr, &w.V, &w.hk, &w.PX, &w.PY, &w.PRUN,
+                        &w.PSEQ, &w.rm, &w.nout, &w.oscan, &w.off, &w.out, &w.scan_ws};
+        for (DevBuf *b : sb) b->release();
+        if (w.h_seqs) (void)hipHostFree(w.h_seqs);
+        if (w.h_out) (void)hipHostFree(w.h_out);
+    }
+    for (nsgpu_ctx::KswWs &w : c->kws) {
+        if (w.stream) (void)hipStreamSynchronize(w.stream);
+        DevBuf *kb[] = {&w.k_tasks, &w.k_order, &w.k_seqs, &w.k_p, &w.k_cig, &w.k_res, &w.k_slab, &w.k_ncig, &w.k_coff, &w.k_cig2, &w.scan_ws};
+        for (DevBuf *b : kb) b->release();
+        for (int i = 0; i < 3; ++i) { if (w.side_stream[i]) (void)hipStreamDestroy(w.side_stream[i]); if (w.side_done[i]) (void)hipEventDestroy(w.side_done[i]); }
+        if (w.side_fork) (void)hipEventDestroy(w.side_fork);
+        if (w.t_a) (void)hipEventDestroy(w.t_a);
+        if (w.t_b) (void)hipEventDestroy(w.t_b);
+        for (hipEvent_t e : w.ev) if (e) (void)hipEventDestroy(e);
+        if (w.stream) (void)hipStreamDestroy(w.stream);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

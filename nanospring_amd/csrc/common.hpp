@@ -8,6 +8,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <mutex>
 #include <algorithm>
 #include "../../include/nsgpu.h"
 #include "consensus.hpp"
@@ -106,13 +107,26 @@ struct nsgpu_ctx {
     uint32_t f_nq = 0;
     nsgpu::DevBuf rep_flags;
     // ksw2 batches
-    nsgpu::DevBuf k_tasks, k_order, k_seqs, k_p, k_cig, k_res, k_slab, k_ncig, k_coff, k_cig2;
+    // two workspaces: the contig engine aligns two half batches from two host threads, so that one half's host work
+    // (seeding, chaining, CIGAR bookkeeping) overlaps the other half's DP kernels
+    struct KswWs {
+        nsgpu::DevBuf k_tasks, k_order, k_seqs, k_p, k_cig, k_res, k_slab, k_ncig, k_coff, k_cig2, scan_ws;
+        std::vector<hipEvent_t> ev;                                  // start/end event pairs, one pair per launch of a batch
+        hipStream_t stream = nullptr;                                // workspace 0 runs on the context's stream
+        hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
+        hipEvent_t side_done[3] = {nullptr, nullptr, nullptr}, side_fork = nullptr, t_a = nullptr, t_b = nullptr;
+    } kws[2];
+    // batched minimizer sketches (mm_sketch.hip): device buffers + pinned staging both ways
+    struct SketchWs {
+        nsgpu::DevBuf seqs, soff, len, sob, vf, mk, vr, linv, npf, pushf, npr, pr, V, hk, PX, PY, PRUN, PSEQ, rm, nout, oscan, off, out, scan_ws;
+        uint8_t *h_seqs = nullptr; size_t h_cap = 0;
+        uint8_t *h_out = nullptr; size_t h_out_cap = 0;
+    } sws;
+    double sketch_mm_ms = 0;                                         // wall of the batched mm_sketch calls
+    std::mutex stat_m;                                               // guards the ksw_* / aln_* counters below
     double ksw_kernel_ms = 0, ksw_cells = 0, ksw_alg_bytes = 0;     // kernel_ms: wall of the (overlapping) DP launches per batch
     double ksw_kernel_sum_ms = 0;                                    // sum of the individual kernel durations (what rocprof reports)
-    std::vector<hipEvent_t> ksw_ev;                                  // start/end event pairs, one pair per launch of a batch
     uint64_t ksw_launches = 0;
-    hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t side_done[3] = {nullptr, nullptr, nullptr}, side_fork = nullptr;
     // align batches
     uint64_t aln_pairs = 0, aln_dp_tasks = 0, aln_rounds = 0;
     double aln_index_ms = 0, aln_host_ms = 0, aln_dp_ms = 0;
@@ -142,6 +156,7 @@ int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, 
 // index.hip
 int build_index(nsgpu_ctx *c);
 int scan_u32_to_u64(nsgpu_ctx *c, const uint32_t *d_in, uint64_t *d_out, uint32_t n);  // exclusive, n+1 outputs
+int scan_u32_to_u64(DevBuf &scratch, hipStream_t stream, const uint32_t *d_in, uint64_t *d_out, uint32_t n);
 
 int store_layout(SeqStore &st, const uint32_t *len, uint32_t n);   // fills h_poff/h_len, allocs
 }  // namespace nsgpu

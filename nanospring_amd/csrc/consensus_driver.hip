@@ -18,6 +18,7 @@
 #include "consensus.hpp"
 #include "host_util.hpp"
 #include <memory>
+#include <thread>
 
 namespace nsgpu {
 
@@ -240,8 +241,11 @@ struct Engine {
     std::string qbuf;
     std::vector<uint64_t> qoff, foff;
     std::vector<uint32_t> fids;
-    std::vector<AlignReq> reqs;
-    std::vector<mm2::AlnOut> outs;
+    std::vector<SketchReq> sk;
+    std::vector<uint32_t> sk_ref;
+    std::vector<uint64_t> mz_off;
+    std::vector<AlignReq> reqs, reqs2;
+    std::vector<mm2::AlnOut> outs, outs2;
     Builder *local(uint32_t gid) { return gid % world == rank ? &D.B[gid / world] : nullptr; }
 };
 
@@ -357,24 +361,54 @@ static int engine_batches(nsgpu_ctx *c)
     for (Builder &b : D.B) if (b.st == Builder::WAIT_ALIGN) who.push_back(b.id);
     if (!who.empty()) {
         const double g0 = now_ms();
+        // minimizers of every changed consensus and every candidate read in one GPU batch (mm_sketch.hip); the
+        // single-sequence index is then only a sort of a few hundred entries per consensus
+        std::vector<SketchReq> &sk = E->sk;
+        std::vector<uint32_t> &sk_ref = E->sk_ref;      // per who-entry: position of its consensus in sk, or ~0u
+        sk.clear(); sk_ref.assign(who.size(), ~0u);
+        for (size_t w = 0; w < who.size(); ++w) {
+            Builder &b = D.B[who[w]];
+            if (!b.idx_valid) { sk_ref[w] = (uint32_t)sk.size(); sk.push_back(SketchReq{b.g->main_path.data(), b.g->main_path.size()}); }
+        }
+        const size_t q_base = sk.size();
+        for (size_t w = 0; w < who.size(); ++w) sk.push_back(SketchReq{D.B[who[w]].query.data(), D.B[who[w]].query.size()});
+        const mm2::Anchor *mz = nullptr;
+        NS_TRY(gpu_mm_sketch(c, sk, (int)c->prm.m_w, (int)c->prm.m_k, mz, E->mz_off));
+        const std::vector<uint64_t> &mo = E->mz_off;
         par_for(who.size(), [&](size_t w) {
             Builder &b = D.B[who[w]];
             if (!b.idx_valid) {
-                b.idx.build(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f);
+                const uint32_t si = sk_ref[w];
+                b.idx.build_from_sketch(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f, mz + mo[si],
+                                        (size_t)(mo[si + 1] - mo[si]));
                 b.idx_valid = true;
             }
         });
         const double g1 = now_ms();
         S.index_ms += g1 - g0;
-        E->reqs.resize(who.size());
+        // two half batches from two host threads: while one half waits for its DP kernels the other half's host
+        // work (seeding, chaining, CIGAR bookkeeping) has the cores; alignments are independent, the split is by position
+        static const bool no_split = getenv("NSGPU_ALIGN_SPLIT") == nullptr;      // measured: no gain (the DP phase is bound by its longest problem), off unless asked for
+        const size_t n0 = who.size() < 64 || no_split ? who.size() : (who.size() + 1) / 2;
+        std::vector<AlignReq> *rq[2] = {&E->reqs, &E->reqs2};
+        std::vector<mm2::AlnOut> *ot[2] = {&E->outs, &E->outs2};
+        rq[0]->clear(), rq[1]->clear();
         for (size_t w = 0; w < who.size(); ++w) {
             Builder &b = D.B[who[w]];
-            E->reqs[w] = AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size()};
+            rq[w >= n0]->push_back(AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), mz + mo[q_base + w],
+                                            (size_t)(mo[q_base + w + 1] - mo[q_base + w])});
         }
-        NS_TRY(align_requests(c, E->reqs, E->outs));
+        int rc1 = NSGPU_OK;
+        std::thread second;
+        if (!rq[1]->empty())
+            second = std::thread([&] { rc1 = hipSetDevice(c->prm.device) == hipSuccess ? align_requests(c, *rq[1], *ot[1], 1) : NSGPU_ERR_HIP; });
+        const int rc0 = align_requests(c, *rq[0], *ot[0], 0);
+        if (second.joinable()) second.join();
+        NS_TRY(rc0);
+        NS_TRY(rc1);
         for (size_t w = 0; w < who.size(); ++w) {
             Builder &b = D.B[who[w]];
-            b.aln = std::move(E->outs[w]);
+            b.aln = std::move(w < n0 ? (*ot[0])[w] : (*ot[1])[w - n0]);
             ++b.n_align_calls;
             b.accepted = false;
             b.st = Builder::ALIGNED;
@@ -477,9 +511,11 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
     }
     const double tf = now_ms();
     const int rc = engine_finish(c, n_threads_out);
-    if (getenv("NSGPU_CONS_DEBUG"))
+    if (getenv("NSGPU_CONS_DEBUG")) {
+        fprintf(stderr, "[cons] gpu mm_sketch wall-ms %.0f\n", c->sketch_mm_ms);
         fprintf(stderr, "[cons] wall-ms: begin %.0f advance %.0f seed %.0f batches %.0f claim %.0f finish %.0f\n", w_begin, w_adv, w_seed, w_batch, w_claim,
                 now_ms() - tf);
+    }
     return rc;
 }
 

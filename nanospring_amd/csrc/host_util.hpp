@@ -21,8 +21,15 @@ struct AlignReq {
     const mm2::RefIndex *idx;     // index of `ref` (owned by the caller, reusable across batches)
     const char *ref; size_t ref_len;
     const char *qry; size_t qry_len;
+    const mm2::Anchor *qry_mz = nullptr;   // the query's minimizers when the caller already has them (gpu_mm_sketch)
+    size_t n_qry_mz = 0;
 };
-int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::AlnOut> &outs);
+struct SketchReq { const char *ptr; size_t len; };
+// (w,k)-minimizers of a batch of sequences, computed on the GPU (mm_sketch.hip).  Sequence i's minimizers are
+// out[out_off[i] .. out_off[i+1]) in mm_sketch's order; `out` points into a pinned buffer owned by the context and
+// stays valid until the next call.
+int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off);
+int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::AlnOut> &outs, int ws_index = 0);
 int filter_strings_device(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq);   // api.hip: results stay in c->f_off / c->f_ids
 
 }  // namespace nsgpu

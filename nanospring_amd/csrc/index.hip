@@ -82,12 +82,14 @@ int build_index(nsgpu_ctx *c)
 
 // exclusive scan of n u32 values into n+1 u64 offsets (d_in must have a readable,
 // zero element at index n).
-int scan_u32_to_u64(nsgpu_ctx *c, const uint32_t *d_in, uint64_t *d_out, uint32_t n)
+int scan_u32_to_u64(nsgpu_ctx *c, const uint32_t *d_in, uint64_t *d_out, uint32_t n) { return scan_u32_to_u64(c->f_scan_ws, c->stream, d_in, d_out, n); }
+
+int scan_u32_to_u64(DevBuf &scratch, hipStream_t stream, const uint32_t *d_in, uint64_t *d_out, uint32_t n)
 {
     size_t ws = 0;
-    NS_HIP(rocprim::exclusive_scan(nullptr, ws, d_in, d_out, (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), c->stream));
-    NS_TRY(c->f_scan_ws.reserve(ws + 16));
-    NS_HIP(rocprim::exclusive_scan(c->f_scan_ws.p, ws, d_in, d_out, (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), c->stream));
+    NS_HIP(rocprim::exclusive_scan(nullptr, ws, d_in, d_out, (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), stream));
+    NS_TRY(scratch.reserve(ws + 16));
+    NS_HIP(rocprim::exclusive_scan(scratch.p, ws, d_in, d_out, (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), stream));
     return NSGPU_OK;
 }
 

@@ -687,9 +687,15 @@ size_t ksw_p_bytes(int qlen, int tlen, int w)
 // Runs a batch.  tasks/seqs are host arrays; results and CIGARs come back to the host.
 // Task fields p_off / cig_off / out_idx are filled here.
 int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs, size_t seq_bytes, const KswParams &pr,
-                  std::vector<KswResult> &results, std::vector<uint32_t> &cigars, std::vector<uint64_t> &cig_off)
+                  std::vector<KswResult> &results, std::vector<uint32_t> &cigars, std::vector<uint64_t> &cig_off, int ws_index)
 {
     const size_t n = tasks.size();
+    NS_CHECK(ws_index == 0 || ws_index == 1, NSGPU_ERR_ARG, "ksw: workspace index must be 0 or 1");
+    nsgpu_ctx::KswWs &W = c->kws[ws_index];
+    // workspace 0 works on the context's stream; workspace 1 owns one (the second half batch of the contig engine)
+    if (ws_index == 1 && !W.stream) NS_HIP(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
+    const hipStream_t S = ws_index == 0 ? c->stream : W.stream;
+    if (!W.t_a) { NS_HIP(hipEventCreate(&W.t_a)); NS_HIP(hipEventCreate(&W.t_b)); }
     results.assign(n, KswResult());
     cig_off.assign(n + 1, 0);
     cigars.clear();
@@ -726,15 +732,15 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
         KswResult &o = results[i];
         o.max = 0; o.zdropped = 0; o.max_q = o.max_t = o.mqe_t = o.mte_q = -1; o.mqe = o.mte = o.score = KSW_NEG_INF; o.n_cigar = 0; o.reach_end = 0;
     }
-    NS_TRY(c->k_tasks.reserve(n * sizeof(KswTask)));
-    NS_TRY(c->k_order.reserve(n * 4 + 16));
-    NS_TRY(c->k_seqs.reserve(seq_bytes + 64));
-    NS_TRY(c->k_p.reserve(p_total + 256));
-    NS_TRY(c->k_cig.reserve((cig_total + 16) * 4));
-    NS_TRY(c->k_res.reserve(n * sizeof(KswResult)));
-    NS_HIP(hipMemcpyAsync(c->k_tasks.p, tasks.data(), n * sizeof(KswTask), hipMemcpyHostToDevice, c->stream));
-    NS_HIP(hipMemcpyAsync(c->k_seqs.p, seqs, seq_bytes, hipMemcpyHostToDevice, c->stream));
-    NS_HIP(hipMemcpyAsync(c->k_res.p, results.data(), n * sizeof(KswResult), hipMemcpyHostToDevice, c->stream));
+    NS_TRY(W.k_tasks.reserve(n * sizeof(KswTask)));
+    NS_TRY(W.k_order.reserve(n * 4 + 16));
+    NS_TRY(W.k_seqs.reserve(seq_bytes + 64));
+    NS_TRY(W.k_p.reserve(p_total + 256));
+    NS_TRY(W.k_cig.reserve((cig_total + 16) * 4));
+    NS_TRY(W.k_res.reserve(n * sizeof(KswResult)));
+    NS_HIP(hipMemcpyAsync(W.k_tasks.p, tasks.data(), n * sizeof(KswTask), hipMemcpyHostToDevice, S));
+    NS_HIP(hipMemcpyAsync(W.k_seqs.p, seqs, seq_bytes, hipMemcpyHostToDevice, S));
+    NS_HIP(hipMemcpyAsync(W.k_res.p, results.data(), n * sizeof(KswResult), hipMemcpyHostToDevice, S));
     std::vector<uint32_t> flat;
     size_t start[5] = {0, 0, 0, 0, 0}, wg_start[3] = {0, 0, 0};
     auto by_size = [&](uint32_t a, uint32_t b) { return (size_t)tasks[a].qlen * tasks[a].tlen > (size_t)tasks[b].qlen * tasks[b].tlen; };
@@ -750,43 +756,44 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
         wg_start[k] = flat.size();
         flat.insert(flat.end(), wg[k].begin(), wg[k].end());
     }
-    if (!flat.empty()) NS_HIP(hipMemcpyAsync(c->k_order.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, c->stream));
+    if (!flat.empty()) NS_HIP(hipMemcpyAsync(W.k_order.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, S));
     static const bool dbg = getenv("NSGPU_KSW_DEBUG") != nullptr;     // per-launch log (adds a sync per launch)
-    NS_HIP(hipEventRecord(c->t_kernel.a, c->stream));
+    NS_HIP(hipEventRecord(W.t_a, S));
     // The few long problems (extensions up to 5000 x 5000) are latency-bound on one wave each and leave the chip
     // idle: they run on side streams, concurrently with the bulk of small gap fills on the main stream.
-    if (!c->side_stream[0]) {
+    if (!W.side_stream[0]) {
         int prio_lo = 0, prio_hi = 0;
         NS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));      // the long problems must be dispatched first: highest priority
-        for (int i = 0; i < 3; ++i) { NS_HIP(hipStreamCreateWithPriority(&c->side_stream[i], hipStreamNonBlocking, prio_hi)); NS_HIP(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming)); }
-        NS_HIP(hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming));
+        for (int i = 0; i < 3; ++i) { NS_HIP(hipStreamCreateWithPriority(&W.side_stream[i], hipStreamNonBlocking, prio_hi)); NS_HIP(hipEventCreateWithFlags(&W.side_done[i], hipEventDisableTiming)); }
+        NS_HIP(hipEventCreateWithFlags(&W.side_fork, hipEventDisableTiming));
     }
-    NS_HIP(hipEventRecord(c->side_fork, c->stream));
+    NS_HIP(hipEventRecord(W.side_fork, S));
     bool side_used[3] = {false, false, false};
     size_t n_ev = 0;
-    auto ev_at = [&](size_t i) -> hipEvent_t { while (c->ksw_ev.size() <= i) { hipEvent_t e = nullptr; (void)hipEventCreate(&e); c->ksw_ev.push_back(e); } return c->ksw_ev[i]; };
+    uint64_t n_launch = 0;
+    auto ev_at = [&](size_t i) -> hipEvent_t { while (W.ev.size() <= i) { hipEvent_t e = nullptr; (void)hipEventCreate(&e); W.ev.push_back(e); } return W.ev[i]; };
     for (int k = 2; k >= 0; --k) {
         const uint32_t m = (uint32_t)wg[k].size();
         if (!m) continue;
-        hipStream_t st = c->stream;
-        if (k > 0 && !dbg) { st = c->side_stream[k]; NS_HIP(hipStreamWaitEvent(st, c->side_fork, 0)); side_used[k] = true; }
+        hipStream_t st = S;
+        if (k > 0 && !dbg) { st = W.side_stream[k]; NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0)); side_used[k] = true; }
         double dbg_t0 = 0;
-        if (dbg) { NS_HIP(hipStreamSynchronize(c->stream)); dbg_t0 = now_ms(); }
-        const uint32_t *ord = c->k_order.as<uint32_t>() + wg_start[k];
+        if (dbg) { NS_HIP(hipStreamSynchronize(S)); dbg_t0 = now_ms(); }
+        const uint32_t *ord = W.k_order.as<uint32_t>() + wg_start[k];
         NS_HIP(hipEventRecord(ev_at(n_ev++), st));
         if (k == 1)
-            hipLaunchKernelGGL((ksw_extd2_wg_kernel<256, 5>), dim3(m), dim3(256), kClass[1], st, c->k_tasks.as<KswTask>(), ord, m, pr, c->k_seqs.as<uint8_t>(),
-                               c->k_p.as<uint8_t>(), c->k_cig.as<uint32_t>(), c->k_res.as<KswResult>());
+            hipLaunchKernelGGL((ksw_extd2_wg_kernel<256, 5>), dim3(m), dim3(256), kClass[1], st, W.k_tasks.as<KswTask>(), ord, m, pr, W.k_seqs.as<uint8_t>(),
+                               W.k_p.as<uint8_t>(), W.k_cig.as<uint32_t>(), W.k_res.as<KswResult>());
         else {
             NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_wg_kernel<256, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClass[2]));
-            hipLaunchKernelGGL((ksw_extd2_wg_kernel<256, 8>), dim3(m), dim3(256), kClass[2], st, c->k_tasks.as<KswTask>(), ord, m, pr, c->k_seqs.as<uint8_t>(),
-                               c->k_p.as<uint8_t>(), c->k_cig.as<uint32_t>(), c->k_res.as<KswResult>());
+            hipLaunchKernelGGL((ksw_extd2_wg_kernel<256, 8>), dim3(m), dim3(256), kClass[2], st, W.k_tasks.as<KswTask>(), ord, m, pr, W.k_seqs.as<uint8_t>(),
+                               W.k_p.as<uint8_t>(), W.k_cig.as<uint32_t>(), W.k_res.as<KswResult>());
         }
         NS_HIP(hipGetLastError());
         NS_HIP(hipEventRecord(ev_at(n_ev++), st));
-        ++c->ksw_launches;
+        ++n_launch;
         if (dbg) {
-            NS_HIP(hipStreamSynchronize(c->stream));
+            NS_HIP(hipStreamSynchronize(S));
             double cells = 0, mx = 0;
             for (uint32_t i : wg[k]) { const double x = (double)tasks[i].qlen * tasks[i].tlen; cells += x; if (x > mx) mx = x; }
             fprintf(stderr, "KSW class %d tasks %u cells %.3g max %.3g (q %d t %d) ms %.3f\n", k + 4, m, cells, mx, tasks[wg[k][0]].qlen, tasks[wg[k][0]].tlen, now_ms() - dbg_t0);
@@ -795,71 +802,77 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
     for (int k = 2; k >= 0; --k) {
         const uint32_t m = (uint32_t)order[k].size();
         if (!m) continue;
-        hipStream_t st = c->stream;
-        if (k > 0 && !dbg) { st = c->side_stream[k]; NS_HIP(hipStreamWaitEvent(st, c->side_fork, 0)); side_used[k] = true; }
+        hipStream_t st = S;
+        if (k > 0 && !dbg) { st = W.side_stream[k]; NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0)); side_used[k] = true; }
         double dbg_t0 = 0;
-        if (dbg) { NS_HIP(hipStreamSynchronize(c->stream)); dbg_t0 = now_ms(); }
+        if (dbg) { NS_HIP(hipStreamSynchronize(S)); dbg_t0 = now_ms(); }
         if (kClass[k] > 49152) NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClass[k]));
         NS_HIP(hipEventRecord(ev_at(n_ev++), st));
-        hipLaunchKernelGGL(ksw_extd2_lds_kernel, dim3(m), dim3(64), kClass[k], st, c->k_tasks.as<KswTask>(),
-                           c->k_order.as<uint32_t>() + start[k], m, pr, c->k_seqs.as<uint8_t>(), c->k_p.as<uint8_t>(), c->k_cig.as<uint32_t>(),
-                           c->k_res.as<KswResult>());
+        hipLaunchKernelGGL(ksw_extd2_lds_kernel, dim3(m), dim3(64), kClass[k], st, W.k_tasks.as<KswTask>(),
+                           W.k_order.as<uint32_t>() + start[k], m, pr, W.k_seqs.as<uint8_t>(), W.k_p.as<uint8_t>(), W.k_cig.as<uint32_t>(),
+                           W.k_res.as<KswResult>());
         NS_HIP(hipGetLastError());
         NS_HIP(hipEventRecord(ev_at(n_ev++), st));
-        ++c->ksw_launches;
+        ++n_launch;
         if (dbg) {
-            NS_HIP(hipStreamSynchronize(c->stream));
+            NS_HIP(hipStreamSynchronize(S));
             double cells = 0, mx = 0;
             for (uint32_t i : order[k]) { const double x = (double)tasks[i].qlen * tasks[i].tlen; cells += x; if (x > mx) mx = x; }
             fprintf(stderr, "KSW class %d tasks %u cells %.3g max %.3g (q %d t %d) ms %.3f\n", k, m, cells, mx, tasks[order[k][0]].qlen, tasks[order[k][0]].tlen, now_ms() - dbg_t0);
         }
     }
     if (!order[3].empty()) {
-        NS_HIP(hipStreamWaitEvent(c->side_stream[0], c->side_fork, 0));
+        NS_HIP(hipStreamWaitEvent(W.side_stream[0], W.side_fork, 0));
         side_used[0] = true;
         const uint32_t m = (uint32_t)order[3].size();
         const uint32_t wgs = m < 512u ? m : 512u;
         hbm_stride = (hbm_stride + 255) & ~(size_t)255;
-        NS_TRY(c->k_slab.reserve((size_t)wgs * hbm_stride));
-        NS_HIP(hipEventRecord(ev_at(n_ev++), c->side_stream[0]));
-        hipLaunchKernelGGL(ksw_extd2_hbm_kernel, dim3(wgs), dim3(64), 0, c->side_stream[0], c->k_tasks.as<KswTask>(), c->k_order.as<uint32_t>() + start[3], m, pr,
-                           c->k_seqs.as<uint8_t>(), c->k_p.as<uint8_t>(), c->k_cig.as<uint32_t>(), c->k_res.as<KswResult>(), c->k_slab.as<uint8_t>(),
+        NS_TRY(W.k_slab.reserve((size_t)wgs * hbm_stride));
+        NS_HIP(hipEventRecord(ev_at(n_ev++), W.side_stream[0]));
+        hipLaunchKernelGGL(ksw_extd2_hbm_kernel, dim3(wgs), dim3(64), 0, W.side_stream[0], W.k_tasks.as<KswTask>(), W.k_order.as<uint32_t>() + start[3], m, pr,
+                           W.k_seqs.as<uint8_t>(), W.k_p.as<uint8_t>(), W.k_cig.as<uint32_t>(), W.k_res.as<KswResult>(), W.k_slab.as<uint8_t>(),
                            hbm_stride);
         NS_HIP(hipGetLastError());
-        NS_HIP(hipEventRecord(ev_at(n_ev++), c->side_stream[0]));
-        ++c->ksw_launches;
+        NS_HIP(hipEventRecord(ev_at(n_ev++), W.side_stream[0]));
+        ++n_launch;
     }
     for (int i = 0; i < 3; ++i)
-        if (side_used[i]) { NS_HIP(hipEventRecord(c->side_done[i], c->side_stream[i])); NS_HIP(hipStreamWaitEvent(c->stream, c->side_done[i], 0)); }
-    NS_HIP(hipEventRecord(c->t_kernel.b, c->stream));
+        if (side_used[i]) { NS_HIP(hipEventRecord(W.side_done[i], W.side_stream[i])); NS_HIP(hipStreamWaitEvent(S, W.side_done[i], 0)); }
+    NS_HIP(hipEventRecord(W.t_b, S));
     // compact the CIGARs on the device, then fetch results + used CIGAR entries only
-    NS_TRY(c->k_ncig.reserve((n + 2) * 4));
-    NS_TRY(c->k_coff.reserve((n + 2) * 8));
-    hipLaunchKernelGGL(ksw_ncigar_kernel, dim3((uint32_t)((n + 256) / 256)), dim3(256), 0, c->stream, c->k_res.as<KswResult>(), (uint32_t)n, c->k_ncig.as<uint32_t>());
+    NS_TRY(W.k_ncig.reserve((n + 2) * 4));
+    NS_TRY(W.k_coff.reserve((n + 2) * 8));
+    hipLaunchKernelGGL(ksw_ncigar_kernel, dim3((uint32_t)((n + 256) / 256)), dim3(256), 0, S, W.k_res.as<KswResult>(), (uint32_t)n, W.k_ncig.as<uint32_t>());
     NS_HIP(hipGetLastError());
-    NS_TRY(scan_u32_to_u64(c, c->k_ncig.as<uint32_t>(), c->k_coff.as<uint64_t>(), (uint32_t)n));
-    NS_HIP(hipMemcpyAsync(results.data(), c->k_res.p, n * sizeof(KswResult), hipMemcpyDeviceToHost, c->stream));
-    NS_HIP(hipMemcpyAsync(cig_off.data(), c->k_coff.p, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_TRY(scan_u32_to_u64(W.scan_ws, S, W.k_ncig.as<uint32_t>(), W.k_coff.as<uint64_t>(), (uint32_t)n));
+    NS_HIP(hipMemcpyAsync(results.data(), W.k_res.p, n * sizeof(KswResult), hipMemcpyDeviceToHost, S));
+    NS_HIP(hipMemcpyAsync(cig_off.data(), W.k_coff.p, (n + 1) * 8, hipMemcpyDeviceToHost, S));
+    NS_HIP(hipStreamSynchronize(S));
     const uint64_t used = cig_off[n];
-    NS_TRY(c->k_cig2.reserve((used + 16) * 4));
+    NS_TRY(W.k_cig2.reserve((used + 16) * 4));
     if (used) {
         uint32_t grid = (uint32_t)((n + 3) / 4);
         if (grid > 16384u) grid = 16384u;
-        hipLaunchKernelGGL(ksw_cigar_gather_kernel, dim3(grid), dim3(256), 0, c->stream, c->k_tasks.as<KswTask>(), c->k_res.as<KswResult>(), (uint32_t)n,
-                           c->k_coff.as<uint64_t>(), c->k_cig.as<uint32_t>(), c->k_cig2.as<uint32_t>());
+        hipLaunchKernelGGL(ksw_cigar_gather_kernel, dim3(grid), dim3(256), 0, S, W.k_tasks.as<KswTask>(), W.k_res.as<KswResult>(), (uint32_t)n,
+                           W.k_coff.as<uint64_t>(), W.k_cig.as<uint32_t>(), W.k_cig2.as<uint32_t>());
         NS_HIP(hipGetLastError());
     }
     cigars.resize(used + 1);
-    if (used) NS_HIP(hipMemcpyAsync(cigars.data(), c->k_cig2.p, used * 4, hipMemcpyDeviceToHost, c->stream));
-    NS_HIP(hipStreamSynchronize(c->stream));
+    if (used) NS_HIP(hipMemcpyAsync(cigars.data(), W.k_cig2.p, used * 4, hipMemcpyDeviceToHost, S));
+    NS_HIP(hipStreamSynchronize(S));
     float ms = 0;
-    NS_HIP(hipEventElapsedTime(&ms, c->t_kernel.a, c->t_kernel.b));
-    c->ksw_kernel_ms += ms;
-    for (size_t i = 0; i + 1 < n_ev; i += 2) { float d = 0; if (hipEventElapsedTime(&d, c->ksw_ev[i], c->ksw_ev[i + 1]) == hipSuccess) c->ksw_kernel_sum_ms += d; }
-    c->ksw_cells += [&] { double s = 0; for (auto &t : tasks) s += (double)t.qlen * t.tlen; return s; }();
+    NS_HIP(hipEventElapsedTime(&ms, W.t_a, W.t_b));
+    double sum_ms = 0, cells = 0, alg = 0;
+    for (size_t i = 0; i + 1 < n_ev; i += 2) { float d = 0; if (hipEventElapsedTime(&d, W.ev[i], W.ev[i + 1]) == hipSuccess) sum_ms += d; }
+    for (auto &t : tasks) cells += (double)t.qlen * t.tlen;
     // algorithmic HBM bytes of a DP problem: both sequences in, CIGAR + result out (the traceback matrix is scratch)
-    for (size_t i = 0; i < n; ++i) c->ksw_alg_bytes += (double)tasks[i].qlen + tasks[i].tlen + 4.0 * results[i].n_cigar + sizeof(KswResult);
+    for (size_t i = 0; i < n; ++i) alg += (double)tasks[i].qlen + tasks[i].tlen + 4.0 * results[i].n_cigar + sizeof(KswResult);
+    std::lock_guard<std::mutex> lk(c->stat_m);
+    c->ksw_kernel_ms += ms;
+    c->ksw_kernel_sum_ms += sum_ms;
+    c->ksw_cells += cells;
+    c->ksw_alg_bytes += alg;
+    c->ksw_launches += n_launch;
     return NSGPU_OK;
 }
 

@@ -26,6 +26,6 @@ struct KswResult {            // ksw_extz_t (minimap2/ksw2.h:23-32) without the 
 size_t ksw_lds_bytes(int qlen, int tlen, int flag);
 size_t ksw_p_bytes(int qlen, int tlen, int w);
 int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs, size_t seq_bytes, const KswParams &pr,
-                  std::vector<KswResult> &results, std::vector<uint32_t> &cigars, std::vector<uint64_t> &cig_off);
+                  std::vector<KswResult> &results, std::vector<uint32_t> &cigars, std::vector<uint64_t> &cig_off, int ws_index = 0);
 
 }  // namespace nsgpu

@@ -180,11 +180,17 @@ void mm_sketch(const char *str, int len, int w, int k, uint32_t rid, std::vector
 // ---------------------------------------------------------------------------
 void RefIndex::build(const char *s, uint32_t n, int w_, int k_, float mid_occ_frac)
 {
+    std::vector<Anchor> mz;
+    if (n > 0) mm_sketch(s, (int)n, w_ < 1 ? 1 : w_, k_, 0, mz);
+    build_from_sketch(s, n, w_, k_, mid_occ_frac, mz.data(), mz.size());
+}
+
+void RefIndex::build_from_sketch(const char *s, uint32_t n, int w_, int k_, float mid_occ_frac, const Anchor *mz_p, size_t mz_n)
+{
     k = k_, w = w_ < 1 ? 1 : w_, len = n;
     seq.resize(n);
     for (uint32_t i = 0; i < n; ++i) seq[i] = kNt4.t[(uint8_t)s[i]];
-    std::vector<Anchor> mz;
-    if (n > 0) mm_sketch(s, (int)n, w, k, 0, mz);
+    struct Span { const Anchor *p; size_t n; size_t size() const { return n; } const Anchor &operator[](size_t i) const { return p[i]; } } mz{mz_p, mz_n};
     // the bucketed hash tables of the reference (index.c:191-248) only define "hash -> positions
     // ascending"; a (hash, position) sort gives the same mapping
     std::vector<std::pair<uint64_t, uint64_t>> kv(mz.size());
@@ -916,6 +922,7 @@ void AlignJob::start(const RefIndex *r, const char *q, int ql, const Opt &o)
 {
     ref = r, qstr = q, qlen = ql, opt = o;
     finished = false, seeded = false, cur = 0;
+    pre_mz = nullptr, n_pre_mz = 0;
     regs.clear(); a.clear(); cache.done.clear(); cache.missing.clear();
 }
 
@@ -1110,7 +1117,8 @@ bool AlignJob::step()
         qseq.resize(qlen);
         for (int i = 0; i < qlen; ++i) qseq[i] = kNt4.t[(uint8_t)qstr[i]];
         std::vector<Anchor> mv;
-        if (qlen > 0) mm_sketch(qstr, qlen, ref->w, ref->k, 0, mv);
+        if (pre_mz) mv.assign(pre_mz, pre_mz + n_pre_mz);            // sketched by the caller (mm_sketch.hip)
+        else if (qlen > 0) mm_sketch(qstr, qlen, ref->w, ref->k, 0, mv);
         collect_seeds(*ref, mv, a);
         std::vector<uint64_t> u;
         chain_dp(opt, a, u);

@@ -58,6 +58,8 @@ struct RefIndex {
     std::vector<uint64_t> pos;         // per key: y values ascending (index.c:230)
     int32_t mid_occ = 0;
     void build(const char *s, uint32_t n, int w_, int k_, float mid_occ_frac);
+    // same, with the sequence's minimizers (mm_sketch order, rid 0) supplied by the caller
+    void build_from_sketch(const char *s, uint32_t n, int w_, int k_, float mid_occ_frac, const Anchor *mz, size_t n_mz);
     const uint64_t *get(uint64_t minier, int *n) const;   // mm_idx_get (index.c:81-98)
 };
 
@@ -108,6 +110,8 @@ struct AlignJob {
     int32_t n_a = 0;
     int cur = 0;                       // region being aligned in the skeleton loop
     bool seeded = false;
+    const Anchor *pre_mz = nullptr;    // the query's minimizers, when the caller sketched it (set after start())
+    size_t n_pre_mz = 0;
     DpCache cache;
     void start(const RefIndex *r, const char *q, int ql, const Opt &o);
     bool step();                       // true when finished; otherwise cache.missing is non-empty

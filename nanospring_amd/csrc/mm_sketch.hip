@@ -1,0 +1,344 @@
+// mm_sketch.hip -- minimizer sketches (mm_sketch, minimap2/sketch.c:77-143) of a batch of sequences on the GPU.
+//
+// The contig engine needs, per round, the (w,k)-minimizers of every changed consensus (the single-sequence index of
+// ConsensusGraph::alignRead, src/ConsensusGraph.cpp:186-198) and of every candidate read (mm_map's query sketch).
+// mm_sketch is written as a sequential state machine (ring buffer of the last w k-mer hashes, a running minimum, tie
+// and palindrome rules); run lane-per-sequence it is latency-bound (measured: 75 ms per batch).  Here it is restated
+// as data-parallel passes over the concatenated batch -- every statement of the state machine is a function of
+//   * the k-mer ending at a position (over the last k VALID bases: invalid bytes are skipped, not shifted in),
+//   * run = valid non-palindromic bases since the last invalid byte (two prefix sums and a running maximum),
+//   * the push sequence (what the reference writes into its ring: every position except palindromic k-mers), and
+//   * RM(p) = the right-most minimum of the last w pushes -- which is what the reference's `min` holds after push p:
+//     `<=` lets a newer equal hash win, and the ring re-scan picks the right-most smallest entry.
+// Outputs are then a per-push event list (old minimum replaced / slid out, ties at the first full window and after a
+// re-scan), counted, prefix-summed and written in order.  Pinned bit for bit against the reference's own object code
+// (tests/golden/mm_sketch_cases.npz, tests/test_mm_sketch_gpu.py).
+#include "common.hpp"
+#include "mm2.hpp"
+#include "host_util.hpp"
+#include <rocprim/rocprim.hpp>
+#include <algorithm>
+#include <cstring>
+
+namespace nsgpu {
+
+namespace {
+
+constexpr uint64_t kU64Max = ~0ull;
+
+__device__ __forceinline__ uint64_t hash64_masked_dev(uint64_t key, uint64_t mask)
+{
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+
+// seq_nt4_table restricted to what it distinguishes: ACGTU in either case and the raw codes 0..3
+__device__ __forceinline__ int nt4_dev(uint8_t ch)
+{
+    if (ch < 4) return ch;
+    switch (ch | 0x20) {
+    case 'a': return 0;
+    case 'c': return 1;
+    case 'g': return 2;
+    case 't': case 'u': return 3;
+    }
+    return 4;
+}
+
+// Layout: sequence s occupies positions soff[s] .. soff[s] + len[s] of the concatenated batch, followed by at least
+// one padding position up to the next multiple of 16 (a padding position is "invalid" for the run count, but pushes
+// nothing); soff[n] = B.
+struct Batch {
+    const uint8_t *seqs; const uint32_t *soff; const uint32_t *len; uint32_t n, B;
+    int w, k;
+};
+
+__global__ __launch_bounds__(256) void sk_block_owner_kernel(Batch b, uint32_t *__restrict__ sob)
+{
+    const uint32_t blk = blockIdx.x * 256 + threadIdx.x;
+    if (blk >= b.B / 16) return;
+    const uint32_t pos = blk * 16;
+    uint32_t lo = 0, hi = b.n;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (b.soff[mid] <= pos) lo = mid; else hi = mid; }
+    sob[blk] = lo;
+}
+
+// pass 1: valid flags and the "last invalid" markers
+__global__ __launch_bounds__(256) void sk_flags_kernel(Batch b, const uint32_t *__restrict__ sob, uint32_t *__restrict__ vf, uint32_t *__restrict__ mk)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i > b.B) return;
+    if (i == b.B) { vf[i] = 0; mk[i] = 0; return; }
+    const uint32_t s = sob[i >> 4];
+    const bool inlen = i - b.soff[s] < b.len[s];
+    const bool valid = inlen && nt4_dev(b.seqs[i]) < 4;
+    vf[i] = valid;
+    mk[i] = valid ? 0u : i + 1;
+}
+
+// pass 2: the valid bases, compacted
+__global__ __launch_bounds__(256) void sk_compact_kernel(Batch b, const uint32_t *__restrict__ vf, const uint32_t *__restrict__ vr, uint8_t *__restrict__ V)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= b.B || !vf[i]) return;
+    V[vr[i]] = (uint8_t)nt4_dev(b.seqs[i]);
+}
+
+// pass 3: k-mer over the last k valid bases of the sequence (fewer at its start: the reference starts from fw = rv = 0),
+// palindrome flag, strand and hash; flags "non-palindromic valid" and "pushes"
+__global__ __launch_bounds__(256) void sk_kmer_kernel(Batch b, const uint32_t *__restrict__ sob, const uint32_t *__restrict__ vf, const uint32_t *__restrict__ vr,
+                                                      const uint8_t *__restrict__ V, uint64_t *__restrict__ hk, uint32_t *__restrict__ npf, uint32_t *__restrict__ pushf)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i > b.B) return;
+    if (i == b.B) { npf[i] = 0; pushf[i] = 0; return; }
+    const uint32_t s = sob[i >> 4];
+    const bool inlen = i - b.soff[s] < b.len[s];
+    if (!vf[i]) { npf[i] = 0; pushf[i] = inlen; return; }
+    const uint32_t r = vr[i], lr = r - vr[b.soff[s]];
+    const int k = b.k;
+    const uint64_t shift1 = 2 * (uint64_t)(k - 1);
+    const int m = lr < (uint32_t)(k - 1) ? (int)lr : k - 1;
+    uint64_t fw = 0, rv = 0;
+    for (int t = 0; t <= m; ++t) {
+        const uint64_t c = V[r - t];
+        fw |= c << (2 * t);
+        rv |= (3ull ^ c) << (shift1 - 2 * t);
+    }
+    const bool pal = fw == rv;
+    const uint64_t strand = fw < rv ? 0 : 1, mask = (1ull << 2 * k) - 1;
+    hk[i] = hash64_masked_dev(strand ? rv : fw, mask) << 8 | strand;
+    npf[i] = !pal;
+    pushf[i] = !pal;
+}
+
+// pass 4: the push sequence: (x, y) the reference writes into its ring, and `run` at that moment
+__global__ __launch_bounds__(256) void sk_push_kernel(Batch b, const uint32_t *__restrict__ sob, const uint32_t *__restrict__ vf, const uint32_t *__restrict__ pushf,
+                                                      const uint32_t *__restrict__ pr, const uint32_t *__restrict__ npr, const uint32_t *__restrict__ linv,
+                                                      const uint64_t *__restrict__ hk, uint64_t *__restrict__ PX, uint64_t *__restrict__ PY, uint32_t *__restrict__ PRUN,
+                                                      uint32_t *__restrict__ PSEQ)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= b.B || !pushf[i]) return;
+    const uint32_t s = sob[i >> 4], p = pr[i];
+    uint64_t cx = kU64Max, cy = kU64Max;
+    uint32_t run = 0;
+    if (vf[i]) {
+        const uint32_t lm = linv[i];                        // position + 1 of the last invalid / padding byte before i (0: none)
+        run = npr[i] + 1 - (lm ? npr[lm - 1] : 0u);
+        if (run >= (uint32_t)b.k) {
+            const uint64_t h = hk[i];
+            cx = (h & ~0xffull) | (uint64_t)b.k;            // span = min(run before this base + 1, k) = k here
+            cy = (uint64_t)((i - b.soff[s]) << 1) | (h & 1);
+        }
+    }
+    PX[p] = cx; PY[p] = cy; PRUN[p] = run; PSEQ[p] = s;
+}
+
+// pass 5: rm[p] = push index of the right-most minimum of the window of push p, (p - w, p] clipped to the sequence.
+// A block stages its 256 pushes plus the w - 1 before them in LDS; every thread scans its window there.
+__global__ __launch_bounds__(256) void sk_window_min_kernel(Batch b, const uint64_t *__restrict__ PX, const uint32_t *__restrict__ PSEQ, const uint32_t *__restrict__ pr,
+                                                            uint32_t P, uint32_t *__restrict__ rm)
+{
+    __shared__ uint64_t tile[512];
+    const uint32_t b0 = blockIdx.x * 256, w = (uint32_t)b.w;
+    const uint32_t first = b0 >= w - 1 ? b0 - (w - 1) : 0;            // tile[j] = PX[first + j]
+    for (uint32_t j = threadIdx.x; j < 512; j += 256) { const uint32_t q = first + j; tile[j] = q < P && q < b0 + 256 ? PX[q] : kU64Max; }
+    __syncthreads();
+    const uint32_t p = b0 + threadIdx.x;
+    if (p >= P) return;
+    const uint32_t p0 = pr[b.soff[PSEQ[p]]];
+    const uint32_t lo = p - p0 >= w ? p - w + 1 : p0;
+    uint64_t bx = tile[p - first];
+    uint32_t bi = p;
+    for (uint32_t q = p; q > lo;) { --q; const uint64_t x = tile[q - first]; if (x < bx) bx = x, bi = q; }
+    rm[p] = bi;
+}
+
+// pass 6/7: the events of push p, in the reference's order.  WRITE = false counts them, WRITE = true writes them at o.
+template <bool WRITE>
+__device__ __forceinline__ uint32_t sk_events(const Batch &b, const uint64_t *__restrict__ PX, const uint64_t *__restrict__ PY, const uint32_t *__restrict__ PRUN,
+                                             const uint32_t *__restrict__ rm, uint32_t p, uint32_t p0, uint32_t p1, uint64_t *__restrict__ o)
+{
+    const uint32_t w = (uint32_t)b.w, k = (uint32_t)b.k;
+    const uint64_t cx = PX[p];
+    const uint32_t run = PRUN[p];
+    uint32_t cnt = 0;
+    auto emit = [&](uint32_t q) { if (WRITE) { o[2 * (size_t)cnt] = PX[q]; o[2 * (size_t)cnt + 1] = PY[q]; } ++cnt; };
+    // ties of the minimum (x, at push `self`) among pushes [lo, hi), oldest first
+    auto ties = [&](uint64_t x, uint32_t self, uint32_t lo, uint32_t hi_excl) { for (uint32_t q = lo; q < hi_excl; ++q) if (PX[q] == x && q != self) emit(q); };
+    const uint32_t lo_cur = p - p0 >= w ? p - w + 1 : p0;                  // window of push p: (p - w, p], clipped to the sequence
+    // `min` before this push: right-most minimum of the previous window (MAX before the first push)
+    uint64_t prev_x = kU64Max;
+    uint32_t prev_i = 0;
+    bool prev_at_expired = false;                                          // the reference's slot == min_slot: min sits in the slot being overwritten
+    if (p > p0) {
+        prev_i = rm[p - 1];
+        prev_x = PX[prev_i];
+        prev_at_expired = p - p0 >= w && prev_i == p - w;
+    }
+    if (run == w + k - 1 && prev_x != kU64Max) ties(prev_x, prev_i, lo_cur, p);             // first full window: older entries only
+    if (cx <= prev_x) {
+        if (run >= w + k && prev_x != kU64Max) emit(prev_i);
+    } else if (prev_at_expired) {
+        if (run >= w + k - 1 && prev_x != kU64Max) emit(prev_i);
+        const uint32_t now_i = rm[p];
+        const uint64_t now_x = PX[now_i];
+        if (run >= w + k - 1 && now_x != kU64Max) ties(now_x, now_i, lo_cur, p + 1);
+    }
+    if (p + 1 == p1) { const uint32_t now_i = rm[p]; if (PX[now_i] != kU64Max) emit(now_i); }   // the closing `if (min.x != UINT64_MAX) push(min)`
+    return cnt;
+}
+
+__global__ __launch_bounds__(256) void sk_count_kernel(Batch b, const uint64_t *__restrict__ PX, const uint64_t *__restrict__ PY, const uint32_t *__restrict__ PRUN,
+                                                       const uint32_t *__restrict__ PSEQ, const uint32_t *__restrict__ pr, const uint32_t *__restrict__ rm, uint32_t P,
+                                                       uint32_t *__restrict__ nout)
+{
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p > P) return;
+    if (p == P) { nout[p] = 0; return; }
+    const uint32_t s = PSEQ[p];
+    nout[p] = sk_events<false>(b, PX, PY, PRUN, rm, p, pr[b.soff[s]], pr[b.soff[s + 1]], nullptr);
+}
+
+__global__ __launch_bounds__(256) void sk_write_kernel(Batch b, const uint64_t *__restrict__ PX, const uint64_t *__restrict__ PY, const uint32_t *__restrict__ PRUN,
+                                                       const uint32_t *__restrict__ PSEQ, const uint32_t *__restrict__ pr, const uint32_t *__restrict__ rm, uint32_t P,
+                                                       const uint32_t *__restrict__ oscan, uint64_t *__restrict__ out)
+{
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P || oscan[p + 1] == oscan[p]) return;
+    const uint32_t s = PSEQ[p];
+    sk_events<true>(b, PX, PY, PRUN, rm, p, pr[b.soff[s]], pr[b.soff[s + 1]], out + 2 * (size_t)oscan[p]);
+}
+
+// output offset of every sequence = events before its first push
+__global__ __launch_bounds__(256) void sk_offsets_kernel(Batch b, const uint32_t *__restrict__ pr, const uint32_t *__restrict__ oscan, uint64_t *__restrict__ off)
+{
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s > b.n) return;
+    off[s] = oscan[pr[b.soff[s]]];
+}
+
+}  // namespace
+
+static int pinned_reserve(uint8_t *&p, size_t &cap, size_t want)
+{
+    if (cap >= want) return NSGPU_OK;
+    if (p) NS_HIP(hipHostFree(p));
+    p = nullptr, cap = 0;
+    const size_t sz = want * 3 / 2 + 4096;
+    NS_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), sz, hipHostMallocDefault));
+    cap = sz;
+    return NSGPU_OK;
+}
+
+template <class Op>
+static int scan_u32(nsgpu_ctx::SketchWs &W, hipStream_t st, const uint32_t *in, uint32_t *out, size_t n, bool inclusive_max, Op)
+{
+    size_t ws = 0;
+    if (inclusive_max) {
+        NS_HIP(rocprim::inclusive_scan(nullptr, ws, in, out, n, rocprim::maximum<uint32_t>(), st));
+        NS_TRY(W.scan_ws.reserve(ws + 16));
+        NS_HIP(rocprim::inclusive_scan(W.scan_ws.p, ws, in, out, n, rocprim::maximum<uint32_t>(), st));
+    } else {
+        NS_HIP(rocprim::exclusive_scan(nullptr, ws, in, out, 0u, n, rocprim::plus<uint32_t>(), st));
+        NS_TRY(W.scan_ws.reserve(ws + 16));
+        NS_HIP(rocprim::exclusive_scan(W.scan_ws.p, ws, in, out, 0u, n, rocprim::plus<uint32_t>(), st));
+    }
+    return NSGPU_OK;
+}
+
+int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off)
+{
+    const size_t n = reqs.size();
+    out_off.assign(n + 1, 0);
+    out = nullptr;
+    if (n == 0) return NSGPU_OK;
+    NS_CHECK(k > 0 && k <= 28 && w > 0 && w < 256, NSGPU_ERR_ARG, "minimap k must be in 1..28 and w in 1..255 (sketch.c:84)");
+    const double t0 = now_ms();
+    nsgpu_ctx::SketchWs &W = c->sws;
+    const hipStream_t st = c->stream;
+    std::vector<uint32_t> soff(n + 1), len(n);
+    uint64_t bytes = 0;
+    for (size_t i = 0; i < n; ++i) {
+        NS_CHECK(reqs[i].len < (1ull << 31), NSGPU_ERR_RANGE, "sequence %zu longer than 2^31", i);
+        soff[i] = (uint32_t)bytes;
+        len[i] = (uint32_t)reqs[i].len;
+        bytes += (reqs[i].len + 16) & ~(uint64_t)15;                   // at least one padding position after every sequence
+        NS_CHECK(bytes < (1ull << 31), NSGPU_ERR_RANGE, "sketch batch exceeds 2 GiB of sequence; use smaller batches");
+    }
+    soff[n] = (uint32_t)bytes;
+    const uint32_t B = (uint32_t)bytes;
+    // sequences through pinned memory, one H2D copy (padding bytes are never interpreted)
+    NS_TRY(pinned_reserve(W.h_seqs, W.h_cap, bytes + 16));
+    par_for(n, [&](size_t i) { memcpy(W.h_seqs + soff[i], reqs[i].ptr, reqs[i].len); });
+    DevBuf *u32bufs[] = {&W.vf, &W.mk, &W.vr, &W.linv, &W.npf, &W.pushf, &W.npr, &W.pr};
+    for (DevBuf *b : u32bufs) NS_TRY(b->reserve(((size_t)B + 2) * 4));
+    NS_TRY(W.seqs.reserve(bytes + 64));
+    NS_TRY(W.soff.reserve((n + 1) * 4));
+    NS_TRY(W.len.reserve(n * 4 + 4));
+    NS_TRY(W.sob.reserve(((size_t)B / 16 + 1) * 4));
+    NS_TRY(W.V.reserve((size_t)B + 64));
+    NS_TRY(W.hk.reserve(((size_t)B + 1) * 8));
+    NS_HIP(hipMemcpyAsync(W.seqs.p, W.h_seqs, bytes, hipMemcpyHostToDevice, st));
+    NS_HIP(hipMemcpyAsync(W.soff.p, soff.data(), (n + 1) * 4, hipMemcpyHostToDevice, st));
+    NS_HIP(hipMemcpyAsync(W.len.p, len.data(), n * 4, hipMemcpyHostToDevice, st));
+    const Batch bt{W.seqs.as<uint8_t>(), W.soff.as<uint32_t>(), W.len.as<uint32_t>(), (uint32_t)n, B, w, k};
+    const uint32_t gB = (B + 1 + 255) / 256;
+    hipLaunchKernelGGL(sk_block_owner_kernel, dim3((B / 16 + 255) / 256), dim3(256), 0, st, bt, W.sob.as<uint32_t>());
+    hipLaunchKernelGGL(sk_flags_kernel, dim3(gB), dim3(256), 0, st, bt, W.sob.as<uint32_t>(), W.vf.as<uint32_t>(), W.mk.as<uint32_t>());
+    NS_HIP(hipGetLastError());
+    NS_TRY(scan_u32(W, st, W.vf.as<uint32_t>(), W.vr.as<uint32_t>(), (size_t)B + 1, false, 0));
+    NS_TRY(scan_u32(W, st, W.mk.as<uint32_t>(), W.linv.as<uint32_t>(), (size_t)B + 1, true, 0));
+    hipLaunchKernelGGL(sk_compact_kernel, dim3(gB), dim3(256), 0, st, bt, W.vf.as<uint32_t>(), W.vr.as<uint32_t>(), W.V.as<uint8_t>());
+    hipLaunchKernelGGL(sk_kmer_kernel, dim3(gB), dim3(256), 0, st, bt, W.sob.as<uint32_t>(), W.vf.as<uint32_t>(), W.vr.as<uint32_t>(), W.V.as<uint8_t>(),
+                       W.hk.as<uint64_t>(), W.npf.as<uint32_t>(), W.pushf.as<uint32_t>());
+    NS_HIP(hipGetLastError());
+    NS_TRY(scan_u32(W, st, W.npf.as<uint32_t>(), W.npr.as<uint32_t>(), (size_t)B + 1, false, 0));
+    NS_TRY(scan_u32(W, st, W.pushf.as<uint32_t>(), W.pr.as<uint32_t>(), (size_t)B + 1, false, 0));
+    uint32_t P = 0;                                                      // pushes of the whole batch
+    NS_HIP(hipMemcpyAsync(&P, W.pr.as<uint32_t>() + B, 4, hipMemcpyDeviceToHost, st));
+    NS_HIP(hipStreamSynchronize(st));
+    NS_TRY(W.PX.reserve(((size_t)P + 1) * 8));
+    NS_TRY(W.PY.reserve(((size_t)P + 1) * 8));
+    NS_TRY(W.PRUN.reserve(((size_t)P + 2) * 4));
+    NS_TRY(W.PSEQ.reserve(((size_t)P + 2) * 4));
+    NS_TRY(W.nout.reserve(((size_t)P + 2) * 4));
+    NS_TRY(W.rm.reserve(((size_t)P + 2) * 4));
+    NS_TRY(W.oscan.reserve(((size_t)P + 2) * 4));
+    NS_TRY(W.off.reserve((n + 1) * 8));
+    const uint32_t gP = (P + 1 + 255) / 256;
+    hipLaunchKernelGGL(sk_push_kernel, dim3(gB), dim3(256), 0, st, bt, W.sob.as<uint32_t>(), W.vf.as<uint32_t>(), W.pushf.as<uint32_t>(), W.pr.as<uint32_t>(),
+                       W.npr.as<uint32_t>(), W.linv.as<uint32_t>(), W.hk.as<uint64_t>(), W.PX.as<uint64_t>(), W.PY.as<uint64_t>(), W.PRUN.as<uint32_t>(),
+                       W.PSEQ.as<uint32_t>());
+    hipLaunchKernelGGL(sk_window_min_kernel, dim3(gP), dim3(256), 0, st, bt, W.PX.as<uint64_t>(), W.PSEQ.as<uint32_t>(), W.pr.as<uint32_t>(), P, W.rm.as<uint32_t>());
+    hipLaunchKernelGGL(sk_count_kernel, dim3(gP), dim3(256), 0, st, bt, W.PX.as<uint64_t>(), W.PY.as<uint64_t>(), W.PRUN.as<uint32_t>(), W.PSEQ.as<uint32_t>(),
+                       W.pr.as<uint32_t>(), W.rm.as<uint32_t>(), P, W.nout.as<uint32_t>());
+    NS_HIP(hipGetLastError());
+    NS_TRY(scan_u32(W, st, W.nout.as<uint32_t>(), W.oscan.as<uint32_t>(), (size_t)P + 1, false, 0));
+    hipLaunchKernelGGL(sk_offsets_kernel, dim3(((uint32_t)n + 1 + 255) / 256), dim3(256), 0, st, bt, W.pr.as<uint32_t>(), W.oscan.as<uint32_t>(), W.off.as<uint64_t>());
+    NS_HIP(hipGetLastError());
+    NS_HIP(hipMemcpyAsync(out_off.data(), W.off.p, (n + 1) * 8, hipMemcpyDeviceToHost, st));
+    NS_HIP(hipStreamSynchronize(st));
+    const uint64_t total = out_off[n];
+    NS_TRY(W.out.reserve(total * 16 + 16));
+    NS_TRY(pinned_reserve(W.h_out, W.h_out_cap, total * 16 + 16));
+    if (total) {
+        hipLaunchKernelGGL(sk_write_kernel, dim3(gP), dim3(256), 0, st, bt, W.PX.as<uint64_t>(), W.PY.as<uint64_t>(), W.PRUN.as<uint32_t>(), W.PSEQ.as<uint32_t>(),
+                           W.pr.as<uint32_t>(), W.rm.as<uint32_t>(), P, W.oscan.as<uint32_t>(), W.out.as<uint64_t>());
+        NS_HIP(hipGetLastError());
+        NS_HIP(hipMemcpyAsync(W.h_out, W.out.p, total * 16, hipMemcpyDeviceToHost, st));
+    }
+    NS_HIP(hipStreamSynchronize(st));
+    out = reinterpret_cast<const mm2::Anchor *>(W.h_out);
+    c->sketch_mm_ms += now_ms() - t0;
+    return NSGPU_OK;
+}
+
+}  // namespace nsgpu

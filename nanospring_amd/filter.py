@@ -280,6 +280,21 @@ class AlignStats(C.Structure):
 EDIT_DT = np.dtype([("type", np.uint8), ("base", np.uint8), ("reserved", np.uint16), ("num", np.uint32)])
 
 
+def mm_sketch_batch(gpu, seqs, w=50, k=20):
+    """mm_sketch (minimap2/sketch.c:77-143, rid 0) of a batch of sequences on the GPU.  seqs: list of str or a
+    (bases, off) tuple.  Returns a list of (n_i, 2) uint64 arrays (x, y) in the reference's output order."""
+    sb, so = seqs if isinstance(seqs, tuple) else _concat(seqs)
+    n = len(so) - 1
+    px, po = C.c_void_p(), C.c_void_p()
+    check(gpu.lib, gpu.lib.nsgpu_mm_sketch_batch(gpu.ctx, _ptr(sb), _ptr(so), n, w, k, C.byref(px), C.byref(po)))
+    off = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+    tot = int(off[n])
+    xy = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_uint64)), shape=(max(tot, 1) * 2,))[:tot * 2].copy().reshape(-1, 2)
+    gpu.lib.nsgpu_free(px)
+    gpu.lib.nsgpu_free(po)
+    return [xy[int(off[i]):int(off[i + 1])] for i in range(n)]
+
+
 def align_batch(gpu, refs, queries, pair_ref):
     """ConsensusGraph::alignRead for a batch: refs/queries are lists of str (or (bases, off) tuples),
     pair_ref[i] = index of the reference of query i.  Returns a list of dicts with alignRead's outputs

@@ -146,13 +146,61 @@ def align_case():
     v = np.array(vals)
     print("align_pairs.npz:", len(ps), "pairs,", int((v[:, 0] > 0).sum()), "with hits,", int((v[:, 0] > 1).sum()), "multi-hit")
 
+def sketch_cases(seed=77):
+    """Sequences for mm_sketch: random DNA, reads with N / lowercase / other bytes, tandem repeats and homopolymers
+    (hash ties inside a window), palindrome-rich stretches (the strand-unknown `continue`), lengths around k and w+k."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for it in range(48):
+        ln = int(rng.choice([0, 1, 7, 19, 20, 21, 68, 69, 70, 71, 200, 1500, 6000, 15000]))
+        s = "".join("ACGT"[i] for i in rng.randint(0, 4, size=ln))
+        if it % 5 == 1 and ln > 30:
+            p = rng.randint(0, ln - 20)
+            s = s[:p] + "N" * int(rng.randint(1, 12)) + s[p:]
+        if it % 7 == 2:
+            s = s.lower()
+        if it % 7 == 3 and ln > 10:
+            s = s[:ln // 2] + "xU-u" + s[ln // 2:]
+        if it % 6 == 4:
+            unit = "".join("ACGT"[i] for i in rng.randint(0, 4, size=int(rng.randint(1, 40))))
+            s = s[:ln // 3] + unit * int(rng.randint(5, 120)) + s[ln // 3:]
+        if it % 9 == 0:
+            s = "AT" * int(rng.randint(5, 200)) + s
+        if it % 11 == 5:
+            s = s + "A" * int(rng.randint(30, 400)) + s[:50]
+        out.append(s)
+    return out
+
+
+SKETCH_WK = [(50, 20), (10, 15), (5, 11), (1, 8), (255, 28), (19, 28), (64, 20), (65, 17)]
+
+
+def sketch_case():
+    """sequences -> the reference's mm_sketch output (minimap2/sketch.c via oracle/_ref/libmm2ref.so), for the
+    (w, k) pairs of SKETCH_WK: the golden vectors of the batched GPU sketch."""
+    seqs = sketch_cases()
+    sb, so = oracle_lib.concat(seqs)
+    xs, offs = [], [0]
+    for w, k in SKETCH_WK:
+        for s in seqs:
+            # the reference asserts len > 0 (sketch.c:84); its callers skip empty sequences
+            xy = oracle_lib.ref_mm_sketch(s, w, k) if s else np.zeros((0, 2), dtype=np.uint64)
+            xs.append(xy.reshape(-1))
+            offs.append(offs[-1] + len(xy))
+    np.savez_compressed(os.path.join(HERE, "mm_sketch_cases.npz"), bases=sb[:int(so[-1])], off=so, wk=np.array(SKETCH_WK, dtype=np.int32),
+                        xy=np.concatenate(xs).astype(np.uint64), xy_off=np.array(offs, dtype=np.int64))
+    print("mm_sketch_cases.npz:", len(seqs), "sequences x", len(SKETCH_WK), "(w,k) pairs,", offs[-1], "minimizers")
+
+
 if __name__ == "__main__":
     if not oracle_lib.have_nsref():
         sys.exit("oracle/_ref/nsref missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["minhash", "ksw2", "align"]
+    which = sys.argv[1:] or ["minhash", "ksw2", "align", "sketch"]
     if "minhash" in which:
         minhash_case()
     if "ksw2" in which:
         ksw2_case()
     if "align" in which:
         align_case()
+    if "sketch" in which:
+        sketch_case()
