@@ -227,6 +227,11 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
     size_t ei = 0;                                   // edgeInPath
     Node *node_in_path = main_edges[0]->source;
     Node *cur = nullptr, *initial = nullptr;
+    // main-path indices (node j = main_edges[j-1]->sink) where this read leaves the path over a side edge: the only
+    // nodes whose greedy choice the update can change (see calculate_main_path_greedy)
+    diverged_.clear();
+    touch_lo_ = (size_t)-1;                          // first main-path node whose out-edges this read changes (its first SAME)
+    ssize_t cur_main = -1;                           // main-path index of `cur` while it is a main-path node reached by SAME
 
     if (begin_offset >= 0 || end_offset >= 0) {
         right_off_ = (size_t)std::max((ssize_t)left_off_, std::min((ssize_t)right_off_, begin_offset));
@@ -256,6 +261,7 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
         }
     }
     auto insert_node = [&](char base) {
+        if (cur_main >= 0) diverged_.push_back((size_t)cur_main), cur_main = -1;
         if (!cur) {
             cur = create_node(base);
             initial = cur;
@@ -270,13 +276,18 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
         if (op.type == 0) {                          // SAME
             if (!cur) initial = cur = node_in_path;
             else {
+                if (cur_main >= 0 && (size_t)cur_main + 1 != ei) diverged_.push_back((size_t)cur_main);   // a jump over deleted main-path nodes
                 Edge *e = cur->edge_to(node_in_path);
                 if (e) e->add_read(arena_, id);
                 else e = create_edge(cur, node_in_path, id);
                 cur = node_in_path;
             }
+            cur_main = (ssize_t)ei;
+            if (touch_lo_ == (size_t)-1) touch_lo_ = ei;
             advance();
             for (size_t i = 1; i < op.num; ++i) {
+                // the walk touches one edge (one cache line) per base, in main-path order: fetch ahead
+                if (ei + 12 < n_path_edges) __builtin_prefetch(main_edges[ei + 12], 1, 1);
                 // cur and node_in_path are consecutive main-path nodes here, and edges are unique per (source, sink)
                 // (update_graph looks before it creates; split_path only adds edges out of fresh nodes), so the edge
                 // getEdgeTo() would find is the main-path edge itself
@@ -284,6 +295,7 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
                               ? main_edges[ei - 1] : cur->edge_to(node_in_path);
                 e->add_read(arena_, id);
                 cur = node_in_path;
+                cur_main = (ssize_t)ei;
                 advance();
             }
         } else if (op.type == 2) advance();          // DELETE
@@ -315,49 +327,104 @@ void ContigGraph::calculate_main_path_greedy()
 {
     static const bool no_splice = getenv("NSGPU_NO_TAIL_SPLICE") != nullptr;     // debugging aid: always re-walk the tail
     const size_t m = main_edges.size();
-    const bool try_splice = !no_splice && have_touch_ && left_off_ == 0 && m > 0 && touch_idx_ < m && right_off_ <= touch_idx_ &&
-                            consistent_from_ != (size_t)-1 && consistent_from_ <= touch_idx_ + 1;
+    const size_t dbg_R = right_off_, dbg_L = left_off_, dbg_cf = consistent_from_;
+    // Main-path nodes the update touched but that lie in the part the reference keeps as it is ([left_off_, right_off_))
+    // are not re-walked: their choice may now differ from best_out, and they stop counting as consistent.
+    if (have_touch_ && touch_lo_ != (size_t)-1 && right_off_ >= 1 && consistent_from_ != (size_t)-1) {
+        const size_t hi = touch_idx_ < right_off_ - 1 ? touch_idx_ : right_off_ - 1, lo = touch_lo_ > left_off_ ? touch_lo_ : left_off_;
+        if (lo <= hi && consistent_from_ < hi + 1) consistent_from_ = hi + 1;
+    }
+    const bool try_splice = !no_splice && have_touch_ && left_off_ == 0 && m > 0 && right_off_ <= m && consistent_from_ != (size_t)-1;
     have_touch_ = false;
     if (try_splice) {
-        // ---- exact shortcut: keep the untouched part of the old tail aside, re-walk only up to where the walk re-joins it ----
-        const size_t R = right_off_, T = touch_idx_;          // node j (j >= 1) = main_edges[j-1]->sink
-        std::vector<Edge *> saved(main_edges.begin() + T, main_edges.end());     // saved[i]->sink = node T+1+i
-        const std::string saved_str = main_path.substr(T + 1);
-        for (size_t i = 0; i < saved.size(); ++i) saved[i]->sink->mark = (uint32_t)i;
-        for (size_t i = R; i < T; ++i) set_on_main(main_edges[i]->sink, false);          // nodes R+1 .. T
-        main_edges.erase(main_edges.begin() + R, main_edges.end());
-        main_path.erase(main_path.begin() + R + 1, main_path.end());
-        Node *cur = right_unchanged_;
-        Edge *e;
-        bool joined = false;
-        while ((e = cur->best_out())) {
-            Node *nx = e->sink;
-            main_edges.push_back(e);
-            main_path.push_back(nx->base);
-            if (nx->on_main) {                                  // a node of the kept tail (everything else was cleared)
-                const size_t j = nx->mark;
-                for (size_t i = 0; i < j; ++i) set_on_main(saved[i]->sink, false);       // by-passed tail nodes
-                main_edges.insert(main_edges.end(), saved.begin() + j + 1, saved.end());
-                main_path.append(saved_str, j + 1, std::string::npos);
-                ++dbg_spliced; dbg_spliced_nodes += saved.size() - j - 1;
-                static const bool dbg_chk = getenv("NSGPU_SPLICE_CHECK") != nullptr;
-                if (dbg_chk) {
-                    Node *c2 = nx;
-                    for (size_t i = j + 1; i < saved.size(); ++i) {
-                        Edge *b = c2->best_out();
-                        if (b != saved[i]) { fprintf(stderr, "SPLICE MISMATCH at tail pos %zu of %zu (j=%zu T=%zu R=%zu m=%zu): best count %u saved count %u nout %zu\n", i, saved.size(), j, T, R, m, b ? b->count : 0, saved[i]->count, c2->out.size()); break; }
-                        c2 = saved[i]->sink;
-                    }
-                    if (c2->best_out() && c2 == saved.back()->sink) fprintf(stderr, "SPLICE: tail end has a best_out now\n");
-                }
-                joined = true;
-                break;
-            }
-            cur = nx;
-            set_on_main(cur, true);
-            ++dbg_walked_nodes;
+        // ---- exact shortcut: re-walk only where the greedy choice can have changed ----
+        // The old path from index consistent_from_ on was chosen by best_out on the counts of its time.  The update
+        // since then added one read: along main-path edges it raises the count of the edge that was already the
+        // (first) maximum, so the choice stands; only where the read left the path over a side edge (diverged_) can
+        // another edge win.  Those nodes, the nodes of [right_off_, consistent_from_) and the old end are checked;
+        // a changed choice is followed until it re-joins the old path (or ends), and everything between is re-used.
+        const size_t R = right_off_;
+        std::vector<size_t> &cand = cand_;
+        cand.clear();
+        const size_t chk_end = consistent_from_ < m + 1 ? consistent_from_ : m + 1;
+        for (size_t i = R; i < chk_end; ++i) cand.push_back(i);
+        for (size_t d : diverged_) if (d >= R && d >= chk_end && d <= m && (cand.empty() || cand.back() < d)) cand.push_back(d);
+        if (cand.empty() || cand.back() != m) cand.push_back(m);
+        auto old_node = [&](size_t i) { return i == 0 ? main_edges[0]->source : main_edges[i - 1]->sink; };
+        // first candidate whose choice changed (nothing to do before it)
+        size_t ci = 0;
+        for (; ci < cand.size(); ++ci) {
+            const size_t c = cand[ci];
+            if (old_node(c)->best_out() != (c < m ? main_edges[c] : nullptr)) break;
         }
-        if (!joined) for (Edge *se : saved) set_on_main(se->sink, false);
+        if (ci < cand.size()) {
+            const size_t c0 = cand[ci];
+            std::vector<Edge *> &saved = saved_;                         // saved[t] = old edge c0 + t, its sink = old node c0 + t + 1
+            saved.assign(main_edges.begin() + c0, main_edges.end());
+            const std::string saved_str = main_path.substr(c0 + 1);
+            Node *at = old_node(c0);
+            main_edges.erase(main_edges.begin() + c0, main_edges.end());
+            main_path.erase(main_path.begin() + c0 + 1, main_path.end());
+            size_t pos = c0;                                             // the new path so far ends at old node `pos` (== at)
+            bool ended = false;
+            for (; ci < cand.size() && !ended; ++ci) {
+                const size_t c = cand[ci];
+                if (c < pos) continue;                                   // by-passed by an earlier detour
+                // old nodes pos .. c keep their edges
+                main_edges.insert(main_edges.end(), saved.begin() + (pos - c0), saved.begin() + (c - c0));
+                main_path.append(saved_str, pos - c0, c - pos);
+                if (c > pos) at = saved[c - c0 - 1]->sink;
+                pos = c;
+                Edge *e = at->best_out();
+                if (e == (c < m ? saved[c - c0] : nullptr)) continue;
+                // detour: follow the greedy walk until it meets the old path again
+                ++dbg_spliced;
+                for (;;) {
+                    if (!e) {                                            // the path ends here: the rest of the old path is off
+                        for (size_t t = pos - c0; t < saved.size(); ++t) set_on_main(saved[t]->sink, false);
+                        ended = true;
+                        break;
+                    }
+                    Node *nx = e->sink;
+                    main_edges.push_back(e);
+                    main_path.push_back(nx->base);
+                    ++dbg_walked_nodes;
+                    if (nx->on_main) {                                   // an old-path node further down (everything else is off the path)
+                        size_t j = pos + 1;
+                        while (saved[j - c0 - 1]->sink != nx) ++j;
+                        for (size_t t = pos + 1; t < j; ++t) set_on_main(saved[t - c0 - 1]->sink, false);
+                        pos = j, at = nx;
+                        break;
+                    }
+                    set_on_main(nx, true);
+                    at = nx;
+                    e = at->best_out();
+                }
+            }
+            if (!ended) {
+                main_edges.insert(main_edges.end(), saved.begin() + (pos - c0), saved.end());
+                main_path.append(saved_str, pos - c0, std::string::npos);
+                dbg_spliced_nodes += saved.size() - (pos - c0);
+            }
+        }
+        static const bool dbg_chk = getenv("NSGPU_SPLICE_CHECK") != nullptr;
+        if (dbg_chk) {                                                   // brute force: the plain walk from R must give the same edges
+            Node *c2 = old_node(R < main_edges.size() + 1 ? R : 0);
+            for (size_t i = R; ; ++i) {
+                Edge *bo = c2->best_out();
+                Edge *have = i < main_edges.size() ? main_edges[i] : nullptr;
+                if (bo != have) {
+                    fprintf(stderr, "SPLICE MISMATCH at index %zu of %zu (R=%zu m=%zu cf=%zu chk_end=%zu touch=%zu)\n", i, main_edges.size(), R, m, consistent_from_, chk_end, touch_idx_);
+                    fprintf(stderr, "  cand tail:"); for (size_t q = cand.size() > 8 ? cand.size() - 8 : 0; q < cand.size(); ++q) fprintf(stderr, " %zu", cand[q]);
+                    fprintf(stderr, "\n  diverged tail:"); for (size_t q = diverged_.size() > 8 ? diverged_.size() - 8 : 0; q < diverged_.size(); ++q) fprintf(stderr, " %zu", diverged_[q]);
+                    fprintf(stderr, "\n  out-edges of node:"); for (Edge *oe : c2->out) fprintf(stderr, " [cnt %u sink_main %d %s%s]", oe->count, (int)oe->sink->on_main, oe == bo ? "best" : "", oe == have ? "have" : "");
+                    fprintf(stderr, "\n");
+                    break;
+                }
+                if (!bo) break;
+                c2 = bo->sink;
+            }
+        }
         const read_t ending = *main_edges.back()->reads.begin();
         const GraphRead &er = reads.at(ending);
         end_pos = er.pos + (long)er.len;
@@ -408,6 +475,14 @@ void ContigGraph::calculate_main_path_greedy()
     right_off_ = main_edges.size();
     left_unchanged_ = main_edges.front()->source;
     left_off_ = 0;
+    static const bool dbg_inv = getenv("NSGPU_SPLICE_CHECK") != nullptr;
+    if (dbg_inv && consistent_from_ != (size_t)-1) {
+        for (size_t i = consistent_from_; i <= main_edges.size(); ++i) {
+            Node *nd = i == 0 ? main_edges[0]->source : main_edges[i - 1]->sink;
+            Edge *bo = nd->best_out(), *have = i < main_edges.size() ? main_edges[i] : nullptr;
+            if (bo != have) { fprintf(stderr, "INVARIANT broken at index %zu of %zu (cf=%zu, spliced=%d, splits %d, call %llu; before: m=%zu R=%zu L=%zu cf=%zu touch=%zu)\n", i, main_edges.size(), consistent_from_, (int)try_splice, (int)(n_splits_ != splits_before), (unsigned long long)dbg_cycles_calls, m, dbg_R, dbg_L, dbg_cf, touch_idx_); break; }
+        }
+    }
 }
 
 void ContigGraph::remove_cycles()
@@ -557,9 +632,16 @@ void ContigGraph::collect_path(const GraphRead &r, read_t id, const ReadBases *s
         const char c = fw[L - 1 - i];
         return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
     };
+    const size_t n_main = main_edges.size();
     for (size_t i = 0; i < L; ++i) {
         path.push_back(cur);
         if (i + 1 == L) break;
+        if (cur->on_main) {
+            // a read mostly follows the consensus: fetch the edge 12 and the node 6 steps down the main path (cum_weight
+            // is the node's main-path index, set by write_reads)
+            const size_t j = cur->cum_weight;
+            if (j + 12 < n_main) { __builtin_prefetch(main_edges[j + 12], 0, 1); __builtin_prefetch(main_edges[j + 6]->sink, 0, 1); }
+        }
         const auto &out = cur->out;
         if (out.size() == 1) { cur = out[0]->sink; continue; }
         const char nb = base_at(i + 1);

@@ -182,7 +182,9 @@ private:
     // tail re-use (exact shortcut of calculate_main_path_greedy): node indices > touch_idx_ were not modified by the
     // last update_graph; if in addition the previous remove_cycles re-routed nothing, the old path beyond the point
     // where the greedy walk re-joins it is what the walk would produce again
-    size_t touch_idx_ = 0;
+    size_t touch_idx_ = 0, touch_lo_ = (size_t)-1;
+    std::vector<size_t> diverged_, cand_;     // main-path indices where the last update left the path / to re-check
+    std::vector<Edge *> saved_;
     bool have_touch_ = false;
     size_t consistent_from_ = (size_t)-1;     // main-path nodes with index >= this were chosen by best_out on the current counts
     uint64_t n_splits_ = 0;
