@@ -335,6 +335,7 @@ void ContigGraph::calculate_main_path_greedy()
         if (lo <= hi && consistent_from_ < hi + 1) consistent_from_ = hi + 1;
     }
     const bool try_splice = !no_splice && have_touch_ && left_off_ == 0 && m > 0 && right_off_ <= m && consistent_from_ != (size_t)-1;
+    if (!try_splice) { static const bool dbg_r = getenv("NSGPU_SPLICE_REASON") != nullptr; if (dbg_r) fprintf(stderr, "FULL %s m=%zu R=%zu L=%zu\n", !have_touch_ ? "first" : left_off_ != 0 ? "left" : consistent_from_ == (size_t)-1 ? "split" : "other", m, right_off_, left_off_); }
     have_touch_ = false;
     if (try_splice) {
         // ---- exact shortcut: re-walk only where the greedy choice can have changed ----
@@ -470,7 +471,11 @@ void ContigGraph::calculate_main_path_greedy()
     const auto tc0 = std::chrono::steady_clock::now();
     remove_cycles();
     dbg_cycles_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
-    if (n_splits_ != splits_before) consistent_from_ = (size_t)-1;   // a re-routing may change greedy choices anywhere on the path
+    // A re-routing (split_path) leaves best_out of every consistent main-path node as it was: at a main-path source it
+    // replaces a side edge by a new edge with the same reads at the END of the out list (the main edge, being the first
+    // maximum, stays the first maximum); deeper levels only touch edges out of side nodes and edges INTO main nodes.
+    static const bool split_invalidates = getenv("NSGPU_SPLIT_INVALIDATES") != nullptr;      // debugging aid: the old, conservative rule
+    if (split_invalidates && n_splits_ != splits_before) consistent_from_ = (size_t)-1;
     right_unchanged_ = main_edges.back()->sink;
     right_off_ = main_edges.size();
     left_unchanged_ = main_edges.front()->source;
