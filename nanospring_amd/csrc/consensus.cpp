@@ -372,7 +372,7 @@ void ContigGraph::calculate_main_path_greedy()
                 const size_t c = cand[ci];
                 if (c < pos) continue;                                   // by-passed by an earlier detour
                 // old nodes pos .. c keep their edges
-                main_edges.insert(main_edges.end(), saved.begin() + (pos - c0), saved.begin() + (c - c0));
+                main_edges.append(saved.begin() + (pos - c0), saved.begin() + (c - c0));
                 main_path.append(saved_str, pos - c0, c - pos);
                 if (c > pos) at = saved[c - c0 - 1]->sink;
                 pos = c;
@@ -403,7 +403,7 @@ void ContigGraph::calculate_main_path_greedy()
                 }
             }
             if (!ended) {
-                main_edges.insert(main_edges.end(), saved.begin() + (pos - c0), saved.end());
+                main_edges.append(saved.begin() + (pos - c0), saved.end());
                 main_path.append(saved_str, pos - c0, std::string::npos);
                 dbg_spliced_nodes += saved.size() - (pos - c0);
             }

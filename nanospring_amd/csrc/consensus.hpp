@@ -146,13 +146,45 @@ void write_var_uint32(uint32_t v, std::string &out);   // src/DirectoryUtils.cpp
 struct GraphRead { long pos; Node *start; size_t len; bool rc; };
 struct ReadBases { const char *bases; size_t len; };   // a read as stored (forward orientation)
 
+// The main path's edges: contiguous (index = position on the path, plain pointer arithmetic in the per-base loops),
+// cheap at both ends (the path grows to the right read by read, and now and then to the left).
+class EdgePath {
+public:
+    size_t size() const { return v_.size() - off_; }
+    bool empty() const { return size() == 0; }
+    Edge **begin() { return v_.data() + off_; }
+    Edge **end() { return v_.data() + v_.size(); }
+    Edge *const *begin() const { return v_.data() + off_; }
+    Edge *const *end() const { return v_.data() + v_.size(); }
+    Edge *&operator[](size_t i) { return v_[off_ + i]; }
+    Edge *operator[](size_t i) const { return v_[off_ + i]; }
+    Edge *front() const { return v_[off_]; }
+    Edge *back() const { return v_.back(); }
+    void push_back(Edge *e) { v_.push_back(e); }
+    void push_front(Edge *e)
+    {
+        if (off_ == 0) { const size_t slack = size() / 2 + 64; v_.insert(v_.begin(), slack, nullptr); off_ = slack; }
+        v_[--off_] = e;
+    }
+    void erase(Edge **first, Edge **last)
+    {
+        if (first == last) return;
+        if (first == begin()) { off_ += (size_t)(last - first); if (off_ == v_.size()) v_.clear(), off_ = 0; return; }
+        v_.erase(v_.begin() + (first - v_.data()), v_.begin() + (last - v_.data()));
+    }
+    template <class It> void append(It first, It last) { v_.insert(v_.end(), first, last); }
+private:
+    std::vector<Edge *> v_;
+    size_t off_ = 0;
+};
+
 class ContigGraph {
 public:
     ContigGraph() = default;
     ContigGraph(const ContigGraph &) = delete;
     ssize_t start_pos = 0, end_pos = 0;
     std::string main_path;                     // mainPath.path
-    std::deque<Edge *> main_edges;             // mainPath.edges
+    EdgePath main_edges;                       // mainPath.edges
     read_t first_read = 0;
     std::map<read_t, GraphRead> reads;         // readsInGraph (ascending id = output order)
 
