@@ -18,6 +18,7 @@
 #include <mutex>
 #include <condition_variable>
 #include "host_util.hpp"
+#include <memory>
 
 namespace nsgpu {
 
@@ -47,11 +48,50 @@ void parallel_for_impl(size_t n, const std::function<void(size_t)> &fn);
 template <class F>
 static void parallel_for(size_t n, F fn) { parallel_for_impl(n, std::function<void(size_t)>(fn)); }
 
-// Persistent host thread pool: workers sleep on a condition variable between jobs; a job is an
-// index range handed out in chunks through an atomic cursor.  (Spawning ~256 std::threads per
-// parallel loop cost more than the loops themselves.)
+// Persistent host thread pool.  Several jobs may be in flight at once (the contig engine's host phase and the host
+// parts of the other group's GPU batches are submitted from two threads): a job is an index range handed out in chunks
+// through an atomic cursor (or, "pinned", one queue per thread with stealing), workers serve the short jobs of the
+// batch thread first so that the GPU is not kept waiting behind a long host phase, and every submitter works on its
+// own job while it waits.  (Spawning ~256 std::threads per parallel loop cost more than the loops themselves.)
 namespace {
 class HostPool {
+    struct Job {
+        const std::function<void(size_t)> *fn = nullptr;
+        size_t total = 0, chunk = 1;
+        bool pinned = false;
+        unsigned n_threads = 1;
+        std::atomic<size_t> next{0}, done{0};
+        std::vector<std::atomic<size_t>> pos;          // pinned: items taken from thread v's queue (item = v + j * n_threads)
+        std::mutex m;
+        std::condition_variable cv;
+        // runs one chunk; false when the job has nothing left to hand out
+        bool work_once(unsigned me)
+        {
+            size_t n_done = 0;
+            if (pinned) {
+                bool got = false;
+                for (unsigned k = 0; k < n_threads && !got; ++k) {
+                    const unsigned v = (me + k) % n_threads;
+                    if ((size_t)v + pos[v].load(std::memory_order_relaxed) * n_threads >= total) continue;     // cheap pre-check
+                    const size_t j = pos[v].fetch_add(1, std::memory_order_relaxed);
+                    const size_t i = (size_t)v + j * n_threads;
+                    if (i >= total) continue;
+                    (*fn)(i);
+                    n_done = 1, got = true;
+                }
+                if (!got) return false;
+            } else {
+                if (next.load(std::memory_order_relaxed) >= total) return false;
+                const size_t b = next.fetch_add(chunk);
+                if (b >= total) return false;
+                const size_t e = b + chunk < total ? b + chunk : total;
+                for (size_t i = b; i < e; ++i) (*fn)(i);
+                n_done = e - b;
+            }
+            if (done.fetch_add(n_done) + n_done == total) { std::lock_guard<std::mutex> lk(m); cv.notify_all(); }
+            return true;
+        }
+    };
 public:
     explicit HostPool(unsigned n) : n_(n) { for (unsigned i = 1; i < n_; ++i) th_.emplace_back([this, i] { worker(i); }); }
     ~HostPool()
@@ -60,74 +100,63 @@ public:
         cv_.notify_all();
         for (auto &t : th_) t.join();
     }
-    // pinned = true: index i always runs on thread i % n_threads (keeps a builder's heap traffic in one malloc arena)
+    // pinned = true: index i is queued for thread i % n_threads (keeps a builder's graph in one core's caches and its
+    // slabs in one thread's cache); a thread that runs out of its own items steals from the others
     void run(size_t n, const std::function<void(size_t)> &fn, bool pinned = false)
     {
-        std::lock_guard<std::mutex> serial(run_m_);       // one job at a time
+        auto job = std::make_shared<Job>();
+        job->fn = &fn, job->total = n, job->pinned = pinned, job->n_threads = n_;
+        job->chunk = n / ((size_t)n_ * 8) ? n / ((size_t)n_ * 8) : 1;
+        if (pinned) { job->pos = std::vector<std::atomic<size_t>>(n_); for (auto &x : job->pos) x.store(0); }
         {
             std::lock_guard<std::mutex> lk(m_);
-            fn_ = &fn; total_ = n; next_.store(0); pinned_ = pinned;
-            if (pinned) { if (pos_.size() != n_) pos_ = std::vector<std::atomic<size_t>>(n_); for (auto &x : pos_) x.store(0); }
-            chunk_ = n / ((size_t)n_ * 8) ? n / ((size_t)n_ * 8) : 1;
-            pending_ = (unsigned)th_.size();
+            // short (unpinned) jobs go to the front: they are the ones a GPU batch is waiting for
+            if (pinned) active_.push_back(job); else active_.insert(active_.begin(), job);
             ++gen_;
         }
         cv_.notify_all();
-        work(0);
-        std::unique_lock<std::mutex> lk(m_);
-        done_cv_.wait(lk, [this] { return pending_ == 0; });
-        fn_ = nullptr;
+        while (job->work_once(0)) {}
+        {
+            std::unique_lock<std::mutex> lk(job->m);
+            job->cv.wait(lk, [&] { return job->done.load() == job->total; });
+        }
+        std::lock_guard<std::mutex> lk(m_);
+        active_.erase(std::find(active_.begin(), active_.end(), job));
     }
 private:
-    void work(unsigned me)
-    {
-        if (pinned_) {
-            // index i belongs to thread i % n_ (keeps a builder's heap traffic in one malloc arena and its graph in one
-            // core's caches); a thread that runs out of its own items steals from the others
-            for (unsigned k = 0; k < n_; ++k) {
-                const unsigned v = (me + k) % n_;
-                for (;;) {
-                    const size_t j = pos_[v].fetch_add(1, std::memory_order_relaxed);
-                    const size_t i = (size_t)v + j * n_;
-                    if (i >= total_) break;
-                    (*fn_)(i);
-                }
-            }
-            return;
-        }
-        for (;;) {
-            const size_t b = next_.fetch_add(chunk_);
-            if (b >= total_) break;
-            const size_t e = b + chunk_ < total_ ? b + chunk_ : total_;
-            for (size_t i = b; i < e; ++i) (*fn_)(i);
-        }
-    }
     void worker(unsigned me)
     {
         uint64_t seen = 0;
+        std::vector<std::shared_ptr<Job>> snap;
         for (;;) {
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return gen_ != seen; });
-                seen = gen_;
+                cv_.wait(lk, [&] { return gen_ != seen || stop_; });
                 if (stop_) return;
+                seen = gen_;
+                snap = active_;
             }
-            work(me);
-            std::lock_guard<std::mutex> lk(m_);
-            if (--pending_ == 0) done_cv_.notify_one();
+            // serve until no job in the snapshot has work left; a job submitted meanwhile changes gen_ and is seen next
+            for (bool any = true; any;) {
+                any = false;
+                for (auto &j : snap) {
+                    if (j->work_once(me)) { any = true; break; }      // re-scan from the front: short jobs first
+                }
+                if (any) {
+                    std::lock_guard<std::mutex> lk(m_);
+                    if (gen_ != seen) { seen = gen_; snap = active_; }
+                }
+            }
+            snap.clear();
         }
     }
     unsigned n_;
     std::vector<std::thread> th_;
-    std::mutex m_, run_m_;
-    std::condition_variable cv_, done_cv_;
-    const std::function<void(size_t)> *fn_ = nullptr;
-    size_t total_ = 0, chunk_ = 1;
-    std::atomic<size_t> next_{0};
-    std::vector<std::atomic<size_t>> pos_;
-    unsigned pending_ = 0;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::vector<std::shared_ptr<Job>> active_;
     uint64_t gen_ = 0;
-    bool stop_ = false, pinned_ = false;
+    bool stop_ = false;
 };
 }  // namespace
 

@@ -28,6 +28,7 @@ struct Builder {
     enum State { NEED_CONTIG, ADVANCE, WAIT_FILTER, WAIT_ALIGN, GOT_FILTER, ALIGNED, GOT_ALIGN, DONE };
     State st = NEED_CONTIG;
     uint32_t id = 0, gid = 0;                 // local index / global builder id
+    int group = 0;                            // pipeline group (a function of gid only, so that it does not depend on the rank count)
     std::unique_ptr<cons::ContigGraph> g;
     read_t cursor = 0;
     // contig walk (src/Consensus.cpp:51-95)
@@ -276,7 +277,7 @@ static int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, 
     E->rank = rank, E->world = world, E->n_total = n_builders_total;
     const uint32_t n_local = n_builders_total > rank ? (n_builders_total - rank + world - 1) / world : 0;
     D.B.resize(n_local);
-    for (uint32_t i = 0; i < n_local; ++i) D.B[i].id = i, D.B[i].gid = rank + i * world;
+    for (uint32_t i = 0; i < n_local; ++i) D.B[i].id = i, D.B[i].gid = rank + i * world, D.B[i].group = (int)((D.B[i].gid >> 3) & 1);
     memset(&c->cons_stats, 0, sizeof(c->cons_stats));
     c->cons_stats.n_builders = n_builders_total;
     c->have_cons = false;
@@ -284,25 +285,27 @@ static int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, 
 }
 
 // phase 1/3: consume deliveries and run every local builder to its next request
-static void engine_advance(nsgpu_ctx *c, bool only_fresh)
+static inline bool in_group(const Builder &b, int group) { return group < 0 || b.group == group; }
+
+static void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
     const double a0 = now_ms();
-    if (only_fresh) par_for_pinned(D.B.size(), [&](size_t i) { if (D.B[i].st == Builder::ADVANCE) D.advance(D.B[i]); });
-    else par_for_pinned(D.B.size(), [&](size_t i) { D.advance(D.B[i]); });
+    if (only_fresh) par_for_pinned(D.B.size(), [&](size_t i) { if (in_group(D.B[i], group) && D.B[i].st == Builder::ADVANCE) D.advance(D.B[i]); });
+    else par_for_pinned(D.B.size(), [&](size_t i) { if (in_group(D.B[i], group)) D.advance(D.B[i]); });
     c->cons_stats.graph_ms += now_ms() - a0;
     double mx = 0;
-    for (Builder &b : D.B) { if (b.last_ms > mx) mx = b.last_ms; b.last_ms = 0; }
+    for (Builder &b : D.B) if (in_group(b, group)) { if (b.last_ms > mx) mx = b.last_ms; b.last_ms = 0; }
     c->cons_stats.graph_crit_ms += mx;       // sum over phases of the slowest builder step: the floor of the phase wall
 }
 
 // phase 2: (gid, cursor) of every local builder that needs a new contig
-static void engine_seed_requests(nsgpu_ctx *c, std::vector<uint32_t> &gids, std::vector<uint32_t> &cursors)
+static void engine_seed_requests(nsgpu_ctx *c, std::vector<uint32_t> &gids, std::vector<uint32_t> &cursors, int group)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     gids.clear(); cursors.clear();
-    for (Builder &b : E->D.B) if (b.st == Builder::NEED_CONTIG) { gids.push_back(b.gid); cursors.push_back(b.cursor); }
+    for (Builder &b : E->D.B) if (in_group(b, group) && b.st == Builder::NEED_CONTIG) { gids.push_back(b.gid); cursors.push_back(b.cursor); }
 }
 
 // resolve the seed requests of ALL ranks on the replicated in_graph[], in global builder order
@@ -329,14 +332,14 @@ static uint32_t engine_seed_resolve(nsgpu_ctx *c, const uint32_t *gids, const ui
 }
 
 // phases 4+5: window queries and alignments of the local builders (GPU batches); no claims yet
-static int engine_batches(nsgpu_ctx *c)
+static int engine_batches(nsgpu_ctx *c, int group)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
     nsgpu_consensus_stats &S = c->cons_stats;
     std::vector<uint32_t> &who = E->who;
     who.clear();
-    for (Builder &b : D.B) if (b.st == Builder::WAIT_FILTER) who.push_back(b.id);
+    for (Builder &b : D.B) if (in_group(b, group) && b.st == Builder::WAIT_FILTER) who.push_back(b.id);
     if (!who.empty()) {
         const double f0 = now_ms();
         E->qbuf.clear(); E->qoff.assign(1, 0);
@@ -358,7 +361,7 @@ static int engine_batches(nsgpu_ctx *c)
         ++S.n_filter_rounds;
     }
     who.clear();
-    for (Builder &b : D.B) if (b.st == Builder::WAIT_ALIGN) who.push_back(b.id);
+    for (Builder &b : D.B) if (in_group(b, group) && b.st == Builder::WAIT_ALIGN) who.push_back(b.id);
     if (!who.empty()) {
         const double g0 = now_ms();
         // minimizers of every changed consensus and every candidate read in one GPU batch (mm_sketch.hip); the
@@ -420,11 +423,11 @@ static int engine_batches(nsgpu_ctx *c)
 }
 
 // phase 6a: (gid, read) of every local builder whose alignment succeeded
-static void engine_claim_requests(nsgpu_ctx *c, std::vector<uint32_t> &gids, std::vector<uint32_t> &reads)
+static void engine_claim_requests(nsgpu_ctx *c, std::vector<uint32_t> &gids, std::vector<uint32_t> &reads, int group)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     gids.clear(); reads.clear();
-    for (Builder &b : E->D.B) if (b.st == Builder::ALIGNED && b.aln.ok) { gids.push_back(b.gid); reads.push_back(b.pend); }
+    for (Builder &b : E->D.B) if (in_group(b, group) && b.st == Builder::ALIGNED && b.aln.ok) { gids.push_back(b.gid); reads.push_back(b.pend); }
 }
 
 // phase 6b: claims of ALL ranks, strictly in global builder order (src/Consensus.cpp:256-277 without lock contention)
@@ -477,44 +480,55 @@ static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
     return NSGPU_OK;
 }
 
+// One pipeline slot: the host phase of group `adv_group` and the GPU batches of group `batch_group`, concurrently.
+static int engine_slot(nsgpu_ctx *c, int adv_group, int batch_group)
+{
+    static const bool serial = getenv("NSGPU_NO_OVERLAP") != nullptr;      // debugging aid: one after the other
+    if (serial) { engine_advance(c, false, adv_group); return engine_batches(c, batch_group); }
+    int rc = NSGPU_OK;
+    std::thread batches([&] { rc = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches(c, batch_group) : NSGPU_ERR_HIP; });
+    engine_advance(c, false, adv_group);
+    batches.join();
+    return rc;
+}
+
 static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_out)
 {
     NS_CHECK(n_threads_out >= 1, NSGPU_ERR_ARG, "n_threads_out must be >= 1");
     NS_TRY(engine_begin(c, n_builders, 0, 1));
     Engine *E = static_cast<Engine *>(c->cons_engine);
     std::vector<uint32_t> ga, gb;
-    double w_adv = 0, w_seed = 0, w_batch = 0, w_claim = 0;
+    double w_slot = 0, w_seed = 0, w_claim = 0;
     const double w_begin = now_ms() - E->t0;
-    for (;;) {
+    // Two builder groups, half a period apart: in slot s group s & 1 runs its host phase (graph updates up to the next
+    // window / alignment request) while the other group's GPU batches (window lookups, sketches, alignment DP) are in
+    // flight, so that the cores are not idle during kernels nor the GPU during graph work.  At the slot boundary the
+    // batch group's read claims and then the host group's seed requests are resolved, in global builder order: the
+    // schedule is a function of the data only.
+    for (uint32_t slot = 0;; ++slot) {
         double t = now_ms();
-        engine_advance(c, false);
-        w_adv += now_ms() - t;
-        for (;;) {
-            t = now_ms();
-            engine_seed_requests(c, ga, gb);
-            if (ga.empty()) break;
-            const uint32_t started = engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size());
-            w_seed += now_ms() - t;
-            if (started == 0) break;
-            t = now_ms();
-            engine_advance(c, true);
-            w_adv += now_ms() - t;
-        }
+        NS_TRY(engine_slot(c, (int)(slot & 1), (int)((slot & 1) ^ 1)));
+        w_slot += now_ms() - t;
         t = now_ms();
-        NS_TRY(engine_batches(c));
-        w_batch += now_ms() - t;
-        t = now_ms();
-        engine_claim_requests(c, ga, gb);
+        engine_claim_requests(c, ga, gb, (int)((slot & 1) ^ 1));
         engine_claim_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size());
         w_claim += now_ms() - t;
+        t = now_ms();
+        for (;;) {
+            engine_seed_requests(c, ga, gb, (int)(slot & 1));
+            if (ga.empty()) break;
+            if (engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) == 0) break;
+            engine_advance(c, true, (int)(slot & 1));
+        }
+        w_seed += now_ms() - t;
         if (E->n_done_global >= E->n_total) break;
     }
     const double tf = now_ms();
     const int rc = engine_finish(c, n_threads_out);
     if (getenv("NSGPU_CONS_DEBUG")) {
         fprintf(stderr, "[cons] gpu mm_sketch wall-ms %.0f\n", c->sketch_mm_ms);
-        fprintf(stderr, "[cons] wall-ms: begin %.0f advance %.0f seed %.0f batches %.0f claim %.0f finish %.0f\n", w_begin, w_adv, w_seed, w_batch, w_claim,
-                now_ms() - tf);
+        fprintf(stderr, "[cons] wall-ms: begin %.0f slots %.0f (host phases %.0f, batches %.0f, overlapped) seed %.0f claim %.0f finish %.0f\n", w_begin, w_slot,
+                c->cons_stats.graph_ms, c->cons_stats.filter_ms + c->cons_stats.index_ms + c->cons_stats.align_ms, w_seed, w_claim, now_ms() - tf);
     }
     return rc;
 }
@@ -543,43 +557,52 @@ int nsgpu_cons_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, uin
     return engine_begin(c, n_builders_total, rank, world);
 }
 
-int nsgpu_cons_advance(nsgpu_ctx *c, int only_fresh)
+int nsgpu_cons_advance(nsgpu_ctx *c, int only_fresh, int group)
 {
     NS_CHECK(c && c->cons_engine, NSGPU_ERR_ARG, "nsgpu_cons_advance: call nsgpu_cons_begin first");
-    engine_advance(c, only_fresh != 0);
+    engine_advance(c, only_fresh != 0, group);
     return NSGPU_OK;
 }
 
-int nsgpu_cons_seed_requests(nsgpu_ctx *c, uint32_t **gids_out, uint32_t **cursors_out, uint32_t *n_out)
+int nsgpu_cons_slot(nsgpu_ctx *c, int adv_group, int batch_group)
+{
+    NS_CHECK(c && c->cons_engine, NSGPU_ERR_ARG, "nsgpu_cons_slot: call nsgpu_cons_begin first");
+    NS_HIP(hipSetDevice(c->prm.device));
+    return engine_slot(c, adv_group, batch_group);
+}
+
+int nsgpu_cons_seed_requests(nsgpu_ctx *c, int group, uint32_t **gids_out, uint32_t **cursors_out, uint32_t *n_out)
 {
     NS_CHECK(c && c->cons_engine && gids_out && cursors_out && n_out, NSGPU_ERR_ARG, "nsgpu_cons_seed_requests: bad argument");
     std::vector<uint32_t> a, b;
-    engine_seed_requests(c, a, b);
+    engine_seed_requests(c, a, b, group);
     NS_TRY(give_u32(a, gids_out));
     NS_TRY(give_u32(b, cursors_out));
     *n_out = (uint32_t)a.size();
     return NSGPU_OK;
 }
 
-int nsgpu_cons_seed_resolve(nsgpu_ctx *c, const uint32_t *gids, const uint32_t *cursors, uint32_t n, uint32_t *n_started_out)
+int nsgpu_cons_seed_resolve(nsgpu_ctx *c, const uint32_t *gids, const uint32_t *cursors, uint32_t n, uint32_t *n_started_out, uint32_t *all_done_out)
 {
-    NS_CHECK(c && c->cons_engine && (n == 0 || (gids && cursors)) && n_started_out, NSGPU_ERR_ARG, "nsgpu_cons_seed_resolve: bad argument");
+    NS_CHECK(c && c->cons_engine && (n == 0 || (gids && cursors)) && n_started_out && all_done_out, NSGPU_ERR_ARG, "nsgpu_cons_seed_resolve: bad argument");
     *n_started_out = engine_seed_resolve(c, gids, cursors, n);
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    *all_done_out = E->n_done_global >= E->n_total;
     return NSGPU_OK;
 }
 
-int nsgpu_cons_batches(nsgpu_ctx *c)
+int nsgpu_cons_batches(nsgpu_ctx *c, int group)
 {
     NS_CHECK(c && c->cons_engine, NSGPU_ERR_ARG, "nsgpu_cons_batches: call nsgpu_cons_begin first");
     NS_HIP(hipSetDevice(c->prm.device));
-    return engine_batches(c);
+    return engine_batches(c, group);
 }
 
-int nsgpu_cons_claim_requests(nsgpu_ctx *c, uint32_t **gids_out, uint32_t **reads_out, uint32_t *n_out)
+int nsgpu_cons_claim_requests(nsgpu_ctx *c, int group, uint32_t **gids_out, uint32_t **reads_out, uint32_t *n_out)
 {
     NS_CHECK(c && c->cons_engine && gids_out && reads_out && n_out, NSGPU_ERR_ARG, "nsgpu_cons_claim_requests: bad argument");
     std::vector<uint32_t> a, b;
-    engine_claim_requests(c, a, b);
+    engine_claim_requests(c, a, b, group);
     NS_TRY(give_u32(a, gids_out));
     NS_TRY(give_u32(b, reads_out));
     *n_out = (uint32_t)a.size();

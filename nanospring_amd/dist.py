@@ -196,9 +196,9 @@ def consensus_exchange(gpu, n_builders_total, dist, n_threads_out=1):
     rank, world = dist.get_rank(), dist.get_world_size()
     F.check(lib, lib.nsgpu_cons_begin(ctx, n_builders_total, rank, world))
 
-    def take(fn):
+    def take(fn, group):
         pa, pb, n = C.c_void_p(), C.c_void_p(), C.c_uint32()
-        F.check(lib, fn(ctx, C.byref(pa), C.byref(pb), C.byref(n)))
+        F.check(lib, fn(ctx, group, C.byref(pa), C.byref(pb), C.byref(n)))
         a = np.ctypeslib.as_array(C.cast(pa, C.POINTER(C.c_uint32)), shape=(max(n.value, 1),))[:n.value].copy()
         b = np.ctypeslib.as_array(C.cast(pb, C.POINTER(C.c_uint32)), shape=(max(n.value, 1),))[:n.value].copy()
         lib.nsgpu_free(pa); lib.nsgpu_free(pb)
@@ -207,28 +207,31 @@ def consensus_exchange(gpu, n_builders_total, dist, n_threads_out=1):
     def ptr(a):
         return a.ctypes.data_as(C.c_void_p) if a.size else None
 
+    # the slot schedule of include/nsgpu.h (nsgpu_consensus_run runs the same one with world = 1)
     n_coll = 0
+    slot = 0
     while True:
-        F.check(lib, lib.nsgpu_cons_advance(ctx, 0))
+        h = slot & 1
+        F.check(lib, lib.nsgpu_cons_slot(ctx, h, h ^ 1))
+        ga, gb = all_gather_u32_lists(*take(lib.nsgpu_cons_claim_requests, h ^ 1), dist)
+        n_coll += 1
+        ga, gb = np.ascontiguousarray(ga), np.ascontiguousarray(gb)
+        done = C.c_uint32()
+        F.check(lib, lib.nsgpu_cons_claim_resolve(ctx, ptr(ga), ptr(gb), ga.size, C.byref(done)))
         while True:
-            ga, gb = all_gather_u32_lists(*take(lib.nsgpu_cons_seed_requests), dist)
+            ga, gb = all_gather_u32_lists(*take(lib.nsgpu_cons_seed_requests, h), dist)
             n_coll += 1
             if ga.size == 0:
                 break
             started = C.c_uint32()
             ga, gb = np.ascontiguousarray(ga), np.ascontiguousarray(gb)
-            F.check(lib, lib.nsgpu_cons_seed_resolve(ctx, ptr(ga), ptr(gb), ga.size, C.byref(started)))
+            F.check(lib, lib.nsgpu_cons_seed_resolve(ctx, ptr(ga), ptr(gb), ga.size, C.byref(started), C.byref(done)))
             if started.value == 0:
                 break
-            F.check(lib, lib.nsgpu_cons_advance(ctx, 1))
-        F.check(lib, lib.nsgpu_cons_batches(ctx))
-        ga, gb = all_gather_u32_lists(*take(lib.nsgpu_cons_claim_requests), dist)
-        n_coll += 1
-        ga, gb = np.ascontiguousarray(ga), np.ascontiguousarray(gb)
-        done = C.c_uint32()
-        F.check(lib, lib.nsgpu_cons_claim_resolve(ctx, ptr(ga), ptr(gb), ga.size, C.byref(done)))
+            F.check(lib, lib.nsgpu_cons_advance(ctx, 1, h))
         if done.value:
             break
+        slot += 1
     st = F.ConsensusStats()
     F.check(lib, lib.nsgpu_cons_finish(ctx, n_threads_out, C.byref(st)))
     out = {k: getattr(st, k) for k, _ in F.ConsensusStats._fields_}
