@@ -18,11 +18,22 @@
 #include "consensus.hpp"
 #include "host_util.hpp"
 #include <memory>
+#include <atomic>
 #include <thread>
 
 namespace nsgpu {
+namespace mm2 { extern std::atomic<uint64_t> g_step_ns[6]; }
 
 using cons::read_t;
+
+// A finished contig waiting for its edit emission (consensus + one edit script per read into the seven streams).  The
+// emission touches nothing but the contig's own graph, so it is taken off the builder's critical path: the builder moves
+// on to its next contig at once and the emission runs as a task of its own in the next host phase.
+struct FinishedContig {
+    std::unique_ptr<cons::ContigGraph> g;     // null once emitted
+    cons::StreamSet out;
+    double write_ms = 0, free_ms = 0;
+};
 
 struct Builder {
     enum State { NEED_CONTIG, ADVANCE, WAIT_FILTER, WAIT_ALIGN, GOT_FILTER, ALIGNED, GOT_ALIGN, DONE };
@@ -48,9 +59,10 @@ struct Builder {
     // cached index of the current main path
     mm2::RefIndex idx;
     bool idx_valid = false;
-    cons::StreamSet out;
+    std::vector<std::unique_ptr<FinishedContig>> contigs;     // in the order they were finished = output order
+    size_t n_queued = 0;                                      // contigs[0 .. n_queued) were handed to the emission queue
     uint64_t n_minhash = 0, n_minhash_new = 0, n_aligner = 0, n_align_calls = 0, n_contigs = 0, n_lone = 0;
-    double cpu_ms = 0, max_ms = 0, last_ms = 0, write_ms = 0, dbg_w1 = 0, dbg_w2 = 0, dbg_w3 = 0, dbg_u = 0, dbg_m = 0, dbg_cyc = 0;
+    double cpu_ms = 0, max_ms = 0, last_ms = 0, write_ms = 0, dbg_w1 = 0, dbg_w2 = 0, dbg_w3 = 0, dbg_u = 0, dbg_m = 0, dbg_cyc = 0, dbg_init = 0, dbg_rc = 0, dbg_win = 0, dbg_start = 0;
     uint64_t dbg_c[5] = {0, 0, 0, 0, 0};
 };
 
@@ -68,6 +80,12 @@ struct Driver {
     // createGraph (src/Consensus.cpp:388-403) for the seed read r the builder was granted
     void start_contig(Builder &b, read_t r)
     {
+        const double s0 = now_ms();
+        start_contig_inner(b, r);
+        b.dbg_start += now_ms() - s0;
+    }
+    void start_contig_inner(Builder &b, read_t r)
+    {
         b.g.reset(new cons::ContigGraph());
         b.g->main_path.assign(read_ptr(r), read_len(r));
         b.g->start_pos = 0;
@@ -84,42 +102,50 @@ struct Driver {
 
     void finish_contig(Builder &b)
     {
-        const double tw = now_ms();
-        finish_contig_inner(b);
-        b.write_ms += now_ms() - tw;
-    }
-    void finish_contig_inner(Builder &b)
-    {
         cons::ContigGraph &g = *b.g;
+        std::unique_ptr<FinishedContig> fc(new FinishedContig());
         if (g.num_reads() == 0) {
-            g.write_read_lone(b.out);
-            b.out.lone_ids.push_back(g.first_read);
-            b.out.reads_in_contig.push_back(1);
+            g.write_read_lone(fc->out);
+            fc->out.lone_ids.push_back(g.first_read);
+            fc->out.reads_in_contig.push_back(1);
             ++b.n_lone;
+            b.g.reset();
         } else {
-            const double t0 = now_ms();
-            g.write_main_path(b.out);
-            const std::function<cons::ReadBases(cons::read_t)> src = [this](cons::read_t id) {
-                const read_t r = id - id_base;
-                return cons::ReadBases{read_ptr(r), read_len(r)};
-            };
-            const double t1 = now_ms();
-            g.write_reads(b.out, &src);
-            const double t2 = now_ms();
-            b.dbg_w1 += t1 - t0, b.dbg_w2 += t2 - t1;
-            b.out.reads_in_contig.push_back((read_t)g.num_reads());
+            b.dbg_cyc += g.dbg_cycles_ms;
+            b.dbg_c[0] += g.dbg_cycles_calls, b.dbg_c[1] += g.dbg_cycles_skipped, b.dbg_c[2] += g.dbg_spliced, b.dbg_c[3] += g.dbg_spliced_nodes, b.dbg_c[4] += g.dbg_walked_nodes;
+            fc->g = std::move(b.g);
         }
+        b.contigs.push_back(std::move(fc));
         ++b.n_contigs;
-        b.dbg_cyc += g.dbg_cycles_ms;
-        b.dbg_c[0] += g.dbg_cycles_calls, b.dbg_c[1] += g.dbg_cycles_skipped, b.dbg_c[2] += g.dbg_spliced, b.dbg_c[3] += g.dbg_spliced_nodes, b.dbg_c[4] += g.dbg_walked_nodes;
-        const double t3 = now_ms();
-        b.g.reset();
-        b.dbg_w3 += now_ms() - t3;
         b.st = Builder::NEED_CONTIG;
+    }
+    // edit emission of one finished contig (ConsensusGraph::writeMainPath + writeReads, src/ConsensusGraph.cpp:979-1012)
+    void emit_contig(FinishedContig &fc)
+    {
+        if (!fc.g) return;
+        const double t0 = now_ms();
+        cons::ContigGraph &g = *fc.g;
+        g.write_main_path(fc.out);
+        const std::function<cons::ReadBases(cons::read_t)> src = [this](cons::read_t id) {
+            const read_t r = id - id_base;
+            return cons::ReadBases{read_ptr(r), read_len(r)};
+        };
+        g.write_reads(fc.out, &src);
+        fc.out.reads_in_contig.push_back((read_t)g.num_reads());
+        const double t1 = now_ms();
+        fc.g.reset();
+        fc.write_ms = t1 - t0, fc.free_ms = now_ms() - t1;
     }
 
     // opens the window at cur_pos (addRelatedReads prologue, src/Consensus.cpp:168-184); false = nothing to query
     bool open_window(Builder &b)
+    {
+        const double w0 = now_ms();
+        const bool r = open_window_inner(b);
+        b.dbg_win += now_ms() - w0;
+        return r;
+    }
+    bool open_window_inner(Builder &b)
     {
         cons::ContigGraph &g = *b.g;
         const ssize_t off = b.cur_pos - g.start_pos;
@@ -176,8 +202,10 @@ struct Driver {
                 if (in_graph[r]) continue;
                 ++b.n_minhash_new;
                 if (read_len(r) < 32) continue;
+                const double r0 = now_ms();
                 if (b.strand) { std::string fwd(read_ptr(r), read_len(r)); cons::reverse_complement(fwd, b.query); }
                 else b.query.assign(read_ptr(r), read_len(r));
+                b.dbg_rc += now_ms() - r0;
                 b.pend = r;
                 b.st = Builder::WAIT_ALIGN;
                 return;
@@ -206,10 +234,12 @@ struct Driver {
             cons::ContigGraph &g = *b.g;
             if (b.accepted) {
                 if (g.num_reads() == 0) {                       // src/Consensus.cpp:319-324
+                    const double i0 = now_ms();
                     const std::string seed = g.main_path;
                     g.main_path.clear();
                     g.initialize(seed, g.first_read, 0);
                     g.calculate_main_path_greedy();
+                    b.dbg_init += now_ms() - i0;
                 }
                 const double u0 = now_ms();
                 g.update_graph(b.query, b.aln.edits, (ssize_t)b.aln.begin_offset, (ssize_t)b.aln.end_offset, b.pend + id_base, (long)b.aln.rel_pos, b.strand == 1);
@@ -242,6 +272,7 @@ struct Engine {
     std::string qbuf;
     std::vector<uint64_t> qoff, foff;
     std::vector<uint32_t> fids;
+    std::vector<FinishedContig *> emit_queue;      // finished contigs whose emission has not run yet
     std::vector<SketchReq> sk;
     std::vector<uint32_t> sk_ref;
     std::vector<uint64_t> mz_off;
@@ -292,8 +323,18 @@ static void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
     const double a0 = now_ms();
-    if (only_fresh) par_for_pinned(D.B.size(), [&](size_t i) { if (in_group(D.B[i], group) && D.B[i].st == Builder::ADVANCE) D.advance(D.B[i]); });
-    else par_for_pinned(D.B.size(), [&](size_t i) { if (in_group(D.B[i], group)) D.advance(D.B[i]); });
+    // one parallel loop: first the emissions of the contigs finished so far (long tasks, any group's), then the builders of
+    // this group; the builder part starts at a multiple of the thread count so that builder i stays on thread i % threads
+    const size_t nt = host_threads() ? host_threads() : 1;
+    const size_t n_emit = only_fresh ? 0 : E->emit_queue.size(), base = (n_emit + nt - 1) / nt * nt;
+    par_for_pinned(base + D.B.size(), [&](size_t i) {
+        if (i < n_emit) { D.emit_contig(*E->emit_queue[i]); return; }
+        if (i < base) return;
+        Builder &b = D.B[i - base];
+        if (in_group(b, group) && (!only_fresh || b.st == Builder::ADVANCE)) D.advance(b);
+    });
+    if (!only_fresh) E->emit_queue.clear();
+    for (Builder &b : D.B) for (; b.n_queued < b.contigs.size(); ++b.n_queued) if (b.contigs[b.n_queued]->g) E->emit_queue.push_back(b.contigs[b.n_queued].get());
     c->cons_stats.graph_ms += now_ms() - a0;
     double mx = 0;
     for (Builder &b : D.B) if (in_group(b, group)) { if (b.last_ms > mx) mx = b.last_ms; b.last_ms = 0; }
@@ -457,17 +498,23 @@ static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
     // merge builders into the requested number of output "threads" (Compressor expects exactly numThr
     // file sets, src/Compressor.cpp:123-124; Decompressor reads numThr from metaData)
     c->cons_out.assign(n_threads_out, cons::StreamSet());
-    for (size_t i = 0; i < D.B.size(); ++i) c->cons_out[i * n_threads_out / (D.B.empty() ? 1 : D.B.size())].append(D.B[i].out);
-    double dbg_w[6] = {0, 0, 0, 0, 0, 0};
+    for (Builder &b : D.B) for (; b.n_queued < b.contigs.size(); ++b.n_queued) if (b.contigs[b.n_queued]->g) E->emit_queue.push_back(b.contigs[b.n_queued].get());
+    par_for(E->emit_queue.size(), [&](size_t i) { D.emit_contig(*E->emit_queue[i]); });
+    E->emit_queue.clear();
+    for (size_t i = 0; i < D.B.size(); ++i)
+        for (auto &fc : D.B[i].contigs) c->cons_out[i * n_threads_out / (D.B.empty() ? 1 : D.B.size())].append(fc->out);
+    double dbg_w[6] = {0, 0, 0, 0, 0, 0}, dbg_x[4] = {0, 0, 0, 0};
     uint64_t dbg_c[5] = {0, 0, 0, 0, 0};
     for (Builder &b : D.B) {
         S.n_contigs += b.n_contigs; S.n_lone += b.n_lone; S.count_minhash += b.n_minhash; S.count_minhash_not_in_graph += b.n_minhash_new;
         S.count_aligner += b.n_aligner; S.n_align_calls += b.n_align_calls;
         S.graph_cpu_ms += b.cpu_ms; if (b.max_ms > S.graph_max_ms) S.graph_max_ms = b.max_ms;
-        S.write_cpu_ms += b.write_ms;
-        dbg_w[0] += b.dbg_w1, dbg_w[1] += b.dbg_w2, dbg_w[2] += b.dbg_w3, dbg_w[3] += b.dbg_u, dbg_w[4] += b.dbg_m, dbg_w[5] += b.dbg_cyc;
+        for (auto &fc : b.contigs) S.write_cpu_ms += fc->write_ms, dbg_w[1] += fc->write_ms, dbg_w[2] += fc->free_ms;
+        dbg_w[0] += b.dbg_w1, dbg_w[3] += b.dbg_u, dbg_w[4] += b.dbg_m, dbg_w[5] += b.dbg_cyc;
         for (int k = 0; k < 5; ++k) dbg_c[k] += b.dbg_c[k];
+        dbg_x[0] += b.dbg_init, dbg_x[1] += b.dbg_rc, dbg_x[2] += b.dbg_win, dbg_x[3] += b.dbg_start;
     }
+    if (getenv("NSGPU_CONS_DEBUG")) fprintf(stderr, "[cons] cpu-ms: graph total %.0f; initialize+first main path %.0f, query copy/revcomp %.0f, open_window %.0f, start_contig %.0f\n", S.graph_cpu_ms, dbg_x[0], dbg_x[1], dbg_x[2], dbg_x[3]);
     if (getenv("NSGPU_CONS_DEBUG"))
         fprintf(stderr, "[cons] cpu-ms: update_graph %.0f main_path %.0f (remove_cycles %.0f) write_main %.0f write_reads %.0f graph_free %.0f; main-path calls %llu cycles-skipped %llu spliced %llu spliced-nodes %llu walked-nodes %llu\n",
                 dbg_w[3], dbg_w[4], dbg_w[5], dbg_w[0], dbg_w[1], dbg_w[2], (unsigned long long)dbg_c[0], (unsigned long long)dbg_c[1], (unsigned long long)dbg_c[2], (unsigned long long)dbg_c[3], (unsigned long long)dbg_c[4]);
@@ -527,6 +574,8 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
     const int rc = engine_finish(c, n_threads_out);
     if (getenv("NSGPU_CONS_DEBUG")) {
         fprintf(stderr, "[cons] gpu mm_sketch wall-ms %.0f\n", c->sketch_mm_ms);
+        fprintf(stderr, "[cons] align host cpu-ms: seeds %.0f chain %.0f regs %.0f plan %.0f execute %.0f\n", mm2::g_step_ns[0] / 1e6, mm2::g_step_ns[1] / 1e6,
+                mm2::g_step_ns[2] / 1e6, mm2::g_step_ns[3] / 1e6, mm2::g_step_ns[4] / 1e6);
         fprintf(stderr, "[cons] wall-ms: begin %.0f slots %.0f (host phases %.0f, batches %.0f, overlapped) seed %.0f claim %.0f finish %.0f\n", w_begin, w_slot,
                 c->cons_stats.graph_ms, c->cons_stats.filter_ms + c->cons_stats.index_ms + c->cons_stats.align_ms, w_seed, w_claim, now_ms() - tf);
     }

@@ -1,6 +1,8 @@
 // mm2.cpp -- see mm2.hpp.  Host-side decision chain of the aligner; all banded DP is
 // delegated to the HIP kernel through DpCache.
 #include "mm2.hpp"
+#include <atomic>
+#include <chrono>
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -1108,10 +1110,15 @@ static bool align1(AlignJob &J, Reg &r_io, Reg &r2, bool plan_only = false)
     return true;
 }
 
+std::atomic<uint64_t> g_step_ns[6];
+static inline uint64_t prof_now() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 bool AlignJob::step()
 {
     if (finished) return true;
     cache.missing.clear();
+    uint64_t t0 = prof_now();
+    auto lap = [&](int k) { const uint64_t t1 = prof_now(); g_step_ns[k].fetch_add(t1 - t0, std::memory_order_relaxed); t0 = t1; };
     if (!seeded) {
         seeded = true;
         qseq.resize(qlen);
@@ -1120,8 +1127,10 @@ bool AlignJob::step()
         if (pre_mz) mv.assign(pre_mz, pre_mz + n_pre_mz);            // sketched by the caller (mm_sketch.hip)
         else if (qlen > 0) mm_sketch(qstr, qlen, ref->w, ref->k, 0, mv);
         collect_seeds(*ref, mv, a);
+        lap(0);
         std::vector<uint64_t> u;
         chain_dp(opt, a, u);
+        lap(1);
         // map.c:290-292: query name is NULL
         uint32_t hash = 0;
         hash ^= wang_hash32((uint32_t)qlen) + wang_hash32((uint32_t)opt.seed);
@@ -1134,6 +1143,7 @@ bool AlignJob::step()
         if (regs.empty()) { finished = true; return true; }
         n_a = squeeze_a(regs, a);            // mm_align_skeleton prologue (align.c:880)
         cur = 0;
+        lap(2);
     }
     while (cur < (int)regs.size()) {
         Reg r2;
@@ -1141,6 +1151,7 @@ bool AlignJob::step()
             // results are missing: also collect the requests of the regions behind this one, so that
             // one DP launch serves them all (their anchors are disjoint from this region's)
             for (int j = cur + 1; j < (int)regs.size(); ++j) { Reg tmp; align1(*this, regs[j], tmp, true); }
+            lap(3);
             return false;
         }
         if (r2.cnt > 0) regs.insert(regs.begin() + cur + 1, r2);     // mm_insert_reg
@@ -1153,6 +1164,7 @@ bool AlignJob::step()
     select_sub(opt, ref->k * 2, regs);
     set_sam_pri(regs);
     finished = true;
+    lap(4);
     return true;
 }
 
