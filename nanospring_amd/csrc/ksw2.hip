@@ -444,6 +444,11 @@ __global__ __launch_bounds__(NT) void ksw_extd2_wg_kernel(const KswTask *__restr
         uint2 sv[MAXPOS];
         uint32_t nb[MAXPOS];
         int zz[MAXPOS];
+        int h_left = 0;
+        // exact max (extensions): the row's H update and arg-max ride along with the write phase -- every cell's H moves by
+        // its own new v (H[en0] by its new u on top of the OLD H[en0 - 1], read above), so no extra pass over the row
+        const int en1 = st0 + (en0 - st0) / 4 * 4;
+        unsigned long long best = 0;
 #pragma unroll
         for (int k = 0; k < MAXPOS; ++k) {
             const int t = st + tid + k * NT;
@@ -456,6 +461,7 @@ __global__ __launch_bounds__(NT) void ksw_extd2_wg_kernel(const KswTask *__restr
                     a.y = (a.y & 0xffff00ffu) | (b1 << 8);
                 }
                 sv[k] = a;
+                if (!approx_max && r > 0 && t == rr.en0 && t > 0) h_left = H[t - 1];   // H[en0 - 1] BEFORE this row's update
                 if (t == st) nb[k] = nb_first;
                 else { const uint2 l = S[t - 1]; nb[k] = ((l.x >> 16) & 0xff) << 16 | ((l.x >> 8) & 0xff) << 8 | (l.y & 0xff); }
                 if (t >= st0 && t < sc_end) {
@@ -518,39 +524,40 @@ __global__ __launch_bounds__(NT) void ksw_extd2_wg_kernel(const KswTask *__restr
                                   (uint32_t)(x2n & 0xff) | (uint32_t)(y2n & 0xff) << 8);
                 if (t >= st0 && t < sc_end) s[t] = (uint8_t)zz[k];
                 prow[t] = (uint8_t)d;
+                if (!approx_max && r > 0) {
+                    if (t >= st0 && t < en0) {
+                        const int h = H[t] + vn;
+                        H[t] = h;
+                        const uint32_t rank = t < en1 ? (uint32_t)((t - st0) & 3) * 0x100000u + (uint32_t)t : 4u * 0x100000u + (uint32_t)t;
+                        const unsigned long long key = ((unsigned long long)((long long)h + 0x80000000ll) << 32) | (0xFFFFFFFEull - rank);
+                        best = key > best ? key : best;
+                    } else if (t == en0) {
+                        const int h = en0 > 0 ? h_left + un : H[en0] + vn;
+                        H[en0] = h;
+                        const unsigned long long key = ((unsigned long long)((long long)h + 0x80000000ll) << 32) | 0xFFFFFFFFull;
+                        best = key > best ? key : best;
+                    }
+                }
             }
         }
         if (has_extra) s[t_extra] = (uint8_t)z_extra;
+        if (!approx_max && r > 0) {
+            best = shfl_max_u64(best);
+            if (NT > 64 && (tid & 63) == 0) s_best[tid >> 6] = best;
+        }
         __syncthreads();
         // ---- score bookkeeping (uniform) ----
         bool brk = false;
         if (!approx_max) {
             int max_H, max_t;
             if (r > 0) {
-                int h_en0;
-                { const uint2 se = S[en0]; h_en0 = en0 > 0 ? H[en0 - 1] + sx8(se.x) : H[en0] + sx8(se.x >> 8); }
-                __syncthreads();
-                const int en1 = st0 + (en0 - st0) / 4 * 4;
-                unsigned long long best = ((unsigned long long)((long long)h_en0 + 0x80000000ll) << 32) | 0xFFFFFFFFull;
-                for (int t = st0 + tid; t < en0; t += NT) {
-                    const int h = H[t] + sx8(S[t].x >> 8);
-                    H[t] = h;
-                    const uint32_t rank = t < en1 ? (uint32_t)((t - st0) & 3) * 0x100000u + (uint32_t)t : 4u * 0x100000u + (uint32_t)t;
-                    const unsigned long long key = ((unsigned long long)((long long)h + 0x80000000ll) << 32) | (0xFFFFFFFEull - rank);
-                    best = key > best ? key : best;
-                }
-                if (tid == 0) H[en0] = h_en0;
-                best = shfl_max_u64(best);
                 if (NT > 64) {
-                    if ((tid & 63) == 0) s_best[tid >> 6] = best;
-                    __syncthreads();
 #pragma unroll
                     for (int i = 0; i < NT / 64; ++i) best = s_best[i] > best ? s_best[i] : best;
                 }
                 max_H = (int)((long long)(best >> 32) - 0x80000000ll);
                 const uint32_t lo = (uint32_t)best;
                 max_t = lo == 0xFFFFFFFFu ? en0 : (int)((0xFFFFFFFEu - lo) & 0xFFFFFu);
-                __syncthreads();
             } else {
                 const int h = sx8(S[0].x >> 8) - qe;
                 __syncthreads();
