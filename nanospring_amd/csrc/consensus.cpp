@@ -114,7 +114,16 @@ void Arena::release(void *p, unsigned cls)
 // ---------------------------------------------------------------------------
 // nodes and edges
 // ---------------------------------------------------------------------------
-void Edge::add_read(Arena &a, read_t r) { ++count; reads.insert_at(a, (size_t)(std::lower_bound(reads.begin(), reads.end(), r) - reads.begin()), r); }
+void Edge::add_read(Arena &a, read_t r)
+{
+    ++count;
+    const read_t *b = reads.begin();
+    size_t n = reads.size(), i;
+    if (n == 0 || b[n - 1] < r) i = n;                                   // the common case while a contig grows: ids above all present
+    else if (n <= 8) { i = 0; while (b[i] < r) ++i; }
+    else i = (size_t)(std::lower_bound(b, b + n, r) - b);
+    reads.insert_at(a, i, r);
+}
 
 Edge *Node::edge_to(Node *n) const { for (Edge *e : out) if (e->sink == n) return e; return nullptr; }
 Edge *Node::edge_to_side(char b) const { for (Edge *e : out) if (!e->sink->on_main && e->sink->base == b) return e; return nullptr; }
@@ -802,14 +811,21 @@ std::string meta_data(uint64_t n_reads, const std::vector<StreamSet> &threads)
     return s;
 }
 
-void reverse_complement(const std::string &s, std::string &out)
+namespace {
+struct CompTable {
+    char t[256];
+    CompTable() { for (int i = 0; i < 256; ++i) t[i] = (char)i; t['A'] = 'T', t['T'] = 'A', t['C'] = 'G', t['G'] = 'C'; }
+};
+const CompTable kComp;
+}  // namespace
+
+void reverse_complement(const char *s, size_t n, std::string &out)
 {
-    out.resize(s.size());
-    for (size_t i = 0; i < s.size(); ++i) {
-        const char c = s[s.size() - 1 - i];
-        out[i] = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
-    }
+    out.resize(n);
+    char *o = &out[0];
+    for (size_t i = 0; i < n; ++i) o[i] = kComp.t[(uint8_t)s[n - 1 - i]];
 }
+void reverse_complement(const std::string &s, std::string &out) { reverse_complement(s.data(), s.size(), out); }
 
 // ---------------------------------------------------------------------------
 // decoder

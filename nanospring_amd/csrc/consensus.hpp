@@ -82,7 +82,8 @@ struct SmallVec {
     {
         if (n == cap) reserve(a, n + 1);
         T *d = data();
-        memmove(d + i + 1, d + i, (n - i) * sizeof(T));
+        if (n - i <= 16) { for (size_t j = n; j > i; --j) d[j] = d[j - 1]; }       // short tails: cheaper than a libc call
+        else memmove(d + i + 1, d + i, (n - i) * sizeof(T));
         d[i] = v;
         ++n;
     }
@@ -253,6 +254,7 @@ bool decode_streams(const StreamSet &s, std::vector<std::pair<read_t, std::strin
 std::string meta_data(uint64_t n_reads, const std::vector<StreamSet> &threads);            // finishWriteConsensus, src/Consensus.cpp:370-386
 
 void reverse_complement(const std::string &s, std::string &out);                            // include/ReadData.h:163-172
+void reverse_complement(const char *s, size_t n, std::string &out);
 
 }  // namespace cons
 }  // namespace nsgpu

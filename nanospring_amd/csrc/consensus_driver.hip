@@ -203,7 +203,7 @@ struct Driver {
                 ++b.n_minhash_new;
                 if (read_len(r) < 32) continue;
                 const double r0 = now_ms();
-                if (b.strand) { std::string fwd(read_ptr(r), read_len(r)); cons::reverse_complement(fwd, b.query); }
+                if (b.strand) cons::reverse_complement(read_ptr(r), read_len(r), b.query);
                 else b.query.assign(read_ptr(r), read_len(r));
                 b.dbg_rc += now_ms() - r0;
                 b.pend = r;
