@@ -102,3 +102,43 @@ def test_cigar_consumes_both_sequences_at_scale(gpu):
                 if op == 1: j += ln
                 else: i += ln
         assert sc == ez[8]
+
+
+VARIANT_WORKER = r'''
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import nanospring_amd as ns
+from tests import oracle_lib
+from tests.test_ksw2_oracle import cases
+orc = oracle_lib.Oracle()
+g = ns.NsGpu()
+probs = cases(4711, 300)
+rng = np.random.RandomState(3)
+for ql, tl, flag, w in [(900, 950, 0x08, 751), (1500, 1400, 0x40, 751), (2100, 2300, 0x42, 751), (700, 40, 0x40, 751), (60, 900, 0xC2, 751)]:
+    q, t = oracle_lib.ksw_random_problem(rng, ql, tl, err=0.06)
+    probs.append((q, t, w, 400, 0 if flag >= 0x40 else -1, flag))
+bad = 0
+for prm in (oracle_lib.KSW_DEFAULT, dict(a=10, b=30, sc_ambi=5, q=30, e=20, q2=80, e2=10), dict(a=1, b=9, sc_ambi=1, q=16, e=2, q2=41, e2=1)):
+    ezs, cigs = ns.ksw_extd2_batch(g, probs, **prm)
+    for i, (q, t, w, zd, eb, fl) in enumerate(probs):
+        we, wc = oracle_lib.oracle_ksw(orc, q, t, w, zd, eb, fl, prm)
+        if ezs[i] != we or not np.array_equal(cigs[i], wc):
+            bad += 1
+print("RESULT", bad)
+'''
+
+
+@pytest.mark.parametrize("env", [{}, {"NSGPU_KSW_NO_WG": "1"}])
+def test_scores_that_wrap_int8_in_earnest(env):
+    """minimap2's scores keep every in-band value small; the int8 wrap-around arithmetic of the reference only shows in
+    the out-of-band cells of 16-cell blocks.  With large scores (q2 + e2 = 90) in-band values wrap too -- the reference
+    wraps, the oracle wraps, the kernels must wrap identically -- for the workgroup kernels and (NSGPU_KSW_NO_WG) for the
+    one-wave kernel alone."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", VARIANT_WORKER % {"root": root}], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert int(line[1]) == 0, (env, line)

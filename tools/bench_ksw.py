@@ -21,3 +21,5 @@ for it in range(3):
     ns.ksw_extd2_batch(g, probs)
     dt = time.perf_counter() - t0
     print(f"batch {n}: wall {dt*1e3:.1f} ms  ({cells/dt/1e9:.1f} GCUPS incl. host packing + copies)")
+st = ns.align_stats(g)
+print(f"kernels: {st['dp_launches']} launches, sum {st['dp_kernel_sum_ms']:.2f} ms -> {3 * cells / st['dp_kernel_sum_ms'] / 1e6:.1f} GCUPS (kernel only)")
