@@ -36,6 +36,8 @@ unsigned host_threads()
             }
             fclose(f);
         }
+        // one process per GPU: the ranks of a node share the cores (torchrun exports LOCAL_WORLD_SIZE)
+        if (const char *e = getenv("LOCAL_WORLD_SIZE")) { const int l = atoi(e); if (l > 1) v = v / (unsigned)l ? v / (unsigned)l : 1; }
         if (const char *e = getenv("NSGPU_THREADS")) { int x = atoi(e); if (x > 0) v = (unsigned)x; }
         if (v == 0) v = 8;
         if (v > 256) v = 256;
