@@ -208,7 +208,7 @@ int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::A
     std::vector<uint32_t> live(n_pairs);
     for (size_t i = 0; i < n_pairs; ++i) live[i] = (uint32_t)i;
     std::vector<KswTask> tasks;
-    std::vector<uint8_t> pool;
+    nsgpu_ctx::KswWs &KW = c->kws[ws_index];       // the DP sequence pool is staged in pinned memory: one DMA, no pageable bounce
     std::vector<KswResult> res;
     std::vector<uint32_t> cig;
     std::vector<uint64_t> coff;
@@ -236,7 +236,14 @@ int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::A
         if (live.empty()) break;
         NS_CHECK(nb < (1ull << 32), NSGPU_ERR_RANGE, "align: DP sequence pool exceeds 4 GiB; use smaller batches");
         tasks.resize(nt);
-        pool.resize(nb + 16);
+        if (KW.h_pool_cap < nb + 16) {
+            if (KW.h_pool) NS_HIP(hipHostFree(KW.h_pool));
+            KW.h_pool = nullptr, KW.h_pool_cap = 0;
+            const size_t want = (nb + 16) * 3 / 2 + 4096;
+            NS_HIP(hipHostMalloc(reinterpret_cast<void **>(&KW.h_pool), want, hipHostMallocDefault));
+            KW.h_pool_cap = want;
+        }
+        uint8_t *const pool = KW.h_pool;
         parallel_for(live.size(), [&](size_t li) {
             AlignJob &J = jobs[live[li]];
             size_t ti = t_off[li], bo = b_off[li];
@@ -245,7 +252,7 @@ int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::A
                 const int ql = k.qe - k.qs, tl = k.re - k.rs;
                 t.qoff = (uint32_t)bo; t.toff = (uint32_t)(bo + ql); t.qlen = ql; t.tlen = tl;
                 t.w = k.w; t.zdrop = k.zdrop; t.end_bonus = k.end_bonus; t.flag = k.flag;
-                uint8_t *q = pool.data() + bo, *tt = q + ql;
+                uint8_t *q = pool + bo, *tt = q + ql;
                 const uint8_t *qs = J.qseq.data() + k.qs, *ts = J.ref->seq.data() + k.rs;
                 if (k.flag & 0x02) {            // left extension: both sequences reversed (align.c:693-696)
                     for (int x = 0; x < ql; ++x) q[x] = qs[ql - 1 - x];
@@ -256,7 +263,7 @@ int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::A
         });
         double a2 = now_ms();
         host_ms += a2 - a1;
-        NS_TRY(ksw_run_batch(c, tasks, pool.data(), nb, kp, res, cig, coff, ws_index));
+        NS_TRY(ksw_run_batch(c, tasks, pool, nb, kp, res, cig, coff, ws_index));
         double a3 = now_ms();
         dp_ms += a3 - a2;
         dp_tasks += nt;

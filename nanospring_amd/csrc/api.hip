@@ -149,6 +149,7 @@ void nsgpu_destroy(nsgpu_ctx *c)
         if (w.t_b) (void)hipEventDestroy(w.t_b);
         for (hipEvent_t e : w.ev) if (e) (void)hipEventDestroy(e);
         if (w.stream) (void)hipStreamDestroy(w.stream);
+        if (w.h_pool) (void)hipHostFree(w.h_pool);
     }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
