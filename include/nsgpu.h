@@ -80,6 +80,12 @@ int nsgpu_load_reads_ascii(nsgpu_ctx *ctx, const char *bases, const uint64_t *of
  * read r occupies packed[byte_off[r] .. byte_off[r] + (len[r]+3)/4). */
 int nsgpu_load_reads_packed(nsgpu_ctx *ctx, const uint8_t *packed, const uint64_t *byte_off,
                             const uint32_t *len, uint32_t n_reads);
+/* ---- f3 (the step in front of the path): ReadData::loadFromFastqFile (src/ReadData.cpp:78-221) for plain FASTQ text
+ *      already in host memory (gzip is the caller's business).  Parsed on the GPU with std::getline's rules: read r =
+ *      the whole line 4r+1 (a '\r' counts as a base and folds through baseToInt like every other byte), a missing base
+ *      line is a read of length 0, an unterminated last line counts when non-empty.  At most 4 GiB of text per call.
+ *      Errors like the reference: no reads, or 2^32-1 reads ("Too many reads for read_t type to handle."). ---- */
+int nsgpu_load_fastq(nsgpu_ctx *ctx, const char *text, size_t n_bytes, uint32_t *n_reads_out);
 uint32_t nsgpu_num_reads(const nsgpu_ctx *ctx);
 uint64_t nsgpu_num_bases(const nsgpu_ctx *ctx);
 /* ReadData::getRead (src/ReadData.cpp:225-235): read r as ASCII (A/T/C/G), out must hold len[r] bytes. */

@@ -45,6 +45,8 @@ static int store_prepare(nsgpu_ctx *c, SeqStore &st, const uint32_t *len, uint32
     return NSGPU_OK;
 }
 
+int store_prepare_lens(nsgpu_ctx *c, SeqStore &st, const uint32_t *len, uint32_t n) { return store_prepare(c, st, len, n); }
+
 static int store_from_ascii(nsgpu_ctx *c, SeqStore &st, const char *bases, const uint64_t *off, uint32_t n)
 {
     std::vector<uint32_t> len(n);
@@ -127,7 +129,7 @@ void nsgpu_destroy(nsgpu_ctx *c)
     c->reads.release(); c->queries.release();
     DevBuf *bufs[] = {&c->ascii, &c->aoff, &c->salts, &c->sketch, &c->sketch_rc, &c->qsketch, &c->idx_keys, &c->idx_ids, &c->idx_tmp_k,
                       &c->idx_tmp_v, &c->idx_tmp_e, &c->idx_tmp_e2, &c->idx_sort_ws, &c->f_pool, &c->f_qstart, &c->f_qcnt, &c->f_qm, &c->f_off,
-                      &c->f_ids, &c->f_ctrl, &c->f_ovf_list, &c->f_ovf_cnt, &c->f_scan_ws, &c->rep_flags};
+                      &c->f_ids, &c->f_ctrl, &c->f_ovf_list, &c->f_ovf_cnt, &c->f_scan_ws, &c->rep_flags, &c->fq_cnt, &c->fq_base, &c->fq_nlpos, &c->fq_len};
     for (DevBuf *b : bufs) b->release();
     c->t_stage.destroy(); c->t_kernel.destroy();
     if (c->cons_engine) c->cons_engine_free(c->cons_engine);

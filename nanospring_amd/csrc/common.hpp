@@ -106,6 +106,8 @@ struct nsgpu_ctx {
     uint64_t f_total = 0;        // candidates of the last filter call
     uint32_t f_nq = 0;
     nsgpu::DevBuf rep_flags;
+    nsgpu::DevBuf fq_cnt, fq_base, fq_nlpos, fq_len;   // FASTQ ingest (fastq.hip)
+    double fastq_ms = 0;
     // ksw2 batches
     // two workspaces: the contig engine aligns two half batches from two host threads, so that one half's host work
     // (seeding, chaining, CIGAR bookkeeping) overlaps the other half's DP kernels

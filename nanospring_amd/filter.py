@@ -110,6 +110,14 @@ class NsGpu:
         self._keep = (bases, off)
         check(self.lib, self.lib.nsgpu_load_reads_ascii(self.ctx, _ptr(bases), _ptr(off), len(off) - 1))
 
+    def load_fastq(self, text):
+        """Plain FASTQ text (bytes) -> reads, parsed on the GPU with the reference's getline rules (ReadData::loadFromFastqFile)."""
+        buf = np.frombuffer(bytes(text), dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, dtype=np.uint8)
+        self._keep = buf
+        n = C.c_uint32()
+        check(self.lib, self.lib.nsgpu_load_fastq(self.ctx, _ptr(buf) if buf.size else None, buf.size, C.byref(n)))
+        return n.value
+
     def load_reads_packed(self, packed, byte_off, lens):
         packed = np.ascontiguousarray(packed, dtype=np.uint8)
         byte_off = np.ascontiguousarray(byte_off, dtype=np.uint64)

@@ -200,6 +200,37 @@ int oracle_check_repetitive(const char *s, uint64_t len)
     return 0;
 }
 
+/* f3: ReadData::loadFromFastqFile_highmem / _lowmem (src/ReadData.cpp:86-151, 156-221) on text in memory, as the
+ * std::getline loop it is:
+ *     while (getline(name)) { getline(bases); ++numReads; getline(plus); getline(quality); }
+ * getline extracts up to (not including) '\n'; it fails -- and leaves the string EMPTY -- only when no character at all
+ * could be extracted.  So a read is the whole line 4r+1 (a '\r' included), a missing base line is a read of length 0,
+ * and an unterminated last line counts when it is not empty.  start[r] / len[r] locate read r's bases in the text.
+ * Returns numReads (also when it exceeds cap; then only the first cap entries are written). */
+static int fq_getline(const char *text, uint64_t n, uint64_t *pos, uint64_t *b, uint64_t *e)
+{
+    if (*pos >= n) { *b = *e = n; return 0; }          /* nothing left: failbit, string erased */
+    *b = *pos;
+    uint64_t i = *pos;
+    while (i < n && text[i] != '\n') ++i;
+    *e = i;
+    *pos = i < n ? i + 1 : n;                          /* the delimiter is extracted and dropped */
+    return 1;
+}
+
+uint64_t oracle_fastq_index(const char *text, uint64_t n, uint64_t *start, uint32_t *len, uint64_t cap)
+{
+    uint64_t pos = 0, nr = 0, b, e;
+    while (fq_getline(text, n, &pos, &b, &e)) {
+        if (!fq_getline(text, n, &pos, &b, &e)) b = e = 0;
+        if (nr < cap) { start[nr] = b; len[nr] = (uint32_t)(e - b); }
+        ++nr;
+        fq_getline(text, n, &pos, &b, &e);
+        fq_getline(text, n, &pos, &b, &e);
+    }
+    return nr;
+}
+
 int oracle_num_threads(void)
 {
 #ifdef _OPENMP

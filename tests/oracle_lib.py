@@ -104,6 +104,17 @@ class Oracle:
         b = s.encode() if isinstance(s, str) else bytes(s)
         return int(self.lib.oracle_check_repetitive(b, C.c_uint64(len(b))))
 
+    def fastq_index(self, text):
+        """(start, len) of every read's base line under the reference's getline loop (oracle_fastq_index)."""
+        b = np.frombuffer(bytes(text), dtype=np.uint8) if not isinstance(text, np.ndarray) else text
+        cap = b.size // 2 + 4
+        st = np.zeros(cap, dtype=np.uint64)
+        ln = np.zeros(cap, dtype=np.uint32)
+        f = self.lib.oracle_fastq_index
+        f.restype = C.c_uint64
+        n = int(f(_p(b) if b.size else None, C.c_uint64(b.size), _p(st), _p(ln), C.c_uint64(cap)))
+        return st[:n].copy(), ln[:n].copy()
+
     def num_threads(self):
         return int(self.lib.oracle_num_threads())
 

@@ -1,0 +1,81 @@
+"""FASTQ ingest.  The oracle restates the reference's std::getline loop (ReadData::loadFromFastqFile,
+src/ReadData.cpp:86-221; that translation unit needs Boost and cannot be built here: parity unpinned against reference
+bytes, pinned against hand-derived expectations of the getline rules below); the GPU parser must reproduce it byte for
+byte, including the reads' 2-bit folding."""
+import numpy as np
+import pytest
+
+from tests import oracle_lib
+
+FOLD = {0: "A", 1: "T", 2: "C", 3: "G"}
+
+
+def fold(b):
+    return "".join(FOLD[(c & 2) | ((c & 4) >> 2)] for c in b)
+
+
+# (text, expected list of base lines) -- derived by hand from std::getline semantics
+CASES = [
+    (b"@r0\nACGT\n+\n!!!!\n", [b"ACGT"]),
+    (b"@r0\nACGT\n+\n!!!!", [b"ACGT"]),                                   # no final newline
+    (b"@r0\nACGT\n+\n!!!!\n@r1\nTTGCA\n+\n#####\n", [b"ACGT", b"TTGCA"]),
+    (b"@r0\r\nACGT\r\n+\r\n!!!!\r\n", [b"ACGT\r"]),                       # CRLF: the '\r' is a base (folds to T)
+    (b"@r0\nACGT\n+\n!!!!\n\n", [b"ACGT", b""]),                          # trailing blank line = a name line of a record without bases
+    (b"@r0\nACGT\n+\n!!!!\n@r1", [b"ACGT", b""]),                         # truncated record: name only
+    (b"@r0\nACGT\n+\n!!!!\n@r1\nGG", [b"ACGT", b"GG"]),                   # truncated record: unterminated base line
+    (b"@r0\nACGT\n+\n!!!!\n@r1\nGG\n+", [b"ACGT", b"GG"]),
+    (b"@r0\n\n+\n\n", [b""]),                                              # empty read
+    (b"\n", [b""]),                                                        # a single empty name line
+    (b"@r0\nacgtnNxX\n+\n........\n", [b"acgtnNxX"]),                      # lower case, N, other bytes fold through baseToInt
+]
+
+
+def test_oracle_follows_getline():
+    orc = oracle_lib.Oracle()
+    for text, want in CASES:
+        st, ln = orc.fastq_index(text)
+        got = [text[int(s):int(s) + int(l)] for s, l in zip(st, ln)]
+        assert got == want, (text, got, want)
+    st, ln = orc.fastq_index(b"")
+    assert len(st) == 0
+
+
+def synth_fastq(seed, n, crlf=False, final_newline=True):
+    rng = np.random.RandomState(seed)
+    parts = []
+    for i in range(n):
+        ln = int(rng.choice([0, 1, 3, 31, 32, 33, 150, 4000, 20000])) + int(rng.randint(0, 40))
+        seq = "".join("ACGTNacgtn"[c] for c in rng.randint(0, 10, size=ln))
+        parts += ["@read%d some description" % i, seq, "+", "I" * ln]
+    nl = "\r\n" if crlf else "\n"
+    t = nl.join(parts) + (nl if final_newline else "")
+    return t.encode()
+
+
+@pytest.mark.gpu
+def test_gpu_ingest_equals_oracle():
+    import nanospring_amd as ns
+    orc = oracle_lib.Oracle()
+    g = ns.NsGpu()
+    texts = [t for t, _ in CASES] + [synth_fastq(1, 300), synth_fastq(2, 257, crlf=True), synth_fastq(3, 64, final_newline=False),
+                                     synth_fastq(4, 1000)[:-7], synth_fastq(5, 3) + b"\n\n\n"]
+    for text in texts:
+        st, ln = orc.fastq_index(text)
+        n = g.load_fastq(text)
+        assert n == len(st), (text[:60], n, len(st))
+        assert g.num_bases == int(ln.sum())
+        for r in range(n):
+            want = fold(text[int(st[r]):int(st[r]) + int(ln[r])])
+            assert g.get_read(r) == want, (text[:60], r)
+    with pytest.raises(ns.NsGpuError):
+        g.load_fastq(b"")
+    # the loaded reads feed the path like any others: sketches equal those of the same reads loaded as strings
+    text = synth_fastq(7, 120)
+    st, ln = orc.fastq_index(text)
+    salts = ns.mt19937_64_salts(60)
+    g.load_fastq(text)
+    a = g.sketch(salts)
+    g.load_reads([text[int(s):int(s) + int(l)] for s, l in zip(st, ln)])
+    b = g.sketch(salts)
+    assert np.array_equal(a, b)
+    g.close()
