@@ -185,115 +185,173 @@ double now_ms()
 }
 
 // One alignment request: query against a reference whose index the caller owns.
-int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::AlnOut> &outs, int ws_index)
+// The batch as a two-part job (align_begin / align_finish), so that the contig engine can leave the DP kernels of one
+// builder group in flight while it works on another group; align_requests is both parts back to back.
+namespace {
+
+// host step of all live jobs, then the DP tasks they are waiting for: descriptors + sequence pool (pinned)
+int batch_prepare_round(nsgpu_ctx *c, AlignBatch &B)
 {
-    double host_ms = 0, dp_ms = 0;
-    uint64_t dp_tasks = 0, rounds = 0;
     using namespace mm2;
-    const size_t n_pairs = reqs.size();
-    static const bool dbg_t = getenv("NSGPU_ALIGN_DEBUG") != nullptr;
-    const double d0 = now_ms();
-    outs.assign(n_pairs, AlnOut());
-    if (n_pairs == 0) return NSGPU_OK;
-    Opt opt;
-    opt.k = (int)c->prm.m_k, opt.w = (int)c->prm.m_w, opt.max_chain_iter = (int)c->prm.max_chain_iter;
-    std::vector<AlignJob> jobs(n_pairs);
-    for (size_t i = 0; i < n_pairs; ++i) {
-        jobs[i].start(reqs[i].idx, reqs[i].qry, (int)reqs[i].qry_len, opt);
-        // a query of length 0 has no sketch either way; pre_mz must be non-null to count as "given"
-        if (reqs[i].qry_mz) jobs[i].pre_mz = reqs[i].qry_mz, jobs[i].n_pre_mz = reqs[i].n_qry_mz;
+    const double a0 = now_ms();
+    parallel_for(B.live.size(), [&](size_t i) { B.jobs[B.live[i]].step(); });
+    std::vector<uint32_t> still;
+    B.t_off.clear(), B.b_off.clear();
+    size_t nt = 0, nb = 0;
+    for (uint32_t j : B.live) {
+        AlignJob &J = B.jobs[j];
+        if (J.finished) continue;
+        still.push_back(j);
+        B.t_off.push_back(nt), B.b_off.push_back(nb);
+        nt += J.cache.missing.size();
+        for (const DpKey &k : J.cache.missing) nb += (size_t)(k.qe - k.qs) + (size_t)(k.re - k.rs);
     }
+    B.live.swap(still);
+    B.nb = nb;
+    if (B.live.empty()) { B.host_ms += now_ms() - a0; return NSGPU_OK; }
+    NS_CHECK(nb < (1ull << 32), NSGPU_ERR_RANGE, "align: DP sequence pool exceeds 4 GiB; use smaller batches");
+    B.tasks.resize(nt);
+    nsgpu_ctx::KswWs &KW = c->kws[B.ws_index];      // the DP sequence pool is staged in pinned memory: one DMA, no pageable bounce
+    if (KW.h_pool_cap < nb + 16) {
+        if (KW.h_pool) NS_HIP(hipHostFree(KW.h_pool));
+        KW.h_pool = nullptr, KW.h_pool_cap = 0;
+        const size_t want = (nb + 16) * 3 / 2 + 4096;
+        NS_HIP(hipHostMalloc(reinterpret_cast<void **>(&KW.h_pool), want, hipHostMallocDefault));
+        KW.h_pool_cap = want;
+    }
+    uint8_t *const pool = KW.h_pool;
+    parallel_for(B.live.size(), [&](size_t li) {
+        AlignJob &J = B.jobs[B.live[li]];
+        size_t ti = B.t_off[li], bo = B.b_off[li];
+        for (const DpKey &k : J.cache.missing) {
+            KswTask &t = B.tasks[ti++];
+            const int ql = k.qe - k.qs, tl = k.re - k.rs;
+            t.qoff = (uint32_t)bo; t.toff = (uint32_t)(bo + ql); t.qlen = ql; t.tlen = tl;
+            t.w = k.w; t.zdrop = k.zdrop; t.end_bonus = k.end_bonus; t.flag = k.flag;
+            uint8_t *q = pool + bo, *tt = q + ql;
+            const uint8_t *qs = J.qseq.data() + k.qs, *ts = J.ref->seq.data() + k.rs;
+            if (k.flag & 0x02) {            // left extension: both sequences reversed (align.c:693-696)
+                for (int x = 0; x < ql; ++x) q[x] = qs[ql - 1 - x];
+                for (int x = 0; x < tl; ++x) tt[x] = ts[tl - 1 - x];
+            } else { memcpy(q, qs, ql); memcpy(tt, ts, tl); }
+            bo += (size_t)ql + tl;
+        }
+    });
+    B.host_ms += now_ms() - a0;
+    return NSGPU_OK;
+}
+
+// DP results back into the jobs' caches
+void batch_deliver(AlignBatch &B)
+{
+    using namespace mm2;
+    const double a0 = now_ms();
+    parallel_for(B.live.size(), [&](size_t li) {
+        AlignJob &J = B.jobs[B.live[li]];
+        size_t ti = B.t_off[li];
+        for (const DpKey &k : J.cache.missing) {
+            const KswResult &r = B.res[ti];
+            DpResult d;
+            d.max = r.max; d.zdropped = r.zdropped; d.max_q = r.max_q; d.max_t = r.max_t; d.mqe = r.mqe; d.mqe_t = r.mqe_t; d.mte = r.mte;
+            d.mte_q = r.mte_q; d.score = r.score; d.reach_end = r.reach_end;
+            d.cigar.assign(B.cig.begin() + B.coff[ti], B.cig.begin() + B.coff[ti] + r.n_cigar);
+            J.cache.done.emplace(k, std::move(d));
+            ++ti;
+        }
+    });
+    B.dp_tasks += B.tasks.size();
+    ++B.rounds;
+    B.host_ms += now_ms() - a0;
+}
+
+mm2::Opt batch_opt(const nsgpu_ctx *c)
+{
+    mm2::Opt opt;
+    opt.k = (int)c->prm.m_k, opt.w = (int)c->prm.m_w, opt.max_chain_iter = (int)c->prm.max_chain_iter;
+    return opt;
+}
+KswParams batch_ksw_params(const mm2::Opt &opt)
+{
     KswParams kp;
     kp.sc_mch = opt.a; kp.sc_mis = -opt.b; kp.sc_ambi = -opt.sc_ambi; kp.q = opt.q; kp.e = opt.e; kp.q2 = opt.q2; kp.e2 = opt.e2;
-    std::vector<uint32_t> live(n_pairs);
-    for (size_t i = 0; i < n_pairs; ++i) live[i] = (uint32_t)i;
-    std::vector<KswTask> tasks;
-    nsgpu_ctx::KswWs &KW = c->kws[ws_index];       // the DP sequence pool is staged in pinned memory: one DMA, no pageable bounce
-    std::vector<KswResult> res;
-    std::vector<uint32_t> cig;
-    std::vector<uint64_t> coff;
-    const double d1 = now_ms();
-    double d_serial = 0;
-    for (int round = 0; !live.empty(); ++round) {
-        NS_CHECK(round < 64, NSGPU_ERR_ARG, "align: no convergence after 64 DP rounds (internal error)");
-        double a0 = now_ms();
-        parallel_for(live.size(), [&](size_t i) { jobs[live[i]].step(); });
-        double a1 = now_ms();
-        host_ms += a1 - a0;
-        std::vector<uint32_t> still;
-        std::vector<size_t> t_off, b_off;
-        size_t nt = 0, nb = 0;
-        for (uint32_t j : live) {
-            AlignJob &J = jobs[j];
-            if (J.finished) continue;
-            still.push_back(j);
-            t_off.push_back(nt), b_off.push_back(nb);
-            nt += J.cache.missing.size();
-            for (const DpKey &k : J.cache.missing) nb += (size_t)(k.qe - k.qs) + (size_t)(k.re - k.rs);
-        }
-        live.swap(still);
-        d_serial += now_ms() - a1;
-        if (live.empty()) break;
-        NS_CHECK(nb < (1ull << 32), NSGPU_ERR_RANGE, "align: DP sequence pool exceeds 4 GiB; use smaller batches");
-        tasks.resize(nt);
-        if (KW.h_pool_cap < nb + 16) {
-            if (KW.h_pool) NS_HIP(hipHostFree(KW.h_pool));
-            KW.h_pool = nullptr, KW.h_pool_cap = 0;
-            const size_t want = (nb + 16) * 3 / 2 + 4096;
-            NS_HIP(hipHostMalloc(reinterpret_cast<void **>(&KW.h_pool), want, hipHostMallocDefault));
-            KW.h_pool_cap = want;
-        }
-        uint8_t *const pool = KW.h_pool;
-        parallel_for(live.size(), [&](size_t li) {
-            AlignJob &J = jobs[live[li]];
-            size_t ti = t_off[li], bo = b_off[li];
-            for (const DpKey &k : J.cache.missing) {
-                KswTask &t = tasks[ti++];
-                const int ql = k.qe - k.qs, tl = k.re - k.rs;
-                t.qoff = (uint32_t)bo; t.toff = (uint32_t)(bo + ql); t.qlen = ql; t.tlen = tl;
-                t.w = k.w; t.zdrop = k.zdrop; t.end_bonus = k.end_bonus; t.flag = k.flag;
-                uint8_t *q = pool + bo, *tt = q + ql;
-                const uint8_t *qs = J.qseq.data() + k.qs, *ts = J.ref->seq.data() + k.rs;
-                if (k.flag & 0x02) {            // left extension: both sequences reversed (align.c:693-696)
-                    for (int x = 0; x < ql; ++x) q[x] = qs[ql - 1 - x];
-                    for (int x = 0; x < tl; ++x) tt[x] = ts[tl - 1 - x];
-                } else { memcpy(q, qs, ql); memcpy(tt, ts, tl); }
-                bo += (size_t)ql + tl;
-            }
-        });
-        double a2 = now_ms();
-        host_ms += a2 - a1;
-        NS_TRY(ksw_run_batch(c, tasks, pool, nb, kp, res, cig, coff, ws_index));
-        double a3 = now_ms();
-        dp_ms += a3 - a2;
-        dp_tasks += nt;
-        ++rounds;
-        parallel_for(live.size(), [&](size_t li) {
-            AlignJob &J = jobs[live[li]];
-            size_t ti = t_off[li];
-            for (const DpKey &k : J.cache.missing) {
-                const KswResult &r = res[ti];
-                DpResult d;
-                d.max = r.max; d.zdropped = r.zdropped; d.max_q = r.max_q; d.max_t = r.max_t; d.mqe = r.mqe; d.mqe_t = r.mqe_t; d.mte = r.mte;
-                d.mte_q = r.mte_q; d.score = r.score; d.reach_end = r.reach_end;
-                d.cigar.assign(cig.begin() + coff[ti], cig.begin() + coff[ti] + r.n_cigar);
-                J.cache.done.emplace(k, std::move(d));
-                ++ti;
-            }
-        });
-        host_ms += now_ms() - a3;
+    return kp;
+}
+
+}  // namespace
+
+// Part 1: seeds, chains, the plan of every region's DP problems, and their launch.  B.reqs (and what its pointers refer to)
+// must stay alive until align_finish.
+int align_begin(nsgpu_ctx *c, AlignBatch &B, int ws_index)
+{
+    using namespace mm2;
+    const size_t n_pairs = B.reqs.size();
+    B.ws_index = ws_index, B.in_flight = false;
+    B.host_ms = B.dp_ms = 0, B.dp_tasks = B.rounds = 0;
+    B.jobs.clear();
+    B.live.clear();
+    if (n_pairs == 0) return NSGPU_OK;
+    const Opt opt = batch_opt(c);
+    B.jobs.resize(n_pairs);
+    for (size_t i = 0; i < n_pairs; ++i) {
+        B.jobs[i].start(B.reqs[i].idx, B.reqs[i].qry, (int)B.reqs[i].qry_len, opt);
+        // a query of length 0 has no sketch either way; pre_mz must be non-null to count as "given"
+        if (B.reqs[i].qry_mz) B.jobs[i].pre_mz = B.reqs[i].qry_mz, B.jobs[i].n_pre_mz = B.reqs[i].n_qry_mz;
     }
-    double b0 = now_ms();
-    parallel_for(n_pairs, [&](size_t i) { align_read_result(jobs[i], reqs[i].ref, reqs[i].ref_len, outs[i]); });
-    host_ms += now_ms() - b0;
+    B.live.resize(n_pairs);
+    for (size_t i = 0; i < n_pairs; ++i) B.live[i] = (uint32_t)i;
+    NS_TRY(batch_prepare_round(c, B));
+    if (B.live.empty()) return NSGPU_OK;
+    const double a0 = now_ms();
+    NS_TRY(ksw_batch_launch(c, B.tasks, c->kws[ws_index].h_pool, B.nb, batch_ksw_params(opt), B.res, B.cig, B.coff, ws_index));
+    B.dp_ms += now_ms() - a0;
+    B.in_flight = true;
+    return NSGPU_OK;
+}
+
+// Part 2: the DP results, the execution of the alignment skeleton on them (further DP rounds, should a plan have missed a
+// problem, run synchronously), and ConsensusGraph::alignRead's conversion of every pair.
+int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs)
+{
+    using namespace mm2;
+    const size_t n_pairs = B.reqs.size();
+    outs.assign(n_pairs, AlnOut());
+    if (n_pairs == 0) return NSGPU_OK;
+    const KswParams kp = batch_ksw_params(batch_opt(c));
+    if (B.in_flight) {
+        const double a0 = now_ms();
+        NS_TRY(ksw_batch_collect(c, B.tasks, B.res, B.cig, B.coff, B.ws_index));
+        B.dp_ms += now_ms() - a0;
+        B.in_flight = false;
+        batch_deliver(B);
+    }
+    for (int round = 0; !B.live.empty(); ++round) {
+        NS_CHECK(round < 64, NSGPU_ERR_ARG, "align: no convergence after 64 DP rounds (internal error)");
+        NS_TRY(batch_prepare_round(c, B));
+        if (B.live.empty()) break;
+        const double a0 = now_ms();
+        NS_TRY(ksw_run_batch(c, B.tasks, c->kws[B.ws_index].h_pool, B.nb, kp, B.res, B.cig, B.coff, B.ws_index));
+        B.dp_ms += now_ms() - a0;
+        batch_deliver(B);
+    }
+    const double b0 = now_ms();
+    parallel_for(n_pairs, [&](size_t i) { align_read_result(B.jobs[i], B.reqs[i].ref, B.reqs[i].ref_len, outs[i]); });
+    parallel_for(n_pairs, [&](size_t i) { AlignJob().swap_storage(B.jobs[i]); });      // free the jobs' heap blocks on all threads
+    B.host_ms += now_ms() - b0;
     {
         std::lock_guard<std::mutex> lk(c->stat_m);
-        c->aln_host_ms += host_ms, c->aln_dp_ms += dp_ms, c->aln_dp_tasks += dp_tasks, c->aln_rounds += rounds, c->aln_pairs += n_pairs;
+        c->aln_host_ms += B.host_ms, c->aln_dp_ms += B.dp_ms, c->aln_dp_tasks += B.dp_tasks, c->aln_rounds += B.rounds, c->aln_pairs += n_pairs;
     }
-    const double d2 = now_ms();
-    parallel_for(n_pairs, [&](size_t i) { AlignJob().swap_storage(jobs[i]); });      // free the jobs' heap blocks on all threads
-    if (dbg_t) fprintf(stderr, "[align] pairs %zu setup %.2f serial-in-rounds %.2f result %.2f free %.2f ms\n", n_pairs, d1 - d0, d_serial, d2 - b0, now_ms() - d2);
     return NSGPU_OK;
+}
+
+int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::AlnOut> &outs, int ws_index)
+{
+    AlignBatch B;
+    B.reqs.swap(reqs);
+    int rc = align_begin(c, B, ws_index);
+    if (rc == NSGPU_OK) rc = align_finish(c, B, outs);
+    B.reqs.swap(reqs);
+    return rc;
 }
 
 int align_batch(nsgpu_ctx *c, const char *refs, const uint64_t *roff, uint32_t n_refs, const char *qrys, const uint64_t *qoff,

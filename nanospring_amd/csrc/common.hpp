@@ -115,6 +115,8 @@ struct nsgpu_ctx {
         nsgpu::DevBuf k_tasks, k_order, k_seqs, k_p, k_cig, k_res, k_slab, k_ncig, k_coff, k_cig2, scan_ws;
         std::vector<hipEvent_t> ev;                                  // start/end event pairs, one pair per launch of a batch
         uint8_t *h_pool = nullptr; size_t h_pool_cap = 0;            // pinned staging of the DP sequence pool
+        std::vector<uint32_t> h_flat;                                // launch order of the batch in flight
+        size_t pend_n = 0, pend_n_ev = 0; uint64_t pend_n_launch = 0; // batch launched, not yet collected (ksw_batch_launch / _collect)
         hipStream_t stream = nullptr;                                // workspace 0 runs on the context's stream
         hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
         hipEvent_t side_done[3] = {nullptr, nullptr, nullptr}, side_fork = nullptr, t_a = nullptr, t_b = nullptr;

@@ -5,6 +5,7 @@
 #include <functional>
 #include <vector>
 #include "mm2.hpp"
+#include "ksw2.hpp"
 
 struct nsgpu_ctx;
 
@@ -30,6 +31,24 @@ struct SketchReq { const char *ptr; size_t len; };
 // stays valid until the next call.
 int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off);
 int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::AlnOut> &outs, int ws_index = 0);
+// the same in two parts, the DP kernels in flight between them (state of one batch)
+struct AlignBatch {
+    std::vector<AlignReq> reqs;
+    std::vector<mm2::AlignJob> jobs;
+    std::vector<uint32_t> live;
+    std::vector<KswTask> tasks;
+    std::vector<KswResult> res;
+    std::vector<uint32_t> cig;
+    std::vector<uint64_t> coff;
+    std::vector<size_t> t_off, b_off;
+    size_t nb = 0;
+    int ws_index = 0;
+    bool in_flight = false;
+    double host_ms = 0, dp_ms = 0;
+    uint64_t dp_tasks = 0, rounds = 0;
+};
+int align_begin(nsgpu_ctx *c, AlignBatch &B, int ws_index);
+int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs);
 int filter_strings_device(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq);   // api.hip: results stay in c->f_off / c->f_ids
 
 }  // namespace nsgpu

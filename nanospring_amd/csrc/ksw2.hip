@@ -696,6 +696,16 @@ size_t ksw_p_bytes(int qlen, int tlen, int w)
 int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs, size_t seq_bytes, const KswParams &pr,
                   std::vector<KswResult> &results, std::vector<uint32_t> &cigars, std::vector<uint64_t> &cig_off, int ws_index)
 {
+    NS_TRY(ksw_batch_launch(c, tasks, seqs, seq_bytes, pr, results, cigars, cig_off, ws_index));
+    return ksw_batch_collect(c, tasks, results, cigars, cig_off, ws_index);
+}
+
+// First half: uploads, all DP launches of the batch and the CIGAR-length scan are enqueued; nothing is waited for.  tasks,
+// results and cig_off must stay alive (and seqs until the stream has consumed it: pinned memory) up to ksw_batch_collect
+// with the same workspace.
+int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs, size_t seq_bytes, const KswParams &pr,
+                     std::vector<KswResult> &results, std::vector<uint32_t> &cigars, std::vector<uint64_t> &cig_off, int ws_index)
+{
     const size_t n = tasks.size();
     NS_CHECK(ws_index == 0 || ws_index == 1, NSGPU_ERR_ARG, "ksw: workspace index must be 0 or 1");
     nsgpu_ctx::KswWs &W = c->kws[ws_index];
@@ -706,6 +716,7 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
     results.assign(n, KswResult());
     cig_off.assign(n + 1, 0);
     cigars.clear();
+    c->kws[ws_index].pend_n = 0;
     if (n == 0) return NSGPU_OK;
     static const size_t kClass[3] = {4096, 16384, 65536};
     std::vector<uint32_t> order[4];          // fallback: one wave per problem (LDS classes 0..2, HBM slab 3)
@@ -748,7 +759,8 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
     NS_HIP(hipMemcpyAsync(W.k_tasks.p, tasks.data(), n * sizeof(KswTask), hipMemcpyHostToDevice, S));
     NS_HIP(hipMemcpyAsync(W.k_seqs.p, seqs, seq_bytes, hipMemcpyHostToDevice, S));
     NS_HIP(hipMemcpyAsync(W.k_res.p, results.data(), n * sizeof(KswResult), hipMemcpyHostToDevice, S));
-    std::vector<uint32_t> flat;
+    std::vector<uint32_t> &flat = W.h_flat;          // stays alive while the upload may still be reading it
+    flat.clear();
     size_t start[5] = {0, 0, 0, 0, 0}, wg_start[3] = {0, 0, 0};
     auto by_size = [&](uint32_t a, uint32_t b) { return (size_t)tasks[a].qlen * tasks[a].tlen > (size_t)tasks[b].qlen * tasks[b].tlen; };
     for (int k = 0; k < 4; ++k) {
@@ -852,6 +864,21 @@ int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs
     hipLaunchKernelGGL(ksw_ncigar_kernel, dim3((uint32_t)((n + 256) / 256)), dim3(256), 0, S, W.k_res.as<KswResult>(), (uint32_t)n, W.k_ncig.as<uint32_t>());
     NS_HIP(hipGetLastError());
     NS_TRY(scan_u32_to_u64(W.scan_ws, S, W.k_ncig.as<uint32_t>(), W.k_coff.as<uint64_t>(), (uint32_t)n));
+    W.pend_n = n, W.pend_n_ev = n_ev, W.pend_n_launch = n_launch;
+    return NSGPU_OK;
+}
+
+// Second half: waits for the batch, compacts the CIGARs on the device and fetches results + used CIGAR entries.
+int ksw_batch_collect(nsgpu_ctx *c, std::vector<KswTask> &tasks, std::vector<KswResult> &results, std::vector<uint32_t> &cigars,
+                      std::vector<uint64_t> &cig_off, int ws_index)
+{
+    nsgpu_ctx::KswWs &W = c->kws[ws_index];
+    const size_t n = W.pend_n, n_ev = W.pend_n_ev;
+    const uint64_t n_launch = W.pend_n_launch;
+    if (n == 0) return NSGPU_OK;
+    NS_CHECK(n == tasks.size() && results.size() == n && cig_off.size() == n + 1, NSGPU_ERR_ARG, "ksw: collect does not match the launched batch");
+    const hipStream_t S = ws_index == 0 ? c->stream : W.stream;
+    W.pend_n = 0;
     NS_HIP(hipMemcpyAsync(results.data(), W.k_res.p, n * sizeof(KswResult), hipMemcpyDeviceToHost, S));
     NS_HIP(hipMemcpyAsync(cig_off.data(), W.k_coff.p, (n + 1) * 8, hipMemcpyDeviceToHost, S));
     NS_HIP(hipStreamSynchronize(S));

@@ -28,4 +28,9 @@ size_t ksw_p_bytes(int qlen, int tlen, int w);
 int ksw_run_batch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs, size_t seq_bytes, const KswParams &pr,
                   std::vector<KswResult> &results, std::vector<uint32_t> &cigars, std::vector<uint64_t> &cig_off, int ws_index = 0);
 
+int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *seqs, size_t seq_bytes, const KswParams &pr,
+                     std::vector<KswResult> &results, std::vector<uint32_t> &cigars, std::vector<uint64_t> &cig_off, int ws_index);
+int ksw_batch_collect(nsgpu_ctx *c, std::vector<KswTask> &tasks, std::vector<KswResult> &results, std::vector<uint32_t> &cigars,
+                      std::vector<uint64_t> &cig_off, int ws_index);
+
 }  // namespace nsgpu
