@@ -120,7 +120,7 @@ struct nsgpu_ctx {
         hipStream_t stream = nullptr;                                // workspace 0 runs on the context's stream
         hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
         hipEvent_t side_done[3] = {nullptr, nullptr, nullptr}, side_fork = nullptr, t_a = nullptr, t_b = nullptr;
-    } kws[2];
+    } kws[3];                                                       // 0: the context's stream (direct API calls); 1, 2: own streams (contig engine, alternating slots)
     // batched minimizer sketches (mm_sketch.hip): device buffers + pinned staging both ways
     struct SketchWs {
         nsgpu::DevBuf seqs, soff, len, sob, vf, mk, vr, linv, npf, pushf, npr, pr, V, hk, PX, PY, PRUN, PSEQ, rm, nout, oscan, off, out, scan_ws;

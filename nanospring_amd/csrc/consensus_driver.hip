@@ -29,6 +29,8 @@ using cons::read_t;
 // A finished contig waiting for its edit emission (consensus + one edit script per read into the seven streams).  The
 // emission touches nothing but the contig's own graph, so it is taken off the builder's critical path: the builder moves
 // on to its next contig at once and the emission runs as a task of its own in the next host phase.
+constexpr int kGroups = 3;                    // pipeline groups: host phase | batches part 1 | batches part 2 (see run_consensus)
+
 struct FinishedContig {
     std::unique_ptr<cons::ContigGraph> g;     // null once emitted
     cons::StreamSet out;
@@ -62,7 +64,8 @@ struct Builder {
     std::vector<std::unique_ptr<FinishedContig>> contigs;     // in the order they were finished = output order
     size_t n_queued = 0;                                      // contigs[0 .. n_queued) were handed to the emission queue
     uint64_t n_minhash = 0, n_minhash_new = 0, n_aligner = 0, n_align_calls = 0, n_contigs = 0, n_lone = 0;
-    double cpu_ms = 0, max_ms = 0, last_ms = 0, write_ms = 0, dbg_w1 = 0, dbg_w2 = 0, dbg_w3 = 0, dbg_u = 0, dbg_m = 0, dbg_cyc = 0, dbg_init = 0, dbg_rc = 0, dbg_win = 0, dbg_start = 0;
+    double cpu_ms = 0, max_ms = 0, last_ms = 0, write_ms = 0, dbg_w1 = 0, dbg_w2 = 0, dbg_w3 = 0, dbg_u = 0, dbg_m = 0, dbg_cyc = 0, dbg_init = 0, dbg_rc = 0, dbg_win = 0, dbg_start = 0, dbg_max_u = 0, dbg_max_m = 0, dbg_long_ms = 0;
+    uint64_t dbg_long_n = 0;
     uint64_t dbg_c[5] = {0, 0, 0, 0, 0};
 };
 
@@ -225,6 +228,7 @@ struct Driver {
         b.cpu_ms += dt;
         b.last_ms = dt;
         if (dt > b.max_ms) b.max_ms = dt;
+        if (dt > 3.0) ++b.dbg_long_n, b.dbg_long_ms += dt;
     }
     void advance_inner(Builder &b)
     {
@@ -245,7 +249,10 @@ struct Driver {
                 g.update_graph(b.query, b.aln.edits, (ssize_t)b.aln.begin_offset, (ssize_t)b.aln.end_offset, b.pend + id_base, (long)b.aln.rel_pos, b.strand == 1);
                 const double u1 = now_ms();
                 g.calculate_main_path_greedy();
-                b.dbg_u += u1 - u0, b.dbg_m += now_ms() - u1;
+                const double u2 = now_ms();
+                b.dbg_u += u1 - u0, b.dbg_m += u2 - u1;
+                if (u1 - u0 > b.dbg_max_u) b.dbg_max_u = u1 - u0;
+                if (u2 - u1 > b.dbg_max_m) b.dbg_max_m = u2 - u1;
                 b.idx_valid = false;
                 b.accepted = false;
             }
@@ -276,8 +283,9 @@ struct Engine {
     std::vector<SketchReq> sk;
     std::vector<uint32_t> sk_ref;
     std::vector<uint64_t> mz_off;
-    std::vector<AlignReq> reqs, reqs2;
-    std::vector<mm2::AlnOut> outs, outs2;
+    AlignBatch ab[kGroups];                        // alignment batch of each group, DP kernels in flight between part 1 and part 2
+    std::vector<uint32_t> awho[kGroups];           // builders of that batch
+    std::vector<mm2::AlnOut> outs;
     Builder *local(uint32_t gid) { return gid % world == rank ? &D.B[gid / world] : nullptr; }
 };
 
@@ -308,7 +316,7 @@ static int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, 
     E->rank = rank, E->world = world, E->n_total = n_builders_total;
     const uint32_t n_local = n_builders_total > rank ? (n_builders_total - rank + world - 1) / world : 0;
     D.B.resize(n_local);
-    for (uint32_t i = 0; i < n_local; ++i) D.B[i].id = i, D.B[i].gid = rank + i * world, D.B[i].group = (int)((D.B[i].gid >> 3) & 1);
+    for (uint32_t i = 0; i < n_local; ++i) D.B[i].id = i, D.B[i].gid = rank + i * world, D.B[i].group = (int)((D.B[i].gid >> 3) % kGroups);
     memset(&c->cons_stats, 0, sizeof(c->cons_stats));
     c->cons_stats.n_builders = n_builders_total;
     c->have_cons = false;
@@ -373,7 +381,9 @@ static uint32_t engine_seed_resolve(nsgpu_ctx *c, const uint32_t *gids, const ui
 }
 
 // phases 4+5: window queries and alignments of the local builders (GPU batches); no claims yet
-static int engine_batches(nsgpu_ctx *c, int group)
+// batches, part 1: window queries (complete) and, for the builders that wait for an alignment, minimizer sketches, index,
+// seeds / chains / DP plan and the launch of the DP kernels -- which stay in flight until part 2
+static int engine_batches_begin(nsgpu_ctx *c, int group, int ws_index)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
@@ -430,37 +440,49 @@ static int engine_batches(nsgpu_ctx *c, int group)
         });
         const double g1 = now_ms();
         S.index_ms += g1 - g0;
-        // two half batches from two host threads: while one half waits for its DP kernels the other half's host
-        // work (seeding, chaining, CIGAR bookkeeping) has the cores; alignments are independent, the split is by position
-        static const bool no_split = getenv("NSGPU_ALIGN_SPLIT") == nullptr;      // measured: no gain (the DP phase is bound by its longest problem), off unless asked for
-        const size_t n0 = who.size() < 64 || no_split ? who.size() : (who.size() + 1) / 2;
-        std::vector<AlignReq> *rq[2] = {&E->reqs, &E->reqs2};
-        std::vector<mm2::AlnOut> *ot[2] = {&E->outs, &E->outs2};
-        rq[0]->clear(), rq[1]->clear();
+        AlignBatch &AB = E->ab[group < 0 ? 0 : group];
+        AB.reqs.clear();
         for (size_t w = 0; w < who.size(); ++w) {
             Builder &b = D.B[who[w]];
-            rq[w >= n0]->push_back(AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), mz + mo[q_base + w],
-                                            (size_t)(mo[q_base + w + 1] - mo[q_base + w])});
+            AB.reqs.push_back(AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), mz + mo[q_base + w],
+                                       (size_t)(mo[q_base + w + 1] - mo[q_base + w])});
         }
-        int rc1 = NSGPU_OK;
-        std::thread second;
-        if (!rq[1]->empty())
-            second = std::thread([&] { rc1 = hipSetDevice(c->prm.device) == hipSuccess ? align_requests(c, *rq[1], *ot[1], 1) : NSGPU_ERR_HIP; });
-        const int rc0 = align_requests(c, *rq[0], *ot[0], 0);
-        if (second.joinable()) second.join();
-        NS_TRY(rc0);
-        NS_TRY(rc1);
-        for (size_t w = 0; w < who.size(); ++w) {
-            Builder &b = D.B[who[w]];
-            b.aln = std::move(w < n0 ? (*ot[0])[w] : (*ot[1])[w - n0]);
-            ++b.n_align_calls;
-            b.accepted = false;
-            b.st = Builder::ALIGNED;
-        }
-        S.align_ms += now_ms() - g1;
-        ++S.n_align_rounds;
+        E->awho[group < 0 ? 0 : group] = who;
+        NS_TRY(align_begin(c, AB, ws_index));
+        { std::lock_guard<std::mutex> lk(c->stat_m); S.align_ms += now_ms() - g1; }
     }
     return NSGPU_OK;
+}
+
+
+// batches, part 2: DP results, execution of the alignment skeletons, alignRead's conversion; the builders become ALIGNED
+static int engine_batches_finish(nsgpu_ctx *c, int group)
+{
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    Driver &D = E->D;
+    nsgpu_consensus_stats &S = c->cons_stats;
+    const int gi = group < 0 ? 0 : group;
+    std::vector<uint32_t> &who = E->awho[gi];
+    if (who.empty()) return NSGPU_OK;
+    const double g1 = now_ms();
+    NS_TRY(align_finish(c, E->ab[gi], E->outs));
+    for (size_t w = 0; w < who.size(); ++w) {
+        Builder &b = D.B[who[w]];
+        b.aln = std::move(E->outs[w]);
+        ++b.n_align_calls;
+        b.accepted = false;
+        b.st = Builder::ALIGNED;
+    }
+    who.clear();
+    E->ab[gi].reqs.clear();
+    { std::lock_guard<std::mutex> lk(c->stat_m); S.align_ms += now_ms() - g1; ++S.n_align_rounds; }
+    return NSGPU_OK;
+}
+
+static int engine_batches(nsgpu_ctx *c, int group)
+{
+    NS_TRY(engine_batches_begin(c, group, 1));
+    return engine_batches_finish(c, group);
 }
 
 // phase 6a: (gid, read) of every local builder whose alignment succeeded
@@ -514,6 +536,11 @@ static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
         for (int k = 0; k < 5; ++k) dbg_c[k] += b.dbg_c[k];
         dbg_x[0] += b.dbg_init, dbg_x[1] += b.dbg_rc, dbg_x[2] += b.dbg_win, dbg_x[3] += b.dbg_start;
     }
+    if (getenv("NSGPU_CONS_DEBUG")) {
+        double mu = 0, mm = 0, lm = 0; uint64_t ln = 0;
+        for (Builder &b : D.B) { if (b.dbg_max_u > mu) mu = b.dbg_max_u; if (b.dbg_max_m > mm) mm = b.dbg_max_m; lm += b.dbg_long_ms; ln += b.dbg_long_n; }
+        fprintf(stderr, "[cons] longest update_graph %.1f ms, longest main path %.1f ms; builder steps > 3 ms: %llu, %.0f ms in total; crit %.0f ms\n", mu, mm, (unsigned long long)ln, lm, S.graph_crit_ms);
+    }
     if (getenv("NSGPU_CONS_DEBUG")) fprintf(stderr, "[cons] cpu-ms: graph total %.0f; initialize+first main path %.0f, query copy/revcomp %.0f, open_window %.0f, start_contig %.0f\n", S.graph_cpu_ms, dbg_x[0], dbg_x[1], dbg_x[2], dbg_x[3]);
     if (getenv("NSGPU_CONS_DEBUG"))
         fprintf(stderr, "[cons] cpu-ms: update_graph %.0f main_path %.0f (remove_cycles %.0f) write_main %.0f write_reads %.0f graph_free %.0f; main-path calls %llu cycles-skipped %llu spliced %llu spliced-nodes %llu walked-nodes %llu\n",
@@ -527,16 +554,26 @@ static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
     return NSGPU_OK;
 }
 
-// One pipeline slot: the host phase of group `adv_group` and the GPU batches of group `batch_group`, concurrently.
-static int engine_slot(nsgpu_ctx *c, int adv_group, int batch_group)
+// One pipeline slot: the host phase of group `host_group`, part 1 of the batches of `begin_group` and part 2 of the
+// batches of `finish_group`, concurrently (any of them may be -2 = nothing).
+static int engine_slot(nsgpu_ctx *c, int host_group, int begin_group, int finish_group, int ws_index)
 {
     static const bool serial = getenv("NSGPU_NO_OVERLAP") != nullptr;      // debugging aid: one after the other
-    if (serial) { engine_advance(c, false, adv_group); return engine_batches(c, batch_group); }
-    int rc = NSGPU_OK;
-    std::thread batches([&] { rc = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches(c, batch_group) : NSGPU_ERR_HIP; });
-    engine_advance(c, false, adv_group);
-    batches.join();
-    return rc;
+    if (serial) {
+        if (host_group != -2) engine_advance(c, false, host_group);
+        if (finish_group != -2) NS_TRY(engine_batches_finish(c, finish_group));
+        if (begin_group != -2) NS_TRY(engine_batches_begin(c, begin_group, ws_index));
+        return NSGPU_OK;
+    }
+    int rc1 = NSGPU_OK, rc2 = NSGPU_OK;
+    std::thread t1, t2;
+    if (begin_group != -2) t1 = std::thread([&] { rc1 = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches_begin(c, begin_group, ws_index) : NSGPU_ERR_HIP; });
+    if (finish_group != -2) t2 = std::thread([&] { rc2 = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches_finish(c, finish_group) : NSGPU_ERR_HIP; });
+    if (host_group != -2) engine_advance(c, false, host_group);
+    if (t1.joinable()) t1.join();
+    if (t2.joinable()) t2.join();
+    NS_TRY(rc1);
+    return rc2;
 }
 
 static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_out)
@@ -547,25 +584,27 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
     std::vector<uint32_t> ga, gb;
     double w_slot = 0, w_seed = 0, w_claim = 0;
     const double w_begin = now_ms() - E->t0;
-    // Two builder groups, half a period apart: in slot s group s & 1 runs its host phase (graph updates up to the next
-    // window / alignment request) while the other group's GPU batches (window lookups, sketches, alignment DP) are in
-    // flight, so that the cores are not idle during kernels nor the GPU during graph work.  At the slot boundary the
-    // batch group's read claims and then the host group's seed requests are resolved, in global builder order: the
-    // schedule is a function of the data only.
+    // Three builder groups, a third of a period apart.  In slot s group h = s % 3 runs its host phase (graph updates up
+    // to the next window / alignment request), group (s + 2) % 3 -- which did that in the slot before -- part 1 of its
+    // GPU batches (window lookups, sketches, seeds / chains, launch of the alignment DP) and group (s + 1) % 3 part 2 (DP
+    // results, alignment skeletons, edit scripts): the cores are not idle during kernels, nor the GPU during graph work,
+    // nor either during the other's bookkeeping.  At the slot boundary the part-2 group's read claims and then the host
+    // group's seed requests are resolved, in global builder order: the schedule is a function of the data only.
     for (uint32_t slot = 0;; ++slot) {
+        const int h = (int)(slot % kGroups), a = (int)((slot + 2) % kGroups), b = (int)((slot + 1) % kGroups);
         double t = now_ms();
-        NS_TRY(engine_slot(c, (int)(slot & 1), (int)((slot & 1) ^ 1)));
+        NS_TRY(engine_slot(c, h, a, b, 1 + (int)(slot & 1)));
         w_slot += now_ms() - t;
         t = now_ms();
-        engine_claim_requests(c, ga, gb, (int)((slot & 1) ^ 1));
+        engine_claim_requests(c, ga, gb, b);
         engine_claim_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size());
         w_claim += now_ms() - t;
         t = now_ms();
         for (;;) {
-            engine_seed_requests(c, ga, gb, (int)(slot & 1));
+            engine_seed_requests(c, ga, gb, h);
             if (ga.empty()) break;
             if (engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) == 0) break;
-            engine_advance(c, true, (int)(slot & 1));
+            engine_advance(c, true, h);
         }
         w_seed += now_ms() - t;
         if (E->n_done_global >= E->n_total) break;
@@ -613,11 +652,11 @@ int nsgpu_cons_advance(nsgpu_ctx *c, int only_fresh, int group)
     return NSGPU_OK;
 }
 
-int nsgpu_cons_slot(nsgpu_ctx *c, int adv_group, int batch_group)
+int nsgpu_cons_slot(nsgpu_ctx *c, uint32_t slot)
 {
     NS_CHECK(c && c->cons_engine, NSGPU_ERR_ARG, "nsgpu_cons_slot: call nsgpu_cons_begin first");
     NS_HIP(hipSetDevice(c->prm.device));
-    return engine_slot(c, adv_group, batch_group);
+    return engine_slot(c, (int)(slot % kGroups), (int)((slot + 2) % kGroups), (int)((slot + 1) % kGroups), 1 + (int)(slot & 1));
 }
 
 int nsgpu_cons_seed_requests(nsgpu_ctx *c, int group, uint32_t **gids_out, uint32_t **cursors_out, uint32_t *n_out)

@@ -211,9 +211,9 @@ def consensus_exchange(gpu, n_builders_total, dist, n_threads_out=1):
     n_coll = 0
     slot = 0
     while True:
-        h = slot & 1
-        F.check(lib, lib.nsgpu_cons_slot(ctx, h, h ^ 1))
-        ga, gb = all_gather_u32_lists(*take(lib.nsgpu_cons_claim_requests, h ^ 1), dist)
+        h, b = slot % 3, (slot + 1) % 3
+        F.check(lib, lib.nsgpu_cons_slot(ctx, slot))
+        ga, gb = all_gather_u32_lists(*take(lib.nsgpu_cons_claim_requests, b), dist)
         n_coll += 1
         ga, gb = np.ascontiguousarray(ga), np.ascontiguousarray(gb)
         done = C.c_uint32()
