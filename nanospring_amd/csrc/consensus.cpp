@@ -9,6 +9,7 @@
 #include <iterator>
 #include <new>
 #include <set>
+#include <sys/mman.h>
 
 #ifdef NSGPU_PROF
 #include <chrono>
@@ -30,8 +31,7 @@ using mm2::EditOp;
 // ---------------------------------------------------------------------------
 namespace {
 struct SlabCache {
-    std::vector<unsigned char *> free;
-    ~SlabCache() { for (unsigned char *p : free) ::free(p); }
+    std::vector<unsigned char *> free;     // region-backed slabs are not handed back at thread exit (process-lifetime regions)
 };
 thread_local SlabCache t_slabs;
 constexpr size_t kMaxCachedSlabsPerThread = 16384;      // x 512 KiB = 8 GiB
@@ -39,10 +39,32 @@ constexpr size_t kMaxCachedSlabsPerThread = 16384;      // x 512 KiB = 8 GiB
 
 static const bool g_no_slab_cache = getenv("NSGPU_NO_SLAB_CACHE") != nullptr;
 
+// Slabs are carved out of 32 MiB regions aligned to 2 MiB and advised as huge pages: a thread's graphs spread over
+// hundreds of MB that are walked edge by edge, and with 4 KiB pages nearly every edge is also a TLB miss.  Regions are
+// never returned to the system (slabs circulate through the per-thread caches for the life of the process).
+static const bool g_no_huge = getenv("NSGPU_NO_HUGEPAGES") != nullptr;
+namespace {
+struct Region { unsigned char *p = nullptr; size_t used = 0; };
+thread_local Region t_region;
+constexpr size_t kRegionBytes = 32u << 20;
+}  // namespace
+
 unsigned char *slab_acquire(size_t bytes)
 {
     if (g_no_slab_cache) return static_cast<unsigned char *>(calloc(1, bytes));
     if (!t_slabs.free.empty()) { unsigned char *p = t_slabs.free.back(); t_slabs.free.pop_back(); return p; }
+    if (!g_no_huge && bytes <= kRegionBytes) {
+        if (!t_region.p || t_region.used + bytes > kRegionBytes) {
+            void *r = mmap(nullptr, kRegionBytes + (2u << 20), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (r == MAP_FAILED) throw std::bad_alloc();
+            unsigned char *a = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(r) + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1));
+            (void)madvise(a, kRegionBytes, MADV_HUGEPAGE);
+            t_region.p = a, t_region.used = 0;
+        }
+        unsigned char *p = t_region.p + t_region.used;
+        t_region.used += bytes;
+        return p;
+    }
     void *p = nullptr;
     if (posix_memalign(&p, 64, bytes) != 0) throw std::bad_alloc();
     return static_cast<unsigned char *>(p);
@@ -51,7 +73,8 @@ unsigned char *slab_acquire(size_t bytes)
 void slab_release(unsigned char *p, size_t)
 {
     if (g_no_slab_cache) { ::free(p); return; }
-    if (t_slabs.free.size() < kMaxCachedSlabsPerThread) t_slabs.free.push_back(p);
+    // region-backed slabs must not reach free(): they stay in a cache (the cap only bounds posix_memalign'ed ones)
+    if (!g_no_huge || t_slabs.free.size() < kMaxCachedSlabsPerThread) t_slabs.free.push_back(p);
     else ::free(p);
 }
 
