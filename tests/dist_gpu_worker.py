@@ -12,7 +12,13 @@ import nanospring_amd as ns
 from nanospring_amd import dist as nd
 from nanospring_amd.filter import STREAMS
 
-dist.init_process_group("gloo")
+BACKEND = os.environ.get("NSGPU_TEST_BACKEND", "gloo")      # "nccl" (= RCCL) needs one GPU per rank: used with world size 1
+if BACKEND == "nccl":
+    import torch
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+else:
+    dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 n_reads, n_builders, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 bases, off = ns.synth_reads(41, 120000, n_reads, 3000.0)

@@ -65,3 +65,26 @@ def test_result_is_independent_of_rank_count(world):
         assert sum(x[2][k] for x in res) == st1[k], k
     m = nd.parse_meta(nd.merge_meta([x[1] for x in res]))
     assert m["numReads"] == N_READS and m["numThr"] == world and sum(m["numReadsInContig"]) == N_READS
+
+
+def test_exchange_path_over_rccl_world_size_one():
+    """The box has one GPU, so RCCL cannot run two ranks here; a world of one still drives every collective of the
+    exchange path (all-gathers of read shards, sketch rows and claim lists, on device tensors) through the real "nccl"
+    backend, and must reproduce the single-process run bit for bit."""
+    bases, off, st1, s1 = single()
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "o.pkl")
+        port = "29611"
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, NSGPU_TEST_BACKEND="nccl")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                            "--master-port", port, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(N_READS), str(N_BUILDERS), out],
+                           env=env, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        res = pickle.load(open(out, "rb"))
+    assert len(res) == 1
+    streams, md, st, bad = res[0]
+    assert bad == 0
+    for k in STREAMS:
+        assert streams[k] == s1[k], k
+    for k in ("n_contigs", "n_lone", "count_minhash", "count_aligner", "n_align_calls"):
+        assert st[k] == st1[k], k
