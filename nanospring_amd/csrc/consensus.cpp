@@ -537,7 +537,9 @@ void ContigGraph::remove_cycles()
             // walk_and_prune returns at once for edges into main-path nodes; only side branches need the
             // (copied, because the walk edits n->out) edge list
             bool side = false;
-            for (Edge *e : n->out) if (!e->sink->on_main) { side = true; break; }
+            // a node whose only out-edge is the path's own edge has no side branch: decided without touching the edge
+            if (!(ei < end && n->out.size() == 1 && n->out[0] == main_edges[ei]))
+                for (Edge *e : n->out) if (!e->sink->on_main) { side = true; break; }
             if (side) {
                 copy.assign(n->out.begin(), n->out.end());
                 for (Edge *e : copy) walk_and_prune(e, stack);
