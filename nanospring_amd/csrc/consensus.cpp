@@ -304,7 +304,29 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
             cur = e->sink;
         }
     };
+    // Between two edits the walk streams along the main path (hardware prefetch copes); every edit lands on a main-path
+    // node somewhere else: its line, its out-edges and their sinks are dependent misses.  The script says where the next
+    // edits fall, so their lines are requested a few edits ahead.
+    std::vector<uint32_t> &op_at = op_at_;           // main-path edge index at which op k starts (the reference's edgeInPath)
+    op_at.resize(script.size() + 1);
+    {
+        size_t e2 = begin_offset >= 1 ? (size_t)begin_offset : 0;
+        for (size_t k = 0; k < script.size(); ++k) {
+            op_at[k] = (uint32_t)(e2 < n_path_edges ? e2 : n_path_edges);
+            if (script[k].type == 0) e2 += script[k].num; else if (script[k].type == 2) ++e2;
+        }
+        op_at[script.size()] = (uint32_t)(e2 < n_path_edges ? e2 : n_path_edges);
+    }
+    size_t op_k = 0;
     for (const EditOp &op : script) {
+        {
+            const size_t k9 = op_k + 9, k6 = op_k + 6, k3 = op_k + 3;
+            if (k9 < script.size() && op_at[k9] >= 1) __builtin_prefetch(main_edges[op_at[k9] - 1], 0, 1);
+            // the edit leaves the path at the edge's source (its out list is searched and extended) and comes back at or behind its sink
+            if (k6 < script.size() && op_at[k6] >= 1) { const Edge *pe = main_edges[op_at[k6] - 1]; __builtin_prefetch(pe->source, 1, 1); __builtin_prefetch(pe->sink, 1, 1); }
+            if (k3 < script.size() && op_at[k3] >= 1) { const Node *n3 = main_edges[op_at[k3] - 1]->source; for (const Edge *pe : n3->out) __builtin_prefetch(pe, 1, 1); }
+            ++op_k;
+        }
         if (op.type == 0) {                          // SAME
             if (!cur) initial = cur = node_in_path;
             else {
@@ -384,10 +406,24 @@ void ContigGraph::calculate_main_path_greedy()
         for (size_t d : diverged_) if (d >= R && d >= chk_end && d <= m && (cand.empty() || cand.back() < d)) cand.push_back(d);
         if (cand.empty() || cand.back() != m) cand.push_back(m);
         auto old_node = [&](size_t i) { return i == 0 ? main_edges[0]->source : main_edges[i - 1]->sink; };
+        // The candidates are scattered over the path: a node, its out-edges and their counts are three dependent cache
+        // misses each.  The list is known up front, so the misses of the next candidates are started while this one is
+        // examined: edge c-1 (holds the node pointer) 9 ahead, the node 6 ahead, its out-edges 3 ahead.
+        Edge *const *old_edges = main_edges.begin();                     // re-pointed at `saved` once the path is cut
+        size_t old_base = 0;                                             // old edge i = old_edges[i - old_base]
+        auto fetch_ahead = [&](size_t ci_now) {
+            if (ci_now + 9 < cand.size()) { const size_t c9 = cand[ci_now + 9]; if (c9 >= 1 && c9 - 1 >= old_base) __builtin_prefetch(old_edges[c9 - 1 - old_base], 0, 1); }
+            if (ci_now + 6 < cand.size()) { const size_t c6 = cand[ci_now + 6]; if (c6 >= 1 && c6 - 1 >= old_base) __builtin_prefetch(old_edges[c6 - 1 - old_base]->sink, 0, 1); }
+            if (ci_now + 3 < cand.size()) {
+                const size_t c3 = cand[ci_now + 3];
+                if (c3 >= 1 && c3 - 1 >= old_base) { const Node *n3 = old_edges[c3 - 1 - old_base]->sink; for (const Edge *pe : n3->out) __builtin_prefetch(pe, 0, 1); }
+            }
+        };
         // first candidate whose choice changed (nothing to do before it)
         size_t ci = 0;
         for (; ci < cand.size(); ++ci) {
             const size_t c = cand[ci];
+            fetch_ahead(ci);
             if (old_node(c)->best_out() != (c < m ? main_edges[c] : nullptr)) break;
         }
         if (ci < cand.size()) {
@@ -400,8 +436,10 @@ void ContigGraph::calculate_main_path_greedy()
             main_path.erase(main_path.begin() + c0 + 1, main_path.end());
             size_t pos = c0;                                             // the new path so far ends at old node `pos` (== at)
             bool ended = false;
+            old_edges = saved.data(), old_base = c0;
             for (; ci < cand.size() && !ended; ++ci) {
                 const size_t c = cand[ci];
+                fetch_ahead(ci);
                 if (c < pos) continue;                                   // by-passed by an earlier detour
                 // old nodes pos .. c keep their edges
                 main_edges.append(saved.begin() + (pos - c0), saved.begin() + (c - c0));

@@ -218,6 +218,7 @@ private:
     size_t touch_idx_ = 0, touch_lo_ = (size_t)-1;
     std::vector<size_t> diverged_, cand_;     // main-path indices where the last update left the path / to re-check
     std::vector<Edge *> saved_;
+    std::vector<uint32_t> op_at_;
     bool have_touch_ = false;
     size_t consistent_from_ = (size_t)-1;     // main-path nodes with index >= this were chosen by best_out on the current counts
     uint64_t n_splits_ = 0;
