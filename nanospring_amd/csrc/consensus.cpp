@@ -693,13 +693,12 @@ size_t optimize_edit_script(const std::vector<EditOp> &in, std::vector<EditOp> &
 // list holds the id, Node::getNextNodeInRead).  With the read's own bases at hand the walk is guided by them: a node
 // with one out-edge needs no test at all, and among several out-edges the one whose sink carries the read's next base
 // is the read's edge whenever it is the only such edge -- the list lookup is only needed to break ties.
-void ContigGraph::collect_path(const GraphRead &r, read_t id, const ReadBases *src, std::vector<const Node *> &path) const
+template <class Visit>
+void ContigGraph::walk_read(const GraphRead &r, read_t id, const ReadBases *src, Visit visit) const
 {
-    path.clear();
-    path.reserve(r.len);
     const Node *cur = r.start;
     if (!src) {
-        while (cur) { path.push_back(cur); const Edge *e = cur->edge_in_read(id); cur = e ? e->sink : nullptr; }
+        while (cur) { visit(cur); const Edge *e = cur->edge_in_read(id); cur = e ? e->sink : nullptr; }
         return;
     }
     const char *fw = src->bases;
@@ -711,7 +710,7 @@ void ContigGraph::collect_path(const GraphRead &r, read_t id, const ReadBases *s
     };
     const size_t n_main = main_edges.size();
     for (size_t i = 0; i < L; ++i) {
-        path.push_back(cur);
+        visit(cur);
         if (i + 1 == L) break;
         if (cur->on_main) {
             // a read mostly follows the consensus: fetch the edge 12 and the node 6 steps down the main path (cum_weight
@@ -730,25 +729,20 @@ void ContigGraph::collect_path(const GraphRead &r, read_t id, const ReadBases *s
     }
 }
 
+// read2EditScript in one pass over the read's nodes: everything before the first main-path node is an insert, `pos` is that
+// node's consensus position (0 for a read that never touches the consensus, whose script is all inserts)
 size_t ContigGraph::read_to_edits(const GraphRead &r, read_t id, const ReadBases *src, std::vector<EditOp> &script, uint32_t &pos) const
 {
     script.clear();
     script.reserve(r.len / 8 + 16);
-    static thread_local std::vector<const Node *> path;
-    collect_path(r, id, src, path);
-    size_t first_main = 0;
-    while (first_main < path.size() && !path[first_main]->on_main) ++first_main;
-    if (first_main == path.size()) {                 // never touches the consensus: all inserts
-        pos = 0;
-        for (const Node *c : path) script.push_back(EditOp{1, (uint8_t)c->base, 0});
-        return path.size();
-    }
-    pos = (uint32_t)path[first_main]->cum_weight;
-    size_t dis = 0, at = path[first_main]->cum_weight, same = 0;
+    bool seen_main = false;
+    size_t dis = 0, at = 0, same = 0;
+    pos = 0;
     auto flush = [&]() { if (same > 0) { script.push_back(EditOp{0, 0, (uint32_t)same}); same = 0; } };
-    for (const Node *cur : path) {
+    walk_read(r, id, src, [&](const Node *cur) {
         if (cur->on_main) {
             const size_t p = cur->cum_weight;
+            if (!seen_main) seen_main = true, pos = (uint32_t)p, at = p;
             if (p > at) flush();
             for (; at < p; ++at) { script.push_back(EditOp{2, (uint8_t)'-', 0}); ++dis; }
             ++same;
@@ -758,7 +752,7 @@ size_t ContigGraph::read_to_edits(const GraphRead &r, read_t id, const ReadBases
             script.push_back(EditOp{1, (uint8_t)cur->base, 0});
             ++dis;
         }
-    }
+    });
     flush();
     return dis;
 }

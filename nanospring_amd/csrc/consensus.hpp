@@ -241,7 +241,7 @@ private:
     void remove_cycles();                                                                   // :653-691
     void walk_and_prune(Edge *e, std::vector<Edge *> &stack);                               // :693-714
     void split_path(Node *new_pre, Edge *e, const std::vector<read_t> &reads2split);        // :716-807
-    void collect_path(const GraphRead &r, read_t id, const ReadBases *src, std::vector<const Node *> &path) const;
+    template <class Visit> void walk_read(const GraphRead &r, read_t id, const ReadBases *src, Visit visit) const;
     size_t read_to_edits(const GraphRead &r, read_t id, const ReadBases *src, std::vector<mm2::EditOp> &script, uint32_t &pos) const;   // :1031-1096
     size_t write_read(StreamSet &o, const GraphRead &r, read_t id, const ReadBases *src) const;   // :1098-1178
 };
