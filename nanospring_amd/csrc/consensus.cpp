@@ -539,7 +539,9 @@ void ContigGraph::calculate_main_path_greedy()
     }
     const uint64_t splits_before = n_splits_;
     const auto tc0 = std::chrono::steady_clock::now();
+    const uint64_t skipped_before = dbg_cycles_skipped;
     remove_cycles();
+    if (dbg_cycles_skipped == skipped_before && n_splits_ == splits_before) ++dbg_cycles_idle;
     dbg_cycles_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
     // A re-routing (split_path) leaves best_out of every consistent main-path node as it was: at a main-path source it
     // replaces a side edge by a new edge with the same reads at the END of the out list (the main edge, being the first

@@ -225,7 +225,7 @@ private:
     static bool multi_in_side(const Node *n) { return !n->on_main && n->in.size() > 1; }
     void set_on_main(Node *n, bool v) { n_multi_in_side_ -= multi_in_side(n); n->on_main = v; n_multi_in_side_ += multi_in_side(n); }
 public:
-    uint64_t dbg_cycles_calls = 0, dbg_cycles_skipped = 0, dbg_spliced = 0, dbg_spliced_nodes = 0, dbg_walked_nodes = 0;
+    uint64_t dbg_cycles_calls = 0, dbg_cycles_skipped = 0, dbg_spliced = 0, dbg_spliced_nodes = 0, dbg_walked_nodes = 0, dbg_cycles_idle = 0;
     double dbg_cycles_ms = 0;
 private:
     Arena arena_;

@@ -115,7 +115,7 @@ struct Driver {
             b.g.reset();
         } else {
             b.dbg_cyc += g.dbg_cycles_ms;
-            b.dbg_c[0] += g.dbg_cycles_calls, b.dbg_c[1] += g.dbg_cycles_skipped, b.dbg_c[2] += g.dbg_spliced, b.dbg_c[3] += g.dbg_spliced_nodes, b.dbg_c[4] += g.dbg_walked_nodes;
+            b.dbg_c[0] += g.dbg_cycles_calls, b.dbg_c[1] += g.dbg_cycles_skipped, b.dbg_c[2] += g.dbg_spliced, b.dbg_c[3] += g.dbg_cycles_idle, b.dbg_c[4] += g.dbg_walked_nodes;
             fc->g = std::move(b.g);
         }
         b.contigs.push_back(std::move(fc));
@@ -543,7 +543,7 @@ static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
     }
     if (getenv("NSGPU_CONS_DEBUG")) fprintf(stderr, "[cons] cpu-ms: graph total %.0f; initialize+first main path %.0f, query copy/revcomp %.0f, open_window %.0f, start_contig %.0f\n", S.graph_cpu_ms, dbg_x[0], dbg_x[1], dbg_x[2], dbg_x[3]);
     if (getenv("NSGPU_CONS_DEBUG"))
-        fprintf(stderr, "[cons] cpu-ms: update_graph %.0f main_path %.0f (remove_cycles %.0f) write_main %.0f write_reads %.0f graph_free %.0f; main-path calls %llu cycles-skipped %llu spliced %llu spliced-nodes %llu walked-nodes %llu\n",
+        fprintf(stderr, "[cons] cpu-ms: update_graph %.0f main_path %.0f (remove_cycles %.0f) write_main %.0f write_reads %.0f graph_free %.0f; main-path calls %llu cycles-skipped %llu detours %llu cycle-scans-without-split %llu walked-nodes %llu\n",
                 dbg_w[3], dbg_w[4], dbg_w[5], dbg_w[0], dbg_w[1], dbg_w[2], (unsigned long long)dbg_c[0], (unsigned long long)dbg_c[1], (unsigned long long)dbg_c[2], (unsigned long long)dbg_c[3], (unsigned long long)dbg_c[4]);
     S.total_ms = now_ms() - E->t0;
     c->cons_n_reads_out = 0;
