@@ -42,6 +42,23 @@ def test_one_builder_equals_sequential_reference_loop():
     g.close()
 
 
+def test_cfg1_one_builder_equals_sequential_reference_loop():
+    """BASELINE configs[0] shape (the reference's CPU-runnable plumbing case: 1 235 reads of mean 8 kb, 20x of a 0.5 Mb
+    genome, -k 23 -n 60 -t 1): the GPU path with one builder must give the streams of the sequential -t 1 restatement
+    byte for byte -- with the reference's own minimap2 answering the alignments there when its object travelled."""
+    from tests import oracle_lib
+    bases, off = ns.synth_reads(7, 500000, 1235, 8000.0)
+    want, wst = host_lib.consensus(bases, off, ns.mt19937_64_salts(60), checks=False, ref_aligner=oracle_lib.mm2ref() is not None)
+    assert wst["n_bad_roundtrip"] == 0
+    g, st, streams, md = run(bases, off, 1)
+    for k in STREAMS:
+        assert streams[0][k] == want[k], k
+    assert md == want["metaData"]
+    assert st["count_aligner"] == wst["count_aligner"] > 1000 and st["n_contigs"] == wst["n_contigs"]
+    assert ns.consensus_verify(g) == 0
+    g.close()
+
+
 @pytest.mark.parametrize("n_builders,n_out", [(16, 1), (64, 3)])
 def test_many_builders_lossless_and_deterministic(n_builders, n_out):
     bases, off = ns.synth_reads(31, 150000, 600, 4000.0)
