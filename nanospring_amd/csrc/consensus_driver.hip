@@ -14,6 +14,9 @@
 // Any such schedule is one of the interleavings the reference's numThr-thread run can produce
 // (no try_lock ever fails); with ONE builder it is the reference's deterministic -t 1 schedule.
 // The result is deterministic for a given (reads, salts, n_builders).
+// The builders form three groups that go through these steps a third of a period apart (host phase |
+// batches part 1 with the DP launch | batches part 2), so that host cores and GPU work at the same
+// time: see run_consensus / engine_slot.
 #include "common.hpp"
 #include "consensus.hpp"
 #include "host_util.hpp"
