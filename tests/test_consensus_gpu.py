@@ -127,3 +127,38 @@ def test_shard_engine_with_global_id_base():
     for i in range(lo, hi):
         assert got[i] == b[int(off[i]):int(off[i + 1])]
     assert nd.parse_meta(md)["numReads"] == hi - lo
+
+
+def test_repeat_rich_genome_many_builders_lossless():
+    """A genome with an exact 4 kb duplication, tandem repeats and reads of both strands: the consensus graphs get cycles
+    to prune and paths to split (removeCycles / splitPath) all the time; any number of builders must stay lossless and
+    deterministic."""
+    from tests.align_cases import make_genome, mutate, revcomp
+    rng = np.random.RandomState(12)
+    g0 = make_genome(rng, 30000)
+    g0 = g0 + g0[5000:9000] + make_genome(rng, 15000) + "ACGGT" * 300 + make_genome(rng, 8000)
+    reads = []
+    for _ in range(320):
+        ln = int(max(400, rng.gamma(2.0, 1500.0)))
+        st = rng.randint(0, max(1, len(g0) - ln))
+        s = mutate(rng, g0[st:st + ln], 0.04)
+        reads.append(revcomp(s) if rng.randint(2) else s)
+    bases = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    outs = []
+    for n_builders in (1, 7, 48):
+        g, st, streams, md = run(bases, off, n_builders, 2)
+        assert ns.consensus_verify(g) == 0, n_builders
+        got = {}
+        for s2 in streams:
+            got.update(decode(s2))
+        assert len(got) == len(reads)
+        for i, r in enumerate(reads):
+            assert got[i] == r.encode(), (n_builders, i)
+        assert st["count_aligner"] > 150
+        outs.append((streams, md))
+        g.close()
+    g, st, streams, md = run(bases, off, 48, 2)
+    assert (streams, md) == outs[2]
+    g.close()
