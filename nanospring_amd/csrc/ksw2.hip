@@ -745,6 +745,20 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         else order[cls].push_back((uint32_t)i);
     }
     cig_off[n] = cig_total;
+    static const bool hist = getenv("NSGPU_KSW_HIST") != nullptr;        // debugging aid: shape of the workgroup-kernel problems
+    if (hist) {
+        for (int k = 1; k <= 2; ++k) {
+            size_t wb[6] = {0, 0, 0, 0, 0, 0}, rb[6] = {0, 0, 0, 0, 0, 0};
+            for (uint32_t i : wg[k]) {
+                const int wdt = ksw_max_width(tasks[i].qlen, tasks[i].tlen, tasks[i].w), rows = tasks[i].qlen + tasks[i].tlen;
+                ++wb[wdt <= 128 ? 0 : wdt <= 256 ? 1 : wdt <= 512 ? 2 : wdt <= 768 ? 3 : wdt <= 1280 ? 4 : 5];
+                ++rb[rows <= 512 ? 0 : rows <= 1024 ? 1 : rows <= 2048 ? 2 : rows <= 4096 ? 3 : rows <= 8192 ? 4 : 5];
+            }
+            if (!wg[k].empty())
+                fprintf(stderr, "KSWHIST class %d n %zu width<=128/256/512/768/1280/more %zu %zu %zu %zu %zu %zu rows<=512/1k/2k/4k/8k/more %zu %zu %zu %zu %zu %zu\n", k + 4,
+                        wg[k].size(), wb[0], wb[1], wb[2], wb[3], wb[4], wb[5], rb[0], rb[1], rb[2], rb[3], rb[4], rb[5]);
+        }
+    }
     // reset-state results for empty problems
     for (size_t i = 0; i < n; ++i) {
         KswResult &o = results[i];
