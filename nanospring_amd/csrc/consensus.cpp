@@ -9,6 +9,7 @@
 #include <iterator>
 #include <new>
 #include <set>
+#include <atomic>
 #include <sys/mman.h>
 
 #ifdef NSGPU_PROF
@@ -695,8 +696,12 @@ size_t optimize_edit_script(const std::vector<EditOp> &in, std::vector<EditOp> &
 // list holds the id, Node::getNextNodeInRead).  With the read's own bases at hand the walk is guided by them: a node
 // with one out-edge needs no test at all, and among several out-edges the one whose sink carries the read's next base
 // is the read's edge whenever it is the only such edge -- the list lookup is only needed to break ties.
-template <class Visit>
-void ContigGraph::walk_read(const GraphRead &r, read_t id, const ReadBases *src, Visit visit) const
+// visit(node) for every node of the read in order; visit_run(k) stands for k consecutive main-path nodes that follow the
+// node visited last on the main path (only used when the read's bases are at hand).
+static inline uint8_t base_bit(char b) { return b == 'A' ? 1 : b == 'C' ? 2 : b == 'G' ? 4 : b == 'T' ? 8 : 16; }
+
+template <class Visit, class VisitRun>
+void ContigGraph::walk_read(const GraphRead &r, read_t id, const ReadBases *src, Visit visit, VisitRun visit_run) const
 {
     const Node *cur = r.start;
     if (!src) {
@@ -711,18 +716,34 @@ void ContigGraph::walk_read(const GraphRead &r, read_t id, const ReadBases *src,
         return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
     };
     const size_t n_main = main_edges.size();
-    for (size_t i = 0; i < L; ++i) {
+    for (size_t i = 0; i < L;) {
         visit(cur);
-        if (i + 1 == L) break;
-        if (cur->on_main) {
-            // a read mostly follows the consensus: fetch the edge 12 and the node 6 steps down the main path (cum_weight
-            // is the node's main-path index, set by write_reads)
-            const size_t j = cur->cum_weight;
-            if (j + 12 < n_main) { __builtin_prefetch(main_edges[j + 12], 0, 1); __builtin_prefetch(main_edges[j + 6]->sink, 0, 1); }
-        }
+        if (++i == L) break;                             // i = bases consumed
         const auto &out = cur->out;
+        if (cur->on_main) {
+            // A read mostly follows the consensus (cum_weight = the node's main-path index, main_nodes_ = the path's nodes,
+            // next_fork_[j] = first index >= j whose node has more than one way out or ends the path; all set by write_reads).
+            // A main-path node with a single way out leads to the next main-path node, and so on up to the next fork: that
+            // stretch is accounted for without looking at its nodes.
+            const size_t j = cur->cum_weight;
+            if (out.size() == 1 && j < n_main) {
+                const size_t j1 = j + 1, stop = next_fork_[j1];
+                const size_t k = stop - j1 < L - i ? stop - j1 : L - i;
+                if (k) { visit_run(k); i += k; if (i == L) break; }
+                cur = main_nodes_[j1 + k];
+                __builtin_prefetch(main_nodes_[next_fork_[j1 + k + 1 <= n_main ? j1 + k + 1 : n_main]], 0, 1);
+                continue;
+            }
+        }
         if (out.size() == 1) { cur = out[0]->sink; continue; }
-        const char nb = base_at(i + 1);
+        const char nb = base_at(i);
+        if (cur->on_main) {
+            // a fork on the main path: when the consensus goes on with the read's next base and no side branch starts with that
+            // base, the read's edge is the path's edge (the only out-edge whose sink carries the base); side_mask_ = bases of
+            // the side sinks, gathered once per contig
+            const size_t j = cur->cum_weight;
+            if (j < n_main && main_nodes_[j + 1]->base == nb && !(side_mask_[j] & base_bit(nb))) { cur = main_nodes_[j + 1]; continue; }
+        }
         const Edge *pick = nullptr;
         int cnt = 0;
         for (const Edge *e : out) if (e->sink->base == nb) { pick = e; ++cnt; }
@@ -754,16 +775,22 @@ size_t ContigGraph::read_to_edits(const GraphRead &r, read_t id, const ReadBases
             script.push_back(EditOp{1, (uint8_t)cur->base, 0});
             ++dis;
         }
-    });
+    }, [&](size_t k) { same += k, at += k; });       // k main-path nodes in a row right behind the last one: k more SAMEs
     flush();
     return dis;
 }
+
+std::atomic<uint64_t> g_emit_ns[4];
+static inline uint64_t emit_now() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 size_t ContigGraph::write_read(StreamSet &o, const GraphRead &r, read_t id, const ReadBases *src) const
 {
     uint32_t offset;
     static thread_local std::vector<EditOp> raw, es;
+    const uint64_t w0 = emit_now();
     read_to_edits(r, id, src, raw, offset);
+    const uint64_t w1 = emit_now();
+    g_emit_ns[1] += w1 - w0;
     write_var_uint32(offset, o.pos);
     const size_t dis = optimize_edit_script(raw, es);
     uint32_t ins_start = 0, ins_end = 0;
@@ -791,6 +818,7 @@ size_t ContigGraph::write_read(StreamSet &o, const GraphRead &r, read_t id, cons
     write_var_uint32(ins_end, o.pos);
     for (size_t i = es.size() - ins_end; i != es.size(); ++i) o.base.push_back((char)es[i].base);
     o.type.push_back('\n');
+    g_emit_ns[2] += emit_now() - w1;
     return dis;
 }
 
@@ -799,9 +827,26 @@ void ContigGraph::write_read_lone(StreamSet &o) const { o.lone += main_path; o.l
 
 void ContigGraph::write_reads(StreamSet &o, const std::function<ReadBases(read_t)> *source)
 {
+    const uint64_t e0 = emit_now();
     main_edges.front()->source->cum_weight = 0;
+    const size_t n_main = main_edges.size();
+    main_nodes_.resize(n_main + 1);
+    main_nodes_[0] = main_edges.front()->source;
     size_t i = 0;
-    for (Edge *e : main_edges) e->sink->cum_weight = ++i;
+    for (Edge *e : main_edges) { e->sink->cum_weight = ++i; main_nodes_[i] = e->sink; }
+    next_fork_.resize(n_main + 1);
+    next_fork_[n_main] = (uint32_t)n_main;
+    for (size_t j = n_main; j-- > 0;) next_fork_[j] = main_nodes_[j]->out.size() != 1 ? (uint32_t)j : next_fork_[j + 1];
+    side_mask_.assign(n_main + 1, 0);
+    for (size_t j = 0; j <= n_main; ++j) {
+        const Node *n = main_nodes_[j];
+        if (n->out.size() == 1 && j < n_main) continue;
+        const Edge *path_edge = j < n_main ? main_edges[j] : nullptr;
+        uint8_t m = 0;
+        for (const Edge *e : n->out) if (e != path_edge) m |= base_bit(e->sink->base);
+        side_mask_[j] = m;
+    }
+    g_emit_ns[0] += emit_now() - e0;
     read_t prev = 0;
     for (auto &it : reads) {
         const read_t diff = it.first - prev;

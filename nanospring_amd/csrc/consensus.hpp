@@ -219,6 +219,9 @@ private:
     std::vector<size_t> diverged_, cand_;     // main-path indices where the last update left the path / to re-check
     std::vector<Edge *> saved_;
     std::vector<uint32_t> op_at_;
+    std::vector<const Node *> main_nodes_;    // the main path's nodes in order (filled by write_reads for the emission walks)
+    std::vector<uint8_t> side_mask_;          // per main-path index: bases of the sinks of the out-edges other than the path's own
+    std::vector<uint32_t> next_fork_;         // per main-path index: next node with more than one way out (or the path's end)
     bool have_touch_ = false;
     size_t consistent_from_ = (size_t)-1;     // main-path nodes with index >= this were chosen by best_out on the current counts
     uint64_t n_splits_ = 0;
@@ -241,7 +244,7 @@ private:
     void remove_cycles();                                                                   // :653-691
     void walk_and_prune(Edge *e, std::vector<Edge *> &stack);                               // :693-714
     void split_path(Node *new_pre, Edge *e, const std::vector<read_t> &reads2split);        // :716-807
-    template <class Visit> void walk_read(const GraphRead &r, read_t id, const ReadBases *src, Visit visit) const;
+    template <class Visit, class VisitRun> void walk_read(const GraphRead &r, read_t id, const ReadBases *src, Visit visit, VisitRun visit_run) const;
     size_t read_to_edits(const GraphRead &r, read_t id, const ReadBases *src, std::vector<mm2::EditOp> &script, uint32_t &pos) const;   // :1031-1096
     size_t write_read(StreamSet &o, const GraphRead &r, read_t id, const ReadBases *src) const;   // :1098-1178
 };
