@@ -96,7 +96,7 @@ struct Edge;
 struct Node {                                 // 64 bytes, slab-aligned: one cache line
     char base;
     bool on_main = false;
-    uint32_t mark = 0;                        // scratch: old main-path index while a tail is being re-used
+    uint32_t reserved_ = 0;
     SmallVec<Edge *, 2> out, in;
     size_t cum_weight = 0;
     explicit Node(char b) : base(b) {}
