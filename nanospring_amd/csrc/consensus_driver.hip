@@ -283,6 +283,8 @@ struct Engine {
     std::string qbuf;
     std::vector<uint64_t> qoff, foff;
     std::vector<uint32_t> fids;
+    uint64_t slot_long_n[3] = {0, 0, 0};
+    double slot_long_ms[3] = {0, 0, 0};
     std::vector<FinishedContig *> emit_queue;      // finished contigs whose emission has not run yet
     std::vector<SketchReq> sk;
     std::vector<uint32_t> sk_ref;
@@ -571,11 +573,20 @@ static int engine_slot(nsgpu_ctx *c, int host_group, int begin_group, int finish
     }
     int rc1 = NSGPU_OK, rc2 = NSGPU_OK;
     std::thread t1, t2;
-    if (begin_group != -2) t1 = std::thread([&] { rc1 = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches_begin(c, begin_group, ws_index) : NSGPU_ERR_HIP; });
-    if (finish_group != -2) t2 = std::thread([&] { rc2 = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches_finish(c, finish_group) : NSGPU_ERR_HIP; });
+    double d1 = 0, d2 = 0;
+    if (begin_group != -2) t1 = std::thread([&] { const double x = now_ms(); rc1 = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches_begin(c, begin_group, ws_index) : NSGPU_ERR_HIP; d1 = now_ms() - x; });
+    if (finish_group != -2) t2 = std::thread([&] { const double x = now_ms(); rc2 = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches_finish(c, finish_group) : NSGPU_ERR_HIP; d2 = now_ms() - x; });
+    const double h0 = now_ms();
     if (host_group != -2) engine_advance(c, false, host_group);
+    const double dh = now_ms() - h0;
     if (t1.joinable()) t1.join();
     if (t2.joinable()) t2.join();
+    {   // which of the three parts set the length of the slot (debug breakdown)
+        Engine *E = static_cast<Engine *>(c->cons_engine);
+        const int w = dh >= d1 && dh >= d2 ? 0 : d1 >= d2 ? 1 : 2;
+        ++E->slot_long_n[w];
+        E->slot_long_ms[w] += w == 0 ? dh : w == 1 ? d1 : d2;
+    }
     NS_TRY(rc1);
     return rc2;
 }
@@ -613,6 +624,9 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
         w_seed += now_ms() - t;
         if (E->n_done_global >= E->n_total) break;
     }
+    if (getenv("NSGPU_CONS_DEBUG"))
+        fprintf(stderr, "[cons] slots set by: host phase %llu (%.0f ms), batches part 1 %llu (%.0f ms), part 2 %llu (%.0f ms)\n", (unsigned long long)E->slot_long_n[0],
+                E->slot_long_ms[0], (unsigned long long)E->slot_long_n[1], E->slot_long_ms[1], (unsigned long long)E->slot_long_n[2], E->slot_long_ms[2]);
     const double tf = now_ms();
     const int rc = engine_finish(c, n_threads_out);
     if (getenv("NSGPU_CONS_DEBUG")) {
