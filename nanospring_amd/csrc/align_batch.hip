@@ -19,6 +19,7 @@
 #include <condition_variable>
 #include "host_util.hpp"
 #include <memory>
+#include <deque>
 
 namespace nsgpu {
 
@@ -125,18 +126,44 @@ public:
         std::lock_guard<std::mutex> lk(m_);
         active_.erase(std::find(active_.begin(), active_.end(), job));
     }
+    // Background work of the lowest priority: run by workers that find nothing to do in any parallel loop, never waited for
+    // except by drain().
+    void post(std::function<void()> fn)
+    {
+        if (th_.empty()) { fn(); return; }
+        { std::lock_guard<std::mutex> lk(m_); bg_.push_back(std::move(fn)); }
+        cv_.notify_one();
+    }
+    void drain()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        bg_cv_.wait(lk, [this] { return bg_.empty() && bg_running_ == 0; });
+    }
 private:
     void worker(unsigned me)
     {
         uint64_t seen = 0;
         std::vector<std::shared_ptr<Job>> snap;
         for (;;) {
+            std::function<void()> bg;
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return gen_ != seen || stop_; });
+                cv_.wait(lk, [&] { return gen_ != seen || stop_ || !bg_.empty(); });
                 if (stop_) return;
-                seen = gen_;
-                snap = active_;
+                if (gen_ == seen) {                       // no new loop: take a background task
+                    bg = std::move(bg_.front());
+                    bg_.pop_front();
+                    ++bg_running_;
+                } else {
+                    seen = gen_;
+                    snap = active_;
+                }
+            }
+            if (bg) {
+                bg();
+                std::lock_guard<std::mutex> lk(m_);
+                if (--bg_running_ == 0 && bg_.empty()) bg_cv_.notify_all();
+                continue;
             }
             // serve until no job in the snapshot has work left; a job submitted meanwhile changes gen_ and is seen next
             for (bool any = true; any;) {
@@ -155,7 +182,9 @@ private:
     unsigned n_;
     std::vector<std::thread> th_;
     std::mutex m_;
-    std::condition_variable cv_;
+    std::condition_variable cv_, bg_cv_;
+    std::deque<std::function<void()>> bg_;
+    unsigned bg_running_ = 0;
     std::vector<std::shared_ptr<Job>> active_;
     uint64_t gen_ = 0;
     bool stop_ = false;
@@ -170,6 +199,13 @@ void parallel_for_impl(size_t n, const std::function<void(size_t)> &fn)
     if (n == 1 || host_threads() <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
     the_pool().run(n, fn);
 }
+
+void pool_post(std::function<void()> fn)
+{
+    if (host_threads() <= 1) { fn(); return; }
+    the_pool().post(std::move(fn));
+}
+void pool_drain() { if (host_threads() > 1) the_pool().drain(); }
 
 void parallel_for_pinned_impl(size_t n, const std::function<void(size_t)> &fn)
 {

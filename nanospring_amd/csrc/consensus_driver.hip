@@ -295,7 +295,7 @@ struct Engine {
     Builder *local(uint32_t gid) { return gid % world == rank ? &D.B[gid / world] : nullptr; }
 };
 
-static void engine_free(void *p) { delete static_cast<Engine *>(p); }
+static void engine_free(void *p) { pool_drain(); delete static_cast<Engine *>(p); }      // no emission task may outlive the engine
 
 static int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, uint32_t world)
 {
@@ -337,18 +337,20 @@ static void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
     const double a0 = now_ms();
-    // one parallel loop: first the emissions of the contigs finished so far (long tasks, any group's), then the builders of
-    // this group; the builder part starts at a multiple of the thread count so that builder i stays on thread i % threads
-    const size_t nt = host_threads() ? host_threads() : 1;
-    const size_t n_emit = only_fresh ? 0 : E->emit_queue.size(), base = (n_emit + nt - 1) / nt * nt;
-    par_for_pinned(base + D.B.size(), [&](size_t i) {
-        if (i < n_emit) { D.emit_contig(*E->emit_queue[i]); return; }
-        if (i < base) return;
-        Builder &b = D.B[i - base];
+    par_for_pinned(D.B.size(), [&](size_t i) {
+        Builder &b = D.B[i];
         if (in_group(b, group) && (!only_fresh || b.st == Builder::ADVANCE)) D.advance(b);
     });
-    if (!only_fresh) E->emit_queue.clear();
-    for (Builder &b : D.B) for (; b.n_queued < b.contigs.size(); ++b.n_queued) if (b.contigs[b.n_queued]->g) E->emit_queue.push_back(b.contigs[b.n_queued].get());
+    // the edit emission of the contigs finished in this phase: background tasks of the host pool, picked up whenever a
+    // thread has nothing else to do (nothing waits for them before the end of the stage)
+    static const bool sync_emit = getenv("NSGPU_SYNC_EMISSION") != nullptr;      // debugging aid: emit at once
+    for (Builder &b : D.B)
+        for (; b.n_queued < b.contigs.size(); ++b.n_queued) {
+            FinishedContig *fc = b.contigs[b.n_queued].get();
+            if (!fc->g) continue;
+            if (sync_emit) D.emit_contig(*fc);
+            else pool_post([&D, fc] { D.emit_contig(*fc); });
+        }
     c->cons_stats.graph_ms += now_ms() - a0;
     double mx = 0;
     for (Builder &b : D.B) if (in_group(b, group)) { if (b.last_ms > mx) mx = b.last_ms; b.last_ms = 0; }
@@ -526,9 +528,7 @@ static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
     // merge builders into the requested number of output "threads" (Compressor expects exactly numThr
     // file sets, src/Compressor.cpp:123-124; Decompressor reads numThr from metaData)
     c->cons_out.assign(n_threads_out, cons::StreamSet());
-    for (Builder &b : D.B) for (; b.n_queued < b.contigs.size(); ++b.n_queued) if (b.contigs[b.n_queued]->g) E->emit_queue.push_back(b.contigs[b.n_queued].get());
-    par_for(E->emit_queue.size(), [&](size_t i) { D.emit_contig(*E->emit_queue[i]); });
-    E->emit_queue.clear();
+    pool_drain();                                 // all edit emissions
     for (size_t i = 0; i < D.B.size(); ++i)
         for (auto &fc : D.B[i].contigs) c->cons_out[i * n_threads_out / (D.B.empty() ? 1 : D.B.size())].append(fc->out);
     double dbg_w[6] = {0, 0, 0, 0, 0, 0}, dbg_x[4] = {0, 0, 0, 0};

@@ -17,6 +17,9 @@ void parallel_for_impl(size_t n, const std::function<void(size_t)> &fn);
 template <class F> inline void par_for(size_t n, F fn) { parallel_for_impl(n, std::function<void(size_t)>(fn)); }
 void parallel_for_pinned_impl(size_t n, const std::function<void(size_t)> &fn);
 template <class F> inline void par_for_pinned(size_t n, F fn) { parallel_for_pinned_impl(n, std::function<void(size_t)>(fn)); }
+// background tasks of the lowest priority (run when no parallel loop has work) and the wait for all of them
+void pool_post(std::function<void()> fn);
+void pool_drain();
 
 struct AlignReq {
     const mm2::RefIndex *idx;     // index of `ref` (owned by the caller, reusable across batches)
