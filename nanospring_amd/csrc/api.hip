@@ -140,6 +140,7 @@ void nsgpu_destroy(nsgpu_ctx *c)
         for (DevBuf *b : sb) b->release();
         if (w.h_seqs) (void)hipHostFree(w.h_seqs);
         if (w.h_out) (void)hipHostFree(w.h_out);
+        if (w.stream) (void)hipStreamDestroy(w.stream);
     }
     for (nsgpu_ctx::KswWs &w : c->kws) {
         if (w.stream) (void)hipStreamSynchronize(w.stream);

@@ -115,6 +115,7 @@ struct nsgpu_ctx {
         nsgpu::DevBuf k_tasks, k_order, k_seqs, k_p, k_cig, k_res, k_slab, k_ncig, k_coff, k_cig2, scan_ws;
         std::vector<hipEvent_t> ev;                                  // start/end event pairs, one pair per launch of a batch
         uint8_t *h_pool = nullptr; size_t h_pool_cap = 0;            // pinned staging of the DP sequence pool
+        std::vector<uint8_t> h_bucket; std::vector<uint32_t> h_tmp;   // scratch of the launch-order bucketing
         std::vector<uint32_t> h_flat;                                // launch order of the batch in flight
         size_t pend_n = 0, pend_n_ev = 0; uint64_t pend_n_launch = 0; // batch launched, not yet collected (ksw_batch_launch / _collect)
         hipStream_t stream = nullptr;                                // workspace 0 runs on the context's stream
@@ -126,6 +127,7 @@ struct nsgpu_ctx {
         nsgpu::DevBuf seqs, soff, len, sob, vf, mk, vr, linv, npf, pushf, npr, pr, V, hk, PX, PY, PRUN, PSEQ, rm, nout, oscan, off, out, scan_ws;
         uint8_t *h_seqs = nullptr; size_t h_cap = 0;
         uint8_t *h_out = nullptr; size_t h_out_cap = 0;
+        hipStream_t stream = nullptr;
     } sws;
     double sketch_mm_ms = 0;                                         // wall of the batched mm_sketch calls
     std::mutex stat_m;                                               // guards the ksw_* / aln_* counters below

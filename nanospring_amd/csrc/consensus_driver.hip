@@ -283,6 +283,7 @@ struct Engine {
     std::string qbuf;
     std::vector<uint64_t> qoff, foff;
     std::vector<uint32_t> fids;
+    double p1_align_ms = 0, p1_host_ms = 0, p1_launch_ms = 0;
     uint64_t slot_long_n[3] = {0, 0, 0};
     double slot_long_ms[3] = {0, 0, 0};
     std::vector<FinishedContig *> emit_queue;      // finished contigs whose emission has not run yet
@@ -290,6 +291,7 @@ struct Engine {
     std::vector<uint32_t> sk_ref;
     std::vector<uint64_t> mz_off;
     AlignBatch ab[kGroups];                        // alignment batch of each group, DP kernels in flight between part 1 and part 2
+    std::vector<uint32_t> fwho;                    // builders of the window-query batch
     std::vector<uint32_t> awho[kGroups];           // builders of that batch
     std::vector<mm2::AlnOut> outs;
     Builder *local(uint32_t gid) { return gid % world == rank ? &D.B[gid / world] : nullptr; }
@@ -389,36 +391,14 @@ static uint32_t engine_seed_resolve(nsgpu_ctx *c, const uint32_t *gids, const ui
 }
 
 // phases 4+5: window queries and alignments of the local builders (GPU batches); no claims yet
-// batches, part 1: window queries (complete) and, for the builders that wait for an alignment, minimizer sketches, index,
-// seeds / chains / DP plan and the launch of the DP kernels -- which stay in flight until part 2
+// batches, part 1: for the builders that wait for an alignment, minimizer sketches, index, seeds / chains / DP plan and the
+// launch of the DP kernels -- which stay in flight until part 2
 static int engine_batches_begin(nsgpu_ctx *c, int group, int ws_index)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
     nsgpu_consensus_stats &S = c->cons_stats;
     std::vector<uint32_t> &who = E->who;
-    who.clear();
-    for (Builder &b : D.B) if (in_group(b, group) && b.st == Builder::WAIT_FILTER) who.push_back(b.id);
-    if (!who.empty()) {
-        const double f0 = now_ms();
-        E->qbuf.clear(); E->qoff.assign(1, 0);
-        for (uint32_t bi : who) for (int s = 0; s < 2; ++s) { E->qbuf += D.B[bi].win[s]; E->qoff.push_back(E->qbuf.size()); }
-        const uint32_t nq = (uint32_t)(2 * who.size());
-        NS_TRY(filter_strings_device(c, E->qbuf.data(), E->qoff.data(), nq));
-        E->foff.resize((size_t)nq + 1);
-        E->fids.resize(c->f_total + 1);
-        NS_HIP(hipMemcpyAsync(E->foff.data(), c->f_off.p, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-        if (c->f_total) NS_HIP(hipMemcpyAsync(E->fids.data(), c->f_ids.p, c->f_total * 4, hipMemcpyDeviceToHost, c->stream));
-        NS_HIP(hipStreamSynchronize(c->stream));
-        for (size_t w = 0; w < who.size(); ++w) {
-            Builder &b = D.B[who[w]];
-            for (int s = 0; s < 2; ++s) b.cand[s].assign(E->fids.begin() + E->foff[2 * w + s], E->fids.begin() + E->foff[2 * w + s + 1]);
-            b.st = Builder::GOT_FILTER;
-        }
-        S.filter_ms += now_ms() - f0;
-        S.n_windows += who.size();
-        ++S.n_filter_rounds;
-    }
     who.clear();
     for (Builder &b : D.B) if (in_group(b, group) && b.st == Builder::WAIT_ALIGN) who.push_back(b.id);
     if (!who.empty()) {
@@ -457,19 +437,46 @@ static int engine_batches_begin(nsgpu_ctx *c, int group, int ws_index)
         }
         E->awho[group < 0 ? 0 : group] = who;
         NS_TRY(align_begin(c, AB, ws_index));
-        { std::lock_guard<std::mutex> lk(c->stat_m); S.align_ms += now_ms() - g1; }
+        { std::lock_guard<std::mutex> lk(c->stat_m); S.align_ms += now_ms() - g1; E->p1_align_ms += now_ms() - g1; E->p1_host_ms += AB.host_ms; E->p1_launch_ms += AB.dp_ms; }
     }
     return NSGPU_OK;
 }
 
 
-// batches, part 2: DP results, execution of the alignment skeletons, alignRead's conversion; the builders become ALIGNED
+// batches, part 2: the group's window queries; DP results, execution of the alignment skeletons, alignRead's conversion (the
+// builders become ALIGNED)
 static int engine_batches_finish(nsgpu_ctx *c, int group)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
     nsgpu_consensus_stats &S = c->cons_stats;
     const int gi = group < 0 ? 0 : group;
+    {   // the group's window queries (builders that wait for a candidate list): independent of its alignments, done in this
+        // part because part 1 is the longer one
+        std::vector<uint32_t> &who = E->fwho;
+        who.clear();
+        for (Builder &b : D.B) if (in_group(b, group) && b.st == Builder::WAIT_FILTER) who.push_back(b.id);
+        if (!who.empty()) {
+            const double f0 = now_ms();
+            E->qbuf.clear(); E->qoff.assign(1, 0);
+            for (uint32_t bi : who) for (int s = 0; s < 2; ++s) { E->qbuf += D.B[bi].win[s]; E->qoff.push_back(E->qbuf.size()); }
+            const uint32_t nq = (uint32_t)(2 * who.size());
+            NS_TRY(filter_strings_device(c, E->qbuf.data(), E->qoff.data(), nq));
+            E->foff.resize((size_t)nq + 1);
+            E->fids.resize(c->f_total + 1);
+            NS_HIP(hipMemcpyAsync(E->foff.data(), c->f_off.p, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+            if (c->f_total) NS_HIP(hipMemcpyAsync(E->fids.data(), c->f_ids.p, c->f_total * 4, hipMemcpyDeviceToHost, c->stream));
+            NS_HIP(hipStreamSynchronize(c->stream));
+            for (size_t w = 0; w < who.size(); ++w) {
+                Builder &b = D.B[who[w]];
+                for (int s = 0; s < 2; ++s) b.cand[s].assign(E->fids.begin() + E->foff[2 * w + s], E->fids.begin() + E->foff[2 * w + s + 1]);
+                b.st = Builder::GOT_FILTER;
+            }
+            S.filter_ms += now_ms() - f0;
+            S.n_windows += who.size();
+            ++S.n_filter_rounds;
+        }
+    }
     std::vector<uint32_t> &who = E->awho[gi];
     if (who.empty()) return NSGPU_OK;
     const double g1 = now_ms();
@@ -625,6 +632,8 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
         if (E->n_done_global >= E->n_total) break;
     }
     if (getenv("NSGPU_CONS_DEBUG"))
+        fprintf(stderr, "[cons] batches part 1 wall-ms: window queries %.0f, sketch+index %.0f (gpu sketch %.0f), align begin %.0f (host loops %.0f, DP launch %.0f)\n", c->cons_stats.filter_ms,
+                c->cons_stats.index_ms, c->sketch_mm_ms, E->p1_align_ms, E->p1_host_ms, E->p1_launch_ms);
         fprintf(stderr, "[cons] slots set by: host phase %llu (%.0f ms), batches part 1 %llu (%.0f ms), part 2 %llu (%.0f ms)\n", (unsigned long long)E->slot_long_n[0],
                 E->slot_long_ms[0], (unsigned long long)E->slot_long_n[1], E->slot_long_ms[1], (unsigned long long)E->slot_long_n[2], E->slot_long_ms[2]);
     const double tf = now_ms();

@@ -776,16 +776,37 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     std::vector<uint32_t> &flat = W.h_flat;          // stays alive while the upload may still be reading it
     flat.clear();
     size_t start[5] = {0, 0, 0, 0, 0}, wg_start[3] = {0, 0, 0};
-    auto by_size = [&](uint32_t a, uint32_t b) { return (size_t)tasks[a].qlen * tasks[a].tlen > (size_t)tasks[b].qlen * tasks[b].tlen; };
+    // big problems first inside a class (longest-processing-time-first): 64 buckets by the logarithm of the cell count, taken
+    // in descending order -- the schedule only needs the rough order, a comparison sort of every batch does not pay
+    auto lpt_order = [&](std::vector<uint32_t> &v) {
+        if (v.size() < 2) return;
+        uint32_t cnt[65] = {0};
+        std::vector<uint8_t> &bk = W.h_bucket;
+        bk.resize(v.size());
+        for (size_t i = 0; i < v.size(); ++i) {
+            const uint64_t cells = (uint64_t)tasks[v[i]].qlen * (uint64_t)tasks[v[i]].tlen;
+            // 4 buckets per doubling: floor(log2) * 4 + the next two bits
+            const int lg = cells > 1 ? 63 - __builtin_clzll(cells) : 0;
+            const int b4 = lg >= 2 ? (int)((cells >> (lg - 2)) & 3) : 0;
+            int b = lg * 4 + b4 - 40;                       // 2^10 cells -> bucket 0
+            b = b < 0 ? 0 : b > 63 ? 63 : b;
+            bk[i] = (uint8_t)(63 - b);                      // descending
+            ++cnt[bk[i] + 1];
+        }
+        for (int i = 0; i < 64; ++i) cnt[i + 1] += cnt[i];
+        std::vector<uint32_t> &tmp = W.h_tmp;
+        tmp.resize(v.size());
+        for (size_t i = 0; i < v.size(); ++i) tmp[cnt[bk[i]]++] = v[i];
+        v.swap(tmp);
+    };
     for (int k = 0; k < 4; ++k) {
-        // big problems first inside a class (longest-processing-time-first)
-        std::stable_sort(order[k].begin(), order[k].end(), by_size);
+        lpt_order(order[k]);
         start[k] = flat.size();
         flat.insert(flat.end(), order[k].begin(), order[k].end());
     }
     start[4] = flat.size();
     for (int k = 0; k < 3; ++k) {
-        std::stable_sort(wg[k].begin(), wg[k].end(), by_size);
+        lpt_order(wg[k]);
         wg_start[k] = flat.size();
         flat.insert(flat.end(), wg[k].begin(), wg[k].end());
     }
@@ -818,7 +839,8 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
             hipLaunchKernelGGL((ksw_extd2_wg_kernel<256, 5>), dim3(m), dim3(256), kClass[1], st, W.k_tasks.as<KswTask>(), ord, m, pr, W.k_seqs.as<uint8_t>(),
                                W.k_p.as<uint8_t>(), W.k_cig.as<uint32_t>(), W.k_res.as<KswResult>());
         else {
-            NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_wg_kernel<256, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClass[2]));
+            static const hipError_t attr_wg8 = hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_wg_kernel<256, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClass[2]);
+            NS_HIP(attr_wg8);
             hipLaunchKernelGGL((ksw_extd2_wg_kernel<256, 8>), dim3(m), dim3(256), kClass[2], st, W.k_tasks.as<KswTask>(), ord, m, pr, W.k_seqs.as<uint8_t>(),
                                W.k_p.as<uint8_t>(), W.k_cig.as<uint32_t>(), W.k_res.as<KswResult>());
         }
@@ -839,7 +861,10 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         if (k > 0 && !dbg) { st = W.side_stream[k]; NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0)); side_used[k] = true; }
         double dbg_t0 = 0;
         if (dbg) { NS_HIP(hipStreamSynchronize(S)); dbg_t0 = now_ms(); }
-        if (kClass[k] > 49152) NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClass[k]));
+        if (kClass[k] > 49152) {
+            static const hipError_t attr_lds = hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClass[2]);
+            NS_HIP(attr_lds);
+        }
         NS_HIP(hipEventRecord(ev_at(n_ev++), st));
         hipLaunchKernelGGL(ksw_extd2_lds_kernel, dim3(m), dim3(64), kClass[k], st, W.k_tasks.as<KswTask>(),
                            W.k_order.as<uint32_t>() + start[k], m, pr, W.k_seqs.as<uint8_t>(), W.k_p.as<uint8_t>(), W.k_cig.as<uint32_t>(),

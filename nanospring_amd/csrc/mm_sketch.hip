@@ -263,7 +263,10 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
     NS_CHECK(k > 0 && k <= 28 && w > 0 && w < 256, NSGPU_ERR_ARG, "minimap k must be in 1..28 and w in 1..255 (sketch.c:84)");
     const double t0 = now_ms();
     nsgpu_ctx::SketchWs &W = c->sws;
-    const hipStream_t st = c->stream;
+    // a stream of its own: in the contig engine the sketches of one builder group run while another group's window queries
+    // use the context's stream
+    if (!W.stream) NS_HIP(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
+    const hipStream_t st = W.stream;
     std::vector<uint32_t> soff(n + 1), len(n);
     uint64_t bytes = 0;
     for (size_t i = 0; i < n; ++i) {
