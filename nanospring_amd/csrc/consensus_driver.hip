@@ -631,11 +631,12 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
         w_seed += now_ms() - t;
         if (E->n_done_global >= E->n_total) break;
     }
-    if (getenv("NSGPU_CONS_DEBUG"))
-        fprintf(stderr, "[cons] batches part 1 wall-ms: window queries %.0f, sketch+index %.0f (gpu sketch %.0f), align begin %.0f (host loops %.0f, DP launch %.0f)\n", c->cons_stats.filter_ms,
+    if (getenv("NSGPU_CONS_DEBUG")) {
+        fprintf(stderr, "[cons] batches wall-ms: window queries %.0f, sketch+index %.0f (gpu sketch %.0f), align begin %.0f (host loops %.0f, DP launch %.0f)\n", c->cons_stats.filter_ms,
                 c->cons_stats.index_ms, c->sketch_mm_ms, E->p1_align_ms, E->p1_host_ms, E->p1_launch_ms);
         fprintf(stderr, "[cons] slots set by: host phase %llu (%.0f ms), batches part 1 %llu (%.0f ms), part 2 %llu (%.0f ms)\n", (unsigned long long)E->slot_long_n[0],
                 E->slot_long_ms[0], (unsigned long long)E->slot_long_n[1], E->slot_long_ms[1], (unsigned long long)E->slot_long_n[2], E->slot_long_ms[2]);
+    }
     const double tf = now_ms();
     const int rc = engine_finish(c, n_threads_out);
     if (getenv("NSGPU_CONS_DEBUG")) {
