@@ -138,6 +138,37 @@ def all_gather_u32_lists(a, b, dist):
     return np.concatenate(aa), np.concatenate(bb)
 
 
+class U32ListGatherer:
+    """all_gather_u32_lists with a known bound on the list length: one collective per call (no size exchange) on buffers
+    allocated once -- the claim / seed lists of the contig engine are exchanged twice per pipeline slot."""
+
+    def __init__(self, cap, dist):
+        torch = _torch()
+        self.dist, self.cap, self.world = dist, int(cap), dist.get_world_size()
+        dev = _dev(dist)
+        self.words = 1 + 2 * self.cap
+        self.mine = torch.zeros(self.words, dtype=torch.int32, device=dev)
+        self.all = torch.zeros(self.words * self.world, dtype=torch.int32, device=dev)
+        self.stage = np.zeros(self.words, dtype=np.uint32)
+
+    def __call__(self, a, b):
+        a = np.asarray(a, dtype=np.uint32)
+        b = np.asarray(b, dtype=np.uint32)
+        n = a.size                                   # (a world of one still goes through the collective: the RCCL test relies on it)
+        assert n == b.size and n <= self.cap, (n, self.cap)
+        torch = _torch()
+        st = self.stage
+        st[0] = n
+        st[1:1 + n] = a
+        st[1 + self.cap:1 + self.cap + n] = b
+        self.mine.copy_(torch.from_numpy(st.view(np.int32)))
+        self.dist.all_gather_into_tensor(self.all, self.mine)
+        v = self.all.cpu().numpy().view(np.uint32).reshape(self.world, self.words)
+        aa = [v[r, 1:1 + int(v[r, 0])] for r in range(self.world)]
+        bb = [v[r, 1 + self.cap:1 + self.cap + int(v[r, 0])] for r in range(self.world)]
+        return np.concatenate(aa), np.concatenate(bb)
+
+
 def replicate_reads(bases, off, dist):
     """Each rank passes its own shard (reads in global id order across ranks).  Returns (all_bases, all_off, lo, hi)
     with [lo, hi) = this rank's id range in the replicated set."""
@@ -207,19 +238,22 @@ def consensus_exchange(gpu, n_builders_total, dist, n_threads_out=1):
     def ptr(a):
         return a.ctypes.data_as(C.c_void_p) if a.size else None
 
+    # a rank never has more requests than local builders
+    gather = U32ListGatherer((n_builders_total + world - 1) // world + 1, dist)
+
     # the slot schedule of include/nsgpu.h (nsgpu_consensus_run runs the same one with world = 1)
     n_coll = 0
     slot = 0
     while True:
         h, b = slot % 3, (slot + 1) % 3
         F.check(lib, lib.nsgpu_cons_slot(ctx, slot))
-        ga, gb = all_gather_u32_lists(*take(lib.nsgpu_cons_claim_requests, b), dist)
+        ga, gb = gather(*take(lib.nsgpu_cons_claim_requests, b))
         n_coll += 1
         ga, gb = np.ascontiguousarray(ga), np.ascontiguousarray(gb)
         done = C.c_uint32()
         F.check(lib, lib.nsgpu_cons_claim_resolve(ctx, ptr(ga), ptr(gb), ga.size, C.byref(done)))
         while True:
-            ga, gb = all_gather_u32_lists(*take(lib.nsgpu_cons_seed_requests, h), dist)
+            ga, gb = gather(*take(lib.nsgpu_cons_seed_requests, h))
             n_coll += 1
             if ga.size == 0:
                 break
