@@ -67,6 +67,16 @@ def test_gpu_ingest_equals_oracle():
         for r in range(n):
             want = fold(text[int(st[r]):int(st[r]) + int(ln[r])])
             assert g.get_read(r) == want, (text[:60], r)
+    # newlines on and around the 16-byte (lane) and 1 KiB (wave) boundaries of the parser
+    for ln in (1008, 1019, 1020, 1021, 1022, 1023, 1024, 1025, 2043, 2044, 2045, 4091, 4092, 4093):
+        name = b"@r"
+        seq = (b"ACGT" * (ln // 4 + 1))[:ln - len(name) - 1]          # the base line ends exactly at byte ln - 1 ... + 1
+        for pad in (0, 1, 2, 15, 16, 17):
+            text = name + b"\n" + seq + b"N" * pad + b"\n+\n" + b"I" * (len(seq) + pad) + b"\n@s\nGATTACA\n+\nIIIIIII\n"
+            st, ln2 = orc.fastq_index(text)
+            assert g.load_fastq(text) == len(st) == 2
+            for r in range(2):
+                assert g.get_read(r) == fold(text[int(st[r]):int(st[r]) + int(ln2[r])]), (ln, pad, r)
     with pytest.raises(ns.NsGpuError):
         g.load_fastq(b"")
     # the loaded reads feed the path like any others: sketches equal those of the same reads loaded as strings
