@@ -23,6 +23,7 @@
 #include <memory>
 #include <atomic>
 #include <thread>
+#include <sys/resource.h>
 
 namespace nsgpu {
 namespace mm2 { extern std::atomic<uint64_t> g_step_ns[6]; }
@@ -605,6 +606,8 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
     Engine *E = static_cast<Engine *>(c->cons_engine);
     std::vector<uint32_t> ga, gb;
     double w_slot = 0, w_seed = 0, w_claim = 0;
+    struct rusage ru0;
+    getrusage(RUSAGE_SELF, &ru0);
     const double w_begin = now_ms() - E->t0;
     // Three builder groups, a third of a period apart.  In slot s group h = s % 3 runs its host phase (graph updates up
     // to the next window / alignment request), group (s + 2) % 3 -- which did that in the slot before -- part 1 of its
@@ -644,6 +647,11 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
         fprintf(stderr, "[cons] emission cpu-ms: path tables %.0f, read walks %.0f, script folding + stream bytes %.0f\n", cons::g_emit_ns[0] / 1e6, cons::g_emit_ns[1] / 1e6, cons::g_emit_ns[2] / 1e6);
         fprintf(stderr, "[cons] align host cpu-ms: seeds %.0f chain %.0f regs %.0f plan %.0f execute %.0f\n", mm2::g_step_ns[0] / 1e6, mm2::g_step_ns[1] / 1e6,
                 mm2::g_step_ns[2] / 1e6, mm2::g_step_ns[3] / 1e6, mm2::g_step_ns[4] / 1e6);
+        struct rusage ru1;
+        getrusage(RUSAGE_SELF, &ru1);
+        const double cpu_s = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec) * 1e-6 +
+                             (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
+        fprintf(stderr, "[cons] process CPU time over the stage: %.1f s = %.1f cores busy on average\n", cpu_s, cpu_s / ((now_ms() - E->t0) * 1e-3));
         fprintf(stderr, "[cons] wall-ms: begin %.0f slots %.0f (host phases %.0f, batches %.0f, overlapped) seed %.0f claim %.0f finish %.0f\n", w_begin, w_slot,
                 c->cons_stats.graph_ms, c->cons_stats.filter_ms + c->cons_stats.index_ms + c->cons_stats.align_ms, w_seed, w_claim, now_ms() - tf);
     }
