@@ -340,6 +340,23 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
             cur_main = (ssize_t)ei;
             if (touch_lo_ == (size_t)-1) touch_lo_ = ei;
             advance();
+            // The rest of the run follows the main-path edges main_edges[ei-1 .. ei+num-3] one after the other (the loop below,
+            // which re-derives that per base, stays for the path's end, where the reference's walk stops advancing): add the read
+            // to each of them and set the walk's state once.
+            static const bool no_run_loop = getenv("NSGPU_NO_RUN_FASTPATH") != nullptr;      // debugging aid: per-base loop only
+            if (!no_run_loop && op.num > 1 && ei >= 1 && ei + op.num - 2 <= n_path_edges && main_edges[ei - 1]->source == cur && main_edges[ei - 1]->sink == node_in_path) {
+                const size_t last_ei = ei + op.num - 2;                 // ei at the start of the run's last base
+                Edge *const *pe = main_edges.begin();
+                for (size_t x = ei - 1; x < last_ei; ++x) {
+                    if (x + 12 < n_path_edges) __builtin_prefetch(pe[x + 12], 1, 1);
+                    pe[x]->add_read(arena_, id);
+                }
+                cur = pe[last_ei - 1]->sink;
+                cur_main = (ssize_t)last_ei;
+                if (last_ei == n_path_edges) ei = n_path_edges, node_in_path = cur;
+                else node_in_path = pe[last_ei]->sink, ei = last_ei + 1;
+                continue;
+            }
             for (size_t i = 1; i < op.num; ++i) {
                 // the walk touches one edge (one cache line) per base, in main-path order: fetch ahead
                 if (ei + 12 < n_path_edges) __builtin_prefetch(main_edges[ei + 12], 1, 1);

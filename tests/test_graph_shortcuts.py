@@ -58,6 +58,6 @@ def run(kind, seed, **env):
 @pytest.mark.parametrize("kind,seed", [("iid", 3), ("repeats", 4), ("repeats", 5), ("long", 1)])
 def test_shortcuts_change_nothing(kind, seed):
     fast = run(kind, seed, NSGPU_SPLICE_CHECK="1")
-    literal = run(kind, seed, NSGPU_NO_CYCLE_SKIP="1", NSGPU_NO_TAIL_SPLICE="1")
+    literal = run(kind, seed, NSGPU_NO_CYCLE_SKIP="1", NSGPU_NO_TAIL_SPLICE="1", NSGPU_NO_RUN_FASTPATH="1")
     assert fast == literal
     assert fast[1] > 100
