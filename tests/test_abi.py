@@ -57,3 +57,16 @@ def test_synth_reads_model():
     assert np.array_equal(bases, b2) and np.array_equal(off, o2)      # deterministic
     b3, _ = ns.synth_reads(8, 500000, 400, 8000.0)
     assert not np.array_equal(bases[:1000], b3[:1000])
+
+
+def test_header_is_plain_c_and_cxx11(tmp_path):
+    """The boundary is a C ABI: include/nsgpu.h must compile as C99 and as C++11 (the reference's language level) with
+    warnings on, nothing but standard headers."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.c"
+    src.write_text('#include "nsgpu.h"\nint main(void) { nsgpu_params p; nsgpu_default_params(&p); return (int)p.k; }\n')
+    inc = os.path.join(root, "include")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror"], ["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-x", "c++"]):
+        r = subprocess.run(cmd + ["-I", inc, "-c", str(src), "-o", str(tmp_path / "t.o")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
