@@ -9,6 +9,7 @@
 #include <iterator>
 #include <new>
 #include <set>
+#include <mutex>
 #include <atomic>
 #include <sys/mman.h>
 
@@ -50,9 +51,22 @@ thread_local Region t_region;
 constexpr size_t kRegionBytes = 32u << 20;
 }  // namespace
 
+// Graphs are built on one thread and often freed on another (the edit emission runs as a background task of whichever worker
+// is idle): a thread's cache hands its surplus to a shared pool and refills from it before new memory is mapped, so slabs
+// circulate instead of piling up on the freeing side.
+namespace {
+std::mutex g_slab_pool_m;
+std::vector<unsigned char *> g_slab_pool;
+constexpr size_t kLocalSlabs = 64, kSlabBatch = 32;
+}  // namespace
+
 unsigned char *slab_acquire(size_t bytes)
 {
     if (g_no_slab_cache) return static_cast<unsigned char *>(calloc(1, bytes));
+    if (t_slabs.free.empty() && bytes == kSlabBytes) {
+        std::lock_guard<std::mutex> lk(g_slab_pool_m);
+        for (size_t i = 0; i < kSlabBatch && !g_slab_pool.empty(); ++i) { t_slabs.free.push_back(g_slab_pool.back()); g_slab_pool.pop_back(); }
+    }
     if (!t_slabs.free.empty()) { unsigned char *p = t_slabs.free.back(); t_slabs.free.pop_back(); return p; }
     if (!g_no_huge && bytes <= kRegionBytes) {
         if (!t_region.p || t_region.used + bytes > kRegionBytes) {
@@ -75,8 +89,13 @@ void slab_release(unsigned char *p, size_t)
 {
     if (g_no_slab_cache) { ::free(p); return; }
     // region-backed slabs must not reach free(): they stay in a cache (the cap only bounds posix_memalign'ed ones)
-    if (!g_no_huge || t_slabs.free.size() < kMaxCachedSlabsPerThread) t_slabs.free.push_back(p);
-    else ::free(p);
+    if (!g_no_huge || t_slabs.free.size() < kMaxCachedSlabsPerThread) {
+        t_slabs.free.push_back(p);
+        if (t_slabs.free.size() > kLocalSlabs) {
+            std::lock_guard<std::mutex> lk(g_slab_pool_m);
+            for (size_t i = 0; i < kSlabBatch; ++i) { g_slab_pool.push_back(t_slabs.free.back()); t_slabs.free.pop_back(); }
+        }
+    } else ::free(p);
 }
 
 template <class T> Pool<T>::~Pool()
