@@ -20,7 +20,7 @@ ARCH = "gfx950"
 # no fast-math anywhere: chaining and the repetitive test compare floats/doubles
 # exactly as the reference does.
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-result",
-         "-ffp-contract=off", "-fno-fast-math", "-I/opt/rocm/include"]
+         "-ffp-contract=off", "-fno-fast-math", "-I/opt/rocm/include"] + os.environ.get("NSGPU_HOST_FLAGS", "").split()
 
 
 def _sources():
