@@ -192,10 +192,78 @@ def sketch_case():
     print("mm_sketch_cases.npz:", len(seqs), "sequences x", len(SKETCH_WK), "(w,k) pairs,", offs[-1], "minimizers")
 
 
+def edit_scripts(seed=5, n_cases=160):
+    """Raw edit scripts as read2EditScript produces them (SAME runs, INSERT with the base, DELETE with '-'): mixes of isolated
+    edits, adjacent insert/delete runs of unequal length (-> substitutions + remainder), leading / trailing edits, empty."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for c in range(n_cases):
+        ops, orig_len = [], 0
+        n_blocks = int(rng.randint(0, 12)) if c else 0
+        for _ in range(n_blocks):
+            if rng.rand() < 0.8:
+                num = int(rng.randint(1, 40))
+                ops.append((0, 0, num)); orig_len += num
+            ni, nd = int(rng.choice([0, 0, 1, 1, 2, 3, 7])), int(rng.choice([0, 0, 1, 1, 2, 3, 7]))
+            block = [(1, ord("ACGT"[rng.randint(4)]), 0)] * 0
+            block = [(1, ord("ACGT"[rng.randint(4)]), 0) for _ in range(ni)] + [(2, ord("-"), 0) for _ in range(nd)]
+            rng.shuffle(block)
+            ops += [tuple(int(v) for v in b) for b in block]
+            orig_len += nd
+        orig = "".join("ACGT"[i] for i in rng.randint(0, 4, size=orig_len))
+        out.append((ops, orig))
+    return out
+
+
+def edits_case():
+    """raw scripts -> what the reference's own Edit::optimizeEditScript and Edits::applyEdits (src/Edits.cpp, include/Edits.h,
+    through oracle/_ref/nsref_edits) make of them: golden vectors of row a15."""
+    import struct
+    import subprocess
+    import tempfile
+    cases = edit_scripts()
+    with tempfile.TemporaryDirectory() as td:
+        fi, fo = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fi, "wb") as f:
+            f.write(struct.pack("<I", len(cases)))
+            for ops, orig in cases:
+                f.write(struct.pack("<II", len(ops), len(orig)) + orig.encode())
+                for t, b, num in ops:
+                    f.write(struct.pack("<BBI", t, b, num))
+        subprocess.run([os.path.join(ROOT, "oracle", "_ref", "nsref_edits"), fi, fo], check=True)
+        raw = open(fo, "rb").read()
+    pos = 0
+    rec = {"in_types": [], "in_bases": [], "in_nums": [], "in_off": [0], "orig": [], "orig_off": [0], "dis": [], "out_types": [], "out_bases": [], "out_nums": [],
+           "out_off": [0], "applied_raw": [], "applied_opt": [], "app_off": [0]}
+    for ops, orig in cases:
+        rec["in_types"] += [o[0] for o in ops]; rec["in_bases"] += [o[1] for o in ops]; rec["in_nums"] += [o[2] for o in ops]
+        rec["in_off"].append(len(rec["in_types"]))
+        rec["orig"].append(orig); rec["orig_off"].append(rec["orig_off"][-1] + len(orig))
+        dis, n_new = struct.unpack_from("<QI", raw, pos); pos += 12
+        rec["dis"].append(dis)
+        for _ in range(n_new):
+            t, b, num = struct.unpack_from("<BBI", raw, pos); pos += 6
+            rec["out_types"].append(t); rec["out_bases"].append(b); rec["out_nums"].append(num)
+        rec["out_off"].append(len(rec["out_types"]))
+        for key in ("applied_raw", "applied_opt"):
+            (ln,) = struct.unpack_from("<I", raw, pos); pos += 4
+            rec[key].append(raw[pos:pos + ln].decode()); pos += ln
+        assert rec["applied_raw"][-1] == rec["applied_opt"][-1]
+        rec["app_off"].append(rec["app_off"][-1] + len(rec["applied_raw"][-1]))
+    assert pos == len(raw)
+    np.savez_compressed(os.path.join(HERE, "edit_cases.npz"), in_types=np.array(rec["in_types"], np.uint8), in_bases=np.array(rec["in_bases"], np.uint8),
+                        in_nums=np.array(rec["in_nums"], np.uint32), in_off=np.array(rec["in_off"], np.int64),
+                        orig=np.frombuffer("".join(rec["orig"]).encode(), np.uint8), orig_off=np.array(rec["orig_off"], np.int64),
+                        dis=np.array(rec["dis"], np.uint64), out_types=np.array(rec["out_types"], np.uint8), out_bases=np.array(rec["out_bases"], np.uint8),
+                        out_nums=np.array(rec["out_nums"], np.uint32), out_off=np.array(rec["out_off"], np.int64),
+                        applied=np.frombuffer("".join(rec["applied_opt"]).encode(), np.uint8), app_off=np.array(rec["app_off"], np.int64))
+    print("edit_cases.npz:", len(cases), "scripts,", len(rec["in_types"]), "raw ops ->", len(rec["out_types"]), "optimised ops")
+
+
 if __name__ == "__main__":
     if not oracle_lib.have_nsref():
         sys.exit("oracle/_ref/nsref missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["minhash", "ksw2", "align", "sketch"]
+    which = sys.argv[1:] or ["minhash", "ksw2", "align", "sketch", "edits"]
     if "minhash" in which:
         minhash_case()
     if "ksw2" in which:
@@ -204,3 +272,5 @@ if __name__ == "__main__":
         align_case()
     if "sketch" in which:
         sketch_case()
+    if "edits" in which:
+        edits_case()

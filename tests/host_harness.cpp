@@ -278,3 +278,15 @@ int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32
 void harness_free(void *p) { free(p); }
 
 }
+
+// a15: the product's Edit::optimizeEditScript restatement (consensus.cpp) on a raw script (types 0 SAME 1 INSERT 2 DELETE)
+extern "C" int64_t harness_optimize_edits(const uint8_t *types, const uint8_t *bases, const uint32_t *nums, uint32_t n, uint8_t *otypes, uint8_t *obases,
+                                          uint32_t *onums, uint32_t cap, uint64_t *dis_out)
+{
+    std::vector<nsgpu::mm2::EditOp> in(n), out;
+    for (uint32_t i = 0; i < n; ++i) in[i] = nsgpu::mm2::EditOp{types[i], bases[i], nums[i]};
+    *dis_out = nsgpu::cons::optimize_edit_script(in, out);
+    if (out.size() > cap) return -1;
+    for (size_t i = 0; i < out.size(); ++i) otypes[i] = out[i].type, obases[i] = out[i].base, onums[i] = out[i].num;
+    return (int64_t)out.size();
+}

@@ -68,6 +68,21 @@ def sketch(s, w, k):
     return xy[:2 * n].reshape(n, 2).copy()
 
 
+def optimize_edits(types, bases, nums):
+    """consensus.cpp's optimize_edit_script: (types, bases, nums) of the raw script -> (editDis, types, bases, nums)."""
+    L = lib()
+    t = np.ascontiguousarray(types, dtype=np.uint8)
+    b = np.ascontiguousarray(bases, dtype=np.uint8)
+    m = np.ascontiguousarray(nums, dtype=np.uint32)
+    cap = len(t) + 4
+    ot, ob, om = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8), np.zeros(cap, np.uint32)
+    dis = C.c_uint64()
+    L.harness_optimize_edits.restype = C.c_int64
+    n = L.harness_optimize_edits(_p(t), _p(b), _p(m), C.c_uint32(len(t)), _p(ot), _p(ob), _p(om), C.c_uint32(cap), C.byref(dis))
+    assert n >= 0
+    return int(dis.value), ot[:n].copy(), ob[:n].copy(), om[:n].copy()
+
+
 class HarnessConsStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_contigs", "n_lone", "count_minhash", "count_minhash_not_in_graph", "count_aligner", "n_align_calls",
                                           "n_bad_roundtrip", "n_graph_check_fail")] + \
