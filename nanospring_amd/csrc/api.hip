@@ -3,6 +3,8 @@
 // gfx950 device nsgpu_create fails with NSGPU_ERR_NODEV.
 #include "common.hpp"
 #include <cstdarg>
+#include <chrono>
+#include <time.h>
 #include <algorithm>
 
 namespace nsgpu {
@@ -15,6 +17,20 @@ void set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+hipError_t stream_wait(hipStream_t s)
+{
+    static const bool spin = [] { const char *e = getenv("NSGPU_SPIN_WAIT"); return e && atoi(e) != 0; }();
+    if (spin) return hipStreamSynchronize(s);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(20)) continue;
+        timespec ts = {0, 20000};                 // + the kernel's timer slack: ~70 us between polls
+        nanosleep(&ts, nullptr);
+    }
 }
 
 static uint64_t row_bytes_h(uint32_t len) { return ((((uint64_t)len + 3) / 4 + 15) & ~(uint64_t)15) + 16; }
@@ -66,7 +82,7 @@ static int store_from_ascii(nsgpu_ctx *c, SeqStore &st, const char *bases, const
     NS_HIP(hipEventRecord(c->t_kernel.a, c->stream));
     NS_TRY(launch_pack_ascii(c, c->ascii.as<char>(), c->aoff.as<uint64_t>(), st));
     NS_HIP(hipEventRecord(c->t_kernel.b, c->stream));
-    NS_HIP(hipStreamSynchronize(c->stream));   // rel / len vectors go out of scope
+    NS_HIP(stream_wait(c->stream));   // rel / len vectors go out of scope
     NS_HIP(hipEventElapsedTime(&c->timing.pack_ms, c->t_kernel.a, c->t_kernel.b));
     return NSGPU_OK;
 }
@@ -125,7 +141,7 @@ void nsgpu_destroy(nsgpu_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->prm.device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)stream_wait(c->stream);
     c->reads.release(); c->queries.release();
     DevBuf *bufs[] = {&c->ascii, &c->aoff, &c->salts, &c->sketch, &c->sketch_rc, &c->qsketch, &c->idx_keys, &c->idx_ids, &c->idx_tmp_k,
                       &c->idx_tmp_v, &c->idx_tmp_e, &c->idx_tmp_e2, &c->idx_sort_ws, &c->f_pool, &c->f_qstart, &c->f_qcnt, &c->f_qm, &c->f_off,
@@ -143,7 +159,7 @@ void nsgpu_destroy(nsgpu_ctx *c)
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }
     for (nsgpu_ctx::KswWs &w : c->kws) {
-        if (w.stream) (void)hipStreamSynchronize(w.stream);
+        if (w.stream) (void)stream_wait(w.stream);
         DevBuf *kb[] = {&w.k_tasks, &w.k_order, &w.k_seqs, &w.k_p, &w.k_cig, &w.k_res, &w.k_slab, &w.k_ncig, &w.k_coff, &w.k_cig2, &w.scan_ws};
         for (DevBuf *b : kb) b->release();
         for (int i = 0; i < 3; ++i) { if (w.side_stream[i]) (void)hipStreamDestroy(w.side_stream[i]); if (w.side_done[i]) (void)hipEventDestroy(w.side_done[i]); }
@@ -161,7 +177,7 @@ void nsgpu_destroy(nsgpu_ctx *c)
 int nsgpu_set_stream(nsgpu_ctx *c, void *s)
 {
     NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
     return NSGPU_OK;
 }
@@ -169,7 +185,7 @@ int nsgpu_set_stream(nsgpu_ctx *c, void *s)
 int nsgpu_sync(nsgpu_ctx *c)
 {
     NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     return NSGPU_OK;
 }
 
@@ -202,7 +218,7 @@ int nsgpu_load_reads_packed(nsgpu_ctx *c, const uint8_t *packed, const uint64_t 
     std::vector<uint8_t> stage(st.packed_bytes + 64, 0);
     for (uint32_t r = 0; r < n; ++r) memcpy(stage.data() + st.h_poff[r], packed + byte_off[r], ((size_t)len[r] + 3) / 4);
     NS_HIP(hipMemcpyAsync(st.packed.p, stage.data(), st.packed_bytes, hipMemcpyHostToDevice, c->stream));
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     {
         static const char dna[4] = {'A', 'T', 'C', 'G'};
         c->h_off.resize((size_t)n + 1);
@@ -231,7 +247,7 @@ int nsgpu_get_read_packed(nsgpu_ctx *c, uint32_t r, uint8_t *out, uint32_t *len_
     if (len_out) *len_out = L;
     const size_t nb = ((size_t)L + 3) / 4;
     if (nb) NS_HIP(hipMemcpyAsync(out, c->reads.packed.as<uint8_t>() + c->reads.h_poff[r], nb, hipMemcpyDeviceToHost, c->stream));
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     return NSGPU_OK;
 }
 
@@ -260,7 +276,7 @@ int nsgpu_sketch(nsgpu_ctx *c, const uint64_t *salts, uint64_t *sketches_out)
     NS_TRY(launch_sketch(c, c->reads, c->sketch.as<uint64_t>(), nullptr));
     NS_HIP(hipEventRecord(c->t_stage.b, c->stream));
     if (sketches_out && N) NS_HIP(hipMemcpyAsync(sketches_out, c->sketch.p, (size_t)N * n * 8, hipMemcpyDeviceToHost, c->stream));
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     NS_HIP(hipEventElapsedTime(&c->timing.sketch_kernel_ms, c->t_stage.a, c->t_stage.b));
     c->timing.sketch_ms = c->timing.sketch_kernel_ms;
     c->have_sketch = true;
@@ -281,7 +297,7 @@ int nsgpu_sketch_range(nsgpu_ctx *c, const uint64_t *salts, uint32_t lo, uint32_
     NS_HIP(hipEventRecord(c->t_stage.a, c->stream));
     NS_TRY(launch_sketch_range(c, c->reads, lo, hi, c->sketch.as<uint64_t>()));
     NS_HIP(hipEventRecord(c->t_stage.b, c->stream));
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     NS_HIP(hipEventElapsedTime(&c->timing.sketch_kernel_ms, c->t_stage.a, c->t_stage.b));
     c->timing.sketch_ms = c->timing.sketch_kernel_ms;
     c->have_index = c->have_filter_all = false;
@@ -298,7 +314,7 @@ static int sketch_rows_copy(nsgpu_ctx *c, uint32_t lo, uint32_t hi, void *buf, i
     uint8_t *rows = c->sketch.as<uint8_t>() + (size_t)lo * n * 8;
     const hipMemcpyKind kind = buf_on_device ? hipMemcpyDeviceToDevice : (to_buf ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice);
     if (bytes) NS_HIP(hipMemcpyAsync(to_buf ? buf : (void *)rows, to_buf ? (const void *)rows : buf, bytes, kind, c->stream));
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     return NSGPU_OK;
 }
 
@@ -327,7 +343,7 @@ int nsgpu_build_index(nsgpu_ctx *c)
     NS_HIP(hipEventRecord(c->t_stage.a, c->stream));
     NS_TRY(build_index(c));
     NS_HIP(hipEventRecord(c->t_stage.b, c->stream));
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     NS_HIP(hipEventElapsedTime(&c->timing.index_ms, c->t_stage.a, c->t_stage.b));
     c->have_index = true;
     c->have_filter_all = false;
@@ -345,7 +361,7 @@ int nsgpu_index_export(nsgpu_ctx *c, uint32_t j, uint64_t *keys_out, uint32_t *s
         NS_HIP(hipMemcpyAsync(k.data(), c->idx_keys.as<uint64_t>() + (size_t)j * N, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
         NS_HIP(hipMemcpyAsync(ids_out, c->idx_ids.as<uint32_t>() + (size_t)j * N, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
     }
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     uint32_t u = 0;
     for (uint32_t i = 0; i < N; ++i)
         if (i == 0 || k[i] != k[i - 1]) { keys_out[u] = k[i]; start_out[u] = i; ++u; }
@@ -364,7 +380,7 @@ int nsgpu_filter_strings_impl(nsgpu_ctx *c, const char *strs, const uint64_t *qo
     NS_TRY(launch_sketch(c, c->queries, c->qsketch.as<uint64_t>(), nullptr));
     NS_TRY(run_filter(c, c->qsketch.as<uint64_t>(), nullptr, nq, false));
     NS_HIP(hipEventRecord(c->t_stage.b, c->stream));
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     NS_HIP(hipEventElapsedTime(&c->timing.filter_ms, c->t_stage.a, c->t_stage.b));
     c->have_filter_all = false;
     return NSGPU_OK;
@@ -379,7 +395,7 @@ int nsgpu_filter_batch(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uin
     NS_CHECK(off && ids, NSGPU_ERR_NOMEM, "malloc failed");
     NS_HIP(hipMemcpyAsync(off, c->f_off.p, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     if (c->f_total) NS_HIP(hipMemcpyAsync(ids, c->f_ids.p, c->f_total * 4, hipMemcpyDeviceToHost, c->stream));
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     *out_off = off;
     *out_ids = ids;
     return NSGPU_OK;
@@ -408,7 +424,7 @@ int nsgpu_filter_all_reads(nsgpu_ctx *c, uint64_t *n_candidates_out)
     NS_TRY(launch_sketch(c, c->reads, nullptr, c->sketch_rc.as<uint64_t>()));
     NS_TRY(run_filter(c, c->sketch.as<uint64_t>(), c->sketch_rc.as<uint64_t>(), 2 * N, true));
     NS_HIP(hipEventRecord(c->t_stage.b, c->stream));
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     NS_HIP(hipEventElapsedTime(&c->timing.filter_ms, c->t_stage.a, c->t_stage.b));
     c->have_filter_all = true;
     if (n_candidates_out) *n_candidates_out = c->f_total;
@@ -421,7 +437,7 @@ int nsgpu_filter_all_fetch(nsgpu_ctx *c, uint64_t *off_out, uint32_t *ids_out)
     NS_CHECK(c->have_filter_all, NSGPU_ERR_ARG, "nsgpu_filter_all_fetch: call nsgpu_filter_all_reads first");
     NS_HIP(hipMemcpyAsync(off_out, c->f_off.p, ((size_t)c->f_nq + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     if (c->f_total && ids_out) NS_HIP(hipMemcpyAsync(ids_out, c->f_ids.p, c->f_total * 4, hipMemcpyDeviceToHost, c->stream));
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     return NSGPU_OK;
 }
 
@@ -435,7 +451,7 @@ int nsgpu_check_repetitive(nsgpu_ctx *c, uint8_t *flags_out)
     NS_TRY(launch_repetitive(c, c->reads, c->rep_flags.as<uint8_t>()));
     NS_HIP(hipEventRecord(c->t_stage.b, c->stream));
     if (N) NS_HIP(hipMemcpyAsync(flags_out, c->rep_flags.p, N, hipMemcpyDeviceToHost, c->stream));
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     NS_HIP(hipEventElapsedTime(&c->timing.repetitive_ms, c->t_stage.a, c->t_stage.b));
     return NSGPU_OK;
 }

@@ -40,6 +40,12 @@ void set_error(const char *fmt, ...);
         if (rc_ != NSGPU_OK) return rc_; \
     } while (0)
 
+// Waits for a stream without holding a core.  hipStreamSynchronize (and hipEventSynchronize, blocking-sync flag or not)
+// busy-waits on this runtime: a waiting thread shows 100 % CPU for the whole wait (tools/spin_probe.py), and the contig stage
+// is bound by the host cores it shares with those waits.  So: poll the stream, spin only for the first ~20 us, then sleep
+// between polls.  NSGPU_SPIN_WAIT=1 restores the runtime's own wait.
+hipError_t stream_wait(hipStream_t s);
+
 // Growable device allocation (never shrinks). No hipMalloc happens inside a
 // stage once the buffers have reached their steady-state size.
 struct DevBuf {

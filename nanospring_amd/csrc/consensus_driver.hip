@@ -467,7 +467,7 @@ static int engine_batches_finish(nsgpu_ctx *c, int group)
             E->fids.resize(c->f_total + 1);
             NS_HIP(hipMemcpyAsync(E->foff.data(), c->f_off.p, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, c->stream));
             if (c->f_total) NS_HIP(hipMemcpyAsync(E->fids.data(), c->f_ids.p, c->f_total * 4, hipMemcpyDeviceToHost, c->stream));
-            NS_HIP(hipStreamSynchronize(c->stream));
+            NS_HIP(stream_wait(c->stream));
             for (size_t w = 0; w < who.size(); ++w) {
                 Builder &b = D.B[who[w]];
                 for (int s = 0; s < 2; ++s) b.cand[s].assign(E->fids.begin() + E->foff[2 * w + s], E->fids.begin() + E->foff[2 * w + s + 1]);

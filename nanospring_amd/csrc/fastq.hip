@@ -115,7 +115,7 @@ int load_fastq(nsgpu_ctx *c, const char *text, size_t n_bytes, uint32_t *n_reads
     }
     uint32_t n_nl = 0;
     NS_HIP(hipMemcpyAsync(&n_nl, c->fq_base.as<uint32_t>() + n_seg, 4, hipMemcpyDeviceToHost, st));
-    NS_HIP(hipStreamSynchronize(st));
+    NS_HIP(stream_wait(st));
     const uint64_t n_lines = (uint64_t)n_nl + (text[n_bytes - 1] != '\n' ? 1 : 0);      // getline: an unterminated last line counts when non-empty
     const uint64_t n_reads64 = (n_lines + 3) / 4;
     NS_CHECK(n_reads64 > 0, NSGPU_ERR_ARG, "nsgpu_load_fastq: no reads");
@@ -133,7 +133,7 @@ int load_fastq(nsgpu_ctx *c, const char *text, size_t n_bytes, uint32_t *n_reads
     std::vector<uint32_t> len(n_reads);
     NS_HIP(hipMemcpyAsync(start.data(), c->aoff.p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, st));
     NS_HIP(hipMemcpyAsync(len.data(), c->fq_len.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
-    NS_HIP(hipStreamSynchronize(st));
+    NS_HIP(stream_wait(st));
     // rows: the pack kernel reads read r at text + start[r], len[r] bases
     c->have_sketch = c->have_index = c->have_filter_all = c->have_cons = false;
     NS_TRY(store_prepare_lens(c, c->reads, len.data(), n_reads));
@@ -151,7 +151,7 @@ int load_fastq(nsgpu_ctx *c, const char *text, size_t n_bytes, uint32_t *n_reads
         char *dst = c->h_bases.data() + c->h_off[r];
         for (uint32_t i = 0; i < len[r]; ++i) dst[i] = dna[(src[i] & 2) | ((src[i] & 4) >> 2)];
     });
-    NS_HIP(hipStreamSynchronize(st));
+    NS_HIP(stream_wait(st));
     NS_HIP(hipEventElapsedTime(&c->timing.pack_ms, c->t_kernel.a, c->t_kernel.b));
     c->fastq_ms = now_ms() - t0;
     if (n_reads_out) *n_reads_out = n_reads;

@@ -501,7 +501,7 @@ int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, 
     NS_TRY(scan_u32_to_u64(c, qcap, soff, nq));
     uint64_t staging_total = 0, m_total = 0;
     NS_HIP(hipMemcpyAsync(&staging_total, soff + nq, 8, hipMemcpyDeviceToHost, c->stream));
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     NS_TRY(c->f_pool.reserve((staging_total + 1) * 4));
     {
         uint32_t grid = nq < 262144u ? nq : 262144u;
@@ -511,7 +511,7 @@ int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, 
     }
     uint32_t n_ovf = 0;
     NS_HIP(hipMemcpyAsync(&n_ovf, c->f_ctrl.p, 4, hipMemcpyDeviceToHost, c->stream));
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     if (n_ovf) {
         const uint32_t wgs = n_ovf < F_HEAVY_WGS ? n_ovf : F_HEAVY_WGS;
         const size_t need = (size_t)F_HEAVY_WGS * N * 4;
@@ -525,7 +525,7 @@ int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, 
     }
     NS_TRY(scan_u32_to_u64(c, qcnt, c->f_off.as<uint64_t>(), nq));
     NS_HIP(hipMemcpyAsync(&c->f_total, c->f_off.as<uint64_t>() + nq, 8, hipMemcpyDeviceToHost, c->stream));
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     NS_TRY(c->f_ids.reserve((c->f_total + 1) * 4));
     {
         uint32_t grid = (nq + 3) / 4;
@@ -543,7 +543,7 @@ int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, 
             NS_HIP(hipMemcpyAsync(&m_total, tmp + nq, 8, hipMemcpyDeviceToHost, c->stream));
         }
     }
-    NS_HIP(hipStreamSynchronize(c->stream));
+    NS_HIP(stream_wait(c->stream));
     NS_HIP(hipEventElapsedTime(&c->timing.filter_kernel_ms, c->t_kernel.a, c->t_kernel.b));
     c->timing.filter_matches = m_total;
     return NSGPU_OK;

@@ -832,7 +832,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         hipStream_t st = S;
         if (k > 0 && !dbg) { st = W.side_stream[k]; NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0)); side_used[k] = true; }
         double dbg_t0 = 0;
-        if (dbg) { NS_HIP(hipStreamSynchronize(S)); dbg_t0 = now_ms(); }
+        if (dbg) { NS_HIP(stream_wait(S)); dbg_t0 = now_ms(); }
         const uint32_t *ord = W.k_order.as<uint32_t>() + wg_start[k];
         NS_HIP(hipEventRecord(ev_at(n_ev++), st));
         if (k == 1)
@@ -848,7 +848,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         NS_HIP(hipEventRecord(ev_at(n_ev++), st));
         ++n_launch;
         if (dbg) {
-            NS_HIP(hipStreamSynchronize(S));
+            NS_HIP(stream_wait(S));
             double cells = 0, mx = 0;
             for (uint32_t i : wg[k]) { const double x = (double)tasks[i].qlen * tasks[i].tlen; cells += x; if (x > mx) mx = x; }
             fprintf(stderr, "KSW class %d tasks %u cells %.3g max %.3g (q %d t %d) ms %.3f\n", k + 4, m, cells, mx, tasks[wg[k][0]].qlen, tasks[wg[k][0]].tlen, now_ms() - dbg_t0);
@@ -860,7 +860,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         hipStream_t st = S;
         if (k > 0 && !dbg) { st = W.side_stream[k]; NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0)); side_used[k] = true; }
         double dbg_t0 = 0;
-        if (dbg) { NS_HIP(hipStreamSynchronize(S)); dbg_t0 = now_ms(); }
+        if (dbg) { NS_HIP(stream_wait(S)); dbg_t0 = now_ms(); }
         if (kClass[k] > 49152) {
             static const hipError_t attr_lds = hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClass[2]);
             NS_HIP(attr_lds);
@@ -873,7 +873,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         NS_HIP(hipEventRecord(ev_at(n_ev++), st));
         ++n_launch;
         if (dbg) {
-            NS_HIP(hipStreamSynchronize(S));
+            NS_HIP(stream_wait(S));
             double cells = 0, mx = 0;
             for (uint32_t i : order[k]) { const double x = (double)tasks[i].qlen * tasks[i].tlen; cells += x; if (x > mx) mx = x; }
             fprintf(stderr, "KSW class %d tasks %u cells %.3g max %.3g (q %d t %d) ms %.3f\n", k, m, cells, mx, tasks[order[k][0]].qlen, tasks[order[k][0]].tlen, now_ms() - dbg_t0);
@@ -920,7 +920,7 @@ int ksw_batch_collect(nsgpu_ctx *c, std::vector<KswTask> &tasks, std::vector<Ksw
     W.pend_n = 0;
     NS_HIP(hipMemcpyAsync(results.data(), W.k_res.p, n * sizeof(KswResult), hipMemcpyDeviceToHost, S));
     NS_HIP(hipMemcpyAsync(cig_off.data(), W.k_coff.p, (n + 1) * 8, hipMemcpyDeviceToHost, S));
-    NS_HIP(hipStreamSynchronize(S));
+    NS_HIP(stream_wait(S));
     const uint64_t used = cig_off[n];
     NS_TRY(W.k_cig2.reserve((used + 16) * 4));
     if (used) {
@@ -932,7 +932,7 @@ int ksw_batch_collect(nsgpu_ctx *c, std::vector<KswTask> &tasks, std::vector<Ksw
     }
     cigars.resize(used + 1);
     if (used) NS_HIP(hipMemcpyAsync(cigars.data(), W.k_cig2.p, used * 4, hipMemcpyDeviceToHost, S));
-    NS_HIP(hipStreamSynchronize(S));
+    NS_HIP(stream_wait(S));
     float ms = 0;
     NS_HIP(hipEventElapsedTime(&ms, W.t_a, W.t_b));
     double sum_ms = 0, cells = 0, alg = 0;

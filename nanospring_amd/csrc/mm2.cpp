@@ -204,6 +204,18 @@ void RefIndex::build_from_sketch(const char *s, uint32_t n, int w_, int k_, floa
         pos[i] = kv[i].second;
     }
     start.push_back((uint32_t)kv.size());
+    {
+        uint32_t bits = 4;
+        while (((size_t)1 << bits) < 2 * keys.size() + 2) ++bits;
+        slot.assign((size_t)1 << bits, 0u);
+        slot_shift = 64 - bits;
+        const size_t m = slot.size() - 1;
+        for (size_t i = 0; i < keys.size(); ++i) {
+            size_t h = (size_t)((keys[i] * 0x9e3779b97f4a7c15ull) >> slot_shift);
+            while (slot[h]) h = (h + 1) & m;
+            slot[h] = (uint32_t)i + 1;
+        }
+    }
     // mm_idx_cal_max_occ(mi, 2e-4f) (index.c:164-185): (k-th smallest occurrence count) + 1,
     // k = (uint32_t)((1. - f) * n_distinct) with f a float promoted to double
     const size_t nd = keys.size();
@@ -220,9 +232,12 @@ void RefIndex::build_from_sketch(const char *s, uint32_t n, int w_, int k_, floa
 
 const uint64_t *RefIndex::get(uint64_t minier, int *n) const
 {
-    auto it = std::lower_bound(keys.begin(), keys.end(), minier);
-    if (it == keys.end() || *it != minier) { *n = 0; return nullptr; }
-    const size_t i = it - keys.begin();
+    if (slot.empty()) { *n = 0; return nullptr; }
+    const size_t m = slot.size() - 1;
+    size_t h = (size_t)((minier * 0x9e3779b97f4a7c15ull) >> slot_shift);
+    while (slot[h] && keys[slot[h] - 1] != minier) h = (h + 1) & m;
+    if (!slot[h]) { *n = 0; return nullptr; }
+    const size_t i = slot[h] - 1;
     *n = (int)(start[i + 1] - start[i]);
     return pos.data() + start[i];
 }
@@ -781,7 +796,30 @@ void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const int8_t
         const uint32_t op = c & 0xf, len = c >> 4;
         if (op == 0) {
             int n_ambi = 0, n_diff = 0;
-            for (uint32_t l = 0; l < len; ++l) {
+            uint32_t l = 0;
+            // eight equal unambiguous bases at a time: the score only climbs over them (a > 0, s >= 0 on entry), so the
+            // running maximum is the value after the last one -- the same numbers as the base-by-base loop below
+            const int a_match = mat[0];
+            if (a_match > 0 && mat[6] == a_match && mat[12] == a_match && mat[18] == a_match)
+                while (l + 8 <= len) {
+                    uint64_t wq, wt;
+                    memcpy(&wq, qseq + qoff + l, 8), memcpy(&wt, tseq + toff + l, 8);
+                    if (wq != wt || (wq & 0xfcfcfcfcfcfcfcfcull)) {
+                        // scalar over this word
+                        for (uint32_t e8 = l + 8; l < e8; ++l) {
+                            const int cq = qseq[qoff + l], ct = tseq[toff + l];
+                            if (ct > 3 || cq > 3) ++n_ambi;
+                            else if (ct != cq) ++n_diff;
+                            s += mat[ct * 5 + cq];
+                            if (s < 0) s = 0; else mx = mx > s ? mx : s;
+                        }
+                        continue;
+                    }
+                    s += 8 * a_match;
+                    mx = mx > s ? mx : s;
+                    l += 8;
+                }
+            for (; l < len; ++l) {
                 const int cq = qseq[qoff + l], ct = tseq[toff + l];
                 if (ct > 3 || cq > 3) ++n_ambi;
                 else if (ct != cq) ++n_diff;
@@ -1196,6 +1234,13 @@ void edits_from_hit(int hits, int rs, int re, int qs, int qe, int blen, int mlen
         if (op == 0) {
             uint32_t same = 0;
             for (uint32_t k = 0; k < len; ++k) {
+                while (k + 8 <= len) {                  // eight equal bases at a time
+                    uint64_t wq, wt;
+                    memcpy(&wq, s + qpos, 8), memcpy(&wt, ref + rpos, 8);
+                    if (wq != wt) break;
+                    same += 8, qpos += 8, rpos += 8, k += 8;
+                }
+                if (k >= len) break;
                 if (s[qpos] == ref[rpos]) ++same;
                 else {
                     if (same > 0) ed.push_back({0, 0, same});

@@ -56,6 +56,8 @@ struct RefIndex {
     std::vector<uint64_t> keys;        // distinct minimizer hashes, ascending
     std::vector<uint32_t> start;       // CSR into pos
     std::vector<uint64_t> pos;         // per key: y values ascending (index.c:230)
+    std::vector<uint32_t> slot;        // open-addressing table over keys (index into keys + 1, 0 = empty); get() probes it
+    uint32_t slot_shift = 64;
     int32_t mid_occ = 0;
     void build(const char *s, uint32_t n, int w_, int k_, float mid_occ_frac);
     // same, with the sequence's minimizers (mm_sketch order, rid 0) supplied by the caller
