@@ -50,15 +50,50 @@ unsigned host_threads()
 void parallel_for_impl(size_t n, const std::function<void(size_t)> &fn);
 template <class F>
 static void parallel_for(size_t n, F fn) { parallel_for_impl(n, std::function<void(size_t)>(fn)); }
+template <class F>
+static void parallel_for(const char *tag, size_t n, F fn) { PoolTag t(tag); parallel_for_impl(n, std::function<void(size_t)>(fn)); }
 
 // Persistent host thread pool.  Several jobs may be in flight at once (the contig engine's host phase and the host
 // parts of the other group's GPU batches are submitted from two threads): a job is an index range handed out in chunks
 // through an atomic cursor (or, "pinned", one queue per thread with stealing), workers serve the short jobs of the
 // batch thread first so that the GPU is not kept waiting behind a long host phase, and every submitter works on its
 // own job while it waits.  (Spawning ~256 std::threads per parallel loop cost more than the loops themselves.)
+// NSGPU_CONS_DEBUG: thread-CPU time of the pool's loops by the submitter's tag (pool_tag), printed by the contig engine
+static const bool g_pool_prof = getenv("NSGPU_CONS_DEBUG") != nullptr;
+static const char *g_tag_name[32];
+static std::atomic<uint64_t> g_tag_ns[32];
+static std::atomic<int> g_n_tags{1};
+static thread_local int tl_tag = 0;
+static thread_local uint64_t tl_work_ns = 0;
+static inline uint64_t thread_cpu_ns() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec; }
+int pool_tag(const char *name)
+{
+    const int prev = tl_tag;
+    if (!name) { tl_tag = 0; return prev; }
+    static std::mutex m;
+    std::lock_guard<std::mutex> lk(m);
+    int n = g_n_tags.load();
+    for (int i = 1; i < n; ++i) if (!strcmp(g_tag_name[i], name)) { tl_tag = i; return prev; }
+    if (n < 32) { g_tag_name[n] = name; g_n_tags.store(n + 1); tl_tag = n; }
+    return prev;
+}
+void pool_tag_restore(int t) { tl_tag = t; }
+uint64_t pool_thread_cpu_ns() { return thread_cpu_ns(); }
+uint64_t pool_thread_work_ns() { return tl_work_ns; }
+void pool_prof_print()
+{
+    if (!g_pool_prof) return;
+    g_tag_name[0] = "untagged";
+    fprintf(stderr, "[pool] thread-CPU ms by loop:");
+    for (int i = 0; i < g_n_tags.load(); ++i) { fprintf(stderr, " %s %.0f", g_tag_name[i], g_tag_ns[i].exchange(0) / 1e6); }
+    fprintf(stderr, " background %.0f", g_tag_ns[31].exchange(0) / 1e6);
+    fprintf(stderr, "\n");
+}
+
 namespace {
 class HostPool {
     struct Job {
+        int tag = 0;
         const std::function<void(size_t)> *fn = nullptr;
         size_t total = 0, chunk = 1;
         bool pinned = false;
@@ -69,6 +104,16 @@ class HostPool {
         std::condition_variable cv;
         // runs one chunk; false when the job has nothing left to hand out
         bool work_once(unsigned me)
+        {
+            if (!g_pool_prof) return work_once_(me);
+            const uint64_t t0 = thread_cpu_ns();
+            const bool r = work_once_(me);
+            const uint64_t d = thread_cpu_ns() - t0;
+            g_tag_ns[tag].fetch_add(d, std::memory_order_relaxed);
+            tl_work_ns += d;
+            return r;
+        }
+        bool work_once_(unsigned me)
         {
             size_t n_done = 0;
             if (pinned) {
@@ -108,7 +153,7 @@ public:
     void run(size_t n, const std::function<void(size_t)> &fn, bool pinned = false)
     {
         auto job = std::make_shared<Job>();
-        job->fn = &fn, job->total = n, job->pinned = pinned, job->n_threads = n_;
+        job->fn = &fn, job->total = n, job->pinned = pinned, job->n_threads = n_, job->tag = tl_tag;
         job->chunk = n / ((size_t)n_ * 8) ? n / ((size_t)n_ * 8) : 1;
         if (pinned) { job->pos = std::vector<std::atomic<size_t>>(n_); for (auto &x : job->pos) x.store(0); }
         {
@@ -160,7 +205,9 @@ private:
                 }
             }
             if (bg) {
+                const uint64_t t0 = g_pool_prof ? thread_cpu_ns() : 0;
                 bg();
+                if (g_pool_prof) g_tag_ns[31].fetch_add(thread_cpu_ns() - t0, std::memory_order_relaxed);
                 std::lock_guard<std::mutex> lk(m_);
                 if (--bg_running_ == 0 && bg_.empty()) bg_cv_.notify_all();
                 continue;
@@ -230,7 +277,7 @@ int batch_prepare_round(nsgpu_ctx *c, AlignBatch &B)
 {
     using namespace mm2;
     const double a0 = now_ms();
-    parallel_for(B.live.size(), [&](size_t i) { B.jobs[B.live[i]].step(); });
+    parallel_for("align.step", B.live.size(), [&](size_t i) { B.jobs[B.live[i]].step(); });
     std::vector<uint32_t> still;
     B.t_off.clear(), B.b_off.clear();
     size_t nt = 0, nb = 0;
@@ -256,7 +303,7 @@ int batch_prepare_round(nsgpu_ctx *c, AlignBatch &B)
         KW.h_pool_cap = want;
     }
     uint8_t *const pool = KW.h_pool;
-    parallel_for(B.live.size(), [&](size_t li) {
+    parallel_for("align.dp_pack", B.live.size(), [&](size_t li) {
         AlignJob &J = B.jobs[B.live[li]];
         size_t ti = B.t_off[li], bo = B.b_off[li];
         for (const DpKey &k : J.cache.missing) {
@@ -282,7 +329,7 @@ void batch_deliver(AlignBatch &B)
 {
     using namespace mm2;
     const double a0 = now_ms();
-    parallel_for(B.live.size(), [&](size_t li) {
+    parallel_for("align.dp_deliver", B.live.size(), [&](size_t li) {
         AlignJob &J = B.jobs[B.live[li]];
         size_t ti = B.t_off[li];
         for (const DpKey &k : J.cache.missing) {
@@ -290,8 +337,7 @@ void batch_deliver(AlignBatch &B)
             DpResult d;
             d.max = r.max; d.zdropped = r.zdropped; d.max_q = r.max_q; d.max_t = r.max_t; d.mqe = r.mqe; d.mqe_t = r.mqe_t; d.mte = r.mte;
             d.mte_q = r.mte_q; d.score = r.score; d.reach_end = r.reach_end;
-            d.cigar.assign(B.cig.begin() + B.coff[ti], B.cig.begin() + B.coff[ti] + r.n_cigar);
-            J.cache.done.emplace(k, std::move(d));
+            J.cache.put(k, d, B.cig.data() + B.coff[ti], (uint32_t)r.n_cigar);
             ++ti;
         }
     });
@@ -323,11 +369,12 @@ int align_begin(nsgpu_ctx *c, AlignBatch &B, int ws_index)
     const size_t n_pairs = B.reqs.size();
     B.ws_index = ws_index, B.in_flight = false;
     B.host_ms = B.dp_ms = 0, B.dp_tasks = B.rounds = 0;
-    B.jobs.clear();
     B.live.clear();
     if (n_pairs == 0) return NSGPU_OK;
     const Opt opt = batch_opt(c);
-    B.jobs.resize(n_pairs);
+    // the job objects (and the capacity of their vectors) are kept from batch to batch: freeing and re-allocating the
+    // ~100 small blocks of every job cost more CPU than the alignment bookkeeping itself
+    if (B.jobs.size() < n_pairs) B.jobs.resize(n_pairs);
     for (size_t i = 0; i < n_pairs; ++i) {
         B.jobs[i].start(B.reqs[i].idx, B.reqs[i].qry, (int)B.reqs[i].qry_len, opt);
         // a query of length 0 has no sketch either way; pre_mz must be non-null to count as "given"
@@ -370,8 +417,7 @@ int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs)
         batch_deliver(B);
     }
     const double b0 = now_ms();
-    parallel_for(n_pairs, [&](size_t i) { align_read_result(B.jobs[i], B.reqs[i].ref, B.reqs[i].ref_len, outs[i]); });
-    parallel_for(n_pairs, [&](size_t i) { AlignJob().swap_storage(B.jobs[i]); });      // free the jobs' heap blocks on all threads
+    parallel_for("align.result", n_pairs, [&](size_t i) { align_read_result(B.jobs[i], B.reqs[i].ref, B.reqs[i].ref_len, outs[i]); });
     B.host_ms += now_ms() - b0;
     {
         std::lock_guard<std::mutex> lk(c->stat_m);
@@ -408,7 +454,7 @@ int align_batch(nsgpu_ctx *c, const char *refs, const uint64_t *roff, uint32_t n
     std::vector<uint64_t> mz_off;
     NS_TRY(gpu_mm_sketch(c, sk, (int)c->prm.m_w, (int)c->prm.m_k, mz, mz_off));
     std::vector<RefIndex> idx(n_refs);
-    parallel_for(n_refs, [&](size_t i) {
+    parallel_for("index.build", n_refs, [&](size_t i) {
         idx[i].build_from_sketch(refs + roff[i], (uint32_t)(roff[i + 1] - roff[i]), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f, mz + mz_off[i], (size_t)(mz_off[i + 1] - mz_off[i]));
     });
     c->aln_index_ms += now_ms() - t0;

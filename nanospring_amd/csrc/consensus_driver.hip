@@ -287,6 +287,7 @@ struct Engine {
     double p1_align_ms = 0, p1_host_ms = 0, p1_launch_ms = 0;
     uint64_t slot_long_n[3] = {0, 0, 0};
     double slot_long_ms[3] = {0, 0, 0};
+    uint64_t role_serial_ns[3] = {0, 0, 0};
     std::vector<FinishedContig *> emit_queue;      // finished contigs whose emission has not run yet
     std::vector<SketchReq> sk;
     std::vector<uint32_t> sk_ref;
@@ -340,7 +341,7 @@ static void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
     const double a0 = now_ms();
-    par_for_pinned(D.B.size(), [&](size_t i) {
+    par_for_pinned("host.phase", D.B.size(), [&](size_t i) {
         Builder &b = D.B[i];
         if (in_group(b, group) && (!only_fresh || b.st == Builder::ADVANCE)) D.advance(b);
     });
@@ -418,7 +419,7 @@ static int engine_batches_begin(nsgpu_ctx *c, int group, int ws_index)
         const mm2::Anchor *mz = nullptr;
         NS_TRY(gpu_mm_sketch(c, sk, (int)c->prm.m_w, (int)c->prm.m_k, mz, E->mz_off));
         const std::vector<uint64_t> &mo = E->mz_off;
-        par_for(who.size(), [&](size_t w) {
+        par_for("index.build", who.size(), [&](size_t w) {
             Builder &b = D.B[who[w]];
             if (!b.idx_valid) {
                 const uint32_t si = sk_ref[w];
@@ -582,16 +583,20 @@ static int engine_slot(nsgpu_ctx *c, int host_group, int begin_group, int finish
     int rc1 = NSGPU_OK, rc2 = NSGPU_OK;
     std::thread t1, t2;
     double d1 = 0, d2 = 0;
-    if (begin_group != -2) t1 = std::thread([&] { const double x = now_ms(); rc1 = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches_begin(c, begin_group, ws_index) : NSGPU_ERR_HIP; d1 = now_ms() - x; });
-    if (finish_group != -2) t2 = std::thread([&] { const double x = now_ms(); rc2 = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches_finish(c, finish_group) : NSGPU_ERR_HIP; d2 = now_ms() - x; });
+    uint64_t ser[3] = {0, 0, 0};          // CPU time of the three role threads outside the pool's loops (debug breakdown)
+    if (begin_group != -2) t1 = std::thread([&] { const double x = now_ms(); const uint64_t c0 = pool_thread_cpu_ns(); rc1 = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches_begin(c, begin_group, ws_index) : NSGPU_ERR_HIP; d1 = now_ms() - x; ser[1] = pool_thread_cpu_ns() - c0 - pool_thread_work_ns(); });
+    if (finish_group != -2) t2 = std::thread([&] { const double x = now_ms(); const uint64_t c0 = pool_thread_cpu_ns(); rc2 = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches_finish(c, finish_group) : NSGPU_ERR_HIP; d2 = now_ms() - x; ser[2] = pool_thread_cpu_ns() - c0 - pool_thread_work_ns(); });
     const double h0 = now_ms();
+    const uint64_t hc0 = pool_thread_cpu_ns(), hw0 = pool_thread_work_ns();
     if (host_group != -2) engine_advance(c, false, host_group);
+    ser[0] = pool_thread_cpu_ns() - hc0 - (pool_thread_work_ns() - hw0);
     const double dh = now_ms() - h0;
     if (t1.joinable()) t1.join();
     if (t2.joinable()) t2.join();
     {   // which of the three parts set the length of the slot (debug breakdown)
         Engine *E = static_cast<Engine *>(c->cons_engine);
         const int w = dh >= d1 && dh >= d2 ? 0 : d1 >= d2 ? 1 : 2;
+        for (int i = 0; i < 3; ++i) E->role_serial_ns[i] += ser[i];
         ++E->slot_long_n[w];
         E->slot_long_ms[w] += w == 0 ? dh : w == 1 ? d1 : d2;
     }
@@ -651,7 +656,12 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
         getrusage(RUSAGE_SELF, &ru1);
         const double cpu_s = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec) * 1e-6 +
                              (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
-        fprintf(stderr, "[cons] process CPU time over the stage: %.1f s = %.1f cores busy on average\n", cpu_s, cpu_s / ((now_ms() - E->t0) * 1e-3));
+        fprintf(stderr, "[cons] serial CPU ms of the role threads (outside pool loops): host %.0f, batches part 1 %.0f, part 2 %.0f\n", E->role_serial_ns[0] / 1e6,
+                E->role_serial_ns[1] / 1e6, E->role_serial_ns[2] / 1e6);
+        pool_prof_print();
+        const double sys_s = (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
+        fprintf(stderr, "[cons] process CPU time over the stage: %.1f s (%.1f s of it in the kernel; %ld minor faults) = %.1f cores busy on average\n", cpu_s, sys_s,
+                ru1.ru_minflt - ru0.ru_minflt, cpu_s / ((now_ms() - E->t0) * 1e-3));
         fprintf(stderr, "[cons] wall-ms: begin %.0f slots %.0f (host phases %.0f, batches %.0f, overlapped) seed %.0f claim %.0f finish %.0f\n", w_begin, w_slot,
                 c->cons_stats.graph_ms, c->cons_stats.filter_ms + c->cons_stats.index_ms + c->cons_stats.align_ms, w_seed, w_claim, now_ms() - tf);
     }

@@ -19,6 +19,15 @@ void parallel_for_pinned_impl(size_t n, const std::function<void(size_t)> &fn);
 template <class F> inline void par_for_pinned(size_t n, F fn) { parallel_for_pinned_impl(n, std::function<void(size_t)>(fn)); }
 // background tasks of the lowest priority (run when no parallel loop has work) and the wait for all of them
 void pool_post(std::function<void()> fn);
+// debug accounting (NSGPU_CONS_DEBUG): loops submitted by this thread are booked under `name` until restored
+int pool_tag(const char *name);
+void pool_tag_restore(int t);
+void pool_prof_print();
+uint64_t pool_thread_cpu_ns();      // this thread's CPU time / the part of it spent inside pool loops
+uint64_t pool_thread_work_ns();
+struct PoolTag { int prev; explicit PoolTag(const char *n) : prev(pool_tag(n)) {} ~PoolTag() { pool_tag_restore(prev); } };
+template <class F> inline void par_for(const char *tag, size_t n, F fn) { PoolTag t(tag); parallel_for_impl(n, std::function<void(size_t)>(fn)); }
+template <class F> inline void par_for_pinned(const char *tag, size_t n, F fn) { PoolTag t(tag); parallel_for_pinned_impl(n, std::function<void(size_t)>(fn)); }
 void pool_drain();
 
 struct AlignReq {

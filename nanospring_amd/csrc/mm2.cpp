@@ -180,6 +180,50 @@ void mm_sketch(const char *str, int len, int w, int k, uint32_t rid, std::vector
 // ---------------------------------------------------------------------------
 // a14b + a14a  single-sequence index and mid_occ
 // ---------------------------------------------------------------------------
+// Ascending sort of distinct 64-bit keys whose top bits are well mixed (hashes): three 8-bit counting passes over the top
+// 24 bits leave the array sorted up to the rare keys that agree there, which one insertion pass puts right.
+static void sort_unique_keys(std::vector<uint64_t> &v, std::vector<uint64_t> &tmp)
+{
+    const size_t n = v.size();
+    if (n < 512) { std::sort(v.begin(), v.end()); return; }
+    tmp.resize(n);
+    uint64_t *a = v.data(), *b = tmp.data();
+    for (int shift = 40; shift <= 56; shift += 8) {
+        uint32_t cnt[257] = {0};
+        for (size_t i = 0; i < n; ++i) ++cnt[((a[i] >> shift) & 0xff) + 1];
+        for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+        for (size_t i = 0; i < n; ++i) b[cnt[(a[i] >> shift) & 0xff]++] = a[i];
+        std::swap(a, b);
+    }
+    // three passes: the result is in tmp
+    for (size_t i = 1; i < n; ++i) {
+        const uint64_t x = a[i];
+        size_t j = i;
+        for (; j > 0 && a[j - 1] > x; --j) a[j] = a[j - 1];
+        a[j] = x;
+    }
+    v.swap(tmp);
+}
+
+// ASCII -> nt4 codes (A0 C1 G2 T3, anything else 4; the reference's seq_nt4_table).  Eight upper-case ACGT at a time:
+// bits 1-2 of the letter are A 00, C 01, T 10, G 11; the word is accepted only if rebuilding the letters from those bits
+// gives the input back, everything else goes through the table.
+void nt4_codes(const char *s, size_t n, uint8_t *out)
+{
+    const uint64_t ones = 0x0101010101010101ull;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, s + i, 8);
+        const uint64_t b0 = (w >> 1) & ones, b1 = (w >> 2) & ones;
+        const uint64_t rebuilt = 0x41 * ones + 2 * b0 + 0x13 * b1 - 0x0f * (b0 & b1);
+        if (rebuilt != w) { for (size_t j = i; j < i + 8; ++j) out[j] = kNt4.t[(uint8_t)s[j]]; continue; }
+        const uint64_t code = (b0 ^ b1) | b1 << 1;          // 00->0, 01->1, 10->3, 11->2
+        memcpy(out + i, &code, 8);
+    }
+    for (; i < n; ++i) out[i] = kNt4.t[(uint8_t)s[i]];
+}
+
 void RefIndex::build(const char *s, uint32_t n, int w_, int k_, float mid_occ_frac)
 {
     std::vector<Anchor> mz;
@@ -191,19 +235,40 @@ void RefIndex::build_from_sketch(const char *s, uint32_t n, int w_, int k_, floa
 {
     k = k_, w = w_ < 1 ? 1 : w_, len = n;
     seq.resize(n);
-    for (uint32_t i = 0; i < n; ++i) seq[i] = kNt4.t[(uint8_t)s[i]];
+    nt4_codes(s, n, seq.data());
     struct Span { const Anchor *p; size_t n; size_t size() const { return n; } const Anchor &operator[](size_t i) const { return p[i]; } } mz{mz_p, mz_n};
     // the bucketed hash tables of the reference (index.c:191-248) only define "hash -> positions
     // ascending"; a (hash, position) sort gives the same mapping
-    std::vector<std::pair<uint64_t, uint64_t>> kv(mz.size());
-    for (size_t i = 0; i < mz.size(); ++i) kv[i] = {mz[i].x >> 8, mz[i].y};
-    std::sort(kv.begin(), kv.end());
-    keys.clear(); start.clear(); pos.resize(kv.size());
-    for (size_t i = 0; i < kv.size(); ++i) {
-        if (i == 0 || kv[i].first != kv[i - 1].first) keys.push_back(kv[i].first), start.push_back((uint32_t)i);
-        pos[i] = kv[i].second;
+    keys.clear(); start.clear(); pos.resize(mz.size());
+    uint32_t idx_bits = 1;
+    while (((size_t)1 << idx_bits) < mz.size()) ++idx_bits;
+    bool ascending = true;                 // mm_sketch emits a sequence's minimizers by position
+    for (size_t i = 1; i < mz.size() && ascending; ++i) ascending = mz[i - 1].y < mz[i].y;
+    if (ascending && 2 * (uint32_t)k + idx_bits <= 64) {
+        // one 64-bit key per minimizer, the 2k-bit hash in the top bits (so that the radix sort's first byte already
+        // separates the keys) above its rank in the sketch: the sorted order is the (hash, position) order
+        const uint32_t hs = 64 - 2 * (uint32_t)k;
+        sort_keys_.resize(mz.size());
+        for (size_t i = 0; i < mz.size(); ++i) sort_keys_[i] = (mz[i].x >> 8) << hs | i;
+        sort_unique_keys(sort_keys_, sort_tmp_);
+        const uint64_t im = ((uint64_t)1 << idx_bits) - 1;
+        uint64_t prev = 0;
+        for (size_t i = 0; i < sort_keys_.size(); ++i) {
+            const uint64_t h = sort_keys_[i] >> hs;
+            if (i == 0 || h != prev) keys.push_back(h), start.push_back((uint32_t)i);
+            prev = h;
+            pos[i] = mz[sort_keys_[i] & im].y;
+        }
+    } else {
+        std::vector<std::pair<uint64_t, uint64_t>> kv(mz.size());
+        for (size_t i = 0; i < mz.size(); ++i) kv[i] = {mz[i].x >> 8, mz[i].y};
+        std::sort(kv.begin(), kv.end());
+        for (size_t i = 0; i < kv.size(); ++i) {
+            if (i == 0 || kv[i].first != kv[i - 1].first) keys.push_back(kv[i].first), start.push_back((uint32_t)i);
+            pos[i] = kv[i].second;
+        }
     }
-    start.push_back((uint32_t)kv.size());
+    start.push_back((uint32_t)mz.size());
     {
         uint32_t bits = 4;
         while (((size_t)1 << bits) < 2 * keys.size() + 2) ++bits;
@@ -246,10 +311,10 @@ const uint64_t *RefIndex::get(uint64_t minier, int *n) const
 // a14d  seeds (collect_matches + collect_seed_hits, map.c:90-123, 215-247) with
 // MM_F_FOR_ONLY (skip_seed, map.c:139-145): only same-strand hits survive.
 // ---------------------------------------------------------------------------
-static void collect_seeds(const RefIndex &ri, const std::vector<Anchor> &mv, std::vector<Anchor> &a)
+static void collect_seeds(const RefIndex &ri, const Anchor *mv, size_t n_mv, std::vector<Anchor> &a)
 {
     a.clear();
-    for (size_t i = 0; i < mv.size(); ++i) {
+    for (size_t i = 0; i < n_mv; ++i) {
         const Anchor &p = mv[i];
         const uint32_t q_pos = (uint32_t)p.y, q_span = (uint32_t)(p.x & 0xff);
         int t;
@@ -257,7 +322,7 @@ static void collect_seeds(const RefIndex &ri, const std::vector<Anchor> &mv, std
         if (t >= ri.mid_occ) continue;                  // too frequent on the reference
         bool tandem = false;
         if (i > 0 && p.x >> 8 == mv[i - 1].x >> 8) tandem = true;
-        if (i + 1 < mv.size() && p.x >> 8 == mv[i + 1].x >> 8) tandem = true;
+        if (i + 1 < n_mv && p.x >> 8 == mv[i + 1].x >> 8) tandem = true;
         for (int k = 0; k < t; ++k) {
             const uint64_t r = cr[k];
             if ((r & 1) != (q_pos & 1)) continue;       // reverse-strand seed dropped
@@ -662,13 +727,41 @@ bool DpKey::operator<(const DpKey &o) const
     return false;
 }
 
+static inline bool same_key(const DpKey &a, const DpKey &b) { return memcmp(&a, &b, sizeof(DpKey)) == 0; }
+
+const DpResult *DpCache::find(const DpKey &k)
+{
+    const size_t n = keys.size();
+    for (size_t t = 0; t < n; ++t) {
+        size_t i = cursor + t;
+        if (i >= n) i -= n;
+        if (same_key(keys[i], k)) { cursor = i + 1 < n ? i + 1 : 0; return &vals[i]; }
+    }
+    return nullptr;
+}
+
 const DpResult *DpCache::get(const DpKey &k)
 {
-    auto it = done.find(k);
-    if (it != done.end()) return &it->second;
-    if (std::find_if(missing.begin(), missing.end(), [&](const DpKey &m) { return !(m < k) && !(k < m); }) == missing.end())
+    if (const DpResult *r = find(k)) return r;
+    if (std::find_if(missing.begin(), missing.end(), [&](const DpKey &m) { return same_key(m, k); }) == missing.end())
         missing.push_back(k);
     return nullptr;
+}
+
+const DpResult &DpCache::at(const DpKey &k)
+{
+    const DpResult *r = find(k);
+    if (!r) { fprintf(stderr, "nsgpu: DP result missing from the job's cache\n"); abort(); }
+    return *r;
+}
+
+void DpCache::put(const DpKey &k, const DpResult &scalars, const uint32_t *cigar, uint32_t n_cigar)
+{
+    DpResult r = scalars;
+    r.cig_off = (uint32_t)pool.size(), r.n_cigar = n_cigar;
+    pool.insert(pool.end(), cigar, cigar + n_cigar);
+    keys.push_back(k);
+    vals.push_back(r);
 }
 
 namespace {
@@ -686,7 +779,7 @@ Mat5 simple_mat(int a, int b, int sc_ambi)                     // align.c:9-22
 }
 
 // align.c:32-89 with MM_F_FOR_ONLY: the inversion branch is unreachable, returns 0 or 1
-int test_zdrop(const Opt &o, const uint8_t *qseq, const uint8_t *tseq, const std::vector<uint32_t> &cigar, const int8_t *mat)
+int test_zdrop(const Opt &o, const uint8_t *qseq, const uint8_t *tseq, CigSpan cigar, const int8_t *mat)
 {
     int32_t score = 0, mx = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
     auto upd = [&](int32_t sc, int ii, int jj) {
@@ -696,12 +789,30 @@ int test_zdrop(const Opt &o, const uint8_t *qseq, const uint8_t *tseq, const std
             if (z > max_zdrop) max_zdrop = z;
         } else mx = sc, max_i = ii, max_j = jj;
     };
+    const int a_match = mat[0];
+    const bool fast = a_match > 0 && mat[6] == a_match && mat[12] == a_match && mat[18] == a_match;
     for (uint32_t c : cigar) {
         const uint32_t op = c & 0xf, len = c >> 4;
         if (op == 0) {
-            for (uint32_t l = 0; l < len; ++l) {
+            uint32_t l = 0;
+            while (l < len) {
+                // Eight equal unambiguous bases at a time.  Over a run of matches the score climbs by a > 0 per base and
+                // both coordinates advance together, so (i) no position of the run can raise max_zdrop above what the
+                // update just before the run saw (same diagonal offset, higher score) and (ii) the maximum, if the run
+                // reaches it, ends up at the run's last base: one update for that base leaves the same state.
+                if (fast && l + 8 <= len) {
+                    uint64_t wq, wt;
+                    memcpy(&wq, qseq + j + l, 8), memcpy(&wt, tseq + i + l, 8);
+                    if (wq == wt && !(wq & 0xfcfcfcfcfcfcfcfcull)) {
+                        score += 8 * a_match;
+                        l += 8;
+                        if (score >= mx) mx = score, max_i = i + (int)l - 1, max_j = j + (int)l - 1;
+                        continue;
+                    }
+                }
                 score += mat[tseq[i + l] * 5 + qseq[j + l]];
                 upd(score, i + (int)l, j + (int)l);
+                ++l;
             }
             i += (int)len, j += (int)len;
         } else if (op == 1 || op == 2 || op == 3) {
@@ -713,7 +824,7 @@ int test_zdrop(const Opt &o, const uint8_t *qseq, const uint8_t *tseq, const std
     return max_zdrop > o.zdrop ? 1 : 0;
 }
 
-void append_cigar(Reg &r, const std::vector<uint32_t> &cigar)  // align.c:288-311
+void append_cigar(Reg &r, CigSpan cigar)  // align.c:288-311
 {
     if (cigar.empty()) return;
     if (!r.has_p) { r.has_p = true; r.p = Extra(); }
@@ -963,7 +1074,7 @@ void AlignJob::start(const RefIndex *r, const char *q, int ql, const Opt &o)
     ref = r, qstr = q, qlen = ql, opt = o;
     finished = false, seeded = false, cur = 0;
     pre_mz = nullptr, n_pre_mz = 0;
-    regs.clear(); a.clear(); cache.done.clear(); cache.missing.clear();
+    regs.clear(); a.clear(); cache.clear();
 }
 
 // One region through mm_align1 (align.c:565-795), plan-then-execute: the plan pass asks the
@@ -1080,7 +1191,7 @@ static bool align1(AlignJob &J, Reg &r_io, Reg &r2, bool plan_only = false)
     for (const Fill &f : fills) {
         const DpResult *r1 = J.cache.get(f.k1);
         if (!r1) { missing = true; continue; }
-        if (test_zdrop(opt, qseq0 + f.k1.qs, tseq_all + f.k1.rs, r1->cigar, mat.m) != 0) {
+        if (test_zdrop(opt, qseq0 + f.k1.qs, tseq_all + f.k1.rs, J.cache.cigar(*r1), mat.m) != 0) {
             DpKey k2 = f.k1;
             k2.flag = 0;
             if (!J.cache.get(k2)) missing = true;
@@ -1098,8 +1209,8 @@ static bool align1(AlignJob &J, Reg &r_io, Reg &r2, bool plan_only = false)
     // ---- execute ----
     bool dropped = false;
     if (do_left) {
-        const DpResult &ez = J.cache.done[left_key];
-        if (!ez.cigar.empty()) { append_cigar(r, ez.cigar); r.p.dp_score += (int32_t)ez.max; }
+        const DpResult &ez = J.cache.at(left_key);
+        if (ez.n_cigar) { append_cigar(r, J.cache.cigar(ez)); r.p.dp_score += (int32_t)ez.max; }
         rs1 = rs - (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
         qs1 = qs - (ez.reach_end ? qs - qs0 : ez.max_q + 1);
     } else rs1 = rs, qs1 = qs;
@@ -1111,13 +1222,13 @@ static bool align1(AlignJob &J, Reg &r_io, Reg &r2, bool plan_only = false)
         re1 = re, qe1 = qe;
         if (i == cnt1 - 1 || (a[as1 + i].y & SEED_LONG_JOIN) || (qe - qs >= opt.min_ksw_len && re - rs >= opt.min_ksw_len)) {
             const Fill &f = fills[fi++];
-            const DpResult *ez = &J.cache.done[f.k1];
-            if (test_zdrop(opt, qseq0 + qs, tseq_all + rs, ez->cigar, mat.m) != 0) {
+            const DpResult *ez = &J.cache.at(f.k1);
+            if (test_zdrop(opt, qseq0 + qs, tseq_all + rs, J.cache.cigar(*ez), mat.m) != 0) {
                 DpKey k2 = f.k1;
                 k2.flag = 0;
-                ez = &J.cache.done[k2];
+                ez = &J.cache.at(k2);
             }
-            if (!ez->cigar.empty()) append_cigar(r, ez->cigar);
+            if (ez->n_cigar) append_cigar(r, J.cache.cigar(*ez));
             if (ez->zdropped) {
                 if (!r.has_p) { r.has_p = true; r.p = Extra(); }
                 int j;
@@ -1136,8 +1247,8 @@ static bool align1(AlignJob &J, Reg &r_io, Reg &r2, bool plan_only = false)
     }
     if (!dropped && qe < qe0 && re < re0) {
         const DpKey right_key = {qe, qe0, re, re0, bw, opt.zdrop, opt.end_bonus, EZ_EXTZ_ONLY};
-        const DpResult &ez = J.cache.done[right_key];
-        if (!ez.cigar.empty()) { append_cigar(r, ez.cigar); r.p.dp_score += (int32_t)ez.max; }
+        const DpResult &ez = J.cache.at(right_key);
+        if (ez.n_cigar) { append_cigar(r, J.cache.cigar(ez)); r.p.dp_score += (int32_t)ez.max; }
         re1 = re + (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
         qe1 = qe + (ez.reach_end ? qe0 - qe : ez.max_q + 1);
     }
@@ -1160,11 +1271,13 @@ bool AlignJob::step()
     if (!seeded) {
         seeded = true;
         qseq.resize(qlen);
-        for (int i = 0; i < qlen; ++i) qseq[i] = kNt4.t[(uint8_t)qstr[i]];
-        std::vector<Anchor> mv;
-        if (pre_mz) mv.assign(pre_mz, pre_mz + n_pre_mz);            // sketched by the caller (mm_sketch.hip)
-        else if (qlen > 0) mm_sketch(qstr, qlen, ref->w, ref->k, 0, mv);
-        collect_seeds(*ref, mv, a);
+        nt4_codes(qstr, (size_t)qlen, qseq.data());
+        if (pre_mz) collect_seeds(*ref, pre_mz, n_pre_mz, a);       // sketched by the caller (mm_sketch.hip)
+        else {
+            std::vector<Anchor> mv;
+            if (qlen > 0) mm_sketch(qstr, qlen, ref->w, ref->k, 0, mv);
+            collect_seeds(*ref, mv.data(), mv.size(), a);
+        }
         lap(0);
         std::vector<uint64_t> u;
         chain_dp(opt, a, u);

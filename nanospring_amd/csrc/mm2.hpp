@@ -44,6 +44,7 @@ struct Opt {
     float max_clip_ratio = 1.0f;
 };
 
+void nt4_codes(const char *s, size_t n, uint8_t *out);                                            // seq_nt4_table applied to a string
 void mm_sketch(const char *str, int len, int w, int k, uint32_t rid, std::vector<Anchor> &out);   // minimap2/sketch.c:77-143
 void radix_sort_128x(Anchor *beg, Anchor *end);                                                  // minimap2/ksort.h:98-151 via misc.c:153-156
 void radix_sort_64(uint64_t *beg, uint64_t *end);                                                // misc.c:158-159
@@ -58,6 +59,7 @@ struct RefIndex {
     std::vector<uint64_t> pos;         // per key: y values ascending (index.c:230)
     std::vector<uint32_t> slot;        // open-addressing table over keys (index into keys + 1, 0 = empty); get() probes it
     uint32_t slot_shift = 64;
+    std::vector<uint64_t> sort_keys_, sort_tmp_;  // scratch of build_from_sketch
     int32_t mid_occ = 0;
     void build(const char *s, uint32_t n, int w_, int k_, float mid_occ_frac);
     // same, with the sequence's minimizers (mm_sketch order, rid 0) supplied by the caller
@@ -87,14 +89,34 @@ struct DpKey {
     int32_t qs, qe, rs, re, w, zdrop, end_bonus, flag;
     bool operator<(const DpKey &o) const;
 };
-struct DpResult {                      // ksw_extz_t
-    uint32_t max = 0; int32_t zdropped = 0, max_q = -1, max_t = -1, mqe = 0, mqe_t = -1, mte = 0, mte_q = -1, score = 0, reach_end = 0;
-    std::vector<uint32_t> cigar;
+struct CigSpan {                       // a CIGAR held by somebody else (the job's DpCache pool)
+    const uint32_t *p = nullptr; uint32_t n = 0;
+    bool empty() const { return n == 0; }
+    size_t size() const { return n; }
+    const uint32_t *begin() const { return p; }
+    const uint32_t *end() const { return p + n; }
+    uint32_t operator[](size_t i) const { return p[i]; }
 };
+struct DpResult {                      // ksw_extz_t; the CIGAR lives in the cache's pool
+    uint32_t max = 0; int32_t zdropped = 0, max_q = -1, max_t = -1, mqe = 0, mqe_t = -1, mte = 0, mte_q = -1, score = 0, reach_end = 0;
+    uint32_t cig_off = 0, n_cigar = 0;
+};
+// The DP results a job has received so far.  Flat arrays that keep their capacity from one alignment to the next: a
+// job asks for a few dozen DPs, in (nearly) the order it later reads them, so a scan that starts behind the last hit
+// finds most keys at once -- and nothing is allocated or freed per result.
 struct DpCache {
-    std::map<DpKey, DpResult> done;
+    std::vector<DpKey> keys;
+    std::vector<DpResult> vals;
+    std::vector<uint32_t> pool;
     std::vector<DpKey> missing;        // requests discovered by the last step()
-    const DpResult *get(const DpKey &k);
+    size_t cursor = 0;
+    const DpResult *find(const DpKey &k);
+    const DpResult *get(const DpKey &k);           // find, or note the key as missing
+    const DpResult &at(const DpKey &k);            // must be present
+    void put(const DpKey &k, const DpResult &scalars, const uint32_t *cigar, uint32_t n_cigar);
+    CigSpan cigar(const DpResult &r) const { return CigSpan{pool.data() + r.cig_off, r.n_cigar}; }
+    void clear() { keys.clear(); vals.clear(); pool.clear(); missing.clear(); cursor = 0; }
+    void swap(DpCache &o) { keys.swap(o.keys); vals.swap(o.vals); pool.swap(o.pool); missing.swap(o.missing); std::swap(cursor, o.cursor); }
 };
 
 // The alignment of one (reference, query) pair as a resumable job.
@@ -117,7 +139,7 @@ struct AlignJob {
     DpCache cache;
     void start(const RefIndex *r, const char *q, int ql, const Opt &o);
     bool step();                       // true when finished; otherwise cache.missing is non-empty
-    void swap_storage(AlignJob &o) { regs.swap(o.regs); qseq.swap(o.qseq); a.swap(o.a); cache.done.swap(o.cache.done); cache.missing.swap(o.cache.missing); }
+    void swap_storage(AlignJob &o) { regs.swap(o.regs); qseq.swap(o.qseq); a.swap(o.a); cache.swap(o.cache); }
 };
 
 // ConsensusGraph::alignRead's conversion of reg[0] (src/ConsensusGraph.cpp:219-397)

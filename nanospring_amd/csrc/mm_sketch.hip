@@ -280,7 +280,7 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
     const uint32_t B = (uint32_t)bytes;
     // sequences through pinned memory, one H2D copy (padding bytes are never interpreted)
     NS_TRY(pinned_reserve(W.h_seqs, W.h_cap, bytes + 16));
-    par_for(n, [&](size_t i) { memcpy(W.h_seqs + soff[i], reqs[i].ptr, reqs[i].len); });
+    par_for("sketch.stage", n, [&](size_t i) { memcpy(W.h_seqs + soff[i], reqs[i].ptr, reqs[i].len); });
     DevBuf *u32bufs[] = {&W.vf, &W.mk, &W.vr, &W.linv, &W.npf, &W.pushf, &W.npr, &W.pr};
     for (DevBuf *b : u32bufs) NS_TRY(b->reserve(((size_t)B + 2) * 4));
     NS_TRY(W.seqs.reserve(bytes + 64));

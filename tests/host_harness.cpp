@@ -35,8 +35,7 @@ static void answer(AlignJob &J)
         DpResult r;
         r.max = ez.max; r.zdropped = ez.zdropped; r.max_q = ez.max_q; r.max_t = ez.max_t; r.mqe = ez.mqe; r.mqe_t = ez.mqe_t;
         r.mte = ez.mte; r.mte_q = ez.mte_q; r.score = ez.score; r.reach_end = ez.reach_end;
-        r.cigar.assign(cig.begin(), cig.begin() + (n > 0 ? n : 0));
-        J.cache.done[k] = r;
+        J.cache.put(k, r, cig.data(), (uint32_t)(n > 0 ? n : 0));
     }
 }
 
