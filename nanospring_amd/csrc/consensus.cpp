@@ -169,10 +169,10 @@ void Edge::add_read(Arena &a, read_t r)
 }
 
 Edge *Node::edge_to(Node *n) const { for (Edge *e : out) if (e->sink == n) return e; return nullptr; }
-Edge *Node::edge_to_side(char b) const { for (Edge *e : out) if (!e->sink->on_main && e->sink->base == b) return e; return nullptr; }
+Edge *Node::edge_to_side(char b) const { for (const OutRef &o : out) if (o.sink_base_is(b) && !o->sink->on_main) return o; return nullptr; }
 Edge *Node::best_out() const
 {
-    if (out.size() == 1) return out[0]->count ? out[0] : nullptr;
+    if (out.size() == 1) return out[0]->count ? out[0].get() : nullptr;
     Edge *best = nullptr; read_t c = 0;
     for (Edge *e : out) if (e->count > c) c = e->count, best = e;
     return best;
@@ -196,7 +196,7 @@ Edge *ContigGraph::create_edge(Node *s, Node *t, read_t r)
     Edge *e = edges_.make();
     e->source = s, e->sink = t, e->count = 1, e->reads.push_back(arena_, r);
     n_multi_in_side_ -= multi_in_side(t);
-    s->out.push_back(arena_, e), t->in.push_back(arena_, e);
+    s->out.push_back(arena_, OutRef(e, t->base)), t->in.push_back(arena_, e);
     n_multi_in_side_ += multi_in_side(t);
     ++n_edges_;
     return e;
@@ -206,7 +206,7 @@ Edge *ContigGraph::create_edge(Node *s, Node *t, const std::vector<read_t> &rs)
     Edge *e = edges_.make();
     e->source = s, e->sink = t, e->reads.assign(arena_, rs.data(), rs.size()), e->count = (read_t)rs.size();
     n_multi_in_side_ -= multi_in_side(t);
-    s->out.push_back(arena_, e), t->in.push_back(arena_, e);
+    s->out.push_back(arena_, OutRef(e, t->base)), t->in.push_back(arena_, e);
     n_multi_in_side_ += multi_in_side(t);
     ++n_edges_;
     return e;
@@ -744,45 +744,57 @@ void ContigGraph::walk_read(const GraphRead &r, read_t id, const ReadBases *src,
         while (cur) { visit(cur); const Edge *e = cur->edge_in_read(id); cur = e ? e->sink : nullptr; }
         return;
     }
-    const char *fw = src->bases;
     const size_t L = src->len;
-    auto base_at = [&](size_t i) -> char {
-        if (!r.rc) return fw[i];
-        const char c = fw[L - 1 - i];
-        return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
-    };
+    // the read as it lies on the graph (reverse-complemented reads once, into a per-thread buffer)
+    static thread_local std::string oriented;
+    const char *rb = src->bases;
+    if (r.rc) { reverse_complement(src->bases, L, oriented); rb = oriented.data(); }
     const size_t n_main = main_edges.size();
+    const char *const cons = main_path.data();           // cons[j] = base of main-path node j
     for (size_t i = 0; i < L;) {
+        // here `cur` carries base i and has not been visited
         visit(cur);
+        if (cur->on_main) {
+            // A read mostly follows the consensus, and while it does no node is looked at: j = index of the current main-path
+            // node (cum_weight), next_fork_[j] = first index >= j whose node has more than one way out or ends the path,
+            // side_mask_[j] = bases of the side sinks of node j, cons = the path's bases (all set by write_reads).
+            size_t j = cur->cum_weight;
+            for (;;) {
+                if (++i == L) return;
+                if (j < n_main && next_fork_[j] != j) {
+                    // single way out: it leads to the next main-path node, and so on up to the next fork
+                    const size_t j1 = j + 1, stop = next_fork_[j1];
+                    const size_t k = stop - j1 < L - i ? stop - j1 : L - i;
+                    if (k) { visit_run(k); i += k; if (i == L) return; }
+                    j = j1 + k;
+                    visit_run(1);                        // node j, right behind the run
+                    continue;
+                }
+                // a fork (or the path's end): when the consensus goes on with the read's next base and no side branch starts
+                // with that base, the read's edge is the path's edge (the only out-edge whose sink carries the base)
+                const char nb = rb[i];
+                if (j < n_main && cons[j + 1] == nb && !(side_mask_[j] & base_bit(nb))) { ++j; visit_run(1); continue; }
+                const Node *n = main_nodes_[j];
+                const auto &out = n->out;
+                if (out.size() == 1) cur = out[0]->sink;
+                else {
+                    const Edge *pick = nullptr;
+                    int cnt = 0;
+                    for (const OutRef &o : out) if (o.sink_base_is(nb)) { pick = o; ++cnt; }
+                    if (cnt != 1) pick = n->edge_in_read(id);
+                    cur = pick->sink;
+                }
+                break;
+            }
+            continue;
+        }
         if (++i == L) break;                             // i = bases consumed
         const auto &out = cur->out;
-        if (cur->on_main) {
-            // A read mostly follows the consensus (cum_weight = the node's main-path index, main_nodes_ = the path's nodes,
-            // next_fork_[j] = first index >= j whose node has more than one way out or ends the path; all set by write_reads).
-            // A main-path node with a single way out leads to the next main-path node, and so on up to the next fork: that
-            // stretch is accounted for without looking at its nodes.
-            const size_t j = cur->cum_weight;
-            if (out.size() == 1 && j < n_main) {
-                const size_t j1 = j + 1, stop = next_fork_[j1];
-                const size_t k = stop - j1 < L - i ? stop - j1 : L - i;
-                if (k) { visit_run(k); i += k; if (i == L) break; }
-                cur = main_nodes_[j1 + k];
-                __builtin_prefetch(main_nodes_[next_fork_[j1 + k + 1 <= n_main ? j1 + k + 1 : n_main]], 0, 1);
-                continue;
-            }
-        }
         if (out.size() == 1) { cur = out[0]->sink; continue; }
-        const char nb = base_at(i);
-        if (cur->on_main) {
-            // a fork on the main path: when the consensus goes on with the read's next base and no side branch starts with that
-            // base, the read's edge is the path's edge (the only out-edge whose sink carries the base); side_mask_ = bases of
-            // the side sinks, gathered once per contig
-            const size_t j = cur->cum_weight;
-            if (j < n_main && main_nodes_[j + 1]->base == nb && !(side_mask_[j] & base_bit(nb))) { cur = main_nodes_[j + 1]; continue; }
-        }
+        const char nb = rb[i];
         const Edge *pick = nullptr;
         int cnt = 0;
-        for (const Edge *e : out) if (e->sink->base == nb) { pick = e; ++cnt; }
+        for (const OutRef &o : out) if (o.sink_base_is(nb)) { pick = o; ++cnt; }
         if (cnt != 1) pick = cur->edge_in_read(id);
         cur = pick->sink;
     }
@@ -868,18 +880,32 @@ void ContigGraph::write_reads(StreamSet &o, const std::function<ReadBases(read_t
     const size_t n_main = main_edges.size();
     main_nodes_.resize(n_main + 1);
     main_nodes_[0] = main_edges.front()->source;
-    size_t i = 0;
-    for (Edge *e : main_edges) { e->sink->cum_weight = ++i; main_nodes_[i] = e->sink; }
+    for (size_t t = 0; t < n_main; ++t) {
+        // two dependent misses per position (edge, then its sink): keep both in flight ahead of the loop
+        if (t + 16 < n_main) __builtin_prefetch(main_edges[t + 16], 0, 1);
+        if (t + 8 < n_main) __builtin_prefetch(main_edges[t + 8]->sink, 1, 1);
+        Node *n = main_edges[t]->sink;
+        n->cum_weight = t + 1;
+        main_nodes_[t + 1] = n;
+    }
     next_fork_.resize(n_main + 1);
     next_fork_[n_main] = (uint32_t)n_main;
-    for (size_t j = n_main; j-- > 0;) next_fork_[j] = main_nodes_[j]->out.size() != 1 ? (uint32_t)j : next_fork_[j + 1];
+    for (size_t j = n_main; j-- > 0;) {
+        if (j >= 8) __builtin_prefetch(main_nodes_[j - 8], 0, 1);
+        next_fork_[j] = main_nodes_[j]->out.size() != 1 ? (uint32_t)j : next_fork_[j + 1];
+    }
     side_mask_.assign(n_main + 1, 0);
     for (size_t j = 0; j <= n_main; ++j) {
+        if (j + 8 <= n_main) {
+            const Node *a = main_nodes_[j + 8];
+            __builtin_prefetch(a, 0, 1);
+            if (j + 4 <= n_main) { const Node *b = main_nodes_[j + 4]; if (b->out.size() != 1) for (const Edge *e : b->out) __builtin_prefetch(e, 0, 1); }
+        }
         const Node *n = main_nodes_[j];
         if (n->out.size() == 1 && j < n_main) continue;
         const Edge *path_edge = j < n_main ? main_edges[j] : nullptr;
         uint8_t m = 0;
-        for (const Edge *e : n->out) if (e != path_edge) m |= base_bit(e->sink->base);
+        for (const OutRef &o : n->out) if (o.get() != path_edge) m |= base_bit(o.sink_base());
         side_mask_[j] = m;
     }
     g_emit_ns[0] += emit_now() - e0;

@@ -93,11 +93,27 @@ struct SmallVec {
 };
 
 struct Edge;
+// An out-edge together with the base of the node it leads to, kept in the low bits of the pointer (edges are 64-byte
+// aligned): choosing among a node's ways out by base -- the common question of update_graph and of the emission walk --
+// then needs neither the edge's nor the sink's cache line.  Code 0-3 = A C G T, 4 = some other byte (look at the node).
+struct OutRef {
+    uintptr_t v;
+    OutRef() = default;
+    OutRef(Edge *e, char sink_base) : v(reinterpret_cast<uintptr_t>(e) | code_of(sink_base)) {}
+    static unsigned code_of(char b) { return b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 4u; }
+    Edge *get() const { return reinterpret_cast<Edge *>(v & ~static_cast<uintptr_t>(63)); }
+    operator Edge *() const { return get(); }
+    Edge *operator->() const { return get(); }
+    unsigned code() const { return (unsigned)(v & 7); }
+    inline bool sink_base_is(char b) const;       // == (get()->sink->base == b)
+    inline char sink_base() const;
+};
 struct Node {                                 // 64 bytes, slab-aligned: one cache line
     char base;
     bool on_main = false;
     uint32_t reserved_ = 0;
-    SmallVec<Edge *, 2> out, in;
+    SmallVec<OutRef, 2> out;
+    SmallVec<Edge *, 2> in;
     size_t cum_weight = 0;
     explicit Node(char b) : base(b) {}
     Edge *edge_to(Node *n) const;             // Node::getEdgeTo          (:33-43)
@@ -113,6 +129,8 @@ struct Edge {                                 // 64 bytes
     void add_read(Arena &a, read_t r);        // Edge::addRead            (:24-28)
 };
 static_assert(sizeof(Node) == 64 && sizeof(Edge) == 64, "graph objects are one cache line each");
+inline bool OutRef::sink_base_is(char b) const { const unsigned c = code(); return c < 4 ? "ACGT"[c] == b : get()->sink->base == b; }
+inline char OutRef::sink_base() const { const unsigned c = code(); return c < 4 ? "ACGT"[c] : get()->sink->base; }
 
 template <class T>
 class Pool {                                   // slab allocator with a free list; everything dies with the graph
