@@ -184,6 +184,7 @@ def main():
                        "stages": ["sketch", "bucket-tables", "overlap (window queries)", "align (batched alignRead, DP on GPU)",
                                   "consensus graph + edit emission (host)"],
                        "bases_per_gpu": n_bases, "builders": st["n_builders"], "host_threads": a["host_threads"],
+                       "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 1),
                        "lossless_roundtrip_bad_reads": bad, "stream_bytes_per_base": round(stream_bytes / n_bases, 4),
                        "contigs": st["n_contigs"], "lone_reads": st["n_lone"], "reads_aligned": st["count_aligner"], "align_calls": st["n_align_calls"],
                        "rounds": st["n_rounds"],

@@ -209,12 +209,12 @@ int nsgpu_consensus_run(nsgpu_ctx *ctx, uint32_t n_builders, uint32_t n_threads_
  * (thread ignored).  *data_out is library-allocated (nsgpu_free). */
 int nsgpu_consensus_stream(nsgpu_ctx *ctx, uint32_t thread, uint32_t which, uint8_t **data_out, size_t *len_out);
 /* The same engine phase by phase, for multi-GPU jobs (one process per GPU, every rank holds all reads and the whole
- * bucket index; rank r owns the builders with gid % world == r).  Builders form three pipeline groups
- * (group = (gid >> 3) % 3, a function of the global id only); in slot s = 0, 1, 2, ... with h = s % 3, b = (s + 1) % 3:
+ * bucket index; rank r owns the builders with gid % world == r).  Builders form G = nsgpu_cons_groups() pipeline groups
+ * (group = (gid >> 3) % G, a function of the global id only; G = 4); in slot s = 0, 1, 2, ... with h = s % G, b = (s + 1) % G:
  *   slot(s)                         concurrently: host phase of group h (graph updates up to the next window / alignment
- *                                   request), part 1 of the GPU batches of group (s + 2) % 3 (window lookups, sketches,
+ *                                   request), part 1 of the GPU batches of group (s + G - 1) % G (window lookups, sketches,
  *                                   seeds / chains, launch of the alignment DP), part 2 of group b (DP results,
- *                                   alignment skeletons, edit scripts)
+ *                                   alignment skeletons, edit scripts); the DP kernels of group (s + 2) % G stay in flight
  *   claim_requests(b) -> [all-gather] -> claim_resolve
  *   { seed_requests(h) -> [all-gather] -> seed_resolve -> advance(only_fresh = 1, h) } until nothing starts
  * until claim_resolve / seed_resolve report that every builder is done.
@@ -223,6 +223,7 @@ int nsgpu_consensus_stream(nsgpu_ctx *ctx, uint32_t thread, uint32_t which, uint
  * nsgpu_consensus_run is exactly this loop with world = 1.  group = -1 addresses all builders.  Lists returned
  * through T** are library-allocated. */
 int nsgpu_cons_begin(nsgpu_ctx *ctx, uint32_t n_builders_total, uint32_t rank, uint32_t world);
+uint32_t nsgpu_cons_groups(void);
 int nsgpu_cons_slot(nsgpu_ctx *ctx, uint32_t slot);
 int nsgpu_cons_advance(nsgpu_ctx *ctx, int only_fresh, int group);
 int nsgpu_cons_seed_requests(nsgpu_ctx *ctx, int group, uint32_t **gids_out, uint32_t **cursors_out, uint32_t *n_out);

@@ -59,6 +59,7 @@ SIGNATURES = {
     "nsgpu_get_align_stats": (C.c_int, [_vp, _vp]),
     "nsgpu_reset_align_stats": (C.c_int, [_vp]),
     "nsgpu_cons_begin": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "nsgpu_cons_groups": (C.c_uint32, []),
     "nsgpu_cons_slot": (C.c_int, [_vp, C.c_uint32]),
     "nsgpu_cons_advance": (C.c_int, [_vp, C.c_int, C.c_int]),
     "nsgpu_cons_seed_requests": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp), _u32p]),

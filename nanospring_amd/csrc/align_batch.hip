@@ -391,6 +391,10 @@ int align_begin(nsgpu_ctx *c, AlignBatch &B, int ws_index)
     return NSGPU_OK;
 }
 
+// debug breakdown of part 2 (single batch thread at a time per group; plain doubles are good enough for a debug print):
+// [0] wait for the launch in flight, [1] later rounds in total, [2] their DP launches, [3] result conversion, [4] #later rounds
+double g_finish_ms[5];
+
 // Part 2: the DP results, the execution of the alignment skeleton on them (further DP rounds, should a plan have missed a
 // problem, run synchronously), and ConsensusGraph::alignRead's conversion of every pair.
 int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs)
@@ -400,13 +404,16 @@ int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs)
     outs.assign(n_pairs, AlnOut());
     if (n_pairs == 0) return NSGPU_OK;
     const KswParams kp = batch_ksw_params(batch_opt(c));
+    const double f0 = now_ms();
     if (B.in_flight) {
         const double a0 = now_ms();
         NS_TRY(ksw_batch_collect(c, B.tasks, B.res, B.cig, B.coff, B.ws_index));
         B.dp_ms += now_ms() - a0;
+        g_finish_ms[0] += now_ms() - a0;
         B.in_flight = false;
         batch_deliver(B);
     }
+    const double f1 = now_ms();
     for (int round = 0; !B.live.empty(); ++round) {
         NS_CHECK(round < 64, NSGPU_ERR_ARG, "align: no convergence after 64 DP rounds (internal error)");
         NS_TRY(batch_prepare_round(c, B));
@@ -414,11 +421,16 @@ int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs)
         const double a0 = now_ms();
         NS_TRY(ksw_run_batch(c, B.tasks, c->kws[B.ws_index].h_pool, B.nb, kp, B.res, B.cig, B.coff, B.ws_index));
         B.dp_ms += now_ms() - a0;
+        g_finish_ms[2] += now_ms() - a0;
+        g_finish_ms[4] += 1;
         batch_deliver(B);
     }
     const double b0 = now_ms();
+    g_finish_ms[1] += b0 - f1;
     parallel_for("align.result", n_pairs, [&](size_t i) { align_read_result(B.jobs[i], B.reqs[i].ref, B.reqs[i].ref_len, outs[i]); });
     B.host_ms += now_ms() - b0;
+    g_finish_ms[3] += now_ms() - b0;
+    (void)f0;
     {
         std::lock_guard<std::mutex> lk(c->stat_m);
         c->aln_host_ms += B.host_ms, c->aln_dp_ms += B.dp_ms, c->aln_dp_tasks += B.dp_tasks, c->aln_rounds += B.rounds, c->aln_pairs += n_pairs;

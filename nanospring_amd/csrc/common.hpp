@@ -127,7 +127,7 @@ struct nsgpu_ctx {
         hipStream_t stream = nullptr;                                // workspace 0 runs on the context's stream
         hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
         hipEvent_t side_done[3] = {nullptr, nullptr, nullptr}, side_fork = nullptr, t_a = nullptr, t_b = nullptr;
-    } kws[3];                                                       // 0: the context's stream (direct API calls); 1, 2: own streams (contig engine, alternating slots)
+    } kws[4];                                                       // 0: the context's stream (direct API calls); 1-3: own streams (contig engine, one per batch in flight)
     // batched minimizer sketches (mm_sketch.hip): device buffers + pinned staging both ways
     struct SketchWs {
         nsgpu::DevBuf seqs, soff, len, sob, vf, mk, vr, linv, npf, pushf, npr, pr, V, hk, PX, PY, PRUN, PSEQ, rm, nout, oscan, off, out, scan_ws;

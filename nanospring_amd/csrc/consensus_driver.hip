@@ -14,9 +14,9 @@
 // Any such schedule is one of the interleavings the reference's numThr-thread run can produce
 // (no try_lock ever fails); with ONE builder it is the reference's deterministic -t 1 schedule.
 // The result is deterministic for a given (reads, salts, n_builders).
-// The builders form three groups that go through these steps a third of a period apart (host phase |
-// batches part 1 with the DP launch | batches part 2), so that host cores and GPU work at the same
-// time: see run_consensus / engine_slot.
+// The builders form four groups that go through these steps a quarter of a period apart (host phase |
+// batches part 1 with the DP launch | DP in flight | batches part 2), so that host cores and GPU work
+// at the same time: see run_consensus / engine_slot.
 #include "common.hpp"
 #include "consensus.hpp"
 #include "host_util.hpp"
@@ -27,6 +27,7 @@
 
 namespace nsgpu {
 namespace mm2 { extern std::atomic<uint64_t> g_step_ns[6]; }
+extern double g_finish_ms[5];
 namespace cons { extern std::atomic<uint64_t> g_emit_ns[4]; }
 
 using cons::read_t;
@@ -34,7 +35,14 @@ using cons::read_t;
 // A finished contig waiting for its edit emission (consensus + one edit script per read into the seven streams).  The
 // emission touches nothing but the contig's own graph, so it is taken off the builder's critical path: the builder moves
 // on to its next contig at once and the emission runs as a task of its own in the next host phase.
-constexpr int kGroups = 3;                    // pipeline groups: host phase | batches part 1 | batches part 2 (see run_consensus)
+constexpr int kMaxGroups = 4;
+// Pipeline groups (see run_consensus): host phase | batches part 1 | [alignment DP in flight] | batches part 2.  With 3 groups
+// part 2 follows part 1 directly and waits for whatever the DP kernels have not finished (NSGPU_GROUPS=3).
+static int n_groups()
+{
+    static const int g = [] { const char *e = getenv("NSGPU_GROUPS"); const int v = e ? atoi(e) : 4; return v == 3 ? 3 : 4; }();
+    return g;
+}
 
 struct FinishedContig {
     std::unique_ptr<cons::ContigGraph> g;     // null once emitted
@@ -292,9 +300,9 @@ struct Engine {
     std::vector<SketchReq> sk;
     std::vector<uint32_t> sk_ref;
     std::vector<uint64_t> mz_off;
-    AlignBatch ab[kGroups];                        // alignment batch of each group, DP kernels in flight between part 1 and part 2
+    AlignBatch ab[kMaxGroups];                        // alignment batch of each group, DP kernels in flight between part 1 and part 2
     std::vector<uint32_t> fwho;                    // builders of the window-query batch
-    std::vector<uint32_t> awho[kGroups];           // builders of that batch
+    std::vector<uint32_t> awho[kMaxGroups];           // builders of that batch
     std::vector<mm2::AlnOut> outs;
     Builder *local(uint32_t gid) { return gid % world == rank ? &D.B[gid / world] : nullptr; }
 };
@@ -326,7 +334,7 @@ static int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, 
     E->rank = rank, E->world = world, E->n_total = n_builders_total;
     const uint32_t n_local = n_builders_total > rank ? (n_builders_total - rank + world - 1) / world : 0;
     D.B.resize(n_local);
-    for (uint32_t i = 0; i < n_local; ++i) D.B[i].id = i, D.B[i].gid = rank + i * world, D.B[i].group = (int)((D.B[i].gid >> 3) % kGroups);
+    for (uint32_t i = 0; i < n_local; ++i) D.B[i].id = i, D.B[i].gid = rank + i * world, D.B[i].group = (int)((D.B[i].gid >> 3) % (uint32_t)n_groups());
     memset(&c->cons_stats, 0, sizeof(c->cons_stats));
     c->cons_stats.n_builders = n_builders_total;
     c->have_cons = false;
@@ -614,16 +622,18 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
     struct rusage ru0;
     getrusage(RUSAGE_SELF, &ru0);
     const double w_begin = now_ms() - E->t0;
-    // Three builder groups, a third of a period apart.  In slot s group h = s % 3 runs its host phase (graph updates up
-    // to the next window / alignment request), group (s + 2) % 3 -- which did that in the slot before -- part 1 of its
-    // GPU batches (window lookups, sketches, seeds / chains, launch of the alignment DP) and group (s + 1) % 3 part 2 (DP
-    // results, alignment skeletons, edit scripts): the cores are not idle during kernels, nor the GPU during graph work,
-    // nor either during the other's bookkeeping.  At the slot boundary the part-2 group's read claims and then the host
-    // group's seed requests are resolved, in global builder order: the schedule is a function of the data only.
+    // G builder groups (4), a G-th of a period apart.  In slot s group h = s % G runs its host phase (graph updates up to
+    // the next window / alignment request), group (s + G - 1) % G -- which did that in the slot before -- part 1 of its GPU
+    // batches (window lookups, sketches, seeds / chains, launch of the alignment DP), the DP kernels of group (s + 2) % G
+    // stay in flight for this slot (their longest problems take about as long as a slot), and group (s + 1) % G runs part 2
+    // (DP results, alignment skeletons, edit scripts): the cores are not idle during kernels, nor the GPU during graph
+    // work, nor either during the other's bookkeeping.  At the slot boundary the part-2 group's read claims and then the
+    // host group's seed requests are resolved, in global builder order: the schedule is a function of the data only.
     for (uint32_t slot = 0;; ++slot) {
-        const int h = (int)(slot % kGroups), a = (int)((slot + 2) % kGroups), b = (int)((slot + 1) % kGroups);
+        const int G = n_groups();
+        const int h = (int)(slot % G), a = (int)((slot + G - 1) % G), b = (int)((slot + 1) % G);
         double t = now_ms();
-        NS_TRY(engine_slot(c, h, a, b, 1 + (int)(slot & 1)));
+        NS_TRY(engine_slot(c, h, a, b, 1 + (int)(slot % 3)));
         w_slot += now_ms() - t;
         t = now_ms();
         engine_claim_requests(c, ga, gb, b);
@@ -659,6 +669,9 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
         fprintf(stderr, "[cons] serial CPU ms of the role threads (outside pool loops): host %.0f, batches part 1 %.0f, part 2 %.0f\n", E->role_serial_ns[0] / 1e6,
                 E->role_serial_ns[1] / 1e6, E->role_serial_ns[2] / 1e6);
         pool_prof_print();
+        fprintf(stderr, "[cons] part 2 wall-ms: wait for the DP in flight %.0f, later rounds %.0f (their DP %.0f, %d rounds), results %.0f\n", g_finish_ms[0], g_finish_ms[1],
+                g_finish_ms[2], (int)g_finish_ms[4], g_finish_ms[3]);
+        for (double &x : g_finish_ms) x = 0;
         const double sys_s = (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
         fprintf(stderr, "[cons] process CPU time over the stage: %.1f s (%.1f s of it in the kernel; %ld minor faults) = %.1f cores busy on average\n", cpu_s, sys_s,
                 ru1.ru_minflt - ru0.ru_minflt, cpu_s / ((now_ms() - E->t0) * 1e-3));
@@ -699,11 +712,14 @@ int nsgpu_cons_advance(nsgpu_ctx *c, int only_fresh, int group)
     return NSGPU_OK;
 }
 
+uint32_t nsgpu_cons_groups(void) { return (uint32_t)n_groups(); }
+
 int nsgpu_cons_slot(nsgpu_ctx *c, uint32_t slot)
 {
     NS_CHECK(c && c->cons_engine, NSGPU_ERR_ARG, "nsgpu_cons_slot: call nsgpu_cons_begin first");
     NS_HIP(hipSetDevice(c->prm.device));
-    return engine_slot(c, (int)(slot % kGroups), (int)((slot + 2) % kGroups), (int)((slot + 1) % kGroups), 1 + (int)(slot & 1));
+    const uint32_t G = (uint32_t)n_groups();
+    return engine_slot(c, (int)(slot % G), (int)((slot + G - 1) % G), (int)((slot + 1) % G), 1 + (int)(slot % 3));
 }
 
 int nsgpu_cons_seed_requests(nsgpu_ctx *c, int group, uint32_t **gids_out, uint32_t **cursors_out, uint32_t *n_out)

@@ -707,7 +707,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
                      std::vector<KswResult> &results, std::vector<uint32_t> &cigars, std::vector<uint64_t> &cig_off, int ws_index)
 {
     const size_t n = tasks.size();
-    NS_CHECK(ws_index >= 0 && ws_index <= 2, NSGPU_ERR_ARG, "ksw: workspace index must be 0, 1 or 2");
+    NS_CHECK(ws_index >= 0 && ws_index <= 3, NSGPU_ERR_ARG, "ksw: workspace index must be 0..3");
     nsgpu_ctx::KswWs &W = c->kws[ws_index];
     // workspace 0 works on the context's stream; workspace 1 owns one (the second half batch of the contig engine)
     if (ws_index >= 1 && !W.stream) NS_HIP(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));

@@ -244,8 +244,9 @@ def consensus_exchange(gpu, n_builders_total, dist, n_threads_out=1):
     # the slot schedule of include/nsgpu.h (nsgpu_consensus_run runs the same one with world = 1)
     n_coll = 0
     slot = 0
+    n_groups = int(lib.nsgpu_cons_groups())
     while True:
-        h, b = slot % 3, (slot + 1) % 3
+        h, b = slot % n_groups, (slot + 1) % n_groups
         F.check(lib, lib.nsgpu_cons_slot(ctx, slot))
         ga, gb = gather(*take(lib.nsgpu_cons_claim_requests, b))
         n_coll += 1
