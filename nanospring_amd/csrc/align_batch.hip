@@ -18,10 +18,78 @@
 #include <mutex>
 #include <condition_variable>
 #include "host_util.hpp"
+#include <sched.h>
+#include <pthread.h>
+#include <cctype>
 #include <memory>
 #include <deque>
 
 namespace nsgpu {
+
+// The host side of the contig stage chases pointers through graphs it allocated itself: on a two-socket box half of those
+// accesses are remote unless the threads stay on the NUMA node the GPU hangs off (first-touch then puts the graphs there
+// too).  Measured on the 2 x 64-core host of an MI355X box: +5 % and a steadier step time; binding tighter (2 or 4 CCDs)
+// loses 10-25 % because the threads then share cores.  NSGPU_NO_NUMA_BIND=1 leaves the threads alone.
+namespace {
+std::mutex g_bind_m;
+cpu_set_t g_bind_set;
+bool g_bind_on = false;
+
+bool parse_cpulist(const char *s, cpu_set_t &set)
+{
+    CPU_ZERO(&set);
+    bool any = false;
+    while (*s) {
+        char *e;
+        long a = strtol(s, &e, 10), b = a;
+        if (e == s) break;
+        if (*e == '-') { s = e + 1; b = strtol(s, &e, 10); if (e == s) break; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, &set); any = true; }
+        s = *e == ',' ? e + 1 : e;
+        if (*s == '\n') break;
+    }
+    return any;
+}
+}  // namespace
+
+void pool_bind_this_thread()
+{
+    std::lock_guard<std::mutex> lk(g_bind_m);
+    if (g_bind_on) (void)pthread_setaffinity_np(pthread_self(), sizeof(g_bind_set), &g_bind_set);
+}
+
+void pool_rebind_workers();
+
+// called once per context with the GPU's PCI address ("0000:xx:yy.z")
+void pool_bind_to_gpu_node(const char *pci_bus_id)
+{
+    static const bool off = getenv("NSGPU_NO_NUMA_BIND") != nullptr;
+    if (off || !pci_bus_id) return;
+    char path[256], buf[4096];
+    std::string id(pci_bus_id);
+    for (char &c : id) c = (char)tolower((unsigned char)c);
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", id.c_str());
+    int node = -1;
+    if (FILE *f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+    if (node < 0) return;
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    const bool got = fgets(buf, sizeof(buf), f) != nullptr;
+    fclose(f);
+    cpu_set_t node_set, cur, both;
+    if (!got || !parse_cpulist(buf, node_set)) return;
+    if (sched_getaffinity(0, sizeof(cur), &cur) != 0) return;
+    CPU_AND(&both, &node_set, &cur);                      // never leave the CPUs the process was given
+    if (CPU_COUNT(&both) < (int)host_threads()) return;   // too few to be worth it (a tight cpuset is somebody's decision already)
+    {
+        std::lock_guard<std::mutex> lk(g_bind_m);
+        if (g_bind_on) return;                            // one binding per process: the first context's GPU
+        g_bind_set = both, g_bind_on = true;
+    }
+    if (getenv("NSGPU_CONS_DEBUG")) fprintf(stderr, "[pool] host threads bound to NUMA node %d of GPU %s: %d CPUs\n", node, id.c_str(), CPU_COUNT(&both));
+    pool_rebind_workers();
+}
 
 unsigned host_threads()
 {
@@ -171,6 +239,11 @@ public:
         std::lock_guard<std::mutex> lk(m_);
         active_.erase(std::find(active_.begin(), active_.end(), job));
     }
+    void rebind()
+    {
+        std::lock_guard<std::mutex> lk(g_bind_m);
+        if (g_bind_on) for (auto &t : th_) (void)pthread_setaffinity_np(t.native_handle(), sizeof(g_bind_set), &g_bind_set);
+    }
     // Background work of the lowest priority: run by workers that find nothing to do in any parallel loop, never waited for
     // except by drain().
     void post(std::function<void()> fn)
@@ -187,6 +260,7 @@ public:
 private:
     void worker(unsigned me)
     {
+        pool_bind_this_thread();
         uint64_t seen = 0;
         std::vector<std::shared_ptr<Job>> snap;
         for (;;) {
@@ -239,6 +313,7 @@ private:
 }  // namespace
 
 static HostPool &the_pool() { static HostPool pool(host_threads()); return pool; }
+void pool_rebind_workers() { if (host_threads() > 1) the_pool().rebind(); }
 
 void parallel_for_impl(size_t n, const std::function<void(size_t)> &fn)
 {

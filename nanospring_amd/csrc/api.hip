@@ -2,6 +2,7 @@
 // HBM read store and the MinHash stages.  No CPU fallback exists: without a
 // gfx950 device nsgpu_create fails with NSGPU_ERR_NODEV.
 #include "common.hpp"
+#include "host_util.hpp"
 #include <cstdarg>
 #include <chrono>
 #include <time.h>
@@ -125,6 +126,10 @@ int nsgpu_create(const nsgpu_params *p, nsgpu_ctx **ctx_out)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
         set_error("device %d is %s; libnsgpu is built for gfx950 only", p->device, prop.gcnArchName);
         return NSGPU_ERR_NODEV;
+    }
+    {
+        char bus[64] = "";
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), p->device) == hipSuccess) pool_bind_to_gpu_node(bus);
     }
     nsgpu_ctx *c = new nsgpu_ctx();
     c->prm = *p;

@@ -23,6 +23,8 @@
 #include <memory>
 #include <atomic>
 #include <thread>
+#include <sched.h>
+#include <pthread.h>
 #include <sys/resource.h>
 
 namespace nsgpu {
@@ -588,12 +590,18 @@ static int engine_slot(nsgpu_ctx *c, int host_group, int begin_group, int finish
         if (begin_group != -2) NS_TRY(engine_batches_begin(c, begin_group, ws_index));
         return NSGPU_OK;
     }
+    // the calling thread works in the host phase's loops: it joins the pool's threads on the GPU's NUMA node for the slot
+    struct Rebind {
+        cpu_set_t old; bool ok;
+        Rebind() { ok = pthread_getaffinity_np(pthread_self(), sizeof(old), &old) == 0; pool_bind_this_thread(); }
+        ~Rebind() { if (ok) (void)pthread_setaffinity_np(pthread_self(), sizeof(old), &old); }
+    } rebind;
     int rc1 = NSGPU_OK, rc2 = NSGPU_OK;
     std::thread t1, t2;
     double d1 = 0, d2 = 0;
     uint64_t ser[3] = {0, 0, 0};          // CPU time of the three role threads outside the pool's loops (debug breakdown)
-    if (begin_group != -2) t1 = std::thread([&] { const double x = now_ms(); const uint64_t c0 = pool_thread_cpu_ns(); rc1 = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches_begin(c, begin_group, ws_index) : NSGPU_ERR_HIP; d1 = now_ms() - x; ser[1] = pool_thread_cpu_ns() - c0 - pool_thread_work_ns(); });
-    if (finish_group != -2) t2 = std::thread([&] { const double x = now_ms(); const uint64_t c0 = pool_thread_cpu_ns(); rc2 = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches_finish(c, finish_group) : NSGPU_ERR_HIP; d2 = now_ms() - x; ser[2] = pool_thread_cpu_ns() - c0 - pool_thread_work_ns(); });
+    if (begin_group != -2) t1 = std::thread([&] { pool_bind_this_thread(); const double x = now_ms(); const uint64_t c0 = pool_thread_cpu_ns(); rc1 = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches_begin(c, begin_group, ws_index) : NSGPU_ERR_HIP; d1 = now_ms() - x; ser[1] = pool_thread_cpu_ns() - c0 - pool_thread_work_ns(); });
+    if (finish_group != -2) t2 = std::thread([&] { pool_bind_this_thread(); const double x = now_ms(); const uint64_t c0 = pool_thread_cpu_ns(); rc2 = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches_finish(c, finish_group) : NSGPU_ERR_HIP; d2 = now_ms() - x; ser[2] = pool_thread_cpu_ns() - c0 - pool_thread_work_ns(); });
     const double h0 = now_ms();
     const uint64_t hc0 = pool_thread_cpu_ns(), hw0 = pool_thread_work_ns();
     if (host_group != -2) engine_advance(c, false, host_group);

@@ -18,6 +18,8 @@ template <class F> inline void par_for(size_t n, F fn) { parallel_for_impl(n, st
 void parallel_for_pinned_impl(size_t n, const std::function<void(size_t)> &fn);
 template <class F> inline void par_for_pinned(size_t n, F fn) { parallel_for_pinned_impl(n, std::function<void(size_t)>(fn)); }
 // background tasks of the lowest priority (run when no parallel loop has work) and the wait for all of them
+void pool_bind_to_gpu_node(const char *pci_bus_id);   // pool threads (and pool_bind_this_thread callers) stay on the GPU's NUMA node
+void pool_bind_this_thread();
 void pool_post(std::function<void()> fn);
 // debug accounting (NSGPU_CONS_DEBUG): loops submitted by this thread are booked under `name` until restored
 int pool_tag(const char *name);
