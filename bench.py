@@ -192,7 +192,7 @@ def main():
                                              "contig_stage_total": round(st["total_ms"], 1), "window_queries": round(st["filter_ms"], 1),
                                              "consensus_index": round(st["index_ms"], 1), "align_total": round(st["align_ms"], 1),
                                              "align_dp_kernel_wall": round(a["dp_kernel_ms"] / steps, 1), "align_dp_kernel_sum": round(a["dp_kernel_sum_ms"] / steps, 1), "graph_host_wall": round(st["graph_ms"], 1),
-                                             "note": "contig-stage parts overlap (three builder groups: host phase | batches part 1 | batches part 2), they do not add up to the total"},
+                                             "note": "contig-stage parts overlap (four builder groups: host phase | batches part 1 | DP in flight | batches part 2), they do not add up to the total"},
                        "parallelism": (f"x{world}: reads sharded by id, replicated by all-gather; per step all-gather of sketch rows + "
                                        f"{st.get('n_collectives', 0)} small all-gathers of claim lists (global builder order)") if exchange
                        else f"reads sharded by id x{world}, no collective"},

@@ -725,6 +725,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     std::vector<uint32_t> wg[3];
     static const int kWgThreads[3] = {0, 256, 256}, kWgMaxPos[3] = {0, 5, 8};
     static const bool no_wg = getenv("NSGPU_KSW_NO_WG") != nullptr;      // debugging aid: fallback kernels only
+    static const int wg_min_rows = [] { const char *e = getenv("NSGPU_KSW_WG_MIN_ROWS"); return e ? atoi(e) : 0; }();   // experiment knob
     size_t p_total = 0, cig_total = 0, hbm_stride = 0;
     for (size_t i = 0; i < n; ++i) {
         KswTask &t = tasks[i];
@@ -741,7 +742,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         const size_t need = ksw_lds_bytes(t.qlen, t.tlen, t.flag);
         int cls = need <= kClass[0] ? 0 : need <= kClass[1] ? 1 : need <= kClass[2] ? 2 : 3;
         if (cls == 3) { const size_t hn = ksw_lds_bytes(t.qlen, t.tlen, 0); if (hn > hbm_stride) hbm_stride = hn; }
-        if (cls >= 1 && cls < 3 && !no_wg && ksw_max_width(t.qlen, t.tlen, t.w) <= kWgThreads[cls] * kWgMaxPos[cls]) wg[cls].push_back((uint32_t)i);
+        if (cls >= 1 && cls < 3 && !no_wg && t.qlen + t.tlen >= wg_min_rows && ksw_max_width(t.qlen, t.tlen, t.w) <= kWgThreads[cls] * kWgMaxPos[cls]) wg[cls].push_back((uint32_t)i);
         else order[cls].push_back((uint32_t)i);
     }
     cig_off[n] = cig_total;
