@@ -215,8 +215,8 @@ int nsgpu_consensus_stream(nsgpu_ctx *ctx, uint32_t thread, uint32_t which, uint
  *                                   request), part 1 of the GPU batches of group (s + G - 1) % G (window lookups, sketches,
  *                                   seeds / chains, launch of the alignment DP), part 2 of group b (DP results,
  *                                   alignment skeletons, edit scripts); the DP kernels of group (s + 2) % G stay in flight
- *   claim_requests(b) -> [all-gather] -> claim_resolve
- *   { seed_requests(h) -> [all-gather] -> seed_resolve -> advance(only_fresh = 1, h) } until nothing starts
+ *   claim_requests(b), seed_requests(h) -> [ONE all-gather of both lists] -> claim_resolve, then seed_resolve,
+ *                                   then advance(only_fresh = 1, h) if a contig started
  * until claim_resolve / seed_resolve report that every builder is done.
  * The *_resolve calls take the request lists of ALL ranks (any order) and apply them to a replicated claim table in
  * global builder order, so every rank stays in step and the result does not depend on the number of ranks.

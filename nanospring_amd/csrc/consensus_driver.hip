@@ -648,12 +648,10 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
         engine_claim_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size());
         w_claim += now_ms() - t;
         t = now_ms();
-        for (;;) {
-            engine_seed_requests(c, ga, gb, h);
-            if (ga.empty()) break;
-            if (engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) == 0) break;
-            engine_advance(c, true, h);
-        }
+        // one round of seeds per slot: a fresh contig that ends at once (nothing to look up) asks again at its group's next
+        // boundary -- a multi-GPU driver then needs one collective per slot for both request lists
+        engine_seed_requests(c, ga, gb, h);
+        if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) engine_advance(c, true, h);
         w_seed += now_ms() - t;
         if (E->n_done_global >= E->n_total) break;
     }

@@ -139,34 +139,43 @@ def all_gather_u32_lists(a, b, dist):
 
 
 class U32ListGatherer:
-    """all_gather_u32_lists with a known bound on the list length: one collective per call (no size exchange) on buffers
-    allocated once -- the claim / seed lists of the contig engine are exchanged twice per pipeline slot."""
+    """all_gather_u32_lists for `n_lists` (a, b) list pairs at once with a known bound on the list length: ONE collective
+    per call (no size exchange) on buffers allocated once -- the claim and seed lists of the contig engine are exchanged
+    together, once per pipeline slot."""
 
-    def __init__(self, cap, dist):
+    def __init__(self, cap, dist, n_lists=1):
         torch = _torch()
-        self.dist, self.cap, self.world = dist, int(cap), dist.get_world_size()
+        self.dist, self.cap, self.world, self.n_lists = dist, int(cap), dist.get_world_size(), int(n_lists)
         dev = _dev(dist)
-        self.words = 1 + 2 * self.cap
+        self.words = self.n_lists * (1 + 2 * self.cap)
         self.mine = torch.zeros(self.words, dtype=torch.int32, device=dev)
         self.all = torch.zeros(self.words * self.world, dtype=torch.int32, device=dev)
         self.stage = np.zeros(self.words, dtype=np.uint32)
 
-    def __call__(self, a, b):
-        a = np.asarray(a, dtype=np.uint32)
-        b = np.asarray(b, dtype=np.uint32)
-        n = a.size                                   # (a world of one still goes through the collective: the RCCL test relies on it)
-        assert n == b.size and n <= self.cap, (n, self.cap)
+    def __call__(self, *lists):
+        """lists = a0, b0, a1, b1, ...; returns the concatenation over ranks of every list, in the same order."""
+        assert len(lists) == 2 * self.n_lists
         torch = _torch()
         st = self.stage
-        st[0] = n
-        st[1:1 + n] = a
-        st[1 + self.cap:1 + self.cap + n] = b
+        blk = 1 + 2 * self.cap
+        for i in range(self.n_lists):
+            a = np.asarray(lists[2 * i], dtype=np.uint32)
+            b = np.asarray(lists[2 * i + 1], dtype=np.uint32)
+            n = a.size                               # (a world of one still goes through the collective: the RCCL test relies on it)
+            assert n == b.size and n <= self.cap, (n, self.cap)
+            o = i * blk
+            st[o] = n
+            st[o + 1:o + 1 + n] = a
+            st[o + 1 + self.cap:o + 1 + self.cap + n] = b
         self.mine.copy_(torch.from_numpy(st.view(np.int32)))
         self.dist.all_gather_into_tensor(self.all, self.mine)
         v = self.all.cpu().numpy().view(np.uint32).reshape(self.world, self.words)
-        aa = [v[r, 1:1 + int(v[r, 0])] for r in range(self.world)]
-        bb = [v[r, 1 + self.cap:1 + self.cap + int(v[r, 0])] for r in range(self.world)]
-        return np.concatenate(aa), np.concatenate(bb)
+        out = []
+        for i in range(self.n_lists):
+            o = i * blk
+            out.append(np.concatenate([v[r, o + 1:o + 1 + int(v[r, o])] for r in range(self.world)]))
+            out.append(np.concatenate([v[r, o + 1 + self.cap:o + 1 + self.cap + int(v[r, o])] for r in range(self.world)]))
+        return tuple(out)
 
 
 def replicate_reads(bases, off, dist):
@@ -239,30 +248,24 @@ def consensus_exchange(gpu, n_builders_total, dist, n_threads_out=1):
         return a.ctypes.data_as(C.c_void_p) if a.size else None
 
     # a rank never has more requests than local builders
-    gather = U32ListGatherer((n_builders_total + world - 1) // world + 1, dist)
+    gather = U32ListGatherer((n_builders_total + world - 1) // world + 1, dist, n_lists=2)
 
-    # the slot schedule of include/nsgpu.h (nsgpu_consensus_run runs the same one with world = 1)
+    # the slot schedule of include/nsgpu.h (nsgpu_consensus_run runs the same one with world = 1): one collective per slot
     n_coll = 0
     slot = 0
     n_groups = int(lib.nsgpu_cons_groups())
     while True:
         h, b = slot % n_groups, (slot + 1) % n_groups
         F.check(lib, lib.nsgpu_cons_slot(ctx, slot))
-        ga, gb = gather(*take(lib.nsgpu_cons_claim_requests, b))
+        ca, cb = take(lib.nsgpu_cons_claim_requests, b)
+        sa, sb = take(lib.nsgpu_cons_seed_requests, h)
+        ca, cb, sa, sb = (np.ascontiguousarray(x) for x in gather(ca, cb, sa, sb))
         n_coll += 1
-        ga, gb = np.ascontiguousarray(ga), np.ascontiguousarray(gb)
         done = C.c_uint32()
-        F.check(lib, lib.nsgpu_cons_claim_resolve(ctx, ptr(ga), ptr(gb), ga.size, C.byref(done)))
-        while True:
-            ga, gb = gather(*take(lib.nsgpu_cons_seed_requests, h))
-            n_coll += 1
-            if ga.size == 0:
-                break
-            started = C.c_uint32()
-            ga, gb = np.ascontiguousarray(ga), np.ascontiguousarray(gb)
-            F.check(lib, lib.nsgpu_cons_seed_resolve(ctx, ptr(ga), ptr(gb), ga.size, C.byref(started), C.byref(done)))
-            if started.value == 0:
-                break
+        F.check(lib, lib.nsgpu_cons_claim_resolve(ctx, ptr(ca), ptr(cb), ca.size, C.byref(done)))
+        started = C.c_uint32()
+        F.check(lib, lib.nsgpu_cons_seed_resolve(ctx, ptr(sa), ptr(sb), sa.size, C.byref(started), C.byref(done)))
+        if started.value:
             F.check(lib, lib.nsgpu_cons_advance(ctx, 1, h))
         if done.value:
             break
