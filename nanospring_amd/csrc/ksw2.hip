@@ -373,6 +373,12 @@ __global__ __launch_bounds__(64) void ksw_extd2_hbm_kernel(const KswTask *__rest
 // Same lane-exact semantics as ksw_extd2_wave (16-aligned sweep, stale scores, s|sf|qr contiguity, int8 wrap).
 // Long problems get 256 threads, i.e. 4 waves per anti-diagonal instead of 1: they are latency-bound.
 // ----------------------------------------------------------------------------
+// Workgroup barrier for LDS-only communication: this wave's LDS traffic is drained (lgkmcnt(0)) before it arrives; the
+// traceback bytes still in flight to HBM are NOT waited for.  (__syncthreads() implies vmcnt(0): with one traceback store
+// per cell and row that was a full HBM store round trip, ~1 us, on every anti-diagonal of the long problems.)  The one
+// __syncthreads() behind the row loop makes the traceback visible before lane 0 walks it.
+static __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int NT, int MAXPOS>
 __global__ __launch_bounds__(NT) void ksw_extd2_wg_kernel(const KswTask *__restrict__ tasks, const uint32_t *__restrict__ order, uint32_t n_tasks,
                                                           KswParams pr, const uint8_t *__restrict__ seqs, uint8_t *__restrict__ p_pool,
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(NT) void ksw_extd2_wg_kernel(const KswTask *__restr
             z_extra = sq == sq2 ? sc_mch : sc_mis;
             if (sq == 4 || sq2 == 4) z_extra = sc_N;
         }
-        __syncthreads();
+        lds_barrier();
         // ---- write phase ----
         uint8_t *prow = p + (size_t)r * ncol16 - st;
 #pragma unroll
@@ -545,7 +551,7 @@ __global__ __launch_bounds__(NT) void ksw_extd2_wg_kernel(const KswTask *__restr
             best = shfl_max_u64(best);
             if (NT > 64 && (tid & 63) == 0) s_best[tid >> 6] = best;
         }
-        __syncthreads();
+        lds_barrier();
         // ---- score bookkeeping (uniform) ----
         bool brk = false;
         if (!approx_max) {
@@ -723,8 +729,9 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     // workgroup kernel for the long, latency-bound problems of LDS classes 1 and 2: 256 threads (more waves only add barrier cost), up to 5 / 8 cells per
     // thread and row; the bulk of small gap fills (class 0) is throughput-bound and stays on one wave per problem
     std::vector<uint32_t> wg[3];
-    static const int kWgThreads[3] = {0, 256, 256}, kWgMaxPos[3] = {0, 5, 8};
+    static const int kWgThreads[3] = {0, 256, 256}, kWgMaxPos[3] = {0, 5, 8};      // widest sweep served: 1280 / 2048 cells (256 x 5 / 8 or 512 x 3 / 4)
     static const bool no_wg = getenv("NSGPU_KSW_NO_WG") != nullptr;      // debugging aid: fallback kernels only
+    static const bool wg512 = getenv("NSGPU_KSW_WG256") == nullptr;     // 512 threads per long problem (8 waves; NSGPU_KSW_WG256=1: 4 waves)
     static const int wg_min_rows = [] { const char *e = getenv("NSGPU_KSW_WG_MIN_ROWS"); return e ? atoi(e) : 0; }();   // experiment knob
     size_t p_total = 0, cig_total = 0, hbm_stride = 0;
     for (size_t i = 0; i < n; ++i) {
@@ -837,11 +844,20 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         const uint32_t *ord = W.k_order.as<uint32_t>() + wg_start[k];
         NS_HIP(hipEventRecord(ev_at(n_ev++), st));
         if (k == 1)
+        {
+            if (wg512) hipLaunchKernelGGL((ksw_extd2_wg_kernel<512, 3>), dim3(m), dim3(512), kClass[1], st, W.k_tasks.as<KswTask>(), ord, m, pr, W.k_seqs.as<uint8_t>(),
+                               W.k_p.as<uint8_t>(), W.k_cig.as<uint32_t>(), W.k_res.as<KswResult>());
+            else
             hipLaunchKernelGGL((ksw_extd2_wg_kernel<256, 5>), dim3(m), dim3(256), kClass[1], st, W.k_tasks.as<KswTask>(), ord, m, pr, W.k_seqs.as<uint8_t>(),
                                W.k_p.as<uint8_t>(), W.k_cig.as<uint32_t>(), W.k_res.as<KswResult>());
-        else {
+        } else {
             static const hipError_t attr_wg8 = hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_wg_kernel<256, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClass[2]);
             NS_HIP(attr_wg8);
+            static const hipError_t attr_wg8b = hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_wg_kernel<512, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClass[2]);
+            NS_HIP(attr_wg8b);
+            if (wg512) hipLaunchKernelGGL((ksw_extd2_wg_kernel<512, 4>), dim3(m), dim3(512), kClass[2], st, W.k_tasks.as<KswTask>(), ord, m, pr, W.k_seqs.as<uint8_t>(),
+                               W.k_p.as<uint8_t>(), W.k_cig.as<uint32_t>(), W.k_res.as<KswResult>());
+            else
             hipLaunchKernelGGL((ksw_extd2_wg_kernel<256, 8>), dim3(m), dim3(256), kClass[2], st, W.k_tasks.as<KswTask>(), ord, m, pr, W.k_seqs.as<uint8_t>(),
                                W.k_p.as<uint8_t>(), W.k_cig.as<uint32_t>(), W.k_res.as<KswResult>());
         }
