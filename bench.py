@@ -196,7 +196,7 @@ def main():
                        "parallelism": (f"x{world}: reads sharded by id, replicated by all-gather; per step all-gather of sketch rows + "
                                        f"{st.get('n_collectives', 0)} small all-gathers of claim lists (global builder order)") if exchange
                        else f"reads sharded by id x{world}, no collective"},
-            "roofline": {"kernel": "ksw_extd2 (ksw_extd2_lds_kernel + ksw_extd2_wg_kernel<256,*>)", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "ksw_extd2 (ksw_extd2_lds_kernel + ksw_extd2_wg_kernel<512,*>)", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": traffic, "traffic_source": traffic_src,
                          "launches": int(a["dp_launches"]), "avg_launch_ms": round(dp_ms, 3),
                          "note": "integer DP, LDS/ALU bound by construction: %.1f GCUPS over %.3g cells" % (
