@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <chrono>
 #include <time.h>
+#include <sys/prctl.h>
 #include <algorithm>
 
 namespace nsgpu {
@@ -24,12 +25,16 @@ hipError_t stream_wait(hipStream_t s)
 {
     static const bool spin = [] { const char *e = getenv("NSGPU_SPIN_WAIT"); return e && atoi(e) != 0; }();
     if (spin) return hipStreamSynchronize(s);
+    // the default timer slack (50 us) would stretch every 20 us sleep to ~75 us, and the batch threads wait a dozen times per
+    // pipeline slot: 1 us of slack for threads that wait here
+    static thread_local const int slack_set = prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
+    (void)slack_set;
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t e = hipStreamQuery(s);
         if (e != hipErrorNotReady) return e;
         if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(20)) continue;
-        timespec ts = {0, 20000};                 // + the kernel's timer slack: ~70 us between polls
+        timespec ts = {0, 20000};
         nanosleep(&ts, nullptr);
     }
 }

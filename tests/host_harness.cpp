@@ -78,6 +78,31 @@ int harness_sketch(const char *s, int len, int w, int k, uint64_t *xy, int cap)
     return (int)v.size();
 }
 
+void harness_nt4(const char *s, int64_t n, uint8_t *out) { nt4_codes(s, (size_t)n, out); }
+
+// RefIndex::build_from_sketch over caller-supplied minimizers: keys / CSR starts / positions, mid_occ, and for every key
+// what get() answers (count and first position)
+int64_t harness_index(const char *s, int len, int w, int k, const uint64_t *xy, int64_t n_mz, uint64_t *keys, uint32_t *start, uint64_t *pos, int64_t cap,
+                      int32_t *mid_occ, uint64_t *get_first, int32_t *get_n)
+{
+    RefIndex ri;
+    ri.build_from_sketch(s, (uint32_t)len, w, k, 2e-4f, (const Anchor *)xy, (size_t)n_mz);
+    *mid_occ = ri.mid_occ;
+    const int64_t nk = (int64_t)ri.keys.size();
+    if (nk > cap || (int64_t)ri.pos.size() > cap) return -1;
+    for (int64_t i = 0; i < nk; ++i) {
+        keys[i] = ri.keys[i], start[i] = ri.start[i];
+        int n = 0;
+        const uint64_t *p = ri.get(ri.keys[i], &n);
+        get_n[i] = n, get_first[i] = p ? p[0] : ~0ull;
+    }
+    start[nk] = ri.start[nk];
+    for (size_t i = 0; i < ri.pos.size(); ++i) pos[i] = ri.pos[i];
+    int n = 7;
+    if (ri.get(0xfffffffffffull, &n) != nullptr || n != 0) return -2;      // a key that no 2k-bit hash can be
+    return nk;
+}
+
 void harness_radix_sort_128x(uint64_t *xy, int64_t n) { radix_sort_128x((Anchor *)xy, (Anchor *)xy + n); }
 void harness_radix_sort_64(uint64_t *x, int64_t n) { radix_sort_64(x, x + n); }
 
