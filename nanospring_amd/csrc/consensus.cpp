@@ -369,7 +369,7 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
                 for (size_t x = ei - 1; x < last_ei; ++x) {
                     if (x + 12 < n_path_edges) __builtin_prefetch(pe[x + 12], 1, 1);
                     // second miss of an edge with more than eight reads: the tail of its read list, one line behind the edge's own
-                    if (x + 6 < n_path_edges) { const Edge *e6 = pe[x + 6]; if (e6->reads.cap != 8) __builtin_prefetch(e6->reads.heap + e6->reads.n, 1, 1); }
+                    if (x + 6 < n_path_edges) { const Edge *e6 = pe[x + 6]; if (e6->reads.cap != kEdgeInlineReads) __builtin_prefetch(e6->reads.heap + e6->reads.n, 1, 1); }
                     pe[x]->add_read(arena_, id);
                 }
                 cur = pe[last_ei - 1]->sink;
