@@ -21,23 +21,28 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
-hipError_t stream_wait(hipStream_t s)
+static hipError_t stream_wait_impl(hipStream_t s, int spin_us)
 {
     static const bool spin = [] { const char *e = getenv("NSGPU_SPIN_WAIT"); return e && atoi(e) != 0; }();
     if (spin) return hipStreamSynchronize(s);
-    // the default timer slack (50 us) would stretch every 20 us sleep to ~75 us, and the batch threads wait a dozen times per
-    // pipeline slot: 1 us of slack for threads that wait here
+    // the default timer slack (50 us) would stretch every 20 us sleep to ~75 us: 1 us of slack for threads that wait here
     static thread_local const int slack_set = prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
     (void)slack_set;
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t e = hipStreamQuery(s);
         if (e != hipErrorNotReady) return e;
-        if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(20)) continue;
+        if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us)) continue;
         timespec ts = {0, 20000};
         nanosleep(&ts, nullptr);
     }
 }
+hipError_t stream_wait(hipStream_t s) { return stream_wait_impl(s, 20); }
+// For the waits between the short kernels of one batch step (a few hundred microseconds of GPU work, several times per
+// pipeline slot, on the slot's critical path): the runtime's own busy-wait.  Measured at cfg2: sleeping between polls costs
+// 100-200 us per wait until the thread is back on a core of the CPU-saturated cgroup (window queries 0.53 -> 1.08 s per
+// step), polling hipStreamQuery for 0.5 ms first still 0.67 s; the spin costs ~1 CPU-second per batch thread and step.
+hipError_t stream_wait_short(hipStream_t s) { return hipStreamSynchronize(s); }
 
 static uint64_t row_bytes_h(uint32_t len) { return ((((uint64_t)len + 3) / 4 + 15) & ~(uint64_t)15) + 16; }
 
@@ -88,7 +93,7 @@ static int store_from_ascii(nsgpu_ctx *c, SeqStore &st, const char *bases, const
     NS_HIP(hipEventRecord(c->t_kernel.a, c->stream));
     NS_TRY(launch_pack_ascii(c, c->ascii.as<char>(), c->aoff.as<uint64_t>(), st));
     NS_HIP(hipEventRecord(c->t_kernel.b, c->stream));
-    NS_HIP(stream_wait(c->stream));   // rel / len vectors go out of scope
+    NS_HIP(stream_wait_short(c->stream));   // rel / len vectors go out of scope
     NS_HIP(hipEventElapsedTime(&c->timing.pack_ms, c->t_kernel.a, c->t_kernel.b));
     return NSGPU_OK;
 }
@@ -166,6 +171,7 @@ void nsgpu_destroy(nsgpu_ctx *c)
         for (DevBuf *b : sb) b->release();
         if (w.h_seqs) (void)hipHostFree(w.h_seqs);
         if (w.h_out) (void)hipHostFree(w.h_out);
+        w.h_meta.release();
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }
     for (nsgpu_ctx::KswWs &w : c->kws) {
@@ -179,7 +185,9 @@ void nsgpu_destroy(nsgpu_ctx *c)
         for (hipEvent_t e : w.ev) if (e) (void)hipEventDestroy(e);
         if (w.stream) (void)hipStreamDestroy(w.stream);
         if (w.h_pool) (void)hipHostFree(w.h_pool);
+        w.h_res.release(); w.h_coff.release(); w.h_cig.release();
     }
+    c->pin_small.release(); c->pin_foff.release(); c->pin_fids.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

@@ -45,6 +45,7 @@ void set_error(const char *fmt, ...);
 // is bound by the host cores it shares with those waits.  So: poll the stream, spin only for the first ~20 us, then sleep
 // between polls.  NSGPU_SPIN_WAIT=1 restores the runtime's own wait.
 hipError_t stream_wait(hipStream_t s);
+hipError_t stream_wait_short(hipStream_t s);     // busy-wait (the runtime's): for waits inside a chain of short kernels on a slot's critical path
 
 // Growable device allocation (never shrinks). No hipMalloc happens inside a
 // stage once the buffers have reached their steady-state size.
@@ -65,6 +66,24 @@ struct DevBuf {
         return NSGPU_OK;
     }
     void release() { if (p) { hipError_t e = hipFree(p); (void)e; } p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Growable pinned host buffer.  Device-to-host copies must land in pinned memory: a hipMemcpyAsync into pageable memory
+// (a std::vector) turns into a blocking staged copy inside the runtime, which busy-waits for everything queued before it.
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return NSGPU_OK;
+        if (p) { hipError_t e = hipHostFree(p); (void)e; p = nullptr; cap = 0; }
+        const size_t want = bytes + (bytes >> 1) + 4096;
+        const hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) { set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); p = nullptr; return NSGPU_ERR_NOMEM; }
+        cap = want;
+        return NSGPU_OK;
+    }
+    void release() { if (p) { hipError_t e = hipHostFree(p); (void)e; } p = nullptr; cap = 0; }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
@@ -123,6 +142,8 @@ struct nsgpu_ctx {
         uint8_t *h_pool = nullptr; size_t h_pool_cap = 0;            // pinned staging of the DP sequence pool
         std::vector<uint8_t> h_bucket; std::vector<uint32_t> h_tmp;   // scratch of the launch-order bucketing
         std::vector<uint32_t> h_flat;                                // launch order of the batch in flight
+        std::vector<uint32_t> h_pbytes; std::vector<uint8_t> h_class;  // per-problem traceback bytes / kernel class (scratch of the launch)
+        nsgpu::PinBuf h_res, h_coff, h_cig;                            // pinned landing zones of the results, CIGAR offsets and CIGARs
         size_t pend_n = 0, pend_n_ev = 0; uint64_t pend_n_launch = 0; // batch launched, not yet collected (ksw_batch_launch / _collect)
         hipStream_t stream = nullptr;                                // workspace 0 runs on the context's stream
         hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
@@ -133,8 +154,10 @@ struct nsgpu_ctx {
         nsgpu::DevBuf seqs, soff, len, sob, vf, mk, vr, linv, npf, pushf, npr, pr, V, hk, PX, PY, PRUN, PSEQ, rm, nout, oscan, off, out, scan_ws;
         uint8_t *h_seqs = nullptr; size_t h_cap = 0;
         uint8_t *h_out = nullptr; size_t h_out_cap = 0;
+        nsgpu::PinBuf h_meta;                                          // pinned landing zone of the small read-backs (push count, offsets)
         hipStream_t stream = nullptr;
     } sws;
+    nsgpu::PinBuf pin_small, pin_foff, pin_fids;                     // pinned landing zones: the filter's scalars / the engine's candidate CSR
     double sketch_mm_ms = 0;                                         // wall of the batched mm_sketch calls
     std::mutex stat_m;                                               // guards the ksw_* / aln_* counters below
     double ksw_kernel_ms = 0, ksw_cells = 0, ksw_alg_bytes = 0;     // kernel_ms: wall of the (overlapping) DP launches per batch

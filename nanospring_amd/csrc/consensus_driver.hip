@@ -476,9 +476,13 @@ static int engine_batches_finish(nsgpu_ctx *c, int group)
             NS_TRY(filter_strings_device(c, E->qbuf.data(), E->qoff.data(), nq));
             E->foff.resize((size_t)nq + 1);
             E->fids.resize(c->f_total + 1);
-            NS_HIP(hipMemcpyAsync(E->foff.data(), c->f_off.p, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-            if (c->f_total) NS_HIP(hipMemcpyAsync(E->fids.data(), c->f_ids.p, c->f_total * 4, hipMemcpyDeviceToHost, c->stream));
-            NS_HIP(stream_wait(c->stream));
+            NS_TRY(c->pin_foff.reserve(((size_t)nq + 1) * 8));
+            NS_TRY(c->pin_fids.reserve((c->f_total + 1) * 4));
+            NS_HIP(hipMemcpyAsync(c->pin_foff.p, c->f_off.p, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+            if (c->f_total) NS_HIP(hipMemcpyAsync(c->pin_fids.p, c->f_ids.p, c->f_total * 4, hipMemcpyDeviceToHost, c->stream));
+            NS_HIP(stream_wait_short(c->stream));
+            memcpy(E->foff.data(), c->pin_foff.p, ((size_t)nq + 1) * 8);
+            if (c->f_total) memcpy(E->fids.data(), c->pin_fids.p, c->f_total * 4);
             for (size_t w = 0; w < who.size(); ++w) {
                 Builder &b = D.B[who[w]];
                 for (int s = 0; s < 2; ++s) b.cand[s].assign(E->fids.begin() + E->foff[2 * w + s], E->fids.begin() + E->foff[2 * w + s + 1]);

@@ -499,9 +499,13 @@ int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, 
         NS_HIP(hipGetLastError());
     }
     NS_TRY(scan_u32_to_u64(c, qcap, soff, nq));
+    // scalars come back through pinned memory: a copy into a pageable variable blocks inside the runtime, busy-waiting
+    NS_TRY(c->pin_small.reserve(64));
+    volatile uint64_t *const ps = c->pin_small.as<volatile uint64_t>();       // [0] staging total [1] overflow count [2] f_total [3] matches
     uint64_t staging_total = 0, m_total = 0;
-    NS_HIP(hipMemcpyAsync(&staging_total, soff + nq, 8, hipMemcpyDeviceToHost, c->stream));
-    NS_HIP(stream_wait(c->stream));
+    NS_HIP(hipMemcpyAsync(c->pin_small.p, soff + nq, 8, hipMemcpyDeviceToHost, c->stream));
+    NS_HIP(stream_wait_short(c->stream));
+    staging_total = ps[0];
     NS_TRY(c->f_pool.reserve((staging_total + 1) * 4));
     {
         uint32_t grid = nq < 262144u ? nq : 262144u;
@@ -509,9 +513,10 @@ int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, 
                            c->f_pool.as<uint32_t>(), qcnt, c->f_ovf_list.as<uint32_t>(), c->f_ctrl.as<uint32_t>());
         NS_HIP(hipGetLastError());
     }
-    uint32_t n_ovf = 0;
-    NS_HIP(hipMemcpyAsync(&n_ovf, c->f_ctrl.p, 4, hipMemcpyDeviceToHost, c->stream));
-    NS_HIP(stream_wait(c->stream));
+    ps[1] = 0;
+    NS_HIP(hipMemcpyAsync(c->pin_small.as<uint64_t>() + 1, c->f_ctrl.p, 4, hipMemcpyDeviceToHost, c->stream));
+    NS_HIP(stream_wait_short(c->stream));
+    const uint32_t n_ovf = (uint32_t)ps[1];
     if (n_ovf) {
         const uint32_t wgs = n_ovf < F_HEAVY_WGS ? n_ovf : F_HEAVY_WGS;
         const size_t need = (size_t)F_HEAVY_WGS * N * 4;
@@ -524,8 +529,9 @@ int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, 
         NS_HIP(hipGetLastError());
     }
     NS_TRY(scan_u32_to_u64(c, qcnt, c->f_off.as<uint64_t>(), nq));
-    NS_HIP(hipMemcpyAsync(&c->f_total, c->f_off.as<uint64_t>() + nq, 8, hipMemcpyDeviceToHost, c->stream));
-    NS_HIP(stream_wait(c->stream));
+    NS_HIP(hipMemcpyAsync(c->pin_small.as<uint64_t>() + 2, c->f_off.as<uint64_t>() + nq, 8, hipMemcpyDeviceToHost, c->stream));
+    NS_HIP(stream_wait_short(c->stream));
+    c->f_total = ps[2];
     NS_TRY(c->f_ids.reserve((c->f_total + 1) * 4));
     {
         uint32_t grid = (nq + 3) / 4;
@@ -540,10 +546,13 @@ int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, 
         uint64_t *tmp = reinterpret_cast<uint64_t *>(lb);
         if ((size_t)nq * n * 8 >= ((size_t)nq + 1) * 8) {
             NS_TRY(scan_u32_to_u64(c, qm, tmp, nq));
-            NS_HIP(hipMemcpyAsync(&m_total, tmp + nq, 8, hipMemcpyDeviceToHost, c->stream));
+            ps[3] = 0;
+            NS_HIP(hipMemcpyAsync(c->pin_small.as<uint64_t>() + 3, tmp + nq, 8, hipMemcpyDeviceToHost, c->stream));
+            m_total = 1;                                   // marker: read ps[3] after the wait
         }
     }
-    NS_HIP(stream_wait(c->stream));
+    NS_HIP(stream_wait_short(c->stream));
+    if (m_total) m_total = ps[3];
     NS_HIP(hipEventElapsedTime(&c->timing.filter_kernel_ms, c->t_kernel.a, c->t_kernel.b));
     c->timing.filter_matches = m_total;
     return NSGPU_OK;

@@ -734,23 +734,47 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     static const bool wg512 = getenv("NSGPU_KSW_WG256") == nullptr;     // 512 threads per long problem (8 waves; NSGPU_KSW_WG256=1: 4 waves)
     static const int wg_min_rows = [] { const char *e = getenv("NSGPU_KSW_WG_MIN_ROWS"); return e ? atoi(e) : 0; }();   // experiment knob
     size_t p_total = 0, cig_total = 0, hbm_stride = 0;
+    // per-problem sizes and classes on all host threads (a batch has ~10^4 problems and this thread is on the slot's critical
+    // path), then one short serial pass for the running offsets and the class lists
+    std::vector<uint32_t> &pb = W.h_pbytes;            // traceback bytes (64-aligned), 0 for an empty problem
+    std::vector<uint8_t> &cl = W.h_class;              // 0..3 one-wave classes, 4 + c workgroup classes, 255 empty, 254 / 253 errors
+    pb.resize(n), cl.resize(n);
+    const size_t chunk = 1024, n_chunks = (n + chunk - 1) / chunk;
+    std::vector<size_t> chunk_stride(n_chunks, 0);
+    par_for("align.dp_classify", n_chunks, [&](size_t ci) {
+        size_t hs = 0;
+        for (size_t i = ci * chunk, e = std::min(n, (ci + 1) * chunk); i < e; ++i) {
+            const KswTask &t = tasks[i];
+            KswResult &o = results[i];                 // reset state (ksw_reset_extz): what an empty problem returns
+            o.max = 0; o.zdropped = 0; o.max_q = o.max_t = o.mqe_t = o.mte_q = -1; o.mqe = o.mte = o.score = KSW_NEG_INF; o.n_cigar = 0; o.reach_end = 0;
+            pb[i] = 0;
+            if (t.qlen < 0 || t.tlen < 0) { cl[i] = 254; continue; }
+            if (t.flag & KSW_EZ_GENERIC_SC) { cl[i] = 253; continue; }
+            if (t.qlen <= 0 || t.tlen <= 0) { cl[i] = 255; continue; }
+            pb[i] = (uint32_t)((ksw_p_bytes(t.qlen, t.tlen, t.w) + 63) & ~(size_t)63);
+            const size_t need = ksw_lds_bytes(t.qlen, t.tlen, t.flag);
+            const int cls = need <= kClass[0] ? 0 : need <= kClass[1] ? 1 : need <= kClass[2] ? 2 : 3;
+            if (cls == 3) { const size_t hn = ksw_lds_bytes(t.qlen, t.tlen, 0); if (hn > hs) hs = hn; }
+            const bool to_wg = cls >= 1 && cls < 3 && !no_wg && t.qlen + t.tlen >= wg_min_rows && ksw_max_width(t.qlen, t.tlen, t.w) <= kWgThreads[cls] * kWgMaxPos[cls];
+            cl[i] = (uint8_t)(to_wg ? 4 + cls : cls);
+        }
+        chunk_stride[ci] = hs;
+    });
+    for (size_t ci = 0; ci < n_chunks; ++ci) if (chunk_stride[ci] > hbm_stride) hbm_stride = chunk_stride[ci];
     for (size_t i = 0; i < n; ++i) {
         KswTask &t = tasks[i];
-        NS_CHECK(t.qlen >= 0 && t.tlen >= 0, NSGPU_ERR_ARG, "ksw: negative length");
-        NS_CHECK(!(t.flag & KSW_EZ_GENERIC_SC), NSGPU_ERR_ARG, "ksw: KSW_EZ_GENERIC_SC is not on NanoSpring's path");
+        NS_CHECK(cl[i] != 254, NSGPU_ERR_ARG, "ksw: negative length");
+        NS_CHECK(cl[i] != 253, NSGPU_ERR_ARG, "ksw: KSW_EZ_GENERIC_SC is not on NanoSpring's path");
         t.out_idx = (uint32_t)i;
         t.p_off = p_total;
         t.cig_off = (uint32_t)cig_total;
         cig_off[i] = cig_total;
-        if (t.qlen <= 0 || t.tlen <= 0) continue;    // result stays "reset" (ksw_reset_extz), as the reference returns early
-        p_total += (ksw_p_bytes(t.qlen, t.tlen, t.w) + 63) & ~(size_t)63;
+        if (cl[i] == 255) continue;                  // result stays "reset" (ksw_reset_extz), as the reference returns early
+        p_total += pb[i];
         cig_total += (size_t)t.qlen + t.tlen + 2;
         NS_CHECK(cig_total < (1ull << 32), NSGPU_ERR_RANGE, "ksw batch too large (cigar pool)");
-        const size_t need = ksw_lds_bytes(t.qlen, t.tlen, t.flag);
-        int cls = need <= kClass[0] ? 0 : need <= kClass[1] ? 1 : need <= kClass[2] ? 2 : 3;
-        if (cls == 3) { const size_t hn = ksw_lds_bytes(t.qlen, t.tlen, 0); if (hn > hbm_stride) hbm_stride = hn; }
-        if (cls >= 1 && cls < 3 && !no_wg && t.qlen + t.tlen >= wg_min_rows && ksw_max_width(t.qlen, t.tlen, t.w) <= kWgThreads[cls] * kWgMaxPos[cls]) wg[cls].push_back((uint32_t)i);
-        else order[cls].push_back((uint32_t)i);
+        if (cl[i] >= 4) wg[cl[i] - 4].push_back((uint32_t)i);
+        else order[cl[i]].push_back((uint32_t)i);
     }
     cig_off[n] = cig_total;
     static const bool hist = getenv("NSGPU_KSW_HIST") != nullptr;        // debugging aid: shape of the workgroup-kernel problems
@@ -766,11 +790,6 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
                 fprintf(stderr, "KSWHIST class %d n %zu width<=128/256/512/768/1280/more %zu %zu %zu %zu %zu %zu rows<=512/1k/2k/4k/8k/more %zu %zu %zu %zu %zu %zu\n", k + 4,
                         wg[k].size(), wb[0], wb[1], wb[2], wb[3], wb[4], wb[5], rb[0], rb[1], rb[2], rb[3], rb[4], rb[5]);
         }
-    }
-    // reset-state results for empty problems
-    for (size_t i = 0; i < n; ++i) {
-        KswResult &o = results[i];
-        o.max = 0; o.zdropped = 0; o.max_q = o.max_t = o.mqe_t = o.mte_q = -1; o.mqe = o.mte = o.score = KSW_NEG_INF; o.n_cigar = 0; o.reach_end = 0;
     }
     NS_TRY(W.k_tasks.reserve(n * sizeof(KswTask)));
     NS_TRY(W.k_order.reserve(n * 4 + 16));
@@ -935,9 +954,15 @@ int ksw_batch_collect(nsgpu_ctx *c, std::vector<KswTask> &tasks, std::vector<Ksw
     NS_CHECK(n == tasks.size() && results.size() == n && cig_off.size() == n + 1, NSGPU_ERR_ARG, "ksw: collect does not match the launched batch");
     const hipStream_t S = ws_index == 0 ? c->stream : W.stream;
     W.pend_n = 0;
-    NS_HIP(hipMemcpyAsync(results.data(), W.k_res.p, n * sizeof(KswResult), hipMemcpyDeviceToHost, S));
-    NS_HIP(hipMemcpyAsync(cig_off.data(), W.k_coff.p, (n + 1) * 8, hipMemcpyDeviceToHost, S));
+    // read-backs land in pinned memory (a copy into the pageable vectors would block inside the runtime, busy-waiting for the
+    // DP kernels queued before it) and are copied out once the stream has drained
+    NS_TRY(W.h_res.reserve(n * sizeof(KswResult) + 64));
+    NS_TRY(W.h_coff.reserve((n + 1) * 8 + 64));
+    NS_HIP(hipMemcpyAsync(W.h_res.p, W.k_res.p, n * sizeof(KswResult), hipMemcpyDeviceToHost, S));
+    NS_HIP(hipMemcpyAsync(W.h_coff.p, W.k_coff.p, (n + 1) * 8, hipMemcpyDeviceToHost, S));
     NS_HIP(stream_wait(S));
+    memcpy(results.data(), W.h_res.p, n * sizeof(KswResult));
+    memcpy(cig_off.data(), W.h_coff.p, (n + 1) * 8);
     const uint64_t used = cig_off[n];
     NS_TRY(W.k_cig2.reserve((used + 16) * 4));
     if (used) {
@@ -948,8 +973,10 @@ int ksw_batch_collect(nsgpu_ctx *c, std::vector<KswTask> &tasks, std::vector<Ksw
         NS_HIP(hipGetLastError());
     }
     cigars.resize(used + 1);
-    if (used) NS_HIP(hipMemcpyAsync(cigars.data(), W.k_cig2.p, used * 4, hipMemcpyDeviceToHost, S));
-    NS_HIP(stream_wait(S));
+    NS_TRY(W.h_cig.reserve((used + 1) * 4 + 64));
+    if (used) NS_HIP(hipMemcpyAsync(W.h_cig.p, W.k_cig2.p, used * 4, hipMemcpyDeviceToHost, S));
+    NS_HIP(stream_wait_short(S));
+    if (used) memcpy(cigars.data(), W.h_cig.p, used * 4);
     float ms = 0;
     NS_HIP(hipEventElapsedTime(&ms, W.t_a, W.t_b));
     double sum_ms = 0, cells = 0, alg = 0;

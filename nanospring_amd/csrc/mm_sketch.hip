@@ -305,9 +305,10 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
     NS_HIP(hipGetLastError());
     NS_TRY(scan_u32(W, st, W.npf.as<uint32_t>(), W.npr.as<uint32_t>(), (size_t)B + 1, false, 0));
     NS_TRY(scan_u32(W, st, W.pushf.as<uint32_t>(), W.pr.as<uint32_t>(), (size_t)B + 1, false, 0));
-    uint32_t P = 0;                                                      // pushes of the whole batch
-    NS_HIP(hipMemcpyAsync(&P, W.pr.as<uint32_t>() + B, 4, hipMemcpyDeviceToHost, st));
-    NS_HIP(stream_wait(st));
+    NS_TRY(W.h_meta.reserve((n + 1) * 8 + 64));
+    NS_HIP(hipMemcpyAsync(W.h_meta.p, W.pr.as<uint32_t>() + B, 4, hipMemcpyDeviceToHost, st));
+    NS_HIP(stream_wait_short(st));
+    const uint32_t P = *W.h_meta.as<uint32_t>();                         // pushes of the whole batch
     NS_TRY(W.PX.reserve(((size_t)P + 1) * 8));
     NS_TRY(W.PY.reserve(((size_t)P + 1) * 8));
     NS_TRY(W.PRUN.reserve(((size_t)P + 2) * 4));
@@ -327,8 +328,9 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
     NS_TRY(scan_u32(W, st, W.nout.as<uint32_t>(), W.oscan.as<uint32_t>(), (size_t)P + 1, false, 0));
     hipLaunchKernelGGL(sk_offsets_kernel, dim3(((uint32_t)n + 1 + 255) / 256), dim3(256), 0, st, bt, W.pr.as<uint32_t>(), W.oscan.as<uint32_t>(), W.off.as<uint64_t>());
     NS_HIP(hipGetLastError());
-    NS_HIP(hipMemcpyAsync(out_off.data(), W.off.p, (n + 1) * 8, hipMemcpyDeviceToHost, st));
-    NS_HIP(stream_wait(st));
+    NS_HIP(hipMemcpyAsync(W.h_meta.p, W.off.p, (n + 1) * 8, hipMemcpyDeviceToHost, st));
+    NS_HIP(stream_wait_short(st));
+    memcpy(out_off.data(), W.h_meta.p, (n + 1) * 8);
     const uint64_t total = out_off[n];
     NS_TRY(W.out.reserve(total * 16 + 16));
     NS_TRY(pinned_reserve(W.h_out, W.h_out_cap, total * 16 + 16));
@@ -338,7 +340,7 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
         NS_HIP(hipGetLastError());
         NS_HIP(hipMemcpyAsync(W.h_out, W.out.p, total * 16, hipMemcpyDeviceToHost, st));
     }
-    NS_HIP(stream_wait(st));
+    NS_HIP(stream_wait_short(st));
     out = reinterpret_cast<const mm2::Anchor *>(W.h_out);
     c->sketch_mm_ms += now_ms() - t0;
     return NSGPU_OK;
