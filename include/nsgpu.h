@@ -212,9 +212,10 @@ int nsgpu_consensus_stream(nsgpu_ctx *ctx, uint32_t thread, uint32_t which, uint
  * bucket index; rank r owns the builders with gid % world == r).  Builders form G = nsgpu_cons_groups() pipeline groups
  * (group = (gid >> 3) % G, a function of the global id only; G = 4); in slot s = 0, 1, 2, ... with h = s % G, b = (s + 1) % G:
  *   slot(s)                         concurrently: host phase of group h (graph updates up to the next window / alignment
- *                                   request), part 1 of the GPU batches of group (s + G - 1) % G (window lookups, sketches,
- *                                   seeds / chains, launch of the alignment DP), part 2 of group b (DP results,
- *                                   alignment skeletons, edit scripts); the DP kernels of group (s + 2) % G stay in flight
+ *                                   request), part 1 of the GPU batches of group (s + G - 1) % G (minimizer sketches,
+ *                                   consensus indexes, seeds / chains, launch of the alignment DP), part 2 of group b (its
+ *                                   window lookups; DP results, alignment skeletons, edit scripts); the DP kernels of
+ *                                   group (s + 2) % G stay in flight
  *   claim_requests(b), seed_requests(h) -> [ONE all-gather of both lists] -> claim_resolve, then seed_resolve,
  *                                   then advance(only_fresh = 1, h) if a contig started
  * until claim_resolve / seed_resolve report that every builder is done.

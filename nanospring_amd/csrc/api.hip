@@ -171,6 +171,7 @@ void nsgpu_destroy(nsgpu_ctx *c)
         for (DevBuf *b : sb) b->release();
         if (w.h_seqs) (void)hipHostFree(w.h_seqs);
         if (w.h_out) (void)hipHostFree(w.h_out);
+        if (w.h_out2) (void)hipHostFree(w.h_out2);
         w.h_meta.release();
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }

@@ -154,6 +154,7 @@ struct nsgpu_ctx {
         nsgpu::DevBuf seqs, soff, len, sob, vf, mk, vr, linv, npf, pushf, npr, pr, V, hk, PX, PY, PRUN, PSEQ, rm, nout, oscan, off, out, scan_ws;
         uint8_t *h_seqs = nullptr; size_t h_cap = 0;
         uint8_t *h_out = nullptr; size_t h_out_cap = 0;
+        uint8_t *h_out2 = nullptr; size_t h_out2_cap = 0;               // second output buffer (the contig engine alternates)
         nsgpu::PinBuf h_meta;                                          // pinned landing zone of the small read-backs (push count, offsets)
         hipStream_t stream = nullptr;
     } sws;

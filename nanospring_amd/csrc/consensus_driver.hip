@@ -37,12 +37,12 @@ using cons::read_t;
 // A finished contig waiting for its edit emission (consensus + one edit script per read into the seven streams).  The
 // emission touches nothing but the contig's own graph, so it is taken off the builder's critical path: the builder moves
 // on to its next contig at once and the emission runs as a task of its own in the next host phase.
-constexpr int kMaxGroups = 4;
-// Pipeline groups (see run_consensus): host phase | batches part 1 | [alignment DP in flight] | batches part 2.  With 3 groups
-// part 2 follows part 1 directly and waits for whatever the DP kernels have not finished (NSGPU_GROUPS=3).
+constexpr int kMaxGroups = 5;
+// Pipeline groups (see run_consensus): host phase | batches part 1 (sketches + index, seeds / chains / DP launch) | alignment
+// DP in flight | batches part 2.  NSGPU_SPLIT_PART1=1 / NSGPU_GROUPS=5 are measured alternatives (engine_slot).
 static int n_groups()
 {
-    static const int g = [] { const char *e = getenv("NSGPU_GROUPS"); const int v = e ? atoi(e) : 4; return v == 3 ? 3 : 4; }();
+    static const int g = [] { const char *e = getenv("NSGPU_GROUPS"); const int v = e ? atoi(e) : 4; return v == 5 ? 5 : 4; }();
     return g;
 }
 
@@ -295,13 +295,13 @@ struct Engine {
     std::vector<uint64_t> qoff, foff;
     std::vector<uint32_t> fids;
     double p1_align_ms = 0, p1_host_ms = 0, p1_launch_ms = 0;
-    uint64_t slot_long_n[3] = {0, 0, 0};
-    double slot_long_ms[3] = {0, 0, 0};
-    uint64_t role_serial_ns[3] = {0, 0, 0};
+    uint64_t slot_long_n[4] = {0, 0, 0, 0};
+    double slot_long_ms[4] = {0, 0, 0, 0};
+    uint64_t role_serial_ns[4] = {0, 0, 0, 0};
     std::vector<FinishedContig *> emit_queue;      // finished contigs whose emission has not run yet
     std::vector<SketchReq> sk;
     std::vector<uint32_t> sk_ref;
-    std::vector<uint64_t> mz_off;
+    std::vector<uint64_t> mz_off[2];                // minimizer offsets of the two sketch batches alive at a time (alternating slots)
     AlignBatch ab[kMaxGroups];                        // alignment batch of each group, DP kernels in flight between part 1 and part 2
     std::vector<uint32_t> fwho;                    // builders of the window-query batch
     std::vector<uint32_t> awho[kMaxGroups];           // builders of that batch
@@ -405,52 +405,66 @@ static uint32_t engine_seed_resolve(nsgpu_ctx *c, const uint32_t *gids, const ui
 // phases 4+5: window queries and alignments of the local builders (GPU batches); no claims yet
 // batches, part 1: for the builders that wait for an alignment, minimizer sketches, index, seeds / chains / DP plan and the
 // launch of the DP kernels -- which stay in flight until part 2
-static int engine_batches_begin(nsgpu_ctx *c, int group, int ws_index)
+static int engine_batches_sketch(nsgpu_ctx *c, int group, int buf)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
     nsgpu_consensus_stats &S = c->cons_stats;
+    const int gi = group < 0 ? 0 : group;
     std::vector<uint32_t> &who = E->who;
     who.clear();
     for (Builder &b : D.B) if (in_group(b, group) && b.st == Builder::WAIT_ALIGN) who.push_back(b.id);
-    if (!who.empty()) {
-        const double g0 = now_ms();
-        // minimizers of every changed consensus and every candidate read in one GPU batch (mm_sketch.hip); the
-        // single-sequence index is then only a sort of a few hundred entries per consensus
-        std::vector<SketchReq> &sk = E->sk;
-        std::vector<uint32_t> &sk_ref = E->sk_ref;      // per who-entry: position of its consensus in sk, or ~0u
-        sk.clear(); sk_ref.assign(who.size(), ~0u);
-        for (size_t w = 0; w < who.size(); ++w) {
-            Builder &b = D.B[who[w]];
-            if (!b.idx_valid) { sk_ref[w] = (uint32_t)sk.size(); sk.push_back(SketchReq{b.g->main_path.data(), b.g->main_path.size()}); }
-        }
-        const size_t q_base = sk.size();
-        for (size_t w = 0; w < who.size(); ++w) sk.push_back(SketchReq{D.B[who[w]].query.data(), D.B[who[w]].query.size()});
-        const mm2::Anchor *mz = nullptr;
-        NS_TRY(gpu_mm_sketch(c, sk, (int)c->prm.m_w, (int)c->prm.m_k, mz, E->mz_off));
-        const std::vector<uint64_t> &mo = E->mz_off;
-        par_for("index.build", who.size(), [&](size_t w) {
-            Builder &b = D.B[who[w]];
-            if (!b.idx_valid) {
-                const uint32_t si = sk_ref[w];
-                b.idx.build_from_sketch(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f, mz + mo[si],
-                                        (size_t)(mo[si + 1] - mo[si]));
-                b.idx_valid = true;
-            }
-        });
-        const double g1 = now_ms();
-        S.index_ms += g1 - g0;
-        AlignBatch &AB = E->ab[group < 0 ? 0 : group];
-        AB.reqs.clear();
-        for (size_t w = 0; w < who.size(); ++w) {
-            Builder &b = D.B[who[w]];
-            AB.reqs.push_back(AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), mz + mo[q_base + w],
-                                       (size_t)(mo[q_base + w + 1] - mo[q_base + w])});
-        }
-        E->awho[group < 0 ? 0 : group] = who;
-        NS_TRY(align_begin(c, AB, ws_index));
-        { std::lock_guard<std::mutex> lk(c->stat_m); S.align_ms += now_ms() - g1; E->p1_align_ms += now_ms() - g1; E->p1_host_ms += AB.host_ms; E->p1_launch_ms += AB.dp_ms; }
+    AlignBatch &AB = E->ab[gi];
+    AB.reqs.clear();
+    E->awho[gi].clear();
+    if (who.empty()) return NSGPU_OK;
+    const double g0 = now_ms();
+    // minimizers of every changed consensus and every candidate read in one GPU batch (mm_sketch.hip); the
+    // single-sequence index is then only a sort of a few hundred entries per consensus
+    std::vector<SketchReq> &sk = E->sk;
+    std::vector<uint32_t> &sk_ref = E->sk_ref;      // per who-entry: position of its consensus in sk, or ~0u
+    sk.clear(); sk_ref.assign(who.size(), ~0u);
+    for (size_t w = 0; w < who.size(); ++w) {
+        Builder &b = D.B[who[w]];
+        if (!b.idx_valid) { sk_ref[w] = (uint32_t)sk.size(); sk.push_back(SketchReq{b.g->main_path.data(), b.g->main_path.size()}); }
     }
+    const size_t q_base = sk.size();
+    for (size_t w = 0; w < who.size(); ++w) sk.push_back(SketchReq{D.B[who[w]].query.data(), D.B[who[w]].query.size()});
+    const mm2::Anchor *mz = nullptr;
+    std::vector<uint64_t> &mo = E->mz_off[buf];
+    NS_TRY(gpu_mm_sketch(c, sk, (int)c->prm.m_w, (int)c->prm.m_k, mz, mo, buf));
+    par_for("index.build", who.size(), [&](size_t w) {
+        Builder &b = D.B[who[w]];
+        if (!b.idx_valid) {
+            const uint32_t si = sk_ref[w];
+            b.idx.build_from_sketch(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f, mz + mo[si],
+                                    (size_t)(mo[si + 1] - mo[si]));
+            b.idx_valid = true;
+        }
+    });
+    // the requests of the stage behind this one; the query minimizers stay in pinned buffer `buf` until that stage has run
+    for (size_t w = 0; w < who.size(); ++w) {
+        Builder &b = D.B[who[w]];
+        AB.reqs.push_back(AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), mz + mo[q_base + w],
+                                   (size_t)(mo[q_base + w + 1] - mo[q_base + w])});
+    }
+    E->awho[gi] = who;
+    { std::lock_guard<std::mutex> lk(c->stat_m); S.index_ms += now_ms() - g0; }
+    return NSGPU_OK;
+}
+
+// batches, part 1: seeds / chains / DP plan of the alignments sketched in the stage before, and the launch of the DP kernels
+// -- which stay in flight until part 2
+static int engine_batches_begin(nsgpu_ctx *c, int group, int ws_index)
+{
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    nsgpu_consensus_stats &S = c->cons_stats;
+    const int gi = group < 0 ? 0 : group;
+    if (E->awho[gi].empty()) return NSGPU_OK;
+    const double g1 = now_ms();
+    AlignBatch &AB = E->ab[gi];
+    NS_TRY(align_begin(c, AB, ws_index));
+    { std::lock_guard<std::mutex> lk(c->stat_m); S.align_ms += now_ms() - g1; E->p1_align_ms += now_ms() - g1; E->p1_host_ms += AB.host_ms; E->p1_launch_ms += AB.dp_ms; }
     return NSGPU_OK;
 }
 
@@ -512,6 +526,7 @@ static int engine_batches_finish(nsgpu_ctx *c, int group)
 
 static int engine_batches(nsgpu_ctx *c, int group)
 {
+    NS_TRY(engine_batches_sketch(c, group, 0));
     NS_TRY(engine_batches_begin(c, group, 1));
     return engine_batches_finish(c, group);
 }
@@ -583,15 +598,21 @@ static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
     return NSGPU_OK;
 }
 
-// One pipeline slot: the host phase of group `host_group`, part 1 of the batches of `begin_group` and part 2 of the
-// batches of `finish_group`, concurrently (any of them may be -2 = nothing).
-static int engine_slot(nsgpu_ctx *c, int host_group, int begin_group, int finish_group, int ws_index)
+// One pipeline slot: the host phase of group h = slot % G, part 1 (sketches + index, then seeds / chains / DP launch) of the
+// group that was there one slot earlier, part 2 of group (slot + 1) % G -- whose DP launch has been in flight for a slot --
+// all concurrently.
+static int engine_slot(nsgpu_ctx *c, uint32_t slot)
 {
+    const uint32_t G = (uint32_t)n_groups();
+    const int host_group = (int)(slot % G), sketch_group = (int)((slot + G - 1) % G), begin_group = (int)((slot + G - 2) % G), finish_group = (int)((slot + 1) % G);
+    const int ws_index = 1 + (int)(slot % 3), buf = (int)(slot & 1);
     static const bool serial = getenv("NSGPU_NO_OVERLAP") != nullptr;      // debugging aid: one after the other
     if (serial) {
-        if (host_group != -2) engine_advance(c, false, host_group);
-        if (finish_group != -2) NS_TRY(engine_batches_finish(c, finish_group));
-        if (begin_group != -2) NS_TRY(engine_batches_begin(c, begin_group, ws_index));
+        engine_advance(c, false, host_group);
+        NS_TRY(engine_batches_finish(c, finish_group));
+        if (getenv("NSGPU_SPLIT_PART1")) NS_TRY(engine_batches_begin(c, begin_group, ws_index));
+        NS_TRY(engine_batches_sketch(c, sketch_group, buf));
+        if (!getenv("NSGPU_SPLIT_PART1")) NS_TRY(engine_batches_begin(c, sketch_group, ws_index));
         return NSGPU_OK;
     }
     // the calling thread works in the host phase's loops: it joins the pool's threads on the GPU's NUMA node for the slot
@@ -600,28 +621,40 @@ static int engine_slot(nsgpu_ctx *c, int host_group, int begin_group, int finish
         Rebind() { ok = pthread_getaffinity_np(pthread_self(), sizeof(old), &old) == 0; pool_bind_this_thread(); }
         ~Rebind() { if (ok) (void)pthread_setaffinity_np(pthread_self(), sizeof(old), &old); }
     } rebind;
-    int rc1 = NSGPU_OK, rc2 = NSGPU_OK;
-    std::thread t1, t2;
-    double d1 = 0, d2 = 0;
-    uint64_t ser[3] = {0, 0, 0};          // CPU time of the three role threads outside the pool's loops (debug breakdown)
-    if (begin_group != -2) t1 = std::thread([&] { pool_bind_this_thread(); const double x = now_ms(); const uint64_t c0 = pool_thread_cpu_ns(); rc1 = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches_begin(c, begin_group, ws_index) : NSGPU_ERR_HIP; d1 = now_ms() - x; ser[1] = pool_thread_cpu_ns() - c0 - pool_thread_work_ns(); });
-    if (finish_group != -2) t2 = std::thread([&] { pool_bind_this_thread(); const double x = now_ms(); const uint64_t c0 = pool_thread_cpu_ns(); rc2 = hipSetDevice(c->prm.device) == hipSuccess ? engine_batches_finish(c, finish_group) : NSGPU_ERR_HIP; d2 = now_ms() - x; ser[2] = pool_thread_cpu_ns() - c0 - pool_thread_work_ns(); });
+    int rc[4] = {NSGPU_OK, NSGPU_OK, NSGPU_OK, NSGPU_OK};
+    double d[4] = {0, 0, 0, 0};
+    uint64_t ser[4] = {0, 0, 0, 0};          // CPU time of the role threads outside the pool's loops (debug breakdown)
+    auto role = [&](int i, const std::function<int()> &fn) {
+        pool_bind_this_thread();
+        const double x = now_ms();
+        const uint64_t c0 = pool_thread_cpu_ns();
+        rc[i] = hipSetDevice(c->prm.device) == hipSuccess ? fn() : NSGPU_ERR_HIP;
+        d[i] = now_ms() - x;
+        ser[i] = pool_thread_cpu_ns() - c0 - pool_thread_work_ns();
+    };
+    // Sketches + index and part 1 of the same group run back to back in one role; the group behind it then has its DP in
+    // flight for a whole slot.  NSGPU_SPLIT_PART1=1 gives part 1 a slot (and a role) of its own instead: measured 5 % slower
+    // at cfg2 (249 vs 263 Mbases/s on one box), as is a fifth group (NSGPU_GROUPS=5) on top of that.
+    static const bool combined = getenv("NSGPU_SPLIT_PART1") == nullptr;
+    std::thread t1([&] { role(1, [&] { const int r = engine_batches_sketch(c, sketch_group, buf); return r != NSGPU_OK || !combined ? r : engine_batches_begin(c, sketch_group, ws_index); }); });
+    std::thread t2([&] { role(2, [&] { return combined ? (int)NSGPU_OK : engine_batches_begin(c, begin_group, ws_index); }); });
+    std::thread t3([&] { role(3, [&] { return engine_batches_finish(c, finish_group); }); });
     const double h0 = now_ms();
     const uint64_t hc0 = pool_thread_cpu_ns(), hw0 = pool_thread_work_ns();
-    if (host_group != -2) engine_advance(c, false, host_group);
+    engine_advance(c, false, host_group);
     ser[0] = pool_thread_cpu_ns() - hc0 - (pool_thread_work_ns() - hw0);
-    const double dh = now_ms() - h0;
-    if (t1.joinable()) t1.join();
-    if (t2.joinable()) t2.join();
-    {   // which of the three parts set the length of the slot (debug breakdown)
+    d[0] = now_ms() - h0;
+    t1.join(); t2.join(); t3.join();
+    {   // which of the roles set the length of the slot (debug breakdown)
         Engine *E = static_cast<Engine *>(c->cons_engine);
-        const int w = dh >= d1 && dh >= d2 ? 0 : d1 >= d2 ? 1 : 2;
-        for (int i = 0; i < 3; ++i) E->role_serial_ns[i] += ser[i];
+        int w = 0;
+        for (int i = 1; i < 4; ++i) if (d[i] > d[w]) w = i;
+        for (int i = 0; i < 4; ++i) E->role_serial_ns[i] += ser[i];
         ++E->slot_long_n[w];
-        E->slot_long_ms[w] += w == 0 ? dh : w == 1 ? d1 : d2;
+        E->slot_long_ms[w] += d[w];
     }
-    NS_TRY(rc1);
-    return rc2;
+    for (int i = 1; i < 4; ++i) NS_TRY(rc[i]);
+    return NSGPU_OK;
 }
 
 static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_out)
@@ -636,16 +669,17 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
     const double w_begin = now_ms() - E->t0;
     // G builder groups (4), a G-th of a period apart.  In slot s group h = s % G runs its host phase (graph updates up to
     // the next window / alignment request), group (s + G - 1) % G -- which did that in the slot before -- part 1 of its GPU
-    // batches (window lookups, sketches, seeds / chains, launch of the alignment DP), the DP kernels of group (s + 2) % G
-    // stay in flight for this slot (their longest problems take about as long as a slot), and group (s + 1) % G runs part 2
-    // (DP results, alignment skeletons, edit scripts): the cores are not idle during kernels, nor the GPU during graph
-    // work, nor either during the other's bookkeeping.  At the slot boundary the part-2 group's read claims and then the
-    // host group's seed requests are resolved, in global builder order: the schedule is a function of the data only.
+    // batches (minimizer sketches, consensus indexes, seeds / chains, launch of the alignment DP), the DP kernels of group
+    // (s + 2) % G stay in flight for this slot (their longest problems take about as long as a slot), and group (s + 1) % G
+    // runs part 2 (its window queries; DP results, alignment skeletons, edit scripts): the cores are not idle during
+    // kernels, nor the GPU during graph work, nor either during the other's bookkeeping.  At the slot boundary the part-2
+    // group's read claims and then the host group's seed requests are resolved, in global builder order: the schedule is a
+    // function of the data only.
     for (uint32_t slot = 0;; ++slot) {
         const int G = n_groups();
-        const int h = (int)(slot % G), a = (int)((slot + G - 1) % G), b = (int)((slot + 1) % G);
+        const int h = (int)(slot % G), b = (int)((slot + 1) % G);
         double t = now_ms();
-        NS_TRY(engine_slot(c, h, a, b, 1 + (int)(slot % 3)));
+        NS_TRY(engine_slot(c, slot));
         w_slot += now_ms() - t;
         t = now_ms();
         engine_claim_requests(c, ga, gb, b);
@@ -662,8 +696,9 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
     if (getenv("NSGPU_CONS_DEBUG")) {
         fprintf(stderr, "[cons] batches wall-ms: window queries %.0f, sketch+index %.0f (gpu sketch %.0f), align begin %.0f (host loops %.0f, DP launch %.0f)\n", c->cons_stats.filter_ms,
                 c->cons_stats.index_ms, c->sketch_mm_ms, E->p1_align_ms, E->p1_host_ms, E->p1_launch_ms);
-        fprintf(stderr, "[cons] slots set by: host phase %llu (%.0f ms), batches part 1 %llu (%.0f ms), part 2 %llu (%.0f ms)\n", (unsigned long long)E->slot_long_n[0],
-                E->slot_long_ms[0], (unsigned long long)E->slot_long_n[1], E->slot_long_ms[1], (unsigned long long)E->slot_long_n[2], E->slot_long_ms[2]);
+        fprintf(stderr, "[cons] slots set by: host phase %llu (%.0f ms), sketches + index %llu (%.0f ms), batches part 1 %llu (%.0f ms), part 2 %llu (%.0f ms)\n",
+                (unsigned long long)E->slot_long_n[0], E->slot_long_ms[0], (unsigned long long)E->slot_long_n[1], E->slot_long_ms[1], (unsigned long long)E->slot_long_n[2],
+                E->slot_long_ms[2], (unsigned long long)E->slot_long_n[3], E->slot_long_ms[3]);
     }
     const double tf = now_ms();
     const int rc = engine_finish(c, n_threads_out);
@@ -676,8 +711,8 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
         getrusage(RUSAGE_SELF, &ru1);
         const double cpu_s = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec) * 1e-6 +
                              (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
-        fprintf(stderr, "[cons] serial CPU ms of the role threads (outside pool loops): host %.0f, batches part 1 %.0f, part 2 %.0f\n", E->role_serial_ns[0] / 1e6,
-                E->role_serial_ns[1] / 1e6, E->role_serial_ns[2] / 1e6);
+        fprintf(stderr, "[cons] serial CPU ms of the role threads (outside pool loops): host %.0f, sketches + index %.0f, batches part 1 %.0f, part 2 %.0f\n",
+                E->role_serial_ns[0] / 1e6, E->role_serial_ns[1] / 1e6, E->role_serial_ns[2] / 1e6, E->role_serial_ns[3] / 1e6);
         pool_prof_print();
         fprintf(stderr, "[cons] part 2 wall-ms: wait for the DP in flight %.0f, later rounds %.0f (their DP %.0f, %d rounds), results %.0f\n", g_finish_ms[0], g_finish_ms[1],
                 g_finish_ms[2], (int)g_finish_ms[4], g_finish_ms[3]);
@@ -728,8 +763,7 @@ int nsgpu_cons_slot(nsgpu_ctx *c, uint32_t slot)
 {
     NS_CHECK(c && c->cons_engine, NSGPU_ERR_ARG, "nsgpu_cons_slot: call nsgpu_cons_begin first");
     NS_HIP(hipSetDevice(c->prm.device));
-    const uint32_t G = (uint32_t)n_groups();
-    return engine_slot(c, (int)(slot % G), (int)((slot + G - 1) % G), (int)((slot + 1) % G), 1 + (int)(slot % 3));
+    return engine_slot(c, slot);
 }
 
 int nsgpu_cons_seed_requests(nsgpu_ctx *c, int group, uint32_t **gids_out, uint32_t **cursors_out, uint32_t *n_out)

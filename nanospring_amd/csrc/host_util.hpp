@@ -43,7 +43,8 @@ struct SketchReq { const char *ptr; size_t len; };
 // (w,k)-minimizers of a batch of sequences, computed on the GPU (mm_sketch.hip).  Sequence i's minimizers are
 // out[out_off[i] .. out_off[i+1]) in mm_sketch's order; `out` points into a pinned buffer owned by the context and
 // stays valid until the next call.
-int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off);
+// `out` points into pinned buffer `out_buf` (0 or 1) of the context and stays valid until the next call with the same buffer
+int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int out_buf = 0);
 int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::AlnOut> &outs, int ws_index = 0);
 // the same in two parts, the DP kernels in flight between them (state of one batch)
 struct AlignBatch {

@@ -254,7 +254,7 @@ static int scan_u32(nsgpu_ctx::SketchWs &W, hipStream_t st, const uint32_t *in, 
     return NSGPU_OK;
 }
 
-int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off)
+int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int out_buf)
 {
     const size_t n = reqs.size();
     out_off.assign(n + 1, 0);
@@ -333,15 +333,18 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
     memcpy(out_off.data(), W.h_meta.p, (n + 1) * 8);
     const uint64_t total = out_off[n];
     NS_TRY(W.out.reserve(total * 16 + 16));
-    NS_TRY(pinned_reserve(W.h_out, W.h_out_cap, total * 16 + 16));
+    NS_CHECK(out_buf == 0 || out_buf == 1, NSGPU_ERR_ARG, "gpu_mm_sketch: output buffer 0 or 1");
+    uint8_t *&h_out = out_buf ? W.h_out2 : W.h_out;
+    size_t &h_out_cap = out_buf ? W.h_out2_cap : W.h_out_cap;
+    NS_TRY(pinned_reserve(h_out, h_out_cap, total * 16 + 16));
     if (total) {
         hipLaunchKernelGGL(sk_write_kernel, dim3(gP), dim3(256), 0, st, bt, W.PX.as<uint64_t>(), W.PY.as<uint64_t>(), W.PRUN.as<uint32_t>(), W.PSEQ.as<uint32_t>(),
                            W.pr.as<uint32_t>(), W.rm.as<uint32_t>(), P, W.oscan.as<uint32_t>(), W.out.as<uint64_t>());
         NS_HIP(hipGetLastError());
-        NS_HIP(hipMemcpyAsync(W.h_out, W.out.p, total * 16, hipMemcpyDeviceToHost, st));
+        NS_HIP(hipMemcpyAsync(h_out, W.out.p, total * 16, hipMemcpyDeviceToHost, st));
     }
     NS_HIP(stream_wait_short(st));
-    out = reinterpret_cast<const mm2::Anchor *>(W.h_out);
+    out = reinterpret_cast<const mm2::Anchor *>(h_out);
     c->sketch_mm_ms += now_ms() - t0;
     return NSGPU_OK;
 }
