@@ -1170,7 +1170,7 @@ static bool align1(AlignJob &J, Reg &r_io, Reg &r2, bool plan_only = false)
     const DpKey left_key = {qs0, qs, rs0, rs, bw, r.split_inv ? opt.zdrop_inv : opt.zdrop, opt.end_bonus, EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR};
 
     // the gap-fill windows depend only on the anchors
-    struct Fill { int i; DpKey k1; };
+    struct Fill { int i; DpKey k1; bool zdrop = false; };
     std::vector<Fill> fills;
     {
         int32_t frs = rs, fqs = qs, fre, fqe;
@@ -1180,7 +1180,7 @@ static bool align1(AlignJob &J, Reg &r_io, Reg &r2, bool plan_only = false)
             if (i == cnt1 - 1 || (a[as1 + i].y & SEED_LONG_JOIN) || (fqe - fqs >= opt.min_ksw_len && fre - frs >= opt.min_ksw_len)) {
                 int bw1 = bw;
                 if (a[as1 + i].y & SEED_LONG_JOIN) bw1 = fqe - fqs > fre - frs ? fqe - fqs : fre - frs;
-                fills.push_back({i, {fqs, fqe, frs, fre, bw1, opt.zdrop, -1, EZ_APPROX_MAX}});
+                fills.push_back(Fill{i, {fqs, fqe, frs, fre, bw1, opt.zdrop, -1, EZ_APPROX_MAX}, false});
                 frs = fre, fqs = fqe;
             }
         }
@@ -1188,10 +1188,11 @@ static bool align1(AlignJob &J, Reg &r_io, Reg &r2, bool plan_only = false)
     // ---- plan ----
     bool missing = false;
     if (do_left && !J.cache.get(left_key)) missing = true;
-    for (const Fill &f : fills) {
+    for (Fill &f : fills) {
         const DpResult *r1 = J.cache.get(f.k1);
         if (!r1) { missing = true; continue; }
-        if (test_zdrop(opt, qseq0 + f.k1.qs, tseq_all + f.k1.rs, J.cache.cigar(*r1), mat.m) != 0) {
+        f.zdrop = test_zdrop(opt, qseq0 + f.k1.qs, tseq_all + f.k1.rs, J.cache.cigar(*r1), mat.m) != 0;   // the execute pass below re-uses it
+        if (f.zdrop) {
             DpKey k2 = f.k1;
             k2.flag = 0;
             if (!J.cache.get(k2)) missing = true;
@@ -1223,7 +1224,7 @@ static bool align1(AlignJob &J, Reg &r_io, Reg &r2, bool plan_only = false)
         if (i == cnt1 - 1 || (a[as1 + i].y & SEED_LONG_JOIN) || (qe - qs >= opt.min_ksw_len && re - rs >= opt.min_ksw_len)) {
             const Fill &f = fills[fi++];
             const DpResult *ez = &J.cache.at(f.k1);
-            if (test_zdrop(opt, qseq0 + qs, tseq_all + rs, J.cache.cigar(*ez), mat.m) != 0) {
+            if (f.zdrop) {                             // test_zdrop of this fill's first result, decided in the plan pass above (qs == f.k1.qs, rs == f.k1.rs)
                 DpKey k2 = f.k1;
                 k2.flag = 0;
                 ez = &J.cache.at(k2);
