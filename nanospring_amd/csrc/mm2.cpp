@@ -333,7 +333,16 @@ static void collect_seeds(const RefIndex &ri, const Anchor *mv, size_t n_mv, std
             a.push_back(s);
         }
     }
-    radix_sort_128x(a.data(), a.data() + a.size());
+    // minimap2 sorts the anchors with its (unstable) radix sort; where all keys differ every correct sort gives the same
+    // array, and a comparison sort of a few hundred nearly sorted anchors is several times faster than the radix passes over
+    // the empty high bytes.  Equal keys (one reference position hit by two query minimizers) fall back to the reference's
+    // algorithm on the original order, whose tie order is what the chaining then sees.
+    static thread_local std::vector<Anchor> orig;
+    orig.assign(a.begin(), a.end());
+    std::sort(a.begin(), a.end(), [](const Anchor &p, const Anchor &q) { return p.x < q.x; });
+    bool ties = false;
+    for (size_t i = 1; i < a.size(); ++i) if (a[i].x == a[i - 1].x) { ties = true; break; }
+    if (ties) { a.assign(orig.begin(), orig.end()); radix_sort_128x(a.data(), a.data() + a.size()); }
 }
 
 // ---------------------------------------------------------------------------
