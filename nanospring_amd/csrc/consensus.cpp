@@ -881,7 +881,21 @@ void ContigGraph::write_reads(StreamSet &o, const std::function<ReadBases(read_t
     main_edges.front()->source->cum_weight = 0;
     const size_t n_main = main_edges.size();
     main_nodes_.resize(n_main + 1);
+    next_fork_.resize(n_main + 1);
+    side_mask_.assign(n_main + 1, 0);
+    // one pass over the path's nodes while their lines are at hand: index, fork flag, bases of the side branches (from the
+    // out-edge references; no edge or sink is touched)
+    auto note = [&](size_t j, const Node *n) {
+        const bool single = n->out.size() == 1 && j < n_main;
+        next_fork_[j] = single ? UINT32_MAX : (uint32_t)j;
+        if (single) return;
+        const Edge *path_edge = j < n_main ? main_edges[j] : nullptr;
+        uint8_t m = 0;
+        for (const OutRef &o : n->out) if (o.get() != path_edge) m |= base_bit(o.sink_base());
+        side_mask_[j] = m;
+    };
     main_nodes_[0] = main_edges.front()->source;
+    note(0, main_nodes_[0]);
     for (size_t t = 0; t < n_main; ++t) {
         // two dependent misses per position (edge, then its sink): keep both in flight ahead of the loop
         if (t + 16 < n_main) __builtin_prefetch(main_edges[t + 16], 0, 1);
@@ -889,27 +903,9 @@ void ContigGraph::write_reads(StreamSet &o, const std::function<ReadBases(read_t
         Node *n = main_edges[t]->sink;
         n->cum_weight = t + 1;
         main_nodes_[t + 1] = n;
+        note(t + 1, n);
     }
-    next_fork_.resize(n_main + 1);
-    next_fork_[n_main] = (uint32_t)n_main;
-    for (size_t j = n_main; j-- > 0;) {
-        if (j >= 8) __builtin_prefetch(main_nodes_[j - 8], 0, 1);
-        next_fork_[j] = main_nodes_[j]->out.size() != 1 ? (uint32_t)j : next_fork_[j + 1];
-    }
-    side_mask_.assign(n_main + 1, 0);
-    for (size_t j = 0; j <= n_main; ++j) {
-        if (j + 8 <= n_main) {
-            const Node *a = main_nodes_[j + 8];
-            __builtin_prefetch(a, 0, 1);
-            if (j + 4 <= n_main) { const Node *b = main_nodes_[j + 4]; if (b->out.size() != 1) for (const Edge *e : b->out) __builtin_prefetch(e, 0, 1); }
-        }
-        const Node *n = main_nodes_[j];
-        if (n->out.size() == 1 && j < n_main) continue;
-        const Edge *path_edge = j < n_main ? main_edges[j] : nullptr;
-        uint8_t m = 0;
-        for (const OutRef &o : n->out) if (o.get() != path_edge) m |= base_bit(o.sink_base());
-        side_mask_[j] = m;
-    }
+    for (size_t j = n_main; j-- > 0;) if (next_fork_[j] == UINT32_MAX) next_fork_[j] = next_fork_[j + 1];
     g_emit_ns[0] += emit_now() - e0;
     read_t prev = 0;
     for (auto &it : reads) {
