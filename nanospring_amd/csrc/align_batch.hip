@@ -476,7 +476,10 @@ int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs)
 {
     using namespace mm2;
     const size_t n_pairs = B.reqs.size();
-    outs.assign(n_pairs, AlnOut());
+    // the result objects keep their vectors (the caller swaps them with the builders' previous results): no 64 KB edit list is
+    // allocated on one thread and freed on another per alignment
+    if (outs.size() < n_pairs) outs.resize(n_pairs);
+    for (size_t i = 0; i < n_pairs; ++i) outs[i].reset();
     if (n_pairs == 0) return NSGPU_OK;
     const KswParams kp = batch_ksw_params(batch_opt(c));
     const double f0 = now_ms();

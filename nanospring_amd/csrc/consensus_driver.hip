@@ -513,7 +513,7 @@ static int engine_batches_finish(nsgpu_ctx *c, int group)
     NS_TRY(align_finish(c, E->ab[gi], E->outs));
     for (size_t w = 0; w < who.size(); ++w) {
         Builder &b = D.B[who[w]];
-        b.aln = std::move(E->outs[w]);
+        std::swap(b.aln, E->outs[w]);              // the builder's previous result goes back into the pool of result objects
         ++b.n_align_calls;
         b.accepted = false;
         b.st = Builder::ALIGNED;
@@ -713,6 +713,13 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
                              (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
         fprintf(stderr, "[cons] serial CPU ms of the role threads (outside pool loops): host %.0f, sketches + index %.0f, batches part 1 %.0f, part 2 %.0f\n",
                 E->role_serial_ns[0] / 1e6, E->role_serial_ns[1] / 1e6, E->role_serial_ns[2] / 1e6, E->role_serial_ns[3] / 1e6);
+        if (FILE *f = fopen("/proc/self/smaps_rollup", "r")) {       // are the graph slabs really on huge pages?
+            char line[256];
+            long rss = 0, thp = 0;
+            while (fgets(line, sizeof(line), f)) { sscanf(line, "Rss: %ld kB", &rss); sscanf(line, "AnonHugePages: %ld kB", &thp); }
+            fclose(f);
+            fprintf(stderr, "[cons] resident %.1f GB, of it on transparent huge pages %.1f GB\n", rss / 1048576.0, thp / 1048576.0);
+        }
         pool_prof_print();
         fprintf(stderr, "[cons] part 2 wall-ms: wait for the DP in flight %.0f, later rounds %.0f (their DP %.0f, %d rounds), results %.0f\n", g_finish_ms[0], g_finish_ms[1],
                 g_finish_ms[2], (int)g_finish_ms[4], g_finish_ms[3]);

@@ -1333,12 +1333,12 @@ bool AlignJob::step()
 void edits_from_hit(int hits, int rs, int re, int qs, int qe, int blen, int mlen, int n_ambi, int dp_max, bool has_p,
                     const std::vector<uint32_t> &cigar, const char *ref, size_t ref_len, const char *s, size_t slen, AlnOut &out)
 {
-    out = AlnOut();
+    out.reset();
     out.hits = hits;
     if (hits <= 0) return;
     out.rs = rs, out.re = re, out.qs = qs, out.qe = qe, out.blen = blen, out.mlen = mlen;
     out.n_ambi = n_ambi, out.dp_max = dp_max;
-    out.cigar = cigar;
+    out.cigar.assign(cigar.begin(), cigar.end());
     out.n_cigar = has_p ? (int32_t)cigar.size() : -1;
     const size_t edit_dis = (size_t)(blen - mlen + n_ambi);
     const int aligned_len = qe - qs;
@@ -1391,7 +1391,7 @@ void edits_from_hit(int hits, int rs, int re, int qs, int qe, int blen, int mlen
 
 void align_read_result(const AlignJob &job, const char *ref, size_t ref_len, AlnOut &out)
 {
-    if (job.regs.empty()) { out = AlnOut(); return; }
+    if (job.regs.empty()) { out.reset(); return; }
     const Reg &r = job.regs[0];
     edits_from_hit((int)job.regs.size(), r.rs, r.re, r.qs, r.qe, r.blen, r.mlen, (int)r.p.n_ambi, r.p.dp_max, r.has_p, r.p.cigar, ref, ref_len,
                    job.qstr, (size_t)job.qlen, out);

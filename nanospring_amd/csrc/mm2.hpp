@@ -150,6 +150,8 @@ struct AlnOut {
     int32_t rs = 0, re = 0, qs = 0, qe = 0, blen = 0, mlen = 0, n_ambi = 0, dp_max = 0, n_cigar = 0;
     std::vector<uint32_t> cigar;
     std::vector<EditOp> edits;
+    // back to the default state, keeping the vectors' storage (results are recycled between builders and batches)
+    void reset() { ok = hits = 0; rel_pos = begin_offset = end_offset = 0; rs = re = qs = qe = blen = mlen = n_ambi = dp_max = n_cigar = 0; cigar.clear(); edits.clear(); }
 };
 void align_read_result(const AlignJob &job, const char *ref, size_t ref_len, AlnOut &out);
 void edits_from_hit(int hits, int rs, int re, int qs, int qe, int blen, int mlen, int n_ambi, int dp_max, bool has_p,
