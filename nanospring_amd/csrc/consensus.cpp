@@ -195,9 +195,11 @@ Edge *ContigGraph::create_edge(Node *s, Node *t, read_t r)
 {
     Edge *e = edges_.make();
     e->source = s, e->sink = t, e->count = 1, e->reads.push_back(arena_, r);
-    n_multi_in_side_ -= multi_in_side(t);
+    const bool was_multi = multi_in_side(t);
+    n_multi_in_side_ -= was_multi;
     s->out.push_back(arena_, OutRef(e, t->base)), t->in.push_back(arena_, e);
     n_multi_in_side_ += multi_in_side(t);
+    note_multi(t, was_multi);
     ++n_edges_;
     return e;
 }
@@ -205,9 +207,11 @@ Edge *ContigGraph::create_edge(Node *s, Node *t, const std::vector<read_t> &rs)
 {
     Edge *e = edges_.make();
     e->source = s, e->sink = t, e->reads.assign(arena_, rs.data(), rs.size()), e->count = (read_t)rs.size();
-    n_multi_in_side_ -= multi_in_side(t);
+    const bool was_multi = multi_in_side(t);
+    n_multi_in_side_ -= was_multi;
     s->out.push_back(arena_, OutRef(e, t->base)), t->in.push_back(arena_, e);
     n_multi_in_side_ += multi_in_side(t);
+    note_multi(t, was_multi);
     ++n_edges_;
     return e;
 }
@@ -230,6 +234,8 @@ void ContigGraph::remove_edge(Edge *e, bool keep_in_source, bool keep_in_sink)
 }
 void ContigGraph::remove_node(Node *n)
 {
+    for (size_t i = 0; i < multi_in_list_.size();)          // the node's memory is recycled: no stale pointer may stay behind
+        if (multi_in_list_[i] == n) multi_in_list_[i] = multi_in_list_.back(), multi_in_list_.pop_back(); else ++i;
     n_multi_in_side_ -= multi_in_side(n);
     n->on_main = true;      // keeps the counter untouched while the node's edges go away
     for (Edge *e : std::vector<Edge *>(n->in.begin(), n->in.end())) remove_edge(e, false, true);
@@ -605,7 +611,9 @@ void ContigGraph::remove_cycles()
 {
     ++dbg_cycles_calls;
     static const bool no_skip = getenv("NSGPU_NO_CYCLE_SKIP") != nullptr;       // debugging aid: always walk, as the reference does
-    if (n_multi_in_side_ == 0 && !no_skip) { ++dbg_cycles_skipped; return; }   // exact: walk_and_prune only ever acts on side nodes with in-degree > 1
+    if (n_multi_in_side_ == 0 && !no_skip) { ++dbg_cycles_skipped; multi_in_list_.clear(); return; }   // exact: walk_and_prune only ever acts on side nodes with in-degree > 1
+    static const bool full_scan = getenv("NSGPU_CYCLE_FULLSCAN") != nullptr;   // debugging aid: always the reference's walk over every side branch
+    if (!no_skip && !full_scan && remove_cycles_from_list()) { ++dbg_cycles_listed; return; }
     std::vector<Edge *> stack;
     {
         size_t ei = right_off_;
@@ -642,6 +650,87 @@ void ContigGraph::remove_cycles()
             if (ei == 0) break;
             --ei;
         }
+    }
+}
+
+// removeCycles without the search.  The reference walks every side branch of the scanned main-path ranges depth-first and
+// splits at each side edge whose sink (still) has in-degree > 1.  The nodes with that property are known (multi_in_list_);
+// every edge at which a split can happen lies on a path main node -> ... -> such a node, i.e. its sink is an ancestor-or-self
+// of one of them.  So: mark those (walking in-edges backwards; side nodes other than the listed ones have exactly one),
+// collect the main-path nodes the marked branches hang off, and run the reference's walk from those nodes only, in the
+// reference's order (first loop: path order from right_off_; second loop: backwards from left_off_), descending only into
+// marked nodes.  The visited edges are a subsequence of the reference's walk that contains every edge it can split at, in
+// the same order; splits create no new node of that kind (split_path gives private copies), so the marks stay a superset.
+bool ContigGraph::remove_cycles_from_list()
+{
+    // the listed nodes that still qualify, each once
+    std::vector<Node *> &L = multi_in_list_;
+    ++scan_epoch_;
+    if (scan_epoch_ == 0) return false;                      // epoch wrapped: one full walk, marks of 2^32 calls ago may linger
+    size_t k = 0;
+    for (Node *n : L) if (multi_in_side(n) && n->reserved_ != scan_epoch_) { n->reserved_ = scan_epoch_; L[k++] = n; }
+    L.resize(k);
+    if (k != n_multi_in_side_) return false;                 // something the list does not know about: the full walk decides
+    // ancestors
+    std::vector<Node *> todo(L.begin(), L.end()), roots;
+    while (!todo.empty()) {
+        Node *n = todo.back();
+        todo.pop_back();
+        for (Edge *e : n->in) {
+            Node *s = e->source;
+            if (s->reserved_ == scan_epoch_) continue;
+            s->reserved_ = scan_epoch_;
+            if (s->on_main) roots.push_back(s); else todo.push_back(s);
+        }
+    }
+    if (roots.empty()) return true;                          // not reachable from the path at all: the full walk would find nothing either
+    // positions of the roots on the path: the path's edge array is searched for the roots' out-edges (no node is touched)
+    const size_t m = main_edges.size();
+    struct Hit { size_t idx; Node *n; };
+    std::vector<Hit> hits;
+    {
+        std::vector<const Edge *> outs;
+        uint64_t bloom = 0;
+        for (Node *r : roots) for (const OutRef &o : r->out) { outs.push_back(o.get()); bloom |= 1ull << ((reinterpret_cast<uintptr_t>(o.get()) >> 6) & 63); }
+        Edge *const *pe = main_edges.begin();
+        auto scan = [&](size_t lo, size_t hi) {                // path edges lo .. hi-1: their sources are path nodes lo .. hi-1
+            for (size_t i = lo; i < hi; ++i) {
+                const Edge *e = pe[i];
+                if (!((bloom >> ((reinterpret_cast<uintptr_t>(e) >> 6) & 63)) & 1)) continue;
+                if (std::find(outs.begin(), outs.end(), e) == outs.end()) continue;
+                hits.push_back(Hit{i, e->source});
+            }
+        };
+        const size_t left_end = left_off_ < m ? left_off_ + 1 : m;      // second loop: edges left_off_ (or m - 1) down to 0
+        if (right_off_ < left_end) scan(0, m);
+        else { scan(0, left_end); scan(right_off_, m); }
+        Node *last = main_edges[m - 1]->sink;                  // the path's last node has no path edge of its own
+        if (last->reserved_ == scan_epoch_) hits.push_back(Hit{m, last});
+    }
+    std::vector<Edge *> stack, copy;
+    auto run = [&](Node *n) {
+        copy.assign(n->out.begin(), n->out.end());
+        for (Edge *e : copy) walk_and_prune_marked(e, stack);
+    };
+    // first loop of the reference: nodes right_off_ .. m in path order
+    std::sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.idx < b.idx; });
+    for (const Hit &h : hits) if (h.idx >= right_off_) run(h.n);
+    // second loop: sources of edges min(left_off_, m - 1) .. 0, backwards
+    const size_t l0 = left_off_ < m ? left_off_ : m - 1;
+    for (size_t i = hits.size(); i-- > 0;) if (hits[i].idx <= l0 && hits[i].idx < m) run(hits[i].n);
+    return true;
+}
+
+void ContigGraph::walk_and_prune_marked(Edge *e, std::vector<Edge *> &stack)
+{
+    stack.push_back(e);
+    while (!stack.empty()) {
+        Edge *curr = stack.back();
+        stack.pop_back();
+        Node *sink = curr->sink, *source = curr->source;
+        if (sink->on_main || sink->reserved_ != scan_epoch_) continue;      // nothing below an unmarked node can be split
+        if (sink->in.size() > 1) split_path(source, curr, std::vector<read_t>(curr->reads.begin(), curr->reads.end()));
+        for (Edge *o : sink->out) stack.push_back(o);
     }
 }
 

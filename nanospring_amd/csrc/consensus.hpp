@@ -250,9 +250,22 @@ private:
     size_t consistent_from_ = (size_t)-1;     // main-path nodes with index >= this were chosen by best_out on the current counts
     uint64_t n_splits_ = 0;
     static bool multi_in_side(const Node *n) { return !n->on_main && n->in.size() > 1; }
-    void set_on_main(Node *n, bool v) { n_multi_in_side_ -= multi_in_side(n); n->on_main = v; n_multi_in_side_ += multi_in_side(n); }
+    // every node that becomes a side node with in-degree > 1 is noted: remove_cycles then starts from these instead of
+    // walking every side branch to find them (entries may be stale; they are re-checked, and the counter is the referee)
+    std::vector<Node *> multi_in_list_;
+    uint32_t scan_epoch_ = 0;                  // Node::reserved_ == scan_epoch_: marked by the current remove_cycles call
+    void note_multi(Node *n, bool was) { if (!was && multi_in_side(n)) multi_in_list_.push_back(n); }
+    void set_on_main(Node *n, bool v)
+    {
+        const bool was = multi_in_side(n);
+        n_multi_in_side_ -= was; n->on_main = v; n_multi_in_side_ += multi_in_side(n);
+        note_multi(n, was);
+    }
+    bool remove_cycles_from_list();            // false: the list does not account for every such node, do the full walk
+    void walk_and_prune_marked(Edge *e, std::vector<Edge *> &stack);
 public:
     uint64_t dbg_cycles_calls = 0, dbg_cycles_skipped = 0, dbg_spliced = 0, dbg_spliced_nodes = 0, dbg_walked_nodes = 0, dbg_cycles_idle = 0;
+    uint64_t dbg_cycles_listed = 0;            // remove_cycles calls served from multi_in_list_ (no walk over the side branches)
     double dbg_cycles_ms = 0;
 private:
     Arena arena_;

@@ -81,7 +81,7 @@ struct Builder {
     uint64_t n_minhash = 0, n_minhash_new = 0, n_aligner = 0, n_align_calls = 0, n_contigs = 0, n_lone = 0;
     double cpu_ms = 0, max_ms = 0, last_ms = 0, write_ms = 0, dbg_w1 = 0, dbg_w2 = 0, dbg_w3 = 0, dbg_u = 0, dbg_m = 0, dbg_cyc = 0, dbg_init = 0, dbg_rc = 0, dbg_win = 0, dbg_start = 0, dbg_max_u = 0, dbg_max_m = 0, dbg_long_ms = 0;
     uint64_t dbg_long_n = 0;
-    uint64_t dbg_c[5] = {0, 0, 0, 0, 0};
+    uint64_t dbg_c[6] = {0, 0, 0, 0, 0, 0};
 };
 
 struct Driver {
@@ -130,7 +130,7 @@ struct Driver {
             b.g.reset();
         } else {
             b.dbg_cyc += g.dbg_cycles_ms;
-            b.dbg_c[0] += g.dbg_cycles_calls, b.dbg_c[1] += g.dbg_cycles_skipped, b.dbg_c[2] += g.dbg_spliced, b.dbg_c[3] += g.dbg_cycles_idle, b.dbg_c[4] += g.dbg_walked_nodes;
+            b.dbg_c[0] += g.dbg_cycles_calls, b.dbg_c[1] += g.dbg_cycles_skipped, b.dbg_c[2] += g.dbg_spliced, b.dbg_c[3] += g.dbg_cycles_idle, b.dbg_c[4] += g.dbg_walked_nodes, b.dbg_c[5] += g.dbg_cycles_listed;
             fc->g = std::move(b.g);
         }
         b.contigs.push_back(std::move(fc));
@@ -570,14 +570,14 @@ static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
     for (size_t i = 0; i < D.B.size(); ++i)
         for (auto &fc : D.B[i].contigs) c->cons_out[i * n_threads_out / (D.B.empty() ? 1 : D.B.size())].append(fc->out);
     double dbg_w[6] = {0, 0, 0, 0, 0, 0}, dbg_x[4] = {0, 0, 0, 0};
-    uint64_t dbg_c[5] = {0, 0, 0, 0, 0};
+    uint64_t dbg_c[6] = {0, 0, 0, 0, 0, 0};
     for (Builder &b : D.B) {
         S.n_contigs += b.n_contigs; S.n_lone += b.n_lone; S.count_minhash += b.n_minhash; S.count_minhash_not_in_graph += b.n_minhash_new;
         S.count_aligner += b.n_aligner; S.n_align_calls += b.n_align_calls;
         S.graph_cpu_ms += b.cpu_ms; if (b.max_ms > S.graph_max_ms) S.graph_max_ms = b.max_ms;
         for (auto &fc : b.contigs) S.write_cpu_ms += fc->write_ms, dbg_w[1] += fc->write_ms, dbg_w[2] += fc->free_ms;
         dbg_w[0] += b.dbg_w1, dbg_w[3] += b.dbg_u, dbg_w[4] += b.dbg_m, dbg_w[5] += b.dbg_cyc;
-        for (int k = 0; k < 5; ++k) dbg_c[k] += b.dbg_c[k];
+        for (int k = 0; k < 6; ++k) dbg_c[k] += b.dbg_c[k];
         dbg_x[0] += b.dbg_init, dbg_x[1] += b.dbg_rc, dbg_x[2] += b.dbg_win, dbg_x[3] += b.dbg_start;
     }
     if (getenv("NSGPU_CONS_DEBUG")) {
@@ -587,8 +587,8 @@ static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
     }
     if (getenv("NSGPU_CONS_DEBUG")) fprintf(stderr, "[cons] cpu-ms: graph total %.0f; initialize+first main path %.0f, query copy/revcomp %.0f, open_window %.0f, start_contig %.0f\n", S.graph_cpu_ms, dbg_x[0], dbg_x[1], dbg_x[2], dbg_x[3]);
     if (getenv("NSGPU_CONS_DEBUG"))
-        fprintf(stderr, "[cons] cpu-ms: update_graph %.0f main_path %.0f (remove_cycles %.0f) write_main %.0f write_reads %.0f graph_free %.0f; main-path calls %llu cycles-skipped %llu detours %llu cycle-scans-without-split %llu walked-nodes %llu\n",
-                dbg_w[3], dbg_w[4], dbg_w[5], dbg_w[0], dbg_w[1], dbg_w[2], (unsigned long long)dbg_c[0], (unsigned long long)dbg_c[1], (unsigned long long)dbg_c[2], (unsigned long long)dbg_c[3], (unsigned long long)dbg_c[4]);
+        fprintf(stderr, "[cons] cpu-ms: update_graph %.0f main_path %.0f (remove_cycles %.0f) write_main %.0f write_reads %.0f graph_free %.0f; main-path calls %llu cycles-skipped %llu detours %llu cycle-scans-without-split %llu walked-nodes %llu cycle-scans-from-list %llu\n",
+                dbg_w[3], dbg_w[4], dbg_w[5], dbg_w[0], dbg_w[1], dbg_w[2], (unsigned long long)dbg_c[0], (unsigned long long)dbg_c[1], (unsigned long long)dbg_c[2], (unsigned long long)dbg_c[3], (unsigned long long)dbg_c[4], (unsigned long long)dbg_c[5]);
     S.total_ms = now_ms() - E->t0;
     c->cons_n_reads_out = 0;
     for (auto &t : c->cons_out) for (read_t x : t.reads_in_contig) c->cons_n_reads_out += x;
