@@ -61,3 +61,10 @@ def test_shortcuts_change_nothing(kind, seed):
     literal = run(kind, seed, NSGPU_NO_CYCLE_SKIP="1", NSGPU_NO_TAIL_SPLICE="1", NSGPU_NO_RUN_FASTPATH="1")
     assert fast == literal
     assert fast[1] > 100
+
+
+@pytest.mark.parametrize("kind,seed", [("repeats", 21), ("repeats", 28), ("long", 3)])
+def test_cycle_pruning_from_the_noted_nodes_equals_the_full_walk(kind, seed):
+    """remove_cycles served from the list of noted multi-in side nodes (default) against the reference's walk over every
+    side branch (NSGPU_CYCLE_FULLSCAN=1), everything else equal."""
+    assert run(kind, seed) == run(kind, seed, NSGPU_CYCLE_FULLSCAN="1")
