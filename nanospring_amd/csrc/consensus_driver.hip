@@ -30,6 +30,7 @@
 namespace nsgpu {
 namespace mm2 { extern std::atomic<uint64_t> g_step_ns[6]; }
 extern double g_finish_ms[5];
+extern double g_sketch_ms[6];
 namespace cons { extern std::atomic<uint64_t> g_emit_ns[4]; }
 
 using cons::read_t;
@@ -724,6 +725,9 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
         fprintf(stderr, "[cons] part 2 wall-ms: wait for the DP in flight %.0f, later rounds %.0f (their DP %.0f, %d rounds), results %.0f\n", g_finish_ms[0], g_finish_ms[1],
                 g_finish_ms[2], (int)g_finish_ms[4], g_finish_ms[3]);
         for (double &x : g_finish_ms) x = 0;
+        fprintf(stderr, "[cons] gpu mm_sketch wall-ms: host staging %.0f, flags..k-mers (1st read-back) %.0f, pushes..offsets (2nd) %.0f, write + read-back %.0f; %.0f MB in, %.1f M minimizers out\n",
+                g_sketch_ms[0], g_sketch_ms[1], g_sketch_ms[2], g_sketch_ms[3], g_sketch_ms[4] / 1e6, g_sketch_ms[5] / 1e6);
+        for (double &x : g_sketch_ms) x = 0;
         const double sys_s = (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
         fprintf(stderr, "[cons] process CPU time over the stage: %.1f s (%.1f s of it in the kernel; %ld minor faults) = %.1f cores busy on average\n", cpu_s, sys_s,
                 ru1.ru_minflt - ru0.ru_minflt, cpu_s / ((now_ms() - E->t0) * 1e-3));

@@ -254,6 +254,9 @@ static int scan_u32(nsgpu_ctx::SketchWs &W, hipStream_t st, const uint32_t *in, 
     return NSGPU_OK;
 }
 
+// debug breakdown (one caller at a time): host staging, up to the push count, up to the offsets, write + read-back; bytes in, minimizers out
+double g_sketch_ms[6];
+
 int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int out_buf)
 {
     const size_t n = reqs.size();
@@ -281,6 +284,7 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
     // sequences through pinned memory, one H2D copy (padding bytes are never interpreted)
     NS_TRY(pinned_reserve(W.h_seqs, W.h_cap, bytes + 16));
     par_for("sketch.stage", n, [&](size_t i) { memcpy(W.h_seqs + soff[i], reqs[i].ptr, reqs[i].len); });
+    const double t_staged = now_ms();
     DevBuf *u32bufs[] = {&W.vf, &W.mk, &W.vr, &W.linv, &W.npf, &W.pushf, &W.npr, &W.pr};
     for (DevBuf *b : u32bufs) NS_TRY(b->reserve(((size_t)B + 2) * 4));
     NS_TRY(W.seqs.reserve(bytes + 64));
@@ -309,6 +313,7 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
     NS_HIP(hipMemcpyAsync(W.h_meta.p, W.pr.as<uint32_t>() + B, 4, hipMemcpyDeviceToHost, st));
     NS_HIP(stream_wait_short(st));
     const uint32_t P = *W.h_meta.as<uint32_t>();                         // pushes of the whole batch
+    const double t1 = now_ms();
     NS_TRY(W.PX.reserve(((size_t)P + 1) * 8));
     NS_TRY(W.PY.reserve(((size_t)P + 1) * 8));
     NS_TRY(W.PRUN.reserve(((size_t)P + 2) * 4));
@@ -332,6 +337,7 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
     NS_HIP(stream_wait_short(st));
     memcpy(out_off.data(), W.h_meta.p, (n + 1) * 8);
     const uint64_t total = out_off[n];
+    const double t2 = now_ms();
     NS_TRY(W.out.reserve(total * 16 + 16));
     NS_CHECK(out_buf == 0 || out_buf == 1, NSGPU_ERR_ARG, "gpu_mm_sketch: output buffer 0 or 1");
     uint8_t *&h_out = out_buf ? W.h_out2 : W.h_out;
@@ -346,6 +352,7 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
     NS_HIP(stream_wait_short(st));
     out = reinterpret_cast<const mm2::Anchor *>(h_out);
     c->sketch_mm_ms += now_ms() - t0;
+    g_sketch_ms[0] += t_staged - t0, g_sketch_ms[1] += t1 - t_staged, g_sketch_ms[2] += t2 - t1, g_sketch_ms[3] += now_ms() - t2, g_sketch_ms[4] += (double)bytes, g_sketch_ms[5] += (double)total;
     return NSGPU_OK;
 }
 
