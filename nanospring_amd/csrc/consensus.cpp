@@ -160,12 +160,19 @@ void Arena::release(void *p, unsigned cls)
 void Edge::add_read(Arena &a, read_t r)
 {
     ++count;
-    const read_t *b = reads.begin();
-    size_t n = reads.size(), i;
-    if (n == 0 || b[n - 1] < r) i = n;                                   // the common case while a contig grows: ids above all present
-    else if (n <= 8) { i = 0; while (b[i] < r) ++i; }
-    else i = (size_t)(std::lower_bound(b, b + n, r) - b);
-    reads.insert_at(a, i, r);
+    const uint32_t n = reads.n;
+    if (sorted_n == n && (n == 0 || reads.data()[n - 1] < r)) sorted_n = n + 1;      // still ascending
+    reads.push_back(a, r);
+}
+
+void Edge::sort_reads()
+{
+    const uint32_t n = reads.n;
+    if (sorted_n == n) return;
+    read_t *b = reads.data();
+    std::sort(b + sorted_n, b + n);
+    if (sorted_n) std::inplace_merge(b, b + sorted_n, b + n);
+    sorted_n = n;
 }
 
 Edge *Node::edge_to(Node *n) const { for (Edge *e : out) if (e->sink == n) return e; return nullptr; }
@@ -181,6 +188,7 @@ Edge *Node::best_in() const { Edge *best = nullptr; read_t c = 0; for (Edge *e :
 Edge *Node::edge_in_read(read_t r) const
 {
     for (Edge *e : out) {
+        e->sort_reads();
         const read_t *b = e->reads.data();
         size_t n = e->reads.size();
         if (n == 0 || r < b[0] || r > b[n - 1]) continue;
@@ -194,7 +202,7 @@ Node *ContigGraph::create_node(char b) { ++n_nodes_; return nodes_.make(b); }
 Edge *ContigGraph::create_edge(Node *s, Node *t, read_t r)
 {
     Edge *e = edges_.make();
-    e->source = s, e->sink = t, e->count = 1, e->reads.push_back(arena_, r);
+    e->source = s, e->sink = t, e->count = 1, e->reads.push_back(arena_, r), e->sorted_n = 1;
     const bool was_multi = multi_in_side(t);
     n_multi_in_side_ -= was_multi;
     s->out.push_back(arena_, OutRef(e, t->base)), t->in.push_back(arena_, e);
@@ -206,7 +214,7 @@ Edge *ContigGraph::create_edge(Node *s, Node *t, read_t r)
 Edge *ContigGraph::create_edge(Node *s, Node *t, const std::vector<read_t> &rs)
 {
     Edge *e = edges_.make();
-    e->source = s, e->sink = t, e->reads.assign(arena_, rs.data(), rs.size()), e->count = (read_t)rs.size();
+    e->source = s, e->sink = t, e->reads.assign(arena_, rs.data(), rs.size()), e->count = (read_t)rs.size(), e->sorted_n = (uint32_t)rs.size();    // rs is ascending
     const bool was_multi = multi_in_side(t);
     n_multi_in_side_ -= was_multi;
     s->out.push_back(arena_, OutRef(e, t->base)), t->in.push_back(arena_, e);
@@ -247,8 +255,10 @@ void ContigGraph::remove_node(Node *n)
 void ContigGraph::remove_reads_from_edge(Edge *e, const std::vector<read_t> &rs)
 {
     // in place: the output never overtakes the input of a set difference
+    e->sort_reads();
     read_t *w = std::set_difference(e->reads.begin(), e->reads.end(), rs.begin(), rs.end(), e->reads.begin());
     e->reads.n = (uint32_t)(w - e->reads.begin());
+    e->sorted_n = e->reads.n;
     e->count = (read_t)e->reads.size();
     if (e->count == 0) remove_edge(e);
 }
@@ -541,6 +551,7 @@ void ContigGraph::calculate_main_path_greedy()
                 c2 = bo->sink;
             }
         }
+        main_edges.back()->sort_reads();
         const read_t ending = *main_edges.back()->reads.begin();
         const GraphRead &er = reads.at(ending);
         end_pos = er.pos + (long)er.len;
@@ -558,6 +569,7 @@ void ContigGraph::calculate_main_path_greedy()
             main_path.push_back(cur->base);
             ++dbg_walked_nodes;
         }
+        main_edges.back()->sort_reads();
         const read_t ending = *main_edges.back()->reads.begin();
         const GraphRead &er = reads.at(ending);
         end_pos = er.pos + (long)er.len;
@@ -579,6 +591,7 @@ void ContigGraph::calculate_main_path_greedy()
             std::reverse(prefix.begin(), prefix.end());
             main_path.insert(0, prefix);
         }
+        main_edges.front()->sort_reads();
         const read_t starting = *main_edges.front()->reads.begin();
         start_pos = reads.at(starting).pos;
     }
@@ -729,7 +742,7 @@ void ContigGraph::walk_and_prune_marked(Edge *e, std::vector<Edge *> &stack)
         stack.pop_back();
         Node *sink = curr->sink, *source = curr->source;
         if (sink->on_main || sink->reserved_ != scan_epoch_) continue;      // nothing below an unmarked node can be split
-        if (sink->in.size() > 1) split_path(source, curr, std::vector<read_t>(curr->reads.begin(), curr->reads.end()));
+        if (sink->in.size() > 1) { curr->sort_reads(); split_path(source, curr, std::vector<read_t>(curr->reads.begin(), curr->reads.end())); }
         for (Edge *o : sink->out) stack.push_back(o);
     }
 }
@@ -742,7 +755,7 @@ void ContigGraph::walk_and_prune(Edge *e, std::vector<Edge *> &stack)
         stack.pop_back();
         Node *sink = curr->sink, *source = curr->source;
         if (sink->on_main) continue;
-        if (sink->in.size() > 1) split_path(source, curr, std::vector<read_t>(curr->reads.begin(), curr->reads.end()));
+        if (sink->in.size() > 1) { curr->sort_reads(); split_path(source, curr, std::vector<read_t>(curr->reads.begin(), curr->reads.end())); }
         for (Edge *o : sink->out) stack.push_back(o);
     }
 }
@@ -771,6 +784,7 @@ void ContigGraph::split_path(Node *new_pre0, Edge *e0, const std::vector<read_t>
             if (oc && oc->in.empty() && oc->out.empty()) remove_node(oc);
             continue;
         }
+        c.e->sort_reads();
         std::set_intersection(c.in_reads->begin(), c.in_reads->end(), c.e->reads.begin(), c.e->reads.end(), std::back_inserter(c.own));
         c.visited = true;
         if (c.own.empty()) continue;

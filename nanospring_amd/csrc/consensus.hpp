@@ -131,10 +131,17 @@ constexpr uint32_t kEdgeInlineReads = NSGPU_EDGE_INLINE_READS;
 struct alignas(64) Edge {                     // 64 bytes (8 inline read ids)
     Node *source, *sink;
     read_t count;
-    SmallVec<read_t, kEdgeInlineReads> reads; // ascending
+    // The reference keeps the ids ascending (a std::set).  Here the first `sorted_n` ids are ascending and the rest is in
+    // arrival order: a read follows ~8000 edges and arrives in no particular id order, so inserting in place cost a search
+    // and a shift per edge and base, while most lists are never looked at in order.  Whoever needs the order (edge_in_read,
+    // the set operations of split_path / remove_reads, the smallest id) calls sort_reads() first.
+    uint32_t sorted_n = 0;
+    SmallVec<read_t, kEdgeInlineReads> reads;
     void add_read(Arena &a, read_t r);        // Edge::addRead            (:24-28)
+    void sort_reads();
 };
 static_assert(sizeof(Node) == 64 && sizeof(Edge) % 64 == 0, "graph objects are whole cache lines");
+static_assert(kEdgeInlineReads != 8 || sizeof(Edge) == 64, "an edge with 8 inline read ids is one cache line");
 inline bool OutRef::sink_base_is(char b) const { const unsigned c = code(); return c < 4 ? "ACGT"[c] == b : get()->sink->base == b; }
 inline char OutRef::sink_base() const { const unsigned c = code(); return c < 4 ? "ACGT"[c] : get()->sink->base; }
 
