@@ -348,11 +348,11 @@ double now_ms()
 namespace {
 
 // host step of all live jobs, then the DP tasks they are waiting for: descriptors + sequence pool (pinned)
-int batch_prepare_round(nsgpu_ctx *c, AlignBatch &B)
+int batch_prepare_round(nsgpu_ctx *c, AlignBatch &B, bool stepped = false)
 {
     using namespace mm2;
     const double a0 = now_ms();
-    parallel_for("align.step", B.live.size(), [&](size_t i) { B.jobs[B.live[i]].step(); });
+    if (!stepped) parallel_for("align.step", B.live.size(), [&](size_t i) { B.jobs[B.live[i]].step(); });
     std::vector<uint32_t> still;
     B.t_off.clear(), B.b_off.clear();
     size_t nt = 0, nb = 0;
@@ -438,29 +438,51 @@ KswParams batch_ksw_params(const mm2::Opt &opt)
 
 // Part 1: seeds, chains, the plan of every region's DP problems, and their launch.  B.reqs (and what its pointers refer to)
 // must stay alive until align_finish.
-int align_begin(nsgpu_ctx *c, AlignBatch &B, int ws_index)
+static void batch_start_jobs(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi)
 {
     using namespace mm2;
-    const size_t n_pairs = B.reqs.size();
-    B.ws_index = ws_index, B.in_flight = false;
-    B.host_ms = B.dp_ms = 0, B.dp_tasks = B.rounds = 0;
-    B.live.clear();
-    if (n_pairs == 0) return NSGPU_OK;
     const Opt opt = batch_opt(c);
-    // the job objects (and the capacity of their vectors) are kept from batch to batch: freeing and re-allocating the
-    // ~100 small blocks of every job cost more CPU than the alignment bookkeeping itself
-    if (B.jobs.size() < n_pairs) B.jobs.resize(n_pairs);
-    for (size_t i = 0; i < n_pairs; ++i) {
+    for (size_t i = lo; i < hi; ++i) {
         B.jobs[i].start(B.reqs[i].idx, B.reqs[i].qry, (int)B.reqs[i].qry_len, opt);
         // a query of length 0 has no sketch either way; pre_mz must be non-null to count as "given"
         if (B.reqs[i].qry_mz) B.jobs[i].pre_mz = B.reqs[i].qry_mz, B.jobs[i].n_pre_mz = B.reqs[i].n_qry_mz;
     }
+}
+
+int align_prestep(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi)
+{
+    NS_CHECK(lo <= hi && hi <= B.reqs.size(), NSGPU_ERR_ARG, "align_prestep: bad range");
+    // (B.jobs must not be resized here: another range of the same batch may be in its step on other threads -- the caller sizes it)
+    NS_CHECK(B.jobs.size() >= B.reqs.size(), NSGPU_ERR_ARG, "align_prestep: size B.jobs first");
+    const double a0 = now_ms();
+    batch_start_jobs(c, B, lo, hi);
+    parallel_for("align.step", hi - lo, [&](size_t i) { B.jobs[lo + i].step(); });
+    B.host_ms += now_ms() - a0;
+    B.prestepped = true;
+    return NSGPU_OK;
+}
+
+int align_begin(nsgpu_ctx *c, AlignBatch &B, int ws_index)
+{
+    using namespace mm2;
+    const size_t n_pairs = B.reqs.size();
+    const bool pre = B.prestepped;
+    B.prestepped = false;
+    B.ws_index = ws_index, B.in_flight = false;
+    if (!pre) B.host_ms = 0;
+    B.dp_ms = 0, B.dp_tasks = B.rounds = 0;
+    B.live.clear();
+    if (n_pairs == 0) return NSGPU_OK;
+    // the job objects (and the capacity of their vectors) are kept from batch to batch: freeing and re-allocating the
+    // ~100 small blocks of every job cost more CPU than the alignment bookkeeping itself
+    if (B.jobs.size() < n_pairs) B.jobs.resize(n_pairs);
+    if (!pre) batch_start_jobs(c, B, 0, n_pairs);
     B.live.resize(n_pairs);
     for (size_t i = 0; i < n_pairs; ++i) B.live[i] = (uint32_t)i;
-    NS_TRY(batch_prepare_round(c, B));
+    NS_TRY(batch_prepare_round(c, B, pre));
     if (B.live.empty()) return NSGPU_OK;
     const double a0 = now_ms();
-    NS_TRY(ksw_batch_launch(c, B.tasks, c->kws[ws_index].h_pool, B.nb, batch_ksw_params(opt), B.res, B.cig, B.coff, ws_index));
+    NS_TRY(ksw_batch_launch(c, B.tasks, c->kws[ws_index].h_pool, B.nb, batch_ksw_params(batch_opt(c)), B.res, B.cig, B.coff, ws_index));
     B.dp_ms += now_ms() - a0;
     B.in_flight = true;
     return NSGPU_OK;

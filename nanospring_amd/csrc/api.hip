@@ -164,14 +164,12 @@ void nsgpu_destroy(nsgpu_ctx *c)
     for (DevBuf *b : bufs) b->release();
     c->t_stage.destroy(); c->t_kernel.destroy();
     if (c->cons_engine) c->cons_engine_free(c->cons_engine);
-    {
-        nsgpu_ctx::SketchWs &w = c->sws;
+    for (nsgpu_ctx::SketchWs &w : c->sws) {
         DevBuf *sb[] = {&w.seqs, &w.soff, &w.len, &w.sob, &w.vf, &w.mk, &w.vr, &w.linv, &w.npf, &w.pushf, &w.npr, &w.pr, &w.V, &w.hk, &w.PX, &w.PY, &w.PRUN,
                         &w.PSEQ, &w.rm, &w.nout, &w.oscan, &w.off, &w.out, &w.scan_ws};
         for (DevBuf *b : sb) b->release();
         if (w.h_seqs) (void)hipHostFree(w.h_seqs);
         if (w.h_out) (void)hipHostFree(w.h_out);
-        if (w.h_out2) (void)hipHostFree(w.h_out2);
         w.h_meta.release();
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }

@@ -154,10 +154,9 @@ struct nsgpu_ctx {
         nsgpu::DevBuf seqs, soff, len, sob, vf, mk, vr, linv, npf, pushf, npr, pr, V, hk, PX, PY, PRUN, PSEQ, rm, nout, oscan, off, out, scan_ws;
         uint8_t *h_seqs = nullptr; size_t h_cap = 0;
         uint8_t *h_out = nullptr; size_t h_out_cap = 0;
-        uint8_t *h_out2 = nullptr; size_t h_out2_cap = 0;               // second output buffer (the contig engine alternates)
         nsgpu::PinBuf h_meta;                                          // pinned landing zone of the small read-backs (push count, offsets)
         hipStream_t stream = nullptr;
-    } sws;
+    } sws[2];                                                       // two workspaces: the contig engine sketches the two halves of a batch concurrently
     nsgpu::PinBuf pin_small, pin_foff, pin_fids;                     // pinned landing zones: the filter's scalars / the engine's candidate CSR
     double sketch_mm_ms = 0;                                         // wall of the batched mm_sketch calls
     std::mutex stat_m;                                               // guards the ksw_* / aln_* counters below

@@ -38,14 +38,10 @@ using cons::read_t;
 // A finished contig waiting for its edit emission (consensus + one edit script per read into the seven streams).  The
 // emission touches nothing but the contig's own graph, so it is taken off the builder's critical path: the builder moves
 // on to its next contig at once and the emission runs as a task of its own in the next host phase.
-constexpr int kMaxGroups = 5;
+constexpr int kMaxGroups = 4;
 // Pipeline groups (see run_consensus): host phase | batches part 1 (sketches + index, seeds / chains / DP launch) | alignment
-// DP in flight | batches part 2.  NSGPU_SPLIT_PART1=1 / NSGPU_GROUPS=5 are measured alternatives (engine_slot).
-static int n_groups()
-{
-    static const int g = [] { const char *e = getenv("NSGPU_GROUPS"); const int v = e ? atoi(e) : 4; return v == 5 ? 5 : 4; }();
-    return g;
-}
+// DP in flight | batches part 2.  (Measured and dropped: part 1 as two pipeline stages, a fifth group -- DESIGN.md.)
+static int n_groups() { return kMaxGroups; }
 
 struct FinishedContig {
     std::unique_ptr<cons::ContigGraph> g;     // null once emitted
@@ -302,7 +298,7 @@ struct Engine {
     std::vector<FinishedContig *> emit_queue;      // finished contigs whose emission has not run yet
     std::vector<SketchReq> sk;
     std::vector<uint32_t> sk_ref;
-    std::vector<uint64_t> mz_off[2];                // minimizer offsets of the two sketch batches alive at a time (alternating slots)
+    std::vector<uint64_t> mz_off[2];                // minimizer offsets of the two halves of a sketch batch
     AlignBatch ab[kMaxGroups];                        // alignment batch of each group, DP kernels in flight between part 1 and part 2
     std::vector<uint32_t> fwho;                    // builders of the window-query batch
     std::vector<uint32_t> awho[kMaxGroups];           // builders of that batch
@@ -406,7 +402,11 @@ static uint32_t engine_seed_resolve(nsgpu_ctx *c, const uint32_t *gids, const ui
 // phases 4+5: window queries and alignments of the local builders (GPU batches); no claims yet
 // batches, part 1: for the builders that wait for an alignment, minimizer sketches, index, seeds / chains / DP plan and the
 // launch of the DP kernels -- which stay in flight until part 2
-static int engine_batches_sketch(nsgpu_ctx *c, int group, int buf)
+// batches, part 1a: for the builders that wait for an alignment, the minimizers of every changed consensus and of every
+// candidate read (GPU, mm_sketch.hip), the consensus indexes, and the first host step of the alignments (seeds / chains /
+// DP plan).  (Optionally the batch is cut in two halves whose sketches run concurrently on the GPU -- two workspaces, two
+// streams -- with the host work of the first half overlapping the sketch of the second: see below.)
+static int engine_batches_sketch(nsgpu_ctx *c, int group)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
@@ -417,38 +417,62 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int buf)
     for (Builder &b : D.B) if (in_group(b, group) && b.st == Builder::WAIT_ALIGN) who.push_back(b.id);
     AlignBatch &AB = E->ab[gi];
     AB.reqs.clear();
+    AB.host_ms = 0;
     E->awho[gi].clear();
     if (who.empty()) return NSGPU_OK;
     const double g0 = now_ms();
-    // minimizers of every changed consensus and every candidate read in one GPU batch (mm_sketch.hip); the
-    // single-sequence index is then only a sort of a few hundred entries per consensus
-    std::vector<SketchReq> &sk = E->sk;
-    std::vector<uint32_t> &sk_ref = E->sk_ref;      // per who-entry: position of its consensus in sk, or ~0u
-    sk.clear(); sk_ref.assign(who.size(), ~0u);
-    for (size_t w = 0; w < who.size(); ++w) {
-        Builder &b = D.B[who[w]];
-        if (!b.idx_valid) { sk_ref[w] = (uint32_t)sk.size(); sk.push_back(SketchReq{b.g->main_path.data(), b.g->main_path.size()}); }
-    }
-    const size_t q_base = sk.size();
-    for (size_t w = 0; w < who.size(); ++w) sk.push_back(SketchReq{D.B[who[w]].query.data(), D.B[who[w]].query.size()});
-    const mm2::Anchor *mz = nullptr;
-    std::vector<uint64_t> &mo = E->mz_off[buf];
-    NS_TRY(gpu_mm_sketch(c, sk, (int)c->prm.m_w, (int)c->prm.m_k, mz, mo, buf));
-    par_for("index.build", who.size(), [&](size_t w) {
-        Builder &b = D.B[who[w]];
-        if (!b.idx_valid) {
-            const uint32_t si = sk_ref[w];
-            b.idx.build_from_sketch(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f, mz + mo[si],
-                                    (size_t)(mo[si + 1] - mo[si]));
-            b.idx_valid = true;
+    const size_t n = who.size();
+    // Measured: two halves are SLOWER (sketch + index 2.6 s instead of 2.0 s per cfg2 step) -- a sketch call costs ~2.4 ms
+    // whatever its size (some 25 kernel launches and 3 host round trips on a busy GPU), so two calls in parallel take as long
+    // each as one call for everything.  NSGPU_SKETCH_TWO_HALVES=1 keeps the variant reachable.
+    static const bool two_halves = getenv("NSGPU_SKETCH_TWO_HALVES") != nullptr;
+    const size_t cut = n < 32 || !two_halves ? n : n / 2;
+    // requests of half h: the changed consensus strings of its builders, then their candidate reads
+    struct Half { size_t lo, hi, q_base; std::vector<SketchReq> sk; std::vector<uint32_t> sk_ref; const mm2::Anchor *mz = nullptr; int rc = NSGPU_OK; } H[2];
+    H[0].lo = 0, H[0].hi = cut, H[1].lo = cut, H[1].hi = n;
+    for (Half &h : H) {
+        h.sk_ref.assign(h.hi - h.lo, ~0u);
+        for (size_t w = h.lo; w < h.hi; ++w) {
+            Builder &b = D.B[who[w]];
+            if (!b.idx_valid) { h.sk_ref[w - h.lo] = (uint32_t)h.sk.size(); h.sk.push_back(SketchReq{b.g->main_path.data(), b.g->main_path.size()}); }
         }
-    });
-    // the requests of the stage behind this one; the query minimizers stay in pinned buffer `buf` until that stage has run
-    for (size_t w = 0; w < who.size(); ++w) {
-        Builder &b = D.B[who[w]];
-        AB.reqs.push_back(AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), mz + mo[q_base + w],
-                                   (size_t)(mo[q_base + w + 1] - mo[q_base + w])});
+        h.q_base = h.sk.size();
+        for (size_t w = h.lo; w < h.hi; ++w) h.sk.push_back(SketchReq{D.B[who[w]].query.data(), D.B[who[w]].query.size()});
     }
+    AB.reqs.resize(n);
+    if (AB.jobs.size() < n) AB.jobs.resize(n);
+    std::thread t2;
+    if (cut < n) t2 = std::thread([&] {
+        pool_bind_this_thread();
+        H[1].rc = hipSetDevice(c->prm.device) == hipSuccess ? gpu_mm_sketch(c, H[1].sk, (int)c->prm.m_w, (int)c->prm.m_k, H[1].mz, E->mz_off[1], 1) : NSGPU_ERR_HIP;
+    });
+    H[0].rc = gpu_mm_sketch(c, H[0].sk, (int)c->prm.m_w, (int)c->prm.m_k, H[0].mz, E->mz_off[0], 0);
+    int rc = NSGPU_OK;
+    for (int hi = 0; hi < 2 && rc == NSGPU_OK; ++hi) {
+        Half &h = H[hi];
+        if (hi == 1) { if (t2.joinable()) t2.join(); }
+        if (h.lo == h.hi) continue;
+        if (h.rc != NSGPU_OK) { rc = h.rc; break; }
+        const std::vector<uint64_t> &mo = E->mz_off[hi];
+        par_for("index.build", h.hi - h.lo, [&](size_t i) {
+            Builder &b = D.B[who[h.lo + i]];
+            if (!b.idx_valid) {
+                const uint32_t si = h.sk_ref[i];
+                b.idx.build_from_sketch(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f, h.mz + mo[si],
+                                        (size_t)(mo[si + 1] - mo[si]));
+                b.idx_valid = true;
+            }
+        });
+        // the query minimizers stay in the pinned buffer of the half's sketch workspace until the alignments have been seeded
+        for (size_t w = h.lo; w < h.hi; ++w) {
+            Builder &b = D.B[who[w]];
+            const size_t qi = h.q_base + (w - h.lo);
+            AB.reqs[w] = AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), h.mz + mo[qi], (size_t)(mo[qi + 1] - mo[qi])};
+        }
+        rc = align_prestep(c, AB, h.lo, h.hi);
+    }
+    if (t2.joinable()) t2.join();
+    NS_TRY(rc);
     E->awho[gi] = who;
     { std::lock_guard<std::mutex> lk(c->stat_m); S.index_ms += now_ms() - g0; }
     return NSGPU_OK;
@@ -527,7 +551,7 @@ static int engine_batches_finish(nsgpu_ctx *c, int group)
 
 static int engine_batches(nsgpu_ctx *c, int group)
 {
-    NS_TRY(engine_batches_sketch(c, group, 0));
+    NS_TRY(engine_batches_sketch(c, group));
     NS_TRY(engine_batches_begin(c, group, 1));
     return engine_batches_finish(c, group);
 }
@@ -599,22 +623,20 @@ static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
     return NSGPU_OK;
 }
 
-// One pipeline slot: the host phase of group h = slot % G, part 1 (sketches + index, then seeds / chains / DP launch) of the
-// group that was there one slot earlier, part 2 of group (slot + 1) % G -- whose DP launch has been in flight for a slot --
-// all concurrently.
+// One pipeline slot: the host phase of group h = slot % G, part 1 (sketches + index + seeds / chains, then the DP launch) of
+// the group that was there one slot earlier, part 2 of group (slot + 1) % G -- whose DP launch has been in flight for a
+// slot -- all concurrently.
 static int engine_slot(nsgpu_ctx *c, uint32_t slot)
 {
     const uint32_t G = (uint32_t)n_groups();
-    const int host_group = (int)(slot % G), sketch_group = (int)((slot + G - 1) % G), begin_group = (int)((slot + G - 2) % G), finish_group = (int)((slot + 1) % G);
-    const int ws_index = 1 + (int)(slot % 3), buf = (int)(slot & 1);
+    const int host_group = (int)(slot % G), begin_group = (int)((slot + G - 1) % G), finish_group = (int)((slot + 1) % G);
+    const int ws_index = 1 + (int)(slot % 3);
     static const bool serial = getenv("NSGPU_NO_OVERLAP") != nullptr;      // debugging aid: one after the other
     if (serial) {
         engine_advance(c, false, host_group);
         NS_TRY(engine_batches_finish(c, finish_group));
-        if (getenv("NSGPU_SPLIT_PART1")) NS_TRY(engine_batches_begin(c, begin_group, ws_index));
-        NS_TRY(engine_batches_sketch(c, sketch_group, buf));
-        if (!getenv("NSGPU_SPLIT_PART1")) NS_TRY(engine_batches_begin(c, sketch_group, ws_index));
-        return NSGPU_OK;
+        NS_TRY(engine_batches_sketch(c, begin_group));
+        return engine_batches_begin(c, begin_group, ws_index);
     }
     // the calling thread works in the host phase's loops: it joins the pool's threads on the GPU's NUMA node for the slot
     struct Rebind {
@@ -622,9 +644,9 @@ static int engine_slot(nsgpu_ctx *c, uint32_t slot)
         Rebind() { ok = pthread_getaffinity_np(pthread_self(), sizeof(old), &old) == 0; pool_bind_this_thread(); }
         ~Rebind() { if (ok) (void)pthread_setaffinity_np(pthread_self(), sizeof(old), &old); }
     } rebind;
-    int rc[4] = {NSGPU_OK, NSGPU_OK, NSGPU_OK, NSGPU_OK};
-    double d[4] = {0, 0, 0, 0};
-    uint64_t ser[4] = {0, 0, 0, 0};          // CPU time of the role threads outside the pool's loops (debug breakdown)
+    int rc[3] = {NSGPU_OK, NSGPU_OK, NSGPU_OK};
+    double d[3] = {0, 0, 0};
+    uint64_t ser[3] = {0, 0, 0};          // CPU time of the role threads outside the pool's loops (debug breakdown)
     auto role = [&](int i, const std::function<int()> &fn) {
         pool_bind_this_thread();
         const double x = now_ms();
@@ -633,28 +655,23 @@ static int engine_slot(nsgpu_ctx *c, uint32_t slot)
         d[i] = now_ms() - x;
         ser[i] = pool_thread_cpu_ns() - c0 - pool_thread_work_ns();
     };
-    // Sketches + index and part 1 of the same group run back to back in one role; the group behind it then has its DP in
-    // flight for a whole slot.  NSGPU_SPLIT_PART1=1 gives part 1 a slot (and a role) of its own instead: measured 5 % slower
-    // at cfg2 (249 vs 263 Mbases/s on one box), as is a fifth group (NSGPU_GROUPS=5) on top of that.
-    static const bool combined = getenv("NSGPU_SPLIT_PART1") == nullptr;
-    std::thread t1([&] { role(1, [&] { const int r = engine_batches_sketch(c, sketch_group, buf); return r != NSGPU_OK || !combined ? r : engine_batches_begin(c, sketch_group, ws_index); }); });
-    std::thread t2([&] { role(2, [&] { return combined ? (int)NSGPU_OK : engine_batches_begin(c, begin_group, ws_index); }); });
-    std::thread t3([&] { role(3, [&] { return engine_batches_finish(c, finish_group); }); });
+    std::thread t1([&] { role(1, [&] { const int r = engine_batches_sketch(c, begin_group); return r != NSGPU_OK ? r : engine_batches_begin(c, begin_group, ws_index); }); });
+    std::thread t2([&] { role(2, [&] { return engine_batches_finish(c, finish_group); }); });
     const double h0 = now_ms();
     const uint64_t hc0 = pool_thread_cpu_ns(), hw0 = pool_thread_work_ns();
     engine_advance(c, false, host_group);
     ser[0] = pool_thread_cpu_ns() - hc0 - (pool_thread_work_ns() - hw0);
     d[0] = now_ms() - h0;
-    t1.join(); t2.join(); t3.join();
+    t1.join(); t2.join();
     {   // which of the roles set the length of the slot (debug breakdown)
         Engine *E = static_cast<Engine *>(c->cons_engine);
         int w = 0;
-        for (int i = 1; i < 4; ++i) if (d[i] > d[w]) w = i;
-        for (int i = 0; i < 4; ++i) E->role_serial_ns[i] += ser[i];
+        for (int i = 1; i < 3; ++i) if (d[i] > d[w]) w = i;
+        for (int i = 0; i < 3; ++i) E->role_serial_ns[i] += ser[i];
         ++E->slot_long_n[w];
         E->slot_long_ms[w] += d[w];
     }
-    for (int i = 1; i < 4; ++i) NS_TRY(rc[i]);
+    for (int i = 1; i < 3; ++i) NS_TRY(rc[i]);
     return NSGPU_OK;
 }
 
@@ -697,9 +714,8 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
     if (getenv("NSGPU_CONS_DEBUG")) {
         fprintf(stderr, "[cons] batches wall-ms: window queries %.0f, sketch+index %.0f (gpu sketch %.0f), align begin %.0f (host loops %.0f, DP launch %.0f)\n", c->cons_stats.filter_ms,
                 c->cons_stats.index_ms, c->sketch_mm_ms, E->p1_align_ms, E->p1_host_ms, E->p1_launch_ms);
-        fprintf(stderr, "[cons] slots set by: host phase %llu (%.0f ms), sketches + index %llu (%.0f ms), batches part 1 %llu (%.0f ms), part 2 %llu (%.0f ms)\n",
-                (unsigned long long)E->slot_long_n[0], E->slot_long_ms[0], (unsigned long long)E->slot_long_n[1], E->slot_long_ms[1], (unsigned long long)E->slot_long_n[2],
-                E->slot_long_ms[2], (unsigned long long)E->slot_long_n[3], E->slot_long_ms[3]);
+        fprintf(stderr, "[cons] slots set by: host phase %llu (%.0f ms), batches part 1 %llu (%.0f ms), part 2 %llu (%.0f ms)\n", (unsigned long long)E->slot_long_n[0],
+                E->slot_long_ms[0], (unsigned long long)E->slot_long_n[1], E->slot_long_ms[1], (unsigned long long)E->slot_long_n[2], E->slot_long_ms[2]);
     }
     const double tf = now_ms();
     const int rc = engine_finish(c, n_threads_out);
@@ -712,8 +728,8 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
         getrusage(RUSAGE_SELF, &ru1);
         const double cpu_s = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec) * 1e-6 +
                              (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
-        fprintf(stderr, "[cons] serial CPU ms of the role threads (outside pool loops): host %.0f, sketches + index %.0f, batches part 1 %.0f, part 2 %.0f\n",
-                E->role_serial_ns[0] / 1e6, E->role_serial_ns[1] / 1e6, E->role_serial_ns[2] / 1e6, E->role_serial_ns[3] / 1e6);
+        fprintf(stderr, "[cons] serial CPU ms of the role threads (outside pool loops): host %.0f, batches part 1 %.0f, part 2 %.0f\n", E->role_serial_ns[0] / 1e6,
+                E->role_serial_ns[1] / 1e6, E->role_serial_ns[2] / 1e6);
         if (FILE *f = fopen("/proc/self/smaps_rollup", "r")) {       // are the graph slabs really on huge pages?
             char line[256];
             long rss = 0, thp = 0;

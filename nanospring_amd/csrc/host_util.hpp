@@ -43,8 +43,9 @@ struct SketchReq { const char *ptr; size_t len; };
 // (w,k)-minimizers of a batch of sequences, computed on the GPU (mm_sketch.hip).  Sequence i's minimizers are
 // out[out_off[i] .. out_off[i+1]) in mm_sketch's order; `out` points into a pinned buffer owned by the context and
 // stays valid until the next call.
-// `out` points into pinned buffer `out_buf` (0 or 1) of the context and stays valid until the next call with the same buffer
-int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int out_buf = 0);
+// `out` points into the pinned buffer of sketch workspace `ws` (0 or 1) and stays valid until the next call with the same workspace;
+// calls with different workspaces may run concurrently
+int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws = 0);
 int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::AlnOut> &outs, int ws_index = 0);
 // the same in two parts, the DP kernels in flight between them (state of one batch)
 struct AlignBatch {
@@ -59,9 +60,13 @@ struct AlignBatch {
     size_t nb = 0;
     int ws_index = 0;
     bool in_flight = false;
+    bool prestepped = false;             // align_prestep has started every job and run its first step (seeds, chains, DP plan)
     double host_ms = 0, dp_ms = 0;
     uint64_t dp_tasks = 0, rounds = 0;
 };
+// first host step (seeds / chains / regions / DP plan) of the requests [lo, hi) of B.reqs, ahead of align_begin: lets the caller
+// overlap it with the GPU sketch of the batch's other requests.  All requests must have been pre-stepped before align_begin.
+int align_prestep(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi);
 int align_begin(nsgpu_ctx *c, AlignBatch &B, int ws_index);
 int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs);
 int filter_strings_device(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq);   // api.hip: results stay in c->f_off / c->f_ids

@@ -257,7 +257,7 @@ static int scan_u32(nsgpu_ctx::SketchWs &W, hipStream_t st, const uint32_t *in, 
 // debug breakdown (one caller at a time): host staging, up to the push count, up to the offsets, write + read-back; bytes in, minimizers out
 double g_sketch_ms[6];
 
-int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int out_buf)
+int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws)
 {
     const size_t n = reqs.size();
     out_off.assign(n + 1, 0);
@@ -265,7 +265,8 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
     if (n == 0) return NSGPU_OK;
     NS_CHECK(k > 0 && k <= 28 && w > 0 && w < 256, NSGPU_ERR_ARG, "minimap k must be in 1..28 and w in 1..255 (sketch.c:84)");
     const double t0 = now_ms();
-    nsgpu_ctx::SketchWs &W = c->sws;
+    NS_CHECK(ws == 0 || ws == 1, NSGPU_ERR_ARG, "gpu_mm_sketch: workspace 0 or 1");
+    nsgpu_ctx::SketchWs &W = c->sws[ws];
     // a stream of its own: in the contig engine the sketches of one builder group run while another group's window queries
     // use the context's stream
     if (!W.stream) NS_HIP(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
@@ -339,10 +340,8 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
     const uint64_t total = out_off[n];
     const double t2 = now_ms();
     NS_TRY(W.out.reserve(total * 16 + 16));
-    NS_CHECK(out_buf == 0 || out_buf == 1, NSGPU_ERR_ARG, "gpu_mm_sketch: output buffer 0 or 1");
-    uint8_t *&h_out = out_buf ? W.h_out2 : W.h_out;
-    size_t &h_out_cap = out_buf ? W.h_out2_cap : W.h_out_cap;
-    NS_TRY(pinned_reserve(h_out, h_out_cap, total * 16 + 16));
+    uint8_t *&h_out = W.h_out;
+    NS_TRY(pinned_reserve(W.h_out, W.h_out_cap, total * 16 + 16));
     if (total) {
         hipLaunchKernelGGL(sk_write_kernel, dim3(gP), dim3(256), 0, st, bt, W.PX.as<uint64_t>(), W.PY.as<uint64_t>(), W.PRUN.as<uint32_t>(), W.PSEQ.as<uint32_t>(),
                            W.pr.as<uint32_t>(), W.rm.as<uint32_t>(), P, W.oscan.as<uint32_t>(), W.out.as<uint64_t>());
@@ -351,6 +350,7 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
     }
     NS_HIP(stream_wait_short(st));
     out = reinterpret_cast<const mm2::Anchor *>(h_out);
+    std::lock_guard<std::mutex> lk(c->stat_m);
     c->sketch_mm_ms += now_ms() - t0;
     g_sketch_ms[0] += t_staged - t0, g_sketch_ms[1] += t1 - t_staged, g_sketch_ms[2] += t2 - t1, g_sketch_ms[3] += now_ms() - t2, g_sketch_ms[4] += (double)bytes, g_sketch_ms[5] += (double)total;
     return NSGPU_OK;
