@@ -129,6 +129,7 @@ struct nsgpu_ctx {
     nsgpu::DevBuf f_pool, f_qstart, f_qcnt, f_qm, f_off, f_ids, f_ctrl, f_ovf_list, f_ovf_cnt, f_scan_ws;
     size_t f_pool_cap = 0;       // ids
     uint64_t f_total = 0;        // candidates of the last filter call
+    bool filter_stats = true;    // also total the matched list lengths (timing.filter_matches): one more scan + read-back per call; the contig engine switches it off
     uint32_t f_nq = 0;
     nsgpu::DevBuf rep_flags;
     nsgpu::DevBuf fq_cnt, fq_base, fq_nlpos, fq_len;   // FASTQ ingest (fastq.hip)

@@ -512,7 +512,10 @@ static int engine_batches_finish(nsgpu_ctx *c, int group)
             E->qbuf.clear(); E->qoff.assign(1, 0);
             for (uint32_t bi : who) for (int s = 0; s < 2; ++s) { E->qbuf += D.B[bi].win[s]; E->qoff.push_back(E->qbuf.size()); }
             const uint32_t nq = (uint32_t)(2 * who.size());
-            NS_TRY(filter_strings_device(c, E->qbuf.data(), E->qoff.data(), nq));
+            c->filter_stats = false;                       // nobody reads the match totals of the engine's window queries
+            const int frc = filter_strings_device(c, E->qbuf.data(), E->qoff.data(), nq);
+            c->filter_stats = true;
+            NS_TRY(frc);
             E->foff.resize((size_t)nq + 1);
             E->fids.resize(c->f_total + 1);
             NS_TRY(c->pin_foff.reserve(((size_t)nq + 1) * 8));

@@ -544,7 +544,7 @@ int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, 
     // total M (for the algorithmic-bytes figure): scan qm into the (now free) lb area
     {
         uint64_t *tmp = reinterpret_cast<uint64_t *>(lb);
-        if ((size_t)nq * n * 8 >= ((size_t)nq + 1) * 8) {
+        if (c->filter_stats && (size_t)nq * n * 8 >= ((size_t)nq + 1) * 8) {
             NS_TRY(scan_u32_to_u64(c, qm, tmp, nq));
             ps[3] = 0;
             NS_HIP(hipMemcpyAsync(c->pin_small.as<uint64_t>() + 3, tmp + nq, 8, hipMemcpyDeviceToHost, c->stream));
