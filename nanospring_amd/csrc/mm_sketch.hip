@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void sk_compact_kernel(Batch b, const uint32_t
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= b.B || !vf[i]) return;
-    V[vr[i]] = (uint8_t)nt4_dev(b.seqs[i]);
+    V[vr[i] - 1] = (uint8_t)nt4_dev(b.seqs[i]);          // vr = INCLUSIVE count of valid positions (one scan with the last-invalid maximum)
 }
 
 // pass 3: k-mer over the last k valid bases of the sequence (fewer at its start: the reference starts from fw = rv = 0),
@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void sk_kmer_kernel(Batch b, const uint32_t *_
     const uint32_t s = sob[i >> 4];
     const bool inlen = i - b.soff[s] < b.len[s];
     if (!vf[i]) { npf[i] = 0; pushf[i] = inlen; return; }
-    const uint32_t r = vr[i], lr = r - vr[b.soff[s]];
+    const uint32_t s0 = b.soff[s];
+    const uint32_t r = vr[i] - 1, lr = r - (vr[s0] - vf[s0]);      // exclusive ranks out of the inclusive scan
     const int k = b.k;
     const uint64_t shift1 = 2 * (uint64_t)(k - 1);
     const int m = lr < (uint32_t)(k - 1) ? (int)lr : k - 1;
@@ -302,14 +303,34 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
     hipLaunchKernelGGL(sk_block_owner_kernel, dim3((B / 16 + 255) / 256), dim3(256), 0, st, bt, W.sob.as<uint32_t>());
     hipLaunchKernelGGL(sk_flags_kernel, dim3(gB), dim3(256), 0, st, bt, W.sob.as<uint32_t>(), W.vf.as<uint32_t>(), W.mk.as<uint32_t>());
     NS_HIP(hipGetLastError());
-    NS_TRY(scan_u32(W, st, W.vf.as<uint32_t>(), W.vr.as<uint32_t>(), (size_t)B + 1, false, 0));
-    NS_TRY(scan_u32(W, st, W.mk.as<uint32_t>(), W.linv.as<uint32_t>(), (size_t)B + 1, true, 0));
+    {   // valid-position count (inclusive sum) and position of the last invalid byte (inclusive maximum) in ONE scan over pairs
+        using T2 = rocprim::tuple<uint32_t, uint32_t>;
+        auto in2 = rocprim::make_zip_iterator(rocprim::make_tuple(W.vf.as<uint32_t>(), W.mk.as<uint32_t>()));
+        auto out2 = rocprim::make_zip_iterator(rocprim::make_tuple(W.vr.as<uint32_t>(), W.linv.as<uint32_t>()));
+        auto sum_max = [] __device__(const T2 &a, const T2 &b) {
+            const uint32_t ma = rocprim::get<1>(a), mb = rocprim::get<1>(b);
+            return T2(rocprim::get<0>(a) + rocprim::get<0>(b), ma > mb ? ma : mb);
+        };
+        size_t ws_bytes = 0;
+        NS_HIP(rocprim::inclusive_scan(nullptr, ws_bytes, in2, out2, (size_t)B + 1, sum_max, st));
+        NS_TRY(W.scan_ws.reserve(ws_bytes + 16));
+        NS_HIP(rocprim::inclusive_scan(W.scan_ws.p, ws_bytes, in2, out2, (size_t)B + 1, sum_max, st));
+    }
     hipLaunchKernelGGL(sk_compact_kernel, dim3(gB), dim3(256), 0, st, bt, W.vf.as<uint32_t>(), W.vr.as<uint32_t>(), W.V.as<uint8_t>());
     hipLaunchKernelGGL(sk_kmer_kernel, dim3(gB), dim3(256), 0, st, bt, W.sob.as<uint32_t>(), W.vf.as<uint32_t>(), W.vr.as<uint32_t>(), W.V.as<uint8_t>(),
                        W.hk.as<uint64_t>(), W.npf.as<uint32_t>(), W.pushf.as<uint32_t>());
     NS_HIP(hipGetLastError());
-    NS_TRY(scan_u32(W, st, W.npf.as<uint32_t>(), W.npr.as<uint32_t>(), (size_t)B + 1, false, 0));
-    NS_TRY(scan_u32(W, st, W.pushf.as<uint32_t>(), W.pr.as<uint32_t>(), (size_t)B + 1, false, 0));
+    {   // the two exclusive sums (non-palindromic k-mers, pushes) in ONE scan over pairs: two launches less per call -- the
+        // stage is bound by the number of GPU operations, not by their size
+        using T2 = rocprim::tuple<uint32_t, uint32_t>;
+        auto in2 = rocprim::make_zip_iterator(rocprim::make_tuple(W.npf.as<uint32_t>(), W.pushf.as<uint32_t>()));
+        auto out2 = rocprim::make_zip_iterator(rocprim::make_tuple(W.npr.as<uint32_t>(), W.pr.as<uint32_t>()));
+        auto plus2 = [] __device__(const T2 &a, const T2 &b) { return T2(rocprim::get<0>(a) + rocprim::get<0>(b), rocprim::get<1>(a) + rocprim::get<1>(b)); };
+        size_t ws_bytes = 0;
+        NS_HIP(rocprim::exclusive_scan(nullptr, ws_bytes, in2, out2, T2(0u, 0u), (size_t)B + 1, plus2, st));
+        NS_TRY(W.scan_ws.reserve(ws_bytes + 16));
+        NS_HIP(rocprim::exclusive_scan(W.scan_ws.p, ws_bytes, in2, out2, T2(0u, 0u), (size_t)B + 1, plus2, st));
+    }
     NS_TRY(W.h_meta.reserve((n + 1) * 8 + 64));
     NS_HIP(hipMemcpyAsync(W.h_meta.p, W.pr.as<uint32_t>() + B, 4, hipMemcpyDeviceToHost, st));
     NS_HIP(stream_wait_short(st));
