@@ -24,6 +24,7 @@
 #include "common.hpp"
 #include "ksw2.hpp"
 #include "host_util.hpp"
+#include <rocprim/rocprim.hpp>
 
 namespace nsgpu {
 
@@ -661,11 +662,10 @@ static int ksw_max_width(int qlen, int tlen, int w)
 
 // CIGAR compaction: every problem owns a worst-case slice (qlen + tlen + 2 entries) of the CIGAR pool, of which it
 // uses a handful; only the used entries travel back over PCIe.
-__global__ __launch_bounds__(256) void ksw_ncigar_kernel(const KswResult *__restrict__ res, uint32_t n, uint32_t *__restrict__ ncig)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= n) ncig[i] = i < n ? (uint32_t)res[i].n_cigar : 0u;
-}
+struct NcigarAt {
+    const KswResult *res; uint32_t n;
+    __host__ __device__ uint64_t operator()(uint32_t i) const { return i < n ? (uint64_t)(uint32_t)res[i].n_cigar : 0ull; }
+};
 
 __global__ __launch_bounds__(256) void ksw_cigar_gather_kernel(const KswTask *__restrict__ tasks, const KswResult *__restrict__ res, uint32_t n,
                                                                const uint64_t *__restrict__ off, const uint32_t *__restrict__ pool,
@@ -934,11 +934,14 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         if (side_used[i]) { NS_HIP(hipEventRecord(W.side_done[i], W.side_stream[i])); NS_HIP(hipStreamWaitEvent(S, W.side_done[i], 0)); }
     NS_HIP(hipEventRecord(W.t_b, S));
     // compact the CIGARs on the device, then fetch results + used CIGAR entries only
-    NS_TRY(W.k_ncig.reserve((n + 2) * 4));
     NS_TRY(W.k_coff.reserve((n + 2) * 8));
-    hipLaunchKernelGGL(ksw_ncigar_kernel, dim3((uint32_t)((n + 256) / 256)), dim3(256), 0, S, W.k_res.as<KswResult>(), (uint32_t)n, W.k_ncig.as<uint32_t>());
-    NS_HIP(hipGetLastError());
-    NS_TRY(scan_u32_to_u64(W.scan_ws, S, W.k_ncig.as<uint32_t>(), W.k_coff.as<uint64_t>(), (uint32_t)n));
+    {   // exclusive sum of the CIGAR lengths, read out of the result records by the scan itself (no pass to extract them first)
+        auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), NcigarAt{W.k_res.as<KswResult>(), (uint32_t)n});
+        size_t ws_bytes = 0;
+        NS_HIP(rocprim::exclusive_scan(nullptr, ws_bytes, in, W.k_coff.as<uint64_t>(), (uint64_t)0, n + 1, rocprim::plus<uint64_t>(), S));
+        NS_TRY(W.scan_ws.reserve(ws_bytes + 16));
+        NS_HIP(rocprim::exclusive_scan(W.scan_ws.p, ws_bytes, in, W.k_coff.as<uint64_t>(), (uint64_t)0, n + 1, rocprim::plus<uint64_t>(), S));
+    }
     W.pend_n = n, W.pend_n_ev = n_ev, W.pend_n_launch = n_launch;
     return NSGPU_OK;
 }
