@@ -59,22 +59,23 @@ struct Batch {
     int w, k;
 };
 
-// pass 1: valid flags and the "last invalid" markers; the owner sequence of every 16-position block (sob) is found here by its
-// first lane and left behind for the later passes (it used to be a launch of its own)
-__global__ __launch_bounds__(256) void sk_flags_kernel(Batch b, uint32_t *__restrict__ sob, uint32_t *__restrict__ vf, uint32_t *__restrict__ mk)
+__global__ __launch_bounds__(256) void sk_block_owner_kernel(Batch b, uint32_t *__restrict__ sob)
 {
-    __shared__ uint32_t owner[16];
+    const uint32_t blk = blockIdx.x * 256 + threadIdx.x;
+    if (blk >= b.B / 16) return;
+    const uint32_t pos = blk * 16;
+    uint32_t lo = 0, hi = b.n;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (b.soff[mid] <= pos) lo = mid; else hi = mid; }
+    sob[blk] = lo;
+}
+
+// pass 1: valid flags and the "last invalid" markers
+__global__ __launch_bounds__(256) void sk_flags_kernel(Batch b, const uint32_t *__restrict__ sob, uint32_t *__restrict__ vf, uint32_t *__restrict__ mk)
+{
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if ((threadIdx.x & 15) == 0 && i < b.B) {                 // B is a multiple of 16: the block [i, i + 16) lies inside
-        uint32_t lo = 0, hi = b.n;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (b.soff[mid] <= i) lo = mid; else hi = mid; }
-        owner[threadIdx.x >> 4] = lo;
-        sob[i >> 4] = lo;
-    }
-    __syncthreads();
     if (i > b.B) return;
     if (i == b.B) { vf[i] = 0; mk[i] = 0; return; }
-    const uint32_t s = owner[threadIdx.x >> 4];
+    const uint32_t s = sob[i >> 4];
     const bool inlen = i - b.soff[s] < b.len[s];
     const bool valid = inlen && nt4_dev(b.seqs[i]) < 4;
     vf[i] = valid;
@@ -299,6 +300,7 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
     NS_HIP(hipMemcpyAsync(W.len.p, len.data(), n * 4, hipMemcpyHostToDevice, st));
     const Batch bt{W.seqs.as<uint8_t>(), W.soff.as<uint32_t>(), W.len.as<uint32_t>(), (uint32_t)n, B, w, k};
     const uint32_t gB = (B + 1 + 255) / 256;
+    hipLaunchKernelGGL(sk_block_owner_kernel, dim3((B / 16 + 255) / 256), dim3(256), 0, st, bt, W.sob.as<uint32_t>());
     hipLaunchKernelGGL(sk_flags_kernel, dim3(gB), dim3(256), 0, st, bt, W.sob.as<uint32_t>(), W.vf.as<uint32_t>(), W.mk.as<uint32_t>());
     NS_HIP(hipGetLastError());
     {   // valid-position count (inclusive sum) and position of the last invalid byte (inclusive maximum) in ONE scan over pairs
