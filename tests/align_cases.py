@@ -104,3 +104,18 @@ def pairs(seed, n, big=True):
             a = rng.randint(0, len(gg) - 9000)
             out.append((gg, mutate(rng, gg[a:a + rng.randint(3000, 9000)], 0.03)))
     return out
+
+
+def long_consensus_reads(seed=42, half=150000, cov=30, mean=8000):
+    """Reads whose -t 1 contig stage grows one consensus of ~190 kb (> 5000 distinct minimizers) through a 23-bp-period
+    tandem repeat: minimap2's mid_occ percentile (index.c:164-185) then drops the repeat's minimizer.
+    Read 0 is a 40 kb read across the repeat so that the first contig starts there with a long window."""
+    rng = np.random.RandomState(seed)
+    unit = rand_seq(rng, 23)
+    g0 = rand_seq(rng, half) + unit * 60 + rand_seq(rng, half)
+    reads = [mutate(rng, g0[half - 20000:half + 20000], 0.03)]
+    for _ in range(int(len(g0) * cov / mean)):
+        ln = int(max(500, rng.gamma(2.0, mean / 2)))
+        st = rng.randint(0, max(1, len(g0) - ln))
+        reads.append(mutate(rng, g0[st:st + ln], 0.03))
+    return reads

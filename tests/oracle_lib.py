@@ -273,3 +273,122 @@ def ref_mm_sketch(s, w, k):
     xy = np.zeros(2 * (len(b) + 8), dtype=np.uint64)
     n = lib.ref_mm_sketch(b, len(b), w, k, 0, 0, _p(xy), len(b) + 8)
     return xy[:2 * n].reshape(n, 2).copy()
+
+
+# ---------------------------------------------------------------------------
+# the contig stage (oracle/consensus_oracle.cpp -> oracle/libconsoracle.so)
+# ---------------------------------------------------------------------------
+CONS_SO = os.path.join(ORACLE_DIR, "libconsoracle.so")
+CONS_STREAMS = ["genome", "lone", "id", "pos", "type", "base", "complement"]
+_CONS = None
+
+
+class ConsOracleStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_contigs", "n_lone", "count_minhash", "count_minhash_not_in_graph", "count_aligner", "n_align_calls",
+                                          "n_bad_roundtrip", "n_check_fail")] + [(n, C.c_double) for n in ("sketch_ms", "consensus_ms")]
+
+
+def cons_lib():
+    global _CONS
+    if _CONS is None:
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("consensus_oracle.cpp", "ns_oracle.c")]
+        if not os.path.exists(CONS_SO) or os.path.getmtime(CONS_SO) < max(os.path.getmtime(s) for s in srcs):
+            subprocess.run(["make", "-C", ORACLE_DIR, "libconsoracle.so"], check=True, capture_output=True)
+        _CONS = C.CDLL(CONS_SO)
+        for f in ("cons_oracle_convert_hit", "cons_oracle_optimize_edits", "cons_oracle_decode"):
+            getattr(_CONS, f).restype = C.c_int64
+    return _CONS
+
+
+def ref_align_fn():
+    """The reference's minimap2 behind ConsensusGraph::alignRead's call sequence (oracle/_ref/libmm2ref.so), as a C function pointer."""
+    lib = mm2ref()
+    assert lib is not None, "oracle/_ref/libmm2ref.so is missing: run `make -C oracle ref` where /root/reference exists"
+    return C.cast(lib.ref_mm2_align, C.c_void_p)
+
+
+def cons_oracle_run(bases, off, salts, k=23, n=60, thr=6, m_k=20, m_w=50, mci=400, edge_thr=4000000, num_thr=1, checks=True, id_base=0, align_fn=None):
+    """The reference's hot path (sketch + tables + Consensus::generateAndWriteConsensus) on the CPU with the reference's own minimap2
+    answering alignRead.  Returns (streams, stats): streams[name] for num_thr == 1, else streams['threads'][t][name]; streams['metaData']."""
+    L = cons_lib()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    salts = np.ascontiguousarray(salts, dtype=np.uint64)
+    ns = 7 * num_thr + 1
+    ptrs = (C.c_void_p * ns)()
+    lens = (C.c_uint64 * ns)()
+    st = ConsOracleStats()
+    rc = L.cons_oracle_run(_p(bases), _p(off), C.c_uint32(len(off) - 1), C.c_uint32(k), C.c_uint32(n), C.c_uint32(thr), _p(salts), m_k, m_w, mci,
+                           C.c_uint64(edge_thr), num_thr, int(checks), align_fn or ref_align_fn(), C.c_uint32(id_base), ptrs, lens, C.byref(st))
+    assert rc == 0, "cons_oracle_run failed: %d" % rc
+    per = []
+    for t in range(num_thr):
+        per.append({name: C.string_at(ptrs[7 * t + i], lens[7 * t + i]) for i, name in enumerate(CONS_STREAMS)})
+    meta = C.string_at(ptrs[7 * num_thr], lens[7 * num_thr])
+    for i in range(ns):
+        L.cons_oracle_free(C.c_void_p(ptrs[i]))
+    stats = {f: getattr(st, f) for f, _ in ConsOracleStats._fields_}
+    if num_thr == 1:
+        out = dict(per[0])
+        out["metaData"] = meta
+        return out, stats
+    return {"threads": per, "metaData": meta}, stats
+
+
+def cons_oracle_convert_hit(hit, ref, qry):
+    """alignRead's conversion (src/ConsensusGraph.cpp:218-397) of reg[0] as ref_mm2_align() returns it -> dict(ok, rel_pos, begin_offset, end_offset, edits)."""
+    L = cons_lib()
+    h = RefAln(**{f: int(hit[f]) for f, _ in RefAln._fields_})
+    cig = np.ascontiguousarray(hit["cigar"], dtype=np.uint32)
+    if cig.size == 0:
+        cig = np.zeros(1, np.uint32)
+    rb, qb = ref.encode(), qry.encode()
+    cap = 2 * (len(rb) + len(qb)) + 8
+    ed = np.zeros(cap, dtype=np.uint64)
+    ok = C.c_int32()
+    rp, bo, eo = C.c_int64(), C.c_int64(), C.c_int64()
+    n = L.cons_oracle_convert_hit(C.byref(h), _p(cig), rb, C.c_uint64(len(rb)), qb, C.c_uint64(len(qb)), C.byref(ok), C.byref(rp), C.byref(bo), C.byref(eo),
+                                  _p(ed), C.c_uint64(cap))
+    assert n >= 0, n
+    return {"ok": ok.value, "rel_pos": rp.value, "begin_offset": bo.value, "end_offset": eo.value, "edits": ed[:n].copy()}
+
+
+def cons_oracle_optimize_edits(types, chars, nums):
+    L = cons_lib()
+    t = np.ascontiguousarray(types, dtype=np.uint8)
+    b = np.ascontiguousarray(chars, dtype=np.uint8)
+    m = np.ascontiguousarray(nums, dtype=np.uint32)
+    cap = len(t) + 4
+    ot, ob, om = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8), np.zeros(cap, np.uint32)
+    dis = C.c_uint64()
+    n = L.cons_oracle_optimize_edits(_p(t), _p(b), _p(m), C.c_uint32(len(t)), _p(ot), _p(ob), _p(om), C.c_uint32(cap), C.byref(dis))
+    assert n >= 0
+    return int(dis.value), ot[:n].copy(), ob[:n].copy(), om[:n].copy()
+
+
+def cons_oracle_check_repetitive(s):
+    b = s.encode() if isinstance(s, str) else bytes(s)
+    return int(cons_lib().cons_oracle_check_repetitive(b, C.c_uint64(len(b))))
+
+
+def cons_oracle_decode(streams):
+    """Decompressor's loop (src/Decompressor.cpp:105-172, 252-314) over one thread's seven streams -> [(id, read bytes)] or None if malformed."""
+    L = cons_lib()
+    bufs = [np.frombuffer(streams[nm], dtype=np.uint8) if len(streams[nm]) else np.zeros(1, np.uint8) for nm in CONS_STREAMS]
+    ptrs = (C.c_void_p * 7)(*[b.ctypes.data for b in bufs])
+    lens = (C.c_uint64 * 7)(*[len(streams[nm]) for nm in CONS_STREAMS])
+    rcap = len(streams["complement"]) + streams["lone"].count(b"\n") + 4
+    bcap = 1 << 16
+    while True:
+        ids = np.zeros(rcap, np.uint32)
+        off = np.zeros(rcap + 1, np.uint64)
+        out = np.zeros(bcap, np.uint8)
+        n = L.cons_oracle_decode(ptrs, lens, _p(ids), _p(off), C.c_uint64(rcap), _p(out), C.c_uint64(bcap))
+        if n == -2 and bcap < (1 << 34):
+            bcap *= 8
+            continue
+        break
+    if n < 0:
+        return None
+    raw = out.tobytes()
+    return [(int(ids[i]), raw[int(off[i]):int(off[i + 1])]) for i in range(n)]

@@ -1,8 +1,12 @@
-"""GPU tests of the contig stage (SURVEY 8 rows a11, a12, a15-a17): nsgpu_consensus_run (virtual
+"""GPU tests of the contig stage (SURVEY 8 rows a11-a13, a15-a17, f1): nsgpu_consensus_run (virtual
 builders in lock-step, window queries and alignments batched on the GPU).
-  - ONE builder must produce byte-identical streams to the plain sequential restatement of the
-    reference's -t 1 loop over the CPU oracles (tests/host_harness.cpp);
-  - any number of builders: lossless (library decoder and the independent Python decoder), deterministic;
+  - ONE builder must produce byte-identical streams to the ORACLE (oracle/consensus_oracle.cpp: an independent,
+    literal restatement of src/Consensus.cpp + src/ConsensusGraph.cpp that shares no code with the product, with the
+    reference's own minimap2 answering alignRead and ns_oracle.c the window queries) at -t 1: BASELINE cfg1, cfg3's
+    depth regime, cfg5's knobs (--num-hash 128, a binding --edge-thr), a consensus long enough for a non-trivial
+    mid_occ, repeat-rich and edge-case inputs;
+  - any number of builders: lossless (library decoder, the oracle's Decompressor restatement and the independent
+    Python decoder), deterministic;
   - file names / metaData as Compressor::compress expects them."""
 import os
 
@@ -10,17 +14,17 @@ import numpy as np
 import pytest
 
 import nanospring_amd as ns
-from tests import host_lib
+from tests import oracle_lib
 from tests.stream_decode import decode, fold
 from nanospring_amd.filter import STREAMS
 
 pytestmark = pytest.mark.gpu
 
 
-def run(bases, off, n_builders, n_out=1, **kw):
-    g = ns.NsGpu(**kw)
+def run(bases, off, n_builders, n_out=1, n=60, **kw):
+    g = ns.NsGpu(n=n, **kw)
     g.load_reads((bases, off))
-    g.sketch(ns.mt19937_64_salts(60), fetch=False)
+    g.sketch(ns.mt19937_64_salts(n), fetch=False)
     g.build_index()
     st = ns.consensus_run(g, n_builders, n_out)
     streams = [{k: ns.consensus_stream(g, t, k) for k in STREAMS} for t in range(n_out)]
@@ -28,35 +32,91 @@ def run(bases, off, n_builders, n_out=1, **kw):
     return g, st, streams, md
 
 
-def test_one_builder_equals_sequential_reference_loop():
-    bases, off = ns.synth_reads(5, 40000, 160, 2500.0)
-    want, wst = host_lib.consensus(bases, off, ns.mt19937_64_salts(60), checks=False)
-    g, st, streams, md = run(bases, off, 1)
-    for k in STREAMS:
-        assert streams[0][k] == want[k], k
-    assert md == want["metaData"]
-    for a, b in (("count_minhash", "count_minhash"), ("count_minhash_not_in_graph", "count_minhash_not_in_graph"), ("count_aligner", "count_aligner"),
-                 ("n_contigs", "n_contigs"), ("n_lone", "n_lone"), ("n_align_calls", "n_align_calls")):
-        assert st[a] == wst[b], a
-    assert ns.consensus_verify(g) == 0
-    g.close()
+def pack(reads):
+    bases = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    return bases, off
 
 
-def test_cfg1_one_builder_equals_sequential_reference_loop():
-    """BASELINE configs[0] shape (the reference's CPU-runnable plumbing case: 1 235 reads of mean 8 kb, 20x of a 0.5 Mb
-    genome, -k 23 -n 60 -t 1): the GPU path with one builder must give the streams of the sequential -t 1 restatement
-    byte for byte -- with the reference's own minimap2 answering the alignments there when its object travelled."""
-    from tests import oracle_lib
-    bases, off = ns.synth_reads(7, 500000, 1235, 8000.0)
-    want, wst = host_lib.consensus(bases, off, ns.mt19937_64_salts(60), checks=False, ref_aligner=oracle_lib.mm2ref() is not None)
+def one_builder_equals_oracle(bases, off, n=60, **kw):
+    """GPU engine with one builder == the oracle at -t 1, all eight streams and the counters of Consensus::CountStats"""
+    want, wst = oracle_lib.cons_oracle_run(bases, off, ns.mt19937_64_salts(n), n=n, checks=False,
+                                           **{{"edge_threshold": "edge_thr", "overlap_sketch_thr": "thr"}.get(a, a): b for a, b in kw.items()})
     assert wst["n_bad_roundtrip"] == 0
-    g, st, streams, md = run(bases, off, 1)
+    g, st, streams, md = run(bases, off, 1, n=n, **kw)
     for k in STREAMS:
         assert streams[0][k] == want[k], k
     assert md == want["metaData"]
-    assert st["count_aligner"] == wst["count_aligner"] > 1000 and st["n_contigs"] == wst["n_contigs"]
+    for f in ("count_minhash", "count_minhash_not_in_graph", "count_aligner", "n_contigs", "n_lone", "n_align_calls"):
+        assert st[f] == wst[f], f
     assert ns.consensus_verify(g) == 0
+    dec = oracle_lib.cons_oracle_decode(streams[0])          # the GPU path's streams through the oracle's Decompressor restatement
+    b = bytes(bases)
+    assert dec is not None and sorted(i for i, _ in dec) == list(range(len(off) - 1))
+    assert all(r == fold(b[int(off[i]):int(off[i + 1])]) for i, r in dec)
     g.close()
+    return want, wst, st
+
+
+def test_one_builder_equals_oracle():
+    bases, off = ns.synth_reads(5, 40000, 160, 2500.0)
+    one_builder_equals_oracle(bases, off)
+
+
+def test_cfg1_one_builder_equals_oracle():
+    """BASELINE configs[0] shape (the reference's CPU-runnable plumbing case: 1 235 reads of mean 8 kb, 20x of a 0.5 Mb
+    genome, -k 23 -n 60 -t 1)."""
+    bases, off = ns.synth_reads(7, 500000, 1235, 8000.0)
+    _, wst, st = one_builder_equals_oracle(bases, off)
+    assert st["count_aligner"] > 1000
+
+
+def test_cfg3_depth_one_builder_equals_oracle_and_many_builders_lossless():
+    """BASELINE configs[2] regime (E. coli-like: ~1 Gbase over a 4.6 Mb genome, ~200x): 160x of a 60 kb genome with 8 kb
+    reads.  Every window query returns a large part of the read set, contigs hold hundreds of reads, edges carry long read
+    lists."""
+    bases, off = ns.synth_reads(19, 60000, 1200, 8000.0)
+    _, wst, st = one_builder_equals_oracle(bases, off)
+    assert wst["n_contigs"] - wst["n_lone"] <= 8 and st["count_aligner"] > 1100
+    g, st, streams, md = run(bases, off, 24, 2)
+    assert ns.consensus_verify(g) == 0
+    got = {}
+    for s2 in streams:
+        got.update(dict(oracle_lib.cons_oracle_decode(s2)))
+    b = bytes(bases)
+    assert sorted(got) == list(range(1200)) and all(got[i] == fold(b[int(off[i]):int(off[i + 1])]) for i in range(1200))
+    g.close()
+
+
+def test_cfg5_num_hash_128_one_builder_equals_oracle():
+    """--num-hash 128 (BASELINE configs[4]'s sweep) through the whole contig stage"""
+    bases, off = ns.synth_reads(23, 120000, 400, 6000.0)
+    one_builder_equals_oracle(bases, off, n=128)
+
+
+def test_cfg5_binding_edge_threshold_one_builder_equals_oracle():
+    """--edge-thr small enough to bind in all three places it is tested (src/Consensus.cpp:73, 86, 200)"""
+    bases, off = ns.synth_reads(9, 30000, 120, 2500.0)
+    free, fst, _ = one_builder_equals_oracle(bases, off)
+    cut, cst, _ = one_builder_equals_oracle(bases, off, edge_threshold=20000)
+    assert cst["n_contigs"] > fst["n_contigs"] and cut["genome"] != free["genome"]
+
+
+def test_long_consensus_nontrivial_mid_occ_one_builder_equals_oracle():
+    """A contig beyond ~125 kb has more than 5000 distinct minimizers, so mm_idx_cal_max_occ's percentile (minimap2/index.c:164-185)
+    stops being 'largest count + 1': with a planted short-period tandem repeat the most frequent minimizer is above mid_occ
+    and its seeds are skipped (map.c:125-147)."""
+    from tests.align_cases import long_consensus_reads
+    reads = long_consensus_reads()
+    bases, off = pack(reads)
+    want, wst, st = one_builder_equals_oracle(bases, off)
+    longest = max(want["genome"].split(b"\n"), key=len).decode()
+    assert len(longest) > 150000
+    mz = oracle_lib.ref_mm_sketch(longest, 50, 20)
+    _, cnt = np.unique(mz[:, 0] >> np.uint64(8), return_counts=True)
+    mid = int(oracle_lib.mm2ref().ref_mm_mid_occ(longest.encode(), 20, 50))
+    assert len(cnt) > 5000 and cnt.max() > mid, (len(cnt), int(cnt.max()), mid)
 
 
 @pytest.mark.parametrize("n_builders,n_out", [(16, 1), (64, 3)])
@@ -91,10 +151,11 @@ def test_edge_cases_and_files(tmp_path):
     bases = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
     off = np.zeros(len(reads) + 1, dtype=np.uint64)
     off[1:] = np.cumsum([len(r) for r in reads])
-    want, _ = host_lib.consensus(bases, off, ns.mt19937_64_salts(60), checks=False)
+    want, _ = oracle_lib.cons_oracle_run(bases, off, ns.mt19937_64_salts(60), checks=False)
     g, st, streams, md = run(bases, off, 1)
     for k in STREAMS:
         assert streams[0][k] == want[k], k
+    assert md == want["metaData"]
     assert ns.consensus_verify(g) == 0
     d = str(tmp_path) + "/"
     ns.consensus_write(g, d, "Stream")
@@ -146,6 +207,7 @@ def test_repeat_rich_genome_many_builders_lossless():
     bases = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
     off = np.zeros(len(reads) + 1, dtype=np.uint64)
     off[1:] = np.cumsum([len(r) for r in reads])
+    one_builder_equals_oracle(bases, off)
     outs = []
     for n_builders in (1, 7, 48):
         g, st, streams, md = run(bases, off, n_builders, 2)

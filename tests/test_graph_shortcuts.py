@@ -1,6 +1,6 @@
 """The two exact shortcuts in the consensus DAG maintenance (skip of no-op cycle pruning, re-use of every
 stretch of the main path whose greedy choices the last update cannot have changed) must not change a single output byte: run the sequential contig loop with and
-without them (NSGPU_NO_CYCLE_SKIP / NSGPU_NO_TAIL_SPLICE make the code take the reference's literal route)
+without them -- and against the independent oracle (oracle/consensus_oracle.cpp), which has no shortcut at all -- (NSGPU_NO_CYCLE_SKIP / NSGPU_NO_TAIL_SPLICE make the code take the reference's literal route)
 on iid and on repeat-rich genomes and compare all streams."""
 import hashlib
 import os
@@ -41,23 +41,32 @@ h = hashlib.sha256()
 for k in sorted(out):
     h.update(out[k])
 print("HASH", h.hexdigest(), st["count_aligner"], st["n_contigs"])
+if len(sys.argv) > 3 and oracle_lib.mm2ref() is not None:    # the independent oracle (oracle/consensus_oracle.cpp) on the same reads
+    want, wst = oracle_lib.cons_oracle_run(bases, off, ns.mt19937_64_salts(60), checks=False)
+    h = hashlib.sha256()
+    for k in sorted(want):
+        h.update(want[k])
+    print("ORACLE", h.hexdigest(), wst["count_aligner"], wst["n_contigs"])
 '''
 
 
-def run(kind, seed, **env):
+def run(kind, seed, oracle=False, **env):
     e = dict(os.environ, **env)
-    r = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT}, kind, str(seed)], env=e, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT}, kind, str(seed)] + (["oracle"] if oracle else []), env=e, capture_output=True,
+                       text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     # NSGPU_SPLICE_CHECK=1: every re-used stretch of the main path is compared with a plain greedy walk, and the
     # "consistent from" bookkeeping with the graph, after every update
     assert "MISMATCH" not in r.stderr and "INVARIANT" not in r.stderr, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0].split()
+    for o in [l.split() for l in r.stdout.splitlines() if l.startswith("ORACLE")]:
+        assert o[1:] == line[1:], "product host graph code differs from oracle/consensus_oracle.cpp"
     return line[1], int(line[2]), int(line[3])
 
 
 @pytest.mark.parametrize("kind,seed", [("iid", 3), ("repeats", 4), ("repeats", 5), ("long", 1)])
 def test_shortcuts_change_nothing(kind, seed):
-    fast = run(kind, seed, NSGPU_SPLICE_CHECK="1")
+    fast = run(kind, seed, oracle=True, NSGPU_SPLICE_CHECK="1")
     literal = run(kind, seed, NSGPU_NO_CYCLE_SKIP="1", NSGPU_NO_TAIL_SPLICE="1", NSGPU_NO_RUN_FASTPATH="1")
     assert fast == literal
     assert fast[1] > 100

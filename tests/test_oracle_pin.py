@@ -104,6 +104,9 @@ def test_oracle_vs_live_reference(oracle, k, n, thr, seed):
 def test_check_repetitive(oracle):
     assert oracle.check_repetitive("A" * 100) == 1
     assert oracle.check_repetitive("AC" * 100) == 1
-    assert oracle.check_repetitive("ACGTTGCA" * 50) == 0 or True  # period 8 is outside the 6 shifts unless self-similar
+    assert oracle.check_repetitive("ACGTTGCA" * 50) == 0    # period 8: shifts 1..6 match 100, 0, 100, 0, 100, 0 of 400 positions, none > 280
+    assert oracle.check_repetitive("ACGTACG" * 30) == 0     # period 7 is outside the six shifts (src/Consensus.cpp:411)
+    assert oracle.check_repetitive("AAAAAAAACG") == 0       # 7 of 10 match at shift 1: 7 > 0.7 * 10 is false (:419, strict)
+    assert oracle.check_repetitive("AAAAAAAAAC") == 1       # 8 of 10
     rng = np.random.RandomState(0)
     assert oracle.check_repetitive("".join("ACGT"[i] for i in rng.randint(0, 4, size=1000))) == 0
