@@ -648,6 +648,7 @@ static int engine_slot(nsgpu_ctx *c, uint32_t slot)
         ~Rebind() { if (ok) (void)pthread_setaffinity_np(pthread_self(), sizeof(old), &old); }
     } rebind;
     int rc[3] = {NSGPU_OK, NSGPU_OK, NSGPU_OK};
+    std::string role_err[3];              // set_error() is thread-local: a role thread's message is re-issued on the calling thread below
     double d[3] = {0, 0, 0};
     uint64_t ser[3] = {0, 0, 0};          // CPU time of the role threads outside the pool's loops (debug breakdown)
     auto role = [&](int i, const std::function<int()> &fn) {
@@ -655,6 +656,7 @@ static int engine_slot(nsgpu_ctx *c, uint32_t slot)
         const double x = now_ms();
         const uint64_t c0 = pool_thread_cpu_ns();
         rc[i] = hipSetDevice(c->prm.device) == hipSuccess ? fn() : NSGPU_ERR_HIP;
+        if (rc[i] != NSGPU_OK) role_err[i] = nsgpu_last_error();
         d[i] = now_ms() - x;
         ser[i] = pool_thread_cpu_ns() - c0 - pool_thread_work_ns();
     };
@@ -674,7 +676,8 @@ static int engine_slot(nsgpu_ctx *c, uint32_t slot)
         ++E->slot_long_n[w];
         E->slot_long_ms[w] += d[w];
     }
-    for (int i = 1; i < 3; ++i) NS_TRY(rc[i]);
+    for (int i = 1; i < 3; ++i)
+        if (rc[i] != NSGPU_OK) { set_error("%s", role_err[i].empty() ? "contig engine: a batch thread failed" : role_err[i].c_str()); return rc[i]; }
     return NSGPU_OK;
 }
 

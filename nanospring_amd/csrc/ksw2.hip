@@ -751,7 +751,9 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
             if (t.qlen < 0 || t.tlen < 0) { cl[i] = 254; continue; }
             if (t.flag & KSW_EZ_GENERIC_SC) { cl[i] = 253; continue; }
             if (t.qlen <= 0 || t.tlen <= 0) { cl[i] = 255; continue; }
-            pb[i] = (uint32_t)((ksw_p_bytes(t.qlen, t.tlen, t.w) + 63) & ~(size_t)63);
+            const size_t pbytes = (ksw_p_bytes(t.qlen, t.tlen, t.w) + 63) & ~(size_t)63;
+            if (pbytes >= (1ull << 32)) { cl[i] = 252; continue; }      // traceback of one problem beyond 4 GiB (e.g. 50 kb x 50 kb unbanded)
+            pb[i] = (uint32_t)pbytes;
             const size_t need = ksw_lds_bytes(t.qlen, t.tlen, t.flag);
             const int cls = need <= kClass[0] ? 0 : need <= kClass[1] ? 1 : need <= kClass[2] ? 2 : 3;
             if (cls == 3) { const size_t hn = ksw_lds_bytes(t.qlen, t.tlen, 0); if (hn > hs) hs = hn; }
@@ -765,6 +767,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         KswTask &t = tasks[i];
         NS_CHECK(cl[i] != 254, NSGPU_ERR_ARG, "ksw: negative length");
         NS_CHECK(cl[i] != 253, NSGPU_ERR_ARG, "ksw: KSW_EZ_GENERIC_SC is not on NanoSpring's path");
+        NS_CHECK(cl[i] != 252, NSGPU_ERR_RANGE, "ksw: traceback matrix of one problem exceeds 4 GiB (band the problem or split it)");
         t.out_idx = (uint32_t)i;
         t.p_off = p_total;
         t.cig_off = (uint32_t)cig_total;

@@ -2,6 +2,8 @@
 (torch.distributed; "nccl" = RCCL on ROCm, "gloo" on CPU for the tests).  Every rank runs the whole hot
 path on its shard with a global read-id base; no data-path collective.  Rank outputs are gathered as
 additional "threads" of one archive: metaData is merged, stream sets are kept per rank/thread."""
+import os
+
 import numpy as np
 
 
@@ -204,7 +206,7 @@ def exchange_sketch_rows(gpu, salts, lo, hi, dist):
     salts = np.ascontiguousarray(salts, dtype=np.uint64)
     F.check(lib, lib.nsgpu_sketch_range(ctx, salts.ctypes.data_as(C.c_void_p), lo, hi))
     world = dist.get_world_size()
-    if world > 1:
+    if world > 1 or os.environ.get("NSGPU_TEST_FORCE_EXCHANGE"):     # the flag lets a world of one drive the device get / all-gather / set path
         dev = _dev(dist)
         on_dev = int(dev.type == "cuda")
         rows = torch.tensor([hi - lo], dtype=torch.int64, device=dev)
@@ -212,16 +214,24 @@ def exchange_sketch_rows(gpu, salts, lo, hi, dist):
         dist.all_gather(cnts, rows)
         cnts = [int(x.item()) for x in cnts]
         mx = max(max(cnts), 1)
-        mine = torch.zeros(mx * n, dtype=torch.int64, device=dev)
+        # The library copies the rows on ITS stream; torch fills / gathers on torch's current stream.  Order the two explicitly:
+        # the buffer is allocated uninitialised, the library's copy is host-synchronised before it returns (rows_get), only the
+        # padding tail is zeroed by torch afterwards, and torch's stream is drained before the library reads the gathered rows.
+        mine = torch.empty(mx * n, dtype=torch.int64, device=dev)
+        if on_dev:
+            torch.cuda.current_stream().synchronize()
         if hi > lo:
             F.check(lib, lib.nsgpu_sketch_rows_get(ctx, lo, hi, C.c_void_p(mine.data_ptr()), on_dev))
+        if (hi - lo) * n < mine.numel():
+            mine[(hi - lo) * n:].zero_()
         allrows = torch.empty(mx * n * world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(allrows, mine)
         if on_dev:
             torch.cuda.synchronize()
         start = 0
+        me = dist.get_rank()
         for r in range(world):
-            if r != dist.get_rank() and cnts[r]:
+            if cnts[r] and (r != me or os.environ.get("NSGPU_TEST_FORCE_EXCHANGE")):
                 ptr = allrows.data_ptr() + r * mx * n * 8
                 F.check(lib, lib.nsgpu_sketch_rows_set(ctx, start, start + cnts[r], C.c_void_p(ptr), on_dev))
             start += cnts[r]

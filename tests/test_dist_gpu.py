@@ -70,12 +70,13 @@ def test_result_is_independent_of_rank_count(world):
 def test_exchange_path_over_rccl_world_size_one():
     """The box has one GPU, so RCCL cannot run two ranks here; a world of one still drives every collective of the
     exchange path (all-gathers of read shards, sketch rows and claim lists, on device tensors) through the real "nccl"
-    backend, and must reproduce the single-process run bit for bit."""
+    backend, and must reproduce the single-process run bit for bit.  NSGPU_TEST_FORCE_EXCHANGE makes the world of one take the
+    device get -> all_gather_into_tensor -> set path of exchange_sketch_rows (re-importing its own rows) instead of skipping it."""
     bases, off, st1, s1 = single()
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "o.pkl")
         port = "29611"
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, NSGPU_TEST_BACKEND="nccl")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, NSGPU_TEST_BACKEND="nccl", NSGPU_TEST_FORCE_EXCHANGE="1")
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                             "--master-port", port, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(N_READS), str(N_BUILDERS), out],
                            env=env, capture_output=True, text=True, timeout=1200)
