@@ -729,6 +729,9 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     // workgroup kernel for the long, latency-bound problems of LDS classes 1 and 2: 256 threads (more waves only add barrier cost), up to 5 / 8 cells per
     // thread and row; the bulk of small gap fills (class 0) is throughput-bound and stays on one wave per problem
     std::vector<uint32_t> wg[3];
+    // second generation (ksw2_reg.hip): state in registers; serves every problem whose parameters and shape keep its proofs valid
+    std::vector<uint32_t> reg[KSW_REG_CLASSES];
+    size_t reg_lds[KSW_REG_CLASSES] = {0, 0, 0, 0};
     static const int kWgThreads[3] = {0, 256, 256}, kWgMaxPos[3] = {0, 5, 8};      // widest sweep served: 1280 / 2048 cells (256 x 5 / 8 or 512 x 3 / 4)
     static const bool no_wg = getenv("NSGPU_KSW_NO_WG") != nullptr;      // debugging aid: fallback kernels only
     static const bool wg512 = getenv("NSGPU_KSW_WG256") == nullptr;     // 512 threads per long problem (8 waves; NSGPU_KSW_WG256=1: 4 waves)
@@ -754,6 +757,8 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
             const size_t pbytes = (ksw_p_bytes(t.qlen, t.tlen, t.w) + 63) & ~(size_t)63;
             if (pbytes >= (1ull << 32)) { cl[i] = 252; continue; }      // traceback of one problem beyond 4 GiB (e.g. 50 kb x 50 kb unbanded)
             pb[i] = (uint32_t)pbytes;
+            const int rcls = ksw_reg_class(t, pr);
+            if (rcls >= 0) { cl[i] = (uint8_t)(16 + rcls); continue; }
             const size_t need = ksw_lds_bytes(t.qlen, t.tlen, t.flag);
             const int cls = need <= kClass[0] ? 0 : need <= kClass[1] ? 1 : need <= kClass[2] ? 2 : 3;
             if (cls == 3) { const size_t hn = ksw_lds_bytes(t.qlen, t.tlen, 0); if (hn > hs) hs = hn; }
@@ -776,7 +781,12 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         p_total += pb[i];
         cig_total += (size_t)t.qlen + t.tlen + 2;
         NS_CHECK(cig_total < (1ull << 32), NSGPU_ERR_RANGE, "ksw batch too large (cigar pool)");
-        if (cl[i] >= 4) wg[cl[i] - 4].push_back((uint32_t)i);
+        if (cl[i] >= 16) {
+            const int rc = cl[i] - 16;
+            reg[rc].push_back((uint32_t)i);
+            const size_t lb = ksw_reg_lds_bytes(rc, t.qlen);
+            if (lb > reg_lds[rc]) reg_lds[rc] = lb;
+        } else if (cl[i] >= 4) wg[cl[i] - 4].push_back((uint32_t)i);
         else order[cl[i]].push_back((uint32_t)i);
     }
     cig_off[n] = cig_total;
@@ -805,7 +815,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     NS_HIP(hipMemcpyAsync(W.k_res.p, results.data(), n * sizeof(KswResult), hipMemcpyHostToDevice, S));
     std::vector<uint32_t> &flat = W.h_flat;          // stays alive while the upload may still be reading it
     flat.clear();
-    size_t start[5] = {0, 0, 0, 0, 0}, wg_start[3] = {0, 0, 0};
+    size_t start[5] = {0, 0, 0, 0, 0}, wg_start[3] = {0, 0, 0}, reg_start[KSW_REG_CLASSES] = {0, 0, 0, 0};
     // big problems first inside a class (longest-processing-time-first): 64 buckets by the logarithm of the cell count, taken
     // in descending order -- the schedule only needs the rough order, a comparison sort of every batch does not pay
     auto lpt_order = [&](std::vector<uint32_t> &v) {
@@ -840,6 +850,11 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         wg_start[k] = flat.size();
         flat.insert(flat.end(), wg[k].begin(), wg[k].end());
     }
+    for (int k = 0; k < KSW_REG_CLASSES; ++k) {
+        lpt_order(reg[k]);
+        reg_start[k] = flat.size();
+        flat.insert(flat.end(), reg[k].begin(), reg[k].end());
+    }
     if (!flat.empty()) NS_HIP(hipMemcpyAsync(W.k_order.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, S));
     static const bool dbg = getenv("NSGPU_KSW_DEBUG") != nullptr;     // per-launch log (adds a sync per launch)
     NS_HIP(hipEventRecord(W.t_a, S));
@@ -856,6 +871,26 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     size_t n_ev = 0;
     uint64_t n_launch = 0;
     auto ev_at = [&](size_t i) -> hipEvent_t { while (W.ev.size() <= i) { hipEvent_t e = nullptr; (void)hipEventCreate(&e); W.ev.push_back(e); } return W.ev[i]; };
+    // register-resident classes: the multi-wave ones (long problems) first and on the high-priority side streams, the one-wave bulk last
+    for (int k = KSW_REG_CLASSES - 1; k >= 0; --k) {
+        const uint32_t m = (uint32_t)reg[k].size();
+        if (!m) continue;
+        hipStream_t st = S;
+        if (k >= 2 && !dbg) { st = W.side_stream[k - 1]; NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0)); side_used[k - 1] = true; }
+        double dbg_t0 = 0;
+        if (dbg) { NS_HIP(stream_wait(S)); dbg_t0 = now_ms(); }
+        NS_HIP(hipEventRecord(ev_at(n_ev++), st));
+        NS_TRY(ksw_reg_launch(k, st, m, reg_lds[k], W.k_tasks.as<KswTask>(), W.k_order.as<uint32_t>() + reg_start[k], pr, W.k_seqs.as<uint8_t>(), W.k_p.as<uint8_t>(),
+                              W.k_cig.as<uint32_t>(), W.k_res.as<KswResult>()));
+        NS_HIP(hipEventRecord(ev_at(n_ev++), st));
+        ++n_launch;
+        if (dbg) {
+            NS_HIP(stream_wait(S));
+            double cells = 0, mx = 0;
+            for (uint32_t i : reg[k]) { const double x = (double)tasks[i].qlen * tasks[i].tlen; cells += x; if (x > mx) mx = x; }
+            fprintf(stderr, "KSW reg class %d tasks %u cells %.3g max %.3g (q %d t %d) ms %.3f\n", k, m, cells, mx, tasks[reg[k][0]].qlen, tasks[reg[k][0]].tlen, now_ms() - dbg_t0);
+        }
+    }
     for (int k = 2; k >= 0; --k) {
         const uint32_t m = (uint32_t)wg[k].size();
         if (!m) continue;

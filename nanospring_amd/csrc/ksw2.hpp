@@ -3,6 +3,7 @@
 #include <cstdint>
 #include <cstddef>
 #include <vector>
+#include <hip/hip_runtime.h>
 
 struct nsgpu_ctx;
 
@@ -32,5 +33,14 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
                      std::vector<KswResult> &results, std::vector<uint32_t> &cigars, std::vector<uint64_t> &cig_off, int ws_index);
 int ksw_batch_collect(nsgpu_ctx *c, std::vector<KswTask> &tasks, std::vector<KswResult> &results, std::vector<uint32_t> &cigars,
                       std::vector<uint64_t> &cig_off, int ws_index);
+
+// second generation (ksw2_reg.hip): DP state in registers, packed int16 arithmetic
+#define KSW_REG_CLASSES 4
+int ksw_reg_class(const KswTask &t, const KswParams &pr);          // 0 .. KSW_REG_CLASSES-1, or -1 (first-generation kernels)
+int ksw_reg_cells(int cls);                                        // widest tlen the class serves
+int ksw_reg_threads(int cls);
+size_t ksw_reg_lds_bytes(int cls, int qlen);
+int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const KswTask *tasks, const uint32_t *order, const KswParams &pr, const uint8_t *seqs,
+                   uint8_t *p_pool, uint32_t *cig_pool, KswResult *res);
 
 }  // namespace nsgpu

@@ -1,0 +1,588 @@
+// ksw2_reg.hip -- a14h, second generation: ksw_extd2 (minimap2/ksw2_extd2_sse.c:34-401, ksw2.h:103-176) with the DP state
+// in REGISTERS.
+//
+// minimap2's formulation keeps u, v, x, y, x2, y2 per TARGET position t; anti-diagonal r updates t in [st, en] from
+// (u, y, y2)[t] and (x, v, x2)[t - 1] of the previous anti-diagonal.  So a lane that owns a FIXED set of t's never has to
+// move its state: it lives in VGPRs for the whole problem, the (t - 1) neighbour arrives by one DPP lane shift, and cells
+// outside [st, en] simply keep their registers -- which is exactly the reference's "stale array content" that the
+// lane-exact semantics need (the SSE kernel sweeps 16-aligned blocks; out-of-band cells of the first / last block are
+// computed from stale values and feed in-band cells once the band binds).
+//
+//   * 2 cells per lane, packed 2 x int16 per VGPR, all arithmetic in v_pk_*_i16 (one instruction = 128 cells per wave);
+//   * lane l of wave w owns t = (c * NW + w) * 128 + 2 l + {0, 1} for c = 0 .. NCH-1 (statically indexed register sets);
+//   * NW = 1: one wave per problem, no LDS traffic for state at all (LDS holds only the reversed query);
+//     NW > 1 (long, latency-bound problems): the waves of a workgroup split the anti-diagonal; only the seam cell between
+//     two waves goes through LDS, ONE barrier per anti-diagonal, the per-row score bookkeeping (exact max / Z-drop) lags
+//     one row behind so that it never adds a second barrier;
+//   * int8 wrap-around: with |scores| and gap costs as small as minimap2's, the only values that can leave int8 are
+//     a, b, a2, b2 after the "- (z - q)" adjustment, in out-of-band garbage cells whose x2 / y2 grow row after row
+//     (checked over thousands of problems with an instrumented oracle); those four are wrapped
+//     ((v << 8) >> 8 per half), everything else provably stays inside int8 and needs no emulation.  The host routes a
+//     problem here only if its parameters keep that proof valid (ksw_reg_eligible) -- anything else runs on ksw2.hip.
+//   * the score row s[] lives in registers too (stale outside the reference's 16-byte score stores of the row).
+//
+// The traceback matrix p (1 B per computed cell, the reference's layout so that the backtrack is index compatible) is
+// scratch in HBM; lane 0 walks it at the end.
+#include "common.hpp"
+#include "ksw2.hpp"
+#include "host_util.hpp"
+
+namespace nsgpu {
+
+#define KSW_NEG_INF (-0x40000000)
+#define KSW_EZ_SCORE_ONLY 0x01
+#define KSW_EZ_RIGHT 0x02
+#define KSW_EZ_APPROX_MAX 0x08
+#define KSW_EZ_APPROX_DROP 0x10
+#define KSW_EZ_EXTZ_ONLY 0x40
+#define KSW_EZ_REV_CIGAR 0x80
+
+typedef short s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+__device__ __forceinline__ s2 S2(int x) { return __builtin_bit_cast(s2, x); }
+__device__ __forceinline__ s2 S2u(u2 x) { return __builtin_bit_cast(s2, x); }
+__device__ __forceinline__ u2 U2(s2 x) { return __builtin_bit_cast(u2, x); }
+__device__ __forceinline__ int I32(s2 x) { return __builtin_bit_cast(int, x); }
+__device__ __forceinline__ s2 splat(int v) { const short s = (short)v; return (s2){s, s}; }
+__device__ __forceinline__ s2 pmax(s2 a, s2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s2 pmin(s2 a, s2 b) { return __builtin_elementwise_min(a, b); }
+// min(x, 1) per unsigned half: 0 stays 0, anything else becomes 1.  Through inline asm: the compiler otherwise recognises the
+// pattern as a compare and scalarises every use into v_cmp (SDWA) + v_cndmask pairs per half (measured: 126 VALU instead of ~75 per
+// 128 cells).
+__device__ __forceinline__ u2 to01(u2 x) { u2 r; asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(x)); return r; }
+// 0 where the halves are equal, 1 where m > c (m >= c required)
+__device__ __forceinline__ u2 ne01(s2 m, s2 c) { return to01(U2((s2)(m - c))); }
+// 0xffff in the halves where lo <= t <= hi (all values < 2^15), else 0
+__device__ __forceinline__ uint32_t range_mask(s2 t, int lo, int hi)
+{
+    const s2 a = t - splat(lo), b = splat(hi) - t;                 // both >= 0 inside
+    const s2 o = S2(I32(a) | I32(b));
+    return ~(uint32_t)I32((s2)(o >> (s2){15, 15}));
+}
+__device__ __forceinline__ s2 wrap8(s2 v) { return (s2)((s2)(v << (s2){8, 8}) >> (s2){8, 8}); }
+// (mask & a) | (~mask & b)
+__device__ __forceinline__ s2 sel(uint32_t mask, s2 a, s2 b) { return S2((int)((mask & (uint32_t)I32(a)) | (~mask & (uint32_t)I32(b)))); }
+// lane l receives lane l-1's value; lane 0 receives `first` (wave_shr:1, bound_ctrl off keeps `old` in lane 0)
+__device__ __forceinline__ int shr1(int first, int v) { return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false); }
+// {lo: the upper half of prev, hi: the lower half of own}
+__device__ __forceinline__ s2 left_nb(s2 own, int prev) { return S2((int)__builtin_amdgcn_alignbit((uint32_t)I32(own), (uint32_t)prev, 16)); }
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    // DPP reduction: quad, row, then across rows; every lane of row 3 / lane 63 ends with the maximum of the wave
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);  v = v > t ? v : t;     // quad_perm [1,0,3,2]
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);  v = v > t ? v : t;     // quad_perm [2,3,0,1]
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true); v = v > t ? v : t;     // row_half_mirror
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true); v = v > t ? v : t;     // row_mirror
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true); v = v > t ? v : t;     // row_bcast15 -> rows 1, 3
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true); v = v > t ? v : t;     // row_bcast31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+struct RowRange { int st0, en0, st, en; bool empty; };
+__device__ __forceinline__ RowRange row_range(int r, int qlen, int tlen, int w)
+{
+    RowRange o;
+    int st = 0, en = tlen - 1;
+    if (st < r - qlen + 1) st = r - qlen + 1;
+    if (en > r) en = r;
+    if (st < ((r - w + 1) >> 1)) st = (r - w + 1) >> 1;
+    if (en > ((r + w) >> 1)) en = (r + w) >> 1;
+    o.empty = st > en;
+    o.st0 = st, o.en0 = en;
+    o.st = st / 16 * 16, o.en = (en + 16) / 16 * 16 - 1;
+    return o;
+}
+
+// everything a row needs that is the same for all lanes
+struct Consts {
+    int q, e, q2, e2, qe, qe2, sc_mch, sc_mis, sc_N, long_thres, long_diff;
+};
+
+// One anti-diagonal for the two cells of a lane.  Inputs: score z, own (u, y, y2), left neighbour's (x, v, x2) -- all of
+// the previous anti-diagonal.  ksw2_extd2_sse.c:228-322 (left-aligned gaps) / the KSW_EZ_RIGHT twin.
+template <bool RIGHT>
+__device__ __forceinline__ void cell_pair(const Consts &K, s2 z, s2 ut, s2 yo, s2 y2o, s2 xt1, s2 vt1, s2 x2t1, s2 &un, s2 &vn, s2 &xn, s2 &yn,
+                                          s2 &x2n, s2 &y2n, uint32_t &dbytes)
+{
+    s2 a = xt1 + vt1, b = yo + ut, a2 = x2t1 + vt1, b2 = y2o + ut;
+    const s2 m = pmax(pmax(pmax(pmax(z, a), b), a2), b2);
+    u2 d;
+    const u2 one = (u2){1, 1};
+    if (!RIGHT) {      // strict '>' at every step: the FIRST of (z, a, b, a2, b2) that reaches the maximum
+        const u2 n0 = ne01(m, z), n1 = ne01(m, a), n2 = ne01(m, b), n3 = ne01(m, a2);
+        d = n0 * (one + n1 * (one + n2 * (one + n3)));
+    } else {           // '>=' at every step: the LAST one that reaches it
+        const u2 n1 = ne01(m, a), n2 = ne01(m, b), n3 = ne01(m, a2), n4 = ne01(m, b2);
+        d = (u2){4, 4} - n4 * (one + n3 * (one + n2 * (one + n1)));
+    }
+    const s2 zc = pmin(m, splat(K.sc_mch));
+    un = zc - vt1, vn = zc - ut;
+    const s2 t1 = zc - splat(K.q), t2 = zc - splat(K.q2);
+    a = wrap8(a - t1), b = wrap8(b - t1), a2 = wrap8(a2 - t2), b2 = wrap8(b2 - t2);
+    const s2 zero = splat(0);
+    const s2 pa = pmax(a, zero), pb = pmax(b, zero), pa2 = pmax(a2, zero), pb2 = pmax(b2, zero);
+    xn = pa - splat(K.qe), yn = pb - splat(K.qe), x2n = pa2 - splat(K.qe2), y2n = pb2 - splat(K.qe2);
+    u2 fa, fb, fa2, fb2;
+    if (!RIGHT) {      // a > 0
+        fa = to01(U2(pa)), fb = to01(U2(pb)), fa2 = to01(U2(pa2)), fb2 = to01(U2(pb2));
+    } else {           // a >= 0
+        const s2 o = splat(1);
+        fa = to01(U2(pmax(a + o, zero))), fb = to01(U2(pmax(b + o, zero)));
+        fa2 = to01(U2(pmax(a2 + o, zero))), fb2 = to01(U2(pmax(b2 + o, zero)));
+    }
+    d = d + fa * (u2){8, 8} + fb * (u2){16, 16} + fa2 * (u2){32, 32} + fb2 * (u2){64, 64};
+    dbytes = __builtin_amdgcn_perm(0u, __builtin_bit_cast(uint32_t, d), 0x0c0c0200u);        // the two low bytes of the halves
+}
+
+// score of the two cells: match / mismatch, either base = 4 -> sc_N (ksw2_extd2_sse.c:165-184)
+__device__ __forceinline__ s2 score_pair(const Consts &K, s2 tq, s2 tt)
+{
+    const s2 x = S2(I32(tq) ^ I32(tt));
+    const u2 ne = to01(U2(x));
+    s2 z = S2u(ne * U2(splat(K.sc_mis - K.sc_mch))) + splat(K.sc_mch);
+    const u2 isn = U2(S2((I32(tq) | I32(tt)) >> 2 & 0x00010001));
+    z = z + S2u(isn * U2((s2)(splat(K.sc_N) - z)));
+    return z;
+}
+
+__device__ __forceinline__ int key_rank(int t, int st0, int en0, int en1)
+{
+    // tie order of the reference's 4-lane scan (ksw2_extd2_sse.c:323-358): en0 first, then lane (t - st0) & 3 by ascending t, then the tail
+    const int cls = t == en0 ? 0 : t < en1 ? 1 + ((t - st0) & 3) : 5;
+    return cls << 13 | t;
+}
+
+// The value of cell t held as half (t & 1) of lane (t >> 1) & 63 of register set (t >> 7) % ... : NW == 1 only.
+template <int NCH>
+__device__ __forceinline__ int fetch16(const s2 (&R)[NCH], int t)
+{
+    const int c = t >> 7, l = (t >> 1) & 63;        // a cell beyond the register sets reads as 0 (never on in-band shapes)
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) { const int x = __builtin_amdgcn_readlane(I32(R[k]), l); v = k == c ? x : v; }
+    return (int)(short)(t & 1 ? v >> 16 : v & 0xffff);
+}
+template <int NCH>
+__device__ __forceinline__ int fetch32(const int (&Rlo)[NCH], const int (&Rhi)[NCH], int t)
+{
+    const int c = t >> 7, l = (t >> 1) & 63;
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) { const int x = __builtin_amdgcn_readlane(t & 1 ? Rhi[k] : Rlo[k], l); v = k == c ? x : v; }
+    return v;
+}
+
+__device__ void backtrack_and_store(const KswTask &tk, int w, int ncol16, const uint8_t *p, uint32_t *cig_pool, KswResult *res_out, int ez_max, int ez_zdropped,
+                                    int ez_max_q, int ez_max_t, int ez_mqe, int ez_mqe_t, int ez_mte, int ez_mte_q, int ez_score)
+{
+    // ksw2_extd2_sse.c:389-398 + ksw_backtrack (ksw2.h:119-151, is_rot = 1); one lane
+    const int qlen = tk.qlen, tlen = tk.tlen, flag = tk.flag;
+    int ez_reach_end = 0;
+    uint32_t n_cigar = 0;
+    if (!(flag & KSW_EZ_SCORE_ONLY)) {
+        int i0 = -1, j0 = -1;
+        if (!ez_zdropped && !(flag & KSW_EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
+        else if (!ez_zdropped && (flag & KSW_EZ_EXTZ_ONLY) && ez_mqe + tk.end_bonus > ez_max) ez_reach_end = 1, i0 = ez_mqe_t, j0 = qlen - 1;
+        else if (ez_max_t >= 0 && ez_max_q >= 0) i0 = ez_max_t, j0 = ez_max_q;
+        if (i0 >= 0 && j0 >= 0) {
+            uint32_t *cig = cig_pool + tk.cig_off;
+            int i = i0, j = j0, state = 0;
+            uint32_t cur_op = 0xffffffffu, cur_len = 0;
+            while (i >= 0 && j >= 0) {
+                const int r = i + j;
+                const RowRange rr = row_range(r, qlen, tlen, w);
+                int force_state = -1;
+                if (i < rr.st) force_state = 2;
+                if (i > rr.en) force_state = 1;
+                const uint32_t tmp = force_state < 0 ? p[(size_t)r * ncol16 + i - rr.st] : 0u;
+                if (state == 0) state = tmp & 7;
+                else if (!(tmp >> (state + 2) & 1)) state = 0;
+                if (state == 0) state = tmp & 7;
+                if (force_state >= 0) state = force_state;
+                uint32_t op;
+                if (state == 0) op = 0, --i, --j;
+                else if (state == 1 || state == 3) op = 2, --i;
+                else op = 1, --j;
+                if (op == cur_op) ++cur_len;
+                else { if (cur_len) cig[n_cigar++] = cur_len << 4 | cur_op; cur_op = op, cur_len = 1; }
+            }
+            if (i >= 0) { if (cur_op == 2) cur_len += i + 1; else { if (cur_len) cig[n_cigar++] = cur_len << 4 | cur_op; cur_op = 2, cur_len = i + 1; } }
+            if (j >= 0) { if (cur_op == 1) cur_len += j + 1; else { if (cur_len) cig[n_cigar++] = cur_len << 4 | cur_op; cur_op = 1, cur_len = j + 1; } }
+            if (cur_len) cig[n_cigar++] = cur_len << 4 | cur_op;
+            if (!(flag & KSW_EZ_REV_CIGAR))
+                for (uint32_t a = 0; a < n_cigar >> 1; ++a) { const uint32_t t_ = cig[a]; cig[a] = cig[n_cigar - 1 - a]; cig[n_cigar - 1 - a] = t_; }
+        }
+    }
+    KswResult o;
+    o.max = (uint32_t)ez_max; o.zdropped = ez_zdropped; o.max_q = ez_max_q; o.max_t = ez_max_t; o.mqe = ez_mqe; o.mqe_t = ez_mqe_t;
+    o.mte = ez_mte; o.mte_q = ez_mte_q; o.score = ez_score; o.n_cigar = (int)n_cigar; o.reach_end = ez_reach_end;
+    res_out[tk.out_idx] = o;
+}
+
+// LDS layout of a problem (bytes):
+//   [0, QB)        qA: T zero bytes, the reversed query, zero bytes up to QB   (QB = 2 T + round16(qlen) + 16)
+//   [QB, 2 QB)     qB: qA shifted by one byte (qB[j] = qA[j + 1]), so that the two query bases of a lane are always ONE aligned 16-bit read
+//   NW > 1 only:   seam[2][NB] {x|v|x2 as 3 x int16 in 8 bytes, H} ; pub[2] {key[NW], h_en0, h_st0} ; uv[2][T] (approx: u16 | v16 per cell)
+// T = NW * NCH * 128 cells.
+__host__ __device__ inline int reg_qb(int T, int qlen) { return 2 * T + (qlen + 15) / 16 * 16 + 16; }
+
+// -------------------------------------------------------------------------------------------------------------------
+// The row loop.  NW waves, NCH register sets per lane.
+// -------------------------------------------------------------------------------------------------------------------
+template <int NW, int NCH, bool APPROX, bool RIGHT>
+__device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_t *__restrict__ seqs, uint8_t *__restrict__ p_pool,
+                            uint32_t *__restrict__ cig_pool, KswResult *__restrict__ res_out, uint8_t *lds)
+{
+    constexpr int T = NW * NCH * 128;
+    constexpr int NB = NW * NCH;                 // blocks of 128 cells
+    const int lane = threadIdx.x & 63, wv = NW > 1 ? (int)(threadIdx.x >> 6) : 0;
+    const int qlen = tk.qlen, tlen = tk.tlen, flag = tk.flag, zdrop = tk.zdrop;
+    Consts K;
+    K.q = pr.q, K.e = pr.e, K.q2 = pr.q2, K.e2 = pr.e2;
+    if (K.q2 + K.e2 < K.q + K.e) { int t_ = K.q; K.q = K.q2; K.q2 = t_; t_ = K.e; K.e = K.e2; K.e2 = t_; }
+    K.qe = K.q + K.e, K.qe2 = K.q2 + K.e2;
+    K.sc_mch = pr.sc_mch, K.sc_mis = pr.sc_mis;
+    K.sc_N = pr.sc_ambi == 0 ? -K.e2 : pr.sc_ambi;
+    K.long_thres = K.e != K.e2 ? (K.q2 - K.q) / (K.e - K.e2) - 1 : 0;
+    if (K.q2 + K.e2 + K.long_thres * K.e2 > K.q + K.e + K.long_thres * K.e) ++K.long_thres;
+    K.long_diff = K.long_thres * (K.e - K.e2) - (K.q2 - K.q) - K.e2;
+    int w = tk.w;
+    if (w < 0) w = tlen > qlen ? tlen : qlen;
+    int n_col_ = qlen < tlen ? qlen : tlen;
+    n_col_ = ((n_col_ < w + 1 ? n_col_ : w + 1) + 15) / 16 + 1;
+    const int ncol16 = n_col_ * 16;
+
+    const int QB = reg_qb(T, qlen);
+    uint8_t *qA = lds, *qB = lds + QB;
+    // NW > 1 scratch (see reg_lds_bytes)
+    uint2 *seam = reinterpret_cast<uint2 *>(lds + 2 * QB);                 // [2][NB] {x | v << 16, x2}: (x, v, x2) of a block's last cell
+    int *seam_h = reinterpret_cast<int *>(lds + 2 * QB + 2 * NB * 8);      // [2][NB] its H
+    uint32_t *pub = reinterpret_cast<uint32_t *>(lds + 2 * QB + 2 * NB * 12);   // [3][NW + 2]: per-wave best key, H[en0], H[st0] of a row
+    uint32_t *uv4 = pub + 3 * (NW + 2);                                    // [3][4] approx: u | v << 16 of cells L .. L + 3 (L = last_H0_t two rows back)
+
+    for (int i = threadIdx.x; i < (2 * QB) / 4; i += NW * 64) reinterpret_cast<uint32_t *>(lds)[i] = 0;
+    if (NW > 1) {
+        for (int i = threadIdx.x; i < 2 * NB * 3 + 3 * (NW + 2) + 12; i += NW * 64) reinterpret_cast<uint32_t *>(lds + 2 * QB)[i] = 0;
+        __syncthreads();
+    } else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+        const uint8_t *query = seqs + tk.qoff;
+        for (int j = threadIdx.x; j < qlen; j += NW * 64) {
+            const uint8_t b = query[qlen - 1 - j];
+            qA[T + j] = b;
+            qB[T + j - 1] = b;
+        }
+    }
+    // register state
+    s2 TT[NCH], TP[NCH], SC[NCH], U[NCH], V[NCH], X[NCH], Y[NCH], X2[NCH], Y2[NCH];      // TP: the two t's of the lane
+    int HL[NCH], HH[NCH];
+    {
+        const uint8_t *target = seqs + tk.toff;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int t0 = (c * NW + wv) * 128 + 2 * lane;
+            const int b0 = t0 < tlen ? target[t0] : 0, b1 = t0 + 1 < tlen ? target[t0 + 1] : 0;
+            TT[c] = S2(b0 | b1 << 16);
+            TP[c] = S2(t0 | (t0 + 1) << 16);
+            SC[c] = splat(0);
+            U[c] = V[c] = X[c] = Y[c] = splat(-K.q - K.e);
+            X2[c] = Y2[c] = splat(-K.q2 - K.e2);
+            HL[c] = HH[c] = KSW_NEG_INF;
+        }
+    }
+    if (NW > 1) {
+        // seams of the initial state: every block's last cell holds the initial values
+        for (int i = threadIdx.x; i < 2 * NB; i += NW * 64) {
+            const uint32_t b0 = (uint32_t)(-K.q - K.e) & 0xffffu, b1 = (uint32_t)(-K.q2 - K.e2) & 0xffffu;
+            seam[i] = make_uint2(b0 | b0 << 16, b1);
+            seam_h[i] = KSW_NEG_INF;
+        }
+        __syncthreads();
+    } else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    int ez_max = 0, ez_zdropped = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1, ez_mte = KSW_NEG_INF, ez_mte_q = -1;
+    int ez_score = KSW_NEG_INF;
+    uint8_t *p = p_pool + tk.p_off;
+    int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0;
+    const int n_rows = qlen + tlen - 1;
+    // NW > 1: the bookkeeping of row r - 1 is done after the barrier of row r (a lag of one row, so that it never costs a
+    // second barrier); these describe the row that is still owed
+    int lag_r = -1, lag_st0 = 0, lag_en0 = 0, lag_en = 0, lag_L = 0;
+    bool brk = false;
+
+    // ---- the per-row bookkeeping (uniform): ksw2_extd2_sse.c:323-383 given the row's published scalars ----
+    auto exact_row = [&](int r, int st0, int en0, int en, int max_H, int max_t, int h_en0, int h_st0) {
+        if (en0 == tlen - 1 && h_en0 > ez_mte) ez_mte = h_en0, ez_mte_q = r - en;
+        if (r - st0 == qlen - 1 && h_st0 > ez_mqe) ez_mqe = h_st0, ez_mqe_t = st0;
+        if (max_H > ez_max) {
+            ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
+        } else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
+            const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+            if (zdrop >= 0 && ez_max - max_H > zdrop + l * K.e2) { ez_zdropped = 1; brk = true; }
+        }
+        if (!brk && r == qlen + tlen - 2 && en0 == tlen - 1) ez_score = h_en0;
+    };
+    auto approx_row = [&](int r, int st0, int en0, auto getv, auto getu) {
+        if (r > 0) {
+            if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+                const int d0 = getv(last_H0_t), d1 = getu(last_H0_t + 1);
+                if (d0 > d1) H0 += d0;
+                else H0 += d1, ++last_H0_t;
+            } else if (last_H0_t >= st0 && last_H0_t <= en0) {
+                H0 += getv(last_H0_t);
+            } else {
+                ++last_H0_t, H0 += getu(last_H0_t);
+            }
+        } else H0 = getv(0) - K.qe, last_H0_t = 0;
+        if (flag & KSW_EZ_APPROX_DROP) {
+            if (H0 > ez_max) {
+                ez_max = H0, ez_max_t = last_H0_t, ez_max_q = r - last_H0_t;
+            } else if (last_H0_t >= ez_max_t && r - last_H0_t >= ez_max_q) {
+                const int tl = last_H0_t - ez_max_t, ql = (r - last_H0_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+                if (zdrop >= 0 && ez_max - H0 > zdrop + l * K.e2) { ez_zdropped = 1; brk = true; }
+            }
+        }
+        if (!brk && r == qlen + tlen - 2 && en0 == tlen - 1) ez_score = H0;
+    };
+    // NW > 1: bookkeeping of the owed row from what its waves published (triple-buffered: a fast wave may already be
+    // publishing row r + 1 while a slow one still reads row r - 1)
+    auto lag_row = [&]() {
+        const int r = lag_r;
+        lag_r = -1;
+        const uint32_t *pb = pub + (r % 3) * (NW + 2);
+        if (!APPROX) {
+            uint32_t best = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) best = pb[i] > best ? pb[i] : best;
+            const int max_H = (int)(best >> 16) - 32768, max_t = (int)((0xffffu - (best & 0xffffu)) & 8191u);
+            exact_row(r, lag_st0, lag_en0, lag_en, max_H, max_t, (int)pb[NW], (int)pb[NW + 1]);
+        } else {
+            const uint32_t *uv = uv4 + (r % 3) * 4;
+            const int L = lag_L;      // the cells published for this row are L .. L + 3
+            approx_row(r, lag_st0, lag_en0, [&](int t) { return (int)(short)(uv[t - L] >> 16); }, [&](int t) { return (int)(short)(uv[t - L] & 0xffffu); });
+        }
+    };
+
+    for (int r = 0; r < n_rows; ++r) {
+        const RowRange rr = row_range(r, qlen, tlen, w);
+        if (rr.empty) {
+            if (NW > 1 && lag_r >= 0) { lag_row(); if (brk) break; }       // the owed row comes first: it may have Z-dropped
+            ez_zdropped = 1;
+            break;
+        }
+        const int st0 = rr.st0, en0 = rr.en0, st = rr.st, en = rr.en;
+        const int bnd = r == 0 ? -K.q - K.e : r < K.long_thres ? -K.e : r == K.long_thres ? K.long_diff : -K.e2;
+        const bool need_const = st == 0 || !(st - 1 >= last_st && st - 1 <= last_en);
+        const int nbv_c = st > 0 ? -K.q - K.e : bnd;
+        const int sc_end = st0 + ((en0 - st0) / 16 + 1) * 16;
+        const int hi_t = en > sc_end - 1 ? en : sc_end - 1;               // last cell touched by this row (state or score store)
+        const int qbase = T + qlen - 1 - r;
+        const uint8_t *qsrc = (qbase & 1) ? qB + qbase - 1 : qA + qbase;   // + t0 (even) is 2-byte aligned either way
+        const int en1 = st0 + (en0 - st0) / 4 * 4;
+        uint8_t *prow = p + (size_t)r * ncol16 - st;
+        s2 pox = splat(0), pov = splat(0), pox2 = splat(0);
+        int pohh = 0;
+        uint32_t best = 0;
+        int pub_en0 = 0, pub_st0 = 0;
+        bool own_en0 = false, own_st0 = false;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int blk = c * NW + wv, tb = blk * 128;
+            const s2 ox = X[c], ov = V[c], ox2 = X2[c];
+            const int ohl = HL[c], ohh = HH[c];
+            if (tb <= hi_t && tb + 127 >= st) {
+                const int t0 = tb + 2 * lane;
+                const uint32_t qw = *reinterpret_cast<const uint16_t *>(qsrc + t0);
+                const s2 tq = S2((int)__builtin_amdgcn_perm(0u, qw, 0x0c010c00u));       // two bytes -> two halves
+                // (x, v, x2) of cell t0 - 1: the upper half of the lane to the left; lane 0: the last cell of the previous block
+                int fx, fv, fx2, fh;
+                if (NW == 1) {
+                    fx = __builtin_amdgcn_readlane(I32(pox), 63), fv = __builtin_amdgcn_readlane(I32(pov), 63), fx2 = __builtin_amdgcn_readlane(I32(pox2), 63);
+                    fh = __builtin_amdgcn_readlane(pohh, 63);
+                } else {
+                    const int sb = ((r + 1) & 1) * NB + (blk > 0 ? blk - 1 : 0);      // written at the end of row r - 1
+                    const uint2 sv = seam[sb];
+                    fx = (int)(sv.x << 16), fv = (int)(sv.x & 0xffff0000u), fx2 = (int)(sv.y << 16);
+                    fh = seam_h[sb];
+                }
+                s2 xt1 = left_nb(ox, shr1(fx, I32(ox))), vt1 = left_nb(ov, shr1(fv, I32(ov))), x2t1 = left_nb(ox2, shr1(fx2, I32(ox2)));
+                const int hleft_lo = !APPROX ? shr1(fh, ohh) : 0;
+                if (need_const && t0 == st) {        // one lane of the row, if any: the sweep's first cell sees the boundary constants
+                    xt1 = sel(0xffffu, splat(-K.q - K.e), xt1), vt1 = sel(0xffffu, splat(nbv_c), vt1), x2t1 = sel(0xffffu, splat(-K.q2 - K.e2), x2t1);
+                }
+                s2 ut = U[c], yo = Y[c], y2o = Y2[c];
+                if (en >= r && (uint32_t)(r - t0) < 2u) {     // the lane that owns cell t == r: u[r], y[r], y2[r] boundary of this row
+                    const uint32_t m = r == t0 ? 0xffffu : 0xffff0000u;
+                    ut = sel(m, splat(bnd), ut), yo = sel(m, splat(-K.q - K.e), yo), y2o = sel(m, splat(-K.q2 - K.e2), y2o);
+                }
+                SC[c] = sel(range_mask(TP[c], st0, sc_end - 1), score_pair(K, tq, TT[c]), SC[c]);
+                if (t0 >= st && t0 <= en) {
+                    s2 un, vn, xn, yn, x2n, y2n;
+                    uint32_t dbytes;
+                    cell_pair<RIGHT>(K, SC[c], ut, yo, y2o, xt1, vt1, x2t1, un, vn, xn, yn, x2n, y2n, dbytes);
+                    U[c] = un, V[c] = vn, X[c] = xn, Y[c] = yn, X2[c] = x2n, Y2[c] = y2n;
+                    *reinterpret_cast<uint16_t *>(prow + t0) = (uint16_t)dbytes;
+                    if (!APPROX) {
+                        const int vlo = (int)vn.x, vhi = (int)vn.y, ulo = (int)un.x, uhi = (int)un.y;
+                        int nl = ohl, nh = ohh;
+                        if (r > 0) {
+                            const bool in_lo = t0 >= st0 && t0 < en0, in_hi = t0 + 1 >= st0 && t0 + 1 < en0;
+                            if (in_lo) nl = ohl + vlo;
+                            if (in_hi) nh = ohh + vhi;
+                            if (t0 == en0) nl = en0 > 0 ? hleft_lo + ulo : ohl + vlo;
+                            if (t0 + 1 == en0) nh = ohl + uhi;                        // en0 = t0 + 1 > 0: H[en0 - 1] is the lane's own lower cell
+                            if (in_lo || t0 == en0) { const uint32_t k = (uint32_t)(nl + 32768) << 16 | (0xffffu - (uint32_t)key_rank(t0, st0, en0, en1)); best = k > best ? k : best; }
+                            if (in_hi || t0 + 1 == en0) { const uint32_t k = (uint32_t)(nh + 32768) << 16 | (0xffffu - (uint32_t)key_rank(t0 + 1, st0, en0, en1)); best = k > best ? k : best; }
+                        } else if (t0 == 0) {
+                            nl = vlo - K.qe;
+                            best = (uint32_t)(nl + 32768) << 16 | (0xffffu - 0u);
+                        }
+                        HL[c] = nl, HH[c] = nh;
+                        if (NW > 1) {
+                            if (t0 == en0 || t0 + 1 == en0) own_en0 = true, pub_en0 = t0 == en0 ? nl : nh;
+                            if (t0 == st0 || t0 + 1 == st0) own_st0 = true, pub_st0 = t0 == st0 ? nl : nh;
+                        }
+                    }
+                }
+            }
+            pox = ox, pov = ov, pox2 = ox2, pohh = ohh;
+        }
+        if (NW == 1) {
+            // bookkeeping of this row, straight from the registers
+            if (!APPROX) {
+                const uint32_t bw = wave_max_u32(best);
+                const int max_H = (int)(bw >> 16) - 32768, max_t = (int)((0xffffu - (bw & 0xffffu)) & 8191u);
+                exact_row(r, st0, en0, en, max_H, max_t, fetch32<NCH>(HL, HH, en0), fetch32<NCH>(HL, HH, st0));
+            } else {
+                approx_row(r, st0, en0, [&](int t) { return fetch16<NCH>(V, t); }, [&](int t) { return fetch16<NCH>(U, t); });
+            }
+            if (brk) break;
+        } else {
+            if (APPROX) {
+                // The bookkeeping of this row will need v[L'] and u[L' + 1] with L' = last_H0_t after row r - 1, which is L or L + 1 for
+                // the L known now (rows up to r - 2 are booked): publish cells L .. L + 3 -- from whatever the registers hold, updated
+                // this row or stale, which is what the reference's arrays would hold
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int t0 = (c * NW + wv) * 128 + 2 * lane;
+                    const uint32_t d0 = (uint32_t)(t0 - last_H0_t);
+                    if (d0 < 4u) uv4[(r % 3) * 4 + d0] = (uint32_t)(uint16_t)U[c].x | (uint32_t)(uint16_t)V[c].x << 16;
+                    if (d0 + 1u < 4u) uv4[(r % 3) * 4 + d0 + 1u] = (uint32_t)(uint16_t)U[c].y | (uint32_t)(uint16_t)V[c].y << 16;
+                }
+            }
+            // publish: the seam cells row r + 1 can need (new values = its "previous anti-diagonal"; cell tb + 128 is inside
+            // [st, en] of row r + 1 only if it is inside [st, en + 16] of this row), this wave's best key, H[en0] / H[st0]
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int blk = c * NW + wv, nx = blk * 128 + 128;
+                if (nx >= st && nx <= en + 16 && lane == 63) {
+                    const uint32_t xx = (uint32_t)I32(X[c]) >> 16, vv = (uint32_t)I32(V[c]) & 0xffff0000u, xx2 = (uint32_t)I32(X2[c]) >> 16;
+                    seam[(r & 1) * NB + blk] = make_uint2(xx | vv, xx2);
+                    if (!APPROX) seam_h[(r & 1) * NB + blk] = HH[c];
+                }
+            }
+            if (!APPROX) {
+                uint32_t *pb = pub + (r % 3) * (NW + 2);
+                const uint32_t bw = wave_max_u32(best);
+                if (lane == 0) pb[wv] = bw;
+                if (own_en0) pb[NW] = (uint32_t)pub_en0;
+                if (own_st0) pb[NW + 1] = (uint32_t)pub_st0;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int L_used = last_H0_t;                 // what this row's uv4 slots are relative to
+            if (lag_r >= 0) { lag_row(); if (brk) break; }
+            lag_r = r, lag_st0 = st0, lag_en0 = en0, lag_en = en, lag_L = L_used;
+        }
+        last_st = st, last_en = en;
+    }
+    if (NW > 1 && lag_r >= 0 && !brk && !ez_zdropped) lag_row();      // the last row's bookkeeping (its publication is behind a barrier already)
+    __threadfence_block();
+    __syncthreads();        // every traceback byte must have landed before one lane walks it
+    if (threadIdx.x == 0)
+        backtrack_and_store(tk, w, ncol16, p, cig_pool, res_out, ez_max, ez_zdropped, ez_max_q, ez_max_t, ez_mqe, ez_mqe_t, ez_mte, ez_mte_q, ez_score);
+}
+
+template <int NW, int NCH>
+__global__ __launch_bounds__(NW * 64) void ksw_extd2_reg_kernel(const KswTask *__restrict__ tasks, const uint32_t *__restrict__ order, uint32_t n, KswParams pr,
+                                                                const uint8_t *__restrict__ seqs, uint8_t *__restrict__ p_pool, uint32_t *__restrict__ cig_pool,
+                                                                KswResult *__restrict__ res)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    if (blockIdx.x >= n) return;
+    const KswTask tk = tasks[order[blockIdx.x]];
+    const bool approx = (tk.flag & KSW_EZ_APPROX_MAX) != 0, right = (tk.flag & KSW_EZ_RIGHT) != 0;      // uniform per workgroup
+    if (approx) {
+        if (right) ksw_reg_run<NW, NCH, true, true>(tk, pr, seqs, p_pool, cig_pool, res, lds);
+        else ksw_reg_run<NW, NCH, true, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
+    } else {
+        if (right) ksw_reg_run<NW, NCH, false, true>(tk, pr, seqs, p_pool, cig_pool, res, lds);
+        else ksw_reg_run<NW, NCH, false, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
+    }
+}
+
+struct RegClass { int nw, nch; };
+constexpr RegClass kRegClass[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {4, 3}, {8, 5}};      // cells per anti-diagonal: 256, 512, 1536, 5120
+
+}  // namespace
+
+int ksw_reg_cells(int cls) { return kRegClass[cls].nw * kRegClass[cls].nch * 128; }
+int ksw_reg_threads(int cls) { return kRegClass[cls].nw * 64; }
+
+size_t ksw_reg_lds_bytes(int cls, int qlen)
+{
+    const int nw = kRegClass[cls].nw, nb = nw * kRegClass[cls].nch;
+    size_t b = 2 * (size_t)reg_qb(ksw_reg_cells(cls), qlen);
+    if (nw > 1) b += (size_t)2 * nb * 12 + (size_t)3 * (nw + 2) * 4 + 48;
+    return b + 16;
+}
+
+// Which register-resident class serves the problem, or -1: the proofs behind the packed arithmetic (no int8 wrap outside the four
+// adjusted gap terms, 16-bit H keys) hold for minimap2-sized scores and gap costs and for problems that fit a class.
+int ksw_reg_class(const KswTask &t, const KswParams &pr)
+{
+    static const bool off = getenv("NSGPU_KSW_NO_REG") != nullptr;       // debugging aid: first-generation kernels only
+    if (off || t.qlen <= 0 || t.tlen <= 0) return -1;
+    int q = pr.q, e = pr.e, q2 = pr.q2, e2 = pr.e2;
+    if (q2 + e2 < q + e) { std::swap(q, q2); std::swap(e, e2); }
+    const int sc_n = pr.sc_ambi == 0 ? -e2 : pr.sc_ambi;
+    if (pr.sc_mch < 0 || pr.sc_mch > 4 || pr.sc_mis > 0 || pr.sc_mis < -8 || sc_n > 0 || sc_n < -8) return -1;
+    if (q < 0 || e < 1 || q + e > 12 || q2 + e2 > 32 || e2 < 1 || q2 < 0) return -1;
+    int w = t.w;
+    if (w < 0 || w > t.qlen + t.tlen) w = t.qlen + t.tlen;
+    const int mn = t.qlen < t.tlen ? t.qlen : t.tlen;
+    if (8 * (long long)mn + 12LL * (w + 1) + 64 >= 32768) return -1;     // |H| of any in-band cell stays a 16-bit key
+    for (int c = 0; c < KSW_REG_CLASSES; ++c)
+        if (t.tlen <= ksw_reg_cells(c)) return c;
+    return -1;
+}
+
+int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const KswTask *tasks, const uint32_t *order, const KswParams &pr, const uint8_t *seqs,
+                   uint8_t *p_pool, uint32_t *cig_pool, KswResult *res)
+{
+#define NS_REG_LAUNCH(NW_, NCH_)                                                                                                              \
+    {                                                                                                                                         \
+        static size_t cap = 0;                                                                                                                \
+        if (lds_bytes > 32768 && lds_bytes > cap) {                                                                                           \
+            NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_reg_kernel<NW_, NCH_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+            cap = lds_bytes;                                                                                                                  \
+        }                                                                                                                                     \
+        hipLaunchKernelGGL((ksw_extd2_reg_kernel<NW_, NCH_>), dim3(m), dim3(NW_ * 64), lds_bytes, st, tasks, order, m, pr, seqs, p_pool, cig_pool, res); \
+    }
+    switch (cls) {
+    case 0: NS_REG_LAUNCH(1, 2) break;
+    case 1: NS_REG_LAUNCH(1, 4) break;
+    case 2: NS_REG_LAUNCH(4, 3) break;
+    case 3: NS_REG_LAUNCH(8, 5) break;
+    default: NS_CHECK(false, NSGPU_ERR_ARG, "ksw: bad register class");
+    }
+#undef NS_REG_LAUNCH
+    NS_HIP(hipGetLastError());
+    return NSGPU_OK;
+}
+
+}  // namespace nsgpu

@@ -142,3 +142,19 @@ def test_scores_that_wrap_int8_in_earnest(env):
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
     assert int(line[1]) == 0, (env, line)
+
+
+def test_register_kernels_diverse_vs_oracle(gpu, oracle):
+    """ksw2_reg.hip (state in registers, packed int16, one wave or a workgroup per problem) on problems of every class: all flag
+    combinations, thin bands that bind (out-of-band garbage cells with int8 wrap-around feed in-band cells), Z-drops, N bases."""
+    from tests.ksw_cases import diverse_cases
+    probs = diverse_cases(7, 640)
+    ezs, cigs = ns.ksw_extd2_batch(gpu, probs)
+    n_long = n_zd = 0
+    for i, (q, t, w, zdrop, eb, flag) in enumerate(probs):
+        we, wc = oracle_lib.oracle_ksw(oracle, q, t, w, zdrop, eb, flag)
+        assert ezs[i] == we, (i, len(q), len(t), w, zdrop, hex(flag), ezs[i], we)
+        assert np.array_equal(cigs[i], wc), (i, len(q), len(t), w, hex(flag))
+        n_long += len(t) > 1536
+        n_zd += we[1]
+    assert n_long > 40 and n_zd > 40
