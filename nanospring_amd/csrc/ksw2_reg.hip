@@ -234,10 +234,41 @@ __host__ __device__ inline int reg_qb(int T, int qlen) { return 2 * T + (qlen + 
 // -------------------------------------------------------------------------------------------------------------------
 // The row loop.  NW waves, NCH register sets per lane.
 // -------------------------------------------------------------------------------------------------------------------
-template <int NW, int NCH, bool APPROX, bool RIGHT>
+// Per-row bookkeeping on the VECTOR unit.  The values are the same in every lane, but on this chip a scalar instruction
+// costs a wave twice the issue time of a vector one (one scalar unit per CU against four SIMD-32s), and the first version
+// of this kernel, with ~300 scalar instructions per anti-diagonal, was bound by exactly that.  vreg() hides a value from
+// the compiler's uniformity analysis so that what is derived from it stays in VGPRs; decisions come back to the scalar
+// unit through one v_readfirstlane per row.
+// -------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int vreg(int x) { asm volatile("" : "+v"(x)); return x; }
+
+struct Ez { int max, max_t, max_q, mte, mte_q, mqe, mqe_t; };
+
+// ksw_apply_zdrop (ksw2.h:160-176, is_rot = 1) in select form; returns 1 when the row Z-drops
+__device__ __forceinline__ int zdrop_row(Ez &z, int r, int max_H, int max_t, int zdrop, int e2)
+{
+    const bool better = max_H > z.max;
+    const int tl = max_t - z.max_t, ql = (r - max_t) - z.max_q;
+    const int l = tl > ql ? tl - ql : ql - tl;
+    const bool drop = !better && max_t >= z.max_t && r - max_t >= z.max_q && zdrop >= 0 && z.max - max_H > zdrop + l * e2;
+    z.max_t = better ? max_t : z.max_t, z.max_q = better ? r - max_t : z.max_q, z.max = better ? max_H : z.max;
+    return drop ? 1 : 0;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// The row loop.  NW waves, NCH register sets per lane.
+//   APPROX        KSW_EZ_APPROX_MAX (gap fills): no per-row maximum
+//   FAST          APPROX, no KSW_EZ_APPROX_DROP and a band that never binds (w >= qlen + tlen): every cell is a true DP
+//                 cell, u and v are differences of ONE well-defined score matrix, so the score the reference accumulates
+//                 along its greedy H0 path equals the sum along ANY path -- here the matrix's left column (v of cell 0 on
+//                 rows < qlen) and then its bottom row (u of cell st0 on the rows after), which each lane adds up for its own
+//                 cells: no per-row bookkeeping at all
+// -------------------------------------------------------------------------------------------------------------------
+template <int NW, int NCH, bool APPROX, bool RIGHT, bool FAST>
 __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_t *__restrict__ seqs, uint8_t *__restrict__ p_pool,
                             uint32_t *__restrict__ cig_pool, KswResult *__restrict__ res_out, uint8_t *lds)
 {
+    static_assert(!FAST || (APPROX && NW == 1), "the path-independent score is used by the one-wave gap-fill classes");
     constexpr int T = NW * NCH * 128;
     constexpr int NB = NW * NCH;                 // blocks of 128 cells
     const int lane = threadIdx.x & 63, wv = NW > 1 ? (int)(threadIdx.x >> 6) : 0;
@@ -280,6 +311,7 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
     }
     // register state
     s2 TT[NCH], TP[NCH], SC[NCH], U[NCH], V[NCH], X[NCH], Y[NCH], X2[NCH], Y2[NCH];      // TP: the two t's of the lane
+    s2 ACC[NCH];                                                                         // FAST: the lane's share of the score
     int HL[NCH], HH[NCH];
     {
         const uint8_t *target = seqs + tk.toff;
@@ -289,7 +321,7 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
             const int b0 = t0 < tlen ? target[t0] : 0, b1 = t0 + 1 < tlen ? target[t0 + 1] : 0;
             TT[c] = S2(b0 | b1 << 16);
             TP[c] = S2(t0 | (t0 + 1) << 16);
-            SC[c] = splat(0);
+            SC[c] = splat(0), ACC[c] = splat(0);
             U[c] = V[c] = X[c] = Y[c] = splat(-K.q - K.e);
             X2[c] = Y2[c] = splat(-K.q2 - K.e2);
             HL[c] = HH[c] = KSW_NEG_INF;
@@ -305,28 +337,25 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
         __syncthreads();
     } else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-    int ez_max = 0, ez_zdropped = 0, ez_max_q = -1, ez_max_t = -1, ez_mqe = KSW_NEG_INF, ez_mqe_t = -1, ez_mte = KSW_NEG_INF, ez_mte_q = -1;
-    int ez_score = KSW_NEG_INF;
+    Ez z;
+    z.max = vreg(0), z.max_t = vreg(-1), z.max_q = vreg(-1), z.mte = vreg(KSW_NEG_INF), z.mte_q = vreg(-1), z.mqe = vreg(KSW_NEG_INF), z.mqe_t = vreg(-1);
+    int ez_zdropped = 0, ez_score = KSW_NEG_INF;
     uint8_t *p = p_pool + tk.p_off;
     int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0;
-    const int n_rows = qlen + tlen - 1;
+    const int n_rows = qlen + tlen - 1, c1 = qlen - 1, c2 = tlen - 1;
     // NW > 1: the bookkeeping of row r - 1 is done after the barrier of row r (a lag of one row, so that it never costs a
     // second barrier); these describe the row that is still owed
     int lag_r = -1, lag_st0 = 0, lag_en0 = 0, lag_en = 0, lag_L = 0;
     bool brk = false;
 
-    // ---- the per-row bookkeeping (uniform): ksw2_extd2_sse.c:323-383 given the row's published scalars ----
+    // ---- exact mode, rows r > 0 and r == 0 alike: ksw2_extd2_sse.c:359-366 given the row's maximum and H[en0], H[st0] ----
     auto exact_row = [&](int r, int st0, int en0, int en, int max_H, int max_t, int h_en0, int h_st0) {
-        if (en0 == tlen - 1 && h_en0 > ez_mte) ez_mte = h_en0, ez_mte_q = r - en;
-        if (r - st0 == qlen - 1 && h_st0 > ez_mqe) ez_mqe = h_st0, ez_mqe_t = st0;
-        if (max_H > ez_max) {
-            ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
-        } else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
-            const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
-            if (zdrop >= 0 && ez_max - max_H > zdrop + l * K.e2) { ez_zdropped = 1; brk = true; }
-        }
-        if (!brk && r == qlen + tlen - 2 && en0 == tlen - 1) ez_score = h_en0;
+        if (en0 == c2) { const bool up = h_en0 > z.mte; z.mte_q = up ? r - en : z.mte_q, z.mte = up ? h_en0 : z.mte; }
+        if (r - st0 == c1) { const bool up = h_st0 > z.mqe; z.mqe_t = up ? st0 : z.mqe_t, z.mqe = up ? h_st0 : z.mqe; }
+        if (__builtin_amdgcn_readfirstlane(zdrop_row(z, r, max_H, max_t, zdrop, K.e2))) { ez_zdropped = 1; brk = true; }
+        if (!brk && r == n_rows - 1 && en0 == c2) ez_score = __builtin_amdgcn_readfirstlane(h_en0);
     };
+    // ---- approx mode with the reference's greedy H0 (ksw2_extd2_sse.c:367-383): banded or KSW_EZ_APPROX_DROP problems only ----
     auto approx_row = [&](int r, int st0, int en0, auto getv, auto getu) {
         if (r > 0) {
             if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
@@ -339,15 +368,9 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
                 ++last_H0_t, H0 += getu(last_H0_t);
             }
         } else H0 = getv(0) - K.qe, last_H0_t = 0;
-        if (flag & KSW_EZ_APPROX_DROP) {
-            if (H0 > ez_max) {
-                ez_max = H0, ez_max_t = last_H0_t, ez_max_q = r - last_H0_t;
-            } else if (last_H0_t >= ez_max_t && r - last_H0_t >= ez_max_q) {
-                const int tl = last_H0_t - ez_max_t, ql = (r - last_H0_t) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
-                if (zdrop >= 0 && ez_max - H0 > zdrop + l * K.e2) { ez_zdropped = 1; brk = true; }
-            }
-        }
-        if (!brk && r == qlen + tlen - 2 && en0 == tlen - 1) ez_score = H0;
+        if (flag & KSW_EZ_APPROX_DROP)
+            if (__builtin_amdgcn_readfirstlane(zdrop_row(z, r, H0, last_H0_t, zdrop, K.e2))) { ez_zdropped = 1; brk = true; }
+        if (!brk && r == n_rows - 1 && en0 == c2) ez_score = H0;
     };
     // NW > 1: bookkeeping of the owed row from what its waves published (triple-buffered: a fast wave may already be
     // publishing row r + 1 while a slow one still reads row r - 1)
@@ -359,8 +382,9 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
             uint32_t best = 0;
 #pragma unroll
             for (int i = 0; i < NW; ++i) best = pb[i] > best ? pb[i] : best;
-            const int max_H = (int)(best >> 16) - 32768, max_t = (int)((0xffffu - (best & 0xffffu)) & 8191u);
-            exact_row(r, lag_st0, lag_en0, lag_en, max_H, max_t, (int)pb[NW], (int)pb[NW + 1]);
+            const int bv = vreg((int)best);
+            const int max_H = (int)((uint32_t)bv >> 16) - 32768, max_t = (int)((0xffffu - ((uint32_t)bv & 0xffffu)) & 8191u);
+            exact_row(r, lag_st0, lag_en0, lag_en, max_H, max_t, vreg((int)pb[NW]), vreg((int)pb[NW + 1]));
         } else {
             const uint32_t *uv = uv4 + (r % 3) * 4;
             const int L = lag_L;      // the cells published for this row are L .. L + 3
@@ -369,22 +393,26 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
     };
 
     for (int r = 0; r < n_rows; ++r) {
-        const RowRange rr = row_range(r, qlen, tlen, w);
-        if (rr.empty) {
+        // row limits (ksw2_extd2_sse.c:138-147); st0, en0 >= 0 here, so the 16-alignment is plain bit arithmetic
+        int st0 = r - c1, en0 = r;
+        { const int b = (r - w + 1) >> 1; st0 = st0 > b ? st0 : b; st0 = st0 > 0 ? st0 : 0; }
+        { const int b = (r + w) >> 1; en0 = en0 < b ? en0 : b; en0 = en0 < c2 ? en0 : c2; }
+        if (st0 > en0) {
             if (NW > 1 && lag_r >= 0) { lag_row(); if (brk) break; }       // the owed row comes first: it may have Z-dropped
             ez_zdropped = 1;
             break;
         }
-        const int st0 = rr.st0, en0 = rr.en0, st = rr.st, en = rr.en;
-        const int bnd = r == 0 ? -K.q - K.e : r < K.long_thres ? -K.e : r == K.long_thres ? K.long_diff : -K.e2;
-        const bool need_const = st == 0 || !(st - 1 >= last_st && st - 1 <= last_en);
+        const int st = st0 & ~15, en = en0 | 15;
+        const int sc_last = st0 + ((en0 - st0) & ~15) + 15;               // last cell of the row's 16-byte score stores
+        const int hi_t = en > sc_last ? en : sc_last;                     // last cell touched by this row (state or score store)
+        int bnd = -K.e2;
+        if (r <= K.long_thres) bnd = r == 0 ? -K.q - K.e : r < K.long_thres ? -K.e : K.long_diff;
+        const bool need_const = st == 0 || st - 1 < last_st || st - 1 > last_en;
         const int nbv_c = st > 0 ? -K.q - K.e : bnd;
-        const int sc_end = st0 + ((en0 - st0) / 16 + 1) * 16;
-        const int hi_t = en > sc_end - 1 ? en : sc_end - 1;               // last cell touched by this row (state or score store)
-        const int qbase = T + qlen - 1 - r;
+        const int qbase = T + c1 - r;
         const uint8_t *qsrc = (qbase & 1) ? qB + qbase - 1 : qA + qbase;   // + t0 (even) is 2-byte aligned either way
-        const int en1 = st0 + (en0 - st0) / 4 * 4;
-        uint8_t *prow = p + (size_t)r * ncol16 - st;
+        const int en1 = st0 + ((en0 - st0) & ~3);
+        const uint32_t prow = (uint32_t)r * (uint32_t)ncol16 - (uint32_t)st;     // the traceback of one problem is < 4 GiB (host check)
         s2 pox = splat(0), pov = splat(0), pox2 = splat(0);
         int pohh = 0;
         uint32_t best = 0;
@@ -400,15 +428,15 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
                 const uint32_t qw = *reinterpret_cast<const uint16_t *>(qsrc + t0);
                 const s2 tq = S2((int)__builtin_amdgcn_perm(0u, qw, 0x0c010c00u));       // two bytes -> two halves
                 // (x, v, x2) of cell t0 - 1: the upper half of the lane to the left; lane 0: the last cell of the previous block
-                int fx, fv, fx2, fh;
+                int fx, fv, fx2, fh = 0;
                 if (NW == 1) {
                     fx = __builtin_amdgcn_readlane(I32(pox), 63), fv = __builtin_amdgcn_readlane(I32(pov), 63), fx2 = __builtin_amdgcn_readlane(I32(pox2), 63);
-                    fh = __builtin_amdgcn_readlane(pohh, 63);
+                    if (!APPROX) fh = __builtin_amdgcn_readlane(pohh, 63);
                 } else {
                     const int sb = ((r + 1) & 1) * NB + (blk > 0 ? blk - 1 : 0);      // written at the end of row r - 1
                     const uint2 sv = seam[sb];
                     fx = (int)(sv.x << 16), fv = (int)(sv.x & 0xffff0000u), fx2 = (int)(sv.y << 16);
-                    fh = seam_h[sb];
+                    if (!APPROX) fh = seam_h[sb];
                 }
                 s2 xt1 = left_nb(ox, shr1(fx, I32(ox))), vt1 = left_nb(ov, shr1(fv, I32(ov))), x2t1 = left_nb(ox2, shr1(fx2, I32(ox2)));
                 const int hleft_lo = !APPROX ? shr1(fh, ohh) : 0;
@@ -420,13 +448,19 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
                     const uint32_t m = r == t0 ? 0xffffu : 0xffff0000u;
                     ut = sel(m, splat(bnd), ut), yo = sel(m, splat(-K.q - K.e), yo), y2o = sel(m, splat(-K.q2 - K.e2), y2o);
                 }
-                SC[c] = sel(range_mask(TP[c], st0, sc_end - 1), score_pair(K, tq, TT[c]), SC[c]);
+                SC[c] = sel(range_mask(TP[c], st0, sc_last), score_pair(K, tq, TT[c]), SC[c]);
                 if (t0 >= st && t0 <= en) {
                     s2 un, vn, xn, yn, x2n, y2n;
                     uint32_t dbytes;
                     cell_pair<RIGHT>(K, SC[c], ut, yo, y2o, xt1, vt1, x2t1, un, vn, xn, yn, x2n, y2n, dbytes);
                     U[c] = un, V[c] = vn, X[c] = xn, Y[c] = yn, X2[c] = x2n, Y2[c] = y2n;
-                    *reinterpret_cast<uint16_t *>(prow + t0) = (uint16_t)dbytes;
+                    *reinterpret_cast<uint16_t *>(p + (prow + (uint32_t)t0)) = (uint16_t)dbytes;
+                    if (FAST) {
+                        // the one cell of this row on the score path: cell 0 while r < qlen (its v), cell st0 = r - qlen + 1 afterwards (its u)
+                        const s2 e = S2(I32(TP[c]) ^ I32(splat(st0)));
+                        const s2 m = S2u(to01(U2(e))) - splat(1);                     // 0xffff in the half whose t == st0
+                        ACC[c] = ACC[c] + S2(I32(m) & I32(r < qlen ? vn : un));
+                    }
                     if (!APPROX) {
                         const int vlo = (int)vn.x, vhi = (int)vn.y, ulo = (int)un.x, uhi = (int)un.y;
                         int nl = ohl, nh = ohh;
@@ -455,13 +489,17 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
         if (NW == 1) {
             // bookkeeping of this row, straight from the registers
             if (!APPROX) {
-                const uint32_t bw = wave_max_u32(best);
-                const int max_H = (int)(bw >> 16) - 32768, max_t = (int)((0xffffu - (bw & 0xffffu)) & 8191u);
-                exact_row(r, st0, en0, en, max_H, max_t, fetch32<NCH>(HL, HH, en0), fetch32<NCH>(HL, HH, st0));
-            } else {
+                const int bv = vreg((int)wave_max_u32(best));
+                const int max_H = (int)((uint32_t)bv >> 16) - 32768, max_t = (int)((0xffffu - ((uint32_t)bv & 0xffffu)) & 8191u);
+                int h_en0 = 0, h_st0 = 0;
+                if (en0 == c2) h_en0 = vreg(fetch32<NCH>(HL, HH, en0));               // only the rows that can move mte / mqe / the score pay for the fetch
+                if (r - st0 == c1) h_st0 = vreg(fetch32<NCH>(HL, HH, st0));
+                exact_row(r, st0, en0, en, max_H, max_t, h_en0, h_st0);
+                if (brk) break;
+            } else if (!FAST) {
                 approx_row(r, st0, en0, [&](int t) { return fetch16<NCH>(V, t); }, [&](int t) { return fetch16<NCH>(U, t); });
+                if (brk) break;
             }
-            if (brk) break;
         } else {
             if (APPROX) {
                 // The bookkeeping of this row will need v[L'] and u[L' + 1] with L' = last_H0_t after row r - 1, which is L or L + 1 for
@@ -501,10 +539,21 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
         last_st = st, last_en = en;
     }
     if (NW > 1 && lag_r >= 0 && !brk && !ez_zdropped) lag_row();      // the last row's bookkeeping (its publication is behind a barrier already)
+    if (FAST) {
+        // unbanded approx problems never Z-drop and always reach the last row: score = H(tlen - 1, qlen - 1) = the path sum - (q + e)
+        int sum = 0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) sum += (int)ACC[c].x + (int)ACC[c].y;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        ez_score = sum - K.qe;
+    }
     __threadfence_block();
     __syncthreads();        // every traceback byte must have landed before one lane walks it
     if (threadIdx.x == 0)
-        backtrack_and_store(tk, w, ncol16, p, cig_pool, res_out, ez_max, ez_zdropped, ez_max_q, ez_max_t, ez_mqe, ez_mqe_t, ez_mte, ez_mte_q, ez_score);
+        backtrack_and_store(tk, w, ncol16, p, cig_pool, res_out, __builtin_amdgcn_readfirstlane(z.max), ez_zdropped, __builtin_amdgcn_readfirstlane(z.max_q),
+                            __builtin_amdgcn_readfirstlane(z.max_t), __builtin_amdgcn_readfirstlane(z.mqe), __builtin_amdgcn_readfirstlane(z.mqe_t),
+                            __builtin_amdgcn_readfirstlane(z.mte), __builtin_amdgcn_readfirstlane(z.mte_q), ez_score);
 }
 
 template <int NW, int NCH>
@@ -517,11 +566,15 @@ __global__ __launch_bounds__(NW * 64) void ksw_extd2_reg_kernel(const KswTask *_
     const KswTask tk = tasks[order[blockIdx.x]];
     const bool approx = (tk.flag & KSW_EZ_APPROX_MAX) != 0, right = (tk.flag & KSW_EZ_RIGHT) != 0;      // uniform per workgroup
     if (approx) {
-        if (right) ksw_reg_run<NW, NCH, true, true>(tk, pr, seqs, p_pool, cig_pool, res, lds);
-        else ksw_reg_run<NW, NCH, true, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
+        // gap fills whose band never binds and that cannot Z-drop take the path-independent score (see ksw_reg_run)
+        const int w = tk.w < 0 ? tk.qlen + tk.tlen : tk.w;
+        const bool fast = NW == 1 && !(tk.flag & KSW_EZ_APPROX_DROP) && w >= tk.qlen + tk.tlen;
+        if (right) ksw_reg_run<NW, NCH, true, true, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
+        else if (fast) ksw_reg_run<NW, NCH, true, false, NW == 1>(tk, pr, seqs, p_pool, cig_pool, res, lds);
+        else ksw_reg_run<NW, NCH, true, false, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
     } else {
-        if (right) ksw_reg_run<NW, NCH, false, true>(tk, pr, seqs, p_pool, cig_pool, res, lds);
-        else ksw_reg_run<NW, NCH, false, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
+        if (right) ksw_reg_run<NW, NCH, false, true, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
+        else ksw_reg_run<NW, NCH, false, false, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
     }
 }
 
@@ -555,7 +608,9 @@ int ksw_reg_class(const KswTask &t, const KswParams &pr)
     int w = t.w;
     if (w < 0 || w > t.qlen + t.tlen) w = t.qlen + t.tlen;
     const int mn = t.qlen < t.tlen ? t.qlen : t.tlen;
-    if (8 * (long long)mn + 12LL * (w + 1) + 64 >= 32768) return -1;     // |H| of any in-band cell stays a 16-bit key
+    // |H| of any in-band cell stays a 16-bit key: H <= sc_mch * min(qlen, tlen); along a diagonal H drops by at most |sc_mis| per cell, a
+    // cell entering the band starts at most q + e below its neighbour (u >= -(q + e) for sane states), and there are at most w + 1 diagonals
+    if ((long long)(-pr.sc_mis > pr.sc_mch ? -pr.sc_mis : pr.sc_mch) * mn + (long long)(q + e) * (w + 1) + 64 >= 32768) return -1;
     for (int c = 0; c < KSW_REG_CLASSES; ++c)
         if (t.tlen <= ksw_reg_cells(c)) return c;
     return -1;
