@@ -731,7 +731,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     std::vector<uint32_t> wg[3];
     // second generation (ksw2_reg.hip): state in registers; serves every problem whose parameters and shape keep its proofs valid
     std::vector<uint32_t> reg[KSW_REG_CLASSES];
-    size_t reg_lds[KSW_REG_CLASSES] = {0, 0, 0, 0};
+    size_t reg_lds[KSW_REG_CLASSES] = {};
     static const int kWgThreads[3] = {0, 256, 256}, kWgMaxPos[3] = {0, 5, 8};      // widest sweep served: 1280 / 2048 cells (256 x 5 / 8 or 512 x 3 / 4)
     static const bool no_wg = getenv("NSGPU_KSW_NO_WG") != nullptr;      // debugging aid: fallback kernels only
     static const bool wg512 = getenv("NSGPU_KSW_WG256") == nullptr;     // 512 threads per long problem (8 waves; NSGPU_KSW_WG256=1: 4 waves)
@@ -815,7 +815,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     NS_HIP(hipMemcpyAsync(W.k_res.p, results.data(), n * sizeof(KswResult), hipMemcpyHostToDevice, S));
     std::vector<uint32_t> &flat = W.h_flat;          // stays alive while the upload may still be reading it
     flat.clear();
-    size_t start[5] = {0, 0, 0, 0, 0}, wg_start[3] = {0, 0, 0}, reg_start[KSW_REG_CLASSES] = {0, 0, 0, 0};
+    size_t start[5] = {0, 0, 0, 0, 0}, wg_start[3] = {0, 0, 0}, reg_start[KSW_REG_CLASSES] = {};
     // big problems first inside a class (longest-processing-time-first): 64 buckets by the logarithm of the cell count, taken
     // in descending order -- the schedule only needs the rough order, a comparison sort of every batch does not pay
     auto lpt_order = [&](std::vector<uint32_t> &v) {

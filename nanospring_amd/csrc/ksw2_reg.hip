@@ -295,12 +295,12 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
     int *seam_h = reinterpret_cast<int *>(lds + 2 * QB + 2 * NB * 8);      // [2][NB] its H
     uint32_t *pub = reinterpret_cast<uint32_t *>(lds + 2 * QB + 2 * NB * 12);   // [3][NW + 2]: per-wave best key, H[en0], H[st0] of a row
     uint32_t *uv4 = pub + 3 * (NW + 2);                                    // [3][4] approx: u | v << 16 of cells L .. L + 3 (L = last_H0_t two rows back)
+    uint32_t *stop_flag = uv4 + 12;                                        // exact, NW > 1: wave 0 (the only one that keeps the books) saw a Z-drop
 
     for (int i = threadIdx.x; i < (2 * QB) / 4; i += NW * 64) reinterpret_cast<uint32_t *>(lds)[i] = 0;
-    if (NW > 1) {
-        for (int i = threadIdx.x; i < 2 * NB * 3 + 3 * (NW + 2) + 12; i += NW * 64) reinterpret_cast<uint32_t *>(lds + 2 * QB)[i] = 0;
-        __syncthreads();
-    } else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int i = threadIdx.x; i < 2 * NB * 3 + 3 * (NW + 2) + 13; i += NW * 64) reinterpret_cast<uint32_t *>(lds + 2 * QB)[i] = 0;
+    if (NW > 1) __syncthreads();
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     {
         const uint8_t *query = seqs + tk.qoff;
         for (int j = threadIdx.x; j < qlen; j += NW * 64) {
@@ -398,7 +398,7 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
         { const int b = (r - w + 1) >> 1; st0 = st0 > b ? st0 : b; st0 = st0 > 0 ? st0 : 0; }
         { const int b = (r + w) >> 1; en0 = en0 < b ? en0 : b; en0 = en0 < c2 ? en0 : c2; }
         if (st0 > en0) {
-            if (NW > 1 && lag_r >= 0) { lag_row(); if (brk) break; }       // the owed row comes first: it may have Z-dropped
+            if (NW > 1 && lag_r >= 0) { lag_row(); if (brk) break; }       // the owed row comes first: it may have Z-dropped (every wave leaves here: no flag needed)
             ez_zdropped = 1;
             break;
         }
@@ -477,10 +477,8 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
                             best = (uint32_t)(nl + 32768) << 16 | (0xffffu - 0u);
                         }
                         HL[c] = nl, HH[c] = nh;
-                        if (NW > 1) {
-                            if (t0 == en0 || t0 + 1 == en0) own_en0 = true, pub_en0 = t0 == en0 ? nl : nh;
-                            if (t0 == st0 || t0 + 1 == st0) own_st0 = true, pub_st0 = t0 == st0 ? nl : nh;
-                        }
+                        if (t0 == en0 || t0 + 1 == en0) own_en0 = true, pub_en0 = t0 == en0 ? nl : nh;
+                        if (t0 == st0 || t0 + 1 == st0) own_st0 = true, pub_st0 = t0 == st0 ? nl : nh;
                     }
                 }
             }
@@ -491,9 +489,17 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
             if (!APPROX) {
                 const int bv = vreg((int)wave_max_u32(best));
                 const int max_H = (int)((uint32_t)bv >> 16) - 32768, max_t = (int)((0xffffu - ((uint32_t)bv & 0xffffu)) & 8191u);
+                // H[en0] / H[st0]: the owning lane hands it to everybody through LDS (only the rows that can move mte / mqe / the score)
                 int h_en0 = 0, h_st0 = 0;
-                if (en0 == c2) h_en0 = vreg(fetch32<NCH>(HL, HH, en0));               // only the rows that can move mte / mqe / the score pay for the fetch
-                if (r - st0 == c1) h_st0 = vreg(fetch32<NCH>(HL, HH, st0));
+                const bool want_en0 = en0 == c2, want_st0 = r - st0 == c1;
+                if (want_en0 && own_en0) pub[0] = (uint32_t)pub_en0;
+                if (want_st0 && own_st0) pub[1] = (uint32_t)pub_st0;
+                if (want_en0 || want_st0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (want_en0) h_en0 = (int)pub[0];
+                    if (want_st0) h_st0 = (int)pub[1];
+                    h_en0 = vreg(h_en0), h_st0 = vreg(h_st0);
+                }
                 exact_row(r, st0, en0, en, max_H, max_t, h_en0, h_st0);
                 if (brk) break;
             } else if (!FAST) {
@@ -533,8 +539,18 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             const int L_used = last_H0_t;                 // what this row's uv4 slots are relative to
-            if (lag_r >= 0) { lag_row(); if (brk) break; }
-            lag_r = r, lag_st0 = st0, lag_en0 = en0, lag_en = en, lag_L = L_used;
+            if (APPROX || wv == 0) {
+                // exact mode: only wave 0 keeps the books (the same ~100 instructions in every wave were most of a row's cost); when it
+                // sees the Z-drop it raises the flag and still meets the others at their next barrier, where they read it and leave too
+                if (lag_r >= 0) {
+                    lag_row();
+                    if (brk) {
+                        if (!APPROX) { if (lane == 0) *stop_flag = 1u; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+                        break;
+                    }
+                }
+                lag_r = r, lag_st0 = st0, lag_en0 = en0, lag_en = en, lag_L = L_used;
+            } else if (*stop_flag) break;                 // raised by wave 0 before it arrived at this barrier
         }
         last_st = st, last_en = en;
     }
@@ -578,8 +594,11 @@ __global__ __launch_bounds__(NW * 64) void ksw_extd2_reg_kernel(const KswTask *_
     }
 }
 
+// Classes.  Short problems (the gap fills) are throughput: one wave each.  Problems with many anti-diagonals (extensions of a few
+// thousand bases against a few hundred) are latency: the launch is over when its longest problem is, so they get one 128-cell block per
+// wave and row.
 struct RegClass { int nw, nch; };
-constexpr RegClass kRegClass[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {4, 3}, {8, 5}};      // cells per anti-diagonal: 256, 512, 1536, 5120
+constexpr RegClass kRegClass[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {4, 3}, {8, 5}};
 
 }  // namespace
 
@@ -590,7 +609,7 @@ size_t ksw_reg_lds_bytes(int cls, int qlen)
 {
     const int nw = kRegClass[cls].nw, nb = nw * kRegClass[cls].nch;
     size_t b = 2 * (size_t)reg_qb(ksw_reg_cells(cls), qlen);
-    if (nw > 1) b += (size_t)2 * nb * 12 + (size_t)3 * (nw + 2) * 4 + 48;
+    b += (size_t)2 * nb * 12 + (size_t)3 * (nw + 2) * 4 + 52;      // seams / publication slots (a one-wave class uses two of the slots) / stop flag
     return b + 16;
 }
 
