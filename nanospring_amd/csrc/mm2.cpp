@@ -1,3 +1,10 @@
+// ---------------------------------------------------------------------------------------------------------------------
+// Third-party notice.  The functions in this file reproduce, decision for decision, the behaviour of minimap2 v2.17
+// (https://github.com/lh3/minimap2; files cited per function) -- bit-exact tie orders and thresholds are part of the
+// contract of NanoSpring's on-disk format, so the order of the decisions is minimap2's by necessity.  minimap2 is
+//   Copyright (c) 2018- Dana-Farber Cancer Institute, 2017-2018 Broad Institute, Inc.
+// and distributed under the MIT License; its full text is in THIRD_PARTY_NOTICES.md at the root of this repository.
+// ---------------------------------------------------------------------------------------------------------------------
 // mm2.cpp -- see mm2.hpp.  Host-side decision chain of the aligner; all banded DP is
 // delegated to the HIP kernel through DpCache.
 #include "mm2.hpp"
