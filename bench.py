@@ -14,10 +14,12 @@ Workload = BASELINE.json configs[1]: 100 000 synthetic ONT-like reads, mean 8 kb
 genome, 1% sub + 1% ins + 1% del, k=23 n=60 thr=6, minimap k=20 w=50, per GPU.
 
 Multi-GPU (one process per GPU, RCCL): reads shard by id (rank r generates reads [r*R, (r+1)*R) of ONE read set over
-a genome N times larger: weak scaling).  Exchange mode (default): the read shards are replicated by all-gather at load
-time; every step each rank sketches its own id range, the sketch rows are all-gathered, every rank builds the whole
-bucket index and owns the contig builders with gid % N == rank; claims are resolved from all-gathered request lists
-in global builder order (nanospring_amd/dist.py).  --no-exchange: independent shards, no collective.
+a genome N times larger: weak scaling).  Exchange mode (default) runs the C++ driver of csrc/dist.hip on the library's own
+RCCL communicator: the read shards are replicated by all-gather at load time; every step each rank sketches its own id
+range, the (slot, key, id) tuples go by RCCL all-to-all to the bucket-table owners (table j on rank j % N), the sorted
+tables are all-gathered (window queries stay local), and the contig builders with gid % N == rank run on each rank with
+ONE small all-gather of claim / seed request lists per pipeline slot (resolved in global builder order).
+--dist-mode replicate: all-gather of the sketch rows instead.  --no-exchange: independent shards, no collective.
 
 Prints ONE JSON line on rank 0, including
   roofline     : dominant kernel (ksw_extd2 wavefront DP) algorithmic bytes / HIP-event kernel time vs HBM peak
@@ -102,6 +104,8 @@ def main():
     ap.add_argument("--builders", type=int, default=1024, help="virtual contig builders per GPU")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the all-cores CPU-baseline sample (0 = skip; default: 800 per host core)")
     ap.add_argument("--no-exchange", action="store_true", help="multi-GPU: independent shards, no collective")
+    ap.add_argument("--dist-mode", choices=["alltoall", "replicate"], default="alltoall",
+                    help="multi-GPU bucket tables: owners of an RCCL all-to-all of (slot, key, id) tuples, or all-gathered sketch rows")
     args = ap.parse_args()
 
     import torch
@@ -133,19 +137,21 @@ def main():
 
     stream = torch.cuda.Stream()
     g = ns.NsGpu(k=k, n=n, overlap_sketch_thr=thr, device=local, stream=stream.cuda_stream)
+    job = None
     if exchange:
+        # the C++ driver (csrc/dist.hip): the library's own RCCL communicator; Python only calls three entry points
         from nanospring_amd import dist as nd
-        all_b, all_o, lo, hi = nd.replicate_reads(bases, off, dist)     # RCCL all-gather of the shards (load time)
-        g.load_reads((all_b, all_o))
+        job = nd.DistJob(g, dist, backend=os.environ.get("NSGPU_BENCH_BACKEND", "nccl"))
+        lo, hi = job.load_reads(bases, off)                             # all-gather of the shards (load time, untimed)
+        dmode = nd.ALLTOALL if args.dist_mode == "alltoall" else nd.REPLICATE
     else:
         g.load_reads((bases, off))      # host -> HBM + 2-bit pack: outside the timed region
         ns.filter.check(g.lib, g.lib.nsgpu_set_read_id_base(g.ctx, rank * args.reads))   # global read ids of this shard
 
     def step():
         if exchange:
-            nd.exchange_sketch_rows(g, salts, lo, hi, dist)    # own rows + RCCL all-gather of everybody's
-            g.build_index()
-            return nd.consensus_exchange(g, args.builders * world, dist, 8)
+            job.sketch_index(salts, dmode)                     # own rows; all-to-all of tuples to the table owners (or all-gather of rows)
+            return job.consensus_run(args.builders * world, 8)
         g.sketch(salts, fetch=False)
         g.build_index()
         return ns.consensus_run(g, args.builders, 8)
@@ -243,8 +249,10 @@ def main():
                                              "consensus_index": round(st["index_ms"], 1), "align_total": round(st["align_ms"], 1),
                                              "align_dp_kernel_wall": round(a["dp_kernel_ms"] / steps, 1), "align_dp_kernel_sum": round(a["dp_kernel_sum_ms"] / steps, 1), "graph_host_wall": round(st["graph_ms"], 1),
                                              "note": "contig-stage parts overlap (four builder groups: host phase | batches part 1 | DP in flight | batches part 2), they do not add up to the total"},
-                       "parallelism": (f"x{world}: reads sharded by id, replicated by all-gather; per step all-gather of sketch rows + "
-                                       f"{st.get('n_collectives', 0)} small all-gathers of claim lists (global builder order)") if exchange
+                       "parallelism": (f"x{world}: reads sharded by id, replicated by all-gather at load; per step "
+                                       + ("RCCL all-to-all of (slot, key, id) tuples to the bucket-table owners (table j on rank j % world) + all-gather of the sorted tables"
+                                          if args.dist_mode == "alltoall" else "all-gather of sketch rows") +
+                                       f" + {st.get('n_collectives', 0)} small all-gathers of claim lists (global builder order); C++ driver, library-owned RCCL communicator") if exchange
                        else f"reads sharded by id x{world}, no collective"},
             "builders_penalty": penalty,
             "roofline": {"kernel": "ksw_extd2 (ksw_extd2_reg_kernel<NW,NCH>: DP state in registers)", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -260,6 +268,8 @@ def main():
         if args.cpu_sample != 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample if args.cpu_sample > 0 else 800 * host_cores(), args.mean_len, k, n, thr, salts)
         print(json.dumps(out), flush=True)
+    if job is not None:
+        job.close()
     g.close()
     if dist is not None:
         dist.destroy_process_group()

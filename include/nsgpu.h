@@ -240,6 +240,43 @@ int nsgpu_consensus_write(nsgpu_ctx *ctx, const char *temp_dir, const char *temp
  * and counts the reads that do not come back identical (0 = lossless). */
 int nsgpu_consensus_verify(nsgpu_ctx *ctx, uint64_t *n_bad_out);
 
+
+/* ---- multi-GPU: one process per GPU; the reference has no counterpart (it is one process with OpenMP threads,
+ *      src/Consensus.cpp:29) -- this is what lets Compressor::compress() use the 8 GPUs of a node.  Reads shard by id.
+ *      A communicator carries the collectives: RCCL over xGMI (bound at run time; rank 0 makes the id and the host program
+ *      hands it to the other ranks by whatever channel it has), or host callbacks (gloo / MPI / TCP of the caller; used by
+ *      the tests).  One communicator = one thread at a time. ------------------------------------------------------------ */
+#define NSGPU_COMM_ID_BYTES 128
+typedef struct nsgpu_comm nsgpu_comm;
+typedef struct {
+    void *user;
+    /* every rank contributes bytes_per_rank bytes; recv receives world * bytes_per_rank in rank order (host memory); 0 = ok */
+    int (*all_gather)(void *user, const void *send, void *recv, uint64_t bytes_per_rank);
+    /* send_bytes[p] go to peer p, recv_bytes[p] come from peer p; blocks are contiguous in rank order (host memory); 0 = ok */
+    int (*all_to_all)(void *user, const void *send, const uint64_t *send_bytes, void *recv, const uint64_t *recv_bytes);
+} nsgpu_comm_callbacks;
+int nsgpu_comm_unique_id(uint8_t *id_out /* NSGPU_COMM_ID_BYTES */);
+int nsgpu_comm_init_rccl(nsgpu_ctx *ctx, const uint8_t *id, uint32_t rank, uint32_t world, nsgpu_comm **comm_out);
+int nsgpu_comm_init_callbacks(nsgpu_ctx *ctx, const nsgpu_comm_callbacks *cb, uint32_t rank, uint32_t world, nsgpu_comm **comm_out);
+void nsgpu_comm_destroy(nsgpu_comm *comm);
+/* Rank r passes its shard (reads [lo_r, hi_r) of ONE read set, shards in rank order); afterwards every rank holds all reads
+ * (all-gather; ReadData::getRead must answer for any id, src/ReadData.cpp:225-235).  *lo_out / *hi_out = this rank's id range. */
+int nsgpu_dist_load_reads(nsgpu_ctx *ctx, nsgpu_comm *comm, const char *bases, const uint64_t *off, uint32_t n_local, uint32_t *lo_out, uint32_t *hi_out);
+/* MinHashReadFilter::initialize (src/ReadFilter.cpp:11-47) over the ranks: each sketches its own id range, then the n bucket
+ * tables are built
+ *   NSGPU_DIST_REPLICATE  from all-gathered sketch rows, all n tables sorted on every rank;
+ *   NSGPU_DIST_ALLTOALL   table j owned by rank j % world: all-to-all(v) of the (slot, key, id) tuples to the owners (RCCL
+ *                         send/recv to all peers at once: every xGMI link busy), each owner sorts its tables over all reads,
+ *                         the sorted tables are all-gathered (window queries stay local).
+ * Both give the index nsgpu_build_index gives one process, bit for bit. */
+#define NSGPU_DIST_REPLICATE 0
+#define NSGPU_DIST_ALLTOALL 1
+int nsgpu_dist_sketch_index(nsgpu_ctx *ctx, nsgpu_comm *comm, const uint64_t *salts, int mode);
+/* Consensus::generateAndWriteConsensus over the ranks: the slot schedule documented above nsgpu_cons_begin with ONE small
+ * all-gather (claim + seed request lists) per slot; rank r owns the builders with gid % world == r and writes its contigs
+ * (global read ids) into its own n_threads_out stream sets.  The result does not depend on the number of ranks. */
+int nsgpu_dist_consensus_run(nsgpu_ctx *ctx, nsgpu_comm *comm, uint32_t n_builders_total, uint32_t n_threads_out, nsgpu_consensus_stats *stats_out);
+
 /* ---- timing of the last call of each stage, in ms, measured with HIP events on
  *      the context's stream (for bench.py's roofline object) ------------------ */
 typedef struct {

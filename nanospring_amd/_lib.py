@@ -68,6 +68,13 @@ SIGNATURES = {
     "nsgpu_cons_claim_requests": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp), _u32p]),
     "nsgpu_cons_claim_resolve": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _u32p]),
     "nsgpu_cons_finish": (C.c_int, [_vp, C.c_uint32, _vp]),
+    "nsgpu_comm_unique_id": (C.c_int, [_vp]),
+    "nsgpu_comm_init_rccl": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
+    "nsgpu_comm_init_callbacks": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
+    "nsgpu_comm_destroy": (None, [_vp]),
+    "nsgpu_dist_load_reads": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, _u32p, _u32p]),
+    "nsgpu_dist_sketch_index": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "nsgpu_dist_consensus_run": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp]),
     "nsgpu_sketch_range": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32]),
     "nsgpu_sketch_rows_get": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, C.c_int]),
     "nsgpu_sketch_rows_set": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, C.c_int]),

@@ -20,6 +20,7 @@
 #include "common.hpp"
 #include "consensus.hpp"
 #include "host_util.hpp"
+#include "dist.hpp"
 #include <memory>
 #include <atomic>
 #include <thread>
@@ -763,6 +764,53 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
 
 using namespace nsgpu;
 
+// The same loop over the ranks of a communicator: after each slot ONE all-gather carries every rank's claim requests (group b)
+// and seed requests (group h); both lists are then resolved on every rank in global builder order.  A rank never has more
+// requests than local builders, so the exchange buffer has a fixed size and needs no size negotiation.
+static int run_consensus_dist(nsgpu_ctx *c, Comm &C, uint32_t n_builders_total, uint32_t n_threads_out, uint64_t *n_coll_out)
+{
+    NS_CHECK(n_threads_out >= 1, NSGPU_ERR_ARG, "n_threads_out must be >= 1");
+    NS_TRY(engine_begin(c, n_builders_total, C.rank, C.world));
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    const uint32_t W = C.world;
+    const size_t cap = (n_builders_total + W - 1) / W + 1, blk = 1 + 2 * cap, words = 2 * blk;
+    std::vector<uint32_t> mine(words), all(words * W), ca, cb, sa, sb, ga, gb;
+    uint64_t n_coll = 0;
+    for (uint32_t slot = 0;; ++slot) {
+        const int G = n_groups();
+        const int h = (int)(slot % G), b = (int)((slot + 1) % G);
+        NS_TRY(engine_slot(c, slot));
+        engine_claim_requests(c, ca, cb, b);
+        engine_seed_requests(c, sa, sb, h);
+        NS_CHECK(ca.size() <= cap && sa.size() <= cap, NSGPU_ERR_RANGE, "more requests than local builders");
+        mine[0] = (uint32_t)ca.size();
+        std::copy(ca.begin(), ca.end(), mine.begin() + 1);
+        std::copy(cb.begin(), cb.end(), mine.begin() + 1 + cap);
+        mine[blk] = (uint32_t)sa.size();
+        std::copy(sa.begin(), sa.end(), mine.begin() + blk + 1);
+        std::copy(sb.begin(), sb.end(), mine.begin() + blk + 1 + cap);
+        NS_TRY(C.all_gather(mine.data(), all.data(), words * 4, false, c->stream));
+        ++n_coll;
+        ga.clear(); gb.clear();
+        for (uint32_t r = 0; r < W; ++r) {
+            const uint32_t *v = all.data() + (size_t)r * words;
+            ga.insert(ga.end(), v + 1, v + 1 + v[0]);
+            gb.insert(gb.end(), v + 1 + cap, v + 1 + cap + v[0]);
+        }
+        engine_claim_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size());
+        ga.clear(); gb.clear();
+        for (uint32_t r = 0; r < W; ++r) {
+            const uint32_t *v = all.data() + (size_t)r * words + blk;
+            ga.insert(ga.end(), v + 1, v + 1 + v[0]);
+            gb.insert(gb.end(), v + 1 + cap, v + 1 + cap + v[0]);
+        }
+        if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) engine_advance(c, true, h);
+        if (E->n_done_global >= E->n_total) break;
+    }
+    if (n_coll_out) *n_coll_out = n_coll;
+    return engine_finish(c, n_threads_out);
+}
+
 static int give_u32(const std::vector<uint32_t> &v, uint32_t **out)
 {
     uint32_t *p = (uint32_t *)malloc((v.size() + 1) * 4);
@@ -879,6 +927,18 @@ static std::string stream_of(const cons::StreamSet &s, int which)
     case 0: return s.genome; case 1: return s.lone; case 2: return s.id_bytes(); case 3: return s.pos;
     case 4: return s.type; case 5: return s.base; default: return s.complement;
     }
+}
+
+int nsgpu_dist_consensus_run(nsgpu_ctx *c, nsgpu_comm *comm, uint32_t n_builders_total, uint32_t n_threads_out, nsgpu_consensus_stats *stats_out)
+{
+    NS_CHECK(c && comm && nsgpu_comm_impl(comm), NSGPU_ERR_ARG, "nsgpu_dist_consensus_run: null argument");
+    NS_CHECK(c->have_index, NSGPU_ERR_ARG, "nsgpu_dist_consensus_run: build the bucket tables first (nsgpu_dist_sketch_index)");
+    NS_HIP(hipSetDevice(c->prm.device));
+    uint64_t n_coll = 0;
+    NS_TRY(run_consensus_dist(c, *nsgpu_comm_impl(comm), n_builders_total, n_threads_out, &n_coll));
+    c->cons_stats.reserved = (uint32_t)n_coll;           // collectives of the stage
+    if (stats_out) *stats_out = c->cons_stats;
+    return NSGPU_OK;
 }
 
 int nsgpu_consensus_stream(nsgpu_ctx *c, uint32_t thread, uint32_t which, uint8_t **data_out, size_t *len_out)

@@ -285,3 +285,124 @@ def consensus_exchange(gpu, n_builders_total, dist, n_threads_out=1):
     out = {k: getattr(st, k) for k, _ in F.ConsensusStats._fields_}
     out["n_collectives"] = n_coll
     return out
+
+
+# ---------------------------------------------------------------------------
+# The C++ multi-GPU path (csrc/dist.hip, nsgpu_dist_*): Python only creates the communicator and calls three entry points.
+#   backend "nccl": the library's own RCCL communicator (rank 0's unique id travels through torch.distributed's store)
+#   backend "gloo": host callbacks into torch.distributed (tests: several ranks on one GPU, or no RCCL at all)
+# ---------------------------------------------------------------------------
+REPLICATE, ALLTOALL = 0, 1
+
+
+class _Callbacks:
+    """nsgpu_comm_callbacks over torch.distributed (host tensors)."""
+
+    def __init__(self, dist):
+        import ctypes as C
+        torch = _torch()
+        self.dist, self.world = dist, dist.get_world_size()
+
+        AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+        A2A = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64))
+
+        def view(ptr, nbytes):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(max(int(nbytes), 1),))[:int(nbytes)]
+
+        def all_gather(_user, send, recv, nbytes):
+            try:
+                src = torch.from_numpy(view(send, nbytes).copy())
+                out = torch.empty(int(nbytes) * self.world, dtype=torch.uint8)
+                dist.all_gather_into_tensor(out, src)
+                view(recv, int(nbytes) * self.world)[:] = out.numpy()
+                return 0
+            except Exception as e:            # never let an exception cross the C boundary
+                print("nsgpu comm callback all_gather:", e, flush=True)
+                return 1
+
+        def all_to_all(_user, send, sb, recv, rb):
+            try:
+                sbs = [int(sb[p]) for p in range(self.world)]
+                rbs = [int(rb[p]) for p in range(self.world)]
+                sv = view(send, sum(sbs))
+                ins, o = [], 0
+                for n in sbs:
+                    ins.append(torch.from_numpy(sv[o:o + n].copy()))
+                    o += n
+                outs = [torch.empty(n, dtype=torch.uint8) for n in rbs]
+                # gloo has no ragged all_to_all: one gather per destination (test transport, not the product's)
+                for dst in range(self.world):
+                    got = [None] * self.world if dist.get_rank() == dst else None
+                    dist.gather_object(ins[dst].numpy().tobytes(), got, dst=dst)
+                    if dist.get_rank() == dst:
+                        for p in range(self.world):
+                            assert len(got[p]) == rbs[p], (p, len(got[p]), rbs[p])
+                            outs[p] = torch.from_numpy(np.frombuffer(got[p], dtype=np.uint8).copy()) if rbs[p] else outs[p]
+                rv = view(recv, sum(rbs))
+                o = 0
+                for p, n in enumerate(rbs):
+                    if n:
+                        rv[o:o + n] = outs[p].numpy()
+                    o += n
+                return 0
+            except Exception as e:
+                print("nsgpu comm callback all_to_all:", e, flush=True)
+                return 1
+
+        class CB(C.Structure):
+            _fields_ = [("user", C.c_void_p), ("all_gather", AG), ("all_to_all", A2A)]
+        self._keep = (AG(all_gather), A2A(all_to_all))
+        self.struct = CB(None, self._keep[0], self._keep[1])
+
+
+class DistJob:
+    """One rank of a multi-GPU run through the C++ entry points (include/nsgpu.h, multi-GPU section)."""
+
+    def __init__(self, gpu, dist, backend=None):
+        import ctypes as C
+        from . import filter as F
+        self.gpu, self.dist, self.F = gpu, dist, F
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        lib = gpu.lib
+        self.comm = C.c_void_p()
+        backend = backend or dist.get_backend()
+        if backend == "nccl":
+            uid = (C.c_uint8 * 128)()
+            if self.rank == 0:
+                F.check(lib, lib.nsgpu_comm_unique_id(uid))
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=0)
+            uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            F.check(lib, lib.nsgpu_comm_init_rccl(gpu.ctx, uid, self.rank, self.world, C.byref(self.comm)))
+            self._cb = None
+        else:
+            self._cb = _Callbacks(dist)
+            F.check(lib, lib.nsgpu_comm_init_callbacks(gpu.ctx, C.byref(self._cb.struct), self.rank, self.world, C.byref(self.comm)))
+
+    def load_reads(self, bases, off):
+        """this rank's shard (reads in global id order across ranks) -> every rank holds all reads; returns (lo, hi)"""
+        import ctypes as C
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        lo, hi = C.c_uint32(), C.c_uint32()
+        self.F.check(self.gpu.lib, self.gpu.lib.nsgpu_dist_load_reads(self.gpu.ctx, self.comm, bases.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
+                                                                     C.c_uint32(len(off) - 1), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def sketch_index(self, salts, mode=REPLICATE):
+        import ctypes as C
+        salts = np.ascontiguousarray(salts, dtype=np.uint64)
+        self.F.check(self.gpu.lib, self.gpu.lib.nsgpu_dist_sketch_index(self.gpu.ctx, self.comm, salts.ctypes.data_as(C.c_void_p), int(mode)))
+
+    def consensus_run(self, n_builders_total, n_threads_out=1):
+        import ctypes as C
+        st = self.F.ConsensusStats()
+        self.F.check(self.gpu.lib, self.gpu.lib.nsgpu_dist_consensus_run(self.gpu.ctx, self.comm, n_builders_total, n_threads_out, C.byref(st)))
+        out = {k: getattr(st, k) for k, _ in self.F.ConsensusStats._fields_}
+        out["n_collectives"] = out.get("reserved", 0)
+        return out
+
+    def close(self):
+        if self.comm:
+            self.gpu.lib.nsgpu_comm_destroy(self.comm)
+            self.comm = None

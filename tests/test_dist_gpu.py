@@ -33,16 +33,19 @@ def single():
     return bases, off, st, s
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_result_is_independent_of_rank_count(world):
+@pytest.mark.parametrize("world,driver", [(2, "py"), (3, "py"), (2, "replicate"), (3, "replicate"), (2, "alltoall"), (3, "alltoall")])
+def test_result_is_independent_of_rank_count(world, driver):
+    """"py": the phase calls driven from Python; "replicate" / "alltoall": the C++ driver (nsgpu_dist_load_reads / _sketch_index /
+    _consensus_run) with the bucket tables built from all-gathered sketch rows, or by the owners of an all-to-all of (slot, key,
+    id) tuples (table j on rank j % world) -- the same tables, the same contigs as one process."""
     bases, off, st1, s1 = single()
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "o.pkl")
-        port = str(29600 + world)
+        port = str(29600 + world + 10 * ["py", "replicate", "alltoall"].index(driver))
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, NSGPU_THREADS="4")
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                             "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(N_READS),
-                            str(N_BUILDERS), out], env=env, capture_output=True, text=True, timeout=1200)
+                            str(N_BUILDERS), out, driver], env=env, capture_output=True, text=True, timeout=1200)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         res = pickle.load(open(out, "rb"))
     assert len(res) == world
@@ -67,18 +70,21 @@ def test_result_is_independent_of_rank_count(world):
     assert m["numReads"] == N_READS and m["numThr"] == world and sum(m["numReadsInContig"]) == N_READS
 
 
-def test_exchange_path_over_rccl_world_size_one():
+@pytest.mark.parametrize("driver", ["py", "replicate", "alltoall"])
+def test_exchange_path_over_rccl_world_size_one(driver):
     """The box has one GPU, so RCCL cannot run two ranks here; a world of one still drives every collective of the
     exchange path (all-gathers of read shards, sketch rows and claim lists, on device tensors) through the real "nccl"
     backend, and must reproduce the single-process run bit for bit.  NSGPU_TEST_FORCE_EXCHANGE makes the world of one take the
-    device get -> all_gather_into_tensor -> set path of exchange_sketch_rows (re-importing its own rows) instead of skipping it."""
+    device get -> all_gather_into_tensor -> set path of exchange_sketch_rows (re-importing its own rows) instead of skipping it.
+    With the C++ drivers the library's OWN RCCL communicator (dlopen of librccl, ncclCommInitRank from a unique id made by rank 0)
+    carries the collectives -- including, in "alltoall" mode with one rank, the degenerate send-to-self."""
     bases, off, st1, s1 = single()
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "o.pkl")
-        port = "29611"
+        port = str(29641 + ["py", "replicate", "alltoall"].index(driver))
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, NSGPU_TEST_BACKEND="nccl", NSGPU_TEST_FORCE_EXCHANGE="1")
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                            "--master-port", port, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(N_READS), str(N_BUILDERS), out],
+                            "--master-port", port, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(N_READS), str(N_BUILDERS), out, driver],
                            env=env, capture_output=True, text=True, timeout=1200)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         res = pickle.load(open(out, "rb"))
