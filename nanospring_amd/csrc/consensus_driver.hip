@@ -74,6 +74,11 @@ struct Builder {
     // cached index of the current main path
     mm2::RefIndex idx;
     bool idx_valid = false;
+    // incremental consensus sketch: the minimizers of mz_str (the main path they were computed for).  When the path changes only the
+    // stretch that differs (+ a margin on both sides) is sketched again and spliced in -- see engine_batches_sketch
+    std::vector<mm2::Anchor> mz;
+    std::string mz_str;
+    struct Splice { bool full = true; size_t a = 0, B_sub = 0, A = 0, B = 0; ssize_t delta = 0; } sp;
     std::vector<std::unique_ptr<FinishedContig>> contigs;     // in the order they were finished = output order
     size_t n_queued = 0;                                      // contigs[0 .. n_queued) were handed to the emission queue
     uint64_t n_minhash = 0, n_minhash_new = 0, n_aligner = 0, n_align_calls = 0, n_contigs = 0, n_lone = 0;
@@ -113,6 +118,7 @@ struct Driver {
         b.cur_pos = b.g->start_pos;
         b.right_phase = true, b.edges_too_many = false, b.window_open = false;
         b.idx_valid = false;
+        b.mz.clear(), b.mz_str.clear();          // a new consensus: nothing to splice into
         b.st = Builder::ADVANCE;
     }
 
@@ -407,6 +413,73 @@ static uint32_t engine_seed_resolve(nsgpu_ctx *c, const uint32_t *gids, const ui
 // candidate read (GPU, mm_sketch.hip), the consensus indexes, and the first host step of the alignments (seeds / chains /
 // DP plan).  (Optionally the batch is cut in two halves whose sketches run concurrently on the GPU -- two workspaces, two
 // streams -- with the host work of the first half overlapping the sketch of the second: see below.)
+// ---- incremental consensus sketch ---------------------------------------------------------------------------
+// Whether position x is a minimizer of a string depends on the bases within w + k of x only (mm_sketch's state after a push is
+// the right-most minimum of the last w pushes -- mm_sketch.hip -- and an element is emitted at most w pushes after its own).
+// So after an accepted read changed the consensus between a common prefix of P and a common suffix of S bases, only
+// new[P - 2m, Ln - S + 2m), m = w + k + 2, is sketched again; of its minimizers those at least m inside are exact (the artificial
+// start / end of the substring cannot reach them; a substring that starts at 0 or ends at Ln is exact up to that end), the old
+// minimizers left of P - m stay, those right of the old end of the change move by the length difference.  NSGPU_SKETCH_FULL=1
+// sketches whole strings as before; NSGPU_SKETCH_CHECK=1 compares every spliced list with a sketch of the whole string.
+static void plan_splice(Builder &b, int w, int k)
+{
+    static const bool always_full = getenv("NSGPU_SKETCH_FULL") != nullptr;
+    const std::string &nw = b.g->main_path, &od = b.mz_str;
+    Builder::Splice &sp = b.sp;
+    sp = Builder::Splice();
+    if (always_full || od.empty() || b.mz.empty()) return;
+    const size_t Ln = nw.size(), Lo = od.size(), mn = std::min(Ln, Lo);
+    size_t P = 0;
+    while (P + 8 <= mn && memcmp(nw.data() + P, od.data() + P, 8) == 0) P += 8;
+    while (P < mn && nw[P] == od[P]) ++P;
+    size_t S = 0;
+    while (S + 8 <= mn - P && memcmp(nw.data() + Ln - S - 8, od.data() + Lo - S - 8, 8) == 0) S += 8;
+    while (S < mn - P && nw[Ln - 1 - S] == od[Lo - 1 - S]) ++S;
+    const size_t m = (size_t)(w + k + 2);
+    const size_t a = P > 2 * m ? P - 2 * m : 0, e = Ln - S + 2 * m < Ln ? Ln - S + 2 * m : Ln;
+    if ((e - a) * 2 > Ln) return;                                // most of it changed: a whole sketch is as cheap
+    sp.full = false;
+    sp.a = a, sp.B_sub = e;
+    sp.A = a == 0 ? 0 : P - m;                                   // new minimizers are taken from [A, B)
+    sp.B = e == Ln ? Ln : Ln - S + m;
+    sp.delta = (ssize_t)Ln - (ssize_t)Lo;
+}
+
+static void apply_splice(Builder &b, const mm2::Anchor *sub, size_t n_sub, int w, int k)
+{
+    auto pos_of = [](const mm2::Anchor &x) { return (size_t)((x.y & 0xffffffffull) >> 1); };
+    const Builder::Splice &sp = b.sp;
+    const std::string &nw = b.g->main_path;
+    if (sp.full) b.mz.assign(sub, sub + n_sub);
+    else {
+        std::vector<mm2::Anchor> out;
+        out.reserve(b.mz.size() + n_sub);
+        size_t i = 0;
+        for (; i < b.mz.size() && pos_of(b.mz[i]) < sp.A; ++i) out.push_back(b.mz[i]);
+        for (size_t j = 0; j < n_sub; ++j) {
+            const size_t x = pos_of(sub[j]) + sp.a;
+            if (x >= sp.A && x < sp.B) { mm2::Anchor t = sub[j]; t.y = (t.y & ~0xffffffffull) | ((uint64_t)x << 1 | (t.y & 1)); out.push_back(t); }
+        }
+        const size_t B_old = (size_t)((ssize_t)sp.B - sp.delta);
+        for (; i < b.mz.size() && pos_of(b.mz[i]) < B_old; ++i) {}
+        for (; i < b.mz.size(); ++i) { mm2::Anchor t = b.mz[i]; const size_t x = (size_t)((ssize_t)pos_of(t) + sp.delta); t.y = (t.y & ~0xffffffffull) | ((uint64_t)x << 1 | (t.y & 1)); out.push_back(t); }
+        b.mz.swap(out);
+    }
+    b.mz_str = nw;
+    static const bool check = getenv("NSGPU_SKETCH_CHECK") != nullptr;
+    if (check) {
+        std::vector<mm2::Anchor> full;
+        mm2::mm_sketch(nw.data(), (int)nw.size(), w, k, 0, full);
+        bool same = full.size() == b.mz.size();
+        for (size_t i = 0; same && i < full.size(); ++i) same = full[i].x == b.mz[i].x && full[i].y == b.mz[i].y;
+        if (!same) {
+            fprintf(stderr, "SKETCH SPLICE MISMATCH: builder %u, path %zu bases, full %zu vs spliced %zu minimizers (a %zu e %zu A %zu B %zu delta %zd full %d)\n", b.gid, nw.size(), full.size(),
+                    b.mz.size(), sp.a, sp.B_sub, sp.A, sp.B, sp.delta, (int)sp.full);
+            abort();
+        }
+    }
+}
+
 static int engine_batches_sketch(nsgpu_ctx *c, int group)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
@@ -431,11 +504,18 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group)
     // requests of half h: the changed consensus strings of its builders, then their candidate reads
     struct Half { size_t lo, hi, q_base; std::vector<SketchReq> sk; std::vector<uint32_t> sk_ref; const mm2::Anchor *mz = nullptr; int rc = NSGPU_OK; } H[2];
     H[0].lo = 0, H[0].hi = cut, H[1].lo = cut, H[1].hi = n;
+    // which stretch of every changed consensus has to be sketched again (a comparison of the whole string with the one the cached
+    // minimizers belong to: on all host threads, this thread is on the slot's critical path)
+    par_for("sketch.plan", n, [&](size_t w) { Builder &b = D.B[who[w]]; if (!b.idx_valid) plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k); });
     for (Half &h : H) {
         h.sk_ref.assign(h.hi - h.lo, ~0u);
         for (size_t w = h.lo; w < h.hi; ++w) {
             Builder &b = D.B[who[w]];
-            if (!b.idx_valid) { h.sk_ref[w - h.lo] = (uint32_t)h.sk.size(); h.sk.push_back(SketchReq{b.g->main_path.data(), b.g->main_path.size()}); }
+            if (!b.idx_valid) {
+                h.sk_ref[w - h.lo] = (uint32_t)h.sk.size();
+                if (b.sp.full) h.sk.push_back(SketchReq{b.g->main_path.data(), b.g->main_path.size()});
+                else h.sk.push_back(SketchReq{b.g->main_path.data() + b.sp.a, b.sp.B_sub - b.sp.a});
+            }
         }
         h.q_base = h.sk.size();
         for (size_t w = h.lo; w < h.hi; ++w) h.sk.push_back(SketchReq{D.B[who[w]].query.data(), D.B[who[w]].query.size()});
@@ -459,8 +539,8 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group)
             Builder &b = D.B[who[h.lo + i]];
             if (!b.idx_valid) {
                 const uint32_t si = h.sk_ref[i];
-                b.idx.build_from_sketch(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f, h.mz + mo[si],
-                                        (size_t)(mo[si + 1] - mo[si]));
+                apply_splice(b, h.mz + mo[si], (size_t)(mo[si + 1] - mo[si]), (int)c->prm.m_w, (int)c->prm.m_k);
+                b.idx.build_from_sketch(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f, b.mz.data(), b.mz.size());
                 b.idx_valid = true;
             }
         });

@@ -226,6 +226,239 @@ __global__ __launch_bounds__(256) void sk_offsets_kernel(Batch b, const uint32_t
     off[s] = oscan[pr[b.soff[s]]];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused path.  What the contig engine sketches are consensus strings and reads: pure A/C/G/T.  Then every position is a valid
+// base, a k-mer is positional, and the state machine is local: a workgroup takes 1024 consecutive positions of one sequence
+// plus a halo, builds k-mers and hashes in LDS, the right-most minima of the windows of the last w PUSHES and the events --
+// once to count (skf_kernel<false>), once, after ONE scan over the tile counts, to write (skf_kernel<true>): 6 GPU operations
+// and one host synchronisation per call instead of ~25 and three.
+// Symmetric k-mers (equal to their reverse complement: 4^-(k/2) per position, i.e. a few per batch, and whole runs of them in
+// (AT)n or (ACGT)n repeats) push nothing and do not count in `run`: inside a tile they are marked and skipped exactly; a tile
+// whose halo would need more than kPalHalo of them, any byte that is not ACGT, or a sequence so full of them that `run`
+// could still be short beyond its first tile (checked by the host from the per-tile counts) sends the batch to the general
+// passes above instead.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kTile = 1024, kPalHalo = 16;
+constexpr uint64_t kPal = ~0ull - 1;            // px marker of a symmetric k-mer (a hash << 8 never gets there)
+
+struct Tile { uint32_t seq, t0; };
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void skf_kernel(Batch b, const Tile *__restrict__ tiles, uint32_t n_tiles, uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ tile_pal,
+                                                  const uint32_t *__restrict__ tile_off, uint64_t *__restrict__ out, uint64_t out_cap,
+                                                  uint32_t *__restrict__ flags /* [0] bad input, [1] output overflow */)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int w = b.w, k = b.k;
+    const int back = w + kPalHalo + 1;                                      // positions before t0 held in px
+    const int n_px = kTile + back + kPalHalo, n_rm = kTile + kPalHalo + 1;  // px also looks kPalHalo positions ahead (is a push the sequence's last?); rm / lo for positions t0 - kPalHalo - 1 ..
+    uint64_t *px = reinterpret_cast<uint64_t *>(lds);                       // px[j] = position t0 - back + j
+    uint32_t *rmv = reinterpret_cast<uint32_t *>(px + n_px + 1);            // right-most minimum of the window ending at the position (a push)
+    uint32_t *lov = rmv + n_rm + 1;                                         // oldest push of that window | full << 31
+    uint32_t *cnt = lov + n_rm + 1;                                         // per-thread event counts
+    uint8_t *code = reinterpret_cast<uint8_t *>(cnt + 260) + 2 * (size_t)(n_px + 2) * 2;     // behind the two uint16 doubling arrays; code[j] = base t0 - back - k + 1 + j
+    const uint32_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const uint32_t s = tiles[tile].seq, t0 = tiles[tile].t0, len = b.len[s];
+    const uint8_t *seq = b.seqs + b.soff[s];
+    const int tid = threadIdx.x;
+    const long px0 = (long)t0 - back, base0 = px0 - k + 1;
+    const int n_code = n_px + k - 1;
+    bool bad = false;
+    for (int j = tid; j < n_code; j += 256) {
+        const long i = base0 + j;
+        uint8_t c = 0;
+        if (i >= 0 && i < (long)len) { const int v = nt4_dev(seq[i]); bad |= v > 3; c = (uint8_t)(v & 3); }
+        code[j] = c;
+    }
+    __syncthreads();
+    // px: hash << 8 | strand of the k-mer ending at the position; MAX before the first whole k-mer; kPal for symmetric k-mers
+    const uint64_t mask = (1ull << 2 * k) - 1, shift1 = 2 * (uint64_t)(k - 1);
+    const int per = (n_px + 255) / 256;
+    uint32_t my_pal = 0, my_pal_region = 0;
+    {
+        const int j0 = tid * per;
+        uint64_t fw = 0, rv = 0;
+        bool have = false;
+        for (int jj = 0; jj < per; ++jj) {
+            const int j = j0 + jj;
+            if (j >= n_px) break;
+            const long i = px0 + j;
+            uint64_t x = kU64Max;
+            if (i >= (long)k - 1 && i < (long)len) {
+                const int cj = j + k - 1;                              // index of base i in code[]
+                if (!have) {
+                    fw = rv = 0;
+                    for (int t = 0; t < k; ++t) { const uint64_t c = code[cj - t]; fw |= c << (2 * t); rv |= (3ull ^ c) << (shift1 - 2 * t); }
+                    have = true;
+                } else {
+                    const uint64_t c = code[cj];
+                    fw = (fw << 2 | c) & mask;
+                    rv = rv >> 2 | (3ull ^ c) << shift1;
+                }
+                if (fw == rv) { x = kPal; ++my_pal_region; my_pal += i >= (long)t0 && i < (long)t0 + kTile; }
+                else { const uint64_t strand = fw < rv ? 0 : 1; x = hash64_masked_dev(strand ? rv : fw, mask) << 8 | strand; }
+            } else if (i >= 0 && i < (long)len) {
+                // a position before the first whole k-mer: symmetric there means the partial words agree (sketch.c:100 compares them as they are)
+                const int cj = j + k - 1;
+                uint64_t f2 = 0, r2 = 0;
+                for (int t = 0; t <= (int)i; ++t) { const uint64_t c = code[cj - t]; f2 |= c << (2 * t); r2 |= (3ull ^ c) << (shift1 - 2 * t); }
+                if (f2 == r2) { x = kPal; ++my_pal_region; my_pal += i >= (long)t0 && i < (long)t0 + kTile; }
+            }
+            px[j] = x;
+        }
+    }
+    if (bad) flags[0] = 1;
+    cnt[tid] = my_pal | my_pal_region << 16;
+    __syncthreads();
+    uint32_t pal_in_tile = 0, pal_region = 0;
+    for (int i = 0; i < 256; ++i) pal_in_tile += cnt[i] & 0xffffu, pal_region += cnt[i] >> 16;
+    __syncthreads();
+    if (t0 == 0) {
+        // `info` stays empty until l (= run) reaches k (sketch.c:104): symmetric k-mers among the first bases delay that
+        if (tid == 0) {
+            int run = 0;
+            for (long i = 0; i < (long)len && i < (long)kTile; ++i) {
+                const uint64_t v = px[(int)(i - px0)];
+                if (v == kPal) continue;
+                if (++run >= k) break;
+                px[(int)(i - px0)] = kU64Max;
+            }
+        }
+    }
+    __syncthreads();
+    auto hashOf = [&](long q) -> uint64_t { const uint64_t v = px[(int)(q - px0)]; return v >= kPal ? v : v >> 8; };      // MAX: a push without k-mer; kPal: no push
+    // window of the last w pushes ending at every push position in [t0 - kPalHalo - 1, t0 + kTile)
+    if (pal_region == 0) {
+        // no symmetric k-mer anywhere in the region (all but a handful of tiles): pushes = positions, and the right-most minimum of a
+        // window comes from log2(w) doubling steps -- R_j[p] = right-most minimum of the last 2^j positions -- instead of w compares
+        uint16_t *ra = reinterpret_cast<uint16_t *>(cnt + 260), *rb = ra + n_px + 2;            // positions relative to px0
+        auto better = [&](uint32_t a, uint32_t bq) { const uint64_t xa = px[a], xb = px[bq]; return (xb >= kPal ? kU64Max : xb >> 8) <= (xa >= kPal ? kU64Max : xa >> 8) ? bq : a; };
+        for (int j = tid; j < n_px; j += 256) ra[j] = (uint16_t)j;
+        __syncthreads();
+        int span = 1;
+        while (2 * span <= w) {
+            for (int j = tid; j < n_px; j += 256) {
+                const long pos = px0 + j;
+                rb[j] = (j - span >= 0 && pos - span >= 0) ? (uint16_t)better(ra[j - span], ra[j]) : ra[j];
+            }
+            __syncthreads();
+            uint16_t *t_ = ra; ra = rb; rb = t_;
+            span *= 2;
+        }
+        const int rest = w - span;                 // window = [p - w + 1, p - w + span] u [p - span + 1, p]
+        for (int j = tid; j < n_rm; j += 256) {
+            const long p = (long)t0 - kPalHalo - 1 + j;
+            uint32_t bi = 0, lo = 0;
+            if (p >= 0 && p < (long)len) {
+                const int jp = (int)(p - px0);
+                uint32_t r = ra[jp];
+                if (rest > 0 && p - rest >= 0) r = better(ra[jp - rest], r);
+                bi = (uint32_t)(px0 + r);
+                lo = (uint32_t)(p >= w - 1 ? p - w + 1 : 0) | (p >= w - 1 ? 0x80000000u : 0u);
+            }
+            rmv[j] = bi, lov[j] = lo;
+        }
+    } else
+    for (int j = tid; j < n_rm; j += 256) {
+        const long p = (long)t0 - kPalHalo - 1 + j;
+        uint32_t bi = 0, lo = 0;
+        if (p >= 0 && p < (long)len && hashOf(p) != kPal) {
+            uint64_t bx = hashOf(p);
+            bi = (uint32_t)p, lo = (uint32_t)p;
+            int got = 1;
+            long q = p;
+            while (got < w && q > 0) {
+                --q;
+                if (q < px0) { bad = true; break; }                    // more symmetric k-mers in the halo than it was sized for
+                const uint64_t x = hashOf(q);
+                if (x == kPal) continue;
+                ++got, lo = (uint32_t)q;
+                if (x < bx) bx = x, bi = (uint32_t)q;
+            }
+            lo |= got == w ? 0x80000000u : 0u;
+        }
+        rmv[j] = bi, lov[j] = lo;
+    }
+    if (bad) flags[0] = 1;
+    __syncthreads();
+    const long rm0 = (long)t0 - kPalHalo - 1;
+    // pushes before a position and `run` are exact in a sequence's first tile; beyond it they are >= w + k unless the sequence is
+    // riddled with symmetric k-mers (the host checks the per-tile counts and redoes such a batch by the general passes)
+    auto emit_xy = [&](uint32_t q, uint64_t *o) {
+        const uint64_t v = px[(int)((long)q - px0)];
+        o[0] = (v & ~0xffull) | (uint64_t)k;
+        o[1] = (uint64_t)q << 1 | (v & 1);
+    };
+    const int ppt = kTile / 256;                                  // 4 consecutive positions per thread: outputs stay in push order
+    // non-symmetric positions before the thread's first one, inside this tile (first tile: = pushes before it in the sequence)
+    uint32_t my_cnt = 0;
+    uint64_t *o = nullptr;
+    for (int pass = 0; pass < (WRITE ? 2 : 1); ++pass) {
+        if (pass == 1) {
+            cnt[tid] = my_cnt;
+            __syncthreads();
+            uint32_t before = 0;
+            for (int t = 0; t < tid; ++t) before += cnt[t];
+            const uint64_t at = (uint64_t)tile_off[tile] + before;
+            if (at + my_cnt > out_cap) { if (my_cnt) flags[1] = 1; return; }
+            o = out + 2 * at;
+        }
+        uint32_t c = 0;
+        for (int jj = 0; jj < ppt; ++jj) {
+            const uint32_t p = t0 + (uint32_t)(tid * ppt + jj);
+            if (p >= len) break;
+            const uint64_t cx = hashOf(p);
+            if (cx == kPal) continue;
+            uint32_t run = 0x7fffffffu;                               // "large": beyond the first tile
+            if (t0 == 0 && p + 1 < (uint32_t)(w + k) + pal_in_tile) { run = 0; for (uint32_t q = 0; q <= p; ++q) run += hashOf(q) != kPal; }   // only ~w + k deep matters
+            auto emit = [&](uint32_t q) { if (pass == 1) emit_xy(q, o + 2 * (size_t)c); ++c; };
+            auto ties = [&](uint64_t x, uint32_t self, uint32_t lo, uint32_t hi_excl) { for (uint32_t q = lo; q < hi_excl; ++q) if (hashOf(q) == x && q != self) emit(q); };
+            const uint32_t lw = lov[(long)p - rm0], lo_cur = lw & 0x7fffffffu;
+            // the previous push
+            long pp = (long)p - 1;
+            while (pp >= 0 && pp >= rm0 && hashOf(pp) == kPal) --pp;
+            uint64_t prev_x = kU64Max;
+            uint32_t prev_i = 0;
+            bool prev_at_expired = false;
+            if (pp >= 0) {
+                if (pp < rm0) { flags[0] = 1; return; }
+                prev_i = rmv[pp - rm0];
+                prev_x = hashOf(prev_i);
+                const uint32_t plo = lov[pp - rm0];
+                prev_at_expired = (plo & 0x80000000u) && prev_i == (plo & 0x7fffffffu);      // w pushes before p, and the minimum is the one that expires
+            }
+            if (run == (uint32_t)(w + k - 1) && prev_x != kU64Max) ties(prev_x, prev_i, lo_cur, p);
+            if (cx <= prev_x) {
+                if (run >= (uint32_t)(w + k) && prev_x != kU64Max) emit(prev_i);
+            } else if (prev_at_expired) {
+                if (run >= (uint32_t)(w + k - 1) && prev_x != kU64Max) emit(prev_i);
+                const uint32_t now_i = rmv[(long)p - rm0];
+                const uint64_t now_x = hashOf(now_i);
+                if (run >= (uint32_t)(w + k - 1) && now_x != kU64Max) ties(now_x, now_i, lo_cur, p + 1);
+            }
+            // the closing `if (min.x != UINT64_MAX) push(min)`: p is the sequence's last push
+            bool last = true;
+            for (uint32_t q = p + 1; q < len && last; ++q) {
+                if (q >= t0 + kTile + kPalHalo) { flags[0] = 1; last = false; break; }      // a longer run of symmetric k-mers than the look-ahead: general passes
+                last = hashOf(q) == kPal;
+            }
+            if (last) { const uint32_t now_i = rmv[(long)p - rm0]; if (hashOf(now_i) != kU64Max) emit(now_i); }
+        }
+        my_cnt = c;
+        if (!WRITE) {
+            cnt[tid] = c;
+            __syncthreads();
+            if (tid == 0) { uint32_t t = 0; for (int i = 0; i < 256; ++i) t += cnt[i]; tile_cnt[tile] = t; }
+            __syncthreads();
+            cnt[tid] = my_pal;
+            __syncthreads();
+            if (tid == 0) { uint32_t t = 0; for (int i = 0; i < 256; ++i) t += cnt[i]; tile_pal[tile] = t; }
+        }
+    }
+}
+
 }  // namespace
 
 static int pinned_reserve(uint8_t *&p, size_t &cap, size_t want)
@@ -255,8 +488,90 @@ static int scan_u32(nsgpu_ctx::SketchWs &W, hipStream_t st, const uint32_t *in, 
     return NSGPU_OK;
 }
 
+
 // debug breakdown (one caller at a time): host staging, up to the push count, up to the offsets, write + read-back; bytes in, minimizers out
 double g_sketch_ms[6];
+
+// The fused path (skf_kernel).  Returns 1 when the batch has to be redone by the general passes (a byte other than ACGT, a k-mer equal
+// to its reverse complement, or more minimizers than the staging buffer was sized for), 0 when done, < 0 on errors.
+static int gpu_mm_sketch_fused(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws)
+{
+    const size_t n = reqs.size();
+    const double t0 = now_ms();
+    nsgpu_ctx::SketchWs &W = c->sws[ws];
+    if (!W.stream) NS_HIP(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
+    const hipStream_t st = W.stream;
+    uint64_t bytes = 0, n_tiles = 0;
+    for (size_t i = 0; i < n; ++i) {
+        NS_CHECK(reqs[i].len < (1ull << 31), NSGPU_ERR_RANGE, "sequence %zu longer than 2^31", i);
+        bytes += (reqs[i].len + 16) & ~(uint64_t)15;
+        n_tiles += (reqs[i].len + kTile - 1) / kTile;
+    }
+    NS_CHECK(bytes < (1ull << 31), NSGPU_ERR_RANGE, "sketch batch exceeds 2 GiB of sequence; use smaller batches");
+    // ONE pinned staging area: [sequences | soff | len | tiles], one H2D copy
+    const size_t o_soff = (bytes + 15) & ~(size_t)15, o_len = o_soff + (n + 1) * 4, o_tiles = (o_len + n * 4 + 15) & ~(size_t)15, stage_bytes = o_tiles + n_tiles * sizeof(Tile) + 16;
+    NS_TRY(pinned_reserve(W.h_seqs, W.h_cap, stage_bytes));
+    uint32_t *soff = reinterpret_cast<uint32_t *>(W.h_seqs + o_soff), *len = reinterpret_cast<uint32_t *>(W.h_seqs + o_len);
+    Tile *tiles = reinterpret_cast<Tile *>(W.h_seqs + o_tiles);
+    std::vector<uint32_t> first_tile(n + 1);
+    {
+        uint64_t b = 0, t = 0;
+        for (size_t i = 0; i < n; ++i) {
+            soff[i] = (uint32_t)b, len[i] = (uint32_t)reqs[i].len, first_tile[i] = (uint32_t)t;
+            for (uint64_t p = 0; p < reqs[i].len; p += kTile) tiles[t++] = Tile{(uint32_t)i, (uint32_t)p};
+            b += (reqs[i].len + 16) & ~(uint64_t)15;
+        }
+        soff[n] = (uint32_t)b, first_tile[n] = (uint32_t)t;
+    }
+    par_for("sketch.stage", n, [&](size_t i) { memcpy(W.h_seqs + soff[i], reqs[i].ptr, reqs[i].len); });
+    const double t_staged = now_ms();
+    NS_TRY(W.seqs.reserve(stage_bytes + 64));
+    NS_HIP(hipMemcpyAsync(W.seqs.p, W.h_seqs, stage_bytes, hipMemcpyHostToDevice, st));
+    const Batch bt{W.seqs.as<uint8_t>(), reinterpret_cast<const uint32_t *>(W.seqs.as<uint8_t>() + o_soff), reinterpret_cast<const uint32_t *>(W.seqs.as<uint8_t>() + o_len),
+                   (uint32_t)n, (uint32_t)bytes, w, k};
+    const Tile *d_tiles = reinterpret_cast<const Tile *>(W.seqs.as<uint8_t>() + o_tiles);
+    // outputs land in pinned host memory, written by the kernels themselves (the GPU's stores travel over PCIe; no copy operation, no
+    // size known to the host in advance): [flags 2 | tile offsets n_tiles + 1 | minimizers]
+    const uint64_t cap = bytes / 12 + 64 * (uint64_t)n + 1024;                   // ~2x the expected 2 / (w + 1) per base
+    NS_TRY(W.h_meta.reserve((2 * n_tiles + 8) * 4 + 64));
+    NS_TRY(pinned_reserve(W.h_out, W.h_out_cap, cap * 16 + 16));
+    uint32_t *h_flags = W.h_meta.as<uint32_t>(), *h_toff = h_flags + 2, *h_tpal = h_toff + n_tiles + 2;
+    h_flags[0] = h_flags[1] = 0;
+    NS_TRY(W.nout.reserve((n_tiles + 2) * 4));
+    const size_t lds = (size_t)(kTile + w + 2 * kPalHalo + 3) * 8 + 2 * (size_t)(kTile + kPalHalo + 3) * 4 + 260 * 4 + 4 * (size_t)(kTile + w + 2 * kPalHalo + 4) + (size_t)(kTile + w + 2 * kPalHalo + k + 2) + 64;
+    if (n_tiles) {
+        hipLaunchKernelGGL((skf_kernel<false>), dim3((uint32_t)n_tiles), dim3(256), lds, st, bt, d_tiles, (uint32_t)n_tiles, W.nout.as<uint32_t>(), h_tpal, (const uint32_t *)nullptr,
+                           (uint64_t *)nullptr, (uint64_t)0, h_flags);
+        NS_HIP(hipGetLastError());
+        NS_HIP(hipMemsetAsync(W.nout.as<uint32_t>() + n_tiles, 0, 4, st));
+        NS_TRY(scan_u32(W, st, W.nout.as<uint32_t>(), h_toff, n_tiles + 1, false, 0));
+        hipLaunchKernelGGL((skf_kernel<true>), dim3((uint32_t)n_tiles), dim3(256), lds, st, bt, d_tiles, (uint32_t)n_tiles, (uint32_t *)nullptr, (uint32_t *)nullptr, h_toff,
+                           reinterpret_cast<uint64_t *>(W.h_out), cap, h_flags);
+        NS_HIP(hipGetLastError());
+    } else h_toff[0] = 0;
+    NS_HIP(stream_wait_short(st));
+    // `run` beyond a sequence's first tile was taken as >= w + k: true unless symmetric k-mers ate the difference
+    bool run_ok = true;
+    for (size_t i = 0; i < n && run_ok; ++i) {
+        uint64_t pal = 0;
+        for (uint32_t t = first_tile[i]; t < first_tile[i + 1]; ++t) {
+            if (t > first_tile[i] && (uint64_t)tiles[t].t0 < pal + (uint64_t)(w + k)) { run_ok = false; break; }
+            pal += h_tpal[t];
+        }
+    }
+    if (h_flags[0] || h_flags[1] || h_toff[n_tiles] > cap || !run_ok) {
+        static const bool dbg = getenv("NSGPU_SKETCH_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "[sketch] fused path gives up: bad input %u, overflow %u, minimizers %u of %llu slots, %zu sequences, %llu tiles\n", h_flags[0], h_flags[1],
+                         h_toff[n_tiles], (unsigned long long)cap, n, (unsigned long long)n_tiles);
+        return 1;
+    }
+    for (size_t i = 0; i <= n; ++i) out_off[i] = h_toff[first_tile[i]];
+    out = reinterpret_cast<const mm2::Anchor *>(W.h_out);
+    std::lock_guard<std::mutex> lk(c->stat_m);
+    c->sketch_mm_ms += now_ms() - t0;
+    g_sketch_ms[0] += t_staged - t0, g_sketch_ms[3] += now_ms() - t_staged, g_sketch_ms[4] += (double)bytes, g_sketch_ms[5] += (double)out_off[n];
+    return 0;
+}
 
 int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws)
 {
@@ -264,6 +579,13 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
     out_off.assign(n + 1, 0);
     out = nullptr;
     if (n == 0) return NSGPU_OK;
+    static const bool general_only = getenv("NSGPU_SKETCH_GENERAL") != nullptr;      // debugging aid: the general passes for everything
+    if (!general_only && k > 0 && k <= 28 && w > 0 && w < 256 && (ws == 0 || ws == 1)) {
+        const int rc = gpu_mm_sketch_fused(c, reqs, w, k, out, out_off, ws);
+        if (rc <= 0) return rc;
+        out_off.assign(n + 1, 0);
+        out = nullptr;
+    }
     NS_CHECK(k > 0 && k <= 28 && w > 0 && w < 256, NSGPU_ERR_ARG, "minimap k must be in 1..28 and w in 1..255 (sketch.c:84)");
     const double t0 = now_ms();
     NS_CHECK(ws == 0 || ws == 1, NSGPU_ERR_ARG, "gpu_mm_sketch: workspace 0 or 1");
