@@ -13,10 +13,14 @@
  *   - inputs are borrowed for the duration of the call; outputs named *_out are
  *     caller-allocated; outputs returned through T** are library-allocated and
  *     released with nsgpu_free().
- *   - all device work of a context is issued on ONE HIP stream (nsgpu_set_stream,
- *     default: a stream created by the context).  Calls whose name ends in
- *     _async only enqueue; everything else synchronises that stream before
- *     returning host-visible results.
+ *   - every call is host-synchronous: results are complete (and host-visible) when it returns.
+ *     The read store, the MinHash stages and the direct batch calls issue their device work on the
+ *     context's stream (nsgpu_set_stream; default: a stream the context creates).  The contig stage,
+ *     the batched minimizer sketches and the alignment DP additionally use PRIVATE non-blocking
+ *     streams of the context (one per pipeline role and DP batch in flight, plus highest-priority side
+ *     streams for the long DP problems); they are ordered against each other inside the library and
+ *     drained before the call returns.  A caller that shares the GPU with other work on its own
+ *     streams therefore needs no extra synchronisation, but cannot order INTO the middle of a call.
  *   - base alphabet is the reference's: code(c) = (c & 2) | ((c & 4) >> 2), i.e.
  *     A0 T1 C2 G3, N (and anything else) folds through the same bits
  *     (src/dnaToBits.cpp:6-8); 2-bit packing is MSB-first, 4 bases per byte
@@ -86,6 +90,12 @@ int nsgpu_load_reads_packed(nsgpu_ctx *ctx, const uint8_t *packed, const uint64_
  *      line is a read of length 0, an unterminated last line counts when non-empty.  At most 4 GiB of text per call.
  *      Errors like the reference: no reads, or 2^32-1 reads ("Too many reads for read_t type to handle."). ---- */
 int nsgpu_load_fastq(nsgpu_ctx *ctx, const char *text, size_t n_bytes, uint32_t *n_reads_out);
+/* The same for inputs of any size, piece by piece (the reference's logs are 85-130 Gbases): consecutive pieces of the file in order,
+ * cut anywhere -- a record may straddle pieces; each piece < 3.75 GiB.  The result (rows in HBM, read ids, nsgpu_get_read) is what
+ * ONE call over the whole text gives. */
+int nsgpu_load_fastq_begin(nsgpu_ctx *ctx);
+int nsgpu_load_fastq_chunk(nsgpu_ctx *ctx, const char *text, size_t n_bytes);
+int nsgpu_load_fastq_end(nsgpu_ctx *ctx, uint32_t *n_reads_out);
 uint32_t nsgpu_num_reads(const nsgpu_ctx *ctx);
 uint64_t nsgpu_num_bases(const nsgpu_ctx *ctx);
 /* ReadData::getRead (src/ReadData.cpp:225-235): read r as ASCII (A/T/C/G), out must hold len[r] bytes. */

@@ -337,6 +337,13 @@ static int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, 
     if (D.N) NS_TRY(nsgpu_check_repetitive(c, D.rep.data()));
     if (n_builders_total > D.N && D.N > 0) n_builders_total = D.N;
     if (D.N == 0) n_builders_total = 1;
+    {   // one group's alignments of one slot share a DP sequence pool addressed with 32 bits (align_batch.hip): an alignment needs at most a few
+        // times its read and the stretch of consensus under it, so this many builders per group and rank can never overflow it.  A function of
+        // replicated values only (every rank holds all reads): all ranks clamp alike.
+        const uint64_t per_aln = 6ull * std::max<uint64_t>(c->reads.max_len, 1024);
+        const uint64_t cap = std::max<uint64_t>(8, (3500ull << 20) / per_aln) * (uint64_t)n_groups() * world;
+        if (n_builders_total > cap) n_builders_total = (uint32_t)cap;
+    }
     E->rank = rank, E->world = world, E->n_total = n_builders_total;
     const uint32_t n_local = n_builders_total > rank ? (n_builders_total - rank + world - 1) / world : 0;
     D.B.resize(n_local);

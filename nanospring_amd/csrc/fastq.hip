@@ -12,6 +12,9 @@
 #include "host_util.hpp"
 #include <rocprim/rocprim.hpp>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
 
 namespace nsgpu {
 
@@ -158,9 +161,139 @@ int load_fastq(nsgpu_ctx *c, const char *text, size_t n_bytes, uint32_t *n_reads
     return NSGPU_OK;
 }
 
+// ---- chunked ingest: inputs beyond 4 GiB (the reference's logs are 85-130 Gbases), records may straddle chunk borders -------------------
+// State of an ingest in progress.  Every chunk is parsed on the GPU like a small file of its own after the unfinished tail of the
+// previous one (everything behind the last complete 4-line record) has been put in front of it; its reads are packed into a scratch
+// store and appended to the accumulated rows in HBM (row offsets are relative, so appending is one device copy).
+struct FastqIngest {
+    std::string carry;                  // bytes behind the last complete record
+    DevBuf rows;                        // accumulated 2-bit rows
+    uint64_t row_bytes = 0;
+    std::vector<uint64_t> poff;         // row offsets of the accumulated reads
+    std::vector<uint32_t> len;
+    std::vector<char> h_bases;          // folded host mirror
+    std::vector<uint64_t> h_off{0};
+    bool active = false;
+};
+
+static FastqIngest &ingest_of(nsgpu_ctx *c)
+{
+    static std::mutex m;
+    static std::map<nsgpu_ctx *, FastqIngest> table;        // a context ingests one file at a time; state dies with ..._end
+    std::lock_guard<std::mutex> lk(m);
+    return table[c];
+}
+
+// reads of `text` (a whole number of records unless `last`): parsed + packed into c->queries, appended to the ingest
+static int ingest_text(nsgpu_ctx *c, FastqIngest &I, const char *text, size_t n_bytes)
+{
+    if (n_bytes == 0) return NSGPU_OK;
+    SeqStore keep;
+    std::swap(keep, c->reads);                                    // load_fastq fills c->reads: borrow it
+    std::vector<char> hb;
+    std::vector<uint64_t> ho;
+    hb.swap(c->h_bases), ho.swap(c->h_off);
+    uint32_t n = 0;
+    int rc = load_fastq(c, text, n_bytes, &n);
+    if (rc == NSGPU_OK) {
+        SeqStore &S = c->reads;
+        // grow-with-copy of the accumulated rows
+        if (I.row_bytes + S.packed_bytes + 64 > I.rows.cap) {
+            DevBuf bigger;
+            rc = bigger.reserve((I.row_bytes + S.packed_bytes) * 2 + (64 << 20));
+            if (rc == NSGPU_OK && I.row_bytes) { if (hipMemcpyAsync(bigger.p, I.rows.p, I.row_bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rc = NSGPU_ERR_HIP; }
+            if (rc == NSGPU_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = NSGPU_ERR_HIP;
+            if (rc == NSGPU_OK) { std::swap(bigger.p, I.rows.p); std::swap(bigger.cap, I.rows.cap); }
+            bigger.release();
+        }
+        if (rc == NSGPU_OK && S.packed_bytes) {
+            if (hipMemcpyAsync(static_cast<uint8_t *>(I.rows.p) + I.row_bytes, S.packed.p, S.packed_bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rc = NSGPU_ERR_HIP;
+            if (rc == NSGPU_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = NSGPU_ERR_HIP;
+        }
+        if (rc == NSGPU_OK) {
+            for (uint32_t r = 0; r < n; ++r) I.poff.push_back(I.row_bytes + S.h_poff[r]);
+            I.len.insert(I.len.end(), S.h_len.begin(), S.h_len.end());
+            I.row_bytes += S.packed_bytes;
+            const uint64_t base = I.h_off.back();
+            I.h_bases.insert(I.h_bases.end(), c->h_bases.begin(), c->h_bases.begin() + (ptrdiff_t)c->h_off[n]);
+            for (uint32_t r = 1; r <= n; ++r) I.h_off.push_back(base + c->h_off[r]);
+        }
+    }
+    std::swap(keep, c->reads);
+    keep.release();
+    hb.swap(c->h_bases), ho.swap(c->h_off);
+    return rc;
+}
+
 }  // namespace nsgpu
 
 using namespace nsgpu;
+
+extern "C" int nsgpu_load_fastq_begin(nsgpu_ctx *c)
+{
+    NS_CHECK(c, NSGPU_ERR_ARG, "nsgpu_load_fastq_begin: null context");
+    FastqIngest &I = ingest_of(c);
+    I = FastqIngest();
+    I.active = true;
+    return NSGPU_OK;
+}
+
+extern "C" int nsgpu_load_fastq_chunk(nsgpu_ctx *c, const char *text, size_t n_bytes)
+{
+    NS_CHECK(c && (text || n_bytes == 0), NSGPU_ERR_ARG, "nsgpu_load_fastq_chunk: null argument");
+    FastqIngest &I = ingest_of(c);
+    NS_CHECK(I.active, NSGPU_ERR_ARG, "nsgpu_load_fastq_chunk: call nsgpu_load_fastq_begin first");
+    NS_CHECK(n_bytes < 0xF0000000ull, NSGPU_ERR_RANGE, "nsgpu_load_fastq_chunk: at most 3.75 GiB per chunk");
+    NS_HIP(hipSetDevice(c->prm.device));
+    // complete records of carry + chunk: everything up to the newline that ends line 4m
+    std::string &buf = I.carry;
+    buf.append(text, n_bytes);
+    uint64_t nl = 0;
+    size_t cut = 0;                                   // one past the newline ending the last complete record
+    for (const char *p = buf.data(), *e = p + buf.size(); (p = static_cast<const char *>(memchr(p, '\n', (size_t)(e - p)))) != nullptr; ++p)
+        if ((++nl & 3) == 0) cut = (size_t)(p - buf.data()) + 1;
+    if (cut == 0) return NSGPU_OK;
+    NS_TRY(ingest_text(c, I, buf.data(), cut));
+    buf.erase(0, cut);
+    return NSGPU_OK;
+}
+
+extern "C" int nsgpu_load_fastq_end(nsgpu_ctx *c, uint32_t *n_reads_out)
+{
+    NS_CHECK(c, NSGPU_ERR_ARG, "nsgpu_load_fastq_end: null context");
+    FastqIngest &I = ingest_of(c);
+    NS_CHECK(I.active, NSGPU_ERR_ARG, "nsgpu_load_fastq_end: no ingest in progress");
+    NS_HIP(hipSetDevice(c->prm.device));
+    // the tail: an incomplete last record, parsed with getline's end-of-file rules (a missing base line is an empty read; an
+    // unterminated last line counts when it is not empty)
+    if (!I.carry.empty()) NS_TRY(ingest_text(c, I, I.carry.data(), I.carry.size()));
+    const size_t n = I.len.size();
+    NS_CHECK(n > 0, NSGPU_ERR_ARG, "nsgpu_load_fastq: no reads");
+    NS_CHECK(n < 0xFFFFFFFFull, NSGPU_ERR_RANGE, "Too many reads for read_t type to handle.");
+    SeqStore &S = c->reads;
+    S.release();
+    S.n = (uint32_t)n;
+    S.h_len = I.len;
+    S.h_poff = I.poff;
+    S.h_poff.push_back(I.row_bytes);
+    S.packed_bytes = I.row_bytes;
+    S.n_bases = I.h_off.back();
+    S.max_len = 0;
+    for (uint32_t l : I.len) S.max_len = std::max(S.max_len, l);
+    std::swap(S.packed.p, I.rows.p), std::swap(S.packed.cap, I.rows.cap);
+    NS_TRY(S.poff.reserve((n + 1) * 8));
+    NS_TRY(S.len.reserve((n + 1) * 4));
+    NS_HIP(hipMemcpyAsync(S.poff.p, S.h_poff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    NS_HIP(hipMemcpyAsync(S.len.p, S.h_len.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+    NS_HIP(hipStreamSynchronize(c->stream));
+    c->h_bases.swap(I.h_bases);
+    c->h_bases.push_back(0);
+    c->h_off.swap(I.h_off);
+    c->have_sketch = c->have_index = c->have_filter_all = c->have_cons = false;
+    I = FastqIngest();
+    if (n_reads_out) *n_reads_out = (uint32_t)n;
+    return NSGPU_OK;
+}
 
 extern "C" int nsgpu_load_fastq(nsgpu_ctx *c, const char *text, size_t n_bytes, uint32_t *n_reads_out)
 {

@@ -573,7 +573,39 @@ static int gpu_mm_sketch_fused(nsgpu_ctx *c, const std::vector<SketchReq> &reqs,
     return 0;
 }
 
+static int gpu_mm_sketch_one(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws);
+
+// Any number of sequences: batches beyond the 32-bit position space of the kernels (2 GiB of sequence) are sketched piece by piece and
+// the results concatenated (a contig engine with many builders on multi-megabase contigs can get there; it cannot act on an error).
 int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws)
+{
+    const uint64_t kPiece = 1500ull << 20;
+    uint64_t bytes = 0;
+    for (const SketchReq &r : reqs) bytes += (r.len + 16) & ~(uint64_t)15;
+    if (bytes < kPiece) return gpu_mm_sketch_one(c, reqs, w, k, out, out_off, ws);
+    static std::vector<mm2::Anchor> concat[2];                  // per workspace; the result stays valid until the workspace's next call
+    NS_CHECK(ws == 0 || ws == 1, NSGPU_ERR_ARG, "gpu_mm_sketch: workspace 0 or 1");
+    std::vector<mm2::Anchor> &all = concat[ws];
+    all.clear();
+    out_off.assign(reqs.size() + 1, 0);
+    std::vector<SketchReq> part;
+    std::vector<uint64_t> poff;
+    size_t i = 0;
+    while (i < reqs.size()) {
+        part.clear();
+        uint64_t b = 0;
+        const size_t first = i;
+        while (i < reqs.size() && (part.empty() || b + ((reqs[i].len + 16) & ~(uint64_t)15) < kPiece)) { b += (reqs[i].len + 16) & ~(uint64_t)15; part.push_back(reqs[i++]); }
+        const mm2::Anchor *po = nullptr;
+        NS_TRY(gpu_mm_sketch_one(c, part, w, k, po, poff, ws));
+        for (size_t j = 0; j < part.size(); ++j) out_off[first + j + 1] = all.size() + poff[j + 1];
+        all.insert(all.end(), po, po + poff[part.size()]);
+    }
+    out = all.data();
+    return NSGPU_OK;
+}
+
+static int gpu_mm_sketch_one(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws)
 {
     const size_t n = reqs.size();
     out_off.assign(n + 1, 0);

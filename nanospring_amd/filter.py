@@ -118,6 +118,16 @@ class NsGpu:
         check(self.lib, self.lib.nsgpu_load_fastq(self.ctx, _ptr(buf) if buf.size else None, buf.size, C.byref(n)))
         return n.value
 
+    def load_fastq_chunks(self, pieces):
+        """The same from consecutive pieces of the text, cut anywhere (nsgpu_load_fastq_begin / _chunk / _end)."""
+        check(self.lib, self.lib.nsgpu_load_fastq_begin(self.ctx))
+        for piece in pieces:
+            buf = np.frombuffer(bytes(piece), dtype=np.uint8)
+            check(self.lib, self.lib.nsgpu_load_fastq_chunk(self.ctx, _ptr(buf) if buf.size else None, buf.size))
+        n = C.c_uint32()
+        check(self.lib, self.lib.nsgpu_load_fastq_end(self.ctx, C.byref(n)))
+        return n.value
+
     def load_reads_packed(self, packed, byte_off, lens):
         packed = np.ascontiguousarray(packed, dtype=np.uint8)
         byte_off = np.ascontiguousarray(byte_off, dtype=np.uint64)

@@ -89,3 +89,39 @@ def test_gpu_ingest_equals_oracle():
     b = g.sketch(salts)
     assert np.array_equal(a, b)
     g.close()
+
+
+@pytest.mark.gpu
+def test_gpu_chunked_ingest_equals_one_call():
+    """nsgpu_load_fastq_begin / _chunk / _end: pieces cut anywhere (inside names, base lines, between the CR and the LF, right behind
+    a record) must give the reads of one call over the whole text, for well-formed and for truncated files."""
+    import nanospring_amd as ns
+    g, h = ns.NsGpu(), ns.NsGpu()
+    rng = np.random.RandomState(11)
+    small = [t for t, _ in CASES] + [synth_fastq(5, 3) + b"\n\n\n", synth_fastq(6, 4, crlf=True), synth_fastq(8, 5, final_newline=False)]
+    for text in small:
+        if not text:
+            continue
+        n = h.load_fastq(text)
+        want = [h.get_read(r) for r in range(n)]
+        cuts = range(0, len(text) + 1) if len(text) < 400 else sorted(set(rng.randint(0, len(text) + 1, size=60).tolist()))
+        for c in cuts:
+            assert g.load_fastq_chunks([text[:c], text[c:]]) == n, (text[:40], c)
+            assert [g.get_read(r) for r in range(n)] == want, (text[:40], c)
+    for seed, nrec in ((21, 400), (22, 1500)):
+        text = synth_fastq(seed, nrec, crlf=seed == 22)[:-3 if seed == 22 else None]
+        n = h.load_fastq(text)
+        for trial in range(3):
+            k = int(rng.randint(2, 40))
+            cs = [0] + sorted(rng.randint(0, len(text) + 1, size=k).tolist()) + [len(text)]
+            pieces = [text[a:b] for a, b in zip(cs[:-1], cs[1:])]
+            assert g.load_fastq_chunks(pieces) == n
+            assert g.num_bases == h.num_bases
+            for r in list(range(0, n, 17)) + [n - 1]:
+                assert g.get_read(r) == h.get_read(r), (seed, trial, r)
+        # and they feed the path: same sketches
+        salts = ns.mt19937_64_salts(60)
+        assert np.array_equal(g.sketch(salts), h.sketch(salts))
+    with pytest.raises(ns.NsGpuError):
+        g.load_fastq_chunks([b"", b""])
+    g.close(); h.close()
