@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU (cfg2: 100000)")
     ap.add_argument("--mean-len", type=float, default=8000.0)
     ap.add_argument("--builders", type=int, default=1024, help="virtual contig builders per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the all-cores CPU-baseline sample (0 = skip; default: 800 per host core)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the all-cores CPU-baseline sample (0 = skip; default: 2000 per host core)")
     ap.add_argument("--no-exchange", action="store_true", help="multi-GPU: independent shards, no collective")
     ap.add_argument("--dist-mode", choices=["alltoall", "replicate"], default="alltoall",
                     help="multi-GPU bucket tables: owners of an RCCL all-to-all of (slot, key, id) tuples, or all-gathered sketch rows")
@@ -266,7 +266,7 @@ def main():
                          "note": "frac is the HBM fraction the contract asks for; it is ~1e-5 by construction (1 B of sequence per ~250 DP cells)"},
         }
         if args.cpu_sample != 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample if args.cpu_sample > 0 else 800 * host_cores(), args.mean_len, k, n, thr, salts)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample if args.cpu_sample > 0 else 2000 * host_cores(), args.mean_len, k, n, thr, salts)
         print(json.dumps(out), flush=True)
     if job is not None:
         job.close()
