@@ -864,8 +864,31 @@ void ContigGraph::walk_read(const GraphRead &r, read_t id, const ReadBases *src,
             // node (cum_weight), next_fork_[j] = first index >= j whose node has more than one way out or ends the path,
             // side_mask_[j] = bases of the side sinks of node j, cons = the path's bases (all set by write_reads).
             size_t j = cur->cum_weight;
+            static const bool no_word_walk = getenv("NSGPU_NO_WORD_WALK") != nullptr;
             for (;;) {
                 if (++i == L) return;
+                if (!no_word_walk && j < n_main) {
+                    // the longest stretch on which the read's bases are the consensus's and nothing else could carry them: 8 bases per
+                    // compare (read ^ consensus, and the follow_ok_ bytes all 1)
+                    const size_t lim = L - i < n_main - j ? L - i : n_main - j;
+                    const char *a = rb + i, *b = cons + j + 1;
+                    const uint8_t *ok = follow_ok_.data() + j;
+                    size_t t = 0;
+                    while (t + 8 <= lim) {
+                        uint64_t x, y, z;
+                        memcpy(&x, a + t, 8), memcpy(&y, b + t, 8), memcpy(&z, ok + t, 8);
+                        const uint64_t d = (x ^ y) | (z ^ 0x0101010101010101ull);
+                        if (d) { t += (size_t)(__builtin_ctzll(d) >> 3); goto run_done; }
+                        t += 8;
+                    }
+                    while (t < lim && a[t] == b[t] && ok[t]) ++t;
+                run_done:
+                    if (t) {
+                        visit_run(t);
+                        j += t, i += t - 1;
+                        continue;
+                    }
+                }
                 if (j < n_main && next_fork_[j] != j) {
                     // single way out: it leads to the next main-path node, and so on up to the next fork
                     const size_t j1 = j + 1, stop = next_fork_[j1];
@@ -1008,6 +1031,10 @@ void ContigGraph::write_reads(StreamSet &o, const std::function<ReadBases(read_t
         main_nodes_[t + 1] = n;
         note(t + 1, n);
     }
+    // follow_ok_[j]: node j has one way out, or none of its side branches starts with the consensus's next base -- then a read
+    // whose next base equals cons[j + 1] continues on the path, and the walk can compare whole words of read and consensus
+    follow_ok_.assign(n_main + 8, 0);
+    for (size_t j = 0; j < n_main; ++j) follow_ok_[j] = next_fork_[j] == UINT32_MAX || !(side_mask_[j] & base_bit(main_path[j + 1]));
     for (size_t j = n_main; j-- > 0;) if (next_fork_[j] == UINT32_MAX) next_fork_[j] = next_fork_[j + 1];
     g_emit_ns[0] += emit_now() - e0;
     read_t prev = 0;
