@@ -165,6 +165,15 @@ int nsgpu_ksw_extd2_batch(nsgpu_ctx *ctx, uint32_t n, const uint8_t *seqs, const
 int nsgpu_mm_sketch_batch(nsgpu_ctx *ctx, const char *seqs, const uint64_t *seq_off, uint32_t n, uint32_t w, uint32_t k,
                           uint64_t **xy_out, uint64_t **off_out);
 
+/* ---- a14e: the forward pass of mm_chain_dp (minimap2/chain.c:43-92; called by mm_map_frag, minimap2/map.c:295) for a
+ *      batch of anchor lists: list i is the mm128_t pairs xy[2*j], xy[2*j+1] = x (rev<<63 | rid<<32 | ref pos),
+ *      y (query span<<32 | query pos) for j in off[i] .. off[i+1], sorted by x as mm_map_frag leaves them.
+ *      f_out[j] / p_out[j] are chain.c's f[] (best chain score ending in anchor j) and p[] (its predecessor, as an
+ *      index into the same list, or -1), computed with minimap2's default max_gap = 5000, bw = 500,
+ *      max_chain_skip = 25, chain_gap_scale = 1 and params.max_chain_iter.  nsgpu_align_batch and the contig
+ *      engine run the same kernel; this entry exists so that it can be checked on its own. ---- */
+int nsgpu_chain_scores(nsgpu_ctx *ctx, const uint64_t *xy, const uint64_t *off, uint32_t n, int32_t *f_out, int32_t *p_out);
+
 /* ---- a13: batched ConsensusGraph::alignRead (include/ConsensusGraph.h:245-247,
  *      src/ConsensusGraph.cpp:161-398): align query i (qrys[qry_off[i]..qry_off[i+1])) to reference
  *      pair_ref[i] (refs[ref_off[r]..ref_off[r+1])) with minimap2's defaults + MM_F_CIGAR|MM_F_FOR_ONLY,

@@ -449,17 +449,70 @@ static void batch_start_jobs(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi)
     }
 }
 
-int align_prestep(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi)
+// seeds on the host threads and the launch of the chaining kernel (chain.hip) / its results and every job's first step (chains,
+// regions, DP plan)
+static int batch_seed_and_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws, bool seeded = false)
+{
+    const size_t n = hi - lo;
+    if (!seeded) parallel_for("align.seed", n, [&](size_t i) { B.jobs[lo + i].seed(); });
+    nsgpu_ctx::ChainWs &W = c->cws[chain_ws];
+    W.lists.resize(n), W.off.resize(n + 1), W.avg.resize(n);
+    W.off[0] = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const mm2::AlignJob &J = B.jobs[lo + i];
+        W.lists[i] = J.a.data(), W.off[i + 1] = W.off[i] + J.a.size(), W.avg[i] = J.avg_qspan;
+    }
+    return gpu_chain_launch(c, chain_ws, batch_opt(c), W.lists, W.off, W.avg);
+}
+static int batch_wait_and_step(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws)
+{
+    const size_t n = hi - lo;
+    const int32_t *f = nullptr, *p = nullptr;
+    const double g0 = now_ms();
+    NS_TRY(gpu_chain_wait(c, chain_ws, f, p));
+    B.chain_ms += now_ms() - g0;
+    const std::vector<uint64_t> &off = c->cws[chain_ws].off;
+    if (f) for (size_t i = 0; i < n; ++i) B.jobs[lo + i].cf = f + off[i], B.jobs[lo + i].cp = p + off[i];
+    parallel_for("align.step", n, [&](size_t i) { B.jobs[lo + i].step(); });
+    return NSGPU_OK;
+}
+
+static int prestep_check(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws)
 {
     NS_CHECK(lo <= hi && hi <= B.reqs.size(), NSGPU_ERR_ARG, "align_prestep: bad range");
+    NS_CHECK(chain_ws >= 0 && chain_ws < (int)(sizeof(c->cws) / sizeof(c->cws[0])), NSGPU_ERR_ARG, "align_prestep: bad chain workspace");
     // (B.jobs must not be resized here: another range of the same batch may be in its step on other threads -- the caller sizes it)
     NS_CHECK(B.jobs.size() >= B.reqs.size(), NSGPU_ERR_ARG, "align_prestep: size B.jobs first");
-    const double a0 = now_ms();
+    return NSGPU_OK;
+}
+int align_prestep_start(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi)
+{
+    NS_TRY(prestep_check(c, B, lo, hi, 0));
     batch_start_jobs(c, B, lo, hi);
-    parallel_for("align.step", hi - lo, [&](size_t i) { B.jobs[lo + i].step(); });
+    return NSGPU_OK;
+}
+int align_prestep_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws, bool started_and_seeded)
+{
+    NS_TRY(prestep_check(c, B, lo, hi, chain_ws));
+    const double a0 = now_ms();
+    if (!started_and_seeded) batch_start_jobs(c, B, lo, hi);
+    NS_TRY(batch_seed_and_launch(c, B, lo, hi, chain_ws, started_and_seeded));
+    B.host_ms += now_ms() - a0;
+    return NSGPU_OK;
+}
+int align_prestep_finish(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws)
+{
+    NS_TRY(prestep_check(c, B, lo, hi, chain_ws));
+    const double a0 = now_ms();
+    NS_TRY(batch_wait_and_step(c, B, lo, hi, chain_ws));
     B.host_ms += now_ms() - a0;
     B.prestepped = true;
     return NSGPU_OK;
+}
+int align_prestep(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws)
+{
+    NS_TRY(align_prestep_launch(c, B, lo, hi, chain_ws, false));
+    return align_prestep_finish(c, B, lo, hi, chain_ws);
 }
 
 int align_begin(nsgpu_ctx *c, AlignBatch &B, int ws_index)
@@ -476,10 +529,16 @@ int align_begin(nsgpu_ctx *c, AlignBatch &B, int ws_index)
     // the job objects (and the capacity of their vectors) are kept from batch to batch: freeing and re-allocating the
     // ~100 small blocks of every job cost more CPU than the alignment bookkeeping itself
     if (B.jobs.size() < n_pairs) B.jobs.resize(n_pairs);
-    if (!pre) batch_start_jobs(c, B, 0, n_pairs);
+    if (!pre) {
+        const double a0 = now_ms();
+        batch_start_jobs(c, B, 0, n_pairs);
+        NS_TRY(batch_seed_and_launch(c, B, 0, n_pairs, 0));      // direct API calls: chain workspace 0
+        NS_TRY(batch_wait_and_step(c, B, 0, n_pairs, 0));
+        B.host_ms += now_ms() - a0;
+    }
     B.live.resize(n_pairs);
     for (size_t i = 0; i < n_pairs; ++i) B.live[i] = (uint32_t)i;
-    NS_TRY(batch_prepare_round(c, B, pre));
+    NS_TRY(batch_prepare_round(c, B, true));
     if (B.live.empty()) return NSGPU_OK;
     const double a0 = now_ms();
     NS_TRY(ksw_batch_launch(c, B.tasks, c->kws[ws_index].h_pool, B.nb, batch_ksw_params(batch_opt(c)), B.res, B.cig, B.coff, ws_index));
@@ -603,6 +662,29 @@ extern "C" int nsgpu_mm_sketch_batch(nsgpu_ctx *c, const char *seqs, const uint6
     if (off[n]) memcpy(xy, mz, off[n] * 16);
     memcpy(of, off.data(), ((size_t)n + 1) * 8);
     *xy_out = xy, *off_out = of;
+    return NSGPU_OK;
+}
+
+// mm_chain_dp's forward pass (minimap2/chain.c:43-92) for a batch of sorted anchor lists on the GPU: score f and predecessor p
+// of every anchor, with minimap2's default max_gap / bw / max_chain_skip and params.max_chain_iter.
+extern "C" int nsgpu_chain_scores(nsgpu_ctx *c, const uint64_t *xy, const uint64_t *off, uint32_t n, int32_t *f_out, int32_t *p_out)
+{
+    NS_CHECK(c && off && (off[n] == 0 || (xy && f_out && p_out)), NSGPU_ERR_ARG, "nsgpu_chain_scores: null argument");
+    NS_HIP(hipSetDevice(c->prm.device));
+    std::vector<const mm2::Anchor *> lists(n);
+    std::vector<uint64_t> o(off, off + n + 1);
+    std::vector<float> avg(n);
+    std::vector<mm2::Anchor> tmp;
+    for (uint32_t i = 0; i < n; ++i) {
+        NS_CHECK(off[i + 1] >= off[i] && off[i + 1] - off[i] < (1ull << 31), NSGPU_ERR_ARG, "offsets must be non-decreasing, lists shorter than 2^31");
+        lists[i] = reinterpret_cast<const mm2::Anchor *>(xy) + off[i];
+        tmp.assign(lists[i], lists[i] + (off[i + 1] - off[i]));
+        avg[i] = mm2::chain_avg_qspan(tmp);
+    }
+    const int32_t *f = nullptr, *p = nullptr;
+    NS_TRY(gpu_chain_launch(c, 0, batch_opt(c), lists, o, avg));
+    NS_TRY(gpu_chain_wait(c, 0, f, p));
+    if (f) memcpy(f_out, f, off[n] * sizeof(int32_t)), memcpy(p_out, p, off[n] * sizeof(int32_t));
     return NSGPU_OK;
 }
 

@@ -186,6 +186,10 @@ void nsgpu_destroy(nsgpu_ctx *c)
         if (w.h_pool) (void)hipHostFree(w.h_pool);
         w.h_res.release(); w.h_coff.release(); w.h_cig.release();
     }
+    for (nsgpu_ctx::ChainWs &w : c->cws) {
+        w.d_in.release(); w.d_out.release(); w.d_marks.release(); w.h_in.release(); w.h_out.release();
+        if (w.stream) (void)hipStreamDestroy(w.stream);
+    }
     c->pin_small.release(); c->pin_foff.release(); c->pin_fids.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;

@@ -1,0 +1,386 @@
+// Chaining scores on the GPU: the forward pass of minimap2's mm_chain_dp (chain.c:43-92 of the version the reference vendors;
+// SURVEY §8 row a14e) for a batch of anchor lists, one wavefront per list.
+//
+// For anchor i the reference walks its predecessors j = i-1 .. st in order and keeps
+//     max_f  = the running best of  f[j] + gain(i, j)            (a new best only on a STRICTLY larger score),
+//     n_skip = a counter: -1 (floored at 0) on a new best, +1 when j is not a new best and some earlier-visited j' had p[j'] == j,
+// and stops as soon as n_skip exceeds max_skip.  The walk is sequential in j, but every quantity is a prefix function of
+// per-j values that do not depend on the walk:
+//     * new best at j       <=>  score(j) > max(q_span, max over visited j' of score(j'))              -- an exclusive prefix max;
+//     * "marked" at j       <=>  some admissible j' > j in the window has p[j'] == j                        (*);
+//     * n_skip after j      =    the composition of  n -> max(n - 1, 0)  (new best),  n -> n + 1  (marked, not a new best) and
+//                                the identity: maps of the form n -> max(n + a, b), which are closed under composition
+//                                ((a1,b1) then (a2,b2) = (a1 + a2, max(b1 + a2, b2))) -- an inclusive prefix scan of pairs.
+// So a wave takes 64 predecessors at a time (lane l holds j = hi - l), computes the scans across its lanes, finds the first lane
+// where n_skip would exceed max_skip, and commits the last new best in front of it.  Everything behind the break point is
+// discarded, which is exactly what the sequential loop never looked at.
+// (*) the reference sets t[p[j']] = i only for j' that passed the admissibility tests (`continue` skips the store): the kernel
+// does the same -- the store is predicated on `ok`.  Marks written by lanes behind the break point are harmless: a mark with
+// value i is only ever compared with i during this anchor's own walk, by lanes even further behind.
+//
+// Two kernels.  chain_forward_lds_kernel (lists of <= kFastAnchors anchors whose reference coordinate fits 31 bits and bw <=
+// kFastBw -- every list of the contig engine): lane l keeps anchor i-1-l (position, f, p) in registers and the window slides by one
+// lane per anchor (wave_shr:1), so the 64 nearest predecessors -- where almost every walk ends, max_skip being 25 -- never come
+// from memory; older predecessors, the marks and the gap-cost table (a function of |dr - dq| <= bw and the list's mean span,
+// tabulated once per list: no double-precision instruction in the loop) are in LDS; the prefix maxima are v_max_i32_dpp row shifts
+// + row broadcasts, and the skip counter is the reflected +-1 walk  D_l + max(n0, max_{u<=l} -D_u)  with D from v_mbcnt of two
+// ballots -- one more prefix max instead of the pair scan.  One wave per block: its LDS operations complete in program order, so
+// its lanes need compiler ordering only and no s_barrier.  The lists are read from and the results written to pinned host memory
+// directly (one launch, no copy operations).  chain_forward_general_kernel (anything else): the textbook form of the same steps
+// with 64-bit coordinates, f / p / marks in global memory behind agent-scope atomics, ds_bpermute shuffles, the pair scan.
+// Bound: one wave per list is a dependent chain of ~130 instructions per anchor (~0.2 us): a launch lasts as long as its longest
+// list (cfg2: ~250 lists of ~300 anchors per launch, longest ~1000-1500: 0.30 ms on average, profiles/r02_chain_gpu_ab.txt);
+// algorithmic bytes 16 B in + 8 B out per anchor, irrelevant next to the latency.
+//
+// Bit-exactness: the gain is integer arithmetic plus two double-precision products that the reference also evaluates in double
+// ((int)(dd * .01 * avg_qspan) and (int)((double)gap_cost * chain_gap_scale + .499)); the build runs with -ffp-contract=off, and
+// v_mul_f64 / v_add_f64 / v_cvt are IEEE.  tests/test_chain_gpu.py compares f and p with the plain loop on the anchor lists of the
+// alignment cases and on synthetic lists (both kernels; max_skip / max_chain_iter paths); tests/test_align_gpu.py compares whole
+// alignments with the reference's minimap2.
+#include "common.hpp"
+#include "host_util.hpp"
+#include "mm2.hpp"
+#include <algorithm>
+#include <cstring>
+
+namespace nsgpu {
+namespace {
+
+struct ChainParams {
+    int32_t max_dist, bw, max_skip, max_iter;
+    float gap_scale;
+};
+
+constexpr int kNegInf = -(1 << 28);
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// ---- the general kernel: f / p / marks in global memory, read and written past the L1 with agent-scope atomics (one wave is the
+// only reader and writer, the barrier orders its lanes) ----
+__device__ __forceinline__ int32_t ld(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st(int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(64) void chain_forward_general_kernel(const mm2::Anchor *__restrict__ anchors, const uint64_t *__restrict__ off, const float *__restrict__ avg,
+                                                                   const uint32_t *__restrict__ jobs, int32_t *__restrict__ f_out, int32_t *__restrict__ p_out,
+                                                                   int32_t *__restrict__ t_glob, ChainParams P)
+{
+    const uint32_t job = jobs[blockIdx.x];
+    const uint64_t base = off[job];
+    const int32_t n = (int32_t)(off[job + 1] - base);
+    const mm2::Anchor *a = anchors + base;
+    int32_t *F = f_out + base, *Pp = p_out + base, *T = t_glob + base;
+    const int lane = lane_id();
+    for (int32_t i = lane; i < n; i += 64) st(T + i, 0);
+    const double avg_qspan = (double)avg[job], gap_scale = (double)P.gap_scale;
+    int32_t stt = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        __syncthreads();                                   // f[i-1] / p[i-1] (and the marks of the first pass) are visible
+        const uint64_t ri = a[i].x, yi = a[i].y;
+        const int32_t qi = (int32_t)yi, q_span = (int32_t)(yi >> 32 & 0xff);
+        while (stt < i && ri > a[stt].x + (uint64_t)P.max_dist) ++stt;
+        if (i - stt > P.max_iter) stt = i - P.max_iter;
+        int32_t max_f = q_span, max_j = -1, n_skip = 0;
+        bool stop = false;
+        for (int32_t hi = i - 1; hi >= stt && !stop; hi -= 64) {
+            const int32_t j = hi - lane;
+            const bool in = j >= stt;
+            bool ok = false;
+            int32_t sc = kNegInf, pj = -1;
+            if (in) {
+                const uint64_t xj = a[j].x, yj = a[j].y;
+                const int64_t dr = (int64_t)(ri - xj);
+                const int32_t dq = qi - (int32_t)yj;
+                ok = dr != 0 && dq > 0 && dq <= P.max_dist;
+                const int32_t dd = (int32_t)(dr > dq ? dr - dq : dq - dr);
+                ok = ok && dd <= P.bw;
+                if (ok) {
+                    const int32_t min_d = dq < dr ? dq : (int32_t)dr;
+                    sc = min_d > q_span ? q_span : min_d;
+                    const int32_t log_dd = dd ? 31 - __builtin_clz((uint32_t)dd) : 0;
+                    const int32_t gap_cost = (int)((double)dd * .01 * avg_qspan) + (log_dd >> 1);
+                    sc -= (int)((double)gap_cost * gap_scale + .499);
+                    sc += ld(F + j);
+                    pj = ld(Pp + j);
+                    if (pj >= 0) st(T + pj, i);
+                }
+            }
+            __syncthreads();                               // this chunk's marks are visible
+            const bool marked = ok && ld(T + j) == i;
+            // exclusive prefix max of the scores in front of this lane, seeded with the running best
+            int32_t pm = sc;
+            for (int d = 1; d < 64; d <<= 1) { const int32_t y = __shfl_up(pm, d); if (lane >= d) pm = max(pm, y); }
+            pm = __shfl_up(pm, 1);
+            pm = lane ? max(pm, max_f) : max_f;
+            const bool rec = ok && sc > pm;
+            const bool skp = ok && !rec && marked;
+            // n_skip behind this lane: inclusive scan of the maps n -> max(n + ca, cb)
+            int32_t ca = rec ? -1 : (skp ? 1 : 0), cb = rec ? 0 : kNegInf;
+            for (int d = 1; d < 64; d <<= 1) {
+                const int32_t ya = __shfl_up(ca, d), yb = __shfl_up(cb, d);
+                if (lane >= d) { cb = max(yb + ca, cb); ca += ya; }
+            }
+            const int32_t n_after = max(n_skip + ca, cb);
+            const uint64_t brk = __ballot(skp && n_after > P.max_skip);
+            const int first_brk = brk ? __ffsll((unsigned long long)brk) - 1 : 64;
+            const uint64_t recs = __ballot(rec) & (first_brk >= 64 ? ~0ull : (1ull << first_brk) - 1);
+            if (recs) {
+                const int L = 63 - __clzll((long long)recs);
+                max_f = __shfl(sc, L);
+                max_j = hi - L;
+            }
+            n_skip = __shfl(n_after, 63);
+            stop = brk != 0;
+        }
+        if (lane == 0) {
+            st(F + i, max_f), st(Pp + i, max_j);
+        }
+    }
+}
+
+
+// ---- the LDS kernel ----
+constexpr uint32_t kFastAnchors = 7400;         // 21 B of LDS per anchor + the gap-cost table: < 160 KB
+constexpr int32_t kFastBw = 1023;               // the gap-cost table has bw + 1 entries
+constexpr size_t lds_bytes(uint32_t n, int32_t bw) { return (((size_t)n * 21 + 15) & ~(size_t)15) + ((size_t)bw + 1) * 4; }
+
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ int32_t dpp(int32_t ident, int32_t v)
+{
+    return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROW_MASK, 0xf, false);
+}
+constexpr int kWaveShr1 = 0x138;
+
+// inclusive prefix max over the wave (lane order): v_max_i32_dpp with destination = both sources -- a lane without a source
+// (row start, row outside the row mask; bound_ctrl off) is not written and keeps its value.  Inline assembly because the compiler
+// emits mov + dpp-mov + max for the builtin; the s_nop covers the VALU-write -> DPP-read hazard, which it does not see in here.
+#define NS_MAX_DPP(v, ctrl) asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 " ctrl " bank_mask:0xf" : "+v"(v))
+__device__ __forceinline__ int32_t scan_max(int32_t v)
+{
+    NS_MAX_DPP(v, "row_shr:1 row_mask:0xf");
+    NS_MAX_DPP(v, "row_shr:2 row_mask:0xf");
+    NS_MAX_DPP(v, "row_shr:4 row_mask:0xf");
+    NS_MAX_DPP(v, "row_shr:8 row_mask:0xf");
+    NS_MAX_DPP(v, "row_bcast:15 row_mask:0xa");
+    NS_MAX_DPP(v, "row_bcast:31 row_mask:0xc");
+    return v;
+}
+__device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ int32_t count_upto(uint64_t mask, bool self)      // set bits of `mask` in lanes <= this one (self = this lane's bit)
+{
+    return (int32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)) + (self ? 1 : 0);
+}
+
+// The running state of one anchor's walk over its predecessors, and one step of it over 64 predecessors (lane l: predecessor j, its
+// admissibility `ok`, score `sc`, and whether an earlier admissible predecessor points at it).  The skip counter is a +-1 walk
+// reflected at 0: after lane l it is D_l + max(n0, max over u <= l of -D_u) with D = (#marked non-best) - (#new best) up to the
+// lane (Lindley's recursion solved; for +1 steps the reflection never binds) -- the special case of the pair scan in the header
+// that needs one prefix max.
+struct Walk { int32_t max_f, max_j, n_skip; bool stop; };
+__device__ __forceinline__ void walk_chunk(Walk &w, int32_t hi, bool ok, int32_t sc, bool marked, int32_t max_skip)
+{
+    int32_t pm = scan_max(ok ? sc : kNegInf);
+    pm = dpp<kWaveShr1>(kNegInf, pm);              // exclusive
+    pm = max(pm, w.max_f);
+    const bool rec = ok && sc > pm;
+    const bool skp = ok && !rec && marked;
+    const uint64_t recs_all = __ballot(rec), skps = __ballot(skp);
+    const int32_t D = count_upto(skps, skp) - count_upto(recs_all, rec);
+    const int32_t n_after = D + max(w.n_skip, scan_max(-D));
+    const uint64_t brk = __ballot(skp && n_after > max_skip);
+    const int first_brk = brk ? __ffsll((unsigned long long)brk) - 1 : 64;
+    const uint64_t recs = recs_all & (first_brk >= 64 ? ~0ull : (1ull << first_brk) - 1);
+    if (recs) {
+        const int L = 63 - __clzll((long long)recs);
+        w.max_f = __builtin_amdgcn_readlane(sc, L);
+        w.max_j = hi - L;
+    }
+    w.n_skip = __builtin_amdgcn_readlane(n_after, 63);
+    w.stop = brk != 0;
+}
+
+__global__ __launch_bounds__(64) void chain_forward_lds_kernel(const mm2::Anchor *__restrict__ anchors, const uint64_t *__restrict__ off, const float *__restrict__ avg,
+                                                               const uint32_t *__restrict__ jobs, int32_t *__restrict__ f_out, int32_t *__restrict__ p_out, ChainParams P)
+{
+    extern __shared__ int32_t lds[];
+    const uint32_t job = jobs[blockIdx.x];
+    const uint64_t base = off[job];
+    const int32_t n = (int32_t)(off[job + 1] - base);
+    const mm2::Anchor *a = anchors + base;
+    int32_t *F = lds, *Pp = lds + n, *T = lds + 2 * n, *R = lds + 3 * n, *Q = lds + 4 * n;
+    uint8_t *S = reinterpret_cast<uint8_t *>(lds + 5 * n);
+    const int lane = lane_id();
+    // (the list may lie in pinned host memory: four loads in flight per lane)
+    for (int32_t i0 = 0; i0 < n; i0 += 256) {
+        uint64_t x[4], y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int32_t i = i0 + u * 64 + lane; if (i < n) x[u] = a[i].x, y[u] = a[i].y; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int32_t i = i0 + u * 64 + lane;
+            if (i < n) T[i] = 0, R[i] = (int32_t)x[u], Q[i] = (int32_t)y[u], S[i] = (uint8_t)(y[u] >> 32);      // (lists with x >= 2^31 go to the general kernel)
+        }
+    }
+    lds_order();
+    // what a gap of dd = |dr - dq| <= bw costs (chain.c:68-71): depends on dd and the list's mean span only -- tabulated once, so that
+    // no double-precision instruction is left in the per-anchor loop
+    int32_t *G = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(lds) + (((size_t)n * 21 + 15) & ~(size_t)15));
+    {
+        const double avg_qspan = (double)avg[job], gap_scale = (double)P.gap_scale;
+        for (int32_t dd = lane; dd <= P.bw; dd += 64) {
+            const int32_t log_dd = dd ? 31 - __builtin_clz((uint32_t)dd) : 0;
+            const int32_t gap_cost = (int)((double)dd * .01 * avg_qspan) + (log_dd >> 1);
+            G[dd] = (int)((double)gap_cost * gap_scale + .499);
+        }
+    }
+    lds_order();
+    // admissibility and gain of predecessor (rj, qj) for the anchor (ri, qi, q_span): chain.c:58-75 without f[j]
+    auto gain = [&](int32_t ri, int32_t qi, int32_t q_span, int32_t rj, int32_t qj, bool in, int32_t &sc) -> bool {
+        const int32_t dr = ri - rj, dq = qi - qj;
+        const int32_t dd = dr > dq ? dr - dq : dq - dr;
+        const bool ok = in && dr != 0 && dq > 0 && dq <= P.max_dist && dd <= P.bw;
+        sc = min(min(dq, dr), q_span) - G[ok ? dd : 0];
+        return ok;
+    };
+    // Lane l keeps anchor i-1-l -- position, f, p -- in registers: the 64 nearest predecessors of anchor i, which is where the walk
+    // of almost every anchor ends (max_skip = 25 marked predecessors), never come from LDS.  After anchor i the window slides by one
+    // lane (wave_shr:1) and lane 0 takes anchor i itself.  Only the marks go through LDS.
+    int32_t rj = 0, qj = 0, fj = 0, pj = -1;
+    int32_t ri = n ? R[0] : 0, qi = n ? Q[0] : 0, q_span = n ? S[0] : 0;
+    for (int32_t i = 0; i < n; ++i) {
+        // anchor i+1's own values arrive while anchor i is worked on
+        const int32_t i1 = i + 1 < n ? i + 1 : i;
+        const int32_t ri_n = R[i1], qi_n = Q[i1], sp_n = S[i1];
+        Walk w{q_span, -1, 0, false};
+        // the window: predecessors within max_dist on the reference (the list is sorted by it) and at most max_chain_iter back --
+        // what chain.c's `st` pointer amounts to, as a test each lane can make on its own
+        const int32_t j_min = i - P.max_iter > 0 ? i - P.max_iter : 0;
+        {
+            const int32_t j = i - 1 - lane;
+            const bool in = j >= j_min && ri - rj <= P.max_dist;          // (both below 2^31)
+            int32_t sc;
+            const bool ok = gain(ri, qi, q_span, rj, qj, in, sc);
+            sc += fj;
+            if (ok && pj >= 0) T[pj] = i;
+            lds_order();                                   // this chunk's marks are visible to the lanes behind
+            const bool marked = ok && T[j] == i;
+            const bool more = __builtin_amdgcn_readlane((int)in, 63) != 0;     // the window goes on behind lane 63
+            walk_chunk(w, i - 1, ok, sc, marked, P.max_skip);
+            if (!more) w.stop = true;
+        }
+        for (int32_t hi = i - 65; hi >= j_min && !w.stop; hi -= 64) {
+            const int32_t j = hi - lane;
+            const bool in0 = j >= j_min;
+            const int32_t rj2 = in0 ? R[j] : 0, qj2 = in0 ? Q[j] : 0, fj2 = in0 ? F[j] : 0, pj2 = in0 ? Pp[j] : -1;
+            const bool in = in0 && ri - rj2 <= P.max_dist;
+            int32_t sc;
+            const bool ok = gain(ri, qi, q_span, rj2, qj2, in, sc);
+            sc += fj2;
+            if (ok && pj2 >= 0) T[pj2] = i;
+            lds_order();
+            const bool marked = ok && T[j] == i;
+            const bool more = __builtin_amdgcn_readlane((int)in, 63) != 0;
+            walk_chunk(w, hi, ok, sc, marked, P.max_skip);
+            if (!more) w.stop = true;
+        }
+        if (lane == 0) F[i] = w.max_f, Pp[i] = w.max_j;
+        lds_order();
+        rj = dpp<kWaveShr1>(ri, rj), qj = dpp<kWaveShr1>(qi, qj), fj = dpp<kWaveShr1>(w.max_f, fj), pj = dpp<kWaveShr1>(w.max_j, pj);
+        ri = ri_n, qi = qi_n, q_span = sp_n;
+    }
+    for (int32_t i = lane; i < n; i += 64) f_out[base + i] = F[i], p_out[base + i] = Pp[i];
+}
+
+}  // namespace
+
+// f[i] / p[i] of mm_chain_dp's first loop for the anchor lists a[off[q] .. off[q+1]) (host pointers; avg[q] = mean query span):
+// gpu_chain_launch stages the lists and starts the kernel(s) on the workspace's stream, gpu_chain_wait waits for them.  The results
+// land in W.h_out: f at [0, total), p at [total, 2 total), valid until the workspace's next launch.
+int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vector<const mm2::Anchor *> &lists, const std::vector<uint64_t> &off,
+                     const std::vector<float> &avg)
+{
+    nsgpu_ctx::ChainWs &W = c->cws[ws];
+    const size_t nq = lists.size();
+    const uint64_t total = off[nq];
+    W.pend_total = total;
+    if (total == 0) return NSGPU_OK;
+    const double t0 = now_ms();
+    if (!W.stream) {
+        // the chaining pass is short and on a slot's critical path: in front of the DP launches that fill the chip
+        int prio_lo = 0, prio_hi = 0;
+        NS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        NS_HIP(hipStreamCreateWithPriority(&W.stream, hipStreamNonBlocking, prio_hi));
+    }
+    // pinned staging: anchors | offsets | mean spans | job lists (LDS kernel's first)
+    const size_t b_anch = total * sizeof(mm2::Anchor), b_off = (nq + 1) * sizeof(uint64_t), b_avg = (nq * sizeof(float) + 7) & ~(size_t)7, b_jobs = (nq * sizeof(uint32_t) + 7) & ~(size_t)7;
+    NS_TRY(W.h_in.reserve(b_anch + b_off + b_avg + b_jobs));
+    NS_TRY(W.h_out.reserve(total * 2 * sizeof(int32_t)));
+    uint8_t *h = W.h_in.as<uint8_t>();
+    mm2::Anchor *ha = reinterpret_cast<mm2::Anchor *>(h);
+    uint64_t *ho = reinterpret_cast<uint64_t *>(h + b_anch);
+    float *hv = reinterpret_cast<float *>(h + b_anch + b_off);
+    uint32_t *hj = reinterpret_cast<uint32_t *>(h + b_anch + b_off + b_avg);
+    memcpy(ho, off.data(), b_off);
+    memcpy(hv, avg.data(), nq * sizeof(float));
+    // which kernel takes which list; the longest lists first (a wave's time grows with its list: the tail of the launch should be
+    // the short ones)
+    uint32_t n_lds = 0, n_big = 0, max_lds = 0;
+    std::vector<uint8_t> &fast = W.h_fast;
+    fast.assign(nq, 0);
+    par_for(nq, [&](size_t q) {
+        const uint64_t n = off[q + 1] - off[q];
+        if (n == 0) return;
+        memcpy(ha + off[q], lists[q], (size_t)n * sizeof(mm2::Anchor));
+        uint64_t hi_bits = 0;
+        for (uint64_t i = 0; i < n; ++i) hi_bits |= lists[q][i].x;
+        fast[q] = n <= kFastAnchors && (hi_bits >> 31) == 0 && opt.bw >= 0 && opt.bw <= kFastBw;
+    });
+    for (size_t q = 0; q < nq; ++q) if (fast[q]) hj[n_lds++] = (uint32_t)q, max_lds = std::max<uint32_t>(max_lds, (uint32_t)(off[q + 1] - off[q]));
+    for (size_t q = 0; q < nq; ++q) if (!fast[q] && off[q + 1] > off[q]) hj[n_lds + n_big++] = (uint32_t)q;
+    std::sort(hj, hj + n_lds, [&](uint32_t x, uint32_t y) { const uint64_t nx = off[x + 1] - off[x], ny = off[y + 1] - off[y]; return nx != ny ? nx > ny : x < y; });
+    const double t1 = now_ms();
+    // The LDS kernel reads its lists straight from the pinned staging buffer and stores f / p straight into the pinned result buffer
+    // (each anchor crosses PCIe once each way, as a coalesced read / a fire-and-forget write): one launch and one wait, no copy
+    // operations whose scheduling behind the DP streams' traffic cost more than the kernel.  Only the general kernel, which reads
+    // anchors repeatedly, works on device copies.
+    const ChainParams P{opt.max_gap, opt.bw, opt.max_chain_skip, opt.max_chain_iter, opt.chain_gap_scale};
+    int32_t *hf = W.h_out.as<int32_t>(), *hp = hf + total;
+    if (n_lds) {
+        if (!W.lds_set) {
+            NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_forward_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(kFastAnchors, kFastBw)));
+            W.lds_set = lds_bytes(kFastAnchors, kFastBw);
+        }
+        hipLaunchKernelGGL(chain_forward_lds_kernel, dim3(n_lds), dim3(64), lds_bytes(max_lds, opt.bw), W.stream, ha, ho, hv, hj, hf, hp, P);
+    }
+    if (n_big) {
+        NS_TRY(W.d_in.reserve(b_anch + b_off + b_avg + b_jobs));
+        NS_TRY(W.d_out.reserve(total * 2 * sizeof(int32_t)));
+        NS_TRY(W.d_marks.reserve(total * sizeof(int32_t)));
+        uint8_t *d = W.d_in.as<uint8_t>();
+        NS_HIP(hipMemcpyAsync(d, h, b_anch + b_off + b_avg + b_jobs, hipMemcpyHostToDevice, W.stream));
+        int32_t *df = W.d_out.as<int32_t>(), *dp = df + total;
+        hipLaunchKernelGGL(chain_forward_general_kernel, dim3(n_big), dim3(64), 0, W.stream, reinterpret_cast<const mm2::Anchor *>(d), reinterpret_cast<const uint64_t *>(d + b_anch),
+                           reinterpret_cast<const float *>(d + b_anch + b_off), reinterpret_cast<const uint32_t *>(d + b_anch + b_off + b_avg) + n_lds, df, dp, W.d_marks.as<int32_t>(), P);
+        for (uint32_t k = 0; k < n_big; ++k) {
+            const uint32_t q = hj[n_lds + k];
+            const size_t o = (size_t)off[q], nb = (size_t)(off[q + 1] - off[q]) * sizeof(int32_t);
+            NS_HIP(hipMemcpyAsync(hf + o, df + o, nb, hipMemcpyDeviceToHost, W.stream));
+            NS_HIP(hipMemcpyAsync(hp + o, dp + o, nb, hipMemcpyDeviceToHost, W.stream));
+        }
+    }
+    NS_HIP(hipGetLastError());
+    W.ms_stage += t1 - t0, W.ms_enqueue += now_ms() - t1, ++W.calls;
+    return NSGPU_OK;
+}
+
+int gpu_chain_wait(nsgpu_ctx *c, int ws, const int32_t *&f, const int32_t *&p)
+{
+    nsgpu_ctx::ChainWs &W = c->cws[ws];
+    f = p = nullptr;
+    if (W.pend_total == 0) return NSGPU_OK;
+    const double t0 = now_ms();
+    NS_HIP(stream_wait_short(W.stream));
+    W.ms_wait += now_ms() - t0;
+    f = W.h_out.as<int32_t>(), p = f + W.pend_total;
+    return NSGPU_OK;
+}
+
+}  // namespace nsgpu

@@ -109,6 +109,8 @@ struct Timer {
 
 }  // namespace nsgpu
 
+namespace nsgpu { namespace mm2 { struct Anchor; } }
+
 struct nsgpu_ctx {
     nsgpu_params prm;
     hipStream_t stream = nullptr;
@@ -158,6 +160,17 @@ struct nsgpu_ctx {
         nsgpu::PinBuf h_meta;                                          // pinned landing zone of the small read-backs (push count, offsets)
         hipStream_t stream = nullptr;
     } sws[2];                                                       // two workspaces: the contig engine sketches the two halves of a batch concurrently
+    // chaining scores (chain.hip): anchors in, f / p out.  0: direct API calls; 1..: two per group of the contig engine (the halves of a batch are pipelined)
+    struct ChainWs {
+        nsgpu::DevBuf d_in, d_out, d_marks;
+        nsgpu::PinBuf h_in, h_out;
+        std::vector<uint8_t> h_fast;                                   // per list: the LDS kernel takes it
+        size_t lds_set = 0;
+        uint64_t pend_total = 0;                                       // anchors of the launch in flight
+        std::vector<const nsgpu::mm2::Anchor *> lists; std::vector<uint64_t> off; std::vector<float> avg;   // the launch's lists (host side)
+        double ms_stage = 0, ms_enqueue = 0, ms_wait = 0; uint64_t calls = 0;   // host wall of the calls: staging / enqueue / wait for the results
+        hipStream_t stream = nullptr;
+    } cws[9];
     nsgpu::PinBuf pin_small, pin_foff, pin_fids;                     // pinned landing zones: the filter's scalars / the engine's candidate CSR
     double sketch_mm_ms = 0;                                         // wall of the batched mm_sketch calls
     std::mutex stat_m;                                               // guards the ksw_* / aln_* counters below

@@ -536,29 +536,48 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group)
     });
     H[0].rc = gpu_mm_sketch(c, H[0].sk, (int)c->prm.m_w, (int)c->prm.m_k, H[0].mz, E->mz_off[0], 0);
     int rc = NSGPU_OK;
-    for (int hi = 0; hi < 2 && rc == NSGPU_OK; ++hi) {
-        Half &h = H[hi];
-        if (hi == 1) { if (t2.joinable()) t2.join(); }
-        if (h.lo == h.hi) continue;
-        if (h.rc != NSGPU_OK) { rc = h.rc; break; }
-        const std::vector<uint64_t> &mo = E->mz_off[hi];
-        par_for("index.build", h.hi - h.lo, [&](size_t i) {
-            Builder &b = D.B[who[h.lo + i]];
-            if (!b.idx_valid) {
-                const uint32_t si = h.sk_ref[i];
-                apply_splice(b, h.mz + mo[si], (size_t)(mo[si + 1] - mo[si]), (int)c->prm.m_w, (int)c->prm.m_k);
-                b.idx.build_from_sketch(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f, b.mz.data(), b.mz.size());
-                b.idx_valid = true;
-            }
-        });
+    if (t2.joinable()) t2.join();
+    for (const Half &h : H) if (h.lo < h.hi && h.rc != NSGPU_OK && rc == NSGPU_OK) rc = h.rc;
+    // Index builds, seeds, the chaining kernel, then the first step.  NSGPU_CHAIN_PIPELINE=1 does it in two halves -- the second
+    // half's index builds and seeds while the GPU chains the first -- which was measured SLOWER (cfg2: sketch+index wall +130 ms
+    // per step, whole path -2 %): two half-size loops on the pool balance worse than one, and a chaining launch lasts as long as
+    // its longest list whatever the number of lists.
+    static const bool pipe = getenv("NSGPU_CHAIN_PIPELINE") != nullptr;
+    const size_t mid = n >= 64 && pipe ? n / 2 : n;
+    const size_t r_lo[2] = {0, mid}, r_hi[2] = {mid, n};
+    for (int r = 0; r < 2 && rc == NSGPU_OK; ++r) {
+        const size_t lo = r_lo[r], hi = r_hi[r];
+        if (lo == hi) continue;
+        // (w -> the half of the sketch batch it was sketched in)
+        auto half_of = [&](size_t w) -> const Half & { return w < cut ? H[0] : H[1]; };
         // the query minimizers stay in the pinned buffer of the half's sketch workspace until the alignments have been seeded
-        for (size_t w = h.lo; w < h.hi; ++w) {
+        for (size_t w = lo; w < hi; ++w) {
+            const Half &h = half_of(w);
+            const std::vector<uint64_t> &mo = E->mz_off[&h - H];
             Builder &b = D.B[who[w]];
             const size_t qi = h.q_base + (w - h.lo);
             AB.reqs[w] = AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), h.mz + mo[qi], (size_t)(mo[qi + 1] - mo[qi])};
         }
-        rc = align_prestep(c, AB, h.lo, h.hi);
+        rc = align_prestep_start(c, AB, lo, hi);
+        if (rc != NSGPU_OK) break;
+        // one loop over the builders for the index of the changed consensus and the seeds of the candidate against it
+        par_for("index.build", hi - lo, [&](size_t i) {
+            const size_t w = lo + i;
+            const Half &h = half_of(w);
+            const std::vector<uint64_t> &mo = E->mz_off[&h - H];
+            Builder &b = D.B[who[w]];
+            if (!b.idx_valid) {
+                const uint32_t si = h.sk_ref[w - h.lo];
+                apply_splice(b, h.mz + mo[si], (size_t)(mo[si + 1] - mo[si]), (int)c->prm.m_w, (int)c->prm.m_k);
+                b.idx.build_from_sketch(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f, b.mz.data(), b.mz.size());
+                b.idx_valid = true;
+            }
+            AB.jobs[w].seed();
+        });
+        rc = align_prestep_launch(c, AB, lo, hi, 1 + 2 * gi + r, true);
     }
+    for (int r = 0; r < 2 && rc == NSGPU_OK; ++r)
+        if (r_lo[r] < r_hi[r]) rc = align_prestep_finish(c, AB, r_lo[r], r_hi[r], 1 + 2 * gi + r);
     if (t2.joinable()) t2.join();
     NS_TRY(rc);
     E->awho[gi] = who;
@@ -808,6 +827,12 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
     if (getenv("NSGPU_CONS_DEBUG")) {
         fprintf(stderr, "[cons] batches wall-ms: window queries %.0f, sketch+index %.0f (gpu sketch %.0f), align begin %.0f (host loops %.0f, DP launch %.0f)\n", c->cons_stats.filter_ms,
                 c->cons_stats.index_ms, c->sketch_mm_ms, E->p1_align_ms, E->p1_host_ms, E->p1_launch_ms);
+        double chain_ms = 0;
+        for (AlignBatch &ab : E->ab) chain_ms += ab.chain_ms, ab.chain_ms = 0;
+        double cs = 0, ce = 0, cw = 0; uint64_t cn = 0;
+        for (nsgpu_ctx::ChainWs &w : c->cws) cs += w.ms_stage, ce += w.ms_enqueue, cw += w.ms_wait, cn += w.calls, w.ms_stage = w.ms_enqueue = w.ms_wait = 0, w.calls = 0;
+        fprintf(stderr, "[cons] chaining scores on the GPU (inside sketch+index): %.0f ms wall in %llu calls: staging %.0f, enqueue %.0f, wait (copies + kernel) %.0f\n", chain_ms,
+                (unsigned long long)cn, cs, ce, cw);
         fprintf(stderr, "[cons] slots set by: host phase %llu (%.0f ms), batches part 1 %llu (%.0f ms), part 2 %llu (%.0f ms)\n", (unsigned long long)E->slot_long_n[0],
                 E->slot_long_ms[0], (unsigned long long)E->slot_long_n[1], E->slot_long_ms[1], (unsigned long long)E->slot_long_n[2], E->slot_long_ms[2]);
     }

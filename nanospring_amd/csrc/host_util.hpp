@@ -61,12 +61,21 @@ struct AlignBatch {
     int ws_index = 0;
     bool in_flight = false;
     bool prestepped = false;             // align_prestep has started every job and run its first step (seeds, chains, DP plan)
-    double host_ms = 0, dp_ms = 0;
+    double host_ms = 0, dp_ms = 0, chain_ms = 0;
     uint64_t dp_tasks = 0, rounds = 0;
 };
 // first host step (seeds / chains / regions / DP plan) of the requests [lo, hi) of B.reqs, ahead of align_begin: lets the caller
 // overlap it with the GPU sketch of the batch's other requests.  All requests must have been pre-stepped before align_begin.
-int align_prestep(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi);
+int align_prestep(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws);
+// the same in two parts: seeds + launch of the chaining kernel / wait + first step -- the caller pipelines ranges (different chain_ws)
+// (align_prestep_start + the caller's own loop calling B.jobs[i].seed() + launch(..., true): seeds inside another per-builder loop)
+int align_prestep_start(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi);
+int align_prestep_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws, bool started_and_seeded = false);
+int align_prestep_finish(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws);
+// chain.hip: mm_chain_dp's forward pass for a batch of anchor lists (host pointers in, pinned host results out)
+int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vector<const mm2::Anchor *> &lists, const std::vector<uint64_t> &off,
+                     const std::vector<float> &avg);
+int gpu_chain_wait(nsgpu_ctx *c, int ws, const int32_t *&f, const int32_t *&p);
 int align_begin(nsgpu_ctx *c, AlignBatch &B, int ws_index);
 int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs);
 int filter_strings_device(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq);   // api.hip: results stay in c->f_off / c->f_ids

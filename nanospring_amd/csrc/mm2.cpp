@@ -71,7 +71,9 @@ inline uint32_t wang_hash32(uint32_t key)
     return key;
 }
 
+#ifdef NSGPU_HOST_CHAIN
 inline int ilog2_32(uint32_t v) { return 31 - __builtin_clz(v); }   // chain.c:8-20 (v > 0)
+#endif
 
 inline int span_of(const Anchor &p) { return (int)(p.y >> 32 & 0xff); }
 
@@ -353,19 +355,25 @@ static void collect_seeds(const RefIndex &ri, const Anchor *mv, size_t n_mv, std
 }
 
 // ---------------------------------------------------------------------------
-// a14e  chaining DP (chain.c:22-164) for one segment, genomic mode
+// a14e  chaining (chain.c:22-164) for one segment, genomic mode.  The forward pass -- score f[i] and predecessor p[i] of every
+// anchor, the O(n * window) part -- runs on the GPU (chain.hip, one wave per query); chain_forward_host below is the same
+// recurrence as a plain loop and exists only in builds with NSGPU_HOST_CHAIN (the CPU test harness uses it to check the kernel's
+// inputs and outputs against the live reference without a GPU).  chain_finish is the sequential remainder: peak scores, chain
+// ends, backtracking, the order of the chains.
 // ---------------------------------------------------------------------------
-static void chain_dp(const Opt &o, std::vector<Anchor> &a, std::vector<uint64_t> &u)
+float chain_avg_qspan(const std::vector<Anchor> &a)
+{
+    uint64_t sum_qspan = 0;
+    for (const Anchor &x : a) sum_qspan += x.y >> 32 & 0xff;
+    return a.empty() ? 0.f : (float)sum_qspan / (int64_t)a.size();
+}
+
+#ifdef NSGPU_HOST_CHAIN
+void chain_forward_host(const Opt &o, const std::vector<Anchor> &a, float avg_qspan, int32_t *f, int32_t *p)
 {
     const int64_t n = (int64_t)a.size();
     const int max_dist_x = o.max_gap, max_dist_y = o.max_gap, bw = o.bw, max_skip = o.max_chain_skip, max_iter = o.max_chain_iter;
-    const int min_cnt = o.min_cnt, min_sc = o.min_chain_score;
-    u.clear();
-    if (n == 0) return;
-    std::vector<int32_t> f(n), p(n), t(n, 0), v(n);
-    uint64_t sum_qspan = 0;
-    for (int64_t i = 0; i < n; ++i) sum_qspan += a[i].y >> 32 & 0xff;
-    const float avg_qspan = (float)sum_qspan / n;
+    std::vector<int32_t> t(n, 0);
     int64_t st = 0;
     for (int64_t i = 0; i < n; ++i) {
         const uint64_t ri = a[i].x;
@@ -396,10 +404,19 @@ static void chain_dp(const Opt &o, std::vector<Anchor> &a, std::vector<uint64_t>
             if (p[j] >= 0) t[p[j]] = (int32_t)i;
         }
         f[i] = max_f, p[i] = (int32_t)max_j;
-        v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
     }
+}
+#endif
+
+static void chain_finish(const Opt &o, std::vector<Anchor> &a, const int32_t *f, const int32_t *p, std::vector<uint64_t> &u)
+{
+    const int64_t n = (int64_t)a.size();
+    const int min_cnt = o.min_cnt, min_sc = o.min_chain_score;
+    u.clear();
+    if (n == 0) return;
+    std::vector<int32_t> t(n, 0), v(n);
+    for (int64_t i = 0; i < n; ++i) v[i] = p[i] >= 0 && v[p[i]] > f[i] ? v[p[i]] : f[i];
     // chain ends
-    std::fill(t.begin(), t.end(), 0);
     for (int64_t i = 0; i < n; ++i) if (p[i] >= 0) t[p[i]] = 1;
     std::vector<uint64_t> ends;
     for (int64_t i = 0; i < n; ++i)
@@ -1088,7 +1105,8 @@ void fix_bad_ends(const Reg &r, const Anchor *a, int bw, int min_match, int32_t 
 void AlignJob::start(const RefIndex *r, const char *q, int ql, const Opt &o)
 {
     ref = r, qstr = q, qlen = ql, opt = o;
-    finished = false, seeded = false, cur = 0;
+    finished = false, seeded = false, chained = false, cur = 0;
+    cf = cp = nullptr, avg_qspan = 0.f;
     pre_mz = nullptr, n_pre_mz = 0;
     regs.clear(); a.clear(); cache.clear();
 }
@@ -1279,25 +1297,45 @@ static bool align1(AlignJob &J, Reg &r_io, Reg &r2, bool plan_only = false)
 std::atomic<uint64_t> g_step_ns[6];
 static inline uint64_t prof_now() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// query codes, seeds (map.c:232-236 / collect_seed_hits) and what the chaining pass needs besides the anchors
+void AlignJob::seed()
+{
+    if (seeded) return;
+    seeded = true;
+    qseq.resize(qlen);
+    nt4_codes(qstr, (size_t)qlen, qseq.data());
+    if (pre_mz) collect_seeds(*ref, pre_mz, n_pre_mz, a);       // sketched by the caller (mm_sketch.hip)
+    else {
+        std::vector<Anchor> mv;
+        if (qlen > 0) mm_sketch(qstr, qlen, ref->w, ref->k, 0, mv);
+        collect_seeds(*ref, mv.data(), mv.size(), a);
+    }
+    avg_qspan = chain_avg_qspan(a);
+}
+
 bool AlignJob::step()
 {
     if (finished) return true;
     cache.missing.clear();
     uint64_t t0 = prof_now();
     auto lap = [&](int k) { const uint64_t t1 = prof_now(); g_step_ns[k].fetch_add(t1 - t0, std::memory_order_relaxed); t0 = t1; };
-    if (!seeded) {
-        seeded = true;
-        qseq.resize(qlen);
-        nt4_codes(qstr, (size_t)qlen, qseq.data());
-        if (pre_mz) collect_seeds(*ref, pre_mz, n_pre_mz, a);       // sketched by the caller (mm_sketch.hip)
-        else {
-            std::vector<Anchor> mv;
-            if (qlen > 0) mm_sketch(qstr, qlen, ref->w, ref->k, 0, mv);
-            collect_seeds(*ref, mv.data(), mv.size(), a);
-        }
+    if (!seeded) seed();
+    if (!chained) {
+        chained = true;
         lap(0);
+        if (!a.empty() && !(cf && cp)) {
+#ifdef NSGPU_HOST_CHAIN
+            own_f.resize(a.size()), own_p.resize(a.size());
+            chain_forward_host(opt, a, avg_qspan, own_f.data(), own_p.data());
+            cf = own_f.data(), cp = own_p.data();
+#else
+            fprintf(stderr, "nsgpu: AlignJob::step without the chaining scores of the GPU pass (chain.hip) -- there is no host path in this build\n");
+            abort();
+#endif
+        }
         std::vector<uint64_t> u;
-        chain_dp(opt, a, u);
+        chain_finish(opt, a, cf, cp, u);
+        cf = cp = nullptr;
         lap(1);
         // map.c:290-292: query name is NULL
         uint32_t hash = 0;

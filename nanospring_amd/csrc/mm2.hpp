@@ -126,6 +126,12 @@ struct DpCache {
     void swap(DpCache &o) { keys.swap(o.keys); vals.swap(o.vals); pool.swap(o.pool); missing.swap(o.missing); std::swap(cursor, o.cursor); }
 };
 
+float chain_avg_qspan(const std::vector<Anchor> &a);
+#ifdef NSGPU_HOST_CHAIN
+// the chaining recurrence as a plain loop: compiled into the CPU test harness only, the product runs chain.hip
+void chain_forward_host(const Opt &o, const std::vector<Anchor> &a, float avg_qspan, int32_t *f, int32_t *p);
+#endif
+
 // The alignment of one (reference, query) pair as a resumable job.
 struct AlignJob {
     const RefIndex *ref = nullptr;
@@ -140,11 +146,15 @@ struct AlignJob {
     std::vector<Anchor> a;
     int32_t n_a = 0;
     int cur = 0;                       // region being aligned in the skeleton loop
-    bool seeded = false;
+    bool seeded = false, chained = false;
+    float avg_qspan = 0.f;             // mean query span of the anchors (chain.c:36-37), an input of the chaining scores
+    const int32_t *cf = nullptr, *cp = nullptr;   // chaining score / predecessor of every anchor from the GPU pass (chain.hip); consumed by step()
+    std::vector<int32_t> own_f, own_p; // (NSGPU_HOST_CHAIN builds only)
     const Anchor *pre_mz = nullptr;    // the query's minimizers, when the caller sketched it (set after start())
     size_t n_pre_mz = 0;
     DpCache cache;
     void start(const RefIndex *r, const char *q, int ql, const Opt &o);
+    void seed();                       // query codes + anchors (a), sorted as the chaining expects them
     bool step();                       // true when finished; otherwise cache.missing is non-empty
     void swap_storage(AlignJob &o) { regs.swap(o.regs); qseq.swap(o.qseq); a.swap(o.a); cache.swap(o.cache); }
 };

@@ -103,6 +103,28 @@ int64_t harness_index(const char *s, int len, int w, int k, const uint64_t *xy, 
     return nk;
 }
 
+// the anchors mm_map_frag hands to mm_chain_dp for one (reference, query) pair (sorted), and the chaining recurrence over a
+// list of anchors as the plain loop (chain_forward_host): the checker of chain.hip
+int64_t harness_seeds(const char *ref, int rl, const char *qry, int ql, int k, int w, uint64_t *xy, int64_t cap)
+{
+    RefIndex ri;
+    ri.build(ref, (uint32_t)rl, w, k, 2e-4f);
+    Opt o;
+    o.k = k, o.w = w;
+    AlignJob J;
+    J.start(&ri, qry, ql, o);
+    J.seed();
+    for (int64_t i = 0; i < (int64_t)J.a.size() && i < cap; ++i) xy[2 * i] = J.a[i].x, xy[2 * i + 1] = J.a[i].y;
+    return (int64_t)J.a.size();
+}
+void harness_chain_forward(const uint64_t *xy, int64_t n, int max_chain_iter, int32_t *f, int32_t *p)
+{
+    Opt o;
+    o.max_chain_iter = max_chain_iter;
+    std::vector<Anchor> a((const Anchor *)xy, (const Anchor *)xy + n);
+    chain_forward_host(o, a, chain_avg_qspan(a), f, p);
+}
+
 void harness_radix_sort_128x(uint64_t *xy, int64_t n) { radix_sort_128x((Anchor *)xy, (Anchor *)xy + n); }
 void harness_radix_sort_64(uint64_t *x, int64_t n) { radix_sort_64(x, x + n); }
 

@@ -28,7 +28,7 @@ def build():
         obj = os.path.join(os.path.dirname(OUT), os.path.basename(c) + ".o")
         subprocess.run(["gcc", "-O2", "-fPIC", "-fopenmp", "-c", c, "-o", obj], check=True)
         objs.append(obj)
-    subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fopenmp", "-Wall"] + SRCS + objs + ["-o", OUT], check=True)
+    subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fopenmp", "-Wall", "-DNSGPU_HOST_CHAIN"] + SRCS + objs + ["-o", OUT], check=True)
     return OUT
 
 
@@ -58,6 +58,31 @@ def align(ref, qry, k=20, w=50, max_chain_iter=400):
     d["cigar"] = cig[:max(out.n_cigar, 0)].copy()
     d["edits"] = ed[:n].copy()
     return d
+
+
+def seeds(ref, qry, k=20, w=50):
+    """The sorted anchor list (x, y) that the chaining sees for one pair."""
+    L = lib()
+    L.harness_seeds.restype = C.c_int64
+    rb, qb = ref.encode(), qry.encode()
+    cap = 4 * (len(qb) + 64)
+    while True:
+        xy = np.zeros(2 * cap, dtype=np.uint64)
+        n = L.harness_seeds(rb, len(rb), qb, len(qb), k, w, _p(xy), C.c_int64(cap))
+        if n <= cap:
+            return xy[:2 * n].reshape(n, 2).copy()
+        cap = n
+
+
+def chain_forward(xy, max_chain_iter=400):
+    """chain.c's f[] / p[] for one sorted anchor list, by the plain loop."""
+    L = lib()
+    xy = np.ascontiguousarray(xy, dtype=np.uint64)
+    n = len(xy)
+    f = np.zeros(max(n, 1), dtype=np.int32)
+    p = np.zeros(max(n, 1), dtype=np.int32)
+    L.harness_chain_forward(_p(xy), C.c_int64(n), max_chain_iter, _p(f), _p(p))
+    return f[:n], p[:n]
 
 
 def sketch(s, w, k):
