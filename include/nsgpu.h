@@ -174,6 +174,21 @@ int nsgpu_mm_sketch_batch(nsgpu_ctx *ctx, const char *seqs, const uint64_t *seq_
  *      engine run the same kernel; this entry exists so that it can be checked on its own. ---- */
 int nsgpu_chain_scores(nsgpu_ctx *ctx, const uint64_t *xy, const uint64_t *off, uint32_t n, int32_t *f_out, int32_t *p_out);
 
+/* ---- a14a/b/d: what mm_idx_str + mm_idx_cal_max_occ (minimap2/index.c:164-248, 365-402) and collect_seed_hits
+ *      (minimap2/map.c:215-247, with MM_F_FOR_ONLY: map.c:139-145) leave for the chaining, for a batch of pairs:
+ *      reference list r / query list i are mm128_t pairs as nsgpu_mm_sketch_batch returns them, pair i is
+ *      (pair_ref[i], query i).  (*xy_out)[2*j], [2*j+1] for j in (*off_out)[i] .. (*off_out)[i+1] are pair i's
+ *      anchors sorted by reference position (x = ref pos, y = span<<32 | query pos, bit 42 = tandem), mid_occ_out[i]
+ *      the occurrence cut-off of its reference (mid_occ_frac 2e-4), avg_out[i] the mean query span of its anchors.
+ *      flags_out[i] != 0: the kernel did not decide the pair (bit 0: two anchors on one reference position, whose
+ *      order is the reference radix sort's; bit 1: more anchors than the LDS sort takes; bit 2: output capacity;
+ *      bit 3: occurrence count above the histogram; bit 4: reference coordinate above 2^32) and returns no anchors
+ *      for it -- nsgpu_align_batch and the contig engine redo such pairs with the literal host code.
+ *      The arrays behind xy_out / off_out are malloc'ed; release with nsgpu_free. ---- */
+int nsgpu_seed_anchors(nsgpu_ctx *ctx, const uint64_t *ref_xy, const uint64_t *ref_off, uint32_t n_refs, const uint64_t *qry_xy,
+                       const uint64_t *qry_off, const uint32_t *pair_ref, uint32_t n_pairs, uint64_t **xy_out, uint64_t **off_out,
+                       int32_t *mid_occ_out, uint32_t *flags_out, float *avg_out);
+
 /* ---- a13: batched ConsensusGraph::alignRead (include/ConsensusGraph.h:245-247,
  *      src/ConsensusGraph.cpp:161-398): align query i (qrys[qry_off[i]..qry_off[i+1])) to reference
  *      pair_ref[i] (refs[ref_off[r]..ref_off[r+1])) with minimap2's defaults + MM_F_CIGAR|MM_F_FOR_ONLY,

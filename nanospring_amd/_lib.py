@@ -56,6 +56,7 @@ SIGNATURES = {
     "nsgpu_load_fastq": (C.c_int, [_vp, _vp, C.c_size_t, _u32p]),
     "nsgpu_mm_sketch_batch": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_vp), C.POINTER(_vp)]),
     "nsgpu_chain_scores": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp]),
+    "nsgpu_seed_anchors": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, C.c_uint32, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _vp]),
     "nsgpu_align_batch": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, C.c_uint32, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "nsgpu_get_align_stats": (C.c_int, [_vp, _vp]),
     "nsgpu_reset_align_stats": (C.c_int, [_vp]),

@@ -449,38 +449,111 @@ static void batch_start_jobs(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi)
     }
 }
 
-// seeds on the host threads and the launch of the chaining kernel (chain.hip) / its results and every job's first step (chains,
-// regions, DP plan)
-static int batch_seed_and_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws, bool seeded = false)
+// the host code's seeds for the jobs `which` of the batch (lookup table of the references concerned, each once -- pairs may share
+// one --, then collect_seeds) and a chaining launch for their lists on chaining workspace cw
+static int host_seed_and_chain_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, const std::vector<uint32_t> &which, int cw)
 {
-    const size_t n = hi - lo;
-    if (!seeded) parallel_for("align.seed", n, [&](size_t i) { B.jobs[lo + i].seed(); });
-    nsgpu_ctx::ChainWs &W = c->cws[chain_ws];
-    W.lists.resize(n), W.off.resize(n + 1), W.avg.resize(n);
-    W.off[0] = 0;
-    for (size_t i = 0; i < n; ++i) {
-        const mm2::AlignJob &J = B.jobs[lo + i];
-        W.lists[i] = J.a.data(), W.off[i + 1] = W.off[i] + J.a.size(), W.avg[i] = J.avg_qspan;
+    using namespace mm2;
+    const Opt opt = batch_opt(c);
+    nsgpu_ctx::ChainWs &W = c->cws[cw];
+    W.lists.clear(), W.off.assign(1, 0), W.avg.clear();
+    if (!which.empty()) {
+        for (uint32_t i : which) {
+            const AlignReq &r = B.reqs[lo + i];
+            if (r.idx->has_table) continue;
+            if (r.ref_mz) r.idx->build_from_sketch(r.ref, (uint32_t)r.ref_len, opt.w, opt.k, opt.mid_occ_frac, r.ref_mz, r.n_ref_mz);
+            else r.idx->build(r.ref, (uint32_t)r.ref_len, opt.w, opt.k, opt.mid_occ_frac);
+        }
+        parallel_for("align.seed", which.size(), [&](size_t k) { B.jobs[lo + which[k]].seed(); });
+        for (uint32_t i : which) {
+            const AlignJob &J = B.jobs[lo + i];
+            W.lists.push_back(J.a.data()), W.off.push_back(W.off.back() + J.a.size()), W.avg.push_back(J.avg_qspan);
+        }
     }
-    return gpu_chain_launch(c, chain_ws, batch_opt(c), W.lists, W.off, W.avg);
+    return gpu_chain_launch(c, cw, opt, W.lists, W.off, W.avg);
 }
-static int batch_wait_and_step(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws)
+
+// Index + seeds on the GPU (seeds.hip), the chaining kernel on their lists (chain.hip) / the results and every job's first step
+// (chains, regions, DP plan).  Pairs the seeding kernel hands back (anchors sharing a reference position, oversize lists) and
+// requests without pinned minimizer lists are seeded by the host code and chained by a second launch.
+static int batch_seed_and_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int ws, bool prepared = false)
 {
+    using namespace mm2;
     const size_t n = hi - lo;
-    const int32_t *f = nullptr, *p = nullptr;
+    const Opt opt = batch_opt(c);
+    if (!prepared) parallel_for("align.seed", n, [&](size_t i) { B.jobs[lo + i].seed_prepare(); });
+    nsgpu_ctx::SeedWs &S = c->seed_ws[ws];
+    std::vector<SeedPair> &pairs = B.seed_pairs;
+    pairs.clear();
+    S.pair_of.assign(n, ~0u);
+    S.fb.clear();
+    for (size_t i = 0; i < n; ++i) {
+        const AlignReq &r = B.reqs[lo + i];
+        if (r.qry_mz && r.ref_mz && r.n_ref_mz < (1ull << 30) && r.n_qry_mz < (1ull << 31)) {
+            S.pair_of[i] = (uint32_t)pairs.size();
+            SeedPair p{};
+            p.ref = r.ref_mz, p.qry = r.qry_mz, p.n_ref = (uint32_t)r.n_ref_mz, p.n_qry = (uint32_t)r.n_qry_mz;
+            pairs.push_back(p);
+        } else S.fb.push_back((uint32_t)i);
+    }
+    // seeds and, right behind them on the same stream, the chaining of their lists; the host looks at the results once
+    NS_TRY(gpu_seeds_chain_launch(c, ws, 2 * ws, opt, pairs));
+    S.calls += 1, S.pairs += pairs.size();
+    // requests without pinned minimizer lists: the host code now, pairs the kernels hand back: in batch_wait_and_step
+    nsgpu_ctx::ChainWs &W = c->cws[2 * ws + 1];
+    W.lists.clear(), W.off.assign(1, 0), W.avg.clear();
+    NS_TRY(host_seed_and_chain_launch(c, B, lo, S.fb, 2 * ws + 1));
+    return NSGPU_OK;
+}
+static int batch_wait_and_step(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int ws)
+{
+    using namespace mm2;
+    const size_t n = hi - lo;
+    nsgpu_ctx::SeedWs &S = c->seed_ws[ws];
+    const SeedResult *res = nullptr;
+    const Anchor *a = nullptr;
+    const int32_t *f = nullptr, *p = nullptr, *f2 = nullptr, *p2 = nullptr;
     const double g0 = now_ms();
-    NS_TRY(gpu_chain_wait(c, chain_ws, f, p));
+    NS_TRY(gpu_seeds_chain_wait(c, ws, 2 * ws, res, a, f, p));
+    S.ms_wait += now_ms() - g0;
+    NS_TRY(gpu_chain_wait(c, 2 * ws + 1, f2, p2));
+    const std::vector<uint64_t> &off2 = c->cws[2 * ws + 1].off;
+    // (host-seeded jobs keep their own copy of the scores: the workspace's buffer may be used once more below)
+    auto take = [&](const std::vector<uint32_t> &which) {
+        for (size_t k = 0; k < which.size() && f2; ++k) {
+            AlignJob &J = B.jobs[lo + which[k]];
+            J.own_f.assign(f2 + off2[k], f2 + off2[k + 1]), J.own_p.assign(p2 + off2[k], p2 + off2[k + 1]);
+            J.cf = J.own_f.data(), J.cp = J.own_p.data();
+        }
+    };
+    take(S.fb);
+    // pairs handed back by the kernels: host seeds + one more chaining launch (rare: anchors sharing a reference position, oversize lists)
+    std::vector<uint32_t> &late = S.late;
+    late.clear();
+    for (size_t i = 0; i < n; ++i) if (S.pair_of[i] != ~0u && res[S.pair_of[i]].flags) late.push_back((uint32_t)i);
+    if (!late.empty()) {
+        S.fallbacks += late.size();
+        NS_TRY(host_seed_and_chain_launch(c, B, lo, late, 2 * ws + 1));
+        NS_TRY(gpu_chain_wait(c, 2 * ws + 1, f2, p2));
+        take(late);
+    }
     B.chain_ms += now_ms() - g0;
-    const std::vector<uint64_t> &off = c->cws[chain_ws].off;
-    if (f) for (size_t i = 0; i < n; ++i) B.jobs[lo + i].cf = f + off[i], B.jobs[lo + i].cp = p + off[i];
-    parallel_for("align.step", n, [&](size_t i) { B.jobs[lo + i].step(); });
+    parallel_for("align.step", n, [&](size_t i) {
+        AlignJob &J = B.jobs[lo + i];
+        const uint32_t q = S.pair_of[i];
+        if (q != ~0u && !res[q].flags) {
+            J.set_anchors(a ? a + res[q].base : nullptr, res[q].n, res[q].avg);
+            if (res[q].n) J.cf = f + res[q].base, J.cp = p + res[q].base;
+        }
+        J.step();
+    });
     return NSGPU_OK;
 }
 
 static int prestep_check(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws)
 {
     NS_CHECK(lo <= hi && hi <= B.reqs.size(), NSGPU_ERR_ARG, "align_prestep: bad range");
-    NS_CHECK(chain_ws >= 0 && chain_ws < (int)(sizeof(c->cws) / sizeof(c->cws[0])), NSGPU_ERR_ARG, "align_prestep: bad chain workspace");
+    NS_CHECK(chain_ws >= 0 && chain_ws < (int)(sizeof(c->seed_ws) / sizeof(c->seed_ws[0])), NSGPU_ERR_ARG, "align_prestep: bad workspace");
     // (B.jobs must not be resized here: another range of the same batch may be in its step on other threads -- the caller sizes it)
     NS_CHECK(B.jobs.size() >= B.reqs.size(), NSGPU_ERR_ARG, "align_prestep: size B.jobs first");
     return NSGPU_OK;
@@ -626,14 +699,14 @@ int align_batch(nsgpu_ctx *c, const char *refs, const uint64_t *roff, uint32_t n
     NS_TRY(gpu_mm_sketch(c, sk, (int)c->prm.m_w, (int)c->prm.m_k, mz, mz_off));
     std::vector<RefIndex> idx(n_refs);
     parallel_for("index.build", n_refs, [&](size_t i) {
-        idx[i].build_from_sketch(refs + roff[i], (uint32_t)(roff[i + 1] - roff[i]), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f, mz + mz_off[i], (size_t)(mz_off[i + 1] - mz_off[i]));
+        idx[i].set_sequence(refs + roff[i], (uint32_t)(roff[i + 1] - roff[i]), (int)c->prm.m_w, (int)c->prm.m_k);     // the lookup table is the GPU's (seeds.hip)
     });
     c->aln_index_ms += now_ms() - t0;
     std::vector<AlignReq> reqs(n_pairs);
     for (uint32_t i = 0; i < n_pairs; ++i) {
         const uint32_t rf = pair_ref[i];
         reqs[i] = AlignReq{&idx[rf], refs + roff[rf], (size_t)(roff[rf + 1] - roff[rf]), qrys + qoff[i], (size_t)(qoff[i + 1] - qoff[i]),
-                           mz + mz_off[n_refs + i], (size_t)(mz_off[n_refs + i + 1] - mz_off[n_refs + i])};
+                           mz + mz_off[n_refs + i], (size_t)(mz_off[n_refs + i + 1] - mz_off[n_refs + i]), mz + mz_off[rf], (size_t)(mz_off[rf + 1] - mz_off[rf])};
     }
     return align_requests(c, reqs, outs);
 }

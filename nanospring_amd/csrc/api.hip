@@ -190,6 +190,11 @@ void nsgpu_destroy(nsgpu_ctx *c)
         w.d_in.release(); w.d_out.release(); w.d_marks.release(); w.h_in.release(); w.h_out.release();
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }
+    for (nsgpu_ctx::SeedWs &w : c->seed_ws) {
+        w.d_tab.release(); w.d_next.release(); w.d_ys.release(); w.d_tmp.release(); w.d_out.release(); w.d_counter.release();
+        w.h_pairs.release(); w.h_res.release(); w.h_ref.release();
+        if (w.stream) (void)hipStreamDestroy(w.stream);
+    }
     c->pin_small.release(); c->pin_foff.release(); c->pin_fids.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;

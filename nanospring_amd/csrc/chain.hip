@@ -197,14 +197,26 @@ __device__ __forceinline__ void walk_chunk(Walk &w, int32_t hi, bool ok, int32_t
     w.stop = brk != 0;
 }
 
-__global__ __launch_bounds__(64) void chain_forward_lds_kernel(const mm2::Anchor *__restrict__ anchors, const uint64_t *__restrict__ off, const float *__restrict__ avg,
-                                                               const uint32_t *__restrict__ jobs, int32_t *__restrict__ f_out, int32_t *__restrict__ p_out, ChainParams P)
+// list q: anchors[L.beg .. + L.n) in, f / p (and, with a_out, a copy of the anchors: lists that were seeded on the GPU reach the host
+// this way) out at [L.obeg .. + L.n)
+// With `seeded` (lists == jobs == nullptr) block b takes the list that seeds.hip left for pair b -- launched right behind the
+// seeding kernel on its stream, no host round trip in between -- skips pairs that kernel flagged, and flags the ones that do not
+// fit this launch's LDS (lds_anchors) itself.
+__global__ __launch_bounds__(64) void chain_forward_lds_kernel(const mm2::Anchor *__restrict__ anchors, const ChainList *__restrict__ lists,
+                                                               const uint32_t *__restrict__ jobs, int32_t *__restrict__ f_out, int32_t *__restrict__ p_out,
+                                                               mm2::Anchor *__restrict__ a_out, SeedResult *seeded, uint32_t lds_anchors, ChainParams P)
 {
     extern __shared__ int32_t lds[];
-    const uint32_t job = jobs[blockIdx.x];
-    const uint64_t base = off[job];
-    const int32_t n = (int32_t)(off[job + 1] - base);
-    const mm2::Anchor *a = anchors + base;
+    ChainList L;
+    if (seeded) {
+        const SeedResult r = seeded[blockIdx.x];
+        if (r.flags || r.n == 0) return;
+        if (r.n > lds_anchors) { if (threadIdx.x == 0) seeded[blockIdx.x].flags = SEED_FLAG_MANY; return; }
+        L = ChainList{r.base, r.base, r.n, r.avg};
+    } else L = lists[jobs[blockIdx.x]];
+    const uint64_t base = L.obeg;
+    const int32_t n = (int32_t)L.n;
+    const mm2::Anchor *a = anchors + L.beg;
     int32_t *F = lds, *Pp = lds + n, *T = lds + 2 * n, *R = lds + 3 * n, *Q = lds + 4 * n;
     uint8_t *S = reinterpret_cast<uint8_t *>(lds + 5 * n);
     const int lane = lane_id();
@@ -216,7 +228,10 @@ __global__ __launch_bounds__(64) void chain_forward_lds_kernel(const mm2::Anchor
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int32_t i = i0 + u * 64 + lane;
-            if (i < n) T[i] = 0, R[i] = (int32_t)x[u], Q[i] = (int32_t)y[u], S[i] = (uint8_t)(y[u] >> 32);      // (lists with x >= 2^31 go to the general kernel)
+            if (i < n) {
+                T[i] = 0, R[i] = (int32_t)x[u], Q[i] = (int32_t)y[u], S[i] = (uint8_t)(y[u] >> 32);      // (lists with x >= 2^31 go to the general kernel)
+                if (a_out) a_out[base + i] = mm2::Anchor{x[u], y[u]};
+            }
         }
     }
     lds_order();
@@ -224,7 +239,7 @@ __global__ __launch_bounds__(64) void chain_forward_lds_kernel(const mm2::Anchor
     // no double-precision instruction is left in the per-anchor loop
     int32_t *G = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(lds) + (((size_t)n * 21 + 15) & ~(size_t)15));
     {
-        const double avg_qspan = (double)avg[job], gap_scale = (double)P.gap_scale;
+        const double avg_qspan = (double)L.avg, gap_scale = (double)P.gap_scale;
         for (int32_t dd = lane; dd <= P.bw; dd += 64) {
             const int32_t log_dd = dd ? 31 - __builtin_clz((uint32_t)dd) : 0;
             const int32_t gap_cost = (int)((double)dd * .01 * avg_qspan) + (log_dd >> 1);
@@ -309,17 +324,19 @@ int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vecto
         NS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         NS_HIP(hipStreamCreateWithPriority(&W.stream, hipStreamNonBlocking, prio_hi));
     }
-    // pinned staging: anchors | offsets | mean spans | job lists (LDS kernel's first)
+    // pinned staging: anchors | offsets | mean spans | job lists (LDS kernel's first) | list descriptors of the LDS kernel
     const size_t b_anch = total * sizeof(mm2::Anchor), b_off = (nq + 1) * sizeof(uint64_t), b_avg = (nq * sizeof(float) + 7) & ~(size_t)7, b_jobs = (nq * sizeof(uint32_t) + 7) & ~(size_t)7;
-    NS_TRY(W.h_in.reserve(b_anch + b_off + b_avg + b_jobs));
+    NS_TRY(W.h_in.reserve(b_anch + b_off + b_avg + b_jobs + nq * sizeof(ChainList)));
     NS_TRY(W.h_out.reserve(total * 2 * sizeof(int32_t)));
     uint8_t *h = W.h_in.as<uint8_t>();
     mm2::Anchor *ha = reinterpret_cast<mm2::Anchor *>(h);
     uint64_t *ho = reinterpret_cast<uint64_t *>(h + b_anch);
     float *hv = reinterpret_cast<float *>(h + b_anch + b_off);
     uint32_t *hj = reinterpret_cast<uint32_t *>(h + b_anch + b_off + b_avg);
+    ChainList *hl = reinterpret_cast<ChainList *>(h + b_anch + b_off + b_avg + b_jobs);
     memcpy(ho, off.data(), b_off);
     memcpy(hv, avg.data(), nq * sizeof(float));
+    for (size_t q = 0; q < nq; ++q) hl[q] = ChainList{off[q], off[q], (uint32_t)(off[q + 1] - off[q]), avg[q]};
     // which kernel takes which list; the longest lists first (a wave's time grows with its list: the tail of the launch should be
     // the short ones)
     uint32_t n_lds = 0, n_big = 0, max_lds = 0;
@@ -348,7 +365,7 @@ int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vecto
             NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_forward_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(kFastAnchors, kFastBw)));
             W.lds_set = lds_bytes(kFastAnchors, kFastBw);
         }
-        hipLaunchKernelGGL(chain_forward_lds_kernel, dim3(n_lds), dim3(64), lds_bytes(max_lds, opt.bw), W.stream, ha, ho, hv, hj, hf, hp, P);
+        hipLaunchKernelGGL(chain_forward_lds_kernel, dim3(n_lds), dim3(64), lds_bytes(max_lds, opt.bw), W.stream, ha, hl, hj, hf, hp, (mm2::Anchor *)nullptr, (SeedResult *)nullptr, 0u, P);
     }
     if (n_big) {
         NS_TRY(W.d_in.reserve(b_anch + b_off + b_avg + b_jobs));
@@ -369,6 +386,44 @@ int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vecto
     NS_HIP(hipGetLastError());
     W.ms_stage += t1 - t0, W.ms_enqueue += now_ms() - t1, ++W.calls;
     return NSGPU_OK;
+}
+
+// The same for the lists seeds.hip has just been asked for, on the seeding workspace's stream right behind its kernel: res / d_anchors
+// are that launch's (device-visible) results, capacity its anchor capacity, max_n_qry the longest query minimizer list (the LDS of
+// the launch is sized for about twice as many anchors; a list beyond that is flagged and goes the host code's way).  The kernel
+// also copies the anchors out: after the stream has been waited for, anchors / f / p of pair q are at a + res[q].base etc. (pinned).
+int gpu_chain_launch_seeded(nsgpu_ctx *c, int ws, hipStream_t stream, const mm2::Opt &opt, const mm2::Anchor *d_anchors, SeedResult *res, size_t n_pairs,
+                            uint64_t capacity, uint32_t max_n_qry)
+{
+    nsgpu_ctx::ChainWs &W = c->cws[ws];
+    NS_CHECK(opt.bw >= 0 && opt.bw <= kFastBw, NSGPU_ERR_ARG, "chaining of GPU-seeded lists: bw above %d", kFastBw);
+    W.pend_total = n_pairs ? capacity : 0;
+    if (n_pairs == 0) return NSGPU_OK;
+    const double t0 = now_ms();
+    NS_TRY(W.h_out.reserve(capacity * (sizeof(mm2::Anchor) + 2 * sizeof(int32_t))));
+    const ChainParams P{opt.max_gap, opt.bw, opt.max_chain_skip, opt.max_chain_iter, opt.chain_gap_scale};
+    mm2::Anchor *ha = W.h_out.as<mm2::Anchor>();
+    int32_t *hf = reinterpret_cast<int32_t *>(ha + capacity), *hp = hf + capacity;
+    if (!W.lds_set) {
+        NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_forward_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(kFastAnchors, kFastBw)));
+        W.lds_set = lds_bytes(kFastAnchors, kFastBw);
+    }
+    const uint32_t lds_anchors = (uint32_t)std::min<uint64_t>(kFastAnchors, 2 * (uint64_t)max_n_qry + 256);
+    hipLaunchKernelGGL(chain_forward_lds_kernel, dim3((unsigned)n_pairs), dim3(64), lds_bytes(lds_anchors, opt.bw), stream, d_anchors, (const ChainList *)nullptr,
+                       (const uint32_t *)nullptr, hf, hp, ha, res, lds_anchors, P);
+    NS_HIP(hipGetLastError());
+    W.ms_enqueue += now_ms() - t0, ++W.calls;
+    return NSGPU_OK;
+}
+
+// (after the stream of the launch above has been waited for)
+void gpu_chain_results_seeded(nsgpu_ctx *c, int ws, const mm2::Anchor *&a, const int32_t *&f, const int32_t *&p)
+{
+    nsgpu_ctx::ChainWs &W = c->cws[ws];
+    a = nullptr, f = p = nullptr;
+    if (W.pend_total == 0) return;
+    a = W.h_out.as<mm2::Anchor>();
+    f = reinterpret_cast<const int32_t *>(a + W.pend_total), p = f + W.pend_total;
 }
 
 int gpu_chain_wait(nsgpu_ctx *c, int ws, const int32_t *&f, const int32_t *&p)

@@ -170,7 +170,17 @@ struct nsgpu_ctx {
         std::vector<const nsgpu::mm2::Anchor *> lists; std::vector<uint64_t> off; std::vector<float> avg;   // the launch's lists (host side)
         double ms_stage = 0, ms_enqueue = 0, ms_wait = 0; uint64_t calls = 0;   // host wall of the calls: staging / enqueue / wait for the results
         hipStream_t stream = nullptr;
-    } cws[9];
+    } cws[18];                                                      // per batch workspace w: 2w the lists seeded on the GPU, 2w + 1 the ones seeded by the host code
+    // index + seeds (seeds.hip): scratch tables, anchors (device), pair descriptors and results (pinned)
+    struct SeedWs {
+        nsgpu::DevBuf d_tab, d_next, d_ys, d_tmp, d_out, d_counter;
+        nsgpu::PinBuf h_pairs, h_res, h_ref;                          // h_ref: staging of reference minimizer lists that live in pageable memory
+        size_t pend = 0; uint64_t capacity = 0, cap_hint = 0;
+        std::vector<uint32_t> pair_of, fb, late;                       // job -> pair (~0u: host-seeded), the host-seeded jobs, the jobs the kernels handed back
+        const void *res = nullptr;                                    // results of the launch in flight (SeedResult[])
+        double ms_wait = 0; uint64_t calls = 0, pairs = 0, fallbacks = 0;
+        hipStream_t stream = nullptr;
+    } seed_ws[9];
     nsgpu::PinBuf pin_small, pin_foff, pin_fids;                     // pinned landing zones: the filter's scalars / the engine's candidate CSR
     double sketch_mm_ms = 0;                                         // wall of the batched mm_sketch calls
     std::mutex stat_m;                                               // guards the ksw_* / aln_* counters below

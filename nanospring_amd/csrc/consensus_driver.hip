@@ -306,6 +306,7 @@ struct Engine {
     std::vector<SketchReq> sk;
     std::vector<uint32_t> sk_ref;
     std::vector<uint64_t> mz_off[2];                // minimizer offsets of the two halves of a sketch batch
+    std::vector<uint64_t> stage_off;                // offsets of the builders' consensus minimizer lists in the seeding kernel's staging buffer
     AlignBatch ab[kMaxGroups];                        // alignment batch of each group, DP kernels in flight between part 1 and part 2
     std::vector<uint32_t> fwho;                    // builders of the window-query batch
     std::vector<uint32_t> awho[kMaxGroups];           // builders of that batch
@@ -550,17 +551,35 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group)
         if (lo == hi) continue;
         // (w -> the half of the sketch batch it was sketched in)
         auto half_of = [&](size_t w) -> const Half & { return w < cut ? H[0] : H[1]; };
+        // The consensus minimizers of every builder go to the seeding kernel through one pinned staging buffer: room for each list
+        // is set aside from an upper bound of its length after the splice (old list + newly sketched stretch).
+        const int sws_i = 1 + 2 * gi + r;
+        std::vector<uint64_t> &so = E->stage_off;
+        so.assign(hi - lo + 1, 0);
+        for (size_t w = lo; w < hi; ++w) {
+            const Half &h = half_of(w);
+            const std::vector<uint64_t> &mo = E->mz_off[&h - H];
+            const Builder &b = D.B[who[w]];
+            uint64_t bound = b.mz.size();
+            if (!b.idx_valid) { const uint32_t si = h.sk_ref[w - h.lo]; bound += mo[si + 1] - mo[si]; }
+            so[w - lo + 1] = so[w - lo] + bound;
+        }
+        rc = c->seed_ws[sws_i].h_ref.reserve(so[hi - lo] * sizeof(mm2::Anchor) + 16);
+        if (rc != NSGPU_OK) break;
+        mm2::Anchor *stage = c->seed_ws[sws_i].h_ref.as<mm2::Anchor>();
         // the query minimizers stay in the pinned buffer of the half's sketch workspace until the alignments have been seeded
         for (size_t w = lo; w < hi; ++w) {
             const Half &h = half_of(w);
             const std::vector<uint64_t> &mo = E->mz_off[&h - H];
             Builder &b = D.B[who[w]];
             const size_t qi = h.q_base + (w - h.lo);
-            AB.reqs[w] = AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), h.mz + mo[qi], (size_t)(mo[qi + 1] - mo[qi])};
+            AB.reqs[w] = AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), h.mz + mo[qi], (size_t)(mo[qi + 1] - mo[qi]),
+                                  stage + so[w - lo], 0};
         }
         rc = align_prestep_start(c, AB, lo, hi);
         if (rc != NSGPU_OK) break;
-        // one loop over the builders for the index of the changed consensus and the seeds of the candidate against it
+        // one loop over the builders: the minimizers of the changed consensus (splice), its base codes, the list into the staging
+        // buffer, the candidate's base codes.  The index proper -- lookup table, occurrence cut-off -- and the seeds are the GPU's.
         par_for("index.build", hi - lo, [&](size_t i) {
             const size_t w = lo + i;
             const Half &h = half_of(w);
@@ -569,10 +588,13 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group)
             if (!b.idx_valid) {
                 const uint32_t si = h.sk_ref[w - h.lo];
                 apply_splice(b, h.mz + mo[si], (size_t)(mo[si + 1] - mo[si]), (int)c->prm.m_w, (int)c->prm.m_k);
-                b.idx.build_from_sketch(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, 2e-4f, b.mz.data(), b.mz.size());
+                b.idx.set_sequence(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k);
                 b.idx_valid = true;
             }
-            AB.jobs[w].seed();
+            if (b.mz.size() > so[i + 1] - so[i]) { fprintf(stderr, "nsgpu: spliced minimizer list longer than its bound (internal error)\n"); abort(); }
+            if (!b.mz.empty()) memcpy(stage + so[i], b.mz.data(), b.mz.size() * sizeof(mm2::Anchor));
+            AB.reqs[w].n_ref_mz = b.mz.size();
+            AB.jobs[w].seed_prepare();
         });
         rc = align_prestep_launch(c, AB, lo, hi, 1 + 2 * gi + r, true);
     }
@@ -829,6 +851,10 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
                 c->cons_stats.index_ms, c->sketch_mm_ms, E->p1_align_ms, E->p1_host_ms, E->p1_launch_ms);
         double chain_ms = 0;
         for (AlignBatch &ab : E->ab) chain_ms += ab.chain_ms, ab.chain_ms = 0;
+        double sw = 0; uint64_t sn = 0, sp = 0, sf = 0;
+        for (nsgpu_ctx::SeedWs &w : c->seed_ws) sw += w.ms_wait, sn += w.calls, sp += w.pairs, sf += w.fallbacks, w.ms_wait = 0, w.calls = w.pairs = w.fallbacks = 0;
+        fprintf(stderr, "[cons] index + seeds on the GPU: %llu launches, %llu pairs, wait %.0f ms wall; %llu pairs handed back to the host code\n", (unsigned long long)sn,
+                (unsigned long long)sp, sw, (unsigned long long)sf);
         double cs = 0, ce = 0, cw = 0; uint64_t cn = 0;
         for (nsgpu_ctx::ChainWs &w : c->cws) cs += w.ms_stage, ce += w.ms_enqueue, cw += w.ms_wait, cn += w.calls, w.ms_stage = w.ms_enqueue = w.ms_wait = 0, w.calls = 0;
         fprintf(stderr, "[cons] chaining scores on the GPU (inside sketch+index): %.0f ms wall in %llu calls: staging %.0f, enqueue %.0f, wait (copies + kernel) %.0f\n", chain_ms,

@@ -33,11 +33,14 @@ template <class F> inline void par_for_pinned(const char *tag, size_t n, F fn) {
 void pool_drain();
 
 struct AlignReq {
-    const mm2::RefIndex *idx;     // index of `ref` (owned by the caller, reusable across batches)
+    mm2::RefIndex *idx;           // index of `ref` (owned by the caller, reusable across batches): at least set_sequence(); the lookup
+                                  // table is built on demand for the pairs the GPU seeding hands back (from ref_mz)
     const char *ref; size_t ref_len;
     const char *qry; size_t qry_len;
-    const mm2::Anchor *qry_mz = nullptr;   // the query's minimizers when the caller already has them (gpu_mm_sketch)
+    const mm2::Anchor *qry_mz = nullptr;   // the query's minimizers when the caller already has them (gpu_mm_sketch): PINNED memory
     size_t n_qry_mz = 0;
+    const mm2::Anchor *ref_mz = nullptr;   // the reference's minimizers, PINNED memory as well; both given = seeds on the GPU (seeds.hip)
+    size_t n_ref_mz = 0;
 };
 struct SketchReq { const char *ptr; size_t len; };
 // (w,k)-minimizers of a batch of sequences, computed on the GPU (mm_sketch.hip).  Sequence i's minimizers are
@@ -48,6 +51,17 @@ struct SketchReq { const char *ptr; size_t len; };
 int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws = 0);
 int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::AlnOut> &outs, int ws_index = 0);
 // the same in two parts, the DP kernels in flight between them (state of one batch)
+// seeds.hip: index + seeds of a batch of (reference minimizers, query minimizers) pairs on the GPU
+struct SeedPair {
+    const mm2::Anchor *ref; const mm2::Anchor *qry;      // device-readable (pinned host or device memory), mm_sketch order
+    uint32_t n_ref, n_qry;
+    uint32_t tab_bits; uint32_t pad_ = 0;                 // filled by gpu_seeds_launch: the pair's slice of the scratch buffers
+    uint64_t tab_off, next_off;
+};
+struct SeedResult { unsigned long long base; uint32_t n; uint32_t flags; int32_t mid_occ; float avg; };
+constexpr uint32_t SEED_FLAG_TIES = 1, SEED_FLAG_MANY = 2, SEED_FLAG_CAPACITY = 4, SEED_FLAG_OCC = 8, SEED_FLAG_WIDE = 16;
+struct ChainList { uint64_t beg, obeg; uint32_t n; float avg; };
+
 struct AlignBatch {
     std::vector<AlignReq> reqs;
     std::vector<mm2::AlignJob> jobs;
@@ -62,6 +76,7 @@ struct AlignBatch {
     bool in_flight = false;
     bool prestepped = false;             // align_prestep has started every job and run its first step (seeds, chains, DP plan)
     double host_ms = 0, dp_ms = 0, chain_ms = 0;
+    std::vector<SeedPair> seed_pairs;      // scratch of the seeding launch (seeds.hip)
     uint64_t dp_tasks = 0, rounds = 0;
 };
 // first host step (seeds / chains / regions / DP plan) of the requests [lo, hi) of B.reqs, ahead of align_begin: lets the caller
@@ -76,6 +91,12 @@ int align_prestep_finish(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int 
 int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vector<const mm2::Anchor *> &lists, const std::vector<uint64_t> &off,
                      const std::vector<float> &avg);
 int gpu_chain_wait(nsgpu_ctx *c, int ws, const int32_t *&f, const int32_t *&p);
+
+int gpu_seeds_launch(nsgpu_ctx *c, int ws, float mid_occ_frac, std::vector<SeedPair> &pairs);
+int gpu_seeds_wait(nsgpu_ctx *c, int ws, const SeedResult *&res, const mm2::Anchor *&d_anchors);
+// seeds + the chaining kernel behind them on one stream (chain_ws: the chaining workspace whose pinned buffer takes anchors / f / p)
+int gpu_seeds_chain_launch(nsgpu_ctx *c, int ws, int chain_ws, const mm2::Opt &opt, std::vector<SeedPair> &pairs);
+int gpu_seeds_chain_wait(nsgpu_ctx *c, int ws, int chain_ws, const SeedResult *&res, const mm2::Anchor *&a, const int32_t *&f, const int32_t *&p);
 int align_begin(nsgpu_ctx *c, AlignBatch &B, int ws_index);
 int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs);
 int filter_strings_device(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq);   // api.hip: results stay in c->f_off / c->f_ids

@@ -240,11 +240,18 @@ void RefIndex::build(const char *s, uint32_t n, int w_, int k_, float mid_occ_fr
     build_from_sketch(s, n, w_, k_, mid_occ_frac, mz.data(), mz.size());
 }
 
-void RefIndex::build_from_sketch(const char *s, uint32_t n, int w_, int k_, float mid_occ_frac, const Anchor *mz_p, size_t mz_n)
+void RefIndex::set_sequence(const char *s, uint32_t n, int w_, int k_)
 {
     k = k_, w = w_ < 1 ? 1 : w_, len = n;
     seq.resize(n);
     nt4_codes(s, n, seq.data());
+    has_table = false;
+}
+
+void RefIndex::build_from_sketch(const char *s, uint32_t n, int w_, int k_, float mid_occ_frac, const Anchor *mz_p, size_t mz_n)
+{
+    set_sequence(s, n, w_, k_);
+    has_table = true;
     struct Span { const Anchor *p; size_t n; size_t size() const { return n; } const Anchor &operator[](size_t i) const { return p[i]; } } mz{mz_p, mz_n};
     // the bucketed hash tables of the reference (index.c:191-248) only define "hash -> positions
     // ascending"; a (hash, position) sort gives the same mapping
@@ -1105,7 +1112,7 @@ void fix_bad_ends(const Reg &r, const Anchor *a, int bw, int min_match, int32_t 
 void AlignJob::start(const RefIndex *r, const char *q, int ql, const Opt &o)
 {
     ref = r, qstr = q, qlen = ql, opt = o;
-    finished = false, seeded = false, chained = false, cur = 0;
+    finished = false, seeded = false, prepared = false, chained = false, cur = 0;
     cf = cp = nullptr, avg_qspan = 0.f;
     pre_mz = nullptr, n_pre_mz = 0;
     regs.clear(); a.clear(); cache.clear();
@@ -1298,12 +1305,28 @@ std::atomic<uint64_t> g_step_ns[6];
 static inline uint64_t prof_now() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // query codes, seeds (map.c:232-236 / collect_seed_hits) and what the chaining pass needs besides the anchors
+void AlignJob::seed_prepare()
+{
+    if (prepared) return;
+    prepared = true;
+    qseq.resize(qlen);
+    nt4_codes(qstr, (size_t)qlen, qseq.data());
+}
+
+void AlignJob::set_anchors(const Anchor *p, size_t n, float avg)
+{
+    seed_prepare();
+    seeded = true;
+    a.assign(p, p + n);
+    avg_qspan = avg;
+}
+
 void AlignJob::seed()
 {
     if (seeded) return;
+    seed_prepare();
     seeded = true;
-    qseq.resize(qlen);
-    nt4_codes(qstr, (size_t)qlen, qseq.data());
+    if (!ref->has_table) { fprintf(stderr, "nsgpu: AlignJob::seed on an index without its lookup table (internal error)\n"); abort(); }
     if (pre_mz) collect_seeds(*ref, pre_mz, n_pre_mz, a);       // sketched by the caller (mm_sketch.hip)
     else {
         std::vector<Anchor> mv;

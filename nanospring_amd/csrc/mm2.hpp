@@ -68,6 +68,8 @@ struct RefIndex {
     uint32_t slot_shift = 64;
     std::vector<uint64_t> sort_keys_, sort_tmp_;  // scratch of build_from_sketch
     int32_t mid_occ = 0;
+    bool has_table = false;            // keys / pos / slot / mid_occ are built (the batch driver seeds on the GPU and needs only seq)
+    void set_sequence(const char *s, uint32_t n, int w_, int k_);     // k, w, len and the nt4 codes only
     void build(const char *s, uint32_t n, int w_, int k_, float mid_occ_frac);
     // same, with the sequence's minimizers (mm_sketch order, rid 0) supplied by the caller
     void build_from_sketch(const char *s, uint32_t n, int w_, int k_, float mid_occ_frac, const Anchor *mz, size_t n_mz);
@@ -146,15 +148,17 @@ struct AlignJob {
     std::vector<Anchor> a;
     int32_t n_a = 0;
     int cur = 0;                       // region being aligned in the skeleton loop
-    bool seeded = false, chained = false;
+    bool seeded = false, prepared = false, chained = false;
     float avg_qspan = 0.f;             // mean query span of the anchors (chain.c:36-37), an input of the chaining scores
     const int32_t *cf = nullptr, *cp = nullptr;   // chaining score / predecessor of every anchor from the GPU pass (chain.hip); consumed by step()
-    std::vector<int32_t> own_f, own_p; // (NSGPU_HOST_CHAIN builds only)
+    std::vector<int32_t> own_f, own_p; // a job's own copy of the scores (host-seeded jobs of a batch; NSGPU_HOST_CHAIN builds)
     const Anchor *pre_mz = nullptr;    // the query's minimizers, when the caller sketched it (set after start())
     size_t n_pre_mz = 0;
     DpCache cache;
     void start(const RefIndex *r, const char *q, int ql, const Opt &o);
-    void seed();                       // query codes + anchors (a), sorted as the chaining expects them
+    void seed_prepare();               // the query's nt4 codes
+    void seed();                       // + anchors (a) from the host index, sorted as the chaining expects them
+    void set_anchors(const Anchor *p, size_t n, float avg);          // ... or the anchors as seeds.hip computed them
     bool step();                       // true when finished; otherwise cache.missing is non-empty
     void swap_storage(AlignJob &o) { regs.swap(o.regs); qseq.swap(o.qseq); a.swap(o.a); cache.swap(o.cache); }
 };

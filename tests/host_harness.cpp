@@ -105,6 +105,19 @@ int64_t harness_index(const char *s, int len, int w, int k, const uint64_t *xy, 
 
 // the anchors mm_map_frag hands to mm_chain_dp for one (reference, query) pair (sorted), and the chaining recurrence over a
 // list of anchors as the plain loop (chain_forward_host): the checker of chain.hip
+int64_t harness_seeds2(const char *ref, int rl, const char *qry, int ql, int k, int w, uint64_t *xy, int64_t cap, int32_t *mid_occ, float *avg)
+{
+    RefIndex ri;
+    ri.build(ref, (uint32_t)rl, w, k, 2e-4f);
+    Opt o;
+    o.k = k, o.w = w;
+    AlignJob J;
+    J.start(&ri, qry, ql, o);
+    J.seed();
+    *mid_occ = ri.mid_occ, *avg = J.avg_qspan;
+    for (int64_t i = 0; i < (int64_t)J.a.size() && i < cap; ++i) xy[2 * i] = J.a[i].x, xy[2 * i + 1] = J.a[i].y;
+    return (int64_t)J.a.size();
+}
 int64_t harness_seeds(const char *ref, int rl, const char *qry, int ql, int k, int w, uint64_t *xy, int64_t cap)
 {
     RefIndex ri;

@@ -74,6 +74,21 @@ def seeds(ref, qry, k=20, w=50):
         cap = n
 
 
+def seeds_full(ref, qry, k=20, w=50):
+    """(anchors, mid_occ of the reference's index, mean query span) as the host code computes them for one pair."""
+    L = lib()
+    L.harness_seeds2.restype = C.c_int64
+    rb, qb = ref.encode(), qry.encode()
+    cap = 4 * (len(qb) + 64)
+    mid, avg = C.c_int32(), C.c_float()
+    while True:
+        xy = np.zeros(2 * cap, dtype=np.uint64)
+        n = L.harness_seeds2(rb, len(rb), qb, len(qb), k, w, _p(xy), C.c_int64(cap), C.byref(mid), C.byref(avg))
+        if n <= cap:
+            return xy[:2 * n].reshape(n, 2).copy(), mid.value, avg.value
+        cap = n
+
+
 def chain_forward(xy, max_chain_iter=400):
     """chain.c's f[] / p[] for one sorted anchor list, by the plain loop."""
     L = lib()
