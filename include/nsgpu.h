@@ -216,6 +216,8 @@ typedef struct {
     double dp_alg_bytes;      /* sum over DP problems of qlen + tlen + 4 * n_cigar + sizeof(result) */
     uint64_t dp_launches;     /* ksw_extd2 kernel launches (one per LDS size class per DP round) */
     uint32_t host_threads, reserved;
+    uint64_t seed_pairs_gpu;  /* pairs whose index + seeds + chaining scores came from the GPU kernels (seeds.hip, chain.hip) */
+    uint64_t seed_pairs_host; /* pairs the seeding kernel handed back to the host code (anchors sharing a reference position, oversize lists) */
 } nsgpu_align_stats;
 int nsgpu_get_align_stats(const nsgpu_ctx *ctx, nsgpu_align_stats *s);
 int nsgpu_reset_align_stats(nsgpu_ctx *ctx);

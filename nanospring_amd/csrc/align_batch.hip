@@ -538,6 +538,7 @@ static int batch_wait_and_step(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi
         take(late);
     }
     B.chain_ms += now_ms() - g0;
+    { std::lock_guard<std::mutex> lk(c->stat_m); c->aln_seed_host += S.fb.size() + late.size(), c->aln_seed_gpu += n - S.fb.size() - late.size(); }
     parallel_for("align.step", n, [&](size_t i) {
         AlignJob &J = B.jobs[lo + i];
         const uint32_t q = S.pair_of[i];
@@ -799,13 +800,14 @@ extern "C" int nsgpu_get_align_stats(const nsgpu_ctx *c, nsgpu_align_stats *s)
     s->dp_alg_bytes = c->ksw_alg_bytes;
     s->dp_launches = c->ksw_launches;
     s->host_threads = host_threads();
+    s->seed_pairs_gpu = c->aln_seed_gpu, s->seed_pairs_host = c->aln_seed_host;
     return NSGPU_OK;
 }
 
 extern "C" int nsgpu_reset_align_stats(nsgpu_ctx *c)
 {
     NS_CHECK(c, NSGPU_ERR_ARG, "null argument");
-    c->aln_pairs = c->aln_dp_tasks = c->aln_rounds = 0;
+    c->aln_pairs = c->aln_dp_tasks = c->aln_rounds = c->aln_seed_gpu = c->aln_seed_host = 0;
     c->aln_index_ms = c->aln_host_ms = c->aln_dp_ms = 0;
     c->ksw_kernel_ms = c->ksw_cells = c->ksw_alg_bytes = c->ksw_kernel_sum_ms = 0;
     c->ksw_launches = 0;

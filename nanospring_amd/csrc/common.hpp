@@ -188,7 +188,7 @@ struct nsgpu_ctx {
     double ksw_kernel_sum_ms = 0;                                    // sum of the individual kernel durations (what rocprof reports)
     uint64_t ksw_launches = 0;
     // align batches
-    uint64_t aln_pairs = 0, aln_dp_tasks = 0, aln_rounds = 0;
+    uint64_t aln_pairs = 0, aln_dp_tasks = 0, aln_rounds = 0, aln_seed_gpu = 0, aln_seed_host = 0;
     double aln_index_ms = 0, aln_host_ms = 0, aln_dp_ms = 0;
     // host copy of the reads as ReadData::getRead returns them (A/T/C/G after the 2-bit folding)
     std::vector<char> h_bases;

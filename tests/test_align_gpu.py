@@ -68,6 +68,9 @@ def test_random_pairs_equal_live_reference(gpu):
     assert n_ok > 150 and multi > 10
     st = ns.align_stats(gpu)
     assert st["dp_tasks"] > 1000 and st["dp_rounds"] <= 12
+    # both seeding paths ran: the kernels' (seeds.hip + chain.hip) for most pairs, the host code for the pairs the kernel hands
+    # back (tandem duplications: two anchors on one reference position)
+    assert st["seed_pairs_gpu"] > 200 and st["seed_pairs_host"] > 0 and st["seed_pairs_gpu"] + st["seed_pairs_host"] >= len(ps), st
 
 
 def test_many_queries_share_one_reference_at_scale(gpu):
