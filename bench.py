@@ -34,6 +34,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before anything initialises HIP (see nanospring_amd/__init__.py)
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

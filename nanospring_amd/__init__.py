@@ -6,6 +6,12 @@ This package is the thin host-side mirror used by the tests and bench.py; it has
 no CPU fallback: importing works anywhere, but every operator raises
 NsGpuError when the library or a gfx950 device is missing.
 """
+import os as _os
+
+# the HIP runtime's stream -> hardware-queue multiplexing (default 4 queues) serialises the contig stage's ~30 streams; must be in
+# the environment before the runtime initialises (csrc/api.hip nsgpu_create, profiles/r02_stream_priority_ab.txt)
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from ._lib import NsGpuError, lib_path, load_library, Params, Timing  # noqa: F401
 from .filter import NsGpu, MinHashReadFilter, mt19937_64_salts, synth_reads, ksw_extd2_batch, align_batch, align_stats, consensus_run, consensus_stream, consensus_verify, consensus_write  # noqa: F401
 

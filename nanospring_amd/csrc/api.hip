@@ -102,6 +102,22 @@ static int store_from_ascii(nsgpu_ctx *c, SeqStore &st, const char *bases, const
 
 using namespace nsgpu;
 
+namespace nsgpu {
+// Stream priorities.  Measured on MI355X / ROCm 7.2 (profiles/r02_stream_priority_ab.txt): the role defaults below.
+int role_stream_create(hipStream_t *st, const char *role)
+{
+    int least = 0, greatest = 0;
+    NS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    std::string var = std::string("NSGPU_PRIO_") + role;
+    for (char &ch : var) ch = (char)toupper((unsigned char)ch);
+    const char *e = getenv(var.c_str());
+    std::string want = e ? e : (!strcmp(role, "sketch") ? "lo" : !strcmp(role, "seeds") ? "hi" : !strcmp(role, "dp_side") ? "hi" : "mid");
+    const int prio = want == "lo" ? least : want == "hi" ? greatest : (least + greatest) / 2;
+    NS_HIP(hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio));
+    return NSGPU_OK;
+}
+}  // namespace nsgpu
+
 extern "C" {
 
 const char *nsgpu_last_error(void) { return g_err; }
@@ -123,6 +139,12 @@ int nsgpu_create(const nsgpu_params *p, nsgpu_ctx **ctx_out)
     NS_CHECK(p && ctx_out, NSGPU_ERR_ARG, "nsgpu_create: null argument");
     NS_CHECK(p->k >= 1 && p->k <= 31, NSGPU_ERR_ARG, "k must be in 1..31 (2k-bit k-mers in a u64; k=32 is UB in the reference too, src/ReadFilter.cpp:145)");
     NS_CHECK(p->n >= 1 && p->n <= 256, NSGPU_ERR_ARG, "n (sketch size) must be in 1..256");
+    // The contig stage drives ~30 streams (sketch, seeds + chaining, DP main and side streams per builder group, window queries).
+    // The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), in order within a queue: a 0.3 ms
+    // sketch then waits behind another group's 3 ms DP kernel.  8 queues: +12 % whole path (profiles/r02_stream_priority_ab.txt).
+    // Read by the runtime when it initialises, i.e. effective here only if this is the process's first HIP call; set it in the
+    // process environment otherwise.
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {

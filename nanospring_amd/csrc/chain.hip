@@ -318,12 +318,7 @@ int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vecto
     W.pend_total = total;
     if (total == 0) return NSGPU_OK;
     const double t0 = now_ms();
-    if (!W.stream) {
-        // the chaining pass is short and on a slot's critical path: in front of the DP launches that fill the chip
-        int prio_lo = 0, prio_hi = 0;
-        NS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        NS_HIP(hipStreamCreateWithPriority(&W.stream, hipStreamNonBlocking, prio_hi));
-    }
+    if (!W.stream) NS_TRY(role_stream_create(&W.stream, "seeds"));
     // pinned staging: anchors | offsets | mean spans | job lists (LDS kernel's first) | list descriptors of the LDS kernel
     const size_t b_anch = total * sizeof(mm2::Anchor), b_off = (nq + 1) * sizeof(uint64_t), b_avg = (nq * sizeof(float) + 7) & ~(size_t)7, b_jobs = (nq * sizeof(uint32_t) + 7) & ~(size_t)7;
     NS_TRY(W.h_in.reserve(b_anch + b_off + b_avg + b_jobs + nq * sizeof(ChainList)));

@@ -45,6 +45,9 @@ void set_error(const char *fmt, ...);
 // is bound by the host cores it shares with those waits.  So: poll the stream, spin only for the first ~20 us, then sleep
 // between polls.  NSGPU_SPIN_WAIT=1 restores the runtime's own wait.
 hipError_t stream_wait(hipStream_t s);
+// a non-blocking stream for one of the roles "sketch", "seeds" (seeding + chaining kernels), "dp_side" (long DP problems), "dp" (DP workspaces 1-3):
+// priority from NSGPU_PRIO_<ROLE>=lo|mid|hi, else the role's measured default (api.hip)
+int role_stream_create(hipStream_t *st, const char *role);
 hipError_t stream_wait_short(hipStream_t s);     // busy-wait (the runtime's): for waits inside a chain of short kernels on a slot's critical path
 
 // Growable device allocation (never shrinks). No hipMalloc happens inside a

@@ -716,7 +716,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     NS_CHECK(ws_index >= 0 && ws_index <= 3, NSGPU_ERR_ARG, "ksw: workspace index must be 0..3");
     nsgpu_ctx::KswWs &W = c->kws[ws_index];
     // workspace 0 works on the context's stream; workspace 1 owns one (the second half batch of the contig engine)
-    if (ws_index >= 1 && !W.stream) NS_HIP(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
+    if (ws_index >= 1 && !W.stream) NS_TRY(role_stream_create(&W.stream, "dp"));
     const hipStream_t S = ws_index == 0 ? c->stream : W.stream;
     if (!W.t_a) { NS_HIP(hipEventCreate(&W.t_a)); NS_HIP(hipEventCreate(&W.t_b)); }
     results.assign(n, KswResult());
@@ -861,9 +861,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     // The few long problems (extensions up to 5000 x 5000) are latency-bound on one wave each and leave the chip
     // idle: they run on side streams, concurrently with the bulk of small gap fills on the main stream.
     if (!W.side_stream[0]) {
-        int prio_lo = 0, prio_hi = 0;
-        NS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));      // the long problems must be dispatched first: highest priority
-        for (int i = 0; i < 3; ++i) { NS_HIP(hipStreamCreateWithPriority(&W.side_stream[i], hipStreamNonBlocking, prio_hi)); NS_HIP(hipEventCreateWithFlags(&W.side_done[i], hipEventDisableTiming)); }
+        for (int i = 0; i < 3; ++i) { NS_TRY(role_stream_create(&W.side_stream[i], "dp_side")); NS_HIP(hipEventCreateWithFlags(&W.side_done[i], hipEventDisableTiming)); }      // the long problems must be dispatched first
         NS_HIP(hipEventCreateWithFlags(&W.side_fork, hipEventDisableTiming));
     }
     NS_HIP(hipEventRecord(W.side_fork, S));

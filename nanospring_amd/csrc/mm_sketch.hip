@@ -499,7 +499,7 @@ static int gpu_mm_sketch_fused(nsgpu_ctx *c, const std::vector<SketchReq> &reqs,
     const size_t n = reqs.size();
     const double t0 = now_ms();
     nsgpu_ctx::SketchWs &W = c->sws[ws];
-    if (!W.stream) NS_HIP(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
+    if (!W.stream) NS_TRY(role_stream_create(&W.stream, "sketch"));
     const hipStream_t st = W.stream;
     uint64_t bytes = 0, n_tiles = 0;
     for (size_t i = 0; i < n; ++i) {
@@ -624,7 +624,7 @@ static int gpu_mm_sketch_one(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, i
     nsgpu_ctx::SketchWs &W = c->sws[ws];
     // a stream of its own: in the contig engine the sketches of one builder group run while another group's window queries
     // use the context's stream
-    if (!W.stream) NS_HIP(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
+    if (!W.stream) NS_TRY(role_stream_create(&W.stream, "sketch"));
     const hipStream_t st = W.stream;
     std::vector<uint32_t> soff(n + 1), len(n);
     uint64_t bytes = 0;

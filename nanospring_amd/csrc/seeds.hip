@@ -201,11 +201,7 @@ int gpu_seeds_launch(nsgpu_ctx *c, int ws, float mid_occ_frac, std::vector<SeedP
     const size_t n = pairs.size();
     W.pend = n;
     if (n == 0) return NSGPU_OK;
-    if (!W.stream) {
-        int prio_lo = 0, prio_hi = 0;
-        NS_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        NS_HIP(hipStreamCreateWithPriority(&W.stream, hipStreamNonBlocking, prio_hi));
-    }
+    if (!W.stream) NS_TRY(role_stream_create(&W.stream, "seeds"));
     uint64_t tab_total = 0, next_total = 0, qry_total = 0;
     for (SeedPair &p : pairs) {
         uint32_t bits = 4;
