@@ -21,10 +21,18 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
-static hipError_t stream_wait_impl(hipStream_t s, int spin_us)
+// NSGPU_WAIT_TIMEOUT_S=n: a wait for the GPU that lasts longer than n seconds fails (hipErrorNotReady, with a message saying so)
+// instead of blocking for ever -- the tests run with it, so that a lost kernel shows up as an error, not as a hung process.
+static double wait_timeout_s()
+{
+    static const double t = [] { const char *e = getenv("NSGPU_WAIT_TIMEOUT_S"); return e ? atof(e) : 0.0; }();
+    return t;
+}
+static hipError_t stream_wait_impl(hipStream_t s, int spin_us, bool spin_only = false)
 {
     static const bool spin = [] { const char *e = getenv("NSGPU_SPIN_WAIT"); return e && atoi(e) != 0; }();
-    if (spin) return hipStreamSynchronize(s);
+    const double limit = wait_timeout_s();
+    if ((spin || spin_only) && limit <= 0) return hipStreamSynchronize(s);
     // the default timer slack (50 us) would stretch every 20 us sleep to ~75 us: 1 us of slack for threads that wait here
     static thread_local const int slack_set = prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
     (void)slack_set;
@@ -32,7 +40,12 @@ static hipError_t stream_wait_impl(hipStream_t s, int spin_us)
     for (;;) {
         const hipError_t e = hipStreamQuery(s);
         if (e != hipErrorNotReady) return e;
-        if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us)) continue;
+        const auto dt = std::chrono::steady_clock::now() - t0;
+        if (limit > 0 && dt > std::chrono::duration<double>(limit)) {
+            fprintf(stderr, "nsgpu: a wait for stream %p exceeded NSGPU_WAIT_TIMEOUT_S = %g s\n", (void *)s, limit);
+            return hipErrorNotReady;
+        }
+        if (spin || spin_only || dt < std::chrono::microseconds(spin_us)) continue;
         timespec ts = {0, 20000};
         nanosleep(&ts, nullptr);
     }
@@ -42,7 +55,11 @@ hipError_t stream_wait(hipStream_t s) { return stream_wait_impl(s, 20); }
 // pipeline slot, on the slot's critical path): the runtime's own busy-wait.  Measured at cfg2: sleeping between polls costs
 // 100-200 us per wait until the thread is back on a core of the CPU-saturated cgroup (window queries 0.53 -> 1.08 s per
 // step), polling hipStreamQuery for 0.5 ms first still 0.67 s; the spin costs ~1 CPU-second per batch thread and step.
-hipError_t stream_wait_short(hipStream_t s) { return hipStreamSynchronize(s); }
+hipError_t stream_wait_short(hipStream_t s)
+{
+    static const bool sleepy = getenv("NSGPU_SHORT_WAIT_SLEEP") != nullptr;     // A/B switch: poll + sleep here as well
+    return sleepy ? stream_wait_impl(s, 20) : stream_wait_impl(s, 0, true);
+}
 
 static uint64_t row_bytes_h(uint32_t len) { return ((((uint64_t)len + 3) / 4 + 15) & ~(uint64_t)15) + 16; }
 

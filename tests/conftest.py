@@ -8,8 +8,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# a wait for the GPU that never ends becomes an error of the call (csrc/api.hip), and a test that hangs anyway ends the run after
+# 15 minutes instead of occupying the GPU box until someone's outer limit
+os.environ.setdefault("NSGPU_WAIT_TIMEOUT_S", "120")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if config.pluginmanager.hasplugin("timeout") and not config.getoption("timeout", None):
+        config.option.timeout = 900
+        config.option.timeout_method = "thread"
 
 
 @pytest.fixture(scope="session")

@@ -1,8 +1,8 @@
 # the round's record run: tests, smoke, bench (default flags), rocprofv3 kernel stats of the same command
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r02z
-echo skip-tests
-echo skip-smoke
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -2
 ( time timeout 900 python bench.py ) 2>> gpurun_out/r02z/bench.time > gpurun_out/r02z/bench.json 2> gpurun_out/r02z/bench.err; grep -E "^step" gpurun_out/r02z/bench.err | tail -3; tail -4 gpurun_out/r02z/bench.time
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r02z/prof -o b -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 0 --cpu-sample 0 > $GRAFT_REPO_ROOT/gpurun_out/r02z/bench_prof.json 2> $GRAFT_REPO_ROOT/gpurun_out/r02z/bench_prof.err
