@@ -841,6 +841,38 @@ size_t optimize_edit_script(const std::vector<EditOp> &in, std::vector<EditOp> &
 // node visited last on the main path (only used when the read's bases are at hand).
 static inline uint8_t base_bit(char b) { return b == 'A' ? 1 : b == 'C' ? 2 : b == 'G' ? 4 : b == 'T' ? 8 : 16; }
 
+// The out-edge of node n that read `id` takes when its next base is nb: the only out-edge, else the only one whose sink carries
+// the base.  When several do (8 % of the positions of a read at cfg2: a side branch that starts with the consensus's next base --
+// an inserted copy of it, or a deletion edge onto an equal base), the read is on exactly one of them: the short lists are looked
+// through (a side branch holds a read or two, inside the edge's own cache line) and the read is on the longest one if it is on
+// none of those -- the long list, sorted on demand and spilled to the arena, is never touched.
+static inline bool edge_lists_read(const Edge *e, read_t id)
+{
+    const uint32_t n = e->reads.n;
+    const read_t *b = e->reads.data();
+    if (n <= 16) { for (uint32_t x = 0; x < n; ++x) if (b[x] == id) return true; return false; }
+    const_cast<Edge *>(e)->sort_reads();
+    b = e->reads.data();
+    size_t m = n;
+    if (id < b[0] || id > b[m - 1]) return false;
+    while (m > 1) { const size_t h = m >> 1; b = b[h] <= id ? b + h : b; m -= h; }
+    return *b == id;
+}
+static inline const Edge *way_out_of(const Node *n, char nb, read_t id)
+{
+    const auto &out = n->out;
+    if (out.size() == 1) return out[0].get();
+    const Edge *cand[8];
+    int cnt = 0;
+    for (const OutRef &o : out) if (o.sink_base_is(nb)) { if (cnt < 8) cand[cnt] = o.get(); ++cnt; }
+    if (cnt == 1) return cand[0];
+    if (cnt == 0 || cnt > 8) return n->edge_in_read(id);
+    int big = 0;
+    for (int c = 1; c < cnt; ++c) if (cand[c]->reads.n > cand[big]->reads.n) big = c;
+    for (int c = 0; c < cnt; ++c) if (c != big && edge_lists_read(cand[c], id)) return cand[c];
+    return cand[big];
+}
+
 template <class Visit, class VisitRun>
 void ContigGraph::walk_read(const GraphRead &r, read_t id, const ReadBases *src, Visit visit, VisitRun visit_run) const
 {
@@ -901,30 +933,21 @@ void ContigGraph::walk_read(const GraphRead &r, read_t id, const ReadBases *src,
                 // a fork (or the path's end): when the consensus goes on with the read's next base and no side branch starts
                 // with that base, the read's edge is the path's edge (the only out-edge whose sink carries the base)
                 const char nb = rb[i];
-                if (j < n_main && cons[j + 1] == nb && !(side_mask_[j] & base_bit(nb))) { ++j; visit_run(1); continue; }
-                const Node *n = main_nodes_[j];
-                const auto &out = n->out;
-                if (out.size() == 1) cur = out[0]->sink;
-                else {
-                    const Edge *pick = nullptr;
-                    int cnt = 0;
-                    for (const OutRef &o : out) if (o.sink_base_is(nb)) { pick = o; ++cnt; }
-                    if (cnt != 1) pick = n->edge_in_read(id);
-                    cur = pick->sink;
+                if (j < n_main && cons[j + 1] == nb) {
+                    if (!(side_mask_[j] & base_bit(nb))) { ++j; visit_run(1); continue; }
+                    // a side branch starts with the same base: the read stays on the path unless that branch lists it
+                    const read_t *a = amb_ids_.data() + amb_off_[j], *b = amb_ids_.data() + amb_off_[j + 1];
+                    bool side = false;
+                    for (; a != b; ++a) if (*a == id || *a == kAmbComplex) { side = true; break; }
+                    if (!side) { ++j; visit_run(1); continue; }
                 }
+                cur = way_out_of(main_nodes_[j], nb, id)->sink;
                 break;
             }
             continue;
         }
         if (++i == L) break;                             // i = bases consumed
-        const auto &out = cur->out;
-        if (out.size() == 1) { cur = out[0]->sink; continue; }
-        const char nb = rb[i];
-        const Edge *pick = nullptr;
-        int cnt = 0;
-        for (const OutRef &o : out) if (o.sink_base_is(nb)) { pick = o; ++cnt; }
-        if (cnt != 1) pick = cur->edge_in_read(id);
-        cur = pick->sink;
+        cur = way_out_of(cur, rb[i], id)->sink;
     }
 }
 
@@ -1009,16 +1032,33 @@ void ContigGraph::write_reads(StreamSet &o, const std::function<ReadBases(read_t
     main_nodes_.resize(n_main + 1);
     next_fork_.resize(n_main + 1);
     side_mask_.assign(n_main + 1, 0);
+    amb_off_.assign(n_main + 2, 0);
+    amb_ids_.clear();
     // one pass over the path's nodes while their lines are at hand: index, fork flag, bases of the side branches (from the
     // out-edge references; no edge or sink is touched)
     auto note = [&](size_t j, const Node *n) {
         const bool single = n->out.size() == 1 && j < n_main;
         next_fork_[j] = single ? UINT32_MAX : (uint32_t)j;
+        amb_off_[j + 1] = (uint32_t)amb_ids_.size();
         if (single) return;
         const Edge *path_edge = j < n_main ? main_edges[j] : nullptr;
         uint8_t m = 0;
         for (const OutRef &o : n->out) if (o.get() != path_edge) m |= base_bit(o.sink_base());
         side_mask_[j] = m;
+        // side branches that start with the consensus's own next base (an inserted copy of it, a deletion edge onto an equal
+        // base): the reads on them, so that the walk of every other read passes this node without looking at the graph
+        if (j < n_main && (m & base_bit(main_path[j + 1]))) {
+            const size_t at = amb_ids_.size();
+            bool simple = true;
+            for (const OutRef &o : n->out)
+                if (o.get() != path_edge && o.sink_base_is(main_path[j + 1])) {
+                    const Edge *e = o.get();
+                    if (e->reads.n > 16) { simple = false; break; }
+                    amb_ids_.insert(amb_ids_.end(), e->reads.data(), e->reads.data() + e->reads.n);
+                }
+            if (!simple) { amb_ids_.resize(at); amb_ids_.push_back(kAmbComplex); }
+        }
+        amb_off_[j + 1] = (uint32_t)amb_ids_.size();
     };
     main_nodes_[0] = main_edges.front()->source;
     note(0, main_nodes_[0]);

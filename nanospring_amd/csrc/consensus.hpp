@@ -253,6 +253,9 @@ private:
     std::vector<const Node *> main_nodes_;    // the main path's nodes in order (filled by write_reads for the emission walks)
     std::vector<uint8_t> side_mask_;          // per main-path index: bases of the sinks of the out-edges other than the path's own
     std::vector<uint32_t> next_fork_;         // per main-path index: next node with more than one way out (or the path's end)
+    std::vector<uint32_t> amb_off_;           // per main-path index j: amb_ids_[amb_off_[j] .. amb_off_[j + 1]) = the reads on side branches of node j that start with the
+    std::vector<read_t> amb_ids_;             //   consensus's next base (kAmbComplex: too many to list -- look at the graph)
+    static constexpr read_t kAmbComplex = ~(read_t)0;
     std::vector<uint8_t> follow_ok_;          // per main-path index j < n_main: 1 when a read whose next base is the consensus's next base can only go to main-path node j + 1
     bool have_touch_ = false;
     size_t consistent_from_ = (size_t)-1;     // main-path nodes with index >= this were chosen by best_out on the current counts

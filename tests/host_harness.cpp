@@ -306,7 +306,12 @@ int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32
         } else {
             double t0 = hnow();
             g.write_main_path(out);
-            g.write_reads(out);
+            // the engine's route (walks guided by the reads' own bases, several reads in flight) unless NSGPU_EMIT_NO_SOURCE=1 asks
+            // for the walk along the edges' read lists
+            static const bool no_source = getenv("NSGPU_EMIT_NO_SOURCE") != nullptr;
+            const std::function<ReadBases(read_t)> src = [&](read_t id) { const std::string &s = reads[id - id_base]; return ReadBases{s.data(), s.size()}; };
+            if (no_source) g.write_reads(out);
+            else g.write_reads(out, &src);
             st->write_ms += hnow() - t0;
             out.reads_in_contig.push_back((read_t)g.num_reads());
         }

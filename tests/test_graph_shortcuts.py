@@ -70,6 +70,8 @@ def test_shortcuts_change_nothing(kind, seed):
     literal = run(kind, seed, NSGPU_NO_CYCLE_SKIP="1", NSGPU_NO_TAIL_SPLICE="1", NSGPU_NO_RUN_FASTPATH="1")
     assert fast == literal
     assert fast[1] > 100
+    # edit emission: walks guided by the reads' own bases and the per-contig tables (default) / along the edges' read lists
+    assert fast == run(kind, seed, NSGPU_EMIT_NO_SOURCE="1")
 
 
 @pytest.mark.parametrize("kind,seed", [("repeats", 21), ("repeats", 28), ("long", 3)])
