@@ -284,9 +284,14 @@ void ContigGraph::initialize(const std::string &seed, read_t id, long pos)
     end_pos = pos + 1;     // only one base is on the main path until calculate_main_path_greedy runs
 }
 
+static inline uint64_t emit_now();
+std::atomic<uint64_t> g_upd_ns[6];    // diagnostic (NSGPU_UPDATE_STATS=1): setup, run loops, SAME op heads, inserts, tail, calls
 void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &script, ssize_t begin_offset, ssize_t end_offset, read_t id,
                                long pos, bool rc)
 {
+    static const bool upd_stats = getenv("NSGPU_UPDATE_STATS") != nullptr;
+    uint64_t ut[5] = {0, 0, 0, 0, 0}, u0 = upd_stats ? emit_now() : 0;
+    auto lapu = [&](int k) { if (upd_stats) { const uint64_t t = emit_now(); ut[k] += t - u0; u0 = t; } };
     const size_t n_path_edges = main_edges.size();
     std::vector<uint64_t> dbg_before;
     static const bool dbg = getenv("NSGPU_SPLICE_CHECK") != nullptr;      // debugging aid for the tail re-use shortcut
@@ -354,6 +359,7 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
         op_at[script.size()] = (uint32_t)(e2 < n_path_edges ? e2 : n_path_edges);
     }
     size_t op_k = 0;
+    lapu(0);
     for (const EditOp &op : script) {
         {
             const size_t k9 = op_k + 9, k6 = op_k + 6, k3 = op_k + 3;
@@ -375,6 +381,7 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
             cur_main = (ssize_t)ei;
             if (touch_lo_ == (size_t)-1) touch_lo_ = ei;
             advance();
+            lapu(2);
             // The rest of the run follows the main-path edges main_edges[ei-1 .. ei+num-3] one after the other (the loop below,
             // which re-derives that per base, stays for the path's end, where the reference's walk stops advancing): add the read
             // to each of them and set the walk's state once.
@@ -382,21 +389,23 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
             if (!no_run_loop && op.num > 1 && ei >= 1 && ei + op.num - 2 <= n_path_edges && main_edges[ei - 1]->source == cur && main_edges[ei - 1]->sink == node_in_path) {
                 const size_t last_ei = ei + op.num - 2;                 // ei at the start of the run's last base
                 Edge *const *pe = main_edges.begin();
+                static const size_t pf_edge = getenv("NSGPU_PF_EDGE") ? (size_t)atoi(getenv("NSGPU_PF_EDGE")) : 40, pf_tail = getenv("NSGPU_PF_TAIL") ? (size_t)atoi(getenv("NSGPU_PF_TAIL")) : 20;
                 for (size_t x = ei - 1; x < last_ei; ++x) {
-                    if (x + 12 < n_path_edges) __builtin_prefetch(pe[x + 12], 1, 1);
+                    if (x + pf_edge < n_path_edges) __builtin_prefetch(pe[x + pf_edge], 1, 1);
                     // second miss of an edge with more than eight reads: the tail of its read list, one line behind the edge's own
-                    if (x + 6 < n_path_edges) { const Edge *e6 = pe[x + 6]; if (e6->reads.cap != kEdgeInlineReads) __builtin_prefetch(e6->reads.heap + e6->reads.n, 1, 1); }
+                    if (x + pf_tail < n_path_edges) { const Edge *e6 = pe[x + pf_tail]; if (e6->reads.cap != kEdgeInlineReads) __builtin_prefetch(e6->reads.heap + e6->reads.n, 1, 1); }
                     pe[x]->add_read(arena_, id);
                 }
                 cur = pe[last_ei - 1]->sink;
                 cur_main = (ssize_t)last_ei;
                 if (last_ei == n_path_edges) ei = n_path_edges, node_in_path = cur;
                 else node_in_path = pe[last_ei]->sink, ei = last_ei + 1;
+                lapu(1);
                 continue;
             }
             for (size_t i = 1; i < op.num; ++i) {
                 // the walk touches one edge (one cache line) per base, in main-path order: fetch ahead
-                if (ei + 12 < n_path_edges) __builtin_prefetch(main_edges[ei + 12], 1, 1);
+                if (ei + 40 < n_path_edges) __builtin_prefetch(main_edges[ei + 40], 1, 1);
                 // cur and node_in_path are consecutive main-path nodes here, and edges are unique per (source, sink)
                 // (update_graph looks before it creates; split_path only adds edges out of fresh nodes), so the edge
                 // getEdgeTo() would find is the main-path edge itself
@@ -407,13 +416,16 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
                 cur_main = (ssize_t)ei;
                 advance();
             }
-        } else if (op.type == 2) advance();          // DELETE
-        else if (op.type == 1) insert_node((char)op.base);
+            lapu(1);
+        } else if (op.type == 2) { advance(); lapu(3); }         // DELETE
+        else if (op.type == 1) { insert_node((char)op.base); lapu(3); }
     }
     if (end_offset > 0)
         for (size_t i = s.size() - (size_t)end_offset; i < s.size(); ++i) insert_node(s[i]);
     reads.insert(std::make_pair(id, GraphRead{pos, initial, s.length(), rc}));
     touch_idx_ = ei, have_touch_ = true;         // main-path nodes beyond index ei were not modified
+    lapu(4);
+    if (upd_stats) { for (int k = 0; k < 5; ++k) g_upd_ns[k] += ut[k]; g_upd_ns[5] += 1; }
     if (dbg) for (size_t i = ei; i < n_path_edges; ++i) if (dbg_before[i] != out_sig(main_edges[i]->sink)) { fprintf(stderr, "UPDATE touched node %zu beyond ei=%zu (begin %zd end %zd)\n", i + 1, ei, begin_offset, end_offset); break; }
 }
 
@@ -1064,8 +1076,9 @@ void ContigGraph::write_reads(StreamSet &o, const std::function<ReadBases(read_t
     note(0, main_nodes_[0]);
     for (size_t t = 0; t < n_main; ++t) {
         // two dependent misses per position (edge, then its sink): keep both in flight ahead of the loop
-        if (t + 16 < n_main) __builtin_prefetch(main_edges[t + 16], 0, 1);
-        if (t + 8 < n_main) __builtin_prefetch(main_edges[t + 8]->sink, 1, 1);
+        static const size_t pf_a = getenv("NSGPU_PF_TAB") ? (size_t)atoi(getenv("NSGPU_PF_TAB")) : 16;
+        if (t + pf_a < n_main) __builtin_prefetch(main_edges[t + pf_a], 0, 1);
+        if (t + pf_a / 2 < n_main) __builtin_prefetch(main_edges[t + pf_a / 2]->sink, 1, 1);
         Node *n = main_edges[t]->sink;
         n->cum_weight = t + 1;
         main_nodes_[t + 1] = n;

@@ -32,7 +32,7 @@ namespace nsgpu {
 namespace mm2 { extern std::atomic<uint64_t> g_step_ns[6]; }
 extern double g_finish_ms[5];
 extern double g_sketch_ms[6];
-namespace cons { extern std::atomic<uint64_t> g_emit_ns[4]; }
+namespace cons { extern std::atomic<uint64_t> g_emit_ns[4]; extern std::atomic<uint64_t> g_upd_ns[6]; }
 
 using cons::read_t;
 
@@ -866,6 +866,9 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
     const int rc = engine_finish(c, n_threads_out);
     if (getenv("NSGPU_CONS_DEBUG")) {
         fprintf(stderr, "[cons] gpu mm_sketch wall-ms %.0f\n", c->sketch_mm_ms);
+        if (cons::g_upd_ns[5].load())
+            fprintf(stderr, "[cons] update_graph cpu-ms (NSGPU_UPDATE_STATS, cumulative, %llu calls): setup %.0f, SAME runs %.0f, SAME heads %.0f, inserts / deletes %.0f, tail %.0f\n",
+                    (unsigned long long)cons::g_upd_ns[5].load(), cons::g_upd_ns[0] / 1e6, cons::g_upd_ns[1] / 1e6, cons::g_upd_ns[2] / 1e6, cons::g_upd_ns[3] / 1e6, cons::g_upd_ns[4] / 1e6);
         fprintf(stderr, "[cons] emission cpu-ms: path tables %.0f, read walks %.0f, script folding + stream bytes %.0f\n", cons::g_emit_ns[0] / 1e6, cons::g_emit_ns[1] / 1e6, cons::g_emit_ns[2] / 1e6);
         fprintf(stderr, "[cons] align host cpu-ms: seeds %.0f chain %.0f regs %.0f plan %.0f execute %.0f\n", mm2::g_step_ns[0] / 1e6, mm2::g_step_ns[1] / 1e6,
                 mm2::g_step_ns[2] / 1e6, mm2::g_step_ns[3] / 1e6, mm2::g_step_ns[4] / 1e6);

@@ -2,13 +2,14 @@
 cd $GRAFT_REPO_ROOT
 run() {
   ( for kv in "$@"; do export "$kv"; done
-    NSGPU_CONS_DEBUG=1 timeout 400 python bench.py --steps 2 --warmup 1 --cpu-sample 0 2>gpurun_out/sweep_err.txt | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); s=d['config']['stage_ms_per_step']; print('%-75s' % '$*', d['value'], d['ms_per_step'], 'index', s['consensus_index'], 'graph', s['graph_host_wall'])"
-    grep "process CPU time" gpurun_out/sweep_err.txt | tail -1 )
+    NSGPU_CONS_DEBUG=1 timeout 400 python bench.py --steps 1 --warmup 1 --cpu-sample 0 2>gpurun_out/sweep_err.txt | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); s=d['config']['stage_ms_per_step']; print('%-40s' % '$*', d['value'], d['ms_per_step'])"
+    grep "emission cpu-ms" gpurun_out/sweep_err.txt | tail -1 | cut -c1-200 )
 }
 mkdir -p gpurun_out
-for rep in 1 2 3; do
-run A=default
-run MALLOC_MMAP_THRESHOLD_=4294967296 MALLOC_TRIM_THRESHOLD_=17179869184
-run MALLOC_ARENA_MAX=4
+for rep in 1 2; do
+run NSGPU_PF_TAB=16
+run NSGPU_PF_TAB=32
+run NSGPU_PF_TAB=64
+run NSGPU_PF_TAB=128
 done
