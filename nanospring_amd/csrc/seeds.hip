@@ -212,7 +212,10 @@ int gpu_seeds_launch(nsgpu_ctx *c, int ws, float mid_occ_frac, std::vector<SeedP
     }
     // anchors: the engine's lists hold about one anchor per query minimizer; room for 4x, more after an overflow (the flagged pairs
     // of that batch go through the host code)
-    const uint64_t want = std::max<uint64_t>(W.cap_hint, 4 * qry_total + 65536);
+    // (NSGPU_SEED_CAP_FACTOR / NSGPU_SEED_CAP_SLACK: test switches that make the first launches overflow)
+    static const uint64_t cap_factor = getenv("NSGPU_SEED_CAP_FACTOR") ? (uint64_t)atoll(getenv("NSGPU_SEED_CAP_FACTOR")) : 4;
+    static const uint64_t cap_slack = getenv("NSGPU_SEED_CAP_SLACK") ? (uint64_t)atoll(getenv("NSGPU_SEED_CAP_SLACK")) : 65536;
+    const uint64_t want = std::max<uint64_t>(std::max<uint64_t>(W.cap_hint, cap_factor * qry_total + cap_slack), 16);
     NS_TRY(W.d_tab.reserve(tab_total * sizeof(Slot)));
     NS_TRY(W.d_next.reserve(next_total * sizeof(uint32_t) + 16));
     NS_TRY(W.d_ys.reserve(next_total * sizeof(uint64_t) + 16));

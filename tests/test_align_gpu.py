@@ -90,3 +90,44 @@ def test_many_queries_share_one_reference_at_scale(gpu):
             n_ok += 1
     assert n_ok > 40
     assert not ns.align_batch(gpu, [ref], [], [])
+
+
+OVERFLOW_WORKER = r'''
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import nanospring_amd as ns
+from tests import oracle_lib
+from tests.align_cases import pairs
+g = ns.NsGpu()
+ps = pairs(77, 48, big=False)
+refs, rid = [], []
+for r, _ in ps:
+    if r not in refs:
+        refs.append(r)
+    rid.append(refs.index(r))
+for rnd in range(3):
+    res = ns.align_batch(g, refs, [q for _, q in ps], rid)
+    for i, ((ref, q), d) in enumerate(zip(ps, res)):
+        b = oracle_lib.ref_mm2_align(ref, q)
+        assert d["hits"] == b["hits"], (rnd, i)
+        if b["hits"]:
+            assert all(d[f] == b[f] for f in ("rs", "re", "qs", "qe", "blen", "mlen", "dp_max")) and np.array_equal(d["cigar"], b["cigar"]), (rnd, i)
+    st = ns.align_stats(g)
+    print("ROUND", rnd, st["seed_pairs_gpu"], st["seed_pairs_host"])
+'''
+
+
+@pytest.mark.skipif(oracle_lib.mm2ref() is None, reason="oracle/_ref/libmm2ref.so not present")
+def test_anchor_capacity_overflow_goes_through_the_host_code_and_grows():
+    """The seeding kernel's anchor buffer too small (test switches): the pairs that do not fit are flagged and redone by the host
+    code, results unchanged; the next launch has the room."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NSGPU_SEED_CAP_FACTOR="0", NSGPU_SEED_CAP_SLACK="0")
+    r = subprocess.run([sys.executable, "-c", OVERFLOW_WORKER % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rounds = [list(map(int, l.split()[2:])) for l in r.stdout.splitlines() if l.startswith("ROUND")]
+    assert len(rounds) == 3
+    assert rounds[0][1] > 20                                  # first call: (nearly) everything handed back
+    assert rounds[2][0] - rounds[1][0] > 20                   # later calls: the kernels' lists again

@@ -1,6 +1,6 @@
 """Contig stage at other depths / read lengths than cfg2 (robustness + throughput): run_depth.py <reads> <depth> [builders] [mean_len]."""
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import nanospring_amd as ns
 n, depth = int(sys.argv[1]), float(sys.argv[2])

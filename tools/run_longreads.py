@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import nanospring_amd as ns
 from tests.align_cases import make_genome, mutate, revcomp
