@@ -18,6 +18,8 @@
 // batches part 1 with the DP launch | DP in flight | batches part 2), so that host cores and GPU work
 // at the same time: see run_consensus / engine_slot.
 #include "common.hpp"
+#include <dirent.h>
+#include <unistd.h>
 #include "consensus.hpp"
 #include "host_util.hpp"
 #include "dist.hpp"
@@ -893,6 +895,33 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
                 g_sketch_ms[0], g_sketch_ms[1], g_sketch_ms[2], g_sketch_ms[3], g_sketch_ms[4] / 1e6, g_sketch_ms[5] / 1e6);
         for (double &x : g_sketch_ms) x = 0;
         const double sys_s = (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
+        if (getenv("NSGPU_THREAD_TIMES")) {
+            // cumulative user / system time of every thread of the process since it started (ticks -> s), busiest system-time users first
+            std::vector<std::pair<double, std::string>> rows;
+            if (DIR *d = opendir("/proc/self/task")) {
+                while (dirent *de = readdir(d)) {
+                    if (de->d_name[0] == '.') continue;
+                    char path[128], buf[1024];
+                    snprintf(path, sizeof(path), "/proc/self/task/%s/stat", de->d_name);
+                    FILE *tf = fopen(path, "r");
+                    if (!tf) continue;
+                    if (fgets(buf, sizeof(buf), tf)) {
+                        const char *rp = strrchr(buf, ')');
+                        const char *lp = strchr(buf, '(');
+                        unsigned long ut = 0, stt = 0;
+                        if (rp && lp && sscanf(rp + 2, "%*c %*d %*d %*d %*d %*d %*u %*u %*u %*u %*u %lu %lu", &ut, &stt) == 2) {
+                            char row[256];
+                            snprintf(row, sizeof(row), "%s %.*s user %.2f s sys %.2f s", de->d_name, (int)(rp - lp - 1), lp + 1, ut / (double)sysconf(_SC_CLK_TCK), stt / (double)sysconf(_SC_CLK_TCK));
+                            rows.push_back({stt / (double)sysconf(_SC_CLK_TCK), row});
+                        }
+                    }
+                    fclose(tf);
+                }
+                closedir(d);
+            }
+            std::sort(rows.begin(), rows.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+            for (size_t k = 0; k < rows.size() && k < 24; ++k) fprintf(stderr, "[threads] %s\n", rows[k].second.c_str());
+        }
         fprintf(stderr, "[cons] process CPU time over the stage: %.1f s (%.1f s of it in the kernel; %ld minor faults) = %.1f cores busy on average\n", cpu_s, sys_s,
                 ru1.ru_minflt - ru0.ru_minflt, cpu_s / ((now_ms() - E->t0) * 1e-3));
         fprintf(stderr, "[cons] wall-ms: begin %.0f slots %.0f (host phases %.0f, batches %.0f, overlapped) seed %.0f claim %.0f finish %.0f\n", w_begin, w_slot,
