@@ -309,6 +309,7 @@ struct Engine {
     std::vector<uint32_t> sk_ref;
     std::vector<uint64_t> mz_off[2];                // minimizer offsets of the two halves of a sketch batch
     std::vector<uint64_t> stage_off;                // offsets of the builders' consensus minimizer lists in the seeding kernel's staging buffer
+    int deferred_fresh = -1;                          // group whose freshly started contigs take their first steps with the next host phase
     AlignBatch ab[kMaxGroups];                        // alignment batch of each group, DP kernels in flight between part 1 and part 2
     std::vector<uint32_t> fwho;                    // builders of the window-query batch
     std::vector<uint32_t> awho[kMaxGroups];           // builders of that batch
@@ -365,9 +366,13 @@ static void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
     const double a0 = now_ms();
+    // (with the host phase of a group also the first steps of the contigs that the group of the slot before started at the slot
+    // boundary: see run_consensus)
+    const int dg = only_fresh ? -1 : E->deferred_fresh;
+    if (!only_fresh) E->deferred_fresh = -1;
     par_for_pinned("host.phase", D.B.size(), [&](size_t i) {
         Builder &b = D.B[i];
-        if (in_group(b, group) && (!only_fresh || b.st == Builder::ADVANCE)) D.advance(b);
+        if ((in_group(b, group) && (!only_fresh || b.st == Builder::ADVANCE)) || (dg >= 0 && in_group(b, dg) && b.st == Builder::ADVANCE)) D.advance(b);
     });
     // the edit emission of the contigs finished in this phase: background tasks of the host pool, picked up whenever a
     // thread has nothing else to do (nothing waits for them before the end of the stage)
@@ -843,8 +848,16 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
         t = now_ms();
         // one round of seeds per slot: a fresh contig that ends at once (nothing to look up) asks again at its group's next
         // boundary -- a multi-GPU driver then needs one collective per slot for both request lists
+        // The first steps of the contigs started here (graph of the seed read, first main path, first window) are not run at the
+        // boundary, where every other thread would wait for them (170 ms per cfg2 step): the group's next role is part 1 of the
+        // batches, which only looks at builders that wait for an alignment, and nobody needs a fresh contig's window request
+        // before the group's part 2, two slots on -- they run with the next slot's host phase.  (NSGPU_NO_DEFER_FRESH=1: at once.)
         engine_seed_requests(c, ga, gb, h);
-        if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) engine_advance(c, true, h);
+        if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) {
+            static const bool at_once = getenv("NSGPU_NO_DEFER_FRESH") != nullptr;
+            if (at_once) engine_advance(c, true, h);
+            else E->deferred_fresh = h;
+        }
         w_seed += now_ms() - t;
         if (E->n_done_global >= E->n_total) break;
     }
@@ -974,7 +987,11 @@ static int run_consensus_dist(nsgpu_ctx *c, Comm &C, uint32_t n_builders_total, 
             ga.insert(ga.end(), v + 1, v + 1 + v[0]);
             gb.insert(gb.end(), v + 1 + cap, v + 1 + cap + v[0]);
         }
-        if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) engine_advance(c, true, h);
+        if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) {
+            static const bool at_once = getenv("NSGPU_NO_DEFER_FRESH") != nullptr;       // (see run_consensus)
+            if (at_once) engine_advance(c, true, h);
+            else E->deferred_fresh = h;
+        }
         if (E->n_done_global >= E->n_total) break;
     }
     if (n_coll_out) *n_coll_out = n_coll;
