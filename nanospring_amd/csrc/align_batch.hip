@@ -148,6 +148,7 @@ int pool_tag(const char *name)
 void pool_tag_restore(int t) { tl_tag = t; }
 uint64_t pool_thread_cpu_ns() { return thread_cpu_ns(); }
 uint64_t pool_thread_work_ns() { return tl_work_ns; }
+size_t pool_bg_max();
 void pool_prof_print()
 {
     if (!g_pool_prof) return;
@@ -155,7 +156,7 @@ void pool_prof_print()
     fprintf(stderr, "[pool] thread-CPU ms by loop:");
     for (int i = 0; i < g_n_tags.load(); ++i) { fprintf(stderr, " %s %.0f", g_tag_name[i], g_tag_ns[i].exchange(0) / 1e6); }
     fprintf(stderr, " background %.0f", g_tag_ns[31].exchange(0) / 1e6);
-    fprintf(stderr, "\n");
+    fprintf(stderr, "; longest background queue %zu tasks\n", pool_bg_max());
 }
 
 namespace {
@@ -249,7 +250,7 @@ public:
     void post(std::function<void()> fn)
     {
         if (th_.empty()) { fn(); return; }
-        { std::lock_guard<std::mutex> lk(m_); bg_.push_back(std::move(fn)); }
+        { std::lock_guard<std::mutex> lk(m_); bg_.push_back(std::move(fn)); if (bg_.size() > bg_max_) bg_max_ = bg_.size(); }
         cv_.notify_one();
     }
     void drain()
@@ -306,6 +307,9 @@ private:
     std::condition_variable cv_, bg_cv_;
     std::deque<std::function<void()>> bg_;
     unsigned bg_running_ = 0;
+public:
+    size_t bg_max_ = 0;                               // longest the background queue has been (debug print)
+private:
     std::vector<std::shared_ptr<Job>> active_;
     uint64_t gen_ = 0;
     bool stop_ = false;
@@ -313,6 +317,7 @@ private:
 }  // namespace
 
 static HostPool &the_pool() { static HostPool pool(host_threads()); return pool; }
+size_t pool_bg_max() { if (host_threads() <= 1) return 0; const size_t m = the_pool().bg_max_; the_pool().bg_max_ = 0; return m; }
 void pool_rebind_workers() { if (host_threads() > 1) the_pool().rebind(); }
 
 void parallel_for_impl(size_t n, const std::function<void(size_t)> &fn)

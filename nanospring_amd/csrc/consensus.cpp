@@ -60,8 +60,10 @@ std::vector<unsigned char *> g_slab_pool;
 constexpr size_t kLocalSlabs = 64, kSlabBatch = 32;
 }  // namespace
 
+std::atomic<int64_t> g_slabs_in_use{0}, g_slabs_peak{0}, g_slabs_mapped{0};     // debug print: slabs handed out now / at most / ever carved
 unsigned char *slab_acquire(size_t bytes)
 {
+    if (bytes == kSlabBytes) { const int64_t u = ++g_slabs_in_use; int64_t pk = g_slabs_peak.load(); while (u > pk && !g_slabs_peak.compare_exchange_weak(pk, u)) {} }
     if (g_no_slab_cache) return static_cast<unsigned char *>(calloc(1, bytes));
     if (t_slabs.free.empty() && bytes == kSlabBytes) {
         std::lock_guard<std::mutex> lk(g_slab_pool_m);
@@ -78,6 +80,7 @@ unsigned char *slab_acquire(size_t bytes)
         }
         unsigned char *p = t_region.p + t_region.used;
         t_region.used += bytes;
+        ++g_slabs_mapped;
         return p;
     }
     void *p = nullptr;
@@ -85,8 +88,9 @@ unsigned char *slab_acquire(size_t bytes)
     return static_cast<unsigned char *>(p);
 }
 
-void slab_release(unsigned char *p, size_t)
+void slab_release(unsigned char *p, size_t bytes)
 {
+    if (bytes == kSlabBytes) --g_slabs_in_use;
     if (g_no_slab_cache) { ::free(p); return; }
     // region-backed slabs must not reach free(): they stay in a cache (the cap only bounds posix_memalign'ed ones)
     if (!g_no_huge || t_slabs.free.size() < kMaxCachedSlabsPerThread) {

@@ -34,7 +34,7 @@ namespace nsgpu {
 namespace mm2 { extern std::atomic<uint64_t> g_step_ns[6]; }
 extern double g_finish_ms[5];
 extern double g_sketch_ms[6];
-namespace cons { extern std::atomic<uint64_t> g_emit_ns[4]; extern std::atomic<uint64_t> g_upd_ns[6]; }
+namespace cons { extern std::atomic<uint64_t> g_emit_ns[4]; extern std::atomic<uint64_t> g_upd_ns[6]; extern std::atomic<int64_t> g_slabs_in_use, g_slabs_peak, g_slabs_mapped; }
 
 using cons::read_t;
 
@@ -898,7 +898,9 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
             long rss = 0, thp = 0;
             while (fgets(line, sizeof(line), f)) { sscanf(line, "Rss: %ld kB", &rss); sscanf(line, "AnonHugePages: %ld kB", &thp); }
             fclose(f);
-            fprintf(stderr, "[cons] resident %.1f GB, of it on transparent huge pages %.1f GB\n", rss / 1048576.0, thp / 1048576.0);
+            fprintf(stderr, "[cons] resident %.1f GB, of it on transparent huge pages %.1f GB; graph slabs of %zu KB: %lld in use, peak %lld, carved %lld (%.1f GB)\n", rss / 1048576.0, thp / 1048576.0,
+                    cons::kSlabBytes >> 10, (long long)cons::g_slabs_in_use.load(), (long long)cons::g_slabs_peak.load(), (long long)cons::g_slabs_mapped.load(),
+                    cons::g_slabs_mapped.load() * (double)cons::kSlabBytes / (1u << 30));
         }
         pool_prof_print();
         fprintf(stderr, "[cons] part 2 wall-ms: wait for the DP in flight %.0f, later rounds %.0f (their DP %.0f, %d rounds), results %.0f\n", g_finish_ms[0], g_finish_ms[1],
