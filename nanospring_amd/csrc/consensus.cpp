@@ -289,6 +289,7 @@ void ContigGraph::initialize(const std::string &seed, read_t id, long pos)
 }
 
 static inline uint64_t emit_now();
+std::atomic<uint64_t> g_mp_cnt[3];    // diagnostic: main-path edges copied out by the tail re-use, calls that cut the path, path lengths at those calls
 std::atomic<uint64_t> g_upd_ns[6];    // diagnostic (NSGPU_UPDATE_STATS=1): setup, run loops, SAME op heads, inserts, tail, calls
 void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &script, ssize_t begin_offset, ssize_t end_offset, read_t id,
                                long pos, bool rc)
@@ -501,6 +502,7 @@ void ContigGraph::calculate_main_path_greedy()
             const size_t c0 = cand[ci];
             std::vector<Edge *> &saved = saved_;                         // saved[t] = old edge c0 + t, its sink = old node c0 + t + 1
             saved.assign(main_edges.begin() + c0, main_edges.end());
+            g_mp_cnt[0] += saved.size(), g_mp_cnt[1] += 1, g_mp_cnt[2] += main_edges.size();
             const std::string saved_str = main_path.substr(c0 + 1);
             Node *at = old_node(c0);
             main_edges.erase(main_edges.begin() + c0, main_edges.end());

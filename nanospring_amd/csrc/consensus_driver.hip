@@ -34,7 +34,7 @@ namespace nsgpu {
 namespace mm2 { extern std::atomic<uint64_t> g_step_ns[6]; }
 extern double g_finish_ms[5];
 extern double g_sketch_ms[6];
-namespace cons { extern std::atomic<uint64_t> g_emit_ns[4]; extern std::atomic<uint64_t> g_upd_ns[6]; extern std::atomic<int64_t> g_slabs_in_use, g_slabs_peak, g_slabs_mapped; }
+namespace cons { extern std::atomic<uint64_t> g_emit_ns[4]; extern std::atomic<uint64_t> g_upd_ns[6]; extern std::atomic<uint64_t> g_mp_cnt[3]; extern std::atomic<int64_t> g_slabs_in_use, g_slabs_peak, g_slabs_mapped; }
 
 using cons::read_t;
 
@@ -881,6 +881,9 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
     const int rc = engine_finish(c, n_threads_out);
     if (getenv("NSGPU_CONS_DEBUG")) {
         fprintf(stderr, "[cons] gpu mm_sketch wall-ms %.0f\n", c->sketch_mm_ms);
+        if (cons::g_mp_cnt[1].load())
+            fprintf(stderr, "[cons] main path (cumulative): %llu recomputes cut the path, on average at %.0f edges before its end of %.0f\n", (unsigned long long)cons::g_mp_cnt[1].load(),
+                    (double)cons::g_mp_cnt[0].load() / cons::g_mp_cnt[1].load(), (double)cons::g_mp_cnt[2].load() / cons::g_mp_cnt[1].load());
         if (cons::g_upd_ns[5].load())
             fprintf(stderr, "[cons] update_graph cpu-ms (NSGPU_UPDATE_STATS, cumulative, %llu calls): setup %.0f, SAME runs %.0f, SAME heads %.0f, inserts / deletes %.0f, tail %.0f\n",
                     (unsigned long long)cons::g_upd_ns[5].load(), cons::g_upd_ns[0] / 1e6, cons::g_upd_ns[1] / 1e6, cons::g_upd_ns[2] / 1e6, cons::g_upd_ns[3] / 1e6, cons::g_upd_ns[4] / 1e6);
