@@ -96,3 +96,16 @@ def test_seeds_repeats_ties_and_frequent_minimizers():
     for k, w in ((20, 50), (15, 10), (28, 100)):
         n_ties, _ = check_pairs(g, pairs, k, w)
         assert (k, w) != (20, 50) or n_ties > 0
+
+
+@pytest.mark.gpu
+def test_empty_batches():
+    """no pairs / no lists: both entry points return at once with empty results"""
+    import nanospring_amd as ns
+    from tests.test_chain_gpu import gpu_scores
+    g = ns.NsGpu()
+    got, mid, flags, avg = gpu_seeds(g, [np.zeros((0, 2), dtype=np.uint64)], [], [])
+    assert got == [] and len(mid) == 0
+    assert gpu_scores(g, []) == []
+    got, mid, flags, avg = gpu_seeds(g, [np.zeros((0, 2), dtype=np.uint64)], [np.zeros((0, 2), dtype=np.uint64)], [0])
+    assert len(got) == 1 and len(got[0]) == 0 and flags[0] == 0 and mid[0] == 1
