@@ -135,6 +135,40 @@ int role_stream_create(hipStream_t *st, const char *role)
 }
 }  // namespace nsgpu
 
+namespace nsgpu {
+// The host copy of the reads that the contig engine works from is the folded ASCII text (1 B/base) by default.  For inputs where that
+// matters -- every rank of a multi-GPU run holds ALL reads: 50 GB per rank at BASELINE cfg4 -- it can be the packed rows instead,
+// copied back from HBM once: NSGPU_PACKED_MIRROR=1 (0: never; unset: from 16 Gbases on).
+int mirror_finalize(nsgpu_ctx *c)
+{
+    static const char *e = getenv("NSGPU_PACKED_MIRROR");
+    const bool want = e ? atoi(e) != 0 : c->reads.n_bases >= (16ull << 30);
+    c->packed_mirror = false;
+    c->h_packed.clear(), c->h_packed.shrink_to_fit();
+    if (!want || c->reads.n == 0) return NSGPU_OK;
+    c->h_packed.resize(c->reads.packed_bytes + 64);
+    NS_HIP(hipMemcpyAsync(c->h_packed.data(), c->reads.packed.p, c->reads.packed_bytes, hipMemcpyDeviceToHost, c->stream));
+    NS_HIP(stream_wait(c->stream));
+    c->h_bases.clear(), c->h_bases.shrink_to_fit();
+    c->packed_mirror = true;
+    return NSGPU_OK;
+}
+// read r as the engine sees it (folded A/T/C/G): a pointer into the ASCII mirror, or the packed row decoded into `buf`
+const char *mirror_read(const nsgpu_ctx *c, uint32_t r, std::string &buf)
+{
+    if (!c->packed_mirror) return c->h_bases.data() + c->h_off[r];
+    static const struct Lut { uint32_t w[256]; Lut() { static const char dna[4] = {'A', 'T', 'C', 'G'};
+        for (int b = 0; b < 256; ++b) { char t[4] = {dna[b >> 6 & 3], dna[b >> 4 & 3], dna[b >> 2 & 3], dna[b & 3]}; memcpy(&w[b], t, 4); } } } lut;
+    const size_t L = (size_t)(c->h_off[r + 1] - c->h_off[r]);
+    buf.resize((L + 3) & ~(size_t)3);
+    const uint8_t *row = c->h_packed.data() + c->reads.h_poff[r];
+    char *d = &buf[0];
+    for (size_t k = 0; k < (L + 3) / 4; ++k) memcpy(d + 4 * k, &lut.w[row[k]], 4);
+    buf.resize(L);
+    return buf.data();
+}
+}  // namespace nsgpu
+
 extern "C" {
 
 const char *nsgpu_last_error(void) { return g_err; }
@@ -268,7 +302,7 @@ int nsgpu_load_reads_ascii(nsgpu_ctx *c, const char *bases, const uint64_t *off,
     for (uint32_t r = 0; r <= n; ++r) c->h_off[r] = off[r] - off[0];
     const char *src = bases + (n ? off[0] : 0);
     for (uint64_t i = 0; i < total; ++i) c->h_bases[i] = dna[(src[i] & 2) | ((src[i] & 4) >> 2)];
-    return NSGPU_OK;
+    return mirror_finalize(c);
 }
 
 int nsgpu_load_reads_packed(nsgpu_ctx *c, const uint8_t *packed, const uint64_t *byte_off, const uint32_t *len, uint32_t n)
@@ -298,7 +332,7 @@ int nsgpu_load_reads_packed(nsgpu_ctx *c, const uint8_t *packed, const uint64_t 
         }
         c->have_cons = false;
     }
-    return NSGPU_OK;
+    return mirror_finalize(c);
 }
 
 uint32_t nsgpu_num_reads(const nsgpu_ctx *c) { return c ? c->reads.n : 0; }

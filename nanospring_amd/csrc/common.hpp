@@ -48,6 +48,8 @@ hipError_t stream_wait(hipStream_t s);
 // a non-blocking stream for one of the roles "sketch", "seeds" (seeding + chaining kernels), "dp_side" (long DP problems), "dp" (DP workspaces 1-3):
 // priority from NSGPU_PRIO_<ROLE>=lo|mid|hi, else the role's measured default (api.hip)
 int role_stream_create(hipStream_t *st, const char *role);
+int mirror_finalize(nsgpu_ctx *c);                                        // api.hip: ASCII or packed host copy of the reads
+const char *mirror_read(const nsgpu_ctx *c, uint32_t r, std::string &buf);
 hipError_t stream_wait_short(hipStream_t s);     // busy-wait (the runtime's): for waits inside a chain of short kernels on a slot's critical path
 
 // Growable device allocation (never shrinks). No hipMalloc happens inside a
@@ -196,6 +198,10 @@ struct nsgpu_ctx {
     // host copy of the reads as ReadData::getRead returns them (A/T/C/G after the 2-bit folding)
     std::vector<char> h_bases;
     std::vector<uint64_t> h_off;
+    // ... or, for large inputs (NSGPU_PACKED_MIRROR, api.hip mirror_finalize), the 2-bit rows as they lie in HBM (0.25 B/base): the
+    // engine decodes a read when it copies it anyway (seed read, candidate, emission walk)
+    std::vector<uint8_t> h_packed;
+    bool packed_mirror = false;
     // consensus run
     bool have_cons = false;
     uint32_t read_id_base = 0;   // global id of local read 0 (multi-GPU shards)

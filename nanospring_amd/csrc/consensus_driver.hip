@@ -97,7 +97,8 @@ struct Driver {
     std::vector<uint8_t> in_graph, rep;
     std::vector<Builder> B;
 
-    const char *read_ptr(read_t r) const { return c->h_bases.data() + c->h_off[r]; }
+    // read r as ReadData::getRead returns it; with the packed host mirror decoded into a per-thread buffer (valid until the thread's next call)
+    const char *read_ptr(read_t r) const { static thread_local std::string buf; return mirror_read(c, r, buf); }
     size_t read_len(read_t r) const { return (size_t)(c->h_off[r + 1] - c->h_off[r]); }
 
     // createGraph (src/Consensus.cpp:388-403) for the seed read r the builder was granted
@@ -1181,7 +1182,8 @@ int nsgpu_consensus_verify(nsgpu_ctx *c, uint64_t *n_bad_out)
             if (pr.first < c->read_id_base || r >= N || seen[r]) { ++bad; continue; }
             seen[r] = 1;
             const size_t L = (size_t)(c->h_off[r + 1] - c->h_off[r]);
-            if (pr.second.size() != L || memcmp(pr.second.data(), c->h_bases.data() + c->h_off[r], L) != 0) ++bad;
+            std::string rbuf;
+            if (pr.second.size() != L || memcmp(pr.second.data(), mirror_read(c, r, rbuf), L) != 0) ++bad;
         }
     }
     if (c->cons_n_reads_out == N)                       // a multi-GPU rank only holds its builders' share of the reads

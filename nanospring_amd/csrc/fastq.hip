@@ -156,6 +156,7 @@ int load_fastq(nsgpu_ctx *c, const char *text, size_t n_bytes, uint32_t *n_reads
     });
     NS_HIP(stream_wait(st));
     NS_HIP(hipEventElapsedTime(&c->timing.pack_ms, c->t_kernel.a, c->t_kernel.b));
+    NS_TRY(mirror_finalize(c));
     c->fastq_ms = now_ms() - t0;
     if (n_reads_out) *n_reads_out = n_reads;
     return NSGPU_OK;
@@ -292,7 +293,7 @@ extern "C" int nsgpu_load_fastq_end(nsgpu_ctx *c, uint32_t *n_reads_out)
     c->have_sketch = c->have_index = c->have_filter_all = c->have_cons = false;
     I = FastqIngest();
     if (n_reads_out) *n_reads_out = (uint32_t)n;
-    return NSGPU_OK;
+    return mirror_finalize(c);       // (a packed mirror per chunk, so that the text of a large input never lies in memory whole, is the next step)
 }
 
 extern "C" int nsgpu_load_fastq(nsgpu_ctx *c, const char *text, size_t n_bytes, uint32_t *n_reads_out)

@@ -224,3 +224,38 @@ def test_repeat_rich_genome_many_builders_lossless():
     g, st, streams, md = run(bases, off, 48, 2)
     assert (streams, md) == outs[2]
     g.close()
+
+
+MIRROR_WORKER = r'''
+import hashlib, sys
+sys.path.insert(0, %(root)r)
+import nanospring_amd as ns
+from nanospring_amd.filter import STREAMS
+bases, off = ns.synth_reads(9, 120000, 500, 2500.0)
+for nb in (1, 32):
+    g = ns.NsGpu()
+    g.load_reads((bases, off))
+    g.sketch(ns.mt19937_64_salts(60), fetch=False)
+    g.build_index()
+    st = ns.consensus_run(g, nb, 2)
+    h = hashlib.sha256()
+    for t in range(2):
+        for k in STREAMS:
+            h.update(ns.consensus_stream(g, t, k))
+    print("HASH", nb, h.hexdigest(), st["n_contigs"], ns.consensus_verify(g))
+    g.close()
+'''
+
+
+def test_packed_host_mirror_gives_the_same_streams():
+    """NSGPU_PACKED_MIRROR=1: the engine works from the 2-bit rows copied back from HBM instead of the ASCII text of the reads
+    (0.25 instead of 1 B/base of host memory per rank) -- same streams, lossless."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mode in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", MIRROR_WORKER % {"root": root}], env=dict(os.environ, NSGPU_PACKED_MIRROR=mode), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[mode] = [l.split()[1:] for l in r.stdout.splitlines() if l.startswith("HASH")]
+        assert len(out[mode]) == 2 and all(x[-1] == "0" for x in out[mode]), out[mode]
+    assert out["0"] == out["1"]
