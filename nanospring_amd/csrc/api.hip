@@ -139,10 +139,10 @@ namespace nsgpu {
 // The host copy of the reads that the contig engine works from is the folded ASCII text (1 B/base) by default.  For inputs where that
 // matters -- every rank of a multi-GPU run holds ALL reads: 50 GB per rank at BASELINE cfg4 -- it can be the packed rows instead,
 // copied back from HBM once: NSGPU_PACKED_MIRROR=1 (0: never; unset: from 16 Gbases on).
-int mirror_finalize(nsgpu_ctx *c)
+int mirror_finalize(nsgpu_ctx *c, bool force_packed)
 {
     static const char *e = getenv("NSGPU_PACKED_MIRROR");
-    const bool want = e ? atoi(e) != 0 : c->reads.n_bases >= (16ull << 30);
+    const bool want = force_packed || (e ? atoi(e) != 0 : c->reads.n_bases >= (16ull << 30));
     c->packed_mirror = false;
     c->h_packed.clear(), c->h_packed.shrink_to_fit();
     if (!want || c->reads.n == 0) return NSGPU_OK;

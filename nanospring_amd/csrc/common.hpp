@@ -48,7 +48,7 @@ hipError_t stream_wait(hipStream_t s);
 // a non-blocking stream for one of the roles "sketch", "seeds" (seeding + chaining kernels), "dp_side" (long DP problems), "dp" (DP workspaces 1-3):
 // priority from NSGPU_PRIO_<ROLE>=lo|mid|hi, else the role's measured default (api.hip)
 int role_stream_create(hipStream_t *st, const char *role);
-int mirror_finalize(nsgpu_ctx *c);                                        // api.hip: ASCII or packed host copy of the reads
+int mirror_finalize(nsgpu_ctx *c, bool force_packed = false);                                      // api.hip: ASCII or packed host copy of the reads
 const char *mirror_read(const nsgpu_ctx *c, uint32_t r, std::string &buf);
 hipError_t stream_wait_short(hipStream_t s);     // busy-wait (the runtime's): for waits inside a chain of short kernels on a slot's critical path
 

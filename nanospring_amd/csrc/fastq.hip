@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void fq_records_kernel(const uint32_t *__restr
 
 }  // namespace
 
-int load_fastq(nsgpu_ctx *c, const char *text, size_t n_bytes, uint32_t *n_reads_out)
+// mirror: build the host copy of the reads (false: the chunked ingest, which wants the 2-bit rows only once its input is large)
+int load_fastq(nsgpu_ctx *c, const char *text, size_t n_bytes, uint32_t *n_reads_out, bool mirror = true)
 {
     NS_CHECK(n_bytes > 0, NSGPU_ERR_ARG, "nsgpu_load_fastq: empty input (the reference asserts numReads != 0, src/ReadData.cpp:141)");
     NS_CHECK(n_bytes < 0xFFFFFF00ull, NSGPU_ERR_RANGE, "nsgpu_load_fastq: at most 4 GiB of text per call");
@@ -148,15 +149,18 @@ int load_fastq(nsgpu_ctx *c, const char *text, size_t n_bytes, uint32_t *n_reads
     uint64_t tot = 0;
     for (uint32_t r = 0; r < n_reads; ++r) { c->h_off[r] = tot; tot += len[r]; }
     c->h_off[n_reads] = tot;
-    c->h_bases.resize(tot + 1);
-    par_for(n_reads, [&](size_t r) {
-        const char *src = text + start[r];
-        char *dst = c->h_bases.data() + c->h_off[r];
-        for (uint32_t i = 0; i < len[r]; ++i) dst[i] = dna[(src[i] & 2) | ((src[i] & 4) >> 2)];
-    });
+    c->h_bases.clear();
+    if (mirror) {
+        c->h_bases.resize(tot + 1);
+        par_for(n_reads, [&](size_t r) {
+            const char *src = text + start[r];
+            char *dst = c->h_bases.data() + c->h_off[r];
+            for (uint32_t i = 0; i < len[r]; ++i) dst[i] = dna[(src[i] & 2) | ((src[i] & 4) >> 2)];
+        });
+    }
     NS_HIP(stream_wait(st));
     NS_HIP(hipEventElapsedTime(&c->timing.pack_ms, c->t_kernel.a, c->t_kernel.b));
-    NS_TRY(mirror_finalize(c));
+    if (mirror) NS_TRY(mirror_finalize(c));
     c->fastq_ms = now_ms() - t0;
     if (n_reads_out) *n_reads_out = n_reads;
     return NSGPU_OK;
@@ -172,8 +176,9 @@ struct FastqIngest {
     uint64_t row_bytes = 0;
     std::vector<uint64_t> poff;         // row offsets of the accumulated reads
     std::vector<uint32_t> len;
-    std::vector<char> h_bases;          // folded host mirror
+    std::vector<char> h_bases;          // folded host mirror (until the input is large enough for the packed mirror: keep_ascii)
     std::vector<uint64_t> h_off{0};
+    bool keep_ascii = true;
     bool active = false;
 };
 
@@ -195,7 +200,11 @@ static int ingest_text(nsgpu_ctx *c, FastqIngest &I, const char *text, size_t n_
     std::vector<uint64_t> ho;
     hb.swap(c->h_bases), ho.swap(c->h_off);
     uint32_t n = 0;
-    int rc = load_fastq(c, text, n_bytes, &n);
+    // the ASCII text of the reads is kept only while the packed mirror is not (going to be) in use: NSGPU_PACKED_MIRROR, or the
+    // accumulated input past the automatic threshold (api.hip mirror_finalize)
+    static const char *pm = getenv("NSGPU_PACKED_MIRROR");
+    if (pm ? atoi(pm) != 0 : I.h_off.back() >= (16ull << 30)) { I.keep_ascii = false; I.h_bases.clear(); I.h_bases.shrink_to_fit(); }
+    int rc = load_fastq(c, text, n_bytes, &n, I.keep_ascii);
     if (rc == NSGPU_OK) {
         SeqStore &S = c->reads;
         // grow-with-copy of the accumulated rows
@@ -216,7 +225,7 @@ static int ingest_text(nsgpu_ctx *c, FastqIngest &I, const char *text, size_t n_
             I.len.insert(I.len.end(), S.h_len.begin(), S.h_len.end());
             I.row_bytes += S.packed_bytes;
             const uint64_t base = I.h_off.back();
-            I.h_bases.insert(I.h_bases.end(), c->h_bases.begin(), c->h_bases.begin() + (ptrdiff_t)c->h_off[n]);
+            if (I.keep_ascii) I.h_bases.insert(I.h_bases.end(), c->h_bases.begin(), c->h_bases.begin() + (ptrdiff_t)c->h_off[n]);
             for (uint32_t r = 1; r <= n; ++r) I.h_off.push_back(base + c->h_off[r]);
         }
     }
@@ -291,9 +300,10 @@ extern "C" int nsgpu_load_fastq_end(nsgpu_ctx *c, uint32_t *n_reads_out)
     c->h_bases.push_back(0);
     c->h_off.swap(I.h_off);
     c->have_sketch = c->have_index = c->have_filter_all = c->have_cons = false;
+    const bool force_packed = !I.keep_ascii;
     I = FastqIngest();
     if (n_reads_out) *n_reads_out = (uint32_t)n;
-    return mirror_finalize(c);       // (a packed mirror per chunk, so that the text of a large input never lies in memory whole, is the next step)
+    return mirror_finalize(c, force_packed);
 }
 
 extern "C" int nsgpu_load_fastq(nsgpu_ctx *c, const char *text, size_t n_bytes, uint32_t *n_reads_out)

@@ -244,6 +244,20 @@ for nb in (1, 32):
             h.update(ns.consensus_stream(g, t, k))
     print("HASH", nb, h.hexdigest(), st["n_contigs"], ns.consensus_verify(g))
     g.close()
+# the same reads through the chunked FASTQ ingest (pieces cut inside records)
+b = bytes(bases)
+text = b"".join(b"@r%%d\n" %% i + b[int(off[i]):int(off[i + 1])] + b"\n+\n" + b"I" * int(off[i + 1] - off[i]) + b"\n" for i in range(len(off) - 1))
+g = ns.NsGpu()
+assert g.load_fastq_chunks([text[:1000003], text[1000003:1700001], text[1700001:]]) == len(off) - 1
+g.sketch(ns.mt19937_64_salts(60), fetch=False)
+g.build_index()
+st = ns.consensus_run(g, 32, 2)
+h = hashlib.sha256()
+for t in range(2):
+    for k in STREAMS:
+        h.update(ns.consensus_stream(g, t, k))
+print("HASH", 32, h.hexdigest(), st["n_contigs"], ns.consensus_verify(g))
+g.close()
 '''
 
 
@@ -257,5 +271,6 @@ def test_packed_host_mirror_gives_the_same_streams():
         r = subprocess.run([sys.executable, "-c", MIRROR_WORKER % {"root": root}], env=dict(os.environ, NSGPU_PACKED_MIRROR=mode), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         out[mode] = [l.split()[1:] for l in r.stdout.splitlines() if l.startswith("HASH")]
-        assert len(out[mode]) == 2 and all(x[-1] == "0" for x in out[mode]), out[mode]
+        assert len(out[mode]) == 3 and all(x[-1] == "0" for x in out[mode]), out[mode]
+        assert out[mode][1] == out[mode][2]                      # FASTQ chunks == load_reads
     assert out["0"] == out["1"]
