@@ -22,6 +22,16 @@ kind, seed = sys.argv[1], int(sys.argv[2])
 rng = np.random.RandomState(seed)
 if kind == "iid":
     bases, off = ns.synth_reads(seed, 60000, 260, 3500.0)
+elif kind == "homopolymer":                               # low-complexity consensus at depth: at most forks a side branch starts with the consensus's next base,
+    g = "".join(c * int(rng.randint(1, 4)) for c in make_genome(rng, 12000))      # and the lists of reads on such branches grow long (the emission's tables give up: kAmbComplex)
+    reads = []
+    for _ in range(420):
+        ln = int(max(400, rng.gamma(2.0, 1200.0)))
+        st = rng.randint(0, max(1, len(g) - ln))
+        s = mutate(rng, g[st:st + ln], 0.05)
+        reads.append(revcomp(s) if rng.randint(2) else s)
+    bases = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    off = np.zeros(len(reads) + 1, dtype=np.uint64); off[1:] = np.cumsum([len(r) for r in reads])
 elif kind == "long":                                       # cfg2-like: 8 kb reads at 20x, contigs of a dozen reads and more
     bases, off = ns.synth_reads(seed, 800 * 8000 // 20, 800, 8000.0)   # seed 1: holds a left-hanging read that once broke the bookkeeping
 else:
@@ -64,7 +74,7 @@ def run(kind, seed, oracle=False, **env):
     return line[1], int(line[2]), int(line[3])
 
 
-@pytest.mark.parametrize("kind,seed", [("iid", 3), ("repeats", 4), ("repeats", 5), ("long", 1)])
+@pytest.mark.parametrize("kind,seed", [("iid", 3), ("repeats", 4), ("repeats", 5), ("long", 1), ("homopolymer", 7)])
 def test_shortcuts_change_nothing(kind, seed):
     fast = run(kind, seed, oracle=True, NSGPU_SPLICE_CHECK="1")
     literal = run(kind, seed, NSGPU_NO_CYCLE_SKIP="1", NSGPU_NO_TAIL_SPLICE="1", NSGPU_NO_RUN_FASTPATH="1")
