@@ -85,4 +85,10 @@ def test_chain_scores_of_synthetic_lists(mci):
     lists.append(synthetic(rng, 9000, "dense"))          # the skip counter reaches max_skip all the time
     lists.append(synthetic(rng, 14000, "diagonals"))     # longer than the LDS variant takes: f / p / marks in global memory
     lists.append(synthetic(rng, 13500, "dense"))
+    wide = synthetic(rng, 900, "diagonals")               # coordinates above 2^31 (a sequence id in the upper half of x): the general kernel
+    wide[:, 0] += np.uint64(5 << 32)
+    lists.append(wide)
+    far = synthetic(rng, 300, "colinear")
+    far[:, 0] += np.uint64(3000000000)
+    lists.append(far)
     compare(g, lists, mci)
