@@ -268,7 +268,7 @@ void nsgpu_destroy(nsgpu_ctx *c)
         w.h_pairs.release(); w.h_res.release(); w.h_ref.release();
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }
-    c->pin_small.release(); c->pin_foff.release(); c->pin_fids.release();
+    c->pin_small.release(); c->pin_foff.release(); c->pin_fids.release(); c->pin_wq.release(); c->pin_wq_out.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

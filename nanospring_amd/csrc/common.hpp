@@ -186,6 +186,7 @@ struct nsgpu_ctx {
         double ms_wait = 0; uint64_t calls = 0, pairs = 0, fallbacks = 0;
         hipStream_t stream = nullptr;
     } seed_ws[9];
+    nsgpu::PinBuf pin_wq, pin_wq_out;                                // the engine's window queries: staging of the strings / candidate lists as the last kernel writes them
     nsgpu::PinBuf pin_small, pin_foff, pin_fids;                     // pinned landing zones: the filter's scalars / the engine's candidate CSR
     double sketch_mm_ms = 0;                                         // wall of the batched mm_sketch calls
     std::mutex stat_m;                                               // guards the ksw_* / aln_* counters below
@@ -222,6 +223,7 @@ int launch_sketch(nsgpu_ctx *c, const SeqStore &st, uint64_t *d_out_fwd, uint64_
 int launch_sketch_range(nsgpu_ctx *c, const SeqStore &st, uint32_t lo, uint32_t hi, uint64_t *d_out_fwd);   // rows lo..hi only
 int launch_repetitive(nsgpu_ctx *c, const SeqStore &st, uint8_t *d_flags);
 int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, uint32_t nq, bool interleave);
+int run_window_queries_fast(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq, const uint64_t *&off_out, const uint32_t *&ids_out, bool *redo);
 // index.hip
 int build_index(nsgpu_ctx *c);
 int scan_u32_to_u64(nsgpu_ctx *c, const uint32_t *d_in, uint64_t *d_out, uint32_t n);  // exclusive, n+1 outputs

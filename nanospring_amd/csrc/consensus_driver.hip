@@ -310,6 +310,7 @@ struct Engine {
     std::vector<uint32_t> sk_ref;
     std::vector<uint64_t> mz_off[2];                // minimizer offsets of the two halves of a sketch batch
     std::vector<uint64_t> stage_off;                // offsets of the builders' consensus minimizer lists in the seeding kernel's staging buffer
+    uint64_t n_wq_exact = 0;                          // window-query batches that went the exact multi-step way
     int deferred_fresh = -1;                          // group whose freshly started contigs take their first steps with the next host phase
     AlignBatch ab[kMaxGroups];                        // alignment batch of each group, DP kernels in flight between part 1 and part 2
     std::vector<uint32_t> fwho;                    // builders of the window-query batch
@@ -649,19 +650,28 @@ static int engine_batches_finish(nsgpu_ctx *c, int group)
             E->qbuf.clear(); E->qoff.assign(1, 0);
             for (uint32_t bi : who) for (int s = 0; s < 2; ++s) { E->qbuf += D.B[bi].win[s]; E->qoff.push_back(E->qbuf.size()); }
             const uint32_t nq = (uint32_t)(2 * who.size());
-            c->filter_stats = false;                       // nobody reads the match totals of the engine's window queries
-            const int frc = filter_strings_device(c, E->qbuf.data(), E->qoff.data(), nq);
-            c->filter_stats = true;
-            NS_TRY(frc);
-            E->foff.resize((size_t)nq + 1);
-            E->fids.resize(c->f_total + 1);
-            NS_TRY(c->pin_foff.reserve(((size_t)nq + 1) * 8));
-            NS_TRY(c->pin_fids.reserve((c->f_total + 1) * 4));
-            NS_HIP(hipMemcpyAsync(c->pin_foff.p, c->f_off.p, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-            if (c->f_total) NS_HIP(hipMemcpyAsync(c->pin_fids.p, c->f_ids.p, c->f_total * 4, hipMemcpyDeviceToHost, c->stream));
-            NS_HIP(stream_wait_short(c->stream));
-            memcpy(E->foff.data(), c->pin_foff.p, ((size_t)nq + 1) * 8);
-            if (c->f_total) memcpy(E->fids.data(), c->pin_fids.p, c->f_total * 4);
+            // one launch sequence, one wait, candidate lists straight into pinned memory (run_window_queries_fast); the exact
+            // multi-step path when a buffer sized in advance did not fit (it grows them), or with NSGPU_WQ_EXACT=1
+            static const bool wq_exact = getenv("NSGPU_WQ_EXACT") != nullptr;
+            const uint64_t *foff = nullptr;
+            const uint32_t *fids = nullptr;
+            bool redo = wq_exact;
+            if (!wq_exact) NS_TRY(run_window_queries_fast(c, E->qbuf.data(), E->qoff.data(), nq, foff, fids, &redo));
+            if (redo) {
+                c->filter_stats = false;                       // nobody reads the match totals of the engine's window queries
+                const int frc = filter_strings_device(c, E->qbuf.data(), E->qoff.data(), nq);
+                c->filter_stats = true;
+                NS_TRY(frc);
+                NS_TRY(c->pin_foff.reserve(((size_t)nq + 1) * 8));
+                NS_TRY(c->pin_fids.reserve((c->f_total + 1) * 4));
+                NS_HIP(hipMemcpyAsync(c->pin_foff.p, c->f_off.p, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+                if (c->f_total) NS_HIP(hipMemcpyAsync(c->pin_fids.p, c->f_ids.p, c->f_total * 4, hipMemcpyDeviceToHost, c->stream));
+                NS_HIP(stream_wait_short(c->stream));
+                foff = c->pin_foff.as<uint64_t>(), fids = c->pin_fids.as<uint32_t>();
+                ++E->n_wq_exact;
+            }
+            E->foff.assign(foff, foff + nq + 1);
+            E->fids.assign(fids, fids + c->f_total);
             for (size_t w = 0; w < who.size(); ++w) {
                 Builder &b = D.B[who[w]];
                 for (int s = 0; s < 2; ++s) b.cand[s].assign(E->fids.begin() + E->foff[2 * w + s], E->fids.begin() + E->foff[2 * w + s + 1]);
@@ -869,6 +879,7 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
         for (AlignBatch &ab : E->ab) chain_ms += ab.chain_ms, ab.chain_ms = 0;
         double sw = 0; uint64_t sn = 0, sp = 0, sf = 0;
         for (nsgpu_ctx::SeedWs &w : c->seed_ws) sw += w.ms_wait, sn += w.calls, sp += w.pairs, sf += w.fallbacks, w.ms_wait = 0, w.calls = w.pairs = w.fallbacks = 0;
+        fprintf(stderr, "[cons] window-query batches redone the exact multi-step way (a buffer sized in advance did not fit): %llu\n", (unsigned long long)E->n_wq_exact);
         fprintf(stderr, "[cons] index + seeds on the GPU: %llu launches, %llu pairs, wait %.0f ms wall; %llu pairs handed back to the host code\n", (unsigned long long)sn,
                 (unsigned long long)sp, sw, (unsigned long long)sf);
         double cs = 0, ce = 0, cw = 0; uint64_t cn = 0;

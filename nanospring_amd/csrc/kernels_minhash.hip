@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64) void filter_count_kernel(uint32_t nq, uint32_t 
                                                           const uint32_t *__restrict__ cnt_in, const uint32_t *__restrict__ qm,
                                                           const uint64_t *__restrict__ soff, uint32_t *__restrict__ staging,
                                                           uint32_t *__restrict__ qcnt, uint32_t *__restrict__ ovf_list,
-                                                          uint32_t *__restrict__ ctrl)
+                                                          uint32_t *__restrict__ ctrl, uint64_t staging_cap)
 {
     __shared__ uint32_t s_ids[F_CAP];
     __shared__ uint32_t s_off[256];
@@ -343,6 +343,9 @@ __global__ __launch_bounds__(64) void filter_count_kernel(uint32_t nq, uint32_t 
     for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
         const uint32_t M = qm[q];
         if (M == 0) { if (lane == 0) qcnt[q] = 0; continue; }
+        // (the single-wait path sizes the staging area before it knows the total: a query whose slice does not fit is dropped and
+        // the batch flagged -- the caller redoes it the exact way)
+        if (soff[q + 1] > staging_cap) { if (lane == 0) { qcnt[q] = 0; ctrl[1] = 1; } continue; }
         if (M > F_CAP) {
             if (lane == 0) { const uint32_t slot = atomicAdd(&ctrl[0], 1u); ovf_list[slot] = q; qcnt[q] = 0; }
             continue;
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(256) void filter_heavy_kernel(uint32_t n, uint32_t 
                                                            const uint32_t *__restrict__ lb_in, const uint32_t *__restrict__ cnt_in,
                                                            const uint64_t *__restrict__ soff, uint32_t *__restrict__ staging,
                                                            uint32_t *__restrict__ qcnt, const uint32_t *__restrict__ ovf_list,
-                                                           const uint32_t *__restrict__ ctrl, uint32_t *__restrict__ counters)
+                                                           uint32_t *__restrict__ ctrl, uint32_t *__restrict__ counters, uint64_t staging_cap)
 {
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_total;
@@ -420,6 +423,7 @@ __global__ __launch_bounds__(256) void filter_heavy_kernel(uint32_t n, uint32_t 
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t oi = blockIdx.x; oi < n_ovf; oi += gridDim.x) {
         const uint32_t q = ovf_list[oi];
+        if (soff[q + 1] > staging_cap) { if (threadIdx.x == 0) ctrl[1] = 1; continue; }
         for (uint32_t l = 0; l < n; ++l) {
             const uint32_t c = cnt_in[(size_t)q * n + l];
             const uint32_t *src = idx_ids + (size_t)l * N + lb_in[(size_t)q * n + l];
@@ -455,11 +459,14 @@ __global__ __launch_bounds__(256) void filter_heavy_kernel(uint32_t n, uint32_t 
 
 __global__ __launch_bounds__(256) void filter_compact_kernel(uint32_t nq, const uint64_t *__restrict__ soff, const uint32_t *__restrict__ staging,
                                                              const uint32_t *__restrict__ qcnt, const uint64_t *__restrict__ off,
-                                                             uint32_t *__restrict__ ids)
+                                                             uint32_t *__restrict__ ids, uint64_t ids_cap, uint64_t *__restrict__ off_copy, uint32_t *__restrict__ ctrl)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    // (off_copy: the offsets next to the ids, e.g. both in pinned host memory; ids_cap: a destination sized before the total was known)
+    if (off_copy) for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q <= nq; q += gridDim.x * blockDim.x) off_copy[q] = off[q];
+    if (off[nq] > ids_cap) { if (blockIdx.x == 0 && threadIdx.x == 0) ctrl[2] = 1; return; }
     for (uint32_t q = wave_global; q < nq; q += n_waves) {
         const uint32_t c = qcnt[q];
         const uint32_t *src = staging + soff[q];
@@ -510,7 +517,7 @@ int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, 
     {
         uint32_t grid = nq < 262144u ? nq : 262144u;
         hipLaunchKernelGGL(filter_count_kernel, dim3(grid), dim3(64), 0, c->stream, nq, n, thr1, N, c->idx_ids.as<uint32_t>(), lb, cnt, qm, soff,
-                           c->f_pool.as<uint32_t>(), qcnt, c->f_ovf_list.as<uint32_t>(), c->f_ctrl.as<uint32_t>());
+                           c->f_pool.as<uint32_t>(), qcnt, c->f_ovf_list.as<uint32_t>(), c->f_ctrl.as<uint32_t>(), ~0ull);
         NS_HIP(hipGetLastError());
     }
     ps[1] = 0;
@@ -525,7 +532,7 @@ int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, 
             NS_HIP(hipMemsetAsync(c->f_ovf_cnt.p, 0, c->f_ovf_cnt.cap, c->stream));
         }
         hipLaunchKernelGGL(filter_heavy_kernel, dim3(wgs), dim3(256), 0, c->stream, n, thr1, N, c->idx_ids.as<uint32_t>(), lb, cnt, soff,
-                           c->f_pool.as<uint32_t>(), qcnt, c->f_ovf_list.as<uint32_t>(), c->f_ctrl.as<uint32_t>(), c->f_ovf_cnt.as<uint32_t>());
+                           c->f_pool.as<uint32_t>(), qcnt, c->f_ovf_list.as<uint32_t>(), c->f_ctrl.as<uint32_t>(), c->f_ovf_cnt.as<uint32_t>(), ~0ull);
         NS_HIP(hipGetLastError());
     }
     NS_TRY(scan_u32_to_u64(c, qcnt, c->f_off.as<uint64_t>(), nq));
@@ -537,7 +544,7 @@ int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, 
         uint32_t grid = (nq + 3) / 4;
         if (grid > 65536u) grid = 65536u;
         hipLaunchKernelGGL(filter_compact_kernel, dim3(grid), dim3(256), 0, c->stream, nq, soff, c->f_pool.as<uint32_t>(), qcnt,
-                           c->f_off.as<uint64_t>(), c->f_ids.as<uint32_t>());
+                           c->f_off.as<uint64_t>(), c->f_ids.as<uint32_t>(), ~0ull, (uint64_t *)nullptr, c->f_ctrl.as<uint32_t>());
         NS_HIP(hipGetLastError());
     }
     NS_HIP(hipEventRecord(c->t_kernel.b, c->stream));
@@ -555,6 +562,111 @@ int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, 
     if (m_total) m_total = ps[3];
     NS_HIP(hipEventElapsedTime(&c->timing.filter_kernel_ms, c->t_kernel.a, c->t_kernel.b));
     c->timing.filter_matches = m_total;
+    return NSGPU_OK;
+}
+
+
+// The contig engine's window queries with ONE host wait: strings staged through one pinned buffer, pack -> sketch -> search ->
+// count -> heavy -> compact back to back, candidate lists (offsets + ids) written into pinned host memory by the last kernel.
+// The buffers whose size depends on the data (staging area of the matches, the id list) keep their high-water capacity; a batch
+// that does not fit is flagged by the kernels and redone by the exact multi-step path (`*redo` = true), which also grows them.
+// run_filter above asks the device for three sizes and for the overflow count on the way: five round trips of ~0.15 ms per batch.
+int run_window_queries_fast(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq, const uint64_t *&off_out, const uint32_t *&ids_out, bool *redo)
+{
+    *redo = false;
+    off_out = nullptr, ids_out = nullptr;
+    const uint32_t n = c->prm.n, N = c->reads.n;
+    const uint32_t thr1 = c->prm.overlap_sketch_thr ? c->prm.overlap_sketch_thr : 1u;
+    NS_CHECK(nq > 0, NSGPU_ERR_ARG, "run_window_queries_fast: no queries");
+    // one pinned staging block: ascii | aoff | poff | len
+    SeqStore &st = c->queries;
+    const uint64_t total = qoff[nq] - qoff[0];
+    const size_t o_aoff = (total + 15) & ~(size_t)15, o_poff = o_aoff + ((size_t)nq + 1) * 8, o_len = o_poff + ((size_t)nq + 1) * 8, stage_bytes = o_len + (size_t)nq * 4 + 16;
+    NS_TRY(c->pin_wq.reserve(stage_bytes));
+    uint8_t *h = c->pin_wq.as<uint8_t>();
+    uint64_t *h_aoff = reinterpret_cast<uint64_t *>(h + o_aoff), *h_poff = reinterpret_cast<uint64_t *>(h + o_poff);
+    uint32_t *h_len = reinterpret_cast<uint32_t *>(h + o_len);
+    memcpy(h, strs + qoff[0], total);
+    st.n = nq;
+    st.h_len.resize(nq), st.h_poff.resize((size_t)nq + 1);
+    uint64_t po = 0, nb = 0;
+    uint32_t mx = 0;
+    for (uint32_t q = 0; q < nq; ++q) {
+        const uint64_t L = qoff[q + 1] - qoff[q];
+        NS_CHECK(L <= 0xFFFFFFF0ull, NSGPU_ERR_RANGE, "window %u longer than 2^32-16 bases", q);
+        h_aoff[q] = qoff[q] - qoff[0], h_poff[q] = po, h_len[q] = (uint32_t)L;
+        st.h_poff[q] = po, st.h_len[q] = (uint32_t)L;
+        po += ((((uint64_t)L + 3) / 4 + 15) & ~(uint64_t)15) + 16, nb += L, mx = std::max(mx, (uint32_t)L);
+    }
+    h_aoff[nq] = total, h_poff[nq] = po, st.h_poff[nq] = po;
+    st.packed_bytes = po, st.n_bases = nb, st.max_len = mx;
+    NS_TRY(st.packed.reserve(po + 64));
+    NS_TRY(st.poff.reserve(((size_t)nq + 1) * 8));
+    NS_TRY(st.len.reserve(((size_t)nq + 1) * 4));
+    NS_TRY(c->ascii.reserve(total + 64));
+    NS_TRY(c->aoff.reserve(((size_t)nq + 1) * 8));
+    NS_HIP(hipMemcpyAsync(c->ascii.p, h, total, hipMemcpyHostToDevice, c->stream));
+    NS_HIP(hipMemcpyAsync(c->aoff.p, h_aoff, ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    NS_HIP(hipMemcpyAsync(st.poff.p, h_poff, ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    NS_HIP(hipMemcpyAsync(st.len.p, h_len, (size_t)nq * 4, hipMemcpyHostToDevice, c->stream));
+    NS_TRY(launch_pack_ascii(c, c->ascii.as<char>(), c->aoff.as<uint64_t>(), st));
+    NS_TRY(c->qsketch.reserve(((size_t)nq * n + 1) * 8));
+    NS_TRY(launch_sketch(c, st, c->qsketch.as<uint64_t>(), nullptr));
+    // filter buffers
+    c->f_nq = nq;
+    NS_TRY(c->f_off.reserve(((size_t)nq + 1) * 8));
+    NS_TRY(c->f_qstart.reserve(((size_t)nq + 1) * 8));
+    NS_TRY(c->f_qcnt.reserve(((size_t)nq + 1) * 4 * 3));
+    NS_TRY(c->f_qm.reserve((size_t)nq * n * 8));
+    NS_TRY(c->f_ctrl.reserve(64));
+    NS_TRY(c->f_ovf_list.reserve((size_t)nq * 4));
+    static const size_t pool0 = getenv("NSGPU_WQ_POOL_BYTES") ? (size_t)atoll(getenv("NSGPU_WQ_POOL_BYTES")) : (size_t)16 << 20;     // (test switch: start small)
+    if (c->f_pool.cap < pool0) NS_TRY(c->f_pool.reserve(pool0));                             // >= 4 M staged ids; grows through the exact path
+    const size_t need_heavy = (size_t)F_HEAVY_WGS * N * 4;
+    if (c->f_ovf_cnt.cap < need_heavy) {
+        NS_TRY(c->f_ovf_cnt.reserve(need_heavy));
+        NS_HIP(hipMemsetAsync(c->f_ovf_cnt.p, 0, c->f_ovf_cnt.cap, c->stream));
+    }
+    const uint64_t pool_cap = c->f_pool.cap / 4, ids_cap = pool_cap;
+    NS_TRY(c->pin_wq_out.reserve(((size_t)nq + 1) * 8 + ids_cap * 4 + 64));
+    uint64_t *h_off = c->pin_wq_out.as<uint64_t>();
+    uint32_t *h_ids = reinterpret_cast<uint32_t *>(h_off + nq + 1);
+    NS_TRY(c->pin_small.reserve(64));
+    uint32_t *h_ctrl = c->pin_small.as<uint32_t>() + 8;                                    // behind run_filter's four scalars
+    uint32_t *qcnt = c->f_qcnt.as<uint32_t>(), *qm = qcnt + (nq + 1), *qcap = qm + (nq + 1);
+    uint32_t *lb = c->f_qm.as<uint32_t>(), *cnt = lb + (size_t)nq * n;
+    uint64_t *soff = c->f_qstart.as<uint64_t>();
+    NS_HIP(hipMemsetAsync(c->f_ctrl.p, 0, 64, c->stream));
+    NS_HIP(hipMemsetAsync(qcnt, 0, ((size_t)nq + 1) * 4 * 3, c->stream));
+    {
+        uint32_t grid = (nq + 3) / 4;
+        if (grid > 65536u) grid = 65536u;
+        hipLaunchKernelGGL(filter_search_kernel, dim3(grid), dim3(256), 0, c->stream, c->qsketch.as<uint64_t>(), (const uint64_t *)nullptr, 0, nq, n, thr1, N,
+                           c->idx_keys.as<uint64_t>(), lb, cnt, qm, qcap);
+    }
+    NS_TRY(scan_u32_to_u64(c, qcap, soff, nq));
+    {
+        const uint32_t grid = nq < 262144u ? nq : 262144u;
+        hipLaunchKernelGGL(filter_count_kernel, dim3(grid), dim3(64), 0, c->stream, nq, n, thr1, N, c->idx_ids.as<uint32_t>(), lb, cnt, qm, soff,
+                           c->f_pool.as<uint32_t>(), qcnt, c->f_ovf_list.as<uint32_t>(), c->f_ctrl.as<uint32_t>(), pool_cap);
+    }
+    // (queries with more matches than the sort takes: the kernel reads their number on the device and does nothing when there are none)
+    hipLaunchKernelGGL(filter_heavy_kernel, dim3(F_HEAVY_WGS), dim3(256), 0, c->stream, n, thr1, N, c->idx_ids.as<uint32_t>(), lb, cnt, soff,
+                       c->f_pool.as<uint32_t>(), qcnt, c->f_ovf_list.as<uint32_t>(), c->f_ctrl.as<uint32_t>(), c->f_ovf_cnt.as<uint32_t>(), pool_cap);
+    NS_TRY(scan_u32_to_u64(c, qcnt, c->f_off.as<uint64_t>(), nq));
+    {
+        uint32_t grid = (nq + 3) / 4;
+        if (grid > 65536u) grid = 65536u;
+        hipLaunchKernelGGL(filter_compact_kernel, dim3(grid), dim3(256), 0, c->stream, nq, soff, c->f_pool.as<uint32_t>(), qcnt, c->f_off.as<uint64_t>(), h_ids, ids_cap, h_off,
+                           c->f_ctrl.as<uint32_t>());
+    }
+    NS_HIP(hipGetLastError());
+    NS_HIP(hipMemcpyAsync(h_ctrl, c->f_ctrl.p, 16, hipMemcpyDeviceToHost, c->stream));
+    NS_HIP(stream_wait_short(c->stream));
+    c->have_filter_all = false;
+    if (h_ctrl[1] || h_ctrl[2]) { *redo = true; return NSGPU_OK; }
+    c->f_total = h_off[nq];
+    off_out = h_off, ids_out = h_ids;
     return NSGPU_OK;
 }
 

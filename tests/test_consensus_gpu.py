@@ -274,3 +274,18 @@ def test_packed_host_mirror_gives_the_same_streams():
         assert len(out[mode]) == 3 and all(x[-1] == "0" for x in out[mode]), out[mode]
         assert out[mode][1] == out[mode][2]                      # FASTQ chunks == load_reads
     assert out["0"] == out["1"]
+
+
+def test_window_query_buffers_too_small_take_the_exact_path():
+    """The engine's window queries run as one launch sequence with buffers sized in advance (run_window_queries_fast); a batch that
+    does not fit is redone by the exact multi-step path, which grows them (NSGPU_WQ_POOL_BYTES: start with next to nothing), and
+    NSGPU_WQ_EXACT=1 takes that path always: same streams."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for env in ({}, {"NSGPU_WQ_POOL_BYTES": "256"}, {"NSGPU_WQ_EXACT": "1"}):
+        r = subprocess.run([sys.executable, "-c", MIRROR_WORKER % {"root": root}], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append([l.split()[1:] for l in r.stdout.splitlines() if l.startswith("HASH")])
+        assert len(out[-1]) == 3 and all(x[-1] == "0" for x in out[-1]), out[-1]
+    assert out[0] == out[1] == out[2]
