@@ -246,6 +246,9 @@ def main():
                        "lossless_roundtrip_bad_reads": bad, "stream_bytes_per_base": round(stream_bytes / n_bases, 4),
                        "contigs": st["n_contigs"], "lone_reads": st["n_lone"], "reads_aligned": st["count_aligner"], "align_calls": st["n_align_calls"],
                        "rounds": st["n_rounds"],
+                       # index + seeds + chaining scores of the alignments: pairs done by the kernels (seeds.hip, chain.hip) / handed back
+                       # to the host code (anchors sharing a reference position, oversize lists), over the timed steps
+                       "seed_pairs": {"gpu": a["seed_pairs_gpu"], "host": a["seed_pairs_host"]},
                        "stage_ms_per_step": {"sketch": round(sk_ms / steps, 2), "tables": round(idx_ms / steps, 2),
                                              "contig_stage_total": round(st["total_ms"], 1), "window_queries": round(st["filter_ms"], 1),
                                              "consensus_index": round(st["index_ms"], 1), "align_total": round(st["align_ms"], 1),
