@@ -96,6 +96,11 @@ int nsgpu_load_fastq(nsgpu_ctx *ctx, const char *text, size_t n_bytes, uint32_t 
 int nsgpu_load_fastq_begin(nsgpu_ctx *ctx);
 int nsgpu_load_fastq_chunk(nsgpu_ctx *ctx, const char *text, size_t n_bytes);
 int nsgpu_load_fastq_end(nsgpu_ctx *ctx, uint32_t *n_reads_out);
+/* ReadData::loadFromFile(fileName, FASTQ, gzip_flag) (src/ReadData.cpp:12-26; gzip through boost::iostreams::gzip_decompressor,
+ * :95-101, :165-171): the file itself.  gzip_flag 0 = plain text, 1 = gzip (concatenated members are read through, like zcat),
+ * -1 = decide by the file's first two bytes.  zlib inflates piece by piece on the host while the GPU parses the piece before; the
+ * result is what nsgpu_load_fastq over the decompressed text gives.  "Can't open input file" like the reference (:79-81). */
+int nsgpu_load_fastq_file(nsgpu_ctx *ctx, const char *path, int gzip_flag, uint32_t *n_reads_out);
 uint32_t nsgpu_num_reads(const nsgpu_ctx *ctx);
 uint64_t nsgpu_num_bases(const nsgpu_ctx *ctx);
 /* ReadData::getRead (src/ReadData.cpp:225-235): read r as ASCII (A/T/C/G), out must hold len[r] bytes. */

@@ -73,6 +73,7 @@ SIGNATURES = {
     "nsgpu_load_fastq_begin": (C.c_int, [_vp]),
     "nsgpu_load_fastq_chunk": (C.c_int, [_vp, _vp, C.c_size_t]),
     "nsgpu_load_fastq_end": (C.c_int, [_vp, _u32p]),
+    "nsgpu_load_fastq_file": (C.c_int, [_vp, C.c_char_p, C.c_int, _u32p]),
     "nsgpu_comm_unique_id": (C.c_int, [_vp]),
     "nsgpu_comm_init_rccl": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
     "nsgpu_comm_init_callbacks": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),

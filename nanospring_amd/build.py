@@ -62,7 +62,7 @@ def build(force=False, verbose=True):
                 if warn and verbose:
                     sys.stderr.write(warn)
     if jobs or not os.path.exists(LIB):
-        run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-lpthread"])
+        run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-lpthread", "-lz"])
     return LIB
 
 

@@ -244,6 +244,7 @@ void nsgpu_destroy(nsgpu_ctx *c)
         if (w.h_seqs) (void)hipHostFree(w.h_seqs);
         if (w.h_out) (void)hipHostFree(w.h_out);
         w.h_meta.release();
+        w.h_concat.release();
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }
     for (nsgpu_ctx::KswWs &w : c->kws) {

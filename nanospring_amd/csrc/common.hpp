@@ -163,6 +163,7 @@ struct nsgpu_ctx {
         uint8_t *h_seqs = nullptr; size_t h_cap = 0;
         uint8_t *h_out = nullptr; size_t h_out_cap = 0;
         nsgpu::PinBuf h_meta;                                          // pinned landing zone of the small read-backs (push count, offsets)
+        nsgpu::PinBuf h_concat;                                        // results of an oversize batch sketched piece by piece (gpu_mm_sketch)
         hipStream_t stream = nullptr;
     } sws[2];                                                       // two workspaces: the contig engine sketches the two halves of a batch concurrently
     // chaining scores (chain.hip): anchors in, f / p out.  0: direct API calls; 1..: two per group of the contig engine (the halves of a batch are pipelined)

@@ -455,6 +455,20 @@ static void plan_splice(Builder &b, int w, int k)
     const size_t m = (size_t)(w + k + 2);
     const size_t a = P > 2 * m ? P - 2 * m : 0, e = Ln - S + 2 * m < Ln ? Ln - S + 2 * m : Ln;
     if ((e - a) * 2 > Ln) return;                                // most of it changed: a whole sketch is as cheap
+    {   // The locality argument above counts POSITIONS, mm_sketch's window counts PUSHES: a k-mer equal to its own reverse complement
+        // pushes nothing (minimap2/sketch.c:108), so every such k-mer between a kept minimizer and the change stretches the window by one
+        // position -- (AT)n, (CG)n, (ACGT)n runs have many.  With one anywhere within 3m of the changed stretch the whole string is sketched.
+        const size_t lo = P > 3 * m ? P - 3 * m : 0, hi = Ln - S + 3 * m < Ln ? Ln - S + 3 * m : Ln;
+        if ((k & 1) == 0 && hi - lo >= (size_t)k)
+            for (size_t i = lo; i + (size_t)k <= hi; ++i) {
+                bool sym = true;
+                for (int j = 0; j < k / 2 && sym; ++j) {
+                    const char x = nw[i + (size_t)j], y = nw[i + (size_t)(k - 1 - j)];
+                    sym = (x == 'A' && y == 'T') || (x == 'T' && y == 'A') || (x == 'C' && y == 'G') || (x == 'G' && y == 'C');
+                }
+                if (sym) return;
+            }
+    }
     sp.full = false;
     sp.a = a, sp.B_sub = e;
     sp.A = a == 0 ? 0 : P - m;                                   // new minimizers are taken from [A, B)

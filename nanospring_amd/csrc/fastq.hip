@@ -312,3 +312,89 @@ extern "C" int nsgpu_load_fastq(nsgpu_ctx *c, const char *text, size_t n_bytes, 
     NS_HIP(hipSetDevice(c->prm.device));
     return load_fastq(c, text, n_bytes, n_reads_out);
 }
+
+// ---- ReadData::loadFromFile(fileName, FASTQ, gzip_flag) (src/ReadData.cpp:12-26, 78-101, 156-171): the file itself, plain or gzip ----
+// The reference puts boost::iostreams::gzip_decompressor in front of the same getline loop; here zlib inflates piece by piece on a
+// helper thread while the GPU parses and packs the piece before (nsgpu_load_fastq_chunk).  Concatenated gzip members are read
+// through like `zcat` does (what the reference's test script compares with, util/test_script.sh:9).
+#include <zlib.h>
+#include <thread>
+
+namespace {
+struct FileSource {
+    FILE *f = nullptr;
+    bool gz = false, z_open = false, eof = false;
+    z_stream zs;
+    std::vector<unsigned char> in;
+    std::string err;
+    ~FileSource() { if (z_open) inflateEnd(&zs); if (f) fclose(f); }
+    // fills out[0 .. cap) as far as the file goes; returns the bytes written (0 = end of input), or (size_t)-1 on error
+    size_t read(char *out, size_t cap)
+    {
+        if (!gz) { const size_t n = fread(out, 1, cap, f); if (n < cap && ferror(f)) { err = "read error"; return (size_t)-1; } return n; }
+        size_t done = 0;
+        while (done < cap && !eof) {
+            if (zs.avail_in == 0) {
+                zs.next_in = in.data();
+                zs.avail_in = (uInt)fread(in.data(), 1, in.size(), f);
+                if (zs.avail_in == 0) {
+                    if (ferror(f)) { err = "read error"; return (size_t)-1; }
+                    if (z_mid) { err = "unexpected end of the gzip stream"; return (size_t)-1; }
+                    eof = true;
+                    break;
+                }
+            }
+            const size_t room = std::min<size_t>(cap - done, 1u << 30);
+            zs.next_out = reinterpret_cast<Bytef *>(out + done);
+            zs.avail_out = (uInt)room;
+            const int r = inflate(&zs, Z_NO_FLUSH);
+            done += room - zs.avail_out;
+            z_mid = true;
+            if (r == Z_STREAM_END) {                       // next member, if any
+                z_mid = false;
+                if (inflateReset(&zs) != Z_OK) { err = "inflateReset failed"; return (size_t)-1; }
+            } else if (r != Z_OK && r != Z_BUF_ERROR) { err = std::string("gzip data error: ") + (zs.msg ? zs.msg : "?"); return (size_t)-1; }
+        }
+        return done;
+    }
+    bool z_mid = false;
+};
+}  // namespace
+
+extern "C" int nsgpu_load_fastq_file(nsgpu_ctx *c, const char *path, int gzip_flag, uint32_t *n_reads_out)
+{
+    NS_CHECK(c && path, NSGPU_ERR_ARG, "nsgpu_load_fastq_file: null argument");
+    FileSource src;
+    src.f = fopen(path, "rb");
+    NS_CHECK(src.f, NSGPU_ERR_ARG, "Can't open input file: %s", path);
+    if (gzip_flag < 0) {                                   // by content: the two magic bytes of a gzip member
+        unsigned char m[2] = {0, 0};
+        const size_t n = fread(m, 1, 2, src.f);
+        gzip_flag = n == 2 && m[0] == 0x1f && m[1] == 0x8b;
+        rewind(src.f);
+    }
+    src.gz = gzip_flag != 0;
+    if (src.gz) {
+        memset(&src.zs, 0, sizeof(src.zs));
+        NS_CHECK(inflateInit2(&src.zs, 15 + 16) == Z_OK, NSGPU_ERR_NOMEM, "inflateInit2 failed");
+        src.z_open = true;
+        src.in.resize(4u << 20);
+    }
+    static const size_t piece = [] { const char *e = getenv("NSGPU_FASTQ_PIECE_MB"); const size_t mb = e ? strtoull(e, nullptr, 10) : 0; return (mb ? mb : 512) << 20; }();
+    std::vector<char> buf[2];
+    buf[0].resize(piece), buf[1].resize(piece);
+    NS_TRY(nsgpu_load_fastq_begin(c));
+    size_t got = src.read(buf[0].data(), piece);
+    int rc = NSGPU_OK;
+    for (int cur = 0; got != 0 && got != (size_t)-1; cur ^= 1) {
+        size_t next = 0;
+        std::thread t([&] { next = src.read(buf[cur ^ 1].data(), piece); });       // inflate the next piece while the GPU takes this one
+        rc = nsgpu_load_fastq_chunk(c, buf[cur].data(), got);
+        t.join();
+        if (rc != NSGPU_OK) break;
+        got = next;
+    }
+    if (rc == NSGPU_OK && got == (size_t)-1) { set_error("%s: %s", path, src.err.c_str()); rc = NSGPU_ERR_ARG; }
+    if (rc != NSGPU_OK) { ingest_of(c) = FastqIngest(); return rc; }
+    return nsgpu_load_fastq_end(c, n_reads_out);
+}

@@ -25,6 +25,7 @@
 // scratch in HBM; lane 0 walks it at the end.
 #include "common.hpp"
 #include "ksw2.hpp"
+#include <mutex>
 #include "host_util.hpp"
 
 namespace nsgpu {
@@ -641,9 +642,13 @@ int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const 
 #define NS_REG_LAUNCH(NW_, NCH_)                                                                                                              \
     {                                                                                                                                         \
         static size_t cap = 0;                                                                                                                \
-        if (lds_bytes > 32768 && lds_bytes > cap) {                                                                                           \
-            NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_reg_kernel<NW_, NCH_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-            cap = lds_bytes;                                                                                                                  \
+        static std::mutex cap_m;      /* launches come from several DP workspaces / threads: attribute and record change together */        \
+        if (lds_bytes > 32768) {                                                                                                              \
+            std::lock_guard<std::mutex> lk(cap_m);                                                                                            \
+            if (lds_bytes > cap) {                                                                                                            \
+                NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_reg_kernel<NW_, NCH_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+                cap = lds_bytes;                                                                                                              \
+            }                                                                                                                                 \
         }                                                                                                                                     \
         hipLaunchKernelGGL((ksw_extd2_reg_kernel<NW_, NCH_>), dim3(m), dim3(NW_ * 64), lds_bytes, st, tasks, order, m, pr, seqs, p_pool, cig_pool, res); \
     }

@@ -579,14 +579,17 @@ static int gpu_mm_sketch_one(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, i
 // the results concatenated (a contig engine with many builders on multi-megabase contigs can get there; it cannot act on an error).
 int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws)
 {
-    const uint64_t kPiece = 1500ull << 20;
+    // (NSGPU_SKETCH_PIECE_KB: a small piece size lets a test force the split)
+    static const uint64_t kPiece = [] { const char *e = getenv("NSGPU_SKETCH_PIECE_KB"); const uint64_t kb = e ? strtoull(e, nullptr, 10) : 0; return kb ? kb << 10 : 1500ull << 20; }();
     uint64_t bytes = 0;
     for (const SketchReq &r : reqs) bytes += (r.len + 16) & ~(uint64_t)15;
     if (bytes < kPiece) return gpu_mm_sketch_one(c, reqs, w, k, out, out_off, ws);
-    static std::vector<mm2::Anchor> concat[2];                  // per workspace; the result stays valid until the workspace's next call
+    // The pieces' results are concatenated in PINNED memory of this context and workspace: the seeding kernel reads the lists where this
+    // function leaves them (AlignReq.qry_mz / ref_mz are device-visible pointers), and two contexts must not share a buffer.  The result
+    // stays valid until the workspace's next call.
     NS_CHECK(ws == 0 || ws == 1, NSGPU_ERR_ARG, "gpu_mm_sketch: workspace 0 or 1");
-    std::vector<mm2::Anchor> &all = concat[ws];
-    all.clear();
+    nsgpu::PinBuf &all = c->sws[ws].h_concat;
+    uint64_t n_all = 0;
     out_off.assign(reqs.size() + 1, 0);
     std::vector<SketchReq> part;
     std::vector<uint64_t> poff;
@@ -598,10 +601,19 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
         while (i < reqs.size() && (part.empty() || b + ((reqs[i].len + 16) & ~(uint64_t)15) < kPiece)) { b += (reqs[i].len + 16) & ~(uint64_t)15; part.push_back(reqs[i++]); }
         const mm2::Anchor *po = nullptr;
         NS_TRY(gpu_mm_sketch_one(c, part, w, k, po, poff, ws));
-        for (size_t j = 0; j < part.size(); ++j) out_off[first + j + 1] = all.size() + poff[j + 1];
-        all.insert(all.end(), po, po + poff[part.size()]);
+        for (size_t j = 0; j < part.size(); ++j) out_off[first + j + 1] = n_all + poff[j + 1];
+        const uint64_t n_new = poff[part.size()];
+        if ((n_all + n_new + 1) * sizeof(mm2::Anchor) > all.cap) {          // grow, keeping what is there
+            nsgpu::PinBuf bigger;
+            NS_TRY(bigger.reserve(2 * (n_all + n_new + 1) * sizeof(mm2::Anchor)));
+            if (n_all) memcpy(bigger.p, all.p, n_all * sizeof(mm2::Anchor));
+            all.release();
+            all = bigger;
+        }
+        if (n_new) memcpy(all.as<mm2::Anchor>() + n_all, po, n_new * sizeof(mm2::Anchor));
+        n_all += n_new;
     }
-    out = all.data();
+    out = all.as<mm2::Anchor>();
     return NSGPU_OK;
 }
 

@@ -2,6 +2,7 @@
 the path: `MinHashReadFilter` has the reference's public fields and methods
 (include/ReadFilter.h:15-30, 33-111) and forwards to libnsgpu.so."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -126,6 +127,12 @@ class NsGpu:
             check(self.lib, self.lib.nsgpu_load_fastq_chunk(self.ctx, _ptr(buf) if buf.size else None, buf.size))
         n = C.c_uint32()
         check(self.lib, self.lib.nsgpu_load_fastq_end(self.ctx, C.byref(n)))
+        return n.value
+
+    def load_fastq_file(self, path, gzip_flag=-1):
+        """ReadData::loadFromFile(path, FASTQ, gzip_flag): the file itself, plain or gzip (-1: by its first two bytes)."""
+        n = C.c_uint32()
+        check(self.lib, self.lib.nsgpu_load_fastq_file(self.ctx, os.fsencode(path), int(gzip_flag), C.byref(n)))
         return n.value
 
     def load_reads_packed(self, packed, byte_off, lens):

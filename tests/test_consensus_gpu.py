@@ -289,3 +289,18 @@ def test_window_query_buffers_too_small_take_the_exact_path():
         out.append([l.split()[1:] for l in r.stdout.splitlines() if l.startswith("HASH")])
         assert len(out[-1]) == 3 and all(x[-1] == "0" for x in out[-1]), out[-1]
     assert out[0] == out[1] == out[2]
+
+
+def test_oversize_sketch_batch_is_split_and_stays_device_visible():
+    """A minimizer-sketch batch beyond the kernels' 32-bit position space is sketched piece by piece and the results concatenated in
+    pinned memory of the context (the seeding kernel reads the lists where gpu_mm_sketch leaves them).  NSGPU_SKETCH_PIECE_KB=16 forces
+    the split on every batch of the engine: same streams as without."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for env in ({}, {"NSGPU_SKETCH_PIECE_KB": "16"}):
+        r = subprocess.run([sys.executable, "-c", MIRROR_WORKER % {"root": root}], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append([l.split()[1:] for l in r.stdout.splitlines() if l.startswith("HASH")])
+        assert len(out[-1]) == 3 and all(x[-1] == "0" for x in out[-1]), out[-1]
+    assert out[0] == out[1]

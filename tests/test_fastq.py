@@ -125,3 +125,35 @@ def test_gpu_chunked_ingest_equals_one_call():
     with pytest.raises(ns.NsGpuError):
         g.load_fastq_chunks([b"", b""])
     g.close(); h.close()
+
+
+@pytest.mark.gpu
+def test_gpu_gzip_file_ingest_equals_text(tmp_path):
+    """nsgpu_load_fastq_file: ReadData::loadFromFile with gzip_flag (src/ReadData.cpp:95-101) -- a .fastq.gz (BASELINE cfg1 is one), a
+    file of several concatenated gzip members, a plain file and detection by content all give the reads of the decompressed text;
+    pieces smaller than the file (NSGPU_FASTQ_PIECE_MB is read once per process, so the piece size is the default here and the
+    multi-piece path is covered by the chunk test above); a truncated gzip stream and a missing file are errors."""
+    import gzip
+    import nanospring_amd as ns
+    g, h = ns.NsGpu(), ns.NsGpu()
+    text = synth_fastq(31, 800, crlf=False)
+    n = h.load_fastq(text)
+    want = [h.get_read(r) for r in range(0, n, 13)]
+    gz = tmp_path / "reads.fastq.gz"
+    gz.write_bytes(gzip.compress(text, 6))
+    multi = tmp_path / "multi.fastq.gz"
+    cut = len(text) // 3
+    multi.write_bytes(gzip.compress(text[:cut]) + gzip.compress(text[cut:2 * cut + 5]) + gzip.compress(text[2 * cut + 5:]))
+    plain = tmp_path / "reads.fastq"
+    plain.write_bytes(text)
+    for path, flag in ((gz, 1), (gz, -1), (multi, 1), (plain, 0), (plain, -1)):
+        assert g.load_fastq_file(str(path), flag) == n, (path, flag)
+        assert g.num_bases == h.num_bases
+        assert [g.get_read(r) for r in range(0, n, 13)] == want, (path, flag)
+    bad = tmp_path / "cut.fastq.gz"
+    bad.write_bytes(gz.read_bytes()[:-200])
+    with pytest.raises(ns.NsGpuError):
+        g.load_fastq_file(str(bad), 1)
+    with pytest.raises(ns.NsGpuError):
+        g.load_fastq_file(str(tmp_path / "missing.fastq.gz"), 1)
+    g.close(); h.close()
