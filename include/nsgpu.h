@@ -245,6 +245,20 @@ typedef struct {
 /* Multi-GPU shards: global id of this context's read 0; the .id streams then carry global read ids so that the
  * stream sets of all shards can sit side by side as additional "threads" of one archive (default 0). */
 int nsgpu_set_read_id_base(nsgpu_ctx *ctx, uint32_t base);
+/* Schedule of the contig stage (all of nsgpu_consensus_run, nsgpu_dist_consensus_run and the phase calls below).
+ *   groups            1, 2 or 4 (default): a builder steps once per `groups` slots.  4 = the pipelined engine for thousands of builders;
+ *                     1 / 2 = few builders, where a slot is as long as its GPU round trips and the contig with the most reads sets the
+ *                     run time.
+ *   seed_bucket_depth 0 (default) = the reference's rule: the lowest unclaimed read at or after the builder's cursor
+ *                     (Consensus::getRead, src/Consensus.cpp:444-468).  d >= 1 = conflict-aware seeds: reads are grouped into buckets of
+ *                     the whole-read filter graph (every read without a bucket, in id order, takes the bucketless reads within d hops);
+ *                     a contig in flight occupies the buckets of its reads; a new seed is the lowest unclaimed read of a bucket that
+ *                     is neither occupied nor within seed_rings adjacency steps of an occupied one, builders in global order; a builder
+ *                     that finds none waits.  Many concurrent builders then do not start contigs in each other's way (the reference's
+ *                     -t N on a genome that is small for N threads fragments the same way; its streams grow with every extra contig).
+ * With one builder every setting is the reference's -t 1 schedule.  Deterministic for fixed (reads, salts, builders, schedule). */
+int nsgpu_set_schedule(nsgpu_ctx *ctx, uint32_t groups, uint32_t seed_bucket_depth, uint32_t seed_rings);
+int nsgpu_get_schedule(const nsgpu_ctx *ctx, uint32_t *groups, uint32_t *seed_bucket_depth, uint32_t *seed_rings);
 int nsgpu_consensus_run(nsgpu_ctx *ctx, uint32_t n_builders, uint32_t n_threads_out, nsgpu_consensus_stats *stats_out);
 /* stream `which` of output thread `thread`: 0 .genome 1 .lone 2 .id 3 .pos 4 .type 5 .base 6 .complement, 7 = metaData
  * (thread ignored).  *data_out is library-allocated (nsgpu_free). */

@@ -44,7 +44,7 @@ using cons::read_t;
 constexpr int kMaxGroups = 4;
 // Pipeline groups (see run_consensus): host phase | batches part 1 (sketches + index, seeds / chains / DP launch) | alignment
 // DP in flight | batches part 2.  (Measured and dropped: part 1 as two pipeline stages, a fifth group -- DESIGN.md.)
-static int n_groups() { return kMaxGroups; }
+static int n_groups(const nsgpu_ctx *c) { return (int)c->sched_groups; }
 
 struct FinishedContig {
     std::unique_ptr<cons::ContigGraph> g;     // null once emitted
@@ -317,9 +317,45 @@ struct Engine {
     std::vector<uint32_t> awho[kMaxGroups];           // builders of that batch
     std::vector<mm2::AlnOut> outs;
     Builder *local(uint32_t gid) { return gid % world == rank ? &D.B[gid / world] : nullptr; }
+    // ---- conflict-aware seeds (nsgpu_set_schedule; SURVEY 8e "assign seed reads by MinHash bucket locality") ----
+    // Reads are grouped once into buckets of the whole-read filter graph (x -- y when y is a filter result of x or of its reverse
+    // complement, nsgpu_filter_all_reads): in id order every read without a bucket opens one and takes every bucketless read within
+    // `depth` hops (breadth first).  Buckets are adjacent when an edge joins them.  A contig in flight occupies the buckets of its seed
+    // and of every read it claimed; a seed must lie in a bucket that is neither occupied nor within `rings` adjacency steps of an
+    // occupied one, and the lowest unclaimed read that qualifies is taken, by the waiting builders in global builder order.  A builder
+    // that finds none although unclaimed reads exist asks again at its group's next slot.  All of it is a function of replicated data.
+    struct SeedPolicy {
+        uint32_t depth = 0, rings = 1;
+        std::vector<uint32_t> bucket_of;                 // read -> bucket
+        std::vector<uint64_t> adj_off; std::vector<uint32_t> adj;     // bucket adjacency (CSR, ascending, without itself)
+        std::vector<uint64_t> bk_off; std::vector<uint32_t> bk_reads; // reads of every bucket, ascending
+        std::vector<uint32_t> bk_next;                   // per bucket: index into its reads of the first one not known to be claimed
+        std::vector<uint32_t> occ;                       // per bucket: members of contigs in flight
+        std::vector<std::vector<uint32_t>> members;      // per GLOBAL builder: seed + claimed reads of its contig in flight
+        uint64_t n_unclaimed = 0, n_idle = 0;
+        std::vector<uint8_t> blocked;                    // scratch of a seed round: bucket within `rings` steps of an occupied one
+        std::vector<uint32_t> q_cur, q_nxt, stamp;
+        uint32_t epoch = 0;
+        // marks every bucket within `rings` adjacency steps of the buckets in q_cur (a breadth-first walk of its own: a bucket that is
+        // already blocked from elsewhere may still be a step on the way)
+        void spread()
+        {
+            if (stamp.size() != blocked.size()) stamp.assign(blocked.size(), 0), epoch = 0;
+            ++epoch;
+            for (uint32_t x : q_cur) stamp[x] = epoch, blocked[x] = 1;
+            for (uint32_t d = 0; d < rings && !q_cur.empty(); ++d) {
+                q_nxt.clear();
+                for (uint32_t x : q_cur)
+                    for (uint64_t i = adj_off[x]; i < adj_off[x + 1]; ++i) if (stamp[adj[i]] != epoch) { stamp[adj[i]] = epoch; blocked[adj[i]] = 1; q_nxt.push_back(adj[i]); }
+                q_cur.swap(q_nxt);
+            }
+        }
+    } sp;
 };
 
 static void engine_free(void *p) { pool_drain(); delete static_cast<Engine *>(p); }      // no emission task may outlive the engine
+
+static int seed_policy_init(nsgpu_ctx *c, Engine *E);
 
 static int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, uint32_t world)
 {
@@ -347,17 +383,17 @@ static int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, 
         // times its read and the stretch of consensus under it, so this many builders per group and rank can never overflow it.  A function of
         // replicated values only (every rank holds all reads): all ranks clamp alike.
         const uint64_t per_aln = 6ull * std::max<uint64_t>(c->reads.max_len, 1024);
-        const uint64_t cap = std::max<uint64_t>(8, (3500ull << 20) / per_aln) * (uint64_t)n_groups() * world;
+        const uint64_t cap = std::max<uint64_t>(8, (3500ull << 20) / per_aln) * (uint64_t)n_groups(c) * world;
         if (n_builders_total > cap) n_builders_total = (uint32_t)cap;
     }
     E->rank = rank, E->world = world, E->n_total = n_builders_total;
     const uint32_t n_local = n_builders_total > rank ? (n_builders_total - rank + world - 1) / world : 0;
     D.B.resize(n_local);
-    for (uint32_t i = 0; i < n_local; ++i) D.B[i].id = i, D.B[i].gid = rank + i * world, D.B[i].group = (int)((D.B[i].gid >> 3) % (uint32_t)n_groups());
+    for (uint32_t i = 0; i < n_local; ++i) D.B[i].id = i, D.B[i].gid = rank + i * world, D.B[i].group = (int)((D.B[i].gid >> 3) % (uint32_t)n_groups(c));
     memset(&c->cons_stats, 0, sizeof(c->cons_stats));
     c->cons_stats.n_builders = n_builders_total;
     c->have_cons = false;
-    return NSGPU_OK;
+    return seed_policy_init(c, E);
 }
 
 // phase 1/3: consume deliveries and run every local builder to its next request
@@ -410,6 +446,52 @@ static uint32_t engine_seed_resolve(nsgpu_ctx *c, const uint32_t *gids, const ui
     for (uint32_t i = 0; i < n; ++i) ord[i] = i;
     std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return gids[a] < gids[b]; });
     uint32_t started = 0;
+    Engine::SeedPolicy &P = E->sp;
+    if (P.depth) {
+        // conflict-aware seeds (see Engine::SeedPolicy): the contigs the waiting builders finished leave the occupancy, then the free
+        // buckets' lowest unclaimed reads are handed out in ascending read order to the builders in global builder order
+        for (uint32_t k = 0; k < n; ++k) {
+            std::vector<uint32_t> &m = P.members[gids[ord[k]]];
+            for (uint32_t x : m) --P.occ[P.bucket_of[x]];
+            m.clear();
+        }
+        std::vector<std::pair<uint32_t, uint32_t>> cand;          // (lowest unclaimed read, bucket) of every bucket a seed may lie in
+        const uint32_t nb = (uint32_t)P.occ.size();
+        if (P.n_unclaimed) {
+            P.blocked.assign(nb, 0);
+            P.q_cur.clear();
+            for (uint32_t b = 0; b < nb; ++b) if (P.occ[b]) P.q_cur.push_back(b);
+            P.spread();
+            for (uint32_t b = 0; b < nb; ++b) {
+                if (P.blocked[b]) continue;
+                uint32_t &i = P.bk_next[b];
+                const uint32_t cnt = (uint32_t)(P.bk_off[b + 1] - P.bk_off[b]);
+                while (i < cnt && D.in_graph[P.bk_reads[P.bk_off[b] + i]]) ++i;
+                if (i < cnt) cand.emplace_back(P.bk_reads[P.bk_off[b] + i], b);
+            }
+        }
+        std::sort(cand.begin(), cand.end());
+        size_t ci = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t gid = gids[ord[k]];
+            Builder *b = E->local(gid);
+            if (P.n_unclaimed == 0) { ++E->n_done_global; if (b) b->st = Builder::DONE; continue; }
+            while (ci < cand.size() && P.blocked[cand[ci].second]) ++ci;                    // an earlier grant of this round came too close
+            if (ci == cand.size()) { ++P.n_idle; continue; }                                  // asks again at its group's next slot
+            const read_t r = cand[ci].first;
+            const uint32_t bk = cand[ci].second;
+            ++ci;
+            D.in_graph[r] = 1;
+            --P.n_unclaimed;
+            P.members[gid].push_back(r);
+            ++P.occ[bk];
+            P.q_cur.assign(1, bk);
+            P.spread();
+            ++started;
+            if (b) D.start_contig(*b, r);
+        }
+        return started;
+    }
     for (uint32_t k = 0; k < n; ++k) {
         const uint32_t gid = gids[ord[k]];
         read_t r = cursors[ord[k]];
@@ -421,6 +503,62 @@ static uint32_t engine_seed_resolve(nsgpu_ctx *c, const uint32_t *gids, const ui
         if (b) D.start_contig(*b, r);
     }
     return started;
+}
+
+// the buckets of the conflict-aware seed rule (Engine::SeedPolicy), from the whole-read filter results of every read
+static int seed_policy_init(nsgpu_ctx *c, Engine *E)
+{
+    Engine::SeedPolicy &P = E->sp;
+    Driver &D = E->D;
+    P.depth = c->seed_bucket_depth, P.rings = c->seed_rings;
+    if (!P.depth) return NSGPU_OK;
+    const uint32_t N = D.N;
+    uint64_t n_cand = 0;
+    NS_TRY(nsgpu_filter_all_reads(c, &n_cand));
+    std::vector<uint64_t> off(2 * (size_t)N + 1);
+    std::vector<uint32_t> ids(n_cand + 1);
+    NS_TRY(nsgpu_filter_all_fetch(c, off.data(), ids.data()));
+    c->have_filter_all = false;                                     // the engine's window queries reuse the device buffers
+    P.bucket_of.assign(N, ~0u);
+    uint32_t nb = 0;
+    std::vector<uint32_t> cur, nxt;
+    for (uint32_t r = 0; r < N; ++r) {
+        if (P.bucket_of[r] != ~0u) continue;
+        const uint32_t b = nb++;
+        P.bucket_of[r] = b;
+        cur.assign(1, r);
+        for (uint32_t d = 0; d < P.depth && !cur.empty(); ++d) {
+            nxt.clear();
+            for (uint32_t x : cur)
+                for (uint64_t i = off[2 * (size_t)x]; i < off[2 * (size_t)x + 2]; ++i) { const uint32_t y = ids[i]; if (P.bucket_of[y] == ~0u) { P.bucket_of[y] = b; nxt.push_back(y); } }
+            cur.swap(nxt);
+        }
+    }
+    std::vector<std::vector<uint32_t>> adj(nb);
+    for (uint32_t x = 0; x < N; ++x)
+        for (uint64_t i = off[2 * (size_t)x]; i < off[2 * (size_t)x + 2]; ++i) {
+            const uint32_t bx = P.bucket_of[x], by = P.bucket_of[ids[i]];
+            if (bx != by) { adj[bx].push_back(by); adj[by].push_back(bx); }
+        }
+    P.adj_off.assign(nb + 1, 0);
+    P.adj.clear();
+    for (uint32_t b = 0; b < nb; ++b) {
+        std::sort(adj[b].begin(), adj[b].end());
+        adj[b].erase(std::unique(adj[b].begin(), adj[b].end()), adj[b].end());
+        P.adj.insert(P.adj.end(), adj[b].begin(), adj[b].end());
+        P.adj_off[b + 1] = P.adj.size();
+    }
+    P.bk_off.assign(nb + 1, 0);
+    for (uint32_t r = 0; r < N; ++r) ++P.bk_off[P.bucket_of[r] + 1];
+    for (uint32_t b = 0; b < nb; ++b) P.bk_off[b + 1] += P.bk_off[b];
+    P.bk_reads.resize(N);
+    { std::vector<uint64_t> fill(P.bk_off.begin(), P.bk_off.end() - 1); for (uint32_t r = 0; r < N; ++r) P.bk_reads[fill[P.bucket_of[r]]++] = r; }
+    P.bk_next.assign(nb, 0);
+    P.occ.assign(nb, 0);
+    P.members.assign(E->n_total, std::vector<uint32_t>());
+    P.n_unclaimed = N;
+    if (getenv("NSGPU_CONS_DEBUG")) fprintf(stderr, "[cons] seed policy: %u buckets of depth %u over %u reads (%llu filter results), rings %u\n", nb, P.depth, N, (unsigned long long)n_cand, P.rings);
+    return NSGPU_OK;
 }
 
 // phases 4+5: window queries and alignments of the local builders (GPU batches); no claims yet
@@ -648,12 +786,11 @@ static int engine_batches_begin(nsgpu_ctx *c, int group, int ws_index)
 
 // batches, part 2: the group's window queries; DP results, execution of the alignment skeletons, alignRead's conversion (the
 // builders become ALIGNED)
-static int engine_batches_finish(nsgpu_ctx *c, int group)
+static int engine_window_queries(nsgpu_ctx *c, int group)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
     nsgpu_consensus_stats &S = c->cons_stats;
-    const int gi = group < 0 ? 0 : group;
     {   // the group's window queries (builders that wait for a candidate list): independent of its alignments, done in this
         // part because part 1 is the longer one
         std::vector<uint32_t> &who = E->fwho;
@@ -691,11 +828,18 @@ static int engine_batches_finish(nsgpu_ctx *c, int group)
                 for (int s = 0; s < 2; ++s) b.cand[s].assign(E->fids.begin() + E->foff[2 * w + s], E->fids.begin() + E->foff[2 * w + s + 1]);
                 b.st = Builder::GOT_FILTER;
             }
-            S.filter_ms += now_ms() - f0;
-            S.n_windows += who.size();
-            ++S.n_filter_rounds;
+            { std::lock_guard<std::mutex> lk(c->stat_m); S.filter_ms += now_ms() - f0; S.n_windows += who.size(); ++S.n_filter_rounds; }
         }
     }
+    return NSGPU_OK;
+}
+
+static int engine_align_finish(nsgpu_ctx *c, int group)
+{
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    Driver &D = E->D;
+    nsgpu_consensus_stats &S = c->cons_stats;
+    const int gi = group < 0 ? 0 : group;
     std::vector<uint32_t> &who = E->awho[gi];
     if (who.empty()) return NSGPU_OK;
     const double g1 = now_ms();
@@ -711,6 +855,12 @@ static int engine_batches_finish(nsgpu_ctx *c, int group)
     E->ab[gi].reqs.clear();
     { std::lock_guard<std::mutex> lk(c->stat_m); S.align_ms += now_ms() - g1; ++S.n_align_rounds; }
     return NSGPU_OK;
+}
+
+static int engine_batches_finish(nsgpu_ctx *c, int group)
+{
+    NS_TRY(engine_window_queries(c, group));
+    return engine_align_finish(c, group);
 }
 
 static int engine_batches(nsgpu_ctx *c, int group)
@@ -740,6 +890,7 @@ static void engine_claim_resolve(nsgpu_ctx *c, const uint32_t *gids, const uint3
         const uint32_t gid = gids[ord[k]], r = reads[ord[k]];
         if (r >= D.N || D.in_graph[r]) continue;
         D.in_graph[r] = 1;
+        if (E->sp.depth) { E->sp.members[gid].push_back(r); ++E->sp.occ[E->sp.bucket_of[r]]; --E->sp.n_unclaimed; }
         if (Builder *b = E->local(gid)) { b->accepted = true; ++b->n_aligner; }
     }
     for (Builder &b : D.B) if (b.st == Builder::ALIGNED) b.st = Builder::GOT_ALIGN;
@@ -790,12 +941,47 @@ static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
 // One pipeline slot: the host phase of group h = slot % G, part 1 (sketches + index + seeds / chains, then the DP launch) of
 // the group that was there one slot earlier, part 2 of group (slot + 1) % G -- whose DP launch has been in flight for a
 // slot -- all concurrently.
-static int engine_slot(nsgpu_ctx *c, uint32_t slot)
+// part: 0 = the whole slot; with ONE group the seeds are granted between the host phase (part 1) and the batches (part 2): see run_consensus
+static int engine_slot(nsgpu_ctx *c, uint32_t slot, int part = 0)
 {
-    const uint32_t G = (uint32_t)n_groups();
+    const uint32_t G = (uint32_t)n_groups(c);
     const int host_group = (int)(slot % G), begin_group = (int)((slot + G - 1) % G), finish_group = (int)((slot + 1) % G);
     const int ws_index = 1 + (int)(slot % 3);
     static const bool serial = getenv("NSGPU_NO_OVERLAP") != nullptr;      // debugging aid: one after the other
+    if (G <= 2 && !serial) {
+        // One or two groups (nsgpu_set_schedule): a builder's step takes G slots instead of four -- the schedule for few builders,
+        // where the length of a slot is the latency of its GPU round trips and not its volume.  G = 1: host phase, then the batches
+        // (the window queries on a second thread beside sketches / seeds / DP launch), then the DP results.  G = 2: the same chain
+        // for the group that had its host phase in the slot before, beside the host phase of the other group.
+        struct Rebind {
+            cpu_set_t old; bool ok;
+            Rebind() { ok = pthread_getaffinity_np(pthread_self(), sizeof(old), &old) == 0; pool_bind_this_thread(); }
+            ~Rebind() { if (ok) (void)pthread_setaffinity_np(pthread_self(), sizeof(old), &old); }
+        } rebind;
+        int rc1 = NSGPU_OK, rc2 = NSGPU_OK;
+        std::string err1, err2;
+        auto chain = [&] {
+            std::thread tw([&] {
+                pool_bind_this_thread();
+                rc2 = hipSetDevice(c->prm.device) == hipSuccess ? engine_window_queries(c, finish_group) : NSGPU_ERR_HIP;
+                if (rc2 != NSGPU_OK) err2 = nsgpu_last_error();
+            });
+            rc1 = engine_batches_sketch(c, begin_group);
+            if (rc1 == NSGPU_OK) rc1 = engine_batches_begin(c, begin_group, ws_index);
+            if (rc1 != NSGPU_OK) err1 = nsgpu_last_error();
+            tw.join();
+            if (rc1 == NSGPU_OK && rc2 == NSGPU_OK) { rc1 = engine_align_finish(c, finish_group); if (rc1 != NSGPU_OK) err1 = nsgpu_last_error(); }
+        };
+        if (G == 1) { if (part != 2) engine_advance(c, false, host_group); if (part != 1) chain(); }
+        else {
+            std::thread t1([&] { pool_bind_this_thread(); if (hipSetDevice(c->prm.device) == hipSuccess) chain(); else rc1 = NSGPU_ERR_HIP; });
+            engine_advance(c, false, host_group);
+            t1.join();
+        }
+        if (rc1 != NSGPU_OK) { set_error("%s", err1.empty() ? "contig engine: a batch thread failed" : err1.c_str()); return rc1; }
+        if (rc2 != NSGPU_OK) { set_error("%s", err2.empty() ? "contig engine: the window-query thread failed" : err2.c_str()); return rc2; }
+        return NSGPU_OK;
+    }
     if (serial) {
         engine_advance(c, false, host_group);
         NS_TRY(engine_batches_finish(c, finish_group));
@@ -842,6 +1028,21 @@ static int engine_slot(nsgpu_ctx *c, uint32_t slot)
     return NSGPU_OK;
 }
 
+// ONE group: a window costs no slot of its own.  The builders that opened a window get their candidate lists at once and go on (to their
+// next alignment request, their next window, or the end of their contig) until nobody waits for a window any more: one GPU round trip per
+// pass, typically one pass.  Reads inGraph[] only.
+static int engine_window_loop(nsgpu_ctx *c, int group)
+{
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    for (;;) {
+        bool any = false;
+        for (const Builder &b : E->D.B) if (in_group(b, group) && b.st == Builder::WAIT_FILTER) { any = true; break; }
+        if (!any) return NSGPU_OK;
+        NS_TRY(engine_window_queries(c, group));
+        engine_advance(c, false, group);                 // (only builders that hold a delivery move: here the ones with a candidate list)
+    }
+}
+
 static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_out)
 {
     NS_CHECK(n_threads_out >= 1, NSGPU_ERR_ARG, "n_threads_out must be >= 1");
@@ -861,9 +1062,24 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
     // group's read claims and then the host group's seed requests are resolved, in global builder order: the schedule is a
     // function of the data only.
     for (uint32_t slot = 0;; ++slot) {
-        const int G = n_groups();
+        const int G = n_groups(c);
         const int h = (int)(slot % G), b = (int)((slot + 1) % G);
         double t = now_ms();
+        if (G == 1) {
+            // ONE group: host phase (windows are answered at once: engine_window_loop), seeds (the fresh contigs take their first steps
+            // and get their first window at once, so that their first alignment is in this slot's batches), batches, claims -- a read
+            // granted as a seed here cannot be claimed by an alignment of this slot
+            NS_TRY(engine_slot(c, slot, 1));
+            NS_TRY(engine_window_loop(c, h));
+            engine_seed_requests(c, ga, gb, h);
+            if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) { engine_advance(c, true, h); NS_TRY(engine_window_loop(c, h)); }
+            NS_TRY(engine_slot(c, slot, 2));
+            w_slot += now_ms() - t;
+            engine_claim_requests(c, ga, gb, b);
+            engine_claim_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size());
+            if (E->n_done_global >= E->n_total) break;
+            continue;
+        }
         NS_TRY(engine_slot(c, slot));
         w_slot += now_ms() - t;
         t = now_ms();
@@ -880,7 +1096,7 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
         engine_seed_requests(c, ga, gb, h);
         if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) {
             static const bool at_once = getenv("NSGPU_NO_DEFER_FRESH") != nullptr;
-            if (at_once) engine_advance(c, true, h);
+            if (at_once || G < 4) engine_advance(c, true, h);      // (two groups: the group's batches run in the very next slot)
             else E->deferred_fresh = h;
         }
         w_seed += now_ms() - t;
@@ -991,8 +1207,46 @@ static int run_consensus_dist(nsgpu_ctx *c, Comm &C, uint32_t n_builders_total, 
     std::vector<uint32_t> mine(words), all(words * W), ca, cb, sa, sb, ga, gb;
     uint64_t n_coll = 0;
     for (uint32_t slot = 0;; ++slot) {
-        const int G = n_groups();
+        const int G = n_groups(c);
         const int h = (int)(slot % G), b = (int)((slot + 1) % G);
+        if (G == 1) {
+            // ONE group: two small all-gathers per slot -- seed requests after the host phase, claim requests after the batches
+            NS_TRY(engine_slot(c, slot, 1));
+            NS_TRY(engine_window_loop(c, h));
+            engine_seed_requests(c, sa, sb, h);
+            NS_CHECK(sa.size() <= cap, NSGPU_ERR_RANGE, "more requests than local builders");
+            mine[0] = 0;
+            mine[blk] = (uint32_t)sa.size();
+            std::copy(sa.begin(), sa.end(), mine.begin() + blk + 1);
+            std::copy(sb.begin(), sb.end(), mine.begin() + blk + 1 + cap);
+            NS_TRY(C.all_gather(mine.data(), all.data(), words * 4, false, c->stream));
+            ++n_coll;
+            ga.clear(); gb.clear();
+            for (uint32_t r = 0; r < W; ++r) {
+                const uint32_t *v = all.data() + (size_t)r * words + blk;
+                ga.insert(ga.end(), v + 1, v + 1 + v[0]);
+                gb.insert(gb.end(), v + 1 + cap, v + 1 + cap + v[0]);
+            }
+            if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) { engine_advance(c, true, h); NS_TRY(engine_window_loop(c, h)); }
+            NS_TRY(engine_slot(c, slot, 2));
+            engine_claim_requests(c, ca, cb, b);
+            NS_CHECK(ca.size() <= cap, NSGPU_ERR_RANGE, "more requests than local builders");
+            mine[0] = (uint32_t)ca.size();
+            std::copy(ca.begin(), ca.end(), mine.begin() + 1);
+            std::copy(cb.begin(), cb.end(), mine.begin() + 1 + cap);
+            mine[blk] = 0;
+            NS_TRY(C.all_gather(mine.data(), all.data(), words * 4, false, c->stream));
+            ++n_coll;
+            ga.clear(); gb.clear();
+            for (uint32_t r = 0; r < W; ++r) {
+                const uint32_t *v = all.data() + (size_t)r * words;
+                ga.insert(ga.end(), v + 1, v + 1 + v[0]);
+                gb.insert(gb.end(), v + 1 + cap, v + 1 + cap + v[0]);
+            }
+            engine_claim_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size());
+            if (E->n_done_global >= E->n_total) break;
+            continue;
+        }
         NS_TRY(engine_slot(c, slot));
         engine_claim_requests(c, ca, cb, b);
         engine_seed_requests(c, sa, sb, h);
@@ -1020,7 +1274,7 @@ static int run_consensus_dist(nsgpu_ctx *c, Comm &C, uint32_t n_builders_total, 
         }
         if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) {
             static const bool at_once = getenv("NSGPU_NO_DEFER_FRESH") != nullptr;       // (see run_consensus)
-            if (at_once) engine_advance(c, true, h);
+            if (at_once || G < 4) engine_advance(c, true, h);
             else E->deferred_fresh = h;
         }
         if (E->n_done_global >= E->n_total) break;
@@ -1056,7 +1310,7 @@ int nsgpu_cons_advance(nsgpu_ctx *c, int only_fresh, int group)
     return NSGPU_OK;
 }
 
-uint32_t nsgpu_cons_groups(void) { return (uint32_t)n_groups(); }
+uint32_t nsgpu_cons_groups(void) { return (uint32_t)kMaxGroups; }      // the default; nsgpu_get_schedule for a context's own
 
 int nsgpu_cons_slot(nsgpu_ctx *c, uint32_t slot)
 {
@@ -1117,6 +1371,25 @@ int nsgpu_cons_finish(nsgpu_ctx *c, uint32_t n_threads_out, nsgpu_consensus_stat
     NS_CHECK(c && c->cons_engine, NSGPU_ERR_ARG, "nsgpu_cons_finish: call nsgpu_cons_begin first");
     NS_TRY(engine_finish(c, n_threads_out));
     if (stats_out) *stats_out = c->cons_stats;
+    return NSGPU_OK;
+}
+
+int nsgpu_set_schedule(nsgpu_ctx *c, uint32_t groups, uint32_t seed_bucket_depth, uint32_t seed_rings)
+{
+    NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
+    NS_CHECK(groups == 1 || groups == 2 || groups == 4, NSGPU_ERR_ARG, "nsgpu_set_schedule: groups must be 1, 2 or 4");
+    NS_CHECK(seed_bucket_depth <= 64 && seed_rings <= 8, NSGPU_ERR_ARG, "nsgpu_set_schedule: bucket depth at most 64, rings at most 8");
+    NS_CHECK(!c->cons_engine, NSGPU_ERR_ARG, "nsgpu_set_schedule: a contig stage is in progress");
+    c->sched_groups = groups, c->seed_bucket_depth = seed_bucket_depth, c->seed_rings = seed_rings;
+    return NSGPU_OK;
+}
+
+int nsgpu_get_schedule(const nsgpu_ctx *c, uint32_t *groups, uint32_t *seed_bucket_depth, uint32_t *seed_rings)
+{
+    NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
+    if (groups) *groups = c->sched_groups;
+    if (seed_bucket_depth) *seed_bucket_depth = c->seed_bucket_depth;
+    if (seed_rings) *seed_rings = c->seed_rings;
     return NSGPU_OK;
 }
 

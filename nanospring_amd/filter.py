@@ -369,7 +369,14 @@ class ConsensusStats(C.Structure):
 STREAMS = ["genome", "lone", "id", "pos", "type", "base", "complement"]
 
 
-def consensus_run(gpu, n_builders=256, n_threads_out=1):
+def set_schedule(gpu, groups=4, seed_bucket_depth=0, seed_rings=1):
+    """nsgpu_set_schedule: pipeline groups (1, 2, 4) and the conflict-aware seed rule (bucket depth 0 = the reference's getRead rule)."""
+    check(gpu.lib, gpu.lib.nsgpu_set_schedule(gpu.ctx, groups, seed_bucket_depth, seed_rings))
+
+
+def consensus_run(gpu, n_builders=256, n_threads_out=1, schedule=None):
+    if schedule is not None:
+        set_schedule(gpu, *schedule)
     s = ConsensusStats()
     check(gpu.lib, gpu.lib.nsgpu_consensus_run(gpu.ctx, n_builders, n_threads_out, C.byref(s)))
     return {k: getattr(s, k) for k, _ in ConsensusStats._fields_}

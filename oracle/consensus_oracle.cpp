@@ -18,6 +18,10 @@
 // emitted by the reference's src/Edits.cpp object (tests/golden/edit_cases.npz, tests/test_edits.py).
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cassert>
 #include <chrono>
 #include <cstdint>
@@ -679,6 +683,125 @@ bool checkRepetitive(const std::string &readStr)
     return false;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Lock-step virtual threads: the product's deterministic -t N schedule ("Contig stage"), restated as a scheduler AROUND
+// the literal thread body below.  The reference's threads interact in exactly three places, all through timing: getRead (which thread
+// finds which unclaimed read, src/Consensus.cpp:444-468), the claim after a successful alignRead (:256-277), and the moment a thread
+// looks at inGraph[] (:204-208).  Here a logical clock ("slots") arbitrates them instead, so that the result is a function of the data:
+//   * thread v belongs to group (v >> 3) % G, G = 4 (or 2; or all to group 0 with G = 1); its body runs only in slots s with s % G == its group
+//     ("phase A" of the slot); the description below is for G = 4;
+//   * a window query (the forward getFilteredReads of addRelatedReads) and an alignRead each take one period of 4 slots: the thread
+//     continues in phase A of the slot 4 after the one in which it asked (with ONE group a window takes no slot: the thread goes on at once,
+//     the slot's order is A, C, B, and the threads granted a seed in C go on together after the last grant);
+//   * phase B of slot s resolves the claims of group (s + 1) & 3 -- the threads that asked for an alignment in slot s - 3 -- strictly in
+//     thread order: the lowest thread wins a read (no try_lock ever fails);
+//   * phase C of slot s grants seed reads to the threads of group s & 3 that are waiting in getRead, strictly in thread order, one
+//     request per thread and slot; a granted thread runs on (createGraph, its first window) until it has to wait again.
+// With one thread this is the reference's -t 1 run; with more it is one of the interleavings the reference's -t N can produce as long
+// as seedHops == 0.  seedHops >= 1 replaces getRead's "first unclaimed read at or after the thread's cursor" by the conflict-aware rule
+// of LockStep::pickSeed (SURVEY 8e "assign seed reads by MinHash bucket locality").
+// ---------------------------------------------------------------------------------------------------
+struct LockStep {
+    enum Kind { RUN, SEED, SEEDED, WINDOW, ALIGN, DONE };
+    struct VT {
+        Kind kind = RUN;
+        uint32_t at = 0;            // slot in which the thread started to wait
+        bool ok = false, won = false, go = false;
+        read_t r = 0;
+        std::condition_variable cv;
+    };
+    std::mutex m;
+    std::condition_variable schedCv;
+    std::vector<std::unique_ptr<VT>> vt;
+    uint32_t slot = 0;
+    int running = 0;
+    // conflict-aware seeds: MinHash-locality buckets.  Reads are grouped once, before the first contig, into buckets of the
+    // whole-read filter graph (read x -- read y when y is a filter result of x or of x's reverse complement): in id order every read
+    // that has no bucket yet opens one and takes every bucketless read within bucketDepth hops of it (breadth first).  Two buckets are
+    // adjacent when an edge of the graph joins them.  A contig in flight OCCUPIES the buckets of its seed and of every read it claimed.
+    // A seed must lie in a bucket that is neither occupied nor within `rings` adjacency steps of an occupied one; the lowest unclaimed
+    // read that qualifies is taken, by the waiting threads in thread order.  seedHops > 0 switches the rule on.
+    int seedHops = 0;                            // bucketDepth
+    int rings = 1;
+    std::vector<std::vector<read_t>> nbr;        // whole-read filter results of every read (forward and reverse-complement query), incl. itself
+    std::vector<uint32_t> bucketOf;
+    std::vector<std::vector<uint32_t>> adj;      // per bucket: adjacent buckets, ascending, without itself
+    std::vector<uint32_t> occ;                   // per bucket: members of contigs in flight
+    std::vector<std::vector<read_t>> members;    // per thread: seed + claimed reads of its contig in flight
+    uint64_t nIdleSeedRounds = 0;
+    uint32_t G = 4;                              // groups = slots per period (4: the pipelined engine; 1: every thread steps in every slot)
+    int group(uint32_t v) const { return G == 1 ? 0 : (int)((v >> 3) % G); }
+
+    // ---- thread side ----
+    void park(uint32_t v, Kind k) {
+        std::unique_lock<std::mutex> lk(m);
+        VT &t = *vt[v];
+        t.kind = k; t.at = slot;
+        --running;
+        schedCv.notify_one();
+        t.cv.wait(lk, [&] { return t.go; });
+        t.go = false;
+    }
+    void finish(uint32_t v) { std::unique_lock<std::mutex> lk(m); vt[v]->kind = DONE; --running; schedCv.notify_one(); }
+    // ---- scheduler side (called with m held) ----
+    void release(std::unique_lock<std::mutex> &, uint32_t v) { VT &t = *vt[v]; t.kind = RUN; t.go = true; ++running; t.cv.notify_one(); }
+    void waitIdle(std::unique_lock<std::mutex> &lk) { schedCv.wait(lk, [&] { return running == 0; }); }
+
+    void buildBuckets() {
+        const uint32_t N = (uint32_t)nbr.size();
+        bucketOf.assign(N, ~0u);
+        uint32_t nb = 0;
+        std::vector<read_t> cur, nxt;
+        for (read_t r = 0; r < N; ++r) {
+            if (bucketOf[r] != ~0u) continue;
+            const uint32_t b = nb++;
+            bucketOf[r] = b;
+            cur.assign(1, r);
+            for (int d = 0; d < seedHops && !cur.empty(); ++d) {
+                nxt.clear();
+                for (read_t x : cur) for (read_t y : nbr[x]) if (bucketOf[y] == ~0u) { bucketOf[y] = b; nxt.push_back(y); }
+                cur.swap(nxt);
+            }
+        }
+        adj.assign(nb, std::vector<uint32_t>());
+        for (read_t x = 0; x < N; ++x) for (read_t y : nbr[x]) if (bucketOf[x] != bucketOf[y]) { adj[bucketOf[x]].push_back(bucketOf[y]); adj[bucketOf[y]].push_back(bucketOf[x]); }
+        for (auto &a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+        occ.assign(nb, 0);
+    }
+    void addMember(uint32_t v, read_t x) { members[v].push_back(x); ++occ[bucketOf[x]]; }
+    void releaseContig(uint32_t v) { for (read_t x : members[v]) --occ[bucketOf[x]]; members[v].clear(); }
+    // no occupied bucket within r adjacency steps of b (breadth first over the bucket graph, b itself is step 0)
+    bool freeWithin(uint32_t b, int r) const {
+        std::vector<uint32_t> cur(1, b), nxt;
+        std::vector<uint8_t> seen(occ.size(), 0);
+        seen[b] = 1;
+        for (int d = 0;; ++d) {
+            for (uint32_t x : cur) if (occ[x]) return false;
+            if (d == r) return true;
+            nxt.clear();
+            for (uint32_t x : cur) for (uint32_t a : adj[x]) if (!seen[a]) { seen[a] = 1; nxt.push_back(a); }
+            cur.swap(nxt);
+        }
+    }
+    // The seed of thread v (phase C, threads in order; the contigs that the waiting threads finished have left the occupancy before the
+    // first of them is served): the lowest unclaimed read whose bucket qualifies is taken and becomes the first member of the thread's new contig.  No such read although unclaimed reads exist:
+    // the thread asks again at its group's next slot (returns 0).  No unclaimed read: the thread is done (-1).
+    int pickSeed(uint32_t, const std::vector<uint8_t> &inGraph, read_t &out) {
+        bool any = false;
+        std::vector<int8_t> verdict(occ.size(), -1);                 // per bucket, for this request only
+        for (read_t r = 0; r < (read_t)inGraph.size(); ++r) {
+            if (inGraph[r]) continue;
+            any = true;
+            int8_t &v8 = verdict[bucketOf[r]];
+            if (v8 < 0) v8 = freeWithin(bucketOf[r], rings) ? 1 : 0;
+            if (v8) { out = r; return 1; }
+        }
+        if (any) ++nIdleSeedRounds;
+        return any ? 0 : -1;
+    }
+};
+
 class Consensus {
 public:
     const std::vector<std::string> &reads;     // what rD->getRead(r) returns: DnaBitset round trip = letters folded to ATCG
@@ -700,9 +823,11 @@ public:
     std::vector<Writer> writers;
     std::vector<std::vector<read_t>> numReadsInContig, loneReads;
     std::vector<CountStats> countStats;
+    LockStep *ls = nullptr;                   // lock-step virtual threads instead of OpenMP threads (see LockStep)
 
     Consensus(const std::vector<std::string> &rd) : reads(rd), readStatusLock(numLocks) {}
 
+    static uint32_t &lsTid() { static thread_local uint32_t t = 0; return t; }
     bool try_lock(read_t r) { return readStatusLock[r % numLocks].exchange(1, std::memory_order_acquire) == 0; }
     void unlock(read_t r) { readStatusLock[r % numLocks].store(0, std::memory_order_release); }
 
@@ -718,6 +843,24 @@ public:
 
     // :444-468
     bool getRead(read_t &read) {
+        if (ls) {                                                     // wait for the thread's turn in phase C of one of its group's slots
+            const uint32_t v = lsTid();
+            for (;;) {
+                ls->park(v, LockStep::SEED);
+                if (ls->seedHops == 0) break;                         // the literal loop below, alone: no try_lock can fail
+                const int got = ls->pickSeed(v, inGraph, read);
+                if (got < 0) return false;
+                if (got > 0) { inGraph[read] = 1; ls->addMember(v, read); if (ls->G == 1) ls->park(v, LockStep::SEEDED); return true; }
+            }
+            if (ls->G == 1) {                                         // (one group: the granted threads go on together, after the last grant)
+                const bool got = getReadLiteral(read);
+                if (got) ls->park(v, LockStep::SEEDED);
+                return got;
+            }
+        }
+        return getReadLiteral(read);
+    }
+    bool getReadLiteral(read_t &read) {
         if (read >= numReads) return false;
         while (read < numReads) {
             if (!inGraph[read]) {
@@ -773,6 +916,7 @@ public:
         const bool all[] = {false, true};
         for (bool reverseComplement : all) {
             std::vector<read_t> results;
+            if (ls && !reverseComplement && ls->G != 1) ls->park(lsTid(), LockStep::WINDOW);      // one period per window (both strands are asked for at once); none with one group
             getFilteredReads(reverseComplement ? reverseComplementString : originalString, results);
             cs.countMinHash += results.size();
             for (const read_t r : results) {
@@ -787,11 +931,18 @@ public:
                 ssize_t beginOffset = 0, endOffset = 0, pos = 0;
                 ++cs.alignCalls;
                 const bool alignStatus = cG->alignRead(readStr, editScript, pos, beginOffset, endOffset, m_k, m_w, max_chain_iter, aligner);
+                if (ls) {                                                      // one period per alignment; the claim is phase B's, in thread order
+                    LockStep::VT &t = *ls->vt[lsTid()];
+                    t.ok = alignStatus, t.r = r, t.won = false;
+                    ls->park(lsTid(), LockStep::ALIGN);
+                    if (!t.won) continue;
+                } else {
                 if (!alignStatus) continue;
                 if (!try_lock(r)) continue;                                                                      // :256-277
                 if (inGraph[r]) { unlock(r); continue; }
                 inGraph[r] = 1;
                 unlock(r);
+                }
                 ++cs.countAligner;
                 if (runChecks) {                                                                                 // -DCHECKS :280-317
                     const std::string &mp = cG->mainPath.path;
@@ -823,6 +974,7 @@ public:
         loneReads.assign(numThr, std::vector<read_t>());
         countStats.assign(numThr, CountStats());
         writers.assign(numThr, Writer());
+        if (ls) { runLockStep(); return; }
 #pragma omp parallel num_threads(numThr)
         {
 #ifdef _OPENMP
@@ -830,6 +982,13 @@ public:
 #else
             const int tid = 0;
 #endif
+            threadBody(tid);
+        }
+    }
+
+    // the body of the parallel region (:29-137)
+    void threadBody(const int tid) {
+        {
             Writer &cgw = writers[tid];
             ConsensusGraph *cG = nullptr;
             read_t firstUnaddedRead = 0;
@@ -865,6 +1024,60 @@ public:
             }
             ConsensusGraph::writeIdsLone(cgw, loneReads[tid]);                                                   // :129
         }
+    }
+
+    // the scheduler of the lock-step virtual threads (see LockStep)
+    void runLockStep() {
+        LockStep &L = *ls;
+        const uint32_t T = (uint32_t)numThr;
+        L.vt.clear();
+        for (uint32_t v = 0; v < T; ++v) L.vt.emplace_back(new LockStep::VT());
+        L.members.assign(T, std::vector<read_t>());
+        if (L.seedHops) L.buildBuckets();
+        L.slot = 0;
+        std::vector<std::thread> th;
+        std::unique_lock<std::mutex> lk(L.m);
+        L.running = (int)T;
+        for (uint32_t v = 0; v < T; ++v) th.emplace_back([this, v] { lsTid() = v; threadBody((int)v); ls->finish(v); });
+        L.waitIdle(lk);                                                                 // everybody waits in getRead
+        for (;; ++L.slot) {
+            const int g = (int)(L.slot % L.G), b = (int)((L.slot + 1) % L.G);
+            // phase A: the group's threads whose window or alignment has had its period run on, concurrently (they only READ inGraph)
+            for (uint32_t v = 0; v < T; ++v) {
+                LockStep::VT &t = *L.vt[v];
+                if (L.group(v) == g && (t.kind == LockStep::WINDOW || t.kind == LockStep::ALIGN) && t.at < L.slot) L.release(lk, v);
+            }
+            L.waitIdle(lk);
+            auto phaseB = [&] {     // claims of group b (asked for G - 1 slots ago), in thread order
+                for (uint32_t v = 0; v < T; ++v) {
+                    LockStep::VT &t = *L.vt[v];
+                    if (L.group(v) != b || t.kind != LockStep::ALIGN || t.at + L.G - 1 != L.slot || !t.ok) continue;
+                    if (inGraph[t.r]) continue;
+                    inGraph[t.r] = 1;
+                    t.won = true;
+                    if (L.seedHops) L.addMember(v, t.r);
+                }
+            };
+            auto phaseC = [&] {     // seeds of group g, in thread order, one request per thread and slot
+                std::vector<uint32_t> req;
+                for (uint32_t v = 0; v < T; ++v) if (L.group(v) == g && L.vt[v]->kind == LockStep::SEED) req.push_back(v);
+                if (L.seedHops) for (uint32_t v : req) L.releaseContig(v);
+                for (uint32_t v : req) { L.release(lk, v); L.waitIdle(lk); }
+                // one group: the threads that got a seed take their first steps (graph of the seed read, first window, candidates up
+                // to the first alignment) together, after the last grant
+                bool any = false;
+                for (uint32_t v : req) if (L.vt[v]->kind == LockStep::SEEDED) { L.release(lk, v); any = true; }
+                if (any) L.waitIdle(lk);
+            };
+            // with one group the seeds come first: the engine grants them between its host phase and its GPU batches, so that a
+            // fresh contig's first window is asked for in the same slot (a read granted as a seed cannot be claimed in that slot)
+            if (L.G == 1) { phaseC(); phaseB(); } else { phaseB(); phaseC(); }
+            bool all = true;
+            for (uint32_t v = 0; v < T; ++v) all = all && L.vt[v]->kind == LockStep::DONE;
+            if (all) break;
+        }
+        lk.unlock();
+        for (std::thread &t : th) t.join();
     }
 
     // :370-386
@@ -978,9 +1191,32 @@ typedef struct {
 // num_thr OpenMP threads.  num_thr = 1 is deterministic; more threads race for reads exactly as the reference's do.
 // streams_out / lens_out hold 7 * num_thr + 1 entries: per thread genome, lone, id, pos, type, base, complement; then metaData.
 // Buffers are malloc'ed (free with cons_oracle_free).  Returns 0, or -1 with *err (static text) on an exception.
+static int cons_oracle_run_impl(const char *bases, const uint64_t *off, uint32_t N, uint32_t k, uint32_t n, uint32_t thr, const uint64_t *salts, int m_k, int m_w,
+                                int max_chain_iter, uint64_t edge_threshold, int num_thr, int run_checks, void *align_fn, uint32_t id_base, uint8_t **streams_out,
+                                uint64_t *lens_out, cons_oracle_stats *st, int lock_step, int seed_hops, uint64_t *ls_out);
+
 int cons_oracle_run(const char *bases, const uint64_t *off, uint32_t N, uint32_t k, uint32_t n, uint32_t thr, const uint64_t *salts, int m_k, int m_w,
                     int max_chain_iter, uint64_t edge_threshold, int num_thr, int run_checks, void *align_fn, uint32_t id_base, uint8_t **streams_out,
                     uint64_t *lens_out, cons_oracle_stats *st)
+{
+    return cons_oracle_run_impl(bases, off, N, k, n, thr, salts, m_k, m_w, max_chain_iter, edge_threshold, num_thr, run_checks, align_fn, id_base, streams_out, lens_out, st, 0, 0,
+                                nullptr);
+}
+
+// The same with num_thr LOCK-STEP virtual threads (struct LockStep above: the product's deterministic schedule) and, for seed_hops >= 1,
+// conflict-aware seeds.  ls_out[0] = slots of the run, ls_out[1] = seed requests that found every unclaimed read too close to a contig in flight.
+int cons_oracle_run_lockstep(const char *bases, const uint64_t *off, uint32_t N, uint32_t k, uint32_t n, uint32_t thr, const uint64_t *salts, int m_k, int m_w,
+                             int max_chain_iter, uint64_t edge_threshold, int num_thr, int run_checks, void *align_fn, uint32_t id_base, uint8_t **streams_out,
+                             uint64_t *lens_out, cons_oracle_stats *st, int seed_hops, int groups, uint64_t *ls_out)
+{
+    if (groups != 1 && groups != 2 && groups != 4) return -3;
+    return cons_oracle_run_impl(bases, off, N, k, n, thr, salts, m_k, m_w, max_chain_iter, edge_threshold, num_thr, run_checks, align_fn, id_base, streams_out, lens_out, st,
+                                groups, seed_hops, ls_out);
+}
+
+static int cons_oracle_run_impl(const char *bases, const uint64_t *off, uint32_t N, uint32_t k, uint32_t n, uint32_t thr, const uint64_t *salts, int m_k, int m_w,
+                                int max_chain_iter, uint64_t edge_threshold, int num_thr, int run_checks, void *align_fn, uint32_t id_base, uint8_t **streams_out,
+                                uint64_t *lens_out, cons_oracle_stats *st, int lock_step, int seed_hops, uint64_t *ls_out)
 {
     memset(st, 0, sizeof(*st));
     if (!align_fn || num_thr < 1) return -1;
@@ -1008,8 +1244,28 @@ int cons_oracle_run(const char *bases, const uint64_t *off, uint32_t N, uint32_t
         oracle_index_build(sk.data(), N, n, c.keys.data(), c.start.data(), c.ids.data(), c.nkeys.data());
     }
     st->sketch_ms = now_ms() - t0;
+    LockStep L;
+    if (lock_step) {
+        c.ls = &L;
+        L.G = (uint32_t)lock_step;                        // 1 or 4 groups
+        L.seedHops = seed_hops & 255;                     // bucket depth; rings in the next byte (default 1)
+        if (seed_hops >> 8) L.rings = (seed_hops >> 8) - 1;
+        if (seed_hops > 0) {                              // whole-read filter results of every read, both strands (what nsgpu_filter_all_reads holds)
+            L.nbr.assign(N, std::vector<read_t>());
+#pragma omp parallel for schedule(dynamic, 16)
+            for (uint32_t r = 0; r < N; ++r) {
+                std::vector<read_t> a, b;
+                c.numReads = N;
+                c.getFilteredReads(reads[r], a);
+                c.getFilteredReads(toReverseComplement(reads[r]), b);
+                a.insert(a.end(), b.begin(), b.end());
+                L.nbr[r].swap(a);
+            }
+        }
+    }
     t0 = now_ms();
     try { c.generateAndWriteConsensus(); } catch (const std::exception &) { return -1; }
+    if (ls_out) { ls_out[0] = L.slot + 1; ls_out[1] = L.nIdleSeedRounds; }
     st->consensus_ms = now_ms() - t0;
     for (int t = 0; t < num_thr; ++t) {
         st->n_contigs += c.numReadsInContig[t].size();

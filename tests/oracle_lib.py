@@ -307,9 +307,13 @@ def ref_align_fn():
     return C.cast(lib.ref_mm2_align, C.c_void_p)
 
 
-def cons_oracle_run(bases, off, salts, k=23, n=60, thr=6, m_k=20, m_w=50, mci=400, edge_thr=4000000, num_thr=1, checks=True, id_base=0, align_fn=None):
+def cons_oracle_run(bases, off, salts, k=23, n=60, thr=6, m_k=20, m_w=50, mci=400, edge_thr=4000000, num_thr=1, checks=True, id_base=0, align_fn=None,
+                    lock_step=False, seed_hops=0, groups=4, seed_rings=1):
     """The reference's hot path (sketch + tables + Consensus::generateAndWriteConsensus) on the CPU with the reference's own minimap2
-    answering alignRead.  Returns (streams, stats): streams[name] for num_thr == 1, else streams['threads'][t][name]; streams['metaData']."""
+    answering alignRead.  Returns (streams, stats): streams[name] for num_thr == 1, else streams['threads'][t][name]; streams['metaData'].
+    lock_step=True: num_thr LOCK-STEP virtual threads (the product's deterministic schedule restated around the literal thread body,
+    oracle/consensus_oracle.cpp struct LockStep; groups 1 / 2 / 4; seed_hops >= 1: conflict-aware seeds with buckets of that depth and
+    seed_rings rings); stats gains 'slots' and 'idle_seed_rounds'."""
     L = cons_lib()
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     off = np.ascontiguousarray(off, dtype=np.uint64)
@@ -318,8 +322,14 @@ def cons_oracle_run(bases, off, salts, k=23, n=60, thr=6, m_k=20, m_w=50, mci=40
     ptrs = (C.c_void_p * ns)()
     lens = (C.c_uint64 * ns)()
     st = ConsOracleStats()
-    rc = L.cons_oracle_run(_p(bases), _p(off), C.c_uint32(len(off) - 1), C.c_uint32(k), C.c_uint32(n), C.c_uint32(thr), _p(salts), m_k, m_w, mci,
-                           C.c_uint64(edge_thr), num_thr, int(checks), align_fn or ref_align_fn(), C.c_uint32(id_base), ptrs, lens, C.byref(st))
+    ls_out = (C.c_uint64 * 2)()
+    if lock_step:
+        rc = L.cons_oracle_run_lockstep(_p(bases), _p(off), C.c_uint32(len(off) - 1), C.c_uint32(k), C.c_uint32(n), C.c_uint32(thr), _p(salts), m_k, m_w, mci,
+                                        C.c_uint64(edge_thr), num_thr, int(checks), align_fn or ref_align_fn(), C.c_uint32(id_base), ptrs, lens, C.byref(st),
+                                        int(seed_hops) + (256 * (int(seed_rings) + 1) if seed_hops else 0), int(groups), ls_out)
+    else:
+        rc = L.cons_oracle_run(_p(bases), _p(off), C.c_uint32(len(off) - 1), C.c_uint32(k), C.c_uint32(n), C.c_uint32(thr), _p(salts), m_k, m_w, mci,
+                               C.c_uint64(edge_thr), num_thr, int(checks), align_fn or ref_align_fn(), C.c_uint32(id_base), ptrs, lens, C.byref(st))
     assert rc == 0, "cons_oracle_run failed: %d" % rc
     per = []
     for t in range(num_thr):
@@ -328,6 +338,8 @@ def cons_oracle_run(bases, off, salts, k=23, n=60, thr=6, m_k=20, m_w=50, mci=40
     for i in range(ns):
         L.cons_oracle_free(C.c_void_p(ptrs[i]))
     stats = {f: getattr(st, f) for f, _ in ConsOracleStats._fields_}
+    if lock_step:
+        stats["slots"], stats["idle_seed_rounds"] = int(ls_out[0]), int(ls_out[1])
     if num_thr == 1:
         out = dict(per[0])
         out["metaData"] = meta

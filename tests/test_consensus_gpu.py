@@ -304,3 +304,56 @@ def test_oversize_sketch_batch_is_split_and_stays_device_visible():
         out.append([l.split()[1:] for l in r.stdout.splitlines() if l.startswith("HASH")])
         assert len(out[-1]) == 3 and all(x[-1] == "0" for x in out[-1]), out[-1]
     assert out[0] == out[1]
+
+
+# ---- many builders against the oracle's lock-step virtual threads --------------------------------------------------------------------
+# oracle/consensus_oracle.cpp struct LockStep runs the LITERAL thread body of the reference under the schedule the engine documents
+# (slots, groups, claims and seeds in builder order, the conflict-aware seed rule): the engine with B builders and B output threads
+# must give byte for byte the B stream sets of the oracle's B virtual threads.
+def many_builders_equal_lockstep_oracle(bases, off, B, groups=4, depth=0, rings=1, n=60):
+    want, wst = oracle_lib.cons_oracle_run(bases, off, ns.mt19937_64_salts(n), n=n, checks=False, num_thr=B, lock_step=True, groups=groups,
+                                           seed_hops=depth, seed_rings=rings)
+    assert wst["n_bad_roundtrip"] == 0
+    g = ns.NsGpu(n=n)
+    g.load_reads((bases, off))
+    g.sketch(ns.mt19937_64_salts(n), fetch=False)
+    g.build_index()
+    st = ns.consensus_run(g, B, B, schedule=(groups, depth, rings))
+    per = want["threads"] if B > 1 else [want]
+    for t in range(B):
+        for k in STREAMS:
+            assert ns.consensus_stream(g, t, k) == per[t][k], (t, k)
+    assert ns.consensus_stream(g, 0, "metaData") == want["metaData"]
+    for f in ("count_minhash", "count_minhash_not_in_graph", "count_aligner", "n_contigs", "n_lone", "n_align_calls"):
+        assert st[f] == wst[f], f
+    assert st["n_rounds"] == wst["slots"]
+    assert ns.consensus_verify(g) == 0
+    g.close()
+    return wst
+
+
+@pytest.mark.parametrize("B,groups,depth,rings", [(12, 4, 0, 1), (40, 4, 0, 1), (40, 1, 0, 1), (40, 2, 0, 1), (24, 1, 2, 1), (40, 4, 3, 1), (40, 2, 1, 2)])
+def test_many_builders_equal_lockstep_oracle(B, groups, depth, rings):
+    bases, off = ns.synth_reads(31, 150000, 600, 4000.0)
+    wst = many_builders_equal_lockstep_oracle(bases, off, B, groups, depth, rings)
+    assert wst["count_aligner"] > 400
+
+
+def test_many_builders_equal_lockstep_oracle_cfg1_and_repeats():
+    """BASELINE cfg1's shape with 64 builders in the bench's schedule, and the repeat-rich genome of the test above"""
+    bases, off = ns.synth_reads(7, 500000, 1235, 8000.0)
+    wst = many_builders_equal_lockstep_oracle(bases, off, 64, 1, 3, 1)
+    assert wst["idle_seed_rounds"] > 0                      # the seed rule did hold builders back
+    from tests.align_cases import make_genome, mutate, revcomp
+    rng = np.random.RandomState(12)
+    g0 = make_genome(rng, 30000)
+    g0 = g0 + g0[5000:9000] + make_genome(rng, 15000) + "ACGGT" * 300 + make_genome(rng, 8000)
+    reads = []
+    for _ in range(320):
+        ln = int(max(400, rng.gamma(2.0, 1500.0)))
+        st = rng.randint(0, max(1, len(g0) - ln))
+        s = mutate(rng, g0[st:st + ln], 0.04)
+        reads.append(revcomp(s) if rng.randint(2) else s)
+    bases, off = pack(reads)
+    many_builders_equal_lockstep_oracle(bases, off, 20, 4, 0, 1)
+    many_builders_equal_lockstep_oracle(bases, off, 20, 2, 2, 1)

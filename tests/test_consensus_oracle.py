@@ -231,3 +231,24 @@ def test_oracle_threads_race_but_stay_lossless():
         got.update(dict(d))
     b = bytes(bases)
     assert sorted(got) == list(range(160)) and all(got[i] == fold(b[int(off[i]):int(off[i + 1])]) for i in range(160))
+
+
+def test_lockstep_oracle_one_thread_is_t1_and_many_are_lossless_and_deterministic():
+    """The oracle's lock-step virtual threads (struct LockStep: the engine's documented schedule around the literal thread body): one
+    thread gives the -t 1 streams whatever the schedule; many threads are lossless, deterministic (unlike -t N) and every schedule
+    terminates; conflict-aware seeds never make more contigs than the reference's rule on this input."""
+    import nanospring_amd as ns
+    bases, off = ns.synth_reads(31, 150000, 600, 4000.0)
+    salts = ns.mt19937_64_salts(60)
+    t1, s1 = oracle_lib.cons_oracle_run(bases, off, salts, checks=False)
+    for groups, depth in ((4, 0), (1, 0), (2, 3)):
+        a, sa = oracle_lib.cons_oracle_run(bases, off, salts, checks=False, num_thr=1, lock_step=True, groups=groups, seed_hops=depth)
+        assert a == t1 and sa["n_contigs"] == s1["n_contigs"]
+    runs = {}
+    for groups, depth in ((4, 0), (1, 0), (1, 3), (2, 3)):
+        a, sa = oracle_lib.cons_oracle_run(bases, off, salts, checks=True, num_thr=24, lock_step=True, groups=groups, seed_hops=depth)
+        b, sb = oracle_lib.cons_oracle_run(bases, off, salts, checks=False, num_thr=24, lock_step=True, groups=groups, seed_hops=depth)
+        assert a == b and sa["n_bad_roundtrip"] == 0 and sa["n_check_fail"] == 0
+        runs[(groups, depth)] = sa
+    assert runs[(1, 3)]["n_contigs"] <= runs[(1, 0)]["n_contigs"]
+    assert runs[(1, 0)]["slots"] * 3 < runs[(4, 0)]["slots"] * 1.2      # a step per slot instead of one per four

@@ -24,7 +24,8 @@ t0 = time.time()
 streams, st = oracle_lib.cons_oracle_run(bases, off, salts, num_thr=T, checks=False)
 dt = time.time() - t0
 names = oracle_lib.CONS_STREAMS
-tot = {n: sum(len(t[n]) for t in streams["threads"]) for n in names}
+th = streams["threads"] if "threads" in streams else [streams]
+tot = {n: sum(len(t[n]) for t in th) for n in names}
 tot7 = sum(tot.values())
 rec = {
     "workload": "cfg2 (bench.py input: seed 11, %d reads, mean 8000, 20x)" % n_reads,
