@@ -479,6 +479,8 @@ static void chain_finish(const Opt &o, std::vector<Anchor> &a, const int32_t *f,
     a.swap(out);
 }
 
+void chain_finish_scores(const Opt &o, std::vector<Anchor> &a, const int32_t *f, const int32_t *p, std::vector<uint64_t> &u) { chain_finish(o, a, f, p, u); }
+
 // ---------------------------------------------------------------------------
 // a14f  regions (hit.c)
 // ---------------------------------------------------------------------------

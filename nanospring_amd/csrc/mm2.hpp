@@ -129,6 +129,8 @@ struct DpCache {
 };
 
 float chain_avg_qspan(const std::vector<Anchor> &a);
+// the sequential remainder of mm_chain_dp behind the forward pass (chain.c:94-164): chains u[] and the anchors reordered chain by chain
+void chain_finish_scores(const Opt &o, std::vector<Anchor> &a, const int32_t *f, const int32_t *p, std::vector<uint64_t> &u);
 #ifdef NSGPU_HOST_CHAIN
 // the chaining recurrence as a plain loop: compiled into the CPU test harness only, the product runs chain.hip
 void chain_forward_host(const Opt &o, const std::vector<Anchor> &a, float avg_qspan, int32_t *f, int32_t *p);

@@ -6,7 +6,9 @@
  * NanoSpring uses (src/ConsensusGraph.cpp:195-217) and flattens the result
  * structs so that ctypes can read them.
  */
+#include <stdio.h>
 #include <stdlib.h>
+#include <unistd.h>
 #include <string.h>
 #include <stdint.h>
 #include "minimap.h"
@@ -137,3 +139,46 @@ void ref_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
 /* radix_sort_128x / radix_sort_64 (misc.c:153-159) -- tie order matters. */
 void ref_radix_sort_128x(uint64_t *xy, int64_t n) { radix_sort_128x((mm128_t *)xy, (mm128_t *)xy + n); }
 void ref_radix_sort_64(uint64_t *x, int64_t n) { radix_sort_64(x, x + n); }
+
+
+/* The anchors mm_map_frag hands to mm_chain_dp (minimap2/map.c:293-303: collect_minimizers + collect_seed_hits, sorted by
+ * radix_sort_128x), for the call sequence of ConsensusGraph::alignRead.  collect_seed_hits is static, so the anchors are taken from the
+ * library's own debug print (mm_dbg_flag & MM_DBG_PRINT_SEED, map.c:298-303: "SD" lines carry the low 32 bits of x, the strand, the low
+ * 32 bits of y and the span byte, in array order; "RS" the repetitive length): stderr is pointed at a temporary file for the duration
+ * of the call.  xy receives x = strand << 63 | reference position, y = span << 32 | query position.  Returns the number of anchors
+ * (-1: no temporary file). */
+extern int mm_dbg_flag;
+int64_t ref_mm_seeds(const char *ref, int rl, const char *qry, int ql, int k, int w, int max_chain_iter, uint64_t *xy, int64_t cap, int32_t *mid_occ, int32_t *rep_len)
+{
+    ref_aln_t aln;
+    char line[512];
+    int64_t n = 0;
+    int saved, tmpfd, old_flag = mm_dbg_flag;
+    FILE *tmp = tmpfile();
+    if (!tmp) return -1;
+    tmpfd = fileno(tmp);
+    fflush(stderr);
+    saved = dup(2);
+    dup2(tmpfd, 2);
+    mm_dbg_flag |= 4;                       /* MM_DBG_PRINT_SEED */
+    ref_mm2_align(ref, rl, qry, ql, k, w, max_chain_iter, &aln, 0, 0);
+    mm_dbg_flag = old_flag;
+    fflush(stderr);
+    dup2(saved, 2);
+    close(saved);
+    *mid_occ = aln.mid_occ;
+    *rep_len = -1;
+    rewind(tmp);
+    while (fgets(line, sizeof(line), tmp)) {
+        if (line[0] == 'R' && line[1] == 'S') { *rep_len = atoi(line + 3); continue; }
+        if (line[0] == 'S' && line[1] == 'D') {
+            char name[64], strand;
+            int x, y, span, d;
+            if (sscanf(line, "SD\t%63s\t%d\t%c\t%d\t%d\t%d", name, &x, &strand, &y, &span, &d) != 6) continue;
+            if (n < cap) { xy[2 * n] = (uint64_t)(uint32_t)x | (strand == '-' ? 1ull << 63 : 0); xy[2 * n + 1] = (uint64_t)span << 32 | (uint32_t)y; }
+            ++n;
+        }
+    }
+    fclose(tmp);
+    return n;
+}

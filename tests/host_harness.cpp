@@ -138,6 +138,20 @@ void harness_chain_forward(const uint64_t *xy, int64_t n, int max_chain_iter, in
     chain_forward_host(o, a, chain_avg_qspan(a), f, p);
 }
 
+// the product's chain_finish (backtracking, chain order) on forward-pass scores computed elsewhere (the GPU kernel): u[] and the reordered anchors
+int64_t harness_chain_finish(uint64_t *xy, int64_t n, int max_chain_iter, const int32_t *f, const int32_t *p, uint64_t *u_out, int64_t *n_a_out)
+{
+    Opt o;
+    o.max_chain_iter = max_chain_iter;
+    std::vector<Anchor> a((const Anchor *)xy, (const Anchor *)xy + n);
+    std::vector<uint64_t> u;
+    chain_finish_scores(o, a, f, p, u);
+    for (size_t i = 0; i < a.size(); ++i) xy[2 * i] = a[i].x, xy[2 * i + 1] = a[i].y;
+    for (size_t i = 0; i < u.size(); ++i) u_out[i] = u[i];
+    *n_a_out = (int64_t)a.size();
+    return (int64_t)u.size();
+}
+
 void harness_radix_sort_128x(uint64_t *xy, int64_t n) { radix_sort_128x((Anchor *)xy, (Anchor *)xy + n); }
 void harness_radix_sort_64(uint64_t *x, int64_t n) { radix_sort_64(x, x + n); }
 

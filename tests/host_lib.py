@@ -100,6 +100,18 @@ def chain_forward(xy, max_chain_iter=400):
     return f[:n], p[:n]
 
 
+def chain_finish(xy, f, p, max_chain_iter=400):
+    """The product's chain_finish (backtracking + chain order, mm2.cpp) on forward-pass scores computed elsewhere: (u, reordered anchors)."""
+    L = lib()
+    L.harness_chain_finish.restype = C.c_int64
+    a = np.ascontiguousarray(xy, dtype=np.uint64).copy()
+    n = len(a)
+    u = np.zeros(max(n, 1), dtype=np.uint64)
+    na = C.c_int64()
+    nu = L.harness_chain_finish(_p(a), C.c_int64(n), max_chain_iter, _p(np.ascontiguousarray(f, dtype=np.int32)), _p(np.ascontiguousarray(p, dtype=np.int32)), _p(u), C.byref(na))
+    return u[:nu].copy(), a[:int(na.value)].copy()
+
+
 def sketch(s, w, k):
     L = lib()
     b = s.encode()

@@ -275,6 +275,33 @@ def ref_mm_sketch(s, w, k):
     return xy[:2 * n].reshape(n, 2).copy()
 
 
+def ref_mm_seeds(ref, qry, k=20, w=50, max_chain_iter=400):
+    """The anchors the REFERENCE's mm_map_frag hands to mm_chain_dp (collect_seed_hits + radix sort, minimap2/map.c:293-303) in
+    ConsensusGraph::alignRead's call sequence, read off the library's own seed dump: (xy [n, 2], mid_occ, rep_len)."""
+    lib = mm2ref()
+    lib.ref_mm_seeds.restype = C.c_int64
+    rb, qb = ref.encode(), qry.encode()
+    cap = 4 * (len(rb) + len(qb)) // max(w, 1) * 8 + 4096
+    xy = np.zeros(2 * cap, dtype=np.uint64)
+    mid, rep = C.c_int32(), C.c_int32()
+    n = lib.ref_mm_seeds(rb, len(rb), qb, len(qb), k, w, max_chain_iter, _p(xy), C.c_int64(cap), C.byref(mid), C.byref(rep))
+    assert 0 <= n <= cap, (n, cap)
+    return xy[:2 * n].reshape(n, 2).copy(), int(mid.value), int(rep.value)
+
+
+def ref_mm_chain_dp(xy, max_chain_iter=400, max_dist=5000, bw=500, max_skip=25, min_cnt=3, min_sc=40):
+    """The REFERENCE's mm_chain_dp (minimap2/chain.c:22-164) on a sorted anchor list with the parameters of mm_map_frag (map.c:316):
+    (u [n_u], reordered anchors [n_a, 2])."""
+    lib = mm2ref()
+    xy = np.ascontiguousarray(xy, dtype=np.uint64)
+    n = len(xy)
+    u = np.zeros(max(n, 1), dtype=np.uint64)
+    a = np.zeros((max(n, 1), 2), dtype=np.uint64)
+    na = C.c_int64()
+    nu = lib.ref_mm_chain_dp(max_dist, max_dist, bw, max_skip, max_chain_iter, min_cnt, min_sc, C.c_float(1.0), 0, 1, C.c_int64(n), _p(xy), _p(u), _p(a), C.byref(na))
+    return u[:nu].copy(), a[:int(na.value)].copy()
+
+
 # ---------------------------------------------------------------------------
 # the contig stage (oracle/consensus_oracle.cpp -> oracle/libconsoracle.so)
 # ---------------------------------------------------------------------------

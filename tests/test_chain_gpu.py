@@ -92,3 +92,29 @@ def test_chain_scores_of_synthetic_lists(mci):
     far[:, 0] += np.uint64(3000000000)
     lists.append(far)
     compare(g, lists, mci)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mci", [400, 37])
+def test_chain_kernel_against_the_reference_mm_chain_dp(mci):
+    """Pinned directly against the REFERENCE: the kernel's f / p through the product's backtracking give the chains (u[]) and the
+    reordered anchor array that the reference's own mm_chain_dp (oracle/_ref/libmm2ref.so, minimap2/chain.c:22-164, called with
+    mm_map_frag's parameters) returns for the same sorted anchors -- seeded lists of the alignment cases and synthetic lists."""
+    import nanospring_amd as ns
+    from tests import oracle_lib
+    g = ns.NsGpu(max_chain_iter=mci)
+    rng = np.random.RandomState(77 + mci)
+    lists = [host_lib.seeds(r, q) for r, q in align_cases.pairs(23, 60)]
+    for kind in ("diagonals", "dense", "random", "colinear"):
+        for n in (1, 2, 65, 700, 3000):
+            lists.append(synthetic(rng, n, kind))
+    lists.append(synthetic(rng, 9000, "dense"))
+    got = gpu_scores(g, lists)
+    n_chains = 0
+    for a, (f, p) in zip(lists, got):
+        u, ra = host_lib.chain_finish(a, f, p, mci)
+        wu, wa = oracle_lib.ref_mm_chain_dp(a, mci)
+        assert np.array_equal(u, wu) and np.array_equal(ra, wa), (len(a), len(u), len(wu))
+        n_chains += len(wu)
+    assert n_chains > 60
+    g.close()

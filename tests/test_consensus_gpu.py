@@ -357,3 +357,28 @@ def test_many_builders_equal_lockstep_oracle_cfg1_and_repeats():
     bases, off = pack(reads)
     many_builders_equal_lockstep_oracle(bases, off, 20, 4, 0, 1)
     many_builders_equal_lockstep_oracle(bases, off, 20, 2, 2, 1)
+
+
+def test_cfg2_full_one_builder_equals_oracle_hashes():
+    """BASELINE cfg2 at FULL size (100 000 reads, 801 Mbases; bench.py's input): the GPU engine with one builder gives all eight
+    streams with the sizes and sha256 that oracle/consensus_oracle.cpp recorded for its -t 1 run on this input (an hour of CPU with
+    the reference's own minimap2 answering every alignRead, profiles/r02_one_builder_cfg2.json), and the round trip is lossless.
+    About five minutes on the GPU."""
+    import hashlib, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = json.load(open(os.path.join(root, "profiles", "r02_one_builder_cfg2.json")))
+    bases, off = ns.synth_reads(11, int(100000 * 8000 / 20), 100000, 8000.0)
+    assert int(off[-1]) == want["bases"]
+    g = ns.NsGpu()
+    g.load_reads((bases, off))
+    g.sketch(ns.mt19937_64_salts(60, 12345), fetch=False)
+    g.build_index()
+    st = ns.consensus_run(g, 1, 1)
+    for k in STREAMS + ["metaData"]:
+        b = ns.consensus_stream(g, 0, k)
+        assert len(b) == want["stream_bytes"][k], k
+        assert hashlib.sha256(b).hexdigest() == want["sha256"][k], k
+    for f in ("count_minhash", "count_minhash_not_in_graph", "count_aligner", "n_contigs", "n_lone", "n_align_calls"):
+        assert st[f] == want["stats"][f], f
+    assert ns.consensus_verify(g) == 0
+    g.close()

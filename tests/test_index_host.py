@@ -89,3 +89,27 @@ def test_index_falls_back_when_the_key_trick_does_not_apply():
     ek, es, ep, occ, emid = _expect(xy28)
     assert np.array_equal(keys, ek) and np.array_equal(start, es) and np.array_equal(pos, ep) and mid == emid
     assert np.array_equal(gn, occ)
+
+
+def test_host_seeds_and_chains_against_reference_dumps():
+    """The host code that redoes what the seeding kernel hands back (collect_seeds + the radix sort port) and the chain backtracking
+    (chain_finish) against the REFERENCE directly: the anchor array of the library's own seed dump (oracle_lib.ref_mm_seeds) -- order
+    included, ties too -- and the chains of the reference's mm_chain_dp on it."""
+    from tests import align_cases, oracle_lib
+    low = np.uint64(0xFFFFFFFF)
+    n_ties = n_chains = 0
+    for r, q in align_cases.pairs(5, 60):
+        if not r or not q:
+            continue
+        want, wmid, _ = oracle_lib.ref_mm_seeds(r, q)
+        h, hmid, _ = host_lib.seeds_full(r, q, 20, 50)
+        assert hmid == wmid and len(h) == len(want)
+        assert np.array_equal(h[:, 0] & low, want[:, 0] & low) and np.array_equal(h[:, 1] & low, want[:, 1] & low)
+        assert np.array_equal((h[:, 1] >> np.uint64(32)) & np.uint64(0xFF), want[:, 1] >> np.uint64(32))
+        n_ties += int(len(want) > 1 and bool((want[1:, 0] == want[:-1, 0]).any()))
+        f, p = host_lib.chain_forward(h, 400)
+        u, ra = host_lib.chain_finish(h, f, p, 400)
+        wu, wa = oracle_lib.ref_mm_chain_dp(h, 400)
+        assert np.array_equal(u, wu) and np.array_equal(ra, wa)
+        n_chains += len(wu)
+    assert n_ties > 3 and n_chains > 50

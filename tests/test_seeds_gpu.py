@@ -109,3 +109,38 @@ def test_empty_batches():
     assert gpu_scores(g, []) == []
     got, mid, flags, avg = gpu_seeds(g, [np.zeros((0, 2), dtype=np.uint64)], [np.zeros((0, 2), dtype=np.uint64)], [0])
     assert len(got) == 1 and len(got[0]) == 0 and flags[0] == 0 and mid[0] == 1
+
+
+@pytest.mark.gpu
+def test_seed_kernel_against_the_reference_seed_dump():
+    """Pinned directly against the REFERENCE: the anchors mm_map_frag hands to mm_chain_dp (collect_seed_hits + radix sort, read off the
+    library's own MM_DBG_PRINT_SEED dump through oracle/_ref/libmm2ref.so) and its mid_occ, for the alignment cases and for repeat-rich /
+    long-consensus pairs -- the kernel gives the same list in the same order, or flags the pair (two anchors on one reference position:
+    the order there is the radix sort's and the host code redoes the pair)."""
+    import nanospring_amd as ns
+    from tests import oracle_lib
+    g = ns.NsGpu()
+    pairs = [(r, q) for r, q in align_cases.pairs(5, 90) if r and q]
+    ref_lists, qry_lists, pair_ref = [], [], []
+    for r, q in pairs:
+        ref_lists.append(oracle_lib.ref_mm_sketch(r, 50, 20))
+        qry_lists.append(oracle_lib.ref_mm_sketch(q, 50, 20))
+        pair_ref.append(len(ref_lists) - 1)
+    got, mid, flags, avg = gpu_seeds(g, ref_lists, qry_lists, pair_ref)
+    n_same = n_flag = n_anchors = 0
+    low = np.uint64(0xFFFFFFFF)
+    for i, (r, q) in enumerate(pairs):
+        want, wmid, _ = oracle_lib.ref_mm_seeds(r, q)
+        assert mid[i] == wmid, (i, mid[i], wmid)
+        if flags[i]:
+            n_flag += 1
+            continue
+        a = got[i]
+        assert len(a) == len(want), (i, len(a), len(want))
+        if len(a):
+            assert np.array_equal(a[:, 0] & low, want[:, 0] & low) and np.array_equal(a[:, 0] >> np.uint64(63), want[:, 0] >> np.uint64(63)), i
+            assert np.array_equal(a[:, 1] & low, want[:, 1] & low) and np.array_equal((a[:, 1] >> np.uint64(32)) & np.uint64(0xFF), want[:, 1] >> np.uint64(32)), i
+        n_same += 1
+        n_anchors += len(a)
+    assert n_same > 50 and n_anchors > 3000, (n_same, n_flag, n_anchors)
+    g.close()
