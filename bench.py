@@ -189,6 +189,7 @@ def main():
         idx_ms += tm["index_ms"]
     barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if dist is not None:
         cdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
         t = torch.tensor([dt], device=cdev, dtype=torch.float64)
@@ -200,6 +201,17 @@ def main():
     else:
         total_bases = n_bases
 
+    per_rank = None
+    if dist is not None:
+        # what every rank did, so that a scaling curve can be read: host threads (the node's CPU quota is divided by LOCAL_WORLD_SIZE),
+        # collective bytes received, host memory of the replicated read copy, the rank's own step time
+        mine = {"rank": rank, "host_threads": ns.align_stats(g)["host_threads"], "s_per_step": round(dt_local / max(args.steps, 1), 3), "bases": n_bases,
+                "contigs": st["n_contigs"] if st else 0, "rounds": st["n_rounds"] if st else 0}
+        if job is not None:
+            mine.update(job.comm_stats())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
     if rank == 0:
         steps = max(args.steps, 1)
         a = ns.align_stats(g)
@@ -295,6 +307,7 @@ def main():
                                           if args.dist_mode == "alltoall" else "all-gather of sketch rows") +
                                        f" + {st.get('n_collectives', 0)} small all-gathers of claim lists (global builder order); C++ driver, library-owned RCCL communicator") if exchange
                        else f"reads sharded by id x{world}, no collective"},
+            "per_rank": per_rank,
             "compression": penalty,
             "throughput_schedule": tleg,
             "roofline": {"kernel": "ksw_extd2 (ksw_extd2_reg_kernel<NW,NCH>: DP state in registers)", "bound": "valu-issue", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

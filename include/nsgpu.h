@@ -327,6 +327,9 @@ int nsgpu_dist_load_reads(nsgpu_ctx *ctx, nsgpu_comm *comm, const char *bases, c
 #define NSGPU_DIST_REPLICATE 0
 #define NSGPU_DIST_ALLTOALL 1
 int nsgpu_dist_sketch_index(nsgpu_ctx *ctx, nsgpu_comm *comm, const uint64_t *salts, int mode);
+/* Bytes this rank has received in all-gathers / all-to-alls through the communicator so far (load, every sketch_index, every contig
+ * stage), and the host memory its copy of ALL reads occupies (2-bit rows + offset tables: about 0.25 B/base + 20 B/read). */
+int nsgpu_comm_stats(const nsgpu_comm *comm, uint64_t *bytes_all_gather, uint64_t *bytes_all_to_all, uint64_t *host_bytes_reads);
 /* Consensus::generateAndWriteConsensus over the ranks: the slot schedule documented above nsgpu_cons_begin with ONE small
  * all-gather (claim + seed request lists) per slot; rank r owns the builders with gid % world == r and writes its contigs
  * (global read ids) into its own n_threads_out stream sets.  The result does not depend on the number of ranks. */

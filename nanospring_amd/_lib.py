@@ -80,6 +80,7 @@ SIGNATURES = {
     "nsgpu_comm_init_rccl": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
     "nsgpu_comm_init_callbacks": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
     "nsgpu_comm_destroy": (None, [_vp]),
+    "nsgpu_comm_stats": (C.c_int, [_vp, _vp, _vp, _vp]),
     "nsgpu_dist_load_reads": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, _u32p, _u32p]),
     "nsgpu_dist_sketch_index": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "nsgpu_dist_consensus_run": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp]),

@@ -90,6 +90,8 @@ static int store_prepare(nsgpu_ctx *c, SeqStore &st, const uint32_t *len, uint32
 }
 
 int store_prepare_lens(nsgpu_ctx *c, SeqStore &st, const uint32_t *len, uint32_t n) { return store_prepare(c, st, len, n); }
+static int store_from_ascii(nsgpu_ctx *c, SeqStore &st, const char *bases, const uint64_t *off, uint32_t n);
+int store_from_ascii_shard(nsgpu_ctx *c, SeqStore &st, const char *bases, const uint64_t *off, uint32_t n) { return store_from_ascii(c, st, bases, off, n); }   // dist.hip
 
 static int store_from_ascii(nsgpu_ctx *c, SeqStore &st, const char *bases, const uint64_t *off, uint32_t n)
 {

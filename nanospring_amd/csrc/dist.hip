@@ -195,9 +195,16 @@ struct nsgpu_comm {
     // the rank's id range in the replicated read set and everybody's (set by nsgpu_dist_load_reads)
     std::vector<uint32_t> lo;      // [world + 1]
     DevBuf d_a, d_b, d_c, d_d, d_e, d_f, d_meta;
+    uint64_t bytes_all_gather = 0, bytes_all_to_all = 0;      // received by this rank, all calls so far
+    ~nsgpu_comm() { for (DevBuf *b : {&d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_meta}) b->release(); }
 };
 
 Comm *nsgpu_comm_impl(nsgpu_comm *c) { return c ? c->impl.get() : nullptr; }
+void nsgpu_comm_count(nsgpu_comm *c, uint64_t all_gather_bytes, uint64_t all_to_all_bytes) { if (c) c->bytes_all_gather += all_gather_bytes, c->bytes_all_to_all += all_to_all_bytes; }
+namespace nsgpu {
+int store_prepare_lens(nsgpu_ctx *c, SeqStore &st, const uint32_t *len, uint32_t n);       // api.hip
+int store_from_ascii_shard(nsgpu_ctx *c, SeqStore &st, const char *bases, const uint64_t *off, uint32_t n);
+}
 
 extern "C" {
 
@@ -243,52 +250,84 @@ int nsgpu_comm_init_callbacks(nsgpu_ctx *c, const nsgpu_comm_callbacks *cb, uint
 
 void nsgpu_comm_destroy(nsgpu_comm *c) { delete c; }
 
-// Shards in rank order (rank r passes reads [lo_r, hi_r) of one read set) -> every rank holds all reads.
+// Shards in rank order (rank r passes reads [lo_r, hi_r) of one read set) -> every rank holds all reads: 2-bit rows in HBM and, as the
+// contig engine's host copy, the same rows (0.25 B/base per rank; the ASCII text of the other ranks' reads never exists anywhere).
+// Each rank packs its own shard on its GPU; the packed rows are all-gathered device to device in pieces of at most 256 MiB per rank
+// (the row layout is a function of the lengths alone, so a shard's rows are one contiguous byte range of the replicated store).
 int nsgpu_dist_load_reads(nsgpu_ctx *c, nsgpu_comm *cm, const char *bases, const uint64_t *off, uint32_t n_local, uint32_t *lo_out, uint32_t *hi_out)
 {
     NS_CHECK(c && cm && off && cm->ctx == c, NSGPU_ERR_ARG, "nsgpu_dist_load_reads: bad argument");
     NS_HIP(hipSetDevice(c->prm.device));
     Comm &C = *cm->impl;
     const uint32_t W = C.world;
-    const uint64_t my_bytes = n_local ? off[n_local] - off[0] : 0;
+    const hipStream_t st = c->stream;
+    c->have_sketch = c->have_index = c->have_filter_all = c->have_cons = false;
+    // the own shard: ASCII -> 2-bit rows on this GPU (a store of its own)
+    SeqStore mine_st;
+    NS_TRY(store_from_ascii_shard(c, mine_st, bases, off, n_local));
+    c->ascii.release();                                              // the shard's text does not stay in HBM
     std::vector<uint64_t> cnt(2 * (size_t)W);
-    const uint64_t mine[2] = {n_local, my_bytes};
-    NS_TRY(C.all_gather(mine, cnt.data(), sizeof(mine), false, c->stream));
-    uint64_t max_n = 1, max_b = 1, tot_n = 0, tot_b = 0;
-    for (uint32_t p = 0; p < W; ++p) { max_n = std::max(max_n, cnt[2 * p]); max_b = std::max(max_b, cnt[2 * p + 1]); tot_n += cnt[2 * p]; tot_b += cnt[2 * p + 1]; }
+    const uint64_t mine[2] = {n_local, mine_st.packed_bytes};
+    NS_TRY(C.all_gather(mine, cnt.data(), sizeof(mine), false, st));
+    cm->bytes_all_gather += sizeof(mine) * W;
+    uint64_t max_n = 1, max_b = 1, tot_n = 0;
+    for (uint32_t p = 0; p < W; ++p) { max_n = std::max(max_n, cnt[2 * p]); max_b = std::max(max_b, cnt[2 * p + 1]); tot_n += cnt[2 * p]; }
     NS_CHECK(tot_n < (1ull << 32), NSGPU_ERR_RANGE, "Too many reads for read_t (src/ReadData.cpp:194-196)");
-    // lengths
-    std::vector<uint32_t> len_mine(max_n, 0), len_all(max_n * W);
+    // lengths (host) -> the layout of the replicated store
+    std::vector<uint32_t> len_mine(max_n, 0), len_all(max_n * W), lens(tot_n);
     for (uint32_t r = 0; r < n_local; ++r) len_mine[r] = (uint32_t)(off[r + 1] - off[r]);
-    NS_TRY(C.all_gather(len_mine.data(), len_all.data(), max_n * 4, false, c->stream));
-    // bases, in pieces of at most 256 MiB per rank (bounded staging)
-    std::vector<char> all_bases(tot_b + 1);
-    std::vector<uint64_t> base_lo(W + 1, 0);
-    for (uint32_t p = 0; p < W; ++p) base_lo[p + 1] = base_lo[p] + cnt[2 * p + 1];
-    const uint64_t piece = 256ull << 20;
-    std::vector<char> sb(std::min(max_b, piece)), rb(std::min(max_b, piece) * W);
-    for (uint64_t o = 0; o < max_b; o += piece) {
-        const uint64_t m = std::min(piece, max_b - o);
-        const uint64_t have = o < my_bytes ? std::min(m, my_bytes - o) : 0;
-        if (have) memcpy(sb.data(), bases + off[0] + o, have);
-        NS_TRY(C.all_gather(sb.data(), rb.data(), m, false, c->stream));
-        for (uint32_t p = 0; p < W; ++p) {
-            const uint64_t pb = cnt[2 * p + 1];
-            if (o < pb) memcpy(all_bases.data() + base_lo[p] + o, rb.data() + (uint64_t)p * m, std::min(m, pb - o));
-        }
-    }
-    std::vector<uint64_t> all_off(tot_n + 1, 0);
+    NS_TRY(C.all_gather(len_mine.data(), len_all.data(), max_n * 4, false, st));
+    cm->bytes_all_gather += max_n * 4 * W;
     cm->lo.assign(W + 1, 0);
     uint64_t k = 0;
     for (uint32_t p = 0; p < W; ++p) {
         cm->lo[p] = (uint32_t)k;
-        for (uint64_t r = 0; r < cnt[2 * p]; ++r, ++k) all_off[k + 1] = all_off[k] + len_all[(uint64_t)p * max_n + r];
+        for (uint64_t r = 0; r < cnt[2 * p]; ++r) lens[k++] = len_all[(uint64_t)p * max_n + r];
     }
     cm->lo[W] = (uint32_t)k;
-    NS_CHECK(all_off[tot_n] == tot_b, NSGPU_ERR_ARG, "nsgpu_dist_load_reads: the shards' lengths do not add up");
-    NS_TRY(nsgpu_load_reads_ascii(c, all_bases.data(), all_off.data(), (uint32_t)tot_n));
+    SeqStore &S = c->reads;
+    NS_TRY(store_prepare_lens(c, S, lens.data(), (uint32_t)tot_n));
+    for (uint32_t p = 0; p < W; ++p)
+        NS_CHECK(S.h_poff[cm->lo[p + 1]] - S.h_poff[cm->lo[p]] == cnt[2 * p + 1], NSGPU_ERR_ARG, "nsgpu_dist_load_reads: the shards' rows do not add up");
+    // packed rows, device to device, bounded staging
+    const uint64_t piece = std::min<uint64_t>(256ull << 20, max_b);
+    NS_TRY(cm->d_a.reserve(piece + 16));
+    NS_TRY(cm->d_b.reserve(piece * W + 16));
+    for (uint64_t o = 0; o < max_b; o += piece) {
+        const uint64_t m = std::min(piece, max_b - o);
+        const uint64_t have = o < mine_st.packed_bytes ? std::min(m, mine_st.packed_bytes - o) : 0;
+        if (have) NS_HIP(hipMemcpyAsync(cm->d_a.p, mine_st.packed.as<uint8_t>() + o, have, hipMemcpyDeviceToDevice, st));
+        NS_TRY(C.all_gather(cm->d_a.p, cm->d_b.p, m, true, st));
+        cm->bytes_all_gather += m * W;
+        for (uint32_t p = 0; p < W; ++p) {
+            const uint64_t pb = cnt[2 * p + 1];
+            if (o < pb) NS_HIP(hipMemcpyAsync(S.packed.as<uint8_t>() + S.h_poff[cm->lo[p]] + o, cm->d_b.as<uint8_t>() + (uint64_t)p * m, std::min(m, pb - o), hipMemcpyDeviceToDevice, st));
+        }
+        NS_HIP(stream_wait(st));
+    }
+    mine_st.release();
+    cm->d_a.release(); cm->d_b.release();                            // up to W x 256 MiB: not kept for the small exchanges that follow
+    // host side: offsets in bases, and the packed rows as the engine's copy of the reads (never the ASCII text of all reads)
+    c->h_off.assign((size_t)tot_n + 1, 0);
+    for (uint64_t r = 0; r < tot_n; ++r) c->h_off[r + 1] = c->h_off[r] + lens[r];
+    c->h_bases.clear(), c->h_bases.shrink_to_fit();
+    NS_TRY(mirror_finalize(c, true));
     if (lo_out) *lo_out = cm->lo[C.rank];
     if (hi_out) *hi_out = cm->lo[C.rank + 1];
+    return NSGPU_OK;
+}
+
+// bytes this rank received in all-gathers / all-to-alls so far (load + every sketch_index + every consensus run), for bench.py's record
+int nsgpu_comm_stats(const nsgpu_comm *cm, uint64_t *bytes_all_gather, uint64_t *bytes_all_to_all, uint64_t *host_bytes_reads)
+{
+    NS_CHECK(cm, NSGPU_ERR_ARG, "nsgpu_comm_stats: null communicator");
+    if (bytes_all_gather) *bytes_all_gather = cm->bytes_all_gather;
+    if (bytes_all_to_all) *bytes_all_to_all = cm->bytes_all_to_all;
+    // what the contig engine's host copy of ALL reads occupies on this rank: packed rows (or the ASCII text) + the offset tables
+    if (host_bytes_reads) {
+        const nsgpu_ctx *c = cm->ctx;
+        *host_bytes_reads = c->h_packed.capacity() + c->h_bases.capacity() + c->h_off.capacity() * 8 + c->reads.h_poff.capacity() * 8 + c->reads.h_len.capacity() * 4;
+    }
     return NSGPU_OK;
 }
 
@@ -313,6 +352,7 @@ int nsgpu_dist_sketch_index(nsgpu_ctx *c, nsgpu_comm *cm, const uint64_t *salts,
             NS_TRY(cm->d_b.reserve(blk * W + 16));
             if (rows) NS_HIP(hipMemcpyAsync(cm->d_a.p, c->sketch.as<uint8_t>() + (size_t)lo * n * 8, (size_t)rows * n * 8, hipMemcpyDeviceToDevice, st));
             NS_TRY(C.all_gather(cm->d_a.p, cm->d_b.p, blk, true, st));
+            cm->bytes_all_gather += blk * W;
             for (uint32_t p = 0; p < W; ++p) {
                 const uint32_t rp = cm->lo[p + 1] - cm->lo[p];
                 if (p != me && rp)
@@ -351,6 +391,7 @@ int nsgpu_dist_sketch_index(nsgpu_ctx *c, nsgpu_comm *cm, const uint64_t *salts,
     }
     NS_HIP(stream_wait(st));                       // blk_off etc. are stack/host vectors: uploaded before they go out of scope
     NS_TRY(C.all_to_all_v(cm->d_a.p, sb.data(), cm->d_b.p, rb.data(), true, st));
+    cm->bytes_all_to_all += ro * 8;
     // the owner's tables: sort (key) then (slot), as build_index does for all n
     const uint64_t total = (uint64_t)own * N;
     const size_t gblk = (size_t)max_own * N;
@@ -375,6 +416,7 @@ int nsgpu_dist_sketch_index(nsgpu_ctx *c, nsgpu_comm *cm, const uint64_t *salts,
     NS_TRY(c->idx_tmp_e2.reserve(gblk * 4 * W + 16));
     NS_TRY(C.all_gather(c->idx_tmp_k.p, c->idx_tmp_e.p, gblk * 8, true, st));
     NS_TRY(C.all_gather(c->idx_tmp_v.p, c->idx_tmp_e2.p, gblk * 4, true, st));
+    cm->bytes_all_gather += (uint64_t)gblk * 12 * W;
     const uint64_t all = (uint64_t)N * n;
     NS_TRY(c->idx_keys.reserve((all + 1) * 8));
     NS_TRY(c->idx_ids.reserve((all + 1) * 4));

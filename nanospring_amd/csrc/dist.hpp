@@ -21,3 +21,4 @@ struct Comm {
 }  // namespace nsgpu
 
 nsgpu::Comm *nsgpu_comm_impl(nsgpu_comm *c);
+void nsgpu_comm_count(nsgpu_comm *c, uint64_t all_gather_bytes, uint64_t all_to_all_bytes);     // bench.py's record of collective traffic

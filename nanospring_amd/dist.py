@@ -402,6 +402,13 @@ class DistJob:
         out["n_collectives"] = out.get("reserved", 0)
         return out
 
+    def comm_stats(self):
+        """bytes this rank received in all-gathers / all-to-alls so far, and the host memory of its copy of all reads"""
+        import ctypes as C
+        a, b, h = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.F.check(self.gpu.lib, self.gpu.lib.nsgpu_comm_stats(self.comm, C.byref(a), C.byref(b), C.byref(h)))
+        return {"all_gather_bytes": int(a.value), "all_to_all_bytes": int(b.value), "host_bytes_of_the_read_copy": int(h.value)}
+
     def close(self):
         if self.comm:
             self.gpu.lib.nsgpu_comm_destroy(self.comm)

@@ -95,3 +95,59 @@ def test_exchange_path_over_rccl_world_size_one(driver):
         assert streams[k] == s1[k], k
     for k in ("n_contigs", "n_lone", "count_minhash", "count_aligner", "n_align_calls"):
         assert st[k] == st1[k], k
+
+
+@pytest.mark.parametrize("world,groups,depth", [(2, 4, 0), (3, 1, 3), (2, 2, 2)])
+def test_cxx_driver_over_callback_communicator(tmp_path, world, groups, depth):
+    """INTEGRATION.md section 3b executed, not only described: a C++11 program (tests/integration/dist_stage.cpp: no Python, W forked
+    processes on the one GPU, collectives as host callbacks over shared memory -- where a C++ host would plug MPI) drives
+    nsgpu_dist_load_reads / _sketch_index / _consensus_run; its contigs are those of one process with the same number of builders and
+    the same schedule, every read decodes, and a rank's host copy of ALL reads is the 2-bit rows (<= 0.3 B/base + 24 B/read), never
+    the ASCII text."""
+    exe = tmp_path / "dist_stage"
+    lib_dir = os.path.dirname(ns.lib_path())
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "integration", "dist_stage.cpp"),
+                        "-o", str(exe), "-L", lib_dir, "-lnsgpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    bases, off = ns.synth_reads(41, 120000, N_READS, 3000.0)
+    b = bytes(bases)
+    reads = [b[int(off[i]):int(off[i + 1])] for i in range(N_READS)]
+    fq = tmp_path / "reads.fastq"
+    with open(fq, "wb") as f:
+        for i, s in enumerate(reads):
+            f.write(b"@r%d\n" % i + s + b"\n+\n" + b"I" * len(s) + b"\n")
+    out = tmp_path / "tmp"
+    out.mkdir()
+    for rk in range(world):
+        (out / ("rank%d" % rk)).mkdir()
+    r = subprocess.run([str(exe), str(fq), str(out) + "/", str(world), str(N_BUILDERS), str(groups), str(depth), "1"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, NSGPU_THREADS="4"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "lossless check: 0 bad reads" in r.stdout
+    # one process, same builders, same schedule
+    g = ns.NsGpu()
+    g.load_reads((bases, off))
+    g.sketch(ns.mt19937_64_salts(60, 12345), fetch=False)
+    g.build_index()
+    st1 = ns.consensus_run(g, N_BUILDERS, 1, schedule=(groups, depth, 1))
+    want_genomes = sorted(ns.consensus_stream(g, 0, "genome").split(b"\n")[:-1])
+    g.close()
+    tot = {ln.split(" = ")[0]: int(ln.split(" = ")[1]) for ln in r.stdout.splitlines() if " = " in ln}
+    assert tot["numContigs"] == st1["n_contigs"] and tot["#LoneReads"] == st1["n_lone"]
+    got, genomes = {}, []
+    for rk in range(world):
+        streams = {e: open(out / ("rank%d" % rk) / ("Stream.tid.0." + e), "rb").read() for e in STREAMS}
+        d = decode(streams)
+        assert not set(d) & set(got)
+        got.update(d)
+        genomes += streams["genome"].split(b"\n")[:-1]
+    assert sorted(got) == list(range(N_READS)) and all(got[i] == reads[i] for i in range(N_READS))
+    assert sorted(genomes) == want_genomes
+    n_bases = int(off[-1])
+    for ln in r.stdout.splitlines():
+        if ln.startswith("rank "):
+            f = ln.split()
+            host_bytes, ag, aa = int(f[f.index("copy") + 1]), int(f[f.index("all-gather") + 2]), int(f[f.index("all-to-all") + 2])
+            assert host_bytes <= 0.3 * n_bases + 24 * N_READS + (1 << 16), ln
+            assert ag > 0.25 * n_bases and aa > 0, ln                      # the packed rows and the bucket tuples did travel
