@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--groups", type=int, default=1, choices=[1, 2, 4], help="pipeline groups of the contig stage: a builder steps once per `groups` slots (nsgpu_set_schedule)")
     ap.add_argument("--seed-depth", type=int, default=3, help="conflict-aware seeds: bucket depth (0 = the reference's getRead rule)")
     ap.add_argument("--seed-rings", type=int, default=5, help="conflict-aware seeds: adjacency rings around occupied buckets that a seed must keep clear of")
+    ap.add_argument("--genome", choices=["iid", "repeats"], default="iid", help="synthetic genome: iid (BASELINE cfg2) or with planted duplications / tandem repeats / homopolymer and (AT)n runs")
     ap.add_argument("--throughput-leg", type=int, default=-1, help="also time ONE step of the 1024-builder pipelined schedule, which is not iso-compression (default: only with 1 GPU at full cfg2 size; 0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the all-cores CPU-baseline sample (0 = skip; default: 2000 per host core)")
     ap.add_argument("--no-exchange", action="store_true", help="multi-GPU: independent shards, no collective")
@@ -141,7 +142,7 @@ def main():
     exchange = world > 1 and not args.no_exchange
     genome_len = int(world * args.reads * args.mean_len / 20)  # 20x depth; one genome for the whole job
     # rank r owns read ids [r*R, (r+1)*R) of one read set
-    bases, off = ns.synth_reads(11, genome_len, args.reads, args.mean_len, first=rank * args.reads)
+    bases, off = ns.synth_reads(11, genome_len, args.reads, args.mean_len, first=rank * args.reads, genome=args.genome)
     n_bases = int(off[-1])
 
     stream = torch.cuda.Stream()
@@ -240,7 +241,7 @@ def main():
         # OpenMP loop): -t 8 (profiles/r03_oracle_t8_cfg2.json) and -t 1 (profiles/r02_one_builder_cfg2.json).
         def compression_of(stream_bytes_per_base, stats):
             out = {"builders": stats["n_builders"], "stream_bytes_per_base": round(stream_bytes_per_base, 4), "contigs": stats["n_contigs"], "lone_reads": stats["n_lone"]}
-            if args.reads == 100000 and args.mean_len == 8000.0 and world == 1:
+            if args.reads == 100000 and args.mean_len == 8000.0 and world == 1 and args.genome == "iid":
                 for key, name in (("reference_tN", "r03_oracle_t8_cfg2.json"), ("reference_t1", "r02_one_builder_cfg2.json")):
                     pth = os.path.join(ROOT, "profiles", name)
                     if os.path.exists(pth):
@@ -285,7 +286,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "i8", "data": "synthetic",
             "config": {"workload": f"cfg2: {args.reads} synthetic ONT reads/GPU, mean {args.mean_len:.0f} b, 20x of an iid genome, "
-                                   f"1% sub + 1% ins + 1% del, k=23 n=60 thr=6, minimap k=20 w=50 max_chain_iter=400, salts mt19937_64(12345)",
+                                   f"1% sub + 1% ins + 1% del, k=23 n=60 thr=6, minimap k=20 w=50 max_chain_iter=400, salts mt19937_64(12345)"
+                                   + ("" if args.genome == "iid" else "; genome with planted repeats (a 4 kb duplication, a 1.5 kb tandem repeat, a homopolymer run, an (AT)n / (ACGT)n run per ~150 kb): NOT the cfg2 genome"),
+                       "genome": args.genome,
                        "stages": ["sketch", "bucket-tables", "overlap (window queries)", "align (batched alignRead, DP on GPU)",
                                   "consensus graph + edit emission (host)"],
                        "bases_per_gpu": n_bases, "builders": st["n_builders"], "schedule": {"groups": args.groups, "seed_bucket_depth": args.seed_depth, "seed_rings": args.seed_rings},

@@ -355,6 +355,10 @@ int nsgpu_synth_reads(uint64_t seed, uint64_t genome_len, uint32_t n_reads, doub
 /* reads [first, first + n_reads) of the same read set (multi-GPU ranks generate only their id range) */
 int nsgpu_synth_reads_range(uint64_t seed, uint64_t genome_len, uint32_t first, uint32_t n_reads, double mean_len,
                             double p_sub, double p_ins, double p_del, char **bases_out, uint64_t **off_out);
+/* the same read model over a genome with planted repeats (genome_kind 1: every ~40 kb in turn a 4 kb interspersed duplication, a 1.5 kb
+ * tandem repeat, a homopolymer run, an (AT)n / (ACGT)n run); genome_kind 0 = the iid genome of the calls above */
+int nsgpu_synth_reads_kind(uint64_t seed, uint64_t genome_len, uint32_t first, uint32_t n_reads, double mean_len, double p_sub,
+                           double p_ins, double p_del, uint32_t genome_kind, char **bases_out, uint64_t **off_out);
 
 #ifdef __cplusplus
 }

@@ -96,6 +96,8 @@ SIGNATURES = {
     "nsgpu_get_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
     "nsgpu_synth_reads": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_double,
                                     C.POINTER(_vp), C.POINTER(_vp)]),
+    "nsgpu_synth_reads_kind": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32,
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "nsgpu_synth_reads_range": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_double,
                                           C.POINTER(_vp), C.POINTER(_vp)]),
 }

@@ -67,7 +67,33 @@ uint64_t emit_read(const std::vector<char> &genome, const Plan &pl, uint64_t see
 }  // namespace
 
 static int synth_impl(uint64_t seed, uint64_t genome_len, uint32_t first, uint32_t n_reads, double mean_len, double p_sub, double p_ins,
-                      double p_del, char **bases_out, uint64_t **off_out);
+                      double p_del, char **bases_out, uint64_t **off_out, uint32_t genome_kind = 0);
+
+// genome_kind 1: the iid genome with what real ONT genomes have and the iid one lacks, planted every ~150 kb in turn: a 4 kb segment copied
+// from ~40 kb upstream (an interspersed duplication: minimizers with two reference positions, several chains, mm_set_parent / select_sub),
+// a 1.5 kb tandem repeat of a 5-mer-to-40-mer unit (anchors sharing reference positions: the radix sort's tie order), a homopolymer run
+// of 20-60 bases, and a 60-200 base (AT)n / (ACGT)n run (k-mers equal to their own reverse complement: mm_sketch pushes nothing there).
+extern "C" int nsgpu_synth_reads_kind(uint64_t seed, uint64_t genome_len, uint32_t first, uint32_t n_reads, double mean_len, double p_sub,
+                                      double p_ins, double p_del, uint32_t genome_kind, char **bases_out, uint64_t **off_out)
+{
+    return synth_impl(seed, genome_len, first, n_reads, mean_len, p_sub, p_ins, p_del, bases_out, off_out, genome_kind);
+}
+
+static void plant_repeats(std::vector<char> &g, uint64_t seed)
+{
+    const uint64_t L = g.size();
+    uint64_t k = 0;
+    for (uint64_t pos = 60000; pos + 8000 < L; pos += 37000 + (mix(seed ^ 0x77ull, k) % 3000), ++k) {
+        Rng rng(mix(seed ^ 0x9999ull, k));
+        switch (k & 3) {
+        case 0: { const uint64_t src = pos - 40000 + rng.next() % 2000; for (uint64_t i = 0; i < 4000; ++i) g[pos + i] = g[src + i]; break; }
+        case 1: { const uint64_t u = 5 + rng.next() % 36; for (uint64_t i = u; i < 1500; ++i) g[pos + i] = g[pos + i % u]; break; }
+        case 2: { const uint64_t n = 20 + rng.next() % 41; const char b = kBase[rng.next() & 3]; for (uint64_t i = 0; i < n; ++i) g[pos + i] = b; break; }
+        default: { const uint64_t n = 60 + rng.next() % 141; const char *unit = (rng.next() & 1) ? "AT" : "ACGT"; const uint64_t u = strlen(unit);
+                   for (uint64_t i = 0; i < n; ++i) g[pos + i] = unit[i % u]; break; }
+        }
+    }
+}
 
 extern "C" int nsgpu_synth_reads(uint64_t seed, uint64_t genome_len, uint32_t n_reads, double mean_len, double p_sub, double p_ins,
                                  double p_del, char **bases_out, uint64_t **off_out)
@@ -83,7 +109,7 @@ extern "C" int nsgpu_synth_reads_range(uint64_t seed, uint64_t genome_len, uint3
 }
 
 static int synth_impl(uint64_t seed, uint64_t genome_len, uint32_t first, uint32_t n_reads, double mean_len, double p_sub, double p_ins,
-                      double p_del, char **bases_out, uint64_t **off_out)
+                      double p_del, char **bases_out, uint64_t **off_out, uint32_t genome_kind)
 {
     if (!bases_out || !off_out || genome_len < 1000) return NSGPU_ERR_ARG;
     unsigned nt = std::thread::hardware_concurrency();
@@ -106,6 +132,7 @@ static int synth_impl(uint64_t seed, uint64_t genome_len, uint32_t first, uint32
             });
         for (auto &x : th) x.join();
     }
+    if (genome_kind == 1 && genome_len > 200000) plant_repeats(genome, seed);
     std::vector<Plan> plan(n_reads);
     for (uint32_t r = 0; r < n_reads; ++r) {
         Rng rng(mix(seed ^ 0x5151515151ull, (uint64_t)first + r));

@@ -42,12 +42,13 @@ def mt19937_64_salts(n, seed=12345):
     return np.array(out, dtype=np.uint64)
 
 
-def synth_reads(seed, genome_len, n_reads, mean_len=8000.0, p_sub=0.01, p_ins=0.01, p_del=0.01, first=0):
+def synth_reads(seed, genome_len, n_reads, mean_len=8000.0, p_sub=0.01, p_ins=0.01, p_del=0.01, first=0, genome="iid"):
     """SURVEY 8d synthetic reads.  Returns (bases: np.uint8 array of ASCII, off: np.uint64[n+1]).
-    first > 0: reads [first, first + n_reads) of the same read set (a multi-GPU rank's id range)."""
+    first > 0: reads [first, first + n_reads) of the same read set (a multi-GPU rank's id range).
+    genome="repeats": the iid genome with planted interspersed duplications, tandem repeats, homopolymer and (AT)n / (ACGT)n runs."""
     lib = load_library()
     pb, po = C.c_void_p(), C.c_void_p()
-    rc = lib.nsgpu_synth_reads_range(seed, genome_len, first, n_reads, mean_len, p_sub, p_ins, p_del, C.byref(pb), C.byref(po))
+    rc = lib.nsgpu_synth_reads_kind(seed, genome_len, first, n_reads, mean_len, p_sub, p_ins, p_del, {"iid": 0, "repeats": 1}[genome], C.byref(pb), C.byref(po))
     if rc != 0:
         raise NsGpuError(f"nsgpu_synth_reads failed ({rc})")
     off = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), shape=(n_reads + 1,)).copy()

@@ -382,3 +382,22 @@ def test_cfg2_full_one_builder_equals_oracle_hashes():
         assert st[f] == want["stats"][f], f
     assert ns.consensus_verify(g) == 0
     g.close()
+
+
+def test_repeats_genome_sketch_splice_and_schedules():
+    """bench.py --genome repeats: interspersed duplications, tandem repeats, homopolymer runs and (AT)n / (ACGT)n runs (k-mers equal to their
+    own reverse complement push nothing in mm_sketch: the incremental consensus sketch must fall back to a whole sketch around them --
+    NSGPU_SKETCH_CHECK=1 aborts on a spliced list that differs from a whole sketch).  One builder = the oracle at -t 1; the bench's
+    schedule = the oracle's lock-step virtual threads."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import nanospring_amd as ns\n"
+        "from tests import test_consensus_gpu as t\n"
+        "bases, off = ns.synth_reads(3, 420000, 700, 6000.0, genome='repeats')\n"
+        "t.one_builder_equals_oracle(bases, off)\n"
+        "w = t.many_builders_equal_lockstep_oracle(bases, off, 12, 1, 3, 2)\n"
+        "print('OK', w['count_aligner'])\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NSGPU_SKETCH_CHECK="1"), capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
