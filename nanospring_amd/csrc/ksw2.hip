@@ -773,6 +773,8 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         NS_CHECK(cl[i] != 254, NSGPU_ERR_ARG, "ksw: negative length");
         NS_CHECK(cl[i] != 253, NSGPU_ERR_ARG, "ksw: KSW_EZ_GENERIC_SC is not on NanoSpring's path");
         NS_CHECK(cl[i] != 252, NSGPU_ERR_RANGE, "ksw: traceback matrix of one problem exceeds 4 GiB (band the problem or split it)");
+        static const bool no_early = getenv("NSGPU_KSW_NO_EARLY_EXIT") != nullptr;     // A/B switch for the register kernels' exact early exit
+        if (!no_early) t.flag |= 0x10000;                                                // KSW_EZ_NS_EARLY_EXIT (ksw2_reg.hip)
         t.out_idx = (uint32_t)i;
         t.p_off = p_total;
         t.cig_off = (uint32_t)cig_total;

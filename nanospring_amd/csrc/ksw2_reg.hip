@@ -37,6 +37,7 @@ namespace nsgpu {
 #define KSW_EZ_APPROX_DROP 0x10
 #define KSW_EZ_EXTZ_ONLY 0x40
 #define KSW_EZ_REV_CIGAR 0x80
+#define KSW_EZ_NS_EARLY_EXIT 0x10000      // not minimap2's: set by the host code of this library (ksw2.hip) unless NSGPU_KSW_NO_EARLY_EXIT
 
 typedef short s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u2 __attribute__((ext_vector_type(2)));
@@ -350,10 +351,30 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
     bool brk = false;
 
     // ---- exact mode, rows r > 0 and r == 0 alike: ksw2_extd2_sse.c:359-366 given the row's maximum and H[en0], H[st0] ----
+    // ---- exact early exit for extensions that run off the target's end (a read hanging over the end of its contig: qlen in the
+    // thousands against a few hundred target bases; these problems set the length of a DP launch) ----
+    // Once the target is exhausted, the reference keeps sweeping anti-diagonals until the band runs out (st > en: zdropped = 1, break) --
+    // about 2 tlen + w rows, most of them deep in the query's overhang where nothing can happen any more.  A cell (t, q) of row r = t + q
+    // with q >= t holds at most  sc_mch (t + 1) - g(q - t),  g(l) = min(q + e l, q2 + e2 l): the score of t + 1 matches and ONE gap of the
+    // length difference (gap costs are sub-additive).  That is largest at t = tlen - 1 and falls by at least e2 per row.  When it is
+    // below the best last-column score so far (mte <= max) for the NEXT row, no later row can raise max or mte; if, in addition, the band
+    // runs out before any row reaches the query's end (row 2 (tlen - 1) + w + 1 <= qlen - 1: mqe, reach_end and the score stay unset)
+    // the reference's final state is exactly: zdropped = 1 (by its Z-drop test or by the band), max / mte as they are now, and a
+    // backtrack from the maximum, which never looks at a later row.  So the sweep may stop here with that state.  The margin of 32
+    // covers the cells along the band's lower edge, whose inputs from outside the band are a row or two old (they sit w off the
+    // diagonal, hundreds of points below the bound's cell).  NSGPU_KSW_NO_EARLY_EXIT=1 in the host code switches it off (A/B, tests).
+    const bool early_ok = !APPROX && (flag & KSW_EZ_NS_EARLY_EXIT) && 2 * c2 + w + 1 <= c1;
     auto exact_row = [&](int r, int st0, int en0, int en, int max_H, int max_t, int h_en0, int h_st0) {
         if (en0 == c2) { const bool up = h_en0 > z.mte; z.mte_q = up ? r - en : z.mte_q, z.mte = up ? h_en0 : z.mte; }
         if (r - st0 == c1) { const bool up = h_st0 > z.mqe; z.mqe_t = up ? st0 : z.mqe_t, z.mqe = up ? h_st0 : z.mqe; }
-        if (__builtin_amdgcn_readfirstlane(zdrop_row(z, r, max_H, max_t, zdrop, K.e2))) { ez_zdropped = 1; brk = true; }
+        int stop = zdrop_row(z, r, max_H, max_t, zdrop, K.e2);
+        if (early_ok) {
+            const int L = r + 1 - 2 * c2;                       // q - t of the next row's cell on the target's last column
+            const int g1 = K.q + K.e * L, g2 = K.q2 + K.e2 * L;
+            const int bound = K.sc_mch * tlen - (g1 < g2 ? g1 : g2) + 32;
+            stop |= (L >= 1 && bound < z.mte) ? 1 : 0;
+        }
+        if (__builtin_amdgcn_readfirstlane(stop)) { ez_zdropped = 1; brk = true; }
         if (!brk && r == n_rows - 1 && en0 == c2) ez_score = __builtin_amdgcn_readfirstlane(h_en0);
     };
     // ---- approx mode with the reference's greedy H0 (ksw2_extd2_sse.c:367-383): banded or KSW_EZ_APPROX_DROP problems only ----

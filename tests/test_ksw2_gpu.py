@@ -158,3 +158,52 @@ def test_register_kernels_diverse_vs_oracle(gpu, oracle):
         n_long += len(t) > 1536
         n_zd += we[1]
     assert n_long > 40 and n_zd > 40
+
+
+def overhang_cases(seed, n):
+    """Extensions that run off the target's end (a read hanging over the end of its contig): a query of thousands of bases against a
+    short target, band exhausted long before the query's end -- the shape the register kernels' exact early exit serves (ksw2_reg.hip)
+    -- with related, unrelated and low-complexity sequences, all extension flags, thin and default bands, Z-drop on and off, plus
+    near-misses of the exit's precondition (band exhaustion row around the query's end)."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for it in range(n):
+        w = int([751, 751, 751, 300, 100, 50][rng.randint(6)])
+        tl = int(rng.randint(1, 1300))
+        kind = it % 6
+        if kind == 5:                                   # precondition boundary: 2 (tl - 1) + w + 1 around ql - 1
+            ql = max(1, 2 * (tl - 1) + w + 1 + int(rng.randint(-3, 4)) + 1)
+        else:
+            ql = int(rng.randint(2 * tl + w + 2, 2 * tl + w + 3000))
+        ql = min(ql, 5000)
+        flag = int([0x40, 0xC2, 0x42, 0x00, 0x40, 0xC2][rng.randint(6)])
+        zdrop = int([400, 400, -1, 50, 200][rng.randint(5)])
+        if kind in (0, 5):                              # related: the target is the start of the query, with errors
+            q, t = oracle_lib.ksw_random_problem(rng, ql, tl, err=[0.03, 0.1][rng.randint(2)])
+        elif kind == 1:                                 # unrelated
+            q = rng.randint(0, 4, size=ql).astype(np.uint8); t = rng.randint(0, 4, size=tl).astype(np.uint8)
+        elif kind == 2:                                 # homopolymer / short tandem repeat on both sides
+            u = rng.randint(0, 4, size=int(rng.randint(1, 5))).astype(np.uint8)
+            q = np.resize(u, ql).copy(); t = np.resize(u, tl).copy()
+            q[rng.randint(0, ql, size=ql // 50 + 1)] = rng.randint(0, 4); t[rng.randint(0, tl, size=tl // 50 + 1)] = rng.randint(0, 4)
+        elif kind == 3:                                 # the target re-appears deep in the query's overhang
+            q, t = oracle_lib.ksw_random_problem(rng, ql, tl, err=0.03)
+            at = int(rng.randint(tl, max(tl + 1, ql - tl)))
+            q[at:at + tl] = t[:min(tl, ql - at)]
+        else:                                           # N bases
+            q, t = oracle_lib.ksw_random_problem(rng, ql, tl, err=0.05, n_frac=0.03)
+        out.append((np.ascontiguousarray(q, dtype=np.uint8), np.ascontiguousarray(t, dtype=np.uint8), w, zdrop, 0 if flag >= 0x40 else -1, flag))
+    return out
+
+
+def test_overhang_extensions_with_early_exit_vs_oracle(gpu, oracle):
+    probs = overhang_cases(2024, 720)
+    ezs, cigs = ns.ksw_extd2_batch(gpu, probs)
+    n_zd = n_cls = 0
+    for i, (q, t, w, zdrop, eb, flag) in enumerate(probs):
+        we, wc = oracle_lib.oracle_ksw(oracle, q, t, w, zdrop, eb, flag)
+        assert ezs[i] == we, (i, len(q), len(t), w, zdrop, hex(flag), ezs[i], we)
+        assert np.array_equal(cigs[i], wc), (i, len(q), len(t), w, hex(flag))
+        n_zd += we[1]
+        n_cls += len(t) > 512
+    assert n_zd > 500 and n_cls > 200
