@@ -735,6 +735,11 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     static const int kWgThreads[3] = {0, 256, 256}, kWgMaxPos[3] = {0, 5, 8};      // widest sweep served: 1280 / 2048 cells (256 x 5 / 8 or 512 x 3 / 4)
     static const bool no_wg = getenv("NSGPU_KSW_NO_WG") != nullptr;      // debugging aid: fallback kernels only
     static const bool wg512 = getenv("NSGPU_KSW_WG256") == nullptr;     // 512 threads per long problem (8 waves; NSGPU_KSW_WG256=1: 4 waves)
+    // latency twins of the one-wave classes (ksw2_reg.hip: one 128-cell block per wave) for exact-mode problems with at least
+    // NSGPU_KSW_LATENCY_ROWS anti-diagonals.  Off by default.  Measured at the one-group schedule, where a whole round waits for its DP launch
+    // (cfg2, 80 builders, interleaved A/B): 700 rows: wait for the DP 5.4 instead of 4.7 s per step, whole path 72.4 instead of 76.6 Mbases/s;
+    // 400 / 1000 rows the same picture -- a barrier per anti-diagonal costs more than the second block of a lane saves.
+    static const int latency_rows = [] { const char *e = getenv("NSGPU_KSW_LATENCY_ROWS"); return e ? atoi(e) : 0; }();
     static const int wg_min_rows = [] { const char *e = getenv("NSGPU_KSW_WG_MIN_ROWS"); return e ? atoi(e) : 0; }();   // experiment knob
     size_t p_total = 0, cig_total = 0, hbm_stride = 0;
     // per-problem sizes and classes on all host threads (a batch has ~10^4 problems and this thread is on the slot's critical
@@ -757,7 +762,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
             const size_t pbytes = (ksw_p_bytes(t.qlen, t.tlen, t.w) + 63) & ~(size_t)63;
             if (pbytes >= (1ull << 32)) { cl[i] = 252; continue; }      // traceback of one problem beyond 4 GiB (e.g. 50 kb x 50 kb unbanded)
             pb[i] = (uint32_t)pbytes;
-            const int rcls = ksw_reg_class(t, pr);
+            const int rcls = ksw_reg_class(t, pr, latency_rows);
             if (rcls >= 0) { cl[i] = (uint8_t)(16 + rcls); continue; }
             const size_t need = ksw_lds_bytes(t.qlen, t.tlen, t.flag);
             const int cls = need <= kClass[0] ? 0 : need <= kClass[1] ? 1 : need <= kClass[2] ? 2 : 3;
@@ -876,7 +881,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         const uint32_t m = (uint32_t)reg[k].size();
         if (!m) continue;
         hipStream_t st = S;
-        if (k >= 2 && !dbg) { st = W.side_stream[k - 1]; NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0)); side_used[k - 1] = true; }
+        if (k >= 2 && !dbg) { const int si = k >= 4 ? 0 : k - 1; st = W.side_stream[si]; NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0)); side_used[si] = true; }
         double dbg_t0 = 0;
         if (dbg) { NS_HIP(stream_wait(S)); dbg_t0 = now_ms(); }
         NS_HIP(hipEventRecord(ev_at(n_ev++), st));

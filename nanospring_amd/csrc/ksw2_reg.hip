@@ -620,7 +620,9 @@ __global__ __launch_bounds__(NW * 64) void ksw_extd2_reg_kernel(const KswTask *_
 // thousand bases against a few hundred) are latency: the launch is over when its longest problem is, so they get one 128-cell block per
 // wave and row.
 struct RegClass { int nw, nch; };
-constexpr RegClass kRegClass[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {4, 3}, {8, 5}};
+// Classes 4 and 5 are the latency twins of 0 and 1 (same widths, one block per wave): for exact-mode problems with many anti-diagonals when
+// a DP launch is waited for by a whole round of the contig stage (few builders, one group) rather than overlapped with other groups' work.
+constexpr RegClass kRegClass[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {4, 3}, {8, 5}, {2, 1}, {4, 1}};
 
 }  // namespace
 
@@ -637,7 +639,7 @@ size_t ksw_reg_lds_bytes(int cls, int qlen)
 
 // Which register-resident class serves the problem, or -1: the proofs behind the packed arithmetic (no int8 wrap outside the four
 // adjusted gap terms, 16-bit H keys) hold for minimap2-sized scores and gap costs and for problems that fit a class.
-int ksw_reg_class(const KswTask &t, const KswParams &pr)
+int ksw_reg_class(const KswTask &t, const KswParams &pr, int latency_rows)
 {
     static const bool off = getenv("NSGPU_KSW_NO_REG") != nullptr;       // debugging aid: first-generation kernels only
     if (off || t.qlen <= 0 || t.tlen <= 0) return -1;
@@ -652,8 +654,15 @@ int ksw_reg_class(const KswTask &t, const KswParams &pr)
     // |H| of any in-band cell stays a 16-bit key: H <= sc_mch * min(qlen, tlen); along a diagonal H drops by at most |sc_mis| per cell, a
     // cell entering the band starts at most q + e below its neighbour (u >= -(q + e) for sane states), and there are at most w + 1 diagonals
     if ((long long)(-pr.sc_mis > pr.sc_mch ? -pr.sc_mis : pr.sc_mch) * mn + (long long)(q + e) * (w + 1) + 64 >= 32768) return -1;
-    for (int c = 0; c < KSW_REG_CLASSES; ++c)
-        if (t.tlen <= ksw_reg_cells(c)) return c;
+    for (int c = 0; c < 4; ++c)
+        if (t.tlen <= ksw_reg_cells(c)) {
+            if (c < 2 && latency_rows > 0 && !(t.flag & KSW_EZ_APPROX_MAX)) {
+                // anti-diagonals the sweep can take: all of them, or until the band runs out
+                const long long full = (long long)t.qlen + t.tlen - 1, band = 2ll * (t.tlen - 1) + w + 1;
+                if ((full < band ? full : band) >= latency_rows) return 4 + c;
+            }
+            return c;
+        }
     return -1;
 }
 
@@ -678,6 +687,8 @@ int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const 
     case 1: NS_REG_LAUNCH(1, 4) break;
     case 2: NS_REG_LAUNCH(4, 3) break;
     case 3: NS_REG_LAUNCH(8, 5) break;
+    case 4: NS_REG_LAUNCH(2, 1) break;
+    case 5: NS_REG_LAUNCH(4, 1) break;
     default: NS_CHECK(false, NSGPU_ERR_ARG, "ksw: bad register class");
     }
 #undef NS_REG_LAUNCH

@@ -207,3 +207,37 @@ def test_overhang_extensions_with_early_exit_vs_oracle(gpu, oracle):
         n_zd += we[1]
         n_cls += len(t) > 512
     assert n_zd > 500 and n_cls > 200
+
+
+LATENCY_WORKER = r'''
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import nanospring_amd as ns
+from tests import oracle_lib
+from tests.ksw_cases import diverse_cases
+from tests.test_ksw2_gpu import overhang_cases
+orc = oracle_lib.Oracle()
+g = ns.NsGpu()
+probs = diverse_cases(17, 320) + overhang_cases(99, 360)
+ezs, cigs = ns.ksw_extd2_batch(g, probs)
+bad = 0
+for i, (q, t, w, zd, eb, fl) in enumerate(probs):
+    we, wc = oracle_lib.oracle_ksw(orc, q, t, w, zd, eb, fl)
+    if ezs[i] != we or not np.array_equal(cigs[i], wc):
+        bad += 1
+print("RESULT", bad, len(probs))
+'''
+
+
+@pytest.mark.parametrize("env", [{"NSGPU_KSW_LATENCY_ROWS": "200"}, {"NSGPU_KSW_LATENCY_ROWS": "200", "NSGPU_KSW_NO_EARLY_EXIT": "1"}, {"NSGPU_KSW_NO_EARLY_EXIT": "1"}])
+def test_latency_classes_and_early_exit_switches(env):
+    """The latency twins of the one-wave register classes (one 128-cell block per wave: <2,1>, <4,1>; the contig stage with one group
+    uses them for exact-mode problems with many anti-diagonals) and the early exit, each on and off: bit-exact against the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", LATENCY_WORKER % {"root": root}], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert int(line[1]) == 0 and int(line[2]) == 680, (env, line)
