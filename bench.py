@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--groups", type=int, default=1, choices=[1, 2, 4], help="pipeline groups of the contig stage: a builder steps once per `groups` slots (nsgpu_set_schedule)")
     ap.add_argument("--seed-depth", type=int, default=3, help="conflict-aware seeds: bucket depth (0 = the reference's getRead rule)")
     ap.add_argument("--seed-rings", type=int, default=5, help="conflict-aware seeds: adjacency rings around occupied buckets that a seed must keep clear of")
+    ap.add_argument("--depth", type=float, default=20.0, help="sequencing depth of the synthetic read set (cfg2: 20; cfg3's E. coli regime: ~200)")
     ap.add_argument("--genome", choices=["iid", "repeats"], default="iid", help="synthetic genome: iid (BASELINE cfg2) or with planted duplications / tandem repeats / homopolymer and (AT)n runs")
     ap.add_argument("--throughput-leg", type=int, default=-1, help="also time ONE step of the 1024-builder pipelined schedule, which is not iso-compression (default: only with 1 GPU at full cfg2 size; 0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the all-cores CPU-baseline sample (0 = skip; default: 2000 per host core)")
@@ -140,7 +141,7 @@ def main():
     k, n, thr = 23, 60, 6
     salts = ns.mt19937_64_salts(n, 12345)
     exchange = world > 1 and not args.no_exchange
-    genome_len = int(world * args.reads * args.mean_len / 20)  # 20x depth; one genome for the whole job
+    genome_len = int(world * args.reads * args.mean_len / args.depth)  # 20x depth by default; one genome for the whole job
     # rank r owns read ids [r*R, (r+1)*R) of one read set
     bases, off = ns.synth_reads(11, genome_len, args.reads, args.mean_len, first=rank * args.reads, genome=args.genome)
     n_bases = int(off[-1])
@@ -241,7 +242,7 @@ def main():
         # OpenMP loop): -t 8 (profiles/r03_oracle_t8_cfg2.json) and -t 1 (profiles/r02_one_builder_cfg2.json).
         def compression_of(stream_bytes_per_base, stats):
             out = {"builders": stats["n_builders"], "stream_bytes_per_base": round(stream_bytes_per_base, 4), "contigs": stats["n_contigs"], "lone_reads": stats["n_lone"]}
-            if args.reads == 100000 and args.mean_len == 8000.0 and world == 1 and args.genome == "iid":
+            if args.reads == 100000 and args.mean_len == 8000.0 and world == 1 and args.genome == "iid" and args.depth == 20.0:
                 for key, name in (("reference_tN", "r03_oracle_t8_cfg2.json"), ("reference_t1", "r02_one_builder_cfg2.json")):
                     pth = os.path.join(ROOT, "profiles", name)
                     if os.path.exists(pth):
@@ -256,7 +257,7 @@ def main():
         penalty["schedule"] = {"groups": args.groups, "seed_bucket_depth": args.seed_depth, "seed_rings": args.seed_rings}
         # one step of the 1024-builder, four-group pipelined schedule with the reference's seed rule (the round-2 headline): faster, larger streams
         tleg = None
-        want_leg = args.throughput_leg if args.throughput_leg >= 0 else int(world == 1 and args.reads == 100000)
+        want_leg = args.throughput_leg if args.throughput_leg >= 0 else int(world == 1 and args.reads == 100000 and args.depth == 20.0 and args.genome == "iid")
         if want_leg and world == 1 and not (args.builders == 1024 and args.groups == 4 and args.seed_depth == 0):
             ns.set_schedule(g, 4, 0, 1)
             g.sketch(salts, fetch=False); g.build_index()
@@ -285,7 +286,7 @@ def main():
             "ms_per_step": round(dt / steps * 1e3, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "i8", "data": "synthetic",
-            "config": {"workload": f"cfg2: {args.reads} synthetic ONT reads/GPU, mean {args.mean_len:.0f} b, 20x of an iid genome, "
+            "config": {"workload": f"cfg2: {args.reads} synthetic ONT reads/GPU, mean {args.mean_len:.0f} b, {args.depth:g}x of an iid genome, "
                                    f"1% sub + 1% ins + 1% del, k=23 n=60 thr=6, minimap k=20 w=50 max_chain_iter=400, salts mt19937_64(12345)"
                                    + ("" if args.genome == "iid" else "; genome with planted repeats (a 4 kb duplication, a 1.5 kb tandem repeat, a homopolymer run, an (AT)n / (ACGT)n run per ~150 kb): NOT the cfg2 genome"),
                        "genome": args.genome,

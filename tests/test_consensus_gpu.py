@@ -401,3 +401,45 @@ def test_repeats_genome_sketch_splice_and_schedules():
         "print('OK', w['count_aligner'])\n" % root)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NSGPU_SKETCH_CHECK="1"), capture_output=True, text=True, timeout=850)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+CFG3_WORKER = r'''
+import hashlib, resource, sys
+sys.path.insert(0, %(root)r)
+import nanospring_amd as ns
+from nanospring_amd.filter import STREAMS
+bases, off = ns.synth_reads(11, 4600000, 125000, 8000.0)
+g = ns.NsGpu()
+g.load_reads((bases, off))
+for rep in range(2):
+    g.sketch(ns.mt19937_64_salts(60, 12345), fetch=False)
+    g.build_index()
+    st = ns.consensus_run(g, 1024, 4, schedule=(4, 0, 1))
+    h = hashlib.sha256()
+    for t in range(4):
+        for k in STREAMS:
+            h.update(ns.consensus_stream(g, t, k))
+    print("RUN", h.hexdigest(), st["n_contigs"], st["count_aligner"], ns.consensus_verify(g), int(off[-1]), flush=True)
+print("RSS_GB", resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0)
+g.close()
+'''
+
+
+def test_cfg3_at_size_many_builders_lossless_deterministic_bounded_memory():
+    """BASELINE configs[2] at size: ~1 Gbase of 8 kb reads over a 4.6 Mb genome (~217x, the E. coli regime: every window query returns
+    hundreds of candidates, edges carry long read lists).  1024 builders: every read decodes, two runs give the same streams, and the
+    process stays under 28 GB of host memory (the reference: 18-25 GB for 84-133 Gbases with 20 threads; ours is dominated by the
+    graphs of the contigs in flight).  A 5 %% sub-sample with ONE builder equals the oracle at -t 1."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", CFG3_WORKER % {"root": root}], capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    runs = [l.split()[1:] for l in r.stdout.splitlines() if l.startswith("RUN")]
+    assert len(runs) == 2 and runs[0] == runs[1], runs
+    assert runs[0][3] == "0" and int(runs[0][4]) > 990000000 and int(runs[0][2]) > 110000, runs[0]
+    rss = float([l for l in r.stdout.splitlines() if l.startswith("RSS_GB")][0].split()[1])
+    assert rss < 28.0, rss
+    bases, off = ns.synth_reads(11, 4600000, 125000, 8000.0)
+    sub = np.arange(0, 125000, 20)
+    b = bytes(bases)
+    one_builder_equals_oracle(*pack([b[int(off[i]):int(off[i + 1])].decode() for i in sub]))
