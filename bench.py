@@ -231,11 +231,11 @@ def main():
         # comes from rocprofv3 --pmc passes over this very command (profiles/r01_pmc_ksw_traffic.json) and is only
         # reported for the workload it was measured on.
         traffic, traffic_src = None, None
-        for pmc_name in ("r02_pmc_ksw_traffic.json", "r01_pmc_ksw_traffic.json"):
+        for pmc_name in (("r03_pmc_ksw_traffic.json",) if args.groups == 1 else ("r02_pmc_ksw_traffic.json", "r01_pmc_ksw_traffic.json")):
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc) and args.reads == 100000 and world == 1:
                 pj = json.load(open(pmc))
-                traffic, traffic_src = round(pj["traffic_bytes_per_launch"]), "profiles/%s (rocprofv3 --pmc over the 1024-builder schedule: 2*FETCH_SIZE + WRITE_SIZE per launch; traceback scratch dominates)" % pmc_name
+                traffic, traffic_src = round(pj["traffic_bytes_per_launch"]), "profiles/%s (rocprofv3 --pmc passes over bench.py at %s: 2*FETCH_SIZE + WRITE_SIZE per launch; traceback scratch dominates)" % (pmc_name, "the default one-group schedule" if args.groups == 1 else "the 1024-builder schedule")
                 break
         # what the schedule trades: contigs that grow at the same time compete for reads, so more concurrent builders mean more, shorter
         # contigs and larger streams.  The yard-sticks for THIS input are committed measurements of the oracle (the reference's own
@@ -275,9 +275,10 @@ def main():
                     "note": "NOT iso-compression: 1024 contigs grow at once on a 40 Mb genome and cut each other short"}
             ns.set_schedule(g, args.groups, args.seed_depth, args.seed_rings)
         comp = None
-        pv = os.path.join(ROOT, "profiles", "r02_pmc_ksw_issue.json")
+        pv = os.path.join(ROOT, "profiles", "r03_pmc_ksw_issue.json" if args.groups == 1 else "r02_pmc_ksw_issue.json")
         if os.path.exists(pv):
-            comp = json.load(open(pv)).get("summary")
+            pj2 = json.load(open(pv))
+            comp = pj2.get("summary") or {"source": pj2.get("source"), "reading": pj2.get("reading"), "kernels": {k: {"valu_utilisation": v["valu_utilisation"], "waves_per_simd": v["waves_per_simd"], "wave_time_share": v["wave_time_share"]} for k, v in pj2.get("kernels", {}).items()}}
         out = {
             "metric": "Mbases/sec sketch+overlap+align, 8kb ONT reads",
             "value": round(total_bases * steps / 1e6 / dt, 2),
@@ -319,7 +320,7 @@ def main():
                          "traffic": None, "traffic_from_profile": traffic, "traffic_source": traffic_src,
                          "launches": int(a["dp_launches"]), "avg_launch_ms": round(dp_ms, 3),
                          # the kernel is integer DP bound by instruction issue, not by HBM: its real ceiling as first-class fields
-                         "compute": {"bound": "instruction issue (VALU + SALU), integer DP", "cells": a["dp_cells"],
+                         "compute": {"bound": "latency of one wave per problem at the default schedule (a launch holds ~80 alignments' problems and is waited for by a whole round); VALU + SALU instruction issue at the 1024-builder schedule", "cells": a["dp_cells"],
                                      "gcups_over_dp_wall": round(a["dp_cells"] / (a["dp_kernel_ms"] * 1e-3) / 1e9, 1) if a["dp_kernel_ms"] else 0,
                                      "gcups_over_kernel_sum": round(a["dp_cells"] / (a["dp_kernel_sum_ms"] * 1e-3) / 1e9, 1) if a["dp_kernel_sum_ms"] else 0,
                                      "pmc": comp},
