@@ -276,6 +276,7 @@ void ContigGraph::initialize(const std::string &seed, read_t id, long pos)
     reads.insert(std::make_pair(id, GraphRead{pos, cur, seed.length(), false}));
     right_unchanged_ = left_unchanged_ = cur;
     right_off_ = left_off_ = 0;
+    path_changed_from = 0;
     main_path.push_back(cur->base);
     set_on_main(cur, true);
     cur->cum_weight = 0;
@@ -500,6 +501,7 @@ void ContigGraph::calculate_main_path_greedy()
         }
         if (ci < cand.size()) {
             const size_t c0 = cand[ci];
+            if (c0 + 1 < path_changed_from) path_changed_from = c0 + 1;       // main_path[0 .. c0] stays
             std::vector<Edge *> &saved = saved_;                         // saved[t] = old edge c0 + t, its sink = old node c0 + t + 1
             saved.assign(main_edges.begin() + c0, main_edges.end());
             g_mp_cnt[0] += saved.size(), g_mp_cnt[1] += 1, g_mp_cnt[2] += main_edges.size();
@@ -576,6 +578,7 @@ void ContigGraph::calculate_main_path_greedy()
         if (R < consistent_from_) consistent_from_ = R;
     } else {
         if (consistent_from_ != (size_t)-1) consistent_from_ = consistent_from_ > left_off_ ? consistent_from_ - left_off_ : 0;
+        path_changed_from = left_off_ > 0 ? 0 : std::min(path_changed_from, right_off_ + 1);     // what clear_main_path keeps on the left
         clear_main_path();                            // right_off_ is now the index of right_unchanged_
         if (right_off_ < consistent_from_) consistent_from_ = right_off_;
         Node *cur = right_unchanged_;
@@ -608,6 +611,7 @@ void ContigGraph::calculate_main_path_greedy()
         if (!prefix.empty()) {
             std::reverse(prefix.begin(), prefix.end());
             main_path.insert(0, prefix);
+            path_changed_from = 0;
         }
         main_edges.front()->sort_reads();
         const read_t starting = *main_edges.front()->reads.begin();

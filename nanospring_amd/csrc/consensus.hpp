@@ -276,6 +276,10 @@ private:
     void walk_and_prune_marked(Edge *e, std::vector<Edge *> &stack);
 public:
     uint64_t dbg_cycles_calls = 0, dbg_cycles_skipped = 0, dbg_spliced = 0, dbg_spliced_nodes = 0, dbg_walked_nodes = 0, dbg_cycles_idle = 0;
+    // main_path[0 .. path_changed_from) has not changed since the caller last set this to SIZE_MAX (a lower bound of the common prefix:
+    // calculate_main_path_greedy only ever lowers it; 0 = anything may have changed).  Lets the contig engine compare / re-code / re-sketch
+    // the tail of a multi-megabase consensus instead of the whole string after every accepted read.
+    size_t path_changed_from = 0;
     uint64_t dbg_cycles_listed = 0;            // remove_cycles calls served from multi_in_list_ (no walk over the side branches)
     double dbg_cycles_ms = 0;
 private:

@@ -81,6 +81,7 @@ struct Builder {
     std::vector<mm2::Anchor> mz;
     std::string mz_str;
     struct Splice { bool full = true; size_t a = 0, B_sub = 0, A = 0, B = 0; ssize_t delta = 0; } sp;
+    size_t chg_lb = 0;                         // the main path agrees with mz_str (and idx's base codes) on [0, chg_lb): from ContigGraph::path_changed_from
     std::vector<std::unique_ptr<FinishedContig>> contigs;     // in the order they were finished = output order
     size_t n_queued = 0;                                      // contigs[0 .. n_queued) were handed to the emission queue
     uint64_t n_minhash = 0, n_minhash_new = 0, n_aligner = 0, n_align_calls = 0, n_contigs = 0, n_lone = 0;
@@ -122,6 +123,7 @@ struct Driver {
         b.right_phase = true, b.edges_too_many = false, b.window_open = false;
         b.idx_valid = false;
         b.mz.clear(), b.mz_str.clear();          // a new consensus: nothing to splice into
+        b.chg_lb = 0;
         b.st = Builder::ADVANCE;
     }
 
@@ -265,12 +267,15 @@ struct Driver {
                     g.main_path.clear();
                     g.initialize(seed, g.first_read, 0);
                     g.calculate_main_path_greedy();
+                    b.chg_lb = 0;
                     b.dbg_init += now_ms() - i0;
                 }
                 const double u0 = now_ms();
                 g.update_graph(b.query, b.aln.edits, (ssize_t)b.aln.begin_offset, (ssize_t)b.aln.end_offset, b.pend + id_base, (long)b.aln.rel_pos, b.strand == 1);
                 const double u1 = now_ms();
                 g.calculate_main_path_greedy();
+                if (g.path_changed_from < b.chg_lb) b.chg_lb = g.path_changed_from;
+                g.path_changed_from = (size_t)-1;
                 const double u2 = now_ms();
                 b.dbg_u += u1 - u0, b.dbg_m += u2 - u1;
                 if (u1 - u0 > b.dbg_max_u) b.dbg_max_u = u1 - u0;
@@ -593,7 +598,13 @@ static void plan_splice(Builder &b, int w, int k)
     sp = Builder::Splice();
     if (always_full || od.empty() || b.mz.empty()) return;
     const size_t Ln = nw.size(), Lo = od.size(), mn = std::min(Ln, Lo);
-    size_t P = 0;
+    // the graph knows from where on its main path changed (a lower bound of the common prefix): a multi-megabase consensus is compared
+    // from there, not from its first base
+    size_t P = std::min(b.chg_lb, mn);
+    {
+        static const bool check = getenv("NSGPU_SKETCH_CHECK") != nullptr;
+        if (check && P && memcmp(nw.data(), od.data(), P) != 0) { fprintf(stderr, "nsgpu: the main path changed in front of path_changed_from (internal error)\n"); abort(); }
+    }
     while (P + 8 <= mn && memcmp(nw.data() + P, od.data() + P, 8) == 0) P += 8;
     while (P < mn && nw[P] == od[P]) ++P;
     size_t S = 0;
@@ -643,8 +654,13 @@ static void apply_splice(Builder &b, const mm2::Anchor *sub, size_t n_sub, int w
         for (; i < b.mz.size(); ++i) { mm2::Anchor t = b.mz[i]; const size_t x = (size_t)((ssize_t)pos_of(t) + sp.delta); t.y = (t.y & ~0xffffffffull) | ((uint64_t)x << 1 | (t.y & 1)); out.push_back(t); }
         b.mz.swap(out);
     }
-    b.mz_str = nw;
+    {   // mz_str = nw, copying only what can differ
+        const size_t keep = std::min(std::min(b.chg_lb, b.mz_str.size()), nw.size());
+        b.mz_str.resize(keep);
+        b.mz_str.append(nw, keep, std::string::npos);
+    }
     static const bool check = getenv("NSGPU_SKETCH_CHECK") != nullptr;
+    if (check && b.mz_str != nw) { fprintf(stderr, "nsgpu: incremental copy of the main path differs (internal error)\n"); abort(); }
     if (check) {
         std::vector<mm2::Anchor> full;
         mm2::mm_sketch(nw.data(), (int)nw.size(), w, k, 0, full);
@@ -758,7 +774,8 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group)
             if (!b.idx_valid) {
                 const uint32_t si = h.sk_ref[w - h.lo];
                 apply_splice(b, h.mz + mo[si], (size_t)(mo[si + 1] - mo[si]), (int)c->prm.m_w, (int)c->prm.m_k);
-                b.idx.set_sequence(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k);
+                b.idx.set_sequence_from(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, b.chg_lb);
+                b.chg_lb = (size_t)-1;
                 b.idx_valid = true;
             }
             if (b.mz.size() > so[i + 1] - so[i]) { fprintf(stderr, "nsgpu: spliced minimizer list longer than its bound (internal error)\n"); abort(); }

@@ -248,6 +248,15 @@ void RefIndex::set_sequence(const char *s, uint32_t n, int w_, int k_)
     has_table = false;
 }
 
+void RefIndex::set_sequence_from(const char *s, uint32_t n, int w_, int k_, size_t from)
+{
+    if (from > seq.size() || from > n) from = 0;
+    k = k_, w = w_ < 1 ? 1 : w_, len = n;
+    seq.resize(n);
+    nt4_codes(s + from, n - from, seq.data() + from);
+    has_table = false;
+}
+
 void RefIndex::build_from_sketch(const char *s, uint32_t n, int w_, int k_, float mid_occ_frac, const Anchor *mz_p, size_t mz_n)
 {
     set_sequence(s, n, w_, k_);

@@ -287,8 +287,15 @@ int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32
                         if (!g.read_string(r + id_base, back) || back != q) ++st->n_graph_check_fail;
                     }
                     t0 = hnow();
+                    const std::string path_before = run_checks ? g.main_path : std::string();
+                    g.path_changed_from = (size_t)-1;
                     g.calculate_main_path_greedy();
                     st->mainpath_ms += hnow() - t0;
+                    if (run_checks) {            // path_changed_from is a lower bound of the prefix the recompute kept (the contig engine relies on it)
+                        const size_t keep = std::min(std::min(g.path_changed_from, path_before.size()), g.main_path.size());
+                        if (memcmp(path_before.data(), g.main_path.data(), keep) != 0) ++st->n_graph_check_fail;
+                        if (g.path_changed_from == (size_t)-1 && path_before != g.main_path) ++st->n_graph_check_fail;
+                    }
                     if (run_checks) {
                         std::string back;
                         if (!g.read_string(r + id_base, back) || back != q || g.has_cycle()) ++st->n_graph_check_fail;
