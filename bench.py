@@ -71,6 +71,18 @@ def cpu_model():
     return "unknown"
 
 
+def full_input_reference():
+    """The reference's -t N on the FULL cfg2 input (oracle, reference minimap2): a committed measurement of the build container (8 cores),
+    the only place an hour-scale CPU run fits -- rate, contigs and stream size on the very input bench.py times."""
+    pth = os.path.join(ROOT, "profiles", "r03_oracle_t8_cfg2.json")
+    if not os.path.exists(pth):
+        return None
+    oj = json.load(open(pth))
+    return {"value": round(oj["mbases_per_s"], 3), "unit": "Mbases/s", "cores": oj["threads"], "seconds": round(oj["seconds"], 1), "host": "build container, 8 vCPU Xeon 2.1 GHz",
+            "contigs": oj["stats"]["n_contigs"], "lone_reads": oj["stats"]["n_lone"], "stream_bytes_per_base": round(oj["stream_bytes_per_base"], 4),
+            "source": "profiles/r03_oracle_t8_cfg2.json"}
+
+
 def cpu_baseline(n_reads, mean_len, k, n, thr, salts, t1_reads=1500):
     """The reference's hot path on this host's cores, as oracle/consensus_oracle.cpp restates it (kind "port": literal
     Consensus / ConsensusGraph + ns_oracle.c's MinHash filter; every alignRead is answered by the REFERENCE's own minimap2,
@@ -81,9 +93,10 @@ def cpu_baseline(n_reads, mean_len, k, n, thr, salts, t1_reads=1500):
     cores = host_cores()
     bases, off = ns.synth_reads(11, int(n_reads * mean_len / 20), n_reads, mean_len)
     t0 = time.perf_counter()
-    _, st = oracle_lib.cons_oracle_run(bases, off, salts, k=k, n=n, thr=thr, checks=False, num_thr=cores)
+    sm, st = oracle_lib.cons_oracle_run(bases, off, salts, k=k, n=n, thr=thr, checks=False, num_thr=cores)
     dt = time.perf_counter() - t0
     nb = int(off[-1])
+    sample_stream = sum(len(t[x]) for t in (sm["threads"] if "threads" in sm else [sm]) for x in oracle_lib.CONS_STREAMS)
     assert st["n_bad_roundtrip"] == 0
     b1, o1 = ns.synth_reads(11, int(t1_reads * mean_len / 20), t1_reads, mean_len)
     t0 = time.perf_counter()
@@ -94,6 +107,8 @@ def cpu_baseline(n_reads, mean_len, k, n, thr, salts, t1_reads=1500):
             "sample": f"{n_reads} reads / {nb / 1e6:.1f} Mbases, same generator and parameters (20x of a {n_reads * mean_len / 20 / 1e6:.2f} Mb genome), "
                       f"-t {cores} in {dt:.1f} s (sketch + tables {st['sketch_ms'] / 1e3:.1f} s, contig stage {st['consensus_ms'] / 1e3:.1f} s): "
                       f"{st['count_aligner']} reads aligned into {st['n_contigs']} contigs ({st['n_lone']} lone reads)",
+            "sample_stream_bytes_per_base": round(sample_stream / nb, 4),
+            "full_input": full_input_reference(),
             "t1": {"value": round(int(o1[-1]) / 1e6 / d1, 3), "cores": 1,
                    "sample": f"{t1_reads} reads / {int(o1[-1]) / 1e6:.1f} Mbases in {d1:.1f} s; the -t 1 rate falls with the input size (contigs get longer and the "
                              f"reference re-indexes the whole consensus per candidate): 1.10 Mbases/s on the full cfg2 input (profiles/r01_parity_full.txt)"}}

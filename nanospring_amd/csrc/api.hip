@@ -197,7 +197,7 @@ int nsgpu_create(const nsgpu_params *p, nsgpu_ctx **ctx_out)
     // sketch then waits behind another group's 3 ms DP kernel.  8 queues: +12 % whole path (profiles/r02_stream_priority_ab.txt).
     // Read by the runtime when it initialises, i.e. effective here only if this is the process's first HIP call; set it in the
     // process environment otherwise.
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    if (!getenv("NSGPU_NO_SETENV")) setenv("GPU_MAX_HW_QUEUES", "8", 0);       // (a host that manages its own environment opts out)
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
