@@ -277,7 +277,8 @@ int nsgpu_consensus_stream(nsgpu_ctx *ctx, uint32_t thread, uint32_t which, uint
  * The *_resolve calls take the request lists of ALL ranks (any order) and apply them to a replicated claim table in
  * global builder order, so every rank stays in step and the result does not depend on the number of ranks.
  * nsgpu_consensus_run is exactly this loop with world = 1.  group = -1 addresses all builders.  Lists returned
- * through T** are library-allocated. */
+ * through T** are library-allocated.  G is the context's schedule (nsgpu_get_schedule; 4 or 2 here: the one-group schedule grants seeds
+ * between the host phase and the batches of a slot and runs only inside nsgpu_consensus_run / nsgpu_dist_consensus_run). */
 int nsgpu_cons_begin(nsgpu_ctx *ctx, uint32_t n_builders_total, uint32_t rank, uint32_t world);
 uint32_t nsgpu_cons_groups(void);
 int nsgpu_cons_slot(nsgpu_ctx *ctx, uint32_t slot);

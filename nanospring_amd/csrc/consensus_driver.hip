@@ -1314,6 +1314,8 @@ extern "C" {
 int nsgpu_cons_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, uint32_t world)
 {
     NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
+    NS_CHECK(c->sched_groups != 1, NSGPU_ERR_ARG, "nsgpu_cons_begin: the phase calls drive the 2- and 4-group schedules; the one-group schedule (seeds between the host phase and "
+                                                  "the batches) runs inside nsgpu_consensus_run / nsgpu_dist_consensus_run");
     NS_HIP(hipSetDevice(c->prm.device));
     return engine_begin(c, n_builders_total, rank, world);
 }

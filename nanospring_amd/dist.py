@@ -263,7 +263,9 @@ def consensus_exchange(gpu, n_builders_total, dist, n_threads_out=1):
     # the slot schedule of include/nsgpu.h (nsgpu_consensus_run runs the same one with world = 1): one collective per slot
     n_coll = 0
     slot = 0
-    n_groups = int(lib.nsgpu_cons_groups())
+    g_ = C.c_uint32()
+    F.check(lib, lib.nsgpu_get_schedule(ctx, C.byref(g_), None, None))      # 4 (default) or 2; the one-group schedule is the C++ drivers'
+    n_groups = int(g_.value)
     while True:
         h, b = slot % n_groups, (slot + 1) % n_groups
         F.check(lib, lib.nsgpu_cons_slot(ctx, slot))
