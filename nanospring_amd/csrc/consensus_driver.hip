@@ -81,6 +81,10 @@ struct Builder {
     std::vector<mm2::Anchor> mz;
     std::string mz_str;
     struct Splice { bool full = true; size_t a = 0, B_sub = 0, A = 0, B = 0; ssize_t delta = 0; } sp;
+    // the contig's minimizer list resident in HBM (what the seeding kernel reads): mz[0 .. d_mz_n) as of the last upload.  After a splice only
+    // the entries from the first changed one on travel (a contig grows at its ends: a few hundred entries of tens of thousands).
+    DevBuf d_mz;
+    size_t d_mz_n = 0;
     size_t chg_lb = 0;                         // the main path agrees with mz_str (and idx's base codes) on [0, chg_lb): from ContigGraph::path_changed_from
     std::vector<std::unique_ptr<FinishedContig>> contigs;     // in the order they were finished = output order
     size_t n_queued = 0;                                      // contigs[0 .. n_queued) were handed to the emission queue
@@ -124,6 +128,7 @@ struct Driver {
         b.idx_valid = false;
         b.mz.clear(), b.mz_str.clear();          // a new consensus: nothing to splice into
         b.chg_lb = 0;
+        b.d_mz_n = 0;                            // (the resident list's memory stays with the builder)
         b.st = Builder::ADVANCE;
     }
 
@@ -297,6 +302,9 @@ struct Driver {
 // all-gathered request lists, strictly in global builder order -- so the result does not depend on
 // the number of ranks.
 // ---------------------------------------------------------------------------
+// lists of a batch: per builder the tail that changed goes from the pinned staging buffer into the contig's resident list
+struct TailCopy { const mm2::Anchor *src; mm2::Anchor *dst; uint32_t n; uint32_t pad; };
+
 struct Engine {
     Driver D;
     uint32_t rank = 0, world = 1, n_total = 0;     // global builder count
@@ -315,6 +323,10 @@ struct Engine {
     std::vector<uint32_t> sk_ref;
     std::vector<uint64_t> mz_off[2];                // minimizer offsets of the two halves of a sketch batch
     std::vector<uint64_t> stage_off;                // offsets of the builders' consensus minimizer lists in the seeding kernel's staging buffer
+    std::vector<size_t> tail_from;                  // per builder of the batch: first list entry that travels this time
+    std::vector<TailCopy> tail_jobs;
+    PinBuf pin_tail;                                // the scatter kernel's job descriptors
+    std::vector<DevBuf> retired;                    // resident lists replaced by larger ones, freed at the next call
     uint64_t n_wq_exact = 0;                          // window-query batches that went the exact multi-step way
     int deferred_fresh = -1;                          // group whose freshly started contigs take their first steps with the next host phase
     AlignBatch ab[kMaxGroups];                        // alignment batch of each group, DP kernels in flight between part 1 and part 2
@@ -358,7 +370,15 @@ struct Engine {
     } sp;
 };
 
-static void engine_free(void *p) { pool_drain(); delete static_cast<Engine *>(p); }      // no emission task may outlive the engine
+static void engine_free(void *p)
+{
+    pool_drain();                                     // no emission task may outlive the engine
+    Engine *E = static_cast<Engine *>(p);
+    for (Builder &b : E->D.B) b.d_mz.release();
+    for (DevBuf &d : E->retired) d.release();
+    E->pin_tail.release();
+    delete E;
+}
 
 static int seed_policy_init(nsgpu_ctx *c, Engine *E);
 
@@ -634,8 +654,10 @@ static void plan_splice(Builder &b, int w, int k)
     sp.delta = (ssize_t)Ln - (ssize_t)Lo;
 }
 
-static void apply_splice(Builder &b, const mm2::Anchor *sub, size_t n_sub, int w, int k)
+// returns the index of the first list entry that may differ from the list before (everything in front of it was kept)
+static size_t apply_splice(Builder &b, const mm2::Anchor *sub, size_t n_sub, int w, int k)
 {
+    size_t first_diff = 0;
     auto pos_of = [](const mm2::Anchor &x) { return (size_t)((x.y & 0xffffffffull) >> 1); };
     const Builder::Splice &sp = b.sp;
     const std::string &nw = b.g->main_path;
@@ -644,7 +666,13 @@ static void apply_splice(Builder &b, const mm2::Anchor *sub, size_t n_sub, int w
         std::vector<mm2::Anchor> out;
         out.reserve(b.mz.size() + n_sub);
         size_t i = 0;
-        for (; i < b.mz.size() && pos_of(b.mz[i]) < sp.A; ++i) out.push_back(b.mz[i]);
+        {   // the kept prefix ends at the first old minimizer at or behind A (positions ascend: binary search, then one block copy)
+            size_t lo = 0, hi = b.mz.size();
+            while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (pos_of(b.mz[mid]) < sp.A) lo = mid + 1; else hi = mid; }
+            i = lo;
+            out.insert(out.end(), b.mz.begin(), b.mz.begin() + (ptrdiff_t)i);
+        }
+        first_diff = i;
         for (size_t j = 0; j < n_sub; ++j) {
             const size_t x = pos_of(sub[j]) + sp.a;
             if (x >= sp.A && x < sp.B) { mm2::Anchor t = sub[j]; t.y = (t.y & ~0xffffffffull) | ((uint64_t)x << 1 | (t.y & 1)); out.push_back(t); }
@@ -672,6 +700,17 @@ static void apply_splice(Builder &b, const mm2::Anchor *sub, size_t n_sub, int w
             abort();
         }
     }
+    return first_diff;
+}
+
+__global__ void mz_tail_scatter_kernel(const TailCopy *__restrict__ jobs, uint32_t n_jobs)
+{
+    const uint32_t j = blockIdx.y;
+    if (j >= n_jobs) return;
+    const TailCopy t = jobs[j];
+    const uint4 *s = reinterpret_cast<const uint4 *>(t.src);
+    uint4 *d = reinterpret_cast<uint4 *>(t.dst);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < t.n; i += gridDim.x * blockDim.x) d[i] = s[i];
 }
 
 static int engine_batches_sketch(nsgpu_ctx *c, int group)
@@ -730,6 +769,12 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group)
     // per step, whole path -2 %): two half-size loops on the pool balance worse than one, and a chaining launch lasts as long as
     // its longest list whatever the number of lists.
     static const bool pipe = getenv("NSGPU_CHAIN_PIPELINE") != nullptr;
+    static const bool resident_lists = getenv("NSGPU_NO_RESIDENT_LISTS") == nullptr;      // A/B switch: consensus minimizer lists staged whole, as in round 2
+    std::vector<size_t> &tail_from = E->tail_from;
+    tail_from.assign(n, 0);
+    // lists retired by an earlier call: their last reader (that call's seeding kernel) has been waited for since
+    for (DevBuf &d : E->retired) d.release();
+    E->retired.clear();
     const size_t mid = n >= 64 && pipe ? n / 2 : n;
     const size_t r_lo[2] = {0, mid}, r_hi[2] = {mid, n};
     for (int r = 0; r < 2 && rc == NSGPU_OK; ++r) {
@@ -771,18 +816,58 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group)
             const Half &h = half_of(w);
             const std::vector<uint64_t> &mo = E->mz_off[&h - H];
             Builder &b = D.B[who[w]];
+            size_t first_diff = b.d_mz_n;                 // nothing to upload when the consensus did not change
             if (!b.idx_valid) {
                 const uint32_t si = h.sk_ref[w - h.lo];
-                apply_splice(b, h.mz + mo[si], (size_t)(mo[si + 1] - mo[si]), (int)c->prm.m_w, (int)c->prm.m_k);
+                first_diff = apply_splice(b, h.mz + mo[si], (size_t)(mo[si + 1] - mo[si]), (int)c->prm.m_w, (int)c->prm.m_k);
                 b.idx.set_sequence_from(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, b.chg_lb);
                 b.chg_lb = (size_t)-1;
                 b.idx_valid = true;
             }
             if (b.mz.size() > so[i + 1] - so[i]) { fprintf(stderr, "nsgpu: spliced minimizer list longer than its bound (internal error)\n"); abort(); }
-            if (!b.mz.empty()) memcpy(stage + so[i], b.mz.data(), b.mz.size() * sizeof(mm2::Anchor));
+            // The contig's list is resident in HBM (Builder::d_mz): only the entries from the first changed one on go through the pinned
+            // staging buffer (resident_lists off: the whole list, read by the seeding kernel where it lies in pinned memory, as before).
+            if (first_diff > b.d_mz_n) first_diff = b.d_mz_n;
+            const size_t from = resident_lists ? first_diff : 0;
+            if (b.mz.size() > from) memcpy(stage + so[i], b.mz.data() + from, (b.mz.size() - from) * sizeof(mm2::Anchor));
+            tail_from[i] = from;
+            if (resident_lists) AB.reqs[w].ref_mz = b.mz.data();      // host copy: for the pairs the kernel hands back to the host code
             AB.reqs[w].n_ref_mz = b.mz.size();
             AB.jobs[w].seed_prepare();
         });
+        if (resident_lists) {
+            // room in the resident lists (growing one copies what it keeps), then ONE kernel moves every tail into place, on the stream the
+            // seeding kernel is launched on right behind it
+            nsgpu_ctx::SeedWs &SW = c->seed_ws[sws_i];
+            if (!SW.stream) { rc = role_stream_create(&SW.stream, "seeds"); if (rc != NSGPU_OK) break; }
+            std::vector<TailCopy> &jobs = E->tail_jobs;
+            jobs.clear();
+            uint32_t max_n = 0;
+            for (size_t w = lo; w < hi && rc == NSGPU_OK; ++w) {
+                Builder &b = D.B[who[w]];
+                const size_t n_new = b.mz.size(), from = tail_from[w - lo];
+                if (n_new * sizeof(mm2::Anchor) > b.d_mz.cap) {
+                    DevBuf bigger;
+                    rc = bigger.reserve(std::max<size_t>(2 * n_new, 16384) * sizeof(mm2::Anchor));
+                    if (rc != NSGPU_OK) break;
+                    if (from && hipMemcpyAsync(bigger.p, b.d_mz.p, from * sizeof(mm2::Anchor), hipMemcpyDeviceToDevice, SW.stream) != hipSuccess) rc = NSGPU_ERR_HIP;
+                    E->retired.push_back(b.d_mz);         // freed once the stream is known to be past this slot (engine_batches_sketch's next call)
+                    b.d_mz = bigger;
+                }
+                if (n_new > from) { jobs.push_back(TailCopy{stage + so[w - lo], b.d_mz.as<mm2::Anchor>() + from, (uint32_t)(n_new - from), 0}); max_n = std::max(max_n, (uint32_t)(n_new - from)); }
+                b.d_mz_n = n_new;
+                AB.reqs[w].ref_mz_dev = b.d_mz.as<mm2::Anchor>();
+            }
+            if (rc != NSGPU_OK) break;
+            if (!jobs.empty()) {
+                rc = E->pin_tail.reserve(jobs.size() * sizeof(TailCopy));
+                if (rc != NSGPU_OK) break;
+                memcpy(E->pin_tail.p, jobs.data(), jobs.size() * sizeof(TailCopy));
+                const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>(64, (max_n + 255) / 256));
+                hipLaunchKernelGGL(mz_tail_scatter_kernel, dim3(gx, (uint32_t)jobs.size()), dim3(256), 0, SW.stream, E->pin_tail.as<TailCopy>(), (uint32_t)jobs.size());
+                if (hipGetLastError() != hipSuccess) { rc = NSGPU_ERR_HIP; break; }
+            }
+        }
         rc = align_prestep_launch(c, AB, lo, hi, 1 + 2 * gi + r, true);
     }
     for (int r = 0; r < 2 && rc == NSGPU_OK; ++r)

@@ -41,6 +41,8 @@ struct AlignReq {
     size_t n_qry_mz = 0;
     const mm2::Anchor *ref_mz = nullptr;   // the reference's minimizers, PINNED memory as well; both given = seeds on the GPU (seeds.hip)
     size_t n_ref_mz = 0;
+    const mm2::Anchor *ref_mz_dev = nullptr;   // the same list resident in DEVICE memory (the contig engine keeps one per contig): the seeding kernel
+                                               // reads this one, ref_mz (any host memory then) serves the pairs the kernel hands back to the host code
 };
 struct SketchReq { const char *ptr; size_t len; };
 // (w,k)-minimizers of a batch of sequences, computed on the GPU (mm_sketch.hip).  Sequence i's minimizers are
