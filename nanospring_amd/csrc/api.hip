@@ -265,6 +265,7 @@ void nsgpu_destroy(nsgpu_ctx *c)
     for (nsgpu_ctx::ChainWs &w : c->cws) {
         w.d_in.release(); w.d_out.release(); w.d_marks.release(); w.h_in.release(); w.h_out.release();
         if (w.stream) (void)hipStreamDestroy(w.stream);
+        if (w.stream2) (void)hipStreamDestroy(w.stream2);
     }
     for (nsgpu_ctx::SeedWs &w : c->seed_ws) {
         w.d_tab.release(); w.d_next.release(); w.d_ys.release(); w.d_tmp.release(); w.d_out.release(); w.d_counter.release();

@@ -304,6 +304,101 @@ __global__ __launch_bounds__(64) void chain_forward_lds_kernel(const mm2::Anchor
     for (int32_t i = lane; i < n; i += 64) f_out[base + i] = F[i], p_out[base + i] = Pp[i];
 }
 
+// ---- the ring kernel: lists of ANY length at the LDS kernel's pace (round 3) ----
+// A read across a tandem repeat has 10^4 - 10^5 anchors ((repeat length / unit)^2 of them); such lists used to go to the general kernel,
+// whose f / p / marks live in global memory behind L2-latency atomics (~12 us per anchor when the walk runs its full max_chain_iter
+// predecessors, as it does in a dense repeat).  But an anchor only ever looks max_chain_iter back (and marks predecessors' predecessors,
+// at most twice that): f, p, the marks and the coordinates live in rings of kRing entries here, anchors stream in 64 at a time, f / p stream
+// out 64 at a time.  Same steps as chain_forward_lds_kernel otherwise (one wave per list, the 64 nearest predecessors in registers).
+// Needs max_chain_iter <= kRingIter, bw <= kFastBw, coordinates < 2^31.  A stale mark in a re-used ring slot is an anchor index from at
+// least kRing anchors ago: it never equals the current one.
+constexpr int32_t kRing = 1024, kRingMask = kRing - 1, kRingIter = 416;       // 2 * kRingIter + 64 + 128 <= kRing
+constexpr size_t ring_lds_bytes(int32_t bw) { return (size_t)kRing * 21 + 16 + ((size_t)bw + 1) * 4; }
+
+__global__ __launch_bounds__(64) void chain_forward_ring_kernel(const mm2::Anchor *__restrict__ anchors, const ChainList *__restrict__ lists, const uint32_t *__restrict__ jobs,
+                                                                int32_t *__restrict__ f_out, int32_t *__restrict__ p_out, ChainParams P)
+{
+    extern __shared__ int32_t lds[];
+    const ChainList L = lists[jobs[blockIdx.x]];
+    const uint64_t base = L.obeg;
+    const int32_t n = (int32_t)L.n;
+    const mm2::Anchor *a = anchors + L.beg;
+    int32_t *F = lds, *Pp = lds + kRing, *T = lds + 2 * kRing, *R = lds + 3 * kRing, *Q = lds + 4 * kRing;
+    uint8_t *S = reinterpret_cast<uint8_t *>(lds + 5 * kRing);
+    int32_t *G = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(lds) + (((size_t)kRing * 21 + 15) & ~(size_t)15));
+    const int lane = lane_id();
+    for (int32_t i = lane; i < kRing; i += 64) T[i] = -1;
+    // anchors [0, 128) into the rings; block [i + 64, i + 128) follows while anchors i .. i + 63 are worked on
+    for (int32_t i0 = 0; i0 < 128; i0 += 64) {
+        const int32_t i = i0 + lane;
+        if (i < n) { const uint64_t x = a[i].x, y = a[i].y; R[i] = (int32_t)x, Q[i] = (int32_t)y, S[i] = (uint8_t)(y >> 32); }
+    }
+    {
+        const double avg_qspan = (double)L.avg, gap_scale = (double)P.gap_scale;
+        for (int32_t dd = lane; dd <= P.bw; dd += 64) {
+            const int32_t log_dd = dd ? 31 - __builtin_clz((uint32_t)dd) : 0;
+            const int32_t gap_cost = (int)((double)dd * .01 * avg_qspan) + (log_dd >> 1);
+            G[dd] = (int)((double)gap_cost * gap_scale + .499);
+        }
+    }
+    lds_order();
+    auto gain = [&](int32_t ri, int32_t qi, int32_t q_span, int32_t rj, int32_t qj, bool in, int32_t &sc) -> bool {
+        const int32_t dr = ri - rj, dq = qi - qj;
+        const int32_t dd = dr > dq ? dr - dq : dq - dr;
+        const bool ok = in && dr != 0 && dq > 0 && dq <= P.max_dist && dd <= P.bw;
+        sc = min(min(dq, dr), q_span) - G[ok ? dd : 0];
+        return ok;
+    };
+    int32_t rj = 0, qj = 0, fj = 0, pj = -1;
+    int32_t ri = n ? R[0] : 0, qi = n ? Q[0] : 0, q_span = n ? S[0] : 0;
+    uint64_t pf_x = 0, pf_y = 0;                       // the block in flight from memory
+    for (int32_t i = 0; i < n; ++i) {
+        if ((i & 63) == 0) { const int32_t k = i + 64 + lane; if (i > 0 && k < n) pf_x = a[k].x, pf_y = a[k].y; }
+        if ((i & 63) == 32) { const int32_t k = (i & ~63) + 64 + lane; if (i > 63 && k < n) { R[k & kRingMask] = (int32_t)pf_x, Q[k & kRingMask] = (int32_t)pf_y, S[k & kRingMask] = (uint8_t)(pf_y >> 32); } }
+        const int32_t i1 = i + 1 < n ? i + 1 : i;
+        const int32_t ri_n = R[i1 & kRingMask], qi_n = Q[i1 & kRingMask], sp_n = S[i1 & kRingMask];
+        Walk w{q_span, -1, 0, false};
+        const int32_t j_min = i - P.max_iter > 0 ? i - P.max_iter : 0;
+        {
+            const int32_t j = i - 1 - lane;
+            const bool in = j >= j_min && ri - rj <= P.max_dist;
+            int32_t sc;
+            const bool ok = gain(ri, qi, q_span, rj, qj, in, sc);
+            sc += fj;
+            if (ok && pj >= 0) T[pj & kRingMask] = i;
+            lds_order();
+            const bool marked = ok && T[j & kRingMask] == i;
+            const bool more = __builtin_amdgcn_readlane((int)in, 63) != 0;
+            walk_chunk(w, i - 1, ok, sc, marked, P.max_skip);
+            if (!more) w.stop = true;
+        }
+        for (int32_t hi = i - 65; hi >= j_min && !w.stop; hi -= 64) {
+            const int32_t j = hi - lane;
+            const bool in0 = j >= j_min;
+            const int32_t jm = j & kRingMask;
+            const int32_t rj2 = in0 ? R[jm] : 0, qj2 = in0 ? Q[jm] : 0, fj2 = in0 ? F[jm] : 0, pj2 = in0 ? Pp[jm] : -1;
+            const bool in = in0 && ri - rj2 <= P.max_dist;
+            int32_t sc;
+            const bool ok = gain(ri, qi, q_span, rj2, qj2, in, sc);
+            sc += fj2;
+            if (ok && pj2 >= 0) T[pj2 & kRingMask] = i;
+            lds_order();
+            const bool marked = ok && T[jm] == i;
+            const bool more = __builtin_amdgcn_readlane((int)in, 63) != 0;
+            walk_chunk(w, hi, ok, sc, marked, P.max_skip);
+            if (!more) w.stop = true;
+        }
+        if (lane == 0) F[i & kRingMask] = w.max_f, Pp[i & kRingMask] = w.max_j;
+        lds_order();
+        if ((i & 63) == 63 || i == n - 1) {            // the block of results that is complete goes out
+            const int32_t k = (i & ~63) + lane;
+            if (k <= i) f_out[base + k] = F[k & kRingMask], p_out[base + k] = Pp[k & kRingMask];
+        }
+        rj = dpp<kWaveShr1>(ri, rj), qj = dpp<kWaveShr1>(qi, qj), fj = dpp<kWaveShr1>(w.max_f, fj), pj = dpp<kWaveShr1>(w.max_j, pj);
+        ri = ri_n, qi = qi_n, q_span = sp_n;
+    }
+}
+
 }  // namespace
 
 // f[i] / p[i] of mm_chain_dp's first loop for the anchor lists a[off[q] .. off[q+1]) (host pointers; avg[q] = mean query span):
@@ -334,19 +429,23 @@ int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vecto
     for (size_t q = 0; q < nq; ++q) hl[q] = ChainList{off[q], off[q], (uint32_t)(off[q + 1] - off[q]), avg[q]};
     // which kernel takes which list; the longest lists first (a wave's time grows with its list: the tail of the launch should be
     // the short ones)
-    uint32_t n_lds = 0, n_big = 0, max_lds = 0;
-    std::vector<uint8_t> &fast = W.h_fast;
+    uint32_t n_lds = 0, n_big = 0, n_ring = 0, max_lds = 0;
+    std::vector<uint8_t> &fast = W.h_fast;                // 1: the LDS kernel, 2: the ring kernel (same conditions, any length), 0: the general kernel
     fast.assign(nq, 0);
+    static const bool no_ring = getenv("NSGPU_CHAIN_NO_RING") != nullptr;       // A/B switch: long lists through the general kernel, as before
     par_for(nq, [&](size_t q) {
         const uint64_t n = off[q + 1] - off[q];
         if (n == 0) return;
         memcpy(ha + off[q], lists[q], (size_t)n * sizeof(mm2::Anchor));
         uint64_t hi_bits = 0;
         for (uint64_t i = 0; i < n; ++i) hi_bits |= lists[q][i].x;
-        fast[q] = n <= kFastAnchors && (hi_bits >> 31) == 0 && opt.bw >= 0 && opt.bw <= kFastBw;
+        const bool small_coords = (hi_bits >> 31) == 0 && opt.bw >= 0 && opt.bw <= kFastBw;
+        fast[q] = small_coords && n <= kFastAnchors ? 1 : small_coords && !no_ring && opt.max_chain_iter <= kRingIter && opt.max_chain_iter >= 0 ? 2 : 0;
     });
-    for (size_t q = 0; q < nq; ++q) if (fast[q]) hj[n_lds++] = (uint32_t)q, max_lds = std::max<uint32_t>(max_lds, (uint32_t)(off[q + 1] - off[q]));
+    for (size_t q = 0; q < nq; ++q) if (fast[q] == 1) hj[n_lds++] = (uint32_t)q, max_lds = std::max<uint32_t>(max_lds, (uint32_t)(off[q + 1] - off[q]));
     for (size_t q = 0; q < nq; ++q) if (!fast[q] && off[q + 1] > off[q]) hj[n_lds + n_big++] = (uint32_t)q;
+    for (size_t q = 0; q < nq; ++q) if (fast[q] == 2) hj[n_lds + n_big + n_ring++] = (uint32_t)q;
+    std::sort(hj + n_lds + n_big, hj + n_lds + n_big + n_ring, [&](uint32_t x, uint32_t y) { const uint64_t nx = off[x + 1] - off[x], ny = off[y + 1] - off[y]; return nx != ny ? nx > ny : x < y; });
     std::sort(hj, hj + n_lds, [&](uint32_t x, uint32_t y) { const uint64_t nx = off[x + 1] - off[x], ny = off[y + 1] - off[y]; return nx != ny ? nx > ny : x < y; });
     const double t1 = now_ms();
     // The LDS kernel reads its lists straight from the pinned staging buffer and stores f / p straight into the pinned result buffer
@@ -355,6 +454,14 @@ int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vecto
     // anchors repeatedly, works on device copies.
     const ChainParams P{opt.max_gap, opt.bw, opt.max_chain_skip, opt.max_chain_iter, opt.chain_gap_scale};
     int32_t *hf = W.h_out.as<int32_t>(), *hp = hf + total;
+    if (n_ring) {       // the longest lists first; like the LDS kernel it reads the pinned staging buffer and writes the pinned results itself
+        static bool ring_set = false;
+        if (!ring_set) { NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_forward_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds_bytes(kFastBw))); ring_set = true; }
+        if (!W.stream2) NS_TRY(role_stream_create(&W.stream2, "seeds"));
+        hipLaunchKernelGGL(chain_forward_ring_kernel, dim3(n_ring), dim3(64), ring_lds_bytes(opt.bw), W.stream2, ha, hl, hj + n_lds + n_big, hf, hp, P);
+        NS_HIP(hipGetLastError());
+        W.ring_used = true;
+    }
     if (n_lds) {
         if (!W.lds_set) {
             NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_forward_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(kFastAnchors, kFastBw)));
@@ -428,6 +535,7 @@ int gpu_chain_wait(nsgpu_ctx *c, int ws, const int32_t *&f, const int32_t *&p)
     if (W.pend_total == 0) return NSGPU_OK;
     const double t0 = now_ms();
     NS_HIP(stream_wait_short(W.stream));
+    if (W.ring_used) { NS_HIP(stream_wait(W.stream2)); W.ring_used = false; }
     W.ms_wait += now_ms() - t0;
     f = W.h_out.as<int32_t>(), p = f + W.pend_total;
     return NSGPU_OK;

@@ -176,6 +176,7 @@ struct nsgpu_ctx {
         std::vector<const nsgpu::mm2::Anchor *> lists; std::vector<uint64_t> off; std::vector<float> avg;   // the launch's lists (host side)
         double ms_stage = 0, ms_enqueue = 0, ms_wait = 0; uint64_t calls = 0;   // host wall of the calls: staging / enqueue / wait for the results
         hipStream_t stream = nullptr;
+        hipStream_t stream2 = nullptr; bool ring_used = false;         // the ring kernel's long lists run beside the LDS kernel's launch
     } cws[18];                                                      // per batch workspace w: 2w the lists seeded on the GPU, 2w + 1 the ones seeded by the host code
     // index + seeds (seeds.hip): scratch tables, anchors (device), pair descriptors and results (pinned)
     struct SeedWs {

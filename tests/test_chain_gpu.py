@@ -109,6 +109,10 @@ def test_chain_kernel_against_the_reference_mm_chain_dp(mci):
         for n in (1, 2, 65, 700, 3000):
             lists.append(synthetic(rng, n, kind))
     lists.append(synthetic(rng, 9000, "dense"))
+    # what a read across a tandem repeat looks like: tens of thousands of anchors, every reference position hit from many query positions
+    # (beyond the LDS kernel's capacity: the ring kernel, anchors streaming through rings of 1024 entries)
+    lists.append(synthetic(rng, 40000, "dense"))
+    lists.append(synthetic(rng, 25000, "diagonals"))
     got = gpu_scores(g, lists)
     n_chains = 0
     for a, (f, p) in zip(lists, got):
