@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--depth", type=float, default=20.0, help="sequencing depth of the synthetic read set (cfg2: 20; cfg3's E. coli regime: ~200)")
     ap.add_argument("--genome", choices=["iid", "repeats"], default="iid", help="synthetic genome: iid (BASELINE cfg2) or with planted duplications / tandem repeats / homopolymer and (AT)n runs")
     ap.add_argument("--throughput-leg", type=int, default=-1, help="also time ONE step of the 1024-builder pipelined schedule, which is not iso-compression (default: only with 1 GPU at full cfg2 size; 0 = skip)")
+    ap.add_argument("--seed-tail-rings", type=int, default=3, help="conflict-aware seeds: the radius while more than half of all builders wait for a seed (default: --seed-rings)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the all-cores CPU-baseline sample (0 = skip; default: 2000 per host core)")
     ap.add_argument("--no-exchange", action="store_true", help="multi-GPU: independent shards, no collective")
     ap.add_argument("--dist-mode", choices=["alltoall", "replicate"], default="alltoall",
@@ -163,7 +164,9 @@ def main():
 
     stream = torch.cuda.Stream()
     g = ns.NsGpu(k=k, n=n, overlap_sketch_thr=thr, device=local, stream=stream.cuda_stream)
-    ns.set_schedule(g, args.groups, args.seed_depth, args.seed_rings)
+    if args.seed_tail_rings < 0:
+        args.seed_tail_rings = args.seed_rings
+    ns.set_schedule(g, args.groups, args.seed_depth, args.seed_rings, args.seed_tail_rings)
     job = None
     if exchange:
         # the C++ driver (csrc/dist.hip): the library's own RCCL communicator; Python only calls three entry points
@@ -269,7 +272,7 @@ def main():
                     out["iso_compression"] = out["ratio_to_reference_tN"] <= 1.05
             return out
         penalty = compression_of(stream_bytes / n_bases, st)
-        penalty["schedule"] = {"groups": args.groups, "seed_bucket_depth": args.seed_depth, "seed_rings": args.seed_rings}
+        penalty["schedule"] = {"groups": args.groups, "seed_bucket_depth": args.seed_depth, "seed_rings": args.seed_rings, "seed_tail_rings": args.seed_tail_rings}
         # one step of the 1024-builder, four-group pipelined schedule with the reference's seed rule (the round-2 headline): faster, larger streams
         tleg = None
         want_leg = args.throughput_leg if args.throughput_leg >= 0 else int(world == 1 and args.reads == 100000 and args.depth == 20.0 and args.genome == "iid")
@@ -288,7 +291,7 @@ def main():
                     "schedule": {"builders": 1024, "groups": 4, "seed_bucket_depth": 0}, "lossless_roundtrip_bad_reads": ns.consensus_verify(g),
                     "compression": compression_of(sb2 / n_bases, st2),
                     "note": "NOT iso-compression: 1024 contigs grow at once on a 40 Mb genome and cut each other short"}
-            ns.set_schedule(g, args.groups, args.seed_depth, args.seed_rings)
+            ns.set_schedule(g, args.groups, args.seed_depth, args.seed_rings, args.seed_tail_rings)
         comp = None
         pv = os.path.join(ROOT, "profiles", "r03_pmc_ksw_issue.json" if args.groups == 1 else "r02_pmc_ksw_issue.json")
         if os.path.exists(pv):
@@ -308,7 +311,7 @@ def main():
                        "genome": args.genome,
                        "stages": ["sketch", "bucket-tables", "overlap (window queries)", "align (batched alignRead, DP on GPU)",
                                   "consensus graph + edit emission (host)"],
-                       "bases_per_gpu": n_bases, "builders": st["n_builders"], "schedule": {"groups": args.groups, "seed_bucket_depth": args.seed_depth, "seed_rings": args.seed_rings},
+                       "bases_per_gpu": n_bases, "builders": st["n_builders"], "schedule": {"groups": args.groups, "seed_bucket_depth": args.seed_depth, "seed_rings": args.seed_rings, "seed_tail_rings": args.seed_tail_rings},
                        "host_threads": a["host_threads"],
                        "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 1),
                        "lossless_roundtrip_bad_reads": bad, "stream_bytes_per_base": round(stream_bytes / n_bases, 4),

@@ -327,6 +327,7 @@ struct Engine {
     std::vector<TailCopy> tail_jobs;
     PinBuf pin_tail;                                // the scatter kernel's job descriptors
     std::vector<DevBuf> retired;                    // resident lists replaced by larger ones, freed at the next call
+    std::vector<uint32_t> dbg_batch_sizes;          // alignments per batch, in order (debug print: how full the slots are over the run)
     uint64_t n_wq_exact = 0;                          // window-query batches that went the exact multi-step way
     int deferred_fresh = -1;                          // group whose freshly started contigs take their first steps with the next host phase
     AlignBatch ab[kMaxGroups];                        // alignment batch of each group, DP kernels in flight between part 1 and part 2
@@ -342,7 +343,8 @@ struct Engine {
     // occupied one, and the lowest unclaimed read that qualifies is taken, by the waiting builders in global builder order.  A builder
     // that finds none although unclaimed reads exist asks again at its group's next slot.  All of it is a function of replicated data.
     struct SeedPolicy {
-        uint32_t depth = 0, rings = 1;
+        uint32_t depth = 0, rings = 1, tail_rings = 1;        // tail_rings: the exclusion radius while more than half of all builders are waiting for a seed
+        uint32_t rings_now = 1;
         std::vector<uint32_t> bucket_of;                 // read -> bucket
         std::vector<uint64_t> adj_off; std::vector<uint32_t> adj;     // bucket adjacency (CSR, ascending, without itself)
         std::vector<uint64_t> bk_off; std::vector<uint32_t> bk_reads; // reads of every bucket, ascending
@@ -360,7 +362,7 @@ struct Engine {
             if (stamp.size() != blocked.size()) stamp.assign(blocked.size(), 0), epoch = 0;
             ++epoch;
             for (uint32_t x : q_cur) stamp[x] = epoch, blocked[x] = 1;
-            for (uint32_t d = 0; d < rings && !q_cur.empty(); ++d) {
+            for (uint32_t d = 0; d < rings_now && !q_cur.empty(); ++d) {
                 q_nxt.clear();
                 for (uint32_t x : q_cur)
                     for (uint64_t i = adj_off[x]; i < adj_off[x + 1]; ++i) if (stamp[adj[i]] != epoch) { stamp[adj[i]] = epoch; blocked[adj[i]] = 1; q_nxt.push_back(adj[i]); }
@@ -480,6 +482,9 @@ static uint32_t engine_seed_resolve(nsgpu_ctx *c, const uint32_t *gids, const ui
             for (uint32_t x : m) --P.occ[P.bucket_of[x]];
             m.clear();
         }
+        // towards the end of a run most builders wait while a few contigs close the last gaps: when more than half of ALL builders ask for a
+        // seed in one round, the exclusion radius drops to tail_rings -- a seed in such a gap is one more contig, and halves what is left of it
+        P.rings_now = 2ull * n > E->n_total ? P.tail_rings : P.rings;
         std::vector<std::pair<uint32_t, uint32_t>> cand;          // (lowest unclaimed read, bucket) of every bucket a seed may lie in
         const uint32_t nb = (uint32_t)P.occ.size();
         if (P.n_unclaimed) {
@@ -535,7 +540,7 @@ static int seed_policy_init(nsgpu_ctx *c, Engine *E)
 {
     Engine::SeedPolicy &P = E->sp;
     Driver &D = E->D;
-    P.depth = c->seed_bucket_depth, P.rings = c->seed_rings;
+    P.depth = c->seed_bucket_depth, P.rings = c->seed_rings, P.tail_rings = std::min(c->seed_tail_rings, c->seed_rings), P.rings_now = P.rings;
     if (!P.depth) return NSGPU_OK;
     const uint32_t N = D.N;
     uint64_t n_cand = 0;
@@ -875,6 +880,7 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group)
     if (t2.joinable()) t2.join();
     NS_TRY(rc);
     E->awho[gi] = who;
+    E->dbg_batch_sizes.push_back((uint32_t)who.size());
     { std::lock_guard<std::mutex> lk(c->stat_m); S.index_ms += now_ms() - g0; }
     return NSGPU_OK;
 }
@@ -1227,6 +1233,12 @@ static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_o
         for (nsgpu_ctx::ChainWs &w : c->cws) cs += w.ms_stage, ce += w.ms_enqueue, cw += w.ms_wait, cn += w.calls, w.ms_stage = w.ms_enqueue = w.ms_wait = 0, w.calls = 0;
         fprintf(stderr, "[cons] chaining scores on the GPU (inside sketch+index): %.0f ms wall in %llu calls: staging %.0f, enqueue %.0f, wait (copies + kernel) %.0f\n", chain_ms,
                 (unsigned long long)cn, cs, ce, cw);
+        if (!E->dbg_batch_sizes.empty()) {        // alignments per batch over the run, in tenths of the run
+            const size_t nb = E->dbg_batch_sizes.size();
+            fprintf(stderr, "[cons] alignments per batch over the run (%zu batches, mean of each tenth):", nb);
+            for (int d = 0; d < 10; ++d) { uint64_t sum = 0; const size_t a = nb * d / 10, b = nb * (d + 1) / 10; for (size_t i = a; i < b; ++i) sum += E->dbg_batch_sizes[i]; fprintf(stderr, " %.1f", b > a ? (double)sum / (double)(b - a) : 0.0); }
+            fprintf(stderr, "\n");
+        }
         fprintf(stderr, "[cons] slots set by: host phase %llu (%.0f ms), batches part 1 %llu (%.0f ms), part 2 %llu (%.0f ms)\n", (unsigned long long)E->slot_long_n[0],
                 E->slot_long_ms[0], (unsigned long long)E->slot_long_n[1], E->slot_long_ms[1], (unsigned long long)E->slot_long_n[2], E->slot_long_ms[2]);
     }
@@ -1476,13 +1488,16 @@ int nsgpu_cons_finish(nsgpu_ctx *c, uint32_t n_threads_out, nsgpu_consensus_stat
     return NSGPU_OK;
 }
 
-int nsgpu_set_schedule(nsgpu_ctx *c, uint32_t groups, uint32_t seed_bucket_depth, uint32_t seed_rings)
+int nsgpu_set_schedule(nsgpu_ctx *c, uint32_t groups, uint32_t seed_bucket_depth, uint32_t seed_rings) { return nsgpu_set_schedule2(c, groups, seed_bucket_depth, seed_rings, seed_rings); }
+
+int nsgpu_set_schedule2(nsgpu_ctx *c, uint32_t groups, uint32_t seed_bucket_depth, uint32_t seed_rings, uint32_t seed_tail_rings)
 {
     NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
     NS_CHECK(groups == 1 || groups == 2 || groups == 4, NSGPU_ERR_ARG, "nsgpu_set_schedule: groups must be 1, 2 or 4");
     NS_CHECK(seed_bucket_depth <= 64 && seed_rings <= 8, NSGPU_ERR_ARG, "nsgpu_set_schedule: bucket depth at most 64, rings at most 8");
     NS_CHECK(!c->cons_engine, NSGPU_ERR_ARG, "nsgpu_set_schedule: a contig stage is in progress");
-    c->sched_groups = groups, c->seed_bucket_depth = seed_bucket_depth, c->seed_rings = seed_rings;
+    NS_CHECK(seed_tail_rings <= seed_rings, NSGPU_ERR_ARG, "nsgpu_set_schedule2: seed_tail_rings must not exceed seed_rings");
+    c->sched_groups = groups, c->seed_bucket_depth = seed_bucket_depth, c->seed_rings = seed_rings, c->seed_tail_rings = seed_tail_rings;
     return NSGPU_OK;
 }
 

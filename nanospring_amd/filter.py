@@ -370,9 +370,10 @@ class ConsensusStats(C.Structure):
 STREAMS = ["genome", "lone", "id", "pos", "type", "base", "complement"]
 
 
-def set_schedule(gpu, groups=4, seed_bucket_depth=0, seed_rings=1):
-    """nsgpu_set_schedule: pipeline groups (1, 2, 4) and the conflict-aware seed rule (bucket depth 0 = the reference's getRead rule)."""
-    check(gpu.lib, gpu.lib.nsgpu_set_schedule(gpu.ctx, groups, seed_bucket_depth, seed_rings))
+def set_schedule(gpu, groups=4, seed_bucket_depth=0, seed_rings=1, seed_tail_rings=None):
+    """nsgpu_set_schedule(2): pipeline groups (1, 2, 4) and the conflict-aware seed rule (bucket depth 0 = the reference's getRead rule;
+    seed_tail_rings: the smaller radius while more than half of all builders wait for a seed)."""
+    check(gpu.lib, gpu.lib.nsgpu_set_schedule2(gpu.ctx, groups, seed_bucket_depth, seed_rings, seed_rings if seed_tail_rings is None else seed_tail_rings))
 
 
 def consensus_run(gpu, n_builders=256, n_threads_out=1, schedule=None):

@@ -723,7 +723,7 @@ struct LockStep {
     // A seed must lie in a bucket that is neither occupied nor within `rings` adjacency steps of an occupied one; the lowest unclaimed
     // read that qualifies is taken, by the waiting threads in thread order.  seedHops > 0 switches the rule on.
     int seedHops = 0;                            // bucketDepth
-    int rings = 1;
+    int rings = 1, tailRings = 1, ringsNow = 1;      // tailRings: while more than half of ALL threads wait for a seed in one round
     std::vector<std::vector<read_t>> nbr;        // whole-read filter results of every read (forward and reverse-complement query), incl. itself
     std::vector<uint32_t> bucketOf;
     std::vector<std::vector<uint32_t>> adj;      // per bucket: adjacent buckets, ascending, without itself
@@ -794,7 +794,7 @@ struct LockStep {
             if (inGraph[r]) continue;
             any = true;
             int8_t &v8 = verdict[bucketOf[r]];
-            if (v8 < 0) v8 = freeWithin(bucketOf[r], rings) ? 1 : 0;
+            if (v8 < 0) v8 = freeWithin(bucketOf[r], ringsNow) ? 1 : 0;
             if (v8) { out = r; return 1; }
         }
         if (any) ++nIdleSeedRounds;
@@ -1062,6 +1062,7 @@ public:
                 std::vector<uint32_t> req;
                 for (uint32_t v = 0; v < T; ++v) if (L.group(v) == g && L.vt[v]->kind == LockStep::SEED) req.push_back(v);
                 if (L.seedHops) for (uint32_t v : req) L.releaseContig(v);
+                L.ringsNow = 2 * req.size() > (size_t)T ? L.tailRings : L.rings;
                 for (uint32_t v : req) { L.release(lk, v); L.waitIdle(lk); }
                 // one group: the threads that got a seed take their first steps (graph of the seed read, first window, candidates up
                 // to the first alignment) together, after the last grant
@@ -1249,7 +1250,10 @@ static int cons_oracle_run_impl(const char *bases, const uint64_t *off, uint32_t
         c.ls = &L;
         L.G = (uint32_t)lock_step;                        // 1 or 4 groups
         L.seedHops = seed_hops & 255;                     // bucket depth; rings in the next byte (default 1)
-        if (seed_hops >> 8) L.rings = (seed_hops >> 8) - 1;
+        if ((seed_hops >> 8) & 255) L.rings = ((seed_hops >> 8) & 255) - 1;
+        L.tailRings = (seed_hops >> 16) & 255 ? ((seed_hops >> 16) & 255) - 1 : L.rings;
+        if (L.tailRings > L.rings) L.tailRings = L.rings;
+        L.ringsNow = L.rings;
         if (seed_hops > 0) {                              // whole-read filter results of every read, both strands (what nsgpu_filter_all_reads holds)
             L.nbr.assign(N, std::vector<read_t>());
 #pragma omp parallel for schedule(dynamic, 16)

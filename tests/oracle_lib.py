@@ -335,7 +335,7 @@ def ref_align_fn():
 
 
 def cons_oracle_run(bases, off, salts, k=23, n=60, thr=6, m_k=20, m_w=50, mci=400, edge_thr=4000000, num_thr=1, checks=True, id_base=0, align_fn=None,
-                    lock_step=False, seed_hops=0, groups=4, seed_rings=1):
+                    lock_step=False, seed_hops=0, groups=4, seed_rings=1, seed_tail_rings=None):
     """The reference's hot path (sketch + tables + Consensus::generateAndWriteConsensus) on the CPU with the reference's own minimap2
     answering alignRead.  Returns (streams, stats): streams[name] for num_thr == 1, else streams['threads'][t][name]; streams['metaData'].
     lock_step=True: num_thr LOCK-STEP virtual threads (the product's deterministic schedule restated around the literal thread body,
@@ -353,7 +353,7 @@ def cons_oracle_run(bases, off, salts, k=23, n=60, thr=6, m_k=20, m_w=50, mci=40
     if lock_step:
         rc = L.cons_oracle_run_lockstep(_p(bases), _p(off), C.c_uint32(len(off) - 1), C.c_uint32(k), C.c_uint32(n), C.c_uint32(thr), _p(salts), m_k, m_w, mci,
                                         C.c_uint64(edge_thr), num_thr, int(checks), align_fn or ref_align_fn(), C.c_uint32(id_base), ptrs, lens, C.byref(st),
-                                        int(seed_hops) + (256 * (int(seed_rings) + 1) if seed_hops else 0), int(groups), ls_out)
+                                        int(seed_hops) + ((256 * (int(seed_rings) + 1) + 65536 * (int(seed_rings if seed_tail_rings is None else seed_tail_rings) + 1)) if seed_hops else 0), int(groups), ls_out)
     else:
         rc = L.cons_oracle_run(_p(bases), _p(off), C.c_uint32(len(off) - 1), C.c_uint32(k), C.c_uint32(n), C.c_uint32(thr), _p(salts), m_k, m_w, mci,
                                C.c_uint64(edge_thr), num_thr, int(checks), align_fn or ref_align_fn(), C.c_uint32(id_base), ptrs, lens, C.byref(st))

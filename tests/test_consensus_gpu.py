@@ -310,15 +310,15 @@ def test_oversize_sketch_batch_is_split_and_stays_device_visible():
 # oracle/consensus_oracle.cpp struct LockStep runs the LITERAL thread body of the reference under the schedule the engine documents
 # (slots, groups, claims and seeds in builder order, the conflict-aware seed rule): the engine with B builders and B output threads
 # must give byte for byte the B stream sets of the oracle's B virtual threads.
-def many_builders_equal_lockstep_oracle(bases, off, B, groups=4, depth=0, rings=1, n=60):
+def many_builders_equal_lockstep_oracle(bases, off, B, groups=4, depth=0, rings=1, n=60, tail=None):
     want, wst = oracle_lib.cons_oracle_run(bases, off, ns.mt19937_64_salts(n), n=n, checks=False, num_thr=B, lock_step=True, groups=groups,
-                                           seed_hops=depth, seed_rings=rings)
+                                           seed_hops=depth, seed_rings=rings, seed_tail_rings=tail)
     assert wst["n_bad_roundtrip"] == 0
     g = ns.NsGpu(n=n)
     g.load_reads((bases, off))
     g.sketch(ns.mt19937_64_salts(n), fetch=False)
     g.build_index()
-    st = ns.consensus_run(g, B, B, schedule=(groups, depth, rings))
+    st = ns.consensus_run(g, B, B, schedule=(groups, depth, rings, tail))
     per = want["threads"] if B > 1 else [want]
     for t in range(B):
         for k in STREAMS:
@@ -443,3 +443,11 @@ def test_cfg3_at_size_many_builders_lossless_deterministic_bounded_memory():
     sub = np.arange(0, 125000, 20)
     b = bytes(bases)
     one_builder_equals_oracle(*pack([b[int(off[i]):int(off[i + 1])].decode() for i in sub]))
+
+
+def test_tail_rings_equal_lockstep_oracle():
+    """nsgpu_set_schedule2: the smaller exclusion radius for seed rounds in which more than half of all builders wait (the tail of a run)"""
+    bases, off = ns.synth_reads(7, 500000, 1235, 8000.0)
+    a = many_builders_equal_lockstep_oracle(bases, off, 48, 1, 2, 4, tail=1)
+    b = many_builders_equal_lockstep_oracle(bases, off, 48, 1, 2, 4)
+    assert a["slots"] < b["slots"] and a["n_contigs"] >= b["n_contigs"]
