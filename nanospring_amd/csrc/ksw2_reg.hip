@@ -271,9 +271,16 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
                             uint32_t *__restrict__ cig_pool, KswResult *__restrict__ res_out, uint8_t *lds)
 {
     static_assert(!FAST || (APPROX && NW == 1), "the path-independent score is used by the one-wave gap-fill classes");
-    constexpr int T = NW * NCH * 128;
-    constexpr int NB = NW * NCH;                 // blocks of 128 cells
+    // An ODD number of waves (> 1) means: wave 0 owns no cells and only keeps the books (row maximum, mte / mqe, Z-drop, early exit: the
+    // ~100 dependent instructions per row that sat in front of wave 0's own cells on every row's critical path); the other NW - 1 waves
+    // compute.  With an even NW wave 0 does both, as before.
+    constexpr bool BK = NW > 1 && (NW & 1) != 0;
+    constexpr int NWC = BK ? NW - 1 : NW;        // computing waves
+    constexpr int T = NWC * NCH * 128;
+    constexpr int NB = NWC * NCH;                // blocks of 128 cells
     const int lane = threadIdx.x & 63, wv = NW > 1 ? (int)(threadIdx.x >> 6) : 0;
+    const int cw = BK ? wv - 1 : wv;             // index among the computing waves; -1: the books wave
+    const bool computes = !BK || wv > 0;
     const int qlen = tk.qlen, tlen = tk.tlen, flag = tk.flag, zdrop = tk.zdrop;
     Consts K;
     K.q = pr.q, K.e = pr.e, K.q2 = pr.q2, K.e2 = pr.e2;
@@ -319,7 +326,7 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
         const uint8_t *target = seqs + tk.toff;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int t0 = (c * NW + wv) * 128 + 2 * lane;
+            const int t0 = computes ? (c * NWC + cw) * 128 + 2 * lane : T;      // (the books wave: beyond every row)
             const int b0 = t0 < tlen ? target[t0] : 0, b1 = t0 + 1 < tlen ? target[t0 + 1] : 0;
             TT[c] = S2(b0 | b1 << 16);
             TP[c] = S2(t0 | (t0 + 1) << 16);
@@ -442,10 +449,10 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
         bool own_en0 = false, own_st0 = false;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int blk = c * NW + wv, tb = blk * 128;
+            const int blk = c * NWC + cw, tb = blk * 128;
             const s2 ox = X[c], ov = V[c], ox2 = X2[c];
             const int ohl = HL[c], ohh = HH[c];
-            if (tb <= hi_t && tb + 127 >= st) {
+            if (computes && tb <= hi_t && tb + 127 >= st) {
                 const int t0 = tb + 2 * lane;
                 const uint32_t qw = *reinterpret_cast<const uint16_t *>(qsrc + t0);
                 const s2 tq = S2((int)__builtin_amdgcn_perm(0u, qw, 0x0c010c00u));       // two bytes -> two halves
@@ -535,7 +542,7 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
                 // this row or stale, which is what the reference's arrays would hold
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    const int t0 = (c * NW + wv) * 128 + 2 * lane;
+                    const int t0 = computes ? (c * NWC + cw) * 128 + 2 * lane : -(1 << 20);
                     const uint32_t d0 = (uint32_t)(t0 - last_H0_t);
                     if (d0 < 4u) uv4[(r % 3) * 4 + d0] = (uint32_t)(uint16_t)U[c].x | (uint32_t)(uint16_t)V[c].x << 16;
                     if (d0 + 1u < 4u) uv4[(r % 3) * 4 + d0 + 1u] = (uint32_t)(uint16_t)U[c].y | (uint32_t)(uint16_t)V[c].y << 16;
@@ -545,8 +552,8 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
             // [st, en] of row r + 1 only if it is inside [st, en + 16] of this row), this wave's best key, H[en0] / H[st0]
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                const int blk = c * NW + wv, nx = blk * 128 + 128;
-                if (nx >= st && nx <= en + 16 && lane == 63) {
+                const int blk = c * NWC + cw, nx = blk * 128 + 128;
+                if (computes && nx >= st && nx <= en + 16 && lane == 63) {
                     const uint32_t xx = (uint32_t)I32(X[c]) >> 16, vv = (uint32_t)I32(V[c]) & 0xffff0000u, xx2 = (uint32_t)I32(X2[c]) >> 16;
                     seam[(r & 1) * NB + blk] = make_uint2(xx | vv, xx2);
                     if (!APPROX) seam_h[(r & 1) * NB + blk] = HH[c];
@@ -622,16 +629,18 @@ __global__ __launch_bounds__(NW * 64) void ksw_extd2_reg_kernel(const KswTask *_
 struct RegClass { int nw, nch; };
 // Classes 4 and 5 are the latency twins of 0 and 1 (same widths, one block per wave): for exact-mode problems with many anti-diagonals when
 // a DP launch is waited for by a whole round of the contig stage (few builders, one group) rather than overlapped with other groups' work.
-constexpr RegClass kRegClass[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {4, 3}, {8, 5}, {2, 1}, {4, 1}};
+// Classes 6 and 7 are 2 and 3 with a books wave (an odd wave count: see ksw_reg_run): measured, not faster, off by default.
+constexpr RegClass kRegClass[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {4, 3}, {8, 5}, {2, 1}, {4, 1}, {5, 3}, {9, 5}};
+constexpr int reg_compute_waves(int cls) { return kRegClass[cls].nw > 1 && (kRegClass[cls].nw & 1) ? kRegClass[cls].nw - 1 : kRegClass[cls].nw; }
 
 }  // namespace
 
-int ksw_reg_cells(int cls) { return kRegClass[cls].nw * kRegClass[cls].nch * 128; }
+int ksw_reg_cells(int cls) { return reg_compute_waves(cls) * kRegClass[cls].nch * 128; }
 int ksw_reg_threads(int cls) { return kRegClass[cls].nw * 64; }
 
 size_t ksw_reg_lds_bytes(int cls, int qlen)
 {
-    const int nw = kRegClass[cls].nw, nb = nw * kRegClass[cls].nch;
+    const int nw = kRegClass[cls].nw, nb = reg_compute_waves(cls) * kRegClass[cls].nch;
     size_t b = 2 * (size_t)reg_qb(ksw_reg_cells(cls), qlen);
     b += (size_t)2 * nb * 12 + (size_t)3 * (nw + 2) * 4 + 52;      // seams / publication slots (a one-wave class uses two of the slots) / stop flag
     return b + 16;
@@ -656,6 +665,11 @@ int ksw_reg_class(const KswTask &t, const KswParams &pr, int latency_rows)
     if ((long long)(-pr.sc_mis > pr.sc_mch ? -pr.sc_mis : pr.sc_mch) * mn + (long long)(q + e) * (w + 1) + 64 >= 32768) return -1;
     for (int c = 0; c < 4; ++c)
         if (t.tlen <= ksw_reg_cells(c)) {
+            // Measured (cfg2, default schedule, interleaved A/B): a books wave does NOT pay -- wait for the DP 4.64 instead of 4.50 s per step,
+            // mean launch 1.67 instead of 1.62 ms: the bookkeeping of row r - 1 already runs behind the barrier of row r while the other
+            // waves compute, it was not on the critical path.  Off unless NSGPU_KSW_BOOKS_WAVE=1 (bit-exact either way).
+            static const bool books = getenv("NSGPU_KSW_BOOKS_WAVE") != nullptr;
+            if (c >= 2 && books) return 4 + c;                                              // <5,3> / <9,5>
             if (c < 2 && latency_rows > 0 && !(t.flag & KSW_EZ_APPROX_MAX)) {
                 // anti-diagonals the sweep can take: all of them, or until the band runs out
                 const long long full = (long long)t.qlen + t.tlen - 1, band = 2ll * (t.tlen - 1) + w + 1;
@@ -689,6 +703,8 @@ int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const 
     case 3: NS_REG_LAUNCH(8, 5) break;
     case 4: NS_REG_LAUNCH(2, 1) break;
     case 5: NS_REG_LAUNCH(4, 1) break;
+    case 6: NS_REG_LAUNCH(5, 3) break;
+    case 7: NS_REG_LAUNCH(9, 5) break;
     default: NS_CHECK(false, NSGPU_ERR_ARG, "ksw: bad register class");
     }
 #undef NS_REG_LAUNCH
