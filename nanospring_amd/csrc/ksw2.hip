@@ -881,7 +881,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         const uint32_t m = (uint32_t)reg[k].size();
         if (!m) continue;
         hipStream_t st = S;
-        if (k >= 2 && !dbg) { const int si = k >= 6 ? k - 5 : k >= 4 ? 0 : k - 1; st = W.side_stream[si]; NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0)); side_used[si] = true; }
+        if (k >= 2 && !dbg) { const int si = k == 8 ? 1 : k >= 6 ? k - 5 : k >= 4 ? 0 : k - 1; st = W.side_stream[si]; NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0)); side_used[si] = true; }
         double dbg_t0 = 0;
         if (dbg) { NS_HIP(stream_wait(S)); dbg_t0 = now_ms(); }
         NS_HIP(hipEventRecord(ev_at(n_ev++), st));
