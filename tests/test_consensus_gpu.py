@@ -451,3 +451,38 @@ def test_tail_rings_equal_lockstep_oracle():
     a = many_builders_equal_lockstep_oracle(bases, off, 48, 1, 2, 4, tail=1)
     b = many_builders_equal_lockstep_oracle(bases, off, 48, 1, 2, 4)
     assert a["slots"] < b["slots"] and a["n_contigs"] >= b["n_contigs"]
+
+
+def test_cfg2_full_default_schedule_equals_lockstep_oracle_hashes():
+    """BASELINE cfg2 at FULL size in bench.py's DEFAULT schedule (80 builders, one group, conflict-aware seeds: buckets of depth 3, 5 rings, 3
+    in the tail): the engine's 80 stream sets have, stream type by stream type over the builders in order, the sizes and sha256 that the
+    oracle's lock-step virtual threads recorded for this input (the literal thread body of the reference under the documented schedule,
+    the reference's own minimap2 answering every alignRead; tools/oracle_lockstep_cfg2.py -> profiles/r03_lockstep_cfg2.json), the same
+    counters and slot count, and every read decodes.  The headline configuration itself, byte for byte, at the size it is timed at."""
+    import hashlib, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = json.load(open(os.path.join(root, "profiles", "r03_lockstep_cfg2.json")))
+    sc = want["schedule"]
+    bases, off = ns.synth_reads(11, int(100000 * 8000 / 20), 100000, 8000.0)
+    assert int(off[-1]) == want["bases"]
+    g = ns.NsGpu()
+    g.load_reads((bases, off))
+    g.sketch(ns.mt19937_64_salts(60, 12345), fetch=False)
+    g.build_index()
+    B = sc["builders"]
+    st = ns.consensus_run(g, B, B, schedule=(sc["groups"], sc["seed_bucket_depth"], sc["seed_rings"], sc["seed_tail_rings"]))
+    for k in STREAMS:
+        h, tot = hashlib.sha256(), 0
+        for t in range(B):
+            b = ns.consensus_stream(g, t, k)
+            h.update(b)
+            tot += len(b)
+        assert tot == want["stream_bytes"][k], k
+        assert h.hexdigest() == want["sha256_over_threads_in_order"][k], k
+    md = ns.consensus_stream(g, 0, "metaData")
+    assert hashlib.sha256(md).hexdigest() == want["sha256_over_threads_in_order"]["metaData"]
+    for f in ("count_minhash", "count_minhash_not_in_graph", "count_aligner", "n_contigs", "n_lone", "n_align_calls"):
+        assert st[f] == want["stats"][f], f
+    assert st["n_rounds"] == want["stats"]["slots"]
+    assert ns.consensus_verify(g) == 0
+    g.close()
