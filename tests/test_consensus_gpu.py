@@ -453,15 +453,17 @@ def test_tail_rings_equal_lockstep_oracle():
     assert a["slots"] < b["slots"] and a["n_contigs"] >= b["n_contigs"]
 
 
-def test_cfg2_full_default_schedule_equals_lockstep_oracle_hashes():
+@pytest.mark.parametrize("fixture", ["r03_lockstep_cfg2.json", "r03_lockstep_cfg2_1024.json"])
+def test_cfg2_full_default_schedule_equals_lockstep_oracle_hashes(fixture):
     """BASELINE cfg2 at FULL size in bench.py's DEFAULT schedule (80 builders, one group, conflict-aware seeds: buckets of depth 3, 5 rings, 3
     in the tail): the engine's 80 stream sets have, stream type by stream type over the builders in order, the sizes and sha256 that the
     oracle's lock-step virtual threads recorded for this input (the literal thread body of the reference under the documented schedule,
     the reference's own minimap2 answering every alignRead; tools/oracle_lockstep_cfg2.py -> profiles/r03_lockstep_cfg2.json), the same
-    counters and slot count, and every read decodes.  The headline configuration itself, byte for byte, at the size it is timed at."""
+    counters and slot count, and every read decodes.  The headline configuration itself, byte for byte, at the size it is timed at -- and
+    (second fixture) the 1024-builder, four-group pipelined schedule that bench.py times as `throughput_schedule`."""
     import hashlib, json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    want = json.load(open(os.path.join(root, "profiles", "r03_lockstep_cfg2.json")))
+    want = json.load(open(os.path.join(root, "profiles", fixture)))
     sc = want["schedule"]
     bases, off = ns.synth_reads(11, int(100000 * 8000 / 20), 100000, 8000.0)
     assert int(off[-1]) == want["bases"]
@@ -470,7 +472,7 @@ def test_cfg2_full_default_schedule_equals_lockstep_oracle_hashes():
     g.sketch(ns.mt19937_64_salts(60, 12345), fetch=False)
     g.build_index()
     B = sc["builders"]
-    st = ns.consensus_run(g, B, B, schedule=(sc["groups"], sc["seed_bucket_depth"], sc["seed_rings"], sc["seed_tail_rings"]))
+    st = ns.consensus_run(g, B, B, schedule=(sc["groups"], sc["seed_bucket_depth"], max(sc["seed_rings"], 1), max(sc["seed_tail_rings"], 1)))
     for k in STREAMS:
         h, tot = hashlib.sha256(), 0
         for t in range(B):

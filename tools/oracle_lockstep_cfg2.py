@@ -16,12 +16,13 @@ import nanospring_amd as ns
 from tests import oracle_lib
 
 B, depth, rings, tail = (int(x) for x in (sys.argv[1:5] if len(sys.argv) > 4 else (80, 3, 5, 3)))
+groups = int(os.environ.get("NS_ORACLE_GROUPS", "1"))
 out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(ROOT, "profiles", "r03_lockstep_cfg2.json")
 n_reads = int(sys.argv[6]) if len(sys.argv) > 6 else 100000
 bases, off = ns.synth_reads(11, int(n_reads * 8000 / 20), n_reads, 8000.0)
 salts = ns.mt19937_64_salts(60, 12345)
 t0 = time.time()
-streams, st = oracle_lib.cons_oracle_run(bases, off, salts, num_thr=B, checks=False, lock_step=True, groups=1, seed_hops=depth, seed_rings=rings, seed_tail_rings=tail)
+streams, st = oracle_lib.cons_oracle_run(bases, off, salts, num_thr=B, checks=False, lock_step=True, groups=groups, seed_hops=depth, seed_rings=rings, seed_tail_rings=tail)
 dt = time.time() - t0
 names = oracle_lib.CONS_STREAMS
 sha, size = {}, {}
@@ -34,7 +35,7 @@ for n in names:
 sha["metaData"], size["metaData"] = hashlib.sha256(streams["metaData"]).hexdigest(), len(streams["metaData"])
 tot7 = sum(size[n] for n in names)
 rec = {"workload": "cfg2 (bench.py input: seed 11, %d reads, mean 8000, 20x)" % n_reads,
-       "schedule": {"builders": B, "groups": 1, "seed_bucket_depth": depth, "seed_rings": rings, "seed_tail_rings": tail},
+       "schedule": {"builders": B, "groups": groups, "seed_bucket_depth": depth, "seed_rings": rings, "seed_tail_rings": tail},
        "computed_by": "oracle/consensus_oracle.cpp lock-step virtual threads, reference minimap2 (oracle/_ref/libmm2ref.so)",
        "seconds": dt, "bases": int(off[-1]), "stream_bytes": size, "sha256_over_threads_in_order": sha, "stats": st,
        "stream_bytes_total_7": tot7, "stream_bytes_per_base": tot7 / int(off[-1])}
