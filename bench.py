@@ -271,6 +271,28 @@ def main():
                 if "ratio_to_reference_tN" in out:
                     out["iso_compression"] = out["ratio_to_reference_tN"] <= 1.05
             return out
+        def parity_of(fixture, stats):
+            """The run's streams against what the ORACLE's lock-step virtual threads recorded for this very input and schedule
+            (profiles/<fixture>, tools/oracle_lockstep_cfg2.py): sha256 per stream type over all output sets in order.  (.id is left out: the
+            8 merged output sets of this run carry the lone-read id deltas of several builders in one list; the GPU test compares it set by set.)"""
+            import hashlib
+            pth = os.path.join(ROOT, "profiles", fixture)
+            if not os.path.exists(pth) or not (args.reads == 100000 and args.mean_len == 8000.0 and world == 1 and args.genome == "iid" and args.depth == 20.0):
+                return None
+            want = json.load(open(pth))
+            same = {}
+            for kk in ns.filter.STREAMS:
+                if kk == "id":
+                    continue
+                h = hashlib.sha256()
+                for t in range(8):
+                    h.update(ns.consensus_stream(g, t, kk))
+                same[kk] = h.hexdigest() == want["sha256_over_threads_in_order"][kk]
+            return {"fixture": "profiles/" + fixture, "schedule_of_fixture": want["schedule"], "streams_identical_to_the_oracle": same, "all_identical": all(same.values()),
+                    "contigs_slots_equal": stats["n_contigs"] == want["stats"]["n_contigs"] and stats["n_rounds"] == want["stats"]["slots"],
+                    "test": "tests/test_consensus_gpu.py::test_cfg2_full_default_schedule_equals_lockstep_oracle_hashes"}
+        default_sched = (args.builders, args.groups, args.seed_depth, args.seed_rings, args.seed_tail_rings) == (80, 1, 3, 5, 3)
+        parity = parity_of("r03_lockstep_cfg2.json", st) if default_sched else None
         penalty = compression_of(stream_bytes / n_bases, st)
         penalty["schedule"] = {"groups": args.groups, "seed_bucket_depth": args.seed_depth, "seed_rings": args.seed_rings, "seed_tail_rings": args.seed_tail_rings}
         # one step of the 1024-builder, four-group pipelined schedule with the reference's seed rule (the round-2 headline): faster, larger streams
@@ -289,7 +311,7 @@ def main():
             sb2 = sum(len(ns.consensus_stream(g, t, kk)) for t in range(8) for kk in ns.filter.STREAMS)
             tleg = {"value": round(n_bases / 1e6 / dt2, 2), "unit": "Mbases/s", "ms_per_step": round(dt2 * 1e3, 1), "steps": 1,
                     "schedule": {"builders": 1024, "groups": 4, "seed_bucket_depth": 0}, "lossless_roundtrip_bad_reads": ns.consensus_verify(g),
-                    "compression": compression_of(sb2 / n_bases, st2),
+                    "compression": compression_of(sb2 / n_bases, st2), "parity": parity_of("r03_lockstep_cfg2_1024.json", st2),
                     "note": "NOT iso-compression: 1024 contigs grow at once on a 40 Mb genome and cut each other short"}
             ns.set_schedule(g, args.groups, args.seed_depth, args.seed_rings, args.seed_tail_rings)
         comp = None
@@ -332,6 +354,7 @@ def main():
                        else f"reads sharded by id x{world}, no collective"},
             "per_rank": per_rank,
             "compression": penalty,
+            "parity": parity,
             "throughput_schedule": tleg,
             "roofline": {"kernel": "ksw_extd2 (ksw_extd2_reg_kernel<NW,NCH>: DP state in registers)", "bound": "valu-issue", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 7), "hbm_frac": round(achieved / HBM_PEAK_GBS, 7),
