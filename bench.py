@@ -232,6 +232,26 @@ def main():
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         per_rank = gathered
+    hbm_copy = None
+    if rank == 0:
+        # the HBM roof as this box delivers it to a plain device-to-device copy ("confirm with a copy benchmark on the box")
+        try:
+            n_copy = 1 << 30
+            src = torch.empty(n_copy, dtype=torch.uint8, device="cuda")
+            dst = torch.empty_like(src)
+            src.fill_(1)
+            dst.copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            hbm_copy = round(10 * 2 * n_copy / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)      # read + write
+            del src, dst
+        except Exception:
+            hbm_copy = None
     if rank == 0:
         steps = max(args.steps, 1)
         a = ns.align_stats(g)
@@ -357,7 +377,7 @@ def main():
             "parity": parity,
             "throughput_schedule": tleg,
             "roofline": {"kernel": "ksw_extd2 (ksw_extd2_reg_kernel<NW,NCH>: DP state in registers)", "bound": "valu-issue", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 7), "hbm_frac": round(achieved / HBM_PEAK_GBS, 7),
+                         "frac": round(achieved / HBM_PEAK_GBS, 7), "hbm_frac": round(achieved / HBM_PEAK_GBS, 7), "hbm_copy_measured_gbs": hbm_copy,
                          "traffic": None, "traffic_from_profile": traffic, "traffic_source": traffic_src,
                          "launches": int(a["dp_launches"]), "avg_launch_ms": round(dp_ms, 3),
                          # the kernel is integer DP bound by instruction issue, not by HBM: its real ceiling as first-class fields
