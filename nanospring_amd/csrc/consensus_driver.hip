@@ -89,6 +89,7 @@ struct Builder {
     std::vector<std::unique_ptr<FinishedContig>> contigs;     // in the order they were finished = output order
     size_t n_queued = 0;                                      // contigs[0 .. n_queued) were handed to the emission queue
     uint64_t n_minhash = 0, n_minhash_new = 0, n_aligner = 0, n_align_calls = 0, n_contigs = 0, n_lone = 0;
+    double last_u = 0, last_m = 0;
     double cpu_ms = 0, max_ms = 0, last_ms = 0, write_ms = 0, dbg_w1 = 0, dbg_w2 = 0, dbg_w3 = 0, dbg_u = 0, dbg_m = 0, dbg_cyc = 0, dbg_init = 0, dbg_rc = 0, dbg_win = 0, dbg_start = 0, dbg_max_u = 0, dbg_max_m = 0, dbg_long_ms = 0;
     uint64_t dbg_long_n = 0;
     uint64_t dbg_c[6] = {0, 0, 0, 0, 0, 0};
@@ -283,6 +284,7 @@ struct Driver {
                 g.path_changed_from = (size_t)-1;
                 const double u2 = now_ms();
                 b.dbg_u += u1 - u0, b.dbg_m += u2 - u1;
+                b.last_u = u1 - u0, b.last_m = u2 - u1;
                 if (u1 - u0 > b.dbg_max_u) b.dbg_max_u = u1 - u0;
                 if (u2 - u1 > b.dbg_max_m) b.dbg_max_m = u2 - u1;
                 b.idx_valid = false;
@@ -327,6 +329,7 @@ struct Engine {
     std::vector<TailCopy> tail_jobs;
     PinBuf pin_tail;                                // the scatter kernel's job descriptors
     std::vector<DevBuf> retired;                    // resident lists replaced by larger ones, freed at the next call
+    double crit_u_ms = 0, crit_m_ms = 0;              // sum over host phases of the slowest update_graph / main-path recompute (debug print)
     std::vector<uint32_t> dbg_batch_sizes;          // alignments per batch, in order (debug print: how full the slots are over the run)
     uint64_t n_wq_exact = 0;                          // window-query batches that went the exact multi-step way
     int deferred_fresh = -1;                          // group whose freshly started contigs take their first steps with the next host phase
@@ -450,9 +453,10 @@ static void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
             else pool_post([&D, fc] { D.emit_contig(*fc); });
         }
     c->cons_stats.graph_ms += now_ms() - a0;
-    double mx = 0;
-    for (Builder &b : D.B) if (in_group(b, group)) { if (b.last_ms > mx) mx = b.last_ms; b.last_ms = 0; }
+    double mx = 0, mxu = 0, mxm = 0;
+    for (Builder &b : D.B) if (in_group(b, group)) { if (b.last_ms > mx) mx = b.last_ms; b.last_ms = 0; if (b.last_u > mxu) mxu = b.last_u; if (b.last_m > mxm) mxm = b.last_m; b.last_u = b.last_m = 0; }
     c->cons_stats.graph_crit_ms += mx;       // sum over phases of the slowest builder step: the floor of the phase wall
+    E->crit_u_ms += mxu, E->crit_m_ms += mxm;
 }
 
 // phase 2: (gid, cursor) of every local builder that needs a new contig
@@ -1040,7 +1044,7 @@ static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
     if (getenv("NSGPU_CONS_DEBUG")) {
         double mu = 0, mm = 0, lm = 0; uint64_t ln = 0;
         for (Builder &b : D.B) { if (b.dbg_max_u > mu) mu = b.dbg_max_u; if (b.dbg_max_m > mm) mm = b.dbg_max_m; lm += b.dbg_long_ms; ln += b.dbg_long_n; }
-        fprintf(stderr, "[cons] longest update_graph %.1f ms, longest main path %.1f ms; builder steps > 3 ms: %llu, %.0f ms in total; crit %.0f ms\n", mu, mm, (unsigned long long)ln, lm, S.graph_crit_ms);
+        fprintf(stderr, "[cons] longest update_graph %.1f ms, longest main path %.1f ms; builder steps > 3 ms: %llu, %.0f ms in total; crit %.0f ms (slowest update_graph per phase, summed: %.0f; slowest main path: %.0f)\n", mu, mm, (unsigned long long)ln, lm, S.graph_crit_ms, static_cast<Engine *>(c->cons_engine)->crit_u_ms, static_cast<Engine *>(c->cons_engine)->crit_m_ms);
     }
     if (getenv("NSGPU_CONS_DEBUG")) fprintf(stderr, "[cons] cpu-ms: graph total %.0f; initialize+first main path %.0f, query copy/revcomp %.0f, open_window %.0f, start_contig %.0f\n", S.graph_cpu_ms, dbg_x[0], dbg_x[1], dbg_x[2], dbg_x[3]);
     if (getenv("NSGPU_CONS_DEBUG"))
