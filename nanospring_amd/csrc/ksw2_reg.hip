@@ -37,6 +37,7 @@ namespace nsgpu {
 #define KSW_EZ_APPROX_DROP 0x10
 #define KSW_EZ_EXTZ_ONLY 0x40
 #define KSW_EZ_REV_CIGAR 0x80
+#define KSW_EZ_NS_SERIAL_BACKTRACK 0x20000   // debugging aid / A-B switch (NSGPU_KSW_SERIAL_BACKTRACK=1): one lane walks the traceback
 #define KSW_EZ_NS_EARLY_EXIT 0x10000      // not minimap2's: set by the host code of this library (ksw2.hip) unless NSGPU_KSW_NO_EARLY_EXIT
 
 typedef short s2 __attribute__((ext_vector_type(2)));
@@ -224,6 +225,74 @@ __device__ void backtrack_and_store(const KswTask &tk, int w, int ncol16, const 
     o.max = (uint32_t)ez_max; o.zdropped = ez_zdropped; o.max_q = ez_max_q; o.max_t = ez_max_t; o.mqe = ez_mqe; o.mqe_t = ez_mqe_t;
     o.mte = ez_mte; o.mte_q = ez_mte_q; o.score = ez_score; o.n_cigar = (int)n_cigar; o.reach_end = ez_reach_end;
     res_out[tk.out_idx] = o;
+}
+
+// The same walk by one WAVE.  The serial walk is a chain of dependent one-byte loads (one L2 round trip per step, 500-1500 steps for a
+// problem of the multi-wave classes).  Here every round the 64 lanes load the traceback bytes of the next 64 cells ALONG THE DIRECTION THE
+// WALK HAS (diagonal in state 0, up in a deletion, left in an insertion) in one go; the walk then consumes them, in order and with the
+// reference's logic step by step, for as long as its moves follow that direction -- a run of matches, a long gap -- and starts the next
+// round where it left it.  One round trip per run instead of per step; the steps, hence the CIGAR, are the serial walk's.
+__device__ void backtrack_and_store_wave(const KswTask &tk, int w, int ncol16, const uint8_t *p, uint32_t *cig_pool, KswResult *res_out, int ez_max, int ez_zdropped,
+                                         int ez_max_q, int ez_max_t, int ez_mqe, int ez_mqe_t, int ez_mte, int ez_mte_q, int ez_score, int lane)
+{
+    const int qlen = tk.qlen, tlen = tk.tlen, flag = tk.flag;
+    int ez_reach_end = 0;
+    uint32_t n_cigar = 0;
+    if (!(flag & KSW_EZ_SCORE_ONLY)) {
+        int i0 = -1, j0 = -1;
+        if (!ez_zdropped && !(flag & KSW_EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
+        else if (!ez_zdropped && (flag & KSW_EZ_EXTZ_ONLY) && ez_mqe + tk.end_bonus > ez_max) ez_reach_end = 1, i0 = ez_mqe_t, j0 = qlen - 1;
+        else if (ez_max_t >= 0 && ez_max_q >= 0) i0 = ez_max_t, j0 = ez_max_q;
+        if (i0 >= 0 && j0 >= 0) {
+            uint32_t *cig = cig_pool + tk.cig_off;
+            int i = i0, j = j0, state = 0;
+            uint32_t cur_op = 0xffffffffu, cur_len = 0;
+            while (i >= 0 && j >= 0) {
+                const int di = state == 2 || state == 4 ? 0 : 1, dj = state == 1 || state == 3 ? 0 : 1;      // the direction of this round
+                uint32_t mine = 0;
+                {
+                    const int li = i - lane * di, lj = j - lane * dj;
+                    if (li >= 0 && lj >= 0) {
+                        const int r = li + lj;
+                        const RowRange rr = row_range(r, qlen, tlen, w);
+                        int force_state = -1;
+                        if (li < rr.st) force_state = 2;
+                        if (li > rr.en) force_state = 1;
+                        mine = (force_state < 0 ? (uint32_t)p[(size_t)r * ncol16 + li - rr.st] : 0u) | (uint32_t)(force_state + 1) << 8;
+                    }
+                }
+                for (int l = 0; l < 64 && i >= 0 && j >= 0; ++l) {
+                    const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)mine, l);
+                    const uint32_t tmp = x & 0xffu;
+                    const int force_state = (int)(x >> 8) - 1;
+                    if (state == 0) state = tmp & 7;
+                    else if (!(tmp >> (state + 2) & 1)) state = 0;
+                    if (state == 0) state = tmp & 7;
+                    if (force_state >= 0) state = force_state;
+                    uint32_t op;
+                    int mi = 0, mj = 0;
+                    if (state == 0) op = 0, mi = mj = 1;
+                    else if (state == 1 || state == 3) op = 2, mi = 1;
+                    else op = 1, mj = 1;
+                    i -= mi, j -= mj;
+                    if (op == cur_op) ++cur_len;
+                    else { if (cur_len) { if (lane == 0) cig[n_cigar] = cur_len << 4 | cur_op; ++n_cigar; } cur_op = op, cur_len = 1; }
+                    if (mi != di || mj != dj) break;                      // the walk turned: the other lanes' bytes are not on its way
+                }
+            }
+            if (i >= 0) { if (cur_op == 2) cur_len += i + 1; else { if (cur_len) { if (lane == 0) cig[n_cigar] = cur_len << 4 | cur_op; ++n_cigar; } cur_op = 2, cur_len = i + 1; } }
+            if (j >= 0) { if (cur_op == 1) cur_len += j + 1; else { if (cur_len) { if (lane == 0) cig[n_cigar] = cur_len << 4 | cur_op; ++n_cigar; } cur_op = 1, cur_len = j + 1; } }
+            if (cur_len) { if (lane == 0) cig[n_cigar] = cur_len << 4 | cur_op; ++n_cigar; }
+            if (!(flag & KSW_EZ_REV_CIGAR) && lane == 0)
+                for (uint32_t a = 0; a < n_cigar >> 1; ++a) { const uint32_t t_ = cig[a]; cig[a] = cig[n_cigar - 1 - a]; cig[n_cigar - 1 - a] = t_; }
+        }
+    }
+    if (lane == 0) {
+        KswResult o;
+        o.max = (uint32_t)ez_max; o.zdropped = ez_zdropped; o.max_q = ez_max_q; o.max_t = ez_max_t; o.mqe = ez_mqe; o.mqe_t = ez_mqe_t;
+        o.mte = ez_mte; o.mte_q = ez_mte_q; o.score = ez_score; o.n_cigar = (int)n_cigar; o.reach_end = ez_reach_end;
+        res_out[tk.out_idx] = o;
+    }
 }
 
 // LDS layout of a problem (bytes):
@@ -595,10 +664,16 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
     }
     __threadfence_block();
     __syncthreads();        // every traceback byte must have landed before one lane walks it
-    if (threadIdx.x == 0)
-        backtrack_and_store(tk, w, ncol16, p, cig_pool, res_out, __builtin_amdgcn_readfirstlane(z.max), ez_zdropped, __builtin_amdgcn_readfirstlane(z.max_q),
-                            __builtin_amdgcn_readfirstlane(z.max_t), __builtin_amdgcn_readfirstlane(z.mqe), __builtin_amdgcn_readfirstlane(z.mqe_t),
-                            __builtin_amdgcn_readfirstlane(z.mte), __builtin_amdgcn_readfirstlane(z.mte_q), ez_score);
+    if (flag & KSW_EZ_NS_SERIAL_BACKTRACK) {
+        if (threadIdx.x == 0)
+            backtrack_and_store(tk, w, ncol16, p, cig_pool, res_out, __builtin_amdgcn_readfirstlane(z.max), ez_zdropped, __builtin_amdgcn_readfirstlane(z.max_q),
+                                __builtin_amdgcn_readfirstlane(z.max_t), __builtin_amdgcn_readfirstlane(z.mqe), __builtin_amdgcn_readfirstlane(z.mqe_t),
+                                __builtin_amdgcn_readfirstlane(z.mte), __builtin_amdgcn_readfirstlane(z.mte_q), ez_score);
+    } else if (threadIdx.x < 64)
+        backtrack_and_store_wave(tk, w, ncol16, p, cig_pool, res_out, __builtin_amdgcn_readfirstlane(z.max), __builtin_amdgcn_readfirstlane(ez_zdropped),
+                                 __builtin_amdgcn_readfirstlane(z.max_q), __builtin_amdgcn_readfirstlane(z.max_t), __builtin_amdgcn_readfirstlane(z.mqe),
+                                 __builtin_amdgcn_readfirstlane(z.mqe_t), __builtin_amdgcn_readfirstlane(z.mte), __builtin_amdgcn_readfirstlane(z.mte_q),
+                                 __builtin_amdgcn_readfirstlane(ez_score), (int)threadIdx.x);
 }
 
 template <int NW, int NCH>
