@@ -277,11 +277,12 @@ def main():
                 break
         # what the schedule trades: contigs that grow at the same time compete for reads, so more concurrent builders mean more, shorter
         # contigs and larger streams.  The yard-sticks for THIS input are committed measurements of the oracle (the reference's own
-        # OpenMP loop): -t 8 (profiles/r03_oracle_t8_cfg2.json) and -t 1 (profiles/r02_one_builder_cfg2.json).
+        # OpenMP loop): -t 8 (profiles/r03_oracle_t8_cfg2.json; iso_compression is judged against this, the smallest, one), -t 16 (the thread
+        # count of cpu_baseline; 16 threads on the container's 8 cores: profiles/r03_oracle_t16_cfg2.json) and -t 1 (profiles/r02_one_builder_cfg2.json).
         def compression_of(stream_bytes_per_base, stats):
             out = {"builders": stats["n_builders"], "stream_bytes_per_base": round(stream_bytes_per_base, 4), "contigs": stats["n_contigs"], "lone_reads": stats["n_lone"]}
             if args.reads == 100000 and args.mean_len == 8000.0 and world == 1 and args.genome == "iid" and args.depth == 20.0:
-                for key, name in (("reference_tN", "r03_oracle_t8_cfg2.json"), ("reference_t1", "r02_one_builder_cfg2.json")):
+                for key, name in (("reference_tN", "r03_oracle_t8_cfg2.json"), ("reference_t16", "r03_oracle_t16_cfg2.json"), ("reference_t1", "r02_one_builder_cfg2.json")):
                     pth = os.path.join(ROOT, "profiles", name)
                     if os.path.exists(pth):
                         oj = json.load(open(pth))

@@ -22,7 +22,7 @@
 //   * the score row s[] lives in registers too (stale outside the reference's 16-byte score stores of the row).
 //
 // The traceback matrix p (1 B per computed cell, the reference's layout so that the backtrack is index compatible) is
-// scratch in HBM; lane 0 walks it at the end.
+// scratch in HBM; wave 0 walks it at the end (backtrack_and_store_wave).
 #include "common.hpp"
 #include "ksw2.hpp"
 #include <mutex>
