@@ -213,7 +213,7 @@ public:
     explicit HostPool(unsigned n) : n_(n) { for (unsigned i = 1; i < n_; ++i) th_.emplace_back([this, i] { worker(i); }); }
     ~HostPool()
     {
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++gen_; }
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_a_.store(++gen_, std::memory_order_release); }
         cv_.notify_all();
         for (auto &t : th_) t.join();
     }
@@ -229,10 +229,11 @@ public:
             std::lock_guard<std::mutex> lk(m_);
             // short (unpinned) jobs go to the front: they are the ones a GPU batch is waiting for
             if (pinned) active_.push_back(job); else active_.insert(active_.begin(), job);
-            ++gen_;
+            gen_a_.store(++gen_, std::memory_order_release);
         }
         cv_.notify_all();
         while (job->work_once(0)) {}
+        spin_until([&] { return job->done.load(std::memory_order_acquire) == job->total; });      // the last chunks are a few microseconds away
         {
             std::unique_lock<std::mutex> lk(job->m);
             job->cv.wait(lk, [&] { return job->done.load() == job->total; });
@@ -266,6 +267,10 @@ private:
         std::vector<std::shared_ptr<Job>> snap;
         for (;;) {
             std::function<void()> bg;
+            // The loops of a slot of the contig engine follow each other within microseconds, and a sleeping worker needs tens of them to
+            // wake up (a futex round trip per loop and worker, on the slot's critical path): a worker that ran out of work keeps looking
+            // for the next loop for a short while before it blocks.  NSGPU_POOL_SPIN_US (default 60; 0 = block at once).
+            spin_until([&] { return gen_a_.load(std::memory_order_acquire) != seen; });
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [&] { return gen_ != seen || stop_ || !bg_.empty(); });
@@ -301,7 +306,19 @@ private:
             snap.clear();
         }
     }
+    template <class P> static void spin_until(P ready)
+    {
+        static const long spin_us = getenv("NSGPU_POOL_SPIN_US") ? atol(getenv("NSGPU_POOL_SPIN_US")) : 60;
+        if (spin_us <= 0 || ready()) return;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned it = 1;; ++it) {
+            __builtin_ia32_pause();
+            if (ready()) return;
+            if ((it & 31) == 0 && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= spin_us) return;
+        }
+    }
     unsigned n_;
+    std::atomic<uint64_t> gen_a_{0};                  // gen_, readable without the lock (spin_until)
     std::vector<std::thread> th_;
     std::mutex m_;
     std::condition_variable cv_, bg_cv_;
