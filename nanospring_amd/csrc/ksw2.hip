@@ -780,6 +780,8 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         NS_CHECK(cl[i] != 252, NSGPU_ERR_RANGE, "ksw: traceback matrix of one problem exceeds 4 GiB (band the problem or split it)");
         static const bool serial_bt = getenv("NSGPU_KSW_SERIAL_BACKTRACK") != nullptr;  // A/B switch: one lane walks the traceback (register kernels)
         static const bool no_early = getenv("NSGPU_KSW_NO_EARLY_EXIT") != nullptr;     // A/B switch for the register kernels' exact early exit
+        static const bool all_books = getenv("NSGPU_KSW_ALL_BOOKS") != nullptr;         // A/B switch: approx mode, several waves: every wave keeps the books
+        if (all_books) t.flag |= 0x40000;                                               // KSW_EZ_NS_ALL_BOOKS (ksw2_reg.hip)
         if (serial_bt) t.flag |= 0x20000;                                               // KSW_EZ_NS_SERIAL_BACKTRACK (ksw2_reg.hip)
         if (!no_early) t.flag |= 0x10000;                                                // KSW_EZ_NS_EARLY_EXIT (ksw2_reg.hip)
         t.out_idx = (uint32_t)i;

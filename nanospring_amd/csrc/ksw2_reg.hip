@@ -38,6 +38,7 @@ namespace nsgpu {
 #define KSW_EZ_EXTZ_ONLY 0x40
 #define KSW_EZ_REV_CIGAR 0x80
 #define KSW_EZ_NS_SERIAL_BACKTRACK 0x20000   // debugging aid / A-B switch (NSGPU_KSW_SERIAL_BACKTRACK=1): one lane walks the traceback
+#define KSW_EZ_NS_ALL_BOOKS 0x40000          // A-B switch (NSGPU_KSW_ALL_BOOKS=1): approx mode, several waves: every wave keeps the books
 #define KSW_EZ_NS_EARLY_EXIT 0x10000      // not minimap2's: set by the host code of this library (ksw2.hip) unless NSGPU_KSW_NO_EARLY_EXIT
 
 typedef short s2 __attribute__((ext_vector_type(2)));
@@ -374,9 +375,11 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
     uint32_t *pub = reinterpret_cast<uint32_t *>(lds + 2 * QB + 2 * NB * 12);   // [3][NW + 2]: per-wave best key, H[en0], H[st0] of a row
     uint32_t *uv4 = pub + 3 * (NW + 2);                                    // [3][4] approx: u | v << 16 of cells L .. L + 3 (L = last_H0_t two rows back)
     uint32_t *stop_flag = uv4 + 12;                                        // exact, NW > 1: wave 0 (the only one that keeps the books) saw a Z-drop
+    // approx, NW > 1 (ROT below): the books' state after each row, [2][8] {last_H0_t, stop, H0, max, max_t, max_q, score}, 16-byte aligned
+    int *bst = reinterpret_cast<int *>(lds + 2 * QB + ((2 * NB * 12 + 3 * (NW + 2) * 4 + 52 + 15) & ~15));
 
     for (int i = threadIdx.x; i < (2 * QB) / 4; i += NW * 64) reinterpret_cast<uint32_t *>(lds)[i] = 0;
-    for (int i = threadIdx.x; i < 2 * NB * 3 + 3 * (NW + 2) + 13; i += NW * 64) reinterpret_cast<uint32_t *>(lds + 2 * QB)[i] = 0;
+    for (int i = threadIdx.x; i < 2 * NB * 3 + 3 * (NW + 2) + 13 + 20; i += NW * 64) reinterpret_cast<uint32_t *>(lds + 2 * QB)[i] = 0;
     if (NW > 1) __syncthreads();
     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     {
@@ -425,6 +428,23 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
     // second barrier); these describe the row that is still owed
     int lag_r = -1, lag_st0 = 0, lag_en0 = 0, lag_en = 0, lag_L = 0;
     bool brk = false;
+    // Approx mode with several waves: the books of a row (the reference's greedy H0 walk: ~100 instructions and two LDS round trips) are
+    // kept by ONE wave per row instead of by all of them -- a wave's row time is its instruction count, and a row lasts as long as its
+    // busiest wave -- namely by the wave that follows the row's last active block, which computes the fewest blocks.  The state travels
+    // through LDS (bst[slot]): the books of row r - 1 are done behind the barrier of row r and written to slot r & 1; behind that
+    // barrier every wave reads slot (r - 1) & 1 -- the state after row r - 2, complete since the barrier before -- for the stop flag and
+    // for last_H0_t, from which the cells to publish for the books two rows on are known (it moves by at most one cell per row, the
+    // four published cells cover that: uv4).  KSW_EZ_NS_ALL_BOOKS (NSGPU_KSW_ALL_BOOKS=1) keeps the books in every wave, as before.
+    const bool ROT = APPROX && NW > 1 && !BK && !(flag & KSW_EZ_NS_ALL_BOOKS);
+    int Lpub = 0, Lpub_prev = 0;                        // last_H0_t the current / the previous row's publication is relative to
+    auto books_load = [&](const int *sp) { last_H0_t = sp[0], H0 = sp[2], z.max = sp[3], z.max_t = sp[4], z.max_q = sp[5], ez_score = sp[6]; };
+    if (ROT) {
+        if (threadIdx.x < 2) {
+            int *sp = bst + threadIdx.x * 8;
+            sp[0] = 0, sp[1] = 0, sp[2] = 0, sp[3] = 0, sp[4] = -1, sp[5] = -1, sp[6] = KSW_NEG_INF;
+        }
+        __syncthreads();
+    }
 
     // ---- exact mode, rows r > 0 and r == 0 alike: ksw2_extd2_sse.c:359-366 given the row's maximum and H[en0], H[st0] ----
     // ---- exact early exit for extensions that run off the target's end (a read hanging over the end of its contig: qlen in the
@@ -490,12 +510,21 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
         }
     };
 
-    for (int r = 0; r < n_rows; ++r) {
+    int r = 0;
+    for (; r < n_rows; ++r) {
         // row limits (ksw2_extd2_sse.c:138-147); st0, en0 >= 0 here, so the 16-alignment is plain bit arithmetic
         int st0 = r - c1, en0 = r;
         { const int b = (r - w + 1) >> 1; st0 = st0 > b ? st0 : b; st0 = st0 > 0 ? st0 : 0; }
         { const int b = (r + w) >> 1; en0 = en0 < b ? en0 : b; en0 = en0 < c2 ? en0 : c2; }
         if (st0 > en0) {
+            if (ROT) {
+                // every wave is here (r is uniform): the state after row r - 2 was written behind the last barrier
+                __syncthreads();
+                const int *sp = bst + ((r + 1) & 1) * 8;
+                books_load(sp);
+                if (sp[1]) { ez_zdropped = 1; brk = true; break; }
+                lag_L = Lpub_prev;                     // (the window the owed row r - 1 was published with)
+            }
             if (NW > 1 && lag_r >= 0) { lag_row(); if (brk) break; }       // the owed row comes first: it may have Z-dropped (every wave leaves here: no flag needed)
             ez_zdropped = 1;
             break;
@@ -612,7 +641,7 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const int t0 = computes ? (c * NWC + cw) * 128 + 2 * lane : -(1 << 20);
-                    const uint32_t d0 = (uint32_t)(t0 - last_H0_t);
+                    const uint32_t d0 = (uint32_t)(t0 - (ROT ? Lpub : last_H0_t));
                     if (d0 < 4u) uv4[(r % 3) * 4 + d0] = (uint32_t)(uint16_t)U[c].x | (uint32_t)(uint16_t)V[c].x << 16;
                     if (d0 + 1u < 4u) uv4[(r % 3) * 4 + d0 + 1u] = (uint32_t)(uint16_t)U[c].y | (uint32_t)(uint16_t)V[c].y << 16;
                 }
@@ -636,7 +665,22 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
                 if (own_st0) pb[NW + 1] = (uint32_t)pub_st0;
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const int L_used = last_H0_t;                 // what this row's uv4 slots are relative to
+            const int L_used = ROT ? Lpub : last_H0_t;    // what this row's uv4 slots are relative to
+            if (ROT) {
+                const int *sp = bst + ((r + 1) & 1) * 8;          // the state after row r - 2
+                const int sL = sp[0], sstop = sp[1];
+                if (sstop) { books_load(sp); ez_zdropped = 1; brk = true; break; }      // every wave reads the same slot: all leave here
+                if (lag_r >= 0 && wv == ((hi_t >> 7) + 1) % NW) {
+                    books_load(sp);
+                    lag_L = Lpub_prev;
+                    lag_row();
+                    int *so = bst + (r & 1) * 8;
+                    if (lane == 0) { so[0] = last_H0_t, so[1] = brk ? 1 : 0, so[2] = H0, so[3] = z.max, so[4] = z.max_t, so[5] = z.max_q, so[6] = ez_score; }
+                    brk = false, ez_zdropped = 0;                 // the others learn of a Z-drop behind the next barrier, and so does this wave
+                }
+                lag_r = r, lag_st0 = st0, lag_en0 = en0, lag_en = en;
+                Lpub_prev = Lpub, Lpub = sL;
+            } else
             if (APPROX || wv == 0) {
                 // exact mode: only wave 0 keeps the books (the same ~100 instructions in every wave were most of a row's cost); when it
                 // sees the Z-drop it raises the flag and still meets the others at their next barrier, where they read it and leave too
@@ -652,6 +696,16 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
         }
         last_st = st, last_en = en;
     }
+    if (ROT) {
+        // the state after the last but one row was written behind the last barrier: one more, then wave 0 (whose lane 0 reports) does the last row
+        __syncthreads();
+        if (wv == 0 && !brk && !ez_zdropped) {
+            const int *sp = bst + ((r + 1) & 1) * 8;
+            books_load(sp);
+            if (sp[1]) ez_zdropped = 1;
+            else if (lag_r >= 0) { lag_L = Lpub_prev; lag_row(); }
+        }
+    } else
     if (NW > 1 && lag_r >= 0 && !brk && !ez_zdropped) lag_row();      // the last row's bookkeeping (its publication is behind a barrier already)
     if (FAST) {
         // unbanded approx problems never Z-drop and always reach the last row: score = H(tlen - 1, qlen - 1) = the path sum - (q + e)
@@ -718,6 +772,7 @@ size_t ksw_reg_lds_bytes(int cls, int qlen)
     const int nw = kRegClass[cls].nw, nb = reg_compute_waves(cls) * kRegClass[cls].nch;
     size_t b = 2 * (size_t)reg_qb(ksw_reg_cells(cls), qlen);
     b += (size_t)2 * nb * 12 + (size_t)3 * (nw + 2) * 4 + 52;      // seams / publication slots (a one-wave class uses two of the slots) / stop flag
+    b += 16 + 64;                                                  // the approx books' state, two slots (aligned)
     return b + 16;
 }
 
