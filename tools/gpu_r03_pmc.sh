@@ -11,7 +11,7 @@ timeout 1500 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_
 cd $R
 F=$(find gpurun_out/r03pmc/fetch -name "*counter_collection.csv" | head -1); W=$(find gpurun_out/r03pmc/write -name "*counter_collection.csv" | head -1); X=$(find gpurun_out/r03pmc/issue -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_traffic.py $F $W > gpurun_out/r03pmc/r03_pmc_ksw_traffic.json; cat gpurun_out/r03pmc/r03_pmc_ksw_traffic.json | head -12
-python3 tools/pmc_issue.py $X > gpurun_out/r03pmc/r03_pmc_ksw_issue.json; python3 - <<'PY'
+python3 tools/pmc_issue.py $X "bench.py --steps 1 --warmup 0 --cpu-sample 0 --throughput-leg 0 (the default schedule)" > gpurun_out/r03pmc/r03_pmc_ksw_issue.json; python3 - <<'PY'
 import json
 d=json.load(open("gpurun_out/r03pmc/r03_pmc_ksw_issue.json"))
 for k,v in d["kernels"].items(): print(k, v["launches"], v["total_ms"], v["valu_utilisation"], v["instructions_issued_per_simd_cycle"], v["waves_per_simd"], v["wave_time_share"])

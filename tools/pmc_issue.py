@@ -28,7 +28,7 @@ for r in rows:
     if r["Dispatch_Id"] not in disp[k]:
         disp[k].add(r["Dispatch_Id"])
         dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-out = {"source": "rocprofv3 --pmc (SQ issue counters) --kernel-trace -- python3 tools/bench_ksw.py", "kernels": {}}
+out = {"source": "rocprofv3 --pmc (SQ issue counters) --kernel-trace -- python3 " + (sys.argv[2] if len(sys.argv) > 2 else "tools/bench_ksw.py"), "kernels": {}}
 for k, c in acc.items():
     cyc = c["GRBM_GUI_ACTIVE"] / 8.0
     simd_cyc = 1024.0 * cyc
