@@ -749,6 +749,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     pb.resize(n), cl.resize(n);
     const size_t chunk = 1024, n_chunks = (n + chunk - 1) / chunk;
     std::vector<size_t> chunk_stride(n_chunks, 0);
+    static const int promote_rows = getenv("NSGPU_KSW_PROMOTE_ROWS") ? atoi(getenv("NSGPU_KSW_PROMOTE_ROWS")) : 520;
     par_for("align.dp_classify", n_chunks, [&](size_t ci) {
         size_t hs = 0;
         for (size_t i = ci * chunk, e = std::min(n, (ci + 1) * chunk); i < e; ++i) {
@@ -762,7 +763,17 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
             const size_t pbytes = (ksw_p_bytes(t.qlen, t.tlen, t.w) + 63) & ~(size_t)63;
             if (pbytes >= (1ull << 32)) { cl[i] = 252; continue; }      // traceback of one problem beyond 4 GiB (e.g. 50 kb x 50 kb unbanded)
             pb[i] = (uint32_t)pbytes;
-            const int rcls = ksw_reg_class(t, pr, latency_rows);
+            int rcls = ksw_reg_class(t, pr, latency_rows);
+            if (rcls == 0 && promote_rows >= 0) {
+                // The <1,2> launch follows the <1,4> launch on the main stream and each lasts as long as its longest problem: the few LONG
+                // problems of the narrow class (a read's overhang against the last bases of a consensus: a thousand anti-diagonals and
+                // more, where a gap fill of this width has at most 511) go with the <1,4> launch, which handles any narrower problem,
+                // so that what follows it is short.  NSGPU_KSW_PROMOTE_ROWS: the threshold (default 520; 0 = all of them -- a test
+                // switch; negative = off).
+                const long long w = t.w < 0 ? (long long)t.qlen + t.tlen : t.w;
+                const long long full = (long long)t.qlen + t.tlen - 1, band = 2ll * t.tlen + w + 1;
+                if ((full < band ? full : band) > promote_rows) rcls = 1;
+            }
             if (rcls >= 0) { cl[i] = (uint8_t)(16 + rcls); continue; }
             const size_t need = ksw_lds_bytes(t.qlen, t.tlen, t.flag);
             const int cls = need <= kClass[0] ? 0 : need <= kClass[1] ? 1 : need <= kClass[2] ? 2 : 3;

@@ -759,7 +759,7 @@ struct RegClass { int nw, nch; };
 // Classes 4 and 5 are the latency twins of 0 and 1 (same widths, one block per wave): for exact-mode problems with many anti-diagonals when
 // a DP launch is waited for by a whole round of the contig stage (few builders, one group) rather than overlapped with other groups' work.
 // Classes 6 and 7 are 2 and 3 with a books wave (an odd wave count: see ksw_reg_run): measured, not faster, off by default.
-constexpr RegClass kRegClass[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {4, 3}, {8, 5}, {2, 1}, {4, 1}, {5, 3}, {9, 5}, {8, 2}};
+constexpr RegClass kRegClass[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {4, 3}, {8, 5}, {2, 1}, {4, 1}, {5, 3}, {9, 5}, {6, 2}};
 constexpr int reg_compute_waves(int cls) { return kRegClass[cls].nw > 1 && (kRegClass[cls].nw & 1) ? kRegClass[cls].nw - 1 : kRegClass[cls].nw; }
 
 }  // namespace
@@ -799,9 +799,13 @@ int ksw_reg_class(const KswTask &t, const KswParams &pr, int latency_rows)
             // mean launch 1.67 instead of 1.62 ms: the bookkeeping of row r - 1 already runs behind the barrier of row r while the other
             // waves compute, it was not on the critical path.  Off unless NSGPU_KSW_BOOKS_WAVE=1 (bit-exact either way).
             static const bool books = getenv("NSGPU_KSW_BOOKS_WAVE") != nullptr;
-            static const bool wide = getenv("NSGPU_KSW_WIDE") != nullptr;                  // experiment: <8,2> instead of <4,3> (one block per wave and row)
-            if (c == 2 && wide) return 8;
+            // <6,2> instead of <4,3> for targets of 513 .. 1536: the band of such a problem is six blocks of 128 cells wide, one per wave and row
+            // instead of 2 / 2 / 1 / 1 -- a row lasts as long as its busiest wave.  tools/bench_ksw_rows.py: 1.22 / 1.34 / 1.41 instead of
+            // 1.41 / 1.47 / 1.50 us per anti-diagonal (gap fills of 600 / 930 / 1500), 1.40 / 1.55 / 1.59 instead of 1.65 / 1.67 / 1.75
+            // (extensions); <8,2> had been measured at -3 %.  NSGPU_KSW_FOUR_WAVES=1: <4,3>, as before (A/B switch; bit-exact either way).
+            static const bool four = getenv("NSGPU_KSW_FOUR_WAVES") != nullptr;
             if (c >= 2 && books) return 4 + c;                                              // <5,3> / <9,5>
+            if (c == 2 && !four) return 8;
             if (c < 2 && latency_rows > 0 && !(t.flag & KSW_EZ_APPROX_MAX)) {
                 // anti-diagonals the sweep can take: all of them, or until the band runs out
                 const long long full = (long long)t.qlen + t.tlen - 1, band = 2ll * (t.tlen - 1) + w + 1;
@@ -837,7 +841,7 @@ int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const 
     case 5: NS_REG_LAUNCH(4, 1) break;
     case 6: NS_REG_LAUNCH(5, 3) break;
     case 7: NS_REG_LAUNCH(9, 5) break;
-    case 8: NS_REG_LAUNCH(8, 2) break;
+    case 8: NS_REG_LAUNCH(6, 2) break;
     default: NS_CHECK(false, NSGPU_ERR_ARG, "ksw: bad register class");
     }
 #undef NS_REG_LAUNCH
