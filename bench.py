@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--depth", type=float, default=20.0, help="sequencing depth of the synthetic read set (cfg2: 20; cfg3's E. coli regime: ~200)")
     ap.add_argument("--genome", choices=["iid", "repeats"], default="iid", help="synthetic genome: iid (BASELINE cfg2) or with planted duplications / tandem repeats / homopolymer and (AT)n runs")
     ap.add_argument("--throughput-leg", type=int, default=-1, help="also time ONE step of the 1024-builder pipelined schedule, which is not iso-compression (default: only with 1 GPU at full cfg2 size; 0 = skip)")
-    ap.add_argument("--seed-tail-rings", type=int, default=3, help="conflict-aware seeds: the radius while more than half of all builders wait for a seed (default: --seed-rings)")
+    ap.add_argument("--seed-tail-rings", type=int, default=3, help="conflict-aware seeds: the radius in a seed round in which more than half of ALL builders ask (one round carries one group's requests, so this only acts with --groups 1; default 3, negative = --seed-rings)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the all-cores CPU-baseline sample (0 = skip; default: 2000 per host core)")
     ap.add_argument("--no-exchange", action="store_true", help="multi-GPU: independent shards, no collective")
     ap.add_argument("--dist-mode", choices=["alltoall", "replicate"], default="alltoall",

@@ -260,7 +260,9 @@ int nsgpu_set_read_id_base(nsgpu_ctx *ctx, uint32_t base);
 int nsgpu_set_schedule(nsgpu_ctx *ctx, uint32_t groups, uint32_t seed_bucket_depth, uint32_t seed_rings);
 /* the same with a smaller exclusion radius (seed_tail_rings <= seed_rings) for the seed rounds in which more than half of ALL builders
  * ask for a seed -- the tail of a run, when a few contigs close the last gaps and everybody else waits: a seed there is one more contig
- * and halves what is left of the gap.  nsgpu_set_schedule = seed_tail_rings equal to seed_rings. */
+ * and halves what is left of the gap.  A seed round carries the requests of ONE builder group, so with 2 or 4 groups (at most a half / a
+ * quarter of all builders per round) the smaller radius never applies: the option acts with groups = 1.  nsgpu_set_schedule =
+ * seed_tail_rings equal to seed_rings. */
 int nsgpu_set_schedule2(nsgpu_ctx *ctx, uint32_t groups, uint32_t seed_bucket_depth, uint32_t seed_rings, uint32_t seed_tail_rings);
 int nsgpu_get_schedule(const nsgpu_ctx *ctx, uint32_t *groups, uint32_t *seed_bucket_depth, uint32_t *seed_rings);
 int nsgpu_consensus_run(nsgpu_ctx *ctx, uint32_t n_builders, uint32_t n_threads_out, nsgpu_consensus_stats *stats_out);

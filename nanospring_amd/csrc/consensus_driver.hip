@@ -1069,7 +1069,7 @@ static int engine_slot(nsgpu_ctx *c, uint32_t slot, int part = 0)
     const int host_group = (int)(slot % G), begin_group = (int)((slot + G - 1) % G), finish_group = (int)((slot + 1) % G);
     const int ws_index = 1 + (int)(slot % 3);
     static const bool serial = getenv("NSGPU_NO_OVERLAP") != nullptr;      // debugging aid: one after the other
-    if (G <= 2 && !serial) {
+    if (G <= 2) {
         // One or two groups (nsgpu_set_schedule): a builder's step takes G slots instead of four -- the schedule for few builders,
         // where the length of a slot is the latency of its GPU round trips and not its volume.  G = 1: host phase, then the batches
         // (the window queries on a second thread beside sketches / seeds / DP launch), then the DP results.  G = 2: the same chain
@@ -1082,18 +1082,22 @@ static int engine_slot(nsgpu_ctx *c, uint32_t slot, int part = 0)
         int rc1 = NSGPU_OK, rc2 = NSGPU_OK;
         std::string err1, err2;
         auto chain = [&] {
-            std::thread tw([&] {
-                pool_bind_this_thread();
+            std::thread tw;
+            auto wq = [&] {
                 rc2 = hipSetDevice(c->prm.device) == hipSuccess ? engine_window_queries(c, finish_group) : NSGPU_ERR_HIP;
                 if (rc2 != NSGPU_OK) err2 = nsgpu_last_error();
-            });
+            };
+            // NSGPU_NO_OVERLAP=1 (debugging aid): the same steps in the same order on this thread -- the schedule, hence the result, is the same
+            if (serial) wq();
+            else tw = std::thread([&] { pool_bind_this_thread(); wq(); });
             rc1 = engine_batches_sketch(c, begin_group);
             if (rc1 == NSGPU_OK) rc1 = engine_batches_begin(c, begin_group, ws_index);
             if (rc1 != NSGPU_OK) err1 = nsgpu_last_error();
-            tw.join();
+            if (tw.joinable()) tw.join();
             if (rc1 == NSGPU_OK && rc2 == NSGPU_OK) { rc1 = engine_align_finish(c, finish_group); if (rc1 != NSGPU_OK) err1 = nsgpu_last_error(); }
         };
         if (G == 1) { if (part != 2) engine_advance(c, false, host_group); if (part != 1) chain(); }
+        else if (serial) { engine_advance(c, false, host_group); chain(); }
         else {
             std::thread t1([&] { pool_bind_this_thread(); if (hipSetDevice(c->prm.device) == hipSuccess) chain(); else rc1 = NSGPU_ERR_HIP; });
             engine_advance(c, false, host_group);
@@ -1164,7 +1168,15 @@ static int engine_window_loop(nsgpu_ctx *c, int group)
     }
 }
 
+static int run_consensus_inner(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_out);
 static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_out)
+{
+    const int rc = run_consensus_inner(c, n_builders, n_threads_out);
+    // a failed stage leaves no engine behind (nsgpu_set_schedule would refuse with "a contig stage is in progress")
+    if (rc != NSGPU_OK && c->cons_engine) { c->cons_engine_free(c->cons_engine); c->cons_engine = nullptr; }
+    return rc;
+}
+static int run_consensus_inner(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_out)
 {
     NS_CHECK(n_threads_out >= 1, NSGPU_ERR_ARG, "n_threads_out must be >= 1");
     NS_TRY(engine_begin(c, n_builders, 0, 1));
@@ -1327,8 +1339,9 @@ using namespace nsgpu;
 static int run_consensus_dist(nsgpu_ctx *c, Comm &C, uint32_t n_builders_total, uint32_t n_threads_out, uint64_t *n_coll_out, uint64_t *bytes_out)
 {
     NS_CHECK(n_threads_out >= 1, NSGPU_ERR_ARG, "n_threads_out must be >= 1");
-    // (a rank whose engine_begin fails returns before the first collective, like every rank: its arguments are replicated values)
-    NS_TRY(engine_begin(c, n_builders_total, C.rank, C.world));
+    // engine_begin does rank-local GPU work (the seed policy sketches and queries all reads, allocates device and pinned memory): one rank may
+    // fail where the others do not, so its return code travels through a status all-gather of its own before anybody enters the slot loop.
+    const int rc_begin = engine_begin(c, n_builders_total, C.rank, C.world);
     Engine *E = static_cast<Engine *>(c->cons_engine);
     const uint32_t W = C.world;
     // one exchange = [status | claim count, gids, reads | seed count, gids, cursors]; a rank never has more requests than local builders
@@ -1361,6 +1374,7 @@ static int run_consensus_dist(nsgpu_ctx *c, Comm &C, uint32_t n_builders_total, 
             gb.insert(gb.end(), v + 1 + cap, v + 1 + cap + v[0]);
         }
     };
+    NS_TRY(exchange(rc_begin, nullptr, nullptr, nullptr, nullptr));
     for (uint32_t slot = 0;; ++slot) {
         const int G = n_groups(c);
         const int h = (int)(slot % G), b = (int)((slot + 1) % G);
