@@ -223,6 +223,13 @@ typedef struct {
     uint32_t host_threads, reserved;
     uint64_t seed_pairs_gpu;  /* pairs whose index + seeds + chaining scores came from the GPU kernels (seeds.hip, chain.hip) */
     uint64_t seed_pairs_host; /* pairs the seeding kernel handed back to the host code (anchors sharing a reference position, oversize lists) */
+    /* the alignment plan on the device (plan.hip: chains, region, DP windows and the DP launch behind the chaining kernel without a host round
+     * trip; the host's own plan looks the results up by key): */
+    uint64_t plan_pairs_dev;  /* alignments whose DP problems the device planned and launched */
+    uint64_t plan_pairs_host; /* alignments the plan kernel left to the host (several chains, seed filtering, span, capacity, no device input) */
+    uint64_t plan_hits;       /* DP problems the host's plan asked for and found among the device-planned results */
+    uint64_t plan_misses;     /* ... asked for and did not find (of alignments the device planned): launched in a later round */
+    uint64_t plan_extra;      /* device-planned problems the host's plan did not ask for */
 } nsgpu_align_stats;
 int nsgpu_get_align_stats(const nsgpu_ctx *ctx, nsgpu_align_stats *s);
 int nsgpu_reset_align_stats(nsgpu_ctx *ctx);

@@ -369,6 +369,139 @@ double now_ms()
 // builder group in flight while it works on another group; align_requests is both parts back to back.
 namespace {
 
+mm2::Opt batch_opt(const nsgpu_ctx *c)
+{
+    mm2::Opt opt;
+    opt.k = (int)c->prm.m_k, opt.w = (int)c->prm.m_w, opt.max_chain_iter = (int)c->prm.max_chain_iter;
+    return opt;
+}
+KswParams batch_ksw_params(const mm2::Opt &opt)
+{
+    KswParams kp;
+    kp.sc_mch = opt.a; kp.sc_mis = -opt.b; kp.sc_ambi = -opt.sc_ambi; kp.q = opt.q; kp.e = opt.e; kp.q2 = opt.q2; kp.e2 = opt.e2;
+    return kp;
+}
+
+// ---- the alignment plan on the device (plan.hip) -----------------------------------------------------------------------------------
+// Job j's plan pass has listed the DP problems it needs (cache.missing); those the plan kernel launched for it are on their way already.
+void plan_match(nsgpu_ctx *c, AlignBatch &B, uint32_t j)
+{
+    using namespace mm2;
+    if (j >= B.plan_pair.size() || B.plan_pair[j] == ~0u) return;
+    const PlanOut po = B.plan_out.as<PlanOut>()[B.plan_pair[j]];
+    AlignJob &J = B.jobs[j];
+    if (po.flags || po.n_tasks == 0) return;
+    const PlanKey *keys = B.plan_keys.as<PlanKey>() + B.plan_base[j];
+    static_assert(sizeof(PlanKey) == sizeof(DpKey), "the device plan's keys are DpKeys");
+    uint64_t hits = 0, used = 0;
+    std::vector<DpKey> &m = J.cache.missing;
+    size_t keep = 0;
+    for (size_t i = 0; i < m.size(); ++i) {
+        bool found = false;
+        for (uint32_t t = 0; t < po.n_tasks && !found; ++t) found = memcmp(&keys[t], &m[i], sizeof(DpKey)) == 0;
+        if (found) ++hits; else m[keep++] = m[i];
+    }
+    const uint64_t misses = keep;
+    m.resize(keep);
+    used = hits;
+    std::lock_guard<std::mutex> lk(c->stat_m);
+    c->plan_hits += hits, c->plan_misses += misses, c->plan_extra += po.n_tasks - used;
+}
+
+// PlanPair of every seeding pair, room for the tasks, the plan kernel behind the chaining kernel on the seeding stream, the DP classes behind it
+int batch_plan_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int seed_ws, int dp_ws)
+{
+    using namespace mm2;
+    static const bool off = getenv("NSGPU_NO_DEVICE_PLAN") != nullptr;          // A/B switch: every DP problem planned by the host, as before
+    B.plan_ws = -1;
+    const size_t n = hi - lo;
+    if (off || n == 0 || lo != 0 || hi != B.reqs.size() || ksw_class_config().off) return NSGPU_OK;
+    nsgpu_ctx::SeedWs &S = c->seed_ws[seed_ws];
+    const size_t n_pairs = B.seed_pairs.size();
+    if (n_pairs == 0) return NSGPU_OK;
+    const Opt opt = batch_opt(c);
+    const KswParams kp = batch_ksw_params(opt);
+    NS_TRY(B.plan_pairs.reserve(n_pairs * sizeof(PlanPair)));
+    NS_TRY(B.plan_out.reserve(n_pairs * sizeof(PlanOut)));
+    PlanPair *pp = B.plan_pairs.as<PlanPair>();
+    memset(pp, 0, n_pairs * sizeof(PlanPair));
+    memset(B.plan_out.p, 0, n_pairs * sizeof(PlanOut));
+    B.plan_base.assign(n, 0), B.plan_pair.assign(n, ~0u);
+    uint64_t slots = 0, seq_bound = 0;
+    int max_q = 0;
+    bool any = false;
+    for (size_t i = 0; i < n; ++i) {
+        const AlignReq &r = B.reqs[lo + i];
+        const uint32_t q = S.pair_of[i];
+        if (q == ~0u || !r.qry_dev || !r.ref_dev || r.qry_len >= (1ull << 31) || r.ref_len >= (1ull << 31)) continue;
+        const uint32_t cap = (uint32_t)std::min<uint64_t>(256, r.qry_len / (uint64_t)opt.min_ksw_len + 4);
+        pp[q] = PlanPair{r.ref_dev, r.qry_dev, r.ref_dev_lo, r.ref_dev_n, (uint32_t)r.ref_len, (uint32_t)r.qry_len, (uint32_t)slots, cap};
+        B.plan_base[i] = (uint32_t)slots, B.plan_pair[i] = q;
+        slots += cap;
+        seq_bound += 3 * (uint64_t)r.qry_len + 4 * (uint64_t)opt.max_gap + 1024;
+        max_q = std::max(max_q, (int)std::min<uint64_t>(r.qry_len, (uint64_t)opt.max_gap + 1024));
+        any = true;
+    }
+    if (!any || seq_bound >= (1ull << 32) - (1u << 20) || slots >= (1u << 24)) return NSGPU_OK;
+    NS_TRY(B.plan_keys.reserve(slots * sizeof(PlanKey)));
+    const SeedChainDev D = gpu_seeds_chain_dev(c, seed_ws, 2 * seed_ws);
+    PlanDp dp;
+    NS_TRY(ksw_dev_prepare(c, dp_ws, (uint32_t)slots, (uint32_t)n_pairs, seq_bound, D.stream, dp));
+    PlanCfg cfg;
+    cfg.k = opt.k, cfg.min_cnt = opt.min_cnt, cfg.min_sc = opt.min_chain_score, cfg.bw = opt.bw, cfg.max_gap = opt.max_gap, cfg.min_ksw_len = opt.min_ksw_len;
+    cfg.zdrop = opt.zdrop, cfg.end_bonus = opt.end_bonus, cfg.a = opt.a, cfg.q = opt.q, cfg.e = opt.e, cfg.q_max = max_q;
+    cfg.kp = kp, cfg.kc = ksw_class_config();
+    NS_TRY(plan_launch(D.stream, (uint32_t)n_pairs, D.lds_anchors, D.res, D.anchors, D.f, D.p, pp, B.plan_out.as<PlanOut>(), B.plan_keys.as<PlanKey>(), dp, cfg));
+    if (!B.plan_ev) NS_HIP(hipEventCreateWithFlags(&B.plan_ev, hipEventDisableTiming));
+    NS_HIP(hipEventRecord(B.plan_ev, D.stream));
+    NS_TRY(ksw_dev_launch(c, dp_ws, max_q, kp, B.plan_ev));
+    B.plan_ws = dp_ws;
+    return NSGPU_OK;
+}
+
+// the device-planned results into the jobs' caches (every task of every alignment the kernel planned: the jobs look them up by key)
+int batch_plan_deliver(nsgpu_ctx *c, AlignBatch &B)
+{
+    using namespace mm2;
+    if (B.plan_ws < 0) return NSGPU_OK;
+    const int ws = B.plan_ws;
+    B.plan_ws = -1;
+    KswDevResults R;
+    NS_TRY(ksw_dev_collect(c, ws, R));
+    const PlanOut *po = B.plan_out.as<PlanOut>();
+    const PlanKey *keys = B.plan_keys.as<PlanKey>();
+    uint64_t n_dev = 0, n_host = 0, n_tasks = 0;
+    for (size_t i = 0; i < B.plan_pair.size(); ++i) {
+        if (B.plan_pair[i] == ~0u) { ++n_host; continue; }
+        const PlanOut o = po[B.plan_pair[i]];
+        if (o.flags) ++n_host; else ++n_dev, n_tasks += o.n_tasks;
+        for (int bit = 0; bit < 8; ++bit) if (o.flags >> bit & 1) __atomic_fetch_add(&c->plan_why[bit], 1, __ATOMIC_RELAXED);
+    }
+    n_host += B.reqs.size() - B.plan_pair.size();
+    if (R.res && R.cig_ok)
+        parallel_for("align.dp_deliver", B.plan_pair.size(), [&](size_t i) {
+            if (B.plan_pair[i] == ~0u) return;
+            const PlanOut o = po[B.plan_pair[i]];
+            if (o.flags) return;
+            AlignJob &J = B.jobs[i];
+            if (J.finished) return;
+            for (uint32_t t = 0; t < o.n_tasks; ++t) {
+                const uint32_t slot = B.plan_base[i] + t;
+                const KswResult &r = R.res[slot];
+                DpResult d;
+                d.max = r.max; d.zdropped = r.zdropped; d.max_q = r.max_q; d.max_t = r.max_t; d.mqe = r.mqe; d.mqe_t = r.mqe_t; d.mte = r.mte;
+                d.mte_q = r.mte_q; d.score = r.score; d.reach_end = r.reach_end;
+                DpKey k;
+                memcpy(&k, &keys[slot], sizeof(DpKey));
+                J.cache.put(k, d, R.cig + R.coff[slot], (uint32_t)r.n_cigar);
+            }
+        });
+    std::lock_guard<std::mutex> lk(c->stat_m);
+    c->plan_pairs_dev += n_dev, c->plan_pairs_host += n_host;
+    c->aln_dp_tasks += n_tasks;
+    return NSGPU_OK;
+}
+
 // host step of all live jobs, then the DP tasks they are waiting for: descriptors + sequence pool (pinned)
 int batch_prepare_round(nsgpu_ctx *c, AlignBatch &B, bool stepped = false)
 {
@@ -382,6 +515,7 @@ int batch_prepare_round(nsgpu_ctx *c, AlignBatch &B, bool stepped = false)
         AlignJob &J = B.jobs[j];
         if (J.finished) continue;
         still.push_back(j);
+        if (B.plan_ws >= 0) plan_match(c, B, j);        // what the device planned and launched is not asked for again
         B.t_off.push_back(nt), B.b_off.push_back(nb);
         nt += J.cache.missing.size();
         for (const DpKey &k : J.cache.missing) nb += (size_t)(k.qe - k.qs) + (size_t)(k.re - k.rs);
@@ -441,19 +575,6 @@ void batch_deliver(AlignBatch &B)
     B.dp_tasks += B.tasks.size();
     ++B.rounds;
     B.host_ms += now_ms() - a0;
-}
-
-mm2::Opt batch_opt(const nsgpu_ctx *c)
-{
-    mm2::Opt opt;
-    opt.k = (int)c->prm.m_k, opt.w = (int)c->prm.m_w, opt.max_chain_iter = (int)c->prm.max_chain_iter;
-    return opt;
-}
-KswParams batch_ksw_params(const mm2::Opt &opt)
-{
-    KswParams kp;
-    kp.sc_mch = opt.a; kp.sc_mis = -opt.b; kp.sc_ambi = -opt.sc_ambi; kp.q = opt.q; kp.e = opt.e; kp.q2 = opt.q2; kp.e2 = opt.e2;
-    return kp;
 }
 
 }  // namespace
@@ -587,12 +708,15 @@ int align_prestep_start(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi)
     batch_start_jobs(c, B, lo, hi);
     return NSGPU_OK;
 }
-int align_prestep_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws, bool started_and_seeded)
+int align_prestep_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws, bool started_and_seeded, int dp_ws)
 {
     NS_TRY(prestep_check(c, B, lo, hi, chain_ws));
     const double a0 = now_ms();
     if (!started_and_seeded) batch_start_jobs(c, B, lo, hi);
+    B.plan_ws = -1;
     NS_TRY(batch_seed_and_launch(c, B, lo, hi, chain_ws, started_and_seeded));
+    // the plan kernel and the DP launch behind the chaining kernel, without waiting for either (plan.hip)
+    if (dp_ws >= 0) NS_TRY(batch_plan_launch(c, B, lo, hi, chain_ws, dp_ws));
     B.host_ms += now_ms() - a0;
     return NSGPU_OK;
 }
@@ -628,7 +752,9 @@ int align_begin(nsgpu_ctx *c, AlignBatch &B, int ws_index)
     if (!pre) {
         const double a0 = now_ms();
         batch_start_jobs(c, B, 0, n_pairs);
+        B.plan_ws = -1;
         NS_TRY(batch_seed_and_launch(c, B, 0, n_pairs, 0));      // direct API calls: chain workspace 0
+        NS_TRY(batch_plan_launch(c, B, 0, n_pairs, 0, ws_index));
         NS_TRY(batch_wait_and_step(c, B, 0, n_pairs, 0));
         B.host_ms += now_ms() - a0;
     }
@@ -637,6 +763,7 @@ int align_begin(nsgpu_ctx *c, AlignBatch &B, int ws_index)
     NS_TRY(batch_prepare_round(c, B, true));
     if (B.live.empty()) return NSGPU_OK;
     const double a0 = now_ms();
+    // (with the device plan this launch is normally empty: the problems are in flight already)
     NS_TRY(ksw_batch_launch(c, B.tasks, c->kws[ws_index].h_pool, B.nb, batch_ksw_params(batch_opt(c)), B.res, B.cig, B.coff, ws_index));
     B.dp_ms += now_ms() - a0;
     B.in_flight = true;
@@ -667,6 +794,12 @@ int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs)
         g_finish_ms[0] += now_ms() - a0;
         B.in_flight = false;
         batch_deliver(B);
+    }
+    {   // what the device planned and launched (plan.hip)
+        const double a0 = now_ms();
+        NS_TRY(batch_plan_deliver(c, B));
+        B.dp_ms += now_ms() - a0;
+        g_finish_ms[0] += now_ms() - a0;
     }
     const double f1 = now_ms();
     for (int round = 0; !B.live.empty(); ++round) {
@@ -730,6 +863,9 @@ int align_batch(nsgpu_ctx *c, const char *refs, const uint64_t *roff, uint32_t n
         const uint32_t rf = pair_ref[i];
         reqs[i] = AlignReq{&idx[rf], refs + roff[rf], (size_t)(roff[rf + 1] - roff[rf]), qrys + qoff[i], (size_t)(qoff[i + 1] - qoff[i]),
                            mz + mz_off[n_refs + i], (size_t)(mz_off[n_refs + i + 1] - mz_off[n_refs + i]), mz + mz_off[rf], (size_t)(mz_off[rf + 1] - mz_off[rf])};
+        // every reference and every query lies whole in the sketch batch's staging buffer in HBM: the plan kernel reads them there
+        reqs[i].qry_dev = sketch_dev_seq(c, 0, n_refs + i), reqs[i].ref_dev = sketch_dev_seq(c, 0, rf);
+        reqs[i].ref_dev_lo = 0, reqs[i].ref_dev_n = (uint32_t)reqs[i].ref_len;
     }
     return align_requests(c, reqs, outs);
 }
@@ -823,6 +959,7 @@ extern "C" int nsgpu_get_align_stats(const nsgpu_ctx *c, nsgpu_align_stats *s)
     s->dp_launches = c->ksw_launches;
     s->host_threads = host_threads();
     s->seed_pairs_gpu = c->aln_seed_gpu, s->seed_pairs_host = c->aln_seed_host;
+    s->plan_pairs_dev = c->plan_pairs_dev, s->plan_pairs_host = c->plan_pairs_host, s->plan_hits = c->plan_hits, s->plan_misses = c->plan_misses, s->plan_extra = c->plan_extra;
     return NSGPU_OK;
 }
 
@@ -830,6 +967,7 @@ extern "C" int nsgpu_reset_align_stats(nsgpu_ctx *c)
 {
     NS_CHECK(c, NSGPU_ERR_ARG, "null argument");
     c->aln_pairs = c->aln_dp_tasks = c->aln_rounds = c->aln_seed_gpu = c->aln_seed_host = 0;
+    c->plan_pairs_dev = c->plan_pairs_host = c->plan_hits = c->plan_misses = c->plan_extra = 0;
     c->aln_index_ms = c->aln_host_ms = c->aln_dp_ms = 0;
     c->ksw_kernel_ms = c->ksw_cells = c->ksw_alg_bytes = c->ksw_kernel_sum_ms = 0;
     c->ksw_launches = 0;

@@ -204,7 +204,8 @@ __device__ __forceinline__ void walk_chunk(Walk &w, int32_t hi, bool ok, int32_t
 // fit this launch's LDS (lds_anchors) itself.
 __global__ __launch_bounds__(64) void chain_forward_lds_kernel(const mm2::Anchor *__restrict__ anchors, const ChainList *__restrict__ lists,
                                                                const uint32_t *__restrict__ jobs, int32_t *__restrict__ f_out, int32_t *__restrict__ p_out,
-                                                               mm2::Anchor *__restrict__ a_out, SeedResult *seeded, uint32_t lds_anchors, ChainParams P)
+                                                               mm2::Anchor *__restrict__ a_out, SeedResult *seeded, uint32_t lds_anchors, ChainParams P,
+                                                               int32_t *__restrict__ f_dev, int32_t *__restrict__ p_dev)
 {
     extern __shared__ int32_t lds[];
     ChainList L;
@@ -302,6 +303,8 @@ __global__ __launch_bounds__(64) void chain_forward_lds_kernel(const mm2::Anchor
         ri = ri_n, qi = qi_n, q_span = sp_n;
     }
     for (int32_t i = lane; i < n; i += 64) f_out[base + i] = F[i], p_out[base + i] = Pp[i];
+    // a copy in device memory for the plan kernel that follows on the stream (plan.hip); f_out / p_out are pinned host memory
+    if (f_dev) for (int32_t i = lane; i < n; i += 64) f_dev[base + i] = F[i], p_dev[base + i] = Pp[i];
 }
 
 // ---- the ring kernel: lists of ANY length at the LDS kernel's pace (round 3) ----
@@ -467,7 +470,8 @@ int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vecto
             NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_forward_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(kFastAnchors, kFastBw)));
             W.lds_set = lds_bytes(kFastAnchors, kFastBw);
         }
-        hipLaunchKernelGGL(chain_forward_lds_kernel, dim3(n_lds), dim3(64), lds_bytes(max_lds, opt.bw), W.stream, ha, hl, hj, hf, hp, (mm2::Anchor *)nullptr, (SeedResult *)nullptr, 0u, P);
+        hipLaunchKernelGGL(chain_forward_lds_kernel, dim3(n_lds), dim3(64), lds_bytes(max_lds, opt.bw), W.stream, ha, hl, hj, hf, hp, (mm2::Anchor *)nullptr, (SeedResult *)nullptr, 0u, P,
+                           (int32_t *)nullptr, (int32_t *)nullptr);
     }
     if (n_big) {
         NS_TRY(W.d_in.reserve(b_anch + b_off + b_avg + b_jobs));
@@ -511,8 +515,11 @@ int gpu_chain_launch_seeded(nsgpu_ctx *c, int ws, hipStream_t stream, const mm2:
         W.lds_set = lds_bytes(kFastAnchors, kFastBw);
     }
     const uint32_t lds_anchors = (uint32_t)std::min<uint64_t>(kFastAnchors, 2 * (uint64_t)max_n_qry + 256);
+    NS_TRY(W.d_out.reserve(capacity * 2 * sizeof(int32_t)));
+    int32_t *df = W.d_out.as<int32_t>(), *dp = df + capacity;
+    W.seeded_lds_anchors = lds_anchors, W.seeded_capacity = capacity;
     hipLaunchKernelGGL(chain_forward_lds_kernel, dim3((unsigned)n_pairs), dim3(64), lds_bytes(lds_anchors, opt.bw), stream, d_anchors, (const ChainList *)nullptr,
-                       (const uint32_t *)nullptr, hf, hp, ha, res, lds_anchors, P);
+                       (const uint32_t *)nullptr, hf, hp, ha, res, lds_anchors, P, df, dp);
     NS_HIP(hipGetLastError());
     W.ms_enqueue += now_ms() - t0, ++W.calls;
     return NSGPU_OK;
@@ -526,6 +533,17 @@ void gpu_chain_results_seeded(nsgpu_ctx *c, int ws, const mm2::Anchor *&a, const
     if (W.pend_total == 0) return;
     a = W.h_out.as<mm2::Anchor>();
     f = reinterpret_cast<const int32_t *>(a + W.pend_total), p = f + W.pend_total;
+}
+
+SeedChainDev gpu_seeds_chain_dev(nsgpu_ctx *c, int ws, int chain_ws)
+{
+    nsgpu_ctx::SeedWs &S = c->seed_ws[ws];
+    nsgpu_ctx::ChainWs &W = c->cws[chain_ws];
+    SeedChainDev d;
+    d.anchors = S.d_out.as<mm2::Anchor>(), d.res = S.h_res.as<SeedResult>();
+    d.f = W.d_out.as<int32_t>(), d.p = d.f + W.seeded_capacity;
+    d.stream = S.stream, d.lds_anchors = W.seeded_lds_anchors;
+    return d;
 }
 
 int gpu_chain_wait(nsgpu_ctx *c, int ws, const int32_t *&f, const int32_t *&p)

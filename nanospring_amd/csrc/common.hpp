@@ -147,6 +147,7 @@ struct nsgpu_ctx {
     struct KswWs {
         nsgpu::DevBuf k_tasks, k_order, k_seqs, k_p, k_cig, k_res, k_slab, k_ncig, k_coff, k_cig2, scan_ws;
         std::vector<hipEvent_t> ev;                                  // start/end event pairs, one pair per launch of a batch
+        std::vector<int> ev_class;                                   // register class of each pair (-1: another kernel)
         uint8_t *h_pool = nullptr; size_t h_pool_cap = 0;            // pinned staging of the DP sequence pool
         std::vector<uint8_t> h_bucket; std::vector<uint32_t> h_tmp;   // scratch of the launch-order bucketing
         std::vector<uint32_t> h_flat;                                // launch order of the batch in flight
@@ -156,6 +157,16 @@ struct nsgpu_ctx {
         hipStream_t stream = nullptr;                                // workspace 0 runs on the context's stream
         hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
         hipEvent_t side_done[3] = {nullptr, nullptr, nullptr}, side_fork = nullptr, t_a = nullptr, t_b = nullptr;
+        // a batch whose tasks the plan kernel writes (plan.hip, ksw_dev_*): buffers of its own, so that a host-planned batch of the same
+        // workspace may follow in the same slot.  dv_ctrl: [0..15] class counters, [16..17] overflow flags, then 8 u64: cursors (traceback bytes,
+        // CIGAR entries, sequence bytes), cells, algorithmic bytes
+        nsgpu::DevBuf dv_tasks, dv_list, dv_ctrl, dv_seqs, dv_p, dv_cig, dv_res, dv_coff, dv_scan_ws;
+        nsgpu::PinBuf hv_res, hv_coff, hv_cig, hv_ctrl;
+        uint32_t dv_slots = 0, dv_pairs = 0, dv_classes = 0;                         // dv_classes: bit k = class k was launched
+        uint64_t dv_p_hint = 0, dv_hcig_hint = 0, dv_hcig_cap = 0;
+        bool dv_pending = false;
+        std::vector<hipEvent_t> dv_ev;
+        hipEvent_t dv_a = nullptr, dv_b = nullptr;
     } kws[4];                                                       // 0: the context's stream (direct API calls); 1-3: own streams (contig engine, one per batch in flight)
     // batched minimizer sketches (mm_sketch.hip): device buffers + pinned staging both ways
     struct SketchWs {
@@ -164,6 +175,8 @@ struct nsgpu_ctx {
         uint8_t *h_out = nullptr; size_t h_out_cap = 0;
         nsgpu::PinBuf h_meta;                                          // pinned landing zone of the small read-backs (push count, offsets)
         nsgpu::PinBuf h_concat;                                        // results of an oversize batch sketched piece by piece (gpu_mm_sketch)
+        const uint32_t *staged_soff = nullptr; size_t staged_n = 0;   // offsets of the last batch's requests in `seqs` (sketch_dev_seq)
+        std::vector<uint32_t> staged_soff_v;
         hipStream_t stream = nullptr;
     } sws[2];                                                       // two workspaces: the contig engine sketches the two halves of a batch concurrently
     // chaining scores (chain.hip): anchors in, f / p out.  0: direct API calls; 1..: two per group of the contig engine (the halves of a batch are pipelined)
@@ -177,6 +190,7 @@ struct nsgpu_ctx {
         double ms_stage = 0, ms_enqueue = 0, ms_wait = 0; uint64_t calls = 0;   // host wall of the calls: staging / enqueue / wait for the results
         hipStream_t stream = nullptr;
         hipStream_t stream2 = nullptr; bool ring_used = false;         // the ring kernel's long lists run beside the LDS kernel's launch
+        uint32_t seeded_lds_anchors = 0; uint64_t seeded_capacity = 0; // of the last seeded launch (d_out then holds f / p for the plan kernel)
     } cws[18];                                                      // per batch workspace w: 2w the lists seeded on the GPU, 2w + 1 the ones seeded by the host code
     // index + seeds (seeds.hip): scratch tables, anchors (device), pair descriptors and results (pinned)
     struct SeedWs {
@@ -195,8 +209,11 @@ struct nsgpu_ctx {
     double ksw_kernel_ms = 0, ksw_cells = 0, ksw_alg_bytes = 0;     // kernel_ms: wall of the (overlapping) DP launches per batch
     double ksw_kernel_sum_ms = 0;                                    // sum of the individual kernel durations (what rocprof reports)
     uint64_t ksw_launches = 0;
+    double ksw_class_ms[16] = {}; uint64_t ksw_class_n[16] = {};    // per register class: summed launch durations / launches (debug print of the contig stage)
     // align batches
     uint64_t aln_pairs = 0, aln_dp_tasks = 0, aln_rounds = 0, aln_seed_gpu = 0, aln_seed_host = 0;
+    uint64_t plan_pairs_dev = 0, plan_pairs_host = 0, plan_hits = 0, plan_misses = 0, plan_extra = 0;      // the alignment plan on the device (plan.hip)
+    uint64_t plan_why[8] = {};                                     // alignments left to the host, by PLAN_* bit (debug print)
     double aln_index_ms = 0, aln_host_ms = 0, aln_dp_ms = 0;
     // host copy of the reads as ReadData::getRead returns them (A/T/C/G after the 2-bit folding)
     std::vector<char> h_bases;

@@ -80,7 +80,12 @@ struct Builder {
     // stretch that differs (+ a margin on both sides) is sketched again and spliced in -- see engine_batches_sketch
     std::vector<mm2::Anchor> mz;
     std::string mz_str;
-    struct Splice { bool full = true; size_t a = 0, B_sub = 0, A = 0, B = 0; ssize_t delta = 0; } sp;
+    struct Splice { bool full = true; size_t a = 0, B_sub = 0, A = 0, B = 0, P = 0, S = 0; ssize_t delta = 0; } sp;      // P / S: common prefix / suffix with the string before
+    // the contig's consensus resident in HBM (what the plan kernel gathers the DP targets from): main_path as of the last alignment batch the
+    // builder was in, at [dc_beg, dc_beg + dc_len) of d_cons -- room on both sides, a contig grows at its ends (cons_update_kernel)
+    DevBuf d_cons;
+    size_t dc_beg = 0, dc_len = 0;
+    bool dc_valid = false;
     // the contig's minimizer list resident in HBM (what the seeding kernel reads): mz[0 .. d_mz_n) as of the last upload.  After a splice only
     // the entries from the first changed one on travel (a contig grows at its ends: a few hundred entries of tens of thousands).
     DevBuf d_mz;
@@ -130,6 +135,7 @@ struct Driver {
         b.mz.clear(), b.mz_str.clear();          // a new consensus: nothing to splice into
         b.chg_lb = 0;
         b.d_mz_n = 0;                            // (the resident list's memory stays with the builder)
+        b.dc_valid = false;
         b.st = Builder::ADVANCE;
     }
 
@@ -306,6 +312,9 @@ struct Driver {
 // ---------------------------------------------------------------------------
 // lists of a batch: per builder the tail that changed goes from the pinned staging buffer into the contig's resident list
 struct TailCopy { const mm2::Anchor *src; mm2::Anchor *dst; uint32_t n; uint32_t pad; };
+// cons_update_kernel's job: see there
+struct ConsJob { uint8_t *buf; const uint8_t *mid; uint64_t beg_old, len_old, beg_new, len_new, P, S; uint32_t full, pad; };
+
 
 struct Engine {
     Driver D;
@@ -328,6 +337,10 @@ struct Engine {
     std::vector<size_t> tail_from;                  // per builder of the batch: first list entry that travels this time
     std::vector<TailCopy> tail_jobs;
     PinBuf pin_tail;                                // the scatter kernel's job descriptors
+    std::vector<uint8_t> cons_changed;              // per builder of the batch: its consensus changed since the batch before
+    std::vector<ConsJob> cons_jobs;
+    PinBuf pin_cons;                                // cons_update_kernel's job descriptors
+    std::vector<char> cons_check;                   // NSGPU_CONS_CHECK: a device copy read back
     std::vector<DevBuf> retired;                    // resident lists replaced by larger ones, freed at the next call
     double crit_u_ms = 0, crit_m_ms = 0;              // sum over host phases of the slowest update_graph / main-path recompute (debug print)
     std::vector<uint32_t> dbg_batch_sizes;          // alignments per batch, in order (debug print: how full the slots are over the run)
@@ -379,9 +392,10 @@ static void engine_free(void *p)
 {
     pool_drain();                                     // no emission task may outlive the engine
     Engine *E = static_cast<Engine *>(p);
-    for (Builder &b : E->D.B) b.d_mz.release();
+    for (Builder &b : E->D.B) { b.d_mz.release(); b.d_cons.release(); }
     for (DevBuf &d : E->retired) d.release();
     E->pin_tail.release();
+    E->pin_cons.release();
     delete E;
 }
 
@@ -657,6 +671,7 @@ static void plan_splice(Builder &b, int w, int k)
             }
     }
     sp.full = false;
+    sp.P = P, sp.S = S;
     sp.a = a, sp.B_sub = e;
     sp.A = a == 0 ? 0 : P - m;                                   // new minimizers are taken from [A, B)
     sp.B = e == Ln ? Ln : Ln - S + m;
@@ -712,6 +727,46 @@ static size_t apply_splice(Builder &b, const mm2::Anchor *sub, size_t n_sub, int
     return first_diff;
 }
 
+// ---- the consensus resident in HBM -----------------------------------------------------------------------------------------------------
+// After an accepted read the new consensus differs from the old one between a common prefix of P and a common suffix of S bases, and the
+// bytes in between travelled with the sketch batch anyway (the re-sketched stretch contains them).  The device copy is brought up to date
+// in place: the SHORTER of prefix and suffix moves by the length difference (a contig is edited near the end it is growing at, so that is
+// a few kilobytes of a megabase string), the middle is written from the staged stretch.  One workgroup per contig; a move is done chunk by
+// chunk in the direction that never overwrites bytes it has yet to read, every chunk loaded whole before it is stored.
+
+__global__ __launch_bounds__(256) void cons_update_kernel(const ConsJob *__restrict__ jobs)
+{
+    const ConsJob J = jobs[blockIdx.x];
+    const int tid = (int)threadIdx.x;
+    uint8_t *buf = J.buf;
+    if (J.full) {                                           // the whole string was staged
+        for (uint64_t i = tid; i < J.len_new; i += 256) buf[J.beg_new + i] = J.mid[i];
+        return;
+    }
+    const uint64_t M = J.len_new - J.P - J.S;               // new middle
+    // the part that moves: prefix (kept suffix in place) or suffix (kept prefix in place)
+    const bool move_prefix = J.beg_new != J.beg_old;
+    const uint64_t n_mv = move_prefix ? J.P : J.S;
+    const uint64_t src = move_prefix ? J.beg_old : J.beg_old + J.len_old - J.S, dst = move_prefix ? J.beg_new : J.beg_new + J.len_new - J.S;
+    if (src != dst && n_mv) {
+        constexpr uint64_t kChunk = 256 * 16;
+        const uint64_t n_ch = (n_mv + kChunk - 1) / kChunk;
+        for (uint64_t k = 0; k < n_ch; ++k) {
+            const uint64_t ch = dst > src ? n_ch - 1 - k : k;          // moving right: from the far end
+            uint8_t v[16];
+            const uint64_t o = ch * kChunk + (uint64_t)tid * 16;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = o + u < n_mv ? buf[src + o + u] : (uint8_t)0;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (o + u < n_mv) buf[dst + o + u] = v[u];
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (uint64_t i = tid; i < M; i += 256) buf[J.beg_new + J.P + i] = J.mid[i];
+}
+
 __global__ void mz_tail_scatter_kernel(const TailCopy *__restrict__ jobs, uint32_t n_jobs)
 {
     const uint32_t j = blockIdx.y;
@@ -722,7 +777,83 @@ __global__ void mz_tail_scatter_kernel(const TailCopy *__restrict__ jobs, uint32
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < t.n; i += gridDim.x * blockDim.x) d[i] = s[i];
 }
 
-static int engine_batches_sketch(nsgpu_ctx *c, int group)
+// The contigs' consensus strings in HBM brought up to date for the builders of an alignment batch (after the sketch batch staged the changed
+// stretches, before the plan kernel reads them), and AlignReq.ref_dev pointed at them.  A builder whose copy cannot be updated (nothing
+// staged to update it from) goes without the device plan this time.
+static int engine_cons_update(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std::vector<uint32_t> &who, const std::vector<uint8_t> &changed, const std::vector<uint32_t> &sk_ref, int sws_i)
+{
+    Driver &D = E->D;
+    nsgpu_ctx::SeedWs &SW = c->seed_ws[sws_i];
+    if (!SW.stream) NS_TRY(role_stream_create(&SW.stream, "seeds"));
+    std::vector<ConsJob> &jobs = E->cons_jobs;
+    jobs.clear();
+    const size_t n = who.size();
+    for (size_t w = 0; w < n; ++w) {
+        Builder &b = D.B[who[w]];
+        const size_t Ln = b.g->main_path.size();
+        const uint8_t *staged = changed[w] && sk_ref[w] != ~0u ? sketch_dev_seq(c, 0, sk_ref[w]) : nullptr;
+        if (changed[w]) {
+            const bool full = b.sp.full || !b.dc_valid;
+            if (!staged || (full && !b.sp.full) || Ln >= (1ull << 31)) { b.dc_valid = false; continue; }      // nothing whole to (re)build the copy from
+            ConsJob J{};
+            J.len_new = Ln, J.full = full;
+            if (full) {
+                const size_t want = 2 * Ln + (256u << 10);
+                if (b.d_cons.cap < want) { if (b.d_cons.p) E->retired.push_back(b.d_cons); b.d_cons = DevBuf(); NS_TRY(b.d_cons.reserve(2 * want)); }
+                J.buf = b.d_cons.as<uint8_t>(), J.mid = staged, J.beg_new = (b.d_cons.cap - Ln) / 2;
+            } else {
+                const size_t Lo = b.dc_len, P = b.sp.P, S = b.sp.S;
+                if (P + S > Lo || P + S > Ln || P < b.sp.a || Ln - S > b.sp.B_sub) { fprintf(stderr, "nsgpu: consensus splice out of range (internal error)\n"); abort(); }
+                // which side moves: the shorter one, if the buffer has the room on that side
+                const ssize_t delta = (ssize_t)Ln - (ssize_t)Lo;
+                const bool pre_fits = (ssize_t)b.dc_beg - delta >= 0, suf_fits = b.dc_beg + Ln <= b.d_cons.cap;
+                bool move_prefix = P <= S;
+                if (move_prefix && !pre_fits) move_prefix = false;
+                if (!move_prefix && !suf_fits) move_prefix = pre_fits;
+                if (!(move_prefix ? pre_fits : suf_fits)) {
+                    // out of room on both sides: a larger buffer, the old content re-centred in it (device to device, on the stream the update runs on)
+                    DevBuf bigger;
+                    NS_TRY(bigger.reserve(4 * Ln + (512u << 10)));
+                    const size_t nb = (bigger.cap - Lo) / 2;
+                    NS_HIP(hipMemcpyAsync(bigger.as<uint8_t>() + nb, b.d_cons.as<uint8_t>() + b.dc_beg, Lo, hipMemcpyDeviceToDevice, SW.stream));
+                    E->retired.push_back(b.d_cons);
+                    b.d_cons = bigger, b.dc_beg = nb;
+                    move_prefix = P <= S;
+                }
+                J.buf = b.d_cons.as<uint8_t>(), J.mid = staged + (P - b.sp.a);
+                J.beg_old = b.dc_beg, J.len_old = Lo, J.P = P, J.S = S;
+                J.beg_new = move_prefix ? (uint64_t)((ssize_t)b.dc_beg - delta) : b.dc_beg;
+            }
+            b.dc_beg = J.beg_new, b.dc_len = Ln, b.dc_valid = true;
+            jobs.push_back(J);
+        }
+        if (b.dc_valid && AB.reqs[w].qry_dev) AB.reqs[w].ref_dev = b.d_cons.as<uint8_t>() + b.dc_beg, AB.reqs[w].ref_dev_lo = 0, AB.reqs[w].ref_dev_n = (uint32_t)b.dc_len;
+        else AB.reqs[w].qry_dev = nullptr;
+    }
+    if (!jobs.empty()) {
+        NS_TRY(E->pin_cons.reserve(jobs.size() * sizeof(ConsJob)));
+        memcpy(E->pin_cons.p, jobs.data(), jobs.size() * sizeof(ConsJob));
+        hipLaunchKernelGGL(cons_update_kernel, dim3((uint32_t)jobs.size()), dim3(256), 0, SW.stream, E->pin_cons.as<ConsJob>());
+        NS_HIP(hipGetLastError());
+    }
+    static const bool check = getenv("NSGPU_CONS_CHECK") != nullptr;          // every device copy against the host's string (the contig tests run under it)
+    if (check) {
+        NS_HIP(hipStreamSynchronize(SW.stream));
+        for (size_t w = 0; w < n; ++w) {
+            Builder &b = D.B[who[w]];
+            if (!b.dc_valid) continue;
+            E->cons_check.resize(b.dc_len);
+            NS_HIP(hipMemcpy(E->cons_check.data(), b.d_cons.as<uint8_t>() + b.dc_beg, b.dc_len, hipMemcpyDeviceToHost));
+            if (b.dc_len != b.g->main_path.size() || memcmp(E->cons_check.data(), b.g->main_path.data(), b.dc_len) != 0) {
+                fprintf(stderr, "CONSENSUS COPY MISMATCH: builder %u, %zu bases (P %zu S %zu full %d)\n", b.gid, b.dc_len, b.sp.P, b.sp.S, (int)b.sp.full);
+                abort();
+            }
+        }
+    }
+    return NSGPU_OK;
+}
+
+static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
@@ -781,6 +912,11 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group)
     static const bool resident_lists = getenv("NSGPU_NO_RESIDENT_LISTS") == nullptr;      // A/B switch: consensus minimizer lists staged whole, as in round 2
     std::vector<size_t> &tail_from = E->tail_from;
     tail_from.assign(n, 0);
+    // the plan kernel (plan.hip) reads the candidate where the sketch batch staged it and the consensus from the contig's resident copy
+    const bool use_dev_plan = dp_ws >= 0 && cut == n && rc == NSGPU_OK;
+    std::vector<uint8_t> &changed = E->cons_changed;
+    changed.assign(n, 0);
+    for (size_t w = 0; w < n; ++w) changed[w] = !D.B[who[w]].idx_valid;
     // lists retired by an earlier call: their last reader (that call's seeding kernel) has been waited for since
     for (DevBuf &d : E->retired) d.release();
     E->retired.clear();
@@ -815,6 +951,7 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group)
             const size_t qi = h.q_base + (w - h.lo);
             AB.reqs[w] = AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), h.mz + mo[qi], (size_t)(mo[qi + 1] - mo[qi]),
                                   stage + so[w - lo], 0};
+            if (use_dev_plan) AB.reqs[w].qry_dev = sketch_dev_seq(c, 0, qi);       // (the consensus side: filled in below, once the device copies are up to date)
         }
         rc = align_prestep_start(c, AB, lo, hi);
         if (rc != NSGPU_OK) break;
@@ -877,7 +1014,9 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group)
                 if (hipGetLastError() != hipSuccess) { rc = NSGPU_ERR_HIP; break; }
             }
         }
-        rc = align_prestep_launch(c, AB, lo, hi, 1 + 2 * gi + r, true);
+        if (use_dev_plan && lo == 0 && hi == n) { rc = engine_cons_update(c, E, AB, who, changed, H[0].sk_ref, sws_i); if (rc != NSGPU_OK) break; }
+        else for (size_t w = lo; w < hi; ++w) if (changed[w]) D.B[who[w]].dc_valid = false;          // (a batch that does not update the device copies leaves them stale)
+        rc = align_prestep_launch(c, AB, lo, hi, 1 + 2 * gi + r, true, use_dev_plan ? dp_ws : -1);
     }
     for (int r = 0; r < 2 && rc == NSGPU_OK; ++r)
         if (r_lo[r] < r_hi[r]) rc = align_prestep_finish(c, AB, r_lo[r], r_hi[r], 1 + 2 * gi + r);
@@ -986,7 +1125,7 @@ static int engine_batches_finish(nsgpu_ctx *c, int group)
 
 static int engine_batches(nsgpu_ctx *c, int group)
 {
-    NS_TRY(engine_batches_sketch(c, group));
+    NS_TRY(engine_batches_sketch(c, group, 1));
     NS_TRY(engine_batches_begin(c, group, 1));
     return engine_batches_finish(c, group);
 }
@@ -1090,7 +1229,7 @@ static int engine_slot(nsgpu_ctx *c, uint32_t slot, int part = 0)
             // NSGPU_NO_OVERLAP=1 (debugging aid): the same steps in the same order on this thread -- the schedule, hence the result, is the same
             if (serial) wq();
             else tw = std::thread([&] { pool_bind_this_thread(); wq(); });
-            rc1 = engine_batches_sketch(c, begin_group);
+            rc1 = engine_batches_sketch(c, begin_group, ws_index);
             if (rc1 == NSGPU_OK) rc1 = engine_batches_begin(c, begin_group, ws_index);
             if (rc1 != NSGPU_OK) err1 = nsgpu_last_error();
             if (tw.joinable()) tw.join();
@@ -1110,7 +1249,7 @@ static int engine_slot(nsgpu_ctx *c, uint32_t slot, int part = 0)
     if (serial) {
         engine_advance(c, false, host_group);
         NS_TRY(engine_batches_finish(c, finish_group));
-        NS_TRY(engine_batches_sketch(c, begin_group));
+        NS_TRY(engine_batches_sketch(c, begin_group, ws_index));
         return engine_batches_begin(c, begin_group, ws_index);
     }
     // the calling thread works in the host phase's loops: it joins the pool's threads on the GPU's NUMA node for the slot
@@ -1132,7 +1271,7 @@ static int engine_slot(nsgpu_ctx *c, uint32_t slot, int part = 0)
         d[i] = now_ms() - x;
         ser[i] = pool_thread_cpu_ns() - c0 - pool_thread_work_ns();
     };
-    std::thread t1([&] { role(1, [&] { const int r = engine_batches_sketch(c, begin_group); return r != NSGPU_OK ? r : engine_batches_begin(c, begin_group, ws_index); }); });
+    std::thread t1([&] { role(1, [&] { const int r = engine_batches_sketch(c, begin_group, ws_index); return r != NSGPU_OK ? r : engine_batches_begin(c, begin_group, ws_index); }); });
     std::thread t2([&] { role(2, [&] { return engine_batches_finish(c, finish_group); }); });
     const double h0 = now_ms();
     const uint64_t hc0 = pool_thread_cpu_ns(), hw0 = pool_thread_work_ns();
@@ -1243,6 +1382,13 @@ static int run_consensus_inner(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_thr
         double sw = 0; uint64_t sn = 0, sp = 0, sf = 0;
         for (nsgpu_ctx::SeedWs &w : c->seed_ws) sw += w.ms_wait, sn += w.calls, sp += w.pairs, sf += w.fallbacks, w.ms_wait = 0, w.calls = w.pairs = w.fallbacks = 0;
         fprintf(stderr, "[cons] window-query batches redone the exact multi-step way (a buffer sized in advance did not fit): %llu\n", (unsigned long long)E->n_wq_exact);
+        fprintf(stderr, "[cons] DP launches by register class (cumulative; ms per launch x launches; wall of the DP phases %.0f ms):", c->ksw_kernel_ms);
+        for (int k = 0; k < 16; ++k) if (c->ksw_class_n[k]) fprintf(stderr, " [%d] %.3f x %llu", k, c->ksw_class_ms[k] / (double)c->ksw_class_n[k], (unsigned long long)c->ksw_class_n[k]);
+        fprintf(stderr, "\n");
+        fprintf(stderr, "[cons] alignments left to the host's plan, by reason (cumulative): no anchors / flagged pair %llu, several chains %llu, seed filtering %llu, outside the staged span %llu, capacity %llu, DP class %llu\n",
+                (unsigned long long)c->plan_why[0], (unsigned long long)c->plan_why[1], (unsigned long long)c->plan_why[2], (unsigned long long)c->plan_why[3], (unsigned long long)c->plan_why[4], (unsigned long long)c->plan_why[5]);
+        fprintf(stderr, "[cons] device plan (cumulative): %llu alignments planned on the device, %llu left to the host; DP problems found %llu, not found %llu, unasked %llu\n",
+                (unsigned long long)c->plan_pairs_dev, (unsigned long long)c->plan_pairs_host, (unsigned long long)c->plan_hits, (unsigned long long)c->plan_misses, (unsigned long long)c->plan_extra);
         fprintf(stderr, "[cons] index + seeds on the GPU: %llu launches, %llu pairs, wait %.0f ms wall; %llu pairs handed back to the host code\n", (unsigned long long)sn,
                 (unsigned long long)sp, sw, (unsigned long long)sf);
         double cs = 0, ce = 0, cw = 0; uint64_t cn = 0;

@@ -6,6 +6,7 @@
 #include <vector>
 #include "mm2.hpp"
 #include "ksw2.hpp"
+#include "ksw_class.hpp"
 
 struct nsgpu_ctx;
 
@@ -43,6 +44,10 @@ struct AlignReq {
     size_t n_ref_mz = 0;
     const mm2::Anchor *ref_mz_dev = nullptr;   // the same list resident in DEVICE memory (the contig engine keeps one per contig): the seeding kernel
                                                // reads this one, ref_mz (any host memory then) serves the pairs the kernel hands back to the host code
+    // for the plan kernel (plan.hip): the query and the stretch [ref_dev_lo, ref_dev_lo + ref_dev_n) of the reference as ASCII in DEVICE memory
+    // (sketch_dev_seq: they travelled with the sketch batch); both given = the DP problems are planned and launched on the device
+    const uint8_t *qry_dev = nullptr, *ref_dev = nullptr;
+    uint32_t ref_dev_lo = 0, ref_dev_n = 0;
 };
 struct SketchReq { const char *ptr; size_t len; };
 // (w,k)-minimizers of a batch of sequences, computed on the GPU (mm_sketch.hip).  Sequence i's minimizers are
@@ -50,7 +55,10 @@ struct SketchReq { const char *ptr; size_t len; };
 // stays valid until the next call.
 // `out` points into the pinned buffer of sketch workspace `ws` (0 or 1) and stays valid until the next call with the same workspace;
 // calls with different workspaces may run concurrently
-int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws = 0);
+// n_stage_only: the last so many requests are copied to HBM with the batch but not sketched (their lists are empty); sketch_dev_seq(c, ws, i) is
+// request i's bytes in DEVICE memory (nullptr when the batch did not go through the fused path's staging), valid until the workspace's next call
+int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws = 0, size_t n_stage_only = 0);
+const uint8_t *sketch_dev_seq(const nsgpu_ctx *c, int ws, size_t i);
 int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::AlnOut> &outs, int ws_index = 0);
 // the same in two parts, the DP kernels in flight between them (state of one batch)
 // seeds.hip: index + seeds of a batch of (reference minimizers, query minimizers) pairs on the GPU
@@ -63,6 +71,36 @@ struct SeedPair {
 struct SeedResult { unsigned long long base; uint32_t n; uint32_t flags; int32_t mid_occ; float avg; };
 constexpr uint32_t SEED_FLAG_TIES = 1, SEED_FLAG_MANY = 2, SEED_FLAG_CAPACITY = 4, SEED_FLAG_OCC = 8, SEED_FLAG_WIDE = 16;
 struct ChainList { uint64_t beg, obeg; uint32_t n; float avg; };
+
+// ---- the alignment plan on the device (plan.hip) and the DP launch that follows it without a host round trip (ksw2.hip) ----
+// One entry per alignment of a batch.  ref: the staged span [ref_lo, ref_lo + ref_n) of the reference (consensus) as ASCII in DEVICE memory;
+// qry: the whole query likewise.  The alignment may use the task slots [task_base, task_base + task_cap).
+struct PlanPair { const uint8_t *ref; const uint8_t *qry; uint32_t ref_lo, ref_n, ref_len, qlen, task_base, task_cap; };
+struct PlanOut { uint32_t n_tasks, flags; };
+// why an alignment was left to the host's plan: no anchors / pair flagged by the kernels before; several chains; long-gap seed filtering;
+// a target window outside the staged span; out of task slots or scratch; a DP problem the register kernels do not serve
+constexpr uint32_t PLAN_NONE = 1, PLAN_COMPLEX = 2, PLAN_BADSEEDS = 4, PLAN_SPAN = 8, PLAN_FULL = 16, PLAN_CLASS = 32;
+struct PlanKey { int32_t qs, qe, rs, re, w, zdrop, end_bonus, flag; };      // = mm2::DpKey: what the host looks a device-planned problem up by
+struct PlanDp {            // where the plan kernel puts its DP tasks (buffers of a DP workspace, ksw2.hip ksw_dev_prepare)
+    KswTask *tasks; KswResult *res; uint32_t *class_list; uint32_t *class_cnt; uint32_t n_slots;
+    uint32_t class_grid[KSW_REG_CLASSES];               // workgroups the class's launch has: entries of its list beyond that are never run
+    uint8_t *seqs; unsigned long long *cursors;          // cursors: traceback bytes, CIGAR entries, sequence bytes handed out so far
+    unsigned long long p_cap; uint32_t cig_cap, seq_cap;
+};
+struct PlanCfg {           // minimap2's options the plan depends on (mm2::Opt) + the DP kernels' parameters and class rule
+    int32_t k, min_cnt, min_sc, bw, max_gap, min_ksw_len, zdrop, end_bonus, a, q, e, q_max;
+    KswParams kp; KswClassCfg kc;
+};
+int plan_launch(hipStream_t st, uint32_t n_pairs, uint32_t lds_anchors, const SeedResult *seeded, const mm2::Anchor *anchors, const int32_t *f, const int32_t *p,
+                const PlanPair *pairs, PlanOut *out, PlanKey *keys_out, const PlanDp &dp, const PlanCfg &cfg);
+// ksw2.hip: a DP batch whose tasks are written by the plan kernel.  prepare: buffers for n_slots task slots (results zeroed, cursors and class
+// counters reset) on the workspace's stream; launch: every register class over its device-side list, CIGAR compaction, results / CIGARs into
+// pinned memory -- all behind `after` (an event on the stream that ran the plan kernel); collect: waits, then res / coff / cig point into the
+// pinned results (valid until the workspace's next prepare) and class_cnt[KSW_REG_CLASSES] tells what was launched.
+struct KswDevResults { const KswResult *res; const uint64_t *coff; const uint32_t *cig; const uint32_t *class_cnt; const unsigned long long *cursors; bool cig_ok; };
+int ksw_dev_prepare(nsgpu_ctx *c, int ws_index, uint32_t n_slots, uint32_t n_pairs, uint64_t seq_bytes_bound, hipStream_t st, PlanDp &dp);
+int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr, hipEvent_t after);
+int ksw_dev_collect(nsgpu_ctx *c, int ws_index, KswDevResults &out);
 
 struct AlignBatch {
     std::vector<AlignReq> reqs;
@@ -80,6 +118,15 @@ struct AlignBatch {
     double host_ms = 0, dp_ms = 0, chain_ms = 0;
     std::vector<SeedPair> seed_pairs;      // scratch of the seeding launch (seeds.hip)
     uint64_t dp_tasks = 0, rounds = 0;
+    // the device plan of the batch (plan.hip): per seeding pair its PlanPair / PlanOut, per task slot its key (all pinned); per request its first slot
+    PinBuf plan_pairs, plan_out, plan_keys;
+    std::vector<uint32_t> plan_base, plan_pair;          // request -> first task slot / seeding pair (~0u: none)
+    int plan_ws = -1;                                    // DP workspace the device-planned batch runs on; -1: none in flight
+    hipEvent_t plan_ev = nullptr;
+    AlignBatch() = default;
+    AlignBatch(const AlignBatch &) = delete;
+    AlignBatch &operator=(const AlignBatch &) = delete;
+    ~AlignBatch() { plan_pairs.release(); plan_out.release(); plan_keys.release(); if (plan_ev) (void)hipEventDestroy(plan_ev); }
 };
 // first host step (seeds / chains / regions / DP plan) of the requests [lo, hi) of B.reqs, ahead of align_begin: lets the caller
 // overlap it with the GPU sketch of the batch's other requests.  All requests must have been pre-stepped before align_begin.
@@ -87,7 +134,7 @@ int align_prestep(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_w
 // the same in two parts: seeds + launch of the chaining kernel / wait + first step -- the caller pipelines ranges (different chain_ws)
 // (align_prestep_start + the caller's own loop calling B.jobs[i].seed() + launch(..., true): seeds inside another per-builder loop)
 int align_prestep_start(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi);
-int align_prestep_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws, bool started_and_seeded = false);
+int align_prestep_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws, bool started_and_seeded = false, int dp_ws = -1);   // dp_ws >= 0: + the device plan and its DP launch
 int align_prestep_finish(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws);
 // chain.hip: mm_chain_dp's forward pass for a batch of anchor lists (host pointers in, pinned host results out)
 int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vector<const mm2::Anchor *> &lists, const std::vector<uint64_t> &off,
@@ -98,6 +145,10 @@ int gpu_seeds_launch(nsgpu_ctx *c, int ws, float mid_occ_frac, std::vector<SeedP
 int gpu_seeds_wait(nsgpu_ctx *c, int ws, const SeedResult *&res, const mm2::Anchor *&d_anchors);
 // seeds + the chaining kernel behind them on one stream (chain_ws: the chaining workspace whose pinned buffer takes anchors / f / p)
 int gpu_seeds_chain_launch(nsgpu_ctx *c, int ws, int chain_ws, const mm2::Opt &opt, std::vector<SeedPair> &pairs);
+// what the launch above left in DEVICE memory (valid on the seeding workspace's stream, behind its kernels): the sorted anchors, the pairs' results
+// (pinned, device-visible) and f / p of every anchor -- the inputs of the plan kernel (plan.hip)
+struct SeedChainDev { const mm2::Anchor *anchors; const SeedResult *res; const int32_t *f, *p; hipStream_t stream; uint32_t lds_anchors; };
+SeedChainDev gpu_seeds_chain_dev(nsgpu_ctx *c, int ws, int chain_ws);
 int gpu_seeds_chain_wait(nsgpu_ctx *c, int ws, int chain_ws, const SeedResult *&res, const mm2::Anchor *&a, const int32_t *&f, const int32_t *&p);
 int align_begin(nsgpu_ctx *c, AlignBatch &B, int ws_index);
 int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs);

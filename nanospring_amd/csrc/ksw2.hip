@@ -23,6 +23,7 @@
 // once with coalesced 64-byte stores and read sparsely by the backtrack.
 #include "common.hpp"
 #include "ksw2.hpp"
+#include "ksw_class.hpp"
 #include "host_util.hpp"
 #include <rocprim/rocprim.hpp>
 
@@ -739,7 +740,6 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     // NSGPU_KSW_LATENCY_ROWS anti-diagonals.  Off by default.  Measured at the one-group schedule, where a whole round waits for its DP launch
     // (cfg2, 80 builders, interleaved A/B): 700 rows: wait for the DP 5.4 instead of 4.7 s per step, whole path 72.4 instead of 76.6 Mbases/s;
     // 400 / 1000 rows the same picture -- a barrier per anti-diagonal costs more than the second block of a lane saves.
-    static const int latency_rows = [] { const char *e = getenv("NSGPU_KSW_LATENCY_ROWS"); return e ? atoi(e) : 0; }();
     static const int wg_min_rows = [] { const char *e = getenv("NSGPU_KSW_WG_MIN_ROWS"); return e ? atoi(e) : 0; }();   // experiment knob
     size_t p_total = 0, cig_total = 0, hbm_stride = 0;
     // per-problem sizes and classes on all host threads (a batch has ~10^4 problems and this thread is on the slot's critical
@@ -749,7 +749,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     pb.resize(n), cl.resize(n);
     const size_t chunk = 1024, n_chunks = (n + chunk - 1) / chunk;
     std::vector<size_t> chunk_stride(n_chunks, 0);
-    static const int promote_rows = getenv("NSGPU_KSW_PROMOTE_ROWS") ? atoi(getenv("NSGPU_KSW_PROMOTE_ROWS")) : 520;
+    const KswClassCfg kcfg = ksw_class_config();
     par_for("align.dp_classify", n_chunks, [&](size_t ci) {
         size_t hs = 0;
         for (size_t i = ci * chunk, e = std::min(n, (ci + 1) * chunk); i < e; ++i) {
@@ -763,17 +763,11 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
             const size_t pbytes = (ksw_p_bytes(t.qlen, t.tlen, t.w) + 63) & ~(size_t)63;
             if (pbytes >= (1ull << 32)) { cl[i] = 252; continue; }      // traceback of one problem beyond 4 GiB (e.g. 50 kb x 50 kb unbanded)
             pb[i] = (uint32_t)pbytes;
-            int rcls = ksw_reg_class(t, pr, latency_rows);
-            if (rcls == 0 && promote_rows >= 0) {
-                // The <1,2> launch follows the <1,4> launch on the main stream and each lasts as long as its longest problem: the few LONG
-                // problems of the narrow class (a read's overhang against the last bases of a consensus: a thousand anti-diagonals and
-                // more, where a gap fill of this width has at most 511) go with the <1,4> launch, which handles any narrower problem,
-                // so that what follows it is short.  NSGPU_KSW_PROMOTE_ROWS: the threshold (default 520; 0 = all of them -- a test
-                // switch; negative = off).
-                const long long w = t.w < 0 ? (long long)t.qlen + t.tlen : t.w;
-                const long long full = (long long)t.qlen + t.tlen - 1, band = 2ll * t.tlen + w + 1;
-                if ((full < band ? full : band) > promote_rows) rcls = 1;
-            }
+            // (the <1,2> launch follows the <1,4> launch on the main stream and each lasts as long as its longest problem: the few LONG
+            // problems of the narrow class -- a read's overhang against the last bases of a consensus: a thousand anti-diagonals and
+            // more, where a gap fill of this width has at most 511 -- go with the <1,4> launch, which handles any narrower problem:
+            // ksw_launch_class_hd, NSGPU_KSW_PROMOTE_ROWS)
+            const int rcls = ksw_launch_class_hd(t.qlen, t.tlen, t.w, t.flag, pr, kcfg);
             if (rcls >= 0) { cl[i] = (uint8_t)(16 + rcls); continue; }
             const size_t need = ksw_lds_bytes(t.qlen, t.tlen, t.flag);
             const int cls = need <= kClass[0] ? 0 : need <= kClass[1] ? 1 : need <= kClass[2] ? 2 : 3;
@@ -789,12 +783,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         NS_CHECK(cl[i] != 254, NSGPU_ERR_ARG, "ksw: negative length");
         NS_CHECK(cl[i] != 253, NSGPU_ERR_ARG, "ksw: KSW_EZ_GENERIC_SC is not on NanoSpring's path");
         NS_CHECK(cl[i] != 252, NSGPU_ERR_RANGE, "ksw: traceback matrix of one problem exceeds 4 GiB (band the problem or split it)");
-        static const bool serial_bt = getenv("NSGPU_KSW_SERIAL_BACKTRACK") != nullptr;  // A/B switch: one lane walks the traceback (register kernels)
-        static const bool no_early = getenv("NSGPU_KSW_NO_EARLY_EXIT") != nullptr;     // A/B switch for the register kernels' exact early exit
-        static const bool all_books = getenv("NSGPU_KSW_ALL_BOOKS") != nullptr;         // A/B switch: approx mode, several waves: every wave keeps the books
-        if (all_books) t.flag |= 0x40000;                                               // KSW_EZ_NS_ALL_BOOKS (ksw2_reg.hip)
-        if (serial_bt) t.flag |= 0x20000;                                               // KSW_EZ_NS_SERIAL_BACKTRACK (ksw2_reg.hip)
-        if (!no_early) t.flag |= 0x10000;                                                // KSW_EZ_NS_EARLY_EXIT (ksw2_reg.hip)
+        t.flag |= kcfg.flag_or;          // KSW_EZ_NS_* bits (ksw2_reg.hip): early exit unless switched off, the A/B switches
         t.out_idx = (uint32_t)i;
         t.p_off = p_total;
         t.cig_off = (uint32_t)cig_total;
@@ -840,8 +829,11 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     size_t start[5] = {0, 0, 0, 0, 0}, wg_start[3] = {0, 0, 0}, reg_start[KSW_REG_CLASSES] = {};
     // big problems first inside a class (longest-processing-time-first): 64 buckets by the logarithm of the cell count, taken
     // in descending order -- the schedule only needs the rough order, a comparison sort of every batch does not pay
+    static const bool no_lpt = getenv("NSGPU_KSW_NO_LPT") != nullptr;          // experiment: launch order = task order
+    static const int lds_floor = getenv("NSGPU_KSW_LDS_QLEN") ? atoi(getenv("NSGPU_KSW_LDS_QLEN")) : 0;   // experiment: LDS sized for at least this query length
+    if (lds_floor) for (int k = 0; k < KSW_REG_CLASSES; ++k) if (!reg[k].empty()) reg_lds[k] = std::max(reg_lds[k], ksw_reg_lds_bytes(k, lds_floor));
     auto lpt_order = [&](std::vector<uint32_t> &v) {
-        if (v.size() < 2) return;
+        if (v.size() < 2 || no_lpt) return;
         uint32_t cnt[65] = {0};
         std::vector<uint8_t> &bk = W.h_bucket;
         bk.resize(v.size());
@@ -899,6 +891,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         if (k >= 2 && !dbg) { const int si = k == 8 ? 1 : k >= 6 ? k - 5 : k >= 4 ? 0 : k - 1; st = W.side_stream[si]; NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0)); side_used[si] = true; }
         double dbg_t0 = 0;
         if (dbg) { NS_HIP(stream_wait(S)); dbg_t0 = now_ms(); }
+        W.ev_class.resize(n_ev / 2 + 1); W.ev_class[n_ev / 2] = k;
         NS_HIP(hipEventRecord(ev_at(n_ev++), st));
         NS_TRY(ksw_reg_launch(k, st, m, reg_lds[k], W.k_tasks.as<KswTask>(), W.k_order.as<uint32_t>() + reg_start[k], pr, W.k_seqs.as<uint8_t>(), W.k_p.as<uint8_t>(),
                               W.k_cig.as<uint32_t>(), W.k_res.as<KswResult>()));
@@ -1041,7 +1034,11 @@ int ksw_batch_collect(nsgpu_ctx *c, std::vector<KswTask> &tasks, std::vector<Ksw
     float ms = 0;
     NS_HIP(hipEventElapsedTime(&ms, W.t_a, W.t_b));
     double sum_ms = 0, cells = 0, alg = 0;
-    for (size_t i = 0; i + 1 < n_ev; i += 2) { float d = 0; if (hipEventElapsedTime(&d, W.ev[i], W.ev[i + 1]) == hipSuccess) sum_ms += d; }
+    for (size_t i = 0; i + 1 < n_ev; i += 2) {
+        float d = 0;
+        if (hipEventElapsedTime(&d, W.ev[i], W.ev[i + 1]) == hipSuccess) { sum_ms += d; if (i / 2 < W.ev_class.size() && W.ev_class[i / 2] >= 0) { c->ksw_class_ms[W.ev_class[i / 2]] += d; ++c->ksw_class_n[W.ev_class[i / 2]]; } }
+    }
+    W.ev_class.assign(W.ev_class.size(), -1);
     for (auto &t : tasks) cells += (double)t.qlen * t.tlen;
     // algorithmic HBM bytes of a DP problem: both sequences in, CIGAR + result out (the traceback matrix is scratch)
     for (size_t i = 0; i < n; ++i) alg += (double)tasks[i].qlen + tasks[i].tlen + 4.0 * results[i].n_cigar + sizeof(KswResult);
@@ -1050,6 +1047,177 @@ int ksw_batch_collect(nsgpu_ctx *c, std::vector<KswTask> &tasks, std::vector<Ksw
     c->ksw_kernel_sum_ms += sum_ms;
     c->ksw_cells += cells;
     c->ksw_alg_bytes += alg;
+    c->ksw_launches += n_launch;
+    return NSGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// A batch whose tasks are written on the DEVICE by the plan kernel (plan.hip) -- the DP launch of the contig engine's slot without a host
+// round trip between chaining and DP.  The host sizes buffers for n_slots task slots and upper bounds of the scratch, the plan kernel fills
+// task descriptors, sequences and one launch list per register class, every class is launched over its list with the count read from
+// device memory (grid = n_slots: the surplus workgroups leave at once), and the results reach the host as the kernels' own stores into
+// pinned memory.
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr uint32_t kDvCtrlWords = 18;                       // class counters + flags in front of the 64-bit fields
+struct DvCtrl { uint32_t class_cnt[16]; uint32_t cig_overflow, pad; unsigned long long cursors[3]; unsigned long long cells, alg_bytes; };
+static_assert(offsetof(DvCtrl, cursors) == kDvCtrlWords * 4, "layout");
+
+__global__ __launch_bounds__(256) void ksw_dev_collect_kernel(const KswTask *__restrict__ tasks, const KswResult *__restrict__ res, uint32_t n, const uint64_t *__restrict__ off,
+                                                              const uint32_t *__restrict__ pool, KswResult *__restrict__ h_res, uint64_t *__restrict__ h_off,
+                                                              uint32_t *__restrict__ h_cig, uint64_t h_cig_cap, DvCtrl *__restrict__ ctrl)
+{
+    const uint32_t lane = threadIdx.x & 63, gt = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    const uint32_t w = gt >> 6, nw = nt >> 6;
+    const bool fits = off[n] <= h_cig_cap;
+    if (!fits && gt == 0) ctrl->cig_overflow = 1;
+    // the result records and the CIGAR offsets as flat words: whole cache lines travel over PCIe
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(res);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(h_res);
+        const size_t words = (size_t)n * (sizeof(KswResult) / 4);
+        for (size_t i = gt; i < words; i += nt) dst[i] = src[i];
+        for (size_t i = gt; i <= n; i += nt) h_off[i] = off[i];
+    }
+    unsigned long long cells = 0, alg = 0;
+    for (uint32_t i = w; i < n; i += nw) {
+        const uint32_t c = (uint32_t)res[i].n_cigar;
+        const KswTask t = tasks[i];
+        if (c && fits) {
+            const uint32_t *src = pool + t.cig_off;
+            uint32_t *dst = h_cig + off[i];
+            for (uint32_t k = lane; k < c; k += 64) dst[k] = src[k];
+        }
+        // (a slot the plan kernel did not use holds an all-zero task and result)
+        if (lane == 0 && t.qlen > 0 && t.tlen > 0) cells += (unsigned long long)t.qlen * (unsigned long long)t.tlen, alg += (unsigned long long)t.qlen + t.tlen + 4ull * c + sizeof(KswResult);
+    }
+    if (lane == 0 && cells) { atomicAdd(&ctrl->cells, cells); atomicAdd(&ctrl->alg_bytes, alg); }
+}
+
+__global__ void ksw_dev_ctrl_kernel(const DvCtrl *__restrict__ ctrl, DvCtrl *__restrict__ h_ctrl) { if (threadIdx.x == 0) *h_ctrl = *ctrl; }
+}  // namespace
+
+// workgroups of a class's launch over its device-side list: every task slot for the narrow classes (the bulk), a few per alignment for the wide
+// ones -- an empty workgroup of those still claims its tens of KB of LDS on a CU for the microseconds it lives.  What a list cannot take is
+// left to the host by the plan kernel.
+static uint32_t dev_class_grid(int cls, uint32_t n_slots, uint32_t n_pairs)
+{
+    const uint32_t per_pair = cls == 0 || cls == 1 || cls == 4 || cls == 5 ? 0u : cls == 3 || cls == 7 ? 4u : 8u;
+    return per_pair ? std::min<uint32_t>(n_slots, per_pair * n_pairs + 32) : n_slots;
+}
+
+int ksw_dev_prepare(nsgpu_ctx *c, int ws_index, uint32_t n_slots, uint32_t n_pairs, uint64_t seq_bytes_bound, hipStream_t st, PlanDp &dp)
+{
+    NS_CHECK(ws_index >= 0 && ws_index <= 3, NSGPU_ERR_ARG, "ksw_dev_prepare: workspace index must be 0..3");
+    nsgpu_ctx::KswWs &W = c->kws[ws_index];
+    NS_CHECK(!W.dv_pending, NSGPU_ERR_ARG, "ksw_dev_prepare: the workspace's last device batch was not collected");
+    NS_CHECK(seq_bytes_bound < (1ull << 32) - 65536, NSGPU_ERR_RANGE, "device-planned DP batch: sequence pool beyond 4 GiB");
+    W.dv_slots = n_slots, W.dv_pairs = n_pairs;
+    const uint64_t p_cap = std::max<uint64_t>(W.dv_p_hint, 768ull << 20);
+    const uint64_t cig_cap = seq_bytes_bound + 2ull * n_slots + 64;
+    NS_TRY(W.dv_tasks.reserve((size_t)n_slots * sizeof(KswTask) + 64));
+    NS_TRY(W.dv_list.reserve((size_t)KSW_REG_CLASSES * n_slots * 4 + 64));
+    NS_TRY(W.dv_ctrl.reserve(sizeof(DvCtrl)));
+    NS_TRY(W.dv_seqs.reserve(seq_bytes_bound + 64));
+    NS_TRY(W.dv_p.reserve(p_cap + 256));
+    NS_TRY(W.dv_cig.reserve(cig_cap * 4));
+    NS_TRY(W.dv_res.reserve((size_t)n_slots * sizeof(KswResult) + 64));
+    NS_TRY(W.dv_coff.reserve(((size_t)n_slots + 2) * 8));
+    NS_HIP(hipMemsetAsync(W.dv_ctrl.p, 0, sizeof(DvCtrl), st));
+    // (the task slots and their results are cleared by the plan kernel itself: every slot belongs to one alignment's wave)
+    dp.tasks = W.dv_tasks.as<KswTask>(), dp.res = W.dv_res.as<KswResult>(), dp.class_list = W.dv_list.as<uint32_t>();
+    dp.class_cnt = W.dv_ctrl.as<DvCtrl>()->class_cnt, dp.n_slots = n_slots, dp.seqs = W.dv_seqs.as<uint8_t>();
+    dp.cursors = W.dv_ctrl.as<DvCtrl>()->cursors;
+    for (int k = 0; k < KSW_REG_CLASSES; ++k) dp.class_grid[k] = dev_class_grid(k, n_slots, n_pairs);
+    dp.p_cap = p_cap, dp.cig_cap = (uint32_t)std::min<uint64_t>(cig_cap, 0xffffffffull), dp.seq_cap = (uint32_t)seq_bytes_bound;
+    return NSGPU_OK;
+}
+
+int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr, hipEvent_t after)
+{
+    nsgpu_ctx::KswWs &W = c->kws[ws_index];
+    const uint32_t n = W.dv_slots;
+    if (n == 0) return NSGPU_OK;
+    if (ws_index >= 1 && !W.stream) NS_TRY(role_stream_create(&W.stream, "dp"));
+    const hipStream_t S = ws_index == 0 ? c->stream : W.stream;
+    if (!W.dv_a) { NS_HIP(hipEventCreate(&W.dv_a)); NS_HIP(hipEventCreate(&W.dv_b)); }
+    if (!W.side_stream[0]) {
+        for (int i = 0; i < 3; ++i) { NS_TRY(role_stream_create(&W.side_stream[i], "dp_side")); NS_HIP(hipEventCreateWithFlags(&W.side_done[i], hipEventDisableTiming)); }
+        NS_HIP(hipEventCreateWithFlags(&W.side_fork, hipEventDisableTiming));
+    }
+    NS_HIP(hipStreamWaitEvent(S, after, 0));
+    NS_HIP(hipEventRecord(W.dv_a, S));
+    NS_HIP(hipEventRecord(W.side_fork, S));
+    const KswClassCfg &kc = ksw_class_config();
+    // the classes the plan kernel's rule (ksw_launch_class_hd) can name under the current switches
+    uint32_t classes = 1u << 0 | 1u << 1;
+    classes |= kc.books ? 1u << 6 : (kc.four ? 1u << 2 : 1u << 8);          // (the widest classes are not planned on the device: plan.hip)
+    if (kc.latency_rows > 0) classes |= 1u << 4 | 1u << 5;
+    W.dv_classes = classes;
+    bool side_used[3] = {false, false, false};
+    while (W.dv_ev.size() < 2 * KSW_REG_CLASSES) { hipEvent_t e = nullptr; NS_HIP(hipEventCreate(&e)); W.dv_ev.push_back(e); }
+    DvCtrl *ctrl = W.dv_ctrl.as<DvCtrl>();
+    // the multi-wave classes (long problems) first and on the side streams, the one-wave bulk last on the main stream: as ksw_batch_launch
+    for (int k = KSW_REG_CLASSES - 1; k >= 0; --k) {
+        if (!(classes >> k & 1)) continue;
+        hipStream_t st = S;
+        if (k >= 2) { const int si = k == 8 ? 1 : k >= 6 ? k - 5 : k >= 4 ? 0 : k - 1; st = W.side_stream[si]; NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0)); side_used[si] = true; }
+        NS_HIP(hipEventRecord(W.dv_ev[2 * k], st));
+        NS_TRY(ksw_reg_launch(k, st, dev_class_grid(k, n, W.dv_pairs), ksw_reg_lds_bytes(k, max_qlen), W.dv_tasks.as<KswTask>(), W.dv_list.as<uint32_t>() + (size_t)k * n, pr, W.dv_seqs.as<uint8_t>(),
+                              W.dv_p.as<uint8_t>(), W.dv_cig.as<uint32_t>(), W.dv_res.as<KswResult>(), ctrl->class_cnt + k));
+        NS_HIP(hipEventRecord(W.dv_ev[2 * k + 1], st));
+    }
+    for (int i = 0; i < 3; ++i)
+        if (side_used[i]) { NS_HIP(hipEventRecord(W.side_done[i], W.side_stream[i])); NS_HIP(hipStreamWaitEvent(S, W.side_done[i], 0)); }
+    NS_HIP(hipEventRecord(W.dv_b, S));
+    {
+        auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), NcigarAt{W.dv_res.as<KswResult>(), n});
+        size_t ws_bytes = 0;
+        NS_HIP(rocprim::exclusive_scan(nullptr, ws_bytes, in, W.dv_coff.as<uint64_t>(), (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), S));
+        NS_TRY(W.dv_scan_ws.reserve(ws_bytes + 16));
+        NS_HIP(rocprim::exclusive_scan(W.dv_scan_ws.p, ws_bytes, in, W.dv_coff.as<uint64_t>(), (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), S));
+    }
+    const uint64_t hcap = std::max<uint64_t>(W.dv_hcig_hint, 1u << 20);          // CIGAR entries the pinned landing zone takes
+    NS_TRY(W.hv_cig.reserve(hcap * 4 + 64));
+    NS_TRY(W.hv_res.reserve((size_t)n * sizeof(KswResult) + 64));
+    NS_TRY(W.hv_coff.reserve(((size_t)n + 1) * 8 + 64));
+    NS_TRY(W.hv_ctrl.reserve(sizeof(DvCtrl)));
+    W.dv_hcig_cap = hcap;
+    uint32_t grid = (n + 3) / 4;
+    if (grid > 4096u) grid = 4096u;
+    hipLaunchKernelGGL(ksw_dev_collect_kernel, dim3(grid), dim3(256), 0, S, W.dv_tasks.as<KswTask>(), W.dv_res.as<KswResult>(), n, W.dv_coff.as<uint64_t>(), W.dv_cig.as<uint32_t>(),
+                       W.hv_res.as<KswResult>(), W.hv_coff.as<uint64_t>(), W.hv_cig.as<uint32_t>(), hcap, ctrl);
+    hipLaunchKernelGGL(ksw_dev_ctrl_kernel, dim3(1), dim3(64), 0, S, ctrl, W.hv_ctrl.as<DvCtrl>());
+    NS_HIP(hipGetLastError());
+    W.dv_pending = true;
+    return NSGPU_OK;
+}
+
+int ksw_dev_collect(nsgpu_ctx *c, int ws_index, KswDevResults &out)
+{
+    nsgpu_ctx::KswWs &W = c->kws[ws_index];
+    out = KswDevResults{nullptr, nullptr, nullptr, nullptr, nullptr, false};
+    if (!W.dv_pending) return NSGPU_OK;
+    W.dv_pending = false;
+    NS_HIP(stream_wait(ws_index == 0 ? c->stream : W.stream));
+    const DvCtrl *hc = W.hv_ctrl.as<DvCtrl>();
+    // scratch that did not fit: the plan kernel left those alignments to the host; larger next time
+    if (hc->cursors[0] > std::max<uint64_t>(W.dv_p_hint, 768ull << 20)) W.dv_p_hint = hc->cursors[0] + hc->cursors[0] / 2;
+    const uint64_t used = W.hv_coff.as<uint64_t>()[W.dv_slots];
+    if (used > W.dv_hcig_cap) W.dv_hcig_hint = used + used / 2;
+    out.res = W.hv_res.as<KswResult>(), out.coff = W.hv_coff.as<uint64_t>(), out.cig = W.hv_cig.as<uint32_t>(), out.class_cnt = hc->class_cnt, out.cursors = hc->cursors;
+    out.cig_ok = hc->cig_overflow == 0;
+    float ms = 0;
+    NS_HIP(hipEventElapsedTime(&ms, W.dv_a, W.dv_b));
+    double sum_ms = 0;
+    uint64_t n_launch = 0;
+    for (int k = 0; k < KSW_REG_CLASSES; ++k)
+        if ((W.dv_classes >> k & 1) && hc->class_cnt[k]) { float d = 0; if (hipEventElapsedTime(&d, W.dv_ev[2 * k], W.dv_ev[2 * k + 1]) == hipSuccess) { sum_ms += d; c->ksw_class_ms[k] += d; ++c->ksw_class_n[k]; } ++n_launch; }
+    std::lock_guard<std::mutex> lk(c->stat_m);
+    c->ksw_kernel_ms += ms;
+    c->ksw_kernel_sum_ms += sum_ms;
+    c->ksw_cells += (double)hc->cells;
+    c->ksw_alg_bytes += (double)hc->alg_bytes;
     c->ksw_launches += n_launch;
     return NSGPU_OK;
 }

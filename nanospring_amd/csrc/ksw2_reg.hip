@@ -25,6 +25,7 @@
 // scratch in HBM; wave 0 walks it at the end (backtrack_and_store_wave).
 #include "common.hpp"
 #include "ksw2.hpp"
+#include "ksw_class.hpp"
 #include <mutex>
 #include "host_util.hpp"
 
@@ -733,11 +734,15 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
 template <int NW, int NCH>
 __global__ __launch_bounds__(NW * 64) void ksw_extd2_reg_kernel(const KswTask *__restrict__ tasks, const uint32_t *__restrict__ order, uint32_t n, KswParams pr,
                                                                 const uint8_t *__restrict__ seqs, uint8_t *__restrict__ p_pool, uint32_t *__restrict__ cig_pool,
-                                                                KswResult *__restrict__ res)
+                                                                KswResult *__restrict__ res, const uint32_t *__restrict__ n_dev)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    // n_dev: the number of problems is in device memory (a list written by the plan kernel, plan.hip; the grid is an upper bound)
+    if (n_dev) n = *n_dev;
     if (blockIdx.x >= n) return;
-    const KswTask tk = tasks[order[blockIdx.x]];
+    const uint32_t ti = order[blockIdx.x];
+    if (ti == ~0u) return;                       // an entry the plan kernel reserved and gave back
+    const KswTask tk = tasks[ti];
     const bool approx = (tk.flag & KSW_EZ_APPROX_MAX) != 0, right = (tk.flag & KSW_EZ_RIGHT) != 0;      // uniform per workgroup
     if (approx) {
         // gap fills whose band never binds and that cannot Z-drop take the path-independent score (see ksw_reg_run)
@@ -777,47 +782,44 @@ size_t ksw_reg_lds_bytes(int cls, int qlen)
 }
 
 // Which register-resident class serves the problem, or -1: the proofs behind the packed arithmetic (no int8 wrap outside the four
-// adjusted gap terms, 16-bit H keys) hold for minimap2-sized scores and gap costs and for problems that fit a class.
+// adjusted gap terms, 16-bit H keys) hold for minimap2-sized scores and gap costs and for problems that fit a class.  The rule itself is
+// ksw_class.hpp's (shared with the device-side alignment plan); the switches are read here, once:
+//   NSGPU_KSW_NO_REG       debugging aid: first-generation kernels only
+//   NSGPU_KSW_BOOKS_WAVE   <5,3> / <9,5> (a books wave) instead of the even wave counts.  Measured (cfg2, default schedule, interleaved A/B):
+//                          does NOT pay -- wait for the DP 4.64 instead of 4.50 s per step: the bookkeeping of row r - 1 already runs behind
+//                          the barrier of row r while the other waves compute, it was not on the critical path
+//   NSGPU_KSW_FOUR_WAVES   <4,3> instead of <6,2> for targets of 513 .. 1536 (tools/bench_ksw_rows.py: <6,2> 1.22 / 1.34 / 1.41 instead of
+//                          1.41 / 1.47 / 1.50 us per anti-diagonal on gap fills of 600 / 930 / 1500)
+//   NSGPU_KSW_LATENCY_ROWS one-block-per-wave twins of the one-wave classes for exact-mode problems with that many anti-diagonals (off)
+//   NSGPU_KSW_PROMOTE_ROWS the long problems of the narrowest class go with the <1,4> launch (ksw2.hip; default 520)
+// (all bit-exact either way)
+const KswClassCfg &ksw_class_config()
+{
+    static const KswClassCfg cfg = [] {
+        KswClassCfg k;
+        k.off = getenv("NSGPU_KSW_NO_REG") != nullptr;
+        k.books = getenv("NSGPU_KSW_BOOKS_WAVE") != nullptr;
+        k.four = getenv("NSGPU_KSW_FOUR_WAVES") != nullptr;
+        k.latency_rows = getenv("NSGPU_KSW_LATENCY_ROWS") ? atoi(getenv("NSGPU_KSW_LATENCY_ROWS")) : 0;
+        k.promote_rows = getenv("NSGPU_KSW_PROMOTE_ROWS") ? atoi(getenv("NSGPU_KSW_PROMOTE_ROWS")) : 520;
+        k.flag_or = 0;
+        if (getenv("NSGPU_KSW_ALL_BOOKS")) k.flag_or |= KSW_EZ_NS_ALL_BOOKS;                  // approx mode, several waves: every wave keeps the books
+        if (getenv("NSGPU_KSW_SERIAL_BACKTRACK")) k.flag_or |= KSW_EZ_NS_SERIAL_BACKTRACK;    // one lane walks the traceback
+        if (!getenv("NSGPU_KSW_NO_EARLY_EXIT")) k.flag_or |= KSW_EZ_NS_EARLY_EXIT;            // the exact early exit of overhang extensions
+        return k;
+    }();
+    return cfg;
+}
+
 int ksw_reg_class(const KswTask &t, const KswParams &pr, int latency_rows)
 {
-    static const bool off = getenv("NSGPU_KSW_NO_REG") != nullptr;       // debugging aid: first-generation kernels only
-    if (off || t.qlen <= 0 || t.tlen <= 0) return -1;
-    int q = pr.q, e = pr.e, q2 = pr.q2, e2 = pr.e2;
-    if (q2 + e2 < q + e) { std::swap(q, q2); std::swap(e, e2); }
-    const int sc_n = pr.sc_ambi == 0 ? -e2 : pr.sc_ambi;
-    if (pr.sc_mch < 0 || pr.sc_mch > 4 || pr.sc_mis > 0 || pr.sc_mis < -8 || sc_n > 0 || sc_n < -8) return -1;
-    if (q < 0 || e < 1 || q + e > 12 || q2 + e2 > 32 || e2 < 1 || q2 < 0) return -1;
-    int w = t.w;
-    if (w < 0 || w > t.qlen + t.tlen) w = t.qlen + t.tlen;
-    const int mn = t.qlen < t.tlen ? t.qlen : t.tlen;
-    // |H| of any in-band cell stays a 16-bit key: H <= sc_mch * min(qlen, tlen); along a diagonal H drops by at most |sc_mis| per cell, a
-    // cell entering the band starts at most q + e below its neighbour (u >= -(q + e) for sane states), and there are at most w + 1 diagonals
-    if ((long long)(-pr.sc_mis > pr.sc_mch ? -pr.sc_mis : pr.sc_mch) * mn + (long long)(q + e) * (w + 1) + 64 >= 32768) return -1;
-    for (int c = 0; c < 4; ++c)
-        if (t.tlen <= ksw_reg_cells(c)) {
-            // Measured (cfg2, default schedule, interleaved A/B): a books wave does NOT pay -- wait for the DP 4.64 instead of 4.50 s per step,
-            // mean launch 1.67 instead of 1.62 ms: the bookkeeping of row r - 1 already runs behind the barrier of row r while the other
-            // waves compute, it was not on the critical path.  Off unless NSGPU_KSW_BOOKS_WAVE=1 (bit-exact either way).
-            static const bool books = getenv("NSGPU_KSW_BOOKS_WAVE") != nullptr;
-            // <6,2> instead of <4,3> for targets of 513 .. 1536: the band of such a problem is six blocks of 128 cells wide, one per wave and row
-            // instead of 2 / 2 / 1 / 1 -- a row lasts as long as its busiest wave.  tools/bench_ksw_rows.py: 1.22 / 1.34 / 1.41 instead of
-            // 1.41 / 1.47 / 1.50 us per anti-diagonal (gap fills of 600 / 930 / 1500), 1.40 / 1.55 / 1.59 instead of 1.65 / 1.67 / 1.75
-            // (extensions); <8,2> had been measured at -3 %.  NSGPU_KSW_FOUR_WAVES=1: <4,3>, as before (A/B switch; bit-exact either way).
-            static const bool four = getenv("NSGPU_KSW_FOUR_WAVES") != nullptr;
-            if (c >= 2 && books) return 4 + c;                                              // <5,3> / <9,5>
-            if (c == 2 && !four) return 8;
-            if (c < 2 && latency_rows > 0 && !(t.flag & KSW_EZ_APPROX_MAX)) {
-                // anti-diagonals the sweep can take: all of them, or until the band runs out
-                const long long full = (long long)t.qlen + t.tlen - 1, band = 2ll * (t.tlen - 1) + w + 1;
-                if ((full < band ? full : band) >= latency_rows) return 4 + c;
-            }
-            return c;
-        }
-    return -1;
+    KswClassCfg cfg = ksw_class_config();
+    cfg.latency_rows = latency_rows;
+    return ksw_reg_class_hd(t.qlen, t.tlen, t.w, t.flag, pr, cfg);
 }
 
 int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const KswTask *tasks, const uint32_t *order, const KswParams &pr, const uint8_t *seqs,
-                   uint8_t *p_pool, uint32_t *cig_pool, KswResult *res)
+                   uint8_t *p_pool, uint32_t *cig_pool, KswResult *res, const uint32_t *n_dev)
 {
 #define NS_REG_LAUNCH(NW_, NCH_)                                                                                                              \
     {                                                                                                                                         \
@@ -830,7 +832,8 @@ int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const 
                 cap = lds_bytes;                                                                                                              \
             }                                                                                                                                 \
         }                                                                                                                                     \
-        hipLaunchKernelGGL((ksw_extd2_reg_kernel<NW_, NCH_>), dim3(m), dim3(NW_ * 64), lds_bytes, st, tasks, order, m, pr, seqs, p_pool, cig_pool, res); \
+        static const uint32_t pad = getenv("NSGPU_KSW_PAD_GRID") ? (uint32_t)atoi(getenv("NSGPU_KSW_PAD_GRID")) : 0u;   /* experiment: surplus workgroups */ \
+        hipLaunchKernelGGL((ksw_extd2_reg_kernel<NW_, NCH_>), dim3(m > pad ? m : pad), dim3(NW_ * 64), lds_bytes, st, tasks, order, m, pr, seqs, p_pool, cig_pool, res, n_dev); \
     }
     switch (cls) {
     case 0: NS_REG_LAUNCH(1, 2) break;

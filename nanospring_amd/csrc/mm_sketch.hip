@@ -494,9 +494,9 @@ double g_sketch_ms[6];
 
 // The fused path (skf_kernel).  Returns 1 when the batch has to be redone by the general passes (a byte other than ACGT, a k-mer equal
 // to its reverse complement, or more minimizers than the staging buffer was sized for), 0 when done, < 0 on errors.
-static int gpu_mm_sketch_fused(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws)
+static int gpu_mm_sketch_fused(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws, size_t n_stage_only)
 {
-    const size_t n = reqs.size();
+    const size_t n = reqs.size(), n_sk = n - n_stage_only;      // the last n_stage_only requests are staged in HBM (sketch_dev_seq) and not sketched
     const double t0 = now_ms();
     nsgpu_ctx::SketchWs &W = c->sws[ws];
     if (!W.stream) NS_TRY(role_stream_create(&W.stream, "sketch"));
@@ -505,7 +505,7 @@ static int gpu_mm_sketch_fused(nsgpu_ctx *c, const std::vector<SketchReq> &reqs,
     for (size_t i = 0; i < n; ++i) {
         NS_CHECK(reqs[i].len < (1ull << 31), NSGPU_ERR_RANGE, "sequence %zu longer than 2^31", i);
         bytes += (reqs[i].len + 16) & ~(uint64_t)15;
-        n_tiles += (reqs[i].len + kTile - 1) / kTile;
+        if (i < n_sk) n_tiles += (reqs[i].len + kTile - 1) / kTile;
     }
     NS_CHECK(bytes < (1ull << 31), NSGPU_ERR_RANGE, "sketch batch exceeds 2 GiB of sequence; use smaller batches");
     // ONE pinned staging area: [sequences | soff | len | tiles], one H2D copy
@@ -518,7 +518,7 @@ static int gpu_mm_sketch_fused(nsgpu_ctx *c, const std::vector<SketchReq> &reqs,
         uint64_t b = 0, t = 0;
         for (size_t i = 0; i < n; ++i) {
             soff[i] = (uint32_t)b, len[i] = (uint32_t)reqs[i].len, first_tile[i] = (uint32_t)t;
-            for (uint64_t p = 0; p < reqs[i].len; p += kTile) tiles[t++] = Tile{(uint32_t)i, (uint32_t)p};
+            if (i < n_sk) for (uint64_t p = 0; p < reqs[i].len; p += kTile) tiles[t++] = Tile{(uint32_t)i, (uint32_t)p};
             b += (reqs[i].len + 16) & ~(uint64_t)15;
         }
         soff[n] = (uint32_t)b, first_tile[n] = (uint32_t)t;
@@ -567,23 +567,34 @@ static int gpu_mm_sketch_fused(nsgpu_ctx *c, const std::vector<SketchReq> &reqs,
     }
     for (size_t i = 0; i <= n; ++i) out_off[i] = h_toff[first_tile[i]];
     out = reinterpret_cast<const mm2::Anchor *>(W.h_out);
+    W.staged_soff = soff, W.staged_n = n;              // (pinned: valid until the workspace's next call, like the device copy of the sequences)
     std::lock_guard<std::mutex> lk(c->stat_m);
     c->sketch_mm_ms += now_ms() - t0;
     g_sketch_ms[0] += t_staged - t0, g_sketch_ms[3] += now_ms() - t_staged, g_sketch_ms[4] += (double)bytes, g_sketch_ms[5] += (double)out_off[n];
     return 0;
 }
 
-static int gpu_mm_sketch_one(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws);
+static int gpu_mm_sketch_one(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws, size_t n_stage_only);
+
+// request i of the workspace's last batch as it lies in HBM (the bytes the caller passed), or nullptr when that batch did not go through the
+// fused path's staging buffer; valid until the workspace's next call
+const uint8_t *sketch_dev_seq(const nsgpu_ctx *c, int ws, size_t i)
+{
+    const nsgpu_ctx::SketchWs &W = c->sws[ws];
+    return W.staged_soff && i < W.staged_n ? W.seqs.as<uint8_t>() + W.staged_soff[i] : nullptr;
+}
 
 // Any number of sequences: batches beyond the 32-bit position space of the kernels (2 GiB of sequence) are sketched piece by piece and
 // the results concatenated (a contig engine with many builders on multi-megabase contigs can get there; it cannot act on an error).
-int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws)
+int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws, size_t n_stage_only)
 {
+    NS_CHECK(n_stage_only <= reqs.size() && (ws == 0 || ws == 1), NSGPU_ERR_ARG, "gpu_mm_sketch: bad arguments");
+    c->sws[ws].staged_soff = nullptr, c->sws[ws].staged_n = 0;
     // (NSGPU_SKETCH_PIECE_KB: a small piece size lets a test force the split)
     static const uint64_t kPiece = [] { const char *e = getenv("NSGPU_SKETCH_PIECE_KB"); const uint64_t kb = e ? strtoull(e, nullptr, 10) : 0; return kb ? kb << 10 : 1500ull << 20; }();
     uint64_t bytes = 0;
     for (const SketchReq &r : reqs) bytes += (r.len + 16) & ~(uint64_t)15;
-    if (bytes < kPiece) return gpu_mm_sketch_one(c, reqs, w, k, out, out_off, ws);
+    if (bytes < kPiece) return gpu_mm_sketch_one(c, reqs, w, k, out, out_off, ws, n_stage_only);
     // The pieces' results are concatenated in PINNED memory of this context and workspace: the seeding kernel reads the lists where this
     // function leaves them (AlignReq.qry_mz / ref_mz are device-visible pointers), and two contexts must not share a buffer.  The result
     // stays valid until the workspace's next call.
@@ -600,7 +611,7 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
         const size_t first = i;
         while (i < reqs.size() && (part.empty() || b + ((reqs[i].len + 16) & ~(uint64_t)15) < kPiece)) { b += (reqs[i].len + 16) & ~(uint64_t)15; part.push_back(reqs[i++]); }
         const mm2::Anchor *po = nullptr;
-        NS_TRY(gpu_mm_sketch_one(c, part, w, k, po, poff, ws));
+        NS_TRY(gpu_mm_sketch_one(c, part, w, k, po, poff, ws, 0));
         for (size_t j = 0; j < part.size(); ++j) out_off[first + j + 1] = n_all + poff[j + 1];
         const uint64_t n_new = poff[part.size()];
         if ((n_all + n_new + 1) * sizeof(mm2::Anchor) > all.cap) {          // grow, keeping what is there
@@ -617,19 +628,25 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
     return NSGPU_OK;
 }
 
-static int gpu_mm_sketch_one(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws)
+static int gpu_mm_sketch_one(nsgpu_ctx *c, const std::vector<SketchReq> &reqs_in, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws, size_t n_stage_only)
 {
-    const size_t n = reqs.size();
-    out_off.assign(n + 1, 0);
+    out_off.assign(reqs_in.size() + 1, 0);
     out = nullptr;
-    if (n == 0) return NSGPU_OK;
+    if (reqs_in.empty()) return NSGPU_OK;
     static const bool general_only = getenv("NSGPU_SKETCH_GENERAL") != nullptr;      // debugging aid: the general passes for everything
     if (!general_only && k > 0 && k <= 28 && w > 0 && w < 256 && (ws == 0 || ws == 1)) {
-        const int rc = gpu_mm_sketch_fused(c, reqs, w, k, out, out_off, ws);
+        const int rc = gpu_mm_sketch_fused(c, reqs_in, w, k, out, out_off, ws, n_stage_only);
         if (rc <= 0) return rc;
-        out_off.assign(n + 1, 0);
+        out_off.assign(reqs_in.size() + 1, 0);
         out = nullptr;
     }
+    // the general passes sketch the requests proper; the staged-only ones have no minimizers and (here) no device copy the caller may use
+    c->sws[ws].staged_soff = nullptr, c->sws[ws].staged_n = 0;
+    const std::vector<SketchReq> reqs(reqs_in.begin(), reqs_in.end() - (ptrdiff_t)n_stage_only);
+    const size_t n = reqs.size();
+    struct PadOff { std::vector<uint64_t> &o; size_t total; ~PadOff() { const uint64_t last = o.empty() ? 0 : o.back(); o.resize(total + 1, last); } } pad_off{out_off, reqs_in.size()};
+    out_off.assign(n + 1, 0);
+    if (n == 0) return NSGPU_OK;
     NS_CHECK(k > 0 && k <= 28 && w > 0 && w < 256, NSGPU_ERR_ARG, "minimap k must be in 1..28 and w in 1..255 (sketch.c:84)");
     const double t0 = now_ms();
     NS_CHECK(ws == 0 || ws == 1, NSGPU_ERR_ARG, "gpu_mm_sketch: workspace 0 or 1");
@@ -662,6 +679,7 @@ static int gpu_mm_sketch_one(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, i
     NS_TRY(W.V.reserve((size_t)B + 64));
     NS_TRY(W.hk.reserve(((size_t)B + 1) * 8));
     NS_HIP(hipMemcpyAsync(W.seqs.p, W.h_seqs, bytes, hipMemcpyHostToDevice, st));
+    if (n_stage_only == 0) { W.staged_soff_v = soff; W.staged_soff = W.staged_soff_v.data(), W.staged_n = n; }      // (sketch_dev_seq: the requests lie in W.seqs here too)
     NS_HIP(hipMemcpyAsync(W.soff.p, soff.data(), (n + 1) * 4, hipMemcpyHostToDevice, st));
     NS_HIP(hipMemcpyAsync(W.len.p, len.data(), n * 4, hipMemcpyHostToDevice, st));
     const Batch bt{W.seqs.as<uint8_t>(), W.soff.as<uint32_t>(), W.len.as<uint32_t>(), (uint32_t)n, B, w, k};

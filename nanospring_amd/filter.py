@@ -301,7 +301,8 @@ class AlignStats(C.Structure):
     _fields_ = [("pairs", C.c_uint64), ("dp_tasks", C.c_uint64), ("dp_rounds", C.c_uint64), ("dp_cells", C.c_double),
                 ("index_ms", C.c_double), ("host_ms", C.c_double), ("dp_ms", C.c_double), ("dp_kernel_ms", C.c_double),
                 ("dp_kernel_sum_ms", C.c_double), ("dp_alg_bytes", C.c_double), ("dp_launches", C.c_uint64), ("host_threads", C.c_uint32), ("reserved", C.c_uint32),
-                ("seed_pairs_gpu", C.c_uint64), ("seed_pairs_host", C.c_uint64)]
+                ("seed_pairs_gpu", C.c_uint64), ("seed_pairs_host", C.c_uint64),
+                ("plan_pairs_dev", C.c_uint64), ("plan_pairs_host", C.c_uint64), ("plan_hits", C.c_uint64), ("plan_misses", C.c_uint64), ("plan_extra", C.c_uint64)]
 
 
 EDIT_DT = np.dtype([("type", np.uint8), ("base", np.uint8), ("reserved", np.uint16), ("num", np.uint32)])

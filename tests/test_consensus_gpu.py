@@ -399,7 +399,7 @@ def test_repeats_genome_sketch_splice_and_schedules():
         "t.one_builder_equals_oracle(bases, off)\n"
         "w = t.many_builders_equal_lockstep_oracle(bases, off, 12, 1, 3, 2)\n"
         "print('OK', w['count_aligner'])\n" % root)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NSGPU_SKETCH_CHECK="1"), capture_output=True, text=True, timeout=850)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NSGPU_SKETCH_CHECK="1", NSGPU_CONS_CHECK="1"), capture_output=True, text=True, timeout=850)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
