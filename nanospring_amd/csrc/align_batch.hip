@@ -451,6 +451,7 @@ int batch_plan_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int see
     cfg.k = opt.k, cfg.min_cnt = opt.min_cnt, cfg.min_sc = opt.min_chain_score, cfg.bw = opt.bw, cfg.max_gap = opt.max_gap, cfg.min_ksw_len = opt.min_ksw_len;
     cfg.zdrop = opt.zdrop, cfg.end_bonus = opt.end_bonus, cfg.a = opt.a, cfg.q = opt.q, cfg.e = opt.e, cfg.q_max = max_q;
     cfg.kp = kp, cfg.kc = ksw_class_config();
+    if (B.plan_wait_ev) NS_HIP(hipStreamWaitEvent(D.stream, B.plan_wait_ev, 0));
     NS_TRY(plan_launch(D.stream, (uint32_t)n_pairs, D.lds_anchors, D.res, D.anchors, D.f, D.p, pp, B.plan_out.as<PlanOut>(), B.plan_keys.as<PlanKey>(), dp, cfg));
     if (!B.plan_ev) NS_HIP(hipEventCreateWithFlags(&B.plan_ev, hipEventDisableTiming));
     NS_HIP(hipEventRecord(B.plan_ev, D.stream));

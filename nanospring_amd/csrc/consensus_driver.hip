@@ -340,6 +340,7 @@ struct Engine {
     std::vector<uint8_t> cons_changed;              // per builder of the batch: its consensus changed since the batch before
     std::vector<ConsJob> cons_jobs;
     PinBuf pin_cons;                                // cons_update_kernel's job descriptors
+    hipStream_t cons_stream = nullptr; hipEvent_t cons_ev = nullptr;
     std::vector<char> cons_check;                   // NSGPU_CONS_CHECK: a device copy read back
     std::vector<DevBuf> retired;                    // resident lists replaced by larger ones, freed at the next call
     double crit_u_ms = 0, crit_m_ms = 0;              // sum over host phases of the slowest update_graph / main-path recompute (debug print)
@@ -396,6 +397,7 @@ static void engine_free(void *p)
     for (DevBuf &d : E->retired) d.release();
     E->pin_tail.release();
     E->pin_cons.release();
+    if (E->cons_stream) { (void)hipStreamSynchronize(E->cons_stream); (void)hipStreamDestroy(E->cons_stream); (void)hipEventDestroy(E->cons_ev); }
     delete E;
 }
 
@@ -736,30 +738,39 @@ static size_t apply_splice(Builder &b, const mm2::Anchor *sub, size_t n_sub, int
 
 __global__ __launch_bounds__(256) void cons_update_kernel(const ConsJob *__restrict__ jobs)
 {
-    const ConsJob J = jobs[blockIdx.x];
+    const ConsJob J = jobs[blockIdx.y];
     const int tid = (int)threadIdx.x;
     uint8_t *buf = J.buf;
-    if (J.full) {                                           // the whole string was staged
-        for (uint64_t i = tid; i < J.len_new; i += 256) buf[J.beg_new + i] = J.mid[i];
+    if (J.full) {                                           // the whole string was staged: every workgroup of the row takes its share
+        uint8_t *d = buf + J.beg_new;
+        const uint8_t *sm = J.mid;
+        // (dwords where both sides allow it: the staging buffer and the copy's start are 16-byte aligned)
+        if (((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(sm)) & 3) == 0) {
+            const uint64_t nw = J.len_new >> 2;
+            for (uint64_t i = (uint64_t)blockIdx.x * 256 + tid; i < nw; i += (uint64_t)gridDim.x * 256) reinterpret_cast<uint32_t *>(d)[i] = reinterpret_cast<const uint32_t *>(sm)[i];
+            if (blockIdx.x == 0 && tid < (int)(J.len_new & 3)) d[(nw << 2) + tid] = sm[(nw << 2) + tid];
+        } else for (uint64_t i = (uint64_t)blockIdx.x * 256 + tid; i < J.len_new; i += (uint64_t)gridDim.x * 256) d[i] = sm[i];
         return;
     }
+    if (blockIdx.x) return;                                 // an in-place update is one workgroup's job (it orders its own reads and writes)
     const uint64_t M = J.len_new - J.P - J.S;               // new middle
     // the part that moves: prefix (kept suffix in place) or suffix (kept prefix in place)
     const bool move_prefix = J.beg_new != J.beg_old;
     const uint64_t n_mv = move_prefix ? J.P : J.S;
     const uint64_t src = move_prefix ? J.beg_old : J.beg_old + J.len_old - J.S, dst = move_prefix ? J.beg_new : J.beg_new + J.len_new - J.S;
     if (src != dst && n_mv) {
-        constexpr uint64_t kChunk = 256 * 16;
+        constexpr int kPer = 64;                            // bytes per thread and chunk: loads of a chunk all in flight, then a barrier, then its stores
+        constexpr uint64_t kChunk = 256 * kPer;
         const uint64_t n_ch = (n_mv + kChunk - 1) / kChunk;
         for (uint64_t k = 0; k < n_ch; ++k) {
             const uint64_t ch = dst > src ? n_ch - 1 - k : k;          // moving right: from the far end
-            uint8_t v[16];
-            const uint64_t o = ch * kChunk + (uint64_t)tid * 16;
+            uint8_t v[kPer];
+            // byte j of thread t: offset ch * kChunk + j * 256 + t (consecutive threads, consecutive bytes)
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = o + u < n_mv ? buf[src + o + u] : (uint8_t)0;
+            for (int u = 0; u < kPer; ++u) { const uint64_t o = ch * kChunk + (uint64_t)u * 256 + tid; v[u] = o < n_mv ? buf[src + o] : (uint8_t)0; }
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 16; ++u) if (o + u < n_mv) buf[dst + o + u] = v[u];
+            for (int u = 0; u < kPer; ++u) { const uint64_t o = ch * kChunk + (uint64_t)u * 256 + tid; if (o < n_mv) buf[dst + o] = v[u]; }
             __syncthreads();
         }
     }
@@ -783,8 +794,7 @@ __global__ void mz_tail_scatter_kernel(const TailCopy *__restrict__ jobs, uint32
 static int engine_cons_update(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std::vector<uint32_t> &who, const std::vector<uint8_t> &changed, const std::vector<uint32_t> &sk_ref, int sws_i)
 {
     Driver &D = E->D;
-    nsgpu_ctx::SeedWs &SW = c->seed_ws[sws_i];
-    if (!SW.stream) NS_TRY(role_stream_create(&SW.stream, "seeds"));
+    (void)sws_i;
     std::vector<ConsJob> &jobs = E->cons_jobs;
     jobs.clear();
     const size_t n = who.size();
@@ -815,7 +825,8 @@ static int engine_cons_update(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std
                     DevBuf bigger;
                     NS_TRY(bigger.reserve(4 * Ln + (512u << 10)));
                     const size_t nb = (bigger.cap - Lo) / 2;
-                    NS_HIP(hipMemcpyAsync(bigger.as<uint8_t>() + nb, b.d_cons.as<uint8_t>() + b.dc_beg, Lo, hipMemcpyDeviceToDevice, SW.stream));
+                    if (!E->cons_stream) { NS_TRY(role_stream_create(&E->cons_stream, "seeds")); NS_HIP(hipEventCreateWithFlags(&E->cons_ev, hipEventDisableTiming)); }
+                    NS_HIP(hipMemcpyAsync(bigger.as<uint8_t>() + nb, b.d_cons.as<uint8_t>() + b.dc_beg, Lo, hipMemcpyDeviceToDevice, E->cons_stream));
                     E->retired.push_back(b.d_cons);
                     b.d_cons = bigger, b.dc_beg = nb;
                     move_prefix = P <= S;
@@ -833,12 +844,16 @@ static int engine_cons_update(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std
     if (!jobs.empty()) {
         NS_TRY(E->pin_cons.reserve(jobs.size() * sizeof(ConsJob)));
         memcpy(E->pin_cons.p, jobs.data(), jobs.size() * sizeof(ConsJob));
-        hipLaunchKernelGGL(cons_update_kernel, dim3((uint32_t)jobs.size()), dim3(256), 0, SW.stream, E->pin_cons.as<ConsJob>());
+        // on a stream of its own beside the seeding and chaining kernels: only the plan kernel behind them reads the copies (it waits for cons_ev)
+        if (!E->cons_stream) { NS_TRY(role_stream_create(&E->cons_stream, "seeds")); NS_HIP(hipEventCreateWithFlags(&E->cons_ev, hipEventDisableTiming)); }
+        hipLaunchKernelGGL(cons_update_kernel, dim3(16, (uint32_t)jobs.size()), dim3(256), 0, E->cons_stream, E->pin_cons.as<ConsJob>());
         NS_HIP(hipGetLastError());
-    }
+        NS_HIP(hipEventRecord(E->cons_ev, E->cons_stream));
+        AB.plan_wait_ev = E->cons_ev;
+    } else AB.plan_wait_ev = nullptr;
     static const bool check = getenv("NSGPU_CONS_CHECK") != nullptr;          // every device copy against the host's string (the contig tests run under it)
     if (check) {
-        NS_HIP(hipStreamSynchronize(SW.stream));
+        if (E->cons_stream) NS_HIP(hipStreamSynchronize(E->cons_stream));
         for (size_t w = 0; w < n; ++w) {
             Builder &b = D.B[who[w]];
             if (!b.dc_valid) continue;

@@ -123,6 +123,7 @@ struct AlignBatch {
     std::vector<uint32_t> plan_base, plan_pair;          // request -> first task slot / seeding pair (~0u: none)
     int plan_ws = -1;                                    // DP workspace the device-planned batch runs on; -1: none in flight
     hipEvent_t plan_ev = nullptr;
+    hipEvent_t plan_wait_ev = nullptr;                   // set by the caller: the plan kernel's inputs (the device copies of the references) are ready behind it
     AlignBatch() = default;
     AlignBatch(const AlignBatch &) = delete;
     AlignBatch &operator=(const AlignBatch &) = delete;

@@ -829,11 +829,10 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     size_t start[5] = {0, 0, 0, 0, 0}, wg_start[3] = {0, 0, 0}, reg_start[KSW_REG_CLASSES] = {};
     // big problems first inside a class (longest-processing-time-first): 64 buckets by the logarithm of the cell count, taken
     // in descending order -- the schedule only needs the rough order, a comparison sort of every batch does not pay
-    static const bool no_lpt = getenv("NSGPU_KSW_NO_LPT") != nullptr;          // experiment: launch order = task order
-    static const int lds_floor = getenv("NSGPU_KSW_LDS_QLEN") ? atoi(getenv("NSGPU_KSW_LDS_QLEN")) : 0;   // experiment: LDS sized for at least this query length
-    if (lds_floor) for (int k = 0; k < KSW_REG_CLASSES; ++k) if (!reg[k].empty()) reg_lds[k] = std::max(reg_lds[k], ksw_reg_lds_bytes(k, lds_floor));
+    // (measured, round 4: neither the order inside a class, nor LDS sized for a 6 kb query, nor thousands of surplus workgroups that leave at
+    // once change a launch's duration -- the problems of a launch are all resident at once)
     auto lpt_order = [&](std::vector<uint32_t> &v) {
-        if (v.size() < 2 || no_lpt) return;
+        if (v.size() < 2) return;
         uint32_t cnt[65] = {0};
         std::vector<uint8_t> &bk = W.h_bucket;
         bk.resize(v.size());
@@ -888,7 +887,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
         const uint32_t m = (uint32_t)reg[k].size();
         if (!m) continue;
         hipStream_t st = S;
-        if (k >= 2 && !dbg) { const int si = k == 8 ? 1 : k >= 6 ? k - 5 : k >= 4 ? 0 : k - 1; st = W.side_stream[si]; NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0)); side_used[si] = true; }
+        if (k >= 2 && !dbg) { const int si = k >= 9 ? k - 9 : k == 8 ? 1 : k >= 6 ? k - 5 : k >= 4 ? 0 : k - 1; st = W.side_stream[si]; NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0)); side_used[si] = true; }
         double dbg_t0 = 0;
         if (dbg) { NS_HIP(stream_wait(S)); dbg_t0 = now_ms(); }
         W.ev_class.resize(n_ev / 2 + 1); W.ev_class[n_ev / 2] = k;
@@ -1102,7 +1101,7 @@ __global__ void ksw_dev_ctrl_kernel(const DvCtrl *__restrict__ ctrl, DvCtrl *__r
 // left to the host by the plan kernel.
 static uint32_t dev_class_grid(int cls, uint32_t n_slots, uint32_t n_pairs)
 {
-    const uint32_t per_pair = cls == 0 || cls == 1 || cls == 4 || cls == 5 ? 0u : cls == 3 || cls == 7 ? 4u : 8u;
+    const uint32_t per_pair = cls == 0 || cls == 1 || cls == 4 || cls == 5 || cls == 9 ? 0u : cls == 3 || cls == 7 ? 4u : 8u;
     return per_pair ? std::min<uint32_t>(n_slots, per_pair * n_pairs + 32) : n_slots;
 }
 
@@ -1153,6 +1152,7 @@ int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr
     uint32_t classes = 1u << 0 | 1u << 1;
     classes |= kc.books ? 1u << 6 : (kc.four ? 1u << 2 : 1u << 8);          // (the widest classes are not planned on the device: plan.hip)
     if (kc.latency_rows > 0) classes |= 1u << 4 | 1u << 5;
+    if (kc.sys) classes = (classes & ~(1u << 1)) | 1u << 9 | 1u << 10 | (kc.sys >= 2 ? 1u << 11 : 0u);
     W.dv_classes = classes;
     bool side_used[3] = {false, false, false};
     while (W.dv_ev.size() < 2 * KSW_REG_CLASSES) { hipEvent_t e = nullptr; NS_HIP(hipEventCreate(&e)); W.dv_ev.push_back(e); }
@@ -1161,7 +1161,7 @@ int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr
     for (int k = KSW_REG_CLASSES - 1; k >= 0; --k) {
         if (!(classes >> k & 1)) continue;
         hipStream_t st = S;
-        if (k >= 2) { const int si = k == 8 ? 1 : k >= 6 ? k - 5 : k >= 4 ? 0 : k - 1; st = W.side_stream[si]; NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0)); side_used[si] = true; }
+        if (k >= 2) { const int si = k >= 9 ? k - 9 : k == 8 ? 1 : k >= 6 ? k - 5 : k >= 4 ? 0 : k - 1; st = W.side_stream[si]; NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0)); side_used[si] = true; }
         NS_HIP(hipEventRecord(W.dv_ev[2 * k], st));
         NS_TRY(ksw_reg_launch(k, st, dev_class_grid(k, n, W.dv_pairs), ksw_reg_lds_bytes(k, max_qlen), W.dv_tasks.as<KswTask>(), W.dv_list.as<uint32_t>() + (size_t)k * n, pr, W.dv_seqs.as<uint8_t>(),
                               W.dv_p.as<uint8_t>(), W.dv_cig.as<uint32_t>(), W.dv_res.as<KswResult>(), ctrl->class_cnt + k));

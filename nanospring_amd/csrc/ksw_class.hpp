@@ -17,6 +17,7 @@ struct KswClassCfg {
     int32_t latency_rows;      // NSGPU_KSW_LATENCY_ROWS (0 = off)
     int32_t promote_rows;      // NSGPU_KSW_PROMOTE_ROWS (default 520; negative = off)
     int32_t flag_or;           // KSW_EZ_NS_* bits the host adds to every task
+    int32_t sys;               // NSGPU_KSW_SYS: the systolic kernel (classes 9 .. 11, ksw2_reg.hip ksw_sys_run) instead of <1,4> / <6,2>
 };
 const KswClassCfg &ksw_class_config();
 
@@ -49,6 +50,9 @@ __host__ __device__ inline int ksw_reg_class_hd(int qlen, int tlen, int w_in, in
     if ((long long)(-pr.sc_mis > pr.sc_mch ? -pr.sc_mis : pr.sc_mch) * mn + (long long)(q + e) * (w + 1) + 64 >= 32768) return -1;
     for (int c = 0; c < 4; ++c)
         if (tlen <= ksw_reg_width(c)) {
+            // four waves on 128 / 256 contiguous cells each, no barrier (384 cells per wave -- class 11 -- lose to <6,2>: tools/bench_ksw_rows.py)
+            if (cfg.sys && (c == 1 || (c == 2 && tlen <= 1024))) return c == 1 ? 9 : 10;
+            if (cfg.sys >= 2 && c == 2) return 11;
             if (c >= 2 && cfg.books) return 4 + c;                                              // <5,3> / <9,5>
             if (c == 2 && !cfg.four) return 8;                                                  // <6,2>
             if (c < 2 && cfg.latency_rows > 0 && !(flag & 0x08 /* KSW_EZ_APPROX_MAX */)) {
@@ -68,7 +72,7 @@ __host__ __device__ inline int ksw_launch_class_hd(int qlen, int tlen, int w_in,
     if (rcls == 0 && cfg.promote_rows >= 0) {
         const long long w = w_in < 0 ? (long long)qlen + tlen : w_in;
         const long long full = (long long)qlen + tlen - 1, band = 2ll * tlen + w + 1;
-        if ((full < band ? full : band) > cfg.promote_rows) rcls = 1;
+        if ((full < band ? full : band) > cfg.promote_rows) rcls = cfg.sys ? 9 : 1;
     }
     return rcls;
 }
