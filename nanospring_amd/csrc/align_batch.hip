@@ -451,55 +451,70 @@ int batch_plan_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int see
     cfg.k = opt.k, cfg.min_cnt = opt.min_cnt, cfg.min_sc = opt.min_chain_score, cfg.bw = opt.bw, cfg.max_gap = opt.max_gap, cfg.min_ksw_len = opt.min_ksw_len;
     cfg.zdrop = opt.zdrop, cfg.end_bonus = opt.end_bonus, cfg.a = opt.a, cfg.q = opt.q, cfg.e = opt.e, cfg.q_max = max_q;
     cfg.kp = kp, cfg.kc = ksw_class_config();
+    const bool two_part = B.plan_two_part && cfg.kc.long_rows > 0;
+    cfg.two_phase = two_part;
     if (B.plan_wait_ev) NS_HIP(hipStreamWaitEvent(D.stream, B.plan_wait_ev, 0));
     NS_TRY(plan_launch(D.stream, (uint32_t)n_pairs, D.lds_anchors, D.res, D.anchors, D.f, D.p, pp, B.plan_out.as<PlanOut>(), B.plan_keys.as<PlanKey>(), dp, cfg));
     if (!B.plan_ev) NS_HIP(hipEventCreateWithFlags(&B.plan_ev, hipEventDisableTiming));
     NS_HIP(hipEventRecord(B.plan_ev, D.stream));
-    NS_TRY(ksw_dev_launch(c, dp_ws, max_q, kp, B.plan_ev));
+    NS_TRY(ksw_dev_launch(c, dp_ws, max_q, kp, B.plan_ev, pp, B.plan_out.as<PlanOut>(), (uint32_t)n_pairs, two_part));
     B.plan_ws = dp_ws;
+    B.plan_delivered.assign(n, 0);
     return NSGPU_OK;
 }
 
-// the device-planned results into the jobs' caches (every task of every alignment the kernel planned: the jobs look them up by key)
-int batch_plan_deliver(nsgpu_ctx *c, AlignBatch &B)
+// the device-planned results into the jobs' caches (every task of every alignment the kernel planned: the jobs look them up by key); part 0:
+// what a two-part batch has ready early, part 1: everything that has not been delivered yet
+int batch_plan_deliver(nsgpu_ctx *c, AlignBatch &B, int part)
 {
     using namespace mm2;
     if (B.plan_ws < 0) return NSGPU_OK;
     const int ws = B.plan_ws;
-    B.plan_ws = -1;
+    if (part == 1) B.plan_ws = -1;
     KswDevResults R;
-    NS_TRY(ksw_dev_collect(c, ws, R));
+    NS_TRY(ksw_dev_collect(c, ws, part, R));
+    if (!R.res) return NSGPU_OK;
     const PlanOut *po = B.plan_out.as<PlanOut>();
     const PlanKey *keys = B.plan_keys.as<PlanKey>();
-    uint64_t n_dev = 0, n_host = 0, n_tasks = 0;
-    for (size_t i = 0; i < B.plan_pair.size(); ++i) {
-        if (B.plan_pair[i] == ~0u) { ++n_host; continue; }
-        const PlanOut o = po[B.plan_pair[i]];
-        if (o.flags) ++n_host; else ++n_dev, n_tasks += o.n_tasks;
-        for (int bit = 0; bit < 8; ++bit) if (o.flags >> bit & 1) __atomic_fetch_add(&c->plan_why[bit], 1, __ATOMIC_RELAXED);
-    }
-    n_host += B.reqs.size() - B.plan_pair.size();
-    if (R.res && R.cig_ok)
-        parallel_for("align.dp_deliver", B.plan_pair.size(), [&](size_t i) {
-            if (B.plan_pair[i] == ~0u) return;
+    std::atomic<uint64_t> n_tasks{0}, n_lost{0};
+    parallel_for("align.dp_deliver", B.plan_pair.size(), [&](size_t i) {
+        if (B.plan_pair[i] == ~0u || B.plan_delivered[i]) return;
+        const uint32_t q = B.plan_pair[i];
+        const PlanOut o = po[q];
+        if (o.flags || o.n_tasks == 0) return;
+        if (part == 0 && o.slow) return;
+        const uint32_t st = __atomic_load_n(&R.status[q], __ATOMIC_ACQUIRE);
+        if (st != 1u) { if (part == 1) n_lost += 1; return; }        // (2: the CIGAR arena overflowed: the job asks for its problems again)
+        B.plan_delivered[i] = 1;
+        AlignJob &J = B.jobs[i];
+        if (J.finished) return;
+        for (uint32_t t = 0; t < o.n_tasks; ++t) {
+            const uint32_t slot = B.plan_base[i] + t;
+            const KswResult &r = R.res[slot];
+            DpResult d;
+            d.max = r.max; d.zdropped = r.zdropped; d.max_q = r.max_q; d.max_t = r.max_t; d.mqe = r.mqe; d.mqe_t = r.mqe_t; d.mte = r.mte;
+            d.mte_q = r.mte_q; d.score = r.score; d.reach_end = r.reach_end;
+            DpKey k;
+            memcpy(&k, &keys[slot], sizeof(DpKey));
+            J.cache.put(k, d, R.cig + R.coff[slot], (uint32_t)r.n_cigar);
+        }
+        n_tasks += o.n_tasks;
+    });
+    if (part == 1) {
+        uint64_t n_dev = 0, n_host = 0;
+        for (size_t i = 0; i < B.plan_pair.size(); ++i) {
+            if (B.plan_pair[i] == ~0u) { ++n_host; continue; }
             const PlanOut o = po[B.plan_pair[i]];
-            if (o.flags) return;
-            AlignJob &J = B.jobs[i];
-            if (J.finished) return;
-            for (uint32_t t = 0; t < o.n_tasks; ++t) {
-                const uint32_t slot = B.plan_base[i] + t;
-                const KswResult &r = R.res[slot];
-                DpResult d;
-                d.max = r.max; d.zdropped = r.zdropped; d.max_q = r.max_q; d.max_t = r.max_t; d.mqe = r.mqe; d.mqe_t = r.mqe_t; d.mte = r.mte;
-                d.mte_q = r.mte_q; d.score = r.score; d.reach_end = r.reach_end;
-                DpKey k;
-                memcpy(&k, &keys[slot], sizeof(DpKey));
-                J.cache.put(k, d, R.cig + R.coff[slot], (uint32_t)r.n_cigar);
-            }
-        });
+            if (o.flags) ++n_host; else ++n_dev;
+            for (int bit = 0; bit < 8; ++bit) if (o.flags >> bit & 1) __atomic_fetch_add(&c->plan_why[bit], 1, __ATOMIC_RELAXED);
+        }
+        n_host += B.reqs.size() - B.plan_pair.size();
+        std::lock_guard<std::mutex> lk(c->stat_m);
+        c->plan_pairs_dev += n_dev, c->plan_pairs_host += n_host;
+    }
     std::lock_guard<std::mutex> lk(c->stat_m);
-    c->plan_pairs_dev += n_dev, c->plan_pairs_host += n_host;
-    c->aln_dp_tasks += n_tasks;
+    c->aln_dp_tasks += n_tasks.load();
+    (void)n_lost;
     return NSGPU_OK;
 }
 
@@ -526,6 +541,7 @@ int batch_prepare_round(nsgpu_ctx *c, AlignBatch &B, bool stepped = false)
     if (B.live.empty()) { B.host_ms += now_ms() - a0; return NSGPU_OK; }
     NS_CHECK(nb < (1ull << 32), NSGPU_ERR_RANGE, "align: DP sequence pool exceeds 4 GiB; use smaller batches");
     B.tasks.resize(nt);
+    B.task_keys.resize(nt);                          // (the jobs' request lists may be rebuilt before the results are delivered: align_finish_early)
     nsgpu_ctx::KswWs &KW = c->kws[B.ws_index];      // the DP sequence pool is staged in pinned memory: one DMA, no pageable bounce
     if (KW.h_pool_cap < nb + 16) {
         if (KW.h_pool) NS_HIP(hipHostFree(KW.h_pool));
@@ -539,6 +555,7 @@ int batch_prepare_round(nsgpu_ctx *c, AlignBatch &B, bool stepped = false)
         AlignJob &J = B.jobs[B.live[li]];
         size_t ti = B.t_off[li], bo = B.b_off[li];
         for (const DpKey &k : J.cache.missing) {
+            B.task_keys[ti] = k;
             KswTask &t = B.tasks[ti++];
             const int ql = k.qe - k.qs, tl = k.re - k.rs;
             t.qoff = (uint32_t)bo; t.toff = (uint32_t)(bo + ql); t.qlen = ql; t.tlen = tl;
@@ -563,8 +580,9 @@ void batch_deliver(AlignBatch &B)
     const double a0 = now_ms();
     parallel_for("align.dp_deliver", B.live.size(), [&](size_t li) {
         AlignJob &J = B.jobs[B.live[li]];
-        size_t ti = B.t_off[li];
-        for (const DpKey &k : J.cache.missing) {
+        const size_t t_end = li + 1 < B.t_off.size() ? B.t_off[li + 1] : B.tasks.size();
+        for (size_t ti = B.t_off[li]; ti < t_end;) {
+            const DpKey &k = B.task_keys[ti];
             const KswResult &r = B.res[ti];
             DpResult d;
             d.max = r.max; d.zdropped = r.zdropped; d.max_q = r.max_q; d.max_t = r.max_t; d.mqe = r.mqe; d.mqe_t = r.mqe_t; d.mte = r.mte;
@@ -784,7 +802,8 @@ int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs)
     // the result objects keep their vectors (the caller swaps them with the builders' previous results): no 64 KB edit list is
     // allocated on one thread and freed on another per alignment
     if (outs.size() < n_pairs) outs.resize(n_pairs);
-    for (size_t i = 0; i < n_pairs; ++i) outs[i].reset();
+    const bool had_early = B.early_done.size() == n_pairs;
+    for (size_t i = 0; i < n_pairs; ++i) if (!(had_early && B.early_done[i])) outs[i].reset();
     if (n_pairs == 0) return NSGPU_OK;
     const KswParams kp = batch_ksw_params(batch_opt(c));
     const double f0 = now_ms();
@@ -796,9 +815,9 @@ int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs)
         B.in_flight = false;
         batch_deliver(B);
     }
-    {   // what the device planned and launched (plan.hip)
+    {   // what the device planned and launched (plan.hip): everything align_finish_early has not delivered yet
         const double a0 = now_ms();
-        NS_TRY(batch_plan_deliver(c, B));
+        NS_TRY(batch_plan_deliver(c, B, 1));
         B.dp_ms += now_ms() - a0;
         g_finish_ms[0] += now_ms() - a0;
     }
@@ -816,7 +835,8 @@ int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs)
     }
     const double b0 = now_ms();
     g_finish_ms[1] += b0 - f1;
-    parallel_for("align.result", n_pairs, [&](size_t i) { align_read_result(B.jobs[i], B.reqs[i].ref, B.reqs[i].ref_len, outs[i]); });
+    parallel_for("align.result", n_pairs, [&](size_t i) { if (!(had_early && B.early_done[i])) align_read_result(B.jobs[i], B.reqs[i].ref, B.reqs[i].ref_len, outs[i]); });
+    B.early_done.clear();
     B.host_ms += now_ms() - b0;
     g_finish_ms[3] += now_ms() - b0;
     (void)f0;
@@ -824,6 +844,34 @@ int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs)
         std::lock_guard<std::mutex> lk(c->stat_m);
         c->aln_host_ms += B.host_ms, c->aln_dp_ms += B.dp_ms, c->aln_dp_tasks += B.dp_tasks, c->aln_rounds += B.rounds, c->aln_pairs += n_pairs;
     }
+    return NSGPU_OK;
+}
+
+int align_finish_early(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs, std::vector<uint8_t> &ready)
+{
+    using namespace mm2;
+    const size_t n_pairs = B.reqs.size();
+    ready.assign(n_pairs, 0);
+    B.early_done.clear();
+    if (n_pairs == 0 || B.plan_ws < 0 || !B.plan_two_part) return NSGPU_OK;
+    if (outs.size() < n_pairs) outs.resize(n_pairs);
+    const double a0 = now_ms();
+    NS_TRY(batch_plan_deliver(c, B, 0));
+    g_finish_ms[0] += now_ms() - a0;
+    B.early_done.assign(n_pairs, 0);
+    // the jobs whose every problem has arrived run their skeleton to the end now (a job that asks for more -- a Z-drop's second pass -- waits for
+    // align_finish's rounds); nothing of a job with a problem in the host-planned batch in flight is touched
+    const double b0 = now_ms();
+    parallel_for("align.early", n_pairs, [&](size_t i) {
+        if (!B.plan_delivered[i]) return;
+        AlignJob &J = B.jobs[i];
+        if (!J.finished) { if (!J.cache.missing.empty()) return; J.step(); }        // (missing: what the plan pass asked for beyond the device's problems)
+        if (!J.finished) return;
+        outs[i].reset();
+        align_read_result(J, B.reqs[i].ref, B.reqs[i].ref_len, outs[i]);
+        B.early_done[i] = 1, ready[i] = 1;
+    });
+    B.host_ms += now_ms() - b0;
     return NSGPU_OK;
 }
 

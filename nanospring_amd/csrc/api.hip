@@ -51,6 +51,23 @@ static hipError_t stream_wait_impl(hipStream_t s, int spin_us, bool spin_only = 
     }
 }
 hipError_t stream_wait(hipStream_t s) { return stream_wait_impl(s, 20); }
+// the same for an event (a point inside a stream's work): poll, sleep between polls
+hipError_t event_wait(hipEvent_t ev)
+{
+    const double limit = wait_timeout_s();
+    static thread_local const int slack_set = prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
+    (void)slack_set;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        const auto dt = std::chrono::steady_clock::now() - t0;
+        if (limit > 0 && dt > std::chrono::duration<double>(limit)) { fprintf(stderr, "nsgpu: a wait for an event exceeded NSGPU_WAIT_TIMEOUT_S = %g s\n", limit); return hipErrorNotReady; }
+        if (dt < std::chrono::microseconds(20)) continue;
+        timespec ts = {0, 20000};
+        nanosleep(&ts, nullptr);
+    }
+}
 // For the waits between the short kernels of one batch step (a few hundred microseconds of GPU work, several times per
 // pipeline slot, on the slot's critical path): the runtime's own busy-wait.  Measured at cfg2: sleeping between polls costs
 // 100-200 us per wait until the thread is back on a core of the CPU-saturated cgroup (window queries 0.53 -> 1.08 s per

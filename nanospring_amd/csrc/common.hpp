@@ -45,6 +45,7 @@ void set_error(const char *fmt, ...);
 // is bound by the host cores it shares with those waits.  So: poll the stream, spin only for the first ~20 us, then sleep
 // between polls.  NSGPU_SPIN_WAIT=1 restores the runtime's own wait.
 hipError_t stream_wait(hipStream_t s);
+hipError_t event_wait(hipEvent_t ev);            // the same for a point inside a stream's work
 // a non-blocking stream for one of the roles "sketch", "seeds" (seeding + chaining kernels), "dp_side" (long DP problems), "dp" (DP workspaces 1-3):
 // priority from NSGPU_PRIO_<ROLE>=lo|mid|hi, else the role's measured default (api.hip)
 int role_stream_create(hipStream_t *st, const char *role);
@@ -161,7 +162,9 @@ struct nsgpu_ctx {
         // workspace may follow in the same slot.  dv_ctrl: [0..15] class counters, [16..17] overflow flags, then 8 u64: cursors (traceback bytes,
         // CIGAR entries, sequence bytes), cells, algorithmic bytes
         nsgpu::DevBuf dv_tasks, dv_list, dv_ctrl, dv_seqs, dv_p, dv_cig, dv_res, dv_coff, dv_scan_ws;
-        nsgpu::PinBuf hv_res, hv_coff, hv_cig, hv_ctrl;
+        nsgpu::PinBuf hv_res, hv_coff, hv_cig, hv_ctrl, hv_status;
+        hipEvent_t dv_part0 = nullptr;                                  // behind the first part of a two-part batch's results
+        uint32_t dv_npairs_launched = 0; bool dv_two_phase = false;
         uint32_t dv_slots = 0, dv_pairs = 0, dv_classes = 0;                         // dv_classes: bit k = class k was launched
         uint64_t dv_p_hint = 0, dv_hcig_hint = 0, dv_hcig_cap = 0;
         bool dv_pending = false;

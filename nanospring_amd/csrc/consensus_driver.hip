@@ -73,6 +73,7 @@ struct Builder {
     std::string query;
     mm2::AlnOut aln;
     bool accepted = false;
+    bool early_updated = false, early_result = false;      // the graph was updated / the result taken over ahead of the slot's end (engine_early_updates)
     // cached index of the current main path
     mm2::RefIndex idx;
     bool idx_valid = false;
@@ -271,34 +272,41 @@ struct Driver {
         if (b.st == Builder::ADVANCE) walk(b, false);
         else if (b.st == Builder::GOT_FILTER) next_candidate(b);
         else if (b.st == Builder::GOT_ALIGN) {
-            cons::ContigGraph &g = *b.g;
             if (b.accepted) {
-                if (g.num_reads() == 0) {                       // src/Consensus.cpp:319-324
-                    const double i0 = now_ms();
-                    const std::string seed = g.main_path;
-                    g.main_path.clear();
-                    g.initialize(seed, g.first_read, 0);
-                    g.calculate_main_path_greedy();
-                    b.chg_lb = 0;
-                    b.dbg_init += now_ms() - i0;
-                }
-                const double u0 = now_ms();
-                g.update_graph(b.query, b.aln.edits, (ssize_t)b.aln.begin_offset, (ssize_t)b.aln.end_offset, b.pend + id_base, (long)b.aln.rel_pos, b.strand == 1);
-                const double u1 = now_ms();
-                g.calculate_main_path_greedy();
-                if (g.path_changed_from < b.chg_lb) b.chg_lb = g.path_changed_from;
-                g.path_changed_from = (size_t)-1;
-                const double u2 = now_ms();
-                b.dbg_u += u1 - u0, b.dbg_m += u2 - u1;
-                b.last_u = u1 - u0, b.last_m = u2 - u1;
-                if (u1 - u0 > b.dbg_max_u) b.dbg_max_u = u1 - u0;
-                if (u2 - u1 > b.dbg_max_m) b.dbg_max_m = u2 - u1;
-                b.idx_valid = false;
+                if (!b.early_updated) apply_alignment(b);
+                b.early_updated = false;
                 b.accepted = false;
             }
             ++b.ci;
             next_candidate(b);
         }
+    }
+    // the accepted read into the contig's graph, the new consensus (src/Consensus.cpp:319-331).  Touches nothing but the builder's own graph:
+    // the engine may run it as soon as the alignment is there and its claim cannot fail (engine_early_updates), ahead of the host phase.
+    void apply_alignment(Builder &b)
+    {
+        cons::ContigGraph &g = *b.g;
+        if (g.num_reads() == 0) {                       // src/Consensus.cpp:319-324
+            const double i0 = now_ms();
+            const std::string seed = g.main_path;
+            g.main_path.clear();
+            g.initialize(seed, g.first_read, 0);
+            g.calculate_main_path_greedy();
+            b.chg_lb = 0;
+            b.dbg_init += now_ms() - i0;
+        }
+        const double u0 = now_ms();
+        g.update_graph(b.query, b.aln.edits, (ssize_t)b.aln.begin_offset, (ssize_t)b.aln.end_offset, b.pend + id_base, (long)b.aln.rel_pos, b.strand == 1);
+        const double u1 = now_ms();
+        g.calculate_main_path_greedy();
+        if (g.path_changed_from < b.chg_lb) b.chg_lb = g.path_changed_from;
+        g.path_changed_from = (size_t)-1;
+        const double u2 = now_ms();
+        b.dbg_u += u1 - u0, b.dbg_m += u2 - u1;
+        b.last_u = u1 - u0, b.last_m = u2 - u1;
+        if (u1 - u0 > b.dbg_max_u) b.dbg_max_u = u1 - u0;
+        if (u2 - u1 > b.dbg_max_m) b.dbg_max_m = u2 - u1;
+        b.idx_valid = false;
     }
 };
 
@@ -338,6 +346,8 @@ struct Engine {
     std::vector<TailCopy> tail_jobs;
     PinBuf pin_tail;                                // the scatter kernel's job descriptors
     std::vector<uint8_t> cons_changed;              // per builder of the batch: its consensus changed since the batch before
+    std::vector<uint8_t> early_ready; std::vector<uint32_t> early_pends, early_todo;      // scratch of engine_early_updates
+    uint64_t n_early = 0; double early_ms = 0;       // graph updates run ahead of the slot's end / wall of that (debug print)
     std::vector<ConsJob> cons_jobs;
     PinBuf pin_cons;                                // cons_update_kernel's job descriptors
     hipStream_t cons_stream = nullptr; hipEvent_t cons_ev = nullptr;
@@ -880,6 +890,8 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
     AlignBatch &AB = E->ab[gi];
     AB.reqs.clear();
     AB.host_ms = 0;
+    static const bool no_early = getenv("NSGPU_NO_EARLY_UPDATES") != nullptr;        // A/B switch: results in one part, graph updates in the host phase, as before
+    AB.plan_two_part = n_groups(c) == 1 && !no_early;
     E->awho[gi].clear();
     if (who.empty()) return NSGPU_OK;
     const double g0 = now_ms();
@@ -1109,6 +1121,54 @@ static int engine_window_queries(nsgpu_ctx *c, int group)
     return NSGPU_OK;
 }
 
+// ONE group: the first part of a two-part batch's DP results is there while the late kernel classes still run (align_finish_early).  The
+// builders whose alignment is final take their result now, and those whose claim cannot fail -- the alignment succeeded, nobody else in the
+// batch aligns the same read, the read is unclaimed (claims and seed grants are only ever written between slots) -- update their graph and
+// consensus at once: the slot's host phase, which used to wait for the slowest DP problem, is left with the stragglers.  Same result: the
+// update touches the builder's own graph only, and the claim it anticipates is the one the slot's end resolves.
+static int engine_early_updates(nsgpu_ctx *c, int group)
+{
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    Driver &D = E->D;
+    const int gi = group < 0 ? 0 : group;
+    std::vector<uint32_t> &who = E->awho[gi];
+    AlignBatch &AB = E->ab[gi];
+    if (who.empty() || !AB.plan_two_part) return NSGPU_OK;
+    const double g0 = now_ms();
+    std::vector<uint8_t> &ready = E->early_ready;
+    NS_TRY(align_finish_early(c, AB, E->outs, ready));
+    const size_t n = who.size();
+    // contested reads: two builders of the batch align the same one (the lower builder's claim decides)
+    std::vector<uint32_t> &pends = E->early_pends;
+    pends.resize(n);
+    for (size_t w = 0; w < n; ++w) pends[w] = D.B[who[w]].pend;
+    std::vector<uint32_t> sorted(pends);
+    std::sort(sorted.begin(), sorted.end());
+    std::vector<uint32_t> &todo = E->early_todo;
+    todo.clear();
+    for (size_t w = 0; w < n; ++w) {
+        if (!ready[w]) continue;
+        Builder &b = D.B[who[w]];
+        std::swap(b.aln, E->outs[w]);
+        b.early_result = true;
+        const auto range = std::equal_range(sorted.begin(), sorted.end(), pends[w]);
+        if (b.aln.ok && range.second - range.first == 1 && !D.in_graph[b.pend] && E->world == 1) todo.push_back(who[w]);
+    }
+    par_for_pinned("host.early", D.B.size(), [&](size_t i) {
+        // (pinned like the host phase: a builder's graph stays with one thread's caches)
+        if (!std::binary_search(todo.begin(), todo.end(), (uint32_t)i)) return;
+        Builder &b = D.B[i];
+        const double t0 = now_ms();
+        D.apply_alignment(b);
+        b.early_updated = true;
+        b.cpu_ms += now_ms() - t0;
+    });
+    E->n_early += todo.size();
+    { std::lock_guard<std::mutex> lk(c->stat_m); c->cons_stats.graph_ms += now_ms() - g0; }
+    E->early_ms += now_ms() - g0;
+    return NSGPU_OK;
+}
+
 static int engine_align_finish(nsgpu_ctx *c, int group)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
@@ -1121,7 +1181,8 @@ static int engine_align_finish(nsgpu_ctx *c, int group)
     NS_TRY(align_finish(c, E->ab[gi], E->outs));
     for (size_t w = 0; w < who.size(); ++w) {
         Builder &b = D.B[who[w]];
-        std::swap(b.aln, E->outs[w]);              // the builder's previous result goes back into the pool of result objects
+        if (!b.early_result) std::swap(b.aln, E->outs[w]);              // the builder's previous result goes back into the pool of result objects
+        b.early_result = false;
         ++b.n_align_calls;
         b.accepted = false;
         b.st = Builder::ALIGNED;
@@ -1248,6 +1309,7 @@ static int engine_slot(nsgpu_ctx *c, uint32_t slot, int part = 0)
             if (rc1 == NSGPU_OK) rc1 = engine_batches_begin(c, begin_group, ws_index);
             if (rc1 != NSGPU_OK) err1 = nsgpu_last_error();
             if (tw.joinable()) tw.join();
+            if (rc1 == NSGPU_OK && rc2 == NSGPU_OK && G == 1) { rc1 = engine_early_updates(c, finish_group); if (rc1 != NSGPU_OK) err1 = nsgpu_last_error(); }
             if (rc1 == NSGPU_OK && rc2 == NSGPU_OK) { rc1 = engine_align_finish(c, finish_group); if (rc1 != NSGPU_OK) err1 = nsgpu_last_error(); }
         };
         if (G == 1) { if (part != 2) engine_advance(c, false, host_group); if (part != 1) chain(); }
@@ -1402,6 +1464,7 @@ static int run_consensus_inner(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_thr
         fprintf(stderr, "\n");
         fprintf(stderr, "[cons] alignments left to the host's plan, by reason (cumulative): no anchors / flagged pair %llu, several chains %llu, seed filtering %llu, outside the staged span %llu, capacity %llu, DP class %llu\n",
                 (unsigned long long)c->plan_why[0], (unsigned long long)c->plan_why[1], (unsigned long long)c->plan_why[2], (unsigned long long)c->plan_why[3], (unsigned long long)c->plan_why[4], (unsigned long long)c->plan_why[5]);
+        fprintf(stderr, "[cons] graph updates run ahead of the slot's end: %llu, %.0f ms wall (first part of the DP results + updates)\n", (unsigned long long)E->n_early, E->early_ms);
         fprintf(stderr, "[cons] device plan (cumulative): %llu alignments planned on the device, %llu left to the host; DP problems found %llu, not found %llu, unasked %llu\n",
                 (unsigned long long)c->plan_pairs_dev, (unsigned long long)c->plan_pairs_host, (unsigned long long)c->plan_hits, (unsigned long long)c->plan_misses, (unsigned long long)c->plan_extra);
         fprintf(stderr, "[cons] index + seeds on the GPU: %llu launches, %llu pairs, wait %.0f ms wall; %llu pairs handed back to the host code\n", (unsigned long long)sn,

@@ -76,7 +76,7 @@ struct ChainList { uint64_t beg, obeg; uint32_t n; float avg; };
 // One entry per alignment of a batch.  ref: the staged span [ref_lo, ref_lo + ref_n) of the reference (consensus) as ASCII in DEVICE memory;
 // qry: the whole query likewise.  The alignment may use the task slots [task_base, task_base + task_cap).
 struct PlanPair { const uint8_t *ref; const uint8_t *qry; uint32_t ref_lo, ref_n, ref_len, qlen, task_base, task_cap; };
-struct PlanOut { uint32_t n_tasks, flags; };
+struct PlanOut { uint32_t n_tasks, flags, slow, pad; };        // slow: one of its problems runs in a class that finishes late (ksw_class_is_slow): its results come with the second part
 // why an alignment was left to the host's plan: no anchors / pair flagged by the kernels before; several chains; long-gap seed filtering;
 // a target window outside the staged span; out of task slots or scratch; a DP problem the register kernels do not serve
 constexpr uint32_t PLAN_NONE = 1, PLAN_COMPLEX = 2, PLAN_BADSEEDS = 4, PLAN_SPAN = 8, PLAN_FULL = 16, PLAN_CLASS = 32;
@@ -88,7 +88,7 @@ struct PlanDp {            // where the plan kernel puts its DP tasks (buffers o
     unsigned long long p_cap; uint32_t cig_cap, seq_cap;
 };
 struct PlanCfg {           // minimap2's options the plan depends on (mm2::Opt) + the DP kernels' parameters and class rule
-    int32_t k, min_cnt, min_sc, bw, max_gap, min_ksw_len, zdrop, end_bonus, a, q, e, q_max;
+    int32_t k, min_cnt, min_sc, bw, max_gap, min_ksw_len, zdrop, end_bonus, a, q, e, q_max, two_phase;
     KswParams kp; KswClassCfg kc;
 };
 int plan_launch(hipStream_t st, uint32_t n_pairs, uint32_t lds_anchors, const SeedResult *seeded, const mm2::Anchor *anchors, const int32_t *f, const int32_t *p,
@@ -97,10 +97,13 @@ int plan_launch(hipStream_t st, uint32_t n_pairs, uint32_t lds_anchors, const Se
 // counters reset) on the workspace's stream; launch: every register class over its device-side list, CIGAR compaction, results / CIGARs into
 // pinned memory -- all behind `after` (an event on the stream that ran the plan kernel); collect: waits, then res / coff / cig point into the
 // pinned results (valid until the workspace's next prepare) and class_cnt[KSW_REG_CLASSES] tells what was launched.
-struct KswDevResults { const KswResult *res; const uint64_t *coff; const uint32_t *cig; const uint32_t *class_cnt; const unsigned long long *cursors; bool cig_ok; };
+// The results come in two parts: the alignments none of whose problems runs in a late class (part 0: behind the bulk of one-wave problems on
+// the main stream), then the rest (part 1: behind everything).  res[slot] / cig + coff[slot] are valid for the task slots of the alignments
+// whose status[pair] == 1 (2: the pinned CIGAR arena overflowed -- those alignments are the host's to redo).
+struct KswDevResults { const KswResult *res; const uint64_t *coff; const uint32_t *cig; const uint32_t *status; };
 int ksw_dev_prepare(nsgpu_ctx *c, int ws_index, uint32_t n_slots, uint32_t n_pairs, uint64_t seq_bytes_bound, hipStream_t st, PlanDp &dp);
-int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr, hipEvent_t after);
-int ksw_dev_collect(nsgpu_ctx *c, int ws_index, KswDevResults &out);
+int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr, hipEvent_t after, const PlanPair *pairs, const PlanOut *outs, uint32_t n_pairs, bool two_phase);
+int ksw_dev_collect(nsgpu_ctx *c, int ws_index, int part, KswDevResults &out);
 
 struct AlignBatch {
     std::vector<AlignReq> reqs;
@@ -111,6 +114,7 @@ struct AlignBatch {
     std::vector<uint32_t> cig;
     std::vector<uint64_t> coff;
     std::vector<size_t> t_off, b_off;
+    std::vector<mm2::DpKey> task_keys;       // key of every task of the host-planned round in flight
     size_t nb = 0;
     int ws_index = 0;
     bool in_flight = false;
@@ -124,6 +128,9 @@ struct AlignBatch {
     int plan_ws = -1;                                    // DP workspace the device-planned batch runs on; -1: none in flight
     hipEvent_t plan_ev = nullptr;
     hipEvent_t plan_wait_ev = nullptr;                   // set by the caller: the plan kernel's inputs (the device copies of the references) are ready behind it
+    bool plan_two_part = false;                          // set by the caller: fetch the device-planned results in two parts (align_finish_early first)
+    std::vector<uint8_t> plan_delivered;                 // per request: its device-planned results are in the job's cache
+    std::vector<uint8_t> early_done;                     // per request: finished by align_finish_early (its AlnOut is final)
     AlignBatch() = default;
     AlignBatch(const AlignBatch &) = delete;
     AlignBatch &operator=(const AlignBatch &) = delete;
@@ -153,6 +160,10 @@ SeedChainDev gpu_seeds_chain_dev(nsgpu_ctx *c, int ws, int chain_ws);
 int gpu_seeds_chain_wait(nsgpu_ctx *c, int ws, int chain_ws, const SeedResult *&res, const mm2::Anchor *&a, const int32_t *&f, const int32_t *&p);
 int align_begin(nsgpu_ctx *c, AlignBatch &B, int ws_index);
 int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs);
+// a two-part batch (B.plan_two_part): waits for the first part of the device-planned DP results -- the alignments none of whose problems runs in a
+// late kernel class -- and finishes those alignments (skeleton execution, alignRead's conversion into outs[i]); ready[i] = 1 for the requests that
+// are final now.  align_finish must follow; it leaves the early ones alone.
+int align_finish_early(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs, std::vector<uint8_t> &ready);
 int filter_strings_device(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq);   // api.hip: results stay in c->f_off / c->f_ids
 
 }  // namespace nsgpu

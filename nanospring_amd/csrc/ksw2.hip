@@ -1059,38 +1059,63 @@ int ksw_batch_collect(nsgpu_ctx *c, std::vector<KswTask> &tasks, std::vector<Ksw
 // ---------------------------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr uint32_t kDvCtrlWords = 18;                       // class counters + flags in front of the 64-bit fields
-struct DvCtrl { uint32_t class_cnt[16]; uint32_t cig_overflow, pad; unsigned long long cursors[3]; unsigned long long cells, alg_bytes; };
+struct DvCtrl { uint32_t class_cnt[16]; uint32_t cig_overflow, pad; unsigned long long cursors[3]; unsigned long long cells, alg_bytes, cig_out; };
 static_assert(offsetof(DvCtrl, cursors) == kDvCtrlWords * 4, "layout");
 
-__global__ __launch_bounds__(256) void ksw_dev_collect_kernel(const KswTask *__restrict__ tasks, const KswResult *__restrict__ res, uint32_t n, const uint64_t *__restrict__ off,
-                                                              const uint32_t *__restrict__ pool, KswResult *__restrict__ h_res, uint64_t *__restrict__ h_off,
-                                                              uint32_t *__restrict__ h_cig, uint64_t h_cig_cap, DvCtrl *__restrict__ ctrl)
+// One workgroup per alignment of the part (0: none of its problems runs in a late class; 1: the others): its results as flat words, its CIGARs
+// compacted into the pinned arena at an offset taken from a device-side cursor, and the word that tells the host they are there.
+__global__ __launch_bounds__(64) void ksw_dev_collect_kernel(const PlanPair *__restrict__ pairs, const PlanOut *__restrict__ outs, uint32_t part, const KswTask *__restrict__ tasks,
+                                                             const KswResult *__restrict__ res, const uint32_t *__restrict__ pool, KswResult *__restrict__ h_res,
+                                                             uint64_t *__restrict__ h_off, uint32_t *__restrict__ h_cig, uint64_t h_cig_cap, uint32_t *__restrict__ h_status,
+                                                             DvCtrl *__restrict__ ctrl)
 {
-    const uint32_t lane = threadIdx.x & 63, gt = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-    const uint32_t w = gt >> 6, nw = nt >> 6;
-    const bool fits = off[n] <= h_cig_cap;
-    if (!fits && gt == 0) ctrl->cig_overflow = 1;
-    // the result records and the CIGAR offsets as flat words: whole cache lines travel over PCIe
-    {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(res);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(h_res);
-        const size_t words = (size_t)n * (sizeof(KswResult) / 4);
-        for (size_t i = gt; i < words; i += nt) dst[i] = src[i];
-        for (size_t i = gt; i <= n; i += nt) h_off[i] = off[i];
-    }
-    unsigned long long cells = 0, alg = 0;
-    for (uint32_t i = w; i < n; i += nw) {
-        const uint32_t c = (uint32_t)res[i].n_cigar;
-        const KswTask t = tasks[i];
-        if (c && fits) {
-            const uint32_t *src = pool + t.cig_off;
-            uint32_t *dst = h_cig + off[i];
-            for (uint32_t k = lane; k < c; k += 64) dst[k] = src[k];
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    const PlanOut o = outs[b];
+    if (o.flags || o.n_tasks == 0 || (o.slow != 0) != (part != 0)) return;
+    const uint32_t s0 = pairs[b].task_base, n = o.n_tasks;          // (n <= 256: plan.hip's kMaxTasks)
+    __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_off[256];
+    // CIGAR entries of the alignment's tasks, their exclusive sums (tasks over lanes, 64 at a time)
+    unsigned long long total = 0, cells = 0, alg = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += 64) {
+        const uint32_t t = t0 + lane;
+        const uint32_t c = t < n ? (uint32_t)res[s0 + t].n_cigar : 0u;
+        uint32_t inc = c;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)inc, d, 64); if ((int)lane >= d) inc += x; }
+        if (t < n) {
+            s_off[t] = (uint32_t)total + inc - c;         // relative to the alignment's base
+            const KswTask tk = tasks[s0 + t];
+            if (tk.qlen > 0 && tk.tlen > 0) cells += (unsigned long long)tk.qlen * (unsigned long long)tk.tlen, alg += (unsigned long long)tk.qlen + tk.tlen + 4ull * c + sizeof(KswResult);
         }
-        // (a slot the plan kernel did not use holds an all-zero task and result)
-        if (lane == 0 && t.qlen > 0 && t.tlen > 0) cells += (unsigned long long)t.qlen * (unsigned long long)t.tlen, alg += (unsigned long long)t.qlen + t.tlen + 4ull * c + sizeof(KswResult);
+        total += (unsigned long long)(uint32_t)__shfl((int)inc, 63, 64);
     }
-    if (lane == 0 && cells) { atomicAdd(&ctrl->cells, cells); atomicAdd(&ctrl->alg_bytes, alg); }
+    for (int d = 32; d > 0; d >>= 1) cells += __shfl_xor((long long)cells, d, 64), alg += __shfl_xor((long long)alg, d, 64);
+    if (lane == 0) {
+        s_base = atomicAdd(&ctrl->cig_out, total);
+        atomicAdd(&ctrl->cells, cells);
+        atomicAdd(&ctrl->alg_bytes, alg);
+    }
+    __syncthreads();
+    const unsigned long long base = s_base;
+    if (base + total > h_cig_cap) {                         // the host redoes this alignment's problems (and sizes the arena for the total next time)
+        if (lane == 0) h_status[b] = 2u;
+        return;
+    }
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(res + s0);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(h_res + s0);
+        for (uint32_t i = lane; i < n * (uint32_t)(sizeof(KswResult) / 4); i += 64) dst[i] = src[i];
+    }
+    for (uint32_t t = 0; t < n; ++t) {
+        const uint32_t c = (uint32_t)res[s0 + t].n_cigar;
+        const unsigned long long at = base + s_off[t];
+        const uint32_t *src = pool + tasks[s0 + t].cig_off;
+        for (uint32_t k = lane; k < c; k += 64) h_cig[at + k] = src[k];
+    }
+    for (uint32_t t = lane; t < n; t += 64) h_off[s0 + t] = base + s_off[t];
+    __threadfence_system();
+    __syncthreads();
+    if (lane == 0) h_status[b] = 1u;
 }
 
 __global__ void ksw_dev_ctrl_kernel(const DvCtrl *__restrict__ ctrl, DvCtrl *__restrict__ h_ctrl) { if (threadIdx.x == 0) *h_ctrl = *ctrl; }
@@ -1132,14 +1157,14 @@ int ksw_dev_prepare(nsgpu_ctx *c, int ws_index, uint32_t n_slots, uint32_t n_pai
     return NSGPU_OK;
 }
 
-int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr, hipEvent_t after)
+int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr, hipEvent_t after, const PlanPair *pairs, const PlanOut *outs, uint32_t n_pairs, bool two_phase)
 {
     nsgpu_ctx::KswWs &W = c->kws[ws_index];
     const uint32_t n = W.dv_slots;
     if (n == 0) return NSGPU_OK;
     if (ws_index >= 1 && !W.stream) NS_TRY(role_stream_create(&W.stream, "dp"));
     const hipStream_t S = ws_index == 0 ? c->stream : W.stream;
-    if (!W.dv_a) { NS_HIP(hipEventCreate(&W.dv_a)); NS_HIP(hipEventCreate(&W.dv_b)); }
+    if (!W.dv_a) { NS_HIP(hipEventCreate(&W.dv_a)); NS_HIP(hipEventCreate(&W.dv_b)); NS_HIP(hipEventCreateWithFlags(&W.dv_part0, hipEventDisableTiming)); }
     if (!W.side_stream[0]) {
         for (int i = 0; i < 3; ++i) { NS_TRY(role_stream_create(&W.side_stream[i], "dp_side")); NS_HIP(hipEventCreateWithFlags(&W.side_done[i], hipEventDisableTiming)); }
         NS_HIP(hipEventCreateWithFlags(&W.side_fork, hipEventDisableTiming));
@@ -1153,60 +1178,76 @@ int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr
     classes |= kc.books ? 1u << 6 : (kc.four ? 1u << 2 : 1u << 8);          // (the widest classes are not planned on the device: plan.hip)
     if (kc.latency_rows > 0) classes |= 1u << 4 | 1u << 5;
     if (kc.sys) classes = (classes & ~(1u << 1)) | 1u << 9 | 1u << 10 | (kc.sys >= 2 ? 1u << 11 : 0u);
+    if (two_phase && kc.long_rows > 0) classes |= 1u << 12;
     W.dv_classes = classes;
     bool side_used[3] = {false, false, false};
     while (W.dv_ev.size() < 2 * KSW_REG_CLASSES) { hipEvent_t e = nullptr; NS_HIP(hipEventCreate(&e)); W.dv_ev.push_back(e); }
     DvCtrl *ctrl = W.dv_ctrl.as<DvCtrl>();
-    // the multi-wave classes (long problems) first and on the side streams, the one-wave bulk last on the main stream: as ksw_batch_launch
-    for (int k = KSW_REG_CLASSES - 1; k >= 0; --k) {
-        if (!(classes >> k & 1)) continue;
-        hipStream_t st = S;
-        if (k >= 2) { const int si = k >= 9 ? k - 9 : k == 8 ? 1 : k >= 6 ? k - 5 : k >= 4 ? 0 : k - 1; st = W.side_stream[si]; NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0)); side_used[si] = true; }
-        NS_HIP(hipEventRecord(W.dv_ev[2 * k], st));
-        NS_TRY(ksw_reg_launch(k, st, dev_class_grid(k, n, W.dv_pairs), ksw_reg_lds_bytes(k, max_qlen), W.dv_tasks.as<KswTask>(), W.dv_list.as<uint32_t>() + (size_t)k * n, pr, W.dv_seqs.as<uint8_t>(),
-                              W.dv_p.as<uint8_t>(), W.dv_cig.as<uint32_t>(), W.dv_res.as<KswResult>(), ctrl->class_cnt + k));
-        NS_HIP(hipEventRecord(W.dv_ev[2 * k + 1], st));
-    }
-    for (int i = 0; i < 3; ++i)
-        if (side_used[i]) { NS_HIP(hipEventRecord(W.side_done[i], W.side_stream[i])); NS_HIP(hipStreamWaitEvent(S, W.side_done[i], 0)); }
-    NS_HIP(hipEventRecord(W.dv_b, S));
-    {
-        auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), NcigarAt{W.dv_res.as<KswResult>(), n});
-        size_t ws_bytes = 0;
-        NS_HIP(rocprim::exclusive_scan(nullptr, ws_bytes, in, W.dv_coff.as<uint64_t>(), (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), S));
-        NS_TRY(W.dv_scan_ws.reserve(ws_bytes + 16));
-        NS_HIP(rocprim::exclusive_scan(W.dv_scan_ws.p, ws_bytes, in, W.dv_coff.as<uint64_t>(), (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), S));
-    }
-    const uint64_t hcap = std::max<uint64_t>(W.dv_hcig_hint, 1u << 20);          // CIGAR entries the pinned landing zone takes
+    // pinned landing zones: results and CIGAR offsets per task slot, the CIGAR arena, one status word per alignment
+    const uint64_t hcap = std::max<uint64_t>(W.dv_hcig_hint, 1u << 20);          // CIGAR entries the arena takes
     NS_TRY(W.hv_cig.reserve(hcap * 4 + 64));
     NS_TRY(W.hv_res.reserve((size_t)n * sizeof(KswResult) + 64));
     NS_TRY(W.hv_coff.reserve(((size_t)n + 1) * 8 + 64));
     NS_TRY(W.hv_ctrl.reserve(sizeof(DvCtrl)));
-    W.dv_hcig_cap = hcap;
-    uint32_t grid = (n + 3) / 4;
-    if (grid > 4096u) grid = 4096u;
-    hipLaunchKernelGGL(ksw_dev_collect_kernel, dim3(grid), dim3(256), 0, S, W.dv_tasks.as<KswTask>(), W.dv_res.as<KswResult>(), n, W.dv_coff.as<uint64_t>(), W.dv_cig.as<uint32_t>(),
-                       W.hv_res.as<KswResult>(), W.hv_coff.as<uint64_t>(), W.hv_cig.as<uint32_t>(), hcap, ctrl);
+    NS_TRY(W.hv_status.reserve((size_t)n_pairs * 4 + 64));
+    memset(W.hv_status.p, 0, (size_t)n_pairs * 4);
+    W.dv_hcig_cap = hcap, W.dv_npairs_launched = n_pairs, W.dv_two_phase = two_phase;
+    auto launch_class = [&](int k, hipStream_t st) -> int {
+        NS_HIP(hipEventRecord(W.dv_ev[2 * k], st));
+        NS_TRY(ksw_reg_launch(k, st, dev_class_grid(k, n, W.dv_pairs), ksw_reg_lds_bytes(k, max_qlen), W.dv_tasks.as<KswTask>(), W.dv_list.as<uint32_t>() + (size_t)k * n, pr, W.dv_seqs.as<uint8_t>(),
+                              W.dv_p.as<uint8_t>(), W.dv_cig.as<uint32_t>(), W.dv_res.as<KswResult>(), ctrl->class_cnt + k));
+        NS_HIP(hipEventRecord(W.dv_ev[2 * k + 1], st));
+        return NSGPU_OK;
+    };
+    auto collect = [&](uint32_t part) {
+        hipLaunchKernelGGL(ksw_dev_collect_kernel, dim3(n_pairs), dim3(64), 0, S, pairs, outs, part, W.dv_tasks.as<KswTask>(), W.dv_res.as<KswResult>(), W.dv_cig.as<uint32_t>(),
+                           W.hv_res.as<KswResult>(), W.hv_coff.as<uint64_t>(), W.hv_cig.as<uint32_t>(), hcap, W.hv_status.as<uint32_t>(), ctrl);
+    };
+    // the late classes -- the multi-wave ones (wide problems) and, in a two-part batch, the long problems of the one-wave classes -- on the side
+    // streams; the bulk on the main stream, and behind it the first part of the results
+    for (int k = KSW_REG_CLASSES - 1; k >= 2; --k) {
+        if (!(classes >> k & 1)) continue;
+        const int si = k == 12 ? 2 : k >= 9 ? k - 9 : k == 8 ? 1 : k >= 6 ? k - 5 : k >= 4 ? 0 : k - 1;
+        hipStream_t st = W.side_stream[si];
+        if (!side_used[si]) NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0));
+        side_used[si] = true;
+        NS_TRY(launch_class(k, st));
+    }
+    for (int k = 1; k >= 0; --k) if (classes >> k & 1) NS_TRY(launch_class(k, S));
+    if (two_phase) {
+        collect(0u);
+        NS_HIP(hipEventRecord(W.dv_part0, S));
+    }
+    for (int i = 0; i < 3; ++i)
+        if (side_used[i]) { NS_HIP(hipEventRecord(W.side_done[i], W.side_stream[i])); NS_HIP(hipStreamWaitEvent(S, W.side_done[i], 0)); }
+    NS_HIP(hipEventRecord(W.dv_b, S));
+    if (!two_phase) collect(0u);
+    collect(1u);
     hipLaunchKernelGGL(ksw_dev_ctrl_kernel, dim3(1), dim3(64), 0, S, ctrl, W.hv_ctrl.as<DvCtrl>());
     NS_HIP(hipGetLastError());
     W.dv_pending = true;
     return NSGPU_OK;
 }
 
-int ksw_dev_collect(nsgpu_ctx *c, int ws_index, KswDevResults &out)
+// part 0: what is behind the bulk of the one-wave problems (a two-part batch only: otherwise nothing is there before part 1); part 1: everything
+int ksw_dev_collect(nsgpu_ctx *c, int ws_index, int part, KswDevResults &out)
 {
     nsgpu_ctx::KswWs &W = c->kws[ws_index];
-    out = KswDevResults{nullptr, nullptr, nullptr, nullptr, nullptr, false};
+    out = KswDevResults{nullptr, nullptr, nullptr, nullptr};
     if (!W.dv_pending) return NSGPU_OK;
+    if (part == 0) {
+        if (!W.dv_two_phase) return NSGPU_OK;
+        NS_HIP(event_wait(W.dv_part0));
+        out.res = W.hv_res.as<KswResult>(), out.coff = W.hv_coff.as<uint64_t>(), out.cig = W.hv_cig.as<uint32_t>(), out.status = W.hv_status.as<uint32_t>();
+        return NSGPU_OK;
+    }
     W.dv_pending = false;
     NS_HIP(stream_wait(ws_index == 0 ? c->stream : W.stream));
     const DvCtrl *hc = W.hv_ctrl.as<DvCtrl>();
     // scratch that did not fit: the plan kernel left those alignments to the host; larger next time
     if (hc->cursors[0] > std::max<uint64_t>(W.dv_p_hint, 768ull << 20)) W.dv_p_hint = hc->cursors[0] + hc->cursors[0] / 2;
-    const uint64_t used = W.hv_coff.as<uint64_t>()[W.dv_slots];
-    if (used > W.dv_hcig_cap) W.dv_hcig_hint = used + used / 2;
-    out.res = W.hv_res.as<KswResult>(), out.coff = W.hv_coff.as<uint64_t>(), out.cig = W.hv_cig.as<uint32_t>(), out.class_cnt = hc->class_cnt, out.cursors = hc->cursors;
-    out.cig_ok = hc->cig_overflow == 0;
+    if (hc->cig_out > W.dv_hcig_cap) W.dv_hcig_hint = hc->cig_out + hc->cig_out / 2;
+    out.res = W.hv_res.as<KswResult>(), out.coff = W.hv_coff.as<uint64_t>(), out.cig = W.hv_cig.as<uint32_t>(), out.status = W.hv_status.as<uint32_t>();
     float ms = 0;
     NS_HIP(hipEventElapsedTime(&ms, W.dv_a, W.dv_b));
     double sum_ms = 0;

@@ -1131,8 +1131,9 @@ struct RegClass { int nw, nch; };
 // a DP launch is waited for by a whole round of the contig stage (few builders, one group) rather than overlapped with other groups' work.
 // Classes 6 and 7 are 2 and 3 with a books wave (an odd wave count: see ksw_reg_run): measured, not faster, off by default.
 // Classes 9 .. 11 are the systolic kernel (ksw_sys_run: four computing waves on contiguous stretches of 128 / 256 / 384 cells and the books wave).
-constexpr RegClass kRegClass[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {4, 3}, {8, 5}, {2, 1}, {4, 1}, {5, 3}, {9, 5}, {6, 2}, {5, 1}, {5, 2}, {5, 3}};
-constexpr int reg_compute_waves(int cls) { return cls >= 9 ? kSysWaves : kRegClass[cls].nw > 1 && (kRegClass[cls].nw & 1) ? kRegClass[cls].nw - 1 : kRegClass[cls].nw; }
+// Class 12 is <1,4> once more: the long problems of the one-wave classes in a launch of their own (device-planned batches, ksw_class.hpp).
+constexpr RegClass kRegClass[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {4, 3}, {8, 5}, {2, 1}, {4, 1}, {5, 3}, {9, 5}, {6, 2}, {5, 1}, {5, 2}, {5, 3}, {1, 4}};
+constexpr int reg_compute_waves(int cls) { return cls >= 9 && cls <= 11 ? kSysWaves : kRegClass[cls].nw > 1 && (kRegClass[cls].nw & 1) ? kRegClass[cls].nw - 1 : kRegClass[cls].nw; }
 
 }  // namespace
 
@@ -1141,7 +1142,7 @@ int ksw_reg_threads(int cls) { return kRegClass[cls].nw * 64; }
 
 size_t ksw_reg_lds_bytes(int cls, int qlen)
 {
-    if (cls >= 9) return 2 * (size_t)reg_qb(ksw_reg_cells(cls), qlen) + sys_ctl_bytes(kRegClass[cls].nch, true) + 16;
+    if (cls >= 9 && cls <= 11) return 2 * (size_t)reg_qb(ksw_reg_cells(cls), qlen) + sys_ctl_bytes(kRegClass[cls].nch, true) + 16;
     const int nw = kRegClass[cls].nw, nb = reg_compute_waves(cls) * kRegClass[cls].nch;
     size_t b = 2 * (size_t)reg_qb(ksw_reg_cells(cls), qlen);
     b += (size_t)2 * nb * 12 + (size_t)3 * (nw + 2) * 4 + 52;      // seams / publication slots (a one-wave class uses two of the slots) / stop flag
@@ -1170,6 +1171,7 @@ const KswClassCfg &ksw_class_config()
         k.four = getenv("NSGPU_KSW_FOUR_WAVES") != nullptr;
         k.latency_rows = getenv("NSGPU_KSW_LATENCY_ROWS") ? atoi(getenv("NSGPU_KSW_LATENCY_ROWS")) : 0;
         k.promote_rows = getenv("NSGPU_KSW_PROMOTE_ROWS") ? atoi(getenv("NSGPU_KSW_PROMOTE_ROWS")) : 520;
+        k.long_rows = getenv("NSGPU_KSW_LONG_ROWS") ? atoi(getenv("NSGPU_KSW_LONG_ROWS")) : 900;
         k.sys = getenv("NSGPU_KSW_SYS") ? atoi(getenv("NSGPU_KSW_SYS")) : 0;       // the systolic kernel (classes 9 .. 11) for targets beyond 256 columns and the long narrow problems
         k.flag_or = 0;
         if (getenv("NSGPU_KSW_ALL_BOOKS")) k.flag_or |= KSW_EZ_NS_ALL_BOOKS;                  // approx mode, several waves: every wave keeps the books
@@ -1229,6 +1231,7 @@ int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const 
     case 9: NS_SYS_LAUNCH(1) break;
     case 10: NS_SYS_LAUNCH(2) break;
     case 11: NS_SYS_LAUNCH(3) break;
+    case 12: NS_REG_LAUNCH(1, 4) break;
 #undef NS_SYS_LAUNCH
     default: NS_CHECK(false, NSGPU_ERR_ARG, "ksw: bad register class");
     }

@@ -18,6 +18,8 @@ struct KswClassCfg {
     int32_t promote_rows;      // NSGPU_KSW_PROMOTE_ROWS (default 520; negative = off)
     int32_t flag_or;           // KSW_EZ_NS_* bits the host adds to every task
     int32_t sys;               // NSGPU_KSW_SYS: the systolic kernel (classes 9 .. 11, ksw2_reg.hip ksw_sys_run) instead of <1,4> / <6,2>
+    int32_t long_rows;         // device-planned batches only: problems of the one-wave classes that can take more anti-diagonals than this run apart
+                               // from the bulk (class 12: the <1,4> kernel on a side stream) -- what is left finishes early (NSGPU_KSW_LONG_ROWS; 0 = off)
 };
 const KswClassCfg &ksw_class_config();
 
@@ -65,16 +67,26 @@ __host__ __device__ inline int ksw_reg_class_hd(int qlen, int tlen, int w_in, in
     return -1;
 }
 
-// the launch rule on top of it (ksw_batch_launch): the few LONG problems of the narrowest class go with the <1,4> launch
-__host__ __device__ inline int ksw_launch_class_hd(int qlen, int tlen, int w_in, int flag, const KswParams &pr, const KswClassCfg &cfg)
+// anti-diagonals the sweep of a problem can take: all of them, or until the band runs out (extensions that run off the target's end stop
+// earlier still: the exact early exit, ksw2_reg.hip)
+__host__ __device__ inline long long ksw_rows_bound(int qlen, int tlen, int w_in)
+{
+    const long long w = w_in < 0 ? (long long)qlen + tlen : w_in;
+    const long long full = (long long)qlen + tlen - 1, band = 2ll * tlen + w + 1;
+    return full < band ? full : band;
+}
+
+// the launch rule on top of it (ksw_batch_launch): the few LONG problems of the narrowest class go with the <1,4> launch.  two_phase (a
+// device-planned batch whose results are fetched in two parts, ksw_dev_launch): the long problems of both one-wave classes form class 12
+__host__ __device__ inline int ksw_launch_class_hd(int qlen, int tlen, int w_in, int flag, const KswParams &pr, const KswClassCfg &cfg, bool two_phase = false)
 {
     int rcls = ksw_reg_class_hd(qlen, tlen, w_in, flag, pr, cfg);
-    if (rcls == 0 && cfg.promote_rows >= 0) {
-        const long long w = w_in < 0 ? (long long)qlen + tlen : w_in;
-        const long long full = (long long)qlen + tlen - 1, band = 2ll * tlen + w + 1;
-        if ((full < band ? full : band) > cfg.promote_rows) rcls = cfg.sys ? 9 : 1;
-    }
+    if (two_phase && cfg.long_rows > 0 && (rcls == 0 || rcls == 1) && ksw_rows_bound(qlen, tlen, w_in) > cfg.long_rows) return 12;
+    if (rcls == 0 && cfg.promote_rows >= 0 && ksw_rows_bound(qlen, tlen, w_in) > cfg.promote_rows) rcls = cfg.sys ? 9 : 1;
     return rcls;
 }
+// a class whose problems a device-planned batch finishes late: everything that does not run on the main stream (ksw_dev_launch) -- the wide
+// problems, the long ones, the variants behind switches
+__host__ __device__ inline bool ksw_class_is_slow(int cls) { return cls >= 2; }
 
 }  // namespace nsgpu

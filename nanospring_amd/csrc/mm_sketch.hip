@@ -625,6 +625,7 @@ int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k
         n_all += n_new;
     }
     out = all.as<mm2::Anchor>();
+    c->sws[ws].staged_soff = nullptr, c->sws[ws].staged_n = 0;      // (the staging buffer holds the last piece only: sketch_dev_seq has nothing to offer)
     return NSGPU_OK;
 }
 

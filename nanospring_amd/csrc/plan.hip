@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kThreads) void align_plan_kernel(const SeedResult *
     for (uint32_t i = tid; i < pp.task_cap * (uint32_t)(sizeof(KswTask) / 4); i += kThreads) reinterpret_cast<uint32_t *>(dp.tasks + pp.task_base)[i] = 0u;
     for (uint32_t i = tid; i < pp.task_cap * (uint32_t)(sizeof(KswResult) / 4); i += kThreads) reinterpret_cast<uint32_t *>(dp.res + pp.task_base)[i] = 0u;
     if (sr.flags || sr.n == 0 || sr.n > lds_anchors || pp.task_cap == 0) {
-        if (tid == 0) out[b] = PlanOut{0u, PLAN_NONE};
+        if (tid == 0) out[b] = PlanOut{0u, PLAN_NONE, 0u, 0u};
         return;
     }
     const int32_t n = (int32_t)sr.n;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kThreads) void align_plan_kernel(const SeedResult *
         L.tq = (uint32_t *)carve(4 * kMaxTasks), L.tp = (uint32_t *)carve(4 * kMaxTasks), L.tc = (uint32_t *)carve(4 * kMaxTasks), L.ts = (uint32_t *)carve(4 * kMaxTasks);
         L.sh = (int32_t *)carve(4 * 48);
     }
-    auto fail = [&](uint32_t why) { if (tid == 0) out[b] = PlanOut{0u, why}; };       // (every thread takes the same exits: the conditions are uniform)
+    auto fail = [&](uint32_t why) { if (tid == 0) out[b] = PlanOut{0u, why, 0u, 0u}; };       // (every thread takes the same exits: the conditions are uniform)
     const mm2::Anchor *a = anchors + sr.base;
     const int32_t *fi = f_in + sr.base, *pi = p_in + sr.base;
     if (tid < 48) L.sh[tid] = 0;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(kThreads) void align_plan_kernel(const SeedResult *
         }
         if (qe < qe0 && re < re0) push(qe, qe0, re, re0, bw, cfg.end_bonus, EZ_EXTZ_ONLY);
         L.sh[3] = flags, L.sh[4] = n_t;
-        L.sh[31] = 0x7fffffff, L.sh[32] = -1, L.sh[33] = 0x7fffffff, L.sh[34] = -1, L.sh[35] = 0, L.sh[36] = 0;
+        L.sh[31] = 0x7fffffff, L.sh[32] = -1, L.sh[33] = 0x7fffffff, L.sh[34] = -1, L.sh[35] = 0, L.sh[36] = 0, L.sh[37] = 0;
     }
     __syncthreads();
     int32_t flags = L.sh[3];
@@ -394,13 +394,14 @@ __global__ __launch_bounds__(kThreads) void align_plan_kernel(const SeedResult *
         if (ql < 0 || tl < 0 || K.qs < 0 || K.qe > (int)pp.qlen) bad |= PLAN_COMPLEX;
         else if (ql > 0 && tl > 0) {
             if (K.rs < (int)pp.ref_lo || K.re > (int)(pp.ref_lo + pp.ref_n)) bad |= PLAN_SPAN;
-            const int c = ksw_launch_class_hd(ql, tl, K.w, K.flag, cfg.kp, cfg.kc);
+            const int c = ksw_launch_class_hd(ql, tl, K.w, K.flag, cfg.kp, cfg.kc, cfg.two_phase != 0);
             const size_t pbytes = (ksw_p_bytes_hd(ql, tl, K.w) + 63) & ~(size_t)63;
             // (the widest classes, targets beyond 1536 columns, are a handful of problems per thousand slots, and an empty workgroup of theirs
             // still claims ~100 KB of LDS on a CU: they are not launched from device lists -- such an alignment is the host's)
             if (c < 0 || c == 3 || c == 7 || ql > cfg.q_max || pbytes >= (1ull << 32)) bad |= PLAN_CLASS;
             else {
                 cls = (uint32_t)c, pb = (uint32_t)pbytes, cg = (uint32_t)(ql + tl + 2);
+                if (ksw_class_is_slow(c)) atomicOr(&L.sh[37], 1);
                 if (K.flag & EZ_RIGHT) { sq = (uint32_t)(ql + tl); atomicAdd(&L.sh[35], ql + tl); }       // its own reversed copies
                 else { atomicMin(&L.sh[31], K.qs); atomicMax(&L.sh[32], K.qe); atomicMin(&L.sh[33], K.rs); atomicMax(&L.sh[34], K.re); }
             }
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(kThreads) void align_plan_kernel(const SeedResult *
             copy_codes(dq, pp.qry + K.qs, ql, true);
             copy_codes(dq + ql, pp.ref + (K.rs - (int)pp.ref_lo), tl, true);
         }
-    if (tid == 0) out[b] = PlanOut{(uint32_t)n_t, 0u};
+    if (tid == 0) out[b] = PlanOut{(uint32_t)n_t, 0u, (uint32_t)L.sh[37], 0u};
 #undef CSPAN
 }
 
