@@ -369,6 +369,14 @@ double now_ms()
 // builder group in flight while it works on another group; align_requests is both parts back to back.
 namespace {
 
+// the aligner never reads the score of a gap fill (mm_align1 adds it into dp_score, which nothing on NanoSpring's path looks at): the DP kernels
+// may skip the books that only produce it (KSW_EZ_NS_NO_SCORE, ksw2_reg.hip).  NSGPU_KSW_KEEP_SCORE=1: computed as before (A/B switch).
+int approx_task_flag(int flag)
+{
+    static const bool keep = getenv("NSGPU_KSW_KEEP_SCORE") != nullptr;
+    return !keep && (flag & 0x08) && !(flag & 0x10) ? 0x80000 : 0;
+}
+
 mm2::Opt batch_opt(const nsgpu_ctx *c)
 {
     mm2::Opt opt;
@@ -451,6 +459,7 @@ int batch_plan_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int see
     cfg.k = opt.k, cfg.min_cnt = opt.min_cnt, cfg.min_sc = opt.min_chain_score, cfg.bw = opt.bw, cfg.max_gap = opt.max_gap, cfg.min_ksw_len = opt.min_ksw_len;
     cfg.zdrop = opt.zdrop, cfg.end_bonus = opt.end_bonus, cfg.a = opt.a, cfg.q = opt.q, cfg.e = opt.e, cfg.q_max = max_q;
     cfg.kp = kp, cfg.kc = ksw_class_config();
+    cfg.approx_flag_or = approx_task_flag(0x08);
     const bool two_part = B.plan_two_part && cfg.kc.long_rows > 0;
     cfg.two_phase = two_part;
     if (B.plan_wait_ev) NS_HIP(hipStreamWaitEvent(D.stream, B.plan_wait_ev, 0));
@@ -559,7 +568,7 @@ int batch_prepare_round(nsgpu_ctx *c, AlignBatch &B, bool stepped = false)
             KswTask &t = B.tasks[ti++];
             const int ql = k.qe - k.qs, tl = k.re - k.rs;
             t.qoff = (uint32_t)bo; t.toff = (uint32_t)(bo + ql); t.qlen = ql; t.tlen = tl;
-            t.w = k.w; t.zdrop = k.zdrop; t.end_bonus = k.end_bonus; t.flag = k.flag;
+            t.w = k.w; t.zdrop = k.zdrop; t.end_bonus = k.end_bonus; t.flag = k.flag | approx_task_flag(k.flag);
             uint8_t *q = pool + bo, *tt = q + ql;
             const uint8_t *qs = J.qseq.data() + k.qs, *ts = J.ref->seq.data() + k.rs;
             if (k.flag & 0x02) {            // left extension: both sequences reversed (align.c:693-696)

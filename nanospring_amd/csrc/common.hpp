@@ -158,6 +158,7 @@ struct nsgpu_ctx {
         hipStream_t stream = nullptr;                                // workspace 0 runs on the context's stream
         hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
         hipEvent_t side_done[3] = {nullptr, nullptr, nullptr}, side_fork = nullptr, t_a = nullptr, t_b = nullptr;
+        hipStream_t bulk_stream = nullptr; hipEvent_t bulk_done = nullptr;   // a two-part device batch: the <1,4> bulk beside the <1,2> bulk
         // a batch whose tasks the plan kernel writes (plan.hip, ksw_dev_*): buffers of its own, so that a host-planned batch of the same
         // workspace may follow in the same slot.  dv_ctrl: [0..15] class counters, [16..17] overflow flags, then 8 u64: cursors (traceback bytes,
         // CIGAR entries, sequence bytes), cells, algorithmic bytes

@@ -1213,6 +1213,18 @@ int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr
         side_used[si] = true;
         NS_TRY(launch_class(k, st));
     }
+    // In a two-part batch the two bulk classes run side by side: what counts is when the LAST of the ordinary problems is done (the first part
+    // of the results), and back to back they take as long as the late classes do.  NSGPU_KSW_BULK_SERIAL=1: one after the other, as in a
+    // one-part batch (where the <1,2> launch behind the <1,4> launch measured better: they share SIMDs otherwise).
+    static const bool bulk_serial = getenv("NSGPU_KSW_BULK_SERIAL") != nullptr;
+    if (two_phase && !bulk_serial && (classes & 3u) == 3u) {
+        if (!W.bulk_stream) { NS_TRY(role_stream_create(&W.bulk_stream, "dp")); NS_HIP(hipEventCreateWithFlags(&W.bulk_done, hipEventDisableTiming)); }
+        NS_HIP(hipStreamWaitEvent(W.bulk_stream, W.side_fork, 0));
+        NS_TRY(launch_class(1, W.bulk_stream));
+        NS_HIP(hipEventRecord(W.bulk_done, W.bulk_stream));
+        NS_TRY(launch_class(0, S));
+        NS_HIP(hipStreamWaitEvent(S, W.bulk_done, 0));
+    } else
     for (int k = 1; k >= 0; --k) if (classes >> k & 1) NS_TRY(launch_class(k, S));
     if (two_phase) {
         collect(0u);

@@ -41,6 +41,12 @@ namespace nsgpu {
 #define KSW_EZ_NS_SERIAL_BACKTRACK 0x20000   // debugging aid / A-B switch (NSGPU_KSW_SERIAL_BACKTRACK=1): one lane walks the traceback
 #define KSW_EZ_NS_ALL_BOOKS 0x40000          // A-B switch (NSGPU_KSW_ALL_BOOKS=1): approx mode, several waves: every wave keeps the books
 #define KSW_EZ_NS_EARLY_EXIT 0x10000      // not minimap2's: set by the host code of this library (ksw2.hip) unless NSGPU_KSW_NO_EARLY_EXIT
+// not minimap2's either: the caller does not read ez.score of this approximate-mode problem (KSW_EZ_APPROX_MAX without KSW_EZ_APPROX_DROP).  The
+// score is all that the per-row books of that mode produce -- the greedy H0 walk (ksw2_extd2_sse.c:367-383) decides nothing: no Z-drop, no
+// maximum, and the backtrack starts at the matrix's corner -- so the kernels skip the books and return score 0.  The aligner's gap fills carry it
+// (align_batch.hip / plan.hip): mm_align1 only ever adds a gap fill's score into dp_score, which NanoSpring never looks at (src/ConsensusGraph.cpp:
+// 219-397 reads rs, re, qs, qe, blen, mlen, n_ambi and the CIGAR); the public nsgpu_ksw_extd2_batch passes callers' flags through untouched.
+#define KSW_EZ_NS_NO_SCORE 0x80000
 
 typedef short s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u2 __attribute__((ext_vector_type(2)));
@@ -436,7 +442,9 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
     // barrier every wave reads slot (r - 1) & 1 -- the state after row r - 2, complete since the barrier before -- for the stop flag and
     // for last_H0_t, from which the cells to publish for the books two rows on are known (it moves by at most one cell per row, the
     // four published cells cover that: uv4).  KSW_EZ_NS_ALL_BOOKS (NSGPU_KSW_ALL_BOOKS=1) keeps the books in every wave, as before.
-    const bool ROT = APPROX && NW > 1 && !BK && !(flag & KSW_EZ_NS_ALL_BOOKS);
+    // KSW_EZ_NS_NO_SCORE: the score is all these books produce (no KSW_EZ_APPROX_DROP): nobody keeps them
+    const bool nob = APPROX && (flag & KSW_EZ_NS_NO_SCORE) && !(flag & KSW_EZ_APPROX_DROP);
+    const bool ROT = APPROX && NW > 1 && !BK && !(flag & KSW_EZ_NS_ALL_BOOKS) && !nob;
     int Lpub = 0, Lpub_prev = 0;                        // last_H0_t the current / the previous row's publication is relative to
     auto books_load = [&](const int *sp) { last_H0_t = sp[0], H0 = sp[2], z.max = sp[3], z.max_t = sp[4], z.max_q = sp[5], ez_score = sp[6]; };
     if (ROT) {
@@ -526,7 +534,7 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
                 if (sp[1]) { ez_zdropped = 1; brk = true; break; }
                 lag_L = Lpub_prev;                     // (the window the owed row r - 1 was published with)
             }
-            if (NW > 1 && lag_r >= 0) { lag_row(); if (brk) break; }       // the owed row comes first: it may have Z-dropped (every wave leaves here: no flag needed)
+            if (NW > 1 && lag_r >= 0 && !nob) { lag_row(); if (brk) break; }       // the owed row comes first: it may have Z-dropped (every wave leaves here: no flag needed)
             ez_zdropped = 1;
             break;
         }
@@ -635,7 +643,7 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
                 if (brk) break;
             }
         } else {
-            if (APPROX) {
+            if (APPROX && !nob) {
                 // The bookkeeping of this row will need v[L'] and u[L' + 1] with L' = last_H0_t after row r - 1, which is L or L + 1 for
                 // the L known now (rows up to r - 2 are booked): publish cells L .. L + 3 -- from whatever the registers hold, updated
                 // this row or stale, which is what the reference's arrays would hold
@@ -682,7 +690,8 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
                 lag_r = r, lag_st0 = st0, lag_en0 = en0, lag_en = en;
                 Lpub_prev = Lpub, Lpub = sL;
             } else
-            if (APPROX || wv == 0) {
+            if (nob) {}
+            else if (APPROX || wv == 0) {
                 // exact mode: only wave 0 keeps the books (the same ~100 instructions in every wave were most of a row's cost); when it
                 // sees the Z-drop it raises the flag and still meets the others at their next barrier, where they read it and leave too
                 if (lag_r >= 0) {
@@ -707,7 +716,8 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
             else if (lag_r >= 0) { lag_L = Lpub_prev; lag_row(); }
         }
     } else
-    if (NW > 1 && lag_r >= 0 && !brk && !ez_zdropped) lag_row();      // the last row's bookkeeping (its publication is behind a barrier already)
+    if (NW > 1 && lag_r >= 0 && !brk && !ez_zdropped && !nob) lag_row();      // the last row's bookkeeping (its publication is behind a barrier already)
+    if (nob && !FAST) ez_score = 0;
     if (FAST) {
         // unbanded approx problems never Z-drop and always reach the last row: score = H(tlen - 1, qlen - 1) = the path sum - (q + e)
         int sum = 0;
@@ -715,7 +725,7 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
         for (int c = 0; c < NCH; ++c) sum += (int)ACC[c].x + (int)ACC[c].y;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        ez_score = sum - K.qe;
+        ez_score = (flag & KSW_EZ_NS_NO_SCORE) ? 0 : sum - K.qe;          // (a banded problem on this path: nobody reads its score)
     }
     __threadfence_block();
     __syncthreads();        // every traceback byte must have landed before one lane walks it
@@ -853,7 +863,7 @@ __device__ void ksw_sys_run(const KswTask &tk, const KswParams &pr, const uint8_
             int st0 = r - c1, en0 = r;
             { const int b = (r - w + 1) >> 1; st0 = st0 > b ? st0 : b; st0 = st0 > 0 ? st0 : 0; }
             { const int b = (r + w) >> 1; en0 = en0 < b ? en0 : b; en0 = en0 < c2 ? en0 : c2; }
-            if (st0 > en0) break;                                            // the band ran out: the same row for every wave
+            if (st0 > en0) { if (FAST && cw == 0 && lane == 0) vctl[7] = 1; break; }      // the band ran out: the same row for every wave (zdropped = 1, ksw2_extd2_sse.c:148)
             const int st = st0 & ~15, en = en0 | 15;
             const int sc_last = st0 + ((en0 - st0) & ~15) + 15;
             const int hi_t = en > sc_last ? en : sc_last;
@@ -1064,8 +1074,8 @@ __device__ void ksw_sys_run(const KswTask &tk, const KswParams &pr, const uint8_
         int ez_max = ctl[16], ez_zd = ctl[17], ez_mq = ctl[18], ez_mt = ctl[19], ez_mqe = ctl[20], ez_mqe_t = ctl[21], ez_mte = ctl[22], ez_mte_q = ctl[23], ez_sc = ctl[24];
         if (FAST) {
             // unbanded approx problems never Z-drop and always reach the last row: score = the path sum - (q + e); the other fields as ksw_reset_extz leaves them
-            ez_max = 0, ez_zd = 0, ez_mq = ez_mt = ez_mqe_t = ez_mte_q = -1, ez_mqe = ez_mte = KSW_NEG_INF;
-            ez_sc = ctl[8] + ctl[9] + ctl[10] + ctl[11] - K.qe;
+            ez_max = 0, ez_zd = ctl[7], ez_mq = ez_mt = ez_mqe_t = ez_mte_q = -1, ez_mqe = ez_mte = KSW_NEG_INF;
+            ez_sc = (flag & KSW_EZ_NS_NO_SCORE) ? 0 : ez_zd ? KSW_NEG_INF : ctl[8] + ctl[9] + ctl[10] + ctl[11] - K.qe;
         }
         if (flag & KSW_EZ_NS_SERIAL_BACKTRACK) {
             if (lane == 0) backtrack_and_store(tk, w, ncol16, p, cig_pool, res_out, ez_max, ez_zd, ez_mq, ez_mt, ez_mqe, ez_mqe_t, ez_mte, ez_mte_q, ez_sc);
@@ -1087,7 +1097,7 @@ __global__ __launch_bounds__((kSysWaves + 1) * 64) void ksw_extd2_sys_kernel(con
     const bool approx = (tk.flag & KSW_EZ_APPROX_MAX) != 0, right = (tk.flag & KSW_EZ_RIGHT) != 0;
     if (approx) {
         const int w = tk.w < 0 ? tk.qlen + tk.tlen : tk.w;
-        const bool fast = !(tk.flag & KSW_EZ_APPROX_DROP) && w >= tk.qlen + tk.tlen;
+        const bool fast = !(tk.flag & KSW_EZ_APPROX_DROP) && (w >= tk.qlen + tk.tlen || (tk.flag & KSW_EZ_NS_NO_SCORE));
         if (right) ksw_sys_run<NCH, true, true, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
         else if (fast) ksw_sys_run<NCH, true, false, true>(tk, pr, seqs, p_pool, cig_pool, res, lds);
         else ksw_sys_run<NCH, true, false, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
@@ -1113,7 +1123,7 @@ __global__ __launch_bounds__(NW * 64) void ksw_extd2_reg_kernel(const KswTask *_
     if (approx) {
         // gap fills whose band never binds and that cannot Z-drop take the path-independent score (see ksw_reg_run)
         const int w = tk.w < 0 ? tk.qlen + tk.tlen : tk.w;
-        const bool fast = NW == 1 && !(tk.flag & KSW_EZ_APPROX_DROP) && w >= tk.qlen + tk.tlen;
+        const bool fast = NW == 1 && !(tk.flag & KSW_EZ_APPROX_DROP) && (w >= tk.qlen + tk.tlen || (tk.flag & KSW_EZ_NS_NO_SCORE));
         if (right) ksw_reg_run<NW, NCH, true, true, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
         else if (fast) ksw_reg_run<NW, NCH, true, false, NW == 1>(tk, pr, seqs, p_pool, cig_pool, res, lds);
         else ksw_reg_run<NW, NCH, true, false, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
