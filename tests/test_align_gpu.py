@@ -131,3 +131,15 @@ def test_anchor_capacity_overflow_goes_through_the_host_code_and_grows():
     assert len(rounds) == 3
     assert rounds[0][1] > 20                                  # first call: (nearly) everything handed back
     assert rounds[2][0] - rounds[1][0] > 20                   # later calls: the kernels' lists again
+
+
+def test_device_plan_finds_every_problem_the_host_asks_for(gpu):
+    """plan.hip: the alignment plan on the device is a prefetch -- the host's own plan looks the DP results up by key.  On the golden pairs
+    (tandem duplications, several chains, N runs: many are left to the host on purpose) every problem of an alignment the device planned must
+    be there, none unasked for, and the results are the reference's (test_golden_pairs runs the same batch)."""
+    g = load_align_golden()
+    ns.align_stats(gpu, reset=True)
+    ns.align_batch(gpu, g["refs"], g["qrys"], g["pair_ref"])
+    st = ns.align_stats(gpu, reset=True)
+    assert st["plan_pairs_dev"] > 10 and st["plan_pairs_dev"] + st["plan_pairs_host"] == st["pairs"], st
+    assert st["plan_hits"] > 100 and st["plan_misses"] == 0 and st["plan_extra"] == 0, st

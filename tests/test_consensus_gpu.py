@@ -291,6 +291,53 @@ def test_window_query_buffers_too_small_take_the_exact_path():
     assert out[0] == out[1] == out[2]
 
 
+PLAN_WORKER = r'''
+import hashlib, sys
+sys.path.insert(0, %(root)r)
+import nanospring_amd as ns
+from nanospring_amd.filter import STREAMS
+bases, off = ns.synth_reads(21, 150000, 700, 3500.0)
+g = ns.NsGpu()
+g.load_reads((bases, off))
+g.sketch(ns.mt19937_64_salts(60), fetch=False)
+g.build_index()
+ns.align_stats(g, reset=True)
+st = ns.consensus_run(g, 24, 24, schedule=(1, 2, 1))
+h = hashlib.sha256()
+for t in range(24):
+    for k in STREAMS:
+        h.update(ns.consensus_stream(g, t, k))
+a = ns.align_stats(g)
+print("HASH", h.hexdigest(), st["n_contigs"], st["count_aligner"], ns.consensus_verify(g))
+print("PLAN", a["pairs"], a["plan_pairs_dev"], a["plan_pairs_host"], a["plan_hits"], a["plan_misses"], a["plan_extra"])
+g.close()
+'''
+
+
+def test_device_plan_two_part_results_and_early_updates_switches():
+    """Round 4's shortening of a slot of the one-group schedule -- the alignment plan on the device (plan.hip), the DP results fetched in two
+    parts with the graph updates of the first part run ahead of the slot's end, the gap fills' score books skipped -- each switched off in
+    turn: the same streams.  By default nearly every alignment of an iid genome is planned on the device and every problem the host asks
+    for is found."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for env in ({}, {"NSGPU_NO_DEVICE_PLAN": "1"}, {"NSGPU_NO_EARLY_UPDATES": "1"}, {"NSGPU_KSW_KEEP_SCORE": "1"}, {"NSGPU_KSW_LONG_ROWS": "0"}, {"NSGPU_KSW_BULK_SERIAL": "1"},
+                {"NSGPU_CONS_CHECK": "1", "NSGPU_SKETCH_CHECK": "1"}):
+        r = subprocess.run([sys.executable, "-c", PLAN_WORKER % {"root": root}], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (env, r.stderr[-2000:])
+        hl = [l.split()[1:] for l in r.stdout.splitlines() if l.startswith("HASH")][0]
+        pl = [int(x) for x in [l.split()[1:] for l in r.stdout.splitlines() if l.startswith("PLAN")][0]]
+        assert hl[-1] == "0", (env, hl)
+        out.append(hl)
+        if not env:
+            pairs, dev, host, hits, misses, extra = pl
+            assert dev + host == pairs and dev > 0.95 * pairs and misses == 0 and extra == 0 and hits > 10 * dev, pl
+        if "NSGPU_NO_DEVICE_PLAN" in env:
+            assert pl[1] == 0 and pl[3] == 0, pl
+    assert all(o == out[0] for o in out), out
+
+
 def test_oversize_sketch_batch_is_split_and_stays_device_visible():
     """A minimizer-sketch batch beyond the kernels' 32-bit position space is sketched piece by piece and the results concatenated in
     pinned memory of the context (the seeding kernel reads the lists where gpu_mm_sketch leaves them).  NSGPU_SKETCH_PIECE_KB=16 forces

@@ -241,3 +241,28 @@ def test_latency_classes_and_early_exit_switches(env):
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
     assert int(line[1]) == 0 and int(line[2]) == 680, (env, line)
+
+
+def test_no_score_flag_changes_nothing_but_the_score(gpu, oracle):
+    """KSW_EZ_NS_NO_SCORE (0x80000, ksw2_reg.hip): what the aligner sets on its gap fills -- approximate mode without KSW_EZ_APPROX_DROP, whose
+    per-row books only produce ez.score, which nothing on NanoSpring's path reads.  Every other field and the CIGAR stay bit-exact against the
+    oracle: one-wave classes (the path without books), the multi-wave class (books skipped), banded problems, and a band that runs out
+    (zdropped = 1, no CIGAR)."""
+    rng = np.random.RandomState(77)
+    probs = []
+    for ql, tl, w in [(240, 250, 751), (300, 310, 751), (420, 400, 751), (500, 512, 100), (700, 690, 751), (1000, 980, 751), (1500, 1400, 751), (900, 300, 64), (2500, 200, 100), (256, 255, 5)]:
+        for _ in range(3):
+            q, t = oracle_lib.ksw_random_problem(rng, ql, tl, err=0.08)
+            probs.append((q, t, w, 400, -1, 0x08))
+            probs.append((q, t, w, 400, -1, 0x08 | 0x02))
+    flagged = [(q, t, w, zd, eb, fl | 0x80000) for q, t, w, zd, eb, fl in probs]
+    ezs, cigs = ns.ksw_extd2_batch(gpu, flagged)
+    n_drop = 0
+    for i, (q, t, w, zd, eb, fl) in enumerate(probs):
+        we, wc = oracle_lib.oracle_ksw(oracle, q, t, w, zd, eb, fl)
+        got = ezs[i]
+        assert got[:8] == we[:8] and got[9:] == we[9:], (i, len(q), len(t), w, hex(fl), got, we)
+        assert got[8] in (0, we[8]), (i, got, we)              # (0: a register kernel skipped the books; the first-generation kernels ignore the flag)
+        assert np.array_equal(cigs[i], wc), i
+        n_drop += we[1]
+    assert n_drop > 0
