@@ -24,8 +24,11 @@ ONE small all-gather of claim / seed request lists per pipeline slot (resolved i
 Prints ONE JSON line on rank 0, including
   roofline     : dominant kernel (ksw_extd2 wavefront DP) algorithmic bytes / HIP-event kernel time vs HBM peak
   cpu_baseline : the reference's hot path as oracle/consensus_oracle.cpp restates it, with the reference's own minimap2
-                 (oracle/_ref) answering the alignments, on ALL host cores (-t N, OpenMP like the reference) and at -t 1,
-                 on bounded samples of the same workload; core count and CPU model stated.
+                 (oracle/_ref) answering the alignments, on ALL host cores (-t N, OpenMP like the reference): on the SAME full input on
+                 this host (`value`; 1 GPU at full cfg2 size, --cpu-full 0 to skip), on a bounded sample and at -t 1; core count and CPU model stated.
+  reference_legal_schedule : one step of the fastest schedule found that is an interleaving the reference's -t N can itself produce
+                 (Consensus::getRead's seed rule, no bucket policy) with streams within 5 % of the reference's -t N.
+  nonideal     : one step on a genome with planted repeats (duplications, tandem repeats, homopolymer / (AT)n runs).
   compression  : stream bytes per base of the timed schedule beside the reference's own -t <cores> and -t 1 runs on the SAME input
                  (oracle/consensus_oracle.cpp, committed measurements under profiles/): the default schedule is chosen so that
                  the streams stay within 5 % of the reference's -t N (iso-compression); `throughput_schedule` times one step of the
@@ -78,9 +81,26 @@ def full_input_reference():
     if not os.path.exists(pth):
         return None
     oj = json.load(open(pth))
-    return {"value": round(oj["mbases_per_s"], 3), "unit": "Mbases/s", "cores": oj["threads"], "seconds": round(oj["seconds"], 1), "host": "build container, 8 vCPU Xeon 2.1 GHz",
+    return {"value": round(oj["mbases_per_s"], 3), "unit": "Mbases/s", "cores": oj["threads"], "seconds": round(oj["seconds"], 1),
+            "host": oj.get("host", "build container, %s CPUs" % oj.get("host_cpus", "?")),
             "contigs": oj["stats"]["n_contigs"], "lone_reads": oj["stats"]["n_lone"], "stream_bytes_per_base": round(oj["stream_bytes_per_base"], 4),
             "source": "profiles/r03_oracle_t8_cfg2.json"}
+
+
+def cpu_full_input(bases, off, k, n, thr, salts):
+    """The reference's -t <cores> on the very input of the timed steps, on THIS host: oracle/consensus_oracle.cpp (the reference's OpenMP loop
+    and try_lock claiming, the reference's own minimap2 answering every alignRead).  Checker code, timed after the timed region."""
+    from tests import oracle_lib
+    cores = host_cores()
+    t0 = time.perf_counter()
+    sm, st = oracle_lib.cons_oracle_run(bases, off, salts, k=k, n=n, thr=thr, checks=False, num_thr=cores)
+    dt = time.perf_counter() - t0
+    nb = int(off[-1])
+    stream = sum(len(t[x]) for t in (sm["threads"] if "threads" in sm else [sm]) for x in oracle_lib.CONS_STREAMS)
+    return {"value": round(nb / 1e6 / dt, 3), "unit": "Mbases/s", "cores": cores, "cpu": cpu_model(), "seconds": round(dt, 1),
+            "contigs": st["n_contigs"], "lone_reads": st["n_lone"], "reads_aligned": st["count_aligner"], "bad_roundtrip": st["n_bad_roundtrip"],
+            "stream_bytes_per_base": round(stream / nb, 4),
+            "note": "timing-dependent for -t > 1: one sample of the reference's own distribution on this input"}
 
 
 def cpu_baseline(n_reads, mean_len, k, n, thr, salts, t1_reads=1500):
@@ -130,6 +150,9 @@ def main():
     ap.add_argument("--throughput-leg", type=int, default=-1, help="also time ONE step of the 1024-builder pipelined schedule, which is not iso-compression (default: only with 1 GPU at full cfg2 size; 0 = skip)")
     ap.add_argument("--seed-tail-rings", type=int, default=3, help="conflict-aware seeds: the radius in a seed round in which more than half of ALL builders ask (one round carries one group's requests, so this only acts with --groups 1; default 3, negative = --seed-rings)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the all-cores CPU-baseline sample (0 = skip; default: 2000 per host core)")
+    ap.add_argument("--cpu-full", type=int, default=-1, help="also time the reference's -t <cores> (oracle) on the FULL input of the timed steps on this host, ~1-2 min (default: only with 1 GPU at full cfg2 size and a CPU sample; 0 = skip)")
+    ap.add_argument("--legal-leg", type=int, default=-1, help="also time ONE step of the fastest reference-legal schedule within 5 %% of the reference's streams: 32 builders, one group, Consensus::getRead's seed rule (default: only with 1 GPU at full cfg2 size; 0 = skip)")
+    ap.add_argument("--nonideal-leg", type=int, default=-1, help="also time ONE step on a genome with planted repeats (default: only with 1 GPU at full cfg2 size; 0 = skip)")
     ap.add_argument("--no-exchange", action="store_true", help="multi-GPU: independent shards, no collective")
     ap.add_argument("--dist-mode", choices=["alltoall", "replicate"], default="alltoall",
                     help="multi-GPU bucket tables: owners of an RCCL all-to-all of (slot, key, id) tuples, or all-gathered sketch rows")
@@ -198,6 +221,7 @@ def main():
     ns.align_stats(g, reset=True)
     sk_ms = idx_ms = 0.0
     st = None
+    waits0, rounds_sum = int(g.lib.nsgpu_host_wait_count()), 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         ts = time.perf_counter()
@@ -207,8 +231,10 @@ def main():
         tm = g.timing()
         sk_ms += tm["sketch_kernel_ms"]
         idx_ms += tm["index_ms"]
+        rounds_sum += int(st["n_rounds"])
     barrier()
     dt = time.perf_counter() - t0
+    waits = int(g.lib.nsgpu_host_wait_count()) - waits0
     dt_local = dt
     if dist is not None:
         cdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
@@ -309,7 +335,8 @@ def main():
                 for t in range(8):
                     h.update(ns.consensus_stream(g, t, kk))
                 same[kk] = h.hexdigest() == want["sha256_over_threads_in_order"][kk]
-            return {"fixture": "profiles/" + fixture, "schedule_of_fixture": want["schedule"], "streams_identical_to_the_oracle": same, "all_identical": all(same.values()),
+            return {"fixture": "profiles/" + fixture, "schedule_of_fixture": want["schedule"], "checked_against": "this repository's oracle (lock-step virtual threads, the same seed policy): parity-unpinned against reference bytes",
+                    "streams_identical_to_the_oracle_6_of_7": same, "all_identical": all(same.values()),
                     "contigs_slots_equal": stats["n_contigs"] == want["stats"]["n_contigs"] and stats["n_rounds"] == want["stats"]["slots"],
                     "test": "tests/test_consensus_gpu.py::test_cfg2_full_default_schedule_equals_lockstep_oracle_hashes"}
         default_sched = (args.builders, args.groups, args.seed_depth, args.seed_rings, args.seed_tail_rings) == (80, 1, 3, 5, 3)
@@ -338,6 +365,48 @@ def main():
                     "compression": compression_of(sb2 / n_bases, st2), "parity": parity_of("r03_lockstep_cfg2_1024.json", st2),
                     "note": "NOT iso-compression: 1024 contigs grow at once on a 40 Mb genome and cut each other short"}
             ns.set_schedule(g, args.groups, args.seed_depth, args.seed_rings, args.seed_tail_rings)
+        full_size = world == 1 and args.reads == 100000 and args.depth == 20.0 and args.genome == "iid" and args.mean_len == 8000.0
+        # the fastest schedule found that the reference's -t N can itself produce (d = 0: no bucket policy, Consensus::getRead's rule; one group) with
+        # streams within 5 % of its -t N: 32 builders (24 / 32 / 40 builders: x1.027 / x1.046 / x1.054 of the -t 8 streams, 47.6 / 58.4 / 69.3 Mbases/s)
+        lleg = None
+        want_legal = args.legal_leg if args.legal_leg >= 0 else int(full_size)
+        if want_legal and world == 1:
+            ns.set_schedule(g, 1, 0, 1, 1)
+            g.sketch(salts, fetch=False); g.build_index()
+            tt = time.perf_counter()
+            g.sketch(salts, fetch=False); g.build_index()
+            st3 = ns.consensus_run(g, 32, 8)
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - tt
+            sb3 = sum(len(ns.consensus_stream(g, t, kk)) for t in range(8) for kk in ns.filter.STREAMS)
+            lleg = {"value": round(n_bases / 1e6 / dt3, 2), "unit": "Mbases/s", "ms_per_step": round(dt3 * 1e3, 1), "steps": 1,
+                    "schedule": {"builders": 32, "groups": 1, "seed_bucket_depth": 0}, "lossless_roundtrip_bad_reads": ns.consensus_verify(g),
+                    "compression": compression_of(sb3 / n_bases, st3), "slots": st3["n_rounds"],
+                    "note": "an interleaving the reference's own -t N can produce (no try_lock ever fails, its getRead seed rule); the headline schedule's seed rule is this repository's extension"}
+            ns.set_schedule(g, args.groups, args.seed_depth, args.seed_rings, args.seed_tail_rings)
+        # one step on data that is not the best case: a genome with planted repeats
+        nleg = None
+        want_non = args.nonideal_leg if args.nonideal_leg >= 0 else int(full_size)
+        if want_non and world == 1:
+            rb, ro = ns.synth_reads(11, genome_len, args.reads, args.mean_len, genome="repeats")
+            g2 = ns.NsGpu(k=k, n=n, overlap_sketch_thr=thr, device=local, stream=stream.cuda_stream)
+            ns.set_schedule(g2, args.groups, args.seed_depth, args.seed_rings, args.seed_tail_rings)
+            g2.load_reads((rb, ro))
+            ns.align_stats(g2, reset=True)
+            tt = time.perf_counter()
+            g2.sketch(salts, fetch=False); g2.build_index()
+            st4 = ns.consensus_run(g2, args.builders, 8)
+            torch.cuda.synchronize()
+            dt4 = time.perf_counter() - tt
+            a4 = ns.align_stats(g2)
+            sb4 = sum(len(ns.consensus_stream(g2, t, kk)) for t in range(8) for kk in ns.filter.STREAMS)
+            nleg = {"value": round(int(ro[-1]) / 1e6 / dt4, 2), "unit": "Mbases/s", "ms_per_step": round(dt4 * 1e3, 1), "steps": 1, "first_step": True,
+                    "genome": "planted repeats: a 4 kb duplication, a 1.5 kb tandem repeat, a homopolymer run, an (AT)n / (ACGT)n run per ~150 kb",
+                    "seed_pairs": {"gpu": a4["seed_pairs_gpu"], "host": a4["seed_pairs_host"]},
+                    "device_plan": {"alignments_planned_on_device": a4["plan_pairs_dev"], "left_to_host": a4["plan_pairs_host"], "problems_found": a4["plan_hits"], "not_found": a4["plan_misses"]},
+                    "stream_bytes_per_base": round(sb4 / int(ro[-1]), 4), "contigs": st4["n_contigs"], "slots": st4["n_rounds"], "lossless_roundtrip_bad_reads": ns.consensus_verify(g2)}
+            g2.close()
+            del rb, ro
         comp = None
         pv = os.path.join(ROOT, "profiles", "r03_pmc_ksw_issue.json" if args.groups == 1 else "r02_pmc_ksw_issue.json")
         if os.path.exists(pv):
@@ -366,6 +435,11 @@ def main():
                        # index + seeds + chaining scores of the alignments: pairs done by the kernels (seeds.hip, chain.hip) / handed back
                        # to the host code (anchors sharing a reference position, oversize lists), over the timed steps
                        "seed_pairs": {"gpu": a["seed_pairs_gpu"], "host": a["seed_pairs_host"]},
+                       # the alignment plan on the device (plan.hip): alignments whose DP problems were planned and launched behind the chaining kernel
+                       # without a host round trip / left to the host's plan; problems the host's own plan asked for and found / did not find
+                       "device_plan": {"alignments_planned_on_device": a["plan_pairs_dev"], "left_to_host": a["plan_pairs_host"], "problems_found": a["plan_hits"], "not_found": a["plan_misses"], "unasked": a["plan_extra"]},
+                       # host waits for GPU work (stream / event waits inside the library) per slot of the contig stage, over the timed steps
+                       "host_waits_per_slot": round(waits / max(rounds_sum, 1), 2),
                        "stage_ms_per_step": {"sketch": round(sk_ms / steps, 2), "tables": round(idx_ms / steps, 2),
                                              "contig_stage_total": round(st["total_ms"], 1), "window_queries": round(st["filter_ms"], 1),
                                              "consensus_index": round(st["index_ms"], 1), "align_total": round(st["align_ms"], 1),
@@ -380,7 +454,9 @@ def main():
             "compression": penalty,
             "parity": parity,
             "throughput_schedule": tleg,
-            "roofline": {"kernel": "ksw_extd2 (ksw_extd2_reg_kernel<NW,NCH>: DP state in registers)", "bound": "valu-issue", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "reference_legal_schedule": lleg,
+            "nonideal": nleg,
+            "roofline": {"kernel": "ksw_extd2 (ksw_extd2_reg_kernel<NW,NCH>: DP state in registers)", "bound": "latency" if args.groups == 1 else "valu-issue", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 7), "hbm_frac": round(achieved / HBM_PEAK_GBS, 7), "hbm_copy_measured_gbs": hbm_copy,
                          "traffic": None, "traffic_from_profile": traffic, "traffic_source": traffic_src,
                          "launches": int(a["dp_launches"]), "avg_launch_ms": round(dp_ms, 3),
@@ -390,11 +466,25 @@ def main():
                                      "gcups_over_kernel_sum": round(a["dp_cells"] / (a["dp_kernel_sum_ms"] * 1e-3) / 1e9, 1) if a["dp_kernel_sum_ms"] else 0,
                                      "pmc": comp},
                          "note": "achieved / peak / frac are the HBM figures the contract asks for (algorithmic bytes per launch / launch time; ~1e-5 by construction: 1 B of sequence per ~250 DP cells); "
-                                 "the kernel is bound by VALU instruction issue (compute.*), hence bound = valu-issue; traffic is not measured inside this run, traffic_from_profile is the "
-                                 "committed rocprofv3 --pmc figure for the workload it names"},
+                                 "neither the HBM nor the MFMA roof applies: at the one-group schedule a launch is as long as the dependent chain of its longest problem (bound = latency: "
+                                 "compute.pmc shows the waves waiting, not issuing), at the 1024-builder schedule the kernels are bound by VALU + SALU instruction issue; traffic is not "
+                                 "measured inside this run, traffic_from_profile is the committed rocprofv3 --pmc figure for the workload it names"},
         }
         if args.cpu_sample != 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample if args.cpu_sample > 0 else 2000 * host_cores(), args.mean_len, k, n, thr, salts)
+            cb = cpu_baseline(args.cpu_sample if args.cpu_sample > 0 else 2000 * host_cores(), args.mean_len, k, n, thr, salts)
+            want_full = args.cpu_full if args.cpu_full >= 0 else int(full_size)
+            if want_full and world == 1:
+                # the reference's -t <cores> on the very input and host of the timed steps: the baseline proper, and the yard-stick of `compression`
+                fi = cpu_full_input(bases, off, k, n, thr, salts)
+                cb["bounded_sample"] = {"value": cb["value"], "sample": cb["sample"], "stream_bytes_per_base": cb["sample_stream_bytes_per_base"]}
+                cb["value"], cb["sample"] = fi["value"], "the FULL input of the timed steps (%d reads / %.1f Mbases) on this host, -t %d in %.1f s: %d reads aligned into %d contigs (%d lone reads), streams %.4f B/base" % (
+                    args.reads, n_bases / 1e6, fi["cores"], fi["seconds"], fi["reads_aligned"], fi["contigs"], fi["lone_reads"], fi["stream_bytes_per_base"])
+                cb["full_input_same_host"] = fi
+                out["compression"]["reference_tN_same_run"] = {"threads": fi["cores"], "stream_bytes_per_base": fi["stream_bytes_per_base"], "contigs": fi["contigs"], "lone_reads": fi["lone_reads"],
+                                                               "source": "oracle/consensus_oracle.cpp -t %d on this host in this run (cpu_baseline.full_input_same_host)" % fi["cores"]}
+                out["compression"]["ratio_to_reference_tN_same_run"] = round(out["compression"]["stream_bytes_per_base"] / fi["stream_bytes_per_base"], 4)
+                out["speedup_over_cpu_same_input_same_host"] = round(out["value"] / fi["value"], 2)
+            out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if job is not None:
         job.close()

@@ -232,6 +232,10 @@ typedef struct {
     uint64_t plan_extra;      /* device-planned problems the host's plan did not ask for */
 } nsgpu_align_stats;
 int nsgpu_get_align_stats(const nsgpu_ctx *ctx, nsgpu_align_stats *s);
+/* host waits for GPU work (stream / event waits inside the library) of this process so far.  No reference counterpart: the reference has no
+ * device; with nsgpu_consensus_stats.n_rounds it gives the host <-> GPU hand-overs per slot of the contig stage (src/Consensus.cpp:29-137 is
+ * one thread's loop there). */
+uint64_t nsgpu_host_wait_count(void);
 int nsgpu_reset_align_stats(nsgpu_ctx *ctx);
 
 /* ---- a11/a12/a16/a17: the contig stage, replaces Consensus::generateAndWriteConsensus

@@ -2,6 +2,7 @@
 // HBM read store and the MinHash stages.  No CPU fallback exists: without a
 // gfx950 device nsgpu_create fails with NSGPU_ERR_NODEV.
 #include "common.hpp"
+#include <atomic>
 #include "host_util.hpp"
 #include <cstdarg>
 #include <chrono>
@@ -28,8 +29,11 @@ static double wait_timeout_s()
     static const double t = [] { const char *e = getenv("NSGPU_WAIT_TIMEOUT_S"); return e ? atof(e) : 0.0; }();
     return t;
 }
+static std::atomic<uint64_t> g_host_waits{0};       // host waits for GPU work (streams and events), process-wide: nsgpu_host_wait_count
+
 static hipError_t stream_wait_impl(hipStream_t s, int spin_us, bool spin_only = false)
 {
+    g_host_waits.fetch_add(1, std::memory_order_relaxed);
     static const bool spin = [] { const char *e = getenv("NSGPU_SPIN_WAIT"); return e && atoi(e) != 0; }();
     const double limit = wait_timeout_s();
     if ((spin || spin_only) && limit <= 0) return hipStreamSynchronize(s);
@@ -54,6 +58,7 @@ hipError_t stream_wait(hipStream_t s) { return stream_wait_impl(s, 20); }
 // the same for an event (a point inside a stream's work): poll, sleep between polls
 hipError_t event_wait(hipEvent_t ev)
 {
+    g_host_waits.fetch_add(1, std::memory_order_relaxed);
     const double limit = wait_timeout_s();
     static thread_local const int slack_set = prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
     (void)slack_set;
@@ -589,3 +594,6 @@ namespace nsgpu {
 int filter_strings_device(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq) { return nsgpu_filter_strings_impl(c, strs, qoff, nq); }
 }
 
+// how many times this process's host threads have waited for GPU work through the library (stream and event waits): with the slot count of a
+// contig stage it says how many hand-overs a slot costs (bench.py: config.host_waits_per_slot)
+extern "C" uint64_t nsgpu_host_wait_count(void) { return g_host_waits.load(std::memory_order_relaxed); }

@@ -31,7 +31,7 @@ launches = max(n1, n2)
 fetch_b, write_b = fetch_kb * 1024.0, write_kb * 1024.0
 print(json.dumps({
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0",
-    "kernel": "ksw_extd2_lds_kernel + ksw_extd2_wg_kernel<512,*> (all launches of one cfg2 step)",
+    "kernel": "ksw_extd2_reg_kernel<NW,NCH> (every register class; all DP launches of one cfg2 step)",
     "launches": launches,
     "fetch_bytes_raw": fetch_b,
     "fetch_bytes_x2_bound": 2 * fetch_b,
