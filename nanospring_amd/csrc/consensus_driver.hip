@@ -77,6 +77,7 @@ struct Builder {
     // cached index of the current main path
     mm2::RefIndex idx;
     bool idx_valid = false;
+    bool sp_ready = false;               // plan_splice has run for the consensus as it is now (right behind the update, on the thread that made it)
     // incremental consensus sketch: the minimizers of mz_str (the main path they were computed for).  When the path changes only the
     // stretch that differs (+ a margin on both sides) is sketched again and spliced in -- see engine_batches_sketch
     std::vector<mm2::Anchor> mz;
@@ -132,7 +133,7 @@ struct Driver {
         b.len = b.g->end_pos - b.g->start_pos;
         b.cur_pos = b.g->start_pos;
         b.right_phase = true, b.edges_too_many = false, b.window_open = false;
-        b.idx_valid = false;
+        b.idx_valid = false, b.sp_ready = false;
         b.mz.clear(), b.mz_str.clear();          // a new consensus: nothing to splice into
         b.chg_lb = 0;
         b.d_mz_n = 0;                            // (the resident list's memory stays with the builder)
@@ -306,7 +307,7 @@ struct Driver {
         b.last_u = u1 - u0, b.last_m = u2 - u1;
         if (u1 - u0 > b.dbg_max_u) b.dbg_max_u = u1 - u0;
         if (u2 - u1 > b.dbg_max_m) b.dbg_max_m = u2 - u1;
-        b.idx_valid = false;
+        b.idx_valid = false, b.sp_ready = false;
     }
 };
 
@@ -336,6 +337,8 @@ struct Engine {
     double p1_align_ms = 0, p1_host_ms = 0, p1_launch_ms = 0;
     uint64_t slot_long_n[4] = {0, 0, 0, 0};
     double slot_long_ms[4] = {0, 0, 0, 0};
+    double g1_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double sk_ms[6] = {0, 0, 0, 0, 0, 0};           // engine_batches_sketch: splice plan, requests, sketch call, index loop, enqueue of seeds..DP, wait + first step     // one-group schedule, wall time of a slot's steps (debug report)
     uint64_t role_serial_ns[4] = {0, 0, 0, 0};
     std::vector<FinishedContig *> emit_queue;      // finished contigs whose emission has not run yet
     std::vector<SketchReq> sk;
@@ -455,6 +458,7 @@ static int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, 
 // phase 1/3: consume deliveries and run every local builder to its next request
 static inline bool in_group(const Builder &b, int group) { return group < 0 || b.group == group; }
 
+static void plan_splice(Builder &b, int w, int k);
 static void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
@@ -466,7 +470,12 @@ static void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
     if (!only_fresh) E->deferred_fresh = -1;
     par_for_pinned("host.phase", D.B.size(), [&](size_t i) {
         Builder &b = D.B[i];
-        if ((in_group(b, group) && (!only_fresh || b.st == Builder::ADVANCE)) || (dg >= 0 && in_group(b, dg) && b.st == Builder::ADVANCE)) D.advance(b);
+        if ((in_group(b, group) && (!only_fresh || b.st == Builder::ADVANCE)) || (dg >= 0 && in_group(b, dg) && b.st == Builder::ADVANCE)) {
+            D.advance(b);
+            // which stretch of the changed consensus has to be sketched again: here, while the strings are in this thread's cache, and not as
+            // a loop of its own at the head of the GPU chain (engine_batches_sketch)
+            if (b.st == Builder::WAIT_ALIGN && !b.idx_valid && !b.sp_ready) { plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k); b.sp_ready = true; }
+        }
     });
     // the edit emission of the contigs finished in this phase: background tasks of the host pool, picked up whenever a
     // thread has nothing else to do (nothing waits for them before the end of the stage)
@@ -906,7 +915,12 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
     H[0].lo = 0, H[0].hi = cut, H[1].lo = cut, H[1].hi = n;
     // which stretch of every changed consensus has to be sketched again (a comparison of the whole string with the one the cached
     // minimizers belong to: on all host threads, this thread is on the slot's critical path)
-    par_for("sketch.plan", n, [&](size_t w) { Builder &b = D.B[who[w]]; if (!b.idx_valid) plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k); });
+    // -- planned where the consensus changed (engine_advance, engine_early_updates); what is left (callers that skip those) on all host threads
+    bool unplanned = false;
+    for (size_t w = 0; w < n && !unplanned; ++w) { const Builder &b = D.B[who[w]]; unplanned = !b.idx_valid && !b.sp_ready; }
+    if (unplanned) par_for("sketch.plan", n, [&](size_t w) { Builder &b = D.B[who[w]]; if (!b.idx_valid && !b.sp_ready) plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k); });
+    double tk = now_ms();
+    E->sk_ms[0] += tk - g0;
     for (Half &h : H) {
         h.sk_ref.assign(h.hi - h.lo, ~0u);
         for (size_t w = h.lo; w < h.hi; ++w) {
@@ -927,7 +941,9 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
         pool_bind_this_thread();
         H[1].rc = hipSetDevice(c->prm.device) == hipSuccess ? gpu_mm_sketch(c, H[1].sk, (int)c->prm.m_w, (int)c->prm.m_k, H[1].mz, E->mz_off[1], 1) : NSGPU_ERR_HIP;
     });
+    E->sk_ms[1] += now_ms() - tk; tk = now_ms();
     H[0].rc = gpu_mm_sketch(c, H[0].sk, (int)c->prm.m_w, (int)c->prm.m_k, H[0].mz, E->mz_off[0], 0);
+    E->sk_ms[2] += now_ms() - tk; tk = now_ms();
     int rc = NSGPU_OK;
     if (t2.joinable()) t2.join();
     for (const Half &h : H) if (h.lo < h.hi && h.rc != NSGPU_OK && rc == NSGPU_OK) rc = h.rc;
@@ -995,7 +1011,7 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
                 first_diff = apply_splice(b, h.mz + mo[si], (size_t)(mo[si + 1] - mo[si]), (int)c->prm.m_w, (int)c->prm.m_k);
                 b.idx.set_sequence_from(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, b.chg_lb);
                 b.chg_lb = (size_t)-1;
-                b.idx_valid = true;
+                b.idx_valid = true, b.sp_ready = false;
             }
             if (b.mz.size() > so[i + 1] - so[i]) { fprintf(stderr, "nsgpu: spliced minimizer list longer than its bound (internal error)\n"); abort(); }
             // The contig's list is resident in HBM (Builder::d_mz): only the entries from the first changed one on go through the pinned
@@ -1008,6 +1024,7 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
             AB.reqs[w].n_ref_mz = b.mz.size();
             AB.jobs[w].seed_prepare();
         });
+        E->sk_ms[3] += now_ms() - tk; tk = now_ms();
         if (resident_lists) {
             // room in the resident lists (growing one copies what it keeps), then ONE kernel moves every tail into place, on the stream the
             // seeding kernel is launched on right behind it
@@ -1045,8 +1062,10 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
         else for (size_t w = lo; w < hi; ++w) if (changed[w]) D.B[who[w]].dc_valid = false;          // (a batch that does not update the device copies leaves them stale)
         rc = align_prestep_launch(c, AB, lo, hi, 1 + 2 * gi + r, true, use_dev_plan ? dp_ws : -1);
     }
+    E->sk_ms[4] += now_ms() - tk; tk = now_ms();
     for (int r = 0; r < 2 && rc == NSGPU_OK; ++r)
         if (r_lo[r] < r_hi[r]) rc = align_prestep_finish(c, AB, r_lo[r], r_hi[r], 1 + 2 * gi + r);
+    E->sk_ms[5] += now_ms() - tk;
     if (t2.joinable()) t2.join();
     NS_TRY(rc);
     E->awho[gi] = who;
@@ -1160,6 +1179,8 @@ static int engine_early_updates(nsgpu_ctx *c, int group)
         Builder &b = D.B[i];
         const double t0 = now_ms();
         D.apply_alignment(b);
+        plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k);
+        b.sp_ready = true;
         b.early_updated = true;
         b.cpu_ms += now_ms() - t0;
     });
@@ -1305,12 +1326,19 @@ static int engine_slot(nsgpu_ctx *c, uint32_t slot, int part = 0)
             // NSGPU_NO_OVERLAP=1 (debugging aid): the same steps in the same order on this thread -- the schedule, hence the result, is the same
             if (serial) wq();
             else tw = std::thread([&] { pool_bind_this_thread(); wq(); });
+            Engine *E = static_cast<Engine *>(c->cons_engine);
+            double t0 = now_ms(), t1;
             rc1 = engine_batches_sketch(c, begin_group, ws_index);
+            t1 = now_ms(); E->g1_ms[3] += t1 - t0; t0 = t1;
             if (rc1 == NSGPU_OK) rc1 = engine_batches_begin(c, begin_group, ws_index);
             if (rc1 != NSGPU_OK) err1 = nsgpu_last_error();
+            t1 = now_ms(); E->g1_ms[4] += t1 - t0; t0 = t1;
             if (tw.joinable()) tw.join();
+            t1 = now_ms(); E->g1_ms[5] += t1 - t0; t0 = t1;
             if (rc1 == NSGPU_OK && rc2 == NSGPU_OK && G == 1) { rc1 = engine_early_updates(c, finish_group); if (rc1 != NSGPU_OK) err1 = nsgpu_last_error(); }
+            t1 = now_ms(); E->g1_ms[6] += t1 - t0; t0 = t1;
             if (rc1 == NSGPU_OK && rc2 == NSGPU_OK) { rc1 = engine_align_finish(c, finish_group); if (rc1 != NSGPU_OK) err1 = nsgpu_last_error(); }
+            E->g1_ms[7] += now_ms() - t0;
         };
         if (G == 1) { if (part != 2) engine_advance(c, false, host_group); if (part != 1) chain(); }
         else if (serial) { engine_advance(c, false, host_group); chain(); }
@@ -1419,9 +1447,13 @@ static int run_consensus_inner(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_thr
             // and get their first window at once, so that their first alignment is in this slot's batches), batches, claims -- a read
             // granted as a seed here cannot be claimed by an alignment of this slot
             NS_TRY(engine_slot(c, slot, 1));
+            double t1 = now_ms();
+            E->g1_ms[0] += t1 - t;
             NS_TRY(engine_window_loop(c, h));
+            E->g1_ms[1] += now_ms() - t1; t1 = now_ms();
             engine_seed_requests(c, ga, gb, h);
             if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) { engine_advance(c, true, h); NS_TRY(engine_window_loop(c, h)); }
+            E->g1_ms[2] += now_ms() - t1;
             NS_TRY(engine_slot(c, slot, 2));
             w_slot += now_ms() - t;
             engine_claim_requests(c, ga, gb, b);
@@ -1479,6 +1511,10 @@ static int run_consensus_inner(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_thr
             for (int d = 0; d < 10; ++d) { uint64_t sum = 0; const size_t a = nb * d / 10, b = nb * (d + 1) / 10; for (size_t i = a; i < b; ++i) sum += E->dbg_batch_sizes[i]; fprintf(stderr, " %.1f", b > a ? (double)sum / (double)(b - a) : 0.0); }
             fprintf(stderr, "\n");
         }
+        fprintf(stderr, "[cons] one-group slot, wall-ms of its steps: host phase %.0f, windows %.0f, seeds + fresh contigs %.0f, sketch..chain %.0f, DP launch %.0f, wait for the window thread %.0f, first results + early updates %.0f, last results %.0f\n",
+                E->g1_ms[0], E->g1_ms[1], E->g1_ms[2], E->g1_ms[3], E->g1_ms[4], E->g1_ms[5], E->g1_ms[6], E->g1_ms[7]);
+        fprintf(stderr, "[cons] sketch..chain, wall-ms of its steps: splice plan %.0f, requests %.0f, sketch call %.0f, splice + index loop %.0f, enqueue of tails / seeds / chain / plan / DP %.0f, wait for seeds + chains and the first step %.0f\n",
+                E->sk_ms[0], E->sk_ms[1], E->sk_ms[2], E->sk_ms[3], E->sk_ms[4], E->sk_ms[5]);
         fprintf(stderr, "[cons] slots set by: host phase %llu (%.0f ms), batches part 1 %llu (%.0f ms), part 2 %llu (%.0f ms)\n", (unsigned long long)E->slot_long_n[0],
                 E->slot_long_ms[0], (unsigned long long)E->slot_long_n[1], E->slot_long_ms[1], (unsigned long long)E->slot_long_n[2], E->slot_long_ms[2]);
     }
