@@ -355,8 +355,7 @@ void parallel_for_pinned_impl(size_t n, const std::function<void(size_t)> &fn)
 {
     if (n == 0) return;
     if (host_threads() <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
-    static const bool dyn = getenv("NSGPU_DYNAMIC_BUILDERS") != nullptr;
-    the_pool().run(n, fn, !dyn);
+    the_pool().run(n, fn, true);
 }
 
 double now_ms()

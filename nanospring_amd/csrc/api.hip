@@ -79,8 +79,7 @@ hipError_t event_wait(hipEvent_t ev)
 // step), polling hipStreamQuery for 0.5 ms first still 0.67 s; the spin costs ~1 CPU-second per batch thread and step.
 hipError_t stream_wait_short(hipStream_t s)
 {
-    static const bool sleepy = getenv("NSGPU_SHORT_WAIT_SLEEP") != nullptr;     // A/B switch: poll + sleep here as well
-    return sleepy ? stream_wait_impl(s, 20) : stream_wait_impl(s, 0, true);
+    return stream_wait_impl(s, 0, true);
 }
 
 static uint64_t row_bytes_h(uint32_t len) { return ((((uint64_t)len + 3) / 4 + 15) & ~(uint64_t)15) + 16; }

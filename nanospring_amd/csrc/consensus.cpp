@@ -395,7 +395,7 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
             if (!no_run_loop && op.num > 1 && ei >= 1 && ei + op.num - 2 <= n_path_edges && main_edges[ei - 1]->source == cur && main_edges[ei - 1]->sink == node_in_path) {
                 const size_t last_ei = ei + op.num - 2;                 // ei at the start of the run's last base
                 Edge *const *pe = main_edges.begin();
-                static const size_t pf_edge = getenv("NSGPU_PF_EDGE") ? (size_t)atoi(getenv("NSGPU_PF_EDGE")) : 40, pf_tail = getenv("NSGPU_PF_TAIL") ? (size_t)atoi(getenv("NSGPU_PF_TAIL")) : 20;
+                constexpr size_t pf_edge = 40, pf_tail = 20;           // prefetch distances (edges ahead), measured at cfg2
                 for (size_t x = ei - 1; x < last_ei; ++x) {
                     if (x + pf_edge < n_path_edges) __builtin_prefetch(pe[x + pf_edge], 1, 1);
                     // second miss of an edge with more than eight reads: the tail of its read list, one line behind the edge's own
@@ -626,8 +626,6 @@ void ContigGraph::calculate_main_path_greedy()
     // A re-routing (split_path) leaves best_out of every consistent main-path node as it was: at a main-path source it
     // replaces a side edge by a new edge with the same reads at the END of the out list (the main edge, being the first
     // maximum, stays the first maximum); deeper levels only touch edges out of side nodes and edges INTO main nodes.
-    static const bool split_invalidates = getenv("NSGPU_SPLIT_INVALIDATES") != nullptr;      // debugging aid: the old, conservative rule
-    if (split_invalidates && n_splits_ != splits_before) consistent_from_ = (size_t)-1;
     right_unchanged_ = main_edges.back()->sink;
     right_off_ = main_edges.size();
     left_unchanged_ = main_edges.front()->source;
@@ -918,10 +916,9 @@ void ContigGraph::walk_read(const GraphRead &r, read_t id, const ReadBases *src,
             // node (cum_weight), next_fork_[j] = first index >= j whose node has more than one way out or ends the path,
             // side_mask_[j] = bases of the side sinks of node j, cons = the path's bases (all set by write_reads).
             size_t j = cur->cum_weight;
-            static const bool no_word_walk = getenv("NSGPU_NO_WORD_WALK") != nullptr;
             for (;;) {
                 if (++i == L) return;
-                if (!no_word_walk && j < n_main) {
+                if (j < n_main) {
                     // the longest stretch on which the read's bases are the consensus's and nothing else could carry them: 8 bases per
                     // compare (read ^ consensus, and the follow_ok_ bytes all 1)
                     const size_t lim = L - i < n_main - j ? L - i : n_main - j;
@@ -1086,7 +1083,7 @@ void ContigGraph::write_reads(StreamSet &o, const std::function<ReadBases(read_t
     note(0, main_nodes_[0]);
     for (size_t t = 0; t < n_main; ++t) {
         // two dependent misses per position (edge, then its sink): keep both in flight ahead of the loop
-        static const size_t pf_a = getenv("NSGPU_PF_TAB") ? (size_t)atoi(getenv("NSGPU_PF_TAB")) : 16;
+        constexpr size_t pf_a = 16;
         if (t + pf_a < n_main) __builtin_prefetch(main_edges[t + pf_a], 0, 1);
         if (t + pf_a / 2 < n_main) __builtin_prefetch(main_edges[t + pf_a / 2]->sink, 1, 1);
         Node *n = main_edges[t]->sink;

@@ -337,13 +337,13 @@ struct Engine {
     double p1_align_ms = 0, p1_host_ms = 0, p1_launch_ms = 0;
     uint64_t slot_long_n[4] = {0, 0, 0, 0};
     double slot_long_ms[4] = {0, 0, 0, 0};
-    double g1_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    double sk_ms[6] = {0, 0, 0, 0, 0, 0};           // engine_batches_sketch: splice plan, requests, sketch call, index loop, enqueue of seeds..DP, wait + first step     // one-group schedule, wall time of a slot's steps (debug report)
+    double g1_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // one-group schedule, wall time of a slot's steps (debug report)
+    double sk_ms[6] = {0, 0, 0, 0, 0, 0};           // engine_batches_sketch: splice plan, requests, sketch call, index loop, enqueue of seeds..DP, wait + first step
     uint64_t role_serial_ns[4] = {0, 0, 0, 0};
     std::vector<FinishedContig *> emit_queue;      // finished contigs whose emission has not run yet
-    std::vector<SketchReq> sk;
-    std::vector<uint32_t> sk_ref;
-    std::vector<uint64_t> mz_off[2];                // minimizer offsets of the two halves of a sketch batch
+    std::vector<uint64_t> mz_off[2];                // minimizer offsets of a sketch batch ([0]; [1] unused)
+    std::vector<SketchReq> sk_reqs;                 // requests of a sketch batch: changed consensus stretches, then the candidates
+    std::vector<uint32_t> sk_ref;                   // per builder of the batch: its consensus request (~0u: consensus unchanged)
     std::vector<uint64_t> stage_off;                // offsets of the builders' consensus minimizer lists in the seeding kernel's staging buffer
     std::vector<size_t> tail_from;                  // per builder of the batch: first list entry that travels this time
     std::vector<TailCopy> tail_jobs;
@@ -905,169 +905,127 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
     if (who.empty()) return NSGPU_OK;
     const double g0 = now_ms();
     const size_t n = who.size();
-    // Measured: two halves are SLOWER (sketch + index 2.6 s instead of 2.0 s per cfg2 step) -- a sketch call costs ~2.4 ms
-    // whatever its size (some 25 kernel launches and 3 host round trips on a busy GPU), so two calls in parallel take as long
-    // each as one call for everything.  NSGPU_SKETCH_TWO_HALVES=1 keeps the variant reachable.
-    static const bool two_halves = getenv("NSGPU_SKETCH_TWO_HALVES") != nullptr;
-    const size_t cut = n < 32 || !two_halves ? n : n / 2;
-    // requests of half h: the changed consensus strings of its builders, then their candidate reads
-    struct Half { size_t lo, hi, q_base; std::vector<SketchReq> sk; std::vector<uint32_t> sk_ref; const mm2::Anchor *mz = nullptr; int rc = NSGPU_OK; } H[2];
-    H[0].lo = 0, H[0].hi = cut, H[1].lo = cut, H[1].hi = n;
-    // which stretch of every changed consensus has to be sketched again (a comparison of the whole string with the one the cached
-    // minimizers belong to: on all host threads, this thread is on the slot's critical path)
-    // -- planned where the consensus changed (engine_advance, engine_early_updates); what is left (callers that skip those) on all host threads
+    // ONE sketch call and ONE chaining launch per batch.  Both were measured in halves (two sketch calls side by side; the second half's
+    // index builds while the GPU chains the first) and were slower: a sketch call costs what its ~25 launches and its round trips cost
+    // whatever its size (sketch + index 2.6 instead of 2.0 s per cfg2 step), and a chaining launch lasts as long as its longest list.
+    // The requests: the changed stretch of every changed consensus (plan_splice, run where the consensus changed), then the candidate reads.
+    std::vector<SketchReq> &sk = E->sk_reqs;
+    std::vector<uint32_t> &sk_ref = E->sk_ref;
+    sk.clear();
+    sk_ref.assign(n, ~0u);
     bool unplanned = false;
     for (size_t w = 0; w < n && !unplanned; ++w) { const Builder &b = D.B[who[w]]; unplanned = !b.idx_valid && !b.sp_ready; }
     if (unplanned) par_for("sketch.plan", n, [&](size_t w) { Builder &b = D.B[who[w]]; if (!b.idx_valid && !b.sp_ready) plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k); });
     double tk = now_ms();
     E->sk_ms[0] += tk - g0;
-    for (Half &h : H) {
-        h.sk_ref.assign(h.hi - h.lo, ~0u);
-        for (size_t w = h.lo; w < h.hi; ++w) {
-            Builder &b = D.B[who[w]];
-            if (!b.idx_valid) {
-                h.sk_ref[w - h.lo] = (uint32_t)h.sk.size();
-                if (b.sp.full) h.sk.push_back(SketchReq{b.g->main_path.data(), b.g->main_path.size()});
-                else h.sk.push_back(SketchReq{b.g->main_path.data() + b.sp.a, b.sp.B_sub - b.sp.a});
-            }
-        }
-        h.q_base = h.sk.size();
-        for (size_t w = h.lo; w < h.hi; ++w) h.sk.push_back(SketchReq{D.B[who[w]].query.data(), D.B[who[w]].query.size()});
+    for (size_t w = 0; w < n; ++w) {
+        Builder &b = D.B[who[w]];
+        if (b.idx_valid) continue;
+        sk_ref[w] = (uint32_t)sk.size();
+        if (b.sp.full) sk.push_back(SketchReq{b.g->main_path.data(), b.g->main_path.size()});
+        else sk.push_back(SketchReq{b.g->main_path.data() + b.sp.a, b.sp.B_sub - b.sp.a});
     }
+    const size_t q_base = sk.size();
+    for (size_t w = 0; w < n; ++w) sk.push_back(SketchReq{D.B[who[w]].query.data(), D.B[who[w]].query.size()});
     AB.reqs.resize(n);
     if (AB.jobs.size() < n) AB.jobs.resize(n);
-    std::thread t2;
-    if (cut < n) t2 = std::thread([&] {
-        pool_bind_this_thread();
-        H[1].rc = hipSetDevice(c->prm.device) == hipSuccess ? gpu_mm_sketch(c, H[1].sk, (int)c->prm.m_w, (int)c->prm.m_k, H[1].mz, E->mz_off[1], 1) : NSGPU_ERR_HIP;
-    });
     E->sk_ms[1] += now_ms() - tk; tk = now_ms();
-    H[0].rc = gpu_mm_sketch(c, H[0].sk, (int)c->prm.m_w, (int)c->prm.m_k, H[0].mz, E->mz_off[0], 0);
+    const mm2::Anchor *mz = nullptr;
+    std::vector<uint64_t> &mo = E->mz_off[0];
+    NS_TRY(gpu_mm_sketch(c, sk, (int)c->prm.m_w, (int)c->prm.m_k, mz, mo, 0));
     E->sk_ms[2] += now_ms() - tk; tk = now_ms();
-    int rc = NSGPU_OK;
-    if (t2.joinable()) t2.join();
-    for (const Half &h : H) if (h.lo < h.hi && h.rc != NSGPU_OK && rc == NSGPU_OK) rc = h.rc;
-    // Index builds, seeds, the chaining kernel, then the first step.  NSGPU_CHAIN_PIPELINE=1 does it in two halves -- the second
-    // half's index builds and seeds while the GPU chains the first -- which was measured SLOWER (cfg2: sketch+index wall +130 ms
-    // per step, whole path -2 %): two half-size loops on the pool balance worse than one, and a chaining launch lasts as long as
-    // its longest list whatever the number of lists.
-    static const bool pipe = getenv("NSGPU_CHAIN_PIPELINE") != nullptr;
     static const bool resident_lists = getenv("NSGPU_NO_RESIDENT_LISTS") == nullptr;      // A/B switch: consensus minimizer lists staged whole, as in round 2
     std::vector<size_t> &tail_from = E->tail_from;
     tail_from.assign(n, 0);
     // the plan kernel (plan.hip) reads the candidate where the sketch batch staged it and the consensus from the contig's resident copy
-    const bool use_dev_plan = dp_ws >= 0 && cut == n && rc == NSGPU_OK;
+    const bool use_dev_plan = dp_ws >= 0;
     std::vector<uint8_t> &changed = E->cons_changed;
     changed.assign(n, 0);
     for (size_t w = 0; w < n; ++w) changed[w] = !D.B[who[w]].idx_valid;
     // lists retired by an earlier call: their last reader (that call's seeding kernel) has been waited for since
     for (DevBuf &d : E->retired) d.release();
     E->retired.clear();
-    const size_t mid = n >= 64 && pipe ? n / 2 : n;
-    const size_t r_lo[2] = {0, mid}, r_hi[2] = {mid, n};
-    for (int r = 0; r < 2 && rc == NSGPU_OK; ++r) {
-        const size_t lo = r_lo[r], hi = r_hi[r];
-        if (lo == hi) continue;
-        // (w -> the half of the sketch batch it was sketched in)
-        auto half_of = [&](size_t w) -> const Half & { return w < cut ? H[0] : H[1]; };
-        // The consensus minimizers of every builder go to the seeding kernel through one pinned staging buffer: room for each list
-        // is set aside from an upper bound of its length after the splice (old list + newly sketched stretch).
-        const int sws_i = 1 + 2 * gi + r;
-        std::vector<uint64_t> &so = E->stage_off;
-        so.assign(hi - lo + 1, 0);
-        for (size_t w = lo; w < hi; ++w) {
-            const Half &h = half_of(w);
-            const std::vector<uint64_t> &mo = E->mz_off[&h - H];
-            const Builder &b = D.B[who[w]];
-            uint64_t bound = b.mz.size();
-            if (!b.idx_valid) { const uint32_t si = h.sk_ref[w - h.lo]; bound += mo[si + 1] - mo[si]; }
-            so[w - lo + 1] = so[w - lo] + bound;
-        }
-        rc = c->seed_ws[sws_i].h_ref.reserve(so[hi - lo] * sizeof(mm2::Anchor) + 16);
-        if (rc != NSGPU_OK) break;
-        mm2::Anchor *stage = c->seed_ws[sws_i].h_ref.as<mm2::Anchor>();
-        // the query minimizers stay in the pinned buffer of the half's sketch workspace until the alignments have been seeded
-        for (size_t w = lo; w < hi; ++w) {
-            const Half &h = half_of(w);
-            const std::vector<uint64_t> &mo = E->mz_off[&h - H];
-            Builder &b = D.B[who[w]];
-            const size_t qi = h.q_base + (w - h.lo);
-            AB.reqs[w] = AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), h.mz + mo[qi], (size_t)(mo[qi + 1] - mo[qi]),
-                                  stage + so[w - lo], 0};
-            if (use_dev_plan) AB.reqs[w].qry_dev = sketch_dev_seq(c, 0, qi);       // (the consensus side: filled in below, once the device copies are up to date)
-        }
-        rc = align_prestep_start(c, AB, lo, hi);
-        if (rc != NSGPU_OK) break;
-        // one loop over the builders: the minimizers of the changed consensus (splice), its base codes, the list into the staging
-        // buffer, the candidate's base codes.  The index proper -- lookup table, occurrence cut-off -- and the seeds are the GPU's.
-        par_for("index.build", hi - lo, [&](size_t i) {
-            const size_t w = lo + i;
-            const Half &h = half_of(w);
-            const std::vector<uint64_t> &mo = E->mz_off[&h - H];
-            Builder &b = D.B[who[w]];
-            size_t first_diff = b.d_mz_n;                 // nothing to upload when the consensus did not change
-            if (!b.idx_valid) {
-                const uint32_t si = h.sk_ref[w - h.lo];
-                first_diff = apply_splice(b, h.mz + mo[si], (size_t)(mo[si + 1] - mo[si]), (int)c->prm.m_w, (int)c->prm.m_k);
-                b.idx.set_sequence_from(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, b.chg_lb);
-                b.chg_lb = (size_t)-1;
-                b.idx_valid = true, b.sp_ready = false;
-            }
-            if (b.mz.size() > so[i + 1] - so[i]) { fprintf(stderr, "nsgpu: spliced minimizer list longer than its bound (internal error)\n"); abort(); }
-            // The contig's list is resident in HBM (Builder::d_mz): only the entries from the first changed one on go through the pinned
-            // staging buffer (resident_lists off: the whole list, read by the seeding kernel where it lies in pinned memory, as before).
-            if (first_diff > b.d_mz_n) first_diff = b.d_mz_n;
-            const size_t from = resident_lists ? first_diff : 0;
-            if (b.mz.size() > from) memcpy(stage + so[i], b.mz.data() + from, (b.mz.size() - from) * sizeof(mm2::Anchor));
-            tail_from[i] = from;
-            if (resident_lists) AB.reqs[w].ref_mz = b.mz.data();      // host copy: for the pairs the kernel hands back to the host code
-            AB.reqs[w].n_ref_mz = b.mz.size();
-            AB.jobs[w].seed_prepare();
-        });
-        E->sk_ms[3] += now_ms() - tk; tk = now_ms();
-        if (resident_lists) {
-            // room in the resident lists (growing one copies what it keeps), then ONE kernel moves every tail into place, on the stream the
-            // seeding kernel is launched on right behind it
-            nsgpu_ctx::SeedWs &SW = c->seed_ws[sws_i];
-            if (!SW.stream) { rc = role_stream_create(&SW.stream, "seeds"); if (rc != NSGPU_OK) break; }
-            std::vector<TailCopy> &jobs = E->tail_jobs;
-            jobs.clear();
-            uint32_t max_n = 0;
-            for (size_t w = lo; w < hi && rc == NSGPU_OK; ++w) {
-                Builder &b = D.B[who[w]];
-                const size_t n_new = b.mz.size(), from = tail_from[w - lo];
-                if (n_new * sizeof(mm2::Anchor) > b.d_mz.cap) {
-                    DevBuf bigger;
-                    rc = bigger.reserve(std::max<size_t>(2 * n_new, 16384) * sizeof(mm2::Anchor));
-                    if (rc != NSGPU_OK) break;
-                    if (from && hipMemcpyAsync(bigger.p, b.d_mz.p, from * sizeof(mm2::Anchor), hipMemcpyDeviceToDevice, SW.stream) != hipSuccess) rc = NSGPU_ERR_HIP;
-                    E->retired.push_back(b.d_mz);         // freed once the stream is known to be past this slot (engine_batches_sketch's next call)
-                    b.d_mz = bigger;
-                }
-                if (n_new > from) { jobs.push_back(TailCopy{stage + so[w - lo], b.d_mz.as<mm2::Anchor>() + from, (uint32_t)(n_new - from), 0}); max_n = std::max(max_n, (uint32_t)(n_new - from)); }
-                b.d_mz_n = n_new;
-                AB.reqs[w].ref_mz_dev = b.d_mz.as<mm2::Anchor>();
-            }
-            if (rc != NSGPU_OK) break;
-            if (!jobs.empty()) {
-                rc = E->pin_tail.reserve(jobs.size() * sizeof(TailCopy));
-                if (rc != NSGPU_OK) break;
-                memcpy(E->pin_tail.p, jobs.data(), jobs.size() * sizeof(TailCopy));
-                const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>(64, (max_n + 255) / 256));
-                hipLaunchKernelGGL(mz_tail_scatter_kernel, dim3(gx, (uint32_t)jobs.size()), dim3(256), 0, SW.stream, E->pin_tail.as<TailCopy>(), (uint32_t)jobs.size());
-                if (hipGetLastError() != hipSuccess) { rc = NSGPU_ERR_HIP; break; }
-            }
-        }
-        if (use_dev_plan && lo == 0 && hi == n) { rc = engine_cons_update(c, E, AB, who, changed, H[0].sk_ref, sws_i); if (rc != NSGPU_OK) break; }
-        else for (size_t w = lo; w < hi; ++w) if (changed[w]) D.B[who[w]].dc_valid = false;          // (a batch that does not update the device copies leaves them stale)
-        rc = align_prestep_launch(c, AB, lo, hi, 1 + 2 * gi + r, true, use_dev_plan ? dp_ws : -1);
+    // The consensus minimizers of every builder go to the seeding kernel through one pinned staging buffer: room for each list
+    // is set aside from an upper bound of its length after the splice (old list + newly sketched stretch).
+    const int sws_i = 1 + 2 * gi;
+    std::vector<uint64_t> &so = E->stage_off;
+    so.assign(n + 1, 0);
+    for (size_t w = 0; w < n; ++w) {
+        const Builder &b = D.B[who[w]];
+        uint64_t bound = b.mz.size();
+        if (!b.idx_valid) { const uint32_t si = sk_ref[w]; bound += mo[si + 1] - mo[si]; }
+        so[w + 1] = so[w] + bound;
     }
+    NS_TRY(c->seed_ws[sws_i].h_ref.reserve(so[n] * sizeof(mm2::Anchor) + 16));
+    mm2::Anchor *stage = c->seed_ws[sws_i].h_ref.as<mm2::Anchor>();
+    // the query minimizers stay in the pinned buffer of the sketch workspace until the alignments have been seeded
+    for (size_t w = 0; w < n; ++w) {
+        Builder &b = D.B[who[w]];
+        const size_t qi = q_base + w;
+        AB.reqs[w] = AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), mz + mo[qi], (size_t)(mo[qi + 1] - mo[qi]), stage + so[w], 0};
+        if (use_dev_plan) AB.reqs[w].qry_dev = sketch_dev_seq(c, 0, qi);       // (the consensus side: filled in below, once the device copies are up to date)
+    }
+    NS_TRY(align_prestep_start(c, AB, 0, n));
+    // one loop over the builders: the minimizers of the changed consensus (splice), its base codes, the list into the staging
+    // buffer, the candidate's base codes.  The index proper -- lookup table, occurrence cut-off -- and the seeds are the GPU's.
+    par_for("index.build", n, [&](size_t w) {
+        Builder &b = D.B[who[w]];
+        size_t first_diff = b.d_mz_n;                 // nothing to upload when the consensus did not change
+        if (!b.idx_valid) {
+            const uint32_t si = sk_ref[w];
+            first_diff = apply_splice(b, mz + mo[si], (size_t)(mo[si + 1] - mo[si]), (int)c->prm.m_w, (int)c->prm.m_k);
+            b.idx.set_sequence_from(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, b.chg_lb);
+            b.chg_lb = (size_t)-1;
+            b.idx_valid = true, b.sp_ready = false;
+        }
+        if (b.mz.size() > so[w + 1] - so[w]) { fprintf(stderr, "nsgpu: spliced minimizer list longer than its bound (internal error)\n"); abort(); }
+        // The contig's list is resident in HBM (Builder::d_mz): only the entries from the first changed one on go through the pinned
+        // staging buffer (resident_lists off: the whole list, read by the seeding kernel where it lies in pinned memory, as before).
+        if (first_diff > b.d_mz_n) first_diff = b.d_mz_n;
+        const size_t from = resident_lists ? first_diff : 0;
+        if (b.mz.size() > from) memcpy(stage + so[w], b.mz.data() + from, (b.mz.size() - from) * sizeof(mm2::Anchor));
+        tail_from[w] = from;
+        if (resident_lists) AB.reqs[w].ref_mz = b.mz.data();      // host copy: for the pairs the kernel hands back to the host code
+        AB.reqs[w].n_ref_mz = b.mz.size();
+        AB.jobs[w].seed_prepare();
+    });
+    E->sk_ms[3] += now_ms() - tk; tk = now_ms();
+    if (resident_lists) {
+        // room in the resident lists (growing one copies what it keeps), then ONE kernel moves every tail into place, on the stream the
+        // seeding kernel is launched on right behind it
+        nsgpu_ctx::SeedWs &SW = c->seed_ws[sws_i];
+        if (!SW.stream) NS_TRY(role_stream_create(&SW.stream, "seeds"));
+        std::vector<TailCopy> &jobs = E->tail_jobs;
+        jobs.clear();
+        uint32_t max_n = 0;
+        for (size_t w = 0; w < n; ++w) {
+            Builder &b = D.B[who[w]];
+            const size_t n_new = b.mz.size(), from = tail_from[w];
+            if (n_new * sizeof(mm2::Anchor) > b.d_mz.cap) {
+                DevBuf bigger;
+                NS_TRY(bigger.reserve(std::max<size_t>(2 * n_new, 16384) * sizeof(mm2::Anchor)));
+                if (from) NS_HIP(hipMemcpyAsync(bigger.p, b.d_mz.p, from * sizeof(mm2::Anchor), hipMemcpyDeviceToDevice, SW.stream));
+                E->retired.push_back(b.d_mz);         // freed once the stream is known to be past this slot (engine_batches_sketch's next call)
+                b.d_mz = bigger;
+            }
+            if (n_new > from) { jobs.push_back(TailCopy{stage + so[w], b.d_mz.as<mm2::Anchor>() + from, (uint32_t)(n_new - from), 0}); max_n = std::max(max_n, (uint32_t)(n_new - from)); }
+            b.d_mz_n = n_new;
+            AB.reqs[w].ref_mz_dev = b.d_mz.as<mm2::Anchor>();
+        }
+        if (!jobs.empty()) {
+            NS_TRY(E->pin_tail.reserve(jobs.size() * sizeof(TailCopy)));
+            memcpy(E->pin_tail.p, jobs.data(), jobs.size() * sizeof(TailCopy));
+            const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>(64, (max_n + 255) / 256));
+            hipLaunchKernelGGL(mz_tail_scatter_kernel, dim3(gx, (uint32_t)jobs.size()), dim3(256), 0, SW.stream, E->pin_tail.as<TailCopy>(), (uint32_t)jobs.size());
+            NS_HIP(hipGetLastError());
+        }
+    }
+    if (use_dev_plan) NS_TRY(engine_cons_update(c, E, AB, who, changed, sk_ref, sws_i));
+    else for (size_t w = 0; w < n; ++w) if (changed[w]) D.B[who[w]].dc_valid = false;          // (a batch that does not update the device copies leaves them stale)
+    NS_TRY(align_prestep_launch(c, AB, 0, n, sws_i, true, use_dev_plan ? dp_ws : -1));
     E->sk_ms[4] += now_ms() - tk; tk = now_ms();
-    for (int r = 0; r < 2 && rc == NSGPU_OK; ++r)
-        if (r_lo[r] < r_hi[r]) rc = align_prestep_finish(c, AB, r_lo[r], r_hi[r], 1 + 2 * gi + r);
+    NS_TRY(align_prestep_finish(c, AB, 0, n, sws_i));
     E->sk_ms[5] += now_ms() - tk;
-    if (t2.joinable()) t2.join();
-    NS_TRY(rc);
     E->awho[gi] = who;
     E->dbg_batch_sizes.push_back((uint32_t)who.size());
     { std::lock_guard<std::mutex> lk(c->stat_m); S.index_ms += now_ms() - g0; }
@@ -1412,6 +1370,113 @@ static int engine_window_loop(nsgpu_ctx *c, int group)
     }
 }
 
+// NSGPU_CONS_DEBUG: where the wall time of the slots went (printed once per stage, before the edit emission is waited for)
+static void debug_report_slots(nsgpu_ctx *c, Engine *E)
+{
+    fprintf(stderr, "[cons] batches wall-ms: window queries %.0f, sketch+index %.0f (gpu sketch %.0f), align begin %.0f (host loops %.0f, DP launch %.0f)\n", c->cons_stats.filter_ms,
+            c->cons_stats.index_ms, c->sketch_mm_ms, E->p1_align_ms, E->p1_host_ms, E->p1_launch_ms);
+    double chain_ms = 0;
+    for (AlignBatch &ab : E->ab) chain_ms += ab.chain_ms, ab.chain_ms = 0;
+    double sw = 0; uint64_t sn = 0, sp = 0, sf = 0;
+    for (nsgpu_ctx::SeedWs &w : c->seed_ws) sw += w.ms_wait, sn += w.calls, sp += w.pairs, sf += w.fallbacks, w.ms_wait = 0, w.calls = w.pairs = w.fallbacks = 0;
+    fprintf(stderr, "[cons] window-query batches redone the exact multi-step way (a buffer sized in advance did not fit): %llu\n", (unsigned long long)E->n_wq_exact);
+    fprintf(stderr, "[cons] DP launches by register class (cumulative; ms per launch x launches; wall of the DP phases %.0f ms):", c->ksw_kernel_ms);
+    for (int k = 0; k < 16; ++k) if (c->ksw_class_n[k]) fprintf(stderr, " [%d] %.3f x %llu", k, c->ksw_class_ms[k] / (double)c->ksw_class_n[k], (unsigned long long)c->ksw_class_n[k]);
+    fprintf(stderr, "\n");
+    fprintf(stderr, "[cons] alignments left to the host's plan, by reason (cumulative): no anchors / flagged pair %llu, several chains %llu, seed filtering %llu, outside the staged span %llu, capacity %llu, DP class %llu\n",
+            (unsigned long long)c->plan_why[0], (unsigned long long)c->plan_why[1], (unsigned long long)c->plan_why[2], (unsigned long long)c->plan_why[3], (unsigned long long)c->plan_why[4], (unsigned long long)c->plan_why[5]);
+    fprintf(stderr, "[cons] graph updates run ahead of the slot's end: %llu, %.0f ms wall (first part of the DP results + updates)\n", (unsigned long long)E->n_early, E->early_ms);
+    fprintf(stderr, "[cons] device plan (cumulative): %llu alignments planned on the device, %llu left to the host; DP problems found %llu, not found %llu, unasked %llu\n",
+            (unsigned long long)c->plan_pairs_dev, (unsigned long long)c->plan_pairs_host, (unsigned long long)c->plan_hits, (unsigned long long)c->plan_misses, (unsigned long long)c->plan_extra);
+    fprintf(stderr, "[cons] index + seeds on the GPU: %llu launches, %llu pairs, wait %.0f ms wall; %llu pairs handed back to the host code\n", (unsigned long long)sn,
+            (unsigned long long)sp, sw, (unsigned long long)sf);
+    double cs = 0, ce = 0, cw = 0; uint64_t cn = 0;
+    for (nsgpu_ctx::ChainWs &w : c->cws) cs += w.ms_stage, ce += w.ms_enqueue, cw += w.ms_wait, cn += w.calls, w.ms_stage = w.ms_enqueue = w.ms_wait = 0, w.calls = 0;
+    fprintf(stderr, "[cons] chaining scores on the GPU (inside sketch+index): %.0f ms wall in %llu calls: staging %.0f, enqueue %.0f, wait (copies + kernel) %.0f\n", chain_ms,
+            (unsigned long long)cn, cs, ce, cw);
+    if (!E->dbg_batch_sizes.empty()) {        // alignments per batch over the run, in tenths of the run
+        const size_t nb = E->dbg_batch_sizes.size();
+        fprintf(stderr, "[cons] alignments per batch over the run (%zu batches, mean of each tenth):", nb);
+        for (int d = 0; d < 10; ++d) { uint64_t sum = 0; const size_t a = nb * d / 10, b = nb * (d + 1) / 10; for (size_t i = a; i < b; ++i) sum += E->dbg_batch_sizes[i]; fprintf(stderr, " %.1f", b > a ? (double)sum / (double)(b - a) : 0.0); }
+        fprintf(stderr, "\n");
+    }
+    fprintf(stderr, "[cons] one-group slot, wall-ms of its steps: host phase %.0f, windows %.0f, seeds + fresh contigs %.0f, sketch..chain %.0f, DP launch %.0f, wait for the window thread %.0f, first results + early updates %.0f, last results %.0f\n",
+            E->g1_ms[0], E->g1_ms[1], E->g1_ms[2], E->g1_ms[3], E->g1_ms[4], E->g1_ms[5], E->g1_ms[6], E->g1_ms[7]);
+    fprintf(stderr, "[cons] sketch..chain, wall-ms of its steps: splice plan %.0f, requests %.0f, sketch call %.0f, splice + index loop %.0f, enqueue of tails / seeds / chain / plan / DP %.0f, wait for seeds + chains and the first step %.0f\n",
+            E->sk_ms[0], E->sk_ms[1], E->sk_ms[2], E->sk_ms[3], E->sk_ms[4], E->sk_ms[5]);
+    fprintf(stderr, "[cons] slots set by: host phase %llu (%.0f ms), batches part 1 %llu (%.0f ms), part 2 %llu (%.0f ms)\n", (unsigned long long)E->slot_long_n[0],
+            E->slot_long_ms[0], (unsigned long long)E->slot_long_n[1], E->slot_long_ms[1], (unsigned long long)E->slot_long_n[2], E->slot_long_ms[2]);
+}
+
+// NSGPU_CONS_DEBUG: CPU time, memory and the per-step counters of the whole stage
+static void debug_report_stage(nsgpu_ctx *c, Engine *E, const struct rusage &ru0, double w_begin, double w_slot, double w_seed, double w_claim, double tf)
+{
+    fprintf(stderr, "[cons] gpu mm_sketch wall-ms %.0f\n", c->sketch_mm_ms);
+    if (cons::g_mp_cnt[1].load())
+        fprintf(stderr, "[cons] main path (cumulative): %llu recomputes cut the path, on average at %.0f edges before its end of %.0f\n", (unsigned long long)cons::g_mp_cnt[1].load(),
+                (double)cons::g_mp_cnt[0].load() / cons::g_mp_cnt[1].load(), (double)cons::g_mp_cnt[2].load() / cons::g_mp_cnt[1].load());
+    if (cons::g_upd_ns[5].load())
+        fprintf(stderr, "[cons] update_graph cpu-ms (NSGPU_UPDATE_STATS, cumulative, %llu calls): setup %.0f, SAME runs %.0f, SAME heads %.0f, inserts / deletes %.0f, tail %.0f\n",
+                (unsigned long long)cons::g_upd_ns[5].load(), cons::g_upd_ns[0] / 1e6, cons::g_upd_ns[1] / 1e6, cons::g_upd_ns[2] / 1e6, cons::g_upd_ns[3] / 1e6, cons::g_upd_ns[4] / 1e6);
+    fprintf(stderr, "[cons] emission cpu-ms: path tables %.0f, read walks %.0f, script folding + stream bytes %.0f\n", cons::g_emit_ns[0] / 1e6, cons::g_emit_ns[1] / 1e6, cons::g_emit_ns[2] / 1e6);
+    fprintf(stderr, "[cons] align host cpu-ms: seeds %.0f chain %.0f regs %.0f plan %.0f execute %.0f\n", mm2::g_step_ns[0] / 1e6, mm2::g_step_ns[1] / 1e6,
+            mm2::g_step_ns[2] / 1e6, mm2::g_step_ns[3] / 1e6, mm2::g_step_ns[4] / 1e6);
+    struct rusage ru1;
+    getrusage(RUSAGE_SELF, &ru1);
+    const double cpu_s = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec) * 1e-6 +
+                         (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
+    fprintf(stderr, "[cons] serial CPU ms of the role threads (outside pool loops): host %.0f, batches part 1 %.0f, part 2 %.0f\n", E->role_serial_ns[0] / 1e6,
+            E->role_serial_ns[1] / 1e6, E->role_serial_ns[2] / 1e6);
+    if (FILE *f = fopen("/proc/self/smaps_rollup", "r")) {       // are the graph slabs really on huge pages?
+        char line[256];
+        long rss = 0, thp = 0;
+        while (fgets(line, sizeof(line), f)) { sscanf(line, "Rss: %ld kB", &rss); sscanf(line, "AnonHugePages: %ld kB", &thp); }
+        fclose(f);
+        fprintf(stderr, "[cons] resident %.1f GB, of it on transparent huge pages %.1f GB; graph slabs of %zu KB: %lld in use, peak %lld, carved %lld (%.1f GB)\n", rss / 1048576.0, thp / 1048576.0,
+                cons::kSlabBytes >> 10, (long long)cons::g_slabs_in_use.load(), (long long)cons::g_slabs_peak.load(), (long long)cons::g_slabs_mapped.load(),
+                cons::g_slabs_mapped.load() * (double)cons::kSlabBytes / (1u << 30));
+    }
+    pool_prof_print();
+    fprintf(stderr, "[cons] part 2 wall-ms: wait for the DP in flight %.0f, later rounds %.0f (their DP %.0f, %d rounds), results %.0f\n", g_finish_ms[0], g_finish_ms[1],
+            g_finish_ms[2], (int)g_finish_ms[4], g_finish_ms[3]);
+    for (double &x : g_finish_ms) x = 0;
+    fprintf(stderr, "[cons] gpu mm_sketch wall-ms: host staging %.0f, flags..k-mers (1st read-back) %.0f, pushes..offsets (2nd) %.0f, write + read-back %.0f; %.0f MB in, %.1f M minimizers out\n",
+            g_sketch_ms[0], g_sketch_ms[1], g_sketch_ms[2], g_sketch_ms[3], g_sketch_ms[4] / 1e6, g_sketch_ms[5] / 1e6);
+    for (double &x : g_sketch_ms) x = 0;
+    const double sys_s = (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
+    if (getenv("NSGPU_THREAD_TIMES")) {
+        // cumulative user / system time of every thread of the process since it started (ticks -> s), busiest system-time users first
+        std::vector<std::pair<double, std::string>> rows;
+        if (DIR *d = opendir("/proc/self/task")) {
+            while (dirent *de = readdir(d)) {
+                if (de->d_name[0] == '.') continue;
+                char path[128], buf[1024];
+                snprintf(path, sizeof(path), "/proc/self/task/%s/stat", de->d_name);
+                FILE *tf = fopen(path, "r");
+                if (!tf) continue;
+                if (fgets(buf, sizeof(buf), tf)) {
+                    const char *rp = strrchr(buf, ')');
+                    const char *lp = strchr(buf, '(');
+                    unsigned long ut = 0, stt = 0;
+                    if (rp && lp && sscanf(rp + 2, "%*c %*d %*d %*d %*d %*d %*u %*u %*u %*u %*u %lu %lu", &ut, &stt) == 2) {
+                        char row[256];
+                        snprintf(row, sizeof(row), "%s %.*s user %.2f s sys %.2f s", de->d_name, (int)(rp - lp - 1), lp + 1, ut / (double)sysconf(_SC_CLK_TCK), stt / (double)sysconf(_SC_CLK_TCK));
+                        rows.push_back({stt / (double)sysconf(_SC_CLK_TCK), row});
+                    }
+                }
+                fclose(tf);
+            }
+            closedir(d);
+        }
+        std::sort(rows.begin(), rows.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+        for (size_t k = 0; k < rows.size() && k < 24; ++k) fprintf(stderr, "[threads] %s\n", rows[k].second.c_str());
+    }
+    fprintf(stderr, "[cons] process CPU time over the stage: %.1f s (%.1f s of it in the kernel; %ld minor faults) = %.1f cores busy on average\n", cpu_s, sys_s,
+            ru1.ru_minflt - ru0.ru_minflt, cpu_s / ((now_ms() - E->t0) * 1e-3));
+    fprintf(stderr, "[cons] wall-ms: begin %.0f slots %.0f (host phases %.0f, batches %.0f, overlapped) seed %.0f claim %.0f finish %.0f\n", w_begin, w_slot,
+            c->cons_stats.graph_ms, c->cons_stats.filter_ms + c->cons_stats.index_ms + c->cons_stats.align_ms, w_seed, w_claim, now_ms() - tf);
+}
+
 static int run_consensus_inner(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_out);
 static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_out)
 {
@@ -1473,119 +1538,19 @@ static int run_consensus_inner(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_thr
         // The first steps of the contigs started here (graph of the seed read, first main path, first window) are not run at the
         // boundary, where every other thread would wait for them (170 ms per cfg2 step): the group's next role is part 1 of the
         // batches, which only looks at builders that wait for an alignment, and nobody needs a fresh contig's window request
-        // before the group's part 2, two slots on -- they run with the next slot's host phase.  (NSGPU_NO_DEFER_FRESH=1: at once.)
+        // before the group's part 2, two slots on -- they run with the next slot's host phase.
         engine_seed_requests(c, ga, gb, h);
         if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) {
-            static const bool at_once = getenv("NSGPU_NO_DEFER_FRESH") != nullptr;
-            if (at_once || G < 4) engine_advance(c, true, h);      // (two groups: the group's batches run in the very next slot)
+            if (G < 4) engine_advance(c, true, h);      // (two groups: the group's batches run in the very next slot)
             else E->deferred_fresh = h;
         }
         w_seed += now_ms() - t;
         if (E->n_done_global >= E->n_total) break;
     }
-    if (getenv("NSGPU_CONS_DEBUG")) {
-        fprintf(stderr, "[cons] batches wall-ms: window queries %.0f, sketch+index %.0f (gpu sketch %.0f), align begin %.0f (host loops %.0f, DP launch %.0f)\n", c->cons_stats.filter_ms,
-                c->cons_stats.index_ms, c->sketch_mm_ms, E->p1_align_ms, E->p1_host_ms, E->p1_launch_ms);
-        double chain_ms = 0;
-        for (AlignBatch &ab : E->ab) chain_ms += ab.chain_ms, ab.chain_ms = 0;
-        double sw = 0; uint64_t sn = 0, sp = 0, sf = 0;
-        for (nsgpu_ctx::SeedWs &w : c->seed_ws) sw += w.ms_wait, sn += w.calls, sp += w.pairs, sf += w.fallbacks, w.ms_wait = 0, w.calls = w.pairs = w.fallbacks = 0;
-        fprintf(stderr, "[cons] window-query batches redone the exact multi-step way (a buffer sized in advance did not fit): %llu\n", (unsigned long long)E->n_wq_exact);
-        fprintf(stderr, "[cons] DP launches by register class (cumulative; ms per launch x launches; wall of the DP phases %.0f ms):", c->ksw_kernel_ms);
-        for (int k = 0; k < 16; ++k) if (c->ksw_class_n[k]) fprintf(stderr, " [%d] %.3f x %llu", k, c->ksw_class_ms[k] / (double)c->ksw_class_n[k], (unsigned long long)c->ksw_class_n[k]);
-        fprintf(stderr, "\n");
-        fprintf(stderr, "[cons] alignments left to the host's plan, by reason (cumulative): no anchors / flagged pair %llu, several chains %llu, seed filtering %llu, outside the staged span %llu, capacity %llu, DP class %llu\n",
-                (unsigned long long)c->plan_why[0], (unsigned long long)c->plan_why[1], (unsigned long long)c->plan_why[2], (unsigned long long)c->plan_why[3], (unsigned long long)c->plan_why[4], (unsigned long long)c->plan_why[5]);
-        fprintf(stderr, "[cons] graph updates run ahead of the slot's end: %llu, %.0f ms wall (first part of the DP results + updates)\n", (unsigned long long)E->n_early, E->early_ms);
-        fprintf(stderr, "[cons] device plan (cumulative): %llu alignments planned on the device, %llu left to the host; DP problems found %llu, not found %llu, unasked %llu\n",
-                (unsigned long long)c->plan_pairs_dev, (unsigned long long)c->plan_pairs_host, (unsigned long long)c->plan_hits, (unsigned long long)c->plan_misses, (unsigned long long)c->plan_extra);
-        fprintf(stderr, "[cons] index + seeds on the GPU: %llu launches, %llu pairs, wait %.0f ms wall; %llu pairs handed back to the host code\n", (unsigned long long)sn,
-                (unsigned long long)sp, sw, (unsigned long long)sf);
-        double cs = 0, ce = 0, cw = 0; uint64_t cn = 0;
-        for (nsgpu_ctx::ChainWs &w : c->cws) cs += w.ms_stage, ce += w.ms_enqueue, cw += w.ms_wait, cn += w.calls, w.ms_stage = w.ms_enqueue = w.ms_wait = 0, w.calls = 0;
-        fprintf(stderr, "[cons] chaining scores on the GPU (inside sketch+index): %.0f ms wall in %llu calls: staging %.0f, enqueue %.0f, wait (copies + kernel) %.0f\n", chain_ms,
-                (unsigned long long)cn, cs, ce, cw);
-        if (!E->dbg_batch_sizes.empty()) {        // alignments per batch over the run, in tenths of the run
-            const size_t nb = E->dbg_batch_sizes.size();
-            fprintf(stderr, "[cons] alignments per batch over the run (%zu batches, mean of each tenth):", nb);
-            for (int d = 0; d < 10; ++d) { uint64_t sum = 0; const size_t a = nb * d / 10, b = nb * (d + 1) / 10; for (size_t i = a; i < b; ++i) sum += E->dbg_batch_sizes[i]; fprintf(stderr, " %.1f", b > a ? (double)sum / (double)(b - a) : 0.0); }
-            fprintf(stderr, "\n");
-        }
-        fprintf(stderr, "[cons] one-group slot, wall-ms of its steps: host phase %.0f, windows %.0f, seeds + fresh contigs %.0f, sketch..chain %.0f, DP launch %.0f, wait for the window thread %.0f, first results + early updates %.0f, last results %.0f\n",
-                E->g1_ms[0], E->g1_ms[1], E->g1_ms[2], E->g1_ms[3], E->g1_ms[4], E->g1_ms[5], E->g1_ms[6], E->g1_ms[7]);
-        fprintf(stderr, "[cons] sketch..chain, wall-ms of its steps: splice plan %.0f, requests %.0f, sketch call %.0f, splice + index loop %.0f, enqueue of tails / seeds / chain / plan / DP %.0f, wait for seeds + chains and the first step %.0f\n",
-                E->sk_ms[0], E->sk_ms[1], E->sk_ms[2], E->sk_ms[3], E->sk_ms[4], E->sk_ms[5]);
-        fprintf(stderr, "[cons] slots set by: host phase %llu (%.0f ms), batches part 1 %llu (%.0f ms), part 2 %llu (%.0f ms)\n", (unsigned long long)E->slot_long_n[0],
-                E->slot_long_ms[0], (unsigned long long)E->slot_long_n[1], E->slot_long_ms[1], (unsigned long long)E->slot_long_n[2], E->slot_long_ms[2]);
-    }
+    if (getenv("NSGPU_CONS_DEBUG")) debug_report_slots(c, E);
     const double tf = now_ms();
     const int rc = engine_finish(c, n_threads_out);
-    if (getenv("NSGPU_CONS_DEBUG")) {
-        fprintf(stderr, "[cons] gpu mm_sketch wall-ms %.0f\n", c->sketch_mm_ms);
-        if (cons::g_mp_cnt[1].load())
-            fprintf(stderr, "[cons] main path (cumulative): %llu recomputes cut the path, on average at %.0f edges before its end of %.0f\n", (unsigned long long)cons::g_mp_cnt[1].load(),
-                    (double)cons::g_mp_cnt[0].load() / cons::g_mp_cnt[1].load(), (double)cons::g_mp_cnt[2].load() / cons::g_mp_cnt[1].load());
-        if (cons::g_upd_ns[5].load())
-            fprintf(stderr, "[cons] update_graph cpu-ms (NSGPU_UPDATE_STATS, cumulative, %llu calls): setup %.0f, SAME runs %.0f, SAME heads %.0f, inserts / deletes %.0f, tail %.0f\n",
-                    (unsigned long long)cons::g_upd_ns[5].load(), cons::g_upd_ns[0] / 1e6, cons::g_upd_ns[1] / 1e6, cons::g_upd_ns[2] / 1e6, cons::g_upd_ns[3] / 1e6, cons::g_upd_ns[4] / 1e6);
-        fprintf(stderr, "[cons] emission cpu-ms: path tables %.0f, read walks %.0f, script folding + stream bytes %.0f\n", cons::g_emit_ns[0] / 1e6, cons::g_emit_ns[1] / 1e6, cons::g_emit_ns[2] / 1e6);
-        fprintf(stderr, "[cons] align host cpu-ms: seeds %.0f chain %.0f regs %.0f plan %.0f execute %.0f\n", mm2::g_step_ns[0] / 1e6, mm2::g_step_ns[1] / 1e6,
-                mm2::g_step_ns[2] / 1e6, mm2::g_step_ns[3] / 1e6, mm2::g_step_ns[4] / 1e6);
-        struct rusage ru1;
-        getrusage(RUSAGE_SELF, &ru1);
-        const double cpu_s = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec) * 1e-6 +
-                             (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
-        fprintf(stderr, "[cons] serial CPU ms of the role threads (outside pool loops): host %.0f, batches part 1 %.0f, part 2 %.0f\n", E->role_serial_ns[0] / 1e6,
-                E->role_serial_ns[1] / 1e6, E->role_serial_ns[2] / 1e6);
-        if (FILE *f = fopen("/proc/self/smaps_rollup", "r")) {       // are the graph slabs really on huge pages?
-            char line[256];
-            long rss = 0, thp = 0;
-            while (fgets(line, sizeof(line), f)) { sscanf(line, "Rss: %ld kB", &rss); sscanf(line, "AnonHugePages: %ld kB", &thp); }
-            fclose(f);
-            fprintf(stderr, "[cons] resident %.1f GB, of it on transparent huge pages %.1f GB; graph slabs of %zu KB: %lld in use, peak %lld, carved %lld (%.1f GB)\n", rss / 1048576.0, thp / 1048576.0,
-                    cons::kSlabBytes >> 10, (long long)cons::g_slabs_in_use.load(), (long long)cons::g_slabs_peak.load(), (long long)cons::g_slabs_mapped.load(),
-                    cons::g_slabs_mapped.load() * (double)cons::kSlabBytes / (1u << 30));
-        }
-        pool_prof_print();
-        fprintf(stderr, "[cons] part 2 wall-ms: wait for the DP in flight %.0f, later rounds %.0f (their DP %.0f, %d rounds), results %.0f\n", g_finish_ms[0], g_finish_ms[1],
-                g_finish_ms[2], (int)g_finish_ms[4], g_finish_ms[3]);
-        for (double &x : g_finish_ms) x = 0;
-        fprintf(stderr, "[cons] gpu mm_sketch wall-ms: host staging %.0f, flags..k-mers (1st read-back) %.0f, pushes..offsets (2nd) %.0f, write + read-back %.0f; %.0f MB in, %.1f M minimizers out\n",
-                g_sketch_ms[0], g_sketch_ms[1], g_sketch_ms[2], g_sketch_ms[3], g_sketch_ms[4] / 1e6, g_sketch_ms[5] / 1e6);
-        for (double &x : g_sketch_ms) x = 0;
-        const double sys_s = (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
-        if (getenv("NSGPU_THREAD_TIMES")) {
-            // cumulative user / system time of every thread of the process since it started (ticks -> s), busiest system-time users first
-            std::vector<std::pair<double, std::string>> rows;
-            if (DIR *d = opendir("/proc/self/task")) {
-                while (dirent *de = readdir(d)) {
-                    if (de->d_name[0] == '.') continue;
-                    char path[128], buf[1024];
-                    snprintf(path, sizeof(path), "/proc/self/task/%s/stat", de->d_name);
-                    FILE *tf = fopen(path, "r");
-                    if (!tf) continue;
-                    if (fgets(buf, sizeof(buf), tf)) {
-                        const char *rp = strrchr(buf, ')');
-                        const char *lp = strchr(buf, '(');
-                        unsigned long ut = 0, stt = 0;
-                        if (rp && lp && sscanf(rp + 2, "%*c %*d %*d %*d %*d %*d %*u %*u %*u %*u %*u %lu %lu", &ut, &stt) == 2) {
-                            char row[256];
-                            snprintf(row, sizeof(row), "%s %.*s user %.2f s sys %.2f s", de->d_name, (int)(rp - lp - 1), lp + 1, ut / (double)sysconf(_SC_CLK_TCK), stt / (double)sysconf(_SC_CLK_TCK));
-                            rows.push_back({stt / (double)sysconf(_SC_CLK_TCK), row});
-                        }
-                    }
-                    fclose(tf);
-                }
-                closedir(d);
-            }
-            std::sort(rows.begin(), rows.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
-            for (size_t k = 0; k < rows.size() && k < 24; ++k) fprintf(stderr, "[threads] %s\n", rows[k].second.c_str());
-        }
-        fprintf(stderr, "[cons] process CPU time over the stage: %.1f s (%.1f s of it in the kernel; %ld minor faults) = %.1f cores busy on average\n", cpu_s, sys_s,
-                ru1.ru_minflt - ru0.ru_minflt, cpu_s / ((now_ms() - E->t0) * 1e-3));
-        fprintf(stderr, "[cons] wall-ms: begin %.0f slots %.0f (host phases %.0f, batches %.0f, overlapped) seed %.0f claim %.0f finish %.0f\n", w_begin, w_slot,
-                c->cons_stats.graph_ms, c->cons_stats.filter_ms + c->cons_stats.index_ms + c->cons_stats.align_ms, w_seed, w_claim, now_ms() - tf);
-    }
+    if (getenv("NSGPU_CONS_DEBUG")) debug_report_stage(c, E, ru0, w_begin, w_slot, w_seed, w_claim, tf);
     return rc;
 }
 
@@ -1662,8 +1627,7 @@ static int run_consensus_dist(nsgpu_ctx *c, Comm &C, uint32_t n_builders_total, 
         engine_claim_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size());
         gathered(1 + blk);
         if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) {
-            static const bool at_once = getenv("NSGPU_NO_DEFER_FRESH") != nullptr;       // (see run_consensus)
-            if (at_once || G < 4) engine_advance(c, true, h);
+            if (G < 4) engine_advance(c, true, h);       // (see run_consensus)
             else E->deferred_fresh = h;
         }
         if (E->n_done_global >= E->n_total) break;

@@ -740,7 +740,6 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     // NSGPU_KSW_LATENCY_ROWS anti-diagonals.  Off by default.  Measured at the one-group schedule, where a whole round waits for its DP launch
     // (cfg2, 80 builders, interleaved A/B): 700 rows: wait for the DP 5.4 instead of 4.7 s per step, whole path 72.4 instead of 76.6 Mbases/s;
     // 400 / 1000 rows the same picture -- a barrier per anti-diagonal costs more than the second block of a lane saves.
-    static const int wg_min_rows = [] { const char *e = getenv("NSGPU_KSW_WG_MIN_ROWS"); return e ? atoi(e) : 0; }();   // experiment knob
     size_t p_total = 0, cig_total = 0, hbm_stride = 0;
     // per-problem sizes and classes on all host threads (a batch has ~10^4 problems and this thread is on the slot's critical
     // path), then one short serial pass for the running offsets and the class lists
@@ -772,7 +771,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
             const size_t need = ksw_lds_bytes(t.qlen, t.tlen, t.flag);
             const int cls = need <= kClass[0] ? 0 : need <= kClass[1] ? 1 : need <= kClass[2] ? 2 : 3;
             if (cls == 3) { const size_t hn = ksw_lds_bytes(t.qlen, t.tlen, 0); if (hn > hs) hs = hn; }
-            const bool to_wg = cls >= 1 && cls < 3 && !no_wg && t.qlen + t.tlen >= wg_min_rows && ksw_max_width(t.qlen, t.tlen, t.w) <= kWgThreads[cls] * kWgMaxPos[cls];
+            const bool to_wg = cls >= 1 && cls < 3 && !no_wg && ksw_max_width(t.qlen, t.tlen, t.w) <= kWgThreads[cls] * kWgMaxPos[cls];
             cl[i] = (uint8_t)(to_wg ? 4 + cls : cls);
         }
         chunk_stride[ci] = hs;

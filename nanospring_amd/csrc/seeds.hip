@@ -52,7 +52,7 @@ __device__ __forceinline__ uint32_t find_slot(const Slot *tab, uint32_t bits, un
 
 // kThreads: a workgroup per pair, and every phase is a loop of dependent L2 round trips per thread -- the more threads the shorter: 1024
 // (index + seeds wait 0.58 instead of 0.71 s per cfg2 step at the one-group schedule, 80 pairs per launch on an empty chip; the
-// 1024-builder schedule with 256 pairs per launch gains 1-3 % as well).  NSGPU_SEED_THREADS=256: the narrow instance, A/B switch.
+// 1024-builder schedule with 256 pairs per launch gains 1-3 % as well).
 template <int kThreads>
 __global__ __launch_bounds__(kThreads) void seed_kernel(const SeedPair *__restrict__ pairs, Slot *__restrict__ tabs, uint32_t *__restrict__ nexts, unsigned long long *__restrict__ ys_all,
                                                         mm2::Anchor *__restrict__ tmp, mm2::Anchor *__restrict__ out, unsigned long long *__restrict__ counter,
@@ -231,16 +231,9 @@ int gpu_seeds_launch(nsgpu_ctx *c, int ws, float mid_occ_frac, std::vector<SeedP
     memcpy(W.h_pairs.p, pairs.data(), n * sizeof(SeedPair));
     NS_HIP(hipMemsetAsync(W.d_counter.p, 0, 8, W.stream));
     // the pair descriptors and the results are read / written in place in pinned memory
-    static const int forced = getenv("NSGPU_SEED_THREADS") ? atoi(getenv("NSGPU_SEED_THREADS")) : 0;      // A/B switch: 256 or 1024
-    const bool wide = forced ? forced >= 1024 : true;
-    if (wide)
-        hipLaunchKernelGGL(seed_kernel<1024>, dim3((unsigned)n), dim3(1024), 0, W.stream, W.h_pairs.as<SeedPair>(), W.d_tab.as<Slot>(), W.d_next.as<uint32_t>(),
-                           W.d_ys.as<unsigned long long>(), W.d_tmp.as<mm2::Anchor>(), W.d_out.as<mm2::Anchor>(), W.d_counter.as<unsigned long long>(), (unsigned long long)want,
-                           W.h_res.as<SeedResult>(), mid_occ_frac);
-    else
-        hipLaunchKernelGGL(seed_kernel<256>, dim3((unsigned)n), dim3(256), 0, W.stream, W.h_pairs.as<SeedPair>(), W.d_tab.as<Slot>(), W.d_next.as<uint32_t>(),
-                           W.d_ys.as<unsigned long long>(), W.d_tmp.as<mm2::Anchor>(), W.d_out.as<mm2::Anchor>(), W.d_counter.as<unsigned long long>(), (unsigned long long)want,
-                           W.h_res.as<SeedResult>(), mid_occ_frac);
+    hipLaunchKernelGGL(seed_kernel<1024>, dim3((unsigned)n), dim3(1024), 0, W.stream, W.h_pairs.as<SeedPair>(), W.d_tab.as<Slot>(), W.d_next.as<uint32_t>(),
+                       W.d_ys.as<unsigned long long>(), W.d_tmp.as<mm2::Anchor>(), W.d_out.as<mm2::Anchor>(), W.d_counter.as<unsigned long long>(), (unsigned long long)want,
+                       W.h_res.as<SeedResult>(), mid_occ_frac);
     NS_HIP(hipGetLastError());
     NS_HIP(hipMemcpyAsync(W.h_res.as<uint8_t>() + n * sizeof(SeedResult), W.d_counter.p, 8, hipMemcpyDeviceToHost, W.stream));
     return NSGPU_OK;

@@ -151,3 +151,41 @@ def test_cxx_driver_over_callback_communicator(tmp_path, world, groups, depth):
             host_bytes, ag, aa = int(f[f.index("copy") + 1]), int(f[f.index("all-gather") + 2]), int(f[f.index("all-to-all") + 2])
             assert host_bytes <= 0.3 * n_bases + 24 * N_READS + (1 << 16), ln
             assert ag > 0.25 * n_bases and aa > 0, ln                      # the packed rows and the bucket tuples did travel
+
+
+@pytest.mark.parametrize("mode", ["alltoall", "replicate"])
+def test_bench_two_ranks_on_one_gpu_default_schedule(mode):
+    """`bench.py --gpus 2` itself, launched the way the driver launches it (torch.distributed.run, one process per rank; the launcher starts
+    before anything touches the GPU), the two ranks sharing the box's one GPU with the collectives over gloo (NSGPU_BENCH_BACKEND): the
+    line is the contract's, every rank reports its host threads, step time and collective bytes, and in the DEFAULT schedule (one group,
+    conflict-aware seeds of depth 3) the job's contigs are those of one process holding all reads with the same number of builders."""
+    import json
+    R, B, L = 600, 12, 3000.0
+    port = "29671" if mode == "alltoall" else "29672"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, NSGPU_BENCH_BACKEND="gloo", NSGPU_THREADS="4")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--reads", str(R), "--mean-len", str(L), "--builders", str(B),
+                        "--cpu-sample", "0", "--dist-mode", mode], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 1 and j["warmup"] == 1 and j["scaling"] == "weak" and j["higher_is_better"] is True and j["value"] > 0
+    assert j["config"]["schedule"] == {"groups": 1, "seed_bucket_depth": 3, "seed_rings": 5, "seed_tail_rings": 3}
+    pr = j["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1]
+    for p in pr:
+        assert p["host_threads"] >= 1 and p["s_per_step"] > 0 and p["bases"] > 0
+        assert p["all_gather_bytes"] > 0 and p["host_bytes_of_the_read_copy"] > 0
+        assert (p["all_to_all_bytes"] > 0) == (mode == "alltoall")
+    # one process, all reads, the same number of builders, the same schedule
+    bases, off = ns.synth_reads(11, int(2 * R * L / 20), 2 * R, L)
+    assert sum(p["bases"] for p in pr) == int(off[-1])
+    g = ns.NsGpu()
+    g.load_reads((bases, off))
+    g.sketch(ns.mt19937_64_salts(60, 12345), fetch=False)
+    g.build_index()
+    st1 = ns.consensus_run(g, 2 * B, 8, schedule=(1, 3, 5, 3))
+    assert ns.consensus_verify(g) == 0
+    g.close()
+    assert sum(p["contigs"] for p in pr) == st1["n_contigs"] and all(p["rounds"] == st1["n_rounds"] for p in pr)

@@ -5,7 +5,10 @@ schedule DESIGN.md 2 documents, the reference's minimap2 answering every alignRe
 sha256 per stream type over the B thread files in thread order -- the fixtures of
 tests/test_consensus_gpu.py::test_cfg2_full_default_schedule_equals_lockstep_oracle_hashes.
 
-    python tools/oracle_lockstep_cfg2.py [builders depth rings tail_rings] [out.json] [n_reads]
+    python tools/oracle_lockstep_cfg2.py [builders depth rings tail_rings] [out.json] [n_reads] [genome_len] [every k-th read] [name]
+
+cfg3's schedule on every 5th read of the cfg3 input (BASELINE configs[2]; 25 000 reads over the 4.6 Mb genome):
+    python tools/oracle_lockstep_cfg2.py 256 1 4 3 profiles/r04_lockstep_cfg3_fifth.json 125000 4600000 5 cfg3
 
 Full size: 8 minutes on 8 cores and 54 GB of memory at the peak (80 naive graphs, the whole genome in flight half way through).
 """
@@ -19,7 +22,16 @@ B, depth, rings, tail = (int(x) for x in (sys.argv[1:5] if len(sys.argv) > 4 els
 groups = int(os.environ.get("NS_ORACLE_GROUPS", "1"))
 out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(ROOT, "profiles", "r03_lockstep_cfg2.json")
 n_reads = int(sys.argv[6]) if len(sys.argv) > 6 else 100000
-bases, off = ns.synth_reads(11, int(n_reads * 8000 / 20), n_reads, 8000.0)
+genome = int(sys.argv[7]) if len(sys.argv) > 7 else int(n_reads * 8000 / 20)
+stride = int(sys.argv[8]) if len(sys.argv) > 8 else 1
+wname = sys.argv[9] if len(sys.argv) > 9 else "cfg2"
+bases, off = ns.synth_reads(11, genome, n_reads, 8000.0)
+if stride > 1:
+    import numpy as np
+    keep = np.arange(0, n_reads, stride)
+    parts = [bases[int(off[i]):int(off[i + 1])] for i in keep]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in parts])]).astype(np.uint64)
+    bases = np.concatenate(parts)
 salts = ns.mt19937_64_salts(60, 12345)
 t0 = time.time()
 streams, st = oracle_lib.cons_oracle_run(bases, off, salts, num_thr=B, checks=False, lock_step=True, groups=groups, seed_hops=depth, seed_rings=rings, seed_tail_rings=tail)
@@ -34,7 +46,7 @@ for n in names:
     sha[n], size[n] = h.hexdigest(), tot
 sha["metaData"], size["metaData"] = hashlib.sha256(streams["metaData"]).hexdigest(), len(streams["metaData"])
 tot7 = sum(size[n] for n in names)
-rec = {"workload": "cfg2 (bench.py input: seed 11, %d reads, mean 8000, 20x)" % n_reads,
+rec = {"workload": "%s (bench.py's generator: seed 11, %d reads, mean 8000, genome %d%s)" % (wname, n_reads, genome, ", every %dth read" % stride if stride > 1 else ""),
        "schedule": {"builders": B, "groups": groups, "seed_bucket_depth": depth, "seed_rings": rings, "seed_tail_rings": tail},
        "computed_by": "oracle/consensus_oracle.cpp lock-step virtual threads, reference minimap2 (oracle/_ref/libmm2ref.so)",
        "seconds": dt, "bases": int(off[-1]), "stream_bytes": size, "sha256_over_threads_in_order": sha, "stats": st,
