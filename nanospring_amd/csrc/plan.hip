@@ -10,9 +10,10 @@
 // per read: the chains (chain.c:94-164), the regions (hit.c:52-88, 125-186, 255-272, 315-371) and, per region, which banded DP problems
 // the alignment skeleton needs (align.c:565-795: left extension, one gap fill per >= min_ksw_len stretch between kept anchors, right
 // extension).  The host code does this in mm2.cpp; every slot of the contig stage used to wait for the chaining kernel, run that code,
-// pack the DP sequences, upload them and launch.  Here ONE WAVE PER ALIGNMENT does it behind the chaining kernel on its stream, writes
-// the DP task descriptors and their sequences (gathered from the consensus span and the candidate read that the sketch batch already
-// staged in HBM) and appends every task to the launch list of its kernel class; the DP kernels start behind it without a host round trip.
+// pack the DP sequences, upload them and launch.  Here ONE WORKGROUP PER ALIGNMENT does it behind the chaining kernel on its stream, writes
+// the DP task descriptors and their sequences (gathered from the contig's consensus, resident in HBM and updated in place --
+// consensus_driver.hip cons_update_kernel -- and from the candidate read where the sketch batch staged it) and appends every task to the
+// launch list of its kernel class; the DP kernels start behind it without a host round trip.
 //
 // The device plan is a PREFETCH, the host remains the authority: the host runs its own plan (mm2.cpp AlignJob::step) while the DP kernels
 // are in flight and then looks every DP problem it needs up among the device's results BY KEY (the eight integers of mm2::DpKey).  What it
@@ -21,8 +22,9 @@
 //
 // What the kernel takes: alignments whose anchors end in ONE chain (every alignment on a genome without repeats; chain_finish below is
 // complete, the region bookkeeping for several chains stays on the host), without long-gap seed filtering (align.c:386-457 acts on chains
-// with two or more indels > 10 bp between adjacent anchors), whose target windows lie inside the staged consensus span, and whose DP
-// problems the register kernels serve.  Everything else is flagged per alignment (PlanOut.flags) and planned by the host as before.
+// with two or more indels > 10 bp between adjacent anchors) and whose DP problems the narrow register kernels serve (a problem for the
+// <8,5> class -- targets beyond 1536 -- is left to the host: its launch would hold LDS for every alignment that does not need it).
+// Everything else is flagged per alignment (PlanOut.flags) and planned by the host as before: 30 of 94 345 alignments of a cfg2 step.
 #include "common.hpp"
 #include "host_util.hpp"
 #include "mm2.hpp"
