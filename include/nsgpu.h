@@ -353,6 +353,18 @@ int nsgpu_comm_stats(const nsgpu_comm *comm, uint64_t *bytes_all_gather, uint64_
  * (global read ids) into its own n_threads_out stream sets.  The result does not depend on the number of ranks. */
 int nsgpu_dist_consensus_run(nsgpu_ctx *ctx, nsgpu_comm *comm, uint32_t n_builders_total, uint32_t n_threads_out, nsgpu_consensus_stats *stats_out);
 
+/* ---- SURVEY 8 row f4, the part of the back end with a unique answer: the block sorter -------------------------------------------
+ * Replaces libbsc's bsc_bwt_encode (/root/reference/libbsc/bwt/bwt.cpp:46-79) as bsc::BSC_compress calls it per 48 MB block of a stream
+ * file (/root/reference/src/bsc.cpp:1045-1057 -> libbsc.cpp bsc_compress -> bsc_bwt_encode), reached from Compressor::compress()
+ * (/root/reference/src/Compressor.cpp:111-143).  in / out: n bytes of HOST memory (out may equal in).  out = T[n-1] followed by
+ * T[SA[k]-1] for the suffixes in ascending order without the row of suffix 0 (the end of the block sorts below every byte);
+ * *primary_index = rank of suffix 0 + 1.  aux_rate (a power of two; 0 = none): aux[j] = rank of suffix j * aux_rate + 1 for
+ * j = 0 .. (n-1)/aux_rate (aux[0] = the primary index): libsais_bwt_aux's I[], from which bsc_bwt_encode derives its `indexes`
+ * (indexes[t] = aux[t + 1] - 1, num_indexes = (n-1)/aux_rate).  *gpu_ms: device time from the first kernel to the last (HIP events),
+ * *rounds: prefix-doubling rounds.  QLFC / LZMA2 stay the caller's. */
+int nsgpu_bwt_block(nsgpu_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *out, int32_t *primary_index, uint32_t aux_rate, int32_t *aux,
+                    uint32_t *n_aux, double *gpu_ms, uint32_t *rounds);
+
 /* ---- timing of the last call of each stage, in ms, measured with HIP events on
  *      the context's stream (for bench.py's roofline object) ------------------ */
 typedef struct {

@@ -60,6 +60,7 @@ SIGNATURES = {
     "nsgpu_align_batch": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, C.c_uint32, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "nsgpu_get_align_stats": (C.c_int, [_vp, _vp]),
     "nsgpu_host_wait_count": (C.c_uint64, []),
+    "nsgpu_bwt_block": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp]),
     "nsgpu_reset_align_stats": (C.c_int, [_vp]),
     "nsgpu_set_schedule": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "nsgpu_set_schedule2": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),

@@ -258,6 +258,31 @@ class KswEz(C.Structure):
                 ("reach_end", C.c_int32)]
 
 
+def bsc_aux_rate(n):
+    """The sampling rate of the auxiliary indexes bsc_bwt_encode asks libsais for (libbsc/bwt/bwt.cpp:50-56): the largest power of two
+    <= n / 8 (halved once more by the bit trick there), at least 1."""
+    mod = n // 8
+    for sh in (1, 2, 4, 8, 16):
+        mod |= mod >> sh
+    return (mod >> 1) + 1
+
+
+def bwt_block(gpu, data, aux_rate=None):
+    """nsgpu_bwt_block: the block sorter of the back end (libbsc's bsc_bwt_encode, libbsc/bwt/bwt.cpp:46-79) on one block.
+    Returns (bwt bytes, primary index, indexes, gpu_ms, rounds); `indexes` are bsc_bwt_encode's (rank of suffix (t + 1) * rate, 0-based),
+    rate = bsc_aux_rate(n) unless given (0 = none)."""
+    buf = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+    n = int(buf.size)
+    rate = bsc_aux_rate(n) if aux_rate is None else int(aux_rate)
+    out = np.empty(max(n, 1), dtype=np.uint8)
+    n_aux = (n - 1) // rate + 1 if rate and n else 0
+    aux = np.zeros(max(n_aux, 1), dtype=np.int32)
+    prim, na, ms, rounds = C.c_int32(), C.c_uint32(), C.c_double(), C.c_uint32()
+    check(gpu.lib, gpu.lib.nsgpu_bwt_block(gpu.ctx, buf.ctypes.data if n else None, n, out.ctypes.data, C.byref(prim), rate, aux.ctypes.data, C.byref(na), C.byref(ms), C.byref(rounds)))
+    assert int(na.value) == n_aux
+    return out[:n].tobytes(), int(prim.value), [int(x) - 1 for x in aux[1:n_aux]], float(ms.value), int(rounds.value)
+
+
 def ksw_extd2_batch(gpu, problems, a=2, b=4, sc_ambi=1, q=4, e=2, q2=24, e2=1):
     """problems: list of (query codes uint8, target codes uint8, w, zdrop, end_bonus, flag).
     Returns (list of ez tuples, list of CIGAR uint32 arrays) -- ksw_extd2_sse semantics."""

@@ -431,3 +431,46 @@ def cons_oracle_decode(streams):
         return None
     raw = out.tobytes()
     return [(int(ids[i]), raw[int(off[i]):int(off[i + 1])]) for i in range(n)]
+
+
+# ---- the block sorter ------------------------------------------------------------------------------------------------
+BACKENDREF = os.path.join(ORACLE_DIR, "_ref", "backendref")
+
+
+def bwt_naive(data):
+    """What bsc_bwt_encode (libbsc/bwt/bwt.cpp:46-79 -> libsais_bwt_aux) returns, restated: suffixes sorted with the end of the block below
+    every byte; B = T[n-1] + T[SA[k]-1] without the row of suffix 0; primary index = rank of suffix 0 + 1; indexes[t] = rank of suffix
+    (t + 1) * r, r = the largest power of two <= n / 16 ... (the bit trick of bwt.cpp:50-56).  Pure Python: small inputs only.
+    Pinned against the reference's own libbsc (oracle/_ref/backendref bwt) in tests/test_bwt_oracle.py."""
+    T = bytes(data)
+    n = len(T)
+    if n == 0:
+        return b"", 0, []
+    sa = sorted(range(n), key=lambda i: T[i:])
+    rank = [0] * n
+    for k, s_ in enumerate(sa):
+        rank[s_] = k
+    out = bytearray([T[n - 1]])
+    for s_ in sa:
+        if s_:
+            out.append(T[s_ - 1])
+    mod = n // 8
+    for sh in (1, 2, 4, 8, 16):
+        mod |= mod >> sh
+    r = (mod >> 1) + 1
+    return bytes(out), rank[0] + 1, [rank[(t + 1) * r] for t in range((n - 1) // r)]
+
+
+def ref_bwt(data):
+    """libbsc's own block sorter on `data` as one block (oracle/_ref/backendref bwt: bsc_bwt_encode); n >= 16 (below that libsais rejects
+    the sampling rate and bsc stores the block).  Returns (bwt bytes, primary index, indexes)."""
+    import struct, tempfile
+    assert os.path.exists(BACKENDREF), "oracle/_ref/backendref is missing: run `make -C oracle ref` where /root/reference exists"
+    with tempfile.TemporaryDirectory() as td:
+        a, b = os.path.join(td, "in"), os.path.join(td, "out")
+        open(a, "wb").write(bytes(data))
+        r = subprocess.run([BACKENDREF, "bwt", a, b], capture_output=True)
+        assert r.returncode == 0, (r.returncode, r.stderr[-500:])
+        d = open(b, "rb").read()
+    index, num = struct.unpack("<ii", d[:8])
+    return d[8 + 4 * num:], index, list(struct.unpack("<%di" % num, d[8:8 + 4 * num]))
