@@ -402,6 +402,128 @@ __global__ __launch_bounds__(64) void chain_forward_ring_kernel(const mm2::Ancho
     }
 }
 
+// ---- the level kernel: the long lists of repeats on a whole workgroup (round 4) ----
+// A read across a tandem repeat has 10^4 - 10^5 anchors because every reference minimizer of the repeat is hit from every copy in the read:
+// tens to hundreds of anchors SHARE a reference position, and anchors with dr == 0 are never each other's predecessors (chain.c:58).  The
+// anchors of one reference position -- a level -- therefore depend only on the levels before them: up to kLvWaves of them are walked at
+// the same time, one wave each, over the shared rings of f / p / coordinates; marks are per wave (a mark is "anchor i saw this
+// predecessor", and the waves work on different i).  One workgroup barrier per batch of a level.  Same walk, same results as the ring kernel;
+// a list without repeated positions degenerates to one anchor per barrier, so only long lists are sent here (gpu_chain_launch).
+constexpr int kLvWaves = 16;
+constexpr int32_t kLvAhead = 272;              // anchors kept loaded beyond the batch's first one
+constexpr size_t level_lds_bytes(int32_t bw) { return (size_t)kRing * 17 + (size_t)kLvWaves * kRing * 4 + 16 + ((size_t)bw + 1) * 4; }
+
+__global__ __launch_bounds__(kLvWaves * 64) void chain_forward_level_kernel(const mm2::Anchor *__restrict__ anchors, const ChainList *__restrict__ lists, const uint32_t *__restrict__ jobs,
+                                                                             int32_t *__restrict__ f_out, int32_t *__restrict__ p_out, ChainParams P)
+{
+    extern __shared__ int32_t lds[];
+    const ChainList L = lists[jobs[blockIdx.x]];
+    const uint64_t base = L.obeg;
+    const int32_t n = (int32_t)L.n;
+    const mm2::Anchor *a = anchors + L.beg;
+    int32_t *F = lds, *Pp = lds + kRing, *R = lds + 2 * kRing, *Q = lds + 3 * kRing;
+    uint8_t *S = reinterpret_cast<uint8_t *>(lds + 4 * kRing);
+    int32_t *T_all = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(lds) + (size_t)kRing * 17 + 16 - ((size_t)kRing * 17) % 16);
+    int32_t *G = T_all + (size_t)kLvWaves * kRing;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int32_t *T = T_all + (size_t)wv * kRing;
+    for (int32_t i = lane; i < kRing; i += 64) T[i] = -1;
+    {
+        const double avg_qspan = (double)L.avg, gap_scale = (double)P.gap_scale;
+        for (int32_t dd = tid; dd <= P.bw; dd += kLvWaves * 64) {
+            const int32_t log_dd = dd ? 31 - __builtin_clz((uint32_t)dd) : 0;
+            const int32_t gap_cost = (int)((double)dd * .01 * avg_qspan) + (log_dd >> 1);
+            G[dd] = (int)((double)gap_cost * gap_scale + .499);
+        }
+    }
+    auto gain = [&](int32_t ri, int32_t qi, int32_t q_span, int32_t rj, int32_t qj, bool in, int32_t &sc) -> bool {
+        const int32_t dr = ri - rj, dq = qi - qj;
+        const int32_t dd = dr > dq ? dr - dq : dq - dr;
+        const bool ok = in && dr != 0 && dq > 0 && dq <= P.max_dist && dd <= P.bw;
+        sc = min(min(dq, dr), q_span) - G[ok ? dd : 0];
+        return ok;
+    };
+    int32_t loaded = 0;                 // anchors [0, loaded) have been through the rings
+    int32_t i0 = 0;                     // first anchor of the batch (all of this is uniform over the workgroup)
+    while (i0 < n) {
+        // 256 more anchors into the rings (their slots held anchors more than max_chain_iter behind the batch: loaded - 768 < i0 - 416)
+        while (loaded < n && loaded < i0 + kLvAhead) {
+            const int32_t k = loaded + tid;
+            if (tid < 256 && k < n) { const uint64_t x = a[k].x, y = a[k].y; R[k & kRingMask] = (int32_t)x, Q[k & kRingMask] = (int32_t)y, S[k & kRingMask] = (uint8_t)(y >> 32); }
+            loaded = loaded + 256 < n ? loaded + 256 : n;
+            __syncthreads();
+        }
+        // the batch: the anchors from i0 on that share its reference position, at most one per wave
+        int32_t cnt;
+        {
+            const int32_t k = i0 + lane;
+            const bool same = lane < kLvWaves && k < n && R[k & kRingMask] == R[i0 & kRingMask];
+            const uint64_t m = __ballot(same);
+            cnt = (int32_t)__builtin_ctzll(~m);
+        }
+        if (wv < cnt) {
+            const int32_t i = i0 + wv;
+            const int32_t ri = R[i & kRingMask], qi = Q[i & kRingMask], q_span = S[i & kRingMask];
+            Walk w{q_span, -1, 0, false};
+            const int32_t j_min = i - P.max_iter > 0 ? i - P.max_iter : 0;
+            // The whole window at once: the loads of all its chunks of 64 predecessors are issued together, then all gap costs, then all
+            // marks, then all mark tests -- three LDS round trips per ANCHOR instead of three per chunk (a chunk's walk is a dependent chain
+            // of ~1000 cycles otherwise, nearly all of it LDS latency); what is left per chunk is the scan of walk_chunk.  Chunks behind the
+            // one where the walk stops were loaded and marked in vain: a mark only ever matters to predecessors further back, which the
+            // stopped walk does not visit either.
+            constexpr int kCh = (kRingIter + 63) / 64;
+            const int32_t nch = (i - j_min + 63) >> 6;                 // <= kCh (max_chain_iter <= kRingIter)
+            int32_t sc[kCh], tm[kCh];
+            bool ok[kCh], in[kCh];
+            {
+                int32_t rj[kCh], qj[kCh], fj[kCh], pj[kCh];
+#pragma unroll
+                for (int c = 0; c < kCh; ++c) {
+                    const int32_t j = i - 1 - 64 * c - lane;
+                    const bool in0 = c < nch && j >= j_min;
+                    const int32_t jm = j & kRingMask;
+                    // (a predecessor inside the batch is being written by its wave: it has dr == 0, its f / p are read and never used)
+                    rj[c] = in0 ? R[jm] : 0, qj[c] = in0 ? Q[jm] : 0, fj[c] = in0 ? F[jm] : 0, pj[c] = in0 ? Pp[jm] : -1;
+                    in[c] = in0;
+                }
+#pragma unroll
+                for (int c = 0; c < kCh; ++c) {
+                    in[c] = in[c] && ri - rj[c] <= P.max_dist;
+                    ok[c] = gain(ri, qi, q_span, rj[c], qj[c], in[c], sc[c]);
+                    sc[c] += fj[c];
+                }
+#pragma unroll
+                for (int c = 0; c < kCh; ++c) if (ok[c] && pj[c] >= 0) T[pj[c] & kRingMask] = i;
+            }
+            lds_order();
+#pragma unroll
+            for (int c = 0; c < kCh; ++c) tm[c] = ok[c] ? T[(i - 1 - 64 * c - lane) & kRingMask] : -1;
+#pragma unroll
+            for (int c = 0; c < kCh; ++c) {
+                if (c < nch && !w.stop) {
+                    const bool more = __builtin_amdgcn_readlane((int)in[c], 63) != 0;
+                    walk_chunk(w, i - 1 - 64 * c, ok[c], sc[c], ok[c] && tm[c] == i, P.max_skip);
+                    if (!more) w.stop = true;
+                }
+            }
+            if (lane == 0) F[i & kRingMask] = w.max_f, Pp[i & kRingMask] = w.max_j;
+        }
+        __syncthreads();
+        const int32_t i1 = i0 + cnt;
+        // the block of 64 results that the batch completed goes out (the last wave is the one most often without an anchor)
+        if (wv == kLvWaves - 1 && ((i1 >> 6) != (i0 >> 6) || i1 == n)) {
+            const int32_t b0 = (i1 >> 6) != (i0 >> 6) ? (i0 & ~63) : (i1 & ~63);
+            const int32_t k = b0 + lane;
+            if (k < i1) f_out[base + k] = F[k & kRingMask], p_out[base + k] = Pp[k & kRingMask];
+            if ((i1 >> 6) != (i0 >> 6) && i1 == n && (i1 & 63)) {       // the batch crossed a boundary AND ended the list: the tail block as well
+                const int32_t k2 = (i1 & ~63) + lane;
+                if (k2 < i1) f_out[base + k2] = F[k2 & kRingMask], p_out[base + k2] = Pp[k2 & kRingMask];
+            }
+        }
+        i0 = i1;
+    }
+}
+
 }  // namespace
 
 // f[i] / p[i] of mm_chain_dp's first loop for the anchor lists a[off[q] .. off[q+1]) (host pointers; avg[q] = mean query span):
@@ -432,10 +554,12 @@ int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vecto
     for (size_t q = 0; q < nq; ++q) hl[q] = ChainList{off[q], off[q], (uint32_t)(off[q + 1] - off[q]), avg[q]};
     // which kernel takes which list; the longest lists first (a wave's time grows with its list: the tail of the launch should be
     // the short ones)
-    uint32_t n_lds = 0, n_big = 0, n_ring = 0, max_lds = 0;
-    std::vector<uint8_t> &fast = W.h_fast;                // 1: the LDS kernel, 2: the ring kernel (same conditions, any length), 0: the general kernel
+    uint32_t n_lds = 0, n_big = 0, n_ring = 0, n_level = 0, max_lds = 0;
+    std::vector<uint8_t> &fast = W.h_fast;                // 1: the LDS kernel, 2: the ring kernel (same conditions, any length), 3: the level kernel (long lists), 0: the general kernel
     fast.assign(nq, 0);
     static const bool no_ring = getenv("NSGPU_CHAIN_NO_RING") != nullptr;       // A/B switch: long lists through the general kernel, as before
+    // lists from this length on go to the level kernel (a workgroup per list; 0 = never): such lists come from repeats
+    static const uint64_t level_min = [] { const char *e = getenv("NSGPU_CHAIN_LEVEL_MIN"); return e ? (uint64_t)atoll(e) : (uint64_t)2048; }();
     par_for(nq, [&](size_t q) {
         const uint64_t n = off[q + 1] - off[q];
         if (n == 0) return;
@@ -443,11 +567,14 @@ int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vecto
         uint64_t hi_bits = 0;
         for (uint64_t i = 0; i < n; ++i) hi_bits |= lists[q][i].x;
         const bool small_coords = (hi_bits >> 31) == 0 && opt.bw >= 0 && opt.bw <= kFastBw;
-        fast[q] = small_coords && n <= kFastAnchors ? 1 : small_coords && !no_ring && opt.max_chain_iter <= kRingIter && opt.max_chain_iter >= 0 ? 2 : 0;
+        const bool ring_ok = small_coords && !no_ring && opt.max_chain_iter <= kRingIter && opt.max_chain_iter >= 0;
+        fast[q] = ring_ok && level_min && n >= level_min ? 3 : small_coords && n <= kFastAnchors ? 1 : ring_ok ? 2 : 0;
     });
     for (size_t q = 0; q < nq; ++q) if (fast[q] == 1) hj[n_lds++] = (uint32_t)q, max_lds = std::max<uint32_t>(max_lds, (uint32_t)(off[q + 1] - off[q]));
     for (size_t q = 0; q < nq; ++q) if (!fast[q] && off[q + 1] > off[q]) hj[n_lds + n_big++] = (uint32_t)q;
     for (size_t q = 0; q < nq; ++q) if (fast[q] == 2) hj[n_lds + n_big + n_ring++] = (uint32_t)q;
+    for (size_t q = 0; q < nq; ++q) if (fast[q] == 3) hj[n_lds + n_big + n_ring + n_level++] = (uint32_t)q;
+    std::sort(hj + n_lds + n_big + n_ring, hj + n_lds + n_big + n_ring + n_level, [&](uint32_t x, uint32_t y) { const uint64_t nx = off[x + 1] - off[x], ny = off[y + 1] - off[y]; return nx != ny ? nx > ny : x < y; });
     std::sort(hj + n_lds + n_big, hj + n_lds + n_big + n_ring, [&](uint32_t x, uint32_t y) { const uint64_t nx = off[x + 1] - off[x], ny = off[y + 1] - off[y]; return nx != ny ? nx > ny : x < y; });
     std::sort(hj, hj + n_lds, [&](uint32_t x, uint32_t y) { const uint64_t nx = off[x + 1] - off[x], ny = off[y + 1] - off[y]; return nx != ny ? nx > ny : x < y; });
     const double t1 = now_ms();
@@ -457,6 +584,14 @@ int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vecto
     // anchors repeatedly, works on device copies.
     const ChainParams P{opt.max_gap, opt.bw, opt.max_chain_skip, opt.max_chain_iter, opt.chain_gap_scale};
     int32_t *hf = W.h_out.as<int32_t>(), *hp = hf + total;
+    if (n_level) {      // a workgroup of sixteen waves per long list (chain_forward_level_kernel), beside the other launches
+        static bool level_set = false;
+        if (!level_set) { NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_forward_level_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)level_lds_bytes(kFastBw))); level_set = true; }
+        if (!W.stream2) NS_TRY(role_stream_create(&W.stream2, "seeds"));
+        hipLaunchKernelGGL(chain_forward_level_kernel, dim3(n_level), dim3(kLvWaves * 64), level_lds_bytes(opt.bw), W.stream2, ha, hl, hj + n_lds + n_big + n_ring, hf, hp, P);
+        NS_HIP(hipGetLastError());
+        W.ring_used = true;
+    }
     if (n_ring) {       // the longest lists first; like the LDS kernel it reads the pinned staging buffer and writes the pinned results itself
         static bool ring_set = false;
         if (!ring_set) { NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_forward_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds_bytes(kFastBw))); ring_set = true; }

@@ -122,3 +122,71 @@ def test_chain_kernel_against_the_reference_mm_chain_dp(mci):
         n_chains += len(wu)
     assert n_chains > 60
     g.close()
+
+
+def tandem_lists():
+    """what the seeding gives for a read across a tandem repeat (1.5 kb of a 7 / 11 / 23 / 40-mer unit between unique flanks, the read with 3 %
+    errors): every reference minimizer of the repeat is hit from every copy in the read -- hundreds of anchors per reference position"""
+    import random
+    rnd = random.Random(4)
+    out = []
+    for unit_len, tlen in ((7, 1500), (11, 900), (23, 1500), (40, 1500)):
+        unit = "".join(rnd.choice("ACGT") for _ in range(unit_len))
+        ref = "".join(rnd.choice("ACGT") for _ in range(2500)) + (unit * (tlen // unit_len + 1))[:tlen] + "".join(rnd.choice("ACGT") for _ in range(3000))
+        q = []
+        for ch in ref:
+            x = rnd.random()
+            if x < 0.01:
+                q.append(rnd.choice("ACGT"))
+            elif x < 0.02:
+                q.append(ch + rnd.choice("ACGT"))
+            elif x >= 0.03:
+                q.append(ch)
+        out.append(host_lib.seeds(ref, "".join(q)))
+    return out
+
+
+LEVEL_WORKER = r'''
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import nanospring_amd as ns
+from tests import host_lib
+from tests.test_chain_gpu import tandem_lists, synthetic, gpu_scores
+from tests import oracle_lib
+g = ns.NsGpu()
+rng = np.random.RandomState(12)
+lists = tandem_lists()
+assert max(len(a) for a in lists) > 15000, [len(a) for a in lists]
+# batches that end exactly at / one short of / one past a block of 64 results, a level longer than the sixteen waves, levels of one
+for n in (2048, 2111, 2112, 2113, 4096):
+    lists.append(synthetic(rng, n, "dense"))
+lists.append(synthetic(rng, 3000, "colinear"))
+lists.append(synthetic(rng, 9000, "diagonals"))
+one = synthetic(rng, 2500, "dense")
+one[:, 0] = 777                                           # ONE reference position: nobody has a predecessor
+lists.append(one)
+got = gpu_scores(g, lists)
+for a, (f, p) in zip(lists, got):
+    wf, wp = host_lib.chain_forward(a, 400)
+    assert np.array_equal(wf, f) and np.array_equal(wp, p), len(a)
+    u, ra = host_lib.chain_finish(a, f, p, 400)
+    wu, wa = oracle_lib.ref_mm_chain_dp(a, 400)
+    assert np.array_equal(u, wu) and np.array_equal(ra, wa), len(a)
+print("OK", len(lists), sum(len(a) for a in lists))
+g.close()
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level_min", ["2048", "1", "0"])
+def test_level_kernel_on_tandem_repeat_lists(level_min):
+    """chain_forward_level_kernel (a workgroup per long list: the anchors of one reference position on sixteen waves at once): f / p identical to
+    the sequential loop, and the chains through the product's backtracking identical to the REFERENCE's mm_chain_dp, on real tandem-repeat
+    seed lists (20 000+ anchors) and on synthetic lists around the kernel's block and batch boundaries.  NSGPU_CHAIN_LEVEL_MIN=1: every
+    list through it, also the ones without a repeated position; 0: the ring / LDS kernels as before (A/B switch)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", LEVEL_WORKER % {"root": root}], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, NSGPU_CHAIN_LEVEL_MIN=level_min, NSGPU_WAIT_TIMEOUT_S="120"))
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
