@@ -295,7 +295,7 @@ def main():
         # comes from rocprofv3 --pmc passes over this very command (profiles/r01_pmc_ksw_traffic.json) and is only
         # reported for the workload it was measured on.
         traffic, traffic_src = None, None
-        for pmc_name in (("r03_pmc_ksw_traffic.json",) if args.groups == 1 else ("r02_pmc_ksw_traffic.json", "r01_pmc_ksw_traffic.json")):
+        for pmc_name in (("r04_pmc_ksw_traffic.json", "r03_pmc_ksw_traffic.json") if args.groups == 1 else ("r02_pmc_ksw_traffic.json", "r01_pmc_ksw_traffic.json")):
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc) and args.reads == 100000 and world == 1:
                 pj = json.load(open(pmc))
@@ -408,7 +408,9 @@ def main():
             g2.close()
             del rb, ro
         comp = None
-        pv = os.path.join(ROOT, "profiles", "r03_pmc_ksw_issue.json" if args.groups == 1 else "r02_pmc_ksw_issue.json")
+        pv = os.path.join(ROOT, "profiles", "r02_pmc_ksw_issue.json")
+        if args.groups == 1:
+            pv = next((x for x in (os.path.join(ROOT, "profiles", nm) for nm in ("r04_pmc_ksw_issue.json", "r03_pmc_ksw_issue.json")) if os.path.exists(x)), pv)
         if os.path.exists(pv):
             pj2 = json.load(open(pv))
             comp = pj2.get("summary") or {"source": pj2.get("source"), "reading": pj2.get("reading"), "kernels": {k: {"valu_utilisation": v["valu_utilisation"], "waves_per_simd": v["waves_per_simd"], "wave_time_share": v["wave_time_share"]} for k, v in pj2.get("kernels", {}).items()}}

@@ -559,7 +559,7 @@ int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vecto
     fast.assign(nq, 0);
     static const bool no_ring = getenv("NSGPU_CHAIN_NO_RING") != nullptr;       // A/B switch: long lists through the general kernel, as before
     // lists from this length on go to the level kernel (a workgroup per list; 0 = never): such lists come from repeats
-    static const uint64_t level_min = [] { const char *e = getenv("NSGPU_CHAIN_LEVEL_MIN"); return e ? (uint64_t)atoll(e) : (uint64_t)2048; }();
+    static const uint64_t level_min = [] { const char *e = getenv("NSGPU_CHAIN_LEVEL_MIN"); return e ? (uint64_t)atoll(e) : (uint64_t)768; }();
     par_for(nq, [&](size_t q) {
         const uint64_t n = off[q + 1] - off[q];
         if (n == 0) return;

@@ -179,7 +179,7 @@ g.close()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("level_min", ["2048", "1", "0"])
+@pytest.mark.parametrize("level_min", ["768", "1", "0"])
 def test_level_kernel_on_tandem_repeat_lists(level_min):
     """chain_forward_level_kernel (a workgroup per long list: the anchors of one reference position on sixteen waves at once): f / p identical to
     the sequential loop, and the chains through the product's backtracking identical to the REFERENCE's mm_chain_dp, on real tandem-repeat
