@@ -736,10 +736,9 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
     static const int kWgThreads[3] = {0, 256, 256}, kWgMaxPos[3] = {0, 5, 8};      // widest sweep served: 1280 / 2048 cells (256 x 5 / 8 or 512 x 3 / 4)
     static const bool no_wg = getenv("NSGPU_KSW_NO_WG") != nullptr;      // debugging aid: fallback kernels only
     static const bool wg512 = getenv("NSGPU_KSW_WG256") == nullptr;     // 512 threads per long problem (8 waves; NSGPU_KSW_WG256=1: 4 waves)
-    // latency twins of the one-wave classes (ksw2_reg.hip: one 128-cell block per wave) for exact-mode problems with at least
-    // NSGPU_KSW_LATENCY_ROWS anti-diagonals.  Off by default.  Measured at the one-group schedule, where a whole round waits for its DP launch
-    // (cfg2, 80 builders, interleaved A/B): 700 rows: wait for the DP 5.4 instead of 4.7 s per step, whole path 72.4 instead of 76.6 Mbases/s;
-    // 400 / 1000 rows the same picture -- a barrier per anti-diagonal costs more than the second block of a lane saves.
+    // (latency twins of the one-wave classes -- one 128-cell block per wave for exact problems with many anti-diagonals -- were measured at the
+    // one-group schedule in round 3: 700 rows: wait for the DP 5.4 instead of 4.7 s per step; a barrier per anti-diagonal costs more than the
+    // second block of a lane saves.  Removed.)
     size_t p_total = 0, cig_total = 0, hbm_stride = 0;
     // per-problem sizes and classes on all host threads (a batch has ~10^4 problems and this thread is on the slot's critical
     // path), then one short serial pass for the running offsets and the class lists
@@ -1174,8 +1173,7 @@ int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr
     const KswClassCfg &kc = ksw_class_config();
     // the classes the plan kernel's rule (ksw_launch_class_hd) can name under the current switches
     uint32_t classes = 1u << 0 | 1u << 1;
-    classes |= kc.books ? 1u << 6 : (kc.four ? 1u << 2 : 1u << 8);          // (the widest classes are not planned on the device: plan.hip)
-    if (kc.latency_rows > 0) classes |= 1u << 4 | 1u << 5;
+    classes |= 1u << 8;                                                      // (the widest class is not planned on the device: plan.hip)
     if (kc.sys) classes = (classes & ~(1u << 1)) | 1u << 9 | 1u << 10 | (kc.sys >= 2 ? 1u << 11 : 0u);
     if (two_phase && kc.long_rows > 0) classes |= 1u << 12;
     W.dv_classes = classes;

@@ -36,7 +36,7 @@ int ksw_batch_collect(nsgpu_ctx *c, std::vector<KswTask> &tasks, std::vector<Ksw
 
 // second generation (ksw2_reg.hip): DP state in registers, packed int16 arithmetic
 #define KSW_REG_CLASSES 13
-int ksw_reg_class(const KswTask &t, const KswParams &pr, int latency_rows = 0);          // 0 .. KSW_REG_CLASSES-1, or -1 (first-generation kernels)
+int ksw_reg_class(const KswTask &t, const KswParams &pr);          // 0 .. KSW_REG_CLASSES-1, or -1 (first-generation kernels)
 int ksw_reg_cells(int cls);                                        // widest tlen the class serves
 int ksw_reg_threads(int cls);
 size_t ksw_reg_lds_bytes(int cls, int qlen);

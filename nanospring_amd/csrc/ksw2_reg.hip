@@ -348,16 +348,14 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
                             uint32_t *__restrict__ cig_pool, KswResult *__restrict__ res_out, uint8_t *lds)
 {
     static_assert(!FAST || (APPROX && NW == 1), "the path-independent score is used by the one-wave gap-fill classes");
-    // An ODD number of waves (> 1) means: wave 0 owns no cells and only keeps the books (row maximum, mte / mqe, Z-drop, early exit: the
-    // ~100 dependent instructions per row that sat in front of wave 0's own cells on every row's critical path); the other NW - 1 waves
-    // compute.  With an even NW wave 0 does both, as before.
-    constexpr bool BK = NW > 1 && (NW & 1) != 0;
-    constexpr int NWC = BK ? NW - 1 : NW;        // computing waves
+    // (a variant with a wave that owns no cells and only keeps the books -- an odd wave count -- was measured in round 3 and did not pay:
+    // the bookkeeping of row r - 1 already runs behind the barrier of row r; removed.  Every wave computes.)
+    constexpr int NWC = NW;                      // computing waves
     constexpr int T = NWC * NCH * 128;
     constexpr int NB = NWC * NCH;                // blocks of 128 cells
     const int lane = threadIdx.x & 63, wv = NW > 1 ? (int)(threadIdx.x >> 6) : 0;
-    const int cw = BK ? wv - 1 : wv;             // index among the computing waves; -1: the books wave
-    const bool computes = !BK || wv > 0;
+    const int cw = wv;                           // index among the computing waves
+    constexpr bool computes = true;
     const int qlen = tk.qlen, tlen = tk.tlen, flag = tk.flag, zdrop = tk.zdrop;
     Consts K;
     K.q = pr.q, K.e = pr.e, K.q2 = pr.q2, K.e2 = pr.e2;
@@ -444,7 +442,7 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
     // four published cells cover that: uv4).  KSW_EZ_NS_ALL_BOOKS (NSGPU_KSW_ALL_BOOKS=1) keeps the books in every wave, as before.
     // KSW_EZ_NS_NO_SCORE: the score is all these books produce (no KSW_EZ_APPROX_DROP): nobody keeps them
     const bool nob = APPROX && (flag & KSW_EZ_NS_NO_SCORE) && !(flag & KSW_EZ_APPROX_DROP);
-    const bool ROT = APPROX && NW > 1 && !BK && !(flag & KSW_EZ_NS_ALL_BOOKS) && !nob;
+    const bool ROT = APPROX && NW > 1 && !(flag & KSW_EZ_NS_ALL_BOOKS) && !nob;
     int Lpub = 0, Lpub_prev = 0;                        // last_H0_t the current / the previous row's publication is relative to
     auto books_load = [&](const int *sp) { last_H0_t = sp[0], H0 = sp[2], z.max = sp[3], z.max_t = sp[4], z.max_q = sp[5], ez_score = sp[6]; };
     if (ROT) {
@@ -1137,13 +1135,12 @@ __global__ __launch_bounds__(NW * 64) void ksw_extd2_reg_kernel(const KswTask *_
 // thousand bases against a few hundred) are latency: the launch is over when its longest problem is, so they get one 128-cell block per
 // wave and row.
 struct RegClass { int nw, nch; };
-// Classes 4 and 5 are the latency twins of 0 and 1 (same widths, one block per wave): for exact-mode problems with many anti-diagonals when
-// a DP launch is waited for by a whole round of the contig stage (few builders, one group) rather than overlapped with other groups' work.
-// Classes 6 and 7 are 2 and 3 with a books wave (an odd wave count: see ksw_reg_run): measured, not faster, off by default.
+// Classes 2 and 4 .. 7 are retired (<4,3>, the latency twins <2,1> / <4,1>, <5,3> / <9,5> with a books wave: measured in rounds 2-3, slower;
+// their numbers stay unused so that the others keep theirs).
 // Classes 9 .. 11 are the systolic kernel (ksw_sys_run: four computing waves on contiguous stretches of 128 / 256 / 384 cells and the books wave).
 // Class 12 is <1,4> once more: the long problems of the one-wave classes in a launch of their own (device-planned batches, ksw_class.hpp).
-constexpr RegClass kRegClass[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {4, 3}, {8, 5}, {2, 1}, {4, 1}, {5, 3}, {9, 5}, {6, 2}, {5, 1}, {5, 2}, {5, 3}, {1, 4}};
-constexpr int reg_compute_waves(int cls) { return cls >= 9 && cls <= 11 ? kSysWaves : kRegClass[cls].nw > 1 && (kRegClass[cls].nw & 1) ? kRegClass[cls].nw - 1 : kRegClass[cls].nw; }
+constexpr RegClass kRegClass[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {6, 2}, {8, 5}, {1, 2}, {1, 4}, {6, 2}, {8, 5}, {6, 2}, {5, 1}, {5, 2}, {5, 3}, {1, 4}};
+constexpr int reg_compute_waves(int cls) { return cls >= 9 && cls <= 11 ? kSysWaves : kRegClass[cls].nw; }
 
 }  // namespace
 
@@ -1164,12 +1161,6 @@ size_t ksw_reg_lds_bytes(int cls, int qlen)
 // adjusted gap terms, 16-bit H keys) hold for minimap2-sized scores and gap costs and for problems that fit a class.  The rule itself is
 // ksw_class.hpp's (shared with the device-side alignment plan); the switches are read here, once:
 //   NSGPU_KSW_NO_REG       debugging aid: first-generation kernels only
-//   NSGPU_KSW_BOOKS_WAVE   <5,3> / <9,5> (a books wave) instead of the even wave counts.  Measured (cfg2, default schedule, interleaved A/B):
-//                          does NOT pay -- wait for the DP 4.64 instead of 4.50 s per step: the bookkeeping of row r - 1 already runs behind
-//                          the barrier of row r while the other waves compute, it was not on the critical path
-//   NSGPU_KSW_FOUR_WAVES   <4,3> instead of <6,2> for targets of 513 .. 1536 (tools/bench_ksw_rows.py: <6,2> 1.22 / 1.34 / 1.41 instead of
-//                          1.41 / 1.47 / 1.50 us per anti-diagonal on gap fills of 600 / 930 / 1500)
-//   NSGPU_KSW_LATENCY_ROWS one-block-per-wave twins of the one-wave classes for exact-mode problems with that many anti-diagonals (off)
 //   NSGPU_KSW_PROMOTE_ROWS the long problems of the narrowest class go with the <1,4> launch (ksw2.hip; default 520)
 // (all bit-exact either way)
 const KswClassCfg &ksw_class_config()
@@ -1177,9 +1168,6 @@ const KswClassCfg &ksw_class_config()
     static const KswClassCfg cfg = [] {
         KswClassCfg k;
         k.off = getenv("NSGPU_KSW_NO_REG") != nullptr;
-        k.books = getenv("NSGPU_KSW_BOOKS_WAVE") != nullptr;
-        k.four = getenv("NSGPU_KSW_FOUR_WAVES") != nullptr;
-        k.latency_rows = getenv("NSGPU_KSW_LATENCY_ROWS") ? atoi(getenv("NSGPU_KSW_LATENCY_ROWS")) : 0;
         k.promote_rows = getenv("NSGPU_KSW_PROMOTE_ROWS") ? atoi(getenv("NSGPU_KSW_PROMOTE_ROWS")) : 520;
         k.long_rows = getenv("NSGPU_KSW_LONG_ROWS") ? atoi(getenv("NSGPU_KSW_LONG_ROWS")) : 900;
         k.sys = getenv("NSGPU_KSW_SYS") ? atoi(getenv("NSGPU_KSW_SYS")) : 0;       // the systolic kernel (classes 9 .. 11) for targets beyond 256 columns and the long narrow problems
@@ -1192,11 +1180,9 @@ const KswClassCfg &ksw_class_config()
     return cfg;
 }
 
-int ksw_reg_class(const KswTask &t, const KswParams &pr, int latency_rows)
+int ksw_reg_class(const KswTask &t, const KswParams &pr)
 {
-    KswClassCfg cfg = ksw_class_config();
-    cfg.latency_rows = latency_rows;
-    return ksw_reg_class_hd(t.qlen, t.tlen, t.w, t.flag, pr, cfg);
+    return ksw_reg_class_hd(t.qlen, t.tlen, t.w, t.flag, pr, ksw_class_config());
 }
 
 int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const KswTask *tasks, const uint32_t *order, const KswParams &pr, const uint8_t *seqs,
@@ -1218,12 +1204,7 @@ int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const 
     switch (cls) {
     case 0: NS_REG_LAUNCH(1, 2) break;
     case 1: NS_REG_LAUNCH(1, 4) break;
-    case 2: NS_REG_LAUNCH(4, 3) break;
     case 3: NS_REG_LAUNCH(8, 5) break;
-    case 4: NS_REG_LAUNCH(2, 1) break;
-    case 5: NS_REG_LAUNCH(4, 1) break;
-    case 6: NS_REG_LAUNCH(5, 3) break;
-    case 7: NS_REG_LAUNCH(9, 5) break;
     case 8: NS_REG_LAUNCH(6, 2) break;
 #define NS_SYS_LAUNCH(NCH_)                                                                                                                   \
     {                                                                                                                                         \

@@ -12,9 +12,6 @@ namespace nsgpu {
 // the A/B switches of the class choice, read from the environment once on the host (ksw_class_config) and handed to device code by value
 struct KswClassCfg {
     int32_t off;               // NSGPU_KSW_NO_REG: first-generation kernels only
-    int32_t books;             // NSGPU_KSW_BOOKS_WAVE
-    int32_t four;              // NSGPU_KSW_FOUR_WAVES
-    int32_t latency_rows;      // NSGPU_KSW_LATENCY_ROWS (0 = off)
     int32_t promote_rows;      // NSGPU_KSW_PROMOTE_ROWS (default 520; negative = off)
     int32_t flag_or;           // KSW_EZ_NS_* bits the host adds to every task
     int32_t sys;               // NSGPU_KSW_SYS: the systolic kernel (classes 9 .. 11, ksw2_reg.hip ksw_sys_run) instead of <1,4> / <6,2>
@@ -32,11 +29,12 @@ __host__ __device__ inline size_t ksw_p_bytes_hd(int qlen, int tlen, int w)
     return ((size_t)(qlen + tlen - 1) * n_col_ + 1) * 16;
 }
 
-// cells per row the register classes 0..3 hold: <1,2> <1,4> <4,3> <8,5> (their twins / variants serve the same widths)
+// cells per row the width classes hold: <1,2> <1,4> <6,2> (class 8) <8,5>.  Class numbers 2 and 4 .. 7 belonged to variants that were
+// measured and lost (<4,3>; the latency twins <2,1> / <4,1>; <5,3> / <9,5> with a books wave: DESIGN.md section 4) and are retired.
 __host__ __device__ inline int ksw_reg_width(int c) { return c == 0 ? 256 : c == 1 ? 512 : c == 2 ? 1536 : 5120; }
 
 // ksw2_reg.hip's eligibility proofs + the class by target width; -1: not for the register kernels
-__host__ __device__ inline int ksw_reg_class_hd(int qlen, int tlen, int w_in, int flag, const KswParams &pr, const KswClassCfg &cfg)
+__host__ __device__ inline int ksw_reg_class_hd(int qlen, int tlen, int w_in, int /*flag*/, const KswParams &pr, const KswClassCfg &cfg)
 {
     if (cfg.off || qlen <= 0 || tlen <= 0) return -1;
     int q = pr.q, e = pr.e, q2 = pr.q2, e2 = pr.e2;
@@ -55,14 +53,7 @@ __host__ __device__ inline int ksw_reg_class_hd(int qlen, int tlen, int w_in, in
             // four waves on 128 / 256 contiguous cells each, no barrier (384 cells per wave -- class 11 -- lose to <6,2>: tools/bench_ksw_rows.py)
             if (cfg.sys && (c == 1 || (c == 2 && tlen <= 1024))) return c == 1 ? 9 : 10;
             if (cfg.sys >= 2 && c == 2) return 11;
-            if (c >= 2 && cfg.books) return 4 + c;                                              // <5,3> / <9,5>
-            if (c == 2 && !cfg.four) return 8;                                                  // <6,2>
-            if (c < 2 && cfg.latency_rows > 0 && !(flag & 0x08 /* KSW_EZ_APPROX_MAX */)) {
-                // anti-diagonals the sweep can take: all of them, or until the band runs out
-                const long long full = (long long)qlen + tlen - 1, band = 2ll * (tlen - 1) + w + 1;
-                if ((full < band ? full : band) >= cfg.latency_rows) return 4 + c;
-            }
-            return c;
+            return c == 2 ? 8 : c;                                                              // (513 .. 1536 columns: <6,2>)
         }
     return -1;
 }

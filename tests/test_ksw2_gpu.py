@@ -230,10 +230,11 @@ print("RESULT", bad, len(probs))
 '''
 
 
-@pytest.mark.parametrize("env", [{"NSGPU_KSW_LATENCY_ROWS": "200"}, {"NSGPU_KSW_LATENCY_ROWS": "200", "NSGPU_KSW_NO_EARLY_EXIT": "1"}, {"NSGPU_KSW_NO_EARLY_EXIT": "1"}, {"NSGPU_KSW_BOOKS_WAVE": "1"}, {"NSGPU_KSW_FOUR_WAVES": "1"}, {"NSGPU_KSW_SERIAL_BACKTRACK": "1"}, {"NSGPU_KSW_ALL_BOOKS": "1"}, {"NSGPU_KSW_PROMOTE_ROWS": "0"}, {"NSGPU_KSW_SYS": "2"}, {"NSGPU_KSW_SYS": "2", "NSGPU_KSW_PROMOTE_ROWS": "0"}])
+@pytest.mark.parametrize("env", [{"NSGPU_KSW_NO_EARLY_EXIT": "1"}, {"NSGPU_KSW_SERIAL_BACKTRACK": "1"}, {"NSGPU_KSW_ALL_BOOKS": "1"}, {"NSGPU_KSW_PROMOTE_ROWS": "0"}, {"NSGPU_KSW_SYS": "2"}, {"NSGPU_KSW_SYS": "2", "NSGPU_KSW_PROMOTE_ROWS": "0"}])
 def test_latency_classes_and_early_exit_switches(env):
-    """The latency twins of the one-wave register classes (one 128-cell block per wave: <2,1>, <4,1>; the contig stage with one group
-    uses them for exact-mode problems with many anti-diagonals) and the early exit, each on and off: bit-exact against the oracle."""
+    """The A/B switches of the register DP kernels that are still in the code -- the exact early exit, the one-lane traceback walk, books in
+    every wave, the promotion rule of long narrow problems, the systolic kernel -- each against the oracle on problems with many
+    anti-diagonals: bit-exact either way."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
