@@ -473,56 +473,86 @@ int batch_plan_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int see
 
 // the device-planned results into the jobs' caches (every task of every alignment the kernel planned: the jobs look them up by key); part 0:
 // what a two-part batch has ready early, part 1: everything that has not been delivered yet
-int batch_plan_deliver(nsgpu_ctx *c, AlignBatch &B, int part)
+}  // namespace
+
+// The device-planned results in two steps: wait for a part of them (0: behind the bulk classes; 1: behind everything -- the workspace is
+// handed back), then per request the copy of its problems' results into the job's cache.  A caller may do the second step for disjoint
+// requests on several threads (the contig engine does it inside each builder's own task).
+int batch_plan_wait(nsgpu_ctx *c, AlignBatch &B, int part, KswDevResults &R)
 {
-    using namespace mm2;
+    R = KswDevResults{nullptr, nullptr, nullptr, nullptr};
     if (B.plan_ws < 0) return NSGPU_OK;
     const int ws = B.plan_ws;
     if (part == 1) B.plan_ws = -1;
-    KswDevResults R;
     NS_TRY(ksw_dev_collect(c, ws, part, R));
-    if (!R.res) return NSGPU_OK;
+    if (!R.res || part != 1) return NSGPU_OK;
     const PlanOut *po = B.plan_out.as<PlanOut>();
-    const PlanKey *keys = B.plan_keys.as<PlanKey>();
-    std::atomic<uint64_t> n_tasks{0}, n_lost{0};
-    parallel_for("align.dp_deliver", B.plan_pair.size(), [&](size_t i) {
-        if (B.plan_pair[i] == ~0u || B.plan_delivered[i]) return;
-        const uint32_t q = B.plan_pair[i];
-        const PlanOut o = po[q];
-        if (o.flags || o.n_tasks == 0) return;
-        if (part == 0 && o.slow) return;
-        const uint32_t st = __atomic_load_n(&R.status[q], __ATOMIC_ACQUIRE);
-        if (st != 1u) { if (part == 1) n_lost += 1; return; }        // (2: the CIGAR arena overflowed: the job asks for its problems again)
-        B.plan_delivered[i] = 1;
-        AlignJob &J = B.jobs[i];
-        if (J.finished) return;
-        for (uint32_t t = 0; t < o.n_tasks; ++t) {
-            const uint32_t slot = B.plan_base[i] + t;
-            const KswResult &r = R.res[slot];
-            DpResult d;
-            d.max = r.max; d.zdropped = r.zdropped; d.max_q = r.max_q; d.max_t = r.max_t; d.mqe = r.mqe; d.mqe_t = r.mqe_t; d.mte = r.mte;
-            d.mte_q = r.mte_q; d.score = r.score; d.reach_end = r.reach_end;
-            DpKey k;
-            memcpy(&k, &keys[slot], sizeof(DpKey));
-            J.cache.put(k, d, R.cig + R.coff[slot], (uint32_t)r.n_cigar);
-        }
-        n_tasks += o.n_tasks;
-    });
-    if (part == 1) {
-        uint64_t n_dev = 0, n_host = 0;
-        for (size_t i = 0; i < B.plan_pair.size(); ++i) {
-            if (B.plan_pair[i] == ~0u) { ++n_host; continue; }
-            const PlanOut o = po[B.plan_pair[i]];
-            if (o.flags) ++n_host; else ++n_dev;
-            for (int bit = 0; bit < 8; ++bit) if (o.flags >> bit & 1) __atomic_fetch_add(&c->plan_why[bit], 1, __ATOMIC_RELAXED);
-        }
-        n_host += B.reqs.size() - B.plan_pair.size();
-        std::lock_guard<std::mutex> lk(c->stat_m);
-        c->plan_pairs_dev += n_dev, c->plan_pairs_host += n_host;
+    uint64_t n_dev = 0, n_host = 0;
+    for (size_t i = 0; i < B.plan_pair.size(); ++i) {
+        if (B.plan_pair[i] == ~0u) { ++n_host; continue; }
+        const PlanOut o = po[B.plan_pair[i]];
+        if (o.flags) ++n_host; else ++n_dev;
+        for (int bit = 0; bit < 8; ++bit) if (o.flags >> bit & 1) __atomic_fetch_add(&c->plan_why[bit], 1, __ATOMIC_RELAXED);
     }
+    n_host += B.reqs.size() - B.plan_pair.size();
+    std::lock_guard<std::mutex> lk(c->stat_m);
+    c->plan_pairs_dev += n_dev, c->plan_pairs_host += n_host;
+    return NSGPU_OK;
+}
+// request i's problems from the results of `part` into its job's cache; returns how many (0: not this part's, not planned, lost, or done before).
+// Part 1 takes whatever has not been delivered yet unless own_part_only.
+uint32_t batch_plan_deliver_one(AlignBatch &B, const KswDevResults &R, size_t i, int part, bool own_part_only)
+{
+    using namespace mm2;
+    if (!R.res || i >= B.plan_pair.size() || B.plan_pair[i] == ~0u || B.plan_delivered[i]) return 0;
+    const uint32_t q = B.plan_pair[i];
+    const PlanOut o = B.plan_out.as<PlanOut>()[q];
+    if (o.flags || o.n_tasks == 0) return 0;
+    if (part == 0 && o.slow) return 0;
+    if (own_part_only && part == 1 && !o.slow) return 0;         // (two threads, one per part: the first part's requests are the other thread's)
+    const uint32_t st = __atomic_load_n(&R.status[q], __ATOMIC_ACQUIRE);
+    if (st != 1u) return 0;                            // (2: the CIGAR arena overflowed: the job asks for its problems again)
+    B.plan_delivered[i] = 1;
+    AlignJob &J = B.jobs[i];
+    if (J.finished) return 0;
+    const PlanKey *keys = B.plan_keys.as<PlanKey>();
+    for (uint32_t t = 0; t < o.n_tasks; ++t) {
+        const uint32_t slot = B.plan_base[i] + t;
+        const KswResult &r = R.res[slot];
+        DpResult d;
+        d.max = r.max; d.zdropped = r.zdropped; d.max_q = r.max_q; d.max_t = r.max_t; d.mqe = r.mqe; d.mqe_t = r.mqe_t; d.mte = r.mte;
+        d.mte_q = r.mte_q; d.score = r.score; d.reach_end = r.reach_end;
+        DpKey k;
+        memcpy(&k, &keys[slot], sizeof(DpKey));
+        J.cache.put(k, d, R.cig + R.coff[slot], (uint32_t)r.n_cigar);
+    }
+    return o.n_tasks;
+}
+// the job of request i to its end if everything it asked for has arrived: its AlnOut is final (B.early_done[i]) -- a job that asks for more (a
+// Z-drop's second pass) waits for align_finish's rounds; nothing of a job with a problem in the host-planned batch in flight is touched
+bool align_early_one(AlignBatch &B, size_t i, mm2::AlnOut &out)
+{
+    using namespace mm2;
+    if (!B.plan_delivered[i] || B.early_done[i]) return false;
+    AlignJob &J = B.jobs[i];
+    if (!J.finished) { if (!J.cache.missing.empty()) return false; J.step(); }        // (missing: what the plan pass asked for beyond the device's problems)
+    if (!J.finished) return false;
+    out.reset();
+    align_read_result(J, B.reqs[i].ref, B.reqs[i].ref_len, out);
+    B.early_done[i] = 1;
+    return true;
+}
+
+namespace {
+int batch_plan_deliver(nsgpu_ctx *c, AlignBatch &B, int part)
+{
+    KswDevResults R;
+    NS_TRY(batch_plan_wait(c, B, part, R));
+    if (!R.res) return NSGPU_OK;
+    std::atomic<uint64_t> n_tasks{0};
+    parallel_for("align.dp_deliver", B.plan_pair.size(), [&](size_t i) { n_tasks += batch_plan_deliver_one(B, R, i, part, false); });
     std::lock_guard<std::mutex> lk(c->stat_m);
     c->aln_dp_tasks += n_tasks.load();
-    (void)n_lost;
     return NSGPU_OK;
 }
 
@@ -855,31 +885,20 @@ int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs)
     return NSGPU_OK;
 }
 
-int align_finish_early(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs, std::vector<uint8_t> &ready)
+// The device-planned results of part `part` (0: the alignments without a problem in a late class, behind the bulk classes; 1: the others,
+// behind everything): the jobs whose every problem has arrived run their skeleton to the end and are converted; ready[i] = 1 for those.
+// The caller sizes outs and B.early_done (one flag per request, zeroed) before the first part.
+int align_finish_early(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs, std::vector<uint8_t> &ready, int part)
 {
     using namespace mm2;
     const size_t n_pairs = B.reqs.size();
     ready.assign(n_pairs, 0);
-    B.early_done.clear();
     if (n_pairs == 0 || B.plan_ws < 0 || !B.plan_two_part) return NSGPU_OK;
-    if (outs.size() < n_pairs) outs.resize(n_pairs);
+    NS_CHECK(outs.size() >= n_pairs && B.early_done.size() == n_pairs, NSGPU_ERR_ARG, "align_finish_early: result vectors not sized by the caller");
     const double a0 = now_ms();
-    NS_TRY(batch_plan_deliver(c, B, 0));
-    g_finish_ms[0] += now_ms() - a0;
-    B.early_done.assign(n_pairs, 0);
-    // the jobs whose every problem has arrived run their skeleton to the end now (a job that asks for more -- a Z-drop's second pass -- waits for
-    // align_finish's rounds); nothing of a job with a problem in the host-planned batch in flight is touched
-    const double b0 = now_ms();
-    parallel_for("align.early", n_pairs, [&](size_t i) {
-        if (!B.plan_delivered[i]) return;
-        AlignJob &J = B.jobs[i];
-        if (!J.finished) { if (!J.cache.missing.empty()) return; J.step(); }        // (missing: what the plan pass asked for beyond the device's problems)
-        if (!J.finished) return;
-        outs[i].reset();
-        align_read_result(J, B.reqs[i].ref, B.reqs[i].ref_len, outs[i]);
-        B.early_done[i] = 1, ready[i] = 1;
-    });
-    B.host_ms += now_ms() - b0;
+    NS_TRY(batch_plan_deliver(c, B, part));
+    if (part == 0) g_finish_ms[0] += now_ms() - a0;
+    parallel_for("align.early", n_pairs, [&](size_t i) { if (align_early_one(B, i, outs[i])) ready[i] = 1; });
     return NSGPU_OK;
 }
 

@@ -349,7 +349,8 @@ struct Engine {
     std::vector<TailCopy> tail_jobs;
     PinBuf pin_tail;                                // the scatter kernel's job descriptors
     std::vector<uint8_t> cons_changed;              // per builder of the batch: its consensus changed since the batch before
-    std::vector<uint8_t> early_ready; std::vector<uint32_t> early_pends, early_todo;      // scratch of engine_early_updates
+    std::vector<uint32_t> early_pends; std::vector<int32_t> early_widx; std::vector<uint8_t> early_sure;      // scratch of engine_early_updates
+    double early_part_ms[2] = {0, 0}, early_task_ms = 0, early_task_max_ms = 0, early_conv_ms = 0;     // debug report: wall of the two parts' loops, sum / per-slot maximum of their tasks, skeleton + conversion inside
     uint64_t n_early = 0; double early_ms = 0;       // graph updates run ahead of the slot's end / wall of that (debug print)
     std::vector<ConsJob> cons_jobs;
     PinBuf pin_cons;                                // cons_update_kernel's job descriptors
@@ -1112,37 +1113,83 @@ static int engine_early_updates(nsgpu_ctx *c, int group)
     AlignBatch &AB = E->ab[gi];
     if (who.empty() || !AB.plan_two_part) return NSGPU_OK;
     const double g0 = now_ms();
-    std::vector<uint8_t> &ready = E->early_ready;
-    NS_TRY(align_finish_early(c, AB, E->outs, ready));
     const size_t n = who.size();
+    if (E->outs.size() < n) E->outs.resize(n);
+    AB.early_done.assign(n, 0);
     // contested reads: two builders of the batch align the same one (the lower builder's claim decides)
     std::vector<uint32_t> &pends = E->early_pends;
     pends.resize(n);
     for (size_t w = 0; w < n; ++w) pends[w] = D.B[who[w]].pend;
     std::vector<uint32_t> sorted(pends);
     std::sort(sorted.begin(), sorted.end());
-    std::vector<uint32_t> &todo = E->early_todo;
-    todo.clear();
+    // builder -> its request in the batch, and whether its claim cannot fail
+    std::vector<int32_t> &widx = E->early_widx;
+    widx.assign(D.B.size(), -1);
+    std::vector<uint8_t> &sure = E->early_sure;
+    sure.assign(n, 0);
     for (size_t w = 0; w < n; ++w) {
-        if (!ready[w]) continue;
-        Builder &b = D.B[who[w]];
-        std::swap(b.aln, E->outs[w]);
-        b.early_result = true;
+        widx[who[w]] = (int32_t)w;
         const auto range = std::equal_range(sorted.begin(), sorted.end(), pends[w]);
-        if (b.aln.ok && range.second - range.first == 1 && !D.in_graph[b.pend] && E->world == 1) todo.push_back(who[w]);
+        sure[w] = range.second - range.first == 1 && !D.in_graph[pends[w]] && E->world == 1;
     }
-    par_for_pinned("host.early", D.B.size(), [&](size_t i) {
-        // (pinned like the host phase: a builder's graph stays with one thread's caches)
-        if (!std::binary_search(todo.begin(), todo.end(), (uint32_t)i)) return;
-        Builder &b = D.B[i];
-        const double t0 = now_ms();
-        D.apply_alignment(b);
-        plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k);
-        b.sp_ready = true;
-        b.early_updated = true;
-        b.cpu_ms += now_ms() - t0;
-    });
-    E->n_early += todo.size();
+    // One part of the results (0: the alignments without a problem in a late class, there behind the bulk classes; 1: the others): ONE task per
+    // builder, on the thread its graph lives with -- its problems' results into its job, the skeleton to the end, the conversion, and when
+    // its claim cannot fail the graph update.  The two parts touch disjoint builders; the second part's thread starts its loop when the late
+    // classes are done, some 0.2 ms behind the first, and the two loops share the pool: a builder of the second part is not held up by the
+    // first part's slowest update (it used to wait for that, then for the claims, and was updated in the next host phase).
+    std::atomic<uint64_t> n_updates{0}, n_tasks{0};
+    std::atomic<uint64_t> task_ns{0}, task_max_ns{0}, conv_ns{0};
+    auto run_part = [&](int part, const KswDevResults &R) {
+        const double p0 = now_ms();
+        struct Fin { Engine *E; int part; double p0; ~Fin() { E->early_part_ms[part] += now_ms() - p0; } } fin{E, part, p0};
+        // (pinned like the host phase: a builder's graph stays with one thread's caches; handing the tasks out longest-first to whichever thread
+        // is free measured the same -- the loop is as long as its longest task, 0.7 ms, and as the tasks' sum over the cores, 0.65 ms)
+        par_for_pinned("host.early", D.B.size(), [&](size_t i) {
+            const int32_t w = widx[i];
+            if (w < 0) return;
+            // (only what THIS call delivered is touched: the other part's builders are the other thread's)
+            const double k0 = now_ms();
+            struct Tk { std::atomic<uint64_t> &sum, &mx; double k0; ~Tk() { const uint64_t d = (uint64_t)((now_ms() - k0) * 1e6); sum += d; uint64_t m = mx.load(); while (d > m && !mx.compare_exchange_weak(m, d)) {} } } tk{task_ns, task_max_ns, k0};
+            const uint32_t got = batch_plan_deliver_one(AB, R, (size_t)w, part, true);
+            if (!got) return;
+            n_tasks += got;
+            if (!align_early_one(AB, (size_t)w, E->outs[w])) return;
+            conv_ns += (uint64_t)((now_ms() - k0) * 1e6);
+            Builder &b = D.B[i];
+            std::swap(b.aln, E->outs[w]);
+            b.early_result = true;
+            if (!(b.aln.ok && sure[w])) return;
+            const double t0 = now_ms();
+            D.apply_alignment(b);
+            plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k);
+            b.sp_ready = true;
+            b.early_updated = true;
+            b.cpu_ms += now_ms() - t0;
+            n_updates += 1;
+        });
+    };
+    static const bool one_part_early = getenv("NSGPU_EARLY_ONE_PART") != nullptr;        // A/B switch: only the first part runs ahead, as in the first version
+    int rc1 = NSGPU_OK;
+    std::string err1;
+    std::thread t1;
+    // (the second part's wait begins once the first part has been waited for: the two never race for the workspace's state)
+    KswDevResults R0;
+    const int rc0 = batch_plan_wait(c, AB, 0, R0);
+    if (rc0 == NSGPU_OK && !one_part_early)
+        t1 = std::thread([&] {
+            pool_bind_this_thread();
+            KswDevResults R1;
+            rc1 = hipSetDevice(c->prm.device) == hipSuccess ? batch_plan_wait(c, AB, 1, R1) : NSGPU_ERR_HIP;
+            if (rc1 != NSGPU_OK) err1 = nsgpu_last_error();
+            else if (R1.res) run_part(1, R1);
+        });
+    if (rc0 == NSGPU_OK && R0.res) run_part(0, R0);
+    if (t1.joinable()) t1.join();
+    if (rc0 != NSGPU_OK) return rc0;
+    if (rc1 != NSGPU_OK) { set_error("%s", err1.empty() ? "contig engine: the second part of the results failed" : err1.c_str()); return rc1; }
+    E->n_early += n_updates.load();
+    E->early_task_ms += task_ns.load() / 1e6, E->early_task_max_ms += task_max_ns.load() / 1e6, E->early_conv_ms += conv_ns.load() / 1e6;
+    { std::lock_guard<std::mutex> lk(c->stat_m); c->aln_dp_tasks += n_tasks.load(); }
     { std::lock_guard<std::mutex> lk(c->stat_m); c->cons_stats.graph_ms += now_ms() - g0; }
     E->early_ms += now_ms() - g0;
     return NSGPU_OK;
@@ -1385,6 +1432,8 @@ static void debug_report_slots(nsgpu_ctx *c, Engine *E)
     fprintf(stderr, "\n");
     fprintf(stderr, "[cons] alignments left to the host's plan, by reason (cumulative): no anchors / flagged pair %llu, several chains %llu, seed filtering %llu, outside the staged span %llu, capacity %llu, DP class %llu\n",
             (unsigned long long)c->plan_why[0], (unsigned long long)c->plan_why[1], (unsigned long long)c->plan_why[2], (unsigned long long)c->plan_why[3], (unsigned long long)c->plan_why[4], (unsigned long long)c->plan_why[5]);
+    fprintf(stderr, "[cons] early tasks: loops of part 0 / part 1 %.0f / %.0f ms wall; tasks %.0f ms in sum (delivery + skeleton + conversion %.0f), the longest of each slot %.0f ms in sum\n",
+            E->early_part_ms[0], E->early_part_ms[1], E->early_task_ms, E->early_conv_ms, E->early_task_max_ms);
     fprintf(stderr, "[cons] graph updates run ahead of the slot's end: %llu, %.0f ms wall (first part of the DP results + updates)\n", (unsigned long long)E->n_early, E->early_ms);
     fprintf(stderr, "[cons] device plan (cumulative): %llu alignments planned on the device, %llu left to the host; DP problems found %llu, not found %llu, unasked %llu\n",
             (unsigned long long)c->plan_pairs_dev, (unsigned long long)c->plan_pairs_host, (unsigned long long)c->plan_hits, (unsigned long long)c->plan_misses, (unsigned long long)c->plan_extra);

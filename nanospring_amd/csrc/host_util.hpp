@@ -163,7 +163,11 @@ int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs);
 // a two-part batch (B.plan_two_part): waits for the first part of the device-planned DP results -- the alignments none of whose problems runs in a
 // late kernel class -- and finishes those alignments (skeleton execution, alignRead's conversion into outs[i]); ready[i] = 1 for the requests that
 // are final now.  align_finish must follow; it leaves the early ones alone.
-int align_finish_early(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs, std::vector<uint8_t> &ready);
+int align_finish_early(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs, std::vector<uint8_t> &ready, int part);
+// the same in steps, for callers that run the per-request part inside their own per-builder tasks (consensus_driver.hip engine_early_updates)
+int batch_plan_wait(nsgpu_ctx *c, AlignBatch &B, int part, KswDevResults &R);
+uint32_t batch_plan_deliver_one(AlignBatch &B, const KswDevResults &R, size_t i, int part, bool own_part_only);
+bool align_early_one(AlignBatch &B, size_t i, mm2::AlnOut &out);
 int filter_strings_device(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq);   // api.hip: results stay in c->f_off / c->f_ids
 
 }  // namespace nsgpu
