@@ -162,7 +162,8 @@ struct nsgpu_ctx {
         // a batch whose tasks the plan kernel writes (plan.hip, ksw_dev_*): buffers of its own, so that a host-planned batch of the same
         // workspace may follow in the same slot.  dv_ctrl: [0..15] class counters, [16..17] overflow flags, then 8 u64: cursors (traceback bytes,
         // CIGAR entries, sequence bytes), cells, algorithmic bytes
-        nsgpu::DevBuf dv_tasks, dv_list, dv_ctrl, dv_seqs, dv_p, dv_cig, dv_res, dv_coff, dv_scan_ws;
+        nsgpu::DevBuf dv_tasks, dv_list, dv_ctrl, dv_seqs, dv_p, dv_cig, dv_res, dv_coff, dv_scan_ws, dv_tpair, dv_pdone;
+        bool dv_inline = false;                  // this batch's DP kernels hand every alignment over themselves (ksw_collect.hpp)
         nsgpu::PinBuf hv_res, hv_coff, hv_cig, hv_ctrl, hv_status;
         hipEvent_t dv_part0 = nullptr;                                  // behind the first part of a two-part batch's results
         uint32_t dv_npairs_launched = 0; bool dv_two_phase = false;

@@ -29,6 +29,8 @@
 #include <sched.h>
 #include <pthread.h>
 #include <sys/resource.h>
+#include <sys/prctl.h>
+#include <time.h>
 
 namespace nsgpu {
 namespace mm2 { extern std::atomic<uint64_t> g_step_ns[6]; }
@@ -1168,6 +1170,75 @@ static int engine_early_updates(nsgpu_ctx *c, int group)
             n_updates += 1;
         });
     };
+    // The DP kernels hand every alignment over the moment its last problem is done (ksw_collect.hpp): no parts -- every pool thread keeps looking at
+    // the status words of ITS builders' alignments (the pinned assignment of the host phase) and runs a builder's task as soon as its word is
+    // up, sleeping 10 us when nothing of its own is ready; the batch's closing word ends the watch for whatever was not handed over (a full
+    // CIGAR arena: align_finish asks for those problems again).  An alignment whose longest problem is short is finished and applied while the
+    // launch's longest problems are still running.
+    {
+        KswDevResults R;
+        const volatile uint32_t *done = nullptr;
+        if (AB.plan_ws >= 0 && ksw_dev_poll(c, AB.plan_ws, R, done)) {
+            const PlanOut *po = AB.plan_out.as<PlanOut>();
+            const size_t T = std::max<size_t>(1, (size_t)host_threads());
+            const double p0 = now_ms();
+            par_for_pinned("host.early", T, [&](size_t t) {
+                static thread_local const int slack_set = prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);      // (a 10 us sleep is 10 us, not 60)
+                (void)slack_set;
+                uint32_t mine[64];
+                size_t n_mine = 0;
+                for (size_t i = t; i < D.B.size() && n_mine < 64; i += T) {
+                    const int32_t w = widx[i];
+                    if (w < 0 || (size_t)w >= AB.plan_pair.size() || AB.plan_pair[w] == ~0u || AB.plan_delivered[w]) continue;
+                    const PlanOut o = po[AB.plan_pair[w]];
+                    if (o.flags || o.n_tasks == 0) continue;
+                    mine[n_mine++] = (uint32_t)i;
+                }
+                bool closing = false;
+                while (n_mine) {
+                    bool progressed = false;
+                    for (size_t k = 0; k < n_mine;) {
+                        const size_t i = mine[k];
+                        const int32_t w = widx[i];
+                        const uint32_t st = __atomic_load_n(&R.status[AB.plan_pair[w]], __ATOMIC_ACQUIRE);
+                        if (st == 0) { ++k; continue; }
+                        mine[k] = mine[--n_mine];
+                        progressed = true;
+                        if (st != 1u) continue;                                   // (not handed over: align_finish's rounds)
+                        const double k0 = now_ms();
+                        struct Tk { std::atomic<uint64_t> &sum, &mx; double k0; ~Tk() { const uint64_t d = (uint64_t)((now_ms() - k0) * 1e6); sum += d; uint64_t m = mx.load(); while (d > m && !mx.compare_exchange_weak(m, d)) {} } } tk{task_ns, task_max_ns, k0};
+                        const uint32_t got = batch_plan_deliver_one(AB, R, (size_t)w, 1, false);
+                        if (!got) continue;
+                        n_tasks += got;
+                        if (!align_early_one(AB, (size_t)w, E->outs[w])) continue;
+                        conv_ns += (uint64_t)((now_ms() - k0) * 1e6);
+                        Builder &b = D.B[i];
+                        std::swap(b.aln, E->outs[w]);
+                        b.early_result = true;
+                        if (!(b.aln.ok && sure[w])) continue;
+                        const double t0 = now_ms();
+                        D.apply_alignment(b);
+                        plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k);
+                        b.sp_ready = true;
+                        b.early_updated = true;
+                        b.cpu_ms += now_ms() - t0;
+                        n_updates += 1;
+                    }
+                    if (progressed || !n_mine) continue;
+                    if (closing) break;                                           // one more look after the closing word, then leave
+                    if (*done) { closing = true; continue; }
+                    timespec ts = {0, 10000};
+                    nanosleep(&ts, nullptr);
+                }
+            });
+            E->early_part_ms[0] += now_ms() - p0;
+            E->n_early += n_updates.load();
+            E->early_task_ms += task_ns.load() / 1e6, E->early_task_max_ms += task_max_ns.load() / 1e6, E->early_conv_ms += conv_ns.load() / 1e6;
+            { std::lock_guard<std::mutex> lk(c->stat_m); c->aln_dp_tasks += n_tasks.load(); c->cons_stats.graph_ms += now_ms() - g0; }
+            E->early_ms += now_ms() - g0;
+            return NSGPU_OK;
+        }
+    }
     static const bool one_part_early = getenv("NSGPU_EARLY_ONE_PART") != nullptr;        // A/B switch: only the first part runs ahead, as in the first version
     int rc1 = NSGPU_OK;
     std::string err1;

@@ -83,6 +83,7 @@ constexpr uint32_t PLAN_NONE = 1, PLAN_COMPLEX = 2, PLAN_BADSEEDS = 4, PLAN_SPAN
 struct PlanKey { int32_t qs, qe, rs, re, w, zdrop, end_bonus, flag; };      // = mm2::DpKey: what the host looks a device-planned problem up by
 struct PlanDp {            // where the plan kernel puts its DP tasks (buffers of a DP workspace, ksw2.hip ksw_dev_prepare)
     KswTask *tasks; KswResult *res; uint32_t *class_list; uint32_t *class_cnt; uint32_t n_slots;
+    uint32_t *task_pair;                                 // task slot -> alignment (for the DP kernels' own hand-over, ksw_collect.hpp)
     uint32_t class_grid[KSW_REG_CLASSES];               // workgroups the class's launch has: entries of its list beyond that are never run
     uint8_t *seqs; unsigned long long *cursors;          // cursors: traceback bytes, CIGAR entries, sequence bytes handed out so far
     unsigned long long p_cap; uint32_t cig_cap, seq_cap;
@@ -166,6 +167,7 @@ int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs);
 int align_finish_early(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs, std::vector<uint8_t> &ready, int part);
 // the same in steps, for callers that run the per-request part inside their own per-builder tasks (consensus_driver.hip engine_early_updates)
 int batch_plan_wait(nsgpu_ctx *c, AlignBatch &B, int part, KswDevResults &R);
+bool ksw_dev_poll(nsgpu_ctx *c, int ws_index, KswDevResults &out, const volatile uint32_t *&done);      // ksw2.hip
 uint32_t batch_plan_deliver_one(AlignBatch &B, const KswDevResults &R, size_t i, int part, bool own_part_only);
 bool align_early_one(AlignBatch &B, size_t i, mm2::AlnOut &out);
 int filter_strings_device(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq);   // api.hip: results stay in c->f_off / c->f_ids

@@ -24,6 +24,7 @@
 #include "common.hpp"
 #include "ksw2.hpp"
 #include "ksw_class.hpp"
+#include "ksw_collect.hpp"
 #include "host_util.hpp"
 #include <rocprim/rocprim.hpp>
 
@@ -1056,67 +1057,28 @@ int ksw_batch_collect(nsgpu_ctx *c, std::vector<KswTask> &tasks, std::vector<Ksw
 // pinned memory.
 // ---------------------------------------------------------------------------------------------------------------------------------
 namespace {
-constexpr uint32_t kDvCtrlWords = 18;                       // class counters + flags in front of the 64-bit fields
-struct DvCtrl { uint32_t class_cnt[16]; uint32_t cig_overflow, pad; unsigned long long cursors[3]; unsigned long long cells, alg_bytes, cig_out; };
-static_assert(offsetof(DvCtrl, cursors) == kDvCtrlWords * 4, "layout");
-
-// One workgroup per alignment of the part (0: none of its problems runs in a late class; 1: the others): its results as flat words, its CIGARs
-// compacted into the pinned arena at an offset taken from a device-side cursor, and the word that tells the host they are there.
-__global__ __launch_bounds__(64) void ksw_dev_collect_kernel(const PlanPair *__restrict__ pairs, const PlanOut *__restrict__ outs, uint32_t part, const KswTask *__restrict__ tasks,
-                                                             const KswResult *__restrict__ res, const uint32_t *__restrict__ pool, KswResult *__restrict__ h_res,
-                                                             uint64_t *__restrict__ h_off, uint32_t *__restrict__ h_cig, uint64_t h_cig_cap, uint32_t *__restrict__ h_status,
-                                                             DvCtrl *__restrict__ ctrl)
+// One workgroup per alignment of the part (0: none of its problems runs in a late class; 1: the others): ksw_collect.hpp's hand-over behind a whole
+// launch -- for batches whose DP kernels do not hand over themselves (NSGPU_KSW_NO_INLINE_COLLECT=1)
+__global__ __launch_bounds__(64) void ksw_dev_collect_kernel(DvCollect dc, uint32_t part)
 {
-    const uint32_t b = blockIdx.x, lane = threadIdx.x;
-    const PlanOut o = outs[b];
-    if (o.flags || o.n_tasks == 0 || (o.slow != 0) != (part != 0)) return;
-    const uint32_t s0 = pairs[b].task_base, n = o.n_tasks;          // (n <= 256: plan.hip's kMaxTasks)
-    __shared__ unsigned long long s_base;
     __shared__ uint32_t s_off[256];
-    // CIGAR entries of the alignment's tasks, their exclusive sums (tasks over lanes, 64 at a time)
-    unsigned long long total = 0, cells = 0, alg = 0;
-    for (uint32_t t0 = 0; t0 < n; t0 += 64) {
-        const uint32_t t = t0 + lane;
-        const uint32_t c = t < n ? (uint32_t)res[s0 + t].n_cigar : 0u;
-        uint32_t inc = c;
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)inc, d, 64); if ((int)lane >= d) inc += x; }
-        if (t < n) {
-            s_off[t] = (uint32_t)total + inc - c;         // relative to the alignment's base
-            const KswTask tk = tasks[s0 + t];
-            if (tk.qlen > 0 && tk.tlen > 0) cells += (unsigned long long)tk.qlen * (unsigned long long)tk.tlen, alg += (unsigned long long)tk.qlen + tk.tlen + 4ull * c + sizeof(KswResult);
-        }
-        total += (unsigned long long)(uint32_t)__shfl((int)inc, 63, 64);
-    }
-    for (int d = 32; d > 0; d >>= 1) cells += __shfl_xor((long long)cells, d, 64), alg += __shfl_xor((long long)alg, d, 64);
-    if (lane == 0) {
-        s_base = atomicAdd(&ctrl->cig_out, total);
-        atomicAdd(&ctrl->cells, cells);
-        atomicAdd(&ctrl->alg_bytes, alg);
-    }
-    __syncthreads();
-    const unsigned long long base = s_base;
-    if (base + total > h_cig_cap) {                         // the host redoes this alignment's problems (and sizes the arena for the total next time)
-        if (lane == 0) h_status[b] = 2u;
-        return;
-    }
-    {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(res + s0);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(h_res + s0);
-        for (uint32_t i = lane; i < n * (uint32_t)(sizeof(KswResult) / 4); i += 64) dst[i] = src[i];
-    }
-    for (uint32_t t = 0; t < n; ++t) {
-        const uint32_t c = (uint32_t)res[s0 + t].n_cigar;
-        const unsigned long long at = base + s_off[t];
-        const uint32_t *src = pool + tasks[s0 + t].cig_off;
-        for (uint32_t k = lane; k < c; k += 64) h_cig[at + k] = src[k];
-    }
-    for (uint32_t t = lane; t < n; t += 64) h_off[s0 + t] = base + s_off[t];
-    __threadfence_system();
-    __syncthreads();
-    if (lane == 0) h_status[b] = 1u;
+    const uint32_t b = blockIdx.x;
+    const PlanOut o = dc.outs[b];
+    if (o.flags || o.n_tasks == 0 || (o.slow != 0) != (part != 0)) return;
+    dev_collect_pair(dc, b, threadIdx.x, s_off);
 }
 
-__global__ void ksw_dev_ctrl_kernel(const DvCtrl *__restrict__ ctrl, DvCtrl *__restrict__ h_ctrl) { if (threadIdx.x == 0) *h_ctrl = *ctrl; }
+// the batch's last kernel: its counters for the host, then the word that says everything has been handed over
+__global__ void ksw_dev_ctrl_kernel(const DvCtrl *__restrict__ ctrl, DvCtrl *__restrict__ h_ctrl)
+{
+    if (threadIdx.x == 0) {
+        DvCtrl v = *ctrl;
+        v.done = 0;
+        *h_ctrl = v;
+        __threadfence_system();
+        h_ctrl->done = 1u;
+    }
+}
 }  // namespace
 
 // workgroups of a class's launch over its device-side list: every task slot for the narrow classes (the bulk), a few per alignment for the wide
@@ -1145,11 +1107,15 @@ int ksw_dev_prepare(nsgpu_ctx *c, int ws_index, uint32_t n_slots, uint32_t n_pai
     NS_TRY(W.dv_cig.reserve(cig_cap * 4));
     NS_TRY(W.dv_res.reserve((size_t)n_slots * sizeof(KswResult) + 64));
     NS_TRY(W.dv_coff.reserve(((size_t)n_slots + 2) * 8));
+    NS_TRY(W.dv_tpair.reserve((size_t)n_slots * 4 + 64));
+    NS_TRY(W.dv_pdone.reserve((size_t)n_pairs * 4 + 64));
+    NS_HIP(hipMemsetAsync(W.dv_pdone.p, 0, (size_t)n_pairs * 4 + 4, st));
     NS_HIP(hipMemsetAsync(W.dv_ctrl.p, 0, sizeof(DvCtrl), st));
     // (the task slots and their results are cleared by the plan kernel itself: every slot belongs to one alignment's wave)
     dp.tasks = W.dv_tasks.as<KswTask>(), dp.res = W.dv_res.as<KswResult>(), dp.class_list = W.dv_list.as<uint32_t>();
     dp.class_cnt = W.dv_ctrl.as<DvCtrl>()->class_cnt, dp.n_slots = n_slots, dp.seqs = W.dv_seqs.as<uint8_t>();
     dp.cursors = W.dv_ctrl.as<DvCtrl>()->cursors;
+    dp.task_pair = W.dv_tpair.as<uint32_t>();
     for (int k = 0; k < KSW_REG_CLASSES; ++k) dp.class_grid[k] = dev_class_grid(k, n_slots, n_pairs);
     dp.p_cap = p_cap, dp.cig_cap = (uint32_t)std::min<uint64_t>(cig_cap, 0xffffffffull), dp.seq_cap = (uint32_t)seq_bytes_bound;
     return NSGPU_OK;
@@ -1188,17 +1154,25 @@ int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr
     NS_TRY(W.hv_ctrl.reserve(sizeof(DvCtrl)));
     NS_TRY(W.hv_status.reserve((size_t)n_pairs * 4 + 64));
     memset(W.hv_status.p, 0, (size_t)n_pairs * 4);
+    W.hv_ctrl.as<DvCtrl>()->done = 0;
     W.dv_hcig_cap = hcap, W.dv_npairs_launched = n_pairs, W.dv_two_phase = two_phase;
+    // The DP kernels hand every alignment over themselves, the moment its last problem is done (ksw_collect.hpp) -- the host finishes and applies
+    // it while the launch's longer problems still run.  NSGPU_KSW_NO_INLINE_COLLECT=1: a collecting kernel behind the bulk classes and one
+    // behind everything, as in the first version (A/B switch).
+    static const bool no_inline = getenv("NSGPU_KSW_NO_INLINE_COLLECT") != nullptr;
+    W.dv_inline = !no_inline;
+    DvCollect dc{pairs, outs, W.dv_tasks.as<KswTask>(), W.dv_res.as<KswResult>(), W.dv_cig.as<uint32_t>(), W.dv_tpair.as<uint32_t>(), W.dv_inline ? W.dv_pdone.as<uint32_t>() : nullptr,
+                 W.hv_res.as<KswResult>(), W.hv_coff.as<uint64_t>(), W.hv_cig.as<uint32_t>(), hcap, W.hv_status.as<uint32_t>(), ctrl};
     auto launch_class = [&](int k, hipStream_t st) -> int {
         NS_HIP(hipEventRecord(W.dv_ev[2 * k], st));
         NS_TRY(ksw_reg_launch(k, st, dev_class_grid(k, n, W.dv_pairs), ksw_reg_lds_bytes(k, max_qlen), W.dv_tasks.as<KswTask>(), W.dv_list.as<uint32_t>() + (size_t)k * n, pr, W.dv_seqs.as<uint8_t>(),
-                              W.dv_p.as<uint8_t>(), W.dv_cig.as<uint32_t>(), W.dv_res.as<KswResult>(), ctrl->class_cnt + k));
+                              W.dv_p.as<uint8_t>(), W.dv_cig.as<uint32_t>(), W.dv_res.as<KswResult>(), ctrl->class_cnt + k, &dc));
         NS_HIP(hipEventRecord(W.dv_ev[2 * k + 1], st));
         return NSGPU_OK;
     };
     auto collect = [&](uint32_t part) {
-        hipLaunchKernelGGL(ksw_dev_collect_kernel, dim3(n_pairs), dim3(64), 0, S, pairs, outs, part, W.dv_tasks.as<KswTask>(), W.dv_res.as<KswResult>(), W.dv_cig.as<uint32_t>(),
-                           W.hv_res.as<KswResult>(), W.hv_coff.as<uint64_t>(), W.hv_cig.as<uint32_t>(), hcap, W.hv_status.as<uint32_t>(), ctrl);
+        if (W.dv_inline) return;
+        hipLaunchKernelGGL(ksw_dev_collect_kernel, dim3(n_pairs), dim3(64), 0, S, dc, part);
     };
     // the late classes -- the multi-wave ones (wide problems) and, in a two-part batch, the long problems of the one-wave classes -- on the side
     // streams; the bulk on the main stream, and behind it the first part of the results
@@ -1236,6 +1210,20 @@ int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr
     NS_HIP(hipGetLastError());
     W.dv_pending = true;
     return NSGPU_OK;
+}
+
+// The landing zones of the workspace's batch in flight, without waiting for anything: when its DP kernels hand the alignments over themselves
+// (ksw_collect.hpp) out.status says per alignment whether its results are there, and *done that the whole batch has been handed over.
+// false: no such batch (the caller waits for the parts with ksw_dev_collect).
+bool ksw_dev_poll(nsgpu_ctx *c, int ws_index, KswDevResults &out, const volatile uint32_t *&done)
+{
+    nsgpu_ctx::KswWs &W = c->kws[ws_index];
+    out = KswDevResults{nullptr, nullptr, nullptr, nullptr};
+    done = nullptr;
+    if (!W.dv_pending || !W.dv_inline) return false;
+    out.res = W.hv_res.as<KswResult>(), out.coff = W.hv_coff.as<uint64_t>(), out.cig = W.hv_cig.as<uint32_t>(), out.status = W.hv_status.as<uint32_t>();
+    done = &W.hv_ctrl.as<DvCtrl>()->done;
+    return true;
 }
 
 // part 0: what is behind the bulk of the one-wave problems (a two-part batch only: otherwise nothing is there before part 1); part 1: everything

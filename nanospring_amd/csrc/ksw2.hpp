@@ -40,7 +40,8 @@ int ksw_reg_class(const KswTask &t, const KswParams &pr);          // 0 .. KSW_R
 int ksw_reg_cells(int cls);                                        // widest tlen the class serves
 int ksw_reg_threads(int cls);
 size_t ksw_reg_lds_bytes(int cls, int qlen);
+struct DvCollect;          // ksw_collect.hpp: with it (device-planned batches) every problem counts itself on its alignment and the last one hands the alignment over
 int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const KswTask *tasks, const uint32_t *order, const KswParams &pr, const uint8_t *seqs,
-                   uint8_t *p_pool, uint32_t *cig_pool, KswResult *res, const uint32_t *n_dev = nullptr);       // n_dev: the count lives in device memory, m bounds it
+                   uint8_t *p_pool, uint32_t *cig_pool, KswResult *res, const uint32_t *n_dev = nullptr, const DvCollect *dc = nullptr);       // n_dev: the count lives in device memory, m bounds it
 
 }  // namespace nsgpu

@@ -26,6 +26,7 @@
 #include "common.hpp"
 #include "ksw2.hpp"
 #include "ksw_class.hpp"
+#include "ksw_collect.hpp"
 #include <mutex>
 #include "host_util.hpp"
 
@@ -1084,7 +1085,7 @@ __device__ void ksw_sys_run(const KswTask &tk, const KswParams &pr, const uint8_
 template <int NCH>
 __global__ __launch_bounds__((kSysWaves + 1) * 64) void ksw_extd2_sys_kernel(const KswTask *__restrict__ tasks, const uint32_t *__restrict__ order, uint32_t n, KswParams pr,
                                                                              const uint8_t *__restrict__ seqs, uint8_t *__restrict__ p_pool, uint32_t *__restrict__ cig_pool,
-                                                                             KswResult *__restrict__ res, const uint32_t *__restrict__ n_dev)
+                                                                             KswResult *__restrict__ res, const uint32_t *__restrict__ n_dev, DvCollect dc)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     if (n_dev) n = *n_dev;
@@ -1103,12 +1104,13 @@ __global__ __launch_bounds__((kSysWaves + 1) * 64) void ksw_extd2_sys_kernel(con
         if (right) ksw_sys_run<NCH, false, true, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
         else ksw_sys_run<NCH, false, false, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
     }
+    dev_problem_done(dc, ti, lds);
 }
 
 template <int NW, int NCH>
 __global__ __launch_bounds__(NW * 64) void ksw_extd2_reg_kernel(const KswTask *__restrict__ tasks, const uint32_t *__restrict__ order, uint32_t n, KswParams pr,
                                                                 const uint8_t *__restrict__ seqs, uint8_t *__restrict__ p_pool, uint32_t *__restrict__ cig_pool,
-                                                                KswResult *__restrict__ res, const uint32_t *__restrict__ n_dev)
+                                                                KswResult *__restrict__ res, const uint32_t *__restrict__ n_dev, DvCollect dc)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     // n_dev: the number of problems is in device memory (a list written by the plan kernel, plan.hip; the grid is an upper bound)
@@ -1129,6 +1131,7 @@ __global__ __launch_bounds__(NW * 64) void ksw_extd2_reg_kernel(const KswTask *_
         if (right) ksw_reg_run<NW, NCH, false, true, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
         else ksw_reg_run<NW, NCH, false, false, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
     }
+    dev_problem_done(dc, ti, lds);             // (device-planned batches: the alignment's last problem hands it to the host)
 }
 
 // Classes.  Short problems (the gap fills) are throughput: one wave each.  Problems with many anti-diagonals (extensions of a few
@@ -1186,8 +1189,10 @@ int ksw_reg_class(const KswTask &t, const KswParams &pr)
 }
 
 int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const KswTask *tasks, const uint32_t *order, const KswParams &pr, const uint8_t *seqs,
-                   uint8_t *p_pool, uint32_t *cig_pool, KswResult *res, const uint32_t *n_dev)
+                   uint8_t *p_pool, uint32_t *cig_pool, KswResult *res, const uint32_t *n_dev, const DvCollect *dc_in)
 {
+    DvCollect dc;
+    if (dc_in) dc = *dc_in; else memset(&dc, 0, sizeof(dc));
 #define NS_REG_LAUNCH(NW_, NCH_)                                                                                                              \
     {                                                                                                                                         \
         static size_t cap = 0;                                                                                                                \
@@ -1199,7 +1204,7 @@ int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const 
                 cap = lds_bytes;                                                                                                              \
             }                                                                                                                                 \
         }                                                                                                                                     \
-        hipLaunchKernelGGL((ksw_extd2_reg_kernel<NW_, NCH_>), dim3(m), dim3(NW_ * 64), lds_bytes, st, tasks, order, m, pr, seqs, p_pool, cig_pool, res, n_dev); \
+        hipLaunchKernelGGL((ksw_extd2_reg_kernel<NW_, NCH_>), dim3(m), dim3(NW_ * 64), lds_bytes, st, tasks, order, m, pr, seqs, p_pool, cig_pool, res, n_dev, dc); \
     }
     switch (cls) {
     case 0: NS_REG_LAUNCH(1, 2) break;
@@ -1217,7 +1222,7 @@ int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const 
                 cap = lds_bytes;                                                                                                              \
             }                                                                                                                                 \
         }                                                                                                                                     \
-        hipLaunchKernelGGL((ksw_extd2_sys_kernel<NCH_>), dim3(m), dim3((kSysWaves + 1) * 64), lds_bytes, st, tasks, order, m, pr, seqs, p_pool, cig_pool, res, n_dev); \
+        hipLaunchKernelGGL((ksw_extd2_sys_kernel<NCH_>), dim3(m), dim3((kSysWaves + 1) * 64), lds_bytes, st, tasks, order, m, pr, seqs, p_pool, cig_pool, res, n_dev, dc); \
     }
     case 9: NS_SYS_LAUNCH(1) break;
     case 10: NS_SYS_LAUNCH(2) break;

@@ -476,6 +476,7 @@ __global__ __launch_bounds__(kThreads) void align_plan_kernel(const SeedResult *
         tk.qlen = ql, tk.tlen = tl, tk.w = K.w, tk.zdrop = K.zdrop, tk.end_bonus = K.end_bonus, tk.flag = K.flag | cfg.kc.flag_or | ((K.flag & EZ_APPROX_MAX) ? cfg.approx_flag_or : 0);
         tk.p_off = p0 + L.tp[t], tk.cig_off = c0 + L.tc[t], tk.out_idx = slot;
         dp.tasks[slot] = tk;
+        dp.task_pair[slot] = b;
         keys_out[slot] = K;
         if (cls < KSW_REG_CLASSES) dp.class_list[(size_t)cls * dp.n_slots + (uint32_t)L.sh[12 + cls] + rank] = slot;
         else {
