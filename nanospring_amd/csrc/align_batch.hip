@@ -480,7 +480,7 @@ int batch_plan_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int see
 // requests on several threads (the contig engine does it inside each builder's own task).
 int batch_plan_wait(nsgpu_ctx *c, AlignBatch &B, int part, KswDevResults &R)
 {
-    R = KswDevResults{nullptr, nullptr, nullptr, nullptr};
+    R = KswDevResults{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (B.plan_ws < 0) return NSGPU_OK;
     const int ws = B.plan_ws;
     if (part == 1) B.plan_ws = -1;
@@ -500,7 +500,8 @@ int batch_plan_wait(nsgpu_ctx *c, AlignBatch &B, int part, KswDevResults &R)
     return NSGPU_OK;
 }
 // request i's problems from the results of `part` into its job's cache; returns how many (0: not this part's, not planned, lost, or done before).
-// Part 1 takes whatever has not been delivered yet unless own_part_only.
+// Part 1 takes whatever has not been delivered yet unless own_part_only.  ~0u: the status word is up but what it announces does not add up yet
+// (a word raised by a kernel that is still running overtook its data): ask again.
 uint32_t batch_plan_deliver_one(AlignBatch &B, const KswDevResults &R, size_t i, int part, bool own_part_only)
 {
     using namespace mm2;
@@ -512,6 +513,20 @@ uint32_t batch_plan_deliver_one(AlignBatch &B, const KswDevResults &R, size_t i,
     if (own_part_only && part == 1 && !o.slow) return 0;         // (two threads, one per part: the first part's requests are the other thread's)
     const uint32_t st = __atomic_load_n(&R.status[q], __ATOMIC_ACQUIRE);
     if (st != 1u) return 0;                            // (2: the CIGAR arena overflowed: the job asks for its problems again)
+    {   // the word may have been raised by a kernel that is still running (ksw_collect.hpp): believe it once what it announces adds up
+        uint32_t sum = 0;
+        const uint32_t *rw = reinterpret_cast<const uint32_t *>(R.res + B.plan_base[i]);
+        for (uint32_t k = 0; k < o.n_tasks * (uint32_t)(sizeof(KswResult) / 4); ++k) sum += rw[k];
+        for (uint32_t t = 0; t < o.n_tasks; ++t) {
+            const uint32_t slot = B.plan_base[i] + t;
+            const uint64_t at = R.coff[slot];
+            const uint32_t nc = (uint32_t)R.res[slot].n_cigar;
+            sum += (uint32_t)at;
+            if (nc > (1u << 24)) return ~0u;
+            for (uint32_t k = 0; k < nc; ++k) sum += R.cig[at + k];
+        }
+        if (sum != __atomic_load_n(&R.check[q], __ATOMIC_ACQUIRE)) return ~0u;       // not all of it is here yet: ask again
+    }
     B.plan_delivered[i] = 1;
     AlignJob &J = B.jobs[i];
     if (J.finished) return 0;
@@ -550,7 +565,12 @@ int batch_plan_deliver(nsgpu_ctx *c, AlignBatch &B, int part)
     NS_TRY(batch_plan_wait(c, B, part, R));
     if (!R.res) return NSGPU_OK;
     std::atomic<uint64_t> n_tasks{0};
-    parallel_for("align.dp_deliver", B.plan_pair.size(), [&](size_t i) { n_tasks += batch_plan_deliver_one(B, R, i, part, false); });
+    parallel_for("align.dp_deliver", B.plan_pair.size(), [&](size_t i) {
+        // (behind a waited-for stream everything has arrived: a sum that does not add up twice is a lost alignment -- the job asks again)
+        uint32_t got = batch_plan_deliver_one(B, R, i, part, false);
+        if (got == ~0u) got = batch_plan_deliver_one(B, R, i, part, false);
+        if (got != ~0u) n_tasks += got;
+    });
     std::lock_guard<std::mutex> lk(c->stat_m);
     c->aln_dp_tasks += n_tasks.load();
     return NSGPU_OK;

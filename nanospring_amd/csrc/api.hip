@@ -29,6 +29,24 @@ static double wait_timeout_s()
     static const double t = [] { const char *e = getenv("NSGPU_WAIT_TIMEOUT_S"); return e ? atof(e) : 0.0; }();
     return t;
 }
+// NSGPU_SEGV_TRACE=1 (debugging aid): a backtrace of the faulting thread on stderr before the process dies of SIGSEGV / SIGBUS / SIGABRT
+#include <execinfo.h>
+#include <signal.h>
+static void segv_trace(int sig)
+{
+    void *bt[64];
+    const int n = backtrace(bt, 64);
+    const char msg[] = "nsgpu: fatal signal, backtrace of the faulting thread:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(bt, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+static const bool g_segv_trace = [] {
+    if (!getenv("NSGPU_SEGV_TRACE")) return false;
+    signal(SIGSEGV, segv_trace), signal(SIGBUS, segv_trace), signal(SIGABRT, segv_trace);
+    return true;
+}();
 static std::atomic<uint64_t> g_host_waits{0};       // host waits for GPU work (streams and events), process-wide: nsgpu_host_wait_count
 
 static hipError_t stream_wait_impl(hipStream_t s, int spin_us, bool spin_only = false)

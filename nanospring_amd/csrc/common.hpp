@@ -164,7 +164,7 @@ struct nsgpu_ctx {
         // CIGAR entries, sequence bytes), cells, algorithmic bytes
         nsgpu::DevBuf dv_tasks, dv_list, dv_ctrl, dv_seqs, dv_p, dv_cig, dv_res, dv_coff, dv_scan_ws, dv_tpair, dv_pdone;
         bool dv_inline = false;                  // this batch's DP kernels hand every alignment over themselves (ksw_collect.hpp)
-        nsgpu::PinBuf hv_res, hv_coff, hv_cig, hv_ctrl, hv_status;
+        nsgpu::PinBuf hv_res, hv_coff, hv_cig, hv_ctrl, hv_status, hv_check;
         hipEvent_t dv_part0 = nullptr;                                  // behind the first part of a two-part batch's results
         uint32_t dv_npairs_launched = 0; bool dv_two_phase = false;
         uint32_t dv_slots = 0, dv_pairs = 0, dv_classes = 0;                         // dv_classes: bit k = class k was launched

@@ -353,7 +353,7 @@ struct Engine {
     std::vector<uint8_t> cons_changed;              // per builder of the batch: its consensus changed since the batch before
     std::vector<uint32_t> early_pends; std::vector<int32_t> early_widx; std::vector<uint8_t> early_sure;      // scratch of engine_early_updates
     double early_part_ms[2] = {0, 0}, early_task_ms = 0, early_task_max_ms = 0, early_conv_ms = 0;     // debug report: wall of the two parts' loops, sum / per-slot maximum of their tasks, skeleton + conversion inside
-    uint64_t n_early = 0; double early_ms = 0;       // graph updates run ahead of the slot's end / wall of that (debug print)
+    uint64_t n_early = 0, n_early_retry = 0; double early_ms = 0;      // (retry: a status word seen before all of its data, ksw_collect.hpp)       // graph updates run ahead of the slot's end / wall of that (debug print)
     std::vector<ConsJob> cons_jobs;
     PinBuf pin_cons;                                // cons_update_kernel's job descriptors
     hipStream_t cons_stream = nullptr; hipEvent_t cons_ev = nullptr;
@@ -1139,7 +1139,7 @@ static int engine_early_updates(nsgpu_ctx *c, int group)
     // its claim cannot fail the graph update.  The two parts touch disjoint builders; the second part's thread starts its loop when the late
     // classes are done, some 0.2 ms behind the first, and the two loops share the pool: a builder of the second part is not held up by the
     // first part's slowest update (it used to wait for that, then for the claims, and was updated in the next host phase).
-    std::atomic<uint64_t> n_updates{0}, n_tasks{0};
+    std::atomic<uint64_t> n_updates{0}, n_tasks{0}, n_retry{0};
     std::atomic<uint64_t> task_ns{0}, task_max_ns{0}, conv_ns{0};
     auto run_part = [&](int part, const KswDevResults &R) {
         const double p0 = now_ms();
@@ -1153,7 +1153,7 @@ static int engine_early_updates(nsgpu_ctx *c, int group)
             const double k0 = now_ms();
             struct Tk { std::atomic<uint64_t> &sum, &mx; double k0; ~Tk() { const uint64_t d = (uint64_t)((now_ms() - k0) * 1e6); sum += d; uint64_t m = mx.load(); while (d > m && !mx.compare_exchange_weak(m, d)) {} } } tk{task_ns, task_max_ns, k0};
             const uint32_t got = batch_plan_deliver_one(AB, R, (size_t)w, part, true);
-            if (!got) return;
+            if (!got || got == ~0u) return;
             n_tasks += got;
             if (!align_early_one(AB, (size_t)w, E->outs[w])) return;
             conv_ns += (uint64_t)((now_ms() - k0) * 1e6);
@@ -1202,14 +1202,17 @@ static int engine_early_updates(nsgpu_ctx *c, int group)
                         const int32_t w = widx[i];
                         const uint32_t st = __atomic_load_n(&R.status[AB.plan_pair[w]], __ATOMIC_ACQUIRE);
                         if (st == 0) { ++k; continue; }
+                        if (st == 1u && !AB.plan_delivered[w]) {
+                            // (the status word is up: is everything it announces here?  If not, look again in a moment)
+                            const uint32_t got = batch_plan_deliver_one(AB, R, (size_t)w, 1, false);
+                            if (got == ~0u) { ++k; n_retry += 1; continue; }
+                            n_tasks += got;
+                        }
                         mine[k] = mine[--n_mine];
                         progressed = true;
                         if (st != 1u) continue;                                   // (not handed over: align_finish's rounds)
                         const double k0 = now_ms();
                         struct Tk { std::atomic<uint64_t> &sum, &mx; double k0; ~Tk() { const uint64_t d = (uint64_t)((now_ms() - k0) * 1e6); sum += d; uint64_t m = mx.load(); while (d > m && !mx.compare_exchange_weak(m, d)) {} } } tk{task_ns, task_max_ns, k0};
-                        const uint32_t got = batch_plan_deliver_one(AB, R, (size_t)w, 1, false);
-                        if (!got) continue;
-                        n_tasks += got;
                         if (!align_early_one(AB, (size_t)w, E->outs[w])) continue;
                         conv_ns += (uint64_t)((now_ms() - k0) * 1e6);
                         Builder &b = D.B[i];
@@ -1232,6 +1235,7 @@ static int engine_early_updates(nsgpu_ctx *c, int group)
                 }
             });
             E->early_part_ms[0] += now_ms() - p0;
+            E->n_early_retry += n_retry.load();
             E->n_early += n_updates.load();
             E->early_task_ms += task_ns.load() / 1e6, E->early_task_max_ms += task_max_ns.load() / 1e6, E->early_conv_ms += conv_ns.load() / 1e6;
             { std::lock_guard<std::mutex> lk(c->stat_m); c->aln_dp_tasks += n_tasks.load(); c->cons_stats.graph_ms += now_ms() - g0; }
@@ -1505,7 +1509,7 @@ static void debug_report_slots(nsgpu_ctx *c, Engine *E)
             (unsigned long long)c->plan_why[0], (unsigned long long)c->plan_why[1], (unsigned long long)c->plan_why[2], (unsigned long long)c->plan_why[3], (unsigned long long)c->plan_why[4], (unsigned long long)c->plan_why[5]);
     fprintf(stderr, "[cons] early tasks: loops of part 0 / part 1 %.0f / %.0f ms wall; tasks %.0f ms in sum (delivery + skeleton + conversion %.0f), the longest of each slot %.0f ms in sum\n",
             E->early_part_ms[0], E->early_part_ms[1], E->early_task_ms, E->early_conv_ms, E->early_task_max_ms);
-    fprintf(stderr, "[cons] graph updates run ahead of the slot's end: %llu, %.0f ms wall (first part of the DP results + updates)\n", (unsigned long long)E->n_early, E->early_ms);
+    fprintf(stderr, "[cons] graph updates run ahead of the slot's end: %llu, %.0f ms wall (DP results + updates); status words seen ahead of their data: %llu\n", (unsigned long long)E->n_early, E->early_ms, (unsigned long long)E->n_early_retry);
     fprintf(stderr, "[cons] device plan (cumulative): %llu alignments planned on the device, %llu left to the host; DP problems found %llu, not found %llu, unasked %llu\n",
             (unsigned long long)c->plan_pairs_dev, (unsigned long long)c->plan_pairs_host, (unsigned long long)c->plan_hits, (unsigned long long)c->plan_misses, (unsigned long long)c->plan_extra);
     fprintf(stderr, "[cons] index + seeds on the GPU: %llu launches, %llu pairs, wait %.0f ms wall; %llu pairs handed back to the host code\n", (unsigned long long)sn,

@@ -101,7 +101,7 @@ int plan_launch(hipStream_t st, uint32_t n_pairs, uint32_t lds_anchors, const Se
 // The results come in two parts: the alignments none of whose problems runs in a late class (part 0: behind the bulk of one-wave problems on
 // the main stream), then the rest (part 1: behind everything).  res[slot] / cig + coff[slot] are valid for the task slots of the alignments
 // whose status[pair] == 1 (2: the pinned CIGAR arena overflowed -- those alignments are the host's to redo).
-struct KswDevResults { const KswResult *res; const uint64_t *coff; const uint32_t *cig; const uint32_t *status; };
+struct KswDevResults { const KswResult *res; const uint64_t *coff; const uint32_t *cig; const uint32_t *status; const uint32_t *check; };
 int ksw_dev_prepare(nsgpu_ctx *c, int ws_index, uint32_t n_slots, uint32_t n_pairs, uint64_t seq_bytes_bound, hipStream_t st, PlanDp &dp);
 int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr, hipEvent_t after, const PlanPair *pairs, const PlanOut *outs, uint32_t n_pairs, bool two_phase);
 int ksw_dev_collect(nsgpu_ctx *c, int ws_index, int part, KswDevResults &out);

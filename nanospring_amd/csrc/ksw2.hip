@@ -1153,6 +1153,7 @@ int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr
     NS_TRY(W.hv_coff.reserve(((size_t)n + 1) * 8 + 64));
     NS_TRY(W.hv_ctrl.reserve(sizeof(DvCtrl)));
     NS_TRY(W.hv_status.reserve((size_t)n_pairs * 4 + 64));
+    NS_TRY(W.hv_check.reserve((size_t)n_pairs * 4 + 64));
     memset(W.hv_status.p, 0, (size_t)n_pairs * 4);
     W.hv_ctrl.as<DvCtrl>()->done = 0;
     W.dv_hcig_cap = hcap, W.dv_npairs_launched = n_pairs, W.dv_two_phase = two_phase;
@@ -1162,7 +1163,7 @@ int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr
     static const bool no_inline = getenv("NSGPU_KSW_NO_INLINE_COLLECT") != nullptr;
     W.dv_inline = !no_inline;
     DvCollect dc{pairs, outs, W.dv_tasks.as<KswTask>(), W.dv_res.as<KswResult>(), W.dv_cig.as<uint32_t>(), W.dv_tpair.as<uint32_t>(), W.dv_inline ? W.dv_pdone.as<uint32_t>() : nullptr,
-                 W.hv_res.as<KswResult>(), W.hv_coff.as<uint64_t>(), W.hv_cig.as<uint32_t>(), hcap, W.hv_status.as<uint32_t>(), ctrl};
+                 W.hv_res.as<KswResult>(), W.hv_coff.as<uint64_t>(), W.hv_cig.as<uint32_t>(), hcap, W.hv_status.as<uint32_t>(), W.hv_check.as<uint32_t>(), ctrl, getenv("NSGPU_KSW_NO_PROBE") ? 1u : 0u};
     auto launch_class = [&](int k, hipStream_t st) -> int {
         NS_HIP(hipEventRecord(W.dv_ev[2 * k], st));
         NS_TRY(ksw_reg_launch(k, st, dev_class_grid(k, n, W.dv_pairs), ksw_reg_lds_bytes(k, max_qlen), W.dv_tasks.as<KswTask>(), W.dv_list.as<uint32_t>() + (size_t)k * n, pr, W.dv_seqs.as<uint8_t>(),
@@ -1218,10 +1219,10 @@ int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr
 bool ksw_dev_poll(nsgpu_ctx *c, int ws_index, KswDevResults &out, const volatile uint32_t *&done)
 {
     nsgpu_ctx::KswWs &W = c->kws[ws_index];
-    out = KswDevResults{nullptr, nullptr, nullptr, nullptr};
+    out = KswDevResults{nullptr, nullptr, nullptr, nullptr, nullptr};
     done = nullptr;
     if (!W.dv_pending || !W.dv_inline) return false;
-    out.res = W.hv_res.as<KswResult>(), out.coff = W.hv_coff.as<uint64_t>(), out.cig = W.hv_cig.as<uint32_t>(), out.status = W.hv_status.as<uint32_t>();
+    out.res = W.hv_res.as<KswResult>(), out.coff = W.hv_coff.as<uint64_t>(), out.cig = W.hv_cig.as<uint32_t>(), out.status = W.hv_status.as<uint32_t>(), out.check = W.hv_check.as<uint32_t>();
     done = &W.hv_ctrl.as<DvCtrl>()->done;
     return true;
 }
@@ -1230,12 +1231,12 @@ bool ksw_dev_poll(nsgpu_ctx *c, int ws_index, KswDevResults &out, const volatile
 int ksw_dev_collect(nsgpu_ctx *c, int ws_index, int part, KswDevResults &out)
 {
     nsgpu_ctx::KswWs &W = c->kws[ws_index];
-    out = KswDevResults{nullptr, nullptr, nullptr, nullptr};
+    out = KswDevResults{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (!W.dv_pending) return NSGPU_OK;
     if (part == 0) {
         if (!W.dv_two_phase) return NSGPU_OK;
         NS_HIP(event_wait(W.dv_part0));
-        out.res = W.hv_res.as<KswResult>(), out.coff = W.hv_coff.as<uint64_t>(), out.cig = W.hv_cig.as<uint32_t>(), out.status = W.hv_status.as<uint32_t>();
+        out.res = W.hv_res.as<KswResult>(), out.coff = W.hv_coff.as<uint64_t>(), out.cig = W.hv_cig.as<uint32_t>(), out.status = W.hv_status.as<uint32_t>(), out.check = W.hv_check.as<uint32_t>();
         return NSGPU_OK;
     }
     W.dv_pending = false;
@@ -1244,7 +1245,7 @@ int ksw_dev_collect(nsgpu_ctx *c, int ws_index, int part, KswDevResults &out)
     // scratch that did not fit: the plan kernel left those alignments to the host; larger next time
     if (hc->cursors[0] > std::max<uint64_t>(W.dv_p_hint, 768ull << 20)) W.dv_p_hint = hc->cursors[0] + hc->cursors[0] / 2;
     if (hc->cig_out > W.dv_hcig_cap) W.dv_hcig_hint = hc->cig_out + hc->cig_out / 2;
-    out.res = W.hv_res.as<KswResult>(), out.coff = W.hv_coff.as<uint64_t>(), out.cig = W.hv_cig.as<uint32_t>(), out.status = W.hv_status.as<uint32_t>();
+    out.res = W.hv_res.as<KswResult>(), out.coff = W.hv_coff.as<uint64_t>(), out.cig = W.hv_cig.as<uint32_t>(), out.status = W.hv_status.as<uint32_t>(), out.check = W.hv_check.as<uint32_t>();
     float ms = 0;
     NS_HIP(hipEventElapsedTime(&ms, W.dv_a, W.dv_b));
     double sum_ms = 0;

@@ -22,7 +22,9 @@ struct DvCollect {
     const uint32_t *task_pair;          // task slot -> alignment
     uint32_t *pair_done;                // alignment -> problems completed so far (nullptr: the DP kernels do not hand over, the collecting kernel does)
     KswResult *h_res; uint64_t *h_off; uint32_t *h_cig; uint64_t h_cig_cap; uint32_t *h_status;                         // pinned landing zones
+    uint32_t *h_check;                  // per alignment: the sum of every word handed over (the host adds up what it reads before it believes the status word)
     DvCtrl *ctrl;
+    uint32_t no_probe;                  // NSGPU_KSW_NO_PROBE=1 (experiment): raise the status word without reading the data back first
 };
 
 // One wave (lane 0 .. 63) hands alignment b over.  s_off: 256 words of LDS of the caller's.
@@ -58,21 +60,35 @@ __device__ inline void dev_collect_pair(const DvCollect &dc, uint32_t b, uint32_
         if (lane == 0) dc.h_status[b] = 2u;
         return;
     }
+    uint32_t chk = 0;
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(dc.res + s0);
         uint32_t *dst = reinterpret_cast<uint32_t *>(dc.h_res + s0);
-        for (uint32_t i = lane; i < n * (uint32_t)(sizeof(KswResult) / 4); i += 64) dst[i] = src[i];
+        for (uint32_t i = lane; i < n * (uint32_t)(sizeof(KswResult) / 4); i += 64) { const uint32_t v = src[i]; dst[i] = v; chk += v; }
     }
     for (uint32_t t = 0; t < n; ++t) {
         const uint32_t c = (uint32_t)dc.res[s0 + t].n_cigar;
         const unsigned long long at = base + s_off[t];
         const uint32_t *src = dc.pool + dc.tasks[s0 + t].cig_off;
-        for (uint32_t k = lane; k < c; k += 64) dc.h_cig[at + k] = src[k];
+        for (uint32_t k = lane; k < c; k += 64) { const uint32_t v = src[k]; dc.h_cig[at + k] = v; chk += v; }
     }
-    for (uint32_t t = lane; t < n; t += 64) dc.h_off[s0 + t] = base + s_off[t];
+    for (uint32_t t = lane; t < n; t += 64) { dc.h_off[s0 + t] = base + s_off[t]; chk += (uint32_t)(base + s_off[t]); }
+    for (int d = 32; d > 0; d >>= 1) chk += (uint32_t)__shfl_xor((int)chk, d, 64);
+    if (lane == 0) dc.h_check[b] = chk;
+    __threadfence_system();
+    // The host may be watching the status word while this kernel is still running (ksw_dev_poll): the word must not overtake the data on the
+    // way to host memory.  Every lane reads one word of what it wrote back from host memory (a system-scope load: a read request does not pass
+    // the posted writes in front of it on the link), and only then does lane 0 raise the word.
+    if (!dc.no_probe) {
+        uint32_t probe = 0;
+        if (lane < n) probe = __hip_atomic_load(reinterpret_cast<const uint32_t *>(dc.h_off + s0 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (total) probe += __hip_atomic_load(dc.h_cig + base + (total - 1 - (lane % (total < 64 ? total : 64))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        probe += __hip_atomic_load(reinterpret_cast<const uint32_t *>(dc.h_res + s0) + lane % (n * (uint32_t)(sizeof(KswResult) / 4)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("" :: "v"(probe) : "memory");
+    }
     __threadfence_system();
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) dc.h_status[b] = 1u;
+    if (lane == 0) __hip_atomic_store(dc.h_status + b, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // At the end of a DP kernel's workgroup, by ALL its threads: the problem in task slot ti is complete -- its result and CIGAR are in device memory.
