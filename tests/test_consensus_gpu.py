@@ -315,14 +315,14 @@ g.close()
 
 
 def test_device_plan_two_part_results_and_early_updates_switches():
-    """Round 4's shortening of a slot of the one-group schedule -- the alignment plan on the device (plan.hip), the DP results fetched in two
-    parts with the graph updates of the first part run ahead of the slot's end, the gap fills' score books skipped -- each switched off in
-    turn: the same streams.  By default nearly every alignment of an iid genome is planned on the device and every problem the host asks
+    """Round 4's shortening of a slot of the one-group schedule -- the alignment plan on the device (plan.hip), the DP results handed over per
+    alignment by the DP kernels themselves (or fetched in two parts behind collecting kernels) with the graph updates run ahead of the slot's
+    end, the gap fills' score books skipped -- each switched off in turn: the same streams.  By default nearly every alignment of an iid genome is planned on the device and every problem the host asks
     for is found."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = []
-    for env in ({}, {"NSGPU_NO_DEVICE_PLAN": "1"}, {"NSGPU_NO_EARLY_UPDATES": "1"}, {"NSGPU_EARLY_ONE_PART": "1"}, {"NSGPU_KSW_KEEP_SCORE": "1"}, {"NSGPU_KSW_LONG_ROWS": "0"}, {"NSGPU_KSW_BULK_SERIAL": "1"},
+    for env in ({}, {"NSGPU_NO_DEVICE_PLAN": "1"}, {"NSGPU_NO_EARLY_UPDATES": "1"}, {"NSGPU_EARLY_ONE_PART": "1"}, {"NSGPU_KSW_NO_INLINE_COLLECT": "1"}, {"NSGPU_KSW_NO_INLINE_COLLECT": "1", "NSGPU_EARLY_ONE_PART": "1"}, {"NSGPU_KSW_NO_PROBE": "1"}, {"NSGPU_KSW_KEEP_SCORE": "1"}, {"NSGPU_KSW_LONG_ROWS": "0"}, {"NSGPU_KSW_BULK_SERIAL": "1"},
                 {"NSGPU_CONS_CHECK": "1", "NSGPU_SKETCH_CHECK": "1"}):
         r = subprocess.run([sys.executable, "-c", PLAN_WORKER % {"root": root}], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (env, r.stderr[-2000:])
