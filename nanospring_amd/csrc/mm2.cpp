@@ -257,6 +257,18 @@ void RefIndex::set_sequence_from(const char *s, uint32_t n, int w_, int k_, size
     has_table = false;
 }
 
+void RefIndex::set_sequence_spliced(const char *s, uint32_t n, int w_, int k_, size_t P, size_t S)
+{
+    const size_t old_n = seq.size();
+    if (P + S > old_n || P + S > n) { set_sequence_from(s, n, w_, k_, 0); return; }
+    k = k_, w = w_ < 1 ? 1 : w_, len = n;
+    if (n > old_n) seq.resize(n);
+    if (S && n != old_n) memmove(seq.data() + (n - S), seq.data() + (old_n - S), S);
+    if (n < old_n) seq.resize(n);
+    nt4_codes(s + P, n - S - P, seq.data() + P);
+    has_table = false;
+}
+
 void RefIndex::build_from_sketch(const char *s, uint32_t n, int w_, int k_, float mid_occ_frac, const Anchor *mz_p, size_t mz_n)
 {
     set_sequence(s, n, w_, k_);

@@ -71,6 +71,8 @@ struct RefIndex {
     bool has_table = false;            // keys / pos / slot / mid_occ are built (the batch driver seeds on the GPU and needs only seq)
     void set_sequence(const char *s, uint32_t n, int w_, int k_);     // k, w, len and the nt4 codes only
     void set_sequence_from(const char *s, uint32_t n, int w_, int k_, size_t from);     // the same when s[0 .. from) is what the codes already hold
+    // the same when s shares a prefix of P and a suffix of S bases with the string the codes belong to: the suffix's codes move, the middle is coded
+    void set_sequence_spliced(const char *s, uint32_t n, int w_, int k_, size_t P, size_t S);
     void build(const char *s, uint32_t n, int w_, int k_, float mid_occ_frac);
     // same, with the sequence's minimizers (mm_sketch order, rid 0) supplied by the caller
     void build_from_sketch(const char *s, uint32_t n, int w_, int k_, float mid_occ_frac, const Anchor *mz, size_t n_mz);
