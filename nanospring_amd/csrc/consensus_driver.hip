@@ -1206,7 +1206,10 @@ static int engine_early_updates(nsgpu_ctx *c, int group)
                     mine[n_mine++] = (uint32_t)i;
                 }
                 bool closing = false;
+                // (a batch that never closes -- a GPU fault -- must not hold the pool for ever: align_finish's wait reports it)
+                static const double give_up_ms = [] { const char *e = getenv("NSGPU_WAIT_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return (v > 0 ? v : 120.0) * 1e3; }();
                 while (n_mine) {
+                    if (now_ms() - p0 > give_up_ms) break;
                     bool progressed = false;
                     for (size_t k = 0; k < n_mine;) {
                         const size_t i = mine[k];
