@@ -463,12 +463,12 @@ def main():
                          "traffic": None, "traffic_from_profile": traffic, "traffic_source": traffic_src,
                          "launches": int(a["dp_launches"]), "avg_launch_ms": round(dp_ms, 3),
                          # the kernel is integer DP bound by instruction issue, not by HBM: its real ceiling as first-class fields
-                         "compute": {"bound": "latency of one wave per problem at the default schedule (a launch holds ~80 alignments' problems and is waited for by a whole round); VALU + SALU instruction issue at the 1024-builder schedule", "cells": a["dp_cells"],
+                         "compute": {"bound": "latency of one wave per problem at the default schedule (a launch holds ~80 alignments' problems; a round waits for its slowest ALIGNMENT -- the DP kernels hand each one over when its last problem is done); VALU + SALU instruction issue at the 1024-builder schedule", "cells": a["dp_cells"],
                                      "gcups_over_dp_wall": round(a["dp_cells"] / (a["dp_kernel_ms"] * 1e-3) / 1e9, 1) if a["dp_kernel_ms"] else 0,
                                      "gcups_over_kernel_sum": round(a["dp_cells"] / (a["dp_kernel_sum_ms"] * 1e-3) / 1e9, 1) if a["dp_kernel_sum_ms"] else 0,
                                      "pmc": comp},
                          "note": "achieved / peak / frac are the HBM figures the contract asks for (algorithmic bytes per launch / launch time; ~1e-5 by construction: 1 B of sequence per ~250 DP cells); "
-                                 "neither the HBM nor the MFMA roof applies: at the one-group schedule a launch is as long as the dependent chain of its longest problem (bound = latency: "
+                                 "neither the HBM nor the MFMA roof applies: at the one-group schedule an alignment is as long as the dependent chain of its longest problem, 1 000-1 800 anti-diagonals of ~1 us (bound = latency: "
                                  "compute.pmc shows the waves waiting, not issuing), at the 1024-builder schedule the kernels are bound by VALU + SALU instruction issue; traffic is not "
                                  "measured inside this run, traffic_from_profile is the committed rocprofv3 --pmc figure for the workload it names"},
         }
