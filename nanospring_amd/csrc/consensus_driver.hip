@@ -351,6 +351,8 @@ struct Engine {
     std::vector<TailCopy> tail_jobs;
     PinBuf pin_tail;                                // the scatter kernel's job descriptors
     std::vector<uint8_t> cons_changed;              // per builder of the batch: its consensus changed since the batch before
+    std::vector<uint32_t> global_pends;             // several ranks, one-group schedule: the reads ALL ranks' builders align in this slot, sorted (run_consensus_dist)
+    bool have_global_pends = false;
     std::vector<uint32_t> early_pends; std::vector<int32_t> early_widx; std::vector<uint8_t> early_sure;      // scratch of engine_early_updates
     double early_part_ms[2] = {0, 0}, early_task_ms = 0, early_task_max_ms = 0, early_conv_ms = 0;     // debug report: wall of the two parts' loops, sum / per-slot maximum of their tasks, skeleton + conversion inside
     uint64_t n_early = 0, n_early_retry = 0; double early_ms = 0;      // (retry: a status word seen before all of its data, ksw_collect.hpp)       // graph updates run ahead of the slot's end / wall of that (debug print)
@@ -1133,8 +1135,11 @@ static int engine_early_updates(nsgpu_ctx *c, int group)
     std::vector<uint32_t> &pends = E->early_pends;
     pends.resize(n);
     for (size_t w = 0; w < n; ++w) pends[w] = D.B[who[w]].pend;
-    std::vector<uint32_t> sorted(pends);
-    std::sort(sorted.begin(), sorted.end());
+    // (several ranks: the other ranks' builders count as well -- their candidate reads came with the slot's exchange, run_consensus_dist)
+    const bool global_known = E->world == 1 || E->have_global_pends;
+    std::vector<uint32_t> sorted(E->world == 1 || !E->have_global_pends ? pends : E->global_pends);
+    if (E->world == 1 || !E->have_global_pends) std::sort(sorted.begin(), sorted.end());
+    E->have_global_pends = false;
     // builder -> its request in the batch, and whether its claim cannot fail
     std::vector<int32_t> &widx = E->early_widx;
     widx.assign(D.B.size(), -1);
@@ -1143,7 +1148,7 @@ static int engine_early_updates(nsgpu_ctx *c, int group)
     for (size_t w = 0; w < n; ++w) {
         widx[who[w]] = (int32_t)w;
         const auto range = std::equal_range(sorted.begin(), sorted.end(), pends[w]);
-        sure[w] = range.second - range.first == 1 && !D.in_graph[pends[w]] && E->world == 1;
+        sure[w] = range.second - range.first == 1 && !D.in_graph[pends[w]] && global_known;
     }
     // One part of the results (0: the alignments without a problem in a late class, there behind the bulk classes; 1: the others): ONE task per
     // builder, on the thread its graph lives with -- its problems' results into its job, the skeleton to the end, the conversion, and when
@@ -1750,7 +1755,19 @@ static int run_consensus_dist(nsgpu_ctx *c, Comm &C, uint32_t n_builders_total, 
             gathered(1 + blk);
             rc = NSGPU_OK;
             if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) { engine_advance(c, true, h); rc = engine_window_loop(c, h); }
-            if (rc == NSGPU_OK) rc = engine_slot(c, slot, 2);
+            // which reads the builders of ALL ranks are about to align: a builder whose read nobody else aligns (and nobody has claimed) cannot
+            // lose its claim, so its graph update may ride on the DP phase as on one GPU (engine_early_updates) instead of waiting for the
+            // claim exchange -- one more small all-gather per slot
+            if (rc == NSGPU_OK) {
+                ca.clear(), cb.clear();
+                for (const Builder &bb : E->D.B) if (bb.st == Builder::WAIT_ALIGN) { ca.push_back(bb.gid); cb.push_back(bb.pend); }
+            }
+            NS_TRY(exchange(rc, &ca, &cb, nullptr, nullptr));
+            gathered(1);
+            E->global_pends.assign(gb.begin(), gb.end());
+            std::sort(E->global_pends.begin(), E->global_pends.end());
+            E->have_global_pends = true;
+            rc = engine_slot(c, slot, 2);
             if (rc == NSGPU_OK) engine_claim_requests(c, ca, cb, b);
             NS_TRY(exchange(rc, &ca, &cb, nullptr, nullptr));
             gathered(1);
