@@ -349,7 +349,9 @@ int nsgpu_dist_sketch_index(nsgpu_ctx *ctx, nsgpu_comm *comm, const uint64_t *sa
  * stage), and the host memory its copy of ALL reads occupies (2-bit rows + offset tables: about 0.25 B/base + 20 B/read). */
 int nsgpu_comm_stats(const nsgpu_comm *comm, uint64_t *bytes_all_gather, uint64_t *bytes_all_to_all, uint64_t *host_bytes_reads);
 /* Consensus::generateAndWriteConsensus over the ranks: the slot schedule documented above nsgpu_cons_begin with ONE small
- * all-gather (claim + seed request lists) per slot; rank r owns the builders with gid % world == r and writes its contigs
+ * all-gather (claim + seed request lists) per slot -- three in the one-group schedule: seed requests after the host phase, the slot's
+ * (builder, candidate read) pairs before the batches (a builder whose read nobody else aligns updates its graph while the DP still runs),
+ * claims after them; rank r owns the builders with gid % world == r and writes its contigs
  * (global read ids) into its own n_threads_out stream sets.  The result does not depend on the number of ranks. */
 int nsgpu_dist_consensus_run(nsgpu_ctx *ctx, nsgpu_comm *comm, uint32_t n_builders_total, uint32_t n_threads_out, nsgpu_consensus_stats *stats_out);
 
