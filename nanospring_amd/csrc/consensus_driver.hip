@@ -381,6 +381,9 @@ struct Engine {
         uint32_t depth = 0, rings = 1, tail_rings = 1;        // tail_rings: the exclusion radius while more than half of all builders are waiting for a seed
         uint32_t rings_now = 1;
         std::vector<uint32_t> bucket_of;                 // read -> bucket
+        // the filter's answer to every whole read, both strands (what the buckets are built from): kept, because a fresh contig's first window
+        // IS its seed read -- that query need not go to the GPU again (engine_window_queries)
+        std::vector<uint64_t> wr_off; std::vector<uint32_t> wr_ids;
         std::vector<uint64_t> adj_off; std::vector<uint32_t> adj;     // bucket adjacency (CSR, ascending, without itself)
         std::vector<uint64_t> bk_off; std::vector<uint32_t> bk_reads; // reads of every bucket, ascending
         std::vector<uint32_t> bk_next;                   // per bucket: index into its reads of the first one not known to be claimed
@@ -636,6 +639,8 @@ static int seed_policy_init(nsgpu_ctx *c, Engine *E)
     for (uint32_t b = 0; b < nb; ++b) P.bk_off[b + 1] += P.bk_off[b];
     P.bk_reads.resize(N);
     { std::vector<uint64_t> fill(P.bk_off.begin(), P.bk_off.end() - 1); for (uint32_t r = 0; r < N; ++r) P.bk_reads[fill[P.bucket_of[r]]++] = r; }
+    static const bool no_wr = getenv("NSGPU_NO_SEED_WINDOW_TABLE") != nullptr;        // A/B switch: every window query on the GPU, as before
+    if (!no_wr) P.wr_off.swap(off), P.wr_ids.swap(ids);
     P.bk_next.assign(nb, 0);
     P.occ.assign(nb, 0);
     P.members.assign(E->n_total, std::vector<uint32_t>());
@@ -1076,6 +1081,28 @@ static int engine_window_queries(nsgpu_ctx *c, int group)
         std::vector<uint32_t> &who = E->fwho;
         who.clear();
         for (Builder &b : D.B) if (in_group(b, group) && b.st == Builder::WAIT_FILTER) who.push_back(b.id);
+        if (!who.empty() && !E->sp.wr_off.empty()) {
+            // A fresh contig's first window is its whole seed read, and the filter is a function of the query string and the tables: the
+            // answer was computed for every read when the seed buckets were built.  (Most seed rounds start a few contigs and nothing else
+            // waits for a window then: the slot saves a GPU round trip.)
+            const Engine::SeedPolicy &P = E->sp;
+            size_t keep = 0, n_tab = 0;
+            for (uint32_t bi : who) {
+                Builder &b = D.B[bi];
+                bool from_table = false;
+                if (b.g && b.g->num_reads() == 0 && b.g->first_read >= D.id_base) {
+                    const read_t r = b.g->first_read - D.id_base;
+                    if (r < D.N && b.win[0].size() == D.read_len(r) && memcmp(b.win[0].data(), D.read_ptr(r), b.win[0].size()) == 0) {
+                        for (int sd = 0; sd < 2; ++sd) b.cand[sd].assign(P.wr_ids.begin() + (ptrdiff_t)P.wr_off[2 * (size_t)r + sd], P.wr_ids.begin() + (ptrdiff_t)P.wr_off[2 * (size_t)r + sd + 1]);
+                        b.st = Builder::GOT_FILTER;
+                        from_table = true, ++n_tab;
+                    }
+                }
+                if (!from_table) who[keep++] = bi;
+            }
+            who.resize(keep);
+            if (n_tab) { std::lock_guard<std::mutex> lk(c->stat_m); S.n_windows += n_tab; }
+        }
         if (!who.empty()) {
             const double f0 = now_ms();
             E->qbuf.clear(); E->qoff.assign(1, 0);

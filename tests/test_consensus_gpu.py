@@ -322,7 +322,7 @@ def test_device_plan_two_part_results_and_early_updates_switches():
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = []
-    for env in ({}, {"NSGPU_NO_DEVICE_PLAN": "1"}, {"NSGPU_NO_EARLY_UPDATES": "1"}, {"NSGPU_EARLY_ONE_PART": "1"}, {"NSGPU_KSW_NO_INLINE_COLLECT": "1"}, {"NSGPU_KSW_NO_INLINE_COLLECT": "1", "NSGPU_EARLY_ONE_PART": "1"}, {"NSGPU_KSW_NO_PROBE": "1"}, {"NSGPU_KSW_KEEP_SCORE": "1"}, {"NSGPU_KSW_LONG_ROWS": "0"}, {"NSGPU_KSW_BULK_SERIAL": "1"},
+    for env in ({}, {"NSGPU_NO_DEVICE_PLAN": "1"}, {"NSGPU_NO_EARLY_UPDATES": "1"}, {"NSGPU_EARLY_ONE_PART": "1"}, {"NSGPU_KSW_NO_INLINE_COLLECT": "1"}, {"NSGPU_KSW_NO_INLINE_COLLECT": "1", "NSGPU_EARLY_ONE_PART": "1"}, {"NSGPU_KSW_NO_PROBE": "1"}, {"NSGPU_NO_SEED_WINDOW_TABLE": "1"}, {"NSGPU_KSW_KEEP_SCORE": "1"}, {"NSGPU_KSW_LONG_ROWS": "0"}, {"NSGPU_KSW_BULK_SERIAL": "1"},
                 {"NSGPU_CONS_CHECK": "1", "NSGPU_SKETCH_CHECK": "1"}):
         r = subprocess.run([sys.executable, "-c", PLAN_WORKER % {"root": root}], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (env, r.stderr[-2000:])
