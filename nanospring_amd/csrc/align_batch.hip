@@ -18,6 +18,7 @@
 #include <mutex>
 #include <condition_variable>
 #include "host_util.hpp"
+#include "ksw_collect.hpp"
 #include <sched.h>
 #include <pthread.h>
 #include <cctype>
@@ -480,7 +481,7 @@ int batch_plan_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int see
 // requests on several threads (the contig engine does it inside each builder's own task).
 int batch_plan_wait(nsgpu_ctx *c, AlignBatch &B, int part, KswDevResults &R)
 {
-    R = KswDevResults{nullptr, nullptr, nullptr, nullptr, nullptr};
+    R = KswDevResults{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     if (B.plan_ws < 0) return NSGPU_OK;
     const int ws = B.plan_ws;
     if (part == 1) B.plan_ws = -1;
@@ -502,6 +503,10 @@ int batch_plan_wait(nsgpu_ctx *c, AlignBatch &B, int part, KswDevResults &R)
 // request i's problems from the results of `part` into its job's cache; returns how many (0: not this part's, not planned, lost, or done before).
 // Part 1 takes whatever has not been delivered yet unless own_part_only.  ~0u: the status word is up but what it announces does not add up yet
 // (a word raised by a kernel that is still running overtook its data): ask again.
+// NSGPU_CONS_DEBUG: alignments by their longest DP problem -- [kind: gap fill / left ext / right ext / left ext, target longer / right ext, target
+// longer][width class of its target][anti-diagonals, bucketed]
+uint64_t g_dp_shape[5][4][8];
+const bool g_dp_shape_on = getenv("NSGPU_CONS_DEBUG") != nullptr;
 uint32_t batch_plan_deliver_one(AlignBatch &B, const KswDevResults &R, size_t i, int part, bool own_part_only)
 {
     using namespace mm2;
@@ -513,24 +518,46 @@ uint32_t batch_plan_deliver_one(AlignBatch &B, const KswDevResults &R, size_t i,
     if (own_part_only && part == 1 && !o.slow) return 0;         // (two threads, one per part: the first part's requests are the other thread's)
     const uint32_t st = __atomic_load_n(&R.status[q], __ATOMIC_ACQUIRE);
     if (st != 1u) return 0;                            // (2: the CIGAR arena overflowed: the job asks for its problems again)
-    {   // the word may have been raised by a kernel that is still running (ksw_collect.hpp): believe it once what it announces adds up
-        uint32_t sum = 0;
+    {   // the word may have been raised by a kernel that is still running (ksw_collect.hpp): believe it once what it announces adds up -- the
+        // check word is seeded with the batch's epoch and the alignment, and every word counts with its position in the hand-over.  Nothing
+        // outside the landing zones is read: an offset that has not arrived yet is all ones (ksw_dev_launch), or anything at all
+        if ((uint64_t)B.plan_base[i] + o.n_tasks > R.n_slots) return ~0u;
+        uint32_t sum = dv_check_seed(R.epoch, q);
+        const uint32_t n_rw = o.n_tasks * (uint32_t)(sizeof(KswResult) / 4);
         const uint32_t *rw = reinterpret_cast<const uint32_t *>(R.res + B.plan_base[i]);
-        for (uint32_t k = 0; k < o.n_tasks * (uint32_t)(sizeof(KswResult) / 4); ++k) sum += rw[k];
+        for (uint32_t k = 0; k < n_rw; ++k) sum += dv_check_term(k, rw[k]);
+        const uint64_t base = R.coff[B.plan_base[i]];
+        uint64_t total = 0;
         for (uint32_t t = 0; t < o.n_tasks; ++t) {
             const uint32_t slot = B.plan_base[i] + t;
             const uint64_t at = R.coff[slot];
             const uint32_t nc = (uint32_t)R.res[slot].n_cigar;
-            sum += (uint32_t)at;
-            if (nc > (1u << 24)) return ~0u;
-            for (uint32_t k = 0; k < nc; ++k) sum += R.cig[at + k];
+            if (nc > (1u << 24) || at < base || at - base != total || at + nc > R.cig_cap) return ~0u;       // (the CIGARs of an alignment lie back to back in task order)
+            for (uint32_t k = 0; k < nc; ++k) sum += dv_check_term(n_rw + (uint32_t)total + k, R.cig[at + k]);
+            total += nc;
         }
+        for (uint32_t t = 0; t < o.n_tasks; ++t) sum += dv_check_term(n_rw + (uint32_t)total + t, (uint32_t)R.coff[B.plan_base[i] + t]);
         if (sum != __atomic_load_n(&R.check[q], __ATOMIC_ACQUIRE)) return ~0u;       // not all of it is here yet: ask again
     }
     B.plan_delivered[i] = 1;
     AlignJob &J = B.jobs[i];
     if (J.finished) return 0;
     const PlanKey *keys = B.plan_keys.as<PlanKey>();
+    if (g_dp_shape_on) {
+        // NSGPU_CONS_DEBUG: what an alignment's longest problem looks like (a slot waits for the slowest of its alignments)
+        long long best = -1; int kind = 0, cell_w = 0;
+        for (uint32_t t = 0; t < o.n_tasks; ++t) {
+            const PlanKey &k = keys[B.plan_base[i] + t];
+            const int ql = k.qe - k.qs, tl = k.re - k.rs;
+            if (ql <= 0 || tl <= 0) continue;
+            const long long rows = ksw_rows_bound(ql, tl, k.w);
+            if (rows > best) best = rows, kind = (k.flag & 0x08) ? 0 : (k.flag & 0x02) ? 1 : 2, cell_w = tl <= 256 ? 0 : tl <= 512 ? 1 : tl <= 1536 ? 2 : 3, kind += (!(k.flag & 0x08) && tl > ql) ? 2 : 0;
+        }
+        if (best >= 0) {
+            const int bk = best < 256 ? 0 : best < 512 ? 1 : best < 768 ? 2 : best < 1024 ? 3 : best < 1536 ? 4 : best < 2048 ? 5 : best < 3072 ? 6 : 7;
+            __atomic_fetch_add(&g_dp_shape[kind][cell_w][bk], 1, __ATOMIC_RELAXED);
+        }
+    }
     for (uint32_t t = 0; t < o.n_tasks; ++t) {
         const uint32_t slot = B.plan_base[i] + t;
         const KswResult &r = R.res[slot];

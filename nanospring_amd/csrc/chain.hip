@@ -585,16 +585,16 @@ int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vecto
     const ChainParams P{opt.max_gap, opt.bw, opt.max_chain_skip, opt.max_chain_iter, opt.chain_gap_scale};
     int32_t *hf = W.h_out.as<int32_t>(), *hp = hf + total;
     if (n_level) {      // a workgroup of sixteen waves per long list (chain_forward_level_kernel), beside the other launches
-        static bool level_set = false;
-        if (!level_set) { NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_forward_level_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)level_lds_bytes(kFastBw))); level_set = true; }
+        static LdsAttr level_attr;
+        NS_TRY(level_attr.raise(level_lds_bytes(kFastBw), reinterpret_cast<const void *>(chain_forward_level_kernel)));
         if (!W.stream2) NS_TRY(role_stream_create(&W.stream2, "seeds"));
         hipLaunchKernelGGL(chain_forward_level_kernel, dim3(n_level), dim3(kLvWaves * 64), level_lds_bytes(opt.bw), W.stream2, ha, hl, hj + n_lds + n_big + n_ring, hf, hp, P);
         NS_HIP(hipGetLastError());
         W.ring_used = true;
     }
     if (n_ring) {       // the longest lists first; like the LDS kernel it reads the pinned staging buffer and writes the pinned results itself
-        static bool ring_set = false;
-        if (!ring_set) { NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_forward_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds_bytes(kFastBw))); ring_set = true; }
+        static LdsAttr ring_attr;
+        NS_TRY(ring_attr.raise(ring_lds_bytes(kFastBw), reinterpret_cast<const void *>(chain_forward_ring_kernel)));
         if (!W.stream2) NS_TRY(role_stream_create(&W.stream2, "seeds"));
         hipLaunchKernelGGL(chain_forward_ring_kernel, dim3(n_ring), dim3(64), ring_lds_bytes(opt.bw), W.stream2, ha, hl, hj + n_lds + n_big, hf, hp, P);
         NS_HIP(hipGetLastError());

@@ -107,6 +107,26 @@ struct SeqStore {
     void release() { packed.release(); poff.release(); len.release(); n = 0; }
 };
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): launches come from several host threads and, with
+// several contexts in one process, for several devices.  One of these per kernel: raise(bytes, kernel) sets the attribute when the
+// current device has not seen that many bytes for the kernel yet.
+struct LdsAttr {
+    std::mutex m;
+    size_t cap[64] = {};
+    int raise(size_t bytes, const void *kernel)
+    {
+        int dev = 0;
+        NS_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64) dev = 0, bytes = bytes > 65536 ? bytes : 65536;
+        std::lock_guard<std::mutex> lk(m);
+        if (bytes > cap[dev]) {
+            NS_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            cap[dev] = bytes;
+        }
+        return NSGPU_OK;
+    }
+};
+
 struct Timer {
     hipEvent_t a = nullptr, b = nullptr;
     int init() { NS_HIP(hipEventCreate(&a)); NS_HIP(hipEventCreate(&b)); return NSGPU_OK; }
@@ -167,6 +187,7 @@ struct nsgpu_ctx {
         nsgpu::PinBuf hv_res, hv_coff, hv_cig, hv_ctrl, hv_status, hv_check;
         hipEvent_t dv_part0 = nullptr;                                  // behind the first part of a two-part batch's results
         uint32_t dv_npairs_launched = 0; bool dv_two_phase = false;
+        uint32_t dv_epoch = 0;                   // device batches launched on this workspace so far (seed of the hand-over's check words)
         uint32_t dv_slots = 0, dv_pairs = 0, dv_classes = 0;                         // dv_classes: bit k = class k was launched
         uint64_t dv_p_hint = 0, dv_hcig_hint = 0, dv_hcig_cap = 0;
         bool dv_pending = false;

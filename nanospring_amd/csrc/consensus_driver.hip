@@ -35,6 +35,7 @@
 namespace nsgpu {
 namespace mm2 { extern std::atomic<uint64_t> g_step_ns[6]; }
 extern double g_finish_ms[5];
+extern uint64_t g_dp_shape[5][4][8];
 extern double g_sketch_ms[6];
 namespace cons { extern std::atomic<uint64_t> g_emit_ns[4]; extern std::atomic<uint64_t> g_upd_ns[6]; extern std::atomic<uint64_t> g_mp_cnt[3]; extern std::atomic<int64_t> g_slabs_in_use, g_slabs_peak, g_slabs_mapped; }
 
@@ -76,6 +77,7 @@ struct Builder {
     mm2::AlnOut aln;
     bool accepted = false;
     bool early_updated = false, early_result = false;      // the graph was updated / the result taken over ahead of the slot's end (engine_early_updates)
+    bool taken = false;                                     // one group: the builder's alignment is in a batch of this slot already (the first lane's, launched before the windows)
     // cached index of the current main path
     mm2::RefIndex idx;
     bool idx_valid = false;
@@ -332,7 +334,6 @@ struct Engine {
     uint32_t rank = 0, world = 1, n_total = 0;     // global builder count
     uint64_t n_done_global = 0;
     double t0 = 0;
-    std::vector<uint32_t> who;
     std::string qbuf;
     std::vector<uint64_t> qoff, foff;
     std::vector<uint32_t> fids;
@@ -340,27 +341,43 @@ struct Engine {
     uint64_t slot_long_n[4] = {0, 0, 0, 0};
     double slot_long_ms[4] = {0, 0, 0, 0};
     double g1_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // one-group schedule, wall time of a slot's steps (debug report)
-    double sk_ms[6] = {0, 0, 0, 0, 0, 0};           // engine_batches_sketch: splice plan, requests, sketch call, index loop, enqueue of seeds..DP, wait + first step
     uint64_t role_serial_ns[4] = {0, 0, 0, 0};
     std::vector<FinishedContig *> emit_queue;      // finished contigs whose emission has not run yet
-    std::vector<uint64_t> mz_off[2];                // minimizer offsets of a sketch batch ([0]; [1] unused)
-    std::vector<SketchReq> sk_reqs;                 // requests of a sketch batch: changed consensus stretches, then the candidates
-    std::vector<uint32_t> sk_ref;                   // per builder of the batch: its consensus request (~0u: consensus unchanged)
-    std::vector<uint64_t> stage_off;                // offsets of the builders' consensus minimizer lists in the seeding kernel's staging buffer
-    std::vector<size_t> tail_from;                  // per builder of the batch: first list entry that travels this time
-    std::vector<TailCopy> tail_jobs;
-    PinBuf pin_tail;                                // the scatter kernel's job descriptors
-    std::vector<uint8_t> cons_changed;              // per builder of the batch: its consensus changed since the batch before
+    // Scratch of one alignment batch in the making (engine_batches_sketch .. engine_align_finish).  One per batch that can be in flight at a
+    // time: a group's (index = group), or -- ONE group -- the two lanes of a slot (0: the builders that wait for an alignment right after the
+    // host phase, launched at once; 1: those that had to open a window or start a contig first), which are made on two threads.
+    struct Lane {
+        std::vector<uint32_t> who;
+        std::vector<uint64_t> mz_off;                   // minimizer offsets of the sketch batch
+        std::vector<SketchReq> sk_reqs;                 // requests of a sketch batch: changed consensus stretches, then the candidates
+        std::vector<uint32_t> sk_ref;                   // per builder of the batch: its consensus request (~0u: consensus unchanged)
+        std::vector<uint64_t> stage_off;                // offsets of the builders' consensus minimizer lists in the seeding kernel's staging buffer
+        std::vector<size_t> tail_from;                  // per builder of the batch: first list entry that travels this time
+        std::vector<TailCopy> tail_jobs;
+        PinBuf pin_tail;                                // the scatter kernel's job descriptors
+        std::vector<uint8_t> cons_changed;              // per builder of the batch: its consensus changed since the batch before
+        std::vector<ConsJob> cons_jobs;
+        PinBuf pin_cons;                                // cons_update_kernel's job descriptors
+        hipStream_t cons_stream = nullptr; hipEvent_t cons_ev = nullptr;
+        std::vector<char> cons_check;                   // NSGPU_CONS_CHECK: a device copy read back
+        std::vector<DevBuf> retired;                    // resident lists replaced by larger ones, freed at the lane's next batch
+        std::vector<mm2::AlnOut> outs;
+        std::vector<uint8_t> early_sure;                // per request: its claim cannot fail (engine_early_updates)
+            double sk_ms[6] = {0, 0, 0, 0, 0, 0};           // engine_batches_sketch: splice plan, requests, sketch call, index loop, enqueue of seeds..DP, wait + first step
+        int sketch_ws = 0;                              // mm_sketch workspace of the lane's batches
+        void release()
+        {
+            for (DevBuf &d : retired) d.release();
+            retired.clear();
+            pin_tail.release(), pin_cons.release();
+            if (cons_stream) { (void)hipStreamSynchronize(cons_stream); (void)hipStreamDestroy(cons_stream); (void)hipEventDestroy(cons_ev); cons_stream = nullptr; }
+        }
+    } lane[kMaxGroups];
     std::vector<uint32_t> global_pends;             // several ranks, one-group schedule: the reads ALL ranks' builders align in this slot, sorted (run_consensus_dist)
     bool have_global_pends = false;
-    std::vector<uint32_t> early_pends; std::vector<int32_t> early_widx; std::vector<uint8_t> early_sure;      // scratch of engine_early_updates
+    std::vector<uint32_t> early_pends; std::vector<int32_t> early_widx; std::vector<int8_t> early_lane;      // scratch of engine_early_updates
     double early_part_ms[2] = {0, 0}, early_task_ms = 0, early_task_max_ms = 0, early_conv_ms = 0;     // debug report: wall of the two parts' loops, sum / per-slot maximum of their tasks, skeleton + conversion inside
     uint64_t n_early = 0, n_early_retry = 0; double early_ms = 0;      // (retry: a status word seen before all of its data, ksw_collect.hpp)       // graph updates run ahead of the slot's end / wall of that (debug print)
-    std::vector<ConsJob> cons_jobs;
-    PinBuf pin_cons;                                // cons_update_kernel's job descriptors
-    hipStream_t cons_stream = nullptr; hipEvent_t cons_ev = nullptr;
-    std::vector<char> cons_check;                   // NSGPU_CONS_CHECK: a device copy read back
-    std::vector<DevBuf> retired;                    // resident lists replaced by larger ones, freed at the next call
     double crit_u_ms = 0, crit_m_ms = 0;              // sum over host phases of the slowest update_graph / main-path recompute (debug print)
     std::vector<uint32_t> dbg_batch_sizes;          // alignments per batch, in order (debug print: how full the slots are over the run)
     uint64_t n_wq_exact = 0;                          // window-query batches that went the exact multi-step way
@@ -368,7 +385,6 @@ struct Engine {
     AlignBatch ab[kMaxGroups];                        // alignment batch of each group, DP kernels in flight between part 1 and part 2
     std::vector<uint32_t> fwho;                    // builders of the window-query batch
     std::vector<uint32_t> awho[kMaxGroups];           // builders of that batch
-    std::vector<mm2::AlnOut> outs;
     Builder *local(uint32_t gid) { return gid % world == rank ? &D.B[gid / world] : nullptr; }
     // ---- conflict-aware seeds (nsgpu_set_schedule; SURVEY 8e "assign seed reads by MinHash bucket locality") ----
     // Reads are grouped once into buckets of the whole-read filter graph (x -- y when y is a filter result of x or of its reverse
@@ -415,10 +431,7 @@ static void engine_free(void *p)
     pool_drain();                                     // no emission task may outlive the engine
     Engine *E = static_cast<Engine *>(p);
     for (Builder &b : E->D.B) { b.d_mz.release(); b.d_cons.release(); }
-    for (DevBuf &d : E->retired) d.release();
-    E->pin_tail.release();
-    E->pin_cons.release();
-    if (E->cons_stream) { (void)hipStreamSynchronize(E->cons_stream); (void)hipStreamDestroy(E->cons_stream); (void)hipEventDestroy(E->cons_ev); }
+    for (Engine::Lane &L : E->lane) L.release();
     delete E;
 }
 
@@ -478,6 +491,7 @@ static void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
     if (!only_fresh) E->deferred_fresh = -1;
     par_for_pinned("host.phase", D.B.size(), [&](size_t i) {
         Builder &b = D.B[i];
+        if (b.taken) return;                  // (its alignment is in a batch of this slot, being made on another thread: nothing to do here, nothing to touch)
         if ((in_group(b, group) && (!only_fresh || b.st == Builder::ADVANCE)) || (dg >= 0 && in_group(b, dg) && b.st == Builder::ADVANCE)) {
             D.advance(b);
             // which stretch of the changed consensus has to be sketched again: here, while the strings are in this thread's cache, and not as
@@ -821,17 +835,16 @@ __global__ void mz_tail_scatter_kernel(const TailCopy *__restrict__ jobs, uint32
 // The contigs' consensus strings in HBM brought up to date for the builders of an alignment batch (after the sketch batch staged the changed
 // stretches, before the plan kernel reads them), and AlignReq.ref_dev pointed at them.  A builder whose copy cannot be updated (nothing
 // staged to update it from) goes without the device plan this time.
-static int engine_cons_update(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std::vector<uint32_t> &who, const std::vector<uint8_t> &changed, const std::vector<uint32_t> &sk_ref, int sws_i)
+static int engine_cons_update(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std::vector<uint32_t> &who, const std::vector<uint8_t> &changed, const std::vector<uint32_t> &sk_ref, Engine::Lane &L)
 {
     Driver &D = E->D;
-    (void)sws_i;
-    std::vector<ConsJob> &jobs = E->cons_jobs;
+    std::vector<ConsJob> &jobs = L.cons_jobs;
     jobs.clear();
     const size_t n = who.size();
     for (size_t w = 0; w < n; ++w) {
         Builder &b = D.B[who[w]];
         const size_t Ln = b.g->main_path.size();
-        const uint8_t *staged = changed[w] && sk_ref[w] != ~0u ? sketch_dev_seq(c, 0, sk_ref[w]) : nullptr;
+        const uint8_t *staged = changed[w] && sk_ref[w] != ~0u ? sketch_dev_seq(c, L.sketch_ws, sk_ref[w]) : nullptr;
         if (changed[w]) {
             const bool full = b.sp.full || !b.dc_valid;
             if (!staged || (full && !b.sp.full) || Ln >= (1ull << 31)) { b.dc_valid = false; continue; }      // nothing whole to (re)build the copy from
@@ -839,7 +852,7 @@ static int engine_cons_update(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std
             J.len_new = Ln, J.full = full;
             if (full) {
                 const size_t want = 2 * Ln + (256u << 10);
-                if (b.d_cons.cap < want) { if (b.d_cons.p) E->retired.push_back(b.d_cons); b.d_cons = DevBuf(); NS_TRY(b.d_cons.reserve(2 * want)); }
+                if (b.d_cons.cap < want) { if (b.d_cons.p) L.retired.push_back(b.d_cons); b.d_cons = DevBuf(); NS_TRY(b.d_cons.reserve(2 * want)); }
                 J.buf = b.d_cons.as<uint8_t>(), J.mid = staged, J.beg_new = (b.d_cons.cap - Ln) / 2;
             } else {
                 const size_t Lo = b.dc_len, P = b.sp.P, S = b.sp.S;
@@ -855,9 +868,9 @@ static int engine_cons_update(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std
                     DevBuf bigger;
                     NS_TRY(bigger.reserve(4 * Ln + (512u << 10)));
                     const size_t nb = (bigger.cap - Lo) / 2;
-                    if (!E->cons_stream) { NS_TRY(role_stream_create(&E->cons_stream, "seeds")); NS_HIP(hipEventCreateWithFlags(&E->cons_ev, hipEventDisableTiming)); }
-                    NS_HIP(hipMemcpyAsync(bigger.as<uint8_t>() + nb, b.d_cons.as<uint8_t>() + b.dc_beg, Lo, hipMemcpyDeviceToDevice, E->cons_stream));
-                    E->retired.push_back(b.d_cons);
+                    if (!L.cons_stream) { NS_TRY(role_stream_create(&L.cons_stream, "seeds")); NS_HIP(hipEventCreateWithFlags(&L.cons_ev, hipEventDisableTiming)); }
+                    NS_HIP(hipMemcpyAsync(bigger.as<uint8_t>() + nb, b.d_cons.as<uint8_t>() + b.dc_beg, Lo, hipMemcpyDeviceToDevice, L.cons_stream));
+                    L.retired.push_back(b.d_cons);
                     b.d_cons = bigger, b.dc_beg = nb;
                     move_prefix = P <= S;
                 }
@@ -872,24 +885,24 @@ static int engine_cons_update(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std
         else AB.reqs[w].qry_dev = nullptr;
     }
     if (!jobs.empty()) {
-        NS_TRY(E->pin_cons.reserve(jobs.size() * sizeof(ConsJob)));
-        memcpy(E->pin_cons.p, jobs.data(), jobs.size() * sizeof(ConsJob));
+        NS_TRY(L.pin_cons.reserve(jobs.size() * sizeof(ConsJob)));
+        memcpy(L.pin_cons.p, jobs.data(), jobs.size() * sizeof(ConsJob));
         // on a stream of its own beside the seeding and chaining kernels: only the plan kernel behind them reads the copies (it waits for cons_ev)
-        if (!E->cons_stream) { NS_TRY(role_stream_create(&E->cons_stream, "seeds")); NS_HIP(hipEventCreateWithFlags(&E->cons_ev, hipEventDisableTiming)); }
-        hipLaunchKernelGGL(cons_update_kernel, dim3(16, (uint32_t)jobs.size()), dim3(256), 0, E->cons_stream, E->pin_cons.as<ConsJob>());
+        if (!L.cons_stream) { NS_TRY(role_stream_create(&L.cons_stream, "seeds")); NS_HIP(hipEventCreateWithFlags(&L.cons_ev, hipEventDisableTiming)); }
+        hipLaunchKernelGGL(cons_update_kernel, dim3(16, (uint32_t)jobs.size()), dim3(256), 0, L.cons_stream, L.pin_cons.as<ConsJob>());
         NS_HIP(hipGetLastError());
-        NS_HIP(hipEventRecord(E->cons_ev, E->cons_stream));
-        AB.plan_wait_ev = E->cons_ev;
+        NS_HIP(hipEventRecord(L.cons_ev, L.cons_stream));
+        AB.plan_wait_ev = L.cons_ev;
     } else AB.plan_wait_ev = nullptr;
     static const bool check = getenv("NSGPU_CONS_CHECK") != nullptr;          // every device copy against the host's string (the contig tests run under it)
     if (check) {
-        if (E->cons_stream) NS_HIP(hipStreamSynchronize(E->cons_stream));
+        if (L.cons_stream) NS_HIP(hipStreamSynchronize(L.cons_stream));
         for (size_t w = 0; w < n; ++w) {
             Builder &b = D.B[who[w]];
             if (!b.dc_valid) continue;
-            E->cons_check.resize(b.dc_len);
-            NS_HIP(hipMemcpy(E->cons_check.data(), b.d_cons.as<uint8_t>() + b.dc_beg, b.dc_len, hipMemcpyDeviceToHost));
-            if (b.dc_len != b.g->main_path.size() || memcmp(E->cons_check.data(), b.g->main_path.data(), b.dc_len) != 0) {
+            L.cons_check.resize(b.dc_len);
+            NS_HIP(hipMemcpy(L.cons_check.data(), b.d_cons.as<uint8_t>() + b.dc_beg, b.dc_len, hipMemcpyDeviceToHost));
+            if (b.dc_len != b.g->main_path.size() || memcmp(L.cons_check.data(), b.g->main_path.data(), b.dc_len) != 0) {
                 fprintf(stderr, "CONSENSUS COPY MISMATCH: builder %u, %zu bases (P %zu S %zu full %d)\n", b.gid, b.dc_len, b.sp.P, b.sp.S, (int)b.sp.full);
                 abort();
             }
@@ -898,15 +911,20 @@ static int engine_cons_update(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std
     return NSGPU_OK;
 }
 
-static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
+// lane >= 0 (ONE group): the batch of the slot's lane `lane` -- every builder that waits for an alignment and is in no batch of the slot yet
+static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws, int lane = -1)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
     nsgpu_consensus_stats &S = c->cons_stats;
-    const int gi = group < 0 ? 0 : group;
-    std::vector<uint32_t> &who = E->who;
-    who.clear();
-    for (Builder &b : D.B) if (in_group(b, group) && b.st == Builder::WAIT_ALIGN) who.push_back(b.id);
+    const int gi = lane >= 0 ? lane : group < 0 ? 0 : group;
+    Engine::Lane &L = E->lane[gi];
+    L.sketch_ws = lane == 1 ? 1 : 0;
+    std::vector<uint32_t> &who = L.who;
+    if (lane < 0) {               // (a lane's builders were chosen by engine_lane_select, on the thread that runs the host phases)
+        who.clear();
+        for (Builder &b : D.B) if (in_group(b, group) && b.st == Builder::WAIT_ALIGN) who.push_back(b.id);
+    }
     AlignBatch &AB = E->ab[gi];
     AB.reqs.clear();
     AB.host_ms = 0;
@@ -920,15 +938,15 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
     // index builds while the GPU chains the first) and were slower: a sketch call costs what its ~25 launches and its round trips cost
     // whatever its size (sketch + index 2.6 instead of 2.0 s per cfg2 step), and a chaining launch lasts as long as its longest list.
     // The requests: the changed stretch of every changed consensus (plan_splice, run where the consensus changed), then the candidate reads.
-    std::vector<SketchReq> &sk = E->sk_reqs;
-    std::vector<uint32_t> &sk_ref = E->sk_ref;
+    std::vector<SketchReq> &sk = L.sk_reqs;
+    std::vector<uint32_t> &sk_ref = L.sk_ref;
     sk.clear();
     sk_ref.assign(n, ~0u);
     bool unplanned = false;
     for (size_t w = 0; w < n && !unplanned; ++w) { const Builder &b = D.B[who[w]]; unplanned = !b.idx_valid && !b.sp_ready; }
     if (unplanned) par_for("sketch.plan", n, [&](size_t w) { Builder &b = D.B[who[w]]; if (!b.idx_valid && !b.sp_ready) plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k); });
     double tk = now_ms();
-    E->sk_ms[0] += tk - g0;
+    L.sk_ms[0] += tk - g0;
     for (size_t w = 0; w < n; ++w) {
         Builder &b = D.B[who[w]];
         if (b.idx_valid) continue;
@@ -940,26 +958,26 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
     for (size_t w = 0; w < n; ++w) sk.push_back(SketchReq{D.B[who[w]].query.data(), D.B[who[w]].query.size()});
     AB.reqs.resize(n);
     if (AB.jobs.size() < n) AB.jobs.resize(n);
-    E->sk_ms[1] += now_ms() - tk; tk = now_ms();
+    L.sk_ms[1] += now_ms() - tk; tk = now_ms();
     const mm2::Anchor *mz = nullptr;
-    std::vector<uint64_t> &mo = E->mz_off[0];
-    NS_TRY(gpu_mm_sketch(c, sk, (int)c->prm.m_w, (int)c->prm.m_k, mz, mo, 0));
-    E->sk_ms[2] += now_ms() - tk; tk = now_ms();
+    std::vector<uint64_t> &mo = L.mz_off;
+    NS_TRY(gpu_mm_sketch(c, sk, (int)c->prm.m_w, (int)c->prm.m_k, mz, mo, L.sketch_ws));
+    L.sk_ms[2] += now_ms() - tk; tk = now_ms();
     static const bool resident_lists = getenv("NSGPU_NO_RESIDENT_LISTS") == nullptr;      // A/B switch: consensus minimizer lists staged whole, as in round 2
-    std::vector<size_t> &tail_from = E->tail_from;
+    std::vector<size_t> &tail_from = L.tail_from;
     tail_from.assign(n, 0);
     // the plan kernel (plan.hip) reads the candidate where the sketch batch staged it and the consensus from the contig's resident copy
     const bool use_dev_plan = dp_ws >= 0;
-    std::vector<uint8_t> &changed = E->cons_changed;
+    std::vector<uint8_t> &changed = L.cons_changed;
     changed.assign(n, 0);
     for (size_t w = 0; w < n; ++w) changed[w] = !D.B[who[w]].idx_valid;
     // lists retired by an earlier call: their last reader (that call's seeding kernel) has been waited for since
-    for (DevBuf &d : E->retired) d.release();
-    E->retired.clear();
+    for (DevBuf &d : L.retired) d.release();
+    L.retired.clear();
     // The consensus minimizers of every builder go to the seeding kernel through one pinned staging buffer: room for each list
     // is set aside from an upper bound of its length after the splice (old list + newly sketched stretch).
     const int sws_i = 1 + 2 * gi;
-    std::vector<uint64_t> &so = E->stage_off;
+    std::vector<uint64_t> &so = L.stage_off;
     so.assign(n + 1, 0);
     for (size_t w = 0; w < n; ++w) {
         const Builder &b = D.B[who[w]];
@@ -974,7 +992,7 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
         Builder &b = D.B[who[w]];
         const size_t qi = q_base + w;
         AB.reqs[w] = AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), mz + mo[qi], (size_t)(mo[qi + 1] - mo[qi]), stage + so[w], 0};
-        if (use_dev_plan) AB.reqs[w].qry_dev = sketch_dev_seq(c, 0, qi);       // (the consensus side: filled in below, once the device copies are up to date)
+        if (use_dev_plan) AB.reqs[w].qry_dev = sketch_dev_seq(c, L.sketch_ws, qi);       // (the consensus side: filled in below, once the device copies are up to date)
     }
     NS_TRY(align_prestep_start(c, AB, 0, n));
     // one loop over the builders: the minimizers of the changed consensus (splice), its base codes, the list into the staging
@@ -1010,13 +1028,13 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
         AB.reqs[w].n_ref_mz = b.mz.size();
         AB.jobs[w].seed_prepare();
     });
-    E->sk_ms[3] += now_ms() - tk; tk = now_ms();
+    L.sk_ms[3] += now_ms() - tk; tk = now_ms();
     if (resident_lists) {
         // room in the resident lists (growing one copies what it keeps), then ONE kernel moves every tail into place, on the stream the
         // seeding kernel is launched on right behind it
         nsgpu_ctx::SeedWs &SW = c->seed_ws[sws_i];
         if (!SW.stream) NS_TRY(role_stream_create(&SW.stream, "seeds"));
-        std::vector<TailCopy> &jobs = E->tail_jobs;
+        std::vector<TailCopy> &jobs = L.tail_jobs;
         jobs.clear();
         uint32_t max_n = 0;
         for (size_t w = 0; w < n; ++w) {
@@ -1026,7 +1044,7 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
                 DevBuf bigger;
                 NS_TRY(bigger.reserve(std::max<size_t>(2 * n_new, 16384) * sizeof(mm2::Anchor)));
                 if (from) NS_HIP(hipMemcpyAsync(bigger.p, b.d_mz.p, from * sizeof(mm2::Anchor), hipMemcpyDeviceToDevice, SW.stream));
-                E->retired.push_back(b.d_mz);         // freed once the stream is known to be past this slot (engine_batches_sketch's next call)
+                L.retired.push_back(b.d_mz);         // freed once the stream is known to be past this slot (engine_batches_sketch's next call)
                 b.d_mz = bigger;
             }
             if (n_new > from) { jobs.push_back(TailCopy{stage + so[w], b.d_mz.as<mm2::Anchor>() + from, (uint32_t)(n_new - from), 0}); max_n = std::max(max_n, (uint32_t)(n_new - from)); }
@@ -1034,32 +1052,32 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
             AB.reqs[w].ref_mz_dev = b.d_mz.as<mm2::Anchor>();
         }
         if (!jobs.empty()) {
-            NS_TRY(E->pin_tail.reserve(jobs.size() * sizeof(TailCopy)));
-            memcpy(E->pin_tail.p, jobs.data(), jobs.size() * sizeof(TailCopy));
+            NS_TRY(L.pin_tail.reserve(jobs.size() * sizeof(TailCopy)));
+            memcpy(L.pin_tail.p, jobs.data(), jobs.size() * sizeof(TailCopy));
             const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>(64, (max_n + 255) / 256));
-            hipLaunchKernelGGL(mz_tail_scatter_kernel, dim3(gx, (uint32_t)jobs.size()), dim3(256), 0, SW.stream, E->pin_tail.as<TailCopy>(), (uint32_t)jobs.size());
+            hipLaunchKernelGGL(mz_tail_scatter_kernel, dim3(gx, (uint32_t)jobs.size()), dim3(256), 0, SW.stream, L.pin_tail.as<TailCopy>(), (uint32_t)jobs.size());
             NS_HIP(hipGetLastError());
         }
     }
-    if (use_dev_plan) NS_TRY(engine_cons_update(c, E, AB, who, changed, sk_ref, sws_i));
+    if (use_dev_plan) NS_TRY(engine_cons_update(c, E, AB, who, changed, sk_ref, L));
     else for (size_t w = 0; w < n; ++w) if (changed[w]) D.B[who[w]].dc_valid = false;          // (a batch that does not update the device copies leaves them stale)
     NS_TRY(align_prestep_launch(c, AB, 0, n, sws_i, true, use_dev_plan ? dp_ws : -1));
-    E->sk_ms[4] += now_ms() - tk; tk = now_ms();
+    L.sk_ms[4] += now_ms() - tk; tk = now_ms();
     NS_TRY(align_prestep_finish(c, AB, 0, n, sws_i));
-    E->sk_ms[5] += now_ms() - tk;
+    L.sk_ms[5] += now_ms() - tk;
     E->awho[gi] = who;
-    E->dbg_batch_sizes.push_back((uint32_t)who.size());
+    if (lane < 0) E->dbg_batch_sizes.push_back((uint32_t)who.size());
     { std::lock_guard<std::mutex> lk(c->stat_m); S.index_ms += now_ms() - g0; }
     return NSGPU_OK;
 }
 
 // batches, part 1: seeds / chains / DP plan of the alignments sketched in the stage before, and the launch of the DP kernels
 // -- which stay in flight until part 2
-static int engine_batches_begin(nsgpu_ctx *c, int group, int ws_index)
+static int engine_batches_begin(nsgpu_ctx *c, int group, int ws_index, int lane = -1)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     nsgpu_consensus_stats &S = c->cons_stats;
-    const int gi = group < 0 ? 0 : group;
+    const int gi = lane >= 0 ? lane : group < 0 ? 0 : group;
     if (E->awho[gi].empty()) return NSGPU_OK;
     const double g1 = now_ms();
     AlignBatch &AB = E->ab[gi];
@@ -1146,36 +1164,44 @@ static int engine_window_queries(nsgpu_ctx *c, int group)
 // batch aligns the same read, the read is unclaimed (claims and seed grants are only ever written between slots) -- update their graph and
 // consensus at once: the slot's host phase, which used to wait for the slowest DP problem, is left with the stragglers.  Same result: the
 // update touches the builder's own graph only, and the claim it anticipates is the one the slot's end resolves.
-static int engine_early_updates(nsgpu_ctx *c, int group)
+static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
-    const int gi = group < 0 ? 0 : group;
-    std::vector<uint32_t> &who = E->awho[gi];
-    AlignBatch &AB = E->ab[gi];
-    if (who.empty() || !AB.plan_two_part) return NSGPU_OK;
+    // the batches this call serves: those with alignments and results in two parts
+    int act[kMaxGroups], n_act = 0;
+    for (int k = 0; k < n_gi; ++k) if (!E->awho[gis[k]].empty() && E->ab[gis[k]].plan_two_part) act[n_act++] = gis[k];
+    if (!n_act) return NSGPU_OK;
     const double g0 = now_ms();
-    const size_t n = who.size();
-    if (E->outs.size() < n) E->outs.resize(n);
-    AB.early_done.assign(n, 0);
-    // contested reads: two builders of the batch align the same one (the lower builder's claim decides)
+    // contested reads: two builders of the slot align the same one (the lower builder's claim decides) -- over ALL the slot's batches
     std::vector<uint32_t> &pends = E->early_pends;
-    pends.resize(n);
-    for (size_t w = 0; w < n; ++w) pends[w] = D.B[who[w]].pend;
+    pends.clear();
+    for (int k = 0; k < n_gi; ++k) for (uint32_t bi : E->awho[gis[k]]) pends.push_back(D.B[bi].pend);
     // (several ranks: the other ranks' builders count as well -- their candidate reads came with the slot's exchange, run_consensus_dist)
     const bool global_known = E->world == 1 || E->have_global_pends;
     std::vector<uint32_t> sorted(E->world == 1 || !E->have_global_pends ? pends : E->global_pends);
     if (E->world == 1 || !E->have_global_pends) std::sort(sorted.begin(), sorted.end());
     E->have_global_pends = false;
-    // builder -> its request in the batch, and whether its claim cannot fail
+    // builder -> its batch and its request in it, and whether its claim cannot fail
     std::vector<int32_t> &widx = E->early_widx;
+    std::vector<int8_t> &lane_of = E->early_lane;
     widx.assign(D.B.size(), -1);
-    std::vector<uint8_t> &sure = E->early_sure;
-    sure.assign(n, 0);
-    for (size_t w = 0; w < n; ++w) {
-        widx[who[w]] = (int32_t)w;
-        const auto range = std::equal_range(sorted.begin(), sorted.end(), pends[w]);
-        sure[w] = range.second - range.first == 1 && !D.in_graph[pends[w]] && global_known;
+    lane_of.assign(D.B.size(), -1);
+    for (int k = 0; k < n_act; ++k) {
+        const int gi = act[k];
+        const std::vector<uint32_t> &who = E->awho[gi];
+        Engine::Lane &L = E->lane[gi];
+        AlignBatch &AB = E->ab[gi];
+        const size_t n = who.size();
+        if (L.outs.size() < n) L.outs.resize(n);
+        AB.early_done.assign(n, 0);
+        L.early_sure.assign(n, 0);
+        for (size_t w = 0; w < n; ++w) {
+            widx[who[w]] = (int32_t)w, lane_of[who[w]] = (int8_t)gi;
+            const uint32_t pend = D.B[who[w]].pend;
+            const auto range = std::equal_range(sorted.begin(), sorted.end(), pend);
+            L.early_sure[w] = range.second - range.first == 1 && !D.in_graph[pend] && global_known;
+        }
     }
     // One part of the results (0: the alignments without a problem in a late class, there behind the bulk classes; 1: the others): ONE task per
     // builder, on the thread its graph lives with -- its problems' results into its job, the skeleton to the end, the conversion, and when
@@ -1184,152 +1210,165 @@ static int engine_early_updates(nsgpu_ctx *c, int group)
     // first part's slowest update (it used to wait for that, then for the claims, and was updated in the next host phase).
     std::atomic<uint64_t> n_updates{0}, n_tasks{0}, n_retry{0};
     std::atomic<uint64_t> task_ns{0}, task_max_ns{0}, conv_ns{0};
-    auto run_part = [&](int part, const KswDevResults &R) {
-        const double p0 = now_ms();
-        struct Fin { Engine *E; int part; double p0; ~Fin() { E->early_part_ms[part] += now_ms() - p0; } } fin{E, part, p0};
-        // (pinned like the host phase: a builder's graph stays with one thread's caches; handing the tasks out longest-first to whichever thread
-        // is free measured the same -- the loop is as long as its longest task, 0.7 ms, and as the tasks' sum over the cores, 0.65 ms)
-        par_for_pinned("host.early", D.B.size(), [&](size_t i) {
-            const int32_t w = widx[i];
-            if (w < 0) return;
-            // (only what THIS call delivered is touched: the other part's builders are the other thread's)
-            const double k0 = now_ms();
-            struct Tk { std::atomic<uint64_t> &sum, &mx; double k0; ~Tk() { const uint64_t d = (uint64_t)((now_ms() - k0) * 1e6); sum += d; uint64_t m = mx.load(); while (d > m && !mx.compare_exchange_weak(m, d)) {} } } tk{task_ns, task_max_ns, k0};
-            const uint32_t got = batch_plan_deliver_one(AB, R, (size_t)w, part, true);
-            if (!got || got == ~0u) return;
-            n_tasks += got;
-            if (!align_early_one(AB, (size_t)w, E->outs[w])) return;
-            conv_ns += (uint64_t)((now_ms() - k0) * 1e6);
-            Builder &b = D.B[i];
-            std::swap(b.aln, E->outs[w]);
-            b.early_result = true;
-            if (!(b.aln.ok && sure[w])) return;
-            const double t0 = now_ms();
-            D.apply_alignment(b);
-            plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k);
-            b.sp_ready = true;
-            b.early_updated = true;
-            b.cpu_ms += now_ms() - t0;
-            n_updates += 1;
-        });
+    struct Tk { std::atomic<uint64_t> &sum, &mx; double k0; ~Tk() { const uint64_t d = (uint64_t)((now_ms() - k0) * 1e6); sum += d; uint64_t m = mx.load(); while (d > m && !mx.compare_exchange_weak(m, d)) {} } };
+    // a builder whose alignment has been delivered: the skeleton to its end, the conversion, and -- its claim cannot fail -- the graph update
+    auto finish_builder = [&](size_t i, int gi, size_t w, double k0) {
+        AlignBatch &AB = E->ab[gi];
+        Engine::Lane &L = E->lane[gi];
+        if (!align_early_one(AB, w, L.outs[w])) return;
+        conv_ns += (uint64_t)((now_ms() - k0) * 1e6);
+        Builder &b = D.B[i];
+        std::swap(b.aln, L.outs[w]);
+        b.early_result = true;
+        if (!(b.aln.ok && L.early_sure[w])) return;
+        const double t0 = now_ms();
+        D.apply_alignment(b);
+        plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k);
+        b.sp_ready = true;
+        b.early_updated = true;
+        b.cpu_ms += now_ms() - t0;
+        n_updates += 1;
     };
     // The DP kernels hand every alignment over the moment its last problem is done (ksw_collect.hpp): no parts -- every pool thread keeps looking at
     // the status words of ITS builders' alignments (the pinned assignment of the host phase) and runs a builder's task as soon as its word is
-    // up, sleeping 10 us when nothing of its own is ready; the batch's closing word ends the watch for whatever was not handed over (a full
+    // up, sleeping 10 us when nothing of its own is ready; the batches' closing words end the watch for whatever was not handed over (a full
     // CIGAR arena: align_finish asks for those problems again).  An alignment whose longest problem is short is finished and applied while the
     // launch's longest problems are still running.
-    {
-        KswDevResults R;
-        const volatile uint32_t *done = nullptr;
-        if (AB.plan_ws >= 0 && ksw_dev_poll(c, AB.plan_ws, R, done)) {
-            const PlanOut *po = AB.plan_out.as<PlanOut>();
-            const size_t T = std::max<size_t>(1, (size_t)host_threads());
-            const double p0 = now_ms();
-            par_for_pinned("host.early", T, [&](size_t t) {
-                static thread_local const int slack_set = prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);      // (a 10 us sleep is 10 us, not 60)
-                (void)slack_set;
-                uint32_t mine[64];
-                size_t n_mine = 0;
-                for (size_t i = t; i < D.B.size() && n_mine < 64; i += T) {
-                    const int32_t w = widx[i];
-                    if (w < 0 || (size_t)w >= AB.plan_pair.size() || AB.plan_pair[w] == ~0u || AB.plan_delivered[w]) continue;
-                    const PlanOut o = po[AB.plan_pair[w]];
-                    if (o.flags || o.n_tasks == 0) continue;
-                    mine[n_mine++] = (uint32_t)i;
-                }
-                bool closing = false;
-                // (a batch that never closes -- a GPU fault -- must not hold the pool for ever: align_finish's wait reports it)
-                static const double give_up_ms = [] { const char *e = getenv("NSGPU_WAIT_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return (v > 0 ? v : 120.0) * 1e3; }();
-                while (n_mine) {
-                    if (now_ms() - p0 > give_up_ms) break;
-                    bool progressed = false;
-                    for (size_t k = 0; k < n_mine;) {
-                        const size_t i = mine[k];
-                        const int32_t w = widx[i];
-                        const uint32_t st = __atomic_load_n(&R.status[AB.plan_pair[w]], __ATOMIC_ACQUIRE);
-                        if (st == 0) { ++k; continue; }
-                        if (st == 1u && !AB.plan_delivered[w]) {
-                            // (the status word is up: is everything it announces here?  If not, look again in a moment)
-                            const uint32_t got = batch_plan_deliver_one(AB, R, (size_t)w, 1, false);
-                            if (got == ~0u) { ++k; n_retry += 1; continue; }
-                            n_tasks += got;
-                        }
-                        mine[k] = mine[--n_mine];
-                        progressed = true;
-                        if (st != 1u) continue;                                   // (not handed over: align_finish's rounds)
-                        const double k0 = now_ms();
-                        struct Tk { std::atomic<uint64_t> &sum, &mx; double k0; ~Tk() { const uint64_t d = (uint64_t)((now_ms() - k0) * 1e6); sum += d; uint64_t m = mx.load(); while (d > m && !mx.compare_exchange_weak(m, d)) {} } } tk{task_ns, task_max_ns, k0};
-                        if (!align_early_one(AB, (size_t)w, E->outs[w])) continue;
-                        conv_ns += (uint64_t)((now_ms() - k0) * 1e6);
-                        Builder &b = D.B[i];
-                        std::swap(b.aln, E->outs[w]);
-                        b.early_result = true;
-                        if (!(b.aln.ok && sure[w])) continue;
-                        const double t0 = now_ms();
-                        D.apply_alignment(b);
-                        plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k);
-                        b.sp_ready = true;
-                        b.early_updated = true;
-                        b.cpu_ms += now_ms() - t0;
-                        n_updates += 1;
-                    }
-                    if (progressed || !n_mine) continue;
-                    if (closing) break;                                           // one more look after the closing word, then leave
-                    if (*done) { closing = true; continue; }
-                    timespec ts = {0, 10000};
-                    nanosleep(&ts, nullptr);
-                }
-            });
-            E->early_part_ms[0] += now_ms() - p0;
-            E->n_early_retry += n_retry.load();
-            E->n_early += n_updates.load();
-            E->early_task_ms += task_ns.load() / 1e6, E->early_task_max_ms += task_max_ns.load() / 1e6, E->early_conv_ms += conv_ns.load() / 1e6;
-            { std::lock_guard<std::mutex> lk(c->stat_m); c->aln_dp_tasks += n_tasks.load(); c->cons_stats.graph_ms += now_ms() - g0; }
-            E->early_ms += now_ms() - g0;
-            return NSGPU_OK;
-        }
+    KswDevResults Rp[kMaxGroups];
+    const volatile uint32_t *donep[kMaxGroups];
+    const PlanOut *pop[kMaxGroups];
+    bool polled[kMaxGroups];
+    int n_polled = 0;
+    for (int gi = 0; gi < kMaxGroups; ++gi) polled[gi] = false, donep[gi] = nullptr, pop[gi] = nullptr;
+    for (int k = 0; k < n_act; ++k) {
+        const int gi = act[k];
+        AlignBatch &AB = E->ab[gi];
+        if (AB.plan_ws >= 0 && ksw_dev_poll(c, AB.plan_ws, Rp[gi], donep[gi])) { polled[gi] = true, pop[gi] = AB.plan_out.as<PlanOut>(), ++n_polled; }
     }
-    static const bool one_part_early = getenv("NSGPU_EARLY_ONE_PART") != nullptr;        // A/B switch: only the first part runs ahead, as in the first version
-    int rc1 = NSGPU_OK;
-    std::string err1;
-    std::thread t1;
-    // (the second part's wait begins once the first part has been waited for: the two never race for the workspace's state)
-    KswDevResults R0;
-    const int rc0 = batch_plan_wait(c, AB, 0, R0);
-    if (rc0 == NSGPU_OK && !one_part_early)
-        t1 = std::thread([&] {
-            pool_bind_this_thread();
-            KswDevResults R1;
-            rc1 = hipSetDevice(c->prm.device) == hipSuccess ? batch_plan_wait(c, AB, 1, R1) : NSGPU_ERR_HIP;
-            if (rc1 != NSGPU_OK) err1 = nsgpu_last_error();
-            else if (R1.res) run_part(1, R1);
+    if (n_polled) {
+        const size_t T = std::max<size_t>(1, (size_t)host_threads());
+        const double p0 = now_ms();
+        par_for_pinned("host.early", T, [&](size_t t) {
+            static thread_local const int slack_set = prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);      // (a 10 us sleep is 10 us, not 60)
+            (void)slack_set;
+            static thread_local std::vector<uint32_t> mine;          // (any number of builders per thread: few threads, many builders)
+            mine.clear();
+            size_t n_mine = 0;
+            for (size_t i = t; i < D.B.size(); i += T) {
+                const int32_t w = widx[i];
+                const int gi = lane_of[i];
+                if (w < 0 || gi < 0 || !polled[gi]) continue;
+                const AlignBatch &AB = E->ab[gi];
+                if ((size_t)w >= AB.plan_pair.size() || AB.plan_pair[w] == ~0u || AB.plan_delivered[w]) continue;
+                const PlanOut o = pop[gi][AB.plan_pair[w]];
+                if (o.flags || o.n_tasks == 0) continue;
+                mine.push_back((uint32_t)i), ++n_mine;
+            }
+            bool closing = false;
+            // (a batch that never closes -- a GPU fault -- must not hold the pool for ever: align_finish's wait reports it)
+            static const double give_up_ms = [] { const char *e = getenv("NSGPU_WAIT_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return (v > 0 ? v : 120.0) * 1e3; }();
+            while (n_mine) {
+                if (now_ms() - p0 > give_up_ms) break;
+                bool progressed = false;
+                for (size_t k = 0; k < n_mine;) {
+                    const size_t i = mine[k];
+                    const int32_t w = widx[i];
+                    const int gi = lane_of[i];
+                    AlignBatch &AB = E->ab[gi];
+                    const uint32_t st = __atomic_load_n(&Rp[gi].status[AB.plan_pair[w]], __ATOMIC_ACQUIRE);
+                    if (st == 0) { ++k; continue; }
+                    if (st == 1u && !AB.plan_delivered[w]) {
+                        // (the status word is up: is everything it announces here?  If not, look again in a moment)
+                        const uint32_t got = batch_plan_deliver_one(AB, Rp[gi], (size_t)w, 1, false);
+                        if (got == ~0u) { ++k; n_retry += 1; continue; }
+                        n_tasks += got;
+                    }
+                    mine[k] = mine[--n_mine];
+                    progressed = true;
+                    if (st != 1u) continue;                                   // (not handed over: align_finish's rounds)
+                    const double k0 = now_ms();
+                    Tk tk{task_ns, task_max_ns, k0};
+                    finish_builder(i, gi, (size_t)w, k0);
+                }
+                if (progressed || !n_mine) continue;
+                if (closing) break;                                           // one more look after the closing words, then leave
+                bool all_done = true;
+                for (int gi = 0; gi < kMaxGroups; ++gi) if (polled[gi] && !*donep[gi]) all_done = false;
+                if (all_done) { closing = true; continue; }
+                timespec ts = {0, 10000};
+                nanosleep(&ts, nullptr);
+            }
         });
-    if (rc0 == NSGPU_OK && R0.res) run_part(0, R0);
-    if (t1.joinable()) t1.join();
-    if (rc0 != NSGPU_OK) return rc0;
-    if (rc1 != NSGPU_OK) { set_error("%s", err1.empty() ? "contig engine: the second part of the results failed" : err1.c_str()); return rc1; }
+        E->early_part_ms[0] += now_ms() - p0;
+        E->n_early_retry += n_retry.load();
+    }
+    // batches whose results come from collecting kernels behind the launches (NSGPU_KSW_NO_INLINE_COLLECT=1): part 0 here, part 1 on a second thread
+    static const bool one_part_early = getenv("NSGPU_EARLY_ONE_PART") != nullptr;        // A/B switch: only the first part runs ahead, as in the first version
+    int rc_all = NSGPU_OK;
+    for (int k = 0; k < n_act && rc_all == NSGPU_OK; ++k) {
+        const int gi = act[k];
+        if (polled[gi]) continue;
+        AlignBatch &AB = E->ab[gi];
+        auto run_part = [&](int part, const KswDevResults &R) {
+            const double p0 = now_ms();
+            struct Fin { Engine *E; int part; double p0; ~Fin() { E->early_part_ms[part] += now_ms() - p0; } } fin{E, part, p0};
+            // (pinned like the host phase: a builder's graph stays with one thread's caches)
+            par_for_pinned("host.early", D.B.size(), [&](size_t i) {
+                const int32_t w = widx[i];
+                if (w < 0 || lane_of[i] != gi) return;
+                // (only what THIS call delivered is touched: the other part's builders are the other thread's)
+                const double k0 = now_ms();
+                Tk tk{task_ns, task_max_ns, k0};
+                const uint32_t got = batch_plan_deliver_one(AB, R, (size_t)w, part, true);
+                if (!got || got == ~0u) return;
+                n_tasks += got;
+                finish_builder(i, gi, (size_t)w, k0);
+            });
+        };
+        int rc1 = NSGPU_OK;
+        std::string err1;
+        std::thread t1;
+        // (the second part's wait begins once the first part has been waited for: the two never race for the workspace's state)
+        KswDevResults R0;
+        const int rc0 = batch_plan_wait(c, AB, 0, R0);
+        if (rc0 == NSGPU_OK && !one_part_early)
+            t1 = std::thread([&] {
+                pool_bind_this_thread();
+                KswDevResults R1;
+                rc1 = hipSetDevice(c->prm.device) == hipSuccess ? batch_plan_wait(c, AB, 1, R1) : NSGPU_ERR_HIP;
+                if (rc1 != NSGPU_OK) err1 = nsgpu_last_error();
+                else if (R1.res) run_part(1, R1);
+            });
+        if (rc0 == NSGPU_OK && R0.res) run_part(0, R0);
+        if (t1.joinable()) t1.join();
+        if (rc0 != NSGPU_OK) rc_all = rc0;
+        else if (rc1 != NSGPU_OK) { set_error("%s", err1.empty() ? "contig engine: the second part of the results failed" : err1.c_str()); rc_all = rc1; }
+    }
+    if (rc_all != NSGPU_OK) return rc_all;
     E->n_early += n_updates.load();
     E->early_task_ms += task_ns.load() / 1e6, E->early_task_max_ms += task_max_ns.load() / 1e6, E->early_conv_ms += conv_ns.load() / 1e6;
-    { std::lock_guard<std::mutex> lk(c->stat_m); c->aln_dp_tasks += n_tasks.load(); }
-    { std::lock_guard<std::mutex> lk(c->stat_m); c->cons_stats.graph_ms += now_ms() - g0; }
+    { std::lock_guard<std::mutex> lk(c->stat_m); c->aln_dp_tasks += n_tasks.load(); c->cons_stats.graph_ms += now_ms() - g0; }
     E->early_ms += now_ms() - g0;
     return NSGPU_OK;
 }
+static int engine_early_updates(nsgpu_ctx *c, int group) { const int gi = group < 0 ? 0 : group; return engine_early_updates(c, &gi, 1); }
 
-static int engine_align_finish(nsgpu_ctx *c, int group)
+static int engine_align_finish(nsgpu_ctx *c, int group, int lane = -1)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
     nsgpu_consensus_stats &S = c->cons_stats;
-    const int gi = group < 0 ? 0 : group;
+    const int gi = lane >= 0 ? lane : group < 0 ? 0 : group;
     std::vector<uint32_t> &who = E->awho[gi];
     if (who.empty()) return NSGPU_OK;
+    Engine::Lane &L = E->lane[gi];
     const double g1 = now_ms();
-    NS_TRY(align_finish(c, E->ab[gi], E->outs));
+    NS_TRY(align_finish(c, E->ab[gi], L.outs));
     for (size_t w = 0; w < who.size(); ++w) {
         Builder &b = D.B[who[w]];
-        if (!b.early_result) std::swap(b.aln, E->outs[w]);              // the builder's previous result goes back into the pool of result objects
+        if (!b.early_result) std::swap(b.aln, L.outs[w]);              // the builder's previous result goes back into the pool of result objects
         b.early_result = false;
+        b.taken = false;
         ++b.n_align_calls;
         b.accepted = false;
         b.st = Builder::ALIGNED;
@@ -1421,11 +1460,86 @@ static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
     return NSGPU_OK;
 }
 
+// ---- ONE group: the slot's alignments in two lanes ------------------------------------------------------------------------------------------
+// Right after the host phase most builders know their next alignment; a few have to open a window (one GPU round trip) or start a contig
+// (seed rule, first steps, first window) first.  The first lane -- the builders that are ready -- is launched at once on a thread of its own
+// (sketch .. chain .. DP launch), the windows and seeds run in its shadow, and the builders they release form the second lane.  Same
+// alignments, same slot, same claims at its end: the schedule (the logical clock of DESIGN.md section 2) does not know about lanes.
+// NSGPU_NO_LANES=1: one batch per slot behind the windows and seeds, as before (A/B switch).
+struct LaneFront {
+    std::thread th;
+    int rc = NSGPU_OK;
+    std::string err;
+    double ms = 0;
+    ~LaneFront() { if (th.joinable()) th.join(); }
+};
+static void engine_lane_select(nsgpu_ctx *c, int lane)
+{
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    std::vector<uint32_t> &who = E->lane[lane].who;
+    who.clear();
+    for (Builder &b : E->D.B) if (b.st == Builder::WAIT_ALIGN && !b.taken) { who.push_back(b.id); b.taken = true; }
+}
+static int engine_lane_front(nsgpu_ctx *c, int lane)
+{
+    const int dp_ws = 1 + lane;
+    NS_TRY(engine_batches_sketch(c, -1, dp_ws, lane));
+    return engine_batches_begin(c, -1, dp_ws, lane);
+}
+static void engine_lane0_start(nsgpu_ctx *c, LaneFront &F)
+{
+    static const bool no_lanes = getenv("NSGPU_NO_LANES") != nullptr;
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    E->lane[0].who.clear();
+    if (no_lanes) return;
+    engine_lane_select(c, 0);
+    if (E->lane[0].who.empty()) return;
+    F.th = std::thread([c, &F] {
+        pool_bind_this_thread();
+        const double t0 = now_ms();
+        F.rc = hipSetDevice(c->prm.device) == hipSuccess ? engine_lane_front(c, 0) : NSGPU_ERR_HIP;
+        if (F.rc != NSGPU_OK) F.err = nsgpu_last_error();
+        F.ms = now_ms() - t0;
+    });
+}
+// the rest of the slot's batches: the second lane, the first lane's thread, the results of both with the graph updates riding on the DP phase
+static int engine_lanes_finish(nsgpu_ctx *c, LaneFront *F)
+{
+    Engine *E = static_cast<Engine *>(c->cons_engine);
+    double t0 = now_ms(), t1;
+    const bool first_started = F && F->th.joinable();
+    int rc = NSGPU_OK;
+    // (nothing launched ahead: everybody in the one lane there is, as before)
+    const int late = first_started ? 1 : 0;
+    engine_lane_select(c, late);
+    if (!first_started) E->awho[0].clear(), E->ab[0].reqs.clear();
+    E->awho[1].clear();
+    if (late == 1) E->ab[1].reqs.clear();
+    if (!E->lane[late].who.empty()) rc = engine_lane_front(c, late);
+    std::string err = rc != NSGPU_OK ? nsgpu_last_error() : "";
+    t1 = now_ms(); E->g1_ms[3] += t1 - t0; t0 = t1;
+    if (first_started) {
+        F->th.join();
+        E->g1_ms[5] += F->ms;
+        if (rc == NSGPU_OK && F->rc != NSGPU_OK) rc = F->rc, err = F->err;
+    }
+    t1 = now_ms(); E->g1_ms[4] += t1 - t0; t0 = t1;
+    if (rc != NSGPU_OK) { set_error("%s", err.empty() ? "contig engine: a batch thread failed" : err.c_str()); return rc; }
+    E->dbg_batch_sizes.push_back((uint32_t)(E->awho[0].size() + E->awho[1].size()));
+    const int gis[2] = {0, 1};
+    NS_TRY(engine_early_updates(c, gis, 2));
+    t1 = now_ms(); E->g1_ms[6] += t1 - t0; t0 = t1;
+    NS_TRY(engine_align_finish(c, -1, 0));
+    NS_TRY(engine_align_finish(c, -1, 1));
+    E->g1_ms[7] += now_ms() - t0;
+    return NSGPU_OK;
+}
+
 // One pipeline slot: the host phase of group h = slot % G, part 1 (sketches + index + seeds / chains, then the DP launch) of
 // the group that was there one slot earlier, part 2 of group (slot + 1) % G -- whose DP launch has been in flight for a
 // slot -- all concurrently.
 // part: 0 = the whole slot; with ONE group the seeds are granted between the host phase (part 1) and the batches (part 2): see run_consensus
-static int engine_slot(nsgpu_ctx *c, uint32_t slot, int part = 0)
+static int engine_slot(nsgpu_ctx *c, uint32_t slot, int part = 0, LaneFront *front = nullptr)
 {
     const uint32_t G = (uint32_t)n_groups(c);
     const int host_group = (int)(slot % G), begin_group = (int)((slot + G - 1) % G), finish_group = (int)((slot + 1) % G);
@@ -1466,7 +1580,13 @@ static int engine_slot(nsgpu_ctx *c, uint32_t slot, int part = 0)
             if (rc1 == NSGPU_OK && rc2 == NSGPU_OK) { rc1 = engine_align_finish(c, finish_group); if (rc1 != NSGPU_OK) err1 = nsgpu_last_error(); }
             E->g1_ms[7] += now_ms() - t0;
         };
-        if (G == 1) { if (part != 2) engine_advance(c, false, host_group); if (part != 1) chain(); }
+        if (G == 1) {
+            // (part 0: the whole slot in one call, for callers that drive the phases themselves -- its window queries are answered here and
+            // consumed by the next slot's host phase, as with more groups)
+            if (part != 2) engine_advance(c, false, host_group);
+            if (part == 0) NS_TRY(engine_window_queries(c, finish_group));
+            if (part != 1) return engine_lanes_finish(c, front);
+        }
         else if (serial) { engine_advance(c, false, host_group); chain(); }
         else {
             std::thread t1([&] { pool_bind_this_thread(); if (hipSetDevice(c->prm.device) == hipSuccess) chain(); else rc1 = NSGPU_ERR_HIP; });
@@ -1553,6 +1673,18 @@ static void debug_report_slots(nsgpu_ctx *c, Engine *E)
     fprintf(stderr, "\n");
     fprintf(stderr, "[cons] alignments left to the host's plan, by reason (cumulative): no anchors / flagged pair %llu, several chains %llu, seed filtering %llu, outside the staged span %llu, capacity %llu, DP class %llu\n",
             (unsigned long long)c->plan_why[0], (unsigned long long)c->plan_why[1], (unsigned long long)c->plan_why[2], (unsigned long long)c->plan_why[3], (unsigned long long)c->plan_why[4], (unsigned long long)c->plan_why[5]);
+    {
+        static const char *kind[5] = {"gap fill", "left ext (query >= target)", "right ext (query >= target)", "left ext (target longer)", "right ext (target longer)"};
+        static const char *wd[4] = {"<=256", "<=512", "<=1536", ">1536"};
+        fprintf(stderr, "[cons] alignments by their longest DP problem (anti-diagonals < 256 / 512 / 768 / 1024 / 1536 / 2048 / 3072 / more):\n");
+        for (int k = 0; k < 5; ++k) for (int w = 0; w < 4; ++w) {
+            uint64_t tot = 0; for (int b = 0; b < 8; ++b) tot += g_dp_shape[k][w][b];
+            if (!tot) continue;
+            fprintf(stderr, "[cons]   %-28s target %-6s:", kind[k], wd[w]);
+            for (int b = 0; b < 8; ++b) fprintf(stderr, " %llu", (unsigned long long)g_dp_shape[k][w][b]);
+            fprintf(stderr, "\n");
+        }
+    }
     fprintf(stderr, "[cons] early tasks: loops of part 0 / part 1 %.0f / %.0f ms wall; tasks %.0f ms in sum (delivery + skeleton + conversion %.0f), the longest of each slot %.0f ms in sum\n",
             E->early_part_ms[0], E->early_part_ms[1], E->early_task_ms, E->early_conv_ms, E->early_task_max_ms);
     fprintf(stderr, "[cons] graph updates run ahead of the slot's end: %llu, %.0f ms wall (DP results + updates); status words seen ahead of their data: %llu\n", (unsigned long long)E->n_early, E->early_ms, (unsigned long long)E->n_early_retry);
@@ -1570,10 +1702,14 @@ static void debug_report_slots(nsgpu_ctx *c, Engine *E)
         for (int d = 0; d < 10; ++d) { uint64_t sum = 0; const size_t a = nb * d / 10, b = nb * (d + 1) / 10; for (size_t i = a; i < b; ++i) sum += E->dbg_batch_sizes[i]; fprintf(stderr, " %.1f", b > a ? (double)sum / (double)(b - a) : 0.0); }
         fprintf(stderr, "\n");
     }
-    fprintf(stderr, "[cons] one-group slot, wall-ms of its steps: host phase %.0f, windows %.0f, seeds + fresh contigs %.0f, sketch..chain %.0f, DP launch %.0f, wait for the window thread %.0f, first results + early updates %.0f, last results %.0f\n",
+    fprintf(stderr, "[cons] one-group slot, wall-ms of its steps: host phase %.0f, windows %.0f, seeds + fresh contigs %.0f, second lane's sketch..DP launch %.0f, wait for the first lane's thread %.0f (its sketch..DP launch, beside the windows and seeds: %.0f), results + early updates %.0f, last results %.0f\n",
             E->g1_ms[0], E->g1_ms[1], E->g1_ms[2], E->g1_ms[3], E->g1_ms[4], E->g1_ms[5], E->g1_ms[6], E->g1_ms[7]);
-    fprintf(stderr, "[cons] sketch..chain, wall-ms of its steps: splice plan %.0f, requests %.0f, sketch call %.0f, splice + index loop %.0f, enqueue of tails / seeds / chain / plan / DP %.0f, wait for seeds + chains and the first step %.0f\n",
-            E->sk_ms[0], E->sk_ms[1], E->sk_ms[2], E->sk_ms[3], E->sk_ms[4], E->sk_ms[5]);
+    for (int l = 0; l < kMaxGroups; ++l) {
+        const double *m = E->lane[l].sk_ms;
+        if (m[0] + m[1] + m[2] + m[3] + m[4] + m[5] > 0)
+            fprintf(stderr, "[cons] sketch..chain of lane / group %d, wall-ms of its steps: splice plan %.0f, requests %.0f, sketch call %.0f, splice + index loop %.0f, enqueue of tails / seeds / chain / plan / DP %.0f, wait for seeds + chains and the first step %.0f\n",
+                    l, m[0], m[1], m[2], m[3], m[4], m[5]);
+    }
     fprintf(stderr, "[cons] slots set by: host phase %llu (%.0f ms), batches part 1 %llu (%.0f ms), part 2 %llu (%.0f ms)\n", (unsigned long long)E->slot_long_n[0],
             E->slot_long_ms[0], (unsigned long long)E->slot_long_n[1], E->slot_long_ms[1], (unsigned long long)E->slot_long_n[2], E->slot_long_ms[2]);
 }
@@ -1684,12 +1820,16 @@ static int run_consensus_inner(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_thr
             NS_TRY(engine_slot(c, slot, 1));
             double t1 = now_ms();
             E->g1_ms[0] += t1 - t;
+            // the builders that know their next alignment go ahead (sketch .. chain .. DP launch on a thread of its own); the windows and the
+            // seeds of the others run in its shadow (engine_lanes_finish picks those up)
+            LaneFront front;
+            engine_lane0_start(c, front);
             NS_TRY(engine_window_loop(c, h));
             E->g1_ms[1] += now_ms() - t1; t1 = now_ms();
             engine_seed_requests(c, ga, gb, h);
             if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) { engine_advance(c, true, h); NS_TRY(engine_window_loop(c, h)); }
             E->g1_ms[2] += now_ms() - t1;
-            NS_TRY(engine_slot(c, slot, 2));
+            NS_TRY(engine_slot(c, slot, 2, &front));
             w_slot += now_ms() - t;
             engine_claim_requests(c, ga, gb, b);
             engine_claim_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size());
@@ -1776,6 +1916,8 @@ static int run_consensus_dist(nsgpu_ctx *c, Comm &C, uint32_t n_builders_total, 
         if (G == 1) {
             // ONE group: two small all-gathers per slot -- seed requests after the host phase, claim requests after the batches
             int rc = engine_slot(c, slot, 1);
+            LaneFront front;                     // (see run_consensus: the builders that are ready go ahead of the windows, the seeds and the exchanges)
+            if (rc == NSGPU_OK) engine_lane0_start(c, front);
             if (rc == NSGPU_OK) rc = engine_window_loop(c, h);
             if (rc == NSGPU_OK) engine_seed_requests(c, sa, sb, h);
             NS_TRY(exchange(rc, nullptr, nullptr, &sa, &sb));
@@ -1794,7 +1936,7 @@ static int run_consensus_dist(nsgpu_ctx *c, Comm &C, uint32_t n_builders_total, 
             E->global_pends.assign(gb.begin(), gb.end());
             std::sort(E->global_pends.begin(), E->global_pends.end());
             E->have_global_pends = true;
-            rc = engine_slot(c, slot, 2);
+            rc = engine_slot(c, slot, 2, &front);
             if (rc == NSGPU_OK) engine_claim_requests(c, ca, cb, b);
             NS_TRY(exchange(rc, &ca, &cb, nullptr, nullptr));
             gathered(1);

@@ -85,6 +85,7 @@ struct PlanDp {            // where the plan kernel puts its DP tasks (buffers o
     KswTask *tasks; KswResult *res; uint32_t *class_list; uint32_t *class_cnt; uint32_t n_slots;
     uint32_t *task_pair;                                 // task slot -> alignment (for the DP kernels' own hand-over, ksw_collect.hpp)
     uint32_t class_grid[KSW_REG_CLASSES];               // workgroups the class's launch has: entries of its list beyond that are never run
+    uint32_t *pair_done;                                 // alignment -> problems that are complete (ksw_collect.hpp): the plan kernel counts the EMPTY problems it resolves itself
     uint8_t *seqs; unsigned long long *cursors;          // cursors: traceback bytes, CIGAR entries, sequence bytes handed out so far
     unsigned long long p_cap; uint32_t cig_cap, seq_cap;
 };
@@ -101,7 +102,9 @@ int plan_launch(hipStream_t st, uint32_t n_pairs, uint32_t lds_anchors, const Se
 // The results come in two parts: the alignments none of whose problems runs in a late class (part 0: behind the bulk of one-wave problems on
 // the main stream), then the rest (part 1: behind everything).  res[slot] / cig + coff[slot] are valid for the task slots of the alignments
 // whose status[pair] == 1 (2: the pinned CIGAR arena overflowed -- those alignments are the host's to redo).
-struct KswDevResults { const KswResult *res; const uint64_t *coff; const uint32_t *cig; const uint32_t *status; const uint32_t *check; };
+// cig_cap / n_slots: how many CIGAR entries / task slots the landing zones hold (nothing beyond is read); epoch: the batch's number on its workspace
+// (seeds the hand-over's check word, ksw_collect.hpp)
+struct KswDevResults { const KswResult *res; const uint64_t *coff; const uint32_t *cig; const uint32_t *status; const uint32_t *check; uint64_t cig_cap; uint32_t n_slots, epoch; };
 int ksw_dev_prepare(nsgpu_ctx *c, int ws_index, uint32_t n_slots, uint32_t n_pairs, uint64_t seq_bytes_bound, hipStream_t st, PlanDp &dp);
 int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr, hipEvent_t after, const PlanPair *pairs, const PlanOut *outs, uint32_t n_pairs, bool two_phase);
 int ksw_dev_collect(nsgpu_ctx *c, int ws_index, int part, KswDevResults &out);

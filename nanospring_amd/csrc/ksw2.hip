@@ -1116,6 +1116,7 @@ int ksw_dev_prepare(nsgpu_ctx *c, int ws_index, uint32_t n_slots, uint32_t n_pai
     dp.class_cnt = W.dv_ctrl.as<DvCtrl>()->class_cnt, dp.n_slots = n_slots, dp.seqs = W.dv_seqs.as<uint8_t>();
     dp.cursors = W.dv_ctrl.as<DvCtrl>()->cursors;
     dp.task_pair = W.dv_tpair.as<uint32_t>();
+    dp.pair_done = W.dv_pdone.as<uint32_t>();
     for (int k = 0; k < KSW_REG_CLASSES; ++k) dp.class_grid[k] = dev_class_grid(k, n_slots, n_pairs);
     dp.p_cap = p_cap, dp.cig_cap = (uint32_t)std::min<uint64_t>(cig_cap, 0xffffffffull), dp.seq_cap = (uint32_t)seq_bytes_bound;
     return NSGPU_OK;
@@ -1154,7 +1155,12 @@ int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr
     NS_TRY(W.hv_ctrl.reserve(sizeof(DvCtrl)));
     NS_TRY(W.hv_status.reserve((size_t)n_pairs * 4 + 64));
     NS_TRY(W.hv_check.reserve((size_t)n_pairs * 4 + 64));
+    // nothing of the batch before may look like this one's: status and check words cleared, offsets beyond every arena, and a new epoch in the
+    // check word's seed (a status word that overtook its data must find no self-consistent old hand-over under it)
     memset(W.hv_status.p, 0, (size_t)n_pairs * 4);
+    memset(W.hv_check.p, 0, (size_t)n_pairs * 4);
+    memset(W.hv_coff.p, 0xff, ((size_t)n + 1) * 8);
+    ++W.dv_epoch;
     W.hv_ctrl.as<DvCtrl>()->done = 0;
     W.dv_hcig_cap = hcap, W.dv_npairs_launched = n_pairs, W.dv_two_phase = two_phase;
     // The DP kernels hand every alignment over themselves, the moment its last problem is done (ksw_collect.hpp) -- the host finishes and applies
@@ -1163,7 +1169,7 @@ int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr
     static const bool no_inline = getenv("NSGPU_KSW_NO_INLINE_COLLECT") != nullptr;
     W.dv_inline = !no_inline;
     DvCollect dc{pairs, outs, W.dv_tasks.as<KswTask>(), W.dv_res.as<KswResult>(), W.dv_cig.as<uint32_t>(), W.dv_tpair.as<uint32_t>(), W.dv_inline ? W.dv_pdone.as<uint32_t>() : nullptr,
-                 W.hv_res.as<KswResult>(), W.hv_coff.as<uint64_t>(), W.hv_cig.as<uint32_t>(), hcap, W.hv_status.as<uint32_t>(), W.hv_check.as<uint32_t>(), ctrl, getenv("NSGPU_KSW_NO_PROBE") ? 1u : 0u};
+                 W.hv_res.as<KswResult>(), W.hv_coff.as<uint64_t>(), W.hv_cig.as<uint32_t>(), hcap, W.hv_status.as<uint32_t>(), W.hv_check.as<uint32_t>(), W.dv_epoch, ctrl, getenv("NSGPU_KSW_NO_PROBE") ? 1u : 0u};
     auto launch_class = [&](int k, hipStream_t st) -> int {
         NS_HIP(hipEventRecord(W.dv_ev[2 * k], st));
         NS_TRY(ksw_reg_launch(k, st, dev_class_grid(k, n, W.dv_pairs), ksw_reg_lds_bytes(k, max_qlen), W.dv_tasks.as<KswTask>(), W.dv_list.as<uint32_t>() + (size_t)k * n, pr, W.dv_seqs.as<uint8_t>(),
@@ -1213,16 +1219,21 @@ int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr
     return NSGPU_OK;
 }
 
+static KswDevResults dev_results_of(const nsgpu_ctx::KswWs &W)
+{
+    return KswDevResults{W.hv_res.as<KswResult>(), W.hv_coff.as<uint64_t>(), W.hv_cig.as<uint32_t>(), W.hv_status.as<uint32_t>(), W.hv_check.as<uint32_t>(), W.dv_hcig_cap, W.dv_slots, W.dv_epoch};
+}
+
 // The landing zones of the workspace's batch in flight, without waiting for anything: when its DP kernels hand the alignments over themselves
 // (ksw_collect.hpp) out.status says per alignment whether its results are there, and *done that the whole batch has been handed over.
 // false: no such batch (the caller waits for the parts with ksw_dev_collect).
 bool ksw_dev_poll(nsgpu_ctx *c, int ws_index, KswDevResults &out, const volatile uint32_t *&done)
 {
     nsgpu_ctx::KswWs &W = c->kws[ws_index];
-    out = KswDevResults{nullptr, nullptr, nullptr, nullptr, nullptr};
+    out = KswDevResults{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     done = nullptr;
     if (!W.dv_pending || !W.dv_inline) return false;
-    out.res = W.hv_res.as<KswResult>(), out.coff = W.hv_coff.as<uint64_t>(), out.cig = W.hv_cig.as<uint32_t>(), out.status = W.hv_status.as<uint32_t>(), out.check = W.hv_check.as<uint32_t>();
+    out = dev_results_of(W);
     done = &W.hv_ctrl.as<DvCtrl>()->done;
     return true;
 }
@@ -1231,12 +1242,12 @@ bool ksw_dev_poll(nsgpu_ctx *c, int ws_index, KswDevResults &out, const volatile
 int ksw_dev_collect(nsgpu_ctx *c, int ws_index, int part, KswDevResults &out)
 {
     nsgpu_ctx::KswWs &W = c->kws[ws_index];
-    out = KswDevResults{nullptr, nullptr, nullptr, nullptr, nullptr};
+    out = KswDevResults{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     if (!W.dv_pending) return NSGPU_OK;
     if (part == 0) {
         if (!W.dv_two_phase) return NSGPU_OK;
         NS_HIP(event_wait(W.dv_part0));
-        out.res = W.hv_res.as<KswResult>(), out.coff = W.hv_coff.as<uint64_t>(), out.cig = W.hv_cig.as<uint32_t>(), out.status = W.hv_status.as<uint32_t>(), out.check = W.hv_check.as<uint32_t>();
+        out = dev_results_of(W);
         return NSGPU_OK;
     }
     W.dv_pending = false;
@@ -1245,7 +1256,7 @@ int ksw_dev_collect(nsgpu_ctx *c, int ws_index, int part, KswDevResults &out)
     // scratch that did not fit: the plan kernel left those alignments to the host; larger next time
     if (hc->cursors[0] > std::max<uint64_t>(W.dv_p_hint, 768ull << 20)) W.dv_p_hint = hc->cursors[0] + hc->cursors[0] / 2;
     if (hc->cig_out > W.dv_hcig_cap) W.dv_hcig_hint = hc->cig_out + hc->cig_out / 2;
-    out.res = W.hv_res.as<KswResult>(), out.coff = W.hv_coff.as<uint64_t>(), out.cig = W.hv_cig.as<uint32_t>(), out.status = W.hv_status.as<uint32_t>(), out.check = W.hv_check.as<uint32_t>();
+    out = dev_results_of(W);
     float ms = 0;
     NS_HIP(hipEventElapsedTime(&ms, W.dv_a, W.dv_b));
     double sum_ms = 0;

@@ -1195,15 +1195,8 @@ int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const 
     if (dc_in) dc = *dc_in; else memset(&dc, 0, sizeof(dc));
 #define NS_REG_LAUNCH(NW_, NCH_)                                                                                                              \
     {                                                                                                                                         \
-        static size_t cap = 0;                                                                                                                \
-        static std::mutex cap_m;      /* launches come from several DP workspaces / threads: attribute and record change together */        \
-        if (lds_bytes > 32768) {                                                                                                              \
-            std::lock_guard<std::mutex> lk(cap_m);                                                                                            \
-            if (lds_bytes > cap) {                                                                                                            \
-                NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_reg_kernel<NW_, NCH_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-                cap = lds_bytes;                                                                                                              \
-            }                                                                                                                                 \
-        }                                                                                                                                     \
+        static LdsAttr attr;          /* launches come from several DP workspaces / threads, and per device */                              \
+        if (lds_bytes > 32768) NS_TRY(attr.raise(lds_bytes, reinterpret_cast<const void *>(ksw_extd2_reg_kernel<NW_, NCH_>)));                \
         hipLaunchKernelGGL((ksw_extd2_reg_kernel<NW_, NCH_>), dim3(m), dim3(NW_ * 64), lds_bytes, st, tasks, order, m, pr, seqs, p_pool, cig_pool, res, n_dev, dc); \
     }
     switch (cls) {
@@ -1213,15 +1206,8 @@ int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const 
     case 8: NS_REG_LAUNCH(6, 2) break;
 #define NS_SYS_LAUNCH(NCH_)                                                                                                                   \
     {                                                                                                                                         \
-        static size_t cap = 0;                                                                                                                \
-        static std::mutex cap_m;                                                                                                              \
-        if (lds_bytes > 32768) {                                                                                                              \
-            std::lock_guard<std::mutex> lk(cap_m);                                                                                            \
-            if (lds_bytes > cap) {                                                                                                            \
-                NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_extd2_sys_kernel<NCH_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-                cap = lds_bytes;                                                                                                              \
-            }                                                                                                                                 \
-        }                                                                                                                                     \
+        static LdsAttr attr;                                                                                                                  \
+        if (lds_bytes > 32768) NS_TRY(attr.raise(lds_bytes, reinterpret_cast<const void *>(ksw_extd2_sys_kernel<NCH_>)));                     \
         hipLaunchKernelGGL((ksw_extd2_sys_kernel<NCH_>), dim3(m), dim3((kSysWaves + 1) * 64), lds_bytes, st, tasks, order, m, pr, seqs, p_pool, cig_pool, res, n_dev, dc); \
     }
     case 9: NS_SYS_LAUNCH(1) break;

@@ -22,10 +22,17 @@ struct DvCollect {
     const uint32_t *task_pair;          // task slot -> alignment
     uint32_t *pair_done;                // alignment -> problems completed so far (nullptr: the DP kernels do not hand over, the collecting kernel does)
     KswResult *h_res; uint64_t *h_off; uint32_t *h_cig; uint64_t h_cig_cap; uint32_t *h_status;                         // pinned landing zones
-    uint32_t *h_check;                  // per alignment: the sum of every word handed over (the host adds up what it reads before it believes the status word)
+    uint32_t *h_check;                  // per alignment: dv_check_* over every word handed over (the host recomputes it from what it reads before it believes the status word)
+    uint32_t epoch;                     // the batch's number on its workspace: seeds the check, so that a previous batch's self-consistent words never pass
     DvCtrl *ctrl;
     uint32_t no_probe;                  // NSGPU_KSW_NO_PROBE=1 (experiment): raise the status word without reading the data back first
 };
+
+// The check word of an alignment's hand-over: seeded with the batch's epoch and the alignment's index, every word weighted by its POSITION in the
+// hand-over (result words, then the CIGAR entries in task order, then the offsets) -- words that arrive permuted, or a previous batch's words
+// under this batch's status word, do not add up.  Host (align_batch.hip) and device compute the same sum.
+__host__ __device__ inline uint32_t dv_check_seed(uint32_t epoch, uint32_t pair) { return epoch * 0x9E3779B1u ^ (pair + 1u) * 0x85EBCA6Bu; }
+__host__ __device__ inline uint32_t dv_check_term(uint32_t idx, uint32_t word) { return word * (2u * idx + 1u); }
 
 // One wave (lane 0 .. 63) hands alignment b over.  s_off: 256 words of LDS of the caller's.
 __device__ inline void dev_collect_pair(const DvCollect &dc, uint32_t b, uint32_t lane, uint32_t *s_off)
@@ -61,20 +68,21 @@ __device__ inline void dev_collect_pair(const DvCollect &dc, uint32_t b, uint32_
         return;
     }
     uint32_t chk = 0;
+    const uint32_t n_rw = n * (uint32_t)(sizeof(KswResult) / 4);
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(dc.res + s0);
         uint32_t *dst = reinterpret_cast<uint32_t *>(dc.h_res + s0);
-        for (uint32_t i = lane; i < n * (uint32_t)(sizeof(KswResult) / 4); i += 64) { const uint32_t v = src[i]; dst[i] = v; chk += v; }
+        for (uint32_t i = lane; i < n_rw; i += 64) { const uint32_t v = src[i]; dst[i] = v; chk += dv_check_term(i, v); }
     }
     for (uint32_t t = 0; t < n; ++t) {
         const uint32_t c = (uint32_t)dc.res[s0 + t].n_cigar;
         const unsigned long long at = base + s_off[t];
         const uint32_t *src = dc.pool + dc.tasks[s0 + t].cig_off;
-        for (uint32_t k = lane; k < c; k += 64) { const uint32_t v = src[k]; dc.h_cig[at + k] = v; chk += v; }
+        for (uint32_t k = lane; k < c; k += 64) { const uint32_t v = src[k]; dc.h_cig[at + k] = v; chk += dv_check_term(n_rw + s_off[t] + k, v); }
     }
-    for (uint32_t t = lane; t < n; t += 64) { dc.h_off[s0 + t] = base + s_off[t]; chk += (uint32_t)(base + s_off[t]); }
+    for (uint32_t t = lane; t < n; t += 64) { dc.h_off[s0 + t] = base + s_off[t]; chk += dv_check_term(n_rw + (uint32_t)total + t, (uint32_t)(base + s_off[t])); }
     for (int d = 32; d > 0; d >>= 1) chk += (uint32_t)__shfl_xor((int)chk, d, 64);
-    if (lane == 0) dc.h_check[b] = chk;
+    if (lane == 0) dc.h_check[b] = chk + dv_check_seed(dc.epoch, b);
     __threadfence_system();
     // The host may be watching the status word while this kernel is still running (ksw_dev_poll): the word must not overtake the data on the
     // way to host memory.  Every lane reads one word of what it wrote back from host memory (a system-scope load: a read request does not pass

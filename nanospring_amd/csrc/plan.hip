@@ -484,6 +484,9 @@ __global__ __launch_bounds__(kThreads) void align_plan_kernel(const SeedResult *
             KswResult o;
             o.max = 0, o.zdropped = 0, o.max_q = o.max_t = o.mqe_t = o.mte_q = -1, o.mqe = o.mte = o.score = KNEG, o.n_cigar = 0, o.reach_end = 0;
             dp.res[slot] = o;
+            // (no DP kernel will count it on its alignment: ksw_collect.hpp's hand-over waits for n_tasks problems.  The DP kernels run behind
+            // this one; an alignment ALL of whose problems are empty is handed over by nobody and comes with the batch's end)
+            if (dp.pair_done) atomicAdd(&dp.pair_done[b], 1u);
         }
     }
     // ---- the sequences: 16-byte loads, four in flight per thread; dst[x] (or dst[n - 1 - x]) = code of src[x] ----
@@ -535,15 +538,8 @@ int plan_launch(hipStream_t st, uint32_t n_pairs, uint32_t lds_anchors, const Se
 {
     if (n_pairs == 0) return NSGPU_OK;
     const size_t lds = plan_lds_bytes(lds_anchors);
-    static size_t cap = 0;
-    static std::mutex cap_m;
-    if (lds > 32768) {
-        std::lock_guard<std::mutex> lk(cap_m);
-        if (lds > cap) {
-            NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(align_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            cap = lds;
-        }
-    }
+    static LdsAttr attr;
+    if (lds > 32768) NS_TRY(attr.raise(lds, reinterpret_cast<const void *>(align_plan_kernel)));
     hipLaunchKernelGGL(align_plan_kernel, dim3(n_pairs), dim3(kThreads), lds, st, seeded, anchors, f, p, pairs, out, keys_out, dp, cfg, lds_anchors);
     NS_HIP(hipGetLastError());
     return NSGPU_OK;
