@@ -312,6 +312,7 @@ void nsgpu_destroy(nsgpu_ctx *c)
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }
     c->pin_small.release(); c->pin_foff.release(); c->pin_fids.release(); c->pin_wq.release(); c->pin_wq_out.release();
+    c->rmz.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -531,6 +532,24 @@ int nsgpu_filter_strings_impl(nsgpu_ctx *c, const char *strs, const uint64_t *qo
 int nsgpu_filter_batch(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq, uint64_t **out_off, uint32_t **out_ids)
 {
     NS_CHECK(c && qoff && out_off && out_ids, NSGPU_ERR_ARG, "nsgpu_filter_batch: null argument");
+    if (nq > 0 && nq <= 4096 && c->have_index && c->have_salts) {
+        // a batch of window queries: one kernel from the strings to the candidate lists (kernels_minhash.hip window_query_kernel); what it
+        // declines -- a query with more than 2048 table matches -- goes through the multi-pass kernels below
+        NS_HIP(hipSetDevice(c->prm.device));
+        const uint64_t *fo = nullptr;
+        const uint32_t *fi = nullptr;
+        bool redo = false;
+        NS_TRY(run_window_queries_fast(c, strs, qoff, nq, fo, fi, &redo));
+        if (!redo) {
+            uint64_t *off = (uint64_t *)malloc(((size_t)nq + 1) * 8);
+            uint32_t *ids = (uint32_t *)malloc((fo[nq] + 1) * 4);
+            NS_CHECK(off && ids, NSGPU_ERR_NOMEM, "malloc failed");
+            memcpy(off, fo, ((size_t)nq + 1) * 8);
+            if (fo[nq]) memcpy(ids, fi, fo[nq] * 4);
+            *out_off = off, *out_ids = ids;
+            return NSGPU_OK;
+        }
+    }
     NS_TRY(nsgpu_filter_strings_impl(c, strs, qoff, nq));
     uint64_t *off = (uint64_t *)malloc(((size_t)nq + 1) * 8);
     uint32_t *ids = (uint32_t *)malloc((c->f_total + 1) * 4);

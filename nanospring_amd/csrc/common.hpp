@@ -93,6 +93,15 @@ struct PinBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// mm_sketch.hip: one sequence sketched by ONE launch into a pinned block, without a host wait (mini_sketch_launch / _collect)
+struct MiniSketch {
+    PinBuf buf;
+    hipEvent_t ev = nullptr;
+    uint32_t len = 0, n_tiles = 0;
+    bool pending = false;
+    void release() { buf.release(); if (ev) { (void)hipEventDestroy(ev); ev = nullptr; } pending = false; }
+};
+
 // A set of 2-bit packed sequences in HBM.  Row r starts at byte poff[r]
 // (16-byte aligned, zero padded to the next 16 bytes plus 16 more so that
 // kernels may over-read two dwords) and holds len[r] bases, MSB-first.
@@ -125,6 +134,21 @@ struct LdsAttr {
         }
         return NSGPU_OK;
     }
+};
+
+// mm_sketch.hip reads_mz_build: the text and the (w,k)-minimizers of every read, both strands, resident in HBM for a contig stage.  Read r,
+// strand sd: text at ascii[sd] + h_aoff[r] (len bases), minimizers mz[off[sd][r] .. + cnt[sd][r]) when ok[sd][r].
+struct ReadMz {
+    DevBuf ascii[2], aoff, mz, soff, len, tiles, tcnt, tpal, tbad, toff, scan_ws, flags;
+    std::vector<uint64_t> h_aoff;
+    std::vector<uint64_t> off[2];
+    std::vector<uint32_t> cnt[2];
+    std::vector<uint8_t> ok[2];
+    int w = 0, k = 0;
+    uint64_t n_mz = 0;
+    double build_ms = 0;
+    bool valid = false;
+    void release() { for (DevBuf *d : {&ascii[0], &ascii[1], &aoff, &mz, &soff, &len, &tiles, &tcnt, &tpal, &tbad, &toff, &scan_ws, &flags}) d->release(); valid = false; }
 };
 
 struct Timer {
@@ -228,6 +252,8 @@ struct nsgpu_ctx {
         double ms_wait = 0; uint64_t calls = 0, pairs = 0, fallbacks = 0;
         hipStream_t stream = nullptr;
     } seed_ws[9];
+    std::vector<uint64_t> wq_off; std::vector<uint32_t> wq_ids;      // the last fused window-query batch's candidate lists (run_window_queries_fast)
+    nsgpu::ReadMz rmz;                                               // every read's text and minimizers, both strands (contig stage)
     nsgpu::PinBuf pin_wq, pin_wq_out;                                // the engine's window queries: staging of the strings / candidate lists as the last kernel writes them
     nsgpu::PinBuf pin_small, pin_foff, pin_fids;                     // pinned landing zones: the filter's scalars / the engine's candidate CSR
     double sketch_mm_ms = 0;                                         // wall of the batched mm_sketch calls

@@ -77,7 +77,6 @@ struct Builder {
     mm2::AlnOut aln;
     bool accepted = false;
     bool early_updated = false, early_result = false;      // the graph was updated / the result taken over ahead of the slot's end (engine_early_updates)
-    bool taken = false;                                     // one group: the builder's alignment is in a batch of this slot already (the first lane's, launched before the windows)
     // cached index of the current main path
     mm2::RefIndex idx;
     bool idx_valid = false;
@@ -96,6 +95,10 @@ struct Builder {
     // the entries from the first changed one on travel (a contig grows at its ends: a few hundred entries of tens of thousands).
     DevBuf d_mz;
     size_t d_mz_n = 0;
+    // the changed stretch of the consensus, sketched the moment the update that changed it was done (engine_mini_start): the next batch finds
+    // the minimizers (and the stretch's text, for the device copy of the consensus) here instead of starting with a sketch call
+    MiniSketch mini;
+    bool mini_valid = false;                   // launched for the consensus as it is now (b.sp describes the stretch)
     size_t chg_lb = 0;                         // the main path agrees with mz_str (and idx's base codes) on [0, chg_lb): from ContigGraph::path_changed_from
     std::vector<std::unique_ptr<FinishedContig>> contigs;     // in the order they were finished = output order
     size_t n_queued = 0;                                      // contigs[0 .. n_queued) were handed to the emission queue
@@ -138,6 +141,7 @@ struct Driver {
         b.cur_pos = b.g->start_pos;
         b.right_phase = true, b.edges_too_many = false, b.window_open = false;
         b.idx_valid = false, b.sp_ready = false;
+        b.mini_valid = false;
         b.mz.clear(), b.mz_str.clear();          // a new consensus: nothing to splice into
         b.chg_lb = 0;
         b.d_mz_n = 0;                            // (the resident list's memory stays with the builder)
@@ -311,7 +315,7 @@ struct Driver {
         b.last_u = u1 - u0, b.last_m = u2 - u1;
         if (u1 - u0 > b.dbg_max_u) b.dbg_max_u = u1 - u0;
         if (u2 - u1 > b.dbg_max_m) b.dbg_max_m = u2 - u1;
-        b.idx_valid = false, b.sp_ready = false;
+        b.idx_valid = false, b.sp_ready = false, b.mini_valid = false;
     }
 };
 
@@ -344,8 +348,7 @@ struct Engine {
     uint64_t role_serial_ns[4] = {0, 0, 0, 0};
     std::vector<FinishedContig *> emit_queue;      // finished contigs whose emission has not run yet
     // Scratch of one alignment batch in the making (engine_batches_sketch .. engine_align_finish).  One per batch that can be in flight at a
-    // time: a group's (index = group), or -- ONE group -- the two lanes of a slot (0: the builders that wait for an alignment right after the
-    // host phase, launched at once; 1: those that had to open a window or start a contig first), which are made on two threads.
+    // time: a group's (index = group; one group: index 0).
     struct Lane {
         std::vector<uint32_t> who;
         std::vector<uint64_t> mz_off;                   // minimizer offsets of the sketch batch
@@ -363,6 +366,10 @@ struct Engine {
         std::vector<DevBuf> retired;                    // resident lists replaced by larger ones, freed at the lane's next batch
         std::vector<mm2::AlnOut> outs;
         std::vector<uint8_t> early_sure;                // per request: its claim cannot fail (engine_early_updates)
+        std::vector<std::vector<mm2::Anchor>> mini_mz;  // per request: the stretch's minimizers as the builder's own launch left them (Builder::mini)
+        std::vector<uint8_t> use_mini;                  // per request: ... and whether they are used
+        std::vector<uint32_t> q_ref;                    // per request: its candidate's request in the sketch batch (~0u: the read's minimizers are resident, nsgpu_ctx::rmz)
+        std::vector<const uint8_t *> staged;            // per request: the changed stretch's text in device-visible memory (cons_update_kernel's source)
             double sk_ms[6] = {0, 0, 0, 0, 0, 0};           // engine_batches_sketch: splice plan, requests, sketch call, index loop, enqueue of seeds..DP, wait + first step
         int sketch_ws = 0;                              // mm_sketch workspace of the lane's batches
         void release()
@@ -385,6 +392,8 @@ struct Engine {
     AlignBatch ab[kMaxGroups];                        // alignment batch of each group, DP kernels in flight between part 1 and part 2
     std::vector<uint32_t> fwho;                    // builders of the window-query batch
     std::vector<uint32_t> awho[kMaxGroups];           // builders of that batch
+    hipStream_t mini_st[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // the builders' own sketch launches (engine_mini_start)
+    std::atomic<uint64_t> n_mini{0}, n_mini_used{0}, n_cand_resident{0}, n_sketch_calls{0};
     Builder *local(uint32_t gid) { return gid % world == rank ? &D.B[gid / world] : nullptr; }
     // ---- conflict-aware seeds (nsgpu_set_schedule; SURVEY 8e "assign seed reads by MinHash bucket locality") ----
     // Reads are grouped once into buckets of the whole-read filter graph (x -- y when y is a filter result of x or of its reverse
@@ -430,7 +439,8 @@ static void engine_free(void *p)
 {
     pool_drain();                                     // no emission task may outlive the engine
     Engine *E = static_cast<Engine *>(p);
-    for (Builder &b : E->D.B) { b.d_mz.release(); b.d_cons.release(); }
+    for (hipStream_t &st : E->mini_st) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
+    for (Builder &b : E->D.B) { b.d_mz.release(); b.d_cons.release(); b.mini.release(); }
     for (Engine::Lane &L : E->lane) L.release();
     delete E;
 }
@@ -473,6 +483,12 @@ static int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, 
     memset(&c->cons_stats, 0, sizeof(c->cons_stats));
     c->cons_stats.n_builders = n_builders_total;
     c->have_cons = false;
+    // every read's text and minimizers, both strands, into HBM: a candidate's side of an alignment needs no sketch call any more
+    // (NSGPU_NO_READ_MZ=1: candidates sketched with every slot's batch, as before -- A/B switch)
+    for (hipStream_t &st : E->mini_st) NS_TRY(role_stream_create(&st, "sketch"));
+    static const bool no_read_mz = getenv("NSGPU_NO_READ_MZ") != nullptr;
+    c->rmz.valid = false;
+    if (!no_read_mz && D.N) NS_TRY(reads_mz_build(c, (int)c->prm.m_w, (int)c->prm.m_k));
     return seed_policy_init(c, E);
 }
 
@@ -491,7 +507,6 @@ static void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
     if (!only_fresh) E->deferred_fresh = -1;
     par_for_pinned("host.phase", D.B.size(), [&](size_t i) {
         Builder &b = D.B[i];
-        if (b.taken) return;                  // (its alignment is in a batch of this slot, being made on another thread: nothing to do here, nothing to touch)
         if ((in_group(b, group) && (!only_fresh || b.st == Builder::ADVANCE)) || (dg >= 0 && in_group(b, dg) && b.st == Builder::ADVANCE)) {
             D.advance(b);
             // which stretch of the changed consensus has to be sketched again: here, while the strings are in this thread's cache, and not as
@@ -773,6 +788,24 @@ static size_t apply_splice(Builder &b, const mm2::Anchor *sub, size_t n_sub, int
     return first_diff;
 }
 
+// The changed stretch of b's consensus (b.sp, plan_splice has just run) into a sketch launch of the builder's own -- called on the thread that
+// made the update, right behind it.  Nothing waits here; engine_batches_sketch collects.  NSGPU_NO_MINI_SKETCH=1: every changed stretch goes
+// with the slot's sketch batch, as before (A/B switch).
+static void engine_mini_start(nsgpu_ctx *c, Engine *E, Builder &b)
+{
+    static const bool off = getenv("NSGPU_NO_MINI_SKETCH") != nullptr;
+    b.mini_valid = false;
+    if (off || !b.g) return;
+    const std::string &mp = b.g->main_path;
+    const char *text = b.sp.full ? mp.data() : mp.data() + b.sp.a;
+    const size_t len = b.sp.full ? mp.size() : b.sp.B_sub - b.sp.a;
+    hipStream_t &st = E->mini_st[b.id % 8];
+    if (!st) return;
+    if (mini_sketch_launch(b.mini, text, len, (int)c->prm.m_w, (int)c->prm.m_k, st) != NSGPU_OK) return;      // (too long for this path, or an error: the batch sketches it)
+    b.mini_valid = true;
+    E->n_mini += 1;
+}
+
 // ---- the consensus resident in HBM -----------------------------------------------------------------------------------------------------
 // After an accepted read the new consensus differs from the old one between a common prefix of P and a common suffix of S bases, and the
 // bytes in between travelled with the sketch batch anyway (the re-sketched stretch contains them).  The device copy is brought up to date
@@ -835,7 +868,7 @@ __global__ void mz_tail_scatter_kernel(const TailCopy *__restrict__ jobs, uint32
 // The contigs' consensus strings in HBM brought up to date for the builders of an alignment batch (after the sketch batch staged the changed
 // stretches, before the plan kernel reads them), and AlignReq.ref_dev pointed at them.  A builder whose copy cannot be updated (nothing
 // staged to update it from) goes without the device plan this time.
-static int engine_cons_update(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std::vector<uint32_t> &who, const std::vector<uint8_t> &changed, const std::vector<uint32_t> &sk_ref, Engine::Lane &L)
+static int engine_cons_update(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std::vector<uint32_t> &who, const std::vector<uint8_t> &changed, const std::vector<const uint8_t *> &staged_of, Engine::Lane &L)
 {
     Driver &D = E->D;
     std::vector<ConsJob> &jobs = L.cons_jobs;
@@ -844,7 +877,7 @@ static int engine_cons_update(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std
     for (size_t w = 0; w < n; ++w) {
         Builder &b = D.B[who[w]];
         const size_t Ln = b.g->main_path.size();
-        const uint8_t *staged = changed[w] && sk_ref[w] != ~0u ? sketch_dev_seq(c, L.sketch_ws, sk_ref[w]) : nullptr;
+        const uint8_t *staged = changed[w] ? staged_of[w] : nullptr;
         if (changed[w]) {
             const bool full = b.sp.full || !b.dc_valid;
             if (!staged || (full && !b.sp.full) || Ln >= (1ull << 31)) { b.dc_valid = false; continue; }      // nothing whole to (re)build the copy from
@@ -911,20 +944,16 @@ static int engine_cons_update(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std
     return NSGPU_OK;
 }
 
-// lane >= 0 (ONE group): the batch of the slot's lane `lane` -- every builder that waits for an alignment and is in no batch of the slot yet
-static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws, int lane = -1)
+static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
     nsgpu_consensus_stats &S = c->cons_stats;
-    const int gi = lane >= 0 ? lane : group < 0 ? 0 : group;
+    const int gi = group < 0 ? 0 : group;
     Engine::Lane &L = E->lane[gi];
-    L.sketch_ws = lane == 1 ? 1 : 0;
     std::vector<uint32_t> &who = L.who;
-    if (lane < 0) {               // (a lane's builders were chosen by engine_lane_select, on the thread that runs the host phases)
-        who.clear();
-        for (Builder &b : D.B) if (in_group(b, group) && b.st == Builder::WAIT_ALIGN) who.push_back(b.id);
-    }
+    who.clear();
+    for (Builder &b : D.B) if (in_group(b, group) && b.st == Builder::WAIT_ALIGN) who.push_back(b.id);
     AlignBatch &AB = E->ab[gi];
     AB.reqs.clear();
     AB.host_ms = 0;
@@ -944,24 +973,56 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws, int lane = 
     sk_ref.assign(n, ~0u);
     bool unplanned = false;
     for (size_t w = 0; w < n && !unplanned; ++w) { const Builder &b = D.B[who[w]]; unplanned = !b.idx_valid && !b.sp_ready; }
-    if (unplanned) par_for("sketch.plan", n, [&](size_t w) { Builder &b = D.B[who[w]]; if (!b.idx_valid && !b.sp_ready) plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k); });
+    if (unplanned) par_for("sketch.plan", n, [&](size_t w) { Builder &b = D.B[who[w]]; if (!b.idx_valid && !b.sp_ready) { plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k); b.mini_valid = false; } });
     double tk = now_ms();
     L.sk_ms[0] += tk - g0;
+    // What is there already: the changed stretches the builders sketched themselves right behind their updates (Builder::mini: the launches are
+    // long done -- their events are looked at, nothing is waited for in the common case), and the candidate reads' minimizers, resident in HBM
+    // for the whole stage (nsgpu_ctx::rmz).  What is left -- a stretch too long for a builder's own launch, a string the fused kernel
+    // declined, a read it declined -- goes into ONE sketch call as before; most batches have nothing left.
+    std::vector<uint8_t> &use_mini = L.use_mini;
+    use_mini.assign(n, 0);
+    if (L.mini_mz.size() < n) L.mini_mz.resize(n);
+    {
+        std::atomic<int> mini_rc{NSGPU_OK};
+        bool any = false;
+        for (size_t w = 0; w < n && !any; ++w) { const Builder &b = D.B[who[w]]; any = !b.idx_valid && b.mini_valid; }
+        if (any) par_for("sketch.mini", n, [&](size_t w) {
+            Builder &b = D.B[who[w]];
+            if (b.idx_valid || !b.mini_valid) return;
+            bool ok = false;
+            const int rc = mini_sketch_collect(b.mini, (int)c->prm.m_w, (int)c->prm.m_k, L.mini_mz[w], ok);
+            if (rc != NSGPU_OK) mini_rc = rc;
+            use_mini[w] = ok;
+        });
+        NS_TRY(mini_rc.load());
+    }
+    const ReadMz &RM = c->rmz;
+    std::vector<uint32_t> &q_ref = L.q_ref;
+    q_ref.assign(n, ~0u);
     for (size_t w = 0; w < n; ++w) {
         Builder &b = D.B[who[w]];
-        if (b.idx_valid) continue;
+        b.mini_valid = false;
+        if (b.idx_valid || use_mini[w]) continue;
         sk_ref[w] = (uint32_t)sk.size();
         if (b.sp.full) sk.push_back(SketchReq{b.g->main_path.data(), b.g->main_path.size()});
         else sk.push_back(SketchReq{b.g->main_path.data() + b.sp.a, b.sp.B_sub - b.sp.a});
     }
-    const size_t q_base = sk.size();
-    for (size_t w = 0; w < n; ++w) sk.push_back(SketchReq{D.B[who[w]].query.data(), D.B[who[w]].query.size()});
+    uint64_t n_res = 0, n_used = 0;
+    for (size_t w = 0; w < n; ++w) {
+        const Builder &b = D.B[who[w]];
+        n_used += use_mini[w];
+        if (RM.valid && RM.ok[b.strand][b.pend] && b.query.size() == D.read_len(b.pend)) { ++n_res; continue; }
+        q_ref[w] = (uint32_t)sk.size();
+        sk.push_back(SketchReq{b.query.data(), b.query.size()});
+    }
+    E->n_cand_resident += n_res, E->n_mini_used += n_used;
     AB.reqs.resize(n);
     if (AB.jobs.size() < n) AB.jobs.resize(n);
     L.sk_ms[1] += now_ms() - tk; tk = now_ms();
     const mm2::Anchor *mz = nullptr;
     std::vector<uint64_t> &mo = L.mz_off;
-    NS_TRY(gpu_mm_sketch(c, sk, (int)c->prm.m_w, (int)c->prm.m_k, mz, mo, L.sketch_ws));
+    if (!sk.empty()) { NS_TRY(gpu_mm_sketch(c, sk, (int)c->prm.m_w, (int)c->prm.m_k, mz, mo, L.sketch_ws)); E->n_sketch_calls += 1; }
     L.sk_ms[2] += now_ms() - tk; tk = now_ms();
     static const bool resident_lists = getenv("NSGPU_NO_RESIDENT_LISTS") == nullptr;      // A/B switch: consensus minimizer lists staged whole, as in round 2
     std::vector<size_t> &tail_from = L.tail_from;
@@ -971,6 +1032,14 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws, int lane = 
     std::vector<uint8_t> &changed = L.cons_changed;
     changed.assign(n, 0);
     for (size_t w = 0; w < n; ++w) changed[w] = !D.B[who[w]].idx_valid;
+    // the changed stretches' text where the device can read it (the source of the resident consensus copies' updates)
+    std::vector<const uint8_t *> &staged = L.staged;
+    staged.assign(n, nullptr);
+    for (size_t w = 0; w < n; ++w) {
+        if (!changed[w]) continue;
+        if (use_mini[w]) staged[w] = mini_sketch_text(D.B[who[w]].mini);
+        else if (sk_ref[w] != ~0u) staged[w] = sketch_dev_seq(c, L.sketch_ws, sk_ref[w]);
+    }
     // lists retired by an earlier call: their last reader (that call's seeding kernel) has been waited for since
     for (DevBuf &d : L.retired) d.release();
     L.retired.clear();
@@ -979,20 +1048,26 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws, int lane = 
     const int sws_i = 1 + 2 * gi;
     std::vector<uint64_t> &so = L.stage_off;
     so.assign(n + 1, 0);
+    auto n_sub_of = [&](size_t w) -> uint64_t { return use_mini[w] ? L.mini_mz[w].size() : sk_ref[w] != ~0u ? mo[sk_ref[w] + 1] - mo[sk_ref[w]] : 0; };
+    auto sub_of = [&](size_t w) -> const mm2::Anchor * { return use_mini[w] ? L.mini_mz[w].data() : sk_ref[w] != ~0u ? mz + mo[sk_ref[w]] : nullptr; };
     for (size_t w = 0; w < n; ++w) {
         const Builder &b = D.B[who[w]];
         uint64_t bound = b.mz.size();
-        if (!b.idx_valid) { const uint32_t si = sk_ref[w]; bound += mo[si + 1] - mo[si]; }
+        if (!b.idx_valid) bound += n_sub_of(w);
         so[w + 1] = so[w] + bound;
     }
     NS_TRY(c->seed_ws[sws_i].h_ref.reserve(so[n] * sizeof(mm2::Anchor) + 16));
     mm2::Anchor *stage = c->seed_ws[sws_i].h_ref.as<mm2::Anchor>();
-    // the query minimizers stay in the pinned buffer of the sketch workspace until the alignments have been seeded
+    // the query minimizers: resident in HBM, or in the pinned buffer of the sketch workspace until the alignments have been seeded
     for (size_t w = 0; w < n; ++w) {
         Builder &b = D.B[who[w]];
-        const size_t qi = q_base + w;
-        AB.reqs[w] = AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), mz + mo[qi], (size_t)(mo[qi + 1] - mo[qi]), stage + so[w], 0};
-        if (use_dev_plan) AB.reqs[w].qry_dev = sketch_dev_seq(c, L.sketch_ws, qi);       // (the consensus side: filled in below, once the device copies are up to date)
+        const uint32_t qi = q_ref[w];
+        AB.reqs[w] = AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), qi != ~0u ? mz + mo[qi] : nullptr,
+                              qi != ~0u ? (size_t)(mo[qi + 1] - mo[qi]) : 0, stage + so[w], 0};
+        if (qi == ~0u) {
+            AB.reqs[w].qry_mz_dev = RM.mz.as<mm2::Anchor>() + RM.off[b.strand][b.pend], AB.reqs[w].n_qry_mz_dev = RM.cnt[b.strand][b.pend];
+            if (use_dev_plan) AB.reqs[w].qry_dev = RM.ascii[b.strand].as<uint8_t>() + RM.h_aoff[b.pend];
+        } else if (use_dev_plan) AB.reqs[w].qry_dev = sketch_dev_seq(c, L.sketch_ws, qi);       // (the consensus side: filled in below, once the device copies are up to date)
     }
     NS_TRY(align_prestep_start(c, AB, 0, n));
     // one loop over the builders: the minimizers of the changed consensus (splice), its base codes, the list into the staging
@@ -1001,8 +1076,7 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws, int lane = 
         Builder &b = D.B[who[w]];
         size_t first_diff = b.d_mz_n;                 // nothing to upload when the consensus did not change
         if (!b.idx_valid) {
-            const uint32_t si = sk_ref[w];
-            first_diff = apply_splice(b, mz + mo[si], (size_t)(mo[si + 1] - mo[si]), (int)c->prm.m_w, (int)c->prm.m_k);
+            first_diff = apply_splice(b, sub_of(w), (size_t)n_sub_of(w), (int)c->prm.m_w, (int)c->prm.m_k);
             // the base codes: prefix kept, suffix moved, the middle coded (a contig that grows at its left end used to be coded whole: 0.1 ms)
             if (b.sp.have_common) b.idx.set_sequence_spliced(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, b.sp.cp, b.sp.cs);
             else b.idx.set_sequence_from(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, b.chg_lb);
@@ -1059,25 +1133,25 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws, int lane = 
             NS_HIP(hipGetLastError());
         }
     }
-    if (use_dev_plan) NS_TRY(engine_cons_update(c, E, AB, who, changed, sk_ref, L));
+    if (use_dev_plan) NS_TRY(engine_cons_update(c, E, AB, who, changed, staged, L));
     else for (size_t w = 0; w < n; ++w) if (changed[w]) D.B[who[w]].dc_valid = false;          // (a batch that does not update the device copies leaves them stale)
     NS_TRY(align_prestep_launch(c, AB, 0, n, sws_i, true, use_dev_plan ? dp_ws : -1));
     L.sk_ms[4] += now_ms() - tk; tk = now_ms();
     NS_TRY(align_prestep_finish(c, AB, 0, n, sws_i));
     L.sk_ms[5] += now_ms() - tk;
     E->awho[gi] = who;
-    if (lane < 0) E->dbg_batch_sizes.push_back((uint32_t)who.size());
+    E->dbg_batch_sizes.push_back((uint32_t)who.size());
     { std::lock_guard<std::mutex> lk(c->stat_m); S.index_ms += now_ms() - g0; }
     return NSGPU_OK;
 }
 
 // batches, part 1: seeds / chains / DP plan of the alignments sketched in the stage before, and the launch of the DP kernels
 // -- which stay in flight until part 2
-static int engine_batches_begin(nsgpu_ctx *c, int group, int ws_index, int lane = -1)
+static int engine_batches_begin(nsgpu_ctx *c, int group, int ws_index)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     nsgpu_consensus_stats &S = c->cons_stats;
-    const int gi = lane >= 0 ? lane : group < 0 ? 0 : group;
+    const int gi = group < 0 ? 0 : group;
     if (E->awho[gi].empty()) return NSGPU_OK;
     const double g1 = now_ms();
     AlignBatch &AB = E->ab[gi];
@@ -1226,6 +1300,7 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
         plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k);
         b.sp_ready = true;
         b.early_updated = true;
+        engine_mini_start(c, E, b);                  // the changed stretch's minimizers are on their way before the slot is over
         b.cpu_ms += now_ms() - t0;
         n_updates += 1;
     };
@@ -1353,12 +1428,12 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
 }
 static int engine_early_updates(nsgpu_ctx *c, int group) { const int gi = group < 0 ? 0 : group; return engine_early_updates(c, &gi, 1); }
 
-static int engine_align_finish(nsgpu_ctx *c, int group, int lane = -1)
+static int engine_align_finish(nsgpu_ctx *c, int group)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
     nsgpu_consensus_stats &S = c->cons_stats;
-    const int gi = lane >= 0 ? lane : group < 0 ? 0 : group;
+    const int gi = group < 0 ? 0 : group;
     std::vector<uint32_t> &who = E->awho[gi];
     if (who.empty()) return NSGPU_OK;
     Engine::Lane &L = E->lane[gi];
@@ -1368,7 +1443,6 @@ static int engine_align_finish(nsgpu_ctx *c, int group, int lane = -1)
         Builder &b = D.B[who[w]];
         if (!b.early_result) std::swap(b.aln, L.outs[w]);              // the builder's previous result goes back into the pool of result objects
         b.early_result = false;
-        b.taken = false;
         ++b.n_align_calls;
         b.accepted = false;
         b.st = Builder::ALIGNED;
@@ -1460,77 +1534,24 @@ static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
     return NSGPU_OK;
 }
 
-// ---- ONE group: the slot's alignments in two lanes ------------------------------------------------------------------------------------------
-// Right after the host phase most builders know their next alignment; a few have to open a window (one GPU round trip) or start a contig
-// (seed rule, first steps, first window) first.  The first lane -- the builders that are ready -- is launched at once on a thread of its own
-// (sketch .. chain .. DP launch), the windows and seeds run in its shadow, and the builders they release form the second lane.  Same
-// alignments, same slot, same claims at its end: the schedule (the logical clock of DESIGN.md section 2) does not know about lanes.
-// NSGPU_NO_LANES=1: one batch per slot behind the windows and seeds, as before (A/B switch).
-struct LaneFront {
-    std::thread th;
-    int rc = NSGPU_OK;
-    std::string err;
-    double ms = 0;
-    ~LaneFront() { if (th.joinable()) th.join(); }
-};
-static void engine_lane_select(nsgpu_ctx *c, int lane)
-{
-    Engine *E = static_cast<Engine *>(c->cons_engine);
-    std::vector<uint32_t> &who = E->lane[lane].who;
-    who.clear();
-    for (Builder &b : E->D.B) if (b.st == Builder::WAIT_ALIGN && !b.taken) { who.push_back(b.id); b.taken = true; }
-}
-static int engine_lane_front(nsgpu_ctx *c, int lane)
-{
-    const int dp_ws = 1 + lane;
-    NS_TRY(engine_batches_sketch(c, -1, dp_ws, lane));
-    return engine_batches_begin(c, -1, dp_ws, lane);
-}
-static void engine_lane0_start(nsgpu_ctx *c, LaneFront &F)
-{
-    static const bool no_lanes = getenv("NSGPU_NO_LANES") != nullptr;
-    Engine *E = static_cast<Engine *>(c->cons_engine);
-    E->lane[0].who.clear();
-    if (no_lanes) return;
-    engine_lane_select(c, 0);
-    if (E->lane[0].who.empty()) return;
-    F.th = std::thread([c, &F] {
-        pool_bind_this_thread();
-        const double t0 = now_ms();
-        F.rc = hipSetDevice(c->prm.device) == hipSuccess ? engine_lane_front(c, 0) : NSGPU_ERR_HIP;
-        if (F.rc != NSGPU_OK) F.err = nsgpu_last_error();
-        F.ms = now_ms() - t0;
-    });
-}
-// the rest of the slot's batches: the second lane, the first lane's thread, the results of both with the graph updates riding on the DP phase
-static int engine_lanes_finish(nsgpu_ctx *c, LaneFront *F)
+// ---- ONE group: the slot's batch -------------------------------------------------------------------------------------------------------------
+// (Measured in round 5 and removed: the slot's alignments in TWO batches -- the builders that know their next alignment right after the host
+// phase launched at once on a thread of their own, the windows and seeds in their shadow, the builders those release as a second batch.  Same
+// schedule, same streams, but slower: 7.86 / 8.73 against 7.11 / 7.26 s per cfg2 step.  A batch's front is latency, not volume -- the second
+// batch's sketch .. DP launch took as long as the whole batch's (1.16 against 1.19 ms) and still started behind the windows and the seeds, so
+// the slot's critical path kept every step it had, and the two batches' kernels got in each other's way: seeds + chaining 0.70 instead of
+// 0.48 ms per launch, windows 0.52 instead of 0.37 ms.)
+static int engine_g1_batches(nsgpu_ctx *c)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     double t0 = now_ms(), t1;
-    const bool first_started = F && F->th.joinable();
-    int rc = NSGPU_OK;
-    // (nothing launched ahead: everybody in the one lane there is, as before)
-    const int late = first_started ? 1 : 0;
-    engine_lane_select(c, late);
-    if (!first_started) E->awho[0].clear(), E->ab[0].reqs.clear();
-    E->awho[1].clear();
-    if (late == 1) E->ab[1].reqs.clear();
-    if (!E->lane[late].who.empty()) rc = engine_lane_front(c, late);
-    std::string err = rc != NSGPU_OK ? nsgpu_last_error() : "";
+    NS_TRY(engine_batches_sketch(c, -1, 1));
     t1 = now_ms(); E->g1_ms[3] += t1 - t0; t0 = t1;
-    if (first_started) {
-        F->th.join();
-        E->g1_ms[5] += F->ms;
-        if (rc == NSGPU_OK && F->rc != NSGPU_OK) rc = F->rc, err = F->err;
-    }
+    NS_TRY(engine_batches_begin(c, -1, 1));
     t1 = now_ms(); E->g1_ms[4] += t1 - t0; t0 = t1;
-    if (rc != NSGPU_OK) { set_error("%s", err.empty() ? "contig engine: a batch thread failed" : err.c_str()); return rc; }
-    E->dbg_batch_sizes.push_back((uint32_t)(E->awho[0].size() + E->awho[1].size()));
-    const int gis[2] = {0, 1};
-    NS_TRY(engine_early_updates(c, gis, 2));
+    NS_TRY(engine_early_updates(c, -1));
     t1 = now_ms(); E->g1_ms[6] += t1 - t0; t0 = t1;
-    NS_TRY(engine_align_finish(c, -1, 0));
-    NS_TRY(engine_align_finish(c, -1, 1));
+    NS_TRY(engine_align_finish(c, -1));
     E->g1_ms[7] += now_ms() - t0;
     return NSGPU_OK;
 }
@@ -1539,7 +1560,7 @@ static int engine_lanes_finish(nsgpu_ctx *c, LaneFront *F)
 // the group that was there one slot earlier, part 2 of group (slot + 1) % G -- whose DP launch has been in flight for a
 // slot -- all concurrently.
 // part: 0 = the whole slot; with ONE group the seeds are granted between the host phase (part 1) and the batches (part 2): see run_consensus
-static int engine_slot(nsgpu_ctx *c, uint32_t slot, int part = 0, LaneFront *front = nullptr)
+static int engine_slot(nsgpu_ctx *c, uint32_t slot, int part = 0)
 {
     const uint32_t G = (uint32_t)n_groups(c);
     const int host_group = (int)(slot % G), begin_group = (int)((slot + G - 1) % G), finish_group = (int)((slot + 1) % G);
@@ -1585,7 +1606,7 @@ static int engine_slot(nsgpu_ctx *c, uint32_t slot, int part = 0, LaneFront *fro
             // consumed by the next slot's host phase, as with more groups)
             if (part != 2) engine_advance(c, false, host_group);
             if (part == 0) NS_TRY(engine_window_queries(c, finish_group));
-            if (part != 1) return engine_lanes_finish(c, front);
+            if (part != 1) return engine_g1_batches(c);
         }
         else if (serial) { engine_advance(c, false, host_group); chain(); }
         else {
@@ -1685,6 +1706,8 @@ static void debug_report_slots(nsgpu_ctx *c, Engine *E)
             fprintf(stderr, "\n");
         }
     }
+    fprintf(stderr, "[cons] sketches: %llu stretches sketched by their builders behind the update (%llu used), %llu candidates with resident minimizers, %llu sketch calls in batches; read minimizers built in %.1f ms (%.1f M entries)\n",
+            (unsigned long long)E->n_mini.load(), (unsigned long long)E->n_mini_used.load(), (unsigned long long)E->n_cand_resident.load(), (unsigned long long)E->n_sketch_calls.load(), c->rmz.build_ms, c->rmz.n_mz / 1e6);
     fprintf(stderr, "[cons] early tasks: loops of part 0 / part 1 %.0f / %.0f ms wall; tasks %.0f ms in sum (delivery + skeleton + conversion %.0f), the longest of each slot %.0f ms in sum\n",
             E->early_part_ms[0], E->early_part_ms[1], E->early_task_ms, E->early_conv_ms, E->early_task_max_ms);
     fprintf(stderr, "[cons] graph updates run ahead of the slot's end: %llu, %.0f ms wall (DP results + updates); status words seen ahead of their data: %llu\n", (unsigned long long)E->n_early, E->early_ms, (unsigned long long)E->n_early_retry);
@@ -1702,8 +1725,8 @@ static void debug_report_slots(nsgpu_ctx *c, Engine *E)
         for (int d = 0; d < 10; ++d) { uint64_t sum = 0; const size_t a = nb * d / 10, b = nb * (d + 1) / 10; for (size_t i = a; i < b; ++i) sum += E->dbg_batch_sizes[i]; fprintf(stderr, " %.1f", b > a ? (double)sum / (double)(b - a) : 0.0); }
         fprintf(stderr, "\n");
     }
-    fprintf(stderr, "[cons] one-group slot, wall-ms of its steps: host phase %.0f, windows %.0f, seeds + fresh contigs %.0f, second lane's sketch..DP launch %.0f, wait for the first lane's thread %.0f (its sketch..DP launch, beside the windows and seeds: %.0f), results + early updates %.0f, last results %.0f\n",
-            E->g1_ms[0], E->g1_ms[1], E->g1_ms[2], E->g1_ms[3], E->g1_ms[4], E->g1_ms[5], E->g1_ms[6], E->g1_ms[7]);
+    fprintf(stderr, "[cons] one-group slot, wall-ms of its steps: host phase %.0f, windows %.0f, seeds + fresh contigs %.0f, sketch..chain %.0f, DP launch %.0f, results + early updates %.0f, last results %.0f\n",
+            E->g1_ms[0], E->g1_ms[1], E->g1_ms[2], E->g1_ms[3], E->g1_ms[4], E->g1_ms[6], E->g1_ms[7]);
     for (int l = 0; l < kMaxGroups; ++l) {
         const double *m = E->lane[l].sk_ms;
         if (m[0] + m[1] + m[2] + m[3] + m[4] + m[5] > 0)
@@ -1820,16 +1843,12 @@ static int run_consensus_inner(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_thr
             NS_TRY(engine_slot(c, slot, 1));
             double t1 = now_ms();
             E->g1_ms[0] += t1 - t;
-            // the builders that know their next alignment go ahead (sketch .. chain .. DP launch on a thread of its own); the windows and the
-            // seeds of the others run in its shadow (engine_lanes_finish picks those up)
-            LaneFront front;
-            engine_lane0_start(c, front);
             NS_TRY(engine_window_loop(c, h));
             E->g1_ms[1] += now_ms() - t1; t1 = now_ms();
             engine_seed_requests(c, ga, gb, h);
             if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) { engine_advance(c, true, h); NS_TRY(engine_window_loop(c, h)); }
             E->g1_ms[2] += now_ms() - t1;
-            NS_TRY(engine_slot(c, slot, 2, &front));
+            NS_TRY(engine_slot(c, slot, 2));
             w_slot += now_ms() - t;
             engine_claim_requests(c, ga, gb, b);
             engine_claim_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size());
@@ -1916,8 +1935,6 @@ static int run_consensus_dist(nsgpu_ctx *c, Comm &C, uint32_t n_builders_total, 
         if (G == 1) {
             // ONE group: two small all-gathers per slot -- seed requests after the host phase, claim requests after the batches
             int rc = engine_slot(c, slot, 1);
-            LaneFront front;                     // (see run_consensus: the builders that are ready go ahead of the windows, the seeds and the exchanges)
-            if (rc == NSGPU_OK) engine_lane0_start(c, front);
             if (rc == NSGPU_OK) rc = engine_window_loop(c, h);
             if (rc == NSGPU_OK) engine_seed_requests(c, sa, sb, h);
             NS_TRY(exchange(rc, nullptr, nullptr, &sa, &sb));
@@ -1936,7 +1953,7 @@ static int run_consensus_dist(nsgpu_ctx *c, Comm &C, uint32_t n_builders_total, 
             E->global_pends.assign(gb.begin(), gb.end());
             std::sort(E->global_pends.begin(), E->global_pends.end());
             E->have_global_pends = true;
-            rc = engine_slot(c, slot, 2, &front);
+            rc = engine_slot(c, slot, 2);
             if (rc == NSGPU_OK) engine_claim_requests(c, ca, cb, b);
             NS_TRY(exchange(rc, &ca, &cb, nullptr, nullptr));
             gathered(1);

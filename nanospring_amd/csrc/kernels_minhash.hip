@@ -566,11 +566,179 @@ int run_filter(nsgpu_ctx *c, const uint64_t *d_q_even, const uint64_t *d_q_odd, 
 }
 
 
-// The contig engine's window queries with ONE host wait: strings staged through one pinned buffer, pack -> sketch -> search ->
-// count -> heavy -> compact back to back, candidate lists (offsets + ids) written into pinned host memory by the last kernel.
-// The buffers whose size depends on the data (staging area of the matches, the id list) keep their high-water capacity; a batch
-// that does not fit is flagged by the kernels and redone by the exact multi-step path (`*redo` = true), which also grows them.
-// run_filter above asks the device for three sizes and for the overflow count on the way: five round trips of ~0.15 ms per batch.
+// ----------------------------------------------------------------------------
+// a5 + a8 + a9 fused: ONE kernel answers a batch of window queries (ReadFilter::getFilteredReads of a string, src/ReadFilter.cpp:49-83).
+// A slot of the contig engine asks for a few dozen windows and waits for the answer: what that costs is the chain of dependent GPU
+// operations, not their volume (pack -> sketch -> search -> scan -> count -> heavy -> scan -> compact + six copies: 0.37 ms per slot for
+// 0.1 ms of kernels).  Here one 256-thread workgroup takes a query from its ASCII string to its candidate list: the sketch (the same
+// stage / expand / reduce as sketch_kernel, the 2-bit dwords made from the text in LDS), one binary search per table (threads over the n
+// tables), the M matching ids gathered into LDS, a bitonic sort by the whole workgroup, the ids whose multiplicity reaches the threshold
+// written in ascending order into the query's slot of a pinned host buffer.  Queries the LDS sort cannot take (M > F_CAP: repeat-rich
+// data) or with more results than a slot holds raise a flag, and the caller redoes the batch with the multi-pass kernels.
+// ----------------------------------------------------------------------------
+constexpr uint32_t WQ_SLOT = 512;            // result ids per query slot (a query can have floor(M / thr) <= F_CAP / thr results)
+
+__global__ __launch_bounds__(256) void window_query_kernel(const uint8_t *__restrict__ ascii, const uint64_t *__restrict__ aoff, uint32_t nq, uint32_t k, uint32_t n,
+                                                           uint32_t thr1, uint32_t N, const uint64_t *__restrict__ salts, const uint64_t *__restrict__ idx_keys,
+                                                           const uint32_t *__restrict__ idx_ids, uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ out_ids,
+                                                           uint32_t *__restrict__ flags)
+{
+    __shared__ uint32_t s_dw[SK_CHUNK / 16 + 4];
+    __shared__ __attribute__((aligned(16))) uint64_t s_kf[SK_CHUNK + 2];
+    __shared__ uint64_t s_red[4][64];
+    __shared__ uint64_t s_sk[256];
+    __shared__ uint32_t s_lb[256], s_cn[256], s_off[257];
+    __shared__ uint32_t s_ids[F_CAP];
+    __shared__ uint32_t s_w[4], s_tot;
+    const uint32_t q = blockIdx.x;
+    if (q >= nq) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t *str = ascii + aoff[q];
+    const uint32_t L = (uint32_t)(aoff[q + 1] - aoff[q]);
+    // ---- the sketch (string2Sketch, src/ReadFilter.cpp:117-131): see sketch_kernel ----
+    {
+        const uint32_t n_groups = (n + 63) >> 6, n_subsets = 4 / n_groups;
+        const uint32_t grp = wave % n_groups, subset = wave / n_groups;
+        const bool wave_on = subset < n_subsets;
+        const uint32_t salt_idx = grp * 64 + lane;
+        const uint64_t salt = wave_on && salt_idx < n ? salts[salt_idx] : 0ull;
+        const uint32_t per = SK_CHUNK / n_subsets;
+        if (L + 1 < k) { if (tid < n) s_sk[tid] = 0ull; }            // len < k-1: the zero-initialised row
+        else {
+            const uint32_t nk = L + 1 - k;                             // 0 (len == k-1): all ones
+            uint64_t mf = ~0ull;
+            for (uint32_t cb = 0; cb < nk; cb += SK_CHUNK) {
+                const uint32_t cnt = (nk - cb) < (uint32_t)SK_CHUNK ? (nk - cb) : (uint32_t)SK_CHUNK;
+                if (tid < SK_CHUNK / 16 + 4) {
+                    // dword gd of the 2-bit row, bit 31 = its first base (pack_ascii_kernel + the byte swap of sketch_kernel's staging)
+                    const uint32_t b0 = (cb / 16 + tid) * 16;
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { const uint32_t p = b0 + i; v = (v << 2) | (p < L ? base_code(str[p]) : 0u); }
+                    s_dw[tid] = v;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t lp = tid * 4 + j;
+                    if (lp < cnt) {
+                        const uint32_t di = lp >> 4, o = (lp & 15) * 2;
+                        const uint64_t hi = ((uint64_t)s_dw[di] << 32) | s_dw[di + 1];
+                        const uint64_t v = (hi << o) | ((uint64_t)s_dw[di + 2] >> (32 - o));
+                        const uint64_t km = v >> (64 - 2 * k);
+                        s_kf[lp] = km;
+                        if (lp + 1 == cnt) s_kf[lp + 1] = km;
+                    }
+                }
+                __syncthreads();
+                if (wave_on) {
+                    const uint32_t lo = subset * per;
+                    uint32_t hi = lo + per < cnt ? lo + per : cnt;
+                    hi = (hi + 1) & ~1u;
+#pragma unroll 4
+                    for (uint32_t i = lo; i < hi; i += 2) {
+                        const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *>(&s_kf[i]);
+                        const uint64_t a = kk.x ^ salt, b = kk.y ^ salt;
+                        mf = a < mf ? a : mf;
+                        mf = b < mf ? b : mf;
+                    }
+                }
+                __syncthreads();
+            }
+            s_red[wave][lane] = mf;
+            __syncthreads();
+            if (tid < n) {
+                const uint32_t g = tid >> 6, l = tid & 63;
+                uint64_t m = ~0ull;
+                for (uint32_t sb = 0; sb < n_subsets; ++sb) { const uint64_t x = s_red[sb * n_groups + g][l]; m = x < m ? x : m; }
+                s_sk[tid] = m;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- one table per thread: the run [lb, lb + c) of the query's sketch value (filter_search_kernel) ----
+    {
+        uint32_t lb = 0, c = 0;
+        if (tid < n && N) {
+            const uint64_t key = s_sk[tid];
+            const uint64_t *K = idx_keys + (size_t)tid * N;
+            uint32_t lo = 0, hi = N;
+            while (lo < hi) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (K[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            lb = lo;
+            if (lb < N && K[lb] == key) {
+                uint32_t step = 1, a = lb, b;
+                while (a + step < N && K[a + step] == key) { a += step; step <<= 1; }
+                b = a + step < N ? a + step : N;
+                while (a + 1 < b) {
+                    const uint32_t mid = a + ((b - a) >> 1);
+                    if (K[mid] == key) a = mid; else b = mid;
+                }
+                c = a + 1 - lb;
+            }
+        }
+        s_lb[tid] = lb, s_cn[tid] = c;
+    }
+    __syncthreads();
+    if (tid == 0) { uint32_t t = 0; for (uint32_t l = 0; l < n; ++l) { s_off[l] = t; t += s_cn[l]; } s_off[n] = t; }
+    __syncthreads();
+    const uint32_t M = s_off[n];
+    if (M == 0) { if (tid == 0) out_cnt[q] = 0; return; }
+    if (M > F_CAP || M / thr1 > WQ_SLOT) { if (tid == 0) { out_cnt[q] = 0; flags[0] = 1; } return; }
+    // ---- the M ids into LDS, sorted (filter_count_kernel, with four waves) ----
+    if (tid < n) {
+        const uint32_t c = s_cn[tid];
+        const uint32_t *src = idx_ids + (size_t)tid * N + s_lb[tid];
+        const uint32_t o = s_off[tid];
+        for (uint32_t t = 0; t < c; ++t) s_ids[o + t] = src[t];
+    }
+    uint32_t P = 64;
+    while (P < M) P <<= 1;
+    __syncthreads();
+    for (uint32_t i = M + tid; i < P; i += 256) s_ids[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= P; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < (P >> 1); i += 256) {
+                const uint32_t pos = 2 * j * (i / j) + (i % j);
+                const uint32_t a = s_ids[pos], b = s_ids[pos + j];
+                const bool up = (pos & k2) == 0;
+                if ((a > b) == up) { s_ids[pos] = b; s_ids[pos + j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- ids whose multiplicity reaches thr1, ascending, into the query's slot ----
+    uint32_t *dst = out_ids + (size_t)q * WQ_SLOT;
+    if (tid == 0) s_tot = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < M; base += 256) {
+        const uint32_t i = base + tid;
+        uint32_t v = 0;
+        bool ok = false;
+        if (i < M) {
+            v = s_ids[i];
+            const bool start = (i == 0) || (s_ids[i - 1] != v);
+            ok = start && (i + thr1 - 1 < M) && (s_ids[i + thr1 - 1] == v);
+        }
+        const unsigned long long mask = __ballot(ok);
+        if (lane == 0) s_w[wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t before = s_tot;
+        for (uint32_t w = 0; w < wave; ++w) before += s_w[w];
+        if (ok) dst[before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = v;
+        __syncthreads();
+        if (tid == 0) s_tot += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    if (tid == 0) out_cnt[q] = s_tot;
+}
+
+// The window queries of a batch with ONE copy, ONE kernel and ONE host wait (window_query_kernel): the strings go to HBM through one pinned
+// staging block, the candidate lists come back as the kernel's own stores into pinned memory and are laid out as a CSR here.  `*redo`: a query
+// the kernel does not take (see there) -- the caller runs the batch through the multi-pass kernels (filter_strings_device).
 int run_window_queries_fast(nsgpu_ctx *c, const char *strs, const uint64_t *qoff, uint32_t nq, const uint64_t *&off_out, const uint32_t *&ids_out, bool *redo)
 {
     *redo = false;
@@ -578,95 +746,42 @@ int run_window_queries_fast(nsgpu_ctx *c, const char *strs, const uint64_t *qoff
     const uint32_t n = c->prm.n, N = c->reads.n;
     const uint32_t thr1 = c->prm.overlap_sketch_thr ? c->prm.overlap_sketch_thr : 1u;
     NS_CHECK(nq > 0, NSGPU_ERR_ARG, "run_window_queries_fast: no queries");
-    // one pinned staging block: ascii | aoff | poff | len
-    SeqStore &st = c->queries;
+    if (n > 256 || c->prm.k < 1 || c->prm.k > 31 || nq > (1u << 20)) { *redo = true; return NSGPU_OK; }
     const uint64_t total = qoff[nq] - qoff[0];
-    const size_t o_aoff = (total + 15) & ~(size_t)15, o_poff = o_aoff + ((size_t)nq + 1) * 8, o_len = o_poff + ((size_t)nq + 1) * 8, stage_bytes = o_len + (size_t)nq * 4 + 16;
+    // one pinned staging block: ascii | aoff
+    const size_t o_aoff = (total + 15) & ~(size_t)15, stage_bytes = o_aoff + ((size_t)nq + 1) * 8 + 16;
     NS_TRY(c->pin_wq.reserve(stage_bytes));
     uint8_t *h = c->pin_wq.as<uint8_t>();
-    uint64_t *h_aoff = reinterpret_cast<uint64_t *>(h + o_aoff), *h_poff = reinterpret_cast<uint64_t *>(h + o_poff);
-    uint32_t *h_len = reinterpret_cast<uint32_t *>(h + o_len);
+    uint64_t *h_aoff = reinterpret_cast<uint64_t *>(h + o_aoff);
     memcpy(h, strs + qoff[0], total);
-    st.n = nq;
-    st.h_len.resize(nq), st.h_poff.resize((size_t)nq + 1);
-    uint64_t po = 0, nb = 0;
-    uint32_t mx = 0;
-    for (uint32_t q = 0; q < nq; ++q) {
-        const uint64_t L = qoff[q + 1] - qoff[q];
-        NS_CHECK(L <= 0xFFFFFFF0ull, NSGPU_ERR_RANGE, "window %u longer than 2^32-16 bases", q);
-        h_aoff[q] = qoff[q] - qoff[0], h_poff[q] = po, h_len[q] = (uint32_t)L;
-        st.h_poff[q] = po, st.h_len[q] = (uint32_t)L;
-        po += ((((uint64_t)L + 3) / 4 + 15) & ~(uint64_t)15) + 16, nb += L, mx = std::max(mx, (uint32_t)L);
+    for (uint32_t q = 0; q <= nq; ++q) {
+        h_aoff[q] = qoff[q] - qoff[0];
+        if (q) NS_CHECK(qoff[q] >= qoff[q - 1] && qoff[q] - qoff[q - 1] <= 0xFFFFFFF0ull, NSGPU_ERR_RANGE, "window %u longer than 2^32-16 bases", q - 1);
     }
-    h_aoff[nq] = total, h_poff[nq] = po, st.h_poff[nq] = po;
-    st.packed_bytes = po, st.n_bases = nb, st.max_len = mx;
-    NS_TRY(st.packed.reserve(po + 64));
-    NS_TRY(st.poff.reserve(((size_t)nq + 1) * 8));
-    NS_TRY(st.len.reserve(((size_t)nq + 1) * 4));
-    NS_TRY(c->ascii.reserve(total + 64));
-    NS_TRY(c->aoff.reserve(((size_t)nq + 1) * 8));
-    NS_HIP(hipMemcpyAsync(c->ascii.p, h, total, hipMemcpyHostToDevice, c->stream));
-    NS_HIP(hipMemcpyAsync(c->aoff.p, h_aoff, ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    NS_HIP(hipMemcpyAsync(st.poff.p, h_poff, ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    NS_HIP(hipMemcpyAsync(st.len.p, h_len, (size_t)nq * 4, hipMemcpyHostToDevice, c->stream));
-    NS_TRY(launch_pack_ascii(c, c->ascii.as<char>(), c->aoff.as<uint64_t>(), st));
-    NS_TRY(c->qsketch.reserve(((size_t)nq * n + 1) * 8));
-    NS_TRY(launch_sketch(c, st, c->qsketch.as<uint64_t>(), nullptr));
-    // filter buffers
-    c->f_nq = nq;
-    NS_TRY(c->f_off.reserve(((size_t)nq + 1) * 8));
-    NS_TRY(c->f_qstart.reserve(((size_t)nq + 1) * 8));
-    NS_TRY(c->f_qcnt.reserve(((size_t)nq + 1) * 4 * 3));
-    NS_TRY(c->f_qm.reserve((size_t)nq * n * 8));
-    NS_TRY(c->f_ctrl.reserve(64));
-    NS_TRY(c->f_ovf_list.reserve((size_t)nq * 4));
-    static const size_t pool0 = getenv("NSGPU_WQ_POOL_BYTES") ? (size_t)atoll(getenv("NSGPU_WQ_POOL_BYTES")) : (size_t)16 << 20;     // (test switch: start small)
-    if (c->f_pool.cap < pool0) NS_TRY(c->f_pool.reserve(pool0));                             // >= 4 M staged ids; grows through the exact path
-    const size_t need_heavy = (size_t)F_HEAVY_WGS * N * 4;
-    if (c->f_ovf_cnt.cap < need_heavy) {
-        NS_TRY(c->f_ovf_cnt.reserve(need_heavy));
-        NS_HIP(hipMemsetAsync(c->f_ovf_cnt.p, 0, c->f_ovf_cnt.cap, c->stream));
-    }
-    const uint64_t pool_cap = c->f_pool.cap / 4, ids_cap = pool_cap;
-    NS_TRY(c->pin_wq_out.reserve(((size_t)nq + 1) * 8 + ids_cap * 4 + 64));
-    uint64_t *h_off = c->pin_wq_out.as<uint64_t>();
-    uint32_t *h_ids = reinterpret_cast<uint32_t *>(h_off + nq + 1);
-    NS_TRY(c->pin_small.reserve(64));
-    uint32_t *h_ctrl = c->pin_small.as<uint32_t>() + 8;                                    // behind run_filter's four scalars
-    uint32_t *qcnt = c->f_qcnt.as<uint32_t>(), *qm = qcnt + (nq + 1), *qcap = qm + (nq + 1);
-    uint32_t *lb = c->f_qm.as<uint32_t>(), *cnt = lb + (size_t)nq * n;
-    uint64_t *soff = c->f_qstart.as<uint64_t>();
-    NS_HIP(hipMemsetAsync(c->f_ctrl.p, 0, 64, c->stream));
-    NS_HIP(hipMemsetAsync(qcnt, 0, ((size_t)nq + 1) * 4 * 3, c->stream));
-    {
-        uint32_t grid = (nq + 3) / 4;
-        if (grid > 65536u) grid = 65536u;
-        hipLaunchKernelGGL(filter_search_kernel, dim3(grid), dim3(256), 0, c->stream, c->qsketch.as<uint64_t>(), (const uint64_t *)nullptr, 0, nq, n, thr1, N,
-                           c->idx_keys.as<uint64_t>(), lb, cnt, qm, qcap);
-    }
-    NS_TRY(scan_u32_to_u64(c, qcap, soff, nq));
-    {
-        const uint32_t grid = nq < 262144u ? nq : 262144u;
-        hipLaunchKernelGGL(filter_count_kernel, dim3(grid), dim3(64), 0, c->stream, nq, n, thr1, N, c->idx_ids.as<uint32_t>(), lb, cnt, qm, soff,
-                           c->f_pool.as<uint32_t>(), qcnt, c->f_ovf_list.as<uint32_t>(), c->f_ctrl.as<uint32_t>(), pool_cap);
-    }
-    // (queries with more matches than the sort takes: the kernel reads their number on the device and does nothing when there are none)
-    hipLaunchKernelGGL(filter_heavy_kernel, dim3(F_HEAVY_WGS), dim3(256), 0, c->stream, n, thr1, N, c->idx_ids.as<uint32_t>(), lb, cnt, soff,
-                       c->f_pool.as<uint32_t>(), qcnt, c->f_ovf_list.as<uint32_t>(), c->f_ctrl.as<uint32_t>(), c->f_ovf_cnt.as<uint32_t>(), pool_cap);
-    NS_TRY(scan_u32_to_u64(c, qcnt, c->f_off.as<uint64_t>(), nq));
-    {
-        uint32_t grid = (nq + 3) / 4;
-        if (grid > 65536u) grid = 65536u;
-        hipLaunchKernelGGL(filter_compact_kernel, dim3(grid), dim3(256), 0, c->stream, nq, soff, c->f_pool.as<uint32_t>(), qcnt, c->f_off.as<uint64_t>(), h_ids, ids_cap, h_off,
-                           c->f_ctrl.as<uint32_t>());
-    }
+    NS_TRY(c->ascii.reserve(stage_bytes + 64));
+    NS_HIP(hipMemcpyAsync(c->ascii.p, h, stage_bytes, hipMemcpyHostToDevice, c->stream));
+    // the answers: cnt[nq] | flags[4] | ids[nq][WQ_SLOT], written by the kernel
+    const size_t o_flags = (size_t)nq * 4, o_ids = (o_flags + 16 + 15) & ~(size_t)15;
+    NS_TRY(c->pin_wq_out.reserve(o_ids + (size_t)nq * WQ_SLOT * 4 + 64));
+    uint32_t *h_cnt = c->pin_wq_out.as<uint32_t>();
+    uint32_t *h_flags = reinterpret_cast<uint32_t *>(c->pin_wq_out.as<uint8_t>() + o_flags);
+    uint32_t *h_ids = reinterpret_cast<uint32_t *>(c->pin_wq_out.as<uint8_t>() + o_ids);
+    h_flags[0] = 0;
+    hipLaunchKernelGGL(window_query_kernel, dim3(nq), dim3(256), 0, c->stream, c->ascii.as<uint8_t>(), reinterpret_cast<const uint64_t *>(c->ascii.as<uint8_t>() + o_aoff), nq,
+                       c->prm.k, n, thr1, N, c->salts.as<uint64_t>(), c->idx_keys.as<uint64_t>(), c->idx_ids.as<uint32_t>(), h_cnt, h_ids, h_flags);
     NS_HIP(hipGetLastError());
-    NS_HIP(hipMemcpyAsync(h_ctrl, c->f_ctrl.p, 16, hipMemcpyDeviceToHost, c->stream));
     NS_HIP(stream_wait_short(c->stream));
     c->have_filter_all = false;
-    if (h_ctrl[1] || h_ctrl[2]) { *redo = true; return NSGPU_OK; }
-    c->f_total = h_off[nq];
-    off_out = h_off, ids_out = h_ids;
+    if (h_flags[0]) { *redo = true; return NSGPU_OK; }
+    c->wq_off.resize((size_t)nq + 1);
+    uint64_t tot = 0;
+    for (uint32_t q = 0; q < nq; ++q) { c->wq_off[q] = tot; tot += h_cnt[q]; }
+    c->wq_off[nq] = tot;
+    c->wq_ids.resize(tot + 1);
+    for (uint32_t q = 0; q < nq; ++q) if (h_cnt[q]) memcpy(c->wq_ids.data() + c->wq_off[q], h_ids + (size_t)q * WQ_SLOT, (size_t)h_cnt[q] * 4);
+    c->f_total = tot;
+    c->f_nq = nq;
+    off_out = c->wq_off.data(), ids_out = c->wq_ids.data();
     return NSGPU_OK;
 }
 

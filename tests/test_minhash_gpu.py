@@ -184,3 +184,40 @@ def test_linearity_property_at_scale():
         assert np.array_equal(np.minimum(sp[2 * i], sp[2 * i + 1]), sk[r])
     g.close()
     g2.close()
+
+
+def test_window_query_kernel_equals_oracle_on_ragged_windows(oracle):
+    """ReadFilter::getFilteredReads of window strings through the one-kernel path (window_query_kernel: sketch + table search + sort + count in
+    one workgroup per query): windows of every awkward length -- below k - 1, k - 1 (all-ones row), k, around the 1024-k-mer chunk seams, a whole
+    read, lower case / N (folded like DnaBitset) -- in one batch with empty strings between them, against oracle/ns_oracle.c."""
+    k, n, thr = 23, 60, 6
+    bases, off = ns.synth_reads(21, 400000, 1500, 4000.0)
+    salts = ns.mt19937_64_salts(n)
+    g = ns.NsGpu(k=k, n=n, overlap_sketch_thr=thr)
+    g.load_reads((bases, off))
+    g.sketch(salts, fetch=False)
+    g.build_index()
+    idx = oracle.index_build(oracle.sketch_reads(bases, off, k, n, salts))
+    b = bytes(bases).decode()
+    rng = np.random.RandomState(9)
+    qs = []
+    for L in (0, 1, k - 2, k - 1, k, k + 1, 64, 1023 + k - 1, 1024 + k - 1, 1025 + k - 1, 2048 + k - 1, 3000):
+        r = int(rng.randint(0, 1500))
+        s = b[int(off[r]):int(off[r + 1])]
+        qs += [s[:L], revcomp(s[:L]), s[max(0, len(s) - L):]]
+    for r in (3, 700, 1499):
+        s = b[int(off[r]):int(off[r + 1])]
+        qs += [s, revcomp(s), s.lower(), s[:500] + "N" * 30 + s[530:]]
+    qs.insert(5, "")
+    o, ids = g.filter_batch(qs)
+    assert len(o) == len(qs) + 1
+    hits = 0
+    for qi, q in enumerate(qs):
+        w, _ = oracle.filter_string(fold(q), k, salts, idx, thr)
+        assert np.array_equal(ids[int(o[qi]):int(o[qi + 1])], w), (qi, len(q))
+        hits += len(w)
+    assert hits > 50
+    # one query at a time gives the same lists
+    for qi in (0, 7, len(qs) - 4, len(qs) - 1):
+        assert np.array_equal(g.filter(qs[qi]), ids[int(o[qi]):int(o[qi + 1])])
+    g.close()
