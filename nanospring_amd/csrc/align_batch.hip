@@ -736,11 +736,10 @@ static int batch_seed_and_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t 
     S.fb.clear();
     for (size_t i = 0; i < n; ++i) {
         const AlignReq &r = B.reqs[lo + i];
-        if ((r.qry_mz || r.qry_mz_dev) && r.ref_mz && r.n_ref_mz < (1ull << 30) && r.n_qry_mz < (1ull << 31) && r.n_qry_mz_dev < (1ull << 31)) {
+        if (r.qry_mz && r.ref_mz && r.n_ref_mz < (1ull << 30) && r.n_qry_mz < (1ull << 31)) {
             S.pair_of[i] = (uint32_t)pairs.size();
             SeedPair p{};
-            p.ref = r.ref_mz_dev ? r.ref_mz_dev : r.ref_mz, p.n_ref = (uint32_t)r.n_ref_mz;
-            p.qry = r.qry_mz_dev ? r.qry_mz_dev : r.qry_mz, p.n_qry = (uint32_t)(r.qry_mz_dev ? r.n_qry_mz_dev : r.n_qry_mz);
+            p.ref = r.ref_mz_dev ? r.ref_mz_dev : r.ref_mz, p.qry = r.qry_mz, p.n_ref = (uint32_t)r.n_ref_mz, p.n_qry = (uint32_t)r.n_qry_mz;
             pairs.push_back(p);
         } else S.fb.push_back((uint32_t)i);
     }

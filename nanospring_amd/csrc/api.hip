@@ -286,6 +286,7 @@ void nsgpu_destroy(nsgpu_ctx *c)
         if (w.h_out) (void)hipHostFree(w.h_out);
         w.h_meta.release();
         w.h_concat.release();
+        w.h_compact.release();
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }
     for (nsgpu_ctx::KswWs &w : c->kws) {
@@ -312,7 +313,6 @@ void nsgpu_destroy(nsgpu_ctx *c)
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }
     c->pin_small.release(); c->pin_foff.release(); c->pin_fids.release(); c->pin_wq.release(); c->pin_wq_out.release();
-    c->rmz.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

@@ -93,15 +93,6 @@ struct PinBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
-// mm_sketch.hip: one sequence sketched by ONE launch into a pinned block, without a host wait (mini_sketch_launch / _collect)
-struct MiniSketch {
-    PinBuf buf;
-    hipEvent_t ev = nullptr;
-    uint32_t len = 0, n_tiles = 0;
-    bool pending = false;
-    void release() { buf.release(); if (ev) { (void)hipEventDestroy(ev); ev = nullptr; } pending = false; }
-};
-
 // A set of 2-bit packed sequences in HBM.  Row r starts at byte poff[r]
 // (16-byte aligned, zero padded to the next 16 bytes plus 16 more so that
 // kernels may over-read two dwords) and holds len[r] bases, MSB-first.
@@ -134,21 +125,6 @@ struct LdsAttr {
         }
         return NSGPU_OK;
     }
-};
-
-// mm_sketch.hip reads_mz_build: the text and the (w,k)-minimizers of every read, both strands, resident in HBM for a contig stage.  Read r,
-// strand sd: text at ascii[sd] + h_aoff[r] (len bases), minimizers mz[off[sd][r] .. + cnt[sd][r]) when ok[sd][r].
-struct ReadMz {
-    DevBuf ascii[2], aoff, mz, soff, len, tiles, tcnt, tpal, tbad, toff, scan_ws, flags;
-    std::vector<uint64_t> h_aoff;
-    std::vector<uint64_t> off[2];
-    std::vector<uint32_t> cnt[2];
-    std::vector<uint8_t> ok[2];
-    int w = 0, k = 0;
-    uint64_t n_mz = 0;
-    double build_ms = 0;
-    bool valid = false;
-    void release() { for (DevBuf *d : {&ascii[0], &ascii[1], &aoff, &mz, &soff, &len, &tiles, &tcnt, &tpal, &tbad, &toff, &scan_ws, &flags}) d->release(); valid = false; }
 };
 
 struct Timer {
@@ -225,6 +201,7 @@ struct nsgpu_ctx {
         uint8_t *h_out = nullptr; size_t h_out_cap = 0;
         nsgpu::PinBuf h_meta;                                          // pinned landing zone of the small read-backs (push count, offsets)
         nsgpu::PinBuf h_concat;                                        // results of an oversize batch sketched piece by piece (gpu_mm_sketch)
+        nsgpu::PinBuf h_compact; std::vector<uint64_t> h_toff;         // the fused path's tile slots laid out back to back / the tiles' offsets there
         const uint32_t *staged_soff = nullptr; size_t staged_n = 0;   // offsets of the last batch's requests in `seqs` (sketch_dev_seq)
         std::vector<uint32_t> staged_soff_v;
         hipStream_t stream = nullptr;
@@ -253,7 +230,6 @@ struct nsgpu_ctx {
         hipStream_t stream = nullptr;
     } seed_ws[9];
     std::vector<uint64_t> wq_off; std::vector<uint32_t> wq_ids;      // the last fused window-query batch's candidate lists (run_window_queries_fast)
-    nsgpu::ReadMz rmz;                                               // every read's text and minimizers, both strands (contig stage)
     nsgpu::PinBuf pin_wq, pin_wq_out;                                // the engine's window queries: staging of the strings / candidate lists as the last kernel writes them
     nsgpu::PinBuf pin_small, pin_foff, pin_fids;                     // pinned landing zones: the filter's scalars / the engine's candidate CSR
     double sketch_mm_ms = 0;                                         // wall of the batched mm_sketch calls

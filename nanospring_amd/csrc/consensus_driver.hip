@@ -95,10 +95,6 @@ struct Builder {
     // the entries from the first changed one on travel (a contig grows at its ends: a few hundred entries of tens of thousands).
     DevBuf d_mz;
     size_t d_mz_n = 0;
-    // the changed stretch of the consensus, sketched the moment the update that changed it was done (engine_mini_start): the next batch finds
-    // the minimizers (and the stretch's text, for the device copy of the consensus) here instead of starting with a sketch call
-    MiniSketch mini;
-    bool mini_valid = false;                   // launched for the consensus as it is now (b.sp describes the stretch)
     size_t chg_lb = 0;                         // the main path agrees with mz_str (and idx's base codes) on [0, chg_lb): from ContigGraph::path_changed_from
     std::vector<std::unique_ptr<FinishedContig>> contigs;     // in the order they were finished = output order
     size_t n_queued = 0;                                      // contigs[0 .. n_queued) were handed to the emission queue
@@ -141,7 +137,6 @@ struct Driver {
         b.cur_pos = b.g->start_pos;
         b.right_phase = true, b.edges_too_many = false, b.window_open = false;
         b.idx_valid = false, b.sp_ready = false;
-        b.mini_valid = false;
         b.mz.clear(), b.mz_str.clear();          // a new consensus: nothing to splice into
         b.chg_lb = 0;
         b.d_mz_n = 0;                            // (the resident list's memory stays with the builder)
@@ -315,7 +310,7 @@ struct Driver {
         b.last_u = u1 - u0, b.last_m = u2 - u1;
         if (u1 - u0 > b.dbg_max_u) b.dbg_max_u = u1 - u0;
         if (u2 - u1 > b.dbg_max_m) b.dbg_max_m = u2 - u1;
-        b.idx_valid = false, b.sp_ready = false, b.mini_valid = false;
+        b.idx_valid = false, b.sp_ready = false;
     }
 };
 
@@ -366,10 +361,7 @@ struct Engine {
         std::vector<DevBuf> retired;                    // resident lists replaced by larger ones, freed at the lane's next batch
         std::vector<mm2::AlnOut> outs;
         std::vector<uint8_t> early_sure;                // per request: its claim cannot fail (engine_early_updates)
-        std::vector<std::vector<mm2::Anchor>> mini_mz;  // per request: the stretch's minimizers as the builder's own launch left them (Builder::mini)
-        std::vector<uint8_t> use_mini;                  // per request: ... and whether they are used
-        std::vector<uint32_t> q_ref;                    // per request: its candidate's request in the sketch batch (~0u: the read's minimizers are resident, nsgpu_ctx::rmz)
-        std::vector<const uint8_t *> staged;            // per request: the changed stretch's text in device-visible memory (cons_update_kernel's source)
+        std::vector<const uint8_t *> staged;            // per request: the changed stretch's text in device memory (cons_update_kernel's source)
             double sk_ms[6] = {0, 0, 0, 0, 0, 0};           // engine_batches_sketch: splice plan, requests, sketch call, index loop, enqueue of seeds..DP, wait + first step
         int sketch_ws = 0;                              // mm_sketch workspace of the lane's batches
         void release()
@@ -392,8 +384,6 @@ struct Engine {
     AlignBatch ab[kMaxGroups];                        // alignment batch of each group, DP kernels in flight between part 1 and part 2
     std::vector<uint32_t> fwho;                    // builders of the window-query batch
     std::vector<uint32_t> awho[kMaxGroups];           // builders of that batch
-    hipStream_t mini_st[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // the builders' own sketch launches (engine_mini_start)
-    std::atomic<uint64_t> n_mini{0}, n_mini_used{0}, n_cand_resident{0}, n_sketch_calls{0};
     Builder *local(uint32_t gid) { return gid % world == rank ? &D.B[gid / world] : nullptr; }
     // ---- conflict-aware seeds (nsgpu_set_schedule; SURVEY 8e "assign seed reads by MinHash bucket locality") ----
     // Reads are grouped once into buckets of the whole-read filter graph (x -- y when y is a filter result of x or of its reverse
@@ -439,8 +429,7 @@ static void engine_free(void *p)
 {
     pool_drain();                                     // no emission task may outlive the engine
     Engine *E = static_cast<Engine *>(p);
-    for (hipStream_t &st : E->mini_st) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
-    for (Builder &b : E->D.B) { b.d_mz.release(); b.d_cons.release(); b.mini.release(); }
+    for (Builder &b : E->D.B) { b.d_mz.release(); b.d_cons.release(); }
     for (Engine::Lane &L : E->lane) L.release();
     delete E;
 }
@@ -483,12 +472,6 @@ static int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, 
     memset(&c->cons_stats, 0, sizeof(c->cons_stats));
     c->cons_stats.n_builders = n_builders_total;
     c->have_cons = false;
-    // every read's text and minimizers, both strands, into HBM: a candidate's side of an alignment needs no sketch call any more
-    // (NSGPU_NO_READ_MZ=1: candidates sketched with every slot's batch, as before -- A/B switch)
-    for (hipStream_t &st : E->mini_st) NS_TRY(role_stream_create(&st, "sketch"));
-    static const bool no_read_mz = getenv("NSGPU_NO_READ_MZ") != nullptr;
-    c->rmz.valid = false;
-    if (!no_read_mz && D.N) NS_TRY(reads_mz_build(c, (int)c->prm.m_w, (int)c->prm.m_k));
     return seed_policy_init(c, E);
 }
 
@@ -788,24 +771,6 @@ static size_t apply_splice(Builder &b, const mm2::Anchor *sub, size_t n_sub, int
     return first_diff;
 }
 
-// The changed stretch of b's consensus (b.sp, plan_splice has just run) into a sketch launch of the builder's own -- called on the thread that
-// made the update, right behind it.  Nothing waits here; engine_batches_sketch collects.  NSGPU_NO_MINI_SKETCH=1: every changed stretch goes
-// with the slot's sketch batch, as before (A/B switch).
-static void engine_mini_start(nsgpu_ctx *c, Engine *E, Builder &b)
-{
-    static const bool off = getenv("NSGPU_NO_MINI_SKETCH") != nullptr;
-    b.mini_valid = false;
-    if (off || !b.g) return;
-    const std::string &mp = b.g->main_path;
-    const char *text = b.sp.full ? mp.data() : mp.data() + b.sp.a;
-    const size_t len = b.sp.full ? mp.size() : b.sp.B_sub - b.sp.a;
-    hipStream_t &st = E->mini_st[b.id % 8];
-    if (!st) return;
-    if (mini_sketch_launch(b.mini, text, len, (int)c->prm.m_w, (int)c->prm.m_k, st) != NSGPU_OK) return;      // (too long for this path, or an error: the batch sketches it)
-    b.mini_valid = true;
-    E->n_mini += 1;
-}
-
 // ---- the consensus resident in HBM -----------------------------------------------------------------------------------------------------
 // After an accepted read the new consensus differs from the old one between a common prefix of P and a common suffix of S bases, and the
 // bytes in between travelled with the sketch batch anyway (the re-sketched stretch contains them).  The device copy is brought up to date
@@ -973,56 +938,29 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
     sk_ref.assign(n, ~0u);
     bool unplanned = false;
     for (size_t w = 0; w < n && !unplanned; ++w) { const Builder &b = D.B[who[w]]; unplanned = !b.idx_valid && !b.sp_ready; }
-    if (unplanned) par_for("sketch.plan", n, [&](size_t w) { Builder &b = D.B[who[w]]; if (!b.idx_valid && !b.sp_ready) { plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k); b.mini_valid = false; } });
+    if (unplanned) par_for("sketch.plan", n, [&](size_t w) { Builder &b = D.B[who[w]]; if (!b.idx_valid && !b.sp_ready) plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k); });
     double tk = now_ms();
     L.sk_ms[0] += tk - g0;
-    // What is there already: the changed stretches the builders sketched themselves right behind their updates (Builder::mini: the launches are
-    // long done -- their events are looked at, nothing is waited for in the common case), and the candidate reads' minimizers, resident in HBM
-    // for the whole stage (nsgpu_ctx::rmz).  What is left -- a stretch too long for a builder's own launch, a string the fused kernel
-    // declined, a read it declined -- goes into ONE sketch call as before; most batches have nothing left.
-    std::vector<uint8_t> &use_mini = L.use_mini;
-    use_mini.assign(n, 0);
-    if (L.mini_mz.size() < n) L.mini_mz.resize(n);
-    {
-        std::atomic<int> mini_rc{NSGPU_OK};
-        bool any = false;
-        for (size_t w = 0; w < n && !any; ++w) { const Builder &b = D.B[who[w]]; any = !b.idx_valid && b.mini_valid; }
-        if (any) par_for("sketch.mini", n, [&](size_t w) {
-            Builder &b = D.B[who[w]];
-            if (b.idx_valid || !b.mini_valid) return;
-            bool ok = false;
-            const int rc = mini_sketch_collect(b.mini, (int)c->prm.m_w, (int)c->prm.m_k, L.mini_mz[w], ok);
-            if (rc != NSGPU_OK) mini_rc = rc;
-            use_mini[w] = ok;
-        });
-        NS_TRY(mini_rc.load());
-    }
-    const ReadMz &RM = c->rmz;
-    std::vector<uint32_t> &q_ref = L.q_ref;
-    q_ref.assign(n, ~0u);
+    // (Measured in round 5 and removed: every read's minimizers, both strands, resident in HBM for the whole stage -- no candidate in the slots'
+    // sketch batches -- and every changed stretch sketched by its builder's own launch right behind the graph update, collected here through an
+    // event.  The sketch call went from 0.25 to 0.07 ms per slot and was gone in 60 % of the slots, but the launches cost the slowest
+    // builder's task as much as the call had cost the batch, and the lists take 0.13 s per step to build: 6.93 / 6.70 s per step with both /
+    // with the resident lists only, against 6.77 s without either.)
     for (size_t w = 0; w < n; ++w) {
         Builder &b = D.B[who[w]];
-        b.mini_valid = false;
-        if (b.idx_valid || use_mini[w]) continue;
+        if (b.idx_valid) continue;
         sk_ref[w] = (uint32_t)sk.size();
         if (b.sp.full) sk.push_back(SketchReq{b.g->main_path.data(), b.g->main_path.size()});
         else sk.push_back(SketchReq{b.g->main_path.data() + b.sp.a, b.sp.B_sub - b.sp.a});
     }
-    uint64_t n_res = 0, n_used = 0;
-    for (size_t w = 0; w < n; ++w) {
-        const Builder &b = D.B[who[w]];
-        n_used += use_mini[w];
-        if (RM.valid && RM.ok[b.strand][b.pend] && b.query.size() == D.read_len(b.pend)) { ++n_res; continue; }
-        q_ref[w] = (uint32_t)sk.size();
-        sk.push_back(SketchReq{b.query.data(), b.query.size()});
-    }
-    E->n_cand_resident += n_res, E->n_mini_used += n_used;
+    const size_t q_base = sk.size();
+    for (size_t w = 0; w < n; ++w) sk.push_back(SketchReq{D.B[who[w]].query.data(), D.B[who[w]].query.size()});
     AB.reqs.resize(n);
     if (AB.jobs.size() < n) AB.jobs.resize(n);
     L.sk_ms[1] += now_ms() - tk; tk = now_ms();
     const mm2::Anchor *mz = nullptr;
     std::vector<uint64_t> &mo = L.mz_off;
-    if (!sk.empty()) { NS_TRY(gpu_mm_sketch(c, sk, (int)c->prm.m_w, (int)c->prm.m_k, mz, mo, L.sketch_ws)); E->n_sketch_calls += 1; }
+    NS_TRY(gpu_mm_sketch(c, sk, (int)c->prm.m_w, (int)c->prm.m_k, mz, mo, L.sketch_ws));
     L.sk_ms[2] += now_ms() - tk; tk = now_ms();
     static const bool resident_lists = getenv("NSGPU_NO_RESIDENT_LISTS") == nullptr;      // A/B switch: consensus minimizer lists staged whole, as in round 2
     std::vector<size_t> &tail_from = L.tail_from;
@@ -1032,14 +970,10 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
     std::vector<uint8_t> &changed = L.cons_changed;
     changed.assign(n, 0);
     for (size_t w = 0; w < n; ++w) changed[w] = !D.B[who[w]].idx_valid;
-    // the changed stretches' text where the device can read it (the source of the resident consensus copies' updates)
+    // the changed stretches' text where the sketch batch staged it in HBM (the source of the resident consensus copies' updates)
     std::vector<const uint8_t *> &staged = L.staged;
     staged.assign(n, nullptr);
-    for (size_t w = 0; w < n; ++w) {
-        if (!changed[w]) continue;
-        if (use_mini[w]) staged[w] = mini_sketch_text(D.B[who[w]].mini);
-        else if (sk_ref[w] != ~0u) staged[w] = sketch_dev_seq(c, L.sketch_ws, sk_ref[w]);
-    }
+    for (size_t w = 0; w < n; ++w) if (changed[w] && sk_ref[w] != ~0u) staged[w] = sketch_dev_seq(c, L.sketch_ws, sk_ref[w]);
     // lists retired by an earlier call: their last reader (that call's seeding kernel) has been waited for since
     for (DevBuf &d : L.retired) d.release();
     L.retired.clear();
@@ -1048,8 +982,8 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
     const int sws_i = 1 + 2 * gi;
     std::vector<uint64_t> &so = L.stage_off;
     so.assign(n + 1, 0);
-    auto n_sub_of = [&](size_t w) -> uint64_t { return use_mini[w] ? L.mini_mz[w].size() : sk_ref[w] != ~0u ? mo[sk_ref[w] + 1] - mo[sk_ref[w]] : 0; };
-    auto sub_of = [&](size_t w) -> const mm2::Anchor * { return use_mini[w] ? L.mini_mz[w].data() : sk_ref[w] != ~0u ? mz + mo[sk_ref[w]] : nullptr; };
+    auto n_sub_of = [&](size_t w) -> uint64_t { return sk_ref[w] != ~0u ? mo[sk_ref[w] + 1] - mo[sk_ref[w]] : 0; };
+    auto sub_of = [&](size_t w) -> const mm2::Anchor * { return sk_ref[w] != ~0u ? mz + mo[sk_ref[w]] : nullptr; };
     for (size_t w = 0; w < n; ++w) {
         const Builder &b = D.B[who[w]];
         uint64_t bound = b.mz.size();
@@ -1058,16 +992,12 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
     }
     NS_TRY(c->seed_ws[sws_i].h_ref.reserve(so[n] * sizeof(mm2::Anchor) + 16));
     mm2::Anchor *stage = c->seed_ws[sws_i].h_ref.as<mm2::Anchor>();
-    // the query minimizers: resident in HBM, or in the pinned buffer of the sketch workspace until the alignments have been seeded
+    // the query minimizers stay in the pinned buffer of the sketch workspace until the alignments have been seeded
     for (size_t w = 0; w < n; ++w) {
         Builder &b = D.B[who[w]];
-        const uint32_t qi = q_ref[w];
-        AB.reqs[w] = AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), qi != ~0u ? mz + mo[qi] : nullptr,
-                              qi != ~0u ? (size_t)(mo[qi + 1] - mo[qi]) : 0, stage + so[w], 0};
-        if (qi == ~0u) {
-            AB.reqs[w].qry_mz_dev = RM.mz.as<mm2::Anchor>() + RM.off[b.strand][b.pend], AB.reqs[w].n_qry_mz_dev = RM.cnt[b.strand][b.pend];
-            if (use_dev_plan) AB.reqs[w].qry_dev = RM.ascii[b.strand].as<uint8_t>() + RM.h_aoff[b.pend];
-        } else if (use_dev_plan) AB.reqs[w].qry_dev = sketch_dev_seq(c, L.sketch_ws, qi);       // (the consensus side: filled in below, once the device copies are up to date)
+        const size_t qi = q_base + w;
+        AB.reqs[w] = AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), mz + mo[qi], (size_t)(mo[qi + 1] - mo[qi]), stage + so[w], 0};
+        if (use_dev_plan) AB.reqs[w].qry_dev = sketch_dev_seq(c, L.sketch_ws, qi);       // (the consensus side: filled in below, once the device copies are up to date)
     }
     NS_TRY(align_prestep_start(c, AB, 0, n));
     // one loop over the builders: the minimizers of the changed consensus (splice), its base codes, the list into the staging
@@ -1300,7 +1230,6 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
         plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k);
         b.sp_ready = true;
         b.early_updated = true;
-        engine_mini_start(c, E, b);                  // the changed stretch's minimizers are on their way before the slot is over
         b.cpu_ms += now_ms() - t0;
         n_updates += 1;
     };
@@ -1706,8 +1635,6 @@ static void debug_report_slots(nsgpu_ctx *c, Engine *E)
             fprintf(stderr, "\n");
         }
     }
-    fprintf(stderr, "[cons] sketches: %llu stretches sketched by their builders behind the update (%llu used), %llu candidates with resident minimizers, %llu sketch calls in batches; read minimizers built in %.1f ms (%.1f M entries)\n",
-            (unsigned long long)E->n_mini.load(), (unsigned long long)E->n_mini_used.load(), (unsigned long long)E->n_cand_resident.load(), (unsigned long long)E->n_sketch_calls.load(), c->rmz.build_ms, c->rmz.n_mz / 1e6);
     fprintf(stderr, "[cons] early tasks: loops of part 0 / part 1 %.0f / %.0f ms wall; tasks %.0f ms in sum (delivery + skeleton + conversion %.0f), the longest of each slot %.0f ms in sum\n",
             E->early_part_ms[0], E->early_part_ms[1], E->early_task_ms, E->early_conv_ms, E->early_task_max_ms);
     fprintf(stderr, "[cons] graph updates run ahead of the slot's end: %llu, %.0f ms wall (DP results + updates); status words seen ahead of their data: %llu\n", (unsigned long long)E->n_early, E->early_ms, (unsigned long long)E->n_early_retry);

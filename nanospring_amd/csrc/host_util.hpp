@@ -42,9 +42,6 @@ struct AlignReq {
     size_t n_qry_mz = 0;
     const mm2::Anchor *ref_mz = nullptr;   // the reference's minimizers, PINNED memory as well; both given = seeds on the GPU (seeds.hip)
     size_t n_ref_mz = 0;
-    const mm2::Anchor *qry_mz_dev = nullptr;   // the query's minimizers in DEVICE memory (reads_mz_build): the seeding kernel reads these; qry_mz may then be null
-                                               // (the host code sketches the query itself for the pairs the kernel hands back)
-    size_t n_qry_mz_dev = 0;
     const mm2::Anchor *ref_mz_dev = nullptr;   // the same list resident in DEVICE memory (the contig engine keeps one per contig): the seeding kernel
                                                // reads this one, ref_mz (any host memory then) serves the pairs the kernel hands back to the host code
     // for the plan kernel (plan.hip): the query and the stretch [ref_dev_lo, ref_dev_lo + ref_dev_n) of the reference as ASCII in DEVICE memory
@@ -62,12 +59,6 @@ struct SketchReq { const char *ptr; size_t len; };
 // request i's bytes in DEVICE memory (nullptr when the batch did not go through the fused path's staging), valid until the workspace's next call
 int gpu_mm_sketch(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws = 0, size_t n_stage_only = 0);
 const uint8_t *sketch_dev_seq(const nsgpu_ctx *c, int ws, size_t i);
-// mm_sketch.hip: every read's text and minimizers, both strands, into HBM (c->rmz) / one sequence by one launch without a host wait
-int reads_mz_build(nsgpu_ctx *c, int w, int k);
-struct MiniSketch;
-int mini_sketch_launch(MiniSketch &M, const char *text, size_t len, int w, int k, hipStream_t st);      // 1: not for this path (too long)
-int mini_sketch_collect(MiniSketch &M, int w, int k, std::vector<mm2::Anchor> &out, bool &ok);
-const uint8_t *mini_sketch_text(const MiniSketch &M);
 int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::AlnOut> &outs, int ws_index = 0);
 // the same in two parts, the DP kernels in flight between them (state of one batch)
 // seeds.hip: index + seeds of a batch of (reference minimizers, query minimizers) pairs on the GPU

@@ -1141,7 +1141,6 @@ int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr
     // the classes the plan kernel's rule (ksw_launch_class_hd) can name under the current switches
     uint32_t classes = 1u << 0 | 1u << 1;
     classes |= 1u << 8;                                                      // (the widest class is not planned on the device: plan.hip)
-    if (kc.sys) classes = (classes & ~(1u << 1)) | 1u << 9 | 1u << 10 | (kc.sys >= 2 ? 1u << 11 : 0u);
     if (two_phase && kc.long_rows > 0) classes |= 1u << 12;
     W.dv_classes = classes;
     bool side_used[3] = {false, false, false};
@@ -1185,7 +1184,7 @@ int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr
     // streams; the bulk on the main stream, and behind it the first part of the results
     for (int k = KSW_REG_CLASSES - 1; k >= 2; --k) {
         if (!(classes >> k & 1)) continue;
-        const int si = k == 12 ? 2 : k >= 9 ? k - 9 : k == 8 ? 1 : k >= 6 ? k - 5 : k >= 4 ? 0 : k - 1;
+        const int si = k == 12 ? 2 : k == 8 ? 1 : k >= 6 ? k - 5 : k >= 4 ? 0 : k - 1;
         hipStream_t st = W.side_stream[si];
         if (!side_used[si]) NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0));
         side_used[si] = true;

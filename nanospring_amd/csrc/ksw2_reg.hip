@@ -740,372 +740,11 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
                                  __builtin_amdgcn_readfirstlane(ez_score), (int)threadIdx.x);
 }
 
-// -------------------------------------------------------------------------------------------------------------------
-// The systolic variant for the problems a launch waits for (round 4): NO per-row barrier.
-//
-// What a row of the barrier kernels above costs is not their arithmetic: one wave needs ~0.6 us for a row whether it owns one block of 128
-// cells or two (the dependent chain of a cell update, not issue slots, is what a single wave waits for), and six waves behind a barrier need
-// 1.2-1.4 us (tools/bench_ksw_rows.py).  Here four waves own CONTIGUOUS stretches of the target (wave w: cells [w C, (w + 1) C), C = NCH x 128:
-// inside a wave the blocks hand over through registers exactly as in the one-wave kernel) and a wave depends on its LEFT neighbour only -- cell
-// t of row r needs cell t - 1 of row r - 1 -- so the waves run free, each a row or so behind the one to its left: the seam cell travels through a
-// ring of tagged 16-byte records in LDS (the tag is the row: a reader that finds another tag reads again), and nobody waits at a barrier.
-// The per-row books -- the exact row maximum with Z-drop / early exit, or the approximate mode's greedy H0 walk -- are kept by a FIFTH wave from
-// what the computing waves publish per row (their best key and H[en0] / H[st0]; u | v of every cell computed in the row); it raises a stop flag
-// that the others poll.  Rows a computing wave finishes beyond the stopping row are never looked at: the reference's state is the books' state.
-// Rings are reused: a writer makes sure every 8 rows that its readers have passed what it is about to overwrite.
-// -------------------------------------------------------------------------------------------------------------------
-constexpr int kSysWaves = 4, kSeamRing = 32, kBookRing = 32, kUvRing = 16;
-constexpr uint32_t kSysSpinLimit = 1u << 21;       // polls a wave waits for a hand-over before it gives the problem up (tenths of a second; ctl[6] = the flag)
-
-// a tagged record: the TAG first, then the payload -- the writer stores payload, then tag; LDS operations of a wave execute in order, so a
-// reader that finds the tag it expects reads a payload at least that new
-// (volatile accesses through a GENERIC pointer stay flat_load / flat_store -- the compiler's address-space inference leaves volatile operations
-// alone -- and a flat access to LDS costs a global-memory round trip: the rings are addressed through explicit LDS pointers)
-typedef volatile uint32_t __attribute__((address_space(3))) *lds_vptr;
-__device__ __forceinline__ lds_vptr to_lds(const void *p) { return (lds_vptr)(uint32_t *)const_cast<void *>(p); }
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 ring_read(const uint4 *p)
-{
-    // ONE 16-byte LDS read: a lane's four words are read in the same pass, so a record whose tag is there has its payload there
-    const u32x4 v = *(volatile u32x4 __attribute__((address_space(3))) *)(u32x4 *)const_cast<uint4 *>(p);
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-
-__host__ __device__ inline size_t sys_ctl_bytes(int nch, bool uv) { return (size_t)(kSysWaves - 1) * kSeamRing * 16 + (size_t)kBookRing * kSysWaves * 16 + 256 + (uv ? (size_t)kUvRing * kSysWaves * nch * 128 * 4 : 0); }
-
-template <int NCH, bool APPROX, bool RIGHT, bool FAST>
-__device__ void ksw_sys_run(const KswTask &tk, const KswParams &pr, const uint8_t *__restrict__ seqs, uint8_t *__restrict__ p_pool, uint32_t *__restrict__ cig_pool,
-                            KswResult *__restrict__ res_out, uint8_t *lds)
-{
-    constexpr int NWC = kSysWaves, CW = NCH * 128, T = NWC * CW;
-    constexpr bool UV = APPROX && !FAST;                     // the books need u | v of the row's cells
-    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
-    const bool is_books = wv == NWC;
-    const int cw = wv;                                       // computing waves 0 .. 3
-    const int qlen = tk.qlen, tlen = tk.tlen, flag = tk.flag, zdrop = tk.zdrop;
-    Consts K;
-    K.q = pr.q, K.e = pr.e, K.q2 = pr.q2, K.e2 = pr.e2;
-    if (K.q2 + K.e2 < K.q + K.e) { int t_ = K.q; K.q = K.q2; K.q2 = t_; t_ = K.e; K.e = K.e2; K.e2 = t_; }
-    K.qe = K.q + K.e, K.qe2 = K.q2 + K.e2;
-    K.sc_mch = pr.sc_mch, K.sc_mis = pr.sc_mis;
-    K.sc_N = pr.sc_ambi == 0 ? -K.e2 : pr.sc_ambi;
-    K.long_thres = K.e != K.e2 ? (K.q2 - K.q) / (K.e - K.e2) - 1 : 0;
-    if (K.q2 + K.e2 + K.long_thres * K.e2 > K.q + K.e + K.long_thres * K.e) ++K.long_thres;
-    K.long_diff = K.long_thres * (K.e - K.e2) - (K.q2 - K.q) - K.e2;
-    int w = tk.w;
-    if (w < 0) w = tlen > qlen ? tlen : qlen;
-    int n_col_ = qlen < tlen ? qlen : tlen;
-    n_col_ = ((n_col_ < w + 1 ? n_col_ : w + 1) + 15) / 16 + 1;
-    const int ncol16 = n_col_ * 16;
-    const int n_rows = qlen + tlen - 1, c1 = qlen - 1, c2 = tlen - 1;
-    // waves whose stretch starts beyond the target never compute: nobody waits for them
-    const int n_act = (tlen + CW - 1) / CW < NWC ? (tlen + CW - 1) / CW : NWC;
-
-    const int QB = reg_qb(T, qlen);
-    uint8_t *qA = lds, *qB = lds + QB;
-    uint4 *seam = reinterpret_cast<uint4 *>(lds + 2 * QB);                              // [NWC - 1][kSeamRing] {x | v << 16, x2, H, tag}
-    uint4 *book = seam + (NWC - 1) * kSeamRing;                                         // [kBookRing][NWC] {best key, H[en0], H[st0], tag | own flags}
-    int *ctl = reinterpret_cast<int *>(book + kBookRing * NWC);                         // [0..3] rows done per wave, [4] rows booked, [5] stop, [8..11] FAST sums, [16..] the books' final state
-    uint32_t *uvr = reinterpret_cast<uint32_t *>(ctl + 64);                             // [kUvRing][T] u | v << 16 (UV only)
-    // tag of row r = r + 1 (0: the state before row 0); slot of row r = (r + 1) % ring
-    for (int i = threadIdx.x; i < (2 * QB) / 4; i += (NWC + 1) * 64) reinterpret_cast<uint32_t *>(lds)[i] = 0;
-    for (int i = threadIdx.x; i < (NWC - 1) * kSeamRing; i += (NWC + 1) * 64) {
-        const uint32_t b0 = (uint32_t)(-K.q - K.e) & 0xffffu, b1 = (uint32_t)(-K.q2 - K.e2) & 0xffffu;
-        seam[i] = make_uint4(b0 | b0 << 16, b1, (uint32_t)KSW_NEG_INF, (i % kSeamRing) == 0 ? 0u : 0xffffffffu);       // slot 0: the initial state (row -1)
-    }
-    for (int i = threadIdx.x; i < kBookRing * NWC; i += (NWC + 1) * 64) book[i] = make_uint4(0u, 0u, 0u, 0u);      // (tag 0 = nothing: rows are tagged from 1)
-    for (int i = threadIdx.x; i < 64; i += (NWC + 1) * 64) ctl[i] = 0;
-    __syncthreads();
-    {
-        const uint8_t *query = seqs + tk.qoff;
-        for (int j = threadIdx.x; j < qlen; j += (NWC + 1) * 64) {
-            const uint8_t b = query[qlen - 1 - j];
-            qA[T + j] = b;
-            qB[T + j - 1] = b;
-        }
-    }
-    __syncthreads();
-    uint8_t *p = p_pool + tk.p_off;
-    lds_vptr vctl = to_lds(ctl);
-    // control words are the same for every lane: through the scalar unit, so that what depends on them (the row loop above all) stays uniform
-    auto uctl = [&](int i) { return __builtin_amdgcn_readfirstlane((int)vctl[i]); };
-
-    if (!is_books) {
-        // ======================================================== a computing wave ========================================================
-        s2 TT[NCH], TP[NCH], SC[NCH], U[NCH], V[NCH], X[NCH], Y[NCH], X2[NCH], Y2[NCH], ACC[NCH];
-        int HL[NCH], HH[NCH];
-        {
-            const uint8_t *target = seqs + tk.toff;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int t0 = cw * CW + c * 128 + 2 * lane;
-                const int b0 = t0 < tlen ? target[t0] : 0, b1 = t0 + 1 < tlen ? target[t0 + 1] : 0;
-                TT[c] = S2(b0 | b1 << 16);
-                TP[c] = S2(t0 | (t0 + 1) << 16);
-                SC[c] = splat(0), ACC[c] = splat(0);
-                U[c] = V[c] = X[c] = Y[c] = splat(-K.q - K.e);
-                X2[c] = Y2[c] = splat(-K.q2 - K.e2);
-                HL[c] = HH[c] = KSW_NEG_INF;
-            }
-        }
-        const int first = cw * CW;
-        int last_st = -1, last_en = -1;
-        // What a row needs from others is asked for a row ahead: the left neighbour's seam record of row r - 1 and the stop flag are loaded at the
-        // end of row r - 1's body and looked at after row r's own preparations, so that their LDS round trip hides behind those (a neighbour that
-        // runs a row ahead has the record there already).
-        const uint4 *seam_in = seam + (cw > 0 ? cw - 1 : 0) * kSeamRing;
-        uint4 pre = ring_read(seam_in);                 // slot 0: the state before row 0 (tag 0)
-        int pre_stop = FAST ? 0 : (int)vctl[5];
-        if (cw < n_act)
-        for (int r = 0; r < n_rows; ++r) {
-            int st0 = r - c1, en0 = r;
-            { const int b = (r - w + 1) >> 1; st0 = st0 > b ? st0 : b; st0 = st0 > 0 ? st0 : 0; }
-            { const int b = (r + w) >> 1; en0 = en0 < b ? en0 : b; en0 = en0 < c2 ? en0 : c2; }
-            if (st0 > en0) { if (FAST && cw == 0 && lane == 0) vctl[7] = 1; break; }      // the band ran out: the same row for every wave (zdropped = 1, ksw2_extd2_sse.c:148)
-            const int st = st0 & ~15, en = en0 | 15;
-            const int sc_last = st0 + ((en0 - st0) & ~15) + 15;
-            const int hi_t = en > sc_last ? en : sc_last;
-            int bnd = -K.e2;
-            if (r <= K.long_thres) bnd = r == 0 ? -K.q - K.e : r < K.long_thres ? -K.e : K.long_diff;
-            const bool need_const = st == 0 || st - 1 < last_st || st - 1 > last_en;
-            const int nbv_c = st > 0 ? -K.q - K.e : bnd;
-            const int qbase = T + c1 - r;
-            const uint8_t *qsrc = (qbase & 1) ? qB + qbase - 1 : qA + qbase;
-            const int en1 = st0 + ((en0 - st0) & ~3);
-            const uint32_t prow = (uint32_t)r * (uint32_t)ncol16 - (uint32_t)st;
-            const bool active = first <= hi_t && first + CW - 1 >= st;
-            // the left neighbour's last cell as of row r - 1
-            if (!FAST && __builtin_amdgcn_readfirstlane(pre_stop)) break;   // the books stopped (Z-drop / early exit)
-            int fx0 = 0, fv0 = 0, fx20 = 0, fh0 = 0;
-            if (cw > 0 && active) {
-                const uint4 *slot = seam_in + (r % kSeamRing);                       // slot of row r - 1
-                uint4 sv = pre;
-                for (uint32_t spin = 0; (uint32_t)__builtin_amdgcn_readfirstlane((int)sv.w) != (uint32_t)r; ++spin) {        // not there yet: the neighbour is not a row ahead
-                    if (uctl(5)) break;
-                    if (spin > kSysSpinLimit) { vctl[5] = 1, vctl[6] = 1; break; }    // (never: a hand-over that does not come is a bug -- end the problem, flag it)
-                    __builtin_amdgcn_s_sleep(1);
-                    sv = ring_read(slot);
-                }
-                fx0 = (int)(sv.x << 16), fv0 = (int)(sv.x & 0xffff0000u), fx20 = (int)(sv.y << 16), fh0 = (int)sv.z;        // (every lane read the same record; lane 0's copy is the one the shifts use)
-            }
-            s2 pox = splat(0), pov = splat(0), pox2 = splat(0);
-            int pohh = 0;
-            uint32_t best = 0;
-            int pub_en0 = 0, pub_st0 = 0;
-            bool own_en0 = false, own_st0 = false;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int tb = first + c * 128;
-                const s2 ox = X[c], ov = V[c], ox2 = X2[c];
-                const int ohh = HH[c], ohl = HL[c];
-                if (tb <= hi_t && tb + 127 >= st) {
-                    const int t0 = tb + 2 * lane;
-                    const uint32_t qw = *reinterpret_cast<const uint16_t *>(qsrc + t0);
-                    const s2 tq = S2((int)__builtin_amdgcn_perm(0u, qw, 0x0c010c00u));
-                    int fx, fv, fx2, fh = 0;
-                    if (c == 0) { fx = fx0, fv = fv0, fx2 = fx20, fh = fh0; }
-                    else {
-                        fx = __builtin_amdgcn_readlane(I32(pox), 63), fv = __builtin_amdgcn_readlane(I32(pov), 63), fx2 = __builtin_amdgcn_readlane(I32(pox2), 63);
-                        if (!APPROX) fh = __builtin_amdgcn_readlane(pohh, 63);
-                    }
-                    s2 xt1 = left_nb(ox, shr1(fx, I32(ox))), vt1 = left_nb(ov, shr1(fv, I32(ov))), x2t1 = left_nb(ox2, shr1(fx2, I32(ox2)));
-                    const int hleft_lo = !APPROX ? shr1(fh, ohh) : 0;
-                    if (need_const && t0 == st) xt1 = sel(0xffffu, splat(-K.q - K.e), xt1), vt1 = sel(0xffffu, splat(nbv_c), vt1), x2t1 = sel(0xffffu, splat(-K.q2 - K.e2), x2t1);
-                    s2 ut = U[c], yo = Y[c], y2o = Y2[c];
-                    if (en >= r && (uint32_t)(r - t0) < 2u) {
-                        const uint32_t m = r == t0 ? 0xffffu : 0xffff0000u;
-                        ut = sel(m, splat(bnd), ut), yo = sel(m, splat(-K.q - K.e), yo), y2o = sel(m, splat(-K.q2 - K.e2), y2o);
-                    }
-                    SC[c] = sel(range_mask(TP[c], st0, sc_last), score_pair(K, tq, TT[c]), SC[c]);
-                    if (t0 >= st && t0 <= en) {
-                        s2 un, vn, xn, yn, x2n, y2n;
-                        uint32_t dbytes;
-                        cell_pair<RIGHT>(K, SC[c], ut, yo, y2o, xt1, vt1, x2t1, un, vn, xn, yn, x2n, y2n, dbytes);
-                        U[c] = un, V[c] = vn, X[c] = xn, Y[c] = yn, X2[c] = x2n, Y2[c] = y2n;
-                        *reinterpret_cast<uint16_t *>(p + (prow + (uint32_t)t0)) = (uint16_t)dbytes;
-                        if (FAST) {
-                            const s2 e = S2(I32(TP[c]) ^ I32(splat(st0)));
-                            const s2 m = S2u(to01(U2(e))) - splat(1);
-                            ACC[c] = ACC[c] + S2(I32(m) & I32(r < qlen ? vn : un));
-                        }
-                        if (UV) reinterpret_cast<uint2 *>(uvr + (size_t)(r % kUvRing) * T)[t0 >> 1] =
-                                    make_uint2((uint32_t)(uint16_t)un.x | (uint32_t)(uint16_t)vn.x << 16, (uint32_t)(uint16_t)un.y | (uint32_t)(uint16_t)vn.y << 16);
-                        if (!APPROX) {
-                            const int vlo = (int)vn.x, vhi = (int)vn.y, ulo = (int)un.x, uhi = (int)un.y;
-                            int nl = ohl, nh = ohh;
-                            if (r > 0) {
-                                const bool in_lo = t0 >= st0 && t0 < en0, in_hi = t0 + 1 >= st0 && t0 + 1 < en0;
-                                if (in_lo) nl = ohl + vlo;
-                                if (in_hi) nh = ohh + vhi;
-                                if (t0 == en0) nl = en0 > 0 ? hleft_lo + ulo : ohl + vlo;
-                                if (t0 + 1 == en0) nh = ohl + uhi;
-                                if (in_lo || t0 == en0) { const uint32_t k = (uint32_t)(nl + 32768) << 16 | (0xffffu - (uint32_t)key_rank(t0, st0, en0, en1)); best = k > best ? k : best; }
-                                if (in_hi || t0 + 1 == en0) { const uint32_t k = (uint32_t)(nh + 32768) << 16 | (0xffffu - (uint32_t)key_rank(t0 + 1, st0, en0, en1)); best = k > best ? k : best; }
-                            } else if (t0 == 0) {
-                                nl = vlo - K.qe;
-                                best = (uint32_t)(nl + 32768) << 16 | (0xffffu - 0u);
-                            }
-                            HL[c] = nl, HH[c] = nh;
-                            if (t0 == en0 || t0 + 1 == en0) own_en0 = true, pub_en0 = t0 == en0 ? nl : nh;
-                            if (t0 == st0 || t0 + 1 == st0) own_st0 = true, pub_st0 = t0 == st0 ? nl : nh;
-                        }
-                    }
-                }
-                pox = ox, pov = ov, pox2 = ox2, pohh = ohh;
-            }
-            // hand-overs of row r: the seam to the right-hand neighbour, this wave's share of the books.  Payload first, tag last (the stores of a
-            // wave reach the LDS in program order; they are volatile so that the compiler keeps that order too).
-            if (cw + 1 < n_act && lane == 63) {
-                const uint32_t xx = (uint32_t)I32(X[NCH - 1]) >> 16, vv = (uint32_t)I32(V[NCH - 1]) & 0xffff0000u, xx2 = (uint32_t)I32(X2[NCH - 1]) >> 16;
-                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                volatile u32x2 __attribute__((address_space(3))) *slot = (volatile u32x2 __attribute__((address_space(3))) *)(u32x2 *)(seam + cw * kSeamRing + ((r + 1) % kSeamRing));
-                slot[0] = (u32x2){xx | vv, xx2};
-                slot[1] = (u32x2){APPROX ? 0u : (uint32_t)HH[NCH - 1], (uint32_t)(r + 1)};
-            }
-            if (!FAST) {
-                lds_vptr e = to_lds(book + ((r + 1) % kBookRing) * NWC + cw);
-                if (!APPROX) {
-                    const uint32_t bw = active ? wave_max_u32(best) : 0u;
-                    if (own_en0) e[1] = (uint32_t)pub_en0;
-                    if (own_st0) e[2] = (uint32_t)pub_st0;
-                    if (lane == 0) e[0] = bw;
-                }
-                if (lane == 0) e[3] = (uint32_t)(r + 1);
-            }
-            // every 8 rows: this wave's progress, and the readers have passed what the next 8 rows overwrite (seam ring 32: the neighbour has done
-            // the rows up to 16 back; the books' rings: up to 8 back)
-            if ((r & 7) == 7) {
-                const int next = r + 1;
-                if (lane == 0) vctl[cw] = next;
-                if (cw + 1 < n_act) for (uint32_t spin = 0; uctl(cw + 1) < next - 16 && !uctl(5); ++spin) { if (spin > kSysSpinLimit) { vctl[5] = 1, vctl[6] = 1; break; } __builtin_amdgcn_s_sleep(1); }
-                if (!FAST) for (uint32_t spin = 0; uctl(4) < next + 8 - (UV ? kUvRing : kBookRing) + 1 && !uctl(5); ++spin) { if (spin > kSysSpinLimit) { vctl[5] = 1, vctl[6] = 1; break; } __builtin_amdgcn_s_sleep(1); }
-            }
-            // asked for now, looked at in the next row
-            if (cw > 0) pre = ring_read(seam_in + ((r + 1) % kSeamRing));
-            if (!FAST) pre_stop = (int)vctl[5];
-            last_st = st, last_en = en;
-        }
-        if (FAST) {
-            int sum = 0;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) sum += (int)ACC[c].x + (int)ACC[c].y;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-            if (lane == 0) ctl[8 + cw] = sum;
-        }
-    } else if (!FAST) {
-        // ======================================================== the books ========================================================
-        Ez z;
-        z.max = 0, z.max_t = -1, z.max_q = -1, z.mte = KSW_NEG_INF, z.mte_q = -1, z.mqe = KSW_NEG_INF, z.mqe_t = -1;
-        int ez_zdropped = 0, ez_score = KSW_NEG_INF, H0 = 0, last_H0_t = 0;
-        const bool early_ok = !APPROX && (flag & KSW_EZ_NS_EARLY_EXIT) && 2 * c2 + w + 1 <= c1;
-        for (int r = 0; r < n_rows; ++r) {
-            int st0 = r - c1, en0 = r;
-            { const int b = (r - w + 1) >> 1; st0 = st0 > b ? st0 : b; st0 = st0 > 0 ? st0 : 0; }
-            { const int b = (r + w) >> 1; en0 = en0 < b ? en0 : b; en0 = en0 < c2 ? en0 : c2; }
-            if (st0 > en0) { ez_zdropped = 1; break; }
-            const int en = en0 | 15;
-            // the row's records of every wave that computes
-            const uint4 *e = book + ((r + 1) % kBookRing) * NWC;
-            uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-            for (uint32_t spin = 0;; ++spin) {
-                if (lane < n_act) rec = ring_read(e + lane);
-                const bool ok = lane >= n_act || rec.w == (uint32_t)(r + 1);
-                if (__ballot(ok) == ~0ull) break;
-                if (spin > kSysSpinLimit) { vctl[6] = 1; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (uctl(6)) { ez_zdropped = 1; break; }
-            bool stop = false;
-            if (!APPROX) {
-                uint32_t best = lane < n_act ? rec.x : 0u;
-                best = wave_max_u32(best);
-                const int max_H = (int)(best >> 16) - 32768, max_t = (int)((0xffffu - (best & 0xffffu)) & 8191u);
-                // H[en0] / H[st0]: written by the one wave that owns the cell (into its own record)
-                const int own_e = en0 / CW < NWC ? en0 / CW : NWC - 1, own_s = st0 / CW < NWC ? st0 / CW : NWC - 1;
-                const int h_en0 = __builtin_amdgcn_readlane((int)rec.y, own_e), h_st0 = __builtin_amdgcn_readlane((int)rec.z, own_s);
-                if (en0 == c2) { const bool up = h_en0 > z.mte; z.mte_q = up ? r - en : z.mte_q, z.mte = up ? h_en0 : z.mte; }
-                if (r - st0 == c1) { const bool up = h_st0 > z.mqe; z.mqe_t = up ? st0 : z.mqe_t, z.mqe = up ? h_st0 : z.mqe; }
-                int s_ = zdrop_row(z, r, max_H, max_t, zdrop, K.e2);
-                if (early_ok) {
-                    const int Lq = r + 1 - 2 * c2;
-                    const int g1 = K.q + K.e * Lq, g2 = K.q2 + K.e2 * Lq;
-                    const int bound = K.sc_mch * tlen - (g1 < g2 ? g1 : g2) + 32;
-                    s_ |= (Lq >= 1 && bound < z.mte) ? 1 : 0;
-                }
-                if (__builtin_amdgcn_readfirstlane(s_)) { ez_zdropped = 1; stop = true; }
-                if (!stop && r == n_rows - 1 && en0 == c2) ez_score = h_en0;
-            } else {
-                const uint32_t *uv = uvr + (size_t)(r % kUvRing) * T;
-                lds_vptr uvp = to_lds(uv);
-                auto getv = [&](int t) { return (int)(short)(uvp[t] >> 16); };
-                auto getu = [&](int t) { return (int)(short)(uvp[t] & 0xffffu); };
-                if (r > 0) {
-                    if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
-                        const int d0 = getv(last_H0_t), d1 = getu(last_H0_t + 1);
-                        if (d0 > d1) H0 += d0;
-                        else H0 += d1, ++last_H0_t;
-                    } else if (last_H0_t >= st0 && last_H0_t <= en0) {
-                        H0 += getv(last_H0_t);
-                    } else {
-                        ++last_H0_t, H0 += getu(last_H0_t);
-                    }
-                } else H0 = getv(0) - K.qe, last_H0_t = 0;
-                if (flag & KSW_EZ_APPROX_DROP)
-                    if (__builtin_amdgcn_readfirstlane(zdrop_row(z, r, H0, last_H0_t, zdrop, K.e2))) { ez_zdropped = 1; stop = true; }
-                if (!stop && r == n_rows - 1 && en0 == c2) ez_score = H0;
-            }
-            if (lane == 0) vctl[4] = r + 1;
-            if (stop) { if (lane == 0) vctl[5] = 1; break; }
-        }
-        if (lane == 0) {
-            ctl[16] = z.max, ctl[17] = ez_zdropped, ctl[18] = z.max_q, ctl[19] = z.max_t, ctl[20] = z.mqe, ctl[21] = z.mqe_t, ctl[22] = z.mte, ctl[23] = z.mte_q, ctl[24] = ez_score;
-            vctl[5] = 1;              // (whatever ended the books ends the computing waves: they may be waiting for the books' progress)
-        }
-    }
-    __threadfence_block();
-    __syncthreads();        // every traceback byte has landed; the books' state is in LDS
-    if (wv == 0 && ctl[6]) {              // a hand-over never came (internal error): a result nobody can mistake for an alignment
-        if (lane == 0) { KswResult o; o.max = 0xdeadbeefu, o.zdropped = -1, o.max_q = o.max_t = o.mqe_t = o.mte_q = -1, o.mqe = o.mte = o.score = KSW_NEG_INF, o.n_cigar = 0, o.reach_end = 0; res_out[tk.out_idx] = o; }
-    } else
-    if (wv == 0) {
-        int ez_max = ctl[16], ez_zd = ctl[17], ez_mq = ctl[18], ez_mt = ctl[19], ez_mqe = ctl[20], ez_mqe_t = ctl[21], ez_mte = ctl[22], ez_mte_q = ctl[23], ez_sc = ctl[24];
-        if (FAST) {
-            // unbanded approx problems never Z-drop and always reach the last row: score = the path sum - (q + e); the other fields as ksw_reset_extz leaves them
-            ez_max = 0, ez_zd = ctl[7], ez_mq = ez_mt = ez_mqe_t = ez_mte_q = -1, ez_mqe = ez_mte = KSW_NEG_INF;
-            ez_sc = (flag & KSW_EZ_NS_NO_SCORE) ? 0 : ez_zd ? KSW_NEG_INF : ctl[8] + ctl[9] + ctl[10] + ctl[11] - K.qe;
-        }
-        if (flag & KSW_EZ_NS_SERIAL_BACKTRACK) {
-            if (lane == 0) backtrack_and_store(tk, w, ncol16, p, cig_pool, res_out, ez_max, ez_zd, ez_mq, ez_mt, ez_mqe, ez_mqe_t, ez_mte, ez_mte_q, ez_sc);
-        } else backtrack_and_store_wave(tk, w, ncol16, p, cig_pool, res_out, ez_max, ez_zd, ez_mq, ez_mt, ez_mqe, ez_mqe_t, ez_mte, ez_mte_q, ez_sc, lane);
-    }
-}
-
-template <int NCH>
-__global__ __launch_bounds__((kSysWaves + 1) * 64) void ksw_extd2_sys_kernel(const KswTask *__restrict__ tasks, const uint32_t *__restrict__ order, uint32_t n, KswParams pr,
-                                                                             const uint8_t *__restrict__ seqs, uint8_t *__restrict__ p_pool, uint32_t *__restrict__ cig_pool,
-                                                                             KswResult *__restrict__ res, const uint32_t *__restrict__ n_dev, DvCollect dc)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    if (n_dev) n = *n_dev;
-    if (blockIdx.x >= n) return;
-    const uint32_t ti = order[blockIdx.x];
-    if (ti == ~0u) return;
-    const KswTask tk = tasks[ti];
-    const bool approx = (tk.flag & KSW_EZ_APPROX_MAX) != 0, right = (tk.flag & KSW_EZ_RIGHT) != 0;
-    if (approx) {
-        const int w = tk.w < 0 ? tk.qlen + tk.tlen : tk.w;
-        const bool fast = !(tk.flag & KSW_EZ_APPROX_DROP) && (w >= tk.qlen + tk.tlen || (tk.flag & KSW_EZ_NS_NO_SCORE));
-        if (right) ksw_sys_run<NCH, true, true, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
-        else if (fast) ksw_sys_run<NCH, true, false, true>(tk, pr, seqs, p_pool, cig_pool, res, lds);
-        else ksw_sys_run<NCH, true, false, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
-    } else {
-        if (right) ksw_sys_run<NCH, false, true, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
-        else ksw_sys_run<NCH, false, false, false>(tk, pr, seqs, p_pool, cig_pool, res, lds);
-    }
-    dev_problem_done(dc, ti, lds);
-}
+// (Rounds 4-5, measured and removed: a systolic variant without a per-row barrier -- four waves on contiguous stretches of the target, the seam
+// cell handed to the right-hand neighbour through tagged records in an LDS ring, a fifth wave keeping the books.  Faster per anti-diagonal
+// than <6,2> on 64 equal problems alone on the chip (0.83 against 1.04 us for 300 .. 500 columns), slower in the engine in every arrangement
+// tried: all ranges 7.54 s per cfg2 step, only 513 .. 1536 columns 7.10 s, only 257 .. 512 columns 6.96 s, against 6.67 / 6.69 s without it
+// (round 5, interleaved on one box) -- five waves and 32 .. 96 KB of LDS per problem beside the 1 700 one-wave problems of the same launch.)
 
 template <int NW, int NCH>
 __global__ __launch_bounds__(NW * 64) void ksw_extd2_reg_kernel(const KswTask *__restrict__ tasks, const uint32_t *__restrict__ order, uint32_t n, KswParams pr,
@@ -1140,10 +779,10 @@ __global__ __launch_bounds__(NW * 64) void ksw_extd2_reg_kernel(const KswTask *_
 struct RegClass { int nw, nch; };
 // Classes 2 and 4 .. 7 are retired (<4,3>, the latency twins <2,1> / <4,1>, <5,3> / <9,5> with a books wave: measured in rounds 2-3, slower;
 // their numbers stay unused so that the others keep theirs).
-// Classes 9 .. 11 are the systolic kernel (ksw_sys_run: four computing waves on contiguous stretches of 128 / 256 / 384 cells and the books wave).
+// Classes 9 .. 11 belonged to the systolic kernel (removed in round 5, see above).
 // Class 12 is <1,4> once more: the long problems of the one-wave classes in a launch of their own (device-planned batches, ksw_class.hpp).
 constexpr RegClass kRegClass[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {6, 2}, {8, 5}, {1, 2}, {1, 4}, {6, 2}, {8, 5}, {6, 2}, {5, 1}, {5, 2}, {5, 3}, {1, 4}};
-constexpr int reg_compute_waves(int cls) { return cls >= 9 && cls <= 11 ? kSysWaves : kRegClass[cls].nw; }
+constexpr int reg_compute_waves(int cls) { return kRegClass[cls].nw; }
 
 }  // namespace
 
@@ -1152,7 +791,6 @@ int ksw_reg_threads(int cls) { return kRegClass[cls].nw * 64; }
 
 size_t ksw_reg_lds_bytes(int cls, int qlen)
 {
-    if (cls >= 9 && cls <= 11) return 2 * (size_t)reg_qb(ksw_reg_cells(cls), qlen) + sys_ctl_bytes(kRegClass[cls].nch, true) + 16;
     const int nw = kRegClass[cls].nw, nb = reg_compute_waves(cls) * kRegClass[cls].nch;
     size_t b = 2 * (size_t)reg_qb(ksw_reg_cells(cls), qlen);
     b += (size_t)2 * nb * 12 + (size_t)3 * (nw + 2) * 4 + 52;      // seams / publication slots (a one-wave class uses two of the slots) / stop flag
@@ -1173,7 +811,6 @@ const KswClassCfg &ksw_class_config()
         k.off = getenv("NSGPU_KSW_NO_REG") != nullptr;
         k.promote_rows = getenv("NSGPU_KSW_PROMOTE_ROWS") ? atoi(getenv("NSGPU_KSW_PROMOTE_ROWS")) : 520;
         k.long_rows = getenv("NSGPU_KSW_LONG_ROWS") ? atoi(getenv("NSGPU_KSW_LONG_ROWS")) : 900;
-        k.sys = getenv("NSGPU_KSW_SYS") ? atoi(getenv("NSGPU_KSW_SYS")) : 0;       // the systolic kernel (classes 9 .. 11) for targets beyond 256 columns and the long narrow problems
         k.flag_or = 0;
         if (getenv("NSGPU_KSW_ALL_BOOKS")) k.flag_or |= KSW_EZ_NS_ALL_BOOKS;                  // approx mode, several waves: every wave keeps the books
         if (getenv("NSGPU_KSW_SERIAL_BACKTRACK")) k.flag_or |= KSW_EZ_NS_SERIAL_BACKTRACK;    // one lane walks the traceback
@@ -1204,17 +841,7 @@ int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const 
     case 1: NS_REG_LAUNCH(1, 4) break;
     case 3: NS_REG_LAUNCH(8, 5) break;
     case 8: NS_REG_LAUNCH(6, 2) break;
-#define NS_SYS_LAUNCH(NCH_)                                                                                                                   \
-    {                                                                                                                                         \
-        static LdsAttr attr;                                                                                                                  \
-        if (lds_bytes > 32768) NS_TRY(attr.raise(lds_bytes, reinterpret_cast<const void *>(ksw_extd2_sys_kernel<NCH_>)));                     \
-        hipLaunchKernelGGL((ksw_extd2_sys_kernel<NCH_>), dim3(m), dim3((kSysWaves + 1) * 64), lds_bytes, st, tasks, order, m, pr, seqs, p_pool, cig_pool, res, n_dev, dc); \
-    }
-    case 9: NS_SYS_LAUNCH(1) break;
-    case 10: NS_SYS_LAUNCH(2) break;
-    case 11: NS_SYS_LAUNCH(3) break;
     case 12: NS_REG_LAUNCH(1, 4) break;
-#undef NS_SYS_LAUNCH
     default: NS_CHECK(false, NSGPU_ERR_ARG, "ksw: bad register class");
     }
 #undef NS_REG_LAUNCH

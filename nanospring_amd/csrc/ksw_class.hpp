@@ -14,7 +14,6 @@ struct KswClassCfg {
     int32_t off;               // NSGPU_KSW_NO_REG: first-generation kernels only
     int32_t promote_rows;      // NSGPU_KSW_PROMOTE_ROWS (default 520; negative = off)
     int32_t flag_or;           // KSW_EZ_NS_* bits the host adds to every task
-    int32_t sys;               // NSGPU_KSW_SYS: the systolic kernel (classes 9 .. 11, ksw2_reg.hip ksw_sys_run) instead of <1,4> / <6,2>
     int32_t long_rows;         // device-planned batches only: problems of the one-wave classes that can take more anti-diagonals than this run apart
                                // from the bulk (class 12: the <1,4> kernel on a side stream) -- what is left finishes early (NSGPU_KSW_LONG_ROWS; 0 = off)
 };
@@ -50,9 +49,6 @@ __host__ __device__ inline int ksw_reg_class_hd(int qlen, int tlen, int w_in, in
     if ((long long)(-pr.sc_mis > pr.sc_mch ? -pr.sc_mis : pr.sc_mch) * mn + (long long)(q + e) * (w + 1) + 64 >= 32768) return -1;
     for (int c = 0; c < 4; ++c)
         if (tlen <= ksw_reg_width(c)) {
-            // four waves on 128 / 256 contiguous cells each, no barrier (384 cells per wave -- class 11 -- lose to <6,2>: tools/bench_ksw_rows.py)
-            if (cfg.sys && (c == 1 || (c == 2 && tlen <= 1024))) return c == 1 ? 9 : 10;
-            if (cfg.sys >= 2 && c == 2) return 11;
             return c == 2 ? 8 : c;                                                              // (513 .. 1536 columns: <6,2>)
         }
     return -1;
@@ -73,7 +69,7 @@ __host__ __device__ inline int ksw_launch_class_hd(int qlen, int tlen, int w_in,
 {
     int rcls = ksw_reg_class_hd(qlen, tlen, w_in, flag, pr, cfg);
     if (two_phase && cfg.long_rows > 0 && (rcls == 0 || rcls == 1) && ksw_rows_bound(qlen, tlen, w_in) > cfg.long_rows) return 12;
-    if (rcls == 0 && cfg.promote_rows >= 0 && ksw_rows_bound(qlen, tlen, w_in) > cfg.promote_rows) rcls = cfg.sys ? 9 : 1;
+    if (rcls == 0 && cfg.promote_rows >= 0 && ksw_rows_bound(qlen, tlen, w_in) > cfg.promote_rows) rcls = 1;
     return rcls;
 }
 // a class whose problems a device-planned batch finishes late: everything that does not run on the main stream (ksw_dev_launch) -- the wide

@@ -504,183 +504,6 @@ static int scan_u32(nsgpu_ctx::SketchWs &W, hipStream_t st, const uint32_t *in, 
 double g_sketch_ms[6];
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// One sequence, one launch, no host wait (MiniSketch, common.hpp): the contig engine sketches the changed stretch of a consensus the moment
-// the graph update that changed it is done -- on the thread that made the update, while the slot's longer DP problems are still running -- so
-// that the next slot's batch finds the minimizers there instead of starting with a sketch call of its own.  The text goes into the caller's
-// pinned block and is read by the kernel where it lies (a few KB over the link); every 1024-position tile writes into its own slot of the
-// block and reports its count: no scan, no second pass.  Pinned block: [flags 2 | soff = 0 | len | .. | tile_cnt 64 | tile_pal 64 | tile_bad 64]
-// [text] [64 slots of 256 minimizers].
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kMiniTiles = 64, kMiniStride = 256, kMiniHdr = 1024, kMiniText = kMiniTiles * kTile + 64;
-
-int mini_sketch_launch(MiniSketch &M, const char *text, size_t len, int w, int k, hipStream_t st)
-{
-    if (M.pending) { NS_HIP(event_wait(M.ev)); M.pending = false; }          // (a launch nobody collected may still be reading the block)
-    if (len == 0 || len > (size_t)kMiniTiles * kTile || k <= 0 || k > 28 || w <= 0 || w >= 256) return 1;       // not for this path
-    NS_TRY(M.buf.reserve(kMiniHdr + kMiniText + (size_t)kMiniTiles * kMiniStride * 16));
-    if (!M.ev) NS_HIP(hipEventCreateWithFlags(&M.ev, hipEventDisableTiming));
-    uint8_t *base = M.buf.as<uint8_t>();
-    uint32_t *hdr = reinterpret_cast<uint32_t *>(base);
-    memset(hdr, 0, kMiniHdr);
-    hdr[3] = (uint32_t)len;
-    memcpy(base + kMiniHdr, text, len);
-    M.len = (uint32_t)len, M.n_tiles = (uint32_t)((len + kTile - 1) / kTile);
-    const Batch bt{base + kMiniHdr, hdr + 2, hdr + 3, 1u, (uint32_t)len, w, k};
-    hipLaunchKernelGGL((skf_kernel<true>), dim3(M.n_tiles), dim3(256), skf_lds_bytes(w, k), st, bt, (const Tile *)nullptr, M.n_tiles, hdr + 16, hdr + 16 + kMiniTiles,
-                       (const uint32_t *)nullptr, reinterpret_cast<uint64_t *>(base + kMiniHdr + kMiniText), (uint64_t)M.n_tiles * kMiniStride, hdr, hdr + 16 + 2 * kMiniTiles, kMiniStride);
-    NS_HIP(hipGetLastError());
-    NS_HIP(hipEventRecord(M.ev, st));
-    M.pending = true;
-    return NSGPU_OK;
-}
-
-const uint8_t *mini_sketch_text(const MiniSketch &M) { return M.buf.as<uint8_t>() + kMiniHdr; }
-
-// waits for the launch (its event), then the minimizers in mm_sketch's order; ok = false: the kernel declined (a byte that is not ACGT, too many
-// symmetric k-mers, a tile with more minimizers than its slot) -- the caller sketches the string the general way
-int mini_sketch_collect(MiniSketch &M, int w, int k, std::vector<mm2::Anchor> &out, bool &ok)
-{
-    ok = false;
-    out.clear();
-    if (!M.pending) return NSGPU_OK;
-    M.pending = false;
-    NS_HIP(event_wait(M.ev));
-    const uint8_t *base = M.buf.as<uint8_t>();
-    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(base);
-    const uint32_t *cnt = hdr + 16, *pal = hdr + 16 + kMiniTiles, *bad = hdr + 16 + 2 * kMiniTiles;
-    if (hdr[0] || hdr[1]) return NSGPU_OK;
-    uint64_t psum = 0, total = 0;
-    for (uint32_t t = 0; t < M.n_tiles; ++t) {
-        if (bad[t] || cnt[t] > kMiniStride) return NSGPU_OK;
-        if (t > 0 && (uint64_t)t * kTile < psum + (uint64_t)(w + k)) return NSGPU_OK;        // `run` beyond the first tile was taken as >= w + k
-        psum += pal[t], total += cnt[t];
-    }
-    out.reserve(total);
-    const mm2::Anchor *ent = reinterpret_cast<const mm2::Anchor *>(base + kMiniHdr + kMiniText);
-    for (uint32_t t = 0; t < M.n_tiles; ++t) out.insert(out.end(), ent + (size_t)t * kMiniStride, ent + (size_t)t * kMiniStride + cnt[t]);
-    ok = true;
-    return NSGPU_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Every read's minimizers, both strands, once per contig stage (ReadMz, common.hpp).  The reference sketches a candidate read inside every
-// alignRead (mm_map -> mm_sketch of the query, minimap2/map.c:232); a read is a candidate a dozen times, and what a slot waits for is the
-// sketch call's round trip, not its volume.  Here the text of both strands is made from the 2-bit rows in HBM, every 1024-position tile of it
-// sketched by skf_kernel (count pass, scan, write pass: the batched form), and the lists stay in HBM where the seeding kernel reads them;
-// the text stays for the plan kernel.  A read whose tiles the fused kernel declines (symmetric k-mers beyond its halo: (AT)n runs) is marked
-// and goes with the slot's own sketch batch, as before.
-// ---------------------------------------------------------------------------------------------------------------------
-namespace {
-__global__ __launch_bounds__(256) void unpack_strands_kernel(const uint8_t *__restrict__ packed, const uint64_t *__restrict__ poff, const uint32_t *__restrict__ len, uint32_t n,
-                                                             const uint64_t *__restrict__ aoff, uint8_t *__restrict__ fwd, uint8_t *__restrict__ rev)
-{
-    for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) {
-        const uint8_t *row = packed + poff[r];
-        const uint32_t L = len[r];
-        uint8_t *f = fwd + aoff[r], *v = rev + aoff[r];
-        for (uint32_t p = threadIdx.x; p < L; p += 256) {
-            const uint32_t code = (row[p >> 2] >> (6 - 2 * (p & 3))) & 3u;         // A0 T1 C2 G3 (src/dnaToBits.cpp), complement = code ^ 1
-            f[p] = (uint8_t)"ATCG"[code];
-            v[L - 1 - p] = (uint8_t)"ATCG"[code ^ 1u];
-        }
-    }
-}
-}  // namespace
-
-int reads_mz_build(nsgpu_ctx *c, int w, int k)
-{
-    ReadMz &R = c->rmz;
-    R.valid = false;
-    const uint32_t N = c->reads.n;
-    if (N == 0 || k <= 0 || k > 28 || w <= 0 || w >= 256) return NSGPU_OK;
-    const hipStream_t st = c->stream;
-    const double t0 = now_ms();
-    R.h_aoff.resize((size_t)N + 1);
-    uint64_t ab = 0;
-    for (uint32_t r = 0; r < N; ++r) { R.h_aoff[r] = ab; ab += ((uint64_t)c->reads.h_len[r] + 16) & ~(uint64_t)15; }
-    R.h_aoff[N] = ab;
-    for (int sd = 0; sd < 2; ++sd) NS_TRY(R.ascii[sd].reserve(ab + 64));
-    NS_TRY(R.aoff.reserve(((size_t)N + 1) * 8));
-    NS_HIP(hipMemcpyAsync(R.aoff.p, R.h_aoff.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(unpack_strands_kernel, dim3(N < 65536u ? N : 65536u), dim3(256), 0, st, c->reads.packed.as<uint8_t>(), c->reads.poff.as<uint64_t>(), c->reads.len.as<uint32_t>(), N,
-                       R.aoff.as<uint64_t>(), R.ascii[0].as<uint8_t>(), R.ascii[1].as<uint8_t>());
-    NS_HIP(hipGetLastError());
-    const uint64_t cap = 2 * ab / 16 + 64ull * N + 1024;               // ~1.6 x the expected 2 / (w + 1) per base at w = 50; what does not fit goes with the slots' batches
-    NS_TRY(R.mz.reserve(cap * 16 + 64));
-    for (int sd = 0; sd < 2; ++sd) { R.off[sd].assign(N, 0); R.cnt[sd].assign(N, 0); R.ok[sd].assign(N, 0); }
-    uint64_t used = 0;
-    std::vector<uint32_t> soff, len, first_tile, h_toff, h_pal, h_bad;
-    std::vector<Tile> tiles;
-    const size_t lds = skf_lds_bytes(w, k);
-    NS_TRY(R.flags.reserve(64));
-    for (uint32_t r0 = 0; r0 < N;) {
-        // a piece: reads [r0, r1) whose text stays below 2^30 bytes (32-bit positions inside a launch)
-        uint32_t r1 = r0;
-        while (r1 < N && R.h_aoff[r1 + 1] - R.h_aoff[r0] < (1ull << 30)) ++r1;
-        if (r1 == r0) { r0 = r1 + 1; continue; }                       // (a single read beyond 2^30 bases: left to the slots' batches)
-        const uint32_t n = r1 - r0;
-        soff.resize((size_t)n + 1), len.resize(n), first_tile.resize((size_t)n + 1);
-        tiles.clear();
-        for (uint32_t i = 0; i < n; ++i) {
-            soff[i] = (uint32_t)(R.h_aoff[r0 + i] - R.h_aoff[r0]), len[i] = c->reads.h_len[r0 + i], first_tile[i] = (uint32_t)tiles.size();
-            for (uint32_t p = 0; p < len[i]; p += kTile) tiles.push_back(Tile{i, p});
-        }
-        soff[n] = (uint32_t)(R.h_aoff[r1] - R.h_aoff[r0]), first_tile[n] = (uint32_t)tiles.size();
-        const size_t nt = tiles.size();
-        if (nt == 0) { r0 = r1; continue; }
-        NS_TRY(R.soff.reserve(((size_t)n + 1) * 4)); NS_TRY(R.len.reserve((size_t)n * 4 + 4)); NS_TRY(R.tiles.reserve(nt * sizeof(Tile)));
-        NS_TRY(R.tcnt.reserve((nt + 2) * 4)); NS_TRY(R.tpal.reserve((nt + 2) * 4)); NS_TRY(R.tbad.reserve((nt + 2) * 4)); NS_TRY(R.toff.reserve((nt + 2) * 4));
-        NS_HIP(hipMemcpyAsync(R.soff.p, soff.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, st));
-        NS_HIP(hipMemcpyAsync(R.len.p, len.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-        NS_HIP(hipMemcpyAsync(R.tiles.p, tiles.data(), nt * sizeof(Tile), hipMemcpyHostToDevice, st));
-        NS_HIP(hipStreamSynchronize(st));                                  // (the host vectors are reused for the other strand / the next piece)
-        for (int sd = 0; sd < 2; ++sd) {
-            const Batch bt{R.ascii[sd].as<uint8_t>() + R.h_aoff[r0], R.soff.as<uint32_t>(), R.len.as<uint32_t>(), n, soff[n], w, k};
-            NS_HIP(hipMemsetAsync(R.tbad.p, 0, (nt + 1) * 4, st));
-            NS_HIP(hipMemsetAsync(R.flags.p, 0, 16, st));
-            hipLaunchKernelGGL((skf_kernel<false>), dim3((uint32_t)nt), dim3(256), lds, st, bt, R.tiles.as<Tile>(), (uint32_t)nt, R.tcnt.as<uint32_t>(), R.tpal.as<uint32_t>(),
-                               (const uint32_t *)nullptr, (uint64_t *)nullptr, (uint64_t)0, R.flags.as<uint32_t>(), R.tbad.as<uint32_t>(), 0u);
-            NS_HIP(hipGetLastError());
-            NS_HIP(hipMemsetAsync(R.tcnt.as<uint32_t>() + nt, 0, 4, st));
-            {
-                size_t ws = 0;
-                NS_HIP(rocprim::exclusive_scan(nullptr, ws, R.tcnt.as<uint32_t>(), R.toff.as<uint32_t>(), 0u, nt + 1, rocprim::plus<uint32_t>(), st));
-                NS_TRY(R.scan_ws.reserve(ws + 16));
-                NS_HIP(rocprim::exclusive_scan(R.scan_ws.p, ws, R.tcnt.as<uint32_t>(), R.toff.as<uint32_t>(), 0u, nt + 1, rocprim::plus<uint32_t>(), st));
-            }
-            h_toff.resize(nt + 1), h_pal.resize(nt), h_bad.resize(nt);
-            NS_HIP(hipMemcpyAsync(h_toff.data(), R.toff.p, (nt + 1) * 4, hipMemcpyDeviceToHost, st));
-            NS_HIP(hipStreamSynchronize(st));
-            const uint64_t total = h_toff[nt];
-            if (used + total > cap) continue;                                // (no room: these reads go with the slots' batches)
-            hipLaunchKernelGGL((skf_kernel<true>), dim3((uint32_t)nt), dim3(256), lds, st, bt, R.tiles.as<Tile>(), (uint32_t)nt, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                               R.toff.as<uint32_t>(), reinterpret_cast<uint64_t *>(R.mz.as<mm2::Anchor>() + used), total, R.flags.as<uint32_t>(), R.tbad.as<uint32_t>(), 0u);
-            NS_HIP(hipGetLastError());
-            NS_HIP(hipMemcpyAsync(h_pal.data(), R.tpal.p, nt * 4, hipMemcpyDeviceToHost, st));
-            NS_HIP(hipMemcpyAsync(h_bad.data(), R.tbad.p, nt * 4, hipMemcpyDeviceToHost, st));
-            NS_HIP(hipStreamSynchronize(st));
-            for (uint32_t i = 0; i < n; ++i) {
-                bool good = true;
-                uint64_t pal = 0;
-                for (uint32_t t = first_tile[i]; t < first_tile[i + 1] && good; ++t) {
-                    if (h_bad[t]) good = false;
-                    if (t > first_tile[i] && (uint64_t)tiles[t].t0 < pal + (uint64_t)(w + k)) good = false;
-                    pal += h_pal[t];
-                }
-                R.off[sd][r0 + i] = used + h_toff[first_tile[i]];
-                R.cnt[sd][r0 + i] = h_toff[first_tile[i + 1]] - h_toff[first_tile[i]];
-                R.ok[sd][r0 + i] = good && first_tile[i + 1] > first_tile[i];
-            }
-            used += total;
-        }
-        r0 = r1;
-    }
-    R.w = w, R.k = k, R.n_mz = used, R.valid = true;
-    R.build_ms = now_ms() - t0;
-    return NSGPU_OK;
-}
-
 // The fused path (skf_kernel).  Returns 1 when the batch has to be redone by the general passes (a byte other than ACGT, a k-mer equal
 // to its reverse complement, or more minimizers than the staging buffer was sized for), 0 when done, < 0 on errors.
 static int gpu_mm_sketch_fused(nsgpu_ctx *c, const std::vector<SketchReq> &reqs, int w, int k, const mm2::Anchor *&out, std::vector<uint64_t> &out_off, int ws, size_t n_stage_only)
@@ -719,25 +542,20 @@ static int gpu_mm_sketch_fused(nsgpu_ctx *c, const std::vector<SketchReq> &reqs,
     const Batch bt{W.seqs.as<uint8_t>(), reinterpret_cast<const uint32_t *>(W.seqs.as<uint8_t>() + o_soff), reinterpret_cast<const uint32_t *>(W.seqs.as<uint8_t>() + o_len),
                    (uint32_t)n, (uint32_t)bytes, w, k};
     const Tile *d_tiles = reinterpret_cast<const Tile *>(W.seqs.as<uint8_t>() + o_tiles);
-    // outputs land in pinned host memory, written by the kernels themselves (the GPU's stores travel over PCIe; no copy operation, no
-    // size known to the host in advance): [flags 2 | tile offsets n_tiles + 1 | minimizers]
-    const uint64_t cap = bytes / 12 + 64 * (uint64_t)n + 1024;                   // ~2x the expected 2 / (w + 1) per base
+    // ONE launch: every tile writes its minimizers into its own slot of `stride` entries in pinned host memory (the GPU's stores travel over
+    // PCIe; no copy operation, no size known to the host in advance) and reports its count; the host lays the slots out back to back below.
+    // (Until round 5: a count pass, a scan over the tile counts and a write pass -- four dependent GPU operations more, 0.1 ms per call.)
+    const uint32_t stride = (uint32_t)std::min<uint64_t>(1100, std::max<uint64_t>(64, 6ull * kTile / (uint64_t)(w + 1) + 32));
     NS_TRY(W.h_meta.reserve((2 * n_tiles + 8) * 4 + 64));
-    NS_TRY(pinned_reserve(W.h_out, W.h_out_cap, cap * 16 + 16));
-    uint32_t *h_flags = W.h_meta.as<uint32_t>(), *h_toff = h_flags + 2, *h_tpal = h_toff + n_tiles + 2;
+    NS_TRY(pinned_reserve(W.h_out, W.h_out_cap, (size_t)n_tiles * stride * 16 + 16));
+    uint32_t *h_flags = W.h_meta.as<uint32_t>(), *h_tcnt = h_flags + 2, *h_tpal = h_tcnt + n_tiles + 2;
     h_flags[0] = h_flags[1] = 0;
-    NS_TRY(W.nout.reserve((n_tiles + 2) * 4));
     const size_t lds = skf_lds_bytes(w, k);
     if (n_tiles) {
-        hipLaunchKernelGGL((skf_kernel<false>), dim3((uint32_t)n_tiles), dim3(256), lds, st, bt, d_tiles, (uint32_t)n_tiles, W.nout.as<uint32_t>(), h_tpal, (const uint32_t *)nullptr,
-                           (uint64_t *)nullptr, (uint64_t)0, h_flags, (uint32_t *)nullptr, 0u);
+        hipLaunchKernelGGL((skf_kernel<true>), dim3((uint32_t)n_tiles), dim3(256), lds, st, bt, d_tiles, (uint32_t)n_tiles, h_tcnt, h_tpal, (const uint32_t *)nullptr,
+                           reinterpret_cast<uint64_t *>(W.h_out), (uint64_t)n_tiles * stride, h_flags, (uint32_t *)nullptr, stride);
         NS_HIP(hipGetLastError());
-        NS_HIP(hipMemsetAsync(W.nout.as<uint32_t>() + n_tiles, 0, 4, st));
-        NS_TRY(scan_u32(W, st, W.nout.as<uint32_t>(), h_toff, n_tiles + 1, false, 0));
-        hipLaunchKernelGGL((skf_kernel<true>), dim3((uint32_t)n_tiles), dim3(256), lds, st, bt, d_tiles, (uint32_t)n_tiles, (uint32_t *)nullptr, (uint32_t *)nullptr, h_toff,
-                           reinterpret_cast<uint64_t *>(W.h_out), cap, h_flags, (uint32_t *)nullptr, 0u);
-        NS_HIP(hipGetLastError());
-    } else h_toff[0] = 0;
+    }
     NS_HIP(stream_wait_short(st));
     // `run` beyond a sequence's first tile was taken as >= w + k: true unless symmetric k-mers ate the difference
     bool run_ok = true;
@@ -748,14 +566,30 @@ static int gpu_mm_sketch_fused(nsgpu_ctx *c, const std::vector<SketchReq> &reqs,
             pal += h_tpal[t];
         }
     }
-    if (h_flags[0] || h_flags[1] || h_toff[n_tiles] > cap || !run_ok) {
+    if (h_flags[0] || h_flags[1] || !run_ok) {
         static const bool dbg = getenv("NSGPU_SKETCH_DEBUG") != nullptr;
-        if (dbg) fprintf(stderr, "[sketch] fused path gives up: bad input %u, overflow %u, minimizers %u of %llu slots, %zu sequences, %llu tiles\n", h_flags[0], h_flags[1],
-                         h_toff[n_tiles], (unsigned long long)cap, n, (unsigned long long)n_tiles);
+        if (dbg) fprintf(stderr, "[sketch] fused path gives up: bad input %u, a tile with more minimizers than its slot %u, %zu sequences, %llu tiles\n", h_flags[0], h_flags[1],
+                         n, (unsigned long long)n_tiles);
         return 1;
     }
+    // the slots back to back, in pinned memory as well (the seeding kernel reads the lists where they are left)
+    std::vector<uint64_t> &toff = W.h_toff;
+    toff.resize(n_tiles + 1);
+    uint64_t total = 0;
+    for (uint64_t t = 0; t < n_tiles; ++t) { toff[t] = total; total += h_tcnt[t]; }
+    toff[n_tiles] = total;
+    NS_TRY(W.h_compact.reserve((total + 1) * 16));
+    {
+        const mm2::Anchor *slots = reinterpret_cast<const mm2::Anchor *>(W.h_out);
+        mm2::Anchor *dst = W.h_compact.as<mm2::Anchor>();
+        if (n_tiles >= 512) par_for("sketch.stage", (size_t)((n_tiles + 255) / 256), [&](size_t c0) {
+            for (uint64_t t = c0 * 256; t < n_tiles && t < (c0 + 1) * 256; ++t) memcpy(dst + toff[t], slots + t * stride, (size_t)h_tcnt[t] * 16);
+        });
+        else for (uint64_t t = 0; t < n_tiles; ++t) memcpy(dst + toff[t], slots + t * stride, (size_t)h_tcnt[t] * 16);
+    }
+    const std::vector<uint64_t> &h_toff = toff;
     for (size_t i = 0; i <= n; ++i) out_off[i] = h_toff[first_tile[i]];
-    out = reinterpret_cast<const mm2::Anchor *>(W.h_out);
+    out = W.h_compact.as<mm2::Anchor>();
     W.staged_soff = soff, W.staged_n = n;              // (pinned: valid until the workspace's next call, like the device copy of the sequences)
     std::lock_guard<std::mutex> lk(c->stat_m);
     c->sketch_mm_ms += now_ms() - t0;

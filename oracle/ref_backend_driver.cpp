@@ -15,6 +15,13 @@
 #include "lzma2_helper.h"
 #include "bwt/bwt.h"
 #include "libbsc.h"
+#ifdef NSGPU_BWT
+// backendref_gpu: the same front ends, libbsc's block sorter served by libnsgpu.so (oracle/bwt_gpu_binding.cpp)
+#include "nsgpu.h"
+extern nsgpu_ctx *g_nsgpu;
+extern double g_bwt_gpu_ms;
+extern unsigned long long g_bwt_blocks, g_bwt_bytes;
+#endif
 
 static int dump_bwt(const char *in, const char *out)
 {
@@ -46,6 +53,14 @@ static int dump_bwt(const char *in, const char *out)
 int main(int argc, char **argv)
 {
     if (argc != 4) { fprintf(stderr, "usage: backendref bsc|lzma2|unbsc|unlzma2|bwt in out\n"); return 2; }
+#ifdef NSGPU_BWT
+    {
+        nsgpu_params p;
+        nsgpu_default_params(&p);
+        if (nsgpu_create(&p, &g_nsgpu) != NSGPU_OK) { fprintf(stderr, "backendref_gpu: %s\n", nsgpu_last_error()); return 4; }
+    }
+    struct Report { ~Report() { if (g_bwt_blocks) fprintf(stderr, "[backendref_gpu] %llu blocks, %llu bytes through nsgpu_bwt_block, %.1f ms on the device\n", g_bwt_blocks, g_bwt_bytes, g_bwt_gpu_ms); nsgpu_destroy(g_nsgpu); } } report;
+#endif
     if (!strcmp(argv[1], "bwt")) return dump_bwt(argv[2], argv[3]);
     if (!strcmp(argv[1], "bsc")) bsc::BSC_compress(argv[2], argv[3]);
     else if (!strcmp(argv[1], "lzma2")) lzma2::lzma2_compress(argv[2], argv[3]);

@@ -230,10 +230,10 @@ print("RESULT", bad, len(probs))
 '''
 
 
-@pytest.mark.parametrize("env", [{"NSGPU_KSW_NO_EARLY_EXIT": "1"}, {"NSGPU_KSW_SERIAL_BACKTRACK": "1"}, {"NSGPU_KSW_ALL_BOOKS": "1"}, {"NSGPU_KSW_PROMOTE_ROWS": "0"}, {"NSGPU_KSW_SYS": "2"}, {"NSGPU_KSW_SYS": "2", "NSGPU_KSW_PROMOTE_ROWS": "0"}])
+@pytest.mark.parametrize("env", [{"NSGPU_KSW_NO_EARLY_EXIT": "1"}, {"NSGPU_KSW_SERIAL_BACKTRACK": "1"}, {"NSGPU_KSW_ALL_BOOKS": "1"}, {"NSGPU_KSW_PROMOTE_ROWS": "0"}])
 def test_latency_classes_and_early_exit_switches(env):
     """The A/B switches of the register DP kernels that are still in the code -- the exact early exit, the one-lane traceback walk, books in
-    every wave, the promotion rule of long narrow problems, the systolic kernel -- each against the oracle on problems with many
+    every wave, the promotion rule of long narrow problems -- each against the oracle on problems with many
     anti-diagonals: bit-exact either way."""
     import subprocess
     import sys

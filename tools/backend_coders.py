@@ -20,6 +20,7 @@ from nanospring_amd.filter import STREAMS
 import bench
 
 BIN = os.path.join(ROOT, "oracle", "_ref", "backendref")
+BIN_GPU = os.path.join(ROOT, "oracle", "_ref", "backendref_gpu")      # the same front end and coders, libbsc's block sorter served by nsgpu_bwt_block (oracle/bwt_gpu_binding.cpp)
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 n_out = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 builders = [int(x) for x in sys.argv[3:]] or [1024, 256, 64]
@@ -64,11 +65,36 @@ for nb in builders:
         with ThreadPoolExecutor(max_workers=cores) as ex:
             list(ex.map(lambda j: code(j[1], j[2]), jobs))
         wall_pool = time.perf_counter() - t0
+        # (c) the BSC files once more, one after the other, with the reference's sorter and with the GPU's (round 5: the .bsc files are
+        # byte-identical, tests/test_bwt_gpu.py): CPU seconds of the whole coder with either, and the device's share
+        gpu_sorter = None
+        if os.path.exists(BIN_GPU):
+            import re
+            bsc_files = [f for ext, fs in files.items() if ext != "base" for f in fs]
+            t0 = time.perf_counter()
+            for f in bsc_files:
+                subprocess.run([BIN, "bsc", f, f + "Compressed"], check=True, capture_output=True)
+            cpu_ref = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            dev_ms, n_blocks, startup = 0.0, 0, 0.0
+            for f in bsc_files:
+                r = subprocess.run([BIN_GPU, "bsc", f, f + "CompressedGpu"], check=True, capture_output=True, text=True)
+                m = re.search(r"(\d+) blocks, (\d+) bytes through nsgpu_bwt_block, ([0-9.]+) ms", r.stderr)
+                if m:
+                    n_blocks += int(m.group(1)); dev_ms += float(m.group(3))
+                assert open(f + "Compressed", "rb").read() == open(f + "CompressedGpu", "rb").read()
+            wall_gpu = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            subprocess.run([BIN_GPU, "bsc", "/dev/null", td + "/null.bsc"], capture_output=True)
+            startup = time.perf_counter() - t0
+            gpu_sorter = {"bsc_files": len(bsc_files), "serial_s_reference_sorter": round(cpu_ref, 2), "serial_s_gpu_sorter": round(wall_gpu, 2),
+                          "of_it_process_start_and_context_s": round(startup * len(bsc_files), 2), "blocks": n_blocks, "device_ms_in_the_sorter": round(dev_ms, 1),
+                          "files_identical": True}
     res["runs"].append({"builders": nb, "contig_stage_s": round(t_stage, 2), "contigs": st["n_contigs"], "lone_reads": st["n_lone"],
                         "raw_bytes": raw, "coded_bytes": comp, "raw_bytes_per_base": round(sum(raw.values()) / n_bases, 4),
                         "coded_bytes_per_base": round(sum(comp.values()) / n_bases, 4), "coder_cpu_s": {k: round(v, 2) for k, v in cpu.items()},
                         "coder_cpu_s_total": round(sum(cpu.values()), 2), "coder_rate_MB_per_core_s": round(sum(raw.values()) / 1e6 / sum(cpu.values()), 2),
-                        "wall_reference_schedule_s": round(wall_ref, 2), "wall_one_pool_s": round(wall_pool, 2)})
+                        "wall_reference_schedule_s": round(wall_ref, 2), "wall_one_pool_s": round(wall_pool, 2), "gpu_block_sorter": gpu_sorter})
     print(json.dumps(res["runs"][-1]), flush=True)
 g.close()
 print(json.dumps(res))
