@@ -275,6 +275,16 @@ int nsgpu_set_schedule(nsgpu_ctx *ctx, uint32_t groups, uint32_t seed_bucket_dep
  * quarter of all builders per round) the smaller radius never applies: the option acts with groups = 1.  nsgpu_set_schedule =
  * seed_tail_rings equal to seed_rings. */
 int nsgpu_set_schedule2(nsgpu_ctx *ctx, uint32_t groups, uint32_t seed_bucket_depth, uint32_t seed_rings, uint32_t seed_tail_rings);
+/* The schedule derived from the input -- what a drop-in caller wants: the reference has ONE knob, -t (src/main.cpp:46-78), and no way to know
+ * what this library's five should be.  After nsgpu_build_index the library knows the read count, the bases and -- from the whole-read filter
+ * results per read -- the coverage, hence the genome size; from those it derives one group, the seed rule's bucket depth and radii (deep
+ * coverage of a small genome: small buckets; shallow coverage of a large one: depth 3, 5 rings) and, when nsgpu_consensus_run /
+ * nsgpu_dist_consensus_run is called with 0 builders, the builder count (1 per 10 Mbases, within what the seed rule can keep busy): streams
+ * within 5 % of the reference's own -t 8 on the inputs it was measured on.  nsgpu_consensus_run(ctx, 0, ...) on a context
+ * whose schedule was never set does the same without this call.  nsgpu_get_schedule2 reports what a run used (all out-pointers optional).
+ * Deterministic for fixed (reads, salts); independent of the rank count. */
+int nsgpu_set_schedule_auto(nsgpu_ctx *ctx);
+int nsgpu_get_schedule2(const nsgpu_ctx *ctx, uint32_t *groups, uint32_t *seed_bucket_depth, uint32_t *seed_rings, uint32_t *seed_tail_rings, uint32_t *builders);
 int nsgpu_get_schedule(const nsgpu_ctx *ctx, uint32_t *groups, uint32_t *seed_bucket_depth, uint32_t *seed_rings);
 int nsgpu_consensus_run(nsgpu_ctx *ctx, uint32_t n_builders, uint32_t n_threads_out, nsgpu_consensus_stats *stats_out);
 /* stream `which` of output thread `thread`: 0 .genome 1 .lone 2 .id 3 .pos 4 .type 5 .base 6 .complement, 7 = metaData

@@ -371,10 +371,17 @@ namespace {
 
 // the aligner never reads the score of a gap fill (mm_align1 adds it into dp_score, which nothing on NanoSpring's path looks at): the DP kernels
 // may skip the books that only produce it (KSW_EZ_NS_NO_SCORE, ksw2_reg.hip).  NSGPU_KSW_KEEP_SCORE=1: computed as before (A/B switch).
+// ... nor the best score on the target's last column of an extension (mm_align1 reads max / max_t / max_q, mqe_t, reach_end and the CIGAR): the
+// register kernels may end the sweep of an extension whose target is longer than its query once nothing but ez.mte can still change
+// (KSW_EZ_NS_NO_MTE, ksw2_reg.hip).  NSGPU_KSW_KEEP_SCORE=1 keeps both (A/B switch, tests).
 int approx_task_flag(int flag)
 {
     static const bool keep = getenv("NSGPU_KSW_KEEP_SCORE") != nullptr;
-    return !keep && (flag & 0x08) && !(flag & 0x10) ? 0x80000 : 0;
+    if (keep) return 0;
+    if ((flag & 0x08) && !(flag & 0x10)) return 0x80000;
+    static const bool keep_mte = getenv("NSGPU_KSW_KEEP_MTE") != nullptr;
+    if ((flag & 0x40) && !(flag & 0x08) && !keep_mte) return 0x100000;
+    return 0;
 }
 
 mm2::Opt batch_opt(const nsgpu_ctx *c)
@@ -459,7 +466,7 @@ int batch_plan_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int see
     cfg.k = opt.k, cfg.min_cnt = opt.min_cnt, cfg.min_sc = opt.min_chain_score, cfg.bw = opt.bw, cfg.max_gap = opt.max_gap, cfg.min_ksw_len = opt.min_ksw_len;
     cfg.zdrop = opt.zdrop, cfg.end_bonus = opt.end_bonus, cfg.a = opt.a, cfg.q = opt.q, cfg.e = opt.e, cfg.q_max = max_q;
     cfg.kp = kp, cfg.kc = ksw_class_config();
-    cfg.approx_flag_or = approx_task_flag(0x08);
+    cfg.approx_flag_or = approx_task_flag(0x08), cfg.ext_flag_or = approx_task_flag(0x40);
     const bool two_part = B.plan_two_part && cfg.kc.long_rows > 0;
     cfg.two_phase = two_part;
     if (B.plan_wait_ev) NS_HIP(hipStreamWaitEvent(D.stream, B.plan_wait_ev, 0));

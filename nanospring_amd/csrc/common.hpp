@@ -255,6 +255,7 @@ struct nsgpu_ctx {
     uint32_t read_id_base = 0;   // global id of local read 0 (multi-GPU shards)
     // schedule of the contig stage (nsgpu_set_schedule): pipeline groups (1, 2 or 4) and the conflict-aware seed rule (0 = off)
     uint32_t sched_groups = 4, seed_bucket_depth = 0, seed_rings = 1, seed_tail_rings = 1;
+    bool sched_auto = false, sched_set = false;      // nsgpu_set_schedule_auto / an explicit nsgpu_set_schedule: 0 builders with neither = the automatic schedule
     void *cons_engine = nullptr;                 // resumable contig engine (consensus_driver.hip)
     void (*cons_engine_free)(void *) = nullptr;
     uint64_t cons_n_reads_out = 0;               // reads covered by this context's output streams

@@ -405,6 +405,7 @@ struct Engine {
         std::vector<uint32_t> occ;                       // per bucket: members of contigs in flight
         std::vector<std::vector<uint32_t>> members;      // per GLOBAL builder: seed + claimed reads of its contig in flight
         uint64_t n_unclaimed = 0, n_idle = 0;
+        uint64_t n_filter_results = 0; bool have_wr = false;      // whole_read_filter has run for this stage (wr_off / wr_ids hold its answers)
         std::vector<uint8_t> blocked;                    // scratch of a seed round: bucket within `rings` steps of an occupied one
         std::vector<uint32_t> q_cur, q_nxt, stamp;
         uint32_t epoch = 0;
@@ -435,11 +436,38 @@ static void engine_free(void *p)
 }
 
 static int seed_policy_init(nsgpu_ctx *c, Engine *E);
+static int whole_read_filter(nsgpu_ctx *c, Engine *E);
+
+// ---- the schedule derived from the input (nsgpu_set_schedule_auto; nsgpu_consensus_run with 0 builders) ---------------------------------
+// The reference has one knob, -t (src/main.cpp:46-78), and its streams grow with it: contigs that grow at the same time cut each other short.
+// This library's knobs -- builders, groups, the seed rule's bucket depth and radii -- trade the same thing, and the right values differ per
+// input (cfg2's on cfg3: 19 Mbases/s instead of 80).  What the library knows after nsgpu_build_index decides them:
+//   * coverage, from the whole-read filter results per read r (both strands, the read itself included; r = 12 at 20x, 120 at 217x): a deep
+//     read set over a small genome has few places for contigs to grow apart, so the buckets must be small (depth 1) for the exclusion radius
+//     not to block the whole genome, while a shallow one over a large genome wants depth 3 / 5 rings;
+//   * the input size: every builder beyond the first costs ~80 kB of streams (one more contig boundary now and then); 1 builder per 10 Mbases
+//     keeps that within 5 % of the streams the reference's own -t 8 writes, but never fewer than the seed rule can keep busy.
+// One group: with this few builders a slot is as long as its GPU round trips.  A function of replicated values only: every rank of a
+// multi-GPU job derives the same schedule.  tests/oracle_lib.py auto_schedule restates the rule for the lock-step oracle.
+struct AutoSchedule { uint32_t builders, depth, rings, tail; };
+static AutoSchedule auto_schedule(uint64_t n_reads, uint64_t n_bases, uint64_t n_filter_results)
+{
+    const double r = n_reads ? (double)n_filter_results / (double)n_reads : 0.0;
+    AutoSchedule a;
+    uint64_t b_min;
+    if (r < 30.0) a.depth = 3, a.rings = 5, a.tail = 3, b_min = 32;
+    else if (r < 70.0) a.depth = 2, a.rings = 4, a.tail = 3, b_min = 96;
+    else a.depth = 1, a.rings = 4, a.tail = 3, b_min = 128;
+    const uint64_t b = std::min<uint64_t>(1024, std::max<uint64_t>(b_min, n_bases / 10000000ull));
+    a.builders = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(b, n_reads ? n_reads : 1));
+    return a;
+}
 
 static int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, uint32_t world)
 {
     NS_CHECK(c->have_index && c->have_salts, NSGPU_ERR_ARG, "consensus: call nsgpu_sketch and nsgpu_build_index first");
-    NS_CHECK(n_builders_total >= 1 && world >= 1 && rank < world, NSGPU_ERR_ARG, "consensus: bad builder / rank arguments");
+    const bool auto_now = c->sched_auto || (n_builders_total == 0 && !c->sched_set);
+    NS_CHECK((n_builders_total >= 1 || auto_now) && world >= 1 && rank < world, NSGPU_ERR_ARG, "consensus: bad builder / rank arguments (0 builders = the library's choice needs the automatic schedule: nsgpu_set_schedule_auto)");
     NS_CHECK(c->h_off.size() == (size_t)c->reads.n + 1, NSGPU_ERR_ARG, "consensus: reads must be loaded first");
     if (c->cons_engine) { c->cons_engine_free(c->cons_engine); c->cons_engine = nullptr; }
     Engine *E = new Engine();
@@ -456,6 +484,16 @@ static int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, 
     D.rep.assign((size_t)D.N + 1, 0);
     E->t0 = now_ms();
     if (D.N) NS_TRY(nsgpu_check_repetitive(c, D.rep.data()));
+    if (!auto_now && !c->sched_set) c->sched_groups = 4, c->seed_bucket_depth = 0, c->seed_rings = 1, c->seed_tail_rings = 1;      // (nothing chosen, builders given: the defaults, whatever an automatic run before derived)
+    if (auto_now) {
+        c->sched_groups = 1;
+        if (D.N) NS_TRY(whole_read_filter(c, E));
+        const AutoSchedule a = auto_schedule(D.N, c->reads.n_bases, E->sp.n_filter_results);
+        c->seed_bucket_depth = a.depth, c->seed_rings = a.rings, c->seed_tail_rings = a.tail;
+        if (n_builders_total == 0) n_builders_total = a.builders;
+        if (getenv("NSGPU_CONS_DEBUG")) fprintf(stderr, "[cons] automatic schedule: %.1f filter results per read -> %u builders, one group, buckets of depth %u, %u rings (%u in the tail)\n",
+                                                D.N ? (double)E->sp.n_filter_results / D.N : 0.0, n_builders_total, a.depth, a.rings, a.tail);
+    }
     if (n_builders_total > D.N && D.N > 0) n_builders_total = D.N;
     if (D.N == 0) n_builders_total = 1;
     {   // one group's alignments of one slot share a DP sequence pool addressed with 32 bits (align_batch.hip): an alignment needs at most a few
@@ -595,13 +633,13 @@ static uint32_t engine_seed_resolve(nsgpu_ctx *c, const uint32_t *gids, const ui
 }
 
 // the buckets of the conflict-aware seed rule (Engine::SeedPolicy), from the whole-read filter results of every read
-static int seed_policy_init(nsgpu_ctx *c, Engine *E)
+// the filter's answer to every whole read, both strands (the edges of the graph the seed buckets are built on; their number per read is what
+// the automatic schedule reads the coverage from): into P.wr_off / P.wr_ids
+static int whole_read_filter(nsgpu_ctx *c, Engine *E)
 {
     Engine::SeedPolicy &P = E->sp;
-    Driver &D = E->D;
-    P.depth = c->seed_bucket_depth, P.rings = c->seed_rings, P.tail_rings = std::min(c->seed_tail_rings, c->seed_rings), P.rings_now = P.rings;
-    if (!P.depth) return NSGPU_OK;
-    const uint32_t N = D.N;
+    const uint32_t N = E->D.N;
+    if (P.have_wr) return NSGPU_OK;
     uint64_t n_cand = 0;
     if (!c->have_sketch) {
         // a rank of a multi-GPU job whose tables came from the all-to-all holds the sketch rows of its own id range only: the whole-read
@@ -613,10 +651,25 @@ static int seed_policy_init(nsgpu_ctx *c, Engine *E)
         c->have_sketch = true;
     }
     NS_TRY(nsgpu_filter_all_reads(c, &n_cand));
-    std::vector<uint64_t> off(2 * (size_t)N + 1);
-    std::vector<uint32_t> ids(n_cand + 1);
-    NS_TRY(nsgpu_filter_all_fetch(c, off.data(), ids.data()));
+    P.wr_off.assign(2 * (size_t)N + 1, 0);
+    P.wr_ids.assign(n_cand + 1, 0);
+    NS_TRY(nsgpu_filter_all_fetch(c, P.wr_off.data(), P.wr_ids.data()));
     c->have_filter_all = false;                                     // the engine's window queries reuse the device buffers
+    P.n_filter_results = n_cand, P.have_wr = true;
+    return NSGPU_OK;
+}
+
+static int seed_policy_init(nsgpu_ctx *c, Engine *E)
+{
+    Engine::SeedPolicy &P = E->sp;
+    Driver &D = E->D;
+    P.depth = c->seed_bucket_depth, P.rings = c->seed_rings, P.tail_rings = std::min(c->seed_tail_rings, c->seed_rings), P.rings_now = P.rings;
+    if (!P.depth) { P.wr_off.clear(), P.wr_ids.clear(); return NSGPU_OK; }
+    const uint32_t N = D.N;
+    NS_TRY(whole_read_filter(c, E));
+    const uint64_t n_cand = P.n_filter_results;
+    const std::vector<uint64_t> &off = P.wr_off;
+    const std::vector<uint32_t> &ids = P.wr_ids;
     P.bucket_of.assign(N, ~0u);
     uint32_t nb = 0;
     std::vector<uint32_t> cur, nxt;
@@ -652,7 +705,7 @@ static int seed_policy_init(nsgpu_ctx *c, Engine *E)
     P.bk_reads.resize(N);
     { std::vector<uint64_t> fill(P.bk_off.begin(), P.bk_off.end() - 1); for (uint32_t r = 0; r < N; ++r) P.bk_reads[fill[P.bucket_of[r]]++] = r; }
     static const bool no_wr = getenv("NSGPU_NO_SEED_WINDOW_TABLE") != nullptr;        // A/B switch: every window query on the GPU, as before
-    if (!no_wr) P.wr_off.swap(off), P.wr_ids.swap(ids);
+    if (no_wr) P.wr_off.clear(), P.wr_ids.clear();
     P.bk_next.assign(nb, 0);
     P.occ.assign(nb, 0);
     P.members.assign(E->n_total, std::vector<uint32_t>());
@@ -2008,6 +2061,26 @@ int nsgpu_set_schedule2(nsgpu_ctx *c, uint32_t groups, uint32_t seed_bucket_dept
     NS_CHECK(!c->cons_engine, NSGPU_ERR_ARG, "nsgpu_set_schedule: a contig stage is in progress");
     NS_CHECK(seed_tail_rings <= seed_rings, NSGPU_ERR_ARG, "nsgpu_set_schedule2: seed_tail_rings must not exceed seed_rings");
     c->sched_groups = groups, c->seed_bucket_depth = seed_bucket_depth, c->seed_rings = seed_rings, c->seed_tail_rings = seed_tail_rings;
+    c->sched_set = true, c->sched_auto = false;
+    return NSGPU_OK;
+}
+
+int nsgpu_set_schedule_auto(nsgpu_ctx *c)
+{
+    NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
+    NS_CHECK(!c->cons_engine, NSGPU_ERR_ARG, "nsgpu_set_schedule_auto: a contig stage is in progress");
+    c->sched_auto = true, c->sched_set = false;
+    return NSGPU_OK;
+}
+
+int nsgpu_get_schedule2(const nsgpu_ctx *c, uint32_t *groups, uint32_t *seed_bucket_depth, uint32_t *seed_rings, uint32_t *seed_tail_rings, uint32_t *builders)
+{
+    NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
+    if (groups) *groups = c->sched_groups;
+    if (seed_bucket_depth) *seed_bucket_depth = c->seed_bucket_depth;
+    if (seed_rings) *seed_rings = c->seed_rings;
+    if (seed_tail_rings) *seed_tail_rings = c->seed_tail_rings;
+    if (builders) *builders = c->cons_stats.n_builders;
     return NSGPU_OK;
 }
 

@@ -90,7 +90,7 @@ struct PlanDp {            // where the plan kernel puts its DP tasks (buffers o
     unsigned long long p_cap; uint32_t cig_cap, seq_cap;
 };
 struct PlanCfg {           // minimap2's options the plan depends on (mm2::Opt) + the DP kernels' parameters and class rule
-    int32_t k, min_cnt, min_sc, bw, max_gap, min_ksw_len, zdrop, end_bonus, a, q, e, q_max, two_phase, approx_flag_or;
+    int32_t k, min_cnt, min_sc, bw, max_gap, min_ksw_len, zdrop, end_bonus, a, q, e, q_max, two_phase, approx_flag_or, ext_flag_or;
     KswParams kp; KswClassCfg kc;
 };
 int plan_launch(hipStream_t st, uint32_t n_pairs, uint32_t lds_anchors, const SeedResult *seeded, const mm2::Anchor *anchors, const int32_t *f, const int32_t *p,

@@ -48,6 +48,11 @@ namespace nsgpu {
 // (align_batch.hip / plan.hip): mm_align1 only ever adds a gap fill's score into dp_score, which NanoSpring never looks at (src/ConsensusGraph.cpp:
 // 219-397 reads rs, re, qs, qe, blen, mlen, n_ambi and the CIGAR); the public nsgpu_ksw_extd2_batch passes callers' flags through untouched.
 #define KSW_EZ_NS_NO_SCORE 0x80000
+// not minimap2's either: the caller does not read ez.mte / ez.mte_q / ez.score of this exact-mode extension (KSW_EZ_EXTZ_ONLY).  mm_align1 reads
+// max / max_t / max_q, mqe_t, reach_end, zdropped and the CIGAR of an extension (align.c:700-780), never the best score on the target's last
+// column -- and that column is all the sweep still works for once the query has ended on every diagonal that can matter: see the second early
+// exit in ksw_reg_run.  The aligner's extensions carry the flag (align_batch.hip / plan.hip); nsgpu_ksw_extd2_batch passes callers' flags through.
+#define KSW_EZ_NS_NO_MTE 0x100000
 
 typedef short s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u2 __attribute__((ext_vector_type(2)));
@@ -468,6 +473,21 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
     // covers the cells along the band's lower edge, whose inputs from outside the band are a row or two old (they sit w off the
     // diagonal, hundreds of points below the bound's cell).  NSGPU_KSW_NO_EARLY_EXIT=1 in the host code switches it off (A/B, tests).
     const bool early_ok = !APPROX && (flag & KSW_EZ_NS_EARLY_EXIT) && 2 * c2 + w + 1 <= c1;
+    // ---- the mirror image: an extension whose TARGET window is longer than the query (minimap2 hands the DP about twice the query's length
+    // of target, align.c:617-677: every read that ends inside its contig).  Past row 2 (qlen - 1) every cell (t, q) of a row r has
+    // t - q >= d = r - 2 (qlen - 1): the query has ended on the main diagonal and the sweep goes on, cell by cell, along diagonals ever further
+    // to the right, until the target's last column -- qlen + tlen - 1 rows in all, the last third of them for nothing but ez.mte.  Such a cell
+    // holds at most  U(d) = sc_mch qlen - g(d),  g(l) = min(q + e l, q2 + e2 l): qlen matches and the deletions of the length difference in one
+    // run (gap costs are sub-additive), falling with every row.  Once U(d0) + 32 <= min(max, mqe) for the NEXT row's d0 (margin as above, for
+    // the cells along the band's edge) no later row can raise max or mqe (both need a strictly greater score).  What is left is the Z-drop
+    // test: a later row r + j has the cell (r + j - c1, c1) on the query's last row, which holds at least  H(r - c1, c1) - g(j)  (one more
+    // deletion run), so max - max_H' <= max - H[st0] + q2 + e2 j, while its threshold is zdrop + e2 l with l >= (d0 - 1 + j) - (max_t - max_q)
+    // for whichever cell is the row's maximum: no row drops when  max - H[st0] + q2 + 32 <= zdrop + e2 (d0 - 1 - (max_t - max_q)).  Then the
+    // reference's final state is the present one -- zdropped = 0, or 1 when the band runs out before the target does (c2 > (c1 + c2 + w) / 2:
+    // its loop ends with `st > en`, a later Z-drop would say the same) -- except for mte / mte_q / score, which the caller has declared unread
+    // (KSW_EZ_NS_NO_MTE).  Validated against the oracle on target-longer problems of every kind (tests/test_ksw2_gpu.py).
+    const bool tl_exit = !APPROX && (flag & KSW_EZ_NS_NO_MTE) && (flag & KSW_EZ_EXTZ_ONLY) && (flag & KSW_EZ_NS_EARLY_EXIT) && c2 > c1;
+    const bool band_out = c2 > ((c1 + c2 + w) >> 1);
     auto exact_row = [&](int r, int st0, int en0, int en, int max_H, int max_t, int h_en0, int h_st0) {
         if (en0 == c2) { const bool up = h_en0 > z.mte; z.mte_q = up ? r - en : z.mte_q, z.mte = up ? h_en0 : z.mte; }
         if (r - st0 == c1) { const bool up = h_st0 > z.mqe; z.mqe_t = up ? st0 : z.mqe_t, z.mqe = up ? h_st0 : z.mqe; }
@@ -479,6 +499,15 @@ __device__ void ksw_reg_run(const KswTask &tk, const KswParams &pr, const uint8_
             stop |= (L >= 1 && bound < z.mte) ? 1 : 0;
         }
         if (__builtin_amdgcn_readfirstlane(stop)) { ez_zdropped = 1; brk = true; }
+        else if (tl_exit && r >= 2 * c1 && r - st0 == c1) {
+            const int d0 = r + 1 - 2 * c1;
+            const int g1 = K.q + K.e * d0, g2 = K.q2 + K.e2 * d0;
+            const int ub = K.sc_mch * qlen - (g1 < g2 ? g1 : g2) + 32;
+            const int room = d0 - 1 - (z.max_t - z.max_q);
+            int done = (ub <= z.max && ub <= z.mqe) ? 1 : 0;
+            if (!band_out) done &= (room >= 0 && (zdrop < 0 || z.max - h_st0 + K.q2 + 32 <= zdrop + K.e2 * room)) ? 1 : 0;
+            if (__builtin_amdgcn_readfirstlane(done)) { ez_zdropped = band_out ? 1 : 0; brk = true; }
+        }
         if (!brk && r == n_rows - 1 && en0 == c2) ez_score = __builtin_amdgcn_readfirstlane(h_en0);
     };
     // ---- approx mode with the reference's greedy H0 (ksw2_extd2_sse.c:367-383): banded or KSW_EZ_APPROX_DROP problems only ----

@@ -473,7 +473,7 @@ __global__ __launch_bounds__(kThreads) void align_plan_kernel(const SeedResult *
         if (K.flag & EZ_RIGHT) tk.qoff = s0 + L.ts[t], tk.toff = tk.qoff + (uint32_t)(ql > 0 ? ql : 0);
         else tk.qoff = s0 + (uint32_t)(K.qs - qa), tk.toff = s0 + len_q + (uint32_t)(K.rs - ta);
         if (cls >= KSW_REG_CLASSES) tk.qoff = tk.toff = s0;           // an empty problem reads nothing
-        tk.qlen = ql, tk.tlen = tl, tk.w = K.w, tk.zdrop = K.zdrop, tk.end_bonus = K.end_bonus, tk.flag = K.flag | cfg.kc.flag_or | ((K.flag & EZ_APPROX_MAX) ? cfg.approx_flag_or : 0);
+        tk.qlen = ql, tk.tlen = tl, tk.w = K.w, tk.zdrop = K.zdrop, tk.end_bonus = K.end_bonus, tk.flag = K.flag | cfg.kc.flag_or | ((K.flag & EZ_APPROX_MAX) ? cfg.approx_flag_or : (K.flag & EZ_EXTZ_ONLY) ? cfg.ext_flag_or : 0);
         tk.p_off = p0 + L.tp[t], tk.cig_off = c0 + L.tc[t], tk.out_idx = slot;
         dp.tasks[slot] = tk;
         dp.task_pair[slot] = b;

@@ -402,8 +402,19 @@ def set_schedule(gpu, groups=4, seed_bucket_depth=0, seed_rings=1, seed_tail_rin
     check(gpu.lib, gpu.lib.nsgpu_set_schedule2(gpu.ctx, groups, seed_bucket_depth, seed_rings, seed_rings if seed_tail_rings is None else seed_tail_rings))
 
 
+def get_schedule(gpu):
+    """(groups, bucket depth, rings, tail rings, builders) of the context: what the last run used when it derived them itself."""
+    v = [C.c_uint32() for _ in range(5)]
+    check(gpu.lib, gpu.lib.nsgpu_get_schedule2(gpu.ctx, *[C.byref(x) for x in v]))
+    return tuple(int(x.value) for x in v)
+
+
 def consensus_run(gpu, n_builders=256, n_threads_out=1, schedule=None):
-    if schedule is not None:
+    """schedule: (groups, depth, rings[, tail rings]), or "auto" (nsgpu_set_schedule_auto; n_builders = 0 lets the library choose the count too)"""
+    if isinstance(schedule, str):
+        assert schedule == "auto"
+        check(gpu.lib, gpu.lib.nsgpu_set_schedule_auto(gpu.ctx))
+    elif schedule is not None:
         set_schedule(gpu, *schedule)
     s = ConsensusStats()
     check(gpu.lib, gpu.lib.nsgpu_consensus_run(gpu.ctx, n_builders, n_threads_out, C.byref(s)))

@@ -334,6 +334,20 @@ def ref_align_fn():
     return C.cast(lib.ref_mm2_align, C.c_void_p)
 
 
+def auto_schedule(n_reads, n_bases, n_filter_results):
+    """The library's automatic schedule (csrc/consensus_driver.hip auto_schedule; nsgpu_set_schedule_auto) restated: (builders, bucket depth,
+    rings, tail rings) in ONE group, from the read count, the bases and the whole-read filter results of all reads, both strands."""
+    r = n_filter_results / n_reads if n_reads else 0.0
+    if r < 30.0:
+        depth, rings, tail, b_min = 3, 5, 3, 32
+    elif r < 70.0:
+        depth, rings, tail, b_min = 2, 4, 3, 96
+    else:
+        depth, rings, tail, b_min = 1, 4, 3, 128
+    b = min(1024, max(b_min, n_bases // 10000000))
+    return max(1, min(b, n_reads if n_reads else 1)), depth, rings, tail
+
+
 def cons_oracle_run(bases, off, salts, k=23, n=60, thr=6, m_k=20, m_w=50, mci=400, edge_thr=4000000, num_thr=1, checks=True, id_base=0, align_fn=None,
                     lock_step=False, seed_hops=0, groups=4, seed_rings=1, seed_tail_rings=None):
     """The reference's hot path (sketch + tables + Consensus::generateAndWriteConsensus) on the CPU with the reference's own minimap2

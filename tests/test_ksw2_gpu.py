@@ -267,3 +267,64 @@ def test_no_score_flag_changes_nothing_but_the_score(gpu, oracle):
         assert np.array_equal(cigs[i], wc), i
         n_drop += we[1]
     assert n_drop > 0
+
+
+def target_longer_cases(seed, n):
+    """Extensions whose target window is longer than the query (what minimap2 hands the DP for every read end inside its contig: about twice the
+    query's length of target, align.c:617-677) -- the shape of the register kernels' second early exit (KSW_EZ_NS_NO_MTE, ksw2_reg.hip): related,
+    unrelated and low-complexity sequences, the query re-appearing further along the target (the one way a far cell can score), N bases, all
+    extension flags, Z-drop on / off / tight, default and thin bands incl. bands that run out before the target does and the boundary of that."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for it in range(n):
+        w = int([751, 751, 751, 300, 100, 50][rng.randint(6)])
+        ql = int(rng.randint(2, 760))
+        kind = it % 7
+        if kind == 6:                                   # the band runs out about where the target ends: c2 ~ (c1 + c2 + w) / 2, i.e. tl ~ ql + w
+            tl = max(ql + 1, ql + w + int(rng.randint(-3, 4)))
+        else:
+            tl = int(rng.randint(ql + 1, int(2.6 * ql) + 40))
+        tl = min(tl, 1536 if it % 11 else 2400)
+        flag = int([0x40, 0xC2, 0x42, 0x40, 0xC2][rng.randint(5)])
+        zdrop = int([400, 400, -1, 50, 200][rng.randint(5)])
+        eb = int([0, 0, -1, 10][rng.randint(4)])
+        if kind in (0, 6):                              # related: the query is the start of the target, with errors
+            q, t = oracle_lib.ksw_random_problem(rng, ql, tl, err=[0.03, 0.1, 0.2][rng.randint(3)])
+        elif kind == 1:                                 # unrelated
+            q = rng.randint(0, 4, size=ql).astype(np.uint8); t = rng.randint(0, 4, size=tl).astype(np.uint8)
+        elif kind == 2:                                 # homopolymer / short tandem repeat on both sides
+            u = rng.randint(0, 4, size=int(rng.randint(1, 5))).astype(np.uint8)
+            q = np.resize(u, ql).copy(); t = np.resize(u, tl).copy()
+            q[rng.randint(0, ql, size=ql // 50 + 1)] = rng.randint(0, 4); t[rng.randint(0, tl, size=tl // 50 + 1)] = rng.randint(0, 4)
+        elif kind == 3:                                 # the query re-appears further along the target
+            q, t = oracle_lib.ksw_random_problem(rng, ql, tl, err=0.03)
+            at = int(rng.randint(min(ql, tl - 1), tl))
+            t[at:at + ql] = q[:min(ql, tl - at)]
+        elif kind == 4:                                 # related only over the first part: the alignment Z-drops or ends early
+            q, t = oracle_lib.ksw_random_problem(rng, ql, tl, err=0.05, diverge_at=int(rng.randint(1, ql)))
+        else:                                           # N bases
+            q, t = oracle_lib.ksw_random_problem(rng, ql, tl, err=0.05, n_frac=0.03)
+        out.append((np.ascontiguousarray(q, dtype=np.uint8), np.ascontiguousarray(t, dtype=np.uint8), w, zdrop, eb, flag))
+    return out
+
+
+def test_target_longer_extensions_with_the_second_early_exit_vs_oracle(gpu, oracle):
+    """KSW_EZ_NS_NO_MTE (0x100000): the aligner's extensions declare ez.mte / mte_q / score unread, and the register kernels stop the sweep of an
+    extension whose target is longer than its query once no later row can change max, mqe or the Z-drop decision.  Everything else -- max, max_t,
+    max_q, mqe, mqe_t, zdropped, reach_end and the CIGAR -- stays bit-exact against the oracle (which sweeps to the end, as the reference does); and
+    without the flag the very same problems are bit-exact in every field."""
+    probs = target_longer_cases(515, 840)
+    flagged = [(q, t, w, zd, eb, fl | 0x100000) for q, t, w, zd, eb, fl in probs]
+    ezs, cigs = ns.ksw_extd2_batch(gpu, flagged)
+    ezp, cigp = ns.ksw_extd2_batch(gpu, probs)
+    n_exit = n_zd = n_end = 0
+    for i, (q, t, w, zd, eb, fl) in enumerate(probs):
+        we, wc = oracle_lib.oracle_ksw(oracle, q, t, w, zd, eb, fl)
+        assert ezp[i] == we and np.array_equal(cigp[i], wc), (i, len(q), len(t), w, zd, hex(fl), ezp[i], we)
+        got = ezs[i]
+        assert got[:6] == we[:6] and got[9:] == we[9:], (i, len(q), len(t), w, zd, eb, hex(fl), got, we)
+        assert np.array_equal(cigs[i], wc), (i, len(q), len(t), w, hex(fl))
+        n_exit += got[6:9] != we[6:9]
+        n_zd += we[1]
+        n_end += we[10]
+    assert n_exit > 150 and n_zd > 100 and n_end > 100, (n_exit, n_zd, n_end)
