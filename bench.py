@@ -141,10 +141,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU (cfg2: 100000)")
     ap.add_argument("--mean-len", type=float, default=8000.0)
-    ap.add_argument("--builders", type=int, default=80, help="virtual contig builders per GPU (default: the iso-compression schedule, see --groups)")
-    ap.add_argument("--groups", type=int, default=1, choices=[1, 2, 4], help="pipeline groups of the contig stage: a builder steps once per `groups` slots (nsgpu_set_schedule)")
-    ap.add_argument("--seed-depth", type=int, default=3, help="conflict-aware seeds: bucket depth (0 = the reference's getRead rule)")
-    ap.add_argument("--seed-rings", type=int, default=5, help="conflict-aware seeds: adjacency rings around occupied buckets that a seed must keep clear of")
+    ap.add_argument("--builders", type=int, default=0, help="virtual contig builders per GPU (default 0: the library's own choice, nsgpu_set_schedule_auto -- on cfg2: 80)")
+    ap.add_argument("--groups", type=int, default=0, choices=[0, 1, 2, 4], help="pipeline groups of the contig stage: a builder steps once per `groups` slots (nsgpu_set_schedule); default 0: the library derives the whole schedule from the input (nsgpu_set_schedule_auto; on cfg2: one group, buckets of depth 3, 5 rings, 3 in the tail)")
+    ap.add_argument("--seed-depth", type=int, default=3, help="with --groups: conflict-aware seeds: bucket depth (0 = the reference's getRead rule)")
+    ap.add_argument("--seed-rings", type=int, default=5, help="with --groups: conflict-aware seeds: adjacency rings around occupied buckets that a seed must keep clear of")
+    ap.add_argument("--threads-sweep", type=int, default=-1, help="also time ONE step with 4 and with 2 host threads (what a rank gets of a shared CPU quota), each in a child process (default: only with 1 GPU at full cfg2 size; 0 = skip)")
     ap.add_argument("--depth", type=float, default=20.0, help="sequencing depth of the synthetic read set (cfg2: 20; cfg3's E. coli regime: ~200)")
     ap.add_argument("--genome", choices=["iid", "repeats"], default="iid", help="synthetic genome: iid (BASELINE cfg2) or with planted duplications / tandem repeats / homopolymer and (AT)n runs")
     ap.add_argument("--throughput-leg", type=int, default=-1, help="also time ONE step of the 1024-builder pipelined schedule, which is not iso-compression (default: only with 1 GPU at full cfg2 size; 0 = skip)")
@@ -189,7 +190,13 @@ def main():
     g = ns.NsGpu(k=k, n=n, overlap_sketch_thr=thr, device=local, stream=stream.cuda_stream)
     if args.seed_tail_rings < 0:
         args.seed_tail_rings = args.seed_rings
-    ns.set_schedule(g, args.groups, args.seed_depth, args.seed_rings, args.seed_tail_rings)
+    auto_sched = args.groups == 0
+    def apply_schedule(ctx):
+        if auto_sched:
+            ns.filter.check(ctx.lib, ctx.lib.nsgpu_set_schedule_auto(ctx.ctx))       # builders, bucket depth and radii from the input (include/nsgpu.h)
+        else:
+            ns.set_schedule(ctx, args.groups, args.seed_depth, args.seed_rings, args.seed_tail_rings)
+    apply_schedule(g)
     job = None
     if exchange:
         # the C++ driver (csrc/dist.hip): the library's own RCCL communicator; Python only calls three entry points
@@ -278,6 +285,10 @@ def main():
             del src, dst
         except Exception:
             hbm_copy = None
+    # the schedule the timed steps ran in (derived by the library unless --groups was given)
+    used = ns.filter.get_schedule(g)
+    args.groups, args.seed_depth, args.seed_rings, args.seed_tail_rings = used[0], used[1], used[2], used[3]
+    builders_used = used[4] // world if world > 1 else used[4]
     if rank == 0:
         steps = max(args.steps, 1)
         a = ns.align_stats(g)
@@ -295,7 +306,7 @@ def main():
         # comes from rocprofv3 --pmc passes over this very command (profiles/r01_pmc_ksw_traffic.json) and is only
         # reported for the workload it was measured on.
         traffic, traffic_src = None, None
-        for pmc_name in (("r04_pmc_ksw_traffic.json", "r03_pmc_ksw_traffic.json") if args.groups == 1 else ("r02_pmc_ksw_traffic.json", "r01_pmc_ksw_traffic.json")):
+        for pmc_name in (("r05_pmc_ksw_traffic.json", "r04_pmc_ksw_traffic.json", "r03_pmc_ksw_traffic.json") if args.groups == 1 else ("r02_pmc_ksw_traffic.json", "r01_pmc_ksw_traffic.json")):
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc) and args.reads == 100000 and world == 1:
                 pj = json.load(open(pmc))
@@ -339,14 +350,15 @@ def main():
                     "streams_identical_to_the_oracle_6_of_7": same, "all_identical": all(same.values()),
                     "contigs_slots_equal": stats["n_contigs"] == want["stats"]["n_contigs"] and stats["n_rounds"] == want["stats"]["slots"],
                     "test": "tests/test_consensus_gpu.py::test_cfg2_full_default_schedule_equals_lockstep_oracle_hashes"}
-        default_sched = (args.builders, args.groups, args.seed_depth, args.seed_rings, args.seed_tail_rings) == (80, 1, 3, 5, 3)
+        default_sched = (builders_used, args.groups, args.seed_depth, args.seed_rings, args.seed_tail_rings) == (80, 1, 3, 5, 3)
         parity = parity_of("r03_lockstep_cfg2.json", st) if default_sched else None
         penalty = compression_of(stream_bytes / n_bases, st)
-        penalty["schedule"] = {"groups": args.groups, "seed_bucket_depth": args.seed_depth, "seed_rings": args.seed_rings, "seed_tail_rings": args.seed_tail_rings}
+        penalty["schedule"] = {"groups": args.groups, "seed_bucket_depth": args.seed_depth, "seed_rings": args.seed_rings, "seed_tail_rings": args.seed_tail_rings,
+                               "derived_by": "the library (nsgpu_set_schedule_auto: from reads, bases and the whole-read filter results per read)" if auto_sched else "the command line"}
         # three steps (after one untimed) of the 1024-builder, four-group pipelined schedule with the reference's seed rule (the round-2 headline): faster, larger streams
         tleg = None
         want_leg = args.throughput_leg if args.throughput_leg >= 0 else int(world == 1 and args.reads == 100000 and args.depth == 20.0 and args.genome == "iid")
-        if want_leg and world == 1 and not (args.builders == 1024 and args.groups == 4 and args.seed_depth == 0):
+        if want_leg and world == 1 and not (builders_used == 1024 and args.groups == 4 and args.seed_depth == 0):
             ns.set_schedule(g, 4, 0, 1)
             g.sketch(salts, fetch=False); g.build_index()
             ns.consensus_run(g, 1024, 8)                                   # warm-up (buffers of this batch size)
@@ -364,7 +376,7 @@ def main():
                     "schedule": {"builders": 1024, "groups": 4, "seed_bucket_depth": 0}, "lossless_roundtrip_bad_reads": ns.consensus_verify(g),
                     "compression": compression_of(sb2 / n_bases, st2), "parity": parity_of("r03_lockstep_cfg2_1024.json", st2),
                     "note": "NOT iso-compression: 1024 contigs grow at once on a 40 Mb genome and cut each other short"}
-            ns.set_schedule(g, args.groups, args.seed_depth, args.seed_rings, args.seed_tail_rings)
+            apply_schedule(g)
         full_size = world == 1 and args.reads == 100000 and args.depth == 20.0 and args.genome == "iid" and args.mean_len == 8000.0
         # the fastest schedule found that the reference's -t N can itself produce (d = 0: no bucket policy, Consensus::getRead's rule; one group) with
         # streams within 5 % of its -t N: 32 builders (24 / 32 / 40 builders: x1.027 / x1.046 / x1.054 of the -t 8 streams, 47.6 / 58.4 / 69.3 Mbases/s)
@@ -383,14 +395,14 @@ def main():
                     "schedule": {"builders": 32, "groups": 1, "seed_bucket_depth": 0}, "lossless_roundtrip_bad_reads": ns.consensus_verify(g),
                     "compression": compression_of(sb3 / n_bases, st3), "slots": st3["n_rounds"],
                     "note": "an interleaving the reference's own -t N can produce (no try_lock ever fails, its getRead seed rule); the headline schedule's seed rule is this repository's extension"}
-            ns.set_schedule(g, args.groups, args.seed_depth, args.seed_rings, args.seed_tail_rings)
+            apply_schedule(g)
         # one step on data that is not the best case: a genome with planted repeats
         nleg = None
         want_non = args.nonideal_leg if args.nonideal_leg >= 0 else int(full_size)
         if want_non and world == 1:
             rb, ro = ns.synth_reads(11, genome_len, args.reads, args.mean_len, genome="repeats")
             g2 = ns.NsGpu(k=k, n=n, overlap_sketch_thr=thr, device=local, stream=stream.cuda_stream)
-            ns.set_schedule(g2, args.groups, args.seed_depth, args.seed_rings, args.seed_tail_rings)
+            apply_schedule(g2)
             g2.load_reads((rb, ro))
             ns.align_stats(g2, reset=True)
             tt = time.perf_counter()
@@ -407,10 +419,27 @@ def main():
                     "stream_bytes_per_base": round(sb4 / int(ro[-1]), 4), "contigs": st4["n_contigs"], "slots": st4["n_rounds"], "lossless_roundtrip_bad_reads": ns.consensus_verify(g2)}
             g2.close()
             del rb, ro
+        # what a rank gets of a CPU quota it shares with the other ranks of its node: ONE step with 4 and with 2 host threads (the thread count is
+        # read once per process: a child each, this very script without its other legs; the children's first step includes their allocations)
+        tsweep = None
+        want_ts = args.threads_sweep if args.threads_sweep >= 0 else int(full_size)
+        if want_ts and world == 1:
+            import subprocess
+            tsweep = {"note": "one first step per thread count, each in a child process (NSGPU_THREADS); the timed steps above ran with host_threads = %d" % a["host_threads"], "runs": []}
+            for nthr in (4, 2):
+                cmd = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--throughput-leg", "0", "--cpu-sample", "0", "--cpu-full", "0", "--legal-leg", "0",
+                       "--nonideal-leg", "0", "--threads-sweep", "0", "--reads", str(args.reads), "--mean-len", str(args.mean_len), "--depth", str(args.depth), "--genome", args.genome]
+                try:
+                    rr = subprocess.run(cmd, env=dict(os.environ, NSGPU_THREADS=str(nthr)), capture_output=True, text=True, timeout=600)
+                    cj = json.loads([ln for ln in rr.stdout.splitlines() if ln.startswith("{")][-1])
+                    tsweep["runs"].append({"host_threads": nthr, "value": cj["value"], "unit": "Mbases/s", "ms_per_step": cj["ms_per_step"], "graph_host_wall_ms": cj["config"]["stage_ms_per_step"]["graph_host_wall"],
+                                           "lossless_roundtrip_bad_reads": cj["config"]["lossless_roundtrip_bad_reads"]})
+                except Exception as ex:                 # (a leg, not the measurement: report and go on)
+                    tsweep["runs"].append({"host_threads": nthr, "error": str(ex)[:200]})
         comp = None
         pv = os.path.join(ROOT, "profiles", "r02_pmc_ksw_issue.json")
         if args.groups == 1:
-            pv = next((x for x in (os.path.join(ROOT, "profiles", nm) for nm in ("r04_pmc_ksw_issue.json", "r03_pmc_ksw_issue.json")) if os.path.exists(x)), pv)
+            pv = next((x for x in (os.path.join(ROOT, "profiles", nm) for nm in ("r05_pmc_ksw_issue.json", "r04_pmc_ksw_issue.json", "r03_pmc_ksw_issue.json")) if os.path.exists(x)), pv)
         if os.path.exists(pv):
             pj2 = json.load(open(pv))
             comp = pj2.get("summary") or {"source": pj2.get("source"), "reading": pj2.get("reading"), "kernels": {k: {"valu_utilisation": v["valu_utilisation"], "waves_per_simd": v["waves_per_simd"], "wave_time_share": v["wave_time_share"]} for k, v in pj2.get("kernels", {}).items()}}
@@ -458,6 +487,7 @@ def main():
             "throughput_schedule": tleg,
             "reference_legal_schedule": lleg,
             "nonideal": nleg,
+            "host_threads_sweep": tsweep,
             "roofline": {"kernel": "ksw_extd2 (ksw_extd2_reg_kernel<NW,NCH>: DP state in registers)", "bound": "latency" if args.groups == 1 else "valu-issue", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 7), "hbm_frac": round(achieved / HBM_PEAK_GBS, 7), "hbm_copy_measured_gbs": hbm_copy,
                          "traffic": None, "traffic_from_profile": traffic, "traffic_source": traffic_src,

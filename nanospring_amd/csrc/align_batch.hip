@@ -379,8 +379,7 @@ int approx_task_flag(int flag)
     static const bool keep = getenv("NSGPU_KSW_KEEP_SCORE") != nullptr;
     if (keep) return 0;
     if ((flag & 0x08) && !(flag & 0x10)) return 0x80000;
-    static const bool keep_mte = getenv("NSGPU_KSW_KEEP_MTE") != nullptr;
-    if ((flag & 0x40) && !(flag & 0x08) && !keep_mte) return 0x100000;
+    if ((flag & 0x40) && !(flag & 0x08)) return 0x100000;
     return 0;
 }
 

@@ -52,9 +52,8 @@ static std::atomic<uint64_t> g_host_waits{0};       // host waits for GPU work (
 static hipError_t stream_wait_impl(hipStream_t s, int spin_us, bool spin_only = false)
 {
     g_host_waits.fetch_add(1, std::memory_order_relaxed);
-    static const bool spin = [] { const char *e = getenv("NSGPU_SPIN_WAIT"); return e && atoi(e) != 0; }();
     const double limit = wait_timeout_s();
-    if ((spin || spin_only) && limit <= 0) return hipStreamSynchronize(s);
+    if (spin_only && limit <= 0) return hipStreamSynchronize(s);
     // the default timer slack (50 us) would stretch every 20 us sleep to ~75 us: 1 us of slack for threads that wait here
     static thread_local const int slack_set = prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
     (void)slack_set;
@@ -67,7 +66,7 @@ static hipError_t stream_wait_impl(hipStream_t s, int spin_us, bool spin_only = 
             fprintf(stderr, "nsgpu: a wait for stream %p exceeded NSGPU_WAIT_TIMEOUT_S = %g s\n", (void *)s, limit);
             return hipErrorNotReady;
         }
-        if (spin || spin_only || dt < std::chrono::microseconds(spin_us)) continue;
+        if (spin_only || dt < std::chrono::microseconds(spin_us)) continue;
         timespec ts = {0, 20000};
         nanosleep(&ts, nullptr);
     }

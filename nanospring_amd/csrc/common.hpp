@@ -43,7 +43,7 @@ void set_error(const char *fmt, ...);
 // Waits for a stream without holding a core.  hipStreamSynchronize (and hipEventSynchronize, blocking-sync flag or not)
 // busy-waits on this runtime: a waiting thread shows 100 % CPU for the whole wait (tools/spin_probe.py), and the contig stage
 // is bound by the host cores it shares with those waits.  So: poll the stream, spin only for the first ~20 us, then sleep
-// between polls.  NSGPU_SPIN_WAIT=1 restores the runtime's own wait.
+// between polls.
 hipError_t stream_wait(hipStream_t s);
 hipError_t event_wait(hipEvent_t ev);            // the same for a point inside a stream's work
 // a non-blocking stream for one of the roles "sketch", "seeds" (seeding + chaining kernels), "dp_side" (long DP problems), "dp" (DP workspaces 1-3):

@@ -291,13 +291,9 @@ void ContigGraph::initialize(const std::string &seed, read_t id, long pos)
 
 static inline uint64_t emit_now();
 std::atomic<uint64_t> g_mp_cnt[3];    // diagnostic: main-path edges copied out by the tail re-use, calls that cut the path, path lengths at those calls
-std::atomic<uint64_t> g_upd_ns[6];    // diagnostic (NSGPU_UPDATE_STATS=1): setup, run loops, SAME op heads, inserts, tail, calls
 void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &script, ssize_t begin_offset, ssize_t end_offset, read_t id,
                                long pos, bool rc)
 {
-    static const bool upd_stats = getenv("NSGPU_UPDATE_STATS") != nullptr;
-    uint64_t ut[5] = {0, 0, 0, 0, 0}, u0 = upd_stats ? emit_now() : 0;
-    auto lapu = [&](int k) { if (upd_stats) { const uint64_t t = emit_now(); ut[k] += t - u0; u0 = t; } };
     const size_t n_path_edges = main_edges.size();
     std::vector<uint64_t> dbg_before;
     static const bool dbg = getenv("NSGPU_SPLICE_CHECK") != nullptr;      // debugging aid for the tail re-use shortcut
@@ -365,7 +361,6 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
         op_at[script.size()] = (uint32_t)(e2 < n_path_edges ? e2 : n_path_edges);
     }
     size_t op_k = 0;
-    lapu(0);
     for (const EditOp &op : script) {
         {
             const size_t k9 = op_k + 9, k6 = op_k + 6, k3 = op_k + 3;
@@ -387,7 +382,6 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
             cur_main = (ssize_t)ei;
             if (touch_lo_ == (size_t)-1) touch_lo_ = ei;
             advance();
-            lapu(2);
             // The rest of the run follows the main-path edges main_edges[ei-1 .. ei+num-3] one after the other (the loop below,
             // which re-derives that per base, stays for the path's end, where the reference's walk stops advancing): add the read
             // to each of them and set the walk's state once.
@@ -406,7 +400,6 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
                 cur_main = (ssize_t)last_ei;
                 if (last_ei == n_path_edges) ei = n_path_edges, node_in_path = cur;
                 else node_in_path = pe[last_ei]->sink, ei = last_ei + 1;
-                lapu(1);
                 continue;
             }
             for (size_t i = 1; i < op.num; ++i) {
@@ -422,16 +415,13 @@ void ContigGraph::update_graph(const std::string &s, const std::vector<EditOp> &
                 cur_main = (ssize_t)ei;
                 advance();
             }
-            lapu(1);
-        } else if (op.type == 2) { advance(); lapu(3); }         // DELETE
-        else if (op.type == 1) { insert_node((char)op.base); lapu(3); }
+        } else if (op.type == 2) { advance(); }         // DELETE
+        else if (op.type == 1) { insert_node((char)op.base); }
     }
     if (end_offset > 0)
         for (size_t i = s.size() - (size_t)end_offset; i < s.size(); ++i) insert_node(s[i]);
     reads.insert(std::make_pair(id, GraphRead{pos, initial, s.length(), rc}));
     touch_idx_ = ei, have_touch_ = true;         // main-path nodes beyond index ei were not modified
-    lapu(4);
-    if (upd_stats) { for (int k = 0; k < 5; ++k) g_upd_ns[k] += ut[k]; g_upd_ns[5] += 1; }
     if (dbg) for (size_t i = ei; i < n_path_edges; ++i) if (dbg_before[i] != out_sig(main_edges[i]->sink)) { fprintf(stderr, "UPDATE touched node %zu beyond ei=%zu (begin %zd end %zd)\n", i + 1, ei, begin_offset, end_offset); break; }
 }
 
@@ -462,7 +452,6 @@ void ContigGraph::calculate_main_path_greedy()
         if (lo <= hi && consistent_from_ < hi + 1) consistent_from_ = hi + 1;
     }
     const bool try_splice = !no_splice && have_touch_ && left_off_ == 0 && m > 0 && right_off_ <= m && consistent_from_ != (size_t)-1;
-    if (!try_splice) { static const bool dbg_r = getenv("NSGPU_SPLICE_REASON") != nullptr; if (dbg_r) fprintf(stderr, "FULL %s m=%zu R=%zu L=%zu\n", !have_touch_ ? "first" : left_off_ != 0 ? "left" : consistent_from_ == (size_t)-1 ? "split" : "other", m, right_off_, left_off_); }
     have_touch_ = false;
     if (try_splice) {
         // ---- exact shortcut: re-walk only where the greedy choice can have changed ----

@@ -37,7 +37,7 @@ namespace mm2 { extern std::atomic<uint64_t> g_step_ns[6]; }
 extern double g_finish_ms[5];
 extern uint64_t g_dp_shape[5][4][8];
 extern double g_sketch_ms[6];
-namespace cons { extern std::atomic<uint64_t> g_emit_ns[4]; extern std::atomic<uint64_t> g_upd_ns[6]; extern std::atomic<uint64_t> g_mp_cnt[3]; extern std::atomic<int64_t> g_slabs_in_use, g_slabs_peak, g_slabs_mapped; }
+namespace cons { extern std::atomic<uint64_t> g_emit_ns[4]; extern std::atomic<uint64_t> g_mp_cnt[3]; extern std::atomic<int64_t> g_slabs_in_use, g_slabs_peak, g_slabs_mapped; }
 
 using cons::read_t;
 
@@ -537,13 +537,11 @@ static void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
     });
     // the edit emission of the contigs finished in this phase: background tasks of the host pool, picked up whenever a
     // thread has nothing else to do (nothing waits for them before the end of the stage)
-    static const bool sync_emit = getenv("NSGPU_SYNC_EMISSION") != nullptr;      // debugging aid: emit at once
     for (Builder &b : D.B)
         for (; b.n_queued < b.contigs.size(); ++b.n_queued) {
             FinishedContig *fc = b.contigs[b.n_queued].get();
             if (!fc->g) continue;
-            if (sync_emit) D.emit_contig(*fc);
-            else pool_post([&D, fc] { D.emit_contig(*fc); });
+            pool_post([&D, fc] { D.emit_contig(*fc); });
         }
     c->cons_stats.graph_ms += now_ms() - a0;
     double mx = 0, mxu = 0, mxm = 0;
@@ -704,8 +702,6 @@ static int seed_policy_init(nsgpu_ctx *c, Engine *E)
     for (uint32_t b = 0; b < nb; ++b) P.bk_off[b + 1] += P.bk_off[b];
     P.bk_reads.resize(N);
     { std::vector<uint64_t> fill(P.bk_off.begin(), P.bk_off.end() - 1); for (uint32_t r = 0; r < N; ++r) P.bk_reads[fill[P.bucket_of[r]]++] = r; }
-    static const bool no_wr = getenv("NSGPU_NO_SEED_WINDOW_TABLE") != nullptr;        // A/B switch: every window query on the GPU, as before
-    if (no_wr) P.wr_off.clear(), P.wr_ids.clear();
     P.bk_next.assign(nb, 0);
     P.occ.assign(nb, 0);
     P.members.assign(E->n_total, std::vector<uint32_t>());
@@ -1015,7 +1011,7 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
     std::vector<uint64_t> &mo = L.mz_off;
     NS_TRY(gpu_mm_sketch(c, sk, (int)c->prm.m_w, (int)c->prm.m_k, mz, mo, L.sketch_ws));
     L.sk_ms[2] += now_ms() - tk; tk = now_ms();
-    static const bool resident_lists = getenv("NSGPU_NO_RESIDENT_LISTS") == nullptr;      // A/B switch: consensus minimizer lists staged whole, as in round 2
+    constexpr bool resident_lists = true;           // (round 3's A/B, settled: the whole list through the pinned buffer cost the seeding kernel 16 MB over PCIe per slot)
     std::vector<size_t> &tail_from = L.tail_from;
     tail_from.assign(n, 0);
     // the plan kernel (plan.hip) reads the candidate where the sketch batch staged it and the consensus from the contig's resident copy
@@ -1360,7 +1356,6 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
         E->n_early_retry += n_retry.load();
     }
     // batches whose results come from collecting kernels behind the launches (NSGPU_KSW_NO_INLINE_COLLECT=1): part 0 here, part 1 on a second thread
-    static const bool one_part_early = getenv("NSGPU_EARLY_ONE_PART") != nullptr;        // A/B switch: only the first part runs ahead, as in the first version
     int rc_all = NSGPU_OK;
     for (int k = 0; k < n_act && rc_all == NSGPU_OK; ++k) {
         const int gi = act[k];
@@ -1388,7 +1383,7 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
         // (the second part's wait begins once the first part has been waited for: the two never race for the workspace's state)
         KswDevResults R0;
         const int rc0 = batch_plan_wait(c, AB, 0, R0);
-        if (rc0 == NSGPU_OK && !one_part_early)
+        if (rc0 == NSGPU_OK)
             t1 = std::thread([&] {
                 pool_bind_this_thread();
                 KswDevResults R1;
@@ -1724,9 +1719,6 @@ static void debug_report_stage(nsgpu_ctx *c, Engine *E, const struct rusage &ru0
     if (cons::g_mp_cnt[1].load())
         fprintf(stderr, "[cons] main path (cumulative): %llu recomputes cut the path, on average at %.0f edges before its end of %.0f\n", (unsigned long long)cons::g_mp_cnt[1].load(),
                 (double)cons::g_mp_cnt[0].load() / cons::g_mp_cnt[1].load(), (double)cons::g_mp_cnt[2].load() / cons::g_mp_cnt[1].load());
-    if (cons::g_upd_ns[5].load())
-        fprintf(stderr, "[cons] update_graph cpu-ms (NSGPU_UPDATE_STATS, cumulative, %llu calls): setup %.0f, SAME runs %.0f, SAME heads %.0f, inserts / deletes %.0f, tail %.0f\n",
-                (unsigned long long)cons::g_upd_ns[5].load(), cons::g_upd_ns[0] / 1e6, cons::g_upd_ns[1] / 1e6, cons::g_upd_ns[2] / 1e6, cons::g_upd_ns[3] / 1e6, cons::g_upd_ns[4] / 1e6);
     fprintf(stderr, "[cons] emission cpu-ms: path tables %.0f, read walks %.0f, script folding + stream bytes %.0f\n", cons::g_emit_ns[0] / 1e6, cons::g_emit_ns[1] / 1e6, cons::g_emit_ns[2] / 1e6);
     fprintf(stderr, "[cons] align host cpu-ms: seeds %.0f chain %.0f regs %.0f plan %.0f execute %.0f\n", mm2::g_step_ns[0] / 1e6, mm2::g_step_ns[1] / 1e6,
             mm2::g_step_ns[2] / 1e6, mm2::g_step_ns[3] / 1e6, mm2::g_step_ns[4] / 1e6);
@@ -1753,33 +1745,6 @@ static void debug_report_stage(nsgpu_ctx *c, Engine *E, const struct rusage &ru0
             g_sketch_ms[0], g_sketch_ms[1], g_sketch_ms[2], g_sketch_ms[3], g_sketch_ms[4] / 1e6, g_sketch_ms[5] / 1e6);
     for (double &x : g_sketch_ms) x = 0;
     const double sys_s = (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
-    if (getenv("NSGPU_THREAD_TIMES")) {
-        // cumulative user / system time of every thread of the process since it started (ticks -> s), busiest system-time users first
-        std::vector<std::pair<double, std::string>> rows;
-        if (DIR *d = opendir("/proc/self/task")) {
-            while (dirent *de = readdir(d)) {
-                if (de->d_name[0] == '.') continue;
-                char path[128], buf[1024];
-                snprintf(path, sizeof(path), "/proc/self/task/%s/stat", de->d_name);
-                FILE *tf = fopen(path, "r");
-                if (!tf) continue;
-                if (fgets(buf, sizeof(buf), tf)) {
-                    const char *rp = strrchr(buf, ')');
-                    const char *lp = strchr(buf, '(');
-                    unsigned long ut = 0, stt = 0;
-                    if (rp && lp && sscanf(rp + 2, "%*c %*d %*d %*d %*d %*d %*u %*u %*u %*u %*u %lu %lu", &ut, &stt) == 2) {
-                        char row[256];
-                        snprintf(row, sizeof(row), "%s %.*s user %.2f s sys %.2f s", de->d_name, (int)(rp - lp - 1), lp + 1, ut / (double)sysconf(_SC_CLK_TCK), stt / (double)sysconf(_SC_CLK_TCK));
-                        rows.push_back({stt / (double)sysconf(_SC_CLK_TCK), row});
-                    }
-                }
-                fclose(tf);
-            }
-            closedir(d);
-        }
-        std::sort(rows.begin(), rows.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
-        for (size_t k = 0; k < rows.size() && k < 24; ++k) fprintf(stderr, "[threads] %s\n", rows[k].second.c_str());
-    }
     fprintf(stderr, "[cons] process CPU time over the stage: %.1f s (%.1f s of it in the kernel; %ld minor faults) = %.1f cores busy on average\n", cpu_s, sys_s,
             ru1.ru_minflt - ru0.ru_minflt, cpu_s / ((now_ms() - E->t0) * 1e-3));
     fprintf(stderr, "[cons] wall-ms: begin %.0f slots %.0f (host phases %.0f, batches %.0f, overlapped) seed %.0f claim %.0f finish %.0f\n", w_begin, w_slot,
@@ -1879,7 +1844,10 @@ static int run_consensus_dist(nsgpu_ctx *c, Comm &C, uint32_t n_builders_total, 
     Engine *E = static_cast<Engine *>(c->cons_engine);
     const uint32_t W = C.world;
     // one exchange = [status | claim count, gids, reads | seed count, gids, cursors]; a rank never has more requests than local builders
-    const size_t cap = (n_builders_total + W - 1) / W + 1, blk = 1 + 2 * cap, words = 1 + 2 * blk;
+    // (0 builders = the automatic schedule's own count, at most 1024: the bound must not depend on what a rank derives -- a rank whose
+    // engine_begin failed still has to enter the exchanges with buffers of the size the others use)
+    const uint32_t nb_bound = n_builders_total ? n_builders_total : 1024u;
+    const size_t cap = (nb_bound + W - 1) / W + 1, blk = 1 + 2 * cap, words = 1 + 2 * blk;
     std::vector<uint32_t> mine(words), all(words * W), ca, cb, sa, sb, ga, gb;
     uint64_t n_coll = 0;
     std::string local_err;

@@ -25,7 +25,6 @@ struct DvCollect {
     uint32_t *h_check;                  // per alignment: dv_check_* over every word handed over (the host recomputes it from what it reads before it believes the status word)
     uint32_t epoch;                     // the batch's number on its workspace: seeds the check, so that a previous batch's self-consistent words never pass
     DvCtrl *ctrl;
-    uint32_t no_probe;                  // NSGPU_KSW_NO_PROBE=1 (experiment): raise the status word without reading the data back first
 };
 
 // The check word of an alignment's hand-over: seeded with the batch's epoch and the alignment's index, every word weighted by its POSITION in the
@@ -87,7 +86,7 @@ __device__ inline void dev_collect_pair(const DvCollect &dc, uint32_t b, uint32_
     // The host may be watching the status word while this kernel is still running (ksw_dev_poll): the word must not overtake the data on the
     // way to host memory.  Every lane reads one word of what it wrote back from host memory (a system-scope load: a read request does not pass
     // the posted writes in front of it on the link), and only then does lane 0 raise the word.
-    if (!dc.no_probe) {
+    {
         uint32_t probe = 0;
         if (lane < n) probe = __hip_atomic_load(reinterpret_cast<const uint32_t *>(dc.h_off + s0 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (total) probe += __hip_atomic_load(dc.h_cig + base + (total - 1 - (lane % (total < 64 ? total : 64))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -567,7 +567,7 @@ static int gpu_mm_sketch_fused(nsgpu_ctx *c, const std::vector<SketchReq> &reqs,
         }
     }
     if (h_flags[0] || h_flags[1] || !run_ok) {
-        static const bool dbg = getenv("NSGPU_SKETCH_DEBUG") != nullptr;
+        static const bool dbg = getenv("NSGPU_CONS_DEBUG") != nullptr;
         if (dbg) fprintf(stderr, "[sketch] fused path gives up: bad input %u, a tile with more minimizers than its slot %u, %zu sequences, %llu tiles\n", h_flags[0], h_flags[1],
                          n, (unsigned long long)n_tiles);
         return 1;

@@ -537,6 +537,9 @@ int plan_launch(hipStream_t st, uint32_t n_pairs, uint32_t lds_anchors, const Se
                 const PlanPair *pairs, PlanOut *out, PlanKey *keys_out, const PlanDp &dp, const PlanCfg &cfg)
 {
     if (n_pairs == 0) return NSGPU_OK;
+    // a workgroup has 160 KB of LDS: lists beyond what that takes (reads of 70 kb and more: ~6 000 anchors) are the host's to plan -- the
+    // kernel leaves every alignment with more anchors than `lds_anchors` alone
+    while (lds_anchors > 64 && plan_lds_bytes(lds_anchors) > (size_t)152 << 10) lds_anchors -= lds_anchors / 8;
     const size_t lds = plan_lds_bytes(lds_anchors);
     static LdsAttr attr;
     if (lds > 32768) NS_TRY(attr.raise(lds, reinterpret_cast<const void *>(align_plan_kernel)));

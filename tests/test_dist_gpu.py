@@ -153,7 +153,7 @@ def test_cxx_driver_over_callback_communicator(tmp_path, world, groups, depth):
             assert ag > 0.25 * n_bases and aa > 0, ln                      # the packed rows and the bucket tuples did travel
 
 
-@pytest.mark.parametrize("mode", ["alltoall", "replicate"])
+@pytest.mark.parametrize("mode", ["alltoall", "replicate", "alltoall-auto"])
 def test_bench_two_ranks_on_one_gpu_default_schedule(mode):
     """`bench.py --gpus 2` itself, launched the way the driver launches it (torch.distributed.run, one process per rank; the launcher starts
     before anything touches the GPU), the two ranks sharing the box's one GPU with the collectives over gloo (NSGPU_BENCH_BACKEND): the
@@ -161,11 +161,13 @@ def test_bench_two_ranks_on_one_gpu_default_schedule(mode):
     conflict-aware seeds of depth 3) the job's contigs are those of one process holding all reads with the same number of builders."""
     import json
     R, B, L = 600, 12, 3000.0
-    port = "29671" if mode == "alltoall" else "29672"
+    auto_count = mode.endswith("-auto")             # no --builders either: the count is the library's too (1 per 10 Mbases of the whole job, at least 32)
+    mode = mode.split("-")[0]
+    port = "29673" if auto_count else "29671" if mode == "alltoall" else "29672"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, NSGPU_BENCH_BACKEND="gloo", NSGPU_THREADS="4")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--reads", str(R), "--mean-len", str(L), "--builders", str(B),
-                        "--cpu-sample", "0", "--dist-mode", mode], env=env, capture_output=True, text=True, timeout=1200)
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--reads", str(R), "--mean-len", str(L)] + ([] if auto_count else ["--builders", str(B)]) +
+                       ["--cpu-sample", "0", "--dist-mode", mode], env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -185,7 +187,9 @@ def test_bench_two_ranks_on_one_gpu_default_schedule(mode):
     g.load_reads((bases, off))
     g.sketch(ns.mt19937_64_salts(60, 12345), fetch=False)
     g.build_index()
-    st1 = ns.consensus_run(g, 2 * B, 8, schedule=(1, 3, 5, 3))
+    st1 = ns.consensus_run(g, 0, 8) if auto_count else ns.consensus_run(g, 2 * B, 8, schedule=(1, 3, 5, 3))
+    if auto_count:
+        assert ns.filter.get_schedule(g) == (1, 3, 5, 3, 32) and j["config"]["builders"] == 32
     assert ns.consensus_verify(g) == 0
     g.close()
     assert sum(p["contigs"] for p in pr) == st1["n_contigs"] and all(p["rounds"] == st1["n_rounds"] for p in pr)

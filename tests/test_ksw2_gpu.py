@@ -327,4 +327,4 @@ def test_target_longer_extensions_with_the_second_early_exit_vs_oracle(gpu, orac
         n_exit += got[6:9] != we[6:9]
         n_zd += we[1]
         n_end += we[10]
-    assert n_exit > 150 and n_zd > 100 and n_end > 100, (n_exit, n_zd, n_end)
+    assert n_exit > 150 and n_zd > 100 and n_end > 50, (n_exit, n_zd, n_end)
