@@ -17,415 +17,9 @@
 // The builders form four groups that go through these steps a quarter of a period apart (host phase |
 // batches part 1 with the DP launch | DP in flight | batches part 2), so that host cores and GPU work
 // at the same time: see run_consensus / engine_slot.
-#include "common.hpp"
-#include <dirent.h>
-#include <unistd.h>
-#include "consensus.hpp"
-#include "host_util.hpp"
-#include "dist.hpp"
-#include <memory>
-#include <atomic>
-#include <thread>
-#include <sched.h>
-#include <pthread.h>
-#include <sys/resource.h>
-#include <sys/prctl.h>
-#include <time.h>
+#include "engine.hpp"
 
 namespace nsgpu {
-namespace mm2 { extern std::atomic<uint64_t> g_step_ns[6]; }
-extern double g_finish_ms[5];
-extern uint64_t g_dp_shape[5][4][8];
-extern double g_sketch_ms[6];
-namespace cons { extern std::atomic<uint64_t> g_emit_ns[4]; extern std::atomic<uint64_t> g_mp_cnt[3]; extern std::atomic<int64_t> g_slabs_in_use, g_slabs_peak, g_slabs_mapped; }
-
-using cons::read_t;
-
-// A finished contig waiting for its edit emission (consensus + one edit script per read into the seven streams).  The
-// emission touches nothing but the contig's own graph, so it is taken off the builder's critical path: the builder moves
-// on to its next contig at once and the emission runs as a task of its own in the next host phase.
-constexpr int kMaxGroups = 4;
-// Pipeline groups (see run_consensus): host phase | batches part 1 (sketches + index, seeds / chains / DP launch) | alignment
-// DP in flight | batches part 2.  (Measured and dropped: part 1 as two pipeline stages, a fifth group -- DESIGN.md.)
-static int n_groups(const nsgpu_ctx *c) { return (int)c->sched_groups; }
-
-struct FinishedContig {
-    std::unique_ptr<cons::ContigGraph> g;     // null once emitted
-    cons::StreamSet out;
-    double write_ms = 0, free_ms = 0;
-};
-
-struct Builder {
-    enum State { NEED_CONTIG, ADVANCE, WAIT_FILTER, WAIT_ALIGN, GOT_FILTER, ALIGNED, GOT_ALIGN, DONE };
-    State st = NEED_CONTIG;
-    uint32_t id = 0, gid = 0;                 // local index / global builder id
-    int group = 0;                            // pipeline group (a function of gid only, so that it does not depend on the rank count)
-    std::unique_ptr<cons::ContigGraph> g;
-    read_t cursor = 0;
-    // contig walk (src/Consensus.cpp:51-95)
-    ssize_t init_start = 0, len = 0, cur_pos = 0;
-    bool right_phase = true, edges_too_many = false, window_open = false;
-    // window
-    std::string win[2];
-    std::vector<read_t> cand[2];
-    int strand = 0;
-    size_t ci = 0;
-    bool strand_counted = false;
-    // pending alignment
-    read_t pend = 0;
-    std::string query;
-    mm2::AlnOut aln;
-    bool accepted = false;
-    bool early_updated = false, early_result = false;      // the graph was updated / the result taken over ahead of the slot's end (engine_early_updates)
-    // cached index of the current main path
-    mm2::RefIndex idx;
-    bool idx_valid = false;
-    bool sp_ready = false;               // plan_splice has run for the consensus as it is now (right behind the update, on the thread that made it)
-    // incremental consensus sketch: the minimizers of mz_str (the main path they were computed for).  When the path changes only the
-    // stretch that differs (+ a margin on both sides) is sketched again and spliced in -- see engine_batches_sketch
-    std::vector<mm2::Anchor> mz;
-    std::string mz_str;
-    struct Splice { bool full = true, have_common = false; size_t a = 0, B_sub = 0, A = 0, B = 0, P = 0, S = 0, cp = 0, cs = 0; ssize_t delta = 0; } sp;      // P / S: common prefix / suffix with the string before
-    // the contig's consensus resident in HBM (what the plan kernel gathers the DP targets from): main_path as of the last alignment batch the
-    // builder was in, at [dc_beg, dc_beg + dc_len) of d_cons -- room on both sides, a contig grows at its ends (cons_update_kernel)
-    DevBuf d_cons;
-    size_t dc_beg = 0, dc_len = 0;
-    bool dc_valid = false;
-    // the contig's minimizer list resident in HBM (what the seeding kernel reads): mz[0 .. d_mz_n) as of the last upload.  After a splice only
-    // the entries from the first changed one on travel (a contig grows at its ends: a few hundred entries of tens of thousands).
-    DevBuf d_mz;
-    size_t d_mz_n = 0;
-    size_t chg_lb = 0;                         // the main path agrees with mz_str (and idx's base codes) on [0, chg_lb): from ContigGraph::path_changed_from
-    std::vector<std::unique_ptr<FinishedContig>> contigs;     // in the order they were finished = output order
-    size_t n_queued = 0;                                      // contigs[0 .. n_queued) were handed to the emission queue
-    uint64_t n_minhash = 0, n_minhash_new = 0, n_aligner = 0, n_align_calls = 0, n_contigs = 0, n_lone = 0;
-    double last_u = 0, last_m = 0;
-    double cpu_ms = 0, max_ms = 0, last_ms = 0, write_ms = 0, dbg_w1 = 0, dbg_w2 = 0, dbg_w3 = 0, dbg_u = 0, dbg_m = 0, dbg_cyc = 0, dbg_init = 0, dbg_rc = 0, dbg_win = 0, dbg_start = 0, dbg_max_u = 0, dbg_max_m = 0, dbg_long_ms = 0;
-    uint64_t dbg_long_n = 0;
-    uint64_t dbg_c[6] = {0, 0, 0, 0, 0, 0};
-};
-
-struct Driver {
-    nsgpu_ctx *c;
-    uint32_t N, id_base = 0;
-    uint64_t edge_thr;
-    size_t offset;                     // avgReadLen / 4 (src/Consensus.cpp:54)
-    std::vector<uint8_t> in_graph, rep;
-    std::vector<Builder> B;
-
-    // read r as ReadData::getRead returns it; with the packed host mirror decoded into a per-thread buffer (valid until the thread's next call)
-    const char *read_ptr(read_t r) const { static thread_local std::string buf; return mirror_read(c, r, buf); }
-    size_t read_len(read_t r) const { return (size_t)(c->h_off[r + 1] - c->h_off[r]); }
-
-    // createGraph (src/Consensus.cpp:388-403) for the seed read r the builder was granted
-    void start_contig(Builder &b, read_t r)
-    {
-        const double s0 = now_ms();
-        start_contig_inner(b, r);
-        b.dbg_start += now_ms() - s0;
-    }
-    void start_contig_inner(Builder &b, read_t r)
-    {
-        b.g.reset(new cons::ContigGraph());
-        b.g->main_path.assign(read_ptr(r), read_len(r));
-        b.g->start_pos = 0;
-        b.g->end_pos = (ssize_t)read_len(r);
-        b.g->first_read = r + id_base;       // graph / stream ids are global, array indices local
-        b.cursor = r + 1;
-        b.init_start = 0;
-        b.len = b.g->end_pos - b.g->start_pos;
-        b.cur_pos = b.g->start_pos;
-        b.right_phase = true, b.edges_too_many = false, b.window_open = false;
-        b.idx_valid = false, b.sp_ready = false;
-        b.mz.clear(), b.mz_str.clear();          // a new consensus: nothing to splice into
-        b.chg_lb = 0;
-        b.d_mz_n = 0;                            // (the resident list's memory stays with the builder)
-        b.dc_valid = false;
-        b.st = Builder::ADVANCE;
-    }
-
-    void finish_contig(Builder &b)
-    {
-        cons::ContigGraph &g = *b.g;
-        std::unique_ptr<FinishedContig> fc(new FinishedContig());
-        if (g.num_reads() == 0) {
-            g.write_read_lone(fc->out);
-            fc->out.lone_ids.push_back(g.first_read);
-            fc->out.reads_in_contig.push_back(1);
-            ++b.n_lone;
-            b.g.reset();
-        } else {
-            b.dbg_cyc += g.dbg_cycles_ms;
-            b.dbg_c[0] += g.dbg_cycles_calls, b.dbg_c[1] += g.dbg_cycles_skipped, b.dbg_c[2] += g.dbg_spliced, b.dbg_c[3] += g.dbg_cycles_idle, b.dbg_c[4] += g.dbg_walked_nodes, b.dbg_c[5] += g.dbg_cycles_listed;
-            fc->g = std::move(b.g);
-        }
-        b.contigs.push_back(std::move(fc));
-        ++b.n_contigs;
-        b.st = Builder::NEED_CONTIG;
-    }
-    // edit emission of one finished contig (ConsensusGraph::writeMainPath + writeReads, src/ConsensusGraph.cpp:979-1012)
-    void emit_contig(FinishedContig &fc)
-    {
-        if (!fc.g) return;
-        const double t0 = now_ms();
-        cons::ContigGraph &g = *fc.g;
-        g.write_main_path(fc.out);
-        const std::function<cons::ReadBases(cons::read_t)> src = [this](cons::read_t id) {
-            const read_t r = id - id_base;
-            return cons::ReadBases{read_ptr(r), read_len(r)};
-        };
-        g.write_reads(fc.out, &src);
-        fc.out.reads_in_contig.push_back((read_t)g.num_reads());
-        const double t1 = now_ms();
-        fc.g.reset();
-        fc.write_ms = t1 - t0, fc.free_ms = now_ms() - t1;
-    }
-
-    // opens the window at cur_pos (addRelatedReads prologue, src/Consensus.cpp:168-184); false = nothing to query
-    bool open_window(Builder &b)
-    {
-        const double w0 = now_ms();
-        const bool r = open_window_inner(b);
-        b.dbg_win += now_ms() - w0;
-        return r;
-    }
-    bool open_window_inner(Builder &b)
-    {
-        cons::ContigGraph &g = *b.g;
-        const ssize_t off = b.cur_pos - g.start_pos;
-        if (b.len == 0 || off < 0 || off >= (ssize_t)g.main_path.size()) return false;
-        const size_t n = (ssize_t)g.main_path.size() >= off + b.len ? (size_t)b.len : g.main_path.size() - (size_t)off;
-        b.win[0].assign(g.main_path, (size_t)off, n);
-        cons::reverse_complement(b.win[0], b.win[1]);
-        b.strand = 0, b.ci = 0, b.strand_counted = false;
-        b.window_open = true;
-        b.st = Builder::WAIT_FILTER;
-        return true;
-    }
-
-    // the two while loops of generateAndWriteConsensus as a resumable walk; returns when a window was
-    // opened (state WAIT_FILTER) or the contig is finished (state NEED_CONTIG)
-    void walk(Builder &b, bool window_just_done)
-    {
-        cons::ContigGraph &g = *b.g;
-        const bool usable = b.len >= 32 && !rep[g.first_read - id_base];
-        for (;;) {
-            if (b.right_phase) {
-                if (window_just_done) {
-                    b.cur_pos += (ssize_t)offset;
-                    window_just_done = false;
-                    if (b.cur_pos + b.len > g.end_pos) b.right_phase = false;
-                    else if (g.num_edges() >= edge_thr) b.edges_too_many = true, b.right_phase = false;
-                    if (!b.right_phase) { b.cur_pos = b.init_start - (ssize_t)offset; continue; }
-                }
-                if (!usable) { b.right_phase = false; b.cur_pos = b.init_start - (ssize_t)offset; continue; }
-                if (open_window(b)) return;
-                window_just_done = true;         // addRelatedReads returned immediately
-            } else {
-                if (window_just_done) { b.cur_pos -= (ssize_t)offset; window_just_done = false; }
-                if (!(usable && !b.edges_too_many)) break;
-                if (b.cur_pos < g.start_pos) break;
-                if (g.num_edges() >= edge_thr) { b.edges_too_many = true; break; }
-                if (open_window(b)) return;
-                window_just_done = true;
-            }
-        }
-        finish_contig(b);
-    }
-
-    // candidate loop of addRelatedReads (src/Consensus.cpp:185-246) up to the next alignment request
-    void next_candidate(Builder &b)
-    {
-        cons::ContigGraph &g = *b.g;
-        for (; b.strand < 2; ++b.strand, b.ci = 0, b.strand_counted = false) {
-            if (!b.strand_counted) { b.n_minhash += b.cand[b.strand].size(); b.strand_counted = true; }
-            for (; b.ci < b.cand[b.strand].size(); ++b.ci) {
-                const read_t r = b.cand[b.strand][b.ci];
-                if (g.num_edges() >= edge_thr) { b.window_open = false; walk(b, true); return; }   // `return` out of addRelatedReads
-                if (rep[r]) continue;
-                if (in_graph[r]) continue;
-                ++b.n_minhash_new;
-                if (read_len(r) < 32) continue;
-                const double r0 = now_ms();
-                if (b.strand) cons::reverse_complement(read_ptr(r), read_len(r), b.query);
-                else b.query.assign(read_ptr(r), read_len(r));
-                b.dbg_rc += now_ms() - r0;
-                b.pend = r;
-                b.st = Builder::WAIT_ALIGN;
-                return;
-            }
-        }
-        b.window_open = false;
-        walk(b, true);
-    }
-
-    // parallel phase: consume what the last round delivered and run to the next request
-    void advance(Builder &b)
-    {
-        if (b.st != Builder::ADVANCE && b.st != Builder::GOT_FILTER && b.st != Builder::GOT_ALIGN) return;
-        const double t0 = now_ms();
-        advance_inner(b);
-        const double dt = now_ms() - t0;
-        b.cpu_ms += dt;
-        b.last_ms = dt;
-        if (dt > b.max_ms) b.max_ms = dt;
-        if (dt > 3.0) ++b.dbg_long_n, b.dbg_long_ms += dt;
-    }
-    void advance_inner(Builder &b)
-    {
-        if (b.st == Builder::ADVANCE) walk(b, false);
-        else if (b.st == Builder::GOT_FILTER) next_candidate(b);
-        else if (b.st == Builder::GOT_ALIGN) {
-            if (b.accepted) {
-                if (!b.early_updated) apply_alignment(b);
-                b.early_updated = false;
-                b.accepted = false;
-            }
-            ++b.ci;
-            next_candidate(b);
-        }
-    }
-    // the accepted read into the contig's graph, the new consensus (src/Consensus.cpp:319-331).  Touches nothing but the builder's own graph:
-    // the engine may run it as soon as the alignment is there and its claim cannot fail (engine_early_updates), ahead of the host phase.
-    void apply_alignment(Builder &b)
-    {
-        cons::ContigGraph &g = *b.g;
-        if (g.num_reads() == 0) {                       // src/Consensus.cpp:319-324
-            const double i0 = now_ms();
-            const std::string seed = g.main_path;
-            g.main_path.clear();
-            g.initialize(seed, g.first_read, 0);
-            g.calculate_main_path_greedy();
-            b.chg_lb = 0;
-            b.dbg_init += now_ms() - i0;
-        }
-        const double u0 = now_ms();
-        g.update_graph(b.query, b.aln.edits, (ssize_t)b.aln.begin_offset, (ssize_t)b.aln.end_offset, b.pend + id_base, (long)b.aln.rel_pos, b.strand == 1);
-        const double u1 = now_ms();
-        g.calculate_main_path_greedy();
-        if (g.path_changed_from < b.chg_lb) b.chg_lb = g.path_changed_from;
-        g.path_changed_from = (size_t)-1;
-        const double u2 = now_ms();
-        b.dbg_u += u1 - u0, b.dbg_m += u2 - u1;
-        b.last_u = u1 - u0, b.last_m = u2 - u1;
-        if (u1 - u0 > b.dbg_max_u) b.dbg_max_u = u1 - u0;
-        if (u2 - u1 > b.dbg_max_m) b.dbg_max_m = u2 - u1;
-        b.idx_valid = false, b.sp_ready = false;
-    }
-};
-
-// ---------------------------------------------------------------------------
-// The engine as resumable phases.  A single process (nsgpu_consensus_run) and a multi-GPU job
-// (one process per GPU, nanospring_amd/dist.py) run the SAME phases; in the multi-GPU job every rank
-// holds all reads and the whole bucket index (replicated by all-gather), owns the builders with
-// gid % world == rank, and the two kinds of claims are resolved on a replicated in_graph[] from
-// all-gathered request lists, strictly in global builder order -- so the result does not depend on
-// the number of ranks.
-// ---------------------------------------------------------------------------
-// lists of a batch: per builder the tail that changed goes from the pinned staging buffer into the contig's resident list
-struct TailCopy { const mm2::Anchor *src; mm2::Anchor *dst; uint32_t n; uint32_t pad; };
-// cons_update_kernel's job: see there
-struct ConsJob { uint8_t *buf; const uint8_t *mid; uint64_t beg_old, len_old, beg_new, len_new, P, S; uint32_t full, pad; };
-
-
-struct Engine {
-    Driver D;
-    uint32_t rank = 0, world = 1, n_total = 0;     // global builder count
-    uint64_t n_done_global = 0;
-    double t0 = 0;
-    std::string qbuf;
-    std::vector<uint64_t> qoff, foff;
-    std::vector<uint32_t> fids;
-    double p1_align_ms = 0, p1_host_ms = 0, p1_launch_ms = 0;
-    uint64_t slot_long_n[4] = {0, 0, 0, 0};
-    double slot_long_ms[4] = {0, 0, 0, 0};
-    double g1_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // one-group schedule, wall time of a slot's steps (debug report)
-    uint64_t role_serial_ns[4] = {0, 0, 0, 0};
-    std::vector<FinishedContig *> emit_queue;      // finished contigs whose emission has not run yet
-    // Scratch of one alignment batch in the making (engine_batches_sketch .. engine_align_finish).  One per batch that can be in flight at a
-    // time: a group's (index = group; one group: index 0).
-    struct Lane {
-        std::vector<uint32_t> who;
-        std::vector<uint64_t> mz_off;                   // minimizer offsets of the sketch batch
-        std::vector<SketchReq> sk_reqs;                 // requests of a sketch batch: changed consensus stretches, then the candidates
-        std::vector<uint32_t> sk_ref;                   // per builder of the batch: its consensus request (~0u: consensus unchanged)
-        std::vector<uint64_t> stage_off;                // offsets of the builders' consensus minimizer lists in the seeding kernel's staging buffer
-        std::vector<size_t> tail_from;                  // per builder of the batch: first list entry that travels this time
-        std::vector<TailCopy> tail_jobs;
-        PinBuf pin_tail;                                // the scatter kernel's job descriptors
-        std::vector<uint8_t> cons_changed;              // per builder of the batch: its consensus changed since the batch before
-        std::vector<ConsJob> cons_jobs;
-        PinBuf pin_cons;                                // cons_update_kernel's job descriptors
-        hipStream_t cons_stream = nullptr; hipEvent_t cons_ev = nullptr;
-        std::vector<char> cons_check;                   // NSGPU_CONS_CHECK: a device copy read back
-        std::vector<DevBuf> retired;                    // resident lists replaced by larger ones, freed at the lane's next batch
-        std::vector<mm2::AlnOut> outs;
-        std::vector<uint8_t> early_sure;                // per request: its claim cannot fail (engine_early_updates)
-        std::vector<const uint8_t *> staged;            // per request: the changed stretch's text in device memory (cons_update_kernel's source)
-            double sk_ms[6] = {0, 0, 0, 0, 0, 0};           // engine_batches_sketch: splice plan, requests, sketch call, index loop, enqueue of seeds..DP, wait + first step
-        int sketch_ws = 0;                              // mm_sketch workspace of the lane's batches
-        void release()
-        {
-            for (DevBuf &d : retired) d.release();
-            retired.clear();
-            pin_tail.release(), pin_cons.release();
-            if (cons_stream) { (void)hipStreamSynchronize(cons_stream); (void)hipStreamDestroy(cons_stream); (void)hipEventDestroy(cons_ev); cons_stream = nullptr; }
-        }
-    } lane[kMaxGroups];
-    std::vector<uint32_t> global_pends;             // several ranks, one-group schedule: the reads ALL ranks' builders align in this slot, sorted (run_consensus_dist)
-    bool have_global_pends = false;
-    std::vector<uint32_t> early_pends; std::vector<int32_t> early_widx; std::vector<int8_t> early_lane;      // scratch of engine_early_updates
-    double early_part_ms[2] = {0, 0}, early_task_ms = 0, early_task_max_ms = 0, early_conv_ms = 0;     // debug report: wall of the two parts' loops, sum / per-slot maximum of their tasks, skeleton + conversion inside
-    uint64_t n_early = 0, n_early_retry = 0; double early_ms = 0;      // (retry: a status word seen before all of its data, ksw_collect.hpp)       // graph updates run ahead of the slot's end / wall of that (debug print)
-    double crit_u_ms = 0, crit_m_ms = 0;              // sum over host phases of the slowest update_graph / main-path recompute (debug print)
-    std::vector<uint32_t> dbg_batch_sizes;          // alignments per batch, in order (debug print: how full the slots are over the run)
-    uint64_t n_wq_exact = 0;                          // window-query batches that went the exact multi-step way
-    int deferred_fresh = -1;                          // group whose freshly started contigs take their first steps with the next host phase
-    AlignBatch ab[kMaxGroups];                        // alignment batch of each group, DP kernels in flight between part 1 and part 2
-    std::vector<uint32_t> fwho;                    // builders of the window-query batch
-    std::vector<uint32_t> awho[kMaxGroups];           // builders of that batch
-    Builder *local(uint32_t gid) { return gid % world == rank ? &D.B[gid / world] : nullptr; }
-    // ---- conflict-aware seeds (nsgpu_set_schedule; SURVEY 8e "assign seed reads by MinHash bucket locality") ----
-    // Reads are grouped once into buckets of the whole-read filter graph (x -- y when y is a filter result of x or of its reverse
-    // complement, nsgpu_filter_all_reads): in id order every read without a bucket opens one and takes every bucketless read within
-    // `depth` hops (breadth first).  Buckets are adjacent when an edge joins them.  A contig in flight occupies the buckets of its seed
-    // and of every read it claimed; a seed must lie in a bucket that is neither occupied nor within `rings` adjacency steps of an
-    // occupied one, and the lowest unclaimed read that qualifies is taken, by the waiting builders in global builder order.  A builder
-    // that finds none although unclaimed reads exist asks again at its group's next slot.  All of it is a function of replicated data.
-    struct SeedPolicy {
-        uint32_t depth = 0, rings = 1, tail_rings = 1;        // tail_rings: the exclusion radius while more than half of all builders are waiting for a seed
-        uint32_t rings_now = 1;
-        std::vector<uint32_t> bucket_of;                 // read -> bucket
-        // the filter's answer to every whole read, both strands (what the buckets are built from): kept, because a fresh contig's first window
-        // IS its seed read -- that query need not go to the GPU again (engine_window_queries)
-        std::vector<uint64_t> wr_off; std::vector<uint32_t> wr_ids;
-        std::vector<uint64_t> adj_off; std::vector<uint32_t> adj;     // bucket adjacency (CSR, ascending, without itself)
-        std::vector<uint64_t> bk_off; std::vector<uint32_t> bk_reads; // reads of every bucket, ascending
-        std::vector<uint32_t> bk_next;                   // per bucket: index into its reads of the first one not known to be claimed
-        std::vector<uint32_t> occ;                       // per bucket: members of contigs in flight
-        std::vector<std::vector<uint32_t>> members;      // per GLOBAL builder: seed + claimed reads of its contig in flight
-        uint64_t n_unclaimed = 0, n_idle = 0;
-        uint64_t n_filter_results = 0; bool have_wr = false;      // whole_read_filter has run for this stage (wr_off / wr_ids hold its answers)
-        std::vector<uint8_t> blocked;                    // scratch of a seed round: bucket within `rings` steps of an occupied one
-        std::vector<uint32_t> q_cur, q_nxt, stamp;
-        uint32_t epoch = 0;
-        // marks every bucket within `rings` adjacency steps of the buckets in q_cur (a breadth-first walk of its own: a bucket that is
-        // already blocked from elsewhere may still be a step on the way)
-        void spread()
-        {
-            if (stamp.size() != blocked.size()) stamp.assign(blocked.size(), 0), epoch = 0;
-            ++epoch;
-            for (uint32_t x : q_cur) stamp[x] = epoch, blocked[x] = 1;
-            for (uint32_t d = 0; d < rings_now && !q_cur.empty(); ++d) {
-                q_nxt.clear();
-                for (uint32_t x : q_cur)
-                    for (uint64_t i = adj_off[x]; i < adj_off[x + 1]; ++i) if (stamp[adj[i]] != epoch) { stamp[adj[i]] = epoch; blocked[adj[i]] = 1; q_nxt.push_back(adj[i]); }
-                q_cur.swap(q_nxt);
-            }
-        }
-    } sp;
-};
-
 static void engine_free(void *p)
 {
     pool_drain();                                     // no emission task may outlive the engine
@@ -435,35 +29,8 @@ static void engine_free(void *p)
     delete E;
 }
 
-static int seed_policy_init(nsgpu_ctx *c, Engine *E);
-static int whole_read_filter(nsgpu_ctx *c, Engine *E);
 
-// ---- the schedule derived from the input (nsgpu_set_schedule_auto; nsgpu_consensus_run with 0 builders) ---------------------------------
-// The reference has one knob, -t (src/main.cpp:46-78), and its streams grow with it: contigs that grow at the same time cut each other short.
-// This library's knobs -- builders, groups, the seed rule's bucket depth and radii -- trade the same thing, and the right values differ per
-// input (cfg2's on cfg3: 19 Mbases/s instead of 80).  What the library knows after nsgpu_build_index decides them:
-//   * coverage, from the whole-read filter results per read r (both strands, the read itself included; r = 12 at 20x, 120 at 217x): a deep
-//     read set over a small genome has few places for contigs to grow apart, so the buckets must be small (depth 1) for the exclusion radius
-//     not to block the whole genome, while a shallow one over a large genome wants depth 3 / 5 rings;
-//   * the input size: every builder beyond the first costs ~80 kB of streams (one more contig boundary now and then); 1 builder per 10 Mbases
-//     keeps that within 5 % of the streams the reference's own -t 8 writes, but never fewer than the seed rule can keep busy.
-// One group: with this few builders a slot is as long as its GPU round trips.  A function of replicated values only: every rank of a
-// multi-GPU job derives the same schedule.  tests/oracle_lib.py auto_schedule restates the rule for the lock-step oracle.
-struct AutoSchedule { uint32_t builders, depth, rings, tail; };
-static AutoSchedule auto_schedule(uint64_t n_reads, uint64_t n_bases, uint64_t n_filter_results)
-{
-    const double r = n_reads ? (double)n_filter_results / (double)n_reads : 0.0;
-    AutoSchedule a;
-    uint64_t b_min;
-    if (r < 30.0) a.depth = 3, a.rings = 5, a.tail = 3, b_min = 32;
-    else if (r < 70.0) a.depth = 2, a.rings = 4, a.tail = 3, b_min = 96;
-    else a.depth = 1, a.rings = 4, a.tail = 3, b_min = 128;
-    const uint64_t b = std::min<uint64_t>(1024, std::max<uint64_t>(b_min, n_bases / 10000000ull));
-    a.builders = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(b, n_reads ? n_reads : 1));
-    return a;
-}
-
-static int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, uint32_t world)
+int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, uint32_t world)
 {
     NS_CHECK(c->have_index && c->have_salts, NSGPU_ERR_ARG, "consensus: call nsgpu_sketch and nsgpu_build_index first");
     const bool auto_now = c->sched_auto || (n_builders_total == 0 && !c->sched_set);
@@ -514,10 +81,9 @@ static int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, 
 }
 
 // phase 1/3: consume deliveries and run every local builder to its next request
-static inline bool in_group(const Builder &b, int group) { return group < 0 || b.group == group; }
 
 static void plan_splice(Builder &b, int w, int k);
-static void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
+void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     Driver &D = E->D;
@@ -548,166 +114,6 @@ static void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
     for (Builder &b : D.B) if (in_group(b, group)) { if (b.last_ms > mx) mx = b.last_ms; b.last_ms = 0; if (b.last_u > mxu) mxu = b.last_u; if (b.last_m > mxm) mxm = b.last_m; b.last_u = b.last_m = 0; }
     c->cons_stats.graph_crit_ms += mx;       // sum over phases of the slowest builder step: the floor of the phase wall
     E->crit_u_ms += mxu, E->crit_m_ms += mxm;
-}
-
-// phase 2: (gid, cursor) of every local builder that needs a new contig
-static void engine_seed_requests(nsgpu_ctx *c, std::vector<uint32_t> &gids, std::vector<uint32_t> &cursors, int group)
-{
-    Engine *E = static_cast<Engine *>(c->cons_engine);
-    gids.clear(); cursors.clear();
-    for (Builder &b : E->D.B) if (in_group(b, group) && b.st == Builder::NEED_CONTIG) { gids.push_back(b.gid); cursors.push_back(b.cursor); }
-}
-
-// resolve the seed requests of ALL ranks on the replicated in_graph[], in global builder order
-// (Consensus::getRead + createGraph, src/Consensus.cpp:388-403, 444-468); returns how many builders started a contig
-static uint32_t engine_seed_resolve(nsgpu_ctx *c, const uint32_t *gids, const uint32_t *cursors, uint32_t n)
-{
-    Engine *E = static_cast<Engine *>(c->cons_engine);
-    Driver &D = E->D;
-    std::vector<uint32_t> ord(n);
-    for (uint32_t i = 0; i < n; ++i) ord[i] = i;
-    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return gids[a] < gids[b]; });
-    uint32_t started = 0;
-    Engine::SeedPolicy &P = E->sp;
-    if (P.depth) {
-        // conflict-aware seeds (see Engine::SeedPolicy): the contigs the waiting builders finished leave the occupancy, then the free
-        // buckets' lowest unclaimed reads are handed out in ascending read order to the builders in global builder order
-        for (uint32_t k = 0; k < n; ++k) {
-            std::vector<uint32_t> &m = P.members[gids[ord[k]]];
-            for (uint32_t x : m) --P.occ[P.bucket_of[x]];
-            m.clear();
-        }
-        // towards the end of a run most builders wait while a few contigs close the last gaps: when more than half of ALL builders ask for a
-        // seed in one round, the exclusion radius drops to tail_rings -- a seed in such a gap is one more contig, and halves what is left of it
-        P.rings_now = 2ull * n > E->n_total ? P.tail_rings : P.rings;
-        std::vector<std::pair<uint32_t, uint32_t>> cand;          // (lowest unclaimed read, bucket) of every bucket a seed may lie in
-        const uint32_t nb = (uint32_t)P.occ.size();
-        if (P.n_unclaimed) {
-            P.blocked.assign(nb, 0);
-            P.q_cur.clear();
-            for (uint32_t b = 0; b < nb; ++b) if (P.occ[b]) P.q_cur.push_back(b);
-            P.spread();
-            for (uint32_t b = 0; b < nb; ++b) {
-                if (P.blocked[b]) continue;
-                uint32_t &i = P.bk_next[b];
-                const uint32_t cnt = (uint32_t)(P.bk_off[b + 1] - P.bk_off[b]);
-                while (i < cnt && D.in_graph[P.bk_reads[P.bk_off[b] + i]]) ++i;
-                if (i < cnt) cand.emplace_back(P.bk_reads[P.bk_off[b] + i], b);
-            }
-        }
-        std::sort(cand.begin(), cand.end());
-        size_t ci = 0;
-        for (uint32_t k = 0; k < n; ++k) {
-            const uint32_t gid = gids[ord[k]];
-            Builder *b = E->local(gid);
-            if (P.n_unclaimed == 0) { ++E->n_done_global; if (b) b->st = Builder::DONE; continue; }
-            while (ci < cand.size() && P.blocked[cand[ci].second]) ++ci;                    // an earlier grant of this round came too close
-            if (ci == cand.size()) { ++P.n_idle; continue; }                                  // asks again at its group's next slot
-            const read_t r = cand[ci].first;
-            const uint32_t bk = cand[ci].second;
-            ++ci;
-            D.in_graph[r] = 1;
-            --P.n_unclaimed;
-            P.members[gid].push_back(r);
-            ++P.occ[bk];
-            P.q_cur.assign(1, bk);
-            P.spread();
-            ++started;
-            if (b) D.start_contig(*b, r);
-        }
-        return started;
-    }
-    for (uint32_t k = 0; k < n; ++k) {
-        const uint32_t gid = gids[ord[k]];
-        read_t r = cursors[ord[k]];
-        while (r < D.N && D.in_graph[r]) ++r;
-        Builder *b = E->local(gid);
-        if (r >= D.N) { ++E->n_done_global; if (b) b->st = Builder::DONE; continue; }
-        D.in_graph[r] = 1;
-        ++started;
-        if (b) D.start_contig(*b, r);
-    }
-    return started;
-}
-
-// the buckets of the conflict-aware seed rule (Engine::SeedPolicy), from the whole-read filter results of every read
-// the filter's answer to every whole read, both strands (the edges of the graph the seed buckets are built on; their number per read is what
-// the automatic schedule reads the coverage from): into P.wr_off / P.wr_ids
-static int whole_read_filter(nsgpu_ctx *c, Engine *E)
-{
-    Engine::SeedPolicy &P = E->sp;
-    const uint32_t N = E->D.N;
-    if (P.have_wr) return NSGPU_OK;
-    uint64_t n_cand = 0;
-    if (!c->have_sketch) {
-        // a rank of a multi-GPU job whose tables came from the all-to-all holds the sketch rows of its own id range only: the whole-read
-        // queries need every row, and sketching all reads here (milliseconds) is cheaper than another exchange -- same rows on every rank
-        NS_CHECK(c->have_salts, NSGPU_ERR_ARG, "consensus: no salts");
-        NS_TRY(c->sketch.reserve(((size_t)N * c->prm.n + 1) * 8));
-        NS_TRY(launch_sketch(c, c->reads, c->sketch.as<uint64_t>(), nullptr));
-        NS_HIP(stream_wait(c->stream));
-        c->have_sketch = true;
-    }
-    NS_TRY(nsgpu_filter_all_reads(c, &n_cand));
-    P.wr_off.assign(2 * (size_t)N + 1, 0);
-    P.wr_ids.assign(n_cand + 1, 0);
-    NS_TRY(nsgpu_filter_all_fetch(c, P.wr_off.data(), P.wr_ids.data()));
-    c->have_filter_all = false;                                     // the engine's window queries reuse the device buffers
-    P.n_filter_results = n_cand, P.have_wr = true;
-    return NSGPU_OK;
-}
-
-static int seed_policy_init(nsgpu_ctx *c, Engine *E)
-{
-    Engine::SeedPolicy &P = E->sp;
-    Driver &D = E->D;
-    P.depth = c->seed_bucket_depth, P.rings = c->seed_rings, P.tail_rings = std::min(c->seed_tail_rings, c->seed_rings), P.rings_now = P.rings;
-    if (!P.depth) { P.wr_off.clear(), P.wr_ids.clear(); return NSGPU_OK; }
-    const uint32_t N = D.N;
-    NS_TRY(whole_read_filter(c, E));
-    const uint64_t n_cand = P.n_filter_results;
-    const std::vector<uint64_t> &off = P.wr_off;
-    const std::vector<uint32_t> &ids = P.wr_ids;
-    P.bucket_of.assign(N, ~0u);
-    uint32_t nb = 0;
-    std::vector<uint32_t> cur, nxt;
-    for (uint32_t r = 0; r < N; ++r) {
-        if (P.bucket_of[r] != ~0u) continue;
-        const uint32_t b = nb++;
-        P.bucket_of[r] = b;
-        cur.assign(1, r);
-        for (uint32_t d = 0; d < P.depth && !cur.empty(); ++d) {
-            nxt.clear();
-            for (uint32_t x : cur)
-                for (uint64_t i = off[2 * (size_t)x]; i < off[2 * (size_t)x + 2]; ++i) { const uint32_t y = ids[i]; if (P.bucket_of[y] == ~0u) { P.bucket_of[y] = b; nxt.push_back(y); } }
-            cur.swap(nxt);
-        }
-    }
-    std::vector<std::vector<uint32_t>> adj(nb);
-    for (uint32_t x = 0; x < N; ++x)
-        for (uint64_t i = off[2 * (size_t)x]; i < off[2 * (size_t)x + 2]; ++i) {
-            const uint32_t bx = P.bucket_of[x], by = P.bucket_of[ids[i]];
-            if (bx != by) { adj[bx].push_back(by); adj[by].push_back(bx); }
-        }
-    P.adj_off.assign(nb + 1, 0);
-    P.adj.clear();
-    for (uint32_t b = 0; b < nb; ++b) {
-        std::sort(adj[b].begin(), adj[b].end());
-        adj[b].erase(std::unique(adj[b].begin(), adj[b].end()), adj[b].end());
-        P.adj.insert(P.adj.end(), adj[b].begin(), adj[b].end());
-        P.adj_off[b + 1] = P.adj.size();
-    }
-    P.bk_off.assign(nb + 1, 0);
-    for (uint32_t r = 0; r < N; ++r) ++P.bk_off[P.bucket_of[r] + 1];
-    for (uint32_t b = 0; b < nb; ++b) P.bk_off[b + 1] += P.bk_off[b];
-    P.bk_reads.resize(N);
-    { std::vector<uint64_t> fill(P.bk_off.begin(), P.bk_off.end() - 1); for (uint32_t r = 0; r < N; ++r) P.bk_reads[fill[P.bucket_of[r]]++] = r; }
-    P.bk_next.assign(nb, 0);
-    P.occ.assign(nb, 0);
-    P.members.assign(E->n_total, std::vector<uint32_t>());
-    P.n_unclaimed = N;
-    if (getenv("NSGPU_CONS_DEBUG")) fprintf(stderr, "[cons] seed policy: %u buckets of depth %u over %u reads (%llu filter results), rings %u\n", nb, P.depth, N, (unsigned long long)n_cand, P.rings);
-    return NSGPU_OK;
 }
 
 // phases 4+5: window queries and alignments of the local builders (GPU batches); no claims yet
@@ -1436,41 +842,14 @@ static int engine_batches_finish(nsgpu_ctx *c, int group)
     return engine_align_finish(c, group);
 }
 
-static int engine_batches(nsgpu_ctx *c, int group)
+int engine_batches(nsgpu_ctx *c, int group)
 {
     NS_TRY(engine_batches_sketch(c, group, 1));
     NS_TRY(engine_batches_begin(c, group, 1));
     return engine_batches_finish(c, group);
 }
 
-// phase 6a: (gid, read) of every local builder whose alignment succeeded
-static void engine_claim_requests(nsgpu_ctx *c, std::vector<uint32_t> &gids, std::vector<uint32_t> &reads, int group)
-{
-    Engine *E = static_cast<Engine *>(c->cons_engine);
-    gids.clear(); reads.clear();
-    for (Builder &b : E->D.B) if (in_group(b, group) && b.st == Builder::ALIGNED && b.aln.ok) { gids.push_back(b.gid); reads.push_back(b.pend); }
-}
-
-// phase 6b: claims of ALL ranks, strictly in global builder order (src/Consensus.cpp:256-277 without lock contention)
-static void engine_claim_resolve(nsgpu_ctx *c, const uint32_t *gids, const uint32_t *reads, uint32_t n)
-{
-    Engine *E = static_cast<Engine *>(c->cons_engine);
-    Driver &D = E->D;
-    std::vector<uint32_t> ord(n);
-    for (uint32_t i = 0; i < n; ++i) ord[i] = i;
-    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return gids[a] < gids[b]; });
-    for (uint32_t k = 0; k < n; ++k) {
-        const uint32_t gid = gids[ord[k]], r = reads[ord[k]];
-        if (r >= D.N || D.in_graph[r]) continue;
-        D.in_graph[r] = 1;
-        if (E->sp.depth) { E->sp.members[gid].push_back(r); ++E->sp.occ[E->sp.bucket_of[r]]; --E->sp.n_unclaimed; }
-        if (Builder *b = E->local(gid)) { b->accepted = true; ++b->n_aligner; }
-    }
-    for (Builder &b : D.B) if (b.st == Builder::ALIGNED) b.st = Builder::GOT_ALIGN;
-    ++c->cons_stats.n_rounds;
-}
-
-static int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
+int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     NS_CHECK(E && n_threads_out >= 1, NSGPU_ERR_ARG, "consensus: nothing to finish");
@@ -1537,7 +916,7 @@ static int engine_g1_batches(nsgpu_ctx *c)
 // the group that was there one slot earlier, part 2 of group (slot + 1) % G -- whose DP launch has been in flight for a
 // slot -- all concurrently.
 // part: 0 = the whole slot; with ONE group the seeds are granted between the host phase (part 1) and the batches (part 2): see run_consensus
-static int engine_slot(nsgpu_ctx *c, uint32_t slot, int part = 0)
+int engine_slot(nsgpu_ctx *c, uint32_t slot, int part)
 {
     const uint32_t G = (uint32_t)n_groups(c);
     const int host_group = (int)(slot % G), begin_group = (int)((slot + G - 1) % G), finish_group = (int)((slot + 1) % G);
@@ -1644,7 +1023,7 @@ static int engine_slot(nsgpu_ctx *c, uint32_t slot, int part = 0)
 // ONE group: a window costs no slot of its own.  The builders that opened a window get their candidate lists at once and go on (to their
 // next alignment request, their next window, or the end of their contig) until nobody waits for a window any more: one GPU round trip per
 // pass, typically one pass.  Reads inGraph[] only.
-static int engine_window_loop(nsgpu_ctx *c, int group)
+int engine_window_loop(nsgpu_ctx *c, int group)
 {
     Engine *E = static_cast<Engine *>(c->cons_engine);
     for (;;) {
@@ -1656,103 +1035,8 @@ static int engine_window_loop(nsgpu_ctx *c, int group)
     }
 }
 
-// NSGPU_CONS_DEBUG: where the wall time of the slots went (printed once per stage, before the edit emission is waited for)
-static void debug_report_slots(nsgpu_ctx *c, Engine *E)
-{
-    fprintf(stderr, "[cons] batches wall-ms: window queries %.0f, sketch+index %.0f (gpu sketch %.0f), align begin %.0f (host loops %.0f, DP launch %.0f)\n", c->cons_stats.filter_ms,
-            c->cons_stats.index_ms, c->sketch_mm_ms, E->p1_align_ms, E->p1_host_ms, E->p1_launch_ms);
-    double chain_ms = 0;
-    for (AlignBatch &ab : E->ab) chain_ms += ab.chain_ms, ab.chain_ms = 0;
-    double sw = 0; uint64_t sn = 0, sp = 0, sf = 0;
-    for (nsgpu_ctx::SeedWs &w : c->seed_ws) sw += w.ms_wait, sn += w.calls, sp += w.pairs, sf += w.fallbacks, w.ms_wait = 0, w.calls = w.pairs = w.fallbacks = 0;
-    fprintf(stderr, "[cons] window-query batches redone the exact multi-step way (a buffer sized in advance did not fit): %llu\n", (unsigned long long)E->n_wq_exact);
-    fprintf(stderr, "[cons] DP launches by register class (cumulative; ms per launch x launches; wall of the DP phases %.0f ms):", c->ksw_kernel_ms);
-    for (int k = 0; k < 16; ++k) if (c->ksw_class_n[k]) fprintf(stderr, " [%d] %.3f x %llu", k, c->ksw_class_ms[k] / (double)c->ksw_class_n[k], (unsigned long long)c->ksw_class_n[k]);
-    fprintf(stderr, "\n");
-    fprintf(stderr, "[cons] alignments left to the host's plan, by reason (cumulative): no anchors / flagged pair %llu, several chains %llu, seed filtering %llu, outside the staged span %llu, capacity %llu, DP class %llu\n",
-            (unsigned long long)c->plan_why[0], (unsigned long long)c->plan_why[1], (unsigned long long)c->plan_why[2], (unsigned long long)c->plan_why[3], (unsigned long long)c->plan_why[4], (unsigned long long)c->plan_why[5]);
-    {
-        static const char *kind[5] = {"gap fill", "left ext (query >= target)", "right ext (query >= target)", "left ext (target longer)", "right ext (target longer)"};
-        static const char *wd[4] = {"<=256", "<=512", "<=1536", ">1536"};
-        fprintf(stderr, "[cons] alignments by their longest DP problem (anti-diagonals < 256 / 512 / 768 / 1024 / 1536 / 2048 / 3072 / more):\n");
-        for (int k = 0; k < 5; ++k) for (int w = 0; w < 4; ++w) {
-            uint64_t tot = 0; for (int b = 0; b < 8; ++b) tot += g_dp_shape[k][w][b];
-            if (!tot) continue;
-            fprintf(stderr, "[cons]   %-28s target %-6s:", kind[k], wd[w]);
-            for (int b = 0; b < 8; ++b) fprintf(stderr, " %llu", (unsigned long long)g_dp_shape[k][w][b]);
-            fprintf(stderr, "\n");
-        }
-    }
-    fprintf(stderr, "[cons] early tasks: loops of part 0 / part 1 %.0f / %.0f ms wall; tasks %.0f ms in sum (delivery + skeleton + conversion %.0f), the longest of each slot %.0f ms in sum\n",
-            E->early_part_ms[0], E->early_part_ms[1], E->early_task_ms, E->early_conv_ms, E->early_task_max_ms);
-    fprintf(stderr, "[cons] graph updates run ahead of the slot's end: %llu, %.0f ms wall (DP results + updates); status words seen ahead of their data: %llu\n", (unsigned long long)E->n_early, E->early_ms, (unsigned long long)E->n_early_retry);
-    fprintf(stderr, "[cons] device plan (cumulative): %llu alignments planned on the device, %llu left to the host; DP problems found %llu, not found %llu, unasked %llu\n",
-            (unsigned long long)c->plan_pairs_dev, (unsigned long long)c->plan_pairs_host, (unsigned long long)c->plan_hits, (unsigned long long)c->plan_misses, (unsigned long long)c->plan_extra);
-    fprintf(stderr, "[cons] index + seeds on the GPU: %llu launches, %llu pairs, wait %.0f ms wall; %llu pairs handed back to the host code\n", (unsigned long long)sn,
-            (unsigned long long)sp, sw, (unsigned long long)sf);
-    double cs = 0, ce = 0, cw = 0; uint64_t cn = 0;
-    for (nsgpu_ctx::ChainWs &w : c->cws) cs += w.ms_stage, ce += w.ms_enqueue, cw += w.ms_wait, cn += w.calls, w.ms_stage = w.ms_enqueue = w.ms_wait = 0, w.calls = 0;
-    fprintf(stderr, "[cons] chaining scores on the GPU (inside sketch+index): %.0f ms wall in %llu calls: staging %.0f, enqueue %.0f, wait (copies + kernel) %.0f\n", chain_ms,
-            (unsigned long long)cn, cs, ce, cw);
-    if (!E->dbg_batch_sizes.empty()) {        // alignments per batch over the run, in tenths of the run
-        const size_t nb = E->dbg_batch_sizes.size();
-        fprintf(stderr, "[cons] alignments per batch over the run (%zu batches, mean of each tenth):", nb);
-        for (int d = 0; d < 10; ++d) { uint64_t sum = 0; const size_t a = nb * d / 10, b = nb * (d + 1) / 10; for (size_t i = a; i < b; ++i) sum += E->dbg_batch_sizes[i]; fprintf(stderr, " %.1f", b > a ? (double)sum / (double)(b - a) : 0.0); }
-        fprintf(stderr, "\n");
-    }
-    fprintf(stderr, "[cons] one-group slot, wall-ms of its steps: host phase %.0f, windows %.0f, seeds + fresh contigs %.0f, sketch..chain %.0f, DP launch %.0f, results + early updates %.0f, last results %.0f\n",
-            E->g1_ms[0], E->g1_ms[1], E->g1_ms[2], E->g1_ms[3], E->g1_ms[4], E->g1_ms[6], E->g1_ms[7]);
-    for (int l = 0; l < kMaxGroups; ++l) {
-        const double *m = E->lane[l].sk_ms;
-        if (m[0] + m[1] + m[2] + m[3] + m[4] + m[5] > 0)
-            fprintf(stderr, "[cons] sketch..chain of lane / group %d, wall-ms of its steps: splice plan %.0f, requests %.0f, sketch call %.0f, splice + index loop %.0f, enqueue of tails / seeds / chain / plan / DP %.0f, wait for seeds + chains and the first step %.0f\n",
-                    l, m[0], m[1], m[2], m[3], m[4], m[5]);
-    }
-    fprintf(stderr, "[cons] slots set by: host phase %llu (%.0f ms), batches part 1 %llu (%.0f ms), part 2 %llu (%.0f ms)\n", (unsigned long long)E->slot_long_n[0],
-            E->slot_long_ms[0], (unsigned long long)E->slot_long_n[1], E->slot_long_ms[1], (unsigned long long)E->slot_long_n[2], E->slot_long_ms[2]);
-}
-
-// NSGPU_CONS_DEBUG: CPU time, memory and the per-step counters of the whole stage
-static void debug_report_stage(nsgpu_ctx *c, Engine *E, const struct rusage &ru0, double w_begin, double w_slot, double w_seed, double w_claim, double tf)
-{
-    fprintf(stderr, "[cons] gpu mm_sketch wall-ms %.0f\n", c->sketch_mm_ms);
-    if (cons::g_mp_cnt[1].load())
-        fprintf(stderr, "[cons] main path (cumulative): %llu recomputes cut the path, on average at %.0f edges before its end of %.0f\n", (unsigned long long)cons::g_mp_cnt[1].load(),
-                (double)cons::g_mp_cnt[0].load() / cons::g_mp_cnt[1].load(), (double)cons::g_mp_cnt[2].load() / cons::g_mp_cnt[1].load());
-    fprintf(stderr, "[cons] emission cpu-ms: path tables %.0f, read walks %.0f, script folding + stream bytes %.0f\n", cons::g_emit_ns[0] / 1e6, cons::g_emit_ns[1] / 1e6, cons::g_emit_ns[2] / 1e6);
-    fprintf(stderr, "[cons] align host cpu-ms: seeds %.0f chain %.0f regs %.0f plan %.0f execute %.0f\n", mm2::g_step_ns[0] / 1e6, mm2::g_step_ns[1] / 1e6,
-            mm2::g_step_ns[2] / 1e6, mm2::g_step_ns[3] / 1e6, mm2::g_step_ns[4] / 1e6);
-    struct rusage ru1;
-    getrusage(RUSAGE_SELF, &ru1);
-    const double cpu_s = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec) * 1e-6 +
-                         (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
-    fprintf(stderr, "[cons] serial CPU ms of the role threads (outside pool loops): host %.0f, batches part 1 %.0f, part 2 %.0f\n", E->role_serial_ns[0] / 1e6,
-            E->role_serial_ns[1] / 1e6, E->role_serial_ns[2] / 1e6);
-    if (FILE *f = fopen("/proc/self/smaps_rollup", "r")) {       // are the graph slabs really on huge pages?
-        char line[256];
-        long rss = 0, thp = 0;
-        while (fgets(line, sizeof(line), f)) { sscanf(line, "Rss: %ld kB", &rss); sscanf(line, "AnonHugePages: %ld kB", &thp); }
-        fclose(f);
-        fprintf(stderr, "[cons] resident %.1f GB, of it on transparent huge pages %.1f GB; graph slabs of %zu KB: %lld in use, peak %lld, carved %lld (%.1f GB)\n", rss / 1048576.0, thp / 1048576.0,
-                cons::kSlabBytes >> 10, (long long)cons::g_slabs_in_use.load(), (long long)cons::g_slabs_peak.load(), (long long)cons::g_slabs_mapped.load(),
-                cons::g_slabs_mapped.load() * (double)cons::kSlabBytes / (1u << 30));
-    }
-    pool_prof_print();
-    fprintf(stderr, "[cons] part 2 wall-ms: wait for the DP in flight %.0f, later rounds %.0f (their DP %.0f, %d rounds), results %.0f\n", g_finish_ms[0], g_finish_ms[1],
-            g_finish_ms[2], (int)g_finish_ms[4], g_finish_ms[3]);
-    for (double &x : g_finish_ms) x = 0;
-    fprintf(stderr, "[cons] gpu mm_sketch wall-ms: host staging %.0f, flags..k-mers (1st read-back) %.0f, pushes..offsets (2nd) %.0f, write + read-back %.0f; %.0f MB in, %.1f M minimizers out\n",
-            g_sketch_ms[0], g_sketch_ms[1], g_sketch_ms[2], g_sketch_ms[3], g_sketch_ms[4] / 1e6, g_sketch_ms[5] / 1e6);
-    for (double &x : g_sketch_ms) x = 0;
-    const double sys_s = (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
-    fprintf(stderr, "[cons] process CPU time over the stage: %.1f s (%.1f s of it in the kernel; %ld minor faults) = %.1f cores busy on average\n", cpu_s, sys_s,
-            ru1.ru_minflt - ru0.ru_minflt, cpu_s / ((now_ms() - E->t0) * 1e-3));
-    fprintf(stderr, "[cons] wall-ms: begin %.0f slots %.0f (host phases %.0f, batches %.0f, overlapped) seed %.0f claim %.0f finish %.0f\n", w_begin, w_slot,
-            c->cons_stats.graph_ms, c->cons_stats.filter_ms + c->cons_stats.index_ms + c->cons_stats.align_ms, w_seed, w_claim, now_ms() - tf);
-}
-
 static int run_consensus_inner(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_out);
-static int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_out)
+int run_consensus(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_threads_out)
 {
     const int rc = run_consensus_inner(c, n_builders, n_threads_out);
     // a failed stage leaves no engine behind (nsgpu_set_schedule would refuse with "a contig stage is in progress")
@@ -1831,100 +1115,6 @@ static int run_consensus_inner(nsgpu_ctx *c, uint32_t n_builders, uint32_t n_thr
 }  // namespace nsgpu
 
 using namespace nsgpu;
-
-// The same loop over the ranks of a communicator: after each slot ONE all-gather carries every rank's claim requests (group b)
-// and seed requests (group h); both lists are then resolved on every rank in global builder order.  A rank never has more
-// requests than local builders, so the exchange buffer has a fixed size and needs no size negotiation.
-static int run_consensus_dist(nsgpu_ctx *c, Comm &C, uint32_t n_builders_total, uint32_t n_threads_out, uint64_t *n_coll_out, uint64_t *bytes_out)
-{
-    NS_CHECK(n_threads_out >= 1, NSGPU_ERR_ARG, "n_threads_out must be >= 1");
-    // engine_begin does rank-local GPU work (the seed policy sketches and queries all reads, allocates device and pinned memory): one rank may
-    // fail where the others do not, so its return code travels through a status all-gather of its own before anybody enters the slot loop.
-    const int rc_begin = engine_begin(c, n_builders_total, C.rank, C.world);
-    Engine *E = static_cast<Engine *>(c->cons_engine);
-    const uint32_t W = C.world;
-    // one exchange = [status | claim count, gids, reads | seed count, gids, cursors]; a rank never has more requests than local builders
-    // (0 builders = the automatic schedule's own count, at most 1024: the bound must not depend on what a rank derives -- a rank whose
-    // engine_begin failed still has to enter the exchanges with buffers of the size the others use)
-    const uint32_t nb_bound = n_builders_total ? n_builders_total : 1024u;
-    const size_t cap = (nb_bound + W - 1) / W + 1, blk = 1 + 2 * cap, words = 1 + 2 * blk;
-    std::vector<uint32_t> mine(words), all(words * W), ca, cb, sa, sb, ga, gb;
-    uint64_t n_coll = 0;
-    std::string local_err;
-    // Every rank ALWAYS enters the collective and sends its status with its lists, so that one failing rank ends the stage on all ranks
-    // instead of leaving the others blocked in an all-gather it never joins.  rc_local: what this rank's part of the slot returned.
-    auto exchange = [&](int rc_local, const std::vector<uint32_t> *cl_g, const std::vector<uint32_t> *cl_r, const std::vector<uint32_t> *sd_g, const std::vector<uint32_t> *sd_c) -> int {
-        if (rc_local == NSGPU_OK && ((cl_g && cl_g->size() > cap) || (sd_g && sd_g->size() > cap))) { set_error("more requests than local builders"); rc_local = NSGPU_ERR_RANGE; }
-        if (rc_local != NSGPU_OK) local_err = nsgpu_last_error();
-        std::fill(mine.begin(), mine.end(), 0u);
-        mine[0] = (uint32_t)(rc_local != NSGPU_OK);
-        if (rc_local == NSGPU_OK && cl_g) { mine[1] = (uint32_t)cl_g->size(); std::copy(cl_g->begin(), cl_g->end(), mine.begin() + 2); std::copy(cl_r->begin(), cl_r->end(), mine.begin() + 2 + cap); }
-        if (rc_local == NSGPU_OK && sd_g) { mine[1 + blk] = (uint32_t)sd_g->size(); std::copy(sd_g->begin(), sd_g->end(), mine.begin() + 2 + blk); std::copy(sd_c->begin(), sd_c->end(), mine.begin() + 2 + blk + cap); }
-        const int rc_coll = C.all_gather(mine.data(), all.data(), words * 4, false, c->stream);
-        ++n_coll;
-        if (rc_local != NSGPU_OK) { set_error("%s", local_err.c_str()); return rc_local; }
-        NS_TRY(rc_coll);
-        for (uint32_t r = 0; r < W; ++r)
-            if (all[(size_t)r * words]) { set_error("contig stage: rank %u reported an error; stopping on every rank", r); return NSGPU_ERR_HIP; }
-        return NSGPU_OK;
-    };
-    auto gathered = [&](size_t base) {        // request lists of all ranks: (ga, gb)
-        ga.clear(); gb.clear();
-        for (uint32_t r = 0; r < W; ++r) {
-            const uint32_t *v = all.data() + (size_t)r * words + base;
-            ga.insert(ga.end(), v + 1, v + 1 + v[0]);
-            gb.insert(gb.end(), v + 1 + cap, v + 1 + cap + v[0]);
-        }
-    };
-    NS_TRY(exchange(rc_begin, nullptr, nullptr, nullptr, nullptr));
-    for (uint32_t slot = 0;; ++slot) {
-        const int G = n_groups(c);
-        const int h = (int)(slot % G), b = (int)((slot + 1) % G);
-        if (G == 1) {
-            // ONE group: two small all-gathers per slot -- seed requests after the host phase, claim requests after the batches
-            int rc = engine_slot(c, slot, 1);
-            if (rc == NSGPU_OK) rc = engine_window_loop(c, h);
-            if (rc == NSGPU_OK) engine_seed_requests(c, sa, sb, h);
-            NS_TRY(exchange(rc, nullptr, nullptr, &sa, &sb));
-            gathered(1 + blk);
-            rc = NSGPU_OK;
-            if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) { engine_advance(c, true, h); rc = engine_window_loop(c, h); }
-            // which reads the builders of ALL ranks are about to align: a builder whose read nobody else aligns (and nobody has claimed) cannot
-            // lose its claim, so its graph update may ride on the DP phase as on one GPU (engine_early_updates) instead of waiting for the
-            // claim exchange -- one more small all-gather per slot
-            if (rc == NSGPU_OK) {
-                ca.clear(), cb.clear();
-                for (const Builder &bb : E->D.B) if (bb.st == Builder::WAIT_ALIGN) { ca.push_back(bb.gid); cb.push_back(bb.pend); }
-            }
-            NS_TRY(exchange(rc, &ca, &cb, nullptr, nullptr));
-            gathered(1);
-            E->global_pends.assign(gb.begin(), gb.end());
-            std::sort(E->global_pends.begin(), E->global_pends.end());
-            E->have_global_pends = true;
-            rc = engine_slot(c, slot, 2);
-            if (rc == NSGPU_OK) engine_claim_requests(c, ca, cb, b);
-            NS_TRY(exchange(rc, &ca, &cb, nullptr, nullptr));
-            gathered(1);
-            engine_claim_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size());
-            if (E->n_done_global >= E->n_total) break;
-            continue;
-        }
-        const int rc = engine_slot(c, slot);
-        if (rc == NSGPU_OK) { engine_claim_requests(c, ca, cb, b); engine_seed_requests(c, sa, sb, h); }
-        NS_TRY(exchange(rc, &ca, &cb, &sa, &sb));
-        gathered(1);
-        engine_claim_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size());
-        gathered(1 + blk);
-        if (!ga.empty() && engine_seed_resolve(c, ga.data(), gb.data(), (uint32_t)ga.size()) != 0) {
-            if (G < 4) engine_advance(c, true, h);       // (see run_consensus)
-            else E->deferred_fresh = h;
-        }
-        if (E->n_done_global >= E->n_total) break;
-    }
-    if (n_coll_out) *n_coll_out = n_coll;
-    if (bytes_out) *bytes_out = n_coll * (uint64_t)words * 4 * W;
-    return engine_finish(c, n_threads_out);
-}
 
 static int give_u32(const std::vector<uint32_t> &v, uint32_t **out)
 {
@@ -2086,20 +1276,6 @@ static std::string stream_of(const cons::StreamSet &s, int which)
     case 0: return s.genome; case 1: return s.lone; case 2: return s.id_bytes(); case 3: return s.pos;
     case 4: return s.type; case 5: return s.base; default: return s.complement;
     }
-}
-
-int nsgpu_dist_consensus_run(nsgpu_ctx *c, nsgpu_comm *comm, uint32_t n_builders_total, uint32_t n_threads_out, nsgpu_consensus_stats *stats_out)
-{
-    NS_CHECK(c && comm && nsgpu_comm_impl(comm), NSGPU_ERR_ARG, "nsgpu_dist_consensus_run: null argument");
-    NS_CHECK(c->have_index, NSGPU_ERR_ARG, "nsgpu_dist_consensus_run: build the bucket tables first (nsgpu_dist_sketch_index)");
-    NS_HIP(hipSetDevice(c->prm.device));
-    uint64_t n_coll = 0, bytes = 0;
-    const int rc = run_consensus_dist(c, *nsgpu_comm_impl(comm), n_builders_total, n_threads_out, &n_coll, &bytes);
-    if (rc != NSGPU_OK) { if (c->cons_engine) { c->cons_engine_free(c->cons_engine); c->cons_engine = nullptr; } return rc; }
-    nsgpu_comm_count(comm, bytes, 0);
-    c->cons_stats.reserved = (uint32_t)n_coll;           // collectives of the stage
-    if (stats_out) *stats_out = c->cons_stats;
-    return NSGPU_OK;
 }
 
 int nsgpu_consensus_stream(nsgpu_ctx *c, uint32_t thread, uint32_t which, uint8_t **data_out, size_t *len_out)

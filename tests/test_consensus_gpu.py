@@ -592,24 +592,29 @@ def test_tail_rings_equal_lockstep_oracle():
     assert a["slots"] < b["slots"] and a["n_contigs"] >= b["n_contigs"]
 
 
-@pytest.mark.parametrize("fixture", ["r03_lockstep_cfg2.json", "auto:r03_lockstep_cfg2.json", "r03_lockstep_cfg2_1024.json"])
+@pytest.mark.parametrize("fixture", ["r03_lockstep_cfg2.json", "auto:r03_lockstep_cfg2.json", "r03_lockstep_cfg2_1024.json", "r05_lockstep_cfg5knobs.json"])
 def test_cfg2_full_default_schedule_equals_lockstep_oracle_hashes(fixture):
     """BASELINE cfg2 at FULL size in bench.py's DEFAULT schedule (80 builders, one group, conflict-aware seeds: buckets of depth 3, 5 rings, 3
     in the tail): the engine's 80 stream sets have, stream type by stream type over the builders in order, the sizes and sha256 that the
     oracle's lock-step virtual threads recorded for this input (the literal thread body of the reference under the documented schedule,
     the reference's own minimap2 answering every alignRead; tools/oracle_lockstep_cfg2.py -> profiles/r03_lockstep_cfg2.json), the same
     counters and slot count, and every read decodes.  The headline configuration itself, byte for byte, at the size it is timed at -- and
-    (second fixture) the 1024-builder, four-group pipelined schedule that bench.py times as `throughput_schedule`."""
+    (other fixtures) the same with NO schedule argument (the library derives it), the 1024-builder, four-group pipelined schedule that bench.py
+    times as `throughput_schedule`, and BASELINE configs[4]'s knobs at this size: --num-hash 128 with the default --edge-thr of 4 M
+    (profiles/r05_lockstep_cfg5knobs.json: 128 tables instead of 60 change every candidate list, hence every contig)."""
     import hashlib, json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     auto = fixture.startswith("auto:")              # with NO schedule argument and 0 builders: the library derives bench.py's default itself
+    if not os.path.exists(os.path.join(root, "profiles", fixture.split(":")[-1])):
+        pytest.skip("profiles/%s has not been generated (tools/oracle_lockstep_cfg2.py)" % fixture.split(":")[-1])
     want = json.load(open(os.path.join(root, "profiles", fixture.split(":")[-1])))
     sc = want["schedule"]
     bases, off = ns.synth_reads(11, int(100000 * 8000 / 20), 100000, 8000.0)
     assert int(off[-1]) == want["bases"]
-    g = ns.NsGpu()
+    n_hash = want.get("num_hash", 60)
+    g = ns.NsGpu(n=n_hash)
     g.load_reads((bases, off))
-    g.sketch(ns.mt19937_64_salts(60, 12345), fetch=False)
+    g.sketch(ns.mt19937_64_salts(n_hash, 12345), fetch=False)
     g.build_index()
     B = sc["builders"]
     if auto:

@@ -32,9 +32,10 @@ if stride > 1:
     parts = [bases[int(off[i]):int(off[i + 1])] for i in keep]
     off = np.concatenate([[0], np.cumsum([len(x) for x in parts])]).astype(np.uint64)
     bases = np.concatenate(parts)
-salts = ns.mt19937_64_salts(60, 12345)
+n_hash = int(os.environ.get("NS_ORACLE_NHASH", "60"))          # --num-hash (BASELINE configs[4] sweeps 60 / 128)
+salts = ns.mt19937_64_salts(n_hash, 12345)
 t0 = time.time()
-streams, st = oracle_lib.cons_oracle_run(bases, off, salts, num_thr=B, checks=False, lock_step=True, groups=groups, seed_hops=depth, seed_rings=rings, seed_tail_rings=tail)
+streams, st = oracle_lib.cons_oracle_run(bases, off, salts, n=n_hash, num_thr=B, checks=False, lock_step=True, groups=groups, seed_hops=depth, seed_rings=rings, seed_tail_rings=tail)
 dt = time.time() - t0
 names = oracle_lib.CONS_STREAMS
 sha, size = {}, {}
@@ -47,7 +48,7 @@ for n in names:
 sha["metaData"], size["metaData"] = hashlib.sha256(streams["metaData"]).hexdigest(), len(streams["metaData"])
 tot7 = sum(size[n] for n in names)
 rec = {"workload": "%s (bench.py's generator: seed 11, %d reads, mean 8000, genome %d%s)" % (wname, n_reads, genome, ", every %dth read" % stride if stride > 1 else ""),
-       "schedule": {"builders": B, "groups": groups, "seed_bucket_depth": depth, "seed_rings": rings, "seed_tail_rings": tail},
+       "num_hash": n_hash, "schedule": {"builders": B, "groups": groups, "seed_bucket_depth": depth, "seed_rings": rings, "seed_tail_rings": tail},
        "computed_by": "oracle/consensus_oracle.cpp lock-step virtual threads, reference minimap2 (oracle/_ref/libmm2ref.so)",
        "seconds": dt, "bases": int(off[-1]), "stream_bytes": size, "sha256_over_threads_in_order": sha, "stats": st,
        "stream_bytes_total_7": tot7, "stream_bytes_per_base": tot7 / int(off[-1])}
