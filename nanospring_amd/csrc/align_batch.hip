@@ -746,6 +746,7 @@ static int batch_seed_and_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t 
             S.pair_of[i] = (uint32_t)pairs.size();
             SeedPair p{};
             p.ref = r.ref_mz_dev ? r.ref_mz_dev : r.ref_mz, p.qry = r.qry_mz, p.n_ref = (uint32_t)r.n_ref_mz, p.n_qry = (uint32_t)r.n_qry_mz;
+            p.cnt_tab = r.ref_cnt, p.cnt_meta = r.ref_cnt_meta, p.cnt_bits = r.ref_cnt_bits;
             pairs.push_back(p);
         } else S.fb.push_back((uint32_t)i);
     }

@@ -308,7 +308,7 @@ void nsgpu_destroy(nsgpu_ctx *c)
     }
     for (nsgpu_ctx::SeedWs &w : c->seed_ws) {
         w.d_tab.release(); w.d_next.release(); w.d_ys.release(); w.d_tmp.release(); w.d_out.release(); w.d_counter.release();
-        w.h_pairs.release(); w.h_res.release(); w.h_ref.release();
+        w.h_pairs.release(); w.h_res.release(); w.h_ref.release(); w.h_jobs.release();
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }
     c->pin_small.release(); c->pin_foff.release(); c->pin_fids.release(); c->pin_wq.release(); c->pin_wq_out.release();

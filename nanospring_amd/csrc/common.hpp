@@ -222,7 +222,7 @@ struct nsgpu_ctx {
     // index + seeds (seeds.hip): scratch tables, anchors (device), pair descriptors and results (pinned)
     struct SeedWs {
         nsgpu::DevBuf d_tab, d_next, d_ys, d_tmp, d_out, d_counter;
-        nsgpu::PinBuf h_pairs, h_res, h_ref;                          // h_ref: staging of reference minimizer lists that live in pageable memory
+        nsgpu::PinBuf h_pairs, h_res, h_ref, h_jobs;                  // h_ref: staging of reference minimizer lists that live in pageable memory; h_jobs: count-table jobs
         size_t pend = 0; uint64_t capacity = 0, cap_hint = 0;
         std::vector<uint32_t> pair_of, fb, late;                       // job -> pair (~0u: host-seeded), the host-seeded jobs, the jobs the kernels handed back
         const void *res = nullptr;                                    // results of the launch in flight (SeedResult[])

@@ -24,7 +24,7 @@ static void engine_free(void *p)
 {
     pool_drain();                                     // no emission task may outlive the engine
     Engine *E = static_cast<Engine *>(p);
-    for (Builder &b : E->D.B) { b.d_mz.release(); b.d_cons.release(); }
+    for (Builder &b : E->D.B) { b.d_mz.release(); b.d_cons.release(); b.d_cnt.release(); b.d_cnt_hm.release(); }
     for (Engine::Lane &L : E->lane) L.release();
     delete E;
 }
@@ -184,7 +184,8 @@ static size_t apply_splice(Builder &b, const mm2::Anchor *sub, size_t n_sub, int
     auto pos_of = [](const mm2::Anchor &x) { return (size_t)((x.y & 0xffffffffull) >> 1); };
     const Builder::Splice &sp = b.sp;
     const std::string &nw = b.g->main_path;
-    if (sp.full) b.mz.assign(sub, sub + n_sub);
+    b.cnt_rem.clear(), b.cnt_add.clear();
+    if (sp.full) { b.mz.assign(sub, sub + n_sub); b.cnt_valid = false; }       // (a new list: its count table is rebuilt)
     else {
         std::vector<mm2::Anchor> out;
         out.reserve(b.mz.size() + n_sub);
@@ -200,10 +201,24 @@ static size_t apply_splice(Builder &b, const mm2::Anchor *sub, size_t n_sub, int
             const size_t x = pos_of(sub[j]) + sp.a;
             if (x >= sp.A && x < sp.B) { mm2::Anchor t = sub[j]; t.y = (t.y & ~0xffffffffull) | ((uint64_t)x << 1 | (t.y & 1)); out.push_back(t); }
         }
+        for (size_t j = first_diff; j < out.size(); ++j) b.cnt_add.push_back(out[j].x >> 8);         // what came ...
         const size_t B_old = (size_t)((ssize_t)sp.B - sp.delta);
-        for (; i < b.mz.size() && pos_of(b.mz[i]) < B_old; ++i) {}
+        for (; i < b.mz.size() && pos_of(b.mz[i]) < B_old; ++i) b.cnt_rem.push_back(b.mz[i].x >> 8);      // ... and what left: the count table's update
         for (; i < b.mz.size(); ++i) { mm2::Anchor t = b.mz[i]; const size_t x = (size_t)((ssize_t)pos_of(t) + sp.delta); t.y = (t.y & ~0xffffffffull) | ((uint64_t)x << 1 | (t.y & 1)); out.push_back(t); }
         b.mz.swap(out);
+        // (a re-sketched stretch gives back most of the minimizers it had: a hash on both sides is no change of its count)
+        if (!b.cnt_rem.empty() && !b.cnt_add.empty()) {
+            std::sort(b.cnt_rem.begin(), b.cnt_rem.end()), std::sort(b.cnt_add.begin(), b.cnt_add.end());
+            size_t x = 0, y = 0, nx = 0, ny = 0;
+            while (x < b.cnt_rem.size() && y < b.cnt_add.size()) {
+                if (b.cnt_rem[x] == b.cnt_add[y]) ++x, ++y;
+                else if (b.cnt_rem[x] < b.cnt_add[y]) b.cnt_rem[nx++] = b.cnt_rem[x++];
+                else b.cnt_add[ny++] = b.cnt_add[y++];
+            }
+            while (x < b.cnt_rem.size()) b.cnt_rem[nx++] = b.cnt_rem[x++];
+            while (y < b.cnt_add.size()) b.cnt_add[ny++] = b.cnt_add[y++];
+            b.cnt_rem.resize(nx), b.cnt_add.resize(ny);
+        }
     }
     {   // mz_str = nw, copying only what can differ
         const size_t keep = std::min(std::min(b.chg_lb, b.mz_str.size()), nw.size());
@@ -516,6 +531,88 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
             const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>(64, (max_n + 255) / 256));
             hipLaunchKernelGGL(mz_tail_scatter_kernel, dim3(gx, (uint32_t)jobs.size()), dim3(256), 0, SW.stream, L.pin_tail.as<TailCopy>(), (uint32_t)jobs.size());
             NS_HIP(hipGetLastError());
+        }
+        // the contigs' count tables (seeds.hip): what the splice removed and added, behind the scatter on the same stream -- or the whole list
+        // when the contig is new, was re-sketched whole, or its table has filled up with hashes that left
+        std::vector<CountJob> &cj = L.cnt_jobs;
+        cj.clear();
+        size_t n_keys = 0;
+        for (size_t w = 0; w < n; ++w) if (changed[w]) n_keys += D.B[who[w]].cnt_rem.size() + D.B[who[w]].cnt_add.size();
+        NS_TRY(L.pin_cnt.reserve(n * sizeof(CountJob) + n_keys * sizeof(uint64_t) + 16));
+        unsigned long long *key_stage = reinterpret_cast<unsigned long long *>(L.pin_cnt.as<CountJob>() + n);
+        for (size_t w = 0; w < n; ++w) {
+            Builder &b = D.B[who[w]];
+            const size_t n_mz = b.mz.size();
+            if (changed[w] || !b.cnt_valid) {
+                // (keys whose count went to zero stay in the table: rebuilt once a third of the slots may be taken)
+                const bool rebuild = !b.cnt_valid || (b.cnt_keys + b.cnt_add.size()) * 3 > ((uint64_t)1 << b.cnt_bits);
+                CountJob j{};
+                if (rebuild) {
+                    const uint32_t bits = count_table_bits(n_mz + n_mz / 2);
+                    if ((sizeof(CountSlot) << bits) > b.d_cnt.cap) {
+                        if (b.d_cnt.p) L.retired.push_back(b.d_cnt), b.d_cnt = DevBuf();
+                        NS_TRY(b.d_cnt.reserve(sizeof(CountSlot) << bits));
+                    }
+                    if (!b.d_cnt_hm.p) NS_TRY(b.d_cnt_hm.reserve((1024 + 4) * sizeof(uint32_t)));
+                    b.cnt_bits = bits;
+                    j.rebuild = 1, j.all = b.d_mz.as<mm2::Anchor>(), j.n_all = (uint32_t)n_mz;
+                    b.cnt_keys = n_mz, b.cnt_valid = true;
+                } else {
+                    memcpy(key_stage, b.cnt_rem.data(), b.cnt_rem.size() * sizeof(uint64_t));
+                    j.rem = key_stage, j.n_rem = (uint32_t)b.cnt_rem.size(), key_stage += b.cnt_rem.size();
+                    memcpy(key_stage, b.cnt_add.data(), b.cnt_add.size() * sizeof(uint64_t));
+                    j.add = key_stage, j.n_add = (uint32_t)b.cnt_add.size(), key_stage += b.cnt_add.size();
+                    b.cnt_keys += b.cnt_add.size();
+                }
+                j.tab = b.d_cnt.as<CountSlot>(), j.bits = b.cnt_bits;
+                j.hist = b.d_cnt_hm.as<uint32_t>(), j.meta = b.d_cnt_hm.as<uint32_t>() + 1024;
+                if (j.rebuild || j.n_rem || j.n_add) cj.push_back(j);
+                b.cnt_rem.clear(), b.cnt_add.clear();
+            }
+            AB.reqs[w].ref_cnt = b.d_cnt.as<CountSlot>(), AB.reqs[w].ref_cnt_meta = b.d_cnt_hm.as<uint32_t>() + 1024, AB.reqs[w].ref_cnt_bits = b.cnt_bits;
+        }
+        if (!cj.empty()) {
+            memcpy(L.pin_cnt.p, cj.data(), cj.size() * sizeof(CountJob));
+            NS_TRY(gpu_count_tables_launch(SW.stream, L.pin_cnt.as<CountJob>(), (uint32_t)cj.size(), mm2::Opt().mid_occ_frac));
+        }
+        static const bool check_cnt = getenv("NSGPU_SKETCH_CHECK") != nullptr;
+        if (check_cnt) {
+            // every table against the counts of the host's list: the same hashes with the same counts, no other hash with a count, the
+            // same number of distinct hashes and the host's mid_occ (mm2.cpp RefIndex::build_from_sketch)
+            NS_HIP(hipStreamSynchronize(SW.stream));
+            for (size_t w = 0; w < n; ++w) {
+                Builder &b = D.B[who[w]];
+                std::vector<CountSlot> tab((size_t)1 << b.cnt_bits);
+                uint32_t meta[4];
+                NS_HIP(hipMemcpy(tab.data(), b.d_cnt.p, tab.size() * sizeof(CountSlot), hipMemcpyDeviceToHost));
+                NS_HIP(hipMemcpy(meta, b.d_cnt_hm.as<uint32_t>() + 1024, sizeof(meta), hipMemcpyDeviceToHost));
+                std::vector<uint64_t> h(b.mz.size());
+                for (size_t i = 0; i < h.size(); ++i) h[i] = b.mz[i].x >> 8;
+                std::sort(h.begin(), h.end());
+                std::vector<uint32_t> occ;
+                size_t n_bad = 0, n_live = 0;
+                for (size_t i = 0; i < h.size();) {
+                    size_t j = i;
+                    while (j < h.size() && h[j] == h[i]) ++j;
+                    occ.push_back((uint32_t)(j - i));
+                    uint32_t sl = (uint32_t)(((h[i] + 1) * 0x9e3779b97f4a7c15ull) >> (64 - b.cnt_bits)), cnt = 0;
+                    for (;; sl = (sl + 1) & ((1u << b.cnt_bits) - 1)) { if (tab[sl].key == h[i] + 1) { cnt = tab[sl].count; break; } if (!tab[sl].key) break; }
+                    n_bad += cnt != j - i;
+                    i = j;
+                }
+                for (const CountSlot &t : tab) n_live += t.key && t.count;
+                uint32_t mid = 1;
+                if (!occ.empty()) {
+                    const size_t kk = (uint32_t)((1. - mm2::Opt().mid_occ_frac) * occ.size());
+                    std::nth_element(occ.begin(), occ.begin() + kk, occ.end());
+                    mid = occ[kk] + 1;
+                }
+                if (n_bad || n_live != occ.size() || meta[0] != occ.size() || (meta[1] != mid && !meta[2])) {
+                    fprintf(stderr, "nsgpu: a contig's count table differs from its minimizer list's counts (internal error): %zu wrong counts, %zu / %u / %zu hashes, mid_occ %u / %u\n",
+                            n_bad, n_live, meta[0], occ.size(), meta[1], mid);
+                    abort();
+                }
+            }
         }
     }
     if (use_dev_plan) NS_TRY(engine_cons_update(c, E, AB, who, changed, staged, L));

@@ -74,6 +74,13 @@ struct Builder {
     // the entries from the first changed one on travel (a contig grows at its ends: a few hundred entries of tens of thousands).
     DevBuf d_mz;
     size_t d_mz_n = 0;
+    // the occurrence counts of the list's hashes resident in HBM (seeds.hip count_update_kernel: what mm_idx_str's buckets are reduced to --
+    // mid_occ and "does the consensus have this hash fewer than mid_occ times"): kept up to date with what a splice removed and added
+    DevBuf d_cnt, d_cnt_hm;                    // the table; its histogram (1024 words) + meta (4 words)
+    uint32_t cnt_bits = 0;
+    uint64_t cnt_keys = 0;                     // keys inserted since the table was built (an upper bound of its load)
+    bool cnt_valid = false;
+    std::vector<uint64_t> cnt_rem, cnt_add;    // what a splice changed: the hashes that left the list and the ones that came (a hash on both sides cancelled)
     size_t chg_lb = 0;                         // the main path agrees with mz_str (and idx's base codes) on [0, chg_lb): from ContigGraph::path_changed_from
     std::vector<std::unique_ptr<FinishedContig>> contigs;     // in the order they were finished = output order
     size_t n_queued = 0;                                      // contigs[0 .. n_queued) were handed to the emission queue
@@ -119,6 +126,7 @@ struct Driver {
         b.mz.clear(), b.mz_str.clear();          // a new consensus: nothing to splice into
         b.chg_lb = 0;
         b.d_mz_n = 0;                            // (the resident list's memory stays with the builder)
+        b.cnt_valid = false;
         b.dc_valid = false;
         b.st = Builder::ADVANCE;
     }
@@ -341,13 +349,14 @@ struct Engine {
         std::vector<mm2::AlnOut> outs;
         std::vector<uint8_t> early_sure;                // per request: its claim cannot fail (engine_early_updates)
         std::vector<const uint8_t *> staged;            // per request: the changed stretch's text in device memory (cons_update_kernel's source)
+        std::vector<CountJob> cnt_jobs; PinBuf pin_cnt; // the count tables' update jobs of the batch: descriptors, then the removed minimizers (pinned)
             double sk_ms[6] = {0, 0, 0, 0, 0, 0};           // engine_batches_sketch: splice plan, requests, sketch call, index loop, enqueue of seeds..DP, wait + first step
         int sketch_ws = 0;                              // mm_sketch workspace of the lane's batches
         void release()
         {
             for (DevBuf &d : retired) d.release();
             retired.clear();
-            pin_tail.release(), pin_cons.release();
+            pin_tail.release(), pin_cons.release(), pin_cnt.release();
             if (cons_stream) { (void)hipStreamSynchronize(cons_stream); (void)hipStreamDestroy(cons_stream); (void)hipEventDestroy(cons_ev); cons_stream = nullptr; }
         }
     } lane[kMaxGroups];

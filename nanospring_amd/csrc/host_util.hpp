@@ -33,6 +33,8 @@ template <class F> inline void par_for(const char *tag, size_t n, F fn) { PoolTa
 template <class F> inline void par_for_pinned(const char *tag, size_t n, F fn) { PoolTag t(tag); parallel_for_pinned_impl(n, std::function<void(size_t)>(fn)); }
 void pool_drain();
 
+struct CountSlot { unsigned long long key; uint32_t count, pad; };       // seeds.hip: key = hash + 1 (0: empty)
+
 struct AlignReq {
     mm2::RefIndex *idx;           // index of `ref` (owned by the caller, reusable across batches): at least set_sequence(); the lookup
                                   // table is built on demand for the pairs the GPU seeding hands back (from ref_mz)
@@ -42,6 +44,8 @@ struct AlignReq {
     size_t n_qry_mz = 0;
     const mm2::Anchor *ref_mz = nullptr;   // the reference's minimizers, PINNED memory as well; both given = seeds on the GPU (seeds.hip)
     size_t n_ref_mz = 0;
+    // the reference's occurrence-count table, when the caller keeps one up to date (seeds.hip count_update_kernel); else the seeding launch builds one
+    const CountSlot *ref_cnt = nullptr; const uint32_t *ref_cnt_meta = nullptr; uint32_t ref_cnt_bits = 0;
     const mm2::Anchor *ref_mz_dev = nullptr;   // the same list resident in DEVICE memory (the contig engine keeps one per contig): the seeding kernel
                                                // reads this one, ref_mz (any host memory then) serves the pairs the kernel hands back to the host code
     // for the plan kernel (plan.hip): the query and the stretch [ref_dev_lo, ref_dev_lo + ref_dev_n) of the reference as ASCII in DEVICE memory
@@ -65,9 +69,20 @@ int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::A
 struct SeedPair {
     const mm2::Anchor *ref; const mm2::Anchor *qry;      // device-readable (pinned host or device memory), mm_sketch order
     uint32_t n_ref, n_qry;
-    uint32_t tab_bits; uint32_t pad_ = 0;                 // filled by gpu_seeds_launch: the pair's slice of the scratch buffers
-    uint64_t tab_off, next_off;
+    // the reference's occurrence-count table (seeds.hip count_update_kernel: a contig keeps one in HBM) and its meta words {distinct hashes,
+    // mid_occ, flags}; nullptr: gpu_seeds_launch builds one in scratch for this launch
+    const CountSlot *cnt_tab = nullptr; const uint32_t *cnt_meta = nullptr;
+    uint32_t cnt_bits = 0; uint32_t pad_ = 0;
+    uint64_t tab_off = 0;                                 // filled by gpu_seeds_launch: the pair's slice of the scratch table
 };
+// seeds.hip: one job of count_update_kernel (pinned array, one workgroup per job) -- rebuild = 1: the table cleared and filled from all[0 .. n_all);
+// else the hashes rem[] leave and add[] join (Anchor::x >> 8 each)
+struct CountJob {
+    CountSlot *tab; uint32_t bits, rebuild; uint32_t *hist; uint32_t *meta;          // hist: 1024 words; meta: {distinct hashes, mid_occ, flags, -}
+    const unsigned long long *rem; const unsigned long long *add; const mm2::Anchor *all; uint32_t n_rem, n_add, n_all, pad;
+};
+int gpu_count_tables_launch(hipStream_t st, const CountJob *jobs_pinned, uint32_t n_jobs, float mid_occ_frac);
+uint32_t count_table_bits(uint64_t n_keys);
 struct SeedResult { unsigned long long base; uint32_t n; uint32_t flags; int32_t mid_occ; float avg; };
 constexpr uint32_t SEED_FLAG_TIES = 1, SEED_FLAG_MANY = 2, SEED_FLAG_CAPACITY = 4, SEED_FLAG_OCC = 8, SEED_FLAG_WIDE = 16;
 struct ChainList { uint64_t beg, obeg; uint32_t n; float avg; };
