@@ -787,8 +787,17 @@ static int batch_wait_and_step(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi
     for (size_t i = 0; i < n; ++i) if (S.pair_of[i] != ~0u && res[S.pair_of[i]].flags) late.push_back((uint32_t)i);
     if (!late.empty()) {
         S.fallbacks += late.size();
+        const double l0 = now_ms();
         NS_TRY(host_seed_and_chain_launch(c, B, lo, late, 2 * ws + 1));
+        const double l1 = now_ms();
         NS_TRY(gpu_chain_wait(c, 2 * ws + 1, f2, p2));
+        S.late_seed_ms += l1 - l0, S.late_chain_ms += now_ms() - l1, ++S.late_calls;
+        for (uint32_t i : late) {
+            const uint32_t fl = res[S.pair_of[i]].flags;
+            for (int b = 0; b < 5; ++b) S.late_flag[b] += fl >> b & 1;
+            const uint64_t na = B.jobs[lo + i].a.size();
+            S.late_anchors += na, S.late_longest = std::max(S.late_longest, na);
+        }
         take(late);
     }
     B.chain_ms += now_ms() - g0;

@@ -227,6 +227,8 @@ struct nsgpu_ctx {
         std::vector<uint32_t> pair_of, fb, late;                       // job -> pair (~0u: host-seeded), the host-seeded jobs, the jobs the kernels handed back
         const void *res = nullptr;                                    // results of the launch in flight (SeedResult[])
         double ms_wait = 0; uint64_t calls = 0, pairs = 0, fallbacks = 0;
+        // (debug print) the pairs handed back: by flag bit, their anchors in sum and the longest list, wall-ms of the host seeding and of their chaining launch
+        uint64_t late_flag[5] = {}, late_anchors = 0, late_longest = 0, late_calls = 0; double late_seed_ms = 0, late_chain_ms = 0;
         hipStream_t stream = nullptr;
     } seed_ws[9];
     std::vector<uint64_t> wq_off; std::vector<uint32_t> wq_ids;      // the last fused window-query batch's candidate lists (run_window_queries_fast)

@@ -43,6 +43,17 @@ void debug_report_slots(nsgpu_ctx *c, Engine *E)
             (unsigned long long)c->plan_pairs_dev, (unsigned long long)c->plan_pairs_host, (unsigned long long)c->plan_hits, (unsigned long long)c->plan_misses, (unsigned long long)c->plan_extra);
     fprintf(stderr, "[cons] index + seeds on the GPU: %llu launches, %llu pairs, wait %.0f ms wall; %llu pairs handed back to the host code\n", (unsigned long long)sn,
             (unsigned long long)sp, sw, (unsigned long long)sf);
+    {
+        uint64_t lf[5] = {}, la = 0, ll = 0, lc = 0; double ls = 0, lw = 0;
+        for (nsgpu_ctx::SeedWs &w : c->seed_ws) {
+            for (int b = 0; b < 5; ++b) lf[b] += w.late_flag[b], w.late_flag[b] = 0;
+            la += w.late_anchors, ll = std::max(ll, w.late_longest), lc += w.late_calls, ls += w.late_seed_ms, lw += w.late_chain_ms;
+            w.late_anchors = w.late_longest = w.late_calls = 0, w.late_seed_ms = w.late_chain_ms = 0;
+        }
+        if (lc) fprintf(stderr, "[cons] pairs handed back: ties %llu, many %llu, capacity %llu, occ %llu, wide %llu; %llu anchors in sum, longest list %llu; %llu second launches: host index + seeds %.0f ms, chaining wait %.0f ms\n",
+                        (unsigned long long)lf[0], (unsigned long long)lf[1], (unsigned long long)lf[2], (unsigned long long)lf[3], (unsigned long long)lf[4], (unsigned long long)la, (unsigned long long)ll,
+                        (unsigned long long)lc, ls, lw);
+    }
     double cs = 0, ce = 0, cw = 0; uint64_t cn = 0;
     for (nsgpu_ctx::ChainWs &w : c->cws) cs += w.ms_stage, ce += w.ms_enqueue, cw += w.ms_wait, cn += w.calls, w.ms_stage = w.ms_enqueue = w.ms_wait = 0, w.calls = 0;
     fprintf(stderr, "[cons] chaining scores on the GPU (inside sketch+index): %.0f ms wall in %llu calls: staging %.0f, enqueue %.0f, wait (copies + kernel) %.0f\n", chain_ms,

@@ -788,6 +788,16 @@ __global__ __launch_bounds__(NW * 64) void ksw_extd2_reg_kernel(const KswTask *_
     if (ti == ~0u) return;                       // an entry the plan kernel reserved and gave back
     const KswTask tk = tasks[ti];
     const bool approx = (tk.flag & KSW_EZ_APPROX_MAX) != 0, right = (tk.flag & KSW_EZ_RIGHT) != 0;      // uniform per workgroup
+#ifndef NSGPU_NO_SETPRIO
+    // A launch is over when its longest problem is, and a SIMD's one 16-lane ALU is shared by the waves resident on it: the problems with the
+    // most anti-diagonals win the issue arbitration against the short ones beside them
+    {
+        const long long rows = ksw_rows_bound(tk.qlen, tk.tlen, tk.w);
+        if (rows > 1200) __builtin_amdgcn_s_setprio(3);
+        else if (rows > 600) __builtin_amdgcn_s_setprio(2);
+        else if (rows > 300) __builtin_amdgcn_s_setprio(1);
+    }
+#endif
     if (approx) {
         // gap fills whose band never binds and that cannot Z-drop take the path-independent score (see ksw_reg_run)
         const int w = tk.w < 0 ? tk.qlen + tk.tlen : tk.w;
