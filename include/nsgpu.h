@@ -284,6 +284,16 @@ int nsgpu_set_schedule2(nsgpu_ctx *ctx, uint32_t groups, uint32_t seed_bucket_de
  * whose schedule was never set does the same without this call.  nsgpu_get_schedule2 reports what a run used (all out-pointers optional).
  * Deterministic for fixed (reads, salts); independent of the rank count. */
 int nsgpu_set_schedule_auto(nsgpu_ctx *ctx);
+/* Deferred alignments (one-group schedules).  In lock step a slot lasts as long as its slowest alignment, and a read across a tandem repeat --
+ * 10^4 .. 10^5 anchors: milliseconds of chaining, then DP problems thousands of columns wide -- takes two to three times a whole slot.  With
+ * slots >= 1 an alignment whose anchor list (collect_seed_hits's, minimap2/map.c:215-247, before chaining) is longer than `anchors` takes
+ * `slots` MORE slots than the others: the builder stands still, the other builders' slots go on, and its result is delivered -- its claim
+ * made -- at the end of slot s + slots.  The alignment itself is unchanged (the consensus it refers to does not move while it waits); the
+ * schedule, as always, is a function of the data only, and the lock-step oracle states the same rule (oracle/consensus_oracle.cpp
+ * LockStep::VT::extra).  The automatic schedule sets 4096 anchors / 2 slots unless this was called; explicit schedules leave it off.
+ * nsgpu_get_defer: the setting and how many alignments the last contig stage deferred (out-pointers optional). */
+int nsgpu_set_defer(nsgpu_ctx *ctx, uint32_t anchors, uint32_t slots);
+int nsgpu_get_defer(const nsgpu_ctx *ctx, uint32_t *anchors, uint32_t *slots, uint64_t *n_deferred);
 int nsgpu_get_schedule2(const nsgpu_ctx *ctx, uint32_t *groups, uint32_t *seed_bucket_depth, uint32_t *seed_rings, uint32_t *seed_tail_rings, uint32_t *builders);
 int nsgpu_get_schedule(const nsgpu_ctx *ctx, uint32_t *groups, uint32_t *seed_bucket_depth, uint32_t *seed_rings);
 int nsgpu_consensus_run(nsgpu_ctx *ctx, uint32_t n_builders, uint32_t n_threads_out, nsgpu_consensus_stats *stats_out);

@@ -702,28 +702,42 @@ static void batch_start_jobs(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi)
     }
 }
 
-// the host code's seeds for the jobs `which` of the batch (lookup table of the references concerned, each once -- pairs may share
-// one --, then collect_seeds) and a chaining launch for their lists on chaining workspace cw
-static int host_seed_and_chain_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, const std::vector<uint32_t> &which, int cw)
+// the host code's seeds for the jobs `which` of the batch: lookup table of the references concerned, each once -- pairs may share one --, then collect_seeds
+static void host_seed(nsgpu_ctx *c, AlignBatch &B, size_t lo, const std::vector<uint32_t> &which)
 {
     using namespace mm2;
     const Opt opt = batch_opt(c);
+    std::vector<uint32_t> todo;                       // one request per index without its table
+    for (uint32_t i : which) {
+        const AlignReq &r = B.reqs[lo + i];
+        if (r.idx->has_table) continue;
+        bool seen = false;
+        for (uint32_t j : todo) seen = seen || B.reqs[lo + j].idx == r.idx;
+        if (!seen) todo.push_back(i);
+    }
+    parallel_for("align.index", todo.size(), [&](size_t k) {
+        const AlignReq &r = B.reqs[lo + todo[k]];
+        if (r.ref_mz) r.idx->build_from_sketch(r.ref, (uint32_t)r.ref_len, opt.w, opt.k, opt.mid_occ_frac, r.ref_mz, r.n_ref_mz);
+        else r.idx->build(r.ref, (uint32_t)r.ref_len, opt.w, opt.k, opt.mid_occ_frac);
+    });
+    parallel_for("align.seed", which.size(), [&](size_t k) { B.jobs[lo + which[k]].seed(); });
+}
+// ... and a chaining launch for their lists on chaining workspace cw
+static int host_chain_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, const std::vector<uint32_t> &which, int cw)
+{
+    using namespace mm2;
     nsgpu_ctx::ChainWs &W = c->cws[cw];
     W.lists.clear(), W.off.assign(1, 0), W.avg.clear();
-    if (!which.empty()) {
-        for (uint32_t i : which) {
-            const AlignReq &r = B.reqs[lo + i];
-            if (r.idx->has_table) continue;
-            if (r.ref_mz) r.idx->build_from_sketch(r.ref, (uint32_t)r.ref_len, opt.w, opt.k, opt.mid_occ_frac, r.ref_mz, r.n_ref_mz);
-            else r.idx->build(r.ref, (uint32_t)r.ref_len, opt.w, opt.k, opt.mid_occ_frac);
-        }
-        parallel_for("align.seed", which.size(), [&](size_t k) { B.jobs[lo + which[k]].seed(); });
-        for (uint32_t i : which) {
-            const AlignJob &J = B.jobs[lo + i];
-            W.lists.push_back(J.a.data()), W.off.push_back(W.off.back() + J.a.size()), W.avg.push_back(J.avg_qspan);
-        }
+    for (uint32_t i : which) {
+        const AlignJob &J = B.jobs[lo + i];
+        W.lists.push_back(J.a.data()), W.off.push_back(W.off.back() + J.a.size()), W.avg.push_back(J.avg_qspan);
     }
-    return gpu_chain_launch(c, cw, opt, W.lists, W.off, W.avg);
+    return gpu_chain_launch(c, cw, batch_opt(c), W.lists, W.off, W.avg);
+}
+static int host_seed_and_chain_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, const std::vector<uint32_t> &which, int cw)
+{
+    host_seed(c, B, lo, which);
+    return host_chain_launch(c, B, lo, which, cw);
 }
 
 // Index + seeds on the GPU (seeds.hip), the chaining kernel on their lists (chain.hip) / the results and every job's first step
@@ -785,24 +799,36 @@ static int batch_wait_and_step(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi
     std::vector<uint32_t> &late = S.late;
     late.clear();
     for (size_t i = 0; i < n; ++i) if (S.pair_of[i] != ~0u && res[S.pair_of[i]].flags) late.push_back((uint32_t)i);
+    if (B.skip.size() < B.reqs.size()) B.skip.resize(B.reqs.size(), 0);
     if (!late.empty()) {
         S.fallbacks += late.size();
         const double l0 = now_ms();
-        NS_TRY(host_seed_and_chain_launch(c, B, lo, late, 2 * ws + 1));
-        const double l1 = now_ms();
-        NS_TRY(gpu_chain_wait(c, 2 * ws + 1, f2, p2));
-        S.late_seed_ms += l1 - l0, S.late_chain_ms += now_ms() - l1, ++S.late_calls;
+        host_seed(c, B, lo, late);
         for (uint32_t i : late) {
             const uint32_t fl = res[S.pair_of[i]].flags;
             for (int b = 0; b < 5; ++b) S.late_flag[b] += fl >> b & 1;
             const uint64_t na = B.jobs[lo + i].a.size();
             S.late_anchors += na, S.late_longest = std::max(S.late_longest, na);
         }
+        // the deferred ones (AlignBatch::defer_anchors): a list of 10^4 - 10^5 anchors takes milliseconds to chain and its DP problems as long again
+        if (B.defer_anchors) {
+            size_t keep = 0;
+            for (uint32_t i : late) {
+                if (B.jobs[lo + i].a.size() > B.defer_anchors) B.deferred.push_back((uint32_t)(lo + i)), B.skip[lo + i] = 1;
+                else late[keep++] = i;
+            }
+            late.resize(keep);
+        }
+        const double l1 = now_ms();
+        NS_TRY(host_chain_launch(c, B, lo, late, 2 * ws + 1));
+        NS_TRY(gpu_chain_wait(c, 2 * ws + 1, f2, p2));
+        S.late_seed_ms += l1 - l0, S.late_chain_ms += now_ms() - l1, ++S.late_calls;
         take(late);
     }
     B.chain_ms += now_ms() - g0;
     { std::lock_guard<std::mutex> lk(c->stat_m); c->aln_seed_host += S.fb.size() + late.size(), c->aln_seed_gpu += n - S.fb.size() - late.size(); }
     parallel_for("align.step", n, [&](size_t i) {
+        if (B.skip[lo + i]) return;
         AlignJob &J = B.jobs[lo + i];
         const uint32_t q = S.pair_of[i];
         if (q != ~0u && !res[q].flags) {
@@ -878,8 +904,8 @@ int align_begin(nsgpu_ctx *c, AlignBatch &B, int ws_index)
         NS_TRY(batch_wait_and_step(c, B, 0, n_pairs, 0));
         B.host_ms += now_ms() - a0;
     }
-    B.live.resize(n_pairs);
-    for (size_t i = 0; i < n_pairs; ++i) B.live[i] = (uint32_t)i;
+    B.live.clear();
+    for (size_t i = 0; i < n_pairs; ++i) if (!(i < B.skip.size() && B.skip[i])) B.live.push_back((uint32_t)i);
     NS_TRY(batch_prepare_round(c, B, true));
     if (B.live.empty()) return NSGPU_OK;
     const double a0 = now_ms();
@@ -904,7 +930,8 @@ int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs)
     // allocated on one thread and freed on another per alignment
     if (outs.size() < n_pairs) outs.resize(n_pairs);
     const bool had_early = B.early_done.size() == n_pairs;
-    for (size_t i = 0; i < n_pairs; ++i) if (!(had_early && B.early_done[i])) outs[i].reset();
+    auto skipped = [&](size_t i) { return i < B.skip.size() && B.skip[i]; };         // (deferred: the job has left the batch)
+    for (size_t i = 0; i < n_pairs; ++i) if (!(had_early && B.early_done[i]) && !skipped(i)) outs[i].reset();
     if (n_pairs == 0) return NSGPU_OK;
     const KswParams kp = batch_ksw_params(batch_opt(c));
     const double f0 = now_ms();
@@ -936,8 +963,9 @@ int align_finish(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &outs)
     }
     const double b0 = now_ms();
     g_finish_ms[1] += b0 - f1;
-    parallel_for("align.result", n_pairs, [&](size_t i) { if (!(had_early && B.early_done[i])) align_read_result(B.jobs[i], B.reqs[i].ref, B.reqs[i].ref_len, outs[i]); });
+    parallel_for("align.result", n_pairs, [&](size_t i) { if (!(had_early && B.early_done[i]) && !skipped(i)) align_read_result(B.jobs[i], B.reqs[i].ref, B.reqs[i].ref_len, outs[i]); });
     B.early_done.clear();
+    B.skip.clear(), B.deferred.clear();
     B.host_ms += now_ms() - b0;
     g_finish_ms[3] += now_ms() - b0;
     (void)f0;
@@ -963,6 +991,29 @@ int align_finish_early(nsgpu_ctx *c, AlignBatch &B, std::vector<mm2::AlnOut> &ou
     if (part == 0) g_finish_ms[0] += now_ms() - a0;
     parallel_for("align.early", n_pairs, [&](size_t i) { if (align_early_one(B, i, outs[i])) ready[i] = 1; });
     return NSGPU_OK;
+}
+
+int align_seeded_jobs(nsgpu_ctx *c, AlignBatch &B, int chain_ws, int dp_ws, std::vector<mm2::AlnOut> &outs)
+{
+    using namespace mm2;
+    const size_t n = B.reqs.size();
+    NS_CHECK(B.jobs.size() >= n, NSGPU_ERR_ARG, "align_seeded_jobs: jobs missing");
+    std::vector<uint32_t> all(n);
+    for (size_t i = 0; i < n; ++i) all[i] = (uint32_t)i;
+    B.skip.clear(), B.deferred.clear(), B.defer_anchors = 0, B.plan_ws = -1, B.host_ms = 0;
+    NS_TRY(host_chain_launch(c, B, 0, all, chain_ws));
+    const int32_t *f = nullptr, *p = nullptr;
+    NS_TRY(gpu_chain_wait(c, chain_ws, f, p));
+    const std::vector<uint64_t> &off = c->cws[chain_ws].off;
+    for (size_t i = 0; i < n && f; ++i) {
+        AlignJob &J = B.jobs[i];
+        J.own_f.assign(f + off[i], f + off[i + 1]), J.own_p.assign(p + off[i], p + off[i + 1]);
+        J.cf = J.own_f.data(), J.cp = J.own_p.data();
+    }
+    parallel_for("align.step", n, [&](size_t i) { B.jobs[i].step(); });
+    B.prestepped = true;
+    NS_TRY(align_begin(c, B, dp_ws));
+    return align_finish(c, B, outs);
 }
 
 int align_requests(nsgpu_ctx *c, std::vector<AlignReq> &reqs, std::vector<mm2::AlnOut> &outs, int ws_index)

@@ -193,7 +193,7 @@ struct nsgpu_ctx {
         bool dv_pending = false;
         std::vector<hipEvent_t> dv_ev;
         hipEvent_t dv_a = nullptr, dv_b = nullptr;
-    } kws[4];                                                       // 0: the context's stream (direct API calls); 1-3: own streams (contig engine, one per batch in flight)
+    } kws[8];                                                       // 0: the context's stream (direct API calls); 1-3: own streams (contig engine, one per batch in flight)
     // batched minimizer sketches (mm_sketch.hip): device buffers + pinned staging both ways
     struct SketchWs {
         nsgpu::DevBuf seqs, soff, len, sob, vf, mk, vr, linv, npf, pushf, npr, pr, V, hk, PX, PY, PRUN, PSEQ, rm, nout, oscan, off, out, scan_ws;
@@ -218,7 +218,7 @@ struct nsgpu_ctx {
         hipStream_t stream = nullptr;
         hipStream_t stream2 = nullptr; bool ring_used = false;         // the ring kernel's long lists run beside the LDS kernel's launch
         uint32_t seeded_lds_anchors = 0; uint64_t seeded_capacity = 0; // of the last seeded launch (d_out then holds f / p for the plan kernel)
-    } cws[18];                                                      // per batch workspace w: 2w the lists seeded on the GPU, 2w + 1 the ones seeded by the host code
+    } cws[26];                                                      // per batch workspace w: 2w the lists seeded on the GPU, 2w + 1 the ones seeded by the host code
     // index + seeds (seeds.hip): scratch tables, anchors (device), pair descriptors and results (pinned)
     struct SeedWs {
         nsgpu::DevBuf d_tab, d_next, d_ys, d_tmp, d_out, d_counter;
@@ -257,6 +257,8 @@ struct nsgpu_ctx {
     uint32_t read_id_base = 0;   // global id of local read 0 (multi-GPU shards)
     // schedule of the contig stage (nsgpu_set_schedule): pipeline groups (1, 2 or 4) and the conflict-aware seed rule (0 = off)
     uint32_t sched_groups = 4, seed_bucket_depth = 0, seed_rings = 1, seed_tail_rings = 1;
+    bool defer_set = false; uint64_t cons_n_deferred = 0;            // (cons_n_deferred: alignments deferred in the last contig stage)
+    uint32_t defer_anchors = 0, defer_slots = 0;     // nsgpu_set_defer (the automatic schedule: 4096 / 2): alignments with longer anchor lists take defer_slots more slots
     bool sched_auto = false, sched_set = false;      // nsgpu_set_schedule_auto / an explicit nsgpu_set_schedule: 0 builders with neither = the automatic schedule
     void *cons_engine = nullptr;                 // resumable contig engine (consensus_driver.hip)
     void (*cons_engine_free)(void *) = nullptr;

@@ -54,6 +54,8 @@ void debug_report_slots(nsgpu_ctx *c, Engine *E)
                         (unsigned long long)lf[0], (unsigned long long)lf[1], (unsigned long long)lf[2], (unsigned long long)lf[3], (unsigned long long)lf[4], (unsigned long long)la, (unsigned long long)ll,
                         (unsigned long long)lc, ls, lw);
     }
+    if (c->defer_slots) fprintf(stderr, "[cons] deferred alignments (more than %u anchors: %u more slots): %llu; their batches ran %.0f ms in sum beside the slots, the slots waited %.0f ms for them\n",
+                                c->defer_anchors, c->defer_slots, (unsigned long long)E->n_deferred, E->defer_run_ms, E->defer_join_ms);
     double cs = 0, ce = 0, cw = 0; uint64_t cn = 0;
     for (nsgpu_ctx::ChainWs &w : c->cws) cs += w.ms_stage, ce += w.ms_enqueue, cw += w.ms_wait, cn += w.calls, w.ms_stage = w.ms_enqueue = w.ms_wait = 0, w.calls = 0;
     fprintf(stderr, "[cons] chaining scores on the GPU (inside sketch+index): %.0f ms wall in %llu calls: staging %.0f, enqueue %.0f, wait (copies + kernel) %.0f\n", chain_ms,

@@ -67,7 +67,7 @@ static int run_consensus_dist(nsgpu_ctx *c, Comm &C, uint32_t n_builders_total, 
             // claim exchange -- one more small all-gather per slot
             if (rc == NSGPU_OK) {
                 ca.clear(), cb.clear();
-                for (const Builder &bb : E->D.B) if (bb.st == Builder::WAIT_ALIGN) { ca.push_back(bb.gid); cb.push_back(bb.pend); }
+                for (const Builder &bb : E->D.B) if (bb.st == Builder::WAIT_ALIGN || (bb.st == Builder::DEFERRED && bb.defer_due == slot)) { ca.push_back(bb.gid); cb.push_back(bb.pend); }
             }
             NS_TRY(exchange(rc, &ca, &cb, nullptr, nullptr));
             gathered(1);

@@ -26,6 +26,7 @@ static void engine_free(void *p)
     Engine *E = static_cast<Engine *>(p);
     for (Builder &b : E->D.B) { b.d_mz.release(); b.d_cons.release(); b.d_cnt.release(); b.d_cnt_hm.release(); }
     for (Engine::Lane &L : E->lane) L.release();
+    for (Engine::DeferBatch &DB : E->defer) if (DB.th.joinable()) DB.th.join();       // (a run that ended in an error may leave one in flight)
     delete E;
 }
 
@@ -51,12 +52,14 @@ int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, uint32_
     D.rep.assign((size_t)D.N + 1, 0);
     E->t0 = now_ms();
     if (D.N) NS_TRY(nsgpu_check_repetitive(c, D.rep.data()));
+    if (!auto_now && !c->defer_set) c->defer_anchors = c->defer_slots = 0;
     if (!auto_now && !c->sched_set) c->sched_groups = 4, c->seed_bucket_depth = 0, c->seed_rings = 1, c->seed_tail_rings = 1;      // (nothing chosen, builders given: the defaults, whatever an automatic run before derived)
     if (auto_now) {
         c->sched_groups = 1;
         if (D.N) NS_TRY(whole_read_filter(c, E));
         const AutoSchedule a = auto_schedule(D.N, c->reads.n_bases, E->sp.n_filter_results);
         c->seed_bucket_depth = a.depth, c->seed_rings = a.rings, c->seed_tail_rings = a.tail;
+        if (!c->defer_set) c->defer_anchors = 4096, c->defer_slots = 2;        // (reads across long repeats: Engine::DeferBatch)
         if (n_builders_total == 0) n_builders_total = a.builders;
         if (getenv("NSGPU_CONS_DEBUG")) fprintf(stderr, "[cons] automatic schedule: %.1f filter results per read -> %u builders, one group, buckets of depth %u, %u rings (%u in the tail)\n",
                                                 D.N ? (double)E->sp.n_filter_results / D.N : 0.0, n_builders_total, a.depth, a.rings, a.tail);
@@ -303,6 +306,71 @@ __global__ void mz_tail_scatter_kernel(const TailCopy *__restrict__ jobs, uint32
 // The contigs' consensus strings in HBM brought up to date for the builders of an alignment batch (after the sketch batch staged the changed
 // stretches, before the plan kernel reads them), and AlignReq.ref_dev pointed at them.  A builder whose copy cannot be updated (nothing
 // staged to update it from) goes without the device plan this time.
+// ---- deferred alignments (Engine::DeferBatch) ----
+// The jobs AB.deferred of the slot's batch (started and seeded by the host code, anchors in place) move into a batch of their own, which a thread of
+// its own takes through chaining, DP rounds and conversion; their builders wait until slot cur_slot + defer_slots.
+static int engine_defer_start(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std::vector<uint32_t> &who)
+{
+    Driver &D = E->D;
+    Engine::DeferBatch &DB = E->defer[E->cur_slot & 3];
+    NS_CHECK(!DB.busy && c->defer_slots >= 1 && c->defer_slots <= 3, NSGPU_ERR_ARG, "contig engine: a deferred batch is still in flight after %u slots (internal error)", c->defer_slots);
+    const size_t n = AB.deferred.size();
+    DB.AB.reqs.clear(), DB.builder.clear();
+    if (DB.AB.jobs.size() < n) DB.AB.jobs.resize(n);
+    if (DB.qmz.size() < n) DB.qmz.resize(n);
+    if (DB.outs.size() < n) DB.outs.resize(n);
+    for (size_t k = 0; k < n; ++k) {
+        const uint32_t i = AB.deferred[k];
+        Builder &b = D.B[who[i]];
+        AlignReq r = AB.reqs[i];
+        // (what stays valid while the builder waits: its consensus, its index, its host minimizer list, its query string; the candidate's minimizers
+        // lie in the slot's sketch workspace and are copied)
+        DB.qmz[k].assign(r.qry_mz, r.qry_mz + r.n_qry_mz);
+        r.qry_mz = DB.qmz[k].data();
+        r.ref_mz_dev = nullptr, r.ref_cnt = nullptr, r.ref_cnt_meta = nullptr, r.qry_dev = nullptr, r.ref_dev = nullptr;
+        DB.AB.reqs.push_back(r);
+        std::swap(DB.AB.jobs[k], AB.jobs[i]);
+        DB.AB.jobs[k].pre_mz = DB.qmz[k].data();
+        DB.builder.push_back(who[i]);
+        b.st = Builder::DEFERRED, b.defer_due = E->cur_slot + c->defer_slots;
+    }
+    DB.due = E->cur_slot + c->defer_slots, DB.busy = true, DB.rc = NSGPU_OK, DB.err.clear();
+    const int chain_ws = 18 + (int)(E->cur_slot & 3), dp_ws = 4 + (int)(E->cur_slot & 3);
+    Engine::DeferBatch *dbp = &DB;
+    Engine *Ep = E;
+    DB.th = std::thread([c, dbp, Ep, chain_ws, dp_ws] {
+        pool_bind_this_thread();
+        const double t0 = now_ms();
+        dbp->rc = hipSetDevice(c->prm.device) == hipSuccess ? align_seeded_jobs(c, dbp->AB, chain_ws, dp_ws, dbp->outs) : NSGPU_ERR_HIP;
+        if (dbp->rc != NSGPU_OK) dbp->err = nsgpu_last_error();
+        Ep->defer_run_ms += now_ms() - t0;        // (debug print; one deferred batch ends at a time in practice)
+    });
+    E->n_deferred += n;
+    return NSGPU_OK;
+}
+// the deferred batches due at the end of this slot: their builders are ALIGNED like the slot's own
+static int engine_defer_deliver(nsgpu_ctx *c, Engine *E)
+{
+    Driver &D = E->D;
+    for (Engine::DeferBatch &DB : E->defer) {
+        if (!DB.busy || DB.due != E->cur_slot) continue;
+        const double t0 = now_ms();
+        if (DB.th.joinable()) DB.th.join();
+        E->defer_join_ms += now_ms() - t0;
+        DB.busy = false;
+        if (DB.rc != NSGPU_OK) { set_error("%s", DB.err.empty() ? "contig engine: a deferred alignment batch failed" : DB.err.c_str()); return DB.rc; }
+        for (size_t k = 0; k < DB.builder.size(); ++k) {
+            Builder &b = D.B[DB.builder[k]];
+            std::swap(b.aln, DB.outs[k]);
+            b.early_result = false, b.early_updated = false;
+            ++b.n_align_calls;
+            b.accepted = false;
+            b.st = Builder::ALIGNED;
+        }
+    }
+    return NSGPU_OK;
+}
+
 static int engine_cons_update(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std::vector<uint32_t> &who, const std::vector<uint8_t> &changed, const std::vector<const uint8_t *> &staged_of, Engine::Lane &L)
 {
     Driver &D = E->D;
@@ -617,9 +685,11 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
     }
     if (use_dev_plan) NS_TRY(engine_cons_update(c, E, AB, who, changed, staged, L));
     else for (size_t w = 0; w < n; ++w) if (changed[w]) D.B[who[w]].dc_valid = false;          // (a batch that does not update the device copies leaves them stale)
+    AB.defer_anchors = n_groups(c) == 1 && c->defer_slots ? c->defer_anchors : 0;
     NS_TRY(align_prestep_launch(c, AB, 0, n, sws_i, true, use_dev_plan ? dp_ws : -1));
     L.sk_ms[4] += now_ms() - tk; tk = now_ms();
     NS_TRY(align_prestep_finish(c, AB, 0, n, sws_i));
+    if (!AB.deferred.empty()) NS_TRY(engine_defer_start(c, E, AB, who));
     L.sk_ms[5] += now_ms() - tk;
     E->awho[gi] = who;
     E->dbg_batch_sizes.push_back((uint32_t)who.size());
@@ -733,6 +803,7 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
     std::vector<uint32_t> &pends = E->early_pends;
     pends.clear();
     for (int k = 0; k < n_gi; ++k) for (uint32_t bi : E->awho[gis[k]]) pends.push_back(D.B[bi].pend);
+    for (const Builder &b : D.B) if (b.st == Builder::DEFERRED && b.defer_due == E->cur_slot) pends.push_back(b.pend);      // (deferred alignments that claim with this slot's)
     // (several ranks: the other ranks' builders count as well -- their candidate reads came with the slot's exchange, run_consensus_dist)
     const bool global_known = E->world == 1 || E->have_global_pends;
     std::vector<uint32_t> sorted(E->world == 1 || !E->have_global_pends ? pends : E->global_pends);
@@ -915,12 +986,14 @@ static int engine_align_finish(nsgpu_ctx *c, int group)
     nsgpu_consensus_stats &S = c->cons_stats;
     const int gi = group < 0 ? 0 : group;
     std::vector<uint32_t> &who = E->awho[gi];
-    if (who.empty()) return NSGPU_OK;
+    if (who.empty()) return engine_defer_deliver(c, E);
     Engine::Lane &L = E->lane[gi];
     const double g1 = now_ms();
     NS_TRY(align_finish(c, E->ab[gi], L.outs));
+    NS_TRY(engine_defer_deliver(c, E));
     for (size_t w = 0; w < who.size(); ++w) {
         Builder &b = D.B[who[w]];
+        if (b.st == Builder::DEFERRED) continue;                      // (its alignment left the batch: engine_defer_start)
         if (!b.early_result) std::swap(b.aln, L.outs[w]);              // the builder's previous result goes back into the pool of result objects
         b.early_result = false;
         ++b.n_align_calls;
@@ -955,6 +1028,7 @@ int engine_finish(nsgpu_ctx *c, uint32_t n_threads_out)
     // merge builders into the requested number of output "threads" (Compressor expects exactly numThr
     // file sets, src/Compressor.cpp:123-124; Decompressor reads numThr from metaData)
     c->cons_out.assign(n_threads_out, cons::StreamSet());
+    c->cons_n_deferred = E->n_deferred;
     pool_drain();                                 // all edit emissions
     for (size_t i = 0; i < D.B.size(); ++i)
         for (auto &fc : D.B[i].contigs) c->cons_out[i * n_threads_out / (D.B.empty() ? 1 : D.B.size())].append(fc->out);
@@ -1018,6 +1092,7 @@ int engine_slot(nsgpu_ctx *c, uint32_t slot, int part)
     const uint32_t G = (uint32_t)n_groups(c);
     const int host_group = (int)(slot % G), begin_group = (int)((slot + G - 1) % G), finish_group = (int)((slot + 1) % G);
     const int ws_index = 1 + (int)(slot % 3);
+    static_cast<Engine *>(c->cons_engine)->cur_slot = slot;
     static const bool serial = getenv("NSGPU_NO_OVERLAP") != nullptr;      // debugging aid: one after the other
     if (G <= 2) {
         // One or two groups (nsgpu_set_schedule): a builder's step takes G slots instead of four -- the schedule for few builders,
@@ -1325,6 +1400,24 @@ int nsgpu_set_schedule_auto(nsgpu_ctx *c)
     NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
     NS_CHECK(!c->cons_engine, NSGPU_ERR_ARG, "nsgpu_set_schedule_auto: a contig stage is in progress");
     c->sched_auto = true, c->sched_set = false;
+    return NSGPU_OK;
+}
+
+int nsgpu_set_defer(nsgpu_ctx *c, uint32_t anchors, uint32_t slots)
+{
+    NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
+    NS_CHECK(!c->cons_engine, NSGPU_ERR_ARG, "nsgpu_set_defer: a contig stage is in progress");
+    NS_CHECK(slots <= 3 && (slots == 0 || anchors >= 1), NSGPU_ERR_ARG, "nsgpu_set_defer: 0 .. 3 slots, at least one anchor");
+    c->defer_anchors = slots ? anchors : 0, c->defer_slots = slots, c->defer_set = true;
+    return NSGPU_OK;
+}
+
+int nsgpu_get_defer(const nsgpu_ctx *c, uint32_t *anchors, uint32_t *slots, uint64_t *n_deferred)
+{
+    NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
+    if (anchors) *anchors = c->defer_anchors;
+    if (slots) *slots = c->defer_slots;
+    if (n_deferred) *n_deferred = c->cons_n_deferred;
     return NSGPU_OK;
 }
 

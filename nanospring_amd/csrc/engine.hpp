@@ -35,8 +35,11 @@ struct FinishedContig {
 };
 
 struct Builder {
-    enum State { NEED_CONTIG, ADVANCE, WAIT_FILTER, WAIT_ALIGN, GOT_FILTER, ALIGNED, GOT_ALIGN, DONE };
+    // DEFERRED: its alignment was taken out of its slot's batch (a read across a long repeat, Engine::DeferBatch) and is delivered at the end of
+    // slot defer_due; until then the builder takes part in nothing
+    enum State { NEED_CONTIG, ADVANCE, WAIT_FILTER, WAIT_ALIGN, GOT_FILTER, ALIGNED, GOT_ALIGN, DONE, DEFERRED };
     State st = NEED_CONTIG;
+    uint32_t defer_due = 0;
     uint32_t id = 0, gid = 0;                 // local index / global builder id
     int group = 0;                            // pipeline group (a function of gid only, so that it does not depend on the rank count)
     std::unique_ptr<cons::ContigGraph> g;
@@ -370,6 +373,26 @@ struct Engine {
     uint64_t n_wq_exact = 0;                          // window-query batches that went the exact multi-step way
     int deferred_fresh = -1;                          // group whose freshly started contigs take their first steps with the next host phase
     AlignBatch ab[kMaxGroups];                        // alignment batch of each group, DP kernels in flight between part 1 and part 2
+    // ---- deferred alignments (one-group schedule; nsgpu_set_defer) ----
+    // A read across a tandem repeat has 10^4 - 10^5 anchors; chaining its list and running its DP problems take 5 - 10 ms, twice a whole slot,
+    // and in lock step every builder of the slot waited for it.  The rule (the lock-step oracle's, oracle/consensus_oracle.cpp LockStep::VT::extra):
+    // an alignment whose anchor list -- collect_seed_hits's, before chaining -- is longer than `defer_anchors` takes `defer_slots` MORE slots
+    // than the others: its result is delivered, and its claim made, at the end of slot s + defer_slots.  The builder's consensus does not change
+    // meanwhile, so the result is the one the slot's batch would have had; the jobs leave the batch (AlignBatch::deferred) for a batch of their own
+    // that a thread of its own takes through chaining, DP rounds and conversion on workspaces of its own, joined when due.
+    struct DeferBatch {
+        AlignBatch AB;
+        std::vector<uint32_t> builder;                // per request: the builder
+        std::vector<std::vector<mm2::Anchor>> qmz;    // per request: the candidate's minimizers (the batch's copy lies in a sketch workspace that is reused)
+        std::vector<mm2::AlnOut> outs;
+        uint32_t due = 0;
+        bool busy = false;
+        std::thread th;
+        int rc = NSGPU_OK;
+        std::string err;
+    } defer[4];
+    uint32_t cur_slot = 0;
+    uint64_t n_deferred = 0; double defer_join_ms = 0, defer_run_ms = 0;
     std::vector<uint32_t> fwho;                    // builders of the window-query batch
     std::vector<uint32_t> awho[kMaxGroups];           // builders of that batch
     Builder *local(uint32_t gid) { return gid % world == rank ? &D.B[gid / world] : nullptr; }

@@ -150,6 +150,13 @@ struct AlignBatch {
     bool plan_two_part = false;                          // set by the caller: fetch the device-planned results in two parts (align_finish_early first)
     std::vector<uint8_t> plan_delivered;                 // per request: its device-planned results are in the job's cache
     std::vector<uint8_t> early_done;                     // per request: finished by align_finish_early (its AlnOut is final)
+    // Deferred alignments (the contig engine's rule for reads across long repeats, engine.hpp DeferBatch): with defer_anchors > 0 a pair the
+    // seeding kernel handed back whose host-seeded list has more anchors than that is NOT chained and aligned with the batch: its request index
+    // goes to `deferred`, skip[i] = 1 takes it out of everything that follows (no step, no DP round, no result), and the caller moves its job out
+    // (B.jobs[i], seeded, anchors in J.a) before the batch's next use.
+    uint32_t defer_anchors = 0;
+    std::vector<uint32_t> deferred;
+    std::vector<uint8_t> skip;
     AlignBatch() = default;
     AlignBatch(const AlignBatch &) = delete;
     AlignBatch &operator=(const AlignBatch &) = delete;
@@ -163,6 +170,9 @@ int align_prestep(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_w
 int align_prestep_start(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi);
 int align_prestep_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws, bool started_and_seeded = false, int dp_ws = -1);   // dp_ws >= 0: + the device plan and its DP launch
 int align_prestep_finish(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int chain_ws);
+// a batch of jobs that were started and seeded by the host code elsewhere (AlignBatch::deferred of another batch, moved in): their chaining scores
+// on chaining workspace chain_ws, then align_begin .. align_finish on DP workspace dp_ws.  Safe beside other batches on other workspaces.
+int align_seeded_jobs(nsgpu_ctx *c, AlignBatch &B, int chain_ws, int dp_ws, std::vector<mm2::AlnOut> &outs);
 // chain.hip: mm_chain_dp's forward pass for a batch of anchor lists (host pointers in, pinned host results out)
 int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vector<const mm2::Anchor *> &lists, const std::vector<uint64_t> &off,
                      const std::vector<float> &avg);

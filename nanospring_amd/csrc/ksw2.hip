@@ -715,7 +715,7 @@ int ksw_batch_launch(nsgpu_ctx *c, std::vector<KswTask> &tasks, const uint8_t *s
                      std::vector<KswResult> &results, std::vector<uint32_t> &cigars, std::vector<uint64_t> &cig_off, int ws_index)
 {
     const size_t n = tasks.size();
-    NS_CHECK(ws_index >= 0 && ws_index <= 3, NSGPU_ERR_ARG, "ksw: workspace index must be 0..3");
+    NS_CHECK(ws_index >= 0 && ws_index <= 7, NSGPU_ERR_ARG, "ksw: workspace index must be 0..7");
     nsgpu_ctx::KswWs &W = c->kws[ws_index];
     // workspace 0 works on the context's stream; workspace 1 owns one (the second half batch of the contig engine)
     if (ws_index >= 1 && !W.stream) NS_TRY(role_stream_create(&W.stream, "dp"));
@@ -1072,7 +1072,8 @@ __global__ void ksw_dev_ctrl_kernel(const DvCtrl *__restrict__ ctrl, DvCtrl *__r
 // left to the host by the plan kernel.
 static uint32_t dev_class_grid(int cls, uint32_t n_slots, uint32_t n_pairs)
 {
-    const uint32_t per_pair = cls == 0 || cls == 1 || cls == 4 || cls == 5 || cls == 9 ? 0u : cls == 3 || cls == 7 ? 4u : 8u;
+    if (cls == 3) return std::min<uint32_t>(n_slots, n_pairs / 2 + 16);          // (<8,5>: ~100 KB of LDS per workgroup)
+    const uint32_t per_pair = cls == 0 || cls == 1 || cls == 4 || cls == 5 || cls == 9 ? 0u : cls == 7 ? 4u : 8u;
     return per_pair ? std::min<uint32_t>(n_slots, per_pair * n_pairs + 32) : n_slots;
 }
 
@@ -1126,7 +1127,7 @@ int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr
     const KswClassCfg &kc = ksw_class_config();
     // the classes the plan kernel's rule (ksw_launch_class_hd) can name under the current switches
     uint32_t classes = 1u << 0 | 1u << 1;
-    classes |= 1u << 8;                                                      // (the widest class is not planned on the device: plan.hip)
+    classes |= 1u << 8 | 1u << 3;
     if (two_phase && kc.long_rows > 0) classes |= 1u << 12;
     W.dv_classes = classes;
     bool side_used[3] = {false, false, false};
@@ -1170,7 +1171,7 @@ int ksw_dev_launch(nsgpu_ctx *c, int ws_index, int max_qlen, const KswParams &pr
     // streams; the bulk on the main stream, and behind it the first part of the results
     for (int k = KSW_REG_CLASSES - 1; k >= 2; --k) {
         if (!(classes >> k & 1)) continue;
-        const int si = k == 12 ? 2 : k == 8 ? 1 : k >= 6 ? k - 5 : k >= 4 ? 0 : k - 1;
+        const int si = k == 12 ? 2 : k == 8 ? 1 : k == 3 ? 0 : k >= 6 ? k - 5 : k >= 4 ? 0 : k - 1;        // (each of the three late classes on a stream of its own)
         hipStream_t st = W.side_stream[si];
         if (!side_used[si]) NS_HIP(hipStreamWaitEvent(st, W.side_fork, 0));
         side_used[si] = true;

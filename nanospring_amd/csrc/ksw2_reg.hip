@@ -820,17 +820,28 @@ struct RegClass { int nw, nch; };
 // their numbers stay unused so that the others keep theirs).
 // Classes 9 .. 11 belonged to the systolic kernel (removed in round 5, see above).
 // Class 12 is <1,4> once more: the long problems of the one-wave classes in a launch of their own (device-planned batches, ksw_class.hpp).
-constexpr RegClass kRegClass[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {6, 2}, {8, 5}, {1, 2}, {1, 4}, {6, 2}, {8, 5}, {6, 2}, {5, 1}, {5, 2}, {5, 3}, {1, 4}};
-constexpr int reg_compute_waves(int cls) { return kRegClass[cls].nw; }
+// NSGPU_KSW_VARIANT (A/B, round 5): bit 0: class 12 (the long problems of the one-wave classes) on <4,1> -- one block per wave; bit 1: class 8
+// (513 .. 1536 columns) on <12,1>; bit 2: class 3 (up to 5120 columns) on <16,3>
+static int reg_variant() { static const int v = getenv("NSGPU_KSW_VARIANT") ? atoi(getenv("NSGPU_KSW_VARIANT")) : 0; return v; }
+static RegClass reg_class_of(int cls)
+{
+    constexpr RegClass base[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {6, 2}, {8, 5}, {1, 2}, {1, 4}, {6, 2}, {8, 5}, {6, 2}, {5, 1}, {5, 2}, {5, 3}, {1, 4}};
+    const int v = reg_variant();
+    if (cls == 12 && (v & 1)) return RegClass{4, 1};
+    if (cls == 8 && (v & 2)) return RegClass{12, 1};
+    if (cls == 3 && (v & 4)) return RegClass{16, 3};
+    return base[cls];
+}
+static int reg_compute_waves(int cls) { return reg_class_of(cls).nw; }
 
 }  // namespace
 
-int ksw_reg_cells(int cls) { return reg_compute_waves(cls) * kRegClass[cls].nch * 128; }
-int ksw_reg_threads(int cls) { return kRegClass[cls].nw * 64; }
+int ksw_reg_cells(int cls) { return reg_compute_waves(cls) * reg_class_of(cls).nch * 128; }
+int ksw_reg_threads(int cls) { return reg_class_of(cls).nw * 64; }
 
 size_t ksw_reg_lds_bytes(int cls, int qlen)
 {
-    const int nw = kRegClass[cls].nw, nb = reg_compute_waves(cls) * kRegClass[cls].nch;
+    const int nw = reg_class_of(cls).nw, nb = reg_compute_waves(cls) * reg_class_of(cls).nch;
     size_t b = 2 * (size_t)reg_qb(ksw_reg_cells(cls), qlen);
     b += (size_t)2 * nb * 12 + (size_t)3 * (nw + 2) * 4 + 52;      // seams / publication slots (a one-wave class uses two of the slots) / stop flag
     b += 16 + 64;                                                  // the approx books' state, two slots (aligned)
@@ -878,9 +889,9 @@ int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const 
     switch (cls) {
     case 0: NS_REG_LAUNCH(1, 2) break;
     case 1: NS_REG_LAUNCH(1, 4) break;
-    case 3: NS_REG_LAUNCH(8, 5) break;
-    case 8: NS_REG_LAUNCH(6, 2) break;
-    case 12: NS_REG_LAUNCH(1, 4) break;
+    case 3: if (reg_variant() & 4) NS_REG_LAUNCH(16, 3) else NS_REG_LAUNCH(8, 5) break;
+    case 8: if (reg_variant() & 2) NS_REG_LAUNCH(12, 1) else NS_REG_LAUNCH(6, 2) break;
+    case 12: if (reg_variant() & 1) NS_REG_LAUNCH(4, 1) else NS_REG_LAUNCH(1, 4) break;
     default: NS_CHECK(false, NSGPU_ERR_ARG, "ksw: bad register class");
     }
 #undef NS_REG_LAUNCH

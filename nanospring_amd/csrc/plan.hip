@@ -398,9 +398,9 @@ __global__ __launch_bounds__(kThreads) void align_plan_kernel(const SeedResult *
             if (K.rs < (int)pp.ref_lo || K.re > (int)(pp.ref_lo + pp.ref_n)) bad |= PLAN_SPAN;
             const int c = ksw_launch_class_hd(ql, tl, K.w, K.flag, cfg.kp, cfg.kc, cfg.two_phase != 0);
             const size_t pbytes = (ksw_p_bytes_hd(ql, tl, K.w) + 63) & ~(size_t)63;
-            // (the widest classes, targets beyond 1536 columns, are a handful of problems per thousand slots, and an empty workgroup of theirs
-            // still claims ~100 KB of LDS on a CU: they are not launched from device lists -- such an alignment is the host's)
-            if (c < 0 || c == 3 || c == 7 || ql > cfg.q_max || pbytes >= (1ull << 32)) bad |= PLAN_CLASS;
+            // (the widest class, targets beyond 1536 columns: a handful of problems per thousand slots on an iid genome, two per slot on one with
+            // repeats -- launched from a device list of its own with a small grid, ksw2.hip dev_class_grid: what does not fit is the host's)
+            if (c < 0 || c == 7 || ql > cfg.q_max || pbytes >= (1ull << 32)) bad |= PLAN_CLASS;
             else {
                 cls = (uint32_t)c, pb = (uint32_t)pbytes, cg = (uint32_t)(ql + tl + 2);
                 if (ksw_class_is_slow(c)) atomicOr(&L.sh[37], 1);

@@ -116,7 +116,8 @@ constexpr int kSeedThreads = 512;
 struct SeedLds { uint32_t n_slots; };
 
 __global__ __launch_bounds__(kSeedThreads) void seed_kernel(const SeedPair *__restrict__ pairs, mm2::Anchor *__restrict__ tmp, mm2::Anchor *__restrict__ out,
-                                                            unsigned long long *__restrict__ counter, unsigned long long capacity, SeedResult *__restrict__ res, uint32_t q_slots)
+                                                            unsigned long long *__restrict__ counter, unsigned long long capacity, SeedResult *__restrict__ res, uint32_t q_slots,
+                                                            uint32_t sort_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     // LDS: keys[kSortCap] u64 | qkey[q_slots] u64 | qhead[q_slots] u32 | qnext[q_cap] u32 | qy[q_cap] u32 | qspan[q_cap] u8 (q_cap = q_slots / 2)
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(kSeedThreads) void seed_kernel(const SeedPair *__re
     const uint32_t total = s_emit;
     if (tid == 0) {
         s_base = atomicAdd(counter, (unsigned long long)total);
-        if (total > kSortCap) s_flag |= SEED_FLAG_MANY;
+        if (total > sort_cap) s_flag |= SEED_FLAG_MANY;          // (sort_cap <= kSortCap: the engine's rule for deferred alignments hands shorter lists back, nsgpu_set_defer)
         if (s_base + total > capacity) s_flag |= SEED_FLAG_CAPACITY;
     }
     __syncthreads();
@@ -311,7 +312,8 @@ int gpu_seeds_launch(nsgpu_ctx *c, int ws, float mid_occ_frac, std::vector<SeedP
     if (lds > 32768) NS_TRY(attr.raise(lds, reinterpret_cast<const void *>(seed_kernel)));
     // the pair descriptors and the results are read / written in place in pinned memory
     hipLaunchKernelGGL(seed_kernel, dim3((unsigned)n), dim3(kSeedThreads), lds, W.stream, W.h_pairs.as<SeedPair>(), W.d_tmp.as<mm2::Anchor>(), W.d_out.as<mm2::Anchor>(),
-                       W.d_counter.as<unsigned long long>(), (unsigned long long)want, W.h_res.as<SeedResult>(), q_slots);
+                       W.d_counter.as<unsigned long long>(), (unsigned long long)want, W.h_res.as<SeedResult>(), q_slots,
+                       c->defer_slots && c->defer_anchors < kSortCap ? c->defer_anchors : kSortCap);
     NS_HIP(hipGetLastError());
     NS_HIP(hipMemcpyAsync(W.h_res.as<uint8_t>() + n * sizeof(SeedResult), W.d_counter.p, 8, hipMemcpyDeviceToHost, W.stream));
     return NSGPU_OK;

@@ -409,8 +409,23 @@ def get_schedule(gpu):
     return tuple(int(x.value) for x in v)
 
 
-def consensus_run(gpu, n_builders=256, n_threads_out=1, schedule=None):
-    """schedule: (groups, depth, rings[, tail rings]), or "auto" (nsgpu_set_schedule_auto; n_builders = 0 lets the library choose the count too)"""
+def set_defer(gpu, anchors, slots):
+    """alignments with more than `anchors` anchors take `slots` more slots (nsgpu_set_defer; 0 slots = off)"""
+    check(gpu.lib, gpu.lib.nsgpu_set_defer(gpu.ctx, int(anchors), int(slots)))
+
+
+def get_defer(gpu):
+    """(anchors, slots, alignments deferred in the last contig stage)"""
+    a, s, n = C.c_uint32(), C.c_uint32(), C.c_uint64()
+    check(gpu.lib, gpu.lib.nsgpu_get_defer(gpu.ctx, C.byref(a), C.byref(s), C.byref(n)))
+    return int(a.value), int(s.value), int(n.value)
+
+
+def consensus_run(gpu, n_builders=256, n_threads_out=1, schedule=None, defer=None):
+    """schedule: (groups, depth, rings[, tail rings]), or "auto" (nsgpu_set_schedule_auto; n_builders = 0 lets the library choose the count too);
+    defer: (anchors, slots) for nsgpu_set_defer"""
+    if defer is not None:
+        set_defer(gpu, *defer)
     if isinstance(schedule, str):
         assert schedule == "auto"
         check(gpu.lib, gpu.lib.nsgpu_set_schedule_auto(gpu.ctx))

@@ -53,6 +53,15 @@ uint64_t oracle_filter_string(const char *s, uint64_t len, uint32_t k, uint32_t 
 // reg[0] of mm_map as oracle/ref_mm2_driver.c flattens it
 typedef struct { int32_t hits, rs, re, qs, qe, blen, mlen, n_ambi, dp_max, dp_score, score, cnt, rev, mid_occ, n_cigar; } co_hit_t;
 typedef int (*co_align_fn)(const char *ref, int rl, const char *qry, int ql, int k, int w, int max_chain_iter, co_hit_t *out, uint32_t *cigar, int cigar_cap);
+// the anchors of a pair before chaining (oracle/ref_mm2_driver.c ref_mm_count_seeds): the lock-step schedule's rule for deferred alignments
+typedef int64_t (*co_count_fn)(const char *ref, int rl, const char *qry, int ql, int k, int w);
+static co_count_fn g_count_fn = nullptr;
+static uint32_t g_defer_anchors = 0, g_defer_slots = 0;
+extern "C" void cons_oracle_set_defer(void *count_fn, uint32_t anchors, uint32_t slots)
+{
+    g_count_fn = (co_count_fn)count_fn;
+    g_defer_anchors = anchors, g_defer_slots = count_fn ? slots : 0;
+}
 
 namespace {
 
@@ -707,6 +716,8 @@ struct LockStep {
     struct VT {
         Kind kind = RUN;
         uint32_t at = 0;            // slot in which the thread started to wait
+        uint32_t extra = 0;         // an alignment with a long anchor list takes so many MORE slots (cons_oracle_set_defer; include/nsgpu.h nsgpu_set_defer):
+                                    // the thread goes on, and its claim is made, that much later -- the alignment itself is the same
         bool ok = false, won = false, go = false;
         read_t r = 0;
         std::condition_variable cv;
@@ -934,6 +945,11 @@ public:
                 if (ls) {                                                      // one period per alignment; the claim is phase B's, in thread order
                     LockStep::VT &t = *ls->vt[lsTid()];
                     t.ok = alignStatus, t.r = r, t.won = false;
+                    t.extra = 0;
+                    if (g_defer_slots && ls->G == 1) {
+                        const std::string &ref = cG->mainPath.path;
+                        if (g_count_fn(ref.c_str(), (int)ref.size(), readStr.c_str(), (int)readStr.size(), (int)m_k, (int)m_w) > (int64_t)g_defer_anchors) t.extra = g_defer_slots;
+                    }
                     ls->park(lsTid(), LockStep::ALIGN);
                     if (!t.won) continue;
                 } else {
@@ -1045,13 +1061,13 @@ public:
             // phase A: the group's threads whose window or alignment has had its period run on, concurrently (they only READ inGraph)
             for (uint32_t v = 0; v < T; ++v) {
                 LockStep::VT &t = *L.vt[v];
-                if (L.group(v) == g && (t.kind == LockStep::WINDOW || t.kind == LockStep::ALIGN) && t.at < L.slot) L.release(lk, v);
+                if (L.group(v) == g && (t.kind == LockStep::WINDOW || t.kind == LockStep::ALIGN) && t.at + (t.kind == LockStep::ALIGN ? t.extra : 0u) < L.slot) L.release(lk, v);
             }
             L.waitIdle(lk);
             auto phaseB = [&] {     // claims of group b (asked for G - 1 slots ago), in thread order
                 for (uint32_t v = 0; v < T; ++v) {
                     LockStep::VT &t = *L.vt[v];
-                    if (L.group(v) != b || t.kind != LockStep::ALIGN || t.at + L.G - 1 != L.slot || !t.ok) continue;
+                    if (L.group(v) != b || t.kind != LockStep::ALIGN || t.at + t.extra + L.G - 1 != L.slot || !t.ok) continue;
                     if (inGraph[t.r]) continue;
                     inGraph[t.r] = 1;
                     t.won = true;

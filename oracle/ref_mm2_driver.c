@@ -63,6 +63,35 @@ int ref_mm2_align(const char *ref, int rl, const char *qry, int ql, int k, int w
     return hits;
 }
 
+/* The number of anchors collect_seed_hits (minimap2/map.c:215-247) gives mm_map_frag's first chaining pass for this pair, counted with the
+ * library's own index and sketch through its public calls: every query minimizer whose hash the reference holds fewer than mid_occ times
+ * (collect_matches, map.c:103-118) contributes its same-strand hits (skip_seed with MM_F_FOR_ONLY, map.c:139-145).  The lock-step oracle's
+ * rule for deferred alignments is stated on this number (oracle/consensus_oracle.cpp LockStep::VT::extra).  Thread-safe. */
+int64_t ref_mm_count_seeds(const char *ref, int rl, const char *qry, int ql, int k, int w)
+{
+    mm_idxopt_t iopt;
+    mm_mapopt_t mopt;
+    mm_idx_t *idx;
+    mm128_v mv = {0, 0, 0};
+    int64_t n = 0;
+    size_t i;
+    (void)rl;
+    mm_set_opt(0, &iopt, &mopt);
+    mopt.flag |= MM_F_CIGAR | MM_F_FOR_ONLY;
+    idx = mm_idx_str(w, k, 0, 14, 1, &ref, NULL);
+    mm_mapopt_update(&mopt, idx);
+    mm_sketch(0, qry, ql, idx->w, idx->k, 0, idx->flag & MM_I_HPC, &mv);
+    for (i = 0; i < mv.n; ++i) {
+        int t, j;
+        const uint64_t *cr = mm_idx_get(idx, mv.a[i].x >> 8, &t);
+        if (t >= mopt.mid_occ) continue;
+        for (j = 0; j < t; ++j) if ((cr[j] & 1) == (mv.a[i].y & 1)) ++n;
+    }
+    free(mv.a);
+    mm_idx_destroy(idx);
+    return n;
+}
+
 /* mm_sketch (minimap2/sketch.c:77) -> flat (x,y) pairs. returns count. */
 int ref_mm_sketch(const char *s, int len, int w, int k, uint32_t rid, int is_hpc, uint64_t *xy, int cap)
 {

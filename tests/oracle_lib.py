@@ -349,13 +349,20 @@ def auto_schedule(n_reads, n_bases, n_filter_results):
 
 
 def cons_oracle_run(bases, off, salts, k=23, n=60, thr=6, m_k=20, m_w=50, mci=400, edge_thr=4000000, num_thr=1, checks=True, id_base=0, align_fn=None,
-                    lock_step=False, seed_hops=0, groups=4, seed_rings=1, seed_tail_rings=None):
+                    lock_step=False, seed_hops=0, groups=4, seed_rings=1, seed_tail_rings=None, defer=None):
     """The reference's hot path (sketch + tables + Consensus::generateAndWriteConsensus) on the CPU with the reference's own minimap2
     answering alignRead.  Returns (streams, stats): streams[name] for num_thr == 1, else streams['threads'][t][name]; streams['metaData'].
     lock_step=True: num_thr LOCK-STEP virtual threads (the product's deterministic schedule restated around the literal thread body,
     oracle/consensus_oracle.cpp struct LockStep; groups 1 / 2 / 4; seed_hops >= 1: conflict-aware seeds with buckets of that depth and
-    seed_rings rings); stats gains 'slots' and 'idle_seed_rounds'."""
+    seed_rings rings); stats gains 'slots' and 'idle_seed_rounds'.  defer=(anchors, slots), one group: an alignment whose anchor list before
+    chaining (the reference library's own index and sketch, ref_mm_count_seeds) is longer than `anchors` takes `slots` more slots
+    (include/nsgpu.h nsgpu_set_defer)."""
     L = cons_lib()
+    if defer is not None and defer[1]:
+        assert lock_step and groups == 1
+        L.cons_oracle_set_defer(C.cast(mm2ref().ref_mm_count_seeds, C.c_void_p), C.c_uint32(int(defer[0])), C.c_uint32(int(defer[1])))
+    else:
+        L.cons_oracle_set_defer(None, 0, 0)
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     off = np.ascontiguousarray(off, dtype=np.uint64)
     salts = np.ascontiguousarray(salts, dtype=np.uint64)

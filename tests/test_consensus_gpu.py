@@ -356,15 +356,16 @@ def test_oversize_sketch_batch_is_split_and_stays_device_visible():
 # oracle/consensus_oracle.cpp struct LockStep runs the LITERAL thread body of the reference under the schedule the engine documents
 # (slots, groups, claims and seeds in builder order, the conflict-aware seed rule): the engine with B builders and B output threads
 # must give byte for byte the B stream sets of the oracle's B virtual threads.
-def many_builders_equal_lockstep_oracle(bases, off, B, groups=4, depth=0, rings=1, n=60, tail=None):
+def many_builders_equal_lockstep_oracle(bases, off, B, groups=4, depth=0, rings=1, n=60, tail=None, defer=None):
     want, wst = oracle_lib.cons_oracle_run(bases, off, ns.mt19937_64_salts(n), n=n, checks=False, num_thr=B, lock_step=True, groups=groups,
-                                           seed_hops=depth, seed_rings=rings, seed_tail_rings=tail)
+                                           seed_hops=depth, seed_rings=rings, seed_tail_rings=tail, defer=defer)
     assert wst["n_bad_roundtrip"] == 0
     g = ns.NsGpu(n=n)
     g.load_reads((bases, off))
     g.sketch(ns.mt19937_64_salts(n), fetch=False)
     g.build_index()
-    st = ns.consensus_run(g, B, B, schedule=(groups, depth, rings, tail))
+    st = ns.consensus_run(g, B, B, schedule=(groups, depth, rings, tail), defer=defer if defer is not None else (0, 0))
+    wst["n_deferred"] = ns.get_defer(g)[2]
     per = want["threads"] if B > 1 else [want]
     for t in range(B):
         for k in STREAMS:
@@ -447,6 +448,29 @@ def test_repeats_genome_sketch_splice_and_schedules():
         "print('OK', w['count_aligner'])\n" % root)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NSGPU_SKETCH_CHECK="1", NSGPU_CONS_CHECK="1"), capture_output=True, text=True, timeout=850)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_deferred_alignments_equal_the_lockstep_oracle_s_rule():
+    """nsgpu_set_defer: alignments with long anchor lists take more slots than the others, in the engine (their batch runs on a thread of its
+    own beside the slots) exactly as in the lock-step oracle (VT::extra, counted with the reference library's own index and sketch).  On the
+    repeats genome with thresholds low enough that the rule fires all the time -- also for pairs the seeding kernel would NOT hand back: those
+    are below the kernel's own limit (4096 anchors) and must be deferred by the count alone -- and at the default threshold; 1 .. 3 slots."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import nanospring_amd as ns\n"
+        "from tests import test_consensus_gpu as t\n"
+        "bases, off = ns.synth_reads(3, 420000, 700, 6000.0, genome='repeats')\n"
+        "tot = 0\n"
+        "for defer in ((4096, 2), (300, 1), (120, 3)):\n"
+        "    w = t.many_builders_equal_lockstep_oracle(bases, off, 12, 1, 3, 2, defer=defer)\n"
+        "    print('defer', defer, w['n_deferred'], w['slots'])\n"
+        "    tot += w['n_deferred']\n"
+        "print('OK', tot)\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NSGPU_SKETCH_CHECK="1", NSGPU_CONS_CHECK="1"), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert int(r.stdout.split("OK")[1].split()[0]) >= 10, r.stdout[-600:]
 
 
 CFG3_WORKER = r'''

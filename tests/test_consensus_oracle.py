@@ -252,3 +252,36 @@ def test_lockstep_oracle_one_thread_is_t1_and_many_are_lossless_and_deterministi
         runs[(groups, depth)] = sa
     assert runs[(1, 3)]["n_contigs"] <= runs[(1, 0)]["n_contigs"]
     assert runs[(1, 0)]["slots"] * 3 < runs[(4, 0)]["slots"] * 1.2      # a step per slot instead of one per four
+
+
+def test_lockstep_oracle_deferred_alignments_rule():
+    """The lock-step oracle's rule for deferred alignments (LockStep::VT::extra; include/nsgpu.h nsgpu_set_defer): the anchor count it is stated on
+    -- ref_mm_count_seeds, the reference library's own index and sketch through its public calls -- equals the number of seeds the library's own
+    debug dump prints for the pair (ref_mm_seeds), repeats included; with one thread the rule changes nothing but the slot count (-t 1 streams);
+    with many threads the run stays lossless and deterministic, takes more slots, and a threshold nothing reaches is the run without the rule."""
+    import ctypes as C
+    import nanospring_amd as ns
+    from tests.align_cases import make_genome, mutate
+    lib = oracle_lib.mm2ref()
+    lib.ref_mm_count_seeds.restype = C.c_int64
+    rng = np.random.RandomState(5)
+    g0 = make_genome(rng, 6000)
+    unit = make_genome(rng, 23)
+    g1 = g0[:2500] + unit * 50 + g0[2500:]
+    for ref, qry in ((g0, mutate(rng, g0[300:4000], 0.05)), (g1, mutate(rng, g1[1800:5200], 0.03)), (g1, g1[2000:4500])):
+        rb, qb = ref.encode(), qry.encode()
+        n = lib.ref_mm_count_seeds(rb, len(rb), qb, len(qb), 20, 50)
+        want = oracle_lib.ref_mm_seeds(ref, qry)
+        assert n == len(want[0]), (n, len(want[0]))
+    bases, off = ns.synth_reads(3, 200000, 330, 6000.0, genome="repeats")
+    salts = ns.mt19937_64_salts(60)
+    t1, s1 = oracle_lib.cons_oracle_run(bases, off, salts, checks=False)
+    a, sa = oracle_lib.cons_oracle_run(bases, off, salts, checks=False, num_thr=1, lock_step=True, groups=1, seed_hops=3, defer=(150, 2))
+    assert a == t1 and sa["slots"] > 0
+    base, sb = oracle_lib.cons_oracle_run(bases, off, salts, checks=True, num_thr=10, lock_step=True, groups=1, seed_hops=3, seed_rings=2)
+    off_, so = oracle_lib.cons_oracle_run(bases, off, salts, checks=False, num_thr=10, lock_step=True, groups=1, seed_hops=3, seed_rings=2, defer=(10 ** 9, 2))
+    assert off_ == base and so["slots"] == sb["slots"]
+    d1, sd1 = oracle_lib.cons_oracle_run(bases, off, salts, checks=True, num_thr=10, lock_step=True, groups=1, seed_hops=3, seed_rings=2, defer=(150, 2))
+    d2, sd2 = oracle_lib.cons_oracle_run(bases, off, salts, checks=False, num_thr=10, lock_step=True, groups=1, seed_hops=3, seed_rings=2, defer=(150, 2))
+    assert d1 == d2 and sd1["n_bad_roundtrip"] == 0 and sd1["n_check_fail"] == 0
+    assert sd1["slots"] > sb["slots"]
