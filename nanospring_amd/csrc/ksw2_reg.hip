@@ -820,16 +820,15 @@ struct RegClass { int nw, nch; };
 // their numbers stay unused so that the others keep theirs).
 // Classes 9 .. 11 belonged to the systolic kernel (removed in round 5, see above).
 // Class 12 is <1,4> once more: the long problems of the one-wave classes in a launch of their own (device-planned batches, ksw_class.hpp).
-// NSGPU_KSW_VARIANT (A/B, round 5): bit 0: class 12 (the long problems of the one-wave classes) on <4,1> -- one block per wave; bit 1: class 8
-// (513 .. 1536 columns) on <12,1>; bit 2: class 3 (up to 5120 columns) on <16,3>
-static int reg_variant() { static const int v = getenv("NSGPU_KSW_VARIANT") ? atoi(getenv("NSGPU_KSW_VARIANT")) : 0; return v; }
+// Round 5, interleaved on one box (profiles/r05_wave_shapes_ab.txt): the long problems of the one-wave classes (class 12) on <4,1> -- one 128-cell
+// block per wave and row instead of four -- 1.51 -> 1.22 ms per launch; 513 .. 1536 columns (class 8) on <12,1> instead of <6,2>: 1.74 -> 1.53 ms;
+// up to 5120 columns (class 3) on <16,3> instead of <8,5>: 3.20 -> 3.63 ms, not adopted.  (Rounds 2-3 had measured <2,1> / <4,1> slower than the
+// one-wave classes: that was before the books left the gap fills' rows.)
 static RegClass reg_class_of(int cls)
 {
-    constexpr RegClass base[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {6, 2}, {8, 5}, {1, 2}, {1, 4}, {6, 2}, {8, 5}, {6, 2}, {5, 1}, {5, 2}, {5, 3}, {1, 4}};
-    const int v = reg_variant();
-    if (cls == 12 && (v & 1)) return RegClass{4, 1};
-    if (cls == 8 && (v & 2)) return RegClass{12, 1};
-    if (cls == 3 && (v & 4)) return RegClass{16, 3};
+    // (the bulk classes on more waves -- class 0 on <2,1>, class 1 on <4,1> or <2,2> -- were measured too, profiles/r05_wave_shapes_bulk_ab.txt: the
+    // launches of class 1 1.36 -> 1.29 ms on <4,1>, the wall of the DP phases -1 %, nothing on the step; <2,1> costs class 8 0.15 ms.  Not adopted.)
+    constexpr RegClass base[KSW_REG_CLASSES] = {{1, 2}, {1, 4}, {6, 2}, {8, 5}, {1, 2}, {1, 4}, {6, 2}, {8, 5}, {12, 1}, {5, 1}, {5, 2}, {5, 3}, {4, 1}};
     return base[cls];
 }
 static int reg_compute_waves(int cls) { return reg_class_of(cls).nw; }
@@ -889,9 +888,9 @@ int ksw_reg_launch(int cls, hipStream_t st, uint32_t m, size_t lds_bytes, const 
     switch (cls) {
     case 0: NS_REG_LAUNCH(1, 2) break;
     case 1: NS_REG_LAUNCH(1, 4) break;
-    case 3: if (reg_variant() & 4) NS_REG_LAUNCH(16, 3) else NS_REG_LAUNCH(8, 5) break;
-    case 8: if (reg_variant() & 2) NS_REG_LAUNCH(12, 1) else NS_REG_LAUNCH(6, 2) break;
-    case 12: if (reg_variant() & 1) NS_REG_LAUNCH(4, 1) else NS_REG_LAUNCH(1, 4) break;
+    case 3: NS_REG_LAUNCH(8, 5) break;
+    case 8: NS_REG_LAUNCH(12, 1) break;
+    case 12: NS_REG_LAUNCH(4, 1) break;
     default: NS_CHECK(false, NSGPU_ERR_ARG, "ksw: bad register class");
     }
 #undef NS_REG_LAUNCH

@@ -28,7 +28,7 @@ __host__ __device__ inline size_t ksw_p_bytes_hd(int qlen, int tlen, int w)
     return ((size_t)(qlen + tlen - 1) * n_col_ + 1) * 16;
 }
 
-// cells per row the width classes hold: <1,2> <1,4> <6,2> (class 8) <8,5>.  Class numbers 2 and 4 .. 7 belonged to variants that were
+// cells per row the width classes hold: <1,2> <1,4> <12,1> (class 8) <8,5>.  Class numbers 2 and 4 .. 7 belonged to variants that were
 // measured and lost (<4,3>; the latency twins <2,1> / <4,1>; <5,3> / <9,5> with a books wave: DESIGN.md section 4) and are retired.
 __host__ __device__ inline int ksw_reg_width(int c) { return c == 0 ? 256 : c == 1 ? 512 : c == 2 ? 1536 : 5120; }
 
@@ -49,7 +49,7 @@ __host__ __device__ inline int ksw_reg_class_hd(int qlen, int tlen, int w_in, in
     if ((long long)(-pr.sc_mis > pr.sc_mch ? -pr.sc_mis : pr.sc_mch) * mn + (long long)(q + e) * (w + 1) + 64 >= 32768) return -1;
     for (int c = 0; c < 4; ++c)
         if (tlen <= ksw_reg_width(c)) {
-            return c == 2 ? 8 : c;                                                              // (513 .. 1536 columns: <6,2>)
+            return c == 2 ? 8 : c;                                                              // (513 .. 1536 columns: <12,1>)
         }
     return -1;
 }
