@@ -355,6 +355,8 @@ def main():
         penalty = compression_of(stream_bytes / n_bases, st)
         penalty["schedule"] = {"groups": args.groups, "seed_bucket_depth": args.seed_depth, "seed_rings": args.seed_rings, "seed_tail_rings": args.seed_tail_rings,
                                "derived_by": "the library (nsgpu_set_schedule_auto: from reads, bases and the whole-read filter results per read)" if auto_sched else "the command line"}
+        dfr = ns.get_defer(g)
+        penalty["schedule"]["deferred_alignments"] = {"anchors_above": dfr[0], "more_slots": dfr[1], "in_the_last_step": dfr[2]}      # nsgpu_set_defer (the automatic schedule: 4096 / 2)
         # three steps (after one untimed) of the 1024-builder, four-group pipelined schedule with the reference's seed rule (the round-2 headline): faster, larger streams
         tleg = None
         want_leg = args.throughput_leg if args.throughput_leg >= 0 else int(world == 1 and args.reads == 100000 and args.depth == 20.0 and args.genome == "iid")

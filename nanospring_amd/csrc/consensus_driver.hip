@@ -875,49 +875,78 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
     if (n_polled) {
         const size_t T = std::max<size_t>(1, (size_t)host_threads());
         const double p0 = now_ms();
+        // Every builder of the watch has ONE owner thread (the pinned assignment of the host phase: its graph lives in that thread's caches); a thread
+        // whose own builders are all done does not leave, though: it takes over whatever alignment is handed over while its owner is busy with
+        // another builder's update -- the last results of a slot used to queue up behind each other on one thread while fifteen were idle.
+        // A builder is run by whoever sets its claim flag first (NSGPU_CONS_NO_STEAL=1: owners only, the A/B switch).
+        static const bool no_steal = getenv("NSGPU_CONS_NO_STEAL") != nullptr;
+        std::vector<uint32_t> &cand = E->early_cand;
+        cand.clear();
+        for (size_t i = 0; i < D.B.size(); ++i) {
+            const int32_t w = widx[i];
+            const int gi = lane_of[i];
+            if (w < 0 || gi < 0 || !polled[gi]) continue;
+            const AlignBatch &AB = E->ab[gi];
+            if ((size_t)w >= AB.plan_pair.size() || AB.plan_pair[w] == ~0u || AB.plan_delivered[w]) continue;
+            const PlanOut o = pop[gi][AB.plan_pair[w]];
+            if (o.flags || o.n_tasks == 0) continue;
+            cand.push_back((uint32_t)i);
+        }
+        if (E->early_claim.size() < D.B.size()) E->early_claim = std::vector<std::atomic<uint8_t>>(D.B.size());
+        for (uint32_t i : cand) E->early_claim[i].store(0, std::memory_order_relaxed);
+        std::atomic<uint32_t> n_open{(uint32_t)cand.size()};      // builders of the watch nobody has taken yet
+        std::atomic<uint64_t> n_stolen{0};
         par_for_pinned("host.early", T, [&](size_t t) {
             static thread_local const int slack_set = prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);      // (a 10 us sleep is 10 us, not 60)
             (void)slack_set;
             static thread_local std::vector<uint32_t> mine;          // (any number of builders per thread: few threads, many builders)
             mine.clear();
-            size_t n_mine = 0;
-            for (size_t i = t; i < D.B.size(); i += T) {
+            for (uint32_t i : cand) if (i % T == t) mine.push_back(i);
+            size_t n_mine = mine.size();
+            // one builder whose status word is up: claimed, delivered, finished.  0: not ready (or its data not all there yet), 1: taken by this call, 2: by somebody else
+            auto try_builder = [&](size_t i) -> int {
                 const int32_t w = widx[i];
                 const int gi = lane_of[i];
-                if (w < 0 || gi < 0 || !polled[gi]) continue;
-                const AlignBatch &AB = E->ab[gi];
-                if ((size_t)w >= AB.plan_pair.size() || AB.plan_pair[w] == ~0u || AB.plan_delivered[w]) continue;
-                const PlanOut o = pop[gi][AB.plan_pair[w]];
-                if (o.flags || o.n_tasks == 0) continue;
-                mine.push_back((uint32_t)i), ++n_mine;
-            }
+                AlignBatch &AB = E->ab[gi];
+                if (E->early_claim[i].load(std::memory_order_acquire)) return 2;
+                const uint32_t st = __atomic_load_n(&Rp[gi].status[AB.plan_pair[w]], __ATOMIC_ACQUIRE);
+                if (st == 0) return 0;
+                uint8_t zero = 0;
+                if (!E->early_claim[i].compare_exchange_strong(zero, 1, std::memory_order_acq_rel)) return 2;
+                if (st == 1u && !AB.plan_delivered[w]) {
+                    // (the status word is up: is everything it announces here?  If not, look again in a moment)
+                    const uint32_t got = batch_plan_deliver_one(AB, Rp[gi], (size_t)w, 1, false);
+                    if (got == ~0u) { n_retry += 1; E->early_claim[i].store(0, std::memory_order_release); return 0; }
+                    n_tasks += got;
+                }
+                n_open -= 1;
+                if (st != 1u) return 1;                                       // (not handed over: align_finish's rounds)
+                const double k0 = now_ms();
+                Tk tk{task_ns, task_max_ns, k0};
+                finish_builder(i, gi, (size_t)w, k0);
+                return 1;
+            };
             bool closing = false;
             // (a batch that never closes -- a GPU fault -- must not hold the pool for ever: align_finish's wait reports it)
             static const double give_up_ms = [] { const char *e = getenv("NSGPU_WAIT_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return (v > 0 ? v : 120.0) * 1e3; }();
-            while (n_mine) {
+            while (n_mine || (!no_steal && n_open.load(std::memory_order_acquire))) {
                 if (now_ms() - p0 > give_up_ms) break;
                 bool progressed = false;
                 for (size_t k = 0; k < n_mine;) {
-                    const size_t i = mine[k];
-                    const int32_t w = widx[i];
-                    const int gi = lane_of[i];
-                    AlignBatch &AB = E->ab[gi];
-                    const uint32_t st = __atomic_load_n(&Rp[gi].status[AB.plan_pair[w]], __ATOMIC_ACQUIRE);
-                    if (st == 0) { ++k; continue; }
-                    if (st == 1u && !AB.plan_delivered[w]) {
-                        // (the status word is up: is everything it announces here?  If not, look again in a moment)
-                        const uint32_t got = batch_plan_deliver_one(AB, Rp[gi], (size_t)w, 1, false);
-                        if (got == ~0u) { ++k; n_retry += 1; continue; }
-                        n_tasks += got;
-                    }
+                    const int r = try_builder(mine[k]);
+                    if (r == 0) { ++k; continue; }
                     mine[k] = mine[--n_mine];
                     progressed = true;
-                    if (st != 1u) continue;                                   // (not handed over: align_finish's rounds)
-                    const double k0 = now_ms();
-                    Tk tk{task_ns, task_max_ns, k0};
-                    finish_builder(i, gi, (size_t)w, k0);
                 }
-                if (progressed || !n_mine) continue;
+                if (!n_mine && !no_steal) {
+                    // nothing of its own left: the others' builders, one at a time (then back to the top: the closing test)
+                    for (uint32_t i : cand) {
+                        if (i % T == t) continue;
+                        const int r = try_builder(i);
+                        if (r == 1) { progressed = true; n_stolen += 1; break; }
+                    }
+                }
+                if (progressed) continue;
                 if (closing) break;                                           // one more look after the closing words, then leave
                 bool all_done = true;
                 for (int gi = 0; gi < kMaxGroups; ++gi) if (polled[gi] && !*donep[gi]) all_done = false;
@@ -926,6 +955,7 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
                 nanosleep(&ts, nullptr);
             }
         });
+        E->n_early_stolen += n_stolen.load();
         E->early_part_ms[0] += now_ms() - p0;
         E->n_early_retry += n_retry.load();
     }
