@@ -38,7 +38,7 @@ void debug_report_slots(nsgpu_ctx *c, Engine *E)
     }
     fprintf(stderr, "[cons] early tasks: loops of part 0 / part 1 %.0f / %.0f ms wall; tasks %.0f ms in sum (delivery + skeleton + conversion %.0f), the longest of each slot %.0f ms in sum\n",
             E->early_part_ms[0], E->early_part_ms[1], E->early_task_ms, E->early_conv_ms, E->early_task_max_ms);
-    fprintf(stderr, "[cons] graph updates run ahead of the slot's end: %llu, %.0f ms wall (DP results + updates); status words seen ahead of their data: %llu; builders' tasks taken over by an idle thread: %llu\n", (unsigned long long)E->n_early, E->early_ms, (unsigned long long)E->n_early_retry, (unsigned long long)E->n_early_stolen);
+    fprintf(stderr, "[cons] graph updates run ahead of the slot's end: %llu, %.0f ms wall (DP results + updates); status words seen ahead of their data: %llu; builders' tasks taken over by an idle thread: %llu; the slots' last alignments were taken up %.0f ms into their watches (in sum, of %.0f ms)\n", (unsigned long long)E->n_early, E->early_ms, (unsigned long long)E->n_early_retry, (unsigned long long)E->n_early_stolen, E->early_last_claim_ms, E->early_part_ms[0]);
     fprintf(stderr, "[cons] device plan (cumulative): %llu alignments planned on the device, %llu left to the host; DP problems found %llu, not found %llu, unasked %llu\n",
             (unsigned long long)c->plan_pairs_dev, (unsigned long long)c->plan_pairs_host, (unsigned long long)c->plan_hits, (unsigned long long)c->plan_misses, (unsigned long long)c->plan_extra);
     fprintf(stderr, "[cons] index + seeds on the GPU: %llu launches, %llu pairs, wait %.0f ms wall; %llu pairs handed back to the host code\n", (unsigned long long)sn,

@@ -895,7 +895,7 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
         if (E->early_claim.size() < D.B.size()) E->early_claim = std::vector<std::atomic<uint8_t>>(D.B.size());
         for (uint32_t i : cand) E->early_claim[i].store(0, std::memory_order_relaxed);
         std::atomic<uint32_t> n_open{(uint32_t)cand.size()};      // builders of the watch nobody has taken yet
-        std::atomic<uint64_t> n_stolen{0};
+        std::atomic<uint64_t> n_stolen{0}, last_claim_us{0};
         par_for_pinned("host.early", T, [&](size_t t) {
             static thread_local const int slack_set = prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);      // (a 10 us sleep is 10 us, not 60)
             (void)slack_set;
@@ -922,6 +922,7 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
                 n_open -= 1;
                 if (st != 1u) return 1;                                       // (not handed over: align_finish's rounds)
                 const double k0 = now_ms();
+                { uint64_t m = last_claim_us.load(); const uint64_t v = (uint64_t)((k0 - p0) * 1e3); while (v > m && !last_claim_us.compare_exchange_weak(m, v)) {} }
                 Tk tk{task_ns, task_max_ns, k0};
                 finish_builder(i, gi, (size_t)w, k0);
                 return 1;
@@ -956,6 +957,7 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
             }
         });
         E->n_early_stolen += n_stolen.load();
+        E->early_last_claim_ms += last_claim_us.load() / 1e3;       // (debug print: when the slot's last alignment was taken up, from the watch's start)
         E->early_part_ms[0] += now_ms() - p0;
         E->n_early_retry += n_retry.load();
     }

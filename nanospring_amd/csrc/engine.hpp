@@ -366,7 +366,7 @@ struct Engine {
     std::vector<uint32_t> global_pends;             // several ranks, one-group schedule: the reads ALL ranks' builders align in this slot, sorted (run_consensus_dist)
     bool have_global_pends = false;
     std::vector<uint32_t> early_pends; std::vector<int32_t> early_widx; std::vector<int8_t> early_lane;      // scratch of engine_early_updates
-    std::vector<uint32_t> early_cand; std::vector<std::atomic<uint8_t>> early_claim; uint64_t n_early_stolen = 0;      // the watch's builders / who runs which (a flag each) / tasks run by a thread other than the builder's
+    std::vector<uint32_t> early_cand; std::vector<std::atomic<uint8_t>> early_claim; uint64_t n_early_stolen = 0; double early_last_claim_ms = 0;      // the watch's builders / who runs which (a flag each) / tasks run by a thread other than the builder's
     double early_part_ms[2] = {0, 0}, early_task_ms = 0, early_task_max_ms = 0, early_conv_ms = 0;     // debug report: wall of the two parts' loops, sum / per-slot maximum of their tasks, skeleton + conversion inside
     uint64_t n_early = 0, n_early_retry = 0; double early_ms = 0;      // (retry: a status word seen before all of its data, ksw_collect.hpp)       // graph updates run ahead of the slot's end / wall of that (debug print)
     double crit_u_ms = 0, crit_m_ms = 0;              // sum over host phases of the slowest update_graph / main-path recompute (debug print)
