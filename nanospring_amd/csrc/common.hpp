@@ -192,7 +192,7 @@ struct nsgpu_ctx {
         uint64_t dv_p_hint = 0, dv_hcig_hint = 0, dv_hcig_cap = 0;
         bool dv_pending = false;
         std::vector<hipEvent_t> dv_ev;
-        hipEvent_t dv_a = nullptr, dv_b = nullptr;
+        hipEvent_t dv_a = nullptr, dv_b = nullptr, dv_clear_ev = nullptr;
     } kws[8];                                                       // 0: the context's stream (direct API calls); 1-3: own streams (contig engine, one per batch in flight)
     // batched minimizer sketches (mm_sketch.hip): device buffers + pinned staging both ways
     struct SketchWs {

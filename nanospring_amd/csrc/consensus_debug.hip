@@ -54,6 +54,8 @@ void debug_report_slots(nsgpu_ctx *c, Engine *E)
                         (unsigned long long)lf[0], (unsigned long long)lf[1], (unsigned long long)lf[2], (unsigned long long)lf[3], (unsigned long long)lf[4], (unsigned long long)la, (unsigned long long)ll,
                         (unsigned long long)lc, ls, lw);
     }
+    fprintf(stderr, "[cons] count tables: %llu rebuilt (%llu slots cleared in sum, the longest list %llu), %llu updated in place (%llu hashes removed + added)\n", (unsigned long long)E->dbg_cnt_rebuilds,
+            (unsigned long long)E->dbg_cnt_rebuild_slots, (unsigned long long)E->dbg_cnt_rebuild_max, (unsigned long long)E->dbg_cnt_updates, (unsigned long long)E->dbg_cnt_keys);
     if (c->defer_slots) fprintf(stderr, "[cons] deferred alignments (more than %u anchors: %u more slots): %llu; their batches ran %.0f ms in sum beside the slots, the slots waited %.0f ms for them\n",
                                 c->defer_anchors, c->defer_slots, (unsigned long long)E->n_deferred, E->defer_run_ms, E->defer_join_ms);
     double cs = 0, ce = 0, cw = 0; uint64_t cn = 0;

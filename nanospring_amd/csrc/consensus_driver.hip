@@ -625,12 +625,14 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
                     b.cnt_bits = bits;
                     j.rebuild = 1, j.all = b.d_mz.as<mm2::Anchor>(), j.n_all = (uint32_t)n_mz;
                     b.cnt_keys = n_mz, b.cnt_valid = true;
+                    ++E->dbg_cnt_rebuilds, E->dbg_cnt_rebuild_slots += (uint64_t)1 << bits, E->dbg_cnt_rebuild_max = std::max<uint64_t>(E->dbg_cnt_rebuild_max, n_mz);
                 } else {
                     memcpy(key_stage, b.cnt_rem.data(), b.cnt_rem.size() * sizeof(uint64_t));
                     j.rem = key_stage, j.n_rem = (uint32_t)b.cnt_rem.size(), key_stage += b.cnt_rem.size();
                     memcpy(key_stage, b.cnt_add.data(), b.cnt_add.size() * sizeof(uint64_t));
                     j.add = key_stage, j.n_add = (uint32_t)b.cnt_add.size(), key_stage += b.cnt_add.size();
                     b.cnt_keys += b.cnt_add.size();
+                    ++E->dbg_cnt_updates, E->dbg_cnt_keys += j.n_rem + j.n_add;
                 }
                 j.tab = b.d_cnt.as<CountSlot>(), j.bits = b.cnt_bits;
                 j.hist = b.d_cnt_hm.as<uint32_t>(), j.meta = b.d_cnt_hm.as<uint32_t>() + 1024;

@@ -392,6 +392,7 @@ struct Engine {
         int rc = NSGPU_OK;
         std::string err;
     } defer[4];
+    uint64_t dbg_cnt_rebuilds = 0, dbg_cnt_rebuild_slots = 0, dbg_cnt_rebuild_max = 0, dbg_cnt_updates = 0, dbg_cnt_keys = 0;      // count tables (debug print)
     uint32_t cur_slot = 0;
     uint64_t n_deferred = 0; double defer_join_ms = 0, defer_run_ms = 0;
     std::vector<uint32_t> fwho;                    // builders of the window-query batch

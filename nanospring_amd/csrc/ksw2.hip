@@ -1096,8 +1096,23 @@ int ksw_dev_prepare(nsgpu_ctx *c, int ws_index, uint32_t n_slots, uint32_t n_pai
     NS_TRY(W.dv_coff.reserve(((size_t)n_slots + 2) * 8));
     NS_TRY(W.dv_tpair.reserve((size_t)n_slots * 4 + 64));
     NS_TRY(W.dv_pdone.reserve((size_t)n_pairs * 4 + 64));
-    NS_HIP(hipMemsetAsync(W.dv_pdone.p, 0, (size_t)n_pairs * 4 + 4, st));
-    NS_HIP(hipMemsetAsync(W.dv_ctrl.p, 0, sizeof(DvCtrl), st));
+    // the two clears on the workspace's own stream (idle: its last batch was collected slots ago), beside the seeding and chaining kernels that `st`
+    // is busy with; `st` -- the plan kernel comes next on it -- waits for them.  (On `st` they were four fill kernels, ~70 us, between the chaining and
+    // the plan kernel of every slot: the kernel trace.)
+    {
+        if (ws_index >= 1 && !W.stream) NS_TRY(role_stream_create(&W.stream, "dp"));
+        const hipStream_t cs = ws_index == 0 ? c->stream : W.stream;
+        if (cs == st) {
+            NS_HIP(hipMemsetAsync(W.dv_pdone.p, 0, (size_t)n_pairs * 4 + 4, st));
+            NS_HIP(hipMemsetAsync(W.dv_ctrl.p, 0, sizeof(DvCtrl), st));
+        } else {
+            if (!W.dv_clear_ev) NS_HIP(hipEventCreateWithFlags(&W.dv_clear_ev, hipEventDisableTiming));
+            NS_HIP(hipMemsetAsync(W.dv_pdone.p, 0, (size_t)n_pairs * 4 + 4, cs));
+            NS_HIP(hipMemsetAsync(W.dv_ctrl.p, 0, sizeof(DvCtrl), cs));
+            NS_HIP(hipEventRecord(W.dv_clear_ev, cs));
+            NS_HIP(hipStreamWaitEvent(st, W.dv_clear_ev, 0));
+        }
+    }
     // (the task slots and their results are cleared by the plan kernel itself: every slot belongs to one alignment's wave)
     dp.tasks = W.dv_tasks.as<KswTask>(), dp.res = W.dv_res.as<KswResult>(), dp.class_list = W.dv_list.as<uint32_t>();
     dp.class_cnt = W.dv_ctrl.as<DvCtrl>()->class_cnt, dp.n_slots = n_slots, dp.seqs = W.dv_seqs.as<uint8_t>();

@@ -44,7 +44,10 @@ template <class T> __device__ __forceinline__ T ld_l2(const T *p) { return __hip
 // zero stay as keys).  Until round 5 every alignment rebuilt a table of all of the reference's minimizers WITH their positions (0.20 ms per
 // launch: 4 MB cleared and 40 k atomic insertions for a 1 Mb contig); positions need no table at all -- seed_kernel streams the list.
 // meta: [0] distinct hashes, [1] mid_occ, [2] SEED_FLAG_OCC when the order statistic fell into the histogram's clipped last bin.
-__device__ __forceinline__ void count_change(CountSlot *tab, uint32_t bits, uint32_t *hist, uint32_t *nd, unsigned long long key, bool add)
+// One workgroup owns a job's table for the launch, so the histogram's moves and the number of distinct hashes are kept in LDS (h_delta, nd_delta) and
+// folded into the persistent words once: in global memory every insertion hit the same two words -- bin 1 and the count of distinct hashes --, and
+// same-address atomics are served one after the other (a rebuild of a 19 k list: 0.2 ms, in the slot's critical path; the kernel trace).
+__device__ __forceinline__ void count_change(CountSlot *tab, uint32_t bits, int32_t *h_delta, int32_t *nd_delta, unsigned long long key, bool add)
 {
     const uint32_t mask = (1u << bits) - 1;
     uint32_t s = slot_of(key, bits);
@@ -57,38 +60,49 @@ __device__ __forceinline__ void count_change(CountSlot *tab, uint32_t bits, uint
     }
     if (add) {
         const uint32_t old = atomicAdd(&tab[s].count, 1u);
-        if (old) atomicSub(&hist[old < kHistBins ? old : kHistBins - 1], 1u); else atomicAdd(nd, 1u);
-        atomicAdd(&hist[old + 1 < kHistBins ? old + 1 : kHistBins - 1], 1u);
+        if (old) atomicSub(&h_delta[old < kHistBins ? old : kHistBins - 1], 1); else atomicAdd(nd_delta, 1);
+        atomicAdd(&h_delta[old + 1 < kHistBins ? old + 1 : kHistBins - 1], 1);
     } else {
         const uint32_t old = atomicSub(&tab[s].count, 1u);
-        atomicSub(&hist[old < kHistBins ? old : kHistBins - 1], 1u);
-        if (old > 1) atomicAdd(&hist[old - 1 < kHistBins ? old - 1 : kHistBins - 1], 1u); else atomicSub(nd, 1u);
+        atomicSub(&h_delta[old < kHistBins ? old : kHistBins - 1], 1);
+        if (old > 1) atomicAdd(&h_delta[old - 1 < kHistBins ? old - 1 : kHistBins - 1], 1); else atomicSub(nd_delta, 1);
     }
 }
 
 __global__ __launch_bounds__(1024) void count_update_kernel(const CountJob *__restrict__ jobs, float mid_occ_frac)
 {
+    __shared__ int32_t h_delta[kHistBins];
+    __shared__ uint32_t suf[kHistBins];
+    __shared__ int32_t nd_delta;
     const CountJob J = jobs[blockIdx.x];
     const uint32_t tid = threadIdx.x;
+    h_delta[tid] = 0;
+    if (tid == 0) nd_delta = 0;
     if (J.rebuild) {
         const uint32_t n_slots = 1u << J.bits;
-        for (uint32_t s = tid; s < n_slots; s += 1024) J.tab[s] = CountSlot{0ull, 0u, 0u};
-        for (uint32_t b = tid; b < kHistBins; b += 1024) J.hist[b] = 0;
-        if (tid < 4) J.meta[tid] = 0;
-        __threadfence();
-        __syncthreads();
-        for (uint32_t i = tid; i < J.n_all; i += 1024) count_change(J.tab, J.bits, J.hist, J.meta, (J.all[i].x >> 8) + 1, true);
+        // (cleared with agent-scope stores, which go through to memory like the atomics that follow; a plain store would sit in this XCD's L2, and
+        // __threadfence() between the two is a write-back and an invalidation of that whole L2: `buffer_wbl2 sc1` / `buffer_inv sc1`)
+        for (uint32_t s = tid; s < n_slots; s += 1024) {
+            __hip_atomic_store(&J.tab[s].key, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(&J.tab[s].count), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();               // (the workgroup's stores have been acknowledged: s_waitcnt vmcnt(0) in front of the barrier)
+        for (uint32_t i = tid; i < J.n_all; i += 1024) count_change(J.tab, J.bits, h_delta, &nd_delta, (J.all[i].x >> 8) + 1, true);
     } else {
+        __syncthreads();
         // (removals first: a hash that leaves and comes back keeps its slot either way; the histogram moves are order-independent)
-        for (uint32_t i = tid; i < J.n_rem; i += 1024) count_change(J.tab, J.bits, J.hist, J.meta, J.rem[i] + 1, false);
-        for (uint32_t i = tid; i < J.n_add; i += 1024) count_change(J.tab, J.bits, J.hist, J.meta, J.add[i] + 1, true);
+        for (uint32_t i = tid; i < J.n_rem; i += 1024) count_change(J.tab, J.bits, h_delta, &nd_delta, J.rem[i] + 1, false);
+        for (uint32_t i = tid; i < J.n_add; i += 1024) count_change(J.tab, J.bits, h_delta, &nd_delta, J.add[i] + 1, true);
     }
-    __threadfence();
     __syncthreads();
+    // the persistent histogram and the number of distinct hashes: what they were (nothing, for a rebuilt table) plus what this launch moved
+    const uint32_t h = (J.rebuild ? 0u : ld_l2(&J.hist[tid])) + (uint32_t)h_delta[tid];
+    if (J.rebuild || h_delta[tid]) __hip_atomic_store(&J.hist[tid], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t nd = (J.rebuild ? 0u : ld_l2(&J.meta[0])) + (uint32_t)nd_delta;
+    if (tid == 0) __hip_atomic_store(&J.meta[0], nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // mid_occ (index.c:164-185): 1 + the (uint32)((1 - f) n_distinct)-th smallest count, 0-based = the bin b with more than `above` counts in the
     // bins from b up and at most `above` in the bins above it (a suffix sum over the 1024 bins, one per thread)
-    __shared__ uint32_t suf[kHistBins];
-    suf[tid] = ld_l2(&J.hist[tid]);
+    suf[tid] = h;
     __syncthreads();
     for (uint32_t d = 1; d < kHistBins; d <<= 1) {
         const uint32_t v = tid + d < kHistBins ? suf[tid + d] : 0u;
@@ -96,13 +110,16 @@ __global__ __launch_bounds__(1024) void count_update_kernel(const CountJob *__re
         suf[tid] += v;
         __syncthreads();
     }
-    const uint32_t nd = ld_l2(&J.meta[0]);
-    if (mid_occ_frac <= 0.f || nd == 0) { if (tid == 0) J.meta[1] = mid_occ_frac <= 0.f ? 0x7fffffffu : 1u, J.meta[2] = 0; return; }
+    auto put = [&](uint32_t mid, uint32_t flag) {
+        __hip_atomic_store(&J.meta[1], mid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&J.meta[2], flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (mid_occ_frac <= 0.f || nd == 0) { if (tid == 0) put(mid_occ_frac <= 0.f ? 0x7fffffffu : 1u, 0u); return; }
     uint32_t kk = (uint32_t)((1. - (double)mid_occ_frac) * (double)nd);
     if (kk >= nd) kk = nd - 1;
     const uint32_t above = nd - 1 - kk;                                                   // counts strictly after it in ascending order
     const uint32_t up = tid + 1 < kHistBins ? suf[tid + 1] : 0u;
-    if (suf[tid] > above && up <= above) J.meta[1] = tid + 1, J.meta[2] = tid == kHistBins - 1 ? SEED_FLAG_OCC : 0u;      // (the clipped bin: exact value unknown)
+    if (suf[tid] > above && up <= above) put(tid + 1, tid == kHistBins - 1 ? SEED_FLAG_OCC : 0u);      // (the clipped bin: exact value unknown)
 }
 
 // ---- the anchors of a pair: the query's minimizers in an LDS table, the reference's list streamed past it --------------------------------------
@@ -131,8 +148,8 @@ __global__ __launch_bounds__(kSeedThreads) void seed_kernel(const SeedPair *__re
     __shared__ unsigned long long s_base;
     const SeedPair P = pairs[blockIdx.x];
     const uint32_t tid = threadIdx.x;
-    const uint32_t mid_occ = P.cnt_meta[1];
-    uint32_t flag0 = P.cnt_meta[2];
+    const uint32_t mid_occ = ld_l2(&P.cnt_meta[1]);
+    uint32_t flag0 = ld_l2(&P.cnt_meta[2]);
     if (P.n_qry > q_slots / 2) flag0 |= SEED_FLAG_MANY;
     for (uint32_t s = tid; s < q_slots; s += kSeedThreads) qkey[s] = 0ull, qhead[s] = 0u;
     if (tid == 0) s_emit = 0, s_flag = flag0, s_span = 0;
