@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/tl
-timeout 900 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $R/gpurun_out/tl/prof -o t -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --throughput-leg 0 --legal-leg 0 --nonideal-leg 0 > $R/gpurun_out/tl/b.json 2> $R/gpurun_out/tl/b.err
+timeout 900 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $R/gpurun_out/tl/prof -o t -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --throughput-leg 0 --legal-leg 0 --nonideal-leg 0 "$@" > $R/gpurun_out/tl/b.json 2> $R/gpurun_out/tl/b.err
 cd $R
 python3 - <<'PY'
 import csv, glob, re, collections
