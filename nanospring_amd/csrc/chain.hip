@@ -557,7 +557,6 @@ int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vecto
     uint32_t n_lds = 0, n_big = 0, n_ring = 0, n_level = 0, max_lds = 0;
     std::vector<uint8_t> &fast = W.h_fast;                // 1: the LDS kernel, 2: the ring kernel (same conditions, any length), 3: the level kernel (long lists), 0: the general kernel
     fast.assign(nq, 0);
-    static const bool no_ring = getenv("NSGPU_CHAIN_NO_RING") != nullptr;       // A/B switch: long lists through the general kernel, as before
     // lists from this length on go to the level kernel (a workgroup per list; 0 = never): such lists come from repeats
     static const uint64_t level_min = [] { const char *e = getenv("NSGPU_CHAIN_LEVEL_MIN"); return e ? (uint64_t)atoll(e) : (uint64_t)768; }();
     par_for(nq, [&](size_t q) {
@@ -567,7 +566,7 @@ int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vecto
         uint64_t hi_bits = 0;
         for (uint64_t i = 0; i < n; ++i) hi_bits |= lists[q][i].x;
         const bool small_coords = (hi_bits >> 31) == 0 && opt.bw >= 0 && opt.bw <= kFastBw;
-        const bool ring_ok = small_coords && !no_ring && opt.max_chain_iter <= kRingIter && opt.max_chain_iter >= 0;
+        const bool ring_ok = small_coords && opt.max_chain_iter <= kRingIter && opt.max_chain_iter >= 0;
         fast[q] = ring_ok && level_min && n >= level_min ? 3 : small_coords && n <= kFastAnchors ? 1 : ring_ok ? 2 : 0;
     });
     for (size_t q = 0; q < nq; ++q) if (fast[q] == 1) hj[n_lds++] = (uint32_t)q, max_lds = std::max<uint32_t>(max_lds, (uint32_t)(off[q + 1] - off[q]));

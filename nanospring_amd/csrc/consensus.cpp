@@ -36,15 +36,12 @@ struct SlabCache {
     std::vector<unsigned char *> free;     // region-backed slabs are not handed back at thread exit (process-lifetime regions)
 };
 thread_local SlabCache t_slabs;
-constexpr size_t kMaxCachedSlabsPerThread = 16384;      // x 512 KiB = 8 GiB
 }  // namespace
 
-static const bool g_no_slab_cache = getenv("NSGPU_NO_SLAB_CACHE") != nullptr;
 
 // Slabs are carved out of 32 MiB regions aligned to 2 MiB and advised as huge pages: a thread's graphs spread over
 // hundreds of MB that are walked edge by edge, and with 4 KiB pages nearly every edge is also a TLB miss.  Regions are
 // never returned to the system (slabs circulate through the per-thread caches for the life of the process).
-static const bool g_no_huge = getenv("NSGPU_NO_HUGEPAGES") != nullptr;
 namespace {
 struct Region { unsigned char *p = nullptr; size_t used = 0; };
 thread_local Region t_region;
@@ -64,13 +61,12 @@ std::atomic<int64_t> g_slabs_in_use{0}, g_slabs_peak{0}, g_slabs_mapped{0};     
 unsigned char *slab_acquire(size_t bytes)
 {
     if (bytes == kSlabBytes) { const int64_t u = ++g_slabs_in_use; int64_t pk = g_slabs_peak.load(); while (u > pk && !g_slabs_peak.compare_exchange_weak(pk, u)) {} }
-    if (g_no_slab_cache) return static_cast<unsigned char *>(calloc(1, bytes));
     if (t_slabs.free.empty() && bytes == kSlabBytes) {
         std::lock_guard<std::mutex> lk(g_slab_pool_m);
         for (size_t i = 0; i < kSlabBatch && !g_slab_pool.empty(); ++i) { t_slabs.free.push_back(g_slab_pool.back()); g_slab_pool.pop_back(); }
     }
     if (!t_slabs.free.empty()) { unsigned char *p = t_slabs.free.back(); t_slabs.free.pop_back(); return p; }
-    if (!g_no_huge && bytes <= kRegionBytes) {
+    if (bytes <= kRegionBytes) {
         if (!t_region.p || t_region.used + bytes > kRegionBytes) {
             void *r = mmap(nullptr, kRegionBytes + (2u << 20), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
             if (r == MAP_FAILED) throw std::bad_alloc();
@@ -91,15 +87,12 @@ unsigned char *slab_acquire(size_t bytes)
 void slab_release(unsigned char *p, size_t bytes)
 {
     if (bytes == kSlabBytes) --g_slabs_in_use;
-    if (g_no_slab_cache) { ::free(p); return; }
-    // region-backed slabs must not reach free(): they stay in a cache (the cap only bounds posix_memalign'ed ones)
-    if (!g_no_huge || t_slabs.free.size() < kMaxCachedSlabsPerThread) {
-        t_slabs.free.push_back(p);
-        if (t_slabs.free.size() > kLocalSlabs) {
-            std::lock_guard<std::mutex> lk(g_slab_pool_m);
-            for (size_t i = 0; i < kSlabBatch; ++i) { g_slab_pool.push_back(t_slabs.free.back()); t_slabs.free.pop_back(); }
-        }
-    } else ::free(p);
+    // region-backed slabs never reach free(): they circulate through the caches
+    t_slabs.free.push_back(p);
+    if (t_slabs.free.size() > kLocalSlabs) {
+        std::lock_guard<std::mutex> lk(g_slab_pool_m);
+        for (size_t i = 0; i < kSlabBatch; ++i) { g_slab_pool.push_back(t_slabs.free.back()); t_slabs.free.pop_back(); }
+    }
 }
 
 template <class T> Pool<T>::~Pool()

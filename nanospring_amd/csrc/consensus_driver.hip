@@ -132,15 +132,14 @@ void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
 // So after an accepted read changed the consensus between a common prefix of P and a common suffix of S bases, only
 // new[P - 2m, Ln - S + 2m), m = w + k + 2, is sketched again; of its minimizers those at least m inside are exact (the artificial
 // start / end of the substring cannot reach them; a substring that starts at 0 or ends at Ln is exact up to that end), the old
-// minimizers left of P - m stay, those right of the old end of the change move by the length difference.  NSGPU_SKETCH_FULL=1
-// sketches whole strings as before; NSGPU_SKETCH_CHECK=1 compares every spliced list with a sketch of the whole string.
+// minimizers left of P - m stay, those right of the old end of the change move by the length difference.
+// NSGPU_SKETCH_CHECK=1 compares every spliced list with a sketch of the whole string.
 static void plan_splice(Builder &b, int w, int k)
 {
-    static const bool always_full = getenv("NSGPU_SKETCH_FULL") != nullptr;
     const std::string &nw = b.g->main_path, &od = b.mz_str;
     Builder::Splice &sp = b.sp;
     sp = Builder::Splice();
-    if (always_full || od.empty() || b.mz.empty()) return;
+    if (od.empty() || b.mz.empty()) return;
     const size_t Ln = nw.size(), Lo = od.size(), mn = std::min(Ln, Lo);
     // the graph knows from where on its main path changed (a lower bound of the common prefix): a multi-megabase consensus is compared
     // from there, not from its first base

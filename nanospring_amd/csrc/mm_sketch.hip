@@ -657,8 +657,7 @@ static int gpu_mm_sketch_one(nsgpu_ctx *c, const std::vector<SketchReq> &reqs_in
     out_off.assign(reqs_in.size() + 1, 0);
     out = nullptr;
     if (reqs_in.empty()) return NSGPU_OK;
-    static const bool general_only = getenv("NSGPU_SKETCH_GENERAL") != nullptr;      // debugging aid: the general passes for everything
-    if (!general_only && k > 0 && k <= 28 && w > 0 && w < 256 && (ws == 0 || ws == 1)) {
+    if (k > 0 && k <= 28 && w > 0 && w < 256 && (ws == 0 || ws == 1)) {
         const int rc = gpu_mm_sketch_fused(c, reqs_in, w, k, out, out_off, ws, n_stage_only);
         if (rc <= 0) return rc;
         out_off.assign(reqs_in.size() + 1, 0);
