@@ -765,7 +765,7 @@ static int batch_seed_and_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t 
         } else S.fb.push_back((uint32_t)i);
     }
     // seeds and, right behind them on the same stream, the chaining of their lists; the host looks at the results once
-    NS_TRY(gpu_seeds_chain_launch(c, ws, 2 * ws, opt, pairs));
+    NS_TRY(gpu_seeds_chain_launch(c, ws, 2 * ws, opt, pairs, false));       // (the anchor total: behind the plan kernel, gpu_seeds_total in the callers)
     S.calls += 1, S.pairs += pairs.size();
     // requests without pinned minimizer lists: the host code now, pairs the kernels hand back: in batch_wait_and_step
     nsgpu_ctx::ChainWs &W = c->cws[2 * ws + 1];
@@ -863,6 +863,7 @@ int align_prestep_launch(nsgpu_ctx *c, AlignBatch &B, size_t lo, size_t hi, int 
     NS_TRY(batch_seed_and_launch(c, B, lo, hi, chain_ws, started_and_seeded));
     // the plan kernel and the DP launch behind the chaining kernel, without waiting for either (plan.hip)
     if (dp_ws >= 0) NS_TRY(batch_plan_launch(c, B, lo, hi, chain_ws, dp_ws));
+    NS_TRY(gpu_seeds_total(c, chain_ws));
     B.host_ms += now_ms() - a0;
     return NSGPU_OK;
 }
@@ -901,6 +902,7 @@ int align_begin(nsgpu_ctx *c, AlignBatch &B, int ws_index)
         B.plan_ws = -1;
         NS_TRY(batch_seed_and_launch(c, B, 0, n_pairs, 0));      // direct API calls: chain workspace 0
         NS_TRY(batch_plan_launch(c, B, 0, n_pairs, 0, ws_index));
+        NS_TRY(gpu_seeds_total(c, 0));
         NS_TRY(batch_wait_and_step(c, B, 0, n_pairs, 0));
         B.host_ms += now_ms() - a0;
     }

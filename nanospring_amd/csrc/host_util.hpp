@@ -178,10 +178,11 @@ int gpu_chain_launch(nsgpu_ctx *c, int ws, const mm2::Opt &opt, const std::vecto
                      const std::vector<float> &avg);
 int gpu_chain_wait(nsgpu_ctx *c, int ws, const int32_t *&f, const int32_t *&p);
 
-int gpu_seeds_launch(nsgpu_ctx *c, int ws, float mid_occ_frac, std::vector<SeedPair> &pairs);
+int gpu_seeds_launch(nsgpu_ctx *c, int ws, float mid_occ_frac, std::vector<SeedPair> &pairs, bool with_total = true);
+int gpu_seeds_total(nsgpu_ctx *c, int ws);
 int gpu_seeds_wait(nsgpu_ctx *c, int ws, const SeedResult *&res, const mm2::Anchor *&d_anchors);
 // seeds + the chaining kernel behind them on one stream (chain_ws: the chaining workspace whose pinned buffer takes anchors / f / p)
-int gpu_seeds_chain_launch(nsgpu_ctx *c, int ws, int chain_ws, const mm2::Opt &opt, std::vector<SeedPair> &pairs);
+int gpu_seeds_chain_launch(nsgpu_ctx *c, int ws, int chain_ws, const mm2::Opt &opt, std::vector<SeedPair> &pairs, bool with_total = true);
 // what the launch above left in DEVICE memory (valid on the seeding workspace's stream, behind its kernels): the sorted anchors, the pairs' results
 // (pinned, device-visible) and f / p of every anchor -- the inputs of the plan kernel (plan.hip)
 struct SeedChainDev { const mm2::Anchor *anchors; const SeedResult *res; const int32_t *f, *p; hipStream_t stream; uint32_t lds_anchors; };

@@ -280,7 +280,7 @@ uint32_t count_table_bits(uint64_t n_keys)
 // anchors of pair i are W.d_out[res[i].base .. + res[i].n) in DEVICE memory (for chain.hip); res (pinned) is valid after
 // gpu_seeds_wait.  Pairs with res[i].flags != 0 have no usable list.  A pair without a count table of its reference (cnt_tab == nullptr)
 // gets one built here, in the workspace's scratch.
-int gpu_seeds_launch(nsgpu_ctx *c, int ws, float mid_occ_frac, std::vector<SeedPair> &pairs)
+int gpu_seeds_launch(nsgpu_ctx *c, int ws, float mid_occ_frac, std::vector<SeedPair> &pairs, bool with_total)
 {
     nsgpu_ctx::SeedWs &W = c->seed_ws[ws];
     const size_t n = pairs.size();
@@ -316,12 +316,14 @@ int gpu_seeds_launch(nsgpu_ctx *c, int ws, float mid_occ_frac, std::vector<SeedP
     }
     NS_TRY(W.d_tmp.reserve(n * kSortCap * sizeof(mm2::Anchor)));
     NS_TRY(W.d_out.reserve(want * sizeof(mm2::Anchor)));
+    const bool fresh_counter = W.d_counter.p == nullptr;
     NS_TRY(W.d_counter.reserve(16));
     NS_TRY(W.h_pairs.reserve(n * sizeof(SeedPair)));
     NS_TRY(W.h_res.reserve(n * sizeof(SeedResult) + 16));
     W.capacity = want;
     memcpy(W.h_pairs.p, pairs.data(), n * sizeof(SeedPair));
-    NS_HIP(hipMemsetAsync(W.d_counter.p, 0, 8, W.stream));
+    // (the counter is cleared behind its read-out, gpu_seeds_total: not in front of the seeding kernel, where the fill kernel was 6-9 us of every slot's chain)
+    if (fresh_counter) NS_HIP(hipMemsetAsync(W.d_counter.p, 0, 8, W.stream));
     uint32_t q_slots = 256;
     while (q_slots < 2 * std::min<uint32_t>(max_q, kMaxQry)) q_slots <<= 1;
     const size_t lds = seed_lds_bytes(q_slots);
@@ -332,7 +334,18 @@ int gpu_seeds_launch(nsgpu_ctx *c, int ws, float mid_occ_frac, std::vector<SeedP
                        W.d_counter.as<unsigned long long>(), (unsigned long long)want, W.h_res.as<SeedResult>(), q_slots,
                        c->defer_slots && c->defer_anchors < kSortCap ? c->defer_anchors : kSortCap);
     NS_HIP(hipGetLastError());
-    NS_HIP(hipMemcpyAsync(W.h_res.as<uint8_t>() + n * sizeof(SeedResult), W.d_counter.p, 8, hipMemcpyDeviceToHost, W.stream));
+    if (with_total) NS_TRY(gpu_seeds_total(c, ws));
+    return NSGPU_OK;
+}
+
+// the launch's anchor total to the host (behind the results) and the counter cleared for the workspace's next launch; a caller that puts the chaining
+// kernel right behind the seeding kernel asks for it behind that (gpu_seeds_chain_launch)
+int gpu_seeds_total(nsgpu_ctx *c, int ws)
+{
+    nsgpu_ctx::SeedWs &W = c->seed_ws[ws];
+    if (W.pend == 0) return NSGPU_OK;
+    NS_HIP(hipMemcpyAsync(W.h_res.as<uint8_t>() + W.pend * sizeof(SeedResult), W.d_counter.p, 8, hipMemcpyDeviceToHost, W.stream));
+    NS_HIP(hipMemsetAsync(W.d_counter.p, 0, 8, W.stream));
     return NSGPU_OK;
 }
 
@@ -354,13 +367,16 @@ int gpu_chain_launch_seeded(nsgpu_ctx *c, int ws, hipStream_t stream, const mm2:
                             uint64_t capacity, uint32_t max_n_qry);
 void gpu_chain_results_seeded(nsgpu_ctx *c, int ws, const mm2::Anchor *&a, const int32_t *&f, const int32_t *&p);
 
-int gpu_seeds_chain_launch(nsgpu_ctx *c, int ws, int chain_ws, const mm2::Opt &opt, std::vector<SeedPair> &pairs)
+// with_total = false: the caller puts more kernels behind the chaining kernel (the alignment plan) and calls gpu_seeds_total behind those
+int gpu_seeds_chain_launch(nsgpu_ctx *c, int ws, int chain_ws, const mm2::Opt &opt, std::vector<SeedPair> &pairs, bool with_total)
 {
-    NS_TRY(gpu_seeds_launch(c, ws, opt.mid_occ_frac, pairs));
+    NS_TRY(gpu_seeds_launch(c, ws, opt.mid_occ_frac, pairs, false));
     nsgpu_ctx::SeedWs &W = c->seed_ws[ws];
     uint32_t max_q = 0;
     for (const SeedPair &p : pairs) max_q = std::max(max_q, p.n_qry);
-    return gpu_chain_launch_seeded(c, chain_ws, W.stream, opt, W.d_out.as<mm2::Anchor>(), W.h_res.as<SeedResult>(), pairs.size(), W.capacity, max_q);
+    NS_TRY(gpu_chain_launch_seeded(c, chain_ws, W.stream, opt, W.d_out.as<mm2::Anchor>(), W.h_res.as<SeedResult>(), pairs.size(), W.capacity, max_q));
+    if (with_total) NS_TRY(gpu_seeds_total(c, ws));
+    return NSGPU_OK;
 }
 
 int gpu_seeds_chain_wait(nsgpu_ctx *c, int ws, int chain_ws, const SeedResult *&res, const mm2::Anchor *&a, const int32_t *&f, const int32_t *&p)
