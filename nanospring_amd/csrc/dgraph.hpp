@@ -1,0 +1,1167 @@
+// dgraph.hpp -- the consensus DAG (ConsensusGraph, src/ConsensusGraph.cpp:135-159 initialize, :400-557 updateGraph,
+// :559-615 calculateMainPathGreedy, :617-651 clearMainPath, :653-714 removeCycles / walkAndPrune, :716-807 splitPath, :809-897 the
+// node / edge bookkeeping; tie rules :33-91) as a structure of arrays with 32-bit ids, written ONCE for the host and for gfx950:
+// one workgroup of 256 threads per contig builder runs these functions on the graph where it lies in HBM (dgraph_dev.hip); the
+// CPU test harness and the emission of a finished contig (consensus_soa.cpp) run the very same code with a team of one.
+//
+// Layout (all indices 32 bit, position independent: a graph moves between HBM and host memory by plain copies)
+//   Node 32 B: out[3] | out_ext | in[2] | in_ext | n_out n_in base on_main.  An out reference carries the base code of the edge's
+//              sink in its top three bits (which way out has base b needs neither the edge nor the sink).  Lists beyond the inline
+//              slots continue in chunks.
+//   Edge 64 B: src sink count head tail ids[11].  count == number of read ids; ids beyond 11 continue in chunks of 15 (head .. tail).
+//              The reference keeps the ids ordered (a sorted vector); nothing observable depends on the order (membership, the
+//              smallest id, intersections, differences), so they are kept in arrival order.
+//   path     : pe[] edge ids, pn[] node ids (m + 1), ps[] bases (m + 1), a deque inside arrays of cap_path entries (path_off).
+// Ids are handed out in a fixed order (prefix sums, never atomics), so a team of 256 and a team of one build byte-identical arrays:
+// the GPU tests compare the device arrays with the host run's after every update.
+//
+// What is parallel on the device: the appends of a read along the runs of the main path it follows (lanes over edges), the side
+// excursions of a read (lanes over excursions: each leaves the path at a node of its own and comes back at another), the creation
+// of new nodes and edges (lanes over nodes), the greedy choice at every node of the stretch the reference walks again (lanes over
+// nodes; only where the choice differs from the path the walk is followed step by step), the copies of path stretches, the
+// comparison of the old and the new consensus.  Sequential (thread 0): the stitching of detours, removeCycles / splitPath.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#define DG_HD __host__ __device__ inline
+#else
+#define DG_HD inline
+#endif
+
+namespace nsgpu {
+namespace dg {
+
+constexpr uint32_t NIL = 0xffffffffu;
+constexpr uint32_t kEdgeInl = 11, kChunkIds = 15, kOutInl = 3, kInInl = 2;
+constexpr uint32_t kRefMask = 0x1fffffffu;         // edge id of an out reference (the sink's base code above it)
+
+struct Node { uint32_t out[kOutInl], out_ext, in[kInInl], in_ext; uint8_t n_out, n_in, base, on_main; };
+struct Edge { uint32_t src, sink, count, head, tail, ids[kEdgeInl]; };
+struct Chunk { uint32_t next, v[kChunkIds]; };
+static_assert(sizeof(Node) == 32 && sizeof(Edge) == 64 && sizeof(Chunk) == 64, "graph records are 32 / 64 bytes");
+
+enum : uint32_t {
+    ERR_CAP = 1u,        // an array is full (the host grows the arrays before a launch from worst-case bounds: a bug or a pathological read)
+    ERR_SCRIPT = 2u,     // an edit script that runs off the path
+    ERR_DEGREE = 4u,     // more than 255 edges at one node
+    ERR_WALK = 8u,       // a detour of the greedy walk that does not come back behind where it left (a cycle through the path)
+    ERR_SCRATCH = 16u,   // the work area is too small
+};
+
+// one op of the script: type (0 SAME, 1 INSERT, 2 DELETE) | base << 2 | num << 10
+DG_HD uint32_t op_make(uint32_t type, uint32_t base, uint32_t num) { return type | (base << 2) | (num << 10); }
+DG_HD uint32_t op_type(uint32_t o) { return o & 3u; }
+DG_HD uint32_t op_base(uint32_t o) { return (o >> 2) & 0xffu; }
+DG_HD uint32_t op_num(uint32_t o) { return o >> 10; }
+constexpr uint32_t kOpMaxNum = (1u << 22) - 1;
+
+struct Hdr {
+    uint32_t n_nodes, n_edges, n_chunks;             // ids handed out so far
+    uint32_t live_nodes, live_edges;                  // numNodes / numEdges of the reference
+    uint32_t cap_nodes, cap_edges, cap_chunks, cap_path, cap_wk, cap_multi;
+    uint32_t path_off, m;                             // the path's edges are pe[path_off .. path_off + m), its nodes pn / ps[path_off .. path_off + m]
+    uint32_t right_off, left_off, right_unch, left_unch;     // rightMostUnchangedNodeOffset / leftMost... and the nodes
+    uint32_t n_multi, multi_n;                        // side nodes with more than one edge in; entries of multi_list (a superset, may hold stale ids)
+    uint32_t epoch;
+    uint32_t err;
+    // the last update, for the main-path recompute behind it: its tables stay in wk[0 .. upd_wk)
+    uint32_t upd_wk, upd_n_ops, upd_n_exc, upd_nodes0, upd_edges0;
+    // what an update + recompute reports to the host
+    uint32_t initial;                                 // the read's first node
+    uint32_t P, S, old_len, new_len;                  // the consensus before and after share P bases in front and S at the end
+    uint32_t ending_id, starting_id;                  // the smallest read id on the path's last / first edge
+    uint32_t st_splits, st_detours, st_walked, st_seq_exc, st_cycles_run, st_full_walk, st_dis;
+    uint32_t stage;                                   // of the recompute: 2 = choosing (nothing changed yet), 3 = changing the graph
+    uint32_t dbg_flags;                               // tests: 1 = excursions one at a time, 2 = removeCycles by the reference's full walk
+    uint32_t pad_[2];
+};
+static_assert(sizeof(Hdr) % 16 == 0, "header is whole 16-byte words");
+
+struct G {
+    Hdr *h;
+    Node *nodes; Edge *edges; Chunk *chunks; uint32_t *mark;
+    uint32_t *pe, *pn; uint8_t *ps;
+    uint32_t *sv_e, *sv_n; uint8_t *sv_s;             // the path as it was, where the walk goes over it again (cap_path entries each, same positions)
+    uint32_t *multi_list;
+    uint32_t *wk;                                     // work area, cap_wk words
+};
+
+DG_HD uint32_t code_of(uint32_t b) { return b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 4u; }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// teams: the functions below are written for a team of threads that all run the same statements (every loop bound and every
+// branch around a team call is the same for all of them); `tid == 0` marks what one thread does alone.  HostTeam is the team of one.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct HostTeam {
+    DG_HD uint32_t tid() const { return 0; }
+    DG_HD uint32_t size() const { return 1; }
+    DG_HD void sync() {}
+    DG_HD uint32_t bcast(uint32_t v) { return v; }                                  // thread 0's value
+    DG_HD uint32_t scan(uint32_t v, uint32_t &total) { total = v; return 0; }       // exclusive prefix sum over the team's threads
+    DG_HD uint32_t min_all(uint32_t v) { return v; }
+    DG_HD uint32_t max_all(uint32_t v) { return v; }
+};
+
+// excursion record (8 words) in the update's tables
+enum { X_A = 0, X_CUR = 1, X_K0 = 2, X_NODE0 = 3, X_EDGE0 = 4, X_FLAGS = 5, X_B = 6, X_NINS = 7, X_WORDS = 8 };
+// piece of a re-walked stretch (4 words): kind, a, b, c
+enum { PC_OLD = 0, PC_EDGE = 1, PC_CHAIN = 2 };
+
+template <class T> struct Ops {
+    G g;
+    T &team;
+    DG_HD Ops(const G &gg, T &t) : g(gg), team(t) {}
+
+    DG_HD void fail(uint32_t e) { g.h->err |= e; }
+    DG_HD bool failed() const { return g.h->err != 0; }
+
+    // ---- allocation (sequential contexts: one thread; the parallel phases compute their ids from prefix sums) ----
+    DG_HD uint32_t new_chunk() { Hdr &h = *g.h; if (h.n_chunks >= h.cap_chunks) { fail(ERR_CAP); return 0; } const uint32_t c = h.n_chunks++; g.chunks[c].next = NIL; return c; }
+    DG_HD uint32_t new_node(uint32_t base)
+    {
+        Hdr &h = *g.h;
+        if (h.n_nodes >= h.cap_nodes) { fail(ERR_CAP); return 0; }
+        const uint32_t n = h.n_nodes++;
+        Node &x = g.nodes[n];
+        x.out_ext = x.in_ext = NIL, x.n_out = x.n_in = 0, x.base = (uint8_t)base, x.on_main = 0;
+        g.mark[n] = 0;
+        ++h.live_nodes;
+        return n;
+    }
+
+    // ---- a node's edge lists ----
+    DG_HD uint32_t list_get(const uint32_t *inl, uint32_t n_inl, uint32_t ext, uint32_t i) const
+    {
+        if (i < n_inl) return inl[i];
+        i -= n_inl;
+        uint32_t c = ext;
+        while (i >= kChunkIds) c = g.chunks[c].next, i -= kChunkIds;
+        return g.chunks[c].v[i];
+    }
+    DG_HD void list_set(uint32_t *inl, uint32_t n_inl, uint32_t &ext, uint32_t i, uint32_t v)
+    {
+        if (i < n_inl) { inl[i] = v; return; }
+        i -= n_inl;
+        if (ext == NIL) ext = new_chunk();
+        uint32_t c = ext;
+        while (i >= kChunkIds) { if (g.chunks[c].next == NIL) { const uint32_t nc = new_chunk(); g.chunks[c].next = nc; } c = g.chunks[c].next; i -= kChunkIds; }
+        g.chunks[c].v[i] = v;
+    }
+    DG_HD uint32_t out_ref(const Node &x, uint32_t i) const { return list_get(x.out, kOutInl, x.out_ext, i); }
+    DG_HD uint32_t in_ref(const Node &x, uint32_t i) const { return list_get(x.in, kInInl, x.in_ext, i); }
+    DG_HD void out_push(uint32_t n, uint32_t ref)
+    {
+        Node &x = g.nodes[n];
+        if (x.n_out == 255) { fail(ERR_DEGREE); return; }
+        list_set(x.out, kOutInl, x.out_ext, x.n_out, ref);
+        ++x.n_out;
+    }
+    DG_HD void in_push(uint32_t n, uint32_t e)
+    {
+        Node &x = g.nodes[n];
+        if (x.n_in == 255) { fail(ERR_DEGREE); return; }
+        list_set(x.in, kInInl, x.in_ext, x.n_in, e);
+        ++x.n_in;
+    }
+    DG_HD void out_erase(uint32_t n, uint32_t i)
+    {
+        Node &x = g.nodes[n];
+        for (uint32_t j = i; j + 1 < x.n_out; ++j) list_set(x.out, kOutInl, x.out_ext, j, list_get(x.out, kOutInl, x.out_ext, j + 1));
+        --x.n_out;
+    }
+    DG_HD void in_erase(uint32_t n, uint32_t i)
+    {
+        Node &x = g.nodes[n];
+        for (uint32_t j = i; j + 1 < x.n_in; ++j) list_set(x.in, kInInl, x.in_ext, j, list_get(x.in, kInInl, x.in_ext, j + 1));
+        --x.n_in;
+    }
+
+    // ---- an edge's read ids ----
+    DG_HD static bool append_needs_chunk(uint32_t count) { return count >= kEdgeInl && (count - kEdgeInl) % kChunkIds == 0; }
+    // Edge::addRead (:24-28) with the chunk an id behind the last full one needs handed in
+    DG_HD void append_id(uint32_t ei, uint32_t id, uint32_t fresh_chunk)
+    {
+        Edge &e = g.edges[ei];
+        const uint32_t c = e.count;
+        if (c < kEdgeInl) e.ids[c] = id;
+        else {
+            const uint32_t s = (c - kEdgeInl) % kChunkIds;
+            if (s == 0) {
+                g.chunks[fresh_chunk].next = NIL;
+                if (c == kEdgeInl) e.head = fresh_chunk; else g.chunks[e.tail].next = fresh_chunk;
+                e.tail = fresh_chunk;
+            }
+            g.chunks[e.tail].v[s] = id;
+        }
+        e.count = c + 1;
+    }
+    DG_HD void add_read_seq(uint32_t ei, uint32_t id) { const uint32_t c = append_needs_chunk(g.edges[ei].count) ? new_chunk() : NIL; append_id(ei, id, c); }
+    // the ids of an edge into a list in the work area; returns their number
+    DG_HD uint32_t ids_copy(const Edge &e, uint32_t *dst) const
+    {
+        const uint32_t n = e.count, ni = n < kEdgeInl ? n : kEdgeInl;
+        for (uint32_t p = 0; p < ni; ++p) dst[p] = e.ids[p];
+        uint32_t left = n - ni, c = e.head, w = ni;
+        while (left) { const Chunk &k = g.chunks[c]; const uint32_t t = left < kChunkIds ? left : kChunkIds; for (uint32_t p = 0; p < t; ++p) dst[w++] = k.v[p]; left -= t; c = k.next; }
+        return n;
+    }
+    DG_HD bool edge_has(const Edge &e, uint32_t id) const
+    {
+        const uint32_t n = e.count, ni = n < kEdgeInl ? n : kEdgeInl;
+        for (uint32_t p = 0; p < ni; ++p) if (e.ids[p] == id) return true;
+        uint32_t left = n - ni, c = e.head;
+        while (left) { const Chunk &k = g.chunks[c]; const uint32_t t = left < kChunkIds ? left : kChunkIds; for (uint32_t p = 0; p < t; ++p) if (k.v[p] == id) return true; left -= t; c = k.next; }
+        return false;
+    }
+    DG_HD uint32_t edge_min_id(const Edge &e) const
+    {
+        uint32_t best = NIL;
+        const uint32_t n = e.count, ni = n < kEdgeInl ? n : kEdgeInl;
+        for (uint32_t p = 0; p < ni; ++p) if (e.ids[p] < best) best = e.ids[p];
+        uint32_t left = n - ni, c = e.head;
+        while (left) { const Chunk &k = g.chunks[c]; const uint32_t t = left < kChunkIds ? left : kChunkIds; for (uint32_t p = 0; p < t; ++p) if (k.v[p] < best) best = k.v[p]; left -= t; c = k.next; }
+        return best;
+    }
+
+    // ---- Node::getEdgeTo / getEdgeToSide / getBestEdgeOut / getBestEdgeIn (src/ConsensusGraph.cpp:33-81) ----
+    DG_HD uint32_t edge_to(uint32_t n, uint32_t target) const
+    {
+        const Node &x = g.nodes[n];
+        for (uint32_t i = 0; i < x.n_out; ++i) { const uint32_t e = out_ref(x, i) & kRefMask; if (g.edges[e].sink == target) return e; }
+        return NIL;
+    }
+    DG_HD uint32_t edge_to_side(uint32_t n, uint32_t base) const
+    {
+        const Node &x = g.nodes[n];
+        const uint32_t want = code_of(base);
+        for (uint32_t i = 0; i < x.n_out; ++i) {
+            const uint32_t r = out_ref(x, i), e = r & kRefMask, c = r >> 29;
+            if (c != want) continue;
+            const Node &s = g.nodes[g.edges[e].sink];
+            if (!s.on_main && s.base == base) return e;
+        }
+        return NIL;
+    }
+    DG_HD uint32_t best_out(uint32_t n) const
+    {
+        const Node &x = g.nodes[n];
+        uint32_t best = NIL, c = 0;
+        for (uint32_t i = 0; i < x.n_out; ++i) { const uint32_t e = out_ref(x, i) & kRefMask, k = g.edges[e].count; if (k > c) c = k, best = e; }
+        return best;
+    }
+    DG_HD uint32_t best_in(uint32_t n) const
+    {
+        const Node &x = g.nodes[n];
+        uint32_t best = NIL, c = 0;
+        for (uint32_t i = 0; i < x.n_in; ++i) { const uint32_t e = in_ref(x, i), k = g.edges[e].count; if (k > c) c = k, best = e; }
+        return best;
+    }
+
+    // ---- side nodes with more than one edge in (what removeCycles acts on) ----
+    DG_HD bool multi_in_side(uint32_t n) const { const Node &x = g.nodes[n]; return !x.on_main && x.n_in > 1; }
+    DG_HD void note_multi(uint32_t n) { Hdr &h = *g.h; if (h.multi_n < h.cap_multi) g.multi_list[h.multi_n++] = n; else h.multi_n = h.cap_multi + 1; }     // (a full list: the full walk decides)
+    DG_HD void set_on_main(uint32_t n, bool v)
+    {
+        const bool was = multi_in_side(n);
+        g.nodes[n].on_main = v ? 1 : 0;
+        const bool is = multi_in_side(n);
+        g.h->n_multi += (uint32_t)is - (uint32_t)was;
+        if (!was && is) note_multi(n);
+    }
+    // createEdge (:823-839) with the ids copied from a list in the work area
+    DG_HD uint32_t new_edge(uint32_t s, uint32_t t, const uint32_t *ids, uint32_t n_ids)
+    {
+        Hdr &h = *g.h;
+        if (h.n_edges >= h.cap_edges) { fail(ERR_CAP); return 0; }
+        const uint32_t e = h.n_edges++;
+        Edge &x = g.edges[e];
+        x.src = s, x.sink = t, x.count = 0, x.head = x.tail = NIL;
+        for (uint32_t i = 0; i < n_ids; ++i) add_read_seq(e, ids[i]);
+        const bool was = multi_in_side(t);
+        out_push(s, e | (code_of(g.nodes[t].base) << 29));
+        in_push(t, e);
+        const bool is = multi_in_side(t);
+        h.n_multi += (uint32_t)is - (uint32_t)was;
+        if (!was && is) note_multi(t);
+        ++h.live_edges;
+        return e;
+    }
+    // removeEdge (:861-876): the source side drops the FIRST out-edge that leads to the same sink
+    DG_HD void remove_edge(uint32_t e, bool keep_in_source, bool keep_in_sink)
+    {
+        Edge &x = g.edges[e];
+        if (!keep_in_source) {
+            const Node &s = g.nodes[x.src];
+            for (uint32_t i = 0; i < s.n_out; ++i) if (g.edges[out_ref(s, i) & kRefMask].sink == x.sink) { out_erase(x.src, i); break; }
+        }
+        if (!keep_in_sink) {
+            const bool was = multi_in_side(x.sink);
+            const Node &t = g.nodes[x.sink];
+            for (uint32_t i = 0; i < t.n_in; ++i) if (in_ref(t, i) == e) { in_erase(x.sink, i); break; }
+            g.h->n_multi += (uint32_t)multi_in_side(x.sink) - (uint32_t)was;
+        }
+        x.count = 0, x.src = x.sink = NIL;       // (ids are not handed out again: a dead edge stays dead)
+        --g.h->live_edges;
+    }
+    // removeNode (:878-897)
+    DG_HD void remove_node(uint32_t n)
+    {
+        Hdr &h = *g.h;
+        h.n_multi -= (uint32_t)multi_in_side(n);
+        Node &x = g.nodes[n];
+        x.on_main = 1;                            // keeps the counter untouched while the node's edges go away
+        for (uint32_t i = 0; i < x.n_in; ++i) remove_edge(in_ref(x, i), false, true);
+        for (uint32_t i = 0; i < x.n_out; ++i) remove_edge(out_ref(x, i) & kRefMask, true, false);
+        x.n_in = x.n_out = 0, x.on_main = 0;
+        --h.live_nodes;
+    }
+    // removeReadsFromEdge (:843-859): the ids of `rm` leave the edge; an edge without reads goes
+    DG_HD void remove_reads_from_edge(uint32_t ei, const uint32_t *rm, uint32_t n_rm)
+    {
+        Edge &e = g.edges[ei];
+        const uint32_t n = e.count;
+        // compaction in place, position by position (the write position never overtakes the read position)
+        uint32_t w = 0, rc = e.head, wc = e.head;            // chunks of the read / write positions once they are beyond the inline slots
+        for (uint32_t p = 0; p < n; ++p) {
+            uint32_t v;
+            if (p < kEdgeInl) v = e.ids[p];
+            else { const uint32_t s = (p - kEdgeInl) % kChunkIds; if (s == 0 && p != kEdgeInl) rc = g.chunks[rc].next; v = g.chunks[rc].v[s]; }
+            bool drop = false;
+            for (uint32_t q = 0; q < n_rm; ++q) if (rm[q] == v) { drop = true; break; }
+            if (drop) continue;
+            if (w < kEdgeInl) e.ids[w] = v;
+            else { const uint32_t s = (w - kEdgeInl) % kChunkIds; if (s == 0 && w != kEdgeInl) wc = g.chunks[wc].next; g.chunks[wc].v[s] = v; }
+            ++w;
+        }
+        e.count = w;
+        e.tail = w > kEdgeInl ? wc : NIL;
+        if (w <= kEdgeInl) e.head = NIL;
+        if (w == 0) remove_edge(ei, false, false);
+    }
+
+    DG_HD uint32_t path_node(uint32_t i) const { return g.pn[g.h->path_off + i]; }
+
+    // ================================================================================================================
+    // initialize (:135-159) + the first calculateMainPathGreedy: the seed read as a chain, all of it the main path
+    // ================================================================================================================
+    DG_HD void initialize(const uint8_t *seed, uint32_t len, uint32_t id)
+    {
+        Hdr &h = *g.h;
+        const uint32_t tid = team.tid(), nt = team.size();
+        if (len == 0 || len > h.cap_nodes || len - 1 > h.cap_edges || len + 2 > h.cap_path) { if (tid == 0) fail(ERR_CAP); team.sync(); return; }
+        const uint32_t off = (h.cap_path - len) / 2;
+        for (uint32_t i = tid; i < len; i += nt) {
+            Node &x = g.nodes[i];
+            x.out_ext = x.in_ext = NIL, x.base = seed[i], x.on_main = 1;
+            x.n_out = i + 1 < len ? 1 : 0, x.n_in = i ? 1 : 0;
+            if (i + 1 < len) x.out[0] = i | (code_of(seed[i + 1]) << 29);
+            if (i) x.in[0] = i - 1;
+            g.mark[i] = 0;
+            if (i + 1 < len) { Edge &e = g.edges[i]; e.src = i, e.sink = i + 1, e.count = 1, e.head = e.tail = NIL, e.ids[0] = id; g.pe[off + i] = i; }
+            g.pn[off + i] = i, g.ps[off + i] = seed[i];
+        }
+        team.sync();
+        if (tid == 0) {
+            h.n_nodes = h.live_nodes = len, h.n_edges = h.live_edges = len - 1, h.n_chunks = 0;
+            h.path_off = off, h.m = len - 1;
+            h.right_off = h.m, h.left_off = 0, h.right_unch = len - 1, h.left_unch = 0;
+            h.n_multi = h.multi_n = 0, h.epoch = 0;
+            h.upd_wk = h.upd_n_ops = h.upd_n_exc = 0, h.upd_nodes0 = len, h.upd_edges0 = len - 1;
+            h.initial = 0, h.P = 0, h.S = 0, h.old_len = 0, h.new_len = len, h.ending_id = h.starting_id = id;
+        }
+        team.sync();
+    }
+
+    // ================================================================================================================
+    // updateGraph (:400-557)
+    // ================================================================================================================
+    // words of the update's tables for a script of n ops
+    DG_HD static uint32_t wk_update_words(uint32_t n_ops) { return 14 * (n_ops + 2); }
+
+    // The read `id` with the edit script ops[0 .. n_ops) against the main path.  The script is the aligner's with the read's overhangs
+    // written out: -begin_offset INSERTs in front when the read starts left of the path, end_offset INSERTs at the end when it runs
+    // beyond it (:437-452, :533-541 do exactly insertNode for those); the walk starts at edge max(begin_offset, 0).
+    DG_HD void update(const uint32_t *ops_in, uint32_t n_ops, int64_t begin_offset, int64_t end_offset, uint32_t id)
+    {
+        Hdr &h = *g.h;
+        const uint32_t tid = team.tid(), nt = team.size();
+        const uint32_t m = h.m;
+        if (wk_update_words(n_ops) > h.cap_wk) { if (tid == 0) fail(ERR_SCRATCH); team.sync(); return; }
+        // ---- the unchanged stretch (:409-433) ----
+        if (tid == 0) {
+            if (begin_offset >= 0 || end_offset >= 0) {
+                int64_t r = (int64_t)h.right_off < begin_offset ? (int64_t)h.right_off : begin_offset;
+                if (r < (int64_t)h.left_off) r = (int64_t)h.left_off;
+                h.right_off = (uint32_t)r;
+                h.right_unch = path_node(h.right_off);
+            } else {
+                // (size_t arithmetic in the reference: a read that ends left of the path's first base wraps to a huge value)
+                const int64_t v = (int64_t)m + end_offset;
+                uint32_t l = v < 0 ? NIL : (uint32_t)v;
+                if (l < h.left_off) l = h.left_off;
+                if (l > h.right_off) l = h.right_off;
+                h.left_off = l;
+                h.left_unch = path_node(h.left_off);
+            }
+        }
+        uint32_t *W = g.wk;
+        uint32_t *ops = W;                        // [n_ops]      the script (copied: it may lie in host memory)
+        uint32_t *op_at = ops + n_ops + 1;        // [n_ops + 1]  edgeInPath at the start of op k
+        uint32_t *run_off = op_at + n_ops + 1;    // [n_ops + 1]  main-path appends in front of op k's
+        uint32_t *ins_ord = run_off + n_ops + 1;  // [n_ops + 1]  INSERTs in front of op k
+        uint32_t *ins_op = ins_ord + n_ops + 1;   // [n_ops]      op of the q-th INSERT
+        uint32_t *app = ins_op + n_ops + 1;       // [n_ops + 1]  the existing side / junction edge op k follows (NIL: none); slot k of a SAME op = its first base's edge
+        uint32_t *ex = app + n_ops + 1;           // [n_ops + 1] excursion records
+        const uint32_t ei0 = begin_offset > 0 ? (begin_offset < (int64_t)m ? (uint32_t)begin_offset : m) : 0;
+        for (uint32_t k = tid; k < n_ops; k += nt) ops[k] = ops_in[k];
+        team.sync();
+        // ---- pass A: positions.  An excursion is a maximal run of INSERT / DELETE ops; one starts at op 0 and behind every SAME (possibly
+        // with no op at all: its junction is then the step from one SAME's last node to the next one's first) ----
+        uint32_t carry_e = ei0, carry_r = 0, carry_i = 0, n_exc = 0;
+        for (uint32_t base = 0; base < n_ops + 1; base += nt) {
+            const uint32_t k = base + tid;
+            uint32_t de = 0, dr = 0, di = 0, is_start = 0;
+            if (k < n_ops) {
+                const uint32_t o = ops[k], t = op_type(o);
+                de = t == 0 ? op_num(o) : t == 2 ? 1u : 0u;
+                dr = t == 0 && op_num(o) > 1 ? op_num(o) - 1 : 0u;
+                di = t == 1 ? 1u : 0u;
+            }
+            if (k <= n_ops) is_start = k == 0 || op_type(ops[k - 1]) == 0 ? 1u : 0u;
+            uint32_t te, tr, ti, tx;
+            const uint32_t pe_ = team.scan(de, te), pr_ = team.scan(dr, tr), pi_ = team.scan(di, ti), px_ = team.scan(is_start, tx);
+            if (k <= n_ops) {
+                const uint64_t e2 = (uint64_t)carry_e + pe_;
+                op_at[k] = e2 < m ? (uint32_t)e2 : m;
+                run_off[k] = carry_r + pr_;
+                ins_ord[k] = carry_i + pi_;
+                if (di) ins_op[carry_i + pi_] = k;
+                app[k] = NIL;
+                if (is_start) ex[X_WORDS * (n_exc + px_) + X_A] = k;
+            }
+            { const uint64_t c = (uint64_t)carry_e + te; carry_e = c > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)c; }
+            carry_r += tr, carry_i += ti, n_exc += tx;
+        }
+        team.sync();
+        const uint32_t n_run = carry_r;
+        for (uint32_t x = tid; x < n_exc; x += nt) {
+            uint32_t *r = ex + X_WORDS * x;
+            const uint32_t b = x + 1 < n_exc ? ex[X_WORDS * (x + 1) + X_A] - 1 : n_ops;
+            r[X_B] = b, r[X_NINS] = ins_ord[b] - ins_ord[r[X_A]];
+        }
+        // a SAME run that leaves the path is not a script of this path
+        {
+            uint32_t bad = 0;
+            for (uint32_t k = tid; k < n_ops; k += nt) { const uint32_t o = ops[k]; if (op_type(o) == 0 && ((uint64_t)op_at[k] + op_num(o) - 1 > m || op_num(o) == 0)) bad = 1; }
+            if (team.max_all(bad)) { if (tid == 0) fail(ERR_SCRIPT); team.sync(); return; }
+        }
+        if (tid == 0) h.upd_wk = wk_update_words(n_ops), h.upd_n_ops = n_ops, h.upd_n_exc = n_exc, h.upd_nodes0 = h.n_nodes, h.upd_edges0 = h.n_edges;
+        team.sync();
+        // ---- pass B: the read along the runs of the path it follows (the per-base loop of :486-500 on main-path edges) ----
+        append_runs(n_ops, op_at, run_off, n_run, id);
+        if (failed()) return;
+        // ---- pass C: the excursions ----
+        const bool parallel_exc = h.n_multi == 0 && !(h.dbg_flags & 1u);      // every side node then has one way in: no two excursions can meet
+        const uint32_t nodes_base = h.n_nodes, edges_base = h.n_edges;
+        if (parallel_exc) {
+            uint32_t tot_n = 0, tot_e = 0;
+            for (uint32_t base = 0; base < n_exc; base += nt) {
+                const uint32_t x = base + tid;
+                uint32_t nn = 0, ne = 0;
+                if (x < n_exc) exc_follow(ops, n_ops, op_at, ins_ord, ins_op, app, ex + X_WORDS * x, nn, ne);
+                uint32_t tn, te2;
+                const uint32_t pn_ = team.scan(nn, tn), pe2 = team.scan(ne, te2);
+                if (x < n_exc) { uint32_t *r = ex + X_WORDS * x; r[X_NODE0] = nodes_base + tot_n + pn_, r[X_EDGE0] = edges_base + tot_e + pe2; }
+                tot_n += tn, tot_e += te2;
+            }
+            team.sync();
+            if ((uint64_t)nodes_base + tot_n > h.cap_nodes || (uint64_t)edges_base + tot_e > h.cap_edges) { if (tid == 0) fail(ERR_CAP); team.sync(); return; }
+            exc_create_range(ops, op_at, ins_ord, ins_op, ex, 0, n_exc, nodes_base, tot_n, id);
+            if (tid == 0) h.n_nodes += tot_n, h.live_nodes += tot_n, h.n_edges += tot_e, h.live_edges += tot_e;
+            team.sync();
+        } else {
+            // in the reference's order, one excursion at a time (a side node with two ways in may be reached by two of them)
+            for (uint32_t x = 0; x < n_exc; ++x) {
+                uint32_t nn = 0, ne = 0;
+                uint32_t *r = ex + X_WORDS * x;
+                if (tid == 0) {
+                    exc_follow(ops, n_ops, op_at, ins_ord, ins_op, app, r, nn, ne);
+                    r[X_NODE0] = h.n_nodes, r[X_EDGE0] = h.n_edges;
+                    if ((uint64_t)h.n_nodes + nn > h.cap_nodes || (uint64_t)h.n_edges + ne > h.cap_edges) fail(ERR_CAP);
+                }
+                team.sync();
+                if (failed()) return;
+                nn = team.bcast(nn), ne = team.bcast(ne);
+                exc_create_range(ops, op_at, ins_ord, ins_op, ex, x, x + 1, r[X_NODE0], nn, id);
+                if (tid == 0) h.n_nodes += nn, h.live_nodes += nn, h.n_edges += ne, h.live_edges += ne, ++h.st_seq_exc;
+                team.sync();
+            }
+        }
+        if (failed()) return;
+        // ---- pass D: the read on the existing side and junction edges it follows ----
+        append_listed(app, n_ops + 1, id, !parallel_exc);
+        // ---- the read's first node (`initialNode`) ----
+        if (tid == 0) {
+            uint32_t ini = NIL;
+            if (n_ops && op_type(ops[0]) == 0) ini = path_node(op_at[0]);
+            else if (n_exc) {
+                const uint32_t *r = ex;                                     // excursion 0 starts at op 0 without a node to start from
+                if (r[X_NINS]) ini = r[X_NODE0];
+                else if (r[X_B] < n_ops) ini = path_node(op_at[r[X_B]]);
+            }
+            h.initial = ini;
+        }
+        team.sync();
+    }
+
+    // pass B
+    DG_HD void append_runs(uint32_t n_ops, const uint32_t *op_at, const uint32_t *run_off, uint32_t n_run, uint32_t id)
+    {
+        Hdr &h = *g.h;
+        const uint32_t tid = team.tid(), nt = team.size();
+        uint32_t chunks_base = h.n_chunks;
+        for (uint32_t base = 0; base < n_run; base += nt) {
+            const uint32_t t = base + tid;
+            uint32_t e = NIL, need = 0;
+            if (t < n_run) {
+                // the op whose run holds item t: run_off[lo] <= t < run_off[hi]   (run_off[n_ops] = n_run)
+                uint32_t lo = 0, hi = n_ops;
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (run_off[mid] <= t) lo = mid; else hi = mid; }
+                e = g.pe[h.path_off + op_at[lo] + (t - run_off[lo])];
+                need = append_needs_chunk(g.edges[e].count) ? 1u : 0u;
+            }
+            uint32_t tot;
+            const uint32_t p = team.scan(need, tot);
+            if ((uint64_t)chunks_base + tot > h.cap_chunks) { if (tid == 0) fail(ERR_CAP); team.sync(); return; }
+            if (t < n_run) append_id(e, id, need ? chunks_base + p : NIL);
+            chunks_base += tot;
+        }
+        team.sync();
+        if (tid == 0) h.n_chunks = chunks_base;
+        team.sync();
+    }
+    // pass D (in order on one thread when two excursions may share an edge)
+    DG_HD void append_listed(const uint32_t *app, uint32_t n, uint32_t id, bool sequential)
+    {
+        Hdr &h = *g.h;
+        const uint32_t tid = team.tid(), nt = team.size();
+        if (sequential) {
+            if (tid == 0) for (uint32_t k = 0; k < n; ++k) if (app[k] != NIL) add_read_seq(app[k], id);
+            team.sync();
+            return;
+        }
+        uint32_t chunks_base = h.n_chunks;
+        for (uint32_t base = 0; base < n; base += nt) {
+            const uint32_t k = base + tid;
+            const uint32_t e = k < n ? app[k] : NIL;
+            const uint32_t need = e != NIL && append_needs_chunk(g.edges[e].count) ? 1u : 0u;
+            uint32_t tot;
+            const uint32_t p = team.scan(need, tot);
+            if ((uint64_t)chunks_base + tot > h.cap_chunks) { if (tid == 0) fail(ERR_CAP); team.sync(); return; }
+            if (e != NIL) append_id(e, id, need ? chunks_base + p : NIL);
+            chunks_base += tot;
+        }
+        team.sync();
+        if (tid == 0) h.n_chunks = chunks_base;
+        team.sync();
+    }
+
+    // One excursion [a, b): where it starts, how far it follows side edges that exist (insertNode's getEdgeToSide, :454-468), what it
+    // has to create, and the edge on which it comes back to the path (the first base of the SAME behind it, :472-484).
+    // flags: 1 junction edge to create, 2 junction edge exists
+    DG_HD void exc_follow(const uint32_t *ops, uint32_t n_ops, const uint32_t *op_at, const uint32_t *ins_ord, const uint32_t *ins_op, uint32_t *app, uint32_t *r, uint32_t &nn, uint32_t &ne)
+    {
+        const uint32_t a = r[X_A], b = r[X_B], n_ins = r[X_NINS], q0 = ins_ord[a];
+        // the node the excursion leaves from: the last node of the SAME in front of it
+        uint32_t cur = NIL;
+        if (a > 0) { const uint32_t o = ops[a - 1]; cur = path_node(op_at[a - 1] + op_num(o) - 1); }
+        uint32_t k0 = 0;
+        if (cur != NIL)
+            for (; k0 < n_ins; ++k0) {
+                const uint32_t k = ins_op[q0 + k0];
+                const uint32_t e = edge_to_side(cur, op_base(ops[k]));
+                if (e == NIL) break;
+                app[k] = e;
+                cur = g.edges[e].sink;
+            }
+        nn = n_ins - k0;
+        ne = nn;
+        if (a == 0 && nn) --ne;                       // the read's first node has no edge in
+        uint32_t fl = 0;
+        r[X_CUR] = cur, r[X_K0] = k0;
+        // the junction (b is a SAME op unless the script ends here)
+        if (b < n_ops) {
+            const uint32_t target = path_node(op_at[b]);
+            if (nn) fl = 1, ++ne;
+            else if (cur != NIL) {
+                const uint32_t e = edge_to(cur, target);
+                if (e != NIL) { app[b] = e; fl = 2; } else fl = 1, ++ne;
+            }
+        }
+        r[X_FLAGS] = fl;
+    }
+
+    // creates what the excursions [x0, x1) have to create: lanes over the new nodes (each with its edge in), then over the excursions
+    // (the way out of the node the follow ended at, the junction edge).  New edges of an excursion: [edges into its new nodes][junction].
+    DG_HD void exc_create_range(const uint32_t *ops, const uint32_t *op_at, const uint32_t *ins_ord, const uint32_t *ins_op, uint32_t *ex, uint32_t x0, uint32_t x1,
+                                uint32_t nodes_base, uint32_t tot_n, uint32_t id)
+    {
+        const uint32_t tid = team.tid(), nt = team.size();
+        for (uint32_t t = tid; t < tot_n; t += nt) {
+            const uint32_t nid = nodes_base + t;
+            // the excursion that owns node nid: the last x with NODE0 <= nid (those that create nothing share NODE0 with the next that does)
+            uint32_t lo = x0, hi = x1;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ex[X_WORDS * mid + X_NODE0] <= nid) lo = mid; else hi = mid; }
+            const uint32_t *r = ex + X_WORDS * lo;
+            const uint32_t a = r[X_A], b = r[X_B], k0 = r[X_K0], nn = r[X_NINS] - k0, j = nid - r[X_NODE0];
+            const uint32_t q = ins_ord[a] + k0 + j;                         // this node's INSERT
+            const uint32_t base = op_base(ops[ins_op[q]]);
+            const bool first_has_in = r[X_CUR] != NIL;
+            const uint32_t e0 = r[X_EDGE0];
+            const uint32_t e_in = first_has_in ? e0 + j : (j ? e0 + j - 1 : NIL);
+            const uint32_t n_in_edges = first_has_in ? nn : nn - 1;
+            Node &nd = g.nodes[nid];
+            nd.out_ext = nd.in_ext = NIL, nd.base = (uint8_t)base, nd.on_main = 0;
+            g.mark[nid] = 0;
+            nd.n_in = e_in != NIL ? 1 : 0;
+            if (e_in != NIL) nd.in[0] = e_in;
+            if (j + 1 < nn) nd.n_out = 1, nd.out[0] = (first_has_in ? e0 + j + 1 : e0 + j) | (code_of(op_base(ops[ins_op[q + 1]])) << 29);
+            else if (r[X_FLAGS] & 1u) nd.n_out = 1, nd.out[0] = (e0 + n_in_edges) | (code_of(g.nodes[path_node(op_at[b])].base) << 29);
+            else nd.n_out = 0;
+            if (e_in != NIL) { Edge &e = g.edges[e_in]; e.src = j ? nid - 1 : r[X_CUR], e.sink = nid, e.count = 1, e.head = e.tail = NIL, e.ids[0] = id; }
+        }
+        team.sync();
+        for (uint32_t x = x0 + tid; x < x1; x += nt) {
+            const uint32_t *r = ex + X_WORDS * x;
+            const uint32_t a = r[X_A], b = r[X_B], k0 = r[X_K0], nn = r[X_NINS] - k0;
+            const bool first_has_in = r[X_CUR] != NIL;
+            const uint32_t e0 = r[X_EDGE0];
+            const uint32_t n_in_edges = nn ? (first_has_in ? nn : nn - 1) : 0;
+            if (nn && first_has_in) out_push(r[X_CUR], e0 | (code_of(op_base(ops[ins_op[ins_ord[a] + k0]])) << 29));     // the node the follow ended at gets its one new way out
+            if (r[X_FLAGS] & 1u) {
+                const uint32_t target = path_node(op_at[b]), je = e0 + n_in_edges;
+                Edge &e = g.edges[je];
+                e.src = nn ? r[X_NODE0] + nn - 1 : r[X_CUR], e.sink = target, e.count = 1, e.head = e.tail = NIL, e.ids[0] = id;
+                if (!nn) out_push(r[X_CUR], je | (code_of(g.nodes[target].base) << 29));
+                in_push(target, je);              // (a main-path node is the target of at most one junction per read)
+            }
+        }
+        team.sync();
+    }
+
+    // ================================================================================================================
+    // calculateMainPathGreedy (:559-615) with clearMainPath (:617-651) and removeCycles behind it
+    // ================================================================================================================
+    // The reference drops the path right of rightMostUnchangedNode and left of leftMostUnchangedNode and walks both parts again, one
+    // getBestEdgeOut / getBestEdgeIn after the other.  Here every node of the two stretches is asked for its choice at once (lanes over
+    // nodes); where the choice is the path's old edge the walk would have taken it, so only the nodes that choose differently are
+    // followed step by step (thread 0) until the walk is back on the old path -- through nodes this very update created in whole
+    // chains, whose ids are consecutive and whose choice is forced (one edge in, one edge out).
+    // piece: kind, a, b, c, offset (5 words); gap of by-passed old nodes: lo, hi, offset (3 words)
+    DG_HD uint32_t flat_find(const uint32_t *recs, uint32_t stride, uint32_t off_word, uint32_t n, uint32_t t) const
+    {
+        uint32_t lo = 0, hi = n;                 // recs[lo].off <= t < recs[hi].off
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (recs[stride * mid + off_word] <= t) lo = mid; else hi = mid; }
+        return lo;
+    }
+    // first position where a and b differ, at most n (all threads get the result)
+    DG_HD uint32_t lcp(const uint8_t *a, const uint8_t *b, uint32_t n)
+    {
+        const uint32_t tid = team.tid(), nt = team.size();
+        for (uint32_t base = 0; base < n; base += nt * 16) {
+            uint32_t first = NIL;
+            const uint32_t lo = base + tid * 16, hi = lo + 16 < n ? lo + 16 : n;
+            for (uint32_t i = lo; i < hi; ++i) if (a[i] != b[i]) { first = i; break; }
+            first = team.min_all(first);
+            if (first != NIL) return first;
+        }
+        return n;
+    }
+    // number of equal bytes at the ends of a[0 .. n) and b[0 .. n) read backwards from a_end / b_end (exclusive ends)
+    DG_HD uint32_t lcs(const uint8_t *a_end, const uint8_t *b_end, uint32_t n)
+    {
+        const uint32_t tid = team.tid(), nt = team.size();
+        for (uint32_t base = 0; base < n; base += nt * 16) {
+            uint32_t first = NIL;
+            const uint32_t lo = base + tid * 16, hi = lo + 16 < n ? lo + 16 : n;
+            for (uint32_t i = lo; i < hi; ++i) if (a_end[-(ptrdiff_t)i - 1] != b_end[-(ptrdiff_t)i - 1]) { first = i; break; }
+            first = team.min_all(first);
+            if (first != NIL) return first;
+        }
+        return n;
+    }
+
+    struct Stitch { uint32_t *pc; uint32_t cap_pc, n_pc, len; uint32_t *gp; uint32_t cap_gp, n_gp, gap_len; bool ended; };
+    DG_HD void emit_piece(Stitch &S, uint32_t kind, uint32_t a, uint32_t b, uint32_t c, uint32_t l)
+    {
+        if (S.n_pc >= S.cap_pc) { fail(ERR_SCRATCH); return; }
+        uint32_t *p = S.pc + 5 * S.n_pc++;
+        p[0] = kind, p[1] = a, p[2] = b, p[3] = c, p[4] = S.len;
+        S.len += l;
+    }
+    DG_HD void emit_gap(Stitch &S, uint32_t lo, uint32_t hi)
+    {
+        if (lo >= hi) return;
+        if (S.n_gp >= S.cap_gp) { fail(ERR_SCRATCH); return; }
+        uint32_t *p = S.gp + 3 * S.n_gp++;
+        p[0] = lo, p[1] = hi, p[2] = S.gap_len;
+        S.gap_len += hi - lo;
+    }
+    // the excursion of this update that created edge e
+    DG_HD const uint32_t *exc_of_edge(uint32_t e) const
+    {
+        const Hdr &h = *g.h;
+        const uint32_t n_ops = h.upd_n_ops;
+        const uint32_t *ex = g.wk + 6 * (n_ops + 1);
+        uint32_t lo = 0, hi = h.upd_n_exc;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ex[X_WORDS * mid + X_EDGE0] <= e) lo = mid; else hi = mid; }
+        return ex + X_WORDS * lo;
+    }
+    DG_HD const uint32_t *upd_ops() const { return g.wk; }
+    DG_HD const uint32_t *upd_op_at() const { return g.wk + (g.h->upd_n_ops + 1); }
+
+    // thread 0: the walk from old node R to the right.  D: (index, chosen edge) of the old nodes in [R, m] whose choice is not the path's edge, ascending.
+    DG_HD void stitch_forward(Stitch &S, const uint32_t *D, uint32_t n_dis, uint32_t R, uint32_t m, uint32_t off)
+    {
+        Hdr &h = *g.h;
+        uint32_t pos = R;
+        for (uint32_t q = 0; q < n_dis && !S.ended && !failed(); ++q) {
+            const uint32_t c = D[2 * q];
+            uint32_t e = D[2 * q + 1];
+            if (c < pos) continue;                              // by-passed by an earlier detour
+            if (c > pos) emit_piece(S, PC_OLD, pos, c, 0, c - pos);
+            pos = c;
+            ++h.st_detours;
+            for (;;) {
+                if (e == NIL) { S.ended = true; emit_gap(S, pos + 1, m + 1); break; }
+                if (e >= h.upd_edges0) {                        // created by this update: a chain whose choices are forced
+                    const uint32_t *r = exc_of_edge(e);
+                    const uint32_t nn = r[X_NINS] - r[X_K0], e0 = r[X_EDGE0];
+                    const bool first_has_in = r[X_CUR] != NIL;
+                    const uint32_t n_in_edges = nn ? (first_has_in ? nn : nn - 1) : 0;
+                    if (e < e0 + n_in_edges) {
+                        const uint32_t t = e - e0, cnt = n_in_edges - t;
+                        emit_piece(S, PC_CHAIN, e, cnt, r[X_NODE0] + (first_has_in ? t : t + 1), cnt);
+                        h.st_walked += cnt;
+                        e = (r[X_FLAGS] & 1u) ? e0 + n_in_edges : NIL;
+                        continue;
+                    }
+                    const uint32_t j = upd_op_at()[r[X_B]];        // the junction: back on the path at this index
+                    emit_piece(S, PC_EDGE, e, 1, g.edges[e].sink, 1);
+                    if (j <= pos || j > m || g.sv_n[off + j] != g.edges[e].sink) { fail(ERR_WALK); break; }
+                    emit_gap(S, pos + 1, j);
+                    pos = j;
+                    break;
+                }
+                const uint32_t nx = g.edges[e].sink;
+                const uint32_t was_on = g.nodes[nx].on_main;
+                emit_piece(S, PC_EDGE, e, was_on, nx, 1);
+                ++h.st_walked;
+                if (was_on) {
+                    uint32_t j = pos + 1;
+                    while (j <= m && g.sv_n[off + j] != nx) ++j;
+                    if (j > m) { fail(ERR_WALK); break; }
+                    emit_gap(S, pos + 1, j);
+                    pos = j;
+                    break;
+                }
+                e = best_out(nx);
+                if (failed()) break;
+            }
+        }
+        if (!S.ended && !failed() && pos < m) emit_piece(S, PC_OLD, pos, m, 0, m - pos);
+    }
+    // thread 0: the walk from old node Lf to the left.  D: (index, chosen edge in) of the old nodes in [0, Lf] whose choice is not the path's edge, descending.
+    // Pieces in walk order (right to left): OLD (a, b) = old edges b-1 down to a; EDGE c = the edge's source; CHAIN = edges a, a-1, ..., sources c, c-1, ...
+    DG_HD void stitch_backward(Stitch &S, const uint32_t *D, uint32_t n_dis, uint32_t Lf, uint32_t off)
+    {
+        Hdr &h = *g.h;
+        uint32_t pos = Lf;
+        for (uint32_t q = 0; q < n_dis && !S.ended && !failed(); ++q) {
+            const uint32_t c = D[2 * q];
+            uint32_t e = D[2 * q + 1];
+            if (c > pos) continue;
+            if (c < pos) emit_piece(S, PC_OLD, c, pos, 0, pos - c);
+            pos = c;
+            ++h.st_detours;
+            for (;;) {
+                if (e == NIL) { S.ended = true; emit_gap(S, 0, pos); break; }
+                uint32_t nx = NIL, known_idx = NIL;
+                if (e >= h.upd_edges0) {
+                    const uint32_t *r = exc_of_edge(e);
+                    const uint32_t nn = r[X_NINS] - r[X_K0], e0 = r[X_EDGE0];
+                    const bool first_has_in = r[X_CUR] != NIL;
+                    const uint32_t n_in_edges = nn ? (first_has_in ? nn : nn - 1) : 0;
+                    if (e == e0 + n_in_edges && nn) {           // the junction edge out of the excursion's last new node
+                        emit_piece(S, PC_EDGE, e, 0, r[X_NODE0] + nn - 1, 1);
+                        ++h.st_walked;
+                        e = n_in_edges ? e0 + n_in_edges - 1 : NIL;     // that node's one edge in (none: the read, and the path, start there)
+                        continue;
+                    }
+                    if (e < e0 + n_in_edges) {                  // an edge into new node j: back along the chain
+                        const uint32_t t = e - e0;
+                        if (first_has_in) {
+                            if (t) { emit_piece(S, PC_CHAIN, e, t, r[X_NODE0] + t - 1, t); h.st_walked += t; }
+                            e = e0;                              // the edge from the node the follow ended at: an ordinary step below
+                        } else {
+                            emit_piece(S, PC_CHAIN, e, t + 1, r[X_NODE0] + t, t + 1);
+                            h.st_walked += t + 1;
+                            e = NIL;
+                            continue;
+                        }
+                    }
+                    nx = r[X_CUR];                               // (junction straight from an old node, or the chain's first edge)
+                    if (r[X_K0] == 0 && r[X_A] > 0) known_idx = upd_op_at()[r[X_A] - 1] + op_num(upd_ops()[r[X_A] - 1]) - 1;
+                } else nx = g.edges[e].src;
+                const uint32_t was_on = g.nodes[nx].on_main;
+                emit_piece(S, PC_EDGE, e, was_on, nx, 1);
+                ++h.st_walked;
+                if (was_on) {
+                    uint32_t j = known_idx;
+                    if (j == NIL) { j = pos; while (j > 0 && g.sv_n[off + j - 1] != nx) --j; j = j > 0 ? j - 1 : NIL; }
+                    if (j == NIL || j >= pos || g.sv_n[off + j] != nx) { fail(ERR_WALK); break; }
+                    emit_gap(S, j + 1, pos);
+                    pos = j;
+                    break;
+                }
+                e = best_in(nx);
+                if (failed()) break;
+            }
+        }
+        if (!S.ended && !failed() && pos > 0) emit_piece(S, PC_OLD, 0, pos, 0, pos);
+    }
+
+    // by-passed old nodes leave the path (they become side nodes: one with several edges in is work for removeCycles), the nodes of
+    // the detours join it.  Gaps: lanes over nodes; single detour nodes: thread 0.
+    DG_HD void apply_flags(const Stitch &S, uint32_t off)
+    {
+        Hdr &h = *g.h;
+        const uint32_t tid = team.tid(), nt = team.size();
+        for (uint32_t base = 0; base < S.gap_len; base += nt) {
+            const uint32_t t = base + tid;
+            uint32_t n = NIL, became = 0;
+            if (t < S.gap_len) {
+                const uint32_t *p = S.gp + 3 * flat_find(S.gp, 3, 2, S.n_gp, t);
+                n = g.sv_n[off + p[0] + (t - p[2])];
+                g.nodes[n].on_main = 0;
+                became = g.nodes[n].n_in > 1 ? 1u : 0u;
+            }
+            uint32_t tot;
+            const uint32_t w = team.scan(became, tot);
+            if (became) { const uint32_t at = h.multi_n + w; if (at < h.cap_multi) g.multi_list[at] = n; }
+            team.sync();
+            if (tid == 0) { h.n_multi += tot; h.multi_n = h.multi_n + tot <= h.cap_multi ? h.multi_n + tot : h.cap_multi + 1; }
+            team.sync();
+        }
+        // (the nodes of chains were put on the path where the new stretch was written: main_path)
+        if (tid == 0)
+            for (uint32_t i = 0; i < S.n_pc; ++i) { const uint32_t *p = S.pc + 5 * i; if (p[0] == PC_EDGE && !p[2]) set_on_main(p[3], true); }
+        team.sync();
+    }
+
+    DG_HD void main_path()
+    {
+        Hdr &h = *g.h;
+        const uint32_t tid = team.tid(), nt = team.size();
+        const uint32_t m = h.m, R = h.right_off, Lf = h.left_off, off = h.path_off;
+        if (tid == 0) h.stage = 2;
+        if (Lf > R || R > m || h.upd_wk + 4096 > h.cap_wk) { if (tid == 0) fail(Lf > R || R > m ? ERR_WALK : ERR_SCRATCH); team.sync(); return; }
+        // ---- the path as it was, where the walks go over it again ----
+        for (uint32_t i = tid; i <= Lf; i += nt) { g.sv_n[off + i] = g.pn[off + i], g.sv_s[off + i] = g.ps[off + i]; if (i < Lf) g.sv_e[off + i] = g.pe[off + i]; }
+        for (uint32_t i = R + tid; i <= m; i += nt) { g.sv_n[off + i] = g.pn[off + i], g.sv_s[off + i] = g.ps[off + i]; if (i < m) g.sv_e[off + i] = g.pe[off + i]; }
+        team.sync();
+        uint32_t *W = g.wk + h.upd_wk;
+        const uint32_t wcap = h.cap_wk - h.upd_wk;
+        uint32_t *D = W;                                     // disagreements, 2 words each
+        const uint32_t cap_d = wcap / 4;                     // entries
+        Stitch F, B;
+        F.pc = W + wcap / 2, F.cap_pc = wcap / 8 / 5, F.gp = F.pc + wcap / 8, F.cap_gp = wcap / 16 / 3;
+        B.pc = F.gp + wcap / 16, B.cap_pc = wcap / 8 / 5, B.gp = B.pc + wcap / 8, B.cap_gp = wcap / 16 / 3;
+        F.n_pc = F.len = F.n_gp = F.gap_len = 0, F.ended = false;
+        B.n_pc = B.len = B.n_gp = B.gap_len = 0, B.ended = false;
+        // ---- to the right of old node R ----
+        uint32_t n_dis = 0;
+        for (uint32_t base = R; base <= m; base += nt) {
+            const uint32_t i = base + tid;
+            uint32_t d = 0, ch = NIL;
+            if (i <= m) { ch = best_out(g.sv_n[off + i]); d = ch != (i < m ? g.sv_e[off + i] : NIL) ? 1u : 0u; }
+            uint32_t tot;
+            const uint32_t p = team.scan(d, tot);
+            if (d && n_dis + p < cap_d) D[2 * (n_dis + p)] = i, D[2 * (n_dis + p) + 1] = ch;
+            n_dis += tot;
+        }
+        team.sync();
+        if (n_dis > cap_d) { if (tid == 0) fail(ERR_SCRATCH); team.sync(); return; }
+        if (tid == 0) { h.st_dis += n_dis; stitch_forward(F, D, n_dis, R, m, off); }
+        team.sync();
+        if (failed()) return;
+        F.n_pc = team.bcast(F.n_pc), F.len = team.bcast(F.len), F.n_gp = team.bcast(F.n_gp), F.gap_len = team.bcast(F.gap_len), F.ended = team.bcast(F.ended ? 1u : 0u) != 0;
+        // ---- to the left of old node Lf ----
+        n_dis = 0;
+        for (uint32_t base = 0; base <= Lf; base += nt) {
+            const uint32_t k = base + tid;
+            uint32_t d = 0, ch = NIL, i = 0;
+            if (k <= Lf) { i = Lf - k; ch = best_in(g.sv_n[off + i]); d = ch != (i > 0 ? g.sv_e[off + i - 1] : NIL) ? 1u : 0u; }
+            uint32_t tot;
+            const uint32_t p = team.scan(d, tot);
+            if (d && n_dis + p < cap_d) D[2 * (n_dis + p)] = i, D[2 * (n_dis + p) + 1] = ch;
+            n_dis += tot;
+        }
+        team.sync();
+        if (n_dis > cap_d) { if (tid == 0) fail(ERR_SCRATCH); team.sync(); return; }
+        if (tid == 0) { h.st_dis += n_dis; stitch_backward(B, D, n_dis, Lf, off); }
+        team.sync();
+        if (failed()) return;
+        B.n_pc = team.bcast(B.n_pc), B.len = team.bcast(B.len), B.n_gp = team.bcast(B.n_gp), B.gap_len = team.bcast(B.gap_len), B.ended = team.bcast(B.ended ? 1u : 0u) != 0;
+        const uint32_t la = B.len, lenF = F.len;
+        if (off + Lf < la || (uint64_t)off + R + lenF + 1 > h.cap_path) { if (tid == 0) fail(ERR_CAP); team.sync(); return; }
+        if (tid == 0) h.stage = 3;
+        // ---- the new stretches in place (the kept part [Lf, R] does not move in memory) ----
+        for (uint32_t t = tid; t < lenF; t += nt) {
+            const uint32_t *p = F.pc + 5 * flat_find(F.pc, 5, 4, F.n_pc, t);
+            const uint32_t u = t - p[4], at = off + R + t;
+            uint32_t e, n;
+            uint8_t b;
+            if (p[0] == PC_OLD) e = g.sv_e[off + p[1] + u], n = g.sv_n[off + p[1] + u + 1], b = g.sv_s[off + p[1] + u + 1];
+            else if (p[0] == PC_EDGE) e = p[1], n = p[3], b = g.nodes[n].base;
+            else { e = p[1] + u, n = p[3] + u, b = g.nodes[n].base; g.nodes[n].on_main = 1; }
+            g.pe[at] = e, g.pn[at + 1] = n, g.ps[at + 1] = b;
+        }
+        const uint32_t off2 = off + Lf - la;
+        for (uint32_t t = tid; t < la; t += nt) {
+            const uint32_t *p = B.pc + 5 * flat_find(B.pc, 5, 4, B.n_pc, t);
+            const uint32_t u = t - p[4], at = off + Lf - 1 - t;            // the t-th edge of the walk; its source is the node in front of it
+            uint32_t e, n;
+            uint8_t b;
+            if (p[0] == PC_OLD) e = g.sv_e[off + p[2] - 1 - u], n = g.sv_n[off + p[2] - 1 - u], b = g.sv_s[off + p[2] - 1 - u];
+            else if (p[0] == PC_EDGE) e = p[1], n = p[3], b = g.nodes[n].base;
+            else { e = p[1] - u, n = p[3] - u, b = g.nodes[n].base; g.nodes[n].on_main = 1; }
+            g.pe[at] = e, g.pn[at] = n, g.ps[at] = b;
+        }
+        team.sync();
+        apply_flags(F, off);
+        apply_flags(B, off);
+        const uint32_t m2 = la + (R - Lf) + lenF;
+        if (tid == 0) {
+            h.path_off = off2, h.m = m2;
+            h.right_off = la + (R - Lf), h.left_off = la;
+            h.ending_id = edge_min_id(g.edges[g.pe[off2 + m2 - 1]]);
+            h.starting_id = edge_min_id(g.edges[g.pe[off2]]);
+        }
+        team.sync();
+        // ---- what the consensus kept: P bases in front, S at the end (any valid pair will do for the caller; these are the obvious ones) ----
+        {
+            const uint32_t Lo = m + 1, Ln = m2 + 1;
+            uint32_t P, S;
+            const uint32_t fa = la < Lf ? la : Lf;                       // front stretches: old [0, Lf), new [0, la)
+            uint32_t pa = fa ? lcp(g.sv_s + off, g.ps + off2, fa) : 0;
+            const uint32_t nf = lenF < m - R ? lenF : m - R;             // back stretches: old (R, m], new (R', m2]
+            if (la == Lf && pa == fa) {
+                const uint32_t pf = nf ? lcp(g.sv_s + off + R + 1, g.ps + off + R + 1, nf) : 0;
+                P = R + 1 + pf;
+            } else P = pa;
+            const uint32_t sf = nf ? lcs(g.sv_s + off + m + 1, g.ps + off2 + m2 + 1, nf) : 0;
+            if (lenF == m - R && sf == nf) {
+                const uint32_t sa = fa ? lcs(g.sv_s + off + Lf, g.ps + off2 + la, fa) : 0;
+                S = nf + (R - Lf + 1) + sa;
+            } else S = sf;
+            const uint32_t mn = Lo < Ln ? Lo : Ln;
+            if (P > mn) P = mn;
+            if (P + S > mn) S = mn - P;
+            if (tid == 0) h.P = P, h.S = S, h.old_len = Lo, h.new_len = Ln;
+        }
+        team.sync();
+        remove_cycles();
+        if (tid == 0) {
+            h.right_unch = g.pn[h.path_off + h.m], h.right_off = h.m;
+            h.left_unch = g.pn[h.path_off], h.left_off = 0;
+        }
+        team.sync();
+    }
+
+    // ================================================================================================================
+    // removeCycles (:653-691), walkAndPrune (:693-714), splitPath (:716-807)
+    // ================================================================================================================
+    struct CycWk { uint32_t *todo, *roots, *hits, *estack, *ctx, *lists, *copy; uint32_t cap_todo, cap_roots, cap_hits, cap_estack, cap_ctx, cap_lists, cap_copy; };
+    DG_HD CycWk cyc_wk() const
+    {
+        const Hdr &h = *g.h;
+        uint32_t *W = g.wk + h.upd_wk;
+        const uint32_t wcap = h.cap_wk - h.upd_wk, u = wcap / 16;
+        CycWk c;
+        c.todo = W, c.cap_todo = u;
+        c.roots = W + u, c.cap_roots = u;
+        c.hits = W + 2 * u, c.cap_hits = u;                 // pairs
+        c.estack = W + 4 * u, c.cap_estack = 2 * u;
+        c.ctx = W + 6 * u, c.cap_ctx = 4 * u / 8;          // 8 words each
+        c.lists = W + 10 * u, c.cap_lists = 4 * u;
+        c.copy = W + 14 * u, c.cap_copy = 2 * u;
+        return c;
+    }
+
+    // Gives the reads of edge e0 (a side branch entering a node that has other ways in) a private copy of everything downstream until
+    // the main path is reached again.  The reference's two-visit context stack, iteratively; read lists live in the work area.
+    // ctx: new_pre, e, in_off, in_n, own_off, own_n, visited, old_cur
+    DG_HD void split_path(const CycWk &K, uint32_t new_pre0, uint32_t e0)
+    {
+        Hdr &h = *g.h;
+        ++h.st_splits;
+        uint32_t lists_top = 0, n_ctx = 0;
+        if (g.edges[e0].count > K.cap_lists) { fail(ERR_SCRATCH); return; }
+        lists_top = ids_copy(g.edges[e0], K.lists);          // (a copy: e0's list dies with e0 during the first visit)
+        {
+            uint32_t *c = K.ctx;
+            c[0] = new_pre0, c[1] = e0, c[2] = 0, c[3] = lists_top, c[4] = 0, c[5] = 0, c[6] = 0, c[7] = NIL;
+            n_ctx = 1;
+        }
+        while (n_ctx && !failed()) {
+            uint32_t *c = K.ctx + 8 * (n_ctx - 1);
+            if (c[6]) {
+                const uint32_t oc = c[7];
+                --n_ctx;
+                if (oc != NIL && g.nodes[oc].n_in == 0 && g.nodes[oc].n_out == 0) remove_node(oc);
+                continue;
+            }
+            // the reads of this branch that go down edge c[1]
+            const Edge &ed = g.edges[c[1]];
+            const uint32_t own_off = lists_top;
+            uint32_t own_n = 0;
+            for (uint32_t i = 0; i < c[3]; ++i) {
+                const uint32_t id = K.lists[c[2] + i];
+                if (ed.src != NIL && edge_has(ed, id)) { if (own_off + own_n >= K.cap_lists) { fail(ERR_SCRATCH); return; } K.lists[own_off + own_n++] = id; }
+            }
+            lists_top += own_n;
+            c[4] = own_off, c[5] = own_n, c[6] = 1;
+            if (!own_n) continue;
+            const uint32_t old_cur = ed.sink;
+            c[7] = old_cur;
+            const uint32_t new_pre = c[0];
+            remove_reads_from_edge(c[1], K.lists + own_off, own_n);
+            if (g.nodes[old_cur].on_main) { new_edge(new_pre, old_cur, K.lists + own_off, own_n); continue; }
+            const uint32_t new_cur = new_node(g.nodes[old_cur].base);
+            new_edge(new_pre, new_cur, K.lists + own_off, own_n);
+            const Node &oc = g.nodes[old_cur];
+            const uint32_t no = oc.n_out;
+            if (8 * (n_ctx + no) > K.cap_ctx * 8) { fail(ERR_SCRATCH); return; }
+            for (uint32_t i = 0; i < no; ++i) {
+                uint32_t *d = K.ctx + 8 * n_ctx++;
+                d[0] = new_cur, d[1] = out_ref(oc, i) & kRefMask, d[2] = own_off, d[3] = own_n, d[4] = 0, d[5] = 0, d[6] = 0, d[7] = NIL;
+            }
+        }
+    }
+    DG_HD void walk_and_prune(const CycWk &K, uint32_t e0, bool marked_only)
+    {
+        const Hdr &h = *g.h;
+        uint32_t n = 0;
+        K.estack[n++] = e0;
+        while (n && !failed()) {
+            const uint32_t curr = K.estack[--n];
+            const uint32_t sink = g.edges[curr].sink, source = g.edges[curr].src;
+            if (sink == NIL) continue;                           // (an edge a split before this one took away)
+            if (g.nodes[sink].on_main) continue;
+            if (marked_only && g.mark[sink] != h.epoch) continue;     // nothing below an unmarked node can be split
+            if (g.nodes[sink].n_in > 1) split_path(K, source, curr);
+            const Node &s = g.nodes[sink];
+            if (n + s.n_out > K.cap_estack) { fail(ERR_SCRATCH); return; }
+            for (uint32_t i = 0; i < s.n_out; ++i) K.estack[n++] = out_ref(s, i) & kRefMask;
+        }
+    }
+    DG_HD void run_node(const CycWk &K, uint32_t n, bool marked_only)
+    {
+        const Node &x = g.nodes[n];
+        const uint32_t no = x.n_out;
+        if (no > K.cap_copy) { fail(ERR_SCRATCH); return; }
+        for (uint32_t i = 0; i < no; ++i) K.copy[i] = out_ref(x, i) & kRefMask;      // a copy: the walk edits the node's list
+        for (uint32_t i = 0; i < no && !failed(); ++i) walk_and_prune(K, K.copy[i], marked_only);
+    }
+
+    // removeCycles.  The reference walks every side branch of the two stretches just re-walked and splits at every side edge whose sink
+    // has another way in.  The nodes with that property are known (multi_list: every node that became one was noted); every edge a split
+    // can happen at lies on a way from the path to one of them.  So: mark them and their ancestors (edges in, backwards), find the path
+    // nodes the marked branches hang off (lanes over the path's node array), and run the reference's walk from those nodes only, in
+    // its order, descending only into marked nodes.  When the list does not account for every such node the reference's full walk runs.
+    DG_HD void remove_cycles()
+    {
+        Hdr &h = *g.h;
+        const uint32_t tid = team.tid(), nt = team.size();
+        if (h.n_multi == 0) { if (tid == 0) h.multi_n = 0; team.sync(); return; }
+        const CycWk K = cyc_wk();
+        uint32_t mode = 0, n_roots = 0;                        // 0 nothing to do, 1 from the list, 2 the full walk
+        if (tid == 0) {
+            ++h.st_cycles_run;
+            ++h.epoch;
+            mode = 1;
+            if (h.epoch == 0 || h.multi_n > h.cap_multi || (h.dbg_flags & 2u)) { mode = 2; if (h.epoch == 0) h.epoch = 1; }
+            if (mode == 1) {
+                uint32_t k = 0;
+                for (uint32_t i = 0; i < h.multi_n; ++i) { const uint32_t n = g.multi_list[i]; if (multi_in_side(n) && g.mark[n] != h.epoch) { g.mark[n] = h.epoch; g.multi_list[k++] = n; } }
+                h.multi_n = k;
+                if (k != h.n_multi) mode = 2;
+            }
+            if (mode == 1) {
+                uint32_t n_todo = 0;
+                for (uint32_t i = 0; i < h.multi_n && n_todo < K.cap_todo; ++i) K.todo[n_todo++] = g.multi_list[i];
+                if (h.multi_n > K.cap_todo) mode = 2;
+                while (n_todo && mode == 1) {
+                    const uint32_t n = K.todo[--n_todo];
+                    const Node &x = g.nodes[n];
+                    for (uint32_t i = 0; i < x.n_in; ++i) {
+                        const uint32_t s = g.edges[in_ref(x, i)].src;
+                        if (g.mark[s] == h.epoch) continue;
+                        g.mark[s] = h.epoch;
+                        if (g.nodes[s].on_main) { if (n_roots < K.cap_roots) K.roots[n_roots++] = s; else mode = 2; }
+                        else { if (n_todo < K.cap_todo) K.todo[n_todo++] = s; else mode = 2; }
+                    }
+                }
+                if (mode == 1 && n_roots == 0) mode = 0;        // not reachable from the path: the full walk would find nothing either
+            }
+            if (mode == 2) ++h.st_full_walk;
+        }
+        team.sync();
+        mode = team.bcast(mode), n_roots = team.bcast(n_roots);
+        const uint32_t m = h.m, off = h.path_off;
+        if (mode == 1) {
+            // where the roots lie on the path: node indices [0, left_end) and [right_off, m]
+            uint64_t bloom = 0;
+            for (uint32_t i = 0; i < n_roots; ++i) bloom |= 1ull << (K.roots[i] & 63u);
+            const uint32_t left_end = h.left_off < m ? h.left_off + 1 : m;
+            uint32_t lo1 = 0, hi1 = left_end, lo2 = h.right_off, hi2 = m + 1;
+            if (h.right_off < left_end) lo1 = 0, hi1 = m + 1, lo2 = hi2 = 0;
+            uint32_t n_hits = 0;
+            for (int part = 0; part < 2; ++part) {
+                const uint32_t lo = part ? lo2 : lo1, hi = part ? hi2 : hi1;
+                for (uint32_t base = lo; base < hi; base += nt) {
+                    const uint32_t i = base + tid;
+                    uint32_t hit = 0, n = NIL;
+                    if (i < hi) {
+                        n = g.pn[off + i];
+                        if ((bloom >> (n & 63u)) & 1u) for (uint32_t r = 0; r < n_roots; ++r) if (K.roots[r] == n) { hit = 1; break; }
+                    }
+                    uint32_t tot;
+                    const uint32_t p = team.scan(hit, tot);
+                    if (hit && n_hits + p < K.cap_hits / 2) K.hits[2 * (n_hits + p)] = i, K.hits[2 * (n_hits + p) + 1] = n;
+                    n_hits += tot;
+                }
+            }
+            team.sync();
+            if (n_hits > K.cap_hits / 2) { if (tid == 0) fail(ERR_SCRATCH); team.sync(); return; }
+            if (tid == 0) {
+                // first loop of the reference: nodes right_off .. m in path order; second: nodes min(left_off, m - 1) .. 0, backwards
+                for (uint32_t i = 0; i < n_hits && !failed(); ++i) if (K.hits[2 * i] >= h.right_off) run_node(K, K.hits[2 * i + 1], true);
+                const uint32_t l0 = h.left_off < m ? h.left_off : m - 1;
+                for (uint32_t i = n_hits; i-- > 0 && !failed();) if (K.hits[2 * i] <= l0 && K.hits[2 * i] < m) run_node(K, K.hits[2 * i + 1], true);
+            }
+        } else if (mode == 2 && tid == 0) {
+            for (uint32_t i = h.right_off; i <= m && !failed(); ++i) run_node(K, g.pn[off + i], false);
+            for (uint32_t i = (h.left_off < m ? h.left_off : m - 1) + 1; i-- > 0 && !failed();) run_node(K, g.pn[off + i], false);
+            // (what is left are nodes the walks cannot reach; the list starts over with them)
+            if (h.multi_n > h.cap_multi) h.multi_n = 0;
+        }
+        team.sync();
+    }
+};
+
+}  // namespace dg
+}  // namespace nsgpu

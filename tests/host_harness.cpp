@@ -166,6 +166,7 @@ void harness_radix_sort_64(uint64_t *x, int64_t n) { radix_sort_64(x, x + n); }
 #include <string>
 #include <chrono>
 #include "../nanospring_amd/csrc/consensus.hpp"
+#include "../nanospring_amd/csrc/consensus_soa.hpp"
 static double hnow() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 extern "C" {
@@ -208,14 +209,76 @@ static bool harness_align1(const std::string &ref, const std::string &q, int k, 
     return ao.ok != 0;
 }
 
-uint64_t g_dbg_calls = 0, g_dbg_skipped = 0, g_dbg_spliced = 0, g_dbg_spliced_nodes = 0;
+extern uint64_t g_dbg_calls, g_dbg_skipped, g_dbg_spliced, g_dbg_spliced_nodes;
 extern "C" uint64_t harness_dbg(int which) { return which == 0 ? g_dbg_calls : which == 1 ? g_dbg_skipped : which == 2 ? g_dbg_spliced : g_dbg_spliced_nodes; }
 extern "C" {
 
 typedef struct { uint64_t n_contigs, n_lone, count_minhash, count_minhash_not_in_graph, count_aligner, n_align_calls, n_bad_roundtrip, n_graph_check_fail; double update_ms, mainpath_ms, write_ms; } harness_cons_stats;
 
+}  // extern "C"
+
+// NSGPU_HARNESS_GRAPH=both: the pointer graph (consensus.cpp) and the structure-of-arrays graph (dgraph.hpp with a team of one) side by side on every
+// update -- consensus, positions and sizes must agree after each step; the streams come from the SoA graph's emission
+struct ShadowGraph {
+    ContigGraph a;
+    SoaGraph b;
+    ssize_t start_pos = 0, end_pos = 0;
+    std::string main_path;
+    read_t first_read = 0;
+    size_t path_changed_from = 0;
+    uint64_t dbg_cycles_calls = 0, dbg_cycles_skipped = 0, dbg_spliced = 0, dbg_spliced_nodes = 0;
+    static uint64_t &mismatches() { static uint64_t v = 0; return v; }
+    void sync_out(const char *where)
+    {
+        if (a.main_path != b.main_path || a.start_pos != b.start_pos || a.end_pos != b.end_pos || a.num_edges() != b.num_edges() || a.num_nodes() != b.num_nodes()) {
+            if (mismatches()++ < 5) {
+                size_t d = 0; while (d < a.main_path.size() && d < b.main_path.size() && a.main_path[d] == b.main_path[d]) ++d;
+                fprintf(stderr, "SHADOW MISMATCH after %s (read count %zu): path %zu / %zu bases (first difference at %zu), start %zd / %zd, end %zd / %zd, edges %zu / %zu, nodes %zu / %zu\n", where,
+                        a.num_reads(), a.main_path.size(), b.main_path.size(), d, a.start_pos, b.start_pos, a.end_pos, b.end_pos, a.num_edges(), b.num_edges(), a.num_nodes(), b.num_nodes());
+            }
+        }
+        main_path = b.main_path, start_pos = b.start_pos, end_pos = b.end_pos;
+        path_changed_from = std::min(a.path_changed_from, b.path_changed_from);
+    }
+    void initialize(const std::string &seed, read_t id, long pos) { a.main_path.clear(); a.first_read = b.first_read = first_read; a.initialize(seed, id, pos); b.initialize(seed, id, pos); }
+    void update_graph(const std::string &s, const std::vector<nsgpu::mm2::EditOp> &script, ssize_t bo, ssize_t eo, read_t id, long pos, bool rc)
+    {
+        a.update_graph(s, script, bo, eo, id, pos, rc);
+        b.update_graph(s, script, bo, eo, id, pos, rc);
+    }
+    void calculate_main_path_greedy()
+    {
+        a.path_changed_from = b.path_changed_from = path_changed_from;
+        a.calculate_main_path_greedy();
+        b.calculate_main_path_greedy();
+        sync_out("calculate_main_path_greedy");
+    }
+    size_t num_reads() const { return b.num_reads(); }
+    size_t num_edges() const { return b.num_edges(); }
+    void write_main_path(StreamSet &o) const { b.write_main_path(o); }
+    void write_reads(StreamSet &o, const std::function<ReadBases(read_t)> *source = nullptr)
+    {
+        StreamSet oa;
+        a.write_reads(oa, source);
+        StreamSet ob;
+        b.write_reads(ob, source);
+        if (oa.pos != ob.pos || oa.type != ob.type || oa.base != ob.base || oa.complement != ob.complement || oa.id_contigs != ob.id_contigs) { if (mismatches()++ < 5) fprintf(stderr, "SHADOW MISMATCH in the emission of a contig of %zu reads\n", a.num_reads()); }
+        o.append(ob);
+    }
+    void write_read_lone(StreamSet &o) const { o.lone += main_path; o.lone.push_back('\n'); }
+    bool read_string(read_t id, std::string &out) { return b.read_string(id, out); }
+    bool has_cycle() { return b.has_cycle(); }
+};
+template <class GT> struct GraphDbg { static void take(GT &) {} };
+uint64_t g_dbg_calls = 0, g_dbg_skipped = 0, g_dbg_spliced = 0, g_dbg_spliced_nodes = 0;
+uint64_t g_soa_stats[8];
+template <> struct GraphDbg<SoaGraph> { static void take(SoaGraph &g) { const nsgpu::dg::Hdr &h = g.store().hdr; g_soa_stats[0] += h.st_splits, g_soa_stats[1] += h.st_detours, g_soa_stats[2] += h.st_walked, g_soa_stats[3] += h.st_seq_exc, g_soa_stats[4] += h.st_cycles_run, g_soa_stats[5] += h.st_full_walk, g_soa_stats[6] += h.st_dis, g_soa_stats[7] += h.n_nodes - h.live_nodes; } };
+extern "C" uint64_t harness_soa_stat(int i) { return g_soa_stats[i]; }
+template <> struct GraphDbg<ContigGraph> { static void take(ContigGraph &g) { g_dbg_calls += g.dbg_cycles_calls; g_dbg_skipped += g.dbg_cycles_skipped; g_dbg_spliced += g.dbg_spliced; g_dbg_spliced_nodes += g.dbg_spliced_nodes; } };
+
 // streams_out[0..6] = genome, lone, id, pos, type, base, complement; streams_out[7] = metaData (malloc'ed)
-int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32_t k, uint32_t n, uint32_t thr, const uint64_t *salts,
+template <class GT>
+static int harness_consensus_t(const char *bases, const uint64_t *off, uint32_t N, uint32_t k, uint32_t n, uint32_t thr, const uint64_t *salts,
                       int m_k, int m_w, int mci, uint64_t edge_thr, int run_checks, uint8_t **streams_out, uint64_t *lens_out,
                       harness_cons_stats *st, uint32_t id_base)
 {
@@ -244,7 +307,7 @@ int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32
         if (first >= N) break;
         in_graph[first] = 1;
         cursor = first + 1;
-        ContigGraph g;
+        GT g;
         g.main_path = reads[first];
         g.start_pos = 0, g.end_pos = (ssize_t)reads[first].size(), g.first_read = first + id_base;
         const ssize_t init_start = g.start_pos, len = g.end_pos - g.start_pos;
@@ -337,7 +400,7 @@ int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32
             out.reads_in_contig.push_back((read_t)g.num_reads());
         }
         ++st->n_contigs;
-        g_dbg_calls += g.dbg_cycles_calls; g_dbg_skipped += g.dbg_cycles_skipped; g_dbg_spliced += g.dbg_spliced; g_dbg_spliced_nodes += g.dbg_spliced_nodes;
+        GraphDbg<GT>::take(g);
     }
     // round trip through the decoder
     {
@@ -358,6 +421,22 @@ int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32
         lens_out[i] = parts[i].size();
     }
     return 0;
+}
+
+extern "C" {
+int harness_consensus(const char *bases, const uint64_t *off, uint32_t N, uint32_t k, uint32_t n, uint32_t thr, const uint64_t *salts,
+                      int m_k, int m_w, int mci, uint64_t edge_thr, int run_checks, uint8_t **streams_out, uint64_t *lens_out,
+                      harness_cons_stats *st, uint32_t id_base)
+{
+    const char *e = getenv("NSGPU_HARNESS_GRAPH");
+    if (e && !strcmp(e, "soa")) return harness_consensus_t<SoaGraph>(bases, off, N, k, n, thr, salts, m_k, m_w, mci, edge_thr, run_checks, streams_out, lens_out, st, id_base);
+    if (e && !strcmp(e, "both")) {
+        const int rc = harness_consensus_t<ShadowGraph>(bases, off, N, k, n, thr, salts, m_k, m_w, mci, edge_thr, run_checks, streams_out, lens_out, st, id_base);
+        st->n_graph_check_fail += ShadowGraph::mismatches();
+        ShadowGraph::mismatches() = 0;
+        return rc;
+    }
+    return harness_consensus_t<ContigGraph>(bases, off, N, k, n, thr, salts, m_k, m_w, mci, edge_thr, run_checks, streams_out, lens_out, st, id_base);
 }
 
 void harness_free(void *p) { free(p); }

@@ -9,9 +9,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tests", "_build", "libhostharness.so")
 SRCS = [os.path.join(ROOT, "tests", "host_harness.cpp"), os.path.join(ROOT, "nanospring_amd", "csrc", "mm2.cpp"),
-        os.path.join(ROOT, "nanospring_amd", "csrc", "consensus.cpp")]
+        os.path.join(ROOT, "nanospring_amd", "csrc", "consensus.cpp"), os.path.join(ROOT, "nanospring_amd", "csrc", "consensus_soa.cpp")]
 CSRC = [os.path.join(ROOT, "oracle", "ksw2_oracle.c"), os.path.join(ROOT, "oracle", "ns_oracle.c")]
-DEPS = SRCS + CSRC + [os.path.join(ROOT, "nanospring_amd", "csrc", "mm2.hpp"), os.path.join(ROOT, "nanospring_amd", "csrc", "consensus.hpp")]
+DEPS = SRCS + CSRC + [os.path.join(ROOT, "nanospring_amd", "csrc", "mm2.hpp"), os.path.join(ROOT, "nanospring_amd", "csrc", "consensus.hpp"),
+                      os.path.join(ROOT, "nanospring_amd", "csrc", "consensus_soa.hpp"), os.path.join(ROOT, "nanospring_amd", "csrc", "dgraph.hpp")]
 
 
 class HarnessAln(C.Structure):
