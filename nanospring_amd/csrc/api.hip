@@ -277,6 +277,7 @@ void nsgpu_destroy(nsgpu_ctx *c)
     for (DevBuf *b : bufs) b->release();
     c->t_stage.destroy(); c->t_kernel.destroy();
     if (c->cons_engine) c->cons_engine_free(c->cons_engine);
+    if (c->graph_shared) c->graph_shared_free(c->graph_shared);
     for (nsgpu_ctx::SketchWs &w : c->sws) {
         DevBuf *sb[] = {&w.seqs, &w.soff, &w.len, &w.sob, &w.vf, &w.mk, &w.vr, &w.linv, &w.npf, &w.pushf, &w.npr, &w.pr, &w.V, &w.hk, &w.PX, &w.PY, &w.PRUN,
                         &w.PSEQ, &w.rm, &w.nout, &w.oscan, &w.off, &w.out, &w.scan_ws};

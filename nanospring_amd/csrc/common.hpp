@@ -262,6 +262,8 @@ struct nsgpu_ctx {
     bool sched_auto = false, sched_set = false;      // nsgpu_set_schedule_auto / an explicit nsgpu_set_schedule: 0 builders with neither = the automatic schedule
     void *cons_engine = nullptr;                 // resumable contig engine (consensus_driver.hip)
     void (*cons_engine_free)(void *) = nullptr;
+    void *graph_shared = nullptr;                // pools and streams of the consensus graphs in HBM (graph_dev.hpp), made on first use
+    void (*graph_shared_free)(void *) = nullptr;
     uint64_t cons_n_reads_out = 0;               // reads covered by this context's output streams
     nsgpu_consensus_stats cons_stats;
     std::vector<nsgpu::cons::StreamSet> cons_out;

@@ -84,6 +84,22 @@ void debug_report_slots(nsgpu_ctx *c, Engine *E)
 void debug_report_stage(nsgpu_ctx *c, Engine *E, const struct rusage &ru0, double w_begin, double w_slot, double w_seed, double w_claim, double tf)
 {
     fprintf(stderr, "[cons] gpu mm_sketch wall-ms %.0f\n", c->sketch_mm_ms);
+    if (E->D.gsh) {
+        DevGraphShared &G = *E->D.gsh;
+        uint64_t splits = 0, seq = 0;
+        for (const Builder &b : E->D.B) splits += b.dbg_g[0], seq += b.dbg_g[1];
+        fprintf(stderr, "[cons] consensus graphs in HBM: %llu updates in %llu launches%s, %llu array growths, %llu new stretches longer than a report (copied), host waited %.0f ms for kernels in sum; "
+                        "%.2f GB of finished contigs copied back; splitPath calls %llu, excursions taken one at a time %llu; pool: HBM peak %.2f GB of %.2f GB mapped, pinned peak %.2f GB of %.2f GB\n",
+                (unsigned long long)G.n_updates.load(), (unsigned long long)G.n_launches.load(), G.check ? ", every one checked against the host's arrays" : "", (unsigned long long)G.n_grow.load(), (unsigned long long)G.n_mid_copies.load(),
+                G.kernel_wait_ns.load() / 1e6, G.bytes_back.load() / 1e9, (unsigned long long)splits, (unsigned long long)seq, G.dev.peak() / 1e9, G.dev.mapped() / 1e9, G.pin.peak() / 1e9, G.pin.mapped() / 1e9);
+        fprintf(stderr, "[cons] graph kernels, ms in sum by phase (their own clock): tables %.0f, runs %.0f, excursions %.0f, choices %.0f, stitching %.0f, writing %.0f, flags + kept ends %.0f, removeCycles %.0f; launch to report %.0f ms in sum\n",
+                G.phase_ticks[0].load() / 1e5, G.phase_ticks[1].load() / 1e5, G.phase_ticks[2].load() / 1e5, G.phase_ticks[3].load() / 1e5, G.phase_ticks[4].load() / 1e5, G.phase_ticks[5].load() / 1e5,
+                G.phase_ticks[6].load() / 1e5, G.phase_ticks[7].load() / 1e5, G.update_ns.load() / 1e6);
+        fprintf(stderr, "[cons] graph kernels by duration (< 0.25 / 0.5 / 1 / 2 / 4 / 8 / 16 ms / more): %llu %llu %llu %llu %llu %llu %llu %llu; those of 2 ms and more by their longest phase (tables / runs / excursions / choices / stitching / writing / flags / removeCycles): %llu %llu %llu %llu %llu %llu %llu %llu\n",
+                (unsigned long long)G.hist[0].load(), (unsigned long long)G.hist[1].load(), (unsigned long long)G.hist[2].load(), (unsigned long long)G.hist[3].load(), (unsigned long long)G.hist[4].load(), (unsigned long long)G.hist[5].load(),
+                (unsigned long long)G.hist[6].load(), (unsigned long long)G.hist[7].load(), (unsigned long long)G.slow_phase[0].load(), (unsigned long long)G.slow_phase[1].load(), (unsigned long long)G.slow_phase[2].load(),
+                (unsigned long long)G.slow_phase[3].load(), (unsigned long long)G.slow_phase[4].load(), (unsigned long long)G.slow_phase[5].load(), (unsigned long long)G.slow_phase[6].load(), (unsigned long long)G.slow_phase[7].load());
+    }
     if (cons::g_mp_cnt[1].load())
         fprintf(stderr, "[cons] main path (cumulative): %llu recomputes cut the path, on average at %.0f edges before its end of %.0f\n", (unsigned long long)cons::g_mp_cnt[1].load(),
                 (double)cons::g_mp_cnt[0].load() / cons::g_mp_cnt[1].load(), (double)cons::g_mp_cnt[2].load() / cons::g_mp_cnt[1].load());

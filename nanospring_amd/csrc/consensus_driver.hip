@@ -20,6 +20,32 @@
 #include "engine.hpp"
 
 namespace nsgpu {
+static void graph_shared_free(void *p) { delete static_cast<DevGraphShared *>(p); }
+// pools and streams of the consensus graphs in HBM: made once per context (pinned memory takes its time to map), reused by every stage
+static int graph_shared_get(nsgpu_ctx *c, DevGraphShared **out)
+{
+    *out = nullptr;
+    if (!graph_on_device()) return NSGPU_OK;
+    if (!c->graph_shared) {
+        DevGraphShared *sh = new DevGraphShared();
+        c->graph_shared = sh, c->graph_shared_free = graph_shared_free;
+        NS_TRY(role_stream_create(&sh->serve_stream, "graph"));
+        NS_TRY(role_stream_create(&sh->copy_stream, "graph_copy"));
+        sh->dev.set_slab_bytes((size_t)1 << 30);
+        sh->pin.set_slab_bytes((size_t)256 << 20);
+    }
+    DevGraphShared *sh = static_cast<DevGraphShared *>(c->graph_shared);
+    sh->max_ops = 2 * c->reads.max_len + 64;
+    sh->check = getenv("NSGPU_GRAPH_CHECK") != nullptr;
+    { const char *e = getenv("NSGPU_SOA_DEBUG_FLAGS"); sh->dbg_flags = e ? (uint32_t)atoi(e) : 0; }
+    sh->n_updates = 0, sh->n_launches = 0, sh->n_grow = 0, sh->n_mid_copies = 0, sh->kernel_wait_ns = 0, sh->bytes_back = 0, sh->update_ns = 0;
+    for (auto &t : sh->phase_ticks) t = 0;
+    for (auto &t : sh->hist) t = 0;
+    for (auto &t : sh->slow_phase) t = 0;
+    *out = sh;
+    return NSGPU_OK;
+}
+
 static void engine_free(void *p)
 {
     pool_drain();                                     // no emission task may outlive the engine
@@ -50,6 +76,7 @@ int engine_begin(nsgpu_ctx *c, uint32_t n_builders_total, uint32_t rank, uint32_
     if (D.offset == 0) D.offset = 1;                                  // the reference would never terminate with a zero stride
     D.in_graph.assign(D.N, 0);
     D.rep.assign((size_t)D.N + 1, 0);
+    NS_TRY(graph_shared_get(c, &D.gsh));
     E->t0 = now_ms();
     if (D.N) NS_TRY(nsgpu_check_repetitive(c, D.rep.data()));
     if (!auto_now && !c->defer_set) c->defer_anchors = c->defer_slots = 0;
@@ -95,6 +122,20 @@ void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
     // boundary: see run_consensus)
     const int dg = only_fresh ? -1 : E->deferred_fresh;
     if (!only_fresh) E->deferred_fresh = -1;
+    // The accepted reads this phase puts into graphs in HBM (what the slot's early updates left: contested reads, deferred alignments; with several
+    // groups: every accepted read): ONE launch, one workgroup per graph, handed their scripts by the loop below
+    std::vector<DevGraph *> armed;
+    if (D.gsh && !only_fresh) {
+        for (Builder &b : D.B) {
+            if (!in_group(b, group) || b.st != Builder::GOT_ALIGN || !b.accepted || b.early_updated || !b.g) continue;
+            DevGraph *g = b.g->dev();
+            if (!g) continue;
+            const int rc = g->prepare(b.query.size());
+            if (rc != NSGPU_OK) { D.graph_failed(rc); break; }
+            armed.push_back(g);
+        }
+        if (D.graph_rc.load() == NSGPU_OK && armed.size() > 1) { const int rc = graph_serve_launch(D.gsh, armed.data(), armed.size()); if (rc != NSGPU_OK) D.graph_failed(rc); }
+    }
     par_for_pinned("host.phase", D.B.size(), [&](size_t i) {
         Builder &b = D.B[i];
         if ((in_group(b, group) && (!only_fresh || b.st == Builder::ADVANCE)) || (dg >= 0 && in_group(b, dg) && b.st == Builder::ADVANCE)) {
@@ -104,6 +145,7 @@ void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
             if (b.st == Builder::WAIT_ALIGN && !b.idx_valid && !b.sp_ready) { plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k); b.sp_ready = true; }
         }
     });
+    for (DevGraph *g : armed) if (g->armed()) g->cancel();
     // the edit emission of the contigs finished in this phase: background tasks of the host pool, picked up whenever a
     // thread has nothing else to do (nothing waits for them before the end of the stage)
     for (Builder &b : D.B)
@@ -113,6 +155,7 @@ void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
             pool_post([&D, fc] { D.emit_contig(*fc); });
         }
     c->cons_stats.graph_ms += now_ms() - a0;
+    if (D.graph_rc.load() != NSGPU_OK) set_error("%s", D.graph_err.c_str());      // (reported by the caller: engine_slot checks graph_rc)
     double mx = 0, mxu = 0, mxm = 0;
     for (Builder &b : D.B) if (in_group(b, group)) { if (b.last_ms > mx) mx = b.last_ms; b.last_ms = 0; if (b.last_u > mxu) mxu = b.last_u; if (b.last_m > mxm) mxm = b.last_m; b.last_u = b.last_m = 0; }
     c->cons_stats.graph_crit_ms += mx;       // sum over phases of the slowest builder step: the floor of the phase wall
@@ -136,7 +179,7 @@ void engine_advance(nsgpu_ctx *c, bool only_fresh, int group)
 // NSGPU_SKETCH_CHECK=1 compares every spliced list with a sketch of the whole string.
 static void plan_splice(Builder &b, int w, int k)
 {
-    const std::string &nw = b.g->main_path, &od = b.mz_str;
+    const std::string &nw = b.g->path(), &od = b.mz_str;
     Builder::Splice &sp = b.sp;
     sp = Builder::Splice();
     if (od.empty() || b.mz.empty()) return;
@@ -185,7 +228,7 @@ static size_t apply_splice(Builder &b, const mm2::Anchor *sub, size_t n_sub, int
     size_t first_diff = 0;
     auto pos_of = [](const mm2::Anchor &x) { return (size_t)((x.y & 0xffffffffull) >> 1); };
     const Builder::Splice &sp = b.sp;
-    const std::string &nw = b.g->main_path;
+    const std::string &nw = b.g->path();
     b.cnt_rem.clear(), b.cnt_add.clear();
     if (sp.full) { b.mz.assign(sub, sub + n_sub); b.cnt_valid = false; }       // (a new list: its count table is rebuilt)
     else {
@@ -378,7 +421,7 @@ static int engine_cons_update(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std
     const size_t n = who.size();
     for (size_t w = 0; w < n; ++w) {
         Builder &b = D.B[who[w]];
-        const size_t Ln = b.g->main_path.size();
+        const size_t Ln = b.g->path().size();
         const uint8_t *staged = changed[w] ? staged_of[w] : nullptr;
         if (changed[w]) {
             const bool full = b.sp.full || !b.dc_valid;
@@ -437,7 +480,7 @@ static int engine_cons_update(nsgpu_ctx *c, Engine *E, AlignBatch &AB, const std
             if (!b.dc_valid) continue;
             L.cons_check.resize(b.dc_len);
             NS_HIP(hipMemcpy(L.cons_check.data(), b.d_cons.as<uint8_t>() + b.dc_beg, b.dc_len, hipMemcpyDeviceToHost));
-            if (b.dc_len != b.g->main_path.size() || memcmp(L.cons_check.data(), b.g->main_path.data(), b.dc_len) != 0) {
+            if (b.dc_len != b.g->path().size() || memcmp(L.cons_check.data(), b.g->path().data(), b.dc_len) != 0) {
                 fprintf(stderr, "CONSENSUS COPY MISMATCH: builder %u, %zu bases (P %zu S %zu full %d)\n", b.gid, b.dc_len, b.sp.P, b.sp.S, (int)b.sp.full);
                 abort();
             }
@@ -487,8 +530,8 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
         Builder &b = D.B[who[w]];
         if (b.idx_valid) continue;
         sk_ref[w] = (uint32_t)sk.size();
-        if (b.sp.full) sk.push_back(SketchReq{b.g->main_path.data(), b.g->main_path.size()});
-        else sk.push_back(SketchReq{b.g->main_path.data() + b.sp.a, b.sp.B_sub - b.sp.a});
+        if (b.sp.full) sk.push_back(SketchReq{b.g->path().data(), b.g->path().size()});
+        else sk.push_back(SketchReq{b.g->path().data() + b.sp.a, b.sp.B_sub - b.sp.a});
     }
     const size_t q_base = sk.size();
     for (size_t w = 0; w < n; ++w) sk.push_back(SketchReq{D.B[who[w]].query.data(), D.B[who[w]].query.size()});
@@ -533,7 +576,7 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
     for (size_t w = 0; w < n; ++w) {
         Builder &b = D.B[who[w]];
         const size_t qi = q_base + w;
-        AB.reqs[w] = AlignReq{&b.idx, b.g->main_path.data(), b.g->main_path.size(), b.query.data(), b.query.size(), mz + mo[qi], (size_t)(mo[qi + 1] - mo[qi]), stage + so[w], 0};
+        AB.reqs[w] = AlignReq{&b.idx, b.g->path().data(), b.g->path().size(), b.query.data(), b.query.size(), mz + mo[qi], (size_t)(mo[qi + 1] - mo[qi]), stage + so[w], 0};
         if (use_dev_plan) AB.reqs[w].qry_dev = sketch_dev_seq(c, L.sketch_ws, qi);       // (the consensus side: filled in below, once the device copies are up to date)
     }
     NS_TRY(align_prestep_start(c, AB, 0, n));
@@ -545,13 +588,13 @@ static int engine_batches_sketch(nsgpu_ctx *c, int group, int dp_ws)
         if (!b.idx_valid) {
             first_diff = apply_splice(b, sub_of(w), (size_t)n_sub_of(w), (int)c->prm.m_w, (int)c->prm.m_k);
             // the base codes: prefix kept, suffix moved, the middle coded (a contig that grows at its left end used to be coded whole: 0.1 ms)
-            if (b.sp.have_common) b.idx.set_sequence_spliced(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, b.sp.cp, b.sp.cs);
-            else b.idx.set_sequence_from(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k, b.chg_lb);
+            if (b.sp.have_common) b.idx.set_sequence_spliced(b.g->path().data(), (uint32_t)b.g->path().size(), (int)c->prm.m_w, (int)c->prm.m_k, b.sp.cp, b.sp.cs);
+            else b.idx.set_sequence_from(b.g->path().data(), (uint32_t)b.g->path().size(), (int)c->prm.m_w, (int)c->prm.m_k, b.chg_lb);
             {
                 static const bool check = getenv("NSGPU_SKETCH_CHECK") != nullptr;
                 if (check) {
                     mm2::RefIndex whole;
-                    whole.set_sequence(b.g->main_path.data(), (uint32_t)b.g->main_path.size(), (int)c->prm.m_w, (int)c->prm.m_k);
+                    whole.set_sequence(b.g->path().data(), (uint32_t)b.g->path().size(), (int)c->prm.m_w, (int)c->prm.m_k);
                     if (whole.seq != b.idx.seq) { fprintf(stderr, "nsgpu: spliced base codes differ from the whole string's (internal error)\n"); abort(); }
                 }
             }
@@ -840,7 +883,32 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
     std::atomic<uint64_t> task_ns{0}, task_max_ns{0}, conv_ns{0};
     struct Tk { std::atomic<uint64_t> &sum, &mx; double k0; ~Tk() { const uint64_t d = (uint64_t)((now_ms() - k0) * 1e6); sum += d; uint64_t m = mx.load(); while (d > m && !mx.compare_exchange_weak(m, d)) {} } };
     // a builder whose alignment has been delivered: the skeleton to its end, the conversion, and -- its claim cannot fail -- the graph update
-    auto finish_builder = [&](size_t i, int gi, size_t w, double k0) {
+    // the graphs in HBM of the slot's builders: ONE launch (behind the DP kernels' launches) whose workgroups wait for the accepted reads' scripts;
+    // whatever gets none -- an alignment that failed, a contested read -- is released when this function is left
+    std::vector<DevGraph *> armed;
+    struct Disarm { std::vector<DevGraph *> &v; ~Disarm() { for (DevGraph *g : v) if (g->armed()) g->cancel(); } } disarm{armed};
+    if (D.gsh) {
+        for (int k = 0; k < n_act; ++k)
+            for (uint32_t bi : E->awho[act[k]]) {
+                Builder &b = D.B[bi];
+                DevGraph *dg = b.g ? b.g->dev() : nullptr;
+                if (!dg) continue;
+                NS_TRY(dg->prepare(b.query.size()));
+                armed.push_back(dg);
+            }
+        NS_TRY(graph_serve_launch(D.gsh, armed.data(), armed.size()));
+    }
+    // the second half of a builder's task: the graph has taken the read -- the new consensus, and which stretch of it has to be sketched again
+    auto finish_update = [&](Builder &b) {
+        const double t0 = now_ms();
+        D.apply_complete(b);
+        plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k);
+        b.sp_ready = true;
+        b.early_updated = true;
+        b.cpu_ms += now_ms() - t0;
+        n_updates += 1;
+    };
+    auto finish_builder = [&](size_t i, int gi, size_t w, double k0, bool async) {
         AlignBatch &AB = E->ab[gi];
         Engine::Lane &L = E->lane[gi];
         if (!align_early_one(AB, w, L.outs[w])) return;
@@ -850,12 +918,9 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
         b.early_result = true;
         if (!(b.aln.ok && L.early_sure[w])) return;
         const double t0 = now_ms();
-        D.apply_alignment(b);
-        plan_splice(b, (int)c->prm.m_w, (int)c->prm.m_k);
-        b.sp_ready = true;
-        b.early_updated = true;
+        D.apply_submit(b);                            // (the graph in HBM: a kernel on its way; the pointer graph: done)
         b.cpu_ms += now_ms() - t0;
-        n_updates += 1;
+        if (!async || !b.graph_flying || b.g->ready()) finish_update(b);
     };
     // The DP kernels hand every alignment over the moment its last problem is done (ksw_collect.hpp): no parts -- every pool thread keeps looking at
     // the status words of ITS builders' alignments (the pinned assignment of the host phase) and runs a builder's task as soon as its word is
@@ -901,6 +966,8 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
             static thread_local const int slack_set = prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);      // (a 10 us sleep is 10 us, not 60)
             (void)slack_set;
             static thread_local std::vector<uint32_t> mine;          // (any number of builders per thread: few threads, many builders)
+            static thread_local std::vector<uint32_t> flying;        // builders whose graph update this thread has launched and not yet taken over
+            flying.clear();
             mine.clear();
             for (uint32_t i : cand) if (i % T == t) mine.push_back(i);
             size_t n_mine = mine.size();
@@ -925,15 +992,30 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
                 const double k0 = now_ms();
                 { uint64_t m = last_claim_us.load(); const uint64_t v = (uint64_t)((k0 - p0) * 1e3); while (v > m && !last_claim_us.compare_exchange_weak(m, v)) {} }
                 Tk tk{task_ns, task_max_ns, k0};
-                finish_builder(i, gi, (size_t)w, k0);
+                finish_builder(i, gi, (size_t)w, k0, true);
+                if (D.B[i].graph_flying) flying.push_back((uint32_t)i);
                 return 1;
+            };
+            // graph updates in flight: whichever has reported is taken over (the consensus patched, the splice planned)
+            auto poll_flying = [&]() -> bool {
+                bool any = false;
+                for (size_t k = 0; k < flying.size();) {
+                    Builder &b = D.B[flying[k]];
+                    if (!b.g->ready()) { ++k; continue; }
+                    const double k0 = now_ms();
+                    Tk tk{task_ns, task_max_ns, k0};
+                    finish_update(b);
+                    flying[k] = flying.back(), flying.pop_back();
+                    any = true;
+                }
+                return any;
             };
             bool closing = false;
             // (a batch that never closes -- a GPU fault -- must not hold the pool for ever: align_finish's wait reports it)
             static const double give_up_ms = [] { const char *e = getenv("NSGPU_WAIT_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return (v > 0 ? v : 120.0) * 1e3; }();
-            while (n_mine || (!no_steal && n_open.load(std::memory_order_acquire))) {
+            while (n_mine || !flying.empty() || (!no_steal && n_open.load(std::memory_order_acquire))) {
                 if (now_ms() - p0 > give_up_ms) break;
-                bool progressed = false;
+                bool progressed = poll_flying();
                 for (size_t k = 0; k < n_mine;) {
                     const int r = try_builder(mine[k]);
                     if (r == 0) { ++k; continue; }
@@ -949,13 +1031,16 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
                     }
                 }
                 if (progressed) continue;
-                if (closing) break;                                           // one more look after the closing words, then leave
+                if (closing && flying.empty()) break;                         // one more look after the closing words, then leave
                 bool all_done = true;
                 for (int gi = 0; gi < kMaxGroups; ++gi) if (polled[gi] && !*donep[gi]) all_done = false;
-                if (all_done) { closing = true; continue; }
+                if (all_done && !closing) { closing = true; continue; }
                 timespec ts = {0, 10000};
                 nanosleep(&ts, nullptr);
             }
+            // (a watch that gave up: nothing may stay in flight behind it)
+            for (uint32_t i : flying) finish_update(D.B[i]);
+            flying.clear();
         });
         E->n_early_stolen += n_stolen.load();
         E->early_last_claim_ms += last_claim_us.load() / 1e3;       // (debug print: when the slot's last alignment was taken up, from the watch's start)
@@ -981,7 +1066,7 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
                 const uint32_t got = batch_plan_deliver_one(AB, R, (size_t)w, part, true);
                 if (!got || got == ~0u) return;
                 n_tasks += got;
-                finish_builder(i, gi, (size_t)w, k0);
+                finish_builder(i, gi, (size_t)w, k0, false);
             });
         };
         int rc1 = NSGPU_OK;
@@ -1004,6 +1089,7 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
         else if (rc1 != NSGPU_OK) { set_error("%s", err1.empty() ? "contig engine: the second part of the results failed" : err1.c_str()); rc_all = rc1; }
     }
     if (rc_all != NSGPU_OK) return rc_all;
+    if (D.graph_rc.load() != NSGPU_OK) { set_error("%s", D.graph_err.c_str()); return D.graph_rc.load(); }
     E->n_early += n_updates.load();
     E->early_task_ms += task_ns.load() / 1e6, E->early_task_max_ms += task_max_ns.load() / 1e6, E->early_conv_ms += conv_ns.load() / 1e6;
     { std::lock_guard<std::mutex> lk(c->stat_m); c->aln_dp_tasks += n_tasks.load(); c->cons_stats.graph_ms += now_ms() - g0; }
@@ -1120,7 +1206,15 @@ static int engine_g1_batches(nsgpu_ctx *c)
 // the group that was there one slot earlier, part 2 of group (slot + 1) % G -- whose DP launch has been in flight for a
 // slot -- all concurrently.
 // part: 0 = the whole slot; with ONE group the seeds are granted between the host phase (part 1) and the batches (part 2): see run_consensus
+static int engine_slot_inner(nsgpu_ctx *c, uint32_t slot, int part);
 int engine_slot(nsgpu_ctx *c, uint32_t slot, int part)
+{
+    const int rc = engine_slot_inner(c, slot, part);
+    Driver &D = static_cast<Engine *>(c->cons_engine)->D;
+    if (rc == NSGPU_OK && D.graph_rc.load() != NSGPU_OK) { set_error("%s", D.graph_err.c_str()); return D.graph_rc.load(); }     // (a graph update that failed inside a pool loop)
+    return rc;
+}
+static int engine_slot_inner(nsgpu_ctx *c, uint32_t slot, int part)
 {
     const uint32_t G = (uint32_t)n_groups(c);
     const int host_group = (int)(slot % G), begin_group = (int)((slot + G - 1) % G), finish_group = (int)((slot + 1) % G);

@@ -22,7 +22,7 @@ SoaNeed soa_need(uint32_t n_ops, uint32_t n_run, uint32_t n_ins, uint32_t path_l
     n.chunks = n_run + 3 * n_ops + 256;
     n.path_side = n_ins + 64;
     (void)path_len;
-    n.wk = HostOps::wk_update_words(n_ops) + (1u << 18);
+    n.wk = HostOps::wk_update_words(n_ops) + (1u << 20);
     return n;
 }
 
@@ -117,7 +117,7 @@ void soa_patch_path(std::string &path, uint32_t P, uint32_t S, uint32_t new_len,
 static void die_on(const dg::Hdr &h, const char *where)
 {
     if (!h.err) return;
-    fprintf(stderr, "nsgpu: consensus graph (host arrays): error %u in %s (capacity %u / scripts %u / degree %u / walk %u / work area %u)\n", h.err, where, h.err & dg::ERR_CAP,
+    fprintf(stderr, "nsgpu: consensus graph (host arrays): error %u in %s, raised at dgraph.hpp:%u (capacity %u / scripts %u / degree %u / walk %u / work area %u)\n", h.err, where, h.err_line, h.err & dg::ERR_CAP,
             h.err & dg::ERR_SCRIPT, h.err & dg::ERR_DEGREE, h.err & dg::ERR_WALK, h.err & dg::ERR_SCRATCH);
     abort();
 }

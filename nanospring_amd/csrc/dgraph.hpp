@@ -68,14 +68,18 @@ struct Hdr {
     uint32_t err;
     // the last update, for the main-path recompute behind it: its tables stay in wk[0 .. upd_wk)
     uint32_t upd_wk, upd_n_ops, upd_n_exc, upd_nodes0, upd_edges0;
+    uint32_t upd_touch_lo, upd_touch_hi, have_touch;   // path nodes [lo, hi] are the ones whose edges the update changed (NIL: none)
+    uint32_t cons_from;                               // path nodes from this index on are known to choose the path's edge (NIL: nothing known)
     // what an update + recompute reports to the host
     uint32_t initial;                                 // the read's first node
     uint32_t P, S, old_len, new_len;                  // the consensus before and after share P bases in front and S at the end
     uint32_t ending_id, starting_id;                  // the smallest read id on the path's last / first edge
     uint32_t st_splits, st_detours, st_walked, st_seq_exc, st_cycles_run, st_full_walk, st_dis;
     uint32_t stage;                                   // of the recompute: 2 = choosing (nothing changed yet), 3 = changing the graph
-    uint32_t dbg_flags;                               // tests: 1 = excursions one at a time, 2 = removeCycles by the reference's full walk
-    uint32_t pad_[2];
+    uint32_t dbg_flags;                               // tests: 1 = excursions one at a time, 2 = removeCycles by the reference's full walk, 4 = a longer path always moves its left part
+    uint32_t err_line;                                // where the first error was raised (dgraph.hpp line)
+    uint32_t st_tm[8];                                // ticks of the team's clock by phase: tables, runs, excursions, choices, stitching, writing, flags + P/S, removeCycles
+    uint32_t pad_[1];
 };
 static_assert(sizeof(Hdr) % 16 == 0, "header is whole 16-byte words");
 
@@ -95,6 +99,9 @@ DG_HD uint32_t code_of(uint32_t b) { return b == 'A' ? 0u : b == 'C' ? 1u : b ==
 // branch around a team call is the same for all of them); `tid == 0` marks what one thread does alone.  HostTeam is the team of one.
 // ---------------------------------------------------------------------------------------------------------------------------
 struct HostTeam {
+    uint32_t shared_[1];
+    DG_HD uint32_t *shared() { return shared_; }                                    // a few KB the threads of a team share (the device's LDS)
+    DG_HD uint32_t shared_words() const { return 0; }
     DG_HD uint32_t tid() const { return 0; }
     DG_HD uint32_t size() const { return 1; }
     DG_HD void sync() {}
@@ -102,6 +109,7 @@ struct HostTeam {
     DG_HD uint32_t scan(uint32_t v, uint32_t &total) { total = v; return 0; }       // exclusive prefix sum over the team's threads
     DG_HD uint32_t min_all(uint32_t v) { return v; }
     DG_HD uint32_t max_all(uint32_t v) { return v; }
+    DG_HD uint32_t clock() const { return 0; }                                      // a free-running counter (debug report)
 };
 
 // excursion record (8 words) in the update's tables
@@ -114,15 +122,15 @@ template <class T> struct Ops {
     T &team;
     DG_HD Ops(const G &gg, T &t) : g(gg), team(t) {}
 
-    DG_HD void fail(uint32_t e) { g.h->err |= e; }
+    DG_HD void fail_at(uint32_t line, uint32_t e) { if (!g.h->err) g.h->err_line = line; g.h->err |= e; }
     DG_HD bool failed() const { return g.h->err != 0; }
 
     // ---- allocation (sequential contexts: one thread; the parallel phases compute their ids from prefix sums) ----
-    DG_HD uint32_t new_chunk() { Hdr &h = *g.h; if (h.n_chunks >= h.cap_chunks) { fail(ERR_CAP); return 0; } const uint32_t c = h.n_chunks++; g.chunks[c].next = NIL; return c; }
+    DG_HD uint32_t new_chunk() { Hdr &h = *g.h; if (h.n_chunks >= h.cap_chunks) { fail_at(__LINE__, ERR_CAP); return 0; } const uint32_t c = h.n_chunks++; g.chunks[c].next = NIL; return c; }
     DG_HD uint32_t new_node(uint32_t base)
     {
         Hdr &h = *g.h;
-        if (h.n_nodes >= h.cap_nodes) { fail(ERR_CAP); return 0; }
+        if (h.n_nodes >= h.cap_nodes) { fail_at(__LINE__, ERR_CAP); return 0; }
         const uint32_t n = h.n_nodes++;
         Node &x = g.nodes[n];
         x.out_ext = x.in_ext = NIL, x.n_out = x.n_in = 0, x.base = (uint8_t)base, x.on_main = 0;
@@ -151,17 +159,49 @@ template <class T> struct Ops {
     }
     DG_HD uint32_t out_ref(const Node &x, uint32_t i) const { return list_get(x.out, kOutInl, x.out_ext, i); }
     DG_HD uint32_t in_ref(const Node &x, uint32_t i) const { return list_get(x.in, kInInl, x.in_ext, i); }
+    // a push whose list may need one more chunk, handed in by the caller (the parallel phases get their chunk ids from prefix sums)
+    DG_HD static bool push_needs_chunk(uint32_t n_inl, uint32_t cnt) { return cnt >= n_inl && (cnt - n_inl) % kChunkIds == 0; }
+    DG_HD void list_push_with(uint32_t *inl, uint32_t n_inl, uint32_t &ext, uint32_t cnt, uint32_t v, uint32_t fresh)
+    {
+        if (cnt < n_inl) { inl[cnt] = v; return; }
+        const uint32_t i = cnt - n_inl, s = i % kChunkIds;
+        uint32_t hops = i / kChunkIds;
+        if (s == 0) {
+            g.chunks[fresh].next = NIL;
+            if (hops == 0) ext = fresh;
+            else { uint32_t c = ext; while (--hops) c = g.chunks[c].next; g.chunks[c].next = fresh; }
+            g.chunks[fresh].v[0] = v;
+            return;
+        }
+        uint32_t c = ext;
+        while (hops--) c = g.chunks[c].next;
+        g.chunks[c].v[s] = v;
+    }
+    DG_HD void out_push_with(uint32_t n, uint32_t ref, uint32_t fresh)
+    {
+        Node &x = g.nodes[n];
+        if (x.n_out == 255) { fail_at(__LINE__, ERR_DEGREE); return; }
+        list_push_with(x.out, kOutInl, x.out_ext, x.n_out, ref, fresh);
+        ++x.n_out;
+    }
+    DG_HD void in_push_with(uint32_t n, uint32_t e, uint32_t fresh)
+    {
+        Node &x = g.nodes[n];
+        if (x.n_in == 255) { fail_at(__LINE__, ERR_DEGREE); return; }
+        list_push_with(x.in, kInInl, x.in_ext, x.n_in, e, fresh);
+        ++x.n_in;
+    }
     DG_HD void out_push(uint32_t n, uint32_t ref)
     {
         Node &x = g.nodes[n];
-        if (x.n_out == 255) { fail(ERR_DEGREE); return; }
+        if (x.n_out == 255) { fail_at(__LINE__, ERR_DEGREE); return; }
         list_set(x.out, kOutInl, x.out_ext, x.n_out, ref);
         ++x.n_out;
     }
     DG_HD void in_push(uint32_t n, uint32_t e)
     {
         Node &x = g.nodes[n];
-        if (x.n_in == 255) { fail(ERR_DEGREE); return; }
+        if (x.n_in == 255) { fail_at(__LINE__, ERR_DEGREE); return; }
         list_set(x.in, kInInl, x.in_ext, x.n_in, e);
         ++x.n_in;
     }
@@ -274,7 +314,7 @@ template <class T> struct Ops {
     DG_HD uint32_t new_edge(uint32_t s, uint32_t t, const uint32_t *ids, uint32_t n_ids)
     {
         Hdr &h = *g.h;
-        if (h.n_edges >= h.cap_edges) { fail(ERR_CAP); return 0; }
+        if (h.n_edges >= h.cap_edges) { fail_at(__LINE__, ERR_CAP); return 0; }
         const uint32_t e = h.n_edges++;
         Edge &x = g.edges[e];
         x.src = s, x.sink = t, x.count = 0, x.head = x.tail = NIL;
@@ -350,7 +390,7 @@ template <class T> struct Ops {
     {
         Hdr &h = *g.h;
         const uint32_t tid = team.tid(), nt = team.size();
-        if (len == 0 || len > h.cap_nodes || len - 1 > h.cap_edges || len + 2 > h.cap_path) { if (tid == 0) fail(ERR_CAP); team.sync(); return; }
+        if (len == 0 || len > h.cap_nodes || len - 1 > h.cap_edges || len + 2 > h.cap_path) { if (tid == 0) fail_at(__LINE__, ERR_CAP); team.sync(); return; }
         const uint32_t off = (h.cap_path - len) / 2;
         for (uint32_t i = tid; i < len; i += nt) {
             Node &x = g.nodes[i];
@@ -369,6 +409,7 @@ template <class T> struct Ops {
             h.right_off = h.m, h.left_off = 0, h.right_unch = len - 1, h.left_unch = 0;
             h.n_multi = h.multi_n = 0, h.epoch = 0;
             h.upd_wk = h.upd_n_ops = h.upd_n_exc = 0, h.upd_nodes0 = len, h.upd_edges0 = len - 1;
+            h.upd_touch_lo = h.upd_touch_hi = NIL, h.have_touch = 0, h.cons_from = 0;      // (a chain: every node has its one way out)
             h.initial = 0, h.P = 0, h.S = 0, h.old_len = 0, h.new_len = len, h.ending_id = h.starting_id = id;
         }
         team.sync();
@@ -388,7 +429,7 @@ template <class T> struct Ops {
         Hdr &h = *g.h;
         const uint32_t tid = team.tid(), nt = team.size();
         const uint32_t m = h.m;
-        if (wk_update_words(n_ops) > h.cap_wk) { if (tid == 0) fail(ERR_SCRATCH); team.sync(); return; }
+        if (wk_update_words(n_ops) > h.cap_wk) { if (tid == 0) fail_at(__LINE__, ERR_SCRATCH); team.sync(); return; }
         // ---- the unchanged stretch (:409-433) ----
         if (tid == 0) {
             if (begin_offset >= 0 || end_offset >= 0) {
@@ -406,6 +447,8 @@ template <class T> struct Ops {
                 h.left_unch = path_node(h.left_off);
             }
         }
+        uint32_t tk = team.clock();
+        auto lap = [&](int i) { const uint32_t now = team.clock(); if (tid == 0) h.st_tm[i] += now - tk; tk = now; };
         uint32_t *W = g.wk;
         uint32_t *ops = W;                        // [n_ops]      the script (copied: it may lie in host memory)
         uint32_t *op_at = ops + n_ops + 1;        // [n_ops + 1]  edgeInPath at the start of op k
@@ -455,13 +498,23 @@ template <class T> struct Ops {
         {
             uint32_t bad = 0;
             for (uint32_t k = tid; k < n_ops; k += nt) { const uint32_t o = ops[k]; if (op_type(o) == 0 && ((uint64_t)op_at[k] + op_num(o) - 1 > m || op_num(o) == 0)) bad = 1; }
-            if (team.max_all(bad)) { if (tid == 0) fail(ERR_SCRIPT); team.sync(); return; }
+            if (team.max_all(bad)) { if (tid == 0) fail_at(__LINE__, ERR_SCRIPT); team.sync(); return; }
         }
-        if (tid == 0) h.upd_wk = wk_update_words(n_ops), h.upd_n_ops = n_ops, h.upd_n_exc = n_exc, h.upd_nodes0 = h.n_nodes, h.upd_edges0 = h.n_edges;
+        {   // the first path node the read's SAMEs touch (:470 `touch`), and how far the walk came
+            uint32_t first_same = NIL;
+            for (uint32_t k = tid; k < n_ops; k += nt) if (op_type(ops[k]) == 0) { first_same = k; break; }
+            first_same = team.min_all(first_same);
+            if (tid == 0) {
+                h.upd_wk = wk_update_words(n_ops), h.upd_n_ops = n_ops, h.upd_n_exc = n_exc, h.upd_nodes0 = h.n_nodes, h.upd_edges0 = h.n_edges;
+                h.upd_touch_lo = first_same != NIL ? op_at[first_same] : NIL, h.upd_touch_hi = op_at[n_ops], h.have_touch = 1;
+            }
+        }
         team.sync();
+        lap(0);
         // ---- pass B: the read along the runs of the path it follows (the per-base loop of :486-500 on main-path edges) ----
         append_runs(n_ops, op_at, run_off, n_run, id);
         if (failed()) return;
+        lap(1);
         // ---- pass C: the excursions ----
         const bool parallel_exc = h.n_multi == 0 && !(h.dbg_flags & 1u);      // every side node then has one way in: no two excursions can meet
         const uint32_t nodes_base = h.n_nodes, edges_base = h.n_edges;
@@ -477,7 +530,7 @@ template <class T> struct Ops {
                 tot_n += tn, tot_e += te2;
             }
             team.sync();
-            if ((uint64_t)nodes_base + tot_n > h.cap_nodes || (uint64_t)edges_base + tot_e > h.cap_edges) { if (tid == 0) fail(ERR_CAP); team.sync(); return; }
+            if ((uint64_t)nodes_base + tot_n > h.cap_nodes || (uint64_t)edges_base + tot_e > h.cap_edges) { if (tid == 0) fail_at(__LINE__, ERR_CAP); team.sync(); return; }
             exc_create_range(ops, op_at, ins_ord, ins_op, ex, 0, n_exc, nodes_base, tot_n, id);
             if (tid == 0) h.n_nodes += tot_n, h.live_nodes += tot_n, h.n_edges += tot_e, h.live_edges += tot_e;
             team.sync();
@@ -489,7 +542,7 @@ template <class T> struct Ops {
                 if (tid == 0) {
                     exc_follow(ops, n_ops, op_at, ins_ord, ins_op, app, r, nn, ne);
                     r[X_NODE0] = h.n_nodes, r[X_EDGE0] = h.n_edges;
-                    if ((uint64_t)h.n_nodes + nn > h.cap_nodes || (uint64_t)h.n_edges + ne > h.cap_edges) fail(ERR_CAP);
+                    if ((uint64_t)h.n_nodes + nn > h.cap_nodes || (uint64_t)h.n_edges + ne > h.cap_edges) fail_at(__LINE__, ERR_CAP);
                 }
                 team.sync();
                 if (failed()) return;
@@ -502,6 +555,7 @@ template <class T> struct Ops {
         if (failed()) return;
         // ---- pass D: the read on the existing side and junction edges it follows ----
         append_listed(app, n_ops + 1, id, !parallel_exc);
+        lap(2);
         // ---- the read's first node (`initialNode`) ----
         if (tid == 0) {
             uint32_t ini = NIL;
@@ -522,19 +576,28 @@ template <class T> struct Ops {
         Hdr &h = *g.h;
         const uint32_t tid = team.tid(), nt = team.size();
         uint32_t chunks_base = h.n_chunks;
+        // (the table the items search: in the team's shared memory when it fits -- a dozen dependent reads per item otherwise)
+        const uint32_t *ro = run_off;
+        if (n_ops + 1 <= team.shared_words()) {
+            uint32_t *sh = team.shared();
+            team.sync();
+            for (uint32_t k = tid; k <= n_ops; k += nt) sh[k] = run_off[k];
+            team.sync();
+            ro = sh;
+        }
         for (uint32_t base = 0; base < n_run; base += nt) {
             const uint32_t t = base + tid;
             uint32_t e = NIL, need = 0;
             if (t < n_run) {
                 // the op whose run holds item t: run_off[lo] <= t < run_off[hi]   (run_off[n_ops] = n_run)
                 uint32_t lo = 0, hi = n_ops;
-                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (run_off[mid] <= t) lo = mid; else hi = mid; }
-                e = g.pe[h.path_off + op_at[lo] + (t - run_off[lo])];
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ro[mid] <= t) lo = mid; else hi = mid; }
+                e = g.pe[h.path_off + op_at[lo] + (t - ro[lo])];
                 need = append_needs_chunk(g.edges[e].count) ? 1u : 0u;
             }
             uint32_t tot;
             const uint32_t p = team.scan(need, tot);
-            if ((uint64_t)chunks_base + tot > h.cap_chunks) { if (tid == 0) fail(ERR_CAP); team.sync(); return; }
+            if ((uint64_t)chunks_base + tot > h.cap_chunks) { if (tid == 0) fail_at(__LINE__, ERR_CAP); team.sync(); return; }
             if (t < n_run) append_id(e, id, need ? chunks_base + p : NIL);
             chunks_base += tot;
         }
@@ -559,7 +622,7 @@ template <class T> struct Ops {
             const uint32_t need = e != NIL && append_needs_chunk(g.edges[e].count) ? 1u : 0u;
             uint32_t tot;
             const uint32_t p = team.scan(need, tot);
-            if ((uint64_t)chunks_base + tot > h.cap_chunks) { if (tid == 0) fail(ERR_CAP); team.sync(); return; }
+            if ((uint64_t)chunks_base + tot > h.cap_chunks) { if (tid == 0) fail_at(__LINE__, ERR_CAP); team.sync(); return; }
             if (e != NIL) append_id(e, id, need ? chunks_base + p : NIL);
             chunks_base += tot;
         }
@@ -633,21 +696,40 @@ template <class T> struct Ops {
             if (e_in != NIL) { Edge &e = g.edges[e_in]; e.src = j ? nid - 1 : r[X_CUR], e.sink = nid, e.count = 1, e.head = e.tail = NIL, e.ids[0] = id; }
         }
         team.sync();
-        for (uint32_t x = x0 + tid; x < x1; x += nt) {
-            const uint32_t *r = ex + X_WORDS * x;
-            const uint32_t a = r[X_A], b = r[X_B], k0 = r[X_K0], nn = r[X_NINS] - k0;
-            const bool first_has_in = r[X_CUR] != NIL;
-            const uint32_t e0 = r[X_EDGE0];
-            const uint32_t n_in_edges = nn ? (first_has_in ? nn : nn - 1) : 0;
-            if (nn && first_has_in) out_push(r[X_CUR], e0 | (code_of(op_base(ops[ins_op[ins_ord[a] + k0]])) << 29));     // the node the follow ended at gets its one new way out
-            if (r[X_FLAGS] & 1u) {
-                const uint32_t target = path_node(op_at[b]), je = e0 + n_in_edges;
-                Edge &e = g.edges[je];
-                e.src = nn ? r[X_NODE0] + nn - 1 : r[X_CUR], e.sink = target, e.count = 1, e.head = e.tail = NIL, e.ids[0] = id;
-                if (!nn) out_push(r[X_CUR], je | (code_of(g.nodes[target].base) << 29));
-                in_push(target, je);              // (a main-path node is the target of at most one junction per read)
+        Hdr &h = *g.h;
+        uint32_t chunks_base = h.n_chunks;
+        for (uint32_t base = x0; base < x1; base += nt) {
+            const uint32_t x = base + tid;
+            uint32_t need_o = 0, need_i = 0, nn = 0, e0 = 0, n_in_edges = 0, target = NIL, b = 0;
+            bool do_out = false, do_in = false;
+            const uint32_t *r = ex + X_WORDS * (x < x1 ? x : x0);
+            if (x < x1) {
+                b = r[X_B], nn = r[X_NINS] - r[X_K0], e0 = r[X_EDGE0];
+                const bool first_has_in = r[X_CUR] != NIL;
+                n_in_edges = nn ? (first_has_in ? nn : nn - 1) : 0;
+                do_in = (r[X_FLAGS] & 1u) != 0;
+                do_out = (nn && first_has_in) || (do_in && !nn);          // the node the follow ended at gets its one new way out
+                if (do_in) target = path_node(op_at[b]);
+                need_o = do_out && push_needs_chunk(kOutInl, g.nodes[r[X_CUR]].n_out) ? 1u : 0u;
+                need_i = do_in && push_needs_chunk(kInInl, g.nodes[target].n_in) ? 1u : 0u;
             }
+            uint32_t tot;
+            const uint32_t p = team.scan(need_o + need_i, tot);
+            if ((uint64_t)chunks_base + tot > h.cap_chunks) { if (tid == 0) fail_at(__LINE__, ERR_CAP); team.sync(); return; }
+            if (x < x1) {
+                if (nn && do_out) out_push_with(r[X_CUR], e0 | (code_of(op_base(ops[ins_op[ins_ord[r[X_A]] + r[X_K0]]])) << 29), chunks_base + p);
+                if (do_in) {
+                    const uint32_t je = e0 + n_in_edges;
+                    Edge &e = g.edges[je];
+                    e.src = nn ? r[X_NODE0] + nn - 1 : r[X_CUR], e.sink = target, e.count = 1, e.head = e.tail = NIL, e.ids[0] = id;
+                    if (!nn) out_push_with(r[X_CUR], je | (code_of(g.nodes[target].base) << 29), chunks_base + p);
+                    in_push_with(target, je, chunks_base + p + need_o);              // (a main-path node is the target of at most one junction per read)
+                }
+            }
+            chunks_base += tot;
         }
+        team.sync();
+        if (tid == 0) h.n_chunks = chunks_base;
         team.sync();
     }
 
@@ -696,7 +778,7 @@ template <class T> struct Ops {
     struct Stitch { uint32_t *pc; uint32_t cap_pc, n_pc, len; uint32_t *gp; uint32_t cap_gp, n_gp, gap_len; bool ended; };
     DG_HD void emit_piece(Stitch &S, uint32_t kind, uint32_t a, uint32_t b, uint32_t c, uint32_t l)
     {
-        if (S.n_pc >= S.cap_pc) { fail(ERR_SCRATCH); return; }
+        if (S.n_pc >= S.cap_pc) { fail_at(__LINE__, ERR_SCRATCH); return; }
         uint32_t *p = S.pc + 5 * S.n_pc++;
         p[0] = kind, p[1] = a, p[2] = b, p[3] = c, p[4] = S.len;
         S.len += l;
@@ -704,7 +786,7 @@ template <class T> struct Ops {
     DG_HD void emit_gap(Stitch &S, uint32_t lo, uint32_t hi)
     {
         if (lo >= hi) return;
-        if (S.n_gp >= S.cap_gp) { fail(ERR_SCRATCH); return; }
+        if (S.n_gp >= S.cap_gp) { fail_at(__LINE__, ERR_SCRATCH); return; }
         uint32_t *p = S.gp + 3 * S.n_gp++;
         p[0] = lo, p[1] = hi, p[2] = S.gap_len;
         S.gap_len += hi - lo;
@@ -750,7 +832,7 @@ template <class T> struct Ops {
                     }
                     const uint32_t j = upd_op_at()[r[X_B]];        // the junction: back on the path at this index
                     emit_piece(S, PC_EDGE, e, 1, g.edges[e].sink, 1);
-                    if (j <= pos || j > m || g.sv_n[off + j] != g.edges[e].sink) { fail(ERR_WALK); break; }
+                    if (j <= pos || j > m || g.pn[off + j] != g.edges[e].sink) { fail_at(__LINE__, ERR_WALK); break; }
                     emit_gap(S, pos + 1, j);
                     pos = j;
                     break;
@@ -761,8 +843,8 @@ template <class T> struct Ops {
                 ++h.st_walked;
                 if (was_on) {
                     uint32_t j = pos + 1;
-                    while (j <= m && g.sv_n[off + j] != nx) ++j;
-                    if (j > m) { fail(ERR_WALK); break; }
+                    while (j <= m && g.pn[off + j] != nx) ++j;
+                    if (j > m) { fail_at(__LINE__, ERR_WALK); break; }
                     emit_gap(S, pos + 1, j);
                     pos = j;
                     break;
@@ -820,8 +902,8 @@ template <class T> struct Ops {
                 ++h.st_walked;
                 if (was_on) {
                     uint32_t j = known_idx;
-                    if (j == NIL) { j = pos; while (j > 0 && g.sv_n[off + j - 1] != nx) --j; j = j > 0 ? j - 1 : NIL; }
-                    if (j == NIL || j >= pos || g.sv_n[off + j] != nx) { fail(ERR_WALK); break; }
+                    if (j == NIL) { j = pos; while (j > 0 && g.pn[off + j - 1] != nx) --j; j = j > 0 ? j - 1 : NIL; }
+                    if (j == NIL || j >= pos || g.pn[off + j] != nx) { fail_at(__LINE__, ERR_WALK); break; }
                     emit_gap(S, j + 1, pos);
                     pos = j;
                     break;
@@ -834,8 +916,8 @@ template <class T> struct Ops {
     }
 
     // by-passed old nodes leave the path (they become side nodes: one with several edges in is work for removeCycles), the nodes of
-    // the detours join it.  Gaps: lanes over nodes; single detour nodes: thread 0.
-    DG_HD void apply_flags(const Stitch &S, uint32_t off)
+    // the detours join it.  Gaps and chains: lanes over nodes; single detour nodes: thread 0.  Runs before the path arrays change.
+    DG_HD void apply_flags(const Stitch &S, uint32_t off, bool backward)
     {
         Hdr &h = *g.h;
         const uint32_t tid = team.tid(), nt = team.size();
@@ -844,7 +926,7 @@ template <class T> struct Ops {
             uint32_t n = NIL, became = 0;
             if (t < S.gap_len) {
                 const uint32_t *p = S.gp + 3 * flat_find(S.gp, 3, 2, S.n_gp, t);
-                n = g.sv_n[off + p[0] + (t - p[2])];
+                n = g.pn[off + p[0] + (t - p[2])];
                 g.nodes[n].on_main = 0;
                 became = g.nodes[n].n_in > 1 ? 1u : 0u;
             }
@@ -855,10 +937,23 @@ template <class T> struct Ops {
             if (tid == 0) { h.n_multi += tot; h.multi_n = h.multi_n + tot <= h.cap_multi ? h.multi_n + tot : h.cap_multi + 1; }
             team.sync();
         }
-        // (the nodes of chains were put on the path where the new stretch was written: main_path)
-        if (tid == 0)
-            for (uint32_t i = 0; i < S.n_pc; ++i) { const uint32_t *p = S.pc + 5 * i; if (p[0] == PC_EDGE && !p[2]) set_on_main(p[3], true); }
+        for (uint32_t i = 0; i < S.n_pc; ++i) {
+            const uint32_t *p = S.pc + 5 * i;
+            if (p[0] == PC_CHAIN) for (uint32_t u = tid; u < p[2]; u += nt) g.nodes[backward ? p[3] - u : p[3] + u].on_main = 1;        // (new nodes: one edge in)
+            else if (p[0] == PC_EDGE && !p[2] && tid == 0) set_on_main(p[3], true);
+        }
         team.sync();
+    }
+    // entry t of a stitched stretch: forward -- edge, its sink, the sink's base; backward (walk order) -- edge, its source, the source's base
+    DG_HD void piece_entry(const Stitch &S, uint32_t t, uint32_t off, bool backward, uint32_t &e, uint32_t &n, uint8_t &b) const
+    {
+        const uint32_t *p = S.pc + 5 * flat_find(S.pc, 5, 4, S.n_pc, t);
+        const uint32_t u = t - p[4];
+        if (p[0] == PC_OLD) {
+            if (!backward) e = g.pe[off + p[1] + u], n = g.pn[off + p[1] + u + 1], b = g.ps[off + p[1] + u + 1];
+            else e = g.pe[off + p[2] - 1 - u], n = g.pn[off + p[2] - 1 - u], b = g.ps[off + p[2] - 1 - u];
+        } else if (p[0] == PC_EDGE) e = p[1], n = p[3], b = g.nodes[n].base;
+        else { e = backward ? p[1] - u : p[1] + u, n = backward ? p[3] - u : p[3] + u, b = g.nodes[n].base; }
     }
 
     DG_HD void main_path()
@@ -867,11 +962,9 @@ template <class T> struct Ops {
         const uint32_t tid = team.tid(), nt = team.size();
         const uint32_t m = h.m, R = h.right_off, Lf = h.left_off, off = h.path_off;
         if (tid == 0) h.stage = 2;
-        if (Lf > R || R > m || h.upd_wk + 4096 > h.cap_wk) { if (tid == 0) fail(Lf > R || R > m ? ERR_WALK : ERR_SCRATCH); team.sync(); return; }
-        // ---- the path as it was, where the walks go over it again ----
-        for (uint32_t i = tid; i <= Lf; i += nt) { g.sv_n[off + i] = g.pn[off + i], g.sv_s[off + i] = g.ps[off + i]; if (i < Lf) g.sv_e[off + i] = g.pe[off + i]; }
-        for (uint32_t i = R + tid; i <= m; i += nt) { g.sv_n[off + i] = g.pn[off + i], g.sv_s[off + i] = g.ps[off + i]; if (i < m) g.sv_e[off + i] = g.pe[off + i]; }
-        team.sync();
+        uint32_t tk = team.clock();
+        auto lap = [&](int i) { const uint32_t now = team.clock(); if (tid == 0) h.st_tm[i] += now - tk; tk = now; };
+        if (Lf > R || R > m || h.upd_wk + 4096 > h.cap_wk) { if (tid == 0) fail_at(__LINE__, Lf > R || R > m ? ERR_WALK : ERR_SCRATCH); team.sync(); return; }
         uint32_t *W = g.wk + h.upd_wk;
         const uint32_t wcap = h.cap_wk - h.upd_wk;
         uint32_t *D = W;                                     // disagreements, 2 words each
@@ -882,98 +975,150 @@ template <class T> struct Ops {
         F.n_pc = F.len = F.n_gp = F.gap_len = 0, F.ended = false;
         B.n_pc = B.len = B.n_gp = B.gap_len = 0, B.ended = false;
         // ---- to the right of old node R ----
+        // Which nodes can choose differently from the path: the path from cons_from on was chosen by getBestEdgeOut on the counts of its time, and
+        // an update since then changed the out-edges of the nodes [touch_lo, touch_hi] only (along path edges it raises the count of the edge that was
+        // the first maximum already).  Nodes the update touched inside the part the reference keeps as it is stop being known-consistent; everything
+        // in [R, m] below cons_from or at most touch_hi is asked, and the path's last node (the path may go on behind it).
+        uint32_t cf = h.cons_from;
+        const bool touched = h.have_touch != 0;
+        if (touched && h.upd_touch_lo != NIL && R >= 1 && cf != NIL) {
+            const uint32_t hi = h.upd_touch_hi < R - 1 ? h.upd_touch_hi : R - 1, lo = h.upd_touch_lo > Lf ? h.upd_touch_lo : Lf;
+            if (lo <= hi && cf < hi + 1) cf = hi + 1;
+        }
+        uint32_t hi_f = m;                                   // ask [R, hi_f] and m
+        if (cf != NIL) {
+            uint32_t need = cf;                              // exclusive
+            if (touched && h.upd_touch_hi != NIL && h.upd_touch_hi + 1 > need) need = h.upd_touch_hi + 1;
+            if (!touched) need = m + 1;
+            hi_f = need > m ? m : (need > R ? need - 1 : R);
+        }
         uint32_t n_dis = 0;
-        for (uint32_t base = R; base <= m; base += nt) {
-            const uint32_t i = base + tid;
-            uint32_t d = 0, ch = NIL;
-            if (i <= m) { ch = best_out(g.sv_n[off + i]); d = ch != (i < m ? g.sv_e[off + i] : NIL) ? 1u : 0u; }
-            uint32_t tot;
-            const uint32_t p = team.scan(d, tot);
-            if (d && n_dis + p < cap_d) D[2 * (n_dis + p)] = i, D[2 * (n_dis + p) + 1] = ch;
-            n_dis += tot;
+        for (int part = 0; part < 2; ++part) {
+            const uint32_t lo_i = part ? m : R, hi_i = part ? m : hi_f;
+            if (part && hi_f >= m) break;
+            for (uint32_t base = lo_i; base <= hi_i; base += nt) {
+                const uint32_t i = base + tid;
+                uint32_t d = 0, ch = NIL;
+                if (i <= hi_i) { ch = best_out(g.pn[off + i]); d = ch != (i < m ? g.pe[off + i] : NIL) ? 1u : 0u; }
+                uint32_t tot;
+                const uint32_t p = team.scan(d, tot);
+                if (d && n_dis + p < cap_d) D[2 * (n_dis + p)] = i, D[2 * (n_dis + p) + 1] = ch;
+                n_dis += tot;
+            }
         }
         team.sync();
-        if (n_dis > cap_d) { if (tid == 0) fail(ERR_SCRATCH); team.sync(); return; }
+        if (n_dis > cap_d) { if (tid == 0) fail_at(__LINE__, ERR_SCRATCH); team.sync(); return; }
+        lap(3);
         if (tid == 0) { h.st_dis += n_dis; stitch_forward(F, D, n_dis, R, m, off); }
         team.sync();
         if (failed()) return;
         F.n_pc = team.bcast(F.n_pc), F.len = team.bcast(F.len), F.n_gp = team.bcast(F.n_gp), F.gap_len = team.bcast(F.gap_len), F.ended = team.bcast(F.ended ? 1u : 0u) != 0;
+        lap(4);
         // ---- to the left of old node Lf ----
         n_dis = 0;
         for (uint32_t base = 0; base <= Lf; base += nt) {
             const uint32_t k = base + tid;
             uint32_t d = 0, ch = NIL, i = 0;
-            if (k <= Lf) { i = Lf - k; ch = best_in(g.sv_n[off + i]); d = ch != (i > 0 ? g.sv_e[off + i - 1] : NIL) ? 1u : 0u; }
+            if (k <= Lf) { i = Lf - k; ch = best_in(g.pn[off + i]); d = ch != (i > 0 ? g.pe[off + i - 1] : NIL) ? 1u : 0u; }
             uint32_t tot;
             const uint32_t p = team.scan(d, tot);
             if (d && n_dis + p < cap_d) D[2 * (n_dis + p)] = i, D[2 * (n_dis + p) + 1] = ch;
             n_dis += tot;
         }
         team.sync();
-        if (n_dis > cap_d) { if (tid == 0) fail(ERR_SCRATCH); team.sync(); return; }
+        if (n_dis > cap_d) { if (tid == 0) fail_at(__LINE__, ERR_SCRATCH); team.sync(); return; }
+        lap(3);
         if (tid == 0) { h.st_dis += n_dis; stitch_backward(B, D, n_dis, Lf, off); }
         team.sync();
         if (failed()) return;
         B.n_pc = team.bcast(B.n_pc), B.len = team.bcast(B.len), B.n_gp = team.bcast(B.n_gp), B.gap_len = team.bcast(B.gap_len), B.ended = team.bcast(B.ended ? 1u : 0u) != 0;
+        lap(4);
+        // ---- the new path.  Only what changes is written: the stretches between the first and the last detour of each side, and -- when the
+        // path's length changes -- whichever of the two parts next to the change is the shorter one moves (a contig grows at its ends: the read
+        // lies near one of them, the megabase behind it stays where it is).  Everything is staged in the sv arrays at its final position first. ----
         const uint32_t la = B.len, lenF = F.len;
-        if (off + Lf < la || (uint64_t)off + R + lenF + 1 > h.cap_path) { if (tid == 0) fail(ERR_CAP); team.sync(); return; }
+        const bool bwd_same = B.n_pc == 0 ? Lf == 0 : (B.n_pc == 1 && B.pc[0] == PC_OLD && B.pc[1] == 0 && B.pc[2] == Lf && !B.ended);
+        const bool fwd_same = F.n_pc == 0 ? R == m : (F.n_pc == 1 && F.pc[0] == PC_OLD && F.pc[1] == R && F.pc[2] == m && !F.ended);
+        uint32_t pre_nb = 0, pre_n = 0, suf_n = 0;
+        if (!bwd_same && B.n_pc && B.pc[0] == PC_OLD && B.pc[2] == Lf) pre_nb = B.pc[2] - B.pc[1];
+        if (!fwd_same && F.n_pc && F.pc[0] == PC_OLD && F.pc[1] == R) pre_n = F.pc[2] - F.pc[1];
+        if (!fwd_same && !F.ended && F.n_pc > 1) { const uint32_t *p = F.pc + 5 * (F.n_pc - 1); if (p[0] == PC_OLD && p[2] == m) suf_n = p[2] - p[1]; }
+        const int64_t delta = (int64_t)lenF - (int64_t)(m - R);
+        const uint32_t left_size = la + (R - Lf) + pre_n;                 // edges left of the forward change
+        const bool move_left = !fwd_same && suf_n && delta != 0 && (suf_n > left_size || (h.dbg_flags & 4u));
+        const uint32_t off2 = off + Lf - la;                              // the path's start once the front is written
+        const int64_t shift = move_left ? -delta : 0;                     // of everything left of the forward change's end
+        if (off + Lf < la || (int64_t)off2 + shift < 0 || (uint64_t)off + R + lenF + 1 > h.cap_path) { if (tid == 0) fail_at(__LINE__, ERR_CAP); team.sync(); return; }
         if (tid == 0) h.stage = 3;
-        // ---- the new stretches in place (the kept part [Lf, R] does not move in memory) ----
-        for (uint32_t t = tid; t < lenF; t += nt) {
-            const uint32_t *p = F.pc + 5 * flat_find(F.pc, 5, 4, F.n_pc, t);
-            const uint32_t u = t - p[4], at = off + R + t;
-            uint32_t e, n;
-            uint8_t b;
-            if (p[0] == PC_OLD) e = g.sv_e[off + p[1] + u], n = g.sv_n[off + p[1] + u + 1], b = g.sv_s[off + p[1] + u + 1];
-            else if (p[0] == PC_EDGE) e = p[1], n = p[3], b = g.nodes[n].base;
-            else { e = p[1] + u, n = p[3] + u, b = g.nodes[n].base; g.nodes[n].on_main = 1; }
-            g.pe[at] = e, g.pn[at + 1] = n, g.ps[at + 1] = b;
-        }
-        const uint32_t off2 = off + Lf - la;
-        for (uint32_t t = tid; t < la; t += nt) {
-            const uint32_t *p = B.pc + 5 * flat_find(B.pc, 5, 4, B.n_pc, t);
-            const uint32_t u = t - p[4], at = off + Lf - 1 - t;            // the t-th edge of the walk; its source is the node in front of it
-            uint32_t e, n;
-            uint8_t b;
-            if (p[0] == PC_OLD) e = g.sv_e[off + p[2] - 1 - u], n = g.sv_n[off + p[2] - 1 - u], b = g.sv_s[off + p[2] - 1 - u];
-            else if (p[0] == PC_EDGE) e = p[1], n = p[3], b = g.nodes[n].base;
-            else { e = p[1] - u, n = p[3] - u, b = g.nodes[n].base; g.nodes[n].on_main = 1; }
-            g.pe[at] = e, g.pn[at] = n, g.ps[at] = b;
-        }
         team.sync();
-        apply_flags(F, off);
-        apply_flags(B, off);
+        apply_flags(F, off, false);
+        apply_flags(B, off, true);
+        lap(6);
+        if (!bwd_same) {
+            for (uint32_t t = pre_nb + tid; t < la; t += nt) {
+                uint32_t e, n; uint8_t b;
+                piece_entry(B, t, off, true, e, n, b);
+                const uint32_t at = off + Lf - 1 - t;                     // the t-th edge of the walk; its source is the node in front of it
+                g.sv_e[at] = e, g.sv_n[at] = n, g.sv_s[at] = b;
+            }
+            team.sync();
+            for (uint32_t t = pre_nb + tid; t < la; t += nt) { const uint32_t at = off + Lf - 1 - t; g.pe[at] = g.sv_e[at], g.pn[at] = g.sv_n[at], g.ps[at] = g.sv_s[at]; }
+            team.sync();
+        }
+        if (!fwd_same) {
+            const uint32_t w_end = lenF - (move_left || delta == 0 ? suf_n : 0);      // forward entries [pre_n, w_end) are written
+            if (move_left) {
+                // the front and the kept part move by `shift` (source: the live arrays, which the front's write has just completed)
+                const uint32_t n_left = la + (R - Lf) + pre_n;                         // edges; nodes: one more
+                for (uint32_t t = tid; t <= n_left; t += nt) {
+                    const uint32_t from = off2 + t, to = (uint32_t)((int64_t)from + shift);
+                    g.sv_n[to] = g.pn[from], g.sv_s[to] = g.ps[from];
+                    if (t < n_left) g.sv_e[to] = g.pe[from];
+                }
+            }
+            for (uint32_t t = pre_n + tid; t < w_end; t += nt) {
+                uint32_t e, n; uint8_t b;
+                piece_entry(F, t, off, false, e, n, b);
+                const uint32_t at = (uint32_t)((int64_t)(off + R + t) + shift);
+                g.sv_e[at] = e, g.sv_n[at + 1] = n, g.sv_s[at + 1] = b;
+            }
+            team.sync();
+            if (move_left) {
+                const uint32_t n_left = la + (R - Lf) + pre_n;
+                for (uint32_t t = tid; t <= n_left; t += nt) { const uint32_t to = (uint32_t)((int64_t)(off2 + t) + shift); g.pn[to] = g.sv_n[to], g.ps[to] = g.sv_s[to]; if (t < n_left) g.pe[to] = g.sv_e[to]; }
+            }
+            for (uint32_t t = pre_n + tid; t < w_end; t += nt) { const uint32_t at = (uint32_t)((int64_t)(off + R + t) + shift); g.pe[at] = g.sv_e[at], g.pn[at + 1] = g.sv_n[at + 1], g.ps[at + 1] = g.sv_s[at + 1]; }
+            team.sync();
+        }
+        lap(5);
         const uint32_t m2 = la + (R - Lf) + lenF;
+        const uint32_t off3 = (uint32_t)((int64_t)off2 + shift);
         if (tid == 0) {
-            h.path_off = off2, h.m = m2;
+            h.path_off = off3, h.m = m2;
             h.right_off = la + (R - Lf), h.left_off = la;
-            h.ending_id = edge_min_id(g.edges[g.pe[off2 + m2 - 1]]);
-            h.starting_id = edge_min_id(g.edges[g.pe[off2]]);
-        }
-        team.sync();
-        // ---- what the consensus kept: P bases in front, S at the end (any valid pair will do for the caller; these are the obvious ones) ----
-        {
+            // every node from R on has just been asked or was known to be consistent; the kept part keeps what was known of it; nodes chosen
+            // by getBestEdgeIn (the new front) are not trusted
+            { uint32_t c2 = cf == NIL || cf > R ? R : cf; if (c2 < Lf) c2 = Lf; h.cons_from = c2 - Lf + la; }
+            h.have_touch = 0;
+            h.ending_id = edge_min_id(g.edges[g.pe[off3 + m2 - 1]]);
+            h.starting_id = edge_min_id(g.edges[g.pe[off3]]);
+            // what the consensus kept for sure: P bases in front (same index), S at the end (same distance from the end)
             const uint32_t Lo = m + 1, Ln = m2 + 1;
             uint32_t P, S;
-            const uint32_t fa = la < Lf ? la : Lf;                       // front stretches: old [0, Lf), new [0, la)
-            uint32_t pa = fa ? lcp(g.sv_s + off, g.ps + off2, fa) : 0;
-            const uint32_t nf = lenF < m - R ? lenF : m - R;             // back stretches: old (R, m], new (R', m2]
-            if (la == Lf && pa == fa) {
-                const uint32_t pf = nf ? lcp(g.sv_s + off + R + 1, g.ps + off + R + 1, nf) : 0;
-                P = R + 1 + pf;
-            } else P = pa;
-            const uint32_t sf = nf ? lcs(g.sv_s + off + m + 1, g.ps + off2 + m2 + 1, nf) : 0;
-            if (lenF == m - R && sf == nf) {
-                const uint32_t sa = fa ? lcs(g.sv_s + off + Lf, g.ps + off2 + la, fa) : 0;
-                S = nf + (R - Lf + 1) + sa;
-            } else S = sf;
+            if (bwd_same && fwd_same) P = Ln, S = 0;
+            else {
+                P = bwd_same ? R + pre_n + 1 : 0;
+                S = fwd_same ? m - (Lf - pre_nb) + 1 : suf_n;
+            }
             const uint32_t mn = Lo < Ln ? Lo : Ln;
             if (P > mn) P = mn;
             if (P + S > mn) S = mn - P;
-            if (tid == 0) h.P = P, h.S = S, h.old_len = Lo, h.new_len = Ln;
+            h.P = P, h.S = S, h.old_len = Lo, h.new_len = Ln;
         }
         team.sync();
+        lap(6);
         remove_cycles();
+        lap(7);
         if (tid == 0) {
             h.right_unch = g.pn[h.path_off + h.m], h.right_off = h.m;
             h.left_unch = g.pn[h.path_off], h.left_off = 0;
@@ -984,7 +1129,7 @@ template <class T> struct Ops {
     // ================================================================================================================
     // removeCycles (:653-691), walkAndPrune (:693-714), splitPath (:716-807)
     // ================================================================================================================
-    struct CycWk { uint32_t *todo, *roots, *hits, *estack, *ctx, *lists, *copy; uint32_t cap_todo, cap_roots, cap_hits, cap_estack, cap_ctx, cap_lists, cap_copy; };
+    struct CycWk { uint32_t *todo, *roots, *hits, *estack, *ctx, *lists, *copy, *defer; uint32_t cap_todo, cap_roots, cap_hits, cap_estack, cap_ctx, cap_lists, cap_copy, cap_defer; };
     DG_HD CycWk cyc_wk() const
     {
         const Hdr &h = *g.h;
@@ -995,61 +1140,83 @@ template <class T> struct Ops {
         c.roots = W + u, c.cap_roots = u;
         c.hits = W + 2 * u, c.cap_hits = u;                 // pairs
         c.estack = W + 4 * u, c.cap_estack = 2 * u;
-        c.ctx = W + 6 * u, c.cap_ctx = 4 * u / 8;          // 8 words each
-        c.lists = W + 10 * u, c.cap_lists = 4 * u;
-        c.copy = W + 14 * u, c.cap_copy = 2 * u;
+        c.ctx = W + 6 * u, c.cap_ctx = 2 * u / 8;          // 8 words each
+        c.lists = W + 8 * u, c.cap_lists = 4 * u;
+        c.copy = W + 12 * u, c.cap_copy = u;
+        c.defer = W + 13 * u, c.cap_defer = 3 * u;
         return c;
     }
 
     // Gives the reads of edge e0 (a side branch entering a node that has other ways in) a private copy of everything downstream until
     // the main path is reached again.  The reference's two-visit context stack, iteratively; read lists live in the work area.
-    // ctx: new_pre, e, in_off, in_n, own_off, own_n, visited, old_cur
+    // ctx: new_pre, e, in_off, in_n, own_off, own_n, visited, old_cur.  Two things keep the memory at what the FORKS of the copied part
+    // need, not its length (a by-passed stretch of the path is a chain of thousands of nodes): a context's list is given back when the
+    // context is popped (its descendants are done by then: stack discipline), and a node with ONE way out is not a new context at all --
+    // the walk goes on in the same one, its list filtered in place; whether the old node is left without edges (the reference looks at
+    // the context's second visit) is looked at when the split is over (nothing can reach such a node in between).
     DG_HD void split_path(const CycWk &K, uint32_t new_pre0, uint32_t e0)
     {
         Hdr &h = *g.h;
         ++h.st_splits;
-        uint32_t lists_top = 0, n_ctx = 0;
-        if (g.edges[e0].count > K.cap_lists) { fail(ERR_SCRATCH); return; }
+        uint32_t lists_top = 0, n_ctx = 0, n_def = 0;
+        if (g.edges[e0].count > K.cap_lists) { fail_at(__LINE__, ERR_SCRATCH); return; }
         lists_top = ids_copy(g.edges[e0], K.lists);          // (a copy: e0's list dies with e0 during the first visit)
         {
             uint32_t *c = K.ctx;
-            c[0] = new_pre0, c[1] = e0, c[2] = 0, c[3] = lists_top, c[4] = 0, c[5] = 0, c[6] = 0, c[7] = NIL;
+            c[0] = new_pre0, c[1] = e0, c[2] = 0, c[3] = lists_top, c[4] = lists_top, c[5] = 0, c[6] = 0, c[7] = NIL;
             n_ctx = 1;
         }
         while (n_ctx && !failed()) {
             uint32_t *c = K.ctx + 8 * (n_ctx - 1);
             if (c[6]) {
                 const uint32_t oc = c[7];
+                lists_top = c[4];
                 --n_ctx;
                 if (oc != NIL && g.nodes[oc].n_in == 0 && g.nodes[oc].n_out == 0) remove_node(oc);
                 continue;
             }
-            // the reads of this branch that go down edge c[1]
-            const Edge &ed = g.edges[c[1]];
+            // first visit: the reads of this branch that go down edge c[1]
+            uint32_t new_pre = c[0], e = c[1];
             const uint32_t own_off = lists_top;
             uint32_t own_n = 0;
-            for (uint32_t i = 0; i < c[3]; ++i) {
-                const uint32_t id = K.lists[c[2] + i];
-                if (ed.src != NIL && edge_has(ed, id)) { if (own_off + own_n >= K.cap_lists) { fail(ERR_SCRATCH); return; } K.lists[own_off + own_n++] = id; }
+            {
+                const Edge &ed = g.edges[e];
+                for (uint32_t i = 0; i < c[3]; ++i) {
+                    const uint32_t id = K.lists[c[2] + i];
+                    if (ed.src != NIL && edge_has(ed, id)) { if (own_off + own_n >= K.cap_lists) { fail_at(__LINE__, ERR_SCRATCH); return; } K.lists[own_off + own_n++] = id; }
+                }
             }
-            lists_top += own_n;
+            lists_top = own_off + own_n;
             c[4] = own_off, c[5] = own_n, c[6] = 1;
-            if (!own_n) continue;
-            const uint32_t old_cur = ed.sink;
-            c[7] = old_cur;
-            const uint32_t new_pre = c[0];
-            remove_reads_from_edge(c[1], K.lists + own_off, own_n);
-            if (g.nodes[old_cur].on_main) { new_edge(new_pre, old_cur, K.lists + own_off, own_n); continue; }
-            const uint32_t new_cur = new_node(g.nodes[old_cur].base);
-            new_edge(new_pre, new_cur, K.lists + own_off, own_n);
-            const Node &oc = g.nodes[old_cur];
-            const uint32_t no = oc.n_out;
-            if (8 * (n_ctx + no) > K.cap_ctx * 8) { fail(ERR_SCRATCH); return; }
-            for (uint32_t i = 0; i < no; ++i) {
-                uint32_t *d = K.ctx + 8 * n_ctx++;
-                d[0] = new_cur, d[1] = out_ref(oc, i) & kRefMask, d[2] = own_off, d[3] = own_n, d[4] = 0, d[5] = 0, d[6] = 0, d[7] = NIL;
+            while (own_n && !failed()) {
+                const uint32_t old_cur = g.edges[e].sink;
+                remove_reads_from_edge(e, K.lists + own_off, own_n);
+                if (g.nodes[old_cur].on_main) { new_edge(new_pre, old_cur, K.lists + own_off, own_n); c[7] = old_cur; break; }
+                const uint32_t new_cur = new_node(g.nodes[old_cur].base);
+                new_edge(new_pre, new_cur, K.lists + own_off, own_n);
+                const Node &oc = g.nodes[old_cur];
+                const uint32_t no = oc.n_out;
+                if (no == 1) {                                   // one way on: the same context goes on
+                    if (n_def >= K.cap_defer) { fail_at(__LINE__, ERR_SCRATCH); return; }
+                    K.defer[n_def++] = old_cur;
+                    e = out_ref(oc, 0) & kRefMask, new_pre = new_cur;
+                    const Edge &ed = g.edges[e];
+                    uint32_t w = 0;
+                    for (uint32_t i = 0; i < own_n; ++i) { const uint32_t id = K.lists[own_off + i]; if (edge_has(ed, id)) K.lists[own_off + w++] = id; }
+                    own_n = w, lists_top = own_off + w;
+                    c[5] = own_n;
+                    continue;
+                }
+                c[7] = old_cur;
+                if (n_ctx + no > K.cap_ctx) { fail_at(__LINE__, ERR_SCRATCH); return; }
+                for (uint32_t i = 0; i < no; ++i) {
+                    uint32_t *d = K.ctx + 8 * n_ctx++;
+                    d[0] = new_cur, d[1] = out_ref(oc, i) & kRefMask, d[2] = own_off, d[3] = own_n, d[4] = lists_top, d[5] = 0, d[6] = 0, d[7] = NIL;
+                }
+                break;
             }
         }
+        for (uint32_t i = 0; i < n_def && !failed(); ++i) { const uint32_t oc = K.defer[i]; if (g.nodes[oc].n_in == 0 && g.nodes[oc].n_out == 0 && g.nodes[oc].on_main == 0) remove_node(oc); }
     }
     DG_HD void walk_and_prune(const CycWk &K, uint32_t e0, bool marked_only)
     {
@@ -1064,7 +1231,7 @@ template <class T> struct Ops {
             if (marked_only && g.mark[sink] != h.epoch) continue;     // nothing below an unmarked node can be split
             if (g.nodes[sink].n_in > 1) split_path(K, source, curr);
             const Node &s = g.nodes[sink];
-            if (n + s.n_out > K.cap_estack) { fail(ERR_SCRATCH); return; }
+            if (n + s.n_out > K.cap_estack) { fail_at(__LINE__, ERR_SCRATCH); return; }
             for (uint32_t i = 0; i < s.n_out; ++i) K.estack[n++] = out_ref(s, i) & kRefMask;
         }
     }
@@ -1072,7 +1239,7 @@ template <class T> struct Ops {
     {
         const Node &x = g.nodes[n];
         const uint32_t no = x.n_out;
-        if (no > K.cap_copy) { fail(ERR_SCRATCH); return; }
+        if (no > K.cap_copy) { fail_at(__LINE__, ERR_SCRATCH); return; }
         for (uint32_t i = 0; i < no; ++i) K.copy[i] = out_ref(x, i) & kRefMask;      // a copy: the walk edits the node's list
         for (uint32_t i = 0; i < no && !failed(); ++i) walk_and_prune(K, K.copy[i], marked_only);
     }
@@ -1146,7 +1313,7 @@ template <class T> struct Ops {
                 }
             }
             team.sync();
-            if (n_hits > K.cap_hits / 2) { if (tid == 0) fail(ERR_SCRATCH); team.sync(); return; }
+            if (n_hits > K.cap_hits / 2) { if (tid == 0) fail_at(__LINE__, ERR_SCRATCH); team.sync(); return; }
             if (tid == 0) {
                 // first loop of the reference: nodes right_off .. m in path order; second: nodes min(left_off, m - 1) .. 0, backwards
                 for (uint32_t i = 0; i < n_hits && !failed(); ++i) if (K.hits[2 * i] >= h.right_off) run_node(K, K.hits[2 * i + 1], true);

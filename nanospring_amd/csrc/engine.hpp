@@ -5,6 +5,7 @@
 #include <dirent.h>
 #include <unistd.h>
 #include "consensus.hpp"
+#include "graph_dev.hpp"
 #include "host_util.hpp"
 #include "dist.hpp"
 #include <memory>
@@ -18,7 +19,6 @@
 
 namespace nsgpu {
 
-using cons::read_t;
 
 // A finished contig waiting for its edit emission (consensus + one edit script per read into the seven streams).  The
 // emission touches nothing but the contig's own graph, so it is taken off the builder's critical path: the builder moves
@@ -29,7 +29,7 @@ constexpr int kMaxGroups = 4;
 static inline int n_groups(const nsgpu_ctx *c) { return (int)c->sched_groups; }
 
 struct FinishedContig {
-    std::unique_ptr<cons::ContigGraph> g;     // null once emitted
+    std::unique_ptr<GraphBase> g;             // null once emitted
     cons::StreamSet out;
     double write_ms = 0, free_ms = 0;
 };
@@ -42,7 +42,8 @@ struct Builder {
     uint32_t defer_due = 0;
     uint32_t id = 0, gid = 0;                 // local index / global builder id
     int group = 0;                            // pipeline group (a function of gid only, so that it does not depend on the rank count)
-    std::unique_ptr<cons::ContigGraph> g;
+    std::unique_ptr<GraphBase> g;             // the contig's consensus DAG: in HBM (DevGraph) or, NSGPU_GRAPH=host, the pointer graph on the host
+    bool graph_flying = false;                // an update of the graph is in flight on the GPU (engine_early_updates)
     read_t cursor = 0;
     // contig walk (src/Consensus.cpp:51-95)
     ssize_t init_start = 0, len = 0, cur_pos = 0;
@@ -88,10 +89,11 @@ struct Builder {
     std::vector<std::unique_ptr<FinishedContig>> contigs;     // in the order they were finished = output order
     size_t n_queued = 0;                                      // contigs[0 .. n_queued) were handed to the emission queue
     uint64_t n_minhash = 0, n_minhash_new = 0, n_aligner = 0, n_align_calls = 0, n_contigs = 0, n_lone = 0;
-    double last_u = 0, last_m = 0;
+    double last_u = 0, last_m = 0, apply_t0 = 0;
     double cpu_ms = 0, max_ms = 0, last_ms = 0, write_ms = 0, dbg_w1 = 0, dbg_w2 = 0, dbg_w3 = 0, dbg_u = 0, dbg_m = 0, dbg_cyc = 0, dbg_init = 0, dbg_rc = 0, dbg_win = 0, dbg_start = 0, dbg_max_u = 0, dbg_max_m = 0, dbg_long_ms = 0;
     uint64_t dbg_long_n = 0;
     uint64_t dbg_c[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t dbg_g[2] = {0, 0};               // graph kernels: splits, excursions taken one at a time
 };
 
 struct Driver {
@@ -101,6 +103,11 @@ struct Driver {
     size_t offset;                     // avgReadLen / 4 (src/Consensus.cpp:54)
     std::vector<uint8_t> in_graph, rep;
     std::vector<Builder> B;
+    DevGraphShared *gsh = nullptr;     // pools and streams of the graphs in HBM (lives with the context)
+    std::atomic<int> graph_rc{NSGPU_OK};     // first failure of a graph update (checked between the engine's phases)
+    std::string graph_err;
+    std::mutex graph_err_m;
+    void graph_failed(int rc) { std::lock_guard<std::mutex> lk(graph_err_m); if (graph_rc.load() == NSGPU_OK) { graph_err = nsgpu_last_error(); graph_rc.store(rc); } }
 
     // read r as ReadData::getRead returns it; with the packed host mirror decoded into a per-thread buffer (valid until the thread's next call)
     const char *read_ptr(read_t r) const { static thread_local std::string buf; return mirror_read(c, r, buf); }
@@ -115,15 +122,15 @@ struct Driver {
     }
     void start_contig_inner(Builder &b, read_t r)
     {
-        b.g.reset(new cons::ContigGraph());
-        b.g->main_path.assign(read_ptr(r), read_len(r));
-        b.g->start_pos = 0;
-        b.g->end_pos = (ssize_t)read_len(r);
+        if (gsh) b.g.reset(new DevGraph(gsh, b.id)); else b.g.reset(new HostGraph());
+        b.g->path_mut().assign(read_ptr(r), read_len(r));
+        b.g->set_span(0, (ssize_t)read_len(r));
         b.g->first_read = r + id_base;       // graph / stream ids are global, array indices local
         b.cursor = r + 1;
         b.init_start = 0;
-        b.len = b.g->end_pos - b.g->start_pos;
-        b.cur_pos = b.g->start_pos;
+        b.len = b.g->end_pos() - b.g->start_pos();
+        b.cur_pos = b.g->start_pos();
+        b.graph_flying = false;
         b.right_phase = true, b.edges_too_many = false, b.window_open = false;
         b.idx_valid = false, b.sp_ready = false;
         b.mz.clear(), b.mz_str.clear();          // a new consensus: nothing to splice into
@@ -136,7 +143,7 @@ struct Driver {
 
     void finish_contig(Builder &b)
     {
-        cons::ContigGraph &g = *b.g;
+        GraphBase &g = *b.g;
         std::unique_ptr<FinishedContig> fc(new FinishedContig());
         if (g.num_reads() == 0) {
             g.write_read_lone(fc->out);
@@ -146,7 +153,11 @@ struct Driver {
             b.g.reset();
         } else {
             b.dbg_cyc += g.dbg_cycles_ms;
-            b.dbg_c[0] += g.dbg_cycles_calls, b.dbg_c[1] += g.dbg_cycles_skipped, b.dbg_c[2] += g.dbg_spliced, b.dbg_c[3] += g.dbg_cycles_idle, b.dbg_c[4] += g.dbg_walked_nodes, b.dbg_c[5] += g.dbg_cycles_listed;
+            for (int i = 0; i < 6; ++i) b.dbg_c[i] += g.dbg[i];
+            b.dbg_g[0] += g.dbg[6], b.dbg_g[1] += g.dbg[7];
+            // (a graph in HBM: its arrays start their way back to the host now; the emission task waits for them)
+            const int rc = g.emit_begin();
+            if (rc != NSGPU_OK) graph_failed(rc);
             fc->g = std::move(b.g);
         }
         b.contigs.push_back(std::move(fc));
@@ -158,7 +169,7 @@ struct Driver {
     {
         if (!fc.g) return;
         const double t0 = now_ms();
-        cons::ContigGraph &g = *fc.g;
+        GraphBase &g = *fc.g;
         g.write_main_path(fc.out);
         const std::function<cons::ReadBases(cons::read_t)> src = [this](cons::read_t id) {
             const read_t r = id - id_base;
@@ -181,11 +192,12 @@ struct Driver {
     }
     bool open_window_inner(Builder &b)
     {
-        cons::ContigGraph &g = *b.g;
-        const ssize_t off = b.cur_pos - g.start_pos;
-        if (b.len == 0 || off < 0 || off >= (ssize_t)g.main_path.size()) return false;
-        const size_t n = (ssize_t)g.main_path.size() >= off + b.len ? (size_t)b.len : g.main_path.size() - (size_t)off;
-        b.win[0].assign(g.main_path, (size_t)off, n);
+        GraphBase &g = *b.g;
+        const std::string &mp = g.path();
+        const ssize_t off = b.cur_pos - g.start_pos();
+        if (b.len == 0 || off < 0 || off >= (ssize_t)mp.size()) return false;
+        const size_t n = (ssize_t)mp.size() >= off + b.len ? (size_t)b.len : mp.size() - (size_t)off;
+        b.win[0].assign(mp, (size_t)off, n);
         cons::reverse_complement(b.win[0], b.win[1]);
         b.strand = 0, b.ci = 0, b.strand_counted = false;
         b.window_open = true;
@@ -197,14 +209,14 @@ struct Driver {
     // opened (state WAIT_FILTER) or the contig is finished (state NEED_CONTIG)
     void walk(Builder &b, bool window_just_done)
     {
-        cons::ContigGraph &g = *b.g;
+        GraphBase &g = *b.g;
         const bool usable = b.len >= 32 && !rep[g.first_read - id_base];
         for (;;) {
             if (b.right_phase) {
                 if (window_just_done) {
                     b.cur_pos += (ssize_t)offset;
                     window_just_done = false;
-                    if (b.cur_pos + b.len > g.end_pos) b.right_phase = false;
+                    if (b.cur_pos + b.len > g.end_pos()) b.right_phase = false;
                     else if (g.num_edges() >= edge_thr) b.edges_too_many = true, b.right_phase = false;
                     if (!b.right_phase) { b.cur_pos = b.init_start - (ssize_t)offset; continue; }
                 }
@@ -214,7 +226,7 @@ struct Driver {
             } else {
                 if (window_just_done) { b.cur_pos -= (ssize_t)offset; window_just_done = false; }
                 if (!(usable && !b.edges_too_many)) break;
-                if (b.cur_pos < g.start_pos) break;
+                if (b.cur_pos < g.start_pos()) break;
                 if (g.num_edges() >= edge_thr) { b.edges_too_many = true; break; }
                 if (open_window(b)) return;
                 window_just_done = true;
@@ -226,7 +238,7 @@ struct Driver {
     // candidate loop of addRelatedReads (src/Consensus.cpp:185-246) up to the next alignment request
     void next_candidate(Builder &b)
     {
-        cons::ContigGraph &g = *b.g;
+        GraphBase &g = *b.g;
         for (; b.strand < 2; ++b.strand, b.ci = 0, b.strand_counted = false) {
             if (!b.strand_counted) { b.n_minhash += b.cand[b.strand].size(); b.strand_counted = true; }
             for (; b.ci < b.cand[b.strand].size(); ++b.ci) {
@@ -277,31 +289,30 @@ struct Driver {
     }
     // the accepted read into the contig's graph, the new consensus (src/Consensus.cpp:319-331).  Touches nothing but the builder's own graph:
     // the engine may run it as soon as the alignment is there and its claim cannot fail (engine_early_updates), ahead of the host phase.
-    void apply_alignment(Builder &b)
+    // In two halves: the graph in HBM takes the read (one kernel on a stream of its own) and reports when it is done.
+    void apply_submit(Builder &b)
     {
-        cons::ContigGraph &g = *b.g;
-        if (g.num_reads() == 0) {                       // src/Consensus.cpp:319-324
-            const double i0 = now_ms();
-            const std::string seed = g.main_path;
-            g.main_path.clear();
-            g.initialize(seed, g.first_read, 0);
-            g.calculate_main_path_greedy();
-            b.chg_lb = 0;
-            b.dbg_init += now_ms() - i0;
+        b.apply_t0 = now_ms();
+        const int rc = b.g->submit(b.query, b.aln, b.pend + id_base, b.strand == 1);
+        if (rc != NSGPU_OK) graph_failed(rc);
+        b.graph_flying = rc == NSGPU_OK;
+    }
+    void apply_complete(Builder &b)
+    {
+        GraphBase &g = *b.g;
+        if (b.graph_flying) {
+            const int rc = g.complete();
+            if (rc != NSGPU_OK) graph_failed(rc);
+            b.graph_flying = false;
         }
-        const double u0 = now_ms();
-        g.update_graph(b.query, b.aln.edits, (ssize_t)b.aln.begin_offset, (ssize_t)b.aln.end_offset, b.pend + id_base, (long)b.aln.rel_pos, b.strand == 1);
-        const double u1 = now_ms();
-        g.calculate_main_path_greedy();
         if (g.path_changed_from < b.chg_lb) b.chg_lb = g.path_changed_from;
         g.path_changed_from = (size_t)-1;
-        const double u2 = now_ms();
-        b.dbg_u += u1 - u0, b.dbg_m += u2 - u1;
-        b.last_u = u1 - u0, b.last_m = u2 - u1;
-        if (u1 - u0 > b.dbg_max_u) b.dbg_max_u = u1 - u0;
-        if (u2 - u1 > b.dbg_max_m) b.dbg_max_m = u2 - u1;
+        const double dt = now_ms() - b.apply_t0;
+        b.dbg_u += dt, b.last_u = dt;
+        if (dt > b.dbg_max_u) b.dbg_max_u = dt;
         b.idx_valid = false, b.sp_ready = false;
     }
+    void apply_alignment(Builder &b) { apply_submit(b); apply_complete(b); }
 };
 
 // ---------------------------------------------------------------------------
