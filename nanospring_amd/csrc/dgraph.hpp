@@ -76,8 +76,9 @@ struct Hdr {
     uint32_t ending_id, starting_id;                  // the smallest read id on the path's last / first edge
     uint32_t st_splits, st_detours, st_walked, st_seq_exc, st_cycles_run, st_full_walk, st_dis;
     uint32_t stage;                                   // of the recompute: 2 = choosing (nothing changed yet), 3 = changing the graph
-    uint32_t dbg_flags;                               // tests: 1 = excursions one at a time, 2 = removeCycles by the reference's full walk, 4 = a longer path always moves its left part
+    uint32_t dbg_flags;                               // tests: 1 = excursions one at a time, 2 = removeCycles by the reference's full walk, 4 = a longer path always moves its left part, 8 = chain runs of splitPath with a team of one too
     uint32_t err_line;                                // where the first error was raised (dgraph.hpp line)
+    uint32_t st_search, st_steps, st_idscan, st_ctx;   // thread 0's loops: rejoin searches (entries looked at), detour steps, read ids compared in splitPath, its contexts
     uint32_t st_tm[8];                                // ticks of the team's clock by phase: tables, runs, excursions, choices, stitching, writing, flags + P/S, removeCycles
     uint32_t pad_[1];
 };
@@ -110,6 +111,13 @@ struct HostTeam {
     DG_HD uint32_t min_all(uint32_t v) { return v; }
     DG_HD uint32_t max_all(uint32_t v) { return v; }
     DG_HD uint32_t clock() const { return 0; }                                      // a free-running counter (debug report)
+    DG_HD void add_to(uint32_t *p, uint32_t v) { *p += v; }                         // a sum several threads contribute to
+    DG_HD void min_to(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }              // a minimum ...
+    // Thread 0 working alone while the others wait for its orders (removeCycles): on the device a barrier belongs to a whole wavefront, so the
+    // lanes that share thread 0's wavefront sit such a stretch out and the team that takes the orders is thread 0 + the other wavefronts.
+    DG_HD bool helper() const { return false; }                                      // this thread takes thread 0's orders
+    DG_HD uint32_t crew_rank() const { return 0; }                                   // rank among thread 0 + the helpers
+    DG_HD uint32_t crew_size() const { return 1; }
 };
 
 // excursion record (8 words) in the update's tables
@@ -328,10 +336,12 @@ template <class T> struct Ops {
         ++h.live_edges;
         return e;
     }
-    // removeEdge (:861-876): the source side drops the FIRST out-edge that leads to the same sink
-    DG_HD void remove_edge(uint32_t e, bool keep_in_source, bool keep_in_sink)
+    // removeEdge (:861-876): the source side drops the FIRST out-edge that leads to the same sink.  The quiet form leaves the graph's counters
+    // to the caller (returns the change of n_multi): the lanes of a chain run (split_chain_run) sum theirs up.
+    DG_HD int32_t remove_edge_quiet(uint32_t e, bool keep_in_source, bool keep_in_sink)
     {
         Edge &x = g.edges[e];
+        int32_t d_multi = 0;
         if (!keep_in_source) {
             const Node &s = g.nodes[x.src];
             for (uint32_t i = 0; i < s.n_out; ++i) if (g.edges[out_ref(s, i) & kRefMask].sink == x.sink) { out_erase(x.src, i); break; }
@@ -340,9 +350,14 @@ template <class T> struct Ops {
             const bool was = multi_in_side(x.sink);
             const Node &t = g.nodes[x.sink];
             for (uint32_t i = 0; i < t.n_in; ++i) if (in_ref(t, i) == e) { in_erase(x.sink, i); break; }
-            g.h->n_multi += (uint32_t)multi_in_side(x.sink) - (uint32_t)was;
+            d_multi = (int32_t)multi_in_side(x.sink) - (int32_t)was;
         }
         x.count = 0, x.src = x.sink = NIL;       // (ids are not handed out again: a dead edge stays dead)
+        return d_multi;
+    }
+    DG_HD void remove_edge(uint32_t e, bool keep_in_source, bool keep_in_sink)
+    {
+        g.h->n_multi += (uint32_t)remove_edge_quiet(e, keep_in_source, keep_in_sink);
         --g.h->live_edges;
     }
     // removeNode (:878-897)
@@ -358,7 +373,7 @@ template <class T> struct Ops {
         --h.live_nodes;
     }
     // removeReadsFromEdge (:843-859): the ids of `rm` leave the edge; an edge without reads goes
-    DG_HD void remove_reads_from_edge(uint32_t ei, const uint32_t *rm, uint32_t n_rm)
+    DG_HD uint32_t drop_reads(uint32_t ei, const uint32_t *rm, uint32_t n_rm)        // the ids left
     {
         Edge &e = g.edges[ei];
         const uint32_t n = e.count;
@@ -378,10 +393,12 @@ template <class T> struct Ops {
         e.count = w;
         e.tail = w > kEdgeInl ? wc : NIL;
         if (w <= kEdgeInl) e.head = NIL;
-        if (w == 0) remove_edge(ei, false, false);
+        return w;
     }
+    DG_HD void remove_reads_from_edge(uint32_t ei, const uint32_t *rm, uint32_t n_rm) { if (drop_reads(ei, rm, n_rm) == 0) remove_edge(ei, false, false); }
 
     DG_HD uint32_t path_node(uint32_t i) const { return g.pn[g.h->path_off + i]; }
+    DG_HD uint32_t *order() const { return g.wk + g.h->cap_wk - 64; }       // what thread 0 tells its helpers (the last words of the work area)
 
     // ================================================================================================================
     // initialize (:135-159) + the first calculateMainPathGreedy: the seed read as a chain, all of it the main path
@@ -804,6 +821,65 @@ template <class T> struct Ops {
     DG_HD const uint32_t *upd_ops() const { return g.wk; }
     DG_HD const uint32_t *upd_op_at() const { return g.wk + (g.h->upd_n_ops + 1); }
 
+    // Thread 0 asks its helpers: how far does the stretch of side nodes behind node X0 go on with CONSECUTIVE ids -- node X0 + i with one way on
+    // (edge E0 + i, which leads to node X0 + i + 1)?  Chains are made with consecutive ids (an excursion's nodes, the copies of a split), so a
+    // walk along one -- the greedy walk turning into a side branch, splitPath looking for the end of a by-passed stretch -- need not chase
+    // pointers node by node: the helpers look at a few hundred nodes at once.  kind 0: forward, nodes with one edge in and one out; 1: backward
+    // (in-edges E0 - i from node X0 - i - 1); 2: forward, any number of edges in, and the stretch is written into the chain arrays (from index
+    // order[7], the edge into X0 being order[5]).  Returns the number of nodes of the stretch (0: X0 itself does not qualify).
+    DG_HD uint32_t probe(uint32_t kind, uint32_t X0, uint32_t E0, uint32_t maxn, uint32_t e_into, uint32_t fill_at)
+    {
+        uint32_t *ord = order();
+        ord[1] = kind, ord[2] = X0, ord[3] = E0, ord[4] = maxn, ord[5] = e_into, ord[6] = maxn, ord[7] = fill_at;
+        (void)team.bcast(2);
+        probe_run();
+        return ord[6];
+    }
+    DG_HD void probe_run()
+    {
+        const Hdr &h = *g.h;
+        uint32_t *ord = order();
+        const uint32_t kind = ord[1], X0 = ord[2], E0 = ord[3], maxn = ord[4];
+        const uint32_t cr = team.crew_rank(), nc = team.crew_size();
+        for (uint32_t base = 0; base < maxn; base += nc) {
+            const uint32_t i = base + cr;
+            if (i < maxn) {
+                bool ok = false;
+                if (kind != 1) {
+                    const uint64_t n = (uint64_t)X0 + i, e = (uint64_t)E0 + i;
+                    if (n < h.n_nodes && e < h.n_edges) {
+                        const Node &nd = g.nodes[n];
+                        ok = !nd.on_main && nd.n_out == 1 && (nd.out[0] & kRefMask) == e && (kind == 2 || nd.n_in == 1) && g.edges[e].sink == n + 1;
+                    }
+                } else if (i < X0 && i <= E0) {
+                    const uint32_t n = X0 - i, e = E0 - i;
+                    const Node &nd = g.nodes[n];
+                    ok = !nd.on_main && nd.n_in == 1 && nd.in[0] == e && g.edges[e].src == n - 1;
+                }
+                if (!ok) team.min_to(&ord[6], i);
+            }
+            team.sync();
+            if (ord[6] < base + nc) break;
+        }
+        team.sync();
+        if (kind == 2) {
+            const CycWk K = cyc_wk();
+            const uint32_t L = ord[6], at = ord[7];
+            for (uint32_t i = cr; i < L; i += nc) K.chain[at + i] = i ? E0 + i - 1 : ord[5], K.chain[K.cap_chain + at + i] = X0 + i;
+            team.sync();
+        }
+    }
+    // the threads that take thread 0's orders while it works alone (1: a chain run of splitPath, 2: a probe; 0: done)
+    DG_HD void helpers_loop()
+    {
+        for (;;) {
+            const uint32_t o = team.bcast(0);
+            if (o == 0) break;
+            if (o == 1) split_chain_run(cyc_wk()); else probe_run();
+        }
+    }
+    DG_HD bool probing() const { return team.crew_size() > 1 || (g.h->dbg_flags & 8u); }
+
     // thread 0: the walk from old node R to the right.  D: (index, chosen edge) of the old nodes in [R, m] whose choice is not the path's edge, ascending.
     DG_HD void stitch_forward(Stitch &S, const uint32_t *D, uint32_t n_dis, uint32_t R, uint32_t m, uint32_t off)
     {
@@ -816,6 +892,7 @@ template <class T> struct Ops {
             if (c > pos) emit_piece(S, PC_OLD, pos, c, 0, c - pos);
             pos = c;
             ++h.st_detours;
+            uint32_t streak = 0;
             for (;;) {
                 if (e == NIL) { S.ended = true; emit_gap(S, pos + 1, m + 1); break; }
                 if (e >= h.upd_edges0) {                        // created by this update: a chain whose choices are forced
@@ -841,15 +918,26 @@ template <class T> struct Ops {
                 const uint32_t was_on = g.nodes[nx].on_main;
                 emit_piece(S, PC_EDGE, e, was_on, nx, 1);
                 ++h.st_walked;
+                if (!was_on && probing()) {                    // a side branch: a stretch of it at once when its ids run on
+                    const Node &sn = g.nodes[nx];
+                    if (sn.n_out == 1 && sn.n_in == 1 && ++streak >= 2) {
+                        const uint32_t o0 = sn.out[0] & kRefMask;
+                        const uint32_t L = probe(0, nx, o0, 4 * team.crew_size() + 60, 0, 0);
+                        streak = 0;
+                        if (L >= 2) { emit_piece(S, PC_CHAIN, o0, L - 1, nx + 1, L - 1); h.st_walked += L - 1; e = o0 + L - 1; continue; }
+                    }
+                }
                 if (was_on) {
                     uint32_t j = pos + 1;
                     while (j <= m && g.pn[off + j] != nx) ++j;
+                    h.st_search += j - pos;
                     if (j > m) { fail_at(__LINE__, ERR_WALK); break; }
                     emit_gap(S, pos + 1, j);
                     pos = j;
                     break;
                 }
                 e = best_out(nx);
+                ++h.st_steps;
                 if (failed()) break;
             }
         }
@@ -868,6 +956,7 @@ template <class T> struct Ops {
             if (c < pos) emit_piece(S, PC_OLD, c, pos, 0, pos - c);
             pos = c;
             ++h.st_detours;
+            uint32_t streak = 0;
             for (;;) {
                 if (e == NIL) { S.ended = true; emit_gap(S, 0, pos); break; }
                 uint32_t nx = NIL, known_idx = NIL;
@@ -900,15 +989,25 @@ template <class T> struct Ops {
                 const uint32_t was_on = g.nodes[nx].on_main;
                 emit_piece(S, PC_EDGE, e, was_on, nx, 1);
                 ++h.st_walked;
+                if (!was_on && probing()) {
+                    const Node &sn = g.nodes[nx];
+                    if (sn.n_in == 1 && ++streak >= 2) {
+                        const uint32_t i0 = sn.in[0];
+                        const uint32_t L = probe(1, nx, i0, 4 * team.crew_size() + 60, 0, 0);
+                        streak = 0;
+                        if (L >= 2) { emit_piece(S, PC_CHAIN, i0, L - 1, nx - 1, L - 1); h.st_walked += L - 1; e = i0 - (L - 1); continue; }
+                    }
+                }
                 if (was_on) {
                     uint32_t j = known_idx;
-                    if (j == NIL) { j = pos; while (j > 0 && g.pn[off + j - 1] != nx) --j; j = j > 0 ? j - 1 : NIL; }
+                    if (j == NIL) { j = pos; while (j > 0 && g.pn[off + j - 1] != nx) --j; h.st_search += pos - j; j = j > 0 ? j - 1 : NIL; }
                     if (j == NIL || j >= pos || g.pn[off + j] != nx) { fail_at(__LINE__, ERR_WALK); break; }
                     emit_gap(S, j + 1, pos);
                     pos = j;
                     break;
                 }
                 e = best_in(nx);
+                ++h.st_steps;
                 if (failed()) break;
             }
         }
@@ -966,7 +1065,7 @@ template <class T> struct Ops {
         auto lap = [&](int i) { const uint32_t now = team.clock(); if (tid == 0) h.st_tm[i] += now - tk; tk = now; };
         if (Lf > R || R > m || h.upd_wk + 4096 > h.cap_wk) { if (tid == 0) fail_at(__LINE__, Lf > R || R > m ? ERR_WALK : ERR_SCRATCH); team.sync(); return; }
         uint32_t *W = g.wk + h.upd_wk;
-        const uint32_t wcap = h.cap_wk - h.upd_wk;
+        const uint32_t wcap = h.cap_wk - h.upd_wk - 64;
         uint32_t *D = W;                                     // disagreements, 2 words each
         const uint32_t cap_d = wcap / 4;                     // entries
         Stitch F, B;
@@ -1009,7 +1108,7 @@ template <class T> struct Ops {
         team.sync();
         if (n_dis > cap_d) { if (tid == 0) fail_at(__LINE__, ERR_SCRATCH); team.sync(); return; }
         lap(3);
-        if (tid == 0) { h.st_dis += n_dis; stitch_forward(F, D, n_dis, R, m, off); }
+        if (tid == 0) { h.st_dis += n_dis; stitch_forward(F, D, n_dis, R, m, off); (void)team.bcast(0); } else if (team.helper()) helpers_loop();
         team.sync();
         if (failed()) return;
         F.n_pc = team.bcast(F.n_pc), F.len = team.bcast(F.len), F.n_gp = team.bcast(F.n_gp), F.gap_len = team.bcast(F.gap_len), F.ended = team.bcast(F.ended ? 1u : 0u) != 0;
@@ -1028,7 +1127,7 @@ template <class T> struct Ops {
         team.sync();
         if (n_dis > cap_d) { if (tid == 0) fail_at(__LINE__, ERR_SCRATCH); team.sync(); return; }
         lap(3);
-        if (tid == 0) { h.st_dis += n_dis; stitch_backward(B, D, n_dis, Lf, off); }
+        if (tid == 0) { h.st_dis += n_dis; stitch_backward(B, D, n_dis, Lf, off); (void)team.bcast(0); } else if (team.helper()) helpers_loop();
         team.sync();
         if (failed()) return;
         B.n_pc = team.bcast(B.n_pc), B.len = team.bcast(B.len), B.n_gp = team.bcast(B.n_gp), B.gap_len = team.bcast(B.gap_len), B.ended = team.bcast(B.ended ? 1u : 0u) != 0;
@@ -1129,12 +1228,12 @@ template <class T> struct Ops {
     // ================================================================================================================
     // removeCycles (:653-691), walkAndPrune (:693-714), splitPath (:716-807)
     // ================================================================================================================
-    struct CycWk { uint32_t *todo, *roots, *hits, *estack, *ctx, *lists, *copy, *defer; uint32_t cap_todo, cap_roots, cap_hits, cap_estack, cap_ctx, cap_lists, cap_copy, cap_defer; };
+    struct CycWk { uint32_t *todo, *roots, *hits, *estack, *ctx, *lists, *copy, *defer, *chain, *order; uint32_t cap_todo, cap_roots, cap_hits, cap_estack, cap_ctx, cap_lists, cap_copy, cap_defer, cap_chain; };
     DG_HD CycWk cyc_wk() const
     {
         const Hdr &h = *g.h;
         uint32_t *W = g.wk + h.upd_wk;
-        const uint32_t wcap = h.cap_wk - h.upd_wk, u = wcap / 16;
+        const uint32_t wcap = h.cap_wk - h.upd_wk - 64, u = wcap / 16;
         CycWk c;
         c.todo = W, c.cap_todo = u;
         c.roots = W + u, c.cap_roots = u;
@@ -1143,7 +1242,9 @@ template <class T> struct Ops {
         c.ctx = W + 6 * u, c.cap_ctx = 2 * u / 8;          // 8 words each
         c.lists = W + 8 * u, c.cap_lists = 4 * u;
         c.copy = W + 12 * u, c.cap_copy = u;
-        c.defer = W + 13 * u, c.cap_defer = 3 * u;
+        c.defer = W + 13 * u, c.cap_defer = 2 * u;
+        c.chain = W + 15 * u, c.cap_chain = u / 3;            // a run of a chain: its edges, its nodes, its masks
+        c.order = order();
         return c;
     }
 
@@ -1187,8 +1288,51 @@ template <class T> struct Ops {
                 }
             }
             lists_top = own_off + own_n;
+            h.st_idscan += c[3] * g.edges[e].count; ++h.st_ctx;
             c[4] = own_off, c[5] = own_n, c[6] = 1;
             while (own_n && !failed()) {
+                // A stretch of nodes with one way out each (a by-passed piece of the old path, typically): not one step of this loop after the
+                // other -- the whole team takes the stretch at once (split_chain_run)
+                if (own_n <= kEdgeInl && (team.crew_size() > 1 || (h.dbg_flags & 8u))) {
+                    uint32_t k = 0, ce = e;
+                    const uint32_t lim = K.cap_chain < 4096 ? K.cap_chain : 4096;
+                    uint32_t since = 0;
+                    while (k < lim) {
+                        const uint32_t X = g.edges[ce].sink;
+                        const Node &xn = g.nodes[X];
+                        if (xn.on_main || xn.n_out != 1) break;
+                        const uint32_t o0 = xn.out[0] & kRefMask;
+                        if (++since >= 3 && probing()) {          // the rest of the stretch by its ids, a few hundred nodes at a time
+                            const uint32_t L = probe(2, X, o0, lim - k < 4 * team.crew_size() + 60 ? lim - k : 4 * team.crew_size() + 60, ce, k);
+                            since = L >= 32 ? 3 : 0;
+                            if (L >= 1) { k += L; ce = o0 + L - 1; continue; }
+                        }
+                        K.chain[k] = ce, K.chain[K.cap_chain + k] = X;
+                        ++k;
+                        ce = o0;
+                    }
+                    if (k >= 8) {
+                        if (n_def + k > K.cap_defer || (uint64_t)h.n_nodes + k > h.cap_nodes || (uint64_t)h.n_edges + k > h.cap_edges) { fail_at(__LINE__, n_def + k > K.cap_defer ? ERR_SCRATCH : ERR_CAP); return; }
+                        K.order[1] = new_pre, K.order[2] = k, K.order[3] = own_off, K.order[4] = own_n, K.order[5] = n_def;
+                        (void)team.bcast(1);
+                        split_chain_run(K);
+                        const uint32_t k_eff = K.order[6];
+                        n_def += k_eff;
+                        h.st_ctx += k_eff;
+                        if (k_eff) {
+                            new_pre = h.n_nodes - 1;                      // the copy of the stretch's last node
+                            e = k_eff < k ? K.chain[k_eff] : ce;
+                            // what is left of the reads behind the stretch, and which of them go down the next edge
+                            const uint32_t mk = K.chain[2 * K.cap_chain + k_eff - 1];
+                            const Edge &ed = g.edges[e];
+                            uint32_t w = 0;
+                            for (uint32_t i = 0; i < own_n; ++i) { const uint32_t id = K.lists[own_off + i]; if (((mk >> i) & 1u) && edge_has(ed, id)) K.lists[own_off + w++] = id; }
+                            own_n = w, lists_top = own_off + w;
+                            c[5] = own_n;
+                            continue;
+                        }
+                    }
+                }
                 const uint32_t old_cur = g.edges[e].sink;
                 remove_reads_from_edge(e, K.lists + own_off, own_n);
                 if (g.nodes[old_cur].on_main) { new_edge(new_pre, old_cur, K.lists + own_off, own_n); c[7] = old_cur; break; }
@@ -1203,6 +1347,7 @@ template <class T> struct Ops {
                     const Edge &ed = g.edges[e];
                     uint32_t w = 0;
                     for (uint32_t i = 0; i < own_n; ++i) { const uint32_t id = K.lists[own_off + i]; if (edge_has(ed, id)) K.lists[own_off + w++] = id; }
+                    h.st_idscan += own_n * ed.count; ++h.st_ctx;
                     own_n = w, lists_top = own_off + w;
                     c[5] = own_n;
                     continue;
@@ -1217,6 +1362,63 @@ template <class T> struct Ops {
             }
         }
         for (uint32_t i = 0; i < n_def && !failed(); ++i) { const uint32_t oc = K.defer[i]; if (g.nodes[oc].n_in == 0 && g.nodes[oc].n_out == 0 && g.nodes[oc].on_main == 0) remove_node(oc); }
+    }
+    // The team's part of split_path for a stretch of k nodes with one way out each: edges chain[0 .. k), nodes chain[cap + i], the reads O = lists[own_off ..
+    // own_off + own_n) (at most 11), the node in front of the copy new_pre.  What the loop in split_path does node by node -- take the reads off the old
+    // edge, copy the node, join the copy to the copy before it -- the lanes do for all nodes at once; which reads are still on the stretch at node i is the
+    // AND of the edges' membership masks up to i (thread 0, one pass over k words).  Ids as the loop would hand them out: in order along the stretch.
+    // order[]: 1 new_pre, 2 k, 3 own_off, 4 own_n, 5 n_def; out: 6 k_eff (the nodes copied: up to where the reads run out)
+    DG_HD void split_chain_run(const CycWk &K)
+    {
+        Hdr &h = *g.h;
+        const uint32_t tid = team.tid(), cr = team.crew_rank(), nc = team.crew_size();
+        const uint32_t new_pre = K.order[1], k = K.order[2], own_off = K.order[3], own_n = K.order[4], n_def = K.order[5];
+        const uint32_t *CE = K.chain, *CX = K.chain + K.cap_chain;
+        uint32_t *M = K.chain + 2 * K.cap_chain;
+        uint32_t O[kEdgeInl];
+        for (uint32_t q = 0; q < own_n; ++q) O[q] = K.lists[own_off + q];
+        for (uint32_t i = cr; i < k; i += nc) {
+            const Edge &ed = g.edges[CE[i]];
+            uint32_t mk = 0;
+            for (uint32_t q = 0; q < own_n; ++q) if (edge_has(ed, O[q])) mk |= 1u << q;
+            M[i] = mk;
+        }
+        team.sync();
+        if (tid == 0) {
+            uint32_t acc = (1u << own_n) - 1u, k_eff = 0;
+            for (; k_eff < k; ++k_eff) { acc &= M[k_eff]; if (!acc) break; M[k_eff] = acc; }
+            K.order[6] = k_eff, K.order[7] = 0, K.order[8] = 0;
+        }
+        team.sync();
+        const uint32_t k_eff = K.order[6];
+        const uint32_t nbase = h.n_nodes, ebase = h.n_edges;
+        uint32_t removed = 0, unmulti = 0;
+        for (uint32_t i = cr; i < k_eff; i += nc) {
+            const uint32_t mk = M[i], X = CX[i], oe = CE[i];
+            uint32_t rm[kEdgeInl], n_rm = 0;
+            for (uint32_t q = 0; q < own_n; ++q) if ((mk >> q) & 1u) rm[n_rm++] = O[q];
+            if (drop_reads(oe, rm, n_rm) == 0) { const int32_t d = remove_edge_quiet(oe, false, false); ++removed; if (d < 0) ++unmulti; }
+            const uint32_t nid = nbase + i, ne = ebase + i;
+            Node &nd = g.nodes[nid];
+            nd.out_ext = nd.in_ext = NIL, nd.base = g.nodes[X].base, nd.on_main = 0;
+            g.mark[nid] = 0;
+            nd.n_in = 1, nd.in[0] = ne;
+            if (i + 1 < k_eff) nd.n_out = 1, nd.out[0] = (ne + 1) | (code_of(g.nodes[CX[i + 1]].base) << 29);
+            else nd.n_out = 0;
+            Edge &x = g.edges[ne];
+            x.src = i ? nid - 1 : new_pre, x.sink = nid, x.count = n_rm, x.head = x.tail = NIL;
+            for (uint32_t q = 0; q < n_rm; ++q) x.ids[q] = rm[q];
+            K.defer[n_def + i] = X;
+        }
+        if (removed) team.add_to(&K.order[7], removed);
+        if (unmulti) team.add_to(&K.order[8], unmulti);
+        team.sync();
+        if (tid == 0 && k_eff) {
+            out_push(new_pre, ebase | (code_of(g.nodes[CX[0]].base) << 29));
+            h.n_nodes += k_eff, h.live_nodes += k_eff, h.n_edges += k_eff, h.live_edges += k_eff - K.order[7];
+            h.n_multi -= K.order[8];
+        }
+        team.sync();
     }
     DG_HD void walk_and_prune(const CycWk &K, uint32_t e0, bool marked_only)
     {
@@ -1319,12 +1521,16 @@ template <class T> struct Ops {
                 for (uint32_t i = 0; i < n_hits && !failed(); ++i) if (K.hits[2 * i] >= h.right_off) run_node(K, K.hits[2 * i + 1], true);
                 const uint32_t l0 = h.left_off < m ? h.left_off : m - 1;
                 for (uint32_t i = n_hits; i-- > 0 && !failed();) if (K.hits[2 * i] <= l0 && K.hits[2 * i] < m) run_node(K, K.hits[2 * i + 1], true);
-            }
-        } else if (mode == 2 && tid == 0) {
-            for (uint32_t i = h.right_off; i <= m && !failed(); ++i) run_node(K, g.pn[off + i], false);
-            for (uint32_t i = (h.left_off < m ? h.left_off : m - 1) + 1; i-- > 0 && !failed();) run_node(K, g.pn[off + i], false);
-            // (what is left are nodes the walks cannot reach; the list starts over with them)
-            if (h.multi_n > h.cap_multi) h.multi_n = 0;
+                (void)team.bcast(0);
+            } else if (team.helper()) helpers_loop();
+        } else if (mode == 2) {
+            if (tid == 0) {
+                for (uint32_t i = h.right_off; i <= m && !failed(); ++i) run_node(K, g.pn[off + i], false);
+                for (uint32_t i = (h.left_off < m ? h.left_off : m - 1) + 1; i-- > 0 && !failed();) run_node(K, g.pn[off + i], false);
+                // (what is left are nodes the walks cannot reach; the list starts over with them)
+                if (h.multi_n > h.cap_multi) h.multi_n = 0;
+                (void)team.bcast(0);
+            } else if (team.helper()) helpers_loop();
         }
         team.sync();
     }

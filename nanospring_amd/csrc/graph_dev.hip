@@ -16,6 +16,11 @@ struct DevTeam {
     __device__ uint32_t *shared() { return sh; }
     __device__ uint32_t shared_words() const { return kDgSharedWords; }
     __device__ uint32_t clock() const { return (uint32_t)wall_clock64(); }       // 100 MHz
+    __device__ void add_to(uint32_t *p, uint32_t v) { atomicAdd(p, v); }
+    __device__ void min_to(uint32_t *p, uint32_t v) { atomicMin(p, v); }
+    __device__ bool helper() const { return threadIdx.x >= 64u; }
+    __device__ uint32_t crew_rank() const { return threadIdx.x == 0 ? 0u : threadIdx.x - 63u; }
+    __device__ uint32_t crew_size() const { return blockDim.x > 64u ? blockDim.x - 63u : 1u; }
     __device__ uint32_t tid() const { return threadIdx.x; }
     __device__ uint32_t size() const { return blockDim.x; }
     __device__ void sync() { __syncthreads(); }
@@ -148,7 +153,9 @@ __global__ __launch_bounds__(kDgThreads) void dg_serve_kernel(DgSlot *const *slo
     __syncthreads();
     const DgSlot &L = *reinterpret_cast<const DgSlot *>(slot_w);
     const dg::G g = L.g;
-    DevTeam t{lds, shm};
+    uint32_t *lp = lds, *sp = shm;
+    asm volatile("" : "+s"(lp), "+s"(sp));            // (keeps the compiler from folding the team into a constant it cannot initialise)
+    DevTeam t{lp, sp};
     if (cmd == DG_CMD_INIT_UPDATE) {
         if (threadIdx.x == 0) { uint32_t *w = reinterpret_cast<uint32_t *>(g.h); for (uint32_t i = 0; i < sizeof(dg::Hdr) / 4; ++i) w[i] = 0; }
         __syncthreads();
@@ -539,6 +546,8 @@ int DevGraph::complete()
         sh_->hist[bk] += 1;
         if (tot >= 200000) sh_->slow_phase[worst_i] += 1;                            // updates of 2 ms and more: by their longest phase
     }
+    sh_->cnt[0] += hdr_.st_search - cnt_seen_[0], sh_->cnt[1] += hdr_.st_steps - cnt_seen_[1], sh_->cnt[2] += hdr_.st_idscan - cnt_seen_[2], sh_->cnt[3] += hdr_.st_ctx - cnt_seen_[3];
+    cnt_seen_[0] = hdr_.st_search, cnt_seen_[1] = hdr_.st_steps, cnt_seen_[2] = hdr_.st_idscan, cnt_seen_[3] = hdr_.st_ctx;
     dbg[0] += 1, dbg[1] = dbg[0] - hdr_.st_cycles_run, dbg[2] = hdr_.st_detours, dbg[4] = hdr_.st_walked, dbg[5] = hdr_.st_cycles_run - hdr_.st_full_walk, dbg[6] = hdr_.st_splits, dbg[7] = hdr_.st_seq_exc;
     if (shadow_) NS_TRY(check_against_shadow("update"));
     return NSGPU_OK;

@@ -94,7 +94,7 @@ struct DevGraphShared {
     bool check = false;                               // NSGPU_GRAPH_CHECK: every update also on the host, arrays compared
     uint32_t dbg_flags = 0;
     std::atomic<uint64_t> n_updates{0}, n_grow{0}, n_mid_copies{0}, kernel_wait_ns{0}, bytes_back{0}, update_ns{0};
-    std::atomic<uint64_t> phase_ticks[8], hist[8], slow_phase[8];             // the kernels' own clock (100 MHz) by phase, summed (debug report)
+    std::atomic<uint64_t> phase_ticks[8], hist[8], slow_phase[8], cnt[4];             // the kernels' own clock (100 MHz) by phase, summed (debug report)
     ~DevGraphShared();
 };
 
@@ -137,7 +137,7 @@ private:
     uint32_t epoch_ = 0;
     bool inited_ = false, pending_ = false, prepared_ = false, armed_ = false, moved_path_ = false;
     uint32_t ops_cap_ = 0;
-    uint32_t tm_seen_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t tm_seen_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt_seen_[4] = {0, 0, 0, 0};
     // pending update
     read_t p_id_ = 0; long p_pos_ = 0; size_t p_len_ = 0; bool p_rc_ = false; double p_t0_ = 0;
     // the finished contig on the host
