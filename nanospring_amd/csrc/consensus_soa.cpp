@@ -30,7 +30,7 @@ dg::G SoaStore::view()
 {
     dg::G g;
     g.h = &hdr;
-    g.nodes = nodes.data(), g.edges = edges.data(), g.chunks = chunks.data(), g.mark = mark.data();
+    g.nodes = nodes.data(), g.edges = edges.data(), g.chunks = chunks.data(), g.mark = mark.data(), g.pidx = pidx.data();
     g.pe = pe.data(), g.pn = pn.data(), g.ps = ps.data();
     g.sv_e = sv_e.data(), g.sv_n = sv_n.data(), g.sv_s = sv_s.data();
     g.multi_list = multi.data(), g.wk = wk.data();
@@ -40,13 +40,13 @@ dg::G SoaStore::view()
 size_t SoaStore::bytes() const
 {
     return nodes.capacity() * sizeof(dg::Node) + edges.capacity() * sizeof(dg::Edge) + chunks.capacity() * sizeof(dg::Chunk) +
-           (mark.capacity() + pe.capacity() + pn.capacity() + sv_e.capacity() + sv_n.capacity() + multi.capacity() + wk.capacity()) * 4 + ps.capacity() + sv_s.capacity();
+           (mark.capacity() + pidx.capacity() + pe.capacity() + pn.capacity() + sv_e.capacity() + sv_n.capacity() + multi.capacity() + wk.capacity()) * 4 + ps.capacity() + sv_s.capacity();
 }
 
 void SoaStore::reserve(uint32_t n_nodes, uint32_t n_edges, uint32_t n_chunks, uint32_t path_side, uint32_t wk_words)
 {
     auto grow = [](size_t have, size_t want) { size_t c = have ? have : 1024; while (c < want) c += c / 2 + 1024; return c; };
-    if (nodes.size() < n_nodes) { const size_t c = grow(nodes.size(), n_nodes); nodes.resize(c); mark.resize(c); }
+    if (nodes.size() < n_nodes) { const size_t c = grow(nodes.size(), n_nodes); nodes.resize(c); mark.resize(c); pidx.resize(c); }
     if (edges.size() < n_edges) edges.resize(grow(edges.size(), n_edges));
     if (chunks.size() < n_chunks) chunks.resize(grow(chunks.size(), n_chunks));
     if (wk.size() < wk_words) wk.resize(grow(wk.size(), wk_words));
@@ -66,6 +66,7 @@ void SoaStore::reserve(uint32_t n_nodes, uint32_t n_edges, uint32_t n_chunks, ui
         }
         pe.swap(e2), pn.swap(n2), ps.swap(s2);
         sv_e.assign(cap, 0), sv_n.assign(cap, 0), sv_s.assign(cap, 0);
+        hdr.pos_bias += off2 - hdr.path_off;           // (what the nodes remember of their places moves with the arrays)
         hdr.path_off = off2;
     }
     hdr.cap_nodes = (uint32_t)nodes.size(), hdr.cap_edges = (uint32_t)edges.size(), hdr.cap_chunks = (uint32_t)chunks.size();
@@ -159,6 +160,7 @@ void SoaGraph::calculate_main_path_greedy()
     for (;;) {
         HostOps o(st_.view(), t);
         o.main_path();
+        if (!st_.hdr.err) o.finish_path();
         if (st_.hdr.err == dg::ERR_SCRATCH && st_.hdr.stage < 3) {      // the walks' lists did not fit and nothing was changed yet: a larger work area
             st_.hdr.err = 0;
             st_.wk.resize(st_.wk.size() * 2);

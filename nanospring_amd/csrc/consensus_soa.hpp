@@ -25,7 +25,7 @@ struct SoaStore {
     std::vector<dg::Node> nodes;
     std::vector<dg::Edge> edges;
     std::vector<dg::Chunk> chunks;
-    std::vector<uint32_t> mark, pe, pn, sv_e, sv_n, multi, wk;
+    std::vector<uint32_t> mark, pidx, pe, pn, sv_e, sv_n, multi, wk;
     std::vector<uint8_t> ps, sv_s;
     SoaStore() { memset(&hdr, 0, sizeof(hdr)); }
     dg::G view();

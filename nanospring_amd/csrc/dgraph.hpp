@@ -26,8 +26,10 @@
 
 #if defined(__HIPCC__)
 #define DG_HD __host__ __device__ inline
+#define DG_COLD __host__ __device__ inline
 #else
 #define DG_HD inline
+#define DG_COLD inline
 #endif
 
 namespace nsgpu {
@@ -61,6 +63,7 @@ struct Hdr {
     uint32_t n_nodes, n_edges, n_chunks;             // ids handed out so far
     uint32_t live_nodes, live_edges;                  // numNodes / numEdges of the reference
     uint32_t cap_nodes, cap_edges, cap_chunks, cap_path, cap_wk, cap_multi;
+    uint32_t pos_bias;                                // added to pidx[] entries: the arrays' moves by the host (re-centring) leave pidx[] valid
     uint32_t path_off, m;                             // the path's edges are pe[path_off .. path_off + m), its nodes pn / ps[path_off .. path_off + m]
     uint32_t right_off, left_off, right_unch, left_unch;     // rightMostUnchangedNodeOffset / leftMost... and the nodes
     uint32_t n_multi, multi_n;                        // side nodes with more than one edge in; entries of multi_list (a superset, may hold stale ids)
@@ -79,14 +82,18 @@ struct Hdr {
     uint32_t dbg_flags;                               // tests: 1 = excursions one at a time, 2 = removeCycles by the reference's full walk, 4 = a longer path always moves its left part, 8 = chain runs of splitPath with a team of one too
     uint32_t err_line;                                // where the first error was raised (dgraph.hpp line)
     uint32_t st_search, st_steps, st_idscan, st_ctx;   // thread 0's loops: rejoin searches (entries looked at), detour steps, read ids compared in splitPath, its contexts
+    uint32_t st_gap, st_ended, st_last[6];             // by-passed nodes in sum; walks that ended; the last recompute's R, Lf, m, la, lenF, touch_hi
+    uint32_t st_pops, st_probes, st_anc, st_probed;    // removeCycles' walk: edges popped; probes asked; ancestor steps; nodes the probes covered
+    uint32_t st_cyc[6];                               // removeCycles in parts (thread 0's clock): marking, finding the roots, splitPath: looking for stretches / stretches / the rest, the walks
     uint32_t st_tm[8];                                // ticks of the team's clock by phase: tables, runs, excursions, choices, stitching, writing, flags + P/S, removeCycles
-    uint32_t pad_[1];
+    uint32_t pad_[2];
 };
 static_assert(sizeof(Hdr) % 16 == 0, "header is whole 16-byte words");
 
 struct G {
     Hdr *h;
     Node *nodes; Edge *edges; Chunk *chunks; uint32_t *mark;
+    uint32_t *pidx;                                   // per node: where it was last written into pn[] (minus Hdr::pos_bias); believed only if pn[] there still holds the node
     uint32_t *pe, *pn; uint8_t *ps;
     uint32_t *sv_e, *sv_n; uint8_t *sv_s;             // the path as it was, where the walk goes over it again (cap_path entries each, same positions)
     uint32_t *multi_list;
@@ -142,7 +149,7 @@ template <class T> struct Ops {
         const uint32_t n = h.n_nodes++;
         Node &x = g.nodes[n];
         x.out_ext = x.in_ext = NIL, x.n_out = x.n_in = 0, x.base = (uint8_t)base, x.on_main = 0;
-        g.mark[n] = 0;
+        g.mark[n] = 0, g.pidx[n] = NIL;
         ++h.live_nodes;
         return n;
     }
@@ -326,7 +333,10 @@ template <class T> struct Ops {
         const uint32_t e = h.n_edges++;
         Edge &x = g.edges[e];
         x.src = s, x.sink = t, x.count = 0, x.head = x.tail = NIL;
-        for (uint32_t i = 0; i < n_ids; ++i) add_read_seq(e, ids[i]);
+        const uint32_t ni = n_ids < kEdgeInl ? n_ids : kEdgeInl;
+        for (uint32_t i = 0; i < ni; ++i) x.ids[i] = ids[i];
+        x.count = ni;
+        for (uint32_t i = ni; i < n_ids; ++i) add_read_seq(e, ids[i]);
         const bool was = multi_in_side(t);
         out_push(s, e | (code_of(g.nodes[t].base) << 29));
         in_push(t, e);
@@ -377,6 +387,7 @@ template <class T> struct Ops {
     {
         Edge &e = g.edges[ei];
         const uint32_t n = e.count;
+        if (n_rm >= n) { e.count = 0, e.head = e.tail = NIL; return 0; }      // (the callers' lists are sub-sets of the edge's: as many as it has = all of them)
         // compaction in place, position by position (the write position never overtakes the read position)
         uint32_t w = 0, rc = e.head, wc = e.head;            // chunks of the read / write positions once they are beyond the inline slots
         for (uint32_t p = 0; p < n; ++p) {
@@ -398,6 +409,14 @@ template <class T> struct Ops {
     DG_HD void remove_reads_from_edge(uint32_t ei, const uint32_t *rm, uint32_t n_rm) { if (drop_reads(ei, rm, n_rm) == 0) remove_edge(ei, false, false); }
 
     DG_HD uint32_t path_node(uint32_t i) const { return g.pn[g.h->path_off + i]; }
+    // where node n lies on the path, if what was noted when it was written there still holds (NIL: look for it)
+    DG_HD uint32_t path_index_of(uint32_t n) const
+    {
+        const Hdr &h = *g.h;
+        const uint32_t at = g.pidx[n] + h.pos_bias;
+        if (g.pidx[n] == NIL || at < h.path_off || at > h.path_off + h.m || g.pn[at] != n) return NIL;
+        return at - h.path_off;
+    }
     DG_HD uint32_t *order() const { return g.wk + g.h->cap_wk - 64; }       // what thread 0 tells its helpers (the last words of the work area)
 
     // ================================================================================================================
@@ -418,11 +437,12 @@ template <class T> struct Ops {
             g.mark[i] = 0;
             if (i + 1 < len) { Edge &e = g.edges[i]; e.src = i, e.sink = i + 1, e.count = 1, e.head = e.tail = NIL, e.ids[0] = id; g.pe[off + i] = i; }
             g.pn[off + i] = i, g.ps[off + i] = seed[i];
+            g.pidx[i] = off + i;
         }
         team.sync();
         if (tid == 0) {
             h.n_nodes = h.live_nodes = len, h.n_edges = h.live_edges = len - 1, h.n_chunks = 0;
-            h.path_off = off, h.m = len - 1;
+            h.path_off = off, h.m = len - 1, h.pos_bias = 0;
             h.right_off = h.m, h.left_off = 0, h.right_unch = len - 1, h.left_unch = 0;
             h.n_multi = h.multi_n = 0, h.epoch = 0;
             h.upd_wk = h.upd_n_ops = h.upd_n_exc = 0, h.upd_nodes0 = len, h.upd_edges0 = len - 1;
@@ -704,7 +724,7 @@ template <class T> struct Ops {
             const uint32_t n_in_edges = first_has_in ? nn : nn - 1;
             Node &nd = g.nodes[nid];
             nd.out_ext = nd.in_ext = NIL, nd.base = (uint8_t)base, nd.on_main = 0;
-            g.mark[nid] = 0;
+            g.mark[nid] = 0, g.pidx[nid] = NIL;
             nd.n_in = e_in != NIL ? 1 : 0;
             if (e_in != NIL) nd.in[0] = e_in;
             if (j + 1 < nn) nd.n_out = 1, nd.out[0] = (first_has_in ? e0 + j + 1 : e0 + j) | (code_of(op_base(ops[ins_op[q + 1]])) << 29);
@@ -825,7 +845,7 @@ template <class T> struct Ops {
     // (edge E0 + i, which leads to node X0 + i + 1)?  Chains are made with consecutive ids (an excursion's nodes, the copies of a split), so a
     // walk along one -- the greedy walk turning into a side branch, splitPath looking for the end of a by-passed stretch -- need not chase
     // pointers node by node: the helpers look at a few hundred nodes at once.  kind 0: forward, nodes with one edge in and one out; 1: backward
-    // (in-edges E0 - i from node X0 - i - 1); 2: forward, any number of edges in, and the stretch is written into the chain arrays (from index
+    // (in-edges E0 - i from node X0 - i - 1; 3: the same, and the stretch's nodes get the epoch's mark); 2: forward, any number of edges in, and the stretch is written into the chain arrays (from index
     // order[7], the edge into X0 being order[5]).  Returns the number of nodes of the stretch (0: X0 itself does not qualify).
     DG_HD uint32_t probe(uint32_t kind, uint32_t X0, uint32_t E0, uint32_t maxn, uint32_t e_into, uint32_t fill_at)
     {
@@ -833,19 +853,21 @@ template <class T> struct Ops {
         ord[1] = kind, ord[2] = X0, ord[3] = E0, ord[4] = maxn, ord[5] = e_into, ord[6] = maxn, ord[7] = fill_at;
         (void)team.bcast(2);
         probe_run();
+        ++g.h->st_probes, g.h->st_probed += ord[6];
         return ord[6];
     }
-    DG_HD void probe_run()
+    DG_COLD void probe_run()
     {
         const Hdr &h = *g.h;
         uint32_t *ord = order();
         const uint32_t kind = ord[1], X0 = ord[2], E0 = ord[3], maxn = ord[4];
         const uint32_t cr = team.crew_rank(), nc = team.crew_size();
+        const bool bwd = kind == 1 || kind == 3;
         for (uint32_t base = 0; base < maxn; base += nc) {
             const uint32_t i = base + cr;
             if (i < maxn) {
                 bool ok = false;
-                if (kind != 1) {
+                if (!bwd) {
                     const uint64_t n = (uint64_t)X0 + i, e = (uint64_t)E0 + i;
                     if (n < h.n_nodes && e < h.n_edges) {
                         const Node &nd = g.nodes[n];
@@ -862,6 +884,11 @@ template <class T> struct Ops {
             if (ord[6] < base + nc) break;
         }
         team.sync();
+        if (kind == 3) {                                     // (the stretch's nodes are ancestors of a node removeCycles works on)
+            const uint32_t L = ord[6];
+            for (uint32_t i = cr; i < L; i += nc) g.mark[X0 - i] = h.epoch;
+            team.sync();
+        }
         if (kind == 2) {
             const CycWk K = cyc_wk();
             const uint32_t L = ord[6], at = ord[7];
@@ -881,7 +908,7 @@ template <class T> struct Ops {
     DG_HD bool probing() const { return team.crew_size() > 1 || (g.h->dbg_flags & 8u); }
 
     // thread 0: the walk from old node R to the right.  D: (index, chosen edge) of the old nodes in [R, m] whose choice is not the path's edge, ascending.
-    DG_HD void stitch_forward(Stitch &S, const uint32_t *D, uint32_t n_dis, uint32_t R, uint32_t m, uint32_t off)
+    DG_COLD void stitch_forward(Stitch &S, const uint32_t *D, uint32_t n_dis, uint32_t R, uint32_t m, uint32_t off)
     {
         Hdr &h = *g.h;
         uint32_t pos = R;
@@ -928,9 +955,8 @@ template <class T> struct Ops {
                     }
                 }
                 if (was_on) {
-                    uint32_t j = pos + 1;
-                    while (j <= m && g.pn[off + j] != nx) ++j;
-                    h.st_search += j - pos;
+                    uint32_t j = path_index_of(nx);
+                    if (j == NIL || j <= pos || j > m) { j = pos + 1; while (j <= m && g.pn[off + j] != nx) ++j; h.st_search += j - pos; }
                     if (j > m) { fail_at(__LINE__, ERR_WALK); break; }
                     emit_gap(S, pos + 1, j);
                     pos = j;
@@ -945,7 +971,7 @@ template <class T> struct Ops {
     }
     // thread 0: the walk from old node Lf to the left.  D: (index, chosen edge in) of the old nodes in [0, Lf] whose choice is not the path's edge, descending.
     // Pieces in walk order (right to left): OLD (a, b) = old edges b-1 down to a; EDGE c = the edge's source; CHAIN = edges a, a-1, ..., sources c, c-1, ...
-    DG_HD void stitch_backward(Stitch &S, const uint32_t *D, uint32_t n_dis, uint32_t Lf, uint32_t off)
+    DG_COLD void stitch_backward(Stitch &S, const uint32_t *D, uint32_t n_dis, uint32_t Lf, uint32_t off)
     {
         Hdr &h = *g.h;
         uint32_t pos = Lf;
@@ -1000,6 +1026,7 @@ template <class T> struct Ops {
                 }
                 if (was_on) {
                     uint32_t j = known_idx;
+                    if (j == NIL) { j = path_index_of(nx); if (j != NIL && j >= pos) j = NIL; }
                     if (j == NIL) { j = pos; while (j > 0 && g.pn[off + j - 1] != nx) --j; h.st_search += pos - j; j = j > 0 ? j - 1 : NIL; }
                     if (j == NIL || j >= pos || g.pn[off + j] != nx) { fail_at(__LINE__, ERR_WALK); break; }
                     emit_gap(S, j + 1, pos);
@@ -1016,7 +1043,7 @@ template <class T> struct Ops {
 
     // by-passed old nodes leave the path (they become side nodes: one with several edges in is work for removeCycles), the nodes of
     // the detours join it.  Gaps and chains: lanes over nodes; single detour nodes: thread 0.  Runs before the path arrays change.
-    DG_HD void apply_flags(const Stitch &S, uint32_t off, bool backward)
+    DG_COLD void apply_flags(const Stitch &S, uint32_t off, bool backward)
     {
         Hdr &h = *g.h;
         const uint32_t tid = team.tid(), nt = team.size();
@@ -1136,6 +1163,7 @@ template <class T> struct Ops {
         // path's length changes -- whichever of the two parts next to the change is the shorter one moves (a contig grows at its ends: the read
         // lies near one of them, the megabase behind it stays where it is).  Everything is staged in the sv arrays at its final position first. ----
         const uint32_t la = B.len, lenF = F.len;
+        if (tid == 0) { h.st_gap += F.gap_len + B.gap_len, h.st_ended += (F.ended ? 1u : 0u) + (B.ended ? 2u : 0u); h.st_last[0] = R, h.st_last[1] = Lf, h.st_last[2] = m, h.st_last[3] = la, h.st_last[4] = lenF, h.st_last[5] = h.upd_touch_hi; }
         const bool bwd_same = B.n_pc == 0 ? Lf == 0 : (B.n_pc == 1 && B.pc[0] == PC_OLD && B.pc[1] == 0 && B.pc[2] == Lf && !B.ended);
         const bool fwd_same = F.n_pc == 0 ? R == m : (F.n_pc == 1 && F.pc[0] == PC_OLD && F.pc[1] == R && F.pc[2] == m && !F.ended);
         uint32_t pre_nb = 0, pre_n = 0, suf_n = 0;
@@ -1161,7 +1189,7 @@ template <class T> struct Ops {
                 g.sv_e[at] = e, g.sv_n[at] = n, g.sv_s[at] = b;
             }
             team.sync();
-            for (uint32_t t = pre_nb + tid; t < la; t += nt) { const uint32_t at = off + Lf - 1 - t; g.pe[at] = g.sv_e[at], g.pn[at] = g.sv_n[at], g.ps[at] = g.sv_s[at]; }
+            for (uint32_t t = pre_nb + tid; t < la; t += nt) { const uint32_t at = off + Lf - 1 - t; g.pe[at] = g.sv_e[at], g.pn[at] = g.sv_n[at], g.ps[at] = g.sv_s[at]; g.pidx[g.sv_n[at]] = at - h.pos_bias; }
             team.sync();
         }
         if (!fwd_same) {
@@ -1184,9 +1212,9 @@ template <class T> struct Ops {
             team.sync();
             if (move_left) {
                 const uint32_t n_left = la + (R - Lf) + pre_n;
-                for (uint32_t t = tid; t <= n_left; t += nt) { const uint32_t to = (uint32_t)((int64_t)(off2 + t) + shift); g.pn[to] = g.sv_n[to], g.ps[to] = g.sv_s[to]; if (t < n_left) g.pe[to] = g.sv_e[to]; }
+                for (uint32_t t = tid; t <= n_left; t += nt) { const uint32_t to = (uint32_t)((int64_t)(off2 + t) + shift); g.pn[to] = g.sv_n[to], g.ps[to] = g.sv_s[to]; g.pidx[g.sv_n[to]] = to - h.pos_bias; if (t < n_left) g.pe[to] = g.sv_e[to]; }
             }
-            for (uint32_t t = pre_n + tid; t < w_end; t += nt) { const uint32_t at = (uint32_t)((int64_t)(off + R + t) + shift); g.pe[at] = g.sv_e[at], g.pn[at + 1] = g.sv_n[at + 1], g.ps[at + 1] = g.sv_s[at + 1]; }
+            for (uint32_t t = pre_n + tid; t < w_end; t += nt) { const uint32_t at = (uint32_t)((int64_t)(off + R + t) + shift); g.pe[at] = g.sv_e[at], g.pn[at + 1] = g.sv_n[at + 1], g.ps[at + 1] = g.sv_s[at + 1]; g.pidx[g.sv_n[at + 1]] = at + 1 - h.pos_bias; }
             team.sync();
         }
         lap(5);
@@ -1216,9 +1244,18 @@ template <class T> struct Ops {
         }
         team.sync();
         lap(6);
+    }
+    // removeCycles behind the recompute (:606), and the unchanged stretch is the whole path again (:608-613).  Apart from the graph's size nothing
+    // the caller sees changes here -- the consensus, the contig's span and the path are final when main_path() returns -- so the kernel reports
+    // those first and the caller goes on while this part runs.
+    DG_HD void finish_path()
+    {
+        Hdr &h = *g.h;
+        const uint32_t tid = team.tid();
+        uint32_t tk = team.clock();
         remove_cycles();
-        lap(7);
         if (tid == 0) {
+            h.st_tm[7] += team.clock() - tk;
             h.right_unch = g.pn[h.path_off + h.m], h.right_off = h.m;
             h.left_unch = g.pn[h.path_off], h.left_off = 0;
         }
@@ -1255,10 +1292,11 @@ template <class T> struct Ops {
     // context is popped (its descendants are done by then: stack discipline), and a node with ONE way out is not a new context at all --
     // the walk goes on in the same one, its list filtered in place; whether the old node is left without edges (the reference looks at
     // the context's second visit) is looked at when the split is over (nothing can reach such a node in between).
-    DG_HD void split_path(const CycWk &K, uint32_t new_pre0, uint32_t e0)
+    DG_COLD void split_path(const CycWk &K, uint32_t new_pre0, uint32_t e0)
     {
         Hdr &h = *g.h;
         ++h.st_splits;
+        const uint32_t sp0 = team.clock();
         uint32_t lists_top = 0, n_ctx = 0, n_def = 0;
         if (g.edges[e0].count > K.cap_lists) { fail_at(__LINE__, ERR_SCRATCH); return; }
         lists_top = ids_copy(g.edges[e0], K.lists);          // (a copy: e0's list dies with e0 during the first visit)
@@ -1280,7 +1318,11 @@ template <class T> struct Ops {
             uint32_t new_pre = c[0], e = c[1];
             const uint32_t own_off = lists_top;
             uint32_t own_n = 0;
-            {
+            if (n_ctx == 1 && c[2] == 0) {                       // the split's first edge: its own reads, all of them
+                if (own_off + c[3] > K.cap_lists) { fail_at(__LINE__, ERR_SCRATCH); return; }
+                for (uint32_t i = 0; i < c[3]; ++i) K.lists[own_off + i] = K.lists[i];
+                own_n = c[3];
+            } else {
                 const Edge &ed = g.edges[e];
                 for (uint32_t i = 0; i < c[3]; ++i) {
                     const uint32_t id = K.lists[c[2] + i];
@@ -1295,6 +1337,7 @@ template <class T> struct Ops {
                 // other -- the whole team takes the stretch at once (split_chain_run)
                 if (own_n <= kEdgeInl && (team.crew_size() > 1 || (h.dbg_flags & 8u))) {
                     uint32_t k = 0, ce = e;
+                    const uint32_t d0 = team.clock();
                     const uint32_t lim = K.cap_chain < 4096 ? K.cap_chain : 4096;
                     uint32_t since = 0;
                     while (k < lim) {
@@ -1311,11 +1354,14 @@ template <class T> struct Ops {
                         ++k;
                         ce = o0;
                     }
+                    const uint32_t d1 = team.clock();
+                    h.st_cyc[2] += d1 - d0;
                     if (k >= 8) {
                         if (n_def + k > K.cap_defer || (uint64_t)h.n_nodes + k > h.cap_nodes || (uint64_t)h.n_edges + k > h.cap_edges) { fail_at(__LINE__, n_def + k > K.cap_defer ? ERR_SCRATCH : ERR_CAP); return; }
                         K.order[1] = new_pre, K.order[2] = k, K.order[3] = own_off, K.order[4] = own_n, K.order[5] = n_def;
                         (void)team.bcast(1);
                         split_chain_run(K);
+                        h.st_cyc[3] += team.clock() - d1;
                         const uint32_t k_eff = K.order[6];
                         n_def += k_eff;
                         h.st_ctx += k_eff;
@@ -1362,13 +1408,14 @@ template <class T> struct Ops {
             }
         }
         for (uint32_t i = 0; i < n_def && !failed(); ++i) { const uint32_t oc = K.defer[i]; if (g.nodes[oc].n_in == 0 && g.nodes[oc].n_out == 0 && g.nodes[oc].on_main == 0) remove_node(oc); }
+        h.st_cyc[4] += team.clock() - sp0;
     }
     // The team's part of split_path for a stretch of k nodes with one way out each: edges chain[0 .. k), nodes chain[cap + i], the reads O = lists[own_off ..
     // own_off + own_n) (at most 11), the node in front of the copy new_pre.  What the loop in split_path does node by node -- take the reads off the old
     // edge, copy the node, join the copy to the copy before it -- the lanes do for all nodes at once; which reads are still on the stretch at node i is the
     // AND of the edges' membership masks up to i (thread 0, one pass over k words).  Ids as the loop would hand them out: in order along the stretch.
     // order[]: 1 new_pre, 2 k, 3 own_off, 4 own_n, 5 n_def; out: 6 k_eff (the nodes copied: up to where the reads run out)
-    DG_HD void split_chain_run(const CycWk &K)
+    DG_COLD void split_chain_run(const CycWk &K)
     {
         Hdr &h = *g.h;
         const uint32_t tid = team.tid(), cr = team.crew_rank(), nc = team.crew_size();
@@ -1401,7 +1448,7 @@ template <class T> struct Ops {
             const uint32_t nid = nbase + i, ne = ebase + i;
             Node &nd = g.nodes[nid];
             nd.out_ext = nd.in_ext = NIL, nd.base = g.nodes[X].base, nd.on_main = 0;
-            g.mark[nid] = 0;
+            g.mark[nid] = 0, g.pidx[nid] = NIL;
             nd.n_in = 1, nd.in[0] = ne;
             if (i + 1 < k_eff) nd.n_out = 1, nd.out[0] = (ne + 1) | (code_of(g.nodes[CX[i + 1]].base) << 29);
             else nd.n_out = 0;
@@ -1420,19 +1467,28 @@ template <class T> struct Ops {
         }
         team.sync();
     }
-    DG_HD void walk_and_prune(const CycWk &K, uint32_t e0, bool marked_only)
+    DG_COLD void walk_and_prune(const CycWk &K, uint32_t e0, bool marked_only)
     {
         const Hdr &h = *g.h;
-        uint32_t n = 0;
+        uint32_t n = 0, streak = 0;
         K.estack[n++] = e0;
         while (n && !failed()) {
             const uint32_t curr = K.estack[--n];
+            ++g.h->st_pops;
             const uint32_t sink = g.edges[curr].sink, source = g.edges[curr].src;
             if (sink == NIL) continue;                           // (an edge a split before this one took away)
             if (g.nodes[sink].on_main) continue;
             if (marked_only && g.mark[sink] != h.epoch) continue;     // nothing below an unmarked node can be split
             if (g.nodes[sink].n_in > 1) split_path(K, source, curr);
             const Node &s = g.nodes[sink];
+            if (s.n_out == 1 && s.n_in == 1 && probing()) {
+                if (++streak >= 3) {                          // down a branch without forks or ways in: nothing to split on a stretch of it
+                    const uint32_t o0 = s.out[0] & kRefMask;
+                    const uint32_t L = probe(0, sink, o0, 4 * team.crew_size() + 60, 0, 0);
+                    if (L >= 2) { K.estack[n++] = o0 + L - 1; continue; }
+                    streak = 0;
+                }
+            } else streak = 0;
             if (n + s.n_out > K.cap_estack) { fail_at(__LINE__, ERR_SCRATCH); return; }
             for (uint32_t i = 0; i < s.n_out; ++i) K.estack[n++] = out_ref(s, i) & kRefMask;
         }
@@ -1451,13 +1507,14 @@ template <class T> struct Ops {
     // can happen at lies on a way from the path to one of them.  So: mark them and their ancestors (edges in, backwards), find the path
     // nodes the marked branches hang off (lanes over the path's node array), and run the reference's walk from those nodes only, in
     // its order, descending only into marked nodes.  When the list does not account for every such node the reference's full walk runs.
-    DG_HD void remove_cycles()
+    DG_COLD void remove_cycles()
     {
         Hdr &h = *g.h;
         const uint32_t tid = team.tid(), nt = team.size();
         if (h.n_multi == 0) { if (tid == 0) h.multi_n = 0; team.sync(); return; }
         const CycWk K = cyc_wk();
         uint32_t mode = 0, n_roots = 0;                        // 0 nothing to do, 1 from the list, 2 the full walk
+        const uint32_t c0 = team.clock();
         if (tid == 0) {
             ++h.st_cycles_run;
             ++h.epoch;
@@ -1473,8 +1530,17 @@ template <class T> struct Ops {
                 uint32_t n_todo = 0;
                 for (uint32_t i = 0; i < h.multi_n && n_todo < K.cap_todo; ++i) K.todo[n_todo++] = g.multi_list[i];
                 if (h.multi_n > K.cap_todo) mode = 2;
+                uint32_t streak = 0;
                 while (n_todo && mode == 1) {
-                    const uint32_t n = K.todo[--n_todo];
+                    uint32_t n = K.todo[--n_todo];
+                    ++h.st_anc;
+                    if (g.nodes[n].n_in == 1 && probing()) {
+                        if (++streak >= 3) {                      // up a branch without forks: a stretch of it at once when its ids run on
+                            const uint32_t L = probe(3, n, g.nodes[n].in[0], 4 * team.crew_size() + 60, 0, 0);
+                            if (L >= 2) n = n - (L - 1);          // (its nodes are marked; go on from the last of them)
+                            else streak = 0;
+                        }
+                    } else streak = 0;
                     const Node &x = g.nodes[n];
                     for (uint32_t i = 0; i < x.n_in; ++i) {
                         const uint32_t s = g.edges[in_ref(x, i)].src;
@@ -1487,18 +1553,38 @@ template <class T> struct Ops {
                 if (mode == 1 && n_roots == 0) mode = 0;        // not reachable from the path: the full walk would find nothing either
             }
             if (mode == 2) ++h.st_full_walk;
-        }
+            h.st_cyc[0] += team.clock() - c0;
+            (void)team.bcast(0);
+        } else if (team.helper()) helpers_loop();
         team.sync();
         mode = team.bcast(mode), n_roots = team.bcast(n_roots);
         const uint32_t m = h.m, off = h.path_off;
         if (mode == 1) {
-            // where the roots lie on the path: node indices [0, left_end) and [right_off, m]
+            // where the roots lie on the path: node indices [0, left_end) and [right_off, m].  Each node remembers where it was written last;
+            // only when that does not hold for one of them is the path looked through.
+            uint32_t known = 0;
+            if (tid == 0) {
+                known = 1;
+                const uint32_t left_end0 = h.left_off < m ? h.left_off + 1 : m;
+                uint32_t nh = 0;
+                for (uint32_t r = 0; r < n_roots && known; ++r) {
+                    const uint32_t i = path_index_of(K.roots[r]);
+                    if (i == NIL) { known = 0; break; }
+                    if (!(i < left_end0 || i >= h.right_off)) continue;
+                    uint32_t q = nh++;                              // insertion by index (a handful of roots)
+                    for (; q > 0 && K.hits[2 * (q - 1)] > i; --q) K.hits[2 * q] = K.hits[2 * (q - 1)], K.hits[2 * q + 1] = K.hits[2 * (q - 1) + 1];
+                    K.hits[2 * q] = i, K.hits[2 * q + 1] = K.roots[r];
+                }
+                if (known) K.order[9] = nh;
+            }
+            known = team.bcast(known);
             uint64_t bloom = 0;
             for (uint32_t i = 0; i < n_roots; ++i) bloom |= 1ull << (K.roots[i] & 63u);
             const uint32_t left_end = h.left_off < m ? h.left_off + 1 : m;
             uint32_t lo1 = 0, hi1 = left_end, lo2 = h.right_off, hi2 = m + 1;
             if (h.right_off < left_end) lo1 = 0, hi1 = m + 1, lo2 = hi2 = 0;
             uint32_t n_hits = 0;
+            if (known) { n_hits = K.order[9]; lo1 = hi1 = lo2 = hi2 = 0; }
             for (int part = 0; part < 2; ++part) {
                 const uint32_t lo = part ? lo2 : lo1, hi = part ? hi2 : hi1;
                 for (uint32_t base = lo; base < hi; base += nt) {
@@ -1516,11 +1602,14 @@ template <class T> struct Ops {
             }
             team.sync();
             if (n_hits > K.cap_hits / 2) { if (tid == 0) fail_at(__LINE__, ERR_SCRATCH); team.sync(); return; }
+            const uint32_t c1 = team.clock();
             if (tid == 0) {
+                h.st_cyc[1] += c1 - c0;
                 // first loop of the reference: nodes right_off .. m in path order; second: nodes min(left_off, m - 1) .. 0, backwards
                 for (uint32_t i = 0; i < n_hits && !failed(); ++i) if (K.hits[2 * i] >= h.right_off) run_node(K, K.hits[2 * i + 1], true);
                 const uint32_t l0 = h.left_off < m ? h.left_off : m - 1;
                 for (uint32_t i = n_hits; i-- > 0 && !failed();) if (K.hits[2 * i] <= l0 && K.hits[2 * i] < m) run_node(K, K.hits[2 * i + 1], true);
+                h.st_cyc[5] += team.clock() - c1;
                 (void)team.bcast(0);
             } else if (team.helper()) helpers_loop();
         } else if (mode == 2) {

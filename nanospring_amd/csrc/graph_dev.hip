@@ -71,21 +71,26 @@ struct DevTeam {
     }
 };
 
-struct DgSetup { uint32_t cap_nodes, cap_edges, cap_chunks, cap_path, cap_wk, cap_multi, path_off, dbg_flags; };
+struct DgSetup { uint32_t cap_nodes, cap_edges, cap_chunks, cap_path, cap_wk, cap_multi, path_off, dbg_flags; };      // path_off != NIL: the host has moved the path arrays
 constexpr uint32_t kMidCap = 48u << 10;              // bytes of new consensus a result carries itself (longer: the host copies them)
+// Two reports per update: the first when the consensus is final (header as of then + the new stretch of the consensus), the second when
+// removeCycles behind it is done (the header again: the graph's final size).  A status word == the launch's epoch once its part is in place; the
+// check words = sum of that part's words + epoch.
 struct DgResult {
-    uint32_t status, check;                           // status == the launch's epoch once everything below is in place; check = sum of the words below + epoch
+    uint32_t status, check;                           // the first report
+    uint32_t status2, check2;                         // the second
     dg::Hdr hdr;
+    dg::Hdr hdr2;
     uint32_t mid_len, pad[3];
     uint8_t mid[kMidCap];
 };
-constexpr int kDgThreads = 256;
+constexpr int kDgThreads = 512;                      // the most a launch may have (NSGPU_GRAPH_THREADS: 256 or 512)
 
 __device__ static void dg_apply_setup(const dg::G &g, const DgSetup &s)
 {
     dg::Hdr &h = *g.h;
     h.cap_nodes = s.cap_nodes, h.cap_edges = s.cap_edges, h.cap_chunks = s.cap_chunks, h.cap_path = s.cap_path, h.cap_wk = s.cap_wk, h.cap_multi = s.cap_multi;
-    if (s.path_off != dg::NIL) h.path_off = s.path_off;
+    if (s.path_off != dg::NIL) { h.pos_bias += s.path_off - h.path_off; h.path_off = s.path_off; }
     h.dbg_flags = s.dbg_flags;
 }
 
@@ -102,28 +107,31 @@ struct DgSlot {
 };
 static_assert(sizeof(DgSlot) % 4 == 0, "slot records are read as words");
 
-__device__ static void dg_report(const dg::G &g, DevTeam &t, DgResult *res, uint32_t epoch)
+__device__ static void dg_report(const dg::G &g, DevTeam &t, DgResult *res, uint32_t epoch, bool second)
 {
     const dg::Hdr &h = *g.h;
     const uint32_t *hw = reinterpret_cast<const uint32_t *>(&h);
-    uint32_t *rw = reinterpret_cast<uint32_t *>(&res->hdr);
+    uint32_t *rw = reinterpret_cast<uint32_t *>(second ? &res->hdr2 : &res->hdr);
     uint32_t sum = 0;
     for (uint32_t i = threadIdx.x; i < sizeof(dg::Hdr) / 4; i += blockDim.x) { const uint32_t v = hw[i]; rw[i] = v; sum += v * (i + 1); }
-    uint32_t mid = 0;
-    if (!h.err && h.new_len >= h.P + h.S) mid = h.new_len - h.P - h.S;
-    const uint32_t mid_here = mid <= kMidCap ? mid : 0;
-    const uint8_t *src = g.ps + h.path_off + h.P;
-    for (uint32_t i = threadIdx.x; i < mid_here; i += blockDim.x) { const uint8_t b = src[i]; res->mid[i] = b; sum += (uint32_t)b * (i + 7u); }
-    if (threadIdx.x == 0) { res->mid_len = mid; sum += mid * 3u; }
+    if (!second) {
+        uint32_t mid = 0;
+        if (!h.err && h.new_len >= h.P + h.S) mid = h.new_len - h.P - h.S;
+        const uint32_t mid_here = mid <= kMidCap ? mid : 0;
+        const uint8_t *src = g.ps + h.path_off + h.P;
+        for (uint32_t i = threadIdx.x; i < mid_here; i += blockDim.x) { const uint8_t b = src[i]; res->mid[i] = b; sum += (uint32_t)b * (i + 7u); }
+        if (threadIdx.x == 0) { res->mid_len = mid; sum += mid * 3u; }
+    }
     __threadfence_system();
     uint32_t tot;
     (void)t.scan(sum, tot);
     __syncthreads();
     if (threadIdx.x == 0) {
-        res->check = tot + epoch;
+        *(second ? &res->check2 : &res->check) = tot + epoch;
         __threadfence_system();
-        __hip_atomic_store(&res->status, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(second ? &res->status2 : &res->status, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    __syncthreads();
 }
 
 // One workgroup per graph.  It waits for its graph's order -- the accepted read's script is known only when the alignment's last DP problem
@@ -169,7 +177,10 @@ __global__ __launch_bounds__(kDgThreads) void dg_serve_kernel(DgSlot *const *slo
     __syncthreads();
     if (!o.failed()) o.main_path();
     __syncthreads();
-    dg_report(g, t, L.res, L.epoch);
+    dg_report(g, t, L.res, L.epoch, false);           // the consensus is final: the builder goes on
+    if (!o.failed()) o.finish_path();
+    __syncthreads();
+    dg_report(g, t, L.res, L.epoch, true);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -267,11 +278,12 @@ DevGraph::DevGraph(DevGraphShared *sh, uint32_t builder) : sh_(sh) { (void)build
 DevGraph::~DevGraph()
 {
     if (armed_ && !pending_) cancel();
-    if (pending_) { const double w0 = now_ms_(); while (!ready() && now_ms_() - w0 < 5000.0) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); } }
+    if (pending_) { const double w0 = now_ms_(); while (!ready() && now_ms_() - w0 < 5000.0) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); } if (ready()) (void)complete(); }
+    if (finalizing_) (void)finalize(true);
     if (e_begun_ && e_ev_) (void)hipEventSynchronize(e_ev_);
     if (e_ev_) (void)hipEventDestroy(e_ev_);
     for (Block &b : retired_) give(b);
-    Block *dev[] = {&b_nodes_, &b_mark_, &b_edges_, &b_chunks_, &b_pe_, &b_pn_, &b_ps_, &b_sve_, &b_svn_, &b_svs_, &b_multi_, &b_wk_, &b_hdr_};
+    Block *dev[] = {&b_nodes_, &b_mark_, &b_pidx_, &b_edges_, &b_chunks_, &b_pe_, &b_pn_, &b_ps_, &b_sve_, &b_svn_, &b_svs_, &b_multi_, &b_wk_, &b_hdr_};
     for (Block *b : dev) give(*b);
     Block *pin[] = {&pin_, &e_nodes_, &e_edges_, &e_chunks_, &e_pe_, &e_pn_, &e_ps_};
     for (Block *b : pin) give(*b, true);
@@ -291,7 +303,7 @@ dg::G DevGraph::view() const
 {
     dg::G g;
     g.h = static_cast<dg::Hdr *>(b_hdr_.p);
-    g.nodes = static_cast<dg::Node *>(b_nodes_.p), g.edges = static_cast<dg::Edge *>(b_edges_.p), g.chunks = static_cast<dg::Chunk *>(b_chunks_.p), g.mark = static_cast<uint32_t *>(b_mark_.p);
+    g.nodes = static_cast<dg::Node *>(b_nodes_.p), g.edges = static_cast<dg::Edge *>(b_edges_.p), g.chunks = static_cast<dg::Chunk *>(b_chunks_.p), g.mark = static_cast<uint32_t *>(b_mark_.p), g.pidx = static_cast<uint32_t *>(b_pidx_.p);
     g.pe = static_cast<uint32_t *>(b_pe_.p), g.pn = static_cast<uint32_t *>(b_pn_.p), g.ps = static_cast<uint8_t *>(b_ps_.p);
     g.sv_e = static_cast<uint32_t *>(b_sve_.p), g.sv_n = static_cast<uint32_t *>(b_svn_.p), g.sv_s = static_cast<uint8_t *>(b_svs_.p);
     g.multi_list = static_cast<uint32_t *>(b_multi_.p), g.wk = static_cast<uint32_t *>(b_wk_.p);
@@ -312,14 +324,15 @@ int DevGraph::grow(const cons::SoaNeed &need, uint32_t seed_len)
     NS_CHECK(want_n < dg::kRefMask && want_e < dg::kRefMask && want_c < 0xfffffff0ull, NSGPU_ERR_RANGE, "consensus graph: more than 2^29 nodes or edges in one contig");
     if (want_n > cap_nodes_) {
         const size_t c = bigger(cap_nodes_, want_n);
-        Block nb, mb;
-        NS_TRY(take(nb, c * sizeof(dg::Node))); NS_TRY(take(mb, c * 4));
+        Block nb, mb, xb;
+        NS_TRY(take(nb, c * sizeof(dg::Node))); NS_TRY(take(mb, c * 4)); NS_TRY(take(xb, c * 4));
         if (inited_ && n_nodes) {
             NS_HIP(hipMemcpyAsync(nb.p, b_nodes_.p, (size_t)n_nodes * sizeof(dg::Node), hipMemcpyDeviceToDevice, st));
             NS_HIP(hipMemcpyAsync(mb.p, b_mark_.p, (size_t)n_nodes * 4, hipMemcpyDeviceToDevice, st));
+            NS_HIP(hipMemcpyAsync(xb.p, b_pidx_.p, (size_t)n_nodes * 4, hipMemcpyDeviceToDevice, st));
         }
-        retire(b_nodes_), retire(b_mark_);
-        b_nodes_ = nb, b_mark_ = mb, cap_nodes_ = (uint32_t)c, grew = true;
+        retire(b_nodes_), retire(b_mark_), retire(b_pidx_);
+        b_nodes_ = nb, b_mark_ = mb, b_pidx_ = xb, cap_nodes_ = (uint32_t)c, grew = true;
     }
     if (want_e > cap_edges_) {
         const size_t c = bigger(cap_edges_, want_e);
@@ -372,6 +385,7 @@ int DevGraph::grow(const cons::SoaNeed &need, uint32_t seed_len)
 int DevGraph::prepare(size_t read_len)
 {
     NS_CHECK(!pending_ && !armed_, NSGPU_ERR_ARG, "consensus graph: prepared with an update in flight (internal error)");
+    NS_TRY(finalize(true));
     const uint32_t seed_len = inited_ ? 0 : (uint32_t)path_.size();
     NS_CHECK(inited_ || seed_len >= 1, NSGPU_ERR_ARG, "consensus graph: an empty seed read");
     const uint32_t L = (uint32_t)std::min<size_t>(read_len, 0x3fffffffu);
@@ -393,7 +407,7 @@ int DevGraph::prepare(size_t read_len)
     slot->setup = DgSetup{cap_nodes_, cap_edges_, cap_chunks_, cap_path_, cap_wk_, cap_multi_, moved_path_ ? path_off_ : dg::NIL, sh_->dbg_flags};
     slot->ops = ops_pin, slot->seed = seed_pin, slot->res = res;
     if (!inited_) memcpy(seed_pin, path_.data(), seed_len);
-    res->status = 0;
+    res->status = 0, res->status2 = 0;
     __atomic_thread_fence(__ATOMIC_RELEASE);
     prepared_ = true;
     return NSGPU_OK;
@@ -424,7 +438,8 @@ int graph_serve_launch(DevGraphShared *sh, DevGraph *const *graphs, size_t n)
     }
     __atomic_thread_fence(__ATOMIC_RELEASE);
     static const unsigned long long patience = [] { const char *e = getenv("NSGPU_WAIT_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return (unsigned long long)((v > 0 ? v : 120.0) * 1e8); }();
-    hipLaunchKernelGGL(dg_serve_kernel, dim3((uint32_t)n), dim3(kDgThreads), 0, sh->serve_stream, ptrs, patience);
+    static const int n_thr = [] { const char *e = getenv("NSGPU_GRAPH_THREADS"); const int v = e ? atoi(e) : 0; return v == 512 || v == 256 || v == 128 ? v : 512; }();
+    hipLaunchKernelGGL(dg_serve_kernel, dim3((uint32_t)n), dim3(n_thr), 0, sh->serve_stream, ptrs, patience);
     NS_HIP(hipGetLastError());
     NS_HIP(hipEventRecord(L.done, sh->serve_stream));
     sh->launches.push_back(L);
@@ -446,6 +461,7 @@ void DevGraph::cancel()
 int DevGraph::submit(const std::string &query, const mm2::AlnOut &aln, read_t id, bool rc)
 {
     NS_CHECK(!pending_, NSGPU_ERR_ARG, "consensus graph: an update is still in flight (internal error)");
+    if (fail_rc_ != NSGPU_OK) return fail_rc_;
     if (!armed_) {
         if (!prepared_) NS_TRY(prepare(query.size()));
         DevGraph *self = this;
@@ -468,6 +484,7 @@ int DevGraph::submit(const std::string &query, const mm2::AlnOut &aln, read_t id
         inited_ = true;
         if (sh_->check) { shadow_.reset(new cons::SoaGraph()); shadow_->first_read = first_read; shadow_->initialize(path_, first_read, 0); shadow_->calculate_main_path_greedy(); }
     }
+    p_begin_ = (long long)aln.begin_offset, p_end_ = (long long)aln.end_offset;
     p_id_ = id, p_pos_ = (long)aln.rel_pos, p_len_ = query.size(), p_rc_ = rc, p_t0_ = now_ms_();
     __atomic_store_n(&slot->cmd, (uint32_t)(first ? DG_CMD_INIT_UPDATE : DG_CMD_UPDATE), __ATOMIC_RELEASE);
     pending_ = true, armed_ = false;
@@ -514,14 +531,9 @@ int DevGraph::complete()
     const DgResult *res = reinterpret_cast<const DgResult *>(static_cast<const DgSlot *>(pin_.p) + 1);
     hdr_ = res->hdr;
     pending_ = false;
+    finalizing_ = true;                                   // (removeCycles behind the recompute may still be running: finalize())
     sh_->update_ns += (uint64_t)((now_ms_() - p_t0_) * 1e6);
-    for (Block &b : retired_) give(b);
-    retired_.clear();
-    if (hdr_.err) {
-        set_error("consensus graph kernel: error %u raised at dgraph.hpp:%u (capacity %u / script %u / degree %u / walk %u / work area %u) at read %u, %u nodes, %u edges, path %u", hdr_.err, hdr_.err_line, hdr_.err & dg::ERR_CAP,
-                  hdr_.err & dg::ERR_SCRIPT, hdr_.err & dg::ERR_DEGREE, hdr_.err & dg::ERR_WALK, hdr_.err & dg::ERR_SCRATCH, (unsigned)p_id_, hdr_.n_nodes, hdr_.n_edges, hdr_.m);
-        return NSGPU_ERR_RANGE;
-    }
+    if (hdr_.err) return kernel_error();
     NS_CHECK(hdr_.old_len == path_.size() && hdr_.path_off + hdr_.m + 1 <= cap_path_, NSGPU_ERR_RANGE, "consensus graph: the kernel's path is out of step with the host's (internal error)");
     path_off_ = hdr_.path_off;
     const uint32_t mid = res->mid_len;
@@ -538,6 +550,50 @@ int DevGraph::complete()
     NS_CHECK(er != reads_.end() && sr != reads_.end(), NSGPU_ERR_RANGE, "consensus graph: the path's end reads are not in the read table (internal error)");
     end_ = er->second.pos + (long)er->second.len;
     start_ = sr->second.pos;
+    edges_seen_ = hdr_.live_edges;
+    if (shadow_) NS_TRY(finalize(true));                  // (the check compares whole arrays: both reports first)
+    return NSGPU_OK;
+}
+
+int DevGraph::kernel_error()
+{
+    set_error("consensus graph kernel: error %u raised at dgraph.hpp:%u (capacity %u / script %u / degree %u / walk %u / work area %u) at read %u, %u nodes, %u edges, path %u", hdr_.err, hdr_.err_line, hdr_.err & dg::ERR_CAP,
+              hdr_.err & dg::ERR_SCRIPT, hdr_.err & dg::ERR_DEGREE, hdr_.err & dg::ERR_WALK, hdr_.err & dg::ERR_SCRATCH, (unsigned)p_id_, hdr_.n_nodes, hdr_.n_edges, hdr_.m);
+    return NSGPU_ERR_RANGE;
+}
+
+// The update's second report (removeCycles is done: the graph's final size and counters).  wait = false: only if it is there.
+int DevGraph::finalize(bool wait)
+{
+    if (!finalizing_) return fail_rc_;
+    const DgResult *res = reinterpret_cast<const DgResult *>(static_cast<const DgSlot *>(pin_.p) + 1);
+    auto there = [&]() {
+        if (__atomic_load_n(&res->status2, __ATOMIC_ACQUIRE) != epoch_) return false;
+        const uint32_t *hw = reinterpret_cast<const uint32_t *>(&res->hdr2);
+        uint32_t sum = 0;
+        for (uint32_t i = 0; i < sizeof(dg::Hdr) / 4; ++i) sum += hw[i] * (i + 1);
+        return sum + epoch_ == res->check2;
+    };
+    if (!there()) {
+        if (!wait) return NSGPU_OK;
+        const double w0 = now_ms_();
+        static const double give_up_ms = [] { const char *e = getenv("NSGPU_WAIT_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return (v > 0 ? v : 120.0) * 1e3; }();
+        int spins = 0;
+        while (!there()) {
+            if (++spins > 200) { timespec ts = {0, 5000}; nanosleep(&ts, nullptr); }
+            if (now_ms_() - w0 > give_up_ms) { set_error("consensus graph: an update's second report has not come after %.0f s", give_up_ms / 1e3); return fail_rc_ = NSGPU_ERR_HIP; }
+        }
+        sh_->final_wait_ns += (uint64_t)((now_ms_() - w0) * 1e6);
+    }
+    const uint32_t edges1 = hdr_.live_edges;
+    hdr_ = res->hdr2;
+    finalizing_ = false;
+    for (Block &b : retired_) give(b);
+    retired_.clear();
+    if (hdr_.err) return fail_rc_ = kernel_error();
+    // (num_edges() answered with the first report's count while this one was outstanding, which is exact as long as removeCycles cannot carry
+    // the graph over the edge threshold from kEdgeMargin below it)
+    if (hdr_.live_edges - edges1 >= kEdgeMargin) { set_error("consensus graph: one removeCycles added %u edges (internal limit %u)", hdr_.live_edges - edges1, kEdgeMargin); return fail_rc_ = NSGPU_ERR_RANGE; }
     {
         uint32_t tot = 0, worst = 0, worst_i = 0;
         for (int i = 0; i < 8; ++i) { const uint32_t d = (uint32_t)(hdr_.st_tm[i] - tm_seen_[i]); sh_->phase_ticks[i] += d; tm_seen_[i] = hdr_.st_tm[i]; tot += d; if (d > worst) worst = d, worst_i = (uint32_t)i; }
@@ -545,12 +601,29 @@ int DevGraph::complete()
         for (uint32_t lim = 25000; bk < 7 && tot >= lim; lim *= 2) ++bk;          // < 0.25 / 0.5 / 1 / 2 / 4 / 8 / 16 ms / more
         sh_->hist[bk] += 1;
         if (tot >= 200000) sh_->slow_phase[worst_i] += 1;                            // updates of 2 ms and more: by their longest phase
+        static const bool slow_dbg = getenv("NSGPU_GRAPH_SLOW") != nullptr;
+        if (slow_dbg && tot >= 800000)
+            fprintf(stderr, "[graph] slow update %.1f ms (phase %u: %.1f): path %u, read len %zu, splits %u ctx %u pops %u probes %u covering %u anc %u detours %u steps %u walked %u multi %u gap %u ended %u R %u Lf %u m %u la %u lenF %u touch_hi %u begin %lld end %lld\n", tot / 1e5, worst_i, worst / 1e5, hdr_.m, p_len_,
+                    hdr_.st_splits - dbg_seen_[0], hdr_.st_ctx - dbg_seen_[1], hdr_.st_pops - dbg_seen_[2], hdr_.st_probes - dbg_seen_[3], hdr_.st_probed - dbg_seen_[4], hdr_.st_anc - dbg_seen_[5], hdr_.st_detours - dbg_seen_[6], hdr_.st_steps - dbg_seen_[7], hdr_.st_walked - dbg_seen_[8], hdr_.n_multi, hdr_.st_gap - dbg_seen_[9], hdr_.st_ended - dbg_seen_[10], hdr_.st_last[0], hdr_.st_last[1], hdr_.st_last[2], hdr_.st_last[3], hdr_.st_last[4], hdr_.st_last[5], p_begin_, p_end_);
+        dbg_seen_[0] = hdr_.st_splits, dbg_seen_[1] = hdr_.st_ctx, dbg_seen_[2] = hdr_.st_pops, dbg_seen_[3] = hdr_.st_probes, dbg_seen_[4] = hdr_.st_probed, dbg_seen_[5] = hdr_.st_anc, dbg_seen_[6] = hdr_.st_detours, dbg_seen_[7] = hdr_.st_steps, dbg_seen_[8] = hdr_.st_walked, dbg_seen_[9] = hdr_.st_gap, dbg_seen_[10] = hdr_.st_ended;
     }
+    for (int i = 0; i < 6; ++i) { sh_->cyc[i] += (uint32_t)(hdr_.st_cyc[i] - cyc_seen_[i]); cyc_seen_[i] = hdr_.st_cyc[i]; }
     sh_->cnt[0] += hdr_.st_search - cnt_seen_[0], sh_->cnt[1] += hdr_.st_steps - cnt_seen_[1], sh_->cnt[2] += hdr_.st_idscan - cnt_seen_[2], sh_->cnt[3] += hdr_.st_ctx - cnt_seen_[3];
     cnt_seen_[0] = hdr_.st_search, cnt_seen_[1] = hdr_.st_steps, cnt_seen_[2] = hdr_.st_idscan, cnt_seen_[3] = hdr_.st_ctx;
     dbg[0] += 1, dbg[1] = dbg[0] - hdr_.st_cycles_run, dbg[2] = hdr_.st_detours, dbg[4] = hdr_.st_walked, dbg[5] = hdr_.st_cycles_run - hdr_.st_full_walk, dbg[6] = hdr_.st_splits, dbg[7] = hdr_.st_seq_exc;
-    if (shadow_) NS_TRY(check_against_shadow("update"));
+    if (shadow_) { const int rc = check_against_shadow("update"); if (rc != NSGPU_OK) return fail_rc_ = rc; }
     return NSGPU_OK;
+}
+
+// numEdges for the edge-threshold tests (src/Consensus.cpp:69, 92, 196): final once the update's second report is in; until then the first
+// report's count stands in where that cannot change the test's outcome
+size_t DevGraph::num_edges()
+{
+    if (finalizing_) {
+        (void)finalize(false);
+        if (finalizing_ && (uint64_t)hdr_.live_edges + kEdgeMargin >= sh_->edge_thr) (void)finalize(true);
+    }
+    return hdr_.live_edges;
 }
 
 // NSGPU_GRAPH_CHECK: the arrays in HBM against the same update run on the host by the team of one -- ids are handed out in a fixed order, so
@@ -600,6 +673,7 @@ int DevGraph::emit_begin()
 {
     if (e_begun_ || !inited_) return NSGPU_OK;
     NS_CHECK(!pending_, NSGPU_ERR_ARG, "consensus graph: emission with an update in flight (internal error)");
+    NS_TRY(finalize(true));
     const dg::Hdr &h = hdr_;
     NS_TRY(take(e_nodes_, std::max<size_t>(64, (size_t)h.n_nodes * sizeof(dg::Node)), true));
     NS_TRY(take(e_edges_, std::max<size_t>(64, (size_t)h.n_edges * sizeof(dg::Edge)), true));
@@ -624,7 +698,7 @@ void DevGraph::write_reads(cons::StreamSet &o, const std::function<cons::ReadBas
     if (!e_begun_ && emit_begin() != NSGPU_OK) { fprintf(stderr, "nsgpu: %s\n", nsgpu_last_error()); abort(); }
     if (event_wait(e_ev_) != hipSuccess) { fprintf(stderr, "nsgpu: a finished contig's arrays did not arrive on the host\n"); abort(); }
     // the arrays in HBM are no longer needed
-    Block *dev[] = {&b_nodes_, &b_mark_, &b_edges_, &b_chunks_, &b_pe_, &b_pn_, &b_ps_, &b_sve_, &b_svn_, &b_svs_, &b_multi_, &b_wk_, &b_hdr_};
+    Block *dev[] = {&b_nodes_, &b_mark_, &b_pidx_, &b_edges_, &b_chunks_, &b_pe_, &b_pn_, &b_ps_, &b_sve_, &b_svn_, &b_svs_, &b_multi_, &b_wk_, &b_hdr_};
     for (Block *b : dev) give(*b);
     dg::Hdr h = hdr_;
     h.path_off = 0;

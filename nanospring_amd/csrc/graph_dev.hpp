@@ -50,7 +50,7 @@ struct GraphBase {
     virtual ssize_t end_pos() const = 0;
     virtual void set_span(ssize_t s, ssize_t e) = 0;
     virtual size_t num_reads() const = 0;
-    virtual size_t num_edges() const = 0;
+    virtual size_t num_edges() = 0;
     // the accepted read (src/Consensus.cpp:319-331: initialize on the contig's first, updateGraph, calculateMainPathGreedy)
     virtual int submit(const std::string &query, const mm2::AlnOut &aln, read_t id, bool rc) = 0;
     virtual bool ready() = 0;
@@ -73,7 +73,7 @@ struct HostGraph final : GraphBase {
     ssize_t end_pos() const override { return g.end_pos; }
     void set_span(ssize_t s, ssize_t e) override { g.start_pos = s, g.end_pos = e; }
     size_t num_reads() const override { return g.num_reads(); }
-    size_t num_edges() const override { return g.num_edges(); }
+    size_t num_edges() override { return g.num_edges(); }
     int submit(const std::string &query, const mm2::AlnOut &aln, read_t id, bool rc) override;
     bool ready() override { return true; }
     int complete() override { return NSGPU_OK; }
@@ -93,8 +93,9 @@ struct DevGraphShared {
     uint32_t max_ops = 0;                             // longest script the staging buffers take: 2 * longest read + slack
     bool check = false;                               // NSGPU_GRAPH_CHECK: every update also on the host, arrays compared
     uint32_t dbg_flags = 0;
-    std::atomic<uint64_t> n_updates{0}, n_grow{0}, n_mid_copies{0}, kernel_wait_ns{0}, bytes_back{0}, update_ns{0};
-    std::atomic<uint64_t> phase_ticks[8], hist[8], slow_phase[8], cnt[4];             // the kernels' own clock (100 MHz) by phase, summed (debug report)
+    std::atomic<uint64_t> n_updates{0}, n_grow{0}, n_mid_copies{0}, kernel_wait_ns{0}, bytes_back{0}, update_ns{0}, final_wait_ns{0};
+    uint64_t edge_thr = ~0ull;                        // --edge-thr: num_edges() must be exact near it
+    std::atomic<uint64_t> phase_ticks[8], hist[8], slow_phase[8], cnt[4], cyc[6];             // the kernels' own clock (100 MHz) by phase, summed (debug report)
     ~DevGraphShared();
 };
 
@@ -108,7 +109,7 @@ public:
     ssize_t end_pos() const override { return end_; }
     void set_span(ssize_t s, ssize_t e) override { start_ = s, end_ = e; }
     size_t num_reads() const override { return reads_.size(); }
-    size_t num_edges() const override { return hdr_.live_edges; }
+    size_t num_edges() override;
     int submit(const std::string &query, const mm2::AlnOut &aln, read_t id, bool rc) override;
     bool ready() override;
     int complete() override;
@@ -129,15 +130,22 @@ private:
     std::map<read_t, cons::SoaRead> reads_;
     dg::Hdr hdr_;                                     // as of the last completed update
     // arrays in HBM: capacities in entries
-    Block b_nodes_, b_mark_, b_edges_, b_chunks_, b_pe_, b_pn_, b_ps_, b_sve_, b_svn_, b_svs_, b_multi_, b_wk_, b_hdr_;
+    Block b_nodes_, b_mark_, b_pidx_, b_edges_, b_chunks_, b_pe_, b_pn_, b_ps_, b_sve_, b_svn_, b_svs_, b_multi_, b_wk_, b_hdr_;
     uint32_t cap_nodes_ = 0, cap_edges_ = 0, cap_chunks_ = 0, cap_path_ = 0, cap_wk_ = 0, cap_multi_ = 0;
     uint32_t path_off_ = 0;                           // where the host believes the path lies (re-centring moves it)
     std::vector<Block> retired_;                      // replaced arrays: back to the pool when the update that followed the copy is done
     Block pin_;                                       // staging: script, seed, result
     uint32_t epoch_ = 0;
     bool inited_ = false, pending_ = false, prepared_ = false, armed_ = false, moved_path_ = false;
+    bool finalizing_ = false;                         // the update's first report is in (the consensus), its second (after removeCycles) not yet
+    int fail_rc_ = NSGPU_OK;                          // a failure found where no error could be returned: returned by the next call that can
+    uint32_t edges_seen_ = 0;
+    static constexpr uint32_t kEdgeMargin = 1u << 20;
+    int finalize(bool wait);
+    int kernel_error();
     uint32_t ops_cap_ = 0;
-    uint32_t tm_seen_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt_seen_[4] = {0, 0, 0, 0};
+    uint32_t tm_seen_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt_seen_[4] = {0, 0, 0, 0}, cyc_seen_[6] = {0, 0, 0, 0, 0, 0}, dbg_seen_[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long p_begin_ = 0, p_end_ = 0;
     // pending update
     read_t p_id_ = 0; long p_pos_ = 0; size_t p_len_ = 0; bool p_rc_ = false; double p_t0_ = 0;
     // the finished contig on the host

@@ -10,4 +10,4 @@ for i in $(seq 1 ${REPS:-2}); do
   [ "$TAG" = q ] && NSGPU_GRAPH=host NSGPU_CONS_DEBUG=1 python3 bench.py --steps 1 --warmup 1 $LEAN > gpurun_out/r06_${TAG}_host_$i.json 2> gpurun_out/r06_${TAG}_host_$i.log
 done
 for f in gpurun_out/r06_${TAG}_*.json; do python3 -c "import json,sys; j=json.load(open('$f')); print('$f', j['value'], j['ms_per_step'], j.get('parity',{}).get('all_identical'))"; done
-grep -h "graph kernels\|consensus graphs in HBM" gpurun_out/r06_${TAG}_dev_1.log | tail -4
+grep -h "graph kernels\|consensus graphs in HBM" gpurun_out/r06_${TAG}_dev_1.log | tail -5
