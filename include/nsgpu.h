@@ -294,6 +294,32 @@ int nsgpu_set_schedule_auto(nsgpu_ctx *ctx);
  * nsgpu_get_defer: the setting and how many alignments the last contig stage deferred (out-pointers optional). */
 int nsgpu_set_defer(nsgpu_ctx *ctx, uint32_t anchors, uint32_t slots);
 int nsgpu_get_defer(const nsgpu_ctx *ctx, uint32_t *anchors, uint32_t *slots, uint64_t *n_deferred);
+/* Where the contigs' consensus graphs live (ConsensusGraph: updateGraph, calculateMainPathGreedy, removeCycles / splitPath,
+ * src/ConsensusGraph.cpp:400-807 -- the object behind Consensus::generateAndWriteConsensus's `cG`, src/Consensus.cpp:319-331).
+ *   NSGPU_GRAPH_HOST    the pointer graph on the host, updated by the pool's threads (one update = ~0.1 ms of one core);
+ *   NSGPU_GRAPH_DEVICE  a structure of arrays with 32-bit ids in HBM, one workgroup per update (one launch per slot whose workgroups wait
+ *                       for the accepted reads' scripts), the finished contig copied back once for the edit emission;
+ *   NSGPU_GRAPH_AUTO    (default) in HBM when the process has at most 3 host threads (a rank of a shared node: NSGPU_THREADS / the CPU
+ *                       quota divided by the local ranks), else on the host -- the measured cross-over, DESIGN.md section 6.
+ * `| NSGPU_GRAPH_CHECK`: every update in HBM is also run on the host by the same code with a team of one and the arrays are compared entry
+ * by entry (tests).  The environment's NSGPU_GRAPH = host | device | auto applies while this was never called.  Both placements give the
+ * same streams, byte for byte.  nsgpu_get_graph_stats: what the last contig stage used and what the kernels did. */
+enum { NSGPU_GRAPH_AUTO = 0, NSGPU_GRAPH_HOST = 1, NSGPU_GRAPH_DEVICE = 2, NSGPU_GRAPH_CHECK = 0x100 };
+typedef struct {
+    uint32_t placement, checked;        /* NSGPU_GRAPH_HOST or _DEVICE; every update compared with the host's arrays */
+    uint64_t n_updates, n_launches;     /* accepted reads put into graphs in HBM; kernel launches that served them */
+    uint64_t n_array_growths, n_long_reports;   /* arrays re-allocated; new consensus stretches too long for a report (copied by the host) */
+    uint64_t n_sequential_updates, n_full_walks, n_split_calls;   /* updates whose excursions were taken one at a time; removeCycles by the reference's
+                                                                     full walk (the list of noted nodes did not account for all); splitPath calls */
+    double kernel_ms[8];                /* the kernels' own clock, summed over the updates: tables, runs along the path, excursions, choices,
+                                           stitching, writing the path, flags, removeCycles */
+    double report_ms;                   /* script handed over -> consensus reported, summed */
+    double host_wait_first_ms, host_wait_second_ms;   /* host threads waiting for the first (consensus) / second (after removeCycles) report */
+    uint64_t by_duration[8];            /* updates by kernel time: < 0.25 / 0.5 / 1 / 2 / 4 / 8 / 16 ms / more */
+    double gb_copied_back, hbm_peak_gb, hbm_mapped_gb, pinned_peak_gb, pinned_mapped_gb;
+} nsgpu_graph_stats;
+int nsgpu_set_graph(nsgpu_ctx *ctx, uint32_t mode);
+int nsgpu_get_graph_stats(const nsgpu_ctx *ctx, nsgpu_graph_stats *stats_out);
 int nsgpu_get_schedule2(const nsgpu_ctx *ctx, uint32_t *groups, uint32_t *seed_bucket_depth, uint32_t *seed_rings, uint32_t *seed_tail_rings, uint32_t *builders);
 int nsgpu_get_schedule(const nsgpu_ctx *ctx, uint32_t *groups, uint32_t *seed_bucket_depth, uint32_t *seed_rings);
 int nsgpu_consensus_run(nsgpu_ctx *ctx, uint32_t n_builders, uint32_t n_threads_out, nsgpu_consensus_stats *stats_out);

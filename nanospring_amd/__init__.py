@@ -13,7 +13,7 @@ import os as _os
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from ._lib import NsGpuError, lib_path, load_library, Params, Timing  # noqa: F401
-from .filter import NsGpu, MinHashReadFilter, mt19937_64_salts, synth_reads, ksw_extd2_batch, align_batch, align_stats, consensus_run, consensus_stream, consensus_verify, consensus_write, set_schedule, set_defer, get_defer, bwt_block, bsc_aux_rate  # noqa: F401
+from .filter import NsGpu, MinHashReadFilter, mt19937_64_salts, synth_reads, ksw_extd2_batch, align_batch, align_stats, consensus_run, consensus_stream, consensus_verify, consensus_write, set_schedule, set_defer, get_defer, bwt_block, bsc_aux_rate, set_graph, graph_stats, GRAPH_AUTO, GRAPH_HOST, GRAPH_DEVICE, GRAPH_CHECK  # noqa: F401
 
 __all__ = ["NsGpuError", "lib_path", "load_library", "Params", "Timing", "NsGpu", "MinHashReadFilter",
            "mt19937_64_salts", "synth_reads", "ksw_extd2_batch", "align_batch", "align_stats", "consensus_run", "consensus_stream", "consensus_verify", "consensus_write", "set_schedule"]

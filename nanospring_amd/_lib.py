@@ -67,6 +67,8 @@ SIGNATURES = {
     "nsgpu_set_schedule_auto": (C.c_int, [_vp]),
     "nsgpu_set_defer": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "nsgpu_get_defer": (C.c_int, [_vp, _u32p, _u32p, C.POINTER(C.c_uint64)]),
+    "nsgpu_set_graph": (C.c_int, [_vp, C.c_uint32]),
+    "nsgpu_get_graph_stats": (C.c_int, [_vp, _vp]),
     "nsgpu_get_schedule2": (C.c_int, [_vp, _u32p, _u32p, _u32p, _u32p, _u32p]),
     "nsgpu_get_schedule": (C.c_int, [_vp, _u32p, _u32p, _u32p]),
     "nsgpu_cons_begin": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),

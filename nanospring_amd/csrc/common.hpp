@@ -262,6 +262,8 @@ struct nsgpu_ctx {
     bool sched_auto = false, sched_set = false;      // nsgpu_set_schedule_auto / an explicit nsgpu_set_schedule: 0 builders with neither = the automatic schedule
     void *cons_engine = nullptr;                 // resumable contig engine (consensus_driver.hip)
     void (*cons_engine_free)(void *) = nullptr;
+    uint32_t graph_mode = 0; bool graph_mode_set = false;          // nsgpu_set_graph
+    uint32_t graph_used = 0;                     // what the last contig stage used (NSGPU_GRAPH_HOST / _DEVICE)
     void *graph_shared = nullptr;                // pools and streams of the consensus graphs in HBM (graph_dev.hpp), made on first use
     void (*graph_shared_free)(void *) = nullptr;
     uint64_t cons_n_reads_out = 0;               // reads covered by this context's output streams

@@ -25,7 +25,13 @@ static void graph_shared_free(void *p) { delete static_cast<DevGraphShared *>(p)
 static int graph_shared_get(nsgpu_ctx *c, DevGraphShared **out)
 {
     *out = nullptr;
-    if (!graph_on_device()) return NSGPU_OK;
+    uint32_t mode = c->graph_mode & 0xffu;
+    bool check = (c->graph_mode & NSGPU_GRAPH_CHECK) != 0 || getenv("NSGPU_GRAPH_CHECK") != nullptr;
+    if (!c->graph_mode_set) { const char *e = getenv("NSGPU_GRAPH"); if (e) mode = !strcmp(e, "host") ? NSGPU_GRAPH_HOST : !strcmp(e, "device") ? NSGPU_GRAPH_DEVICE : NSGPU_GRAPH_AUTO; }
+    // (the measured cross-over: with 16 threads the pointer graph's updates ride on the DP phase for nothing, with 2 they ARE the step)
+    if (mode == NSGPU_GRAPH_AUTO) mode = host_threads() <= 3 ? NSGPU_GRAPH_DEVICE : NSGPU_GRAPH_HOST;
+    c->graph_used = mode;
+    if (mode != NSGPU_GRAPH_DEVICE) return NSGPU_OK;
     if (!c->graph_shared) {
         DevGraphShared *sh = new DevGraphShared();
         c->graph_shared = sh, c->graph_shared_free = graph_shared_free;
@@ -36,9 +42,9 @@ static int graph_shared_get(nsgpu_ctx *c, DevGraphShared **out)
     }
     DevGraphShared *sh = static_cast<DevGraphShared *>(c->graph_shared);
     sh->max_ops = 2 * c->reads.max_len + 64;
-    sh->check = getenv("NSGPU_GRAPH_CHECK") != nullptr;
+    sh->check = check;
     { const char *e = getenv("NSGPU_SOA_DEBUG_FLAGS"); sh->dbg_flags = e ? (uint32_t)atoi(e) : 0; }
-    sh->n_updates = 0, sh->n_launches = 0, sh->n_grow = 0, sh->n_mid_copies = 0, sh->kernel_wait_ns = 0, sh->bytes_back = 0, sh->update_ns = 0, sh->final_wait_ns = 0;
+    sh->n_updates = 0, sh->n_launches = 0, sh->n_grow = 0, sh->n_mid_copies = 0, sh->kernel_wait_ns = 0, sh->bytes_back = 0, sh->update_ns = 0, sh->final_wait_ns = 0, sh->n_seq_updates = 0, sh->n_full_walks = 0, sh->n_splits = 0;
     sh->edge_thr = c->prm.edge_threshold;
     for (auto &t : sh->phase_ticks) t = 0;
     for (auto &t : sh->hist) t = 0;
@@ -1539,6 +1545,31 @@ int nsgpu_set_defer(nsgpu_ctx *c, uint32_t anchors, uint32_t slots)
     NS_CHECK(!c->cons_engine, NSGPU_ERR_ARG, "nsgpu_set_defer: a contig stage is in progress");
     NS_CHECK(slots <= 3 && (slots == 0 || anchors >= 1), NSGPU_ERR_ARG, "nsgpu_set_defer: 0 .. 3 slots, at least one anchor");
     c->defer_anchors = slots ? anchors : 0, c->defer_slots = slots, c->defer_set = true;
+    return NSGPU_OK;
+}
+
+int nsgpu_set_graph(nsgpu_ctx *c, uint32_t mode)
+{
+    NS_CHECK(c, NSGPU_ERR_ARG, "null ctx");
+    NS_CHECK(!c->cons_engine, NSGPU_ERR_ARG, "nsgpu_set_graph: a contig stage is in progress");
+    NS_CHECK((mode & 0xffu) <= NSGPU_GRAPH_DEVICE && !(mode & ~(0xffu | NSGPU_GRAPH_CHECK)), NSGPU_ERR_ARG, "nsgpu_set_graph: NSGPU_GRAPH_AUTO / _HOST / _DEVICE, optionally | NSGPU_GRAPH_CHECK");
+    c->graph_mode = mode, c->graph_mode_set = true;
+    return NSGPU_OK;
+}
+
+int nsgpu_get_graph_stats(const nsgpu_ctx *c, nsgpu_graph_stats *o)
+{
+    NS_CHECK(c && o, NSGPU_ERR_ARG, "nsgpu_get_graph_stats: null argument");
+    memset(o, 0, sizeof(*o));
+    o->placement = c->graph_used;
+    if (c->graph_used != NSGPU_GRAPH_DEVICE || !c->graph_shared) return NSGPU_OK;
+    const DevGraphShared &G = *static_cast<const DevGraphShared *>(c->graph_shared);
+    o->checked = G.check;
+    o->n_updates = G.n_updates.load(), o->n_launches = G.n_launches.load(), o->n_array_growths = G.n_grow.load(), o->n_long_reports = G.n_mid_copies.load();
+    o->n_sequential_updates = G.n_seq_updates.load(), o->n_full_walks = G.n_full_walks.load(), o->n_split_calls = G.n_splits.load();
+    for (int i = 0; i < 8; ++i) o->kernel_ms[i] = G.phase_ticks[i].load() / 1e5, o->by_duration[i] = G.hist[i].load();
+    o->report_ms = G.update_ns.load() / 1e6, o->host_wait_first_ms = G.kernel_wait_ns.load() / 1e6, o->host_wait_second_ms = G.final_wait_ns.load() / 1e6;
+    o->gb_copied_back = G.bytes_back.load() / 1e9, o->hbm_peak_gb = G.dev.peak() / 1e9, o->hbm_mapped_gb = G.dev.mapped() / 1e9, o->pinned_peak_gb = G.pin.peak() / 1e9, o->pinned_mapped_gb = G.pin.mapped() / 1e9;
     return NSGPU_OK;
 }
 

@@ -79,8 +79,9 @@ struct Hdr {
     uint32_t ending_id, starting_id;                  // the smallest read id on the path's last / first edge
     uint32_t st_splits, st_detours, st_walked, st_seq_exc, st_cycles_run, st_full_walk, st_dis;
     uint32_t stage;                                   // of the recompute: 2 = choosing (nothing changed yet), 3 = changing the graph
-    uint32_t dbg_flags;                               // tests: 1 = excursions one at a time, 2 = removeCycles by the reference's full walk, 4 = a longer path always moves its left part, 8 = chain runs of splitPath with a team of one too
+    uint32_t dbg_flags;                               // tests: 1 = excursions one at a time, 2 = removeCycles by the reference's full walk, 4 = a longer path always moves its left part, 8 = chain runs of splitPath and probes with a team of one too, 16 = no probes, 32 = no chain runs
     uint32_t err_line;                                // where the first error was raised (dgraph.hpp line)
+    uint32_t err_info[4];                             // what it was about (node / index ...)
     uint32_t st_search, st_steps, st_idscan, st_ctx;   // thread 0's loops: rejoin searches (entries looked at), detour steps, read ids compared in splitPath, its contexts
     uint32_t st_gap, st_ended, st_last[6];             // by-passed nodes in sum; walks that ended; the last recompute's R, Lf, m, la, lenF, touch_hi
     uint32_t st_pops, st_probes, st_anc, st_probed;    // removeCycles' walk: edges popped; probes asked; ancestor steps; nodes the probes covered
@@ -120,6 +121,7 @@ struct HostTeam {
     DG_HD uint32_t clock() const { return 0; }                                      // a free-running counter (debug report)
     DG_HD void add_to(uint32_t *p, uint32_t v) { *p += v; }                         // a sum several threads contribute to
     DG_HD void min_to(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }              // a minimum ...
+    DG_HD uint32_t peek(const uint32_t *p) const { return *p; }                      // ... and how such a word is read (on the device: past the first-level cache, which the others' atomic updates do not reach)
     // Thread 0 working alone while the others wait for its orders (removeCycles): on the device a barrier belongs to a whole wavefront, so the
     // lanes that share thread 0's wavefront sit such a stretch out and the team that takes the orders is thread 0 + the other wavefronts.
     DG_HD bool helper() const { return false; }                                      // this thread takes thread 0's orders
@@ -853,8 +855,9 @@ template <class T> struct Ops {
         ord[1] = kind, ord[2] = X0, ord[3] = E0, ord[4] = maxn, ord[5] = e_into, ord[6] = maxn, ord[7] = fill_at;
         (void)team.bcast(2);
         probe_run();
-        ++g.h->st_probes, g.h->st_probed += ord[6];
-        return ord[6];
+        const uint32_t L = team.peek(&ord[6]);
+        ++g.h->st_probes, g.h->st_probed += L;
+        return L;
     }
     DG_COLD void probe_run()
     {
@@ -881,17 +884,17 @@ template <class T> struct Ops {
                 if (!ok) team.min_to(&ord[6], i);
             }
             team.sync();
-            if (ord[6] < base + nc) break;
+            if (team.peek(&ord[6]) < base + nc) break;
         }
         team.sync();
         if (kind == 3) {                                     // (the stretch's nodes are ancestors of a node removeCycles works on)
-            const uint32_t L = ord[6];
+            const uint32_t L = team.peek(&ord[6]);
             for (uint32_t i = cr; i < L; i += nc) g.mark[X0 - i] = h.epoch;
             team.sync();
         }
         if (kind == 2) {
             const CycWk K = cyc_wk();
-            const uint32_t L = ord[6], at = ord[7];
+            const uint32_t L = team.peek(&ord[6]), at = ord[7];
             for (uint32_t i = cr; i < L; i += nc) K.chain[at + i] = i ? E0 + i - 1 : ord[5], K.chain[K.cap_chain + at + i] = X0 + i;
             team.sync();
         }
@@ -905,7 +908,7 @@ template <class T> struct Ops {
             if (o == 1) split_chain_run(cyc_wk()); else probe_run();
         }
     }
-    DG_HD bool probing() const { return team.crew_size() > 1 || (g.h->dbg_flags & 8u); }
+    DG_HD bool probing() const { return (team.crew_size() > 1 && !(g.h->dbg_flags & 16u)) || (g.h->dbg_flags & 8u); }
 
     // thread 0: the walk from old node R to the right.  D: (index, chosen edge) of the old nodes in [R, m] whose choice is not the path's edge, ascending.
     DG_COLD void stitch_forward(Stitch &S, const uint32_t *D, uint32_t n_dis, uint32_t R, uint32_t m, uint32_t off)
@@ -957,7 +960,7 @@ template <class T> struct Ops {
                 if (was_on) {
                     uint32_t j = path_index_of(nx);
                     if (j == NIL || j <= pos || j > m) { j = pos + 1; while (j <= m && g.pn[off + j] != nx) ++j; h.st_search += j - pos; }
-                    if (j > m) { fail_at(__LINE__, ERR_WALK); break; }
+                    if (j > m) { h.err_info[0] = nx, h.err_info[1] = pos, h.err_info[2] = g.pidx[nx] + h.pos_bias - off, h.err_info[3] = e; fail_at(__LINE__, ERR_WALK); break; }
                     emit_gap(S, pos + 1, j);
                     pos = j;
                     break;
@@ -1335,7 +1338,7 @@ template <class T> struct Ops {
             while (own_n && !failed()) {
                 // A stretch of nodes with one way out each (a by-passed piece of the old path, typically): not one step of this loop after the
                 // other -- the whole team takes the stretch at once (split_chain_run)
-                if (own_n <= kEdgeInl && (team.crew_size() > 1 || (h.dbg_flags & 8u))) {
+                if (own_n <= kEdgeInl && ((team.crew_size() > 1 && !(h.dbg_flags & 32u)) || (h.dbg_flags & 8u))) {
                     uint32_t k = 0, ce = e;
                     const uint32_t d0 = team.clock();
                     const uint32_t lim = K.cap_chain < 4096 ? K.cap_chain : 4096;
@@ -1462,8 +1465,8 @@ template <class T> struct Ops {
         team.sync();
         if (tid == 0 && k_eff) {
             out_push(new_pre, ebase | (code_of(g.nodes[CX[0]].base) << 29));
-            h.n_nodes += k_eff, h.live_nodes += k_eff, h.n_edges += k_eff, h.live_edges += k_eff - K.order[7];
-            h.n_multi -= K.order[8];
+            h.n_nodes += k_eff, h.live_nodes += k_eff, h.n_edges += k_eff, h.live_edges += k_eff - team.peek(&K.order[7]);
+            h.n_multi -= team.peek(&K.order[8]);
         }
         team.sync();
     }

@@ -18,6 +18,7 @@ struct DevTeam {
     __device__ uint32_t clock() const { return (uint32_t)wall_clock64(); }       // 100 MHz
     __device__ void add_to(uint32_t *p, uint32_t v) { atomicAdd(p, v); }
     __device__ void min_to(uint32_t *p, uint32_t v) { atomicMin(p, v); }
+    __device__ uint32_t peek(const uint32_t *p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ bool helper() const { return threadIdx.x >= 64u; }
     __device__ uint32_t crew_rank() const { return threadIdx.x == 0 ? 0u : threadIdx.x - 63u; }
     __device__ uint32_t crew_size() const { return blockDim.x > 64u ? blockDim.x - 63u : 1u; }
@@ -240,12 +241,6 @@ DevGraphShared::~DevGraphShared()
     if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
 }
 
-bool graph_on_device()
-{
-    static const bool dev = [] { const char *e = getenv("NSGPU_GRAPH"); return !(e && !strcmp(e, "host")); }();
-    return dev;
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------
 // the pointer graph on the host
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -360,7 +355,6 @@ int DevGraph::grow(const cons::SoaNeed &need, uint32_t seed_len)
     const uint32_t len = inited_ ? hdr_.m + 1 : 0;
     const uint32_t side = inited_ ? need.path_side : seed_len + need.path_side;
     const bool short_left = path_off_ < side, short_right = (uint64_t)path_off_ + len + side > cap_path_;
-    moved_path_ = false;
     if (!inited_ || short_left || short_right) {
         const size_t c = bigger(0, (size_t)len + (inited_ ? 0 : seed_len) + 4 * (size_t)need.path_side + 4096 + len / 2);
         Block e2, n2, s2;
@@ -482,7 +476,10 @@ int DevGraph::submit(const std::string &query, const mm2::AlnOut &aln, read_t id
         path_changed_from = 0;
         path_off_ = (cap_path_ - (uint32_t)path_.size()) / 2;            // (where initialize puts the seed)
         inited_ = true;
-        if (sh_->check) { shadow_.reset(new cons::SoaGraph()); shadow_->first_read = first_read; shadow_->initialize(path_, first_read, 0); shadow_->calculate_main_path_greedy(); }
+        if (sh_->check) {
+            shadow_.reset(new cons::SoaGraph()); shadow_->first_read = first_read; shadow_->initialize(path_, first_read, 0); shadow_->calculate_main_path_greedy();
+            ptr_shadow_.reset(new cons::ContigGraph()); ptr_shadow_->first_read = first_read; ptr_shadow_->initialize(path_, first_read, 0); ptr_shadow_->calculate_main_path_greedy();
+        }
     }
     p_begin_ = (long long)aln.begin_offset, p_end_ = (long long)aln.end_offset;
     p_id_ = id, p_pos_ = (long)aln.rel_pos, p_len_ = query.size(), p_rc_ = rc, p_t0_ = now_ms_();
@@ -492,6 +489,17 @@ int DevGraph::submit(const std::string &query, const mm2::AlnOut &aln, read_t id
     if (shadow_) {
         shadow_->update_graph(query, aln.edits, (ssize_t)aln.begin_offset, (ssize_t)aln.end_offset, id, (long)aln.rel_pos, rc);
         shadow_->calculate_main_path_greedy();
+        // (and the pointer graph: the two host graphs must agree on the consensus, the span and the size after every read)
+        ptr_shadow_->update_graph(query, aln.edits, (ssize_t)aln.begin_offset, (ssize_t)aln.end_offset, id, (long)aln.rel_pos, rc);
+        ptr_shadow_->calculate_main_path_greedy();
+        if (ptr_shadow_->main_path != shadow_->main_path || ptr_shadow_->start_pos != shadow_->start_pos || ptr_shadow_->end_pos != shadow_->end_pos || ptr_shadow_->num_edges() != shadow_->num_edges()) {
+            size_t d = 0;
+            while (d < ptr_shadow_->main_path.size() && d < shadow_->main_path.size() && ptr_shadow_->main_path[d] == shadow_->main_path[d]) ++d;
+            set_error("consensus graph check: the structure-of-arrays graph and the pointer graph differ after read %u (the contig's read number %zu): consensus %zu / %zu bases, first difference at %zu; start %zd / %zd, end %zd / %zd, edges %zu / %zu; begin %lld end %lld, %zu ops, read of %zu",
+                      (unsigned)id, reads_.size(), shadow_->main_path.size(), ptr_shadow_->main_path.size(), d, shadow_->start_pos, ptr_shadow_->start_pos, shadow_->end_pos, ptr_shadow_->end_pos, shadow_->num_edges(), ptr_shadow_->num_edges(),
+                      (long long)aln.begin_offset, (long long)aln.end_offset, aln.edits.size(), query.size());
+            return fail_rc_ = NSGPU_ERR_RANGE;
+        }
     }
     return NSGPU_OK;
 }
@@ -531,6 +539,7 @@ int DevGraph::complete()
     const DgResult *res = reinterpret_cast<const DgResult *>(static_cast<const DgSlot *>(pin_.p) + 1);
     hdr_ = res->hdr;
     pending_ = false;
+    moved_path_ = false;                                  // (the kernel has taken the arrays' new place over into the graph's header)
     finalizing_ = true;                                   // (removeCycles behind the recompute may still be running: finalize())
     sh_->update_ns += (uint64_t)((now_ms_() - p_t0_) * 1e6);
     if (hdr_.err) return kernel_error();
@@ -557,8 +566,8 @@ int DevGraph::complete()
 
 int DevGraph::kernel_error()
 {
-    set_error("consensus graph kernel: error %u raised at dgraph.hpp:%u (capacity %u / script %u / degree %u / walk %u / work area %u) at read %u, %u nodes, %u edges, path %u", hdr_.err, hdr_.err_line, hdr_.err & dg::ERR_CAP,
-              hdr_.err & dg::ERR_SCRIPT, hdr_.err & dg::ERR_DEGREE, hdr_.err & dg::ERR_WALK, hdr_.err & dg::ERR_SCRATCH, (unsigned)p_id_, hdr_.n_nodes, hdr_.n_edges, hdr_.m);
+    set_error("consensus graph kernel: error %u raised at dgraph.hpp:%u (capacity %u / script %u / degree %u / walk %u / work area %u) at read %u, %u nodes, %u edges, path %u; info %u %u %u %u; R %u Lf %u touch %u..%u cons_from %u begin %lld end %lld", hdr_.err, hdr_.err_line, hdr_.err & dg::ERR_CAP,
+              hdr_.err & dg::ERR_SCRIPT, hdr_.err & dg::ERR_DEGREE, hdr_.err & dg::ERR_WALK, hdr_.err & dg::ERR_SCRATCH, (unsigned)p_id_, hdr_.n_nodes, hdr_.n_edges, hdr_.m, hdr_.err_info[0], hdr_.err_info[1], hdr_.err_info[2], hdr_.err_info[3], hdr_.right_off, hdr_.left_off, hdr_.upd_touch_lo, hdr_.upd_touch_hi, hdr_.cons_from, p_begin_, p_end_);
     return NSGPU_ERR_RANGE;
 }
 
@@ -610,6 +619,8 @@ int DevGraph::finalize(bool wait)
     for (int i = 0; i < 6; ++i) { sh_->cyc[i] += (uint32_t)(hdr_.st_cyc[i] - cyc_seen_[i]); cyc_seen_[i] = hdr_.st_cyc[i]; }
     sh_->cnt[0] += hdr_.st_search - cnt_seen_[0], sh_->cnt[1] += hdr_.st_steps - cnt_seen_[1], sh_->cnt[2] += hdr_.st_idscan - cnt_seen_[2], sh_->cnt[3] += hdr_.st_ctx - cnt_seen_[3];
     cnt_seen_[0] = hdr_.st_search, cnt_seen_[1] = hdr_.st_steps, cnt_seen_[2] = hdr_.st_idscan, cnt_seen_[3] = hdr_.st_ctx;
+    sh_->n_seq_updates += hdr_.st_seq_exc - seen3_[0], sh_->n_full_walks += hdr_.st_full_walk - seen3_[1], sh_->n_splits += hdr_.st_splits - seen3_[2];
+    seen3_[0] = hdr_.st_seq_exc, seen3_[1] = hdr_.st_full_walk, seen3_[2] = hdr_.st_splits;
     dbg[0] += 1, dbg[1] = dbg[0] - hdr_.st_cycles_run, dbg[2] = hdr_.st_detours, dbg[4] = hdr_.st_walked, dbg[5] = hdr_.st_cycles_run - hdr_.st_full_walk, dbg[6] = hdr_.st_splits, dbg[7] = hdr_.st_seq_exc;
     if (shadow_) { const int rc = check_against_shadow("update"); if (rc != NSGPU_OK) return fail_rc_ = rc; }
     return NSGPU_OK;
@@ -674,18 +685,22 @@ int DevGraph::emit_begin()
     if (e_begun_ || !inited_) return NSGPU_OK;
     NS_CHECK(!pending_, NSGPU_ERR_ARG, "consensus graph: emission with an update in flight (internal error)");
     NS_TRY(finalize(true));
-    const dg::Hdr &h = hdr_;
+    const dg::Hdr &h = hdr_;       // (the path lies at path_off_: a prepare() whose update never came may have moved the arrays since the header was reported)
     NS_TRY(take(e_nodes_, std::max<size_t>(64, (size_t)h.n_nodes * sizeof(dg::Node)), true));
     NS_TRY(take(e_edges_, std::max<size_t>(64, (size_t)h.n_edges * sizeof(dg::Edge)), true));
     NS_TRY(take(e_chunks_, std::max<size_t>(64, (size_t)h.n_chunks * sizeof(dg::Chunk)), true));
     NS_TRY(take(e_pe_, ((size_t)h.m + 1) * 4, true)); NS_TRY(take(e_pn_, ((size_t)h.m + 1) * 4, true)); NS_TRY(take(e_ps_, (size_t)h.m + 1, true));
     hipStream_t cs = sh_->copy_stream;
+    // (a prepare() whose update never came may have left array copies queued on the serve stream: the copies back come behind them)
+    if (!e_ev_) NS_HIP(hipEventCreateWithFlags(&e_ev_, hipEventDisableTiming));
+    NS_HIP(hipEventRecord(e_ev_, sh_->serve_stream));
+    NS_HIP(hipStreamWaitEvent(cs, e_ev_, 0));
     NS_HIP(hipMemcpyAsync(e_nodes_.p, b_nodes_.p, (size_t)h.n_nodes * sizeof(dg::Node), hipMemcpyDeviceToHost, cs));
     if (h.n_edges) NS_HIP(hipMemcpyAsync(e_edges_.p, b_edges_.p, (size_t)h.n_edges * sizeof(dg::Edge), hipMemcpyDeviceToHost, cs));
     if (h.n_chunks) NS_HIP(hipMemcpyAsync(e_chunks_.p, b_chunks_.p, (size_t)h.n_chunks * sizeof(dg::Chunk), hipMemcpyDeviceToHost, cs));
-    if (h.m) NS_HIP(hipMemcpyAsync(e_pe_.p, static_cast<uint32_t *>(b_pe_.p) + h.path_off, (size_t)h.m * 4, hipMemcpyDeviceToHost, cs));
-    NS_HIP(hipMemcpyAsync(e_pn_.p, static_cast<uint32_t *>(b_pn_.p) + h.path_off, ((size_t)h.m + 1) * 4, hipMemcpyDeviceToHost, cs));
-    NS_HIP(hipMemcpyAsync(e_ps_.p, static_cast<uint8_t *>(b_ps_.p) + h.path_off, (size_t)h.m + 1, hipMemcpyDeviceToHost, cs));
+    if (h.m) NS_HIP(hipMemcpyAsync(e_pe_.p, static_cast<uint32_t *>(b_pe_.p) + path_off_, (size_t)h.m * 4, hipMemcpyDeviceToHost, cs));
+    NS_HIP(hipMemcpyAsync(e_pn_.p, static_cast<uint32_t *>(b_pn_.p) + path_off_, ((size_t)h.m + 1) * 4, hipMemcpyDeviceToHost, cs));
+    NS_HIP(hipMemcpyAsync(e_ps_.p, static_cast<uint8_t *>(b_ps_.p) + path_off_, (size_t)h.m + 1, hipMemcpyDeviceToHost, cs));
     if (!e_ev_) NS_HIP(hipEventCreateWithFlags(&e_ev_, hipEventDisableTiming));
     NS_HIP(hipEventRecord(e_ev_, cs));
     sh_->bytes_back += (uint64_t)h.n_nodes * sizeof(dg::Node) + (uint64_t)h.n_edges * sizeof(dg::Edge) + (uint64_t)h.n_chunks * sizeof(dg::Chunk) + (uint64_t)h.m * 9;

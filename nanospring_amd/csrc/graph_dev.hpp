@@ -94,6 +94,7 @@ struct DevGraphShared {
     bool check = false;                               // NSGPU_GRAPH_CHECK: every update also on the host, arrays compared
     uint32_t dbg_flags = 0;
     std::atomic<uint64_t> n_updates{0}, n_grow{0}, n_mid_copies{0}, kernel_wait_ns{0}, bytes_back{0}, update_ns{0}, final_wait_ns{0};
+    std::atomic<uint64_t> n_seq_updates{0}, n_full_walks{0}, n_splits{0};
     uint64_t edge_thr = ~0ull;                        // --edge-thr: num_edges() must be exact near it
     std::atomic<uint64_t> phase_ticks[8], hist[8], slow_phase[8], cnt[4], cyc[6];             // the kernels' own clock (100 MHz) by phase, summed (debug report)
     ~DevGraphShared();
@@ -139,7 +140,7 @@ private:
     bool inited_ = false, pending_ = false, prepared_ = false, armed_ = false, moved_path_ = false;
     bool finalizing_ = false;                         // the update's first report is in (the consensus), its second (after removeCycles) not yet
     int fail_rc_ = NSGPU_OK;                          // a failure found where no error could be returned: returned by the next call that can
-    uint32_t edges_seen_ = 0;
+    uint32_t edges_seen_ = 0, seen3_[3] = {0, 0, 0};
     static constexpr uint32_t kEdgeMargin = 1u << 20;
     int finalize(bool wait);
     int kernel_error();
@@ -154,6 +155,7 @@ private:
     bool e_begun_ = false;
     // NSGPU_GRAPH_CHECK
     std::unique_ptr<cons::SoaGraph> shadow_;
+    std::unique_ptr<cons::ContigGraph> ptr_shadow_;
     dg::G view() const;
     int grow(const cons::SoaNeed &need, uint32_t seed_len);
     int take(Block &b, size_t bytes, bool pinned = false);
@@ -164,7 +166,5 @@ private:
 
 int graph_serve_launch(DevGraphShared *sh, DevGraph *const *graphs, size_t n);
 
-// the engine's choice (NSGPU_GRAPH=host keeps the pointer graph on the host)
-bool graph_on_device();
 
 }  // namespace nsgpu

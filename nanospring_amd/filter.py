@@ -421,6 +421,32 @@ def get_defer(gpu):
     return int(a.value), int(s.value), int(n.value)
 
 
+GRAPH_AUTO, GRAPH_HOST, GRAPH_DEVICE, GRAPH_CHECK = 0, 1, 2, 0x100
+
+
+class GraphStats(C.Structure):
+    _fields_ = [("placement", C.c_uint32), ("checked", C.c_uint32)] + \
+               [(n, C.c_uint64) for n in ("n_updates", "n_launches", "n_array_growths", "n_long_reports", "n_sequential_updates", "n_full_walks", "n_split_calls")] + \
+               [("kernel_ms", C.c_double * 8), ("report_ms", C.c_double), ("host_wait_first_ms", C.c_double), ("host_wait_second_ms", C.c_double), ("by_duration", C.c_uint64 * 8)] + \
+               [(n, C.c_double) for n in ("gb_copied_back", "hbm_peak_gb", "hbm_mapped_gb", "pinned_peak_gb", "pinned_mapped_gb")]
+
+
+def set_graph(gpu, mode):
+    """where the contigs' consensus graphs live: GRAPH_AUTO / GRAPH_HOST / GRAPH_DEVICE, optionally | GRAPH_CHECK (nsgpu_set_graph)"""
+    check(gpu.lib, gpu.lib.nsgpu_set_graph(gpu.ctx, int(mode)))
+
+
+def graph_stats(gpu):
+    """what the last contig stage used and what its graph kernels did (nsgpu_get_graph_stats)"""
+    s = GraphStats()
+    check(gpu.lib, gpu.lib.nsgpu_get_graph_stats(gpu.ctx, C.byref(s)))
+    d = {k: getattr(s, k) for k, _ in GraphStats._fields_}
+    d["kernel_ms"] = [float(x) for x in s.kernel_ms]
+    d["by_duration"] = [int(x) for x in s.by_duration]
+    d["placement"] = {1: "host", 2: "device"}.get(int(s.placement), "none")
+    return d
+
+
 def consensus_run(gpu, n_builders=256, n_threads_out=1, schedule=None, defer=None):
     """schedule: (groups, depth, rings[, tail rings]), or "auto" (nsgpu_set_schedule_auto; n_builders = 0 lets the library choose the count too);
     defer: (anchors, slots) for nsgpu_set_defer"""
