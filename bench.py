@@ -154,6 +154,9 @@ def main():
     ap.add_argument("--cpu-full", type=int, default=-1, help="also time the reference's -t <cores> (oracle) on the FULL input of the timed steps on this host, ~1-2 min (default: only with 1 GPU at full cfg2 size and a CPU sample; 0 = skip)")
     ap.add_argument("--legal-leg", type=int, default=-1, help="also time ONE step of the fastest reference-legal schedule within 5 %% of the reference's streams: 32 builders, one group, Consensus::getRead's seed rule (default: only with 1 GPU at full cfg2 size; 0 = skip)")
     ap.add_argument("--nonideal-leg", type=int, default=-1, help="also time ONE step on a genome with planted repeats (default: only with 1 GPU at full cfg2 size; 0 = skip)")
+    ap.add_argument("--graph", choices=["auto", "host", "device"], default="auto", help="where the contigs' consensus graphs live (nsgpu_set_graph): in HBM (one workgroup per accepted read), on the host (pointer graph), or by the host threads this process has (auto: in HBM with at most 3)")
+    ap.add_argument("--graph-leg", type=int, default=-1, help="also time ONE first step with the consensus graphs in the other placement (default: only with 1 GPU at full cfg2 size; 0 = skip)")
+    ap.add_argument("--cfg3-leg", type=int, default=-1, help="also time ONE first step of BASELINE configs[2]'s shape (1.0 Gbase at 217x of a 4.6 Mb genome, automatic schedule) (default: only with 1 GPU at full cfg2 size; 0 = skip)")
     ap.add_argument("--no-exchange", action="store_true", help="multi-GPU: independent shards, no collective")
     ap.add_argument("--dist-mode", choices=["alltoall", "replicate"], default="alltoall",
                     help="multi-GPU bucket tables: owners of an RCCL all-to-all of (slot, key, id) tuples, or all-gathered sketch rows")
@@ -197,6 +200,9 @@ def main():
         else:
             ns.set_schedule(ctx, args.groups, args.seed_depth, args.seed_rings, args.seed_tail_rings)
     apply_schedule(g)
+    graph_mode = {"auto": ns.GRAPH_AUTO, "host": ns.GRAPH_HOST, "device": ns.GRAPH_DEVICE}[args.graph]
+    if args.graph != "auto":
+        ns.set_graph(g, graph_mode)          # (auto: the library's own choice -- NSGPU_GRAPH, else by the host threads of this process)
     job = None
     if exchange:
         # the C++ driver (csrc/dist.hip): the library's own RCCL communicator; Python only calls three entry points
@@ -259,7 +265,7 @@ def main():
         # what every rank did, so that a scaling curve can be read: host threads (the node's CPU quota is divided by LOCAL_WORLD_SIZE),
         # collective bytes received, host memory of the replicated read copy, the rank's own step time
         mine = {"rank": rank, "host_threads": ns.align_stats(g)["host_threads"], "s_per_step": round(dt_local / max(args.steps, 1), 3), "bases": n_bases,
-                "contigs": st["n_contigs"] if st else 0, "rounds": st["n_rounds"] if st else 0}
+                "contigs": st["n_contigs"] if st else 0, "rounds": st["n_rounds"] if st else 0, "consensus_graphs": ns.graph_stats(g)["placement"]}
         if job is not None:
             mine.update(job.comm_stats())
         gathered = [None] * world
@@ -365,7 +371,7 @@ def main():
             g.sketch(salts, fetch=False); g.build_index()
             ns.consensus_run(g, 1024, 8)                                   # warm-up (buffers of this batch size)
             torch.cuda.synchronize()
-            leg_steps, leg_ms = 3, []
+            leg_steps, leg_ms = 2, []
             for _ in range(leg_steps):
                 tt = time.perf_counter()
                 g.sketch(salts, fetch=False); g.build_index()
@@ -427,17 +433,57 @@ def main():
         want_ts = args.threads_sweep if args.threads_sweep >= 0 else int(full_size)
         if want_ts and world == 1:
             import subprocess
-            tsweep = {"note": "one first step per thread count, each in a child process (NSGPU_THREADS); the timed steps above ran with host_threads = %d" % a["host_threads"], "runs": []}
+            tsweep = {"note": "one first step per thread count, each in a child process (NSGPU_THREADS), consensus graphs where the library puts them by itself (in HBM with at most 3 host threads); the timed steps above ran with host_threads = %d.  The pointer graph on the host with 2 threads: profiles/r06_graph_placement_by_threads.txt" % a["host_threads"], "runs": []}
             for nthr in (4, 2):
                 cmd = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--throughput-leg", "0", "--cpu-sample", "0", "--cpu-full", "0", "--legal-leg", "0",
                        "--nonideal-leg", "0", "--threads-sweep", "0", "--reads", str(args.reads), "--mean-len", str(args.mean_len), "--depth", str(args.depth), "--genome", args.genome]
                 try:
                     rr = subprocess.run(cmd, env=dict(os.environ, NSGPU_THREADS=str(nthr)), capture_output=True, text=True, timeout=600)
                     cj = json.loads([ln for ln in rr.stdout.splitlines() if ln.startswith("{")][-1])
-                    tsweep["runs"].append({"host_threads": nthr, "value": cj["value"], "unit": "Mbases/s", "ms_per_step": cj["ms_per_step"], "graph_host_wall_ms": cj["config"]["stage_ms_per_step"]["graph_host_wall"],
+                    tsweep["runs"].append({"host_threads": nthr, "value": cj["value"], "unit": "Mbases/s", "ms_per_step": cj["ms_per_step"], "consensus_graphs": cj["config"]["consensus_graph"]["placement"], "graph_host_wall_ms": cj["config"]["stage_ms_per_step"]["graph_host_wall"],
                                            "lossless_roundtrip_bad_reads": cj["config"]["lossless_roundtrip_bad_reads"]})
                 except Exception as ex:                 # (a leg, not the measurement: report and go on)
                     tsweep["runs"].append({"host_threads": nthr, "error": str(ex)[:200]})
+        gstats = ns.graph_stats(g)               # of the last timed step
+        # ONE first step with the consensus graphs in the other placement (same schedule, same streams): what the choice costs / buys on this host
+        gleg = None
+        want_gl = args.graph_leg if args.graph_leg >= 0 else int(full_size)
+        if want_gl and world == 1:
+            other = ns.GRAPH_HOST if gstats["placement"] == "device" else ns.GRAPH_DEVICE
+            ns.set_graph(g, other)
+            tt = time.perf_counter()
+            g.sketch(salts, fetch=False); g.build_index()
+            st5 = ns.consensus_run(g, args.builders, 8)
+            torch.cuda.synchronize()
+            dt5 = time.perf_counter() - tt
+            sb5 = sum(len(ns.consensus_stream(g, t, kk)) for t in range(8) for kk in ns.filter.STREAMS)
+            gs5 = ns.graph_stats(g)
+            gleg = {"consensus_graphs": gs5["placement"], "value": round(n_bases / 1e6 / dt5, 2), "unit": "Mbases/s", "ms_per_step": round(dt5 * 1e3, 1), "steps": 1, "first_step": True, "host_threads": a["host_threads"],
+                    "same_stream_bytes_as_the_timed_steps": sb5 == stream_bytes, "contigs": st5["n_contigs"], "slots": st5["n_rounds"], "lossless_roundtrip_bad_reads": ns.consensus_verify(g),
+                    "parity": parity_of("r03_lockstep_cfg2.json", st5) if default_sched else None, "graph_host_wall_ms": round(st5["graph_ms"], 1), "kernels": gs5 if gs5["placement"] == "device" else None}
+            ns.set_graph(g, graph_mode)
+        # BASELINE configs[2]'s shape: ONE first step of 1.0 Gbase at 217x of a 4.6 Mb genome in the automatic schedule (the E. coli regime: depth, not size)
+        c3leg = None
+        want_c3 = args.cfg3_leg if args.cfg3_leg >= 0 else int(full_size)
+        if want_c3 and world == 1:
+            b3, o3 = ns.synth_reads(11, int(125000 * 8000.0 / 217.0), 125000, 8000.0)
+            g3 = ns.NsGpu(k=k, n=n, overlap_sketch_thr=thr, device=local, stream=stream.cuda_stream)
+            ns.filter.check(g3.lib, g3.lib.nsgpu_set_schedule_auto(g3.ctx))
+            g3.load_reads((b3, o3))
+            tt = time.perf_counter()
+            g3.sketch(salts, fetch=False); g3.build_index()
+            st6 = ns.consensus_run(g3, 0, 8)
+            torch.cuda.synchronize()
+            dt6 = time.perf_counter() - tt
+            sb6 = sum(len(ns.consensus_stream(g3, t, kk)) for t in range(8) for kk in ns.filter.STREAMS)
+            u6 = ns.filter.get_schedule(g3)
+            c3leg = {"value": round(int(o3[-1]) / 1e6 / dt6, 2), "unit": "Mbases/s", "ms_per_step": round(dt6 * 1e3, 1), "steps": 1, "first_step": True,
+                     "workload": "cfg3's shape: 125 000 synthetic ONT reads, mean 8 kb, 217x of a 4.6 Mb iid genome (1.0 Gbase)", "consensus_graphs": ns.graph_stats(g3)["placement"],
+                     "schedule": {"builders": u6[4], "groups": u6[0], "seed_bucket_depth": u6[1], "seed_rings": u6[2], "seed_tail_rings": u6[3], "derived_by": "the library"},
+                     "stream_bytes_per_base": round(sb6 / int(o3[-1]), 4), "reference_t8_stream_bytes_per_base": 0.1062, "ratio_to_reference_t8": round(sb6 / int(o3[-1]) / 0.1062, 4),
+                     "reference_source": "profiles/r04_oracle_t8_cfg3.json (oracle/consensus_oracle.cpp -t 8 on this input)", "contigs": st6["n_contigs"], "slots": st6["n_rounds"], "lossless_roundtrip_bad_reads": ns.consensus_verify(g3)}
+            g3.close()
+            del b3, o3
         comp = None
         pv = os.path.join(ROOT, "profiles", "r02_pmc_ksw_issue.json")
         if args.groups == 1:
@@ -458,7 +504,10 @@ def main():
                                    + ("" if args.genome == "iid" else "; genome with planted repeats (a 4 kb duplication, a 1.5 kb tandem repeat, a homopolymer run, an (AT)n / (ACGT)n run per ~150 kb): NOT the cfg2 genome"),
                        "genome": args.genome,
                        "stages": ["sketch", "bucket-tables", "overlap (window queries)", "align (batched alignRead, DP on GPU)",
-                                  "consensus graph + edit emission (host)"],
+                                  "consensus graph (%s) + edit emission (host)" % ("structure of arrays in HBM, one workgroup per accepted read" if gstats["placement"] == "device" else "pointer graph on the host")],
+                       # where the contigs' consensus graphs lived in the timed steps (nsgpu_set_graph; auto = by host threads) and, in HBM, what their kernels did in
+                       # the last step: n_sequential_updates / n_full_walks / n_long_reports are the slow paths taken (there is no host fall-back)
+                       "consensus_graph": gstats,
                        "bases_per_gpu": n_bases, "builders": st["n_builders"], "schedule": {"groups": args.groups, "seed_bucket_depth": args.seed_depth, "seed_rings": args.seed_rings, "seed_tail_rings": args.seed_tail_rings},
                        "host_threads": a["host_threads"],
                        "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 1),
@@ -489,6 +538,8 @@ def main():
             "throughput_schedule": tleg,
             "reference_legal_schedule": lleg,
             "nonideal": nleg,
+            "consensus_graph_other_placement": gleg,
+            "cfg3": c3leg,
             "host_threads_sweep": tsweep,
             "roofline": {"kernel": "ksw_extd2 (ksw_extd2_reg_kernel<NW,NCH>: DP state in registers)", "bound": "latency" if args.groups == 1 else "valu-issue", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 7), "hbm_frac": round(achieved / HBM_PEAK_GBS, 7), "hbm_copy_measured_gbs": hbm_copy,
@@ -505,8 +556,9 @@ def main():
                                  "measured inside this run, traffic_from_profile is the committed rocprofv3 --pmc figure for the workload it names"},
         }
         if args.cpu_sample != 0:
-            cb = cpu_baseline(args.cpu_sample if args.cpu_sample > 0 else 2000 * host_cores(), args.mean_len, k, n, thr, salts)
             want_full = args.cpu_full if args.cpu_full >= 0 else int(full_size)
+            # (with the full input timed below the bounded sample is only a side figure: a quarter of it, and a short -t 1 run)
+            cb = cpu_baseline(args.cpu_sample if args.cpu_sample > 0 else (500 if want_full and world == 1 else 2000) * host_cores(), args.mean_len, k, n, thr, salts, t1_reads=600 if want_full and world == 1 else 1500)
             if want_full and world == 1:
                 # the reference's -t <cores> on the very input and host of the timed steps: the baseline proper, and the yard-stick of `compression`
                 fi = cpu_full_input(bases, off, k, n, thr, salts)

@@ -193,3 +193,34 @@ def test_bench_two_ranks_on_one_gpu_default_schedule(mode):
     assert ns.consensus_verify(g) == 0
     g.close()
     assert sum(p["contigs"] for p in pr) == st1["n_contigs"] and all(p["rounds"] == st1["n_rounds"] for p in pr)
+
+
+def test_bench_four_ranks_on_one_gpu_two_host_threads_each_graphs_in_hbm():
+    """What a rank of a full node gets: four ranks (one GPU here, collectives over gloo) with TWO host threads each -- the library then keeps the
+    contigs' consensus graphs in HBM (nsgpu_set_graph's automatic rule) -- in the default schedule: every rank reports it, its step time is
+    printed, and the job's contigs and slots are those of one process holding all reads (the result does not depend on the rank count or on
+    where the graphs live)."""
+    import json
+    R, B, L = 400, 8, 3000.0
+    port = "29677"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, NSGPU_BENCH_BACKEND="gloo", NSGPU_THREADS="2")
+    env.pop("NSGPU_GRAPH", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port", port,
+                        os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0", "--reads", str(R), "--mean-len", str(L), "--builders", str(B),
+                        "--cpu-sample", "0"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    pr = j["per_rank"]
+    assert j["n_gpus"] == 4 and [p["rank"] for p in pr] == [0, 1, 2, 3]
+    for p in pr:
+        assert p["host_threads"] == 2 and p["consensus_graphs"] == "device" and p["s_per_step"] > 0
+    print("per-rank step times with 2 host threads each:", [p["s_per_step"] for p in pr])
+    bases, off = ns.synth_reads(11, int(4 * R * L / 20), 4 * R, L)
+    g = ns.NsGpu()
+    g.load_reads((bases, off))
+    g.sketch(ns.mt19937_64_salts(60, 12345), fetch=False)
+    g.build_index()
+    st1 = ns.consensus_run(g, 4 * B, 8, schedule=(1, 3, 5, 3))
+    assert ns.consensus_verify(g) == 0
+    g.close()
+    assert sum(p["contigs"] for p in pr) == st1["n_contigs"] and all(p["rounds"] == st1["n_rounds"] for p in pr)
