@@ -466,7 +466,7 @@ def main():
         c3leg = None
         want_c3 = args.cfg3_leg if args.cfg3_leg >= 0 else int(full_size)
         if want_c3 and world == 1:
-            b3, o3 = ns.synth_reads(11, int(125000 * 8000.0 / 217.0), 125000, 8000.0)
+            b3, o3 = ns.synth_reads(11, 4600000, 125000, 8000.0)      # (the input of profiles/r04_oracle_t8_cfg3.json)
             g3 = ns.NsGpu(k=k, n=n, overlap_sketch_thr=thr, device=local, stream=stream.cuda_stream)
             ns.filter.check(g3.lib, g3.lib.nsgpu_set_schedule_auto(g3.ctx))
             g3.load_reads((b3, o3))
