@@ -95,10 +95,10 @@ void debug_report_stage(nsgpu_ctx *c, Engine *E, const struct rusage &ru0, doubl
         fprintf(stderr, "[cons] graph kernels, ms in sum by phase (their own clock): tables %.0f, runs %.0f, excursions %.0f, choices %.0f, stitching %.0f, writing %.0f, flags + kept ends %.0f, removeCycles %.0f; launch to report %.0f ms in sum\n",
                 G.phase_ticks[0].load() / 1e5, G.phase_ticks[1].load() / 1e5, G.phase_ticks[2].load() / 1e5, G.phase_ticks[3].load() / 1e5, G.phase_ticks[4].load() / 1e5, G.phase_ticks[5].load() / 1e5,
                 G.phase_ticks[6].load() / 1e5, G.phase_ticks[7].load() / 1e5, G.update_ns.load() / 1e6);
-        fprintf(stderr, "[cons] graph kernels, thread 0's loops: %llu path entries looked at in rejoin searches, %llu detour steps over old side nodes, %llu read ids compared in %llu splitPath contexts\n",
-                (unsigned long long)G.cnt[0].load(), (unsigned long long)G.cnt[1].load(), (unsigned long long)G.cnt[2].load(), (unsigned long long)G.cnt[3].load());
-        fprintf(stderr, "[cons] graph kernels, removeCycles in parts (ms in sum): marking %.0f, finding the roots %.0f, walks + splits %.0f of which splitPath %.0f (looking for stretches %.0f, stretches by the team %.0f)\n",
-                G.cyc[0].load() / 1e5, G.cyc[1].load() / 1e5, G.cyc[5].load() / 1e5, G.cyc[4].load() / 1e5, G.cyc[2].load() / 1e5, G.cyc[3].load() / 1e5);
+        fprintf(stderr, "[cons] graph kernels, thread 0's loops: %llu path entries looked at in rejoin searches, %llu detour steps over old side nodes, %llu read ids compared in %llu splitPath contexts, %llu of them made by %llu splits by routes\n",
+                (unsigned long long)G.cnt[0].load(), (unsigned long long)G.cnt[1].load(), (unsigned long long)G.cnt[2].load(), (unsigned long long)G.cnt[3].load(), (unsigned long long)G.cnt[5].load(), (unsigned long long)G.cnt[4].load());
+        fprintf(stderr, "[cons] graph kernels, removeCycles in parts (ms in sum): marking %.0f, finding the roots %.0f, walks + splits %.0f of which splitPath %.0f (looking for stretches %.0f, stretches and routes by the team %.0f; the splits by routes: walking %.0f, comparing %.0f, copies %.0f, the rest %.0f)\n",
+                G.cyc[0].load() / 1e5, G.cyc[1].load() / 1e5, G.cyc[5].load() / 1e5, G.cyc[4].load() / 1e5, G.cyc[2].load() / 1e5, G.cyc[3].load() / 1e5, G.rt[0].load() / 1e5, G.rt[1].load() / 1e5, G.rt[2].load() / 1e5, G.rt[3].load() / 1e5);
         fprintf(stderr, "[cons] graph kernels by duration (< 0.25 / 0.5 / 1 / 2 / 4 / 8 / 16 ms / more): %llu %llu %llu %llu %llu %llu %llu %llu; those of 2 ms and more by their longest phase (tables / runs / excursions / choices / stitching / writing / flags / removeCycles): %llu %llu %llu %llu %llu %llu %llu %llu\n",
                 (unsigned long long)G.hist[0].load(), (unsigned long long)G.hist[1].load(), (unsigned long long)G.hist[2].load(), (unsigned long long)G.hist[3].load(), (unsigned long long)G.hist[4].load(), (unsigned long long)G.hist[5].load(),
                 (unsigned long long)G.hist[6].load(), (unsigned long long)G.hist[7].load(), (unsigned long long)G.slow_phase[0].load(), (unsigned long long)G.slow_phase[1].load(), (unsigned long long)G.slow_phase[2].load(),

@@ -51,6 +51,7 @@ static int graph_shared_get(nsgpu_ctx *c, DevGraphShared **out)
     for (auto &t : sh->slow_phase) t = 0;
     for (auto &t : sh->cnt) t = 0;
     for (auto &t : sh->cyc) t = 0;
+    for (auto &t : sh->rt) t = 0;
     *out = sh;
     return NSGPU_OK;
 }

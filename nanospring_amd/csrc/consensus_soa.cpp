@@ -22,7 +22,7 @@ SoaNeed soa_need(uint32_t n_ops, uint32_t n_run, uint32_t n_ins, uint32_t path_l
     n.chunks = n_run + 3 * n_ops + 256;
     n.path_side = n_ins + 64;
     (void)path_len;
-    n.wk = HostOps::wk_update_words(n_ops) + (1u << 20);
+    n.wk = HostOps::wk_update_words(n_ops) + (1u << 22);
     return n;
 }
 

@@ -79,7 +79,7 @@ struct Hdr {
     uint32_t ending_id, starting_id;                  // the smallest read id on the path's last / first edge
     uint32_t st_splits, st_detours, st_walked, st_seq_exc, st_cycles_run, st_full_walk, st_dis;
     uint32_t stage;                                   // of the recompute: 2 = choosing (nothing changed yet), 3 = changing the graph
-    uint32_t dbg_flags;                               // tests: 1 = excursions one at a time, 2 = removeCycles by the reference's full walk, 4 = a longer path always moves its left part, 8 = chain runs of splitPath and probes with a team of one too, 16 = no probes, 32 = no chain runs
+    uint32_t dbg_flags;                               // tests: 1 = excursions one at a time, 2 = removeCycles by the reference's full walk, 4 = a longer path always moves its left part, 8 = chain runs of splitPath and probes with a team of one too, 16 = no probes, 32 = no chain runs, 64 = no splits by routes, 128 = every split by routes from its first edge
     uint32_t err_line;                                // where the first error was raised (dgraph.hpp line)
     uint32_t err_info[4];                             // what it was about (node / index ...)
     uint32_t st_search, st_steps, st_idscan, st_ctx;   // thread 0's loops: rejoin searches (entries looked at), detour steps, read ids compared in splitPath, its contexts
@@ -87,7 +87,8 @@ struct Hdr {
     uint32_t st_pops, st_probes, st_anc, st_probed;    // removeCycles' walk: edges popped; probes asked; ancestor steps; nodes the probes covered
     uint32_t st_cyc[6];                               // removeCycles in parts (thread 0's clock): marking, finding the roots, splitPath: looking for stretches / stretches / the rest, the walks
     uint32_t st_tm[8];                                // ticks of the team's clock by phase: tables, runs, excursions, choices, stitching, writing, flags + P/S, removeCycles
-    uint32_t pad_[2];
+    uint32_t st_routes, st_route_ctx;                 // splits by routes (split_routes_run) and the contexts they made
+    uint32_t st_rt[4];                                // ... in parts (thread 0's clock): walking the routes, comparing them, the copies, taking the reads off the old edges + the rest
 };
 static_assert(sizeof(Hdr) % 16 == 0, "header is whole 16-byte words");
 
@@ -122,6 +123,7 @@ struct HostTeam {
     DG_HD void add_to(uint32_t *p, uint32_t v) { *p += v; }                         // a sum several threads contribute to
     DG_HD void min_to(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }              // a minimum ...
     DG_HD uint32_t peek(const uint32_t *p) const { return *p; }                      // ... and how such a word is read (on the device: past the first-level cache, which the others' atomic updates do not reach)
+    DG_HD bool cas(uint32_t *p, uint32_t expect, uint32_t v) { if (*p != expect) return false; *p = v; return true; }      // one of several threads wins
     // Thread 0 working alone while the others wait for its orders (removeCycles): on the device a barrier belongs to a whole wavefront, so the
     // lanes that share thread 0's wavefront sit such a stretch out and the team that takes the orders is thread 0 + the other wavefronts.
     DG_HD bool helper() const { return false; }                                      // this thread takes thread 0's orders
@@ -376,12 +378,13 @@ template <class T> struct Ops {
     DG_HD void remove_node(uint32_t n)
     {
         Hdr &h = *g.h;
-        h.n_multi -= (uint32_t)multi_in_side(n);
         Node &x = g.nodes[n];
+        if (x.base == 0) return;                  // (gone already: base 0 marks a node that was taken away)
+        h.n_multi -= (uint32_t)multi_in_side(n);
         x.on_main = 1;                            // keeps the counter untouched while the node's edges go away
         for (uint32_t i = 0; i < x.n_in; ++i) remove_edge(in_ref(x, i), false, true);
         for (uint32_t i = 0; i < x.n_out; ++i) remove_edge(out_ref(x, i) & kRefMask, true, false);
-        x.n_in = x.n_out = 0, x.on_main = 0;
+        x.n_in = x.n_out = 0, x.on_main = 0, x.base = 0;
         --h.live_nodes;
     }
     // removeReadsFromEdge (:843-859): the ids of `rm` leave the edge; an edge without reads goes
@@ -899,13 +902,13 @@ template <class T> struct Ops {
             team.sync();
         }
     }
-    // the threads that take thread 0's orders while it works alone (1: a chain run of splitPath, 2: a probe; 0: done)
+    // the threads that take thread 0's orders while it works alone (1: a chain run of splitPath, 2: a probe, 3: a split by routes; 0: done)
     DG_HD void helpers_loop()
     {
         for (;;) {
             const uint32_t o = team.bcast(0);
             if (o == 0) break;
-            if (o == 1) split_chain_run(cyc_wk()); else probe_run();
+            if (o == 1) split_chain_run(cyc_wk()); else if (o == 3) split_routes_run(cyc_wk()); else probe_run();
         }
     }
     DG_HD bool probing() const { return (team.crew_size() > 1 && !(g.h->dbg_flags & 16u)) || (g.h->dbg_flags & 8u); }
@@ -1268,22 +1271,23 @@ template <class T> struct Ops {
     // ================================================================================================================
     // removeCycles (:653-691), walkAndPrune (:693-714), splitPath (:716-807)
     // ================================================================================================================
-    struct CycWk { uint32_t *todo, *roots, *hits, *estack, *ctx, *lists, *copy, *defer, *chain, *order; uint32_t cap_todo, cap_roots, cap_hits, cap_estack, cap_ctx, cap_lists, cap_copy, cap_defer, cap_chain; };
+    struct CycWk { uint32_t *todo, *roots, *hits, *estack, *ctx, *lists, *copy, *defer, *chain, *route, *order; uint32_t cap_todo, cap_roots, cap_hits, cap_estack, cap_ctx, cap_lists, cap_copy, cap_defer, cap_chain, cap_route; };
     DG_HD CycWk cyc_wk() const
     {
         const Hdr &h = *g.h;
         uint32_t *W = g.wk + h.upd_wk;
-        const uint32_t wcap = h.cap_wk - h.upd_wk - 64, u = wcap / 16;
+        const uint32_t wcap = h.cap_wk - h.upd_wk - 64, u = wcap / 32;
         CycWk c;
         c.todo = W, c.cap_todo = u;
         c.roots = W + u, c.cap_roots = u;
-        c.hits = W + 2 * u, c.cap_hits = u;                 // pairs
-        c.estack = W + 4 * u, c.cap_estack = 2 * u;
-        c.ctx = W + 6 * u, c.cap_ctx = 2 * u / 8;          // 8 words each
-        c.lists = W + 8 * u, c.cap_lists = 4 * u;
-        c.copy = W + 12 * u, c.cap_copy = u;
-        c.defer = W + 13 * u, c.cap_defer = 2 * u;
-        c.chain = W + 15 * u, c.cap_chain = u / 3;            // a run of a chain: its edges, its nodes, its masks
+        c.hits = W + 2 * u, c.cap_hits = 2 * u;            // pairs
+        c.estack = W + 4 * u, c.cap_estack = 4 * u;
+        c.ctx = W + 8 * u, c.cap_ctx = 4 * u / 8;          // 8 words each
+        c.lists = W + 12 * u, c.cap_lists = 4 * u;
+        c.copy = W + 16 * u, c.cap_copy = u;
+        c.defer = W + 17 * u, c.cap_defer = 2 * u;
+        c.chain = W + 19 * u, c.cap_chain = 2 * u / 3;        // a run of a chain: its edges, its nodes, its masks
+        c.route = W + 21 * u, c.cap_route = 11 * u;           // the routes of a split's reads (split_routes_run)
         c.order = order();
         return c;
     }
@@ -1300,7 +1304,7 @@ template <class T> struct Ops {
         Hdr &h = *g.h;
         ++h.st_splits;
         const uint32_t sp0 = team.clock();
-        uint32_t lists_top = 0, n_ctx = 0, n_def = 0;
+        uint32_t lists_top = 0, n_ctx = 0, n_def = 0, n_done = 0;
         if (g.edges[e0].count > K.cap_lists) { fail_at(__LINE__, ERR_SCRATCH); return; }
         lists_top = ids_copy(g.edges[e0], K.lists);          // (a copy: e0's list dies with e0 during the first visit)
         {
@@ -1335,6 +1339,16 @@ template <class T> struct Ops {
             lists_top = own_off + own_n;
             h.st_idscan += c[3] * g.edges[e].count; ++h.st_ctx;
             c[4] = own_off, c[5] = own_n, c[6] = 1;
+            // a split that has proven large: what hangs below this context is taken by the whole team, read by read (split_routes_run)
+            if (n_done >= ((h.dbg_flags & 128u) ? 0u : kRouteAfter) && own_n && own_n <= kRouteReads && !(h.dbg_flags & 64u)) {
+                const uint32_t r0 = team.clock();
+                K.order[11] = new_pre, K.order[12] = e, K.order[13] = own_off, K.order[14] = own_n, K.order[15] = 0, K.order[16] = 0, K.order[20] = 0, K.order[21] = 0, K.order[22] = 0;
+                (void)team.bcast(3);
+                split_routes_run(K);
+                h.st_cyc[3] += team.clock() - r0;
+                if (failed()) return;
+                if (K.order[16]) { n_done += K.order[17]; lists_top = own_off; continue; }
+            }
             while (own_n && !failed()) {
                 // A stretch of nodes with one way out each (a by-passed piece of the old path, typically): not one step of this loop after the
                 // other -- the whole team takes the stretch at once (split_chain_run)
@@ -1367,7 +1381,7 @@ template <class T> struct Ops {
                         h.st_cyc[3] += team.clock() - d1;
                         const uint32_t k_eff = K.order[6];
                         n_def += k_eff;
-                        h.st_ctx += k_eff;
+                        h.st_ctx += k_eff, n_done += k_eff;
                         if (k_eff) {
                             new_pre = h.n_nodes - 1;                      // the copy of the stretch's last node
                             e = k_eff < k ? K.chain[k_eff] : ce;
@@ -1383,6 +1397,7 @@ template <class T> struct Ops {
                     }
                 }
                 const uint32_t old_cur = g.edges[e].sink;
+                ++n_done;
                 remove_reads_from_edge(e, K.lists + own_off, own_n);
                 if (g.nodes[old_cur].on_main) { new_edge(new_pre, old_cur, K.lists + own_off, own_n); c[7] = old_cur; break; }
                 const uint32_t new_cur = new_node(g.nodes[old_cur].base);
@@ -1470,12 +1485,264 @@ template <class T> struct Ops {
         }
         team.sync();
     }
+
+    // ---- the split by routes ------------------------------------------------------------------------------------------------------
+    // What splitPath builds below an edge e with reads O is the prefix tree of the reads' ROUTES: the edges read r goes down from e until the sink is on the
+    // main path (or the read ends); reads share a copy as long as their routes agree.  The reference walks that tree depth first, the ways out of a node last
+    // to first, and hands out node and edge ids as it goes.  A by-passed stretch of the path makes the tree thousands of nodes deep and a few reads wide, so
+    // here the reads are walked at the same time (one lane each: P1), the tree comes from comparing routes -- lcp(a, b) edges in common, and which of the
+    // two the walk takes first where they part (P2) -- and the walk's order from that: the reads in depth-first order pi, read pi[t] owning the contexts
+    // lp[t] .. len - 1 of its route (lp = what it shares with its predecessor), which are consecutive in the walk's order; so every context knows its edge id,
+    // its node id, the chunks its id list needs and the copy in front of it without looking at another (P4: prefix sums over at most 32 reads), and all copies
+    // are made at once (P5).  The reads leave the old edges read by read (the contexts of ONE read touch different edges and different nodes' lists: P6);
+    // what is appended to lists that exist (the first copy to the node in front, the forks of the tree, the edges back into the path) thread 0 does in the
+    // walk's order (P7); old nodes left without edges go (P8).  order[]: 11 new_pre, 12 e, 13 own_off, 14 n; out: 16 done (0: a route does not fit,
+    // nothing was changed), 17 the contexts.
+    static constexpr uint32_t kRouteReads = 32, kRouteAfter = 48;
+    struct RouteWk { uint32_t *lc, *bf, *len, *lm, *pi, *lp, *cb, *nb, *kb, *d12, *d27, *ids, *rt; uint32_t cap_rt; };
+    DG_HD RouteWk route_wk(const CycWk &K, uint32_t n0) const
+    {
+        RouteWk R;
+        uint32_t *p = K.route;
+        R.lc = p, p += kRouteReads * kRouteReads;
+        R.bf = p, p += kRouteReads * kRouteReads;
+        R.len = p, p += kRouteReads; R.lm = p, p += kRouteReads; R.pi = p, p += kRouteReads; R.lp = p, p += kRouteReads;
+        R.cb = p, p += kRouteReads; R.nb = p, p += kRouteReads; R.kb = p, p += kRouteReads; R.d12 = p, p += kRouteReads;
+        R.d27 = p, p += kRouteReads; R.ids = p, p += kRouteReads;
+        R.rt = p;
+        const uint32_t fixed = (uint32_t)(p - K.route);
+        R.cap_rt = K.cap_route > fixed && n0 ? (K.cap_route - fixed) / n0 : 0;
+        return R;
+    }
+    // the ids with a bit in `mask` (bit s: ids[s]) leave edge ei; returns the ids left
+    DG_HD uint32_t drop_reads_masked(uint32_t ei, const uint32_t *ids, uint32_t mask, uint32_t n_rm)
+    {
+        Edge &e = g.edges[ei];
+        const uint32_t n = e.count;
+        if (n_rm >= n) { e.count = 0, e.head = e.tail = NIL; return 0; }
+        uint32_t w = 0, rc = e.head, wc = e.head;
+        for (uint32_t p = 0; p < n; ++p) {
+            uint32_t v;
+            if (p < kEdgeInl) v = e.ids[p];
+            else { const uint32_t s = (p - kEdgeInl) % kChunkIds; if (s == 0 && p != kEdgeInl) rc = g.chunks[rc].next; v = g.chunks[rc].v[s]; }
+            bool drop = false;
+            for (uint32_t mk = mask, q = 0; mk; mk >>= 1, ++q) if ((mk & 1u) && ids[q] == v) { drop = true; break; }
+            if (drop) continue;
+            if (w < kEdgeInl) e.ids[w] = v;
+            else { const uint32_t s = (w - kEdgeInl) % kChunkIds; if (s == 0 && w != kEdgeInl) wc = g.chunks[wc].next; g.chunks[wc].v[s] = v; }
+            ++w;
+        }
+        e.count = w;
+        e.tail = w > kEdgeInl ? wc : NIL;
+        if (w <= kEdgeInl) e.head = NIL;
+        return w;
+    }
+    DG_HD static uint32_t clamp3(uint32_t v, uint32_t lo, uint32_t hi) { return v < lo ? lo : v > hi ? hi : v; }
+    DG_COLD void split_routes_run(const CycWk &K)
+    {
+        Hdr &h = *g.h;
+        const uint32_t tid = team.tid(), cr = team.crew_rank(), nc = team.crew_size();
+        uint32_t *ord = K.order;
+        const uint32_t new_pre = ord[11], e0 = ord[12], own_off = ord[13], n0 = ord[14];
+        const RouteWk R = route_wk(K, n0);
+        constexpr uint32_t W = kRouteReads;
+        // P1: the routes
+        uint32_t tk = team.clock();
+        auto lap = [&](uint32_t i) { if (tid == 0) { const uint32_t t = team.clock(); h.st_rt[i] += t - tk; tk = t; } };
+        for (uint32_t b = cr; b < n0; b += nc) {
+            const uint32_t r = K.lists[own_off + b];
+            R.ids[b] = r;
+            uint32_t *rt = R.rt + (size_t)b * R.cap_rt;
+            uint32_t ce = e0, L = 0, lm = 0;
+            for (;;) {
+                if (L >= R.cap_rt) { L = NIL; break; }
+                rt[L++] = ce;
+                const Node &x = g.nodes[g.edges[ce].sink];
+                if (x.on_main) { lm = 1; break; }
+                uint32_t next = NIL;
+                for (uint32_t i = 0; i < x.n_out; ++i) { const uint32_t o = out_ref(x, i) & kRefMask; if (edge_has(g.edges[o], r)) { next = o; break; } }
+                if (next == NIL) break;                          // the read ends at this node
+                ce = next;
+            }
+            R.len[b] = L, R.lm[b] = lm;
+            if (L == NIL) team.add_to(&ord[15], 1);
+        }
+        team.sync();
+        lap(0);
+        if (team.peek(&ord[15])) { team.sync(); return; }
+        // P2: what two routes share, and which of the two the walk takes first
+        for (uint32_t p = cr; p < n0 * n0; p += nc) {
+            const uint32_t a = p / n0, b = p % n0;
+            if (a == b) { R.lc[a * W + a] = R.len[a]; R.bf[a * W + a] = 0; continue; }
+            if (a > b) continue;
+            const uint32_t *ra = R.rt + (size_t)a * R.cap_rt, *rb = R.rt + (size_t)b * R.cap_rt;
+            const uint32_t la = R.len[a], lb = R.len[b], mn = la < lb ? la : lb;
+            uint32_t d = 1;                                      // (both start with e)
+            while (d < mn && ra[d] == rb[d]) ++d;
+            bool a_first;
+            if (d == mn) a_first = la <= lb;                     // one runs out where the other goes on (or both do): the shorter one first
+            else {
+                const Node &x = g.nodes[g.edges[ra[d - 1]].sink];
+                uint32_t ia = 0, ib = 0;
+                for (uint32_t i = 0; i < x.n_out; ++i) { const uint32_t o = out_ref(x, i) & kRefMask; if (o == ra[d]) ia = i; if (o == rb[d]) ib = i; }
+                a_first = ia > ib;                               // the reference's stack: the last way out first
+            }
+            R.lc[a * W + b] = R.lc[b * W + a] = d;
+            R.bf[a * W + b] = a_first ? 1u : 0u, R.bf[b * W + a] = a_first ? 0u : 1u;
+        }
+        team.sync();
+        // P3: each read's place in the walk's order; up to which depth it travels with at least 11 / 26 others (id lists beyond the inline slots)
+        for (uint32_t a = cr; a < n0; a += nc) {
+            uint32_t rank = 0;
+            for (uint32_t b = 0; b < n0; ++b) if (b != a) rank += R.bf[b * W + a];
+            R.pi[rank] = a;
+            uint32_t d12 = 0, d27 = 0;
+            if (n0 > kEdgeInl) for (uint32_t s = 0; s < n0; ++s) {
+                const uint32_t v = R.lc[a * W + s];
+                uint32_t cnt = 0;
+                for (uint32_t s2 = 0; s2 < n0; ++s2) cnt += R.lc[a * W + s2] >= v ? 1u : 0u;
+                if (cnt > kEdgeInl && v > d12) d12 = v;
+                if (cnt > kEdgeInl + kChunkIds && v > d27) d27 = v;
+            }
+            R.d12[a] = d12, R.d27[a] = d27;
+        }
+        team.sync();
+        // P4: the contexts each read owns, and where their ids start
+        if (tid == 0) {
+            uint32_t C = 0, Nn = 0, Kc = 0;
+            for (uint32_t t = 0; t < n0; ++t) {
+                const uint32_t r = R.pi[t], len = R.len[r];
+                const uint32_t lp = t ? R.lc[R.pi[t - 1] * W + r] : 0, cnt = len - lp;
+                R.lp[t] = lp, R.cb[t] = C, R.nb[t] = Nn, R.kb[t] = Kc;
+                C += cnt, Nn += cnt - (cnt && R.lm[r] ? 1u : 0u);
+                const uint32_t a = clamp3(R.d27[r], lp, len), b = clamp3(R.d12[r], lp, len);
+                Kc += 2 * (a - lp) + (b - a);
+            }
+            ord[17] = C, ord[18] = Nn, ord[19] = Kc;
+            if ((uint64_t)h.n_nodes + Nn > h.cap_nodes || (uint64_t)h.n_edges + C > h.cap_edges || (uint64_t)h.n_chunks + Kc + 2 * n0 + 8 > h.cap_chunks) { fail_at(__LINE__, ERR_CAP); ord[15] = 1; }
+        }
+        team.sync();
+        if (team.peek(&ord[15])) { team.sync(); return; }
+        const uint32_t nbase = h.n_nodes, ebase = h.n_edges, kbase = h.n_chunks;
+        lap(1);
+        // P5: the copies
+        for (uint32_t t = 0; t < n0; ++t) {
+            const uint32_t r = R.pi[t], len = R.len[r], lp = R.lp[t];
+            const uint32_t *rt = R.rt + (size_t)r * R.cap_rt, *lcr = R.lc + r * W;
+            const uint32_t a27 = clamp3(R.d27[r], lp, len), a12 = clamp3(R.d12[r], lp, len);
+            for (uint32_t d = lp + cr; d < len; d += nc) {
+                const uint32_t q = R.cb[t] + (d - lp), ne = ebase + q;
+                const bool leaf_main = d + 1 == len && R.lm[r];
+                const uint32_t nid = nbase + R.nb[t] + (d - lp);
+                uint32_t parent;
+                if (d == 0) parent = new_pre;
+                else if (d > lp) parent = nid - 1;
+                else {                                           // the copy in front belongs to the first read of the walk that travels with this one that far
+                    uint32_t t2 = 0;
+                    while (R.lc[R.pi[t2] * W + r] < d) ++t2;
+                    parent = nbase + R.nb[t2] + (d - 1 - R.lp[t2]);
+                }
+                const uint32_t X = g.edges[rt[d]].sink;
+                const uint32_t dm = d < a27 ? d : a27, dn = d < a12 ? d : a12;
+                const uint32_t ck = kbase + R.kb[t] + 2 * (dm - lp) + (dn - dm);
+                Edge &x = g.edges[ne];
+                x.src = parent, x.sink = leaf_main ? X : nid, x.head = x.tail = NIL;
+                uint32_t w = 0;
+                for (uint32_t s = 0; s < n0; ++s) {
+                    if (lcr[s] <= d) continue;
+                    const uint32_t id = R.ids[s];
+                    if (w < kEdgeInl) x.ids[w] = id;
+                    else g.chunks[ck + (w - kEdgeInl) / kChunkIds].v[(w - kEdgeInl) % kChunkIds] = id;
+                    ++w;
+                }
+                x.count = w;
+                if (w > kEdgeInl) {
+                    const uint32_t nk = (w - kEdgeInl + kChunkIds - 1) / kChunkIds;
+                    x.head = ck, x.tail = ck + nk - 1;
+                    for (uint32_t i = 0; i < nk; ++i) g.chunks[ck + i].next = i + 1 < nk ? ck + i + 1 : NIL;
+                }
+                if (!leaf_main) {
+                    Node &nd = g.nodes[nid];
+                    nd.out_ext = nd.in_ext = NIL, nd.base = g.nodes[X].base, nd.on_main = 0;
+                    g.mark[nid] = 0, g.pidx[nid] = NIL;
+                    nd.n_in = 1, nd.in[0] = ne;
+                    if (d + 1 < len) nd.n_out = 1, nd.out[0] = (ne + 1) | (code_of(g.nodes[g.edges[rt[d + 1]].sink].base) << 29);
+                    else nd.n_out = 0;
+                }
+            }
+        }
+        team.sync();
+        lap(2);
+        // P6: the reads leave the old edges, one read of the walk after the other
+        uint32_t removed = 0, unmulti = 0;
+        for (uint32_t t = 0; t < n0; ++t) {
+            const uint32_t r = R.pi[t], len = R.len[r], lp = R.lp[t];
+            uint32_t *rt = R.rt + (size_t)r * R.cap_rt;
+            const uint32_t *lcr = R.lc + r * W;
+            for (uint32_t d = lp + cr; d < len; d += nc) {
+                uint32_t mask = 0, n_rm = 0;
+                for (uint32_t s = 0; s < n0; ++s) if (lcr[s] > d) mask |= 1u << s, ++n_rm;
+                const uint32_t oe = rt[d], X = g.edges[oe].sink;
+                if (drop_reads_masked(oe, R.ids, mask, n_rm) == 0) { const int32_t dd = remove_edge_quiet(oe, false, false); ++removed; if (dd < 0) ++unmulti; }
+                rt[d] = d + 1 == len && R.lm[r] ? NIL : X;       // (from here on: the old node the context has copied)
+            }
+            if (lp < len) team.sync();
+        }
+        if (removed) team.add_to(&ord[20], removed);
+        if (unmulti) team.add_to(&ord[21], unmulti);
+        team.sync();
+        // P7: what is appended to lists that were there before
+        if (tid == 0) {
+            out_push(new_pre, ebase | (code_of(g.nodes[g.edges[ebase].sink].base) << 29));
+            for (uint32_t t = 1; t < n0; ++t) {
+                const uint32_t r = R.pi[t], d = R.lp[t];
+                if (d >= R.len[r]) continue;
+                uint32_t t2 = 0;
+                while (R.lc[R.pi[t2] * W + r] < d) ++t2;
+                const uint32_t ne = ebase + R.cb[t];
+                out_push(nbase + R.nb[t2] + (d - 1 - R.lp[t2]), ne | (code_of(g.nodes[g.edges[ne].sink].base) << 29));
+            }
+            for (uint32_t t = 0; t < n0; ++t) {
+                const uint32_t r = R.pi[t];
+                if (R.lp[t] >= R.len[r] || !R.lm[r]) continue;
+                const uint32_t ne = ebase + R.cb[t] + (R.len[r] - R.lp[t]) - 1;
+                in_push(g.edges[ne].sink, ne);
+            }
+            const uint32_t C = ord[17], Nn = ord[18], Kc = ord[19];
+            h.n_nodes += Nn, h.live_nodes += Nn, h.n_edges += C, h.live_edges += C - team.peek(&ord[20]), h.n_chunks += Kc;
+            h.n_multi -= team.peek(&ord[21]);
+            h.st_ctx += C, ++h.st_routes, h.st_route_ctx += C;
+        }
+        team.sync();
+        // P8: old nodes nothing leads to or from any more
+        uint32_t gone = 0;
+        for (uint32_t t = 0; t < n0; ++t) {
+            const uint32_t r = R.pi[t], len = R.len[r], lp = R.lp[t];
+            const uint32_t *rt = R.rt + (size_t)r * R.cap_rt;
+            for (uint32_t d = lp + cr; d < len; d += nc) {
+                const uint32_t X = rt[d];
+                if (X == NIL) continue;
+                Node &x = g.nodes[X];
+                if (x.n_in || x.n_out || x.on_main || !x.base) continue;
+                uint32_t *wd = reinterpret_cast<uint32_t *>(&x.n_out);          // n_out n_in base on_main: one word
+                const uint32_t was = (uint32_t)x.base << 16;
+                if (team.cas(wd, was, 0u)) ++gone;
+            }
+        }
+        if (gone) team.add_to(&ord[22], gone);
+        team.sync();
+        if (tid == 0) { h.live_nodes -= team.peek(&ord[22]); ord[16] = 1; }
+        lap(3);
+        team.sync();
+    }
     DG_COLD void walk_and_prune(const CycWk &K, uint32_t e0, bool marked_only)
     {
         const Hdr &h = *g.h;
         uint32_t n = 0, streak = 0;
         K.estack[n++] = e0;
-        while (n && !failed()) {
+        // (a side node with more than one edge in is what a split needs: when the last of them is gone -- the splits so far have taken them apart -- the
+        // rest of the reference's walk finds nothing to do)
+        while (n && !failed() && h.n_multi) {
             const uint32_t curr = K.estack[--n];
             ++g.h->st_pops;
             const uint32_t sink = g.edges[curr].sink, source = g.edges[curr].src;
@@ -1502,7 +1769,7 @@ template <class T> struct Ops {
         const uint32_t no = x.n_out;
         if (no > K.cap_copy) { fail_at(__LINE__, ERR_SCRATCH); return; }
         for (uint32_t i = 0; i < no; ++i) K.copy[i] = out_ref(x, i) & kRefMask;      // a copy: the walk edits the node's list
-        for (uint32_t i = 0; i < no && !failed(); ++i) walk_and_prune(K, K.copy[i], marked_only);
+        for (uint32_t i = 0; i < no && !failed() && g.h->n_multi; ++i) walk_and_prune(K, K.copy[i], marked_only);
     }
 
     // removeCycles.  The reference walks every side branch of the two stretches just re-walked and splits at every side edge whose sink
@@ -1609,16 +1876,16 @@ template <class T> struct Ops {
             if (tid == 0) {
                 h.st_cyc[1] += c1 - c0;
                 // first loop of the reference: nodes right_off .. m in path order; second: nodes min(left_off, m - 1) .. 0, backwards
-                for (uint32_t i = 0; i < n_hits && !failed(); ++i) if (K.hits[2 * i] >= h.right_off) run_node(K, K.hits[2 * i + 1], true);
+                for (uint32_t i = 0; i < n_hits && !failed() && h.n_multi; ++i) if (K.hits[2 * i] >= h.right_off) run_node(K, K.hits[2 * i + 1], true);
                 const uint32_t l0 = h.left_off < m ? h.left_off : m - 1;
-                for (uint32_t i = n_hits; i-- > 0 && !failed();) if (K.hits[2 * i] <= l0 && K.hits[2 * i] < m) run_node(K, K.hits[2 * i + 1], true);
+                for (uint32_t i = n_hits; i-- > 0 && !failed() && h.n_multi;) if (K.hits[2 * i] <= l0 && K.hits[2 * i] < m) run_node(K, K.hits[2 * i + 1], true);
                 h.st_cyc[5] += team.clock() - c1;
                 (void)team.bcast(0);
             } else if (team.helper()) helpers_loop();
         } else if (mode == 2) {
             if (tid == 0) {
-                for (uint32_t i = h.right_off; i <= m && !failed(); ++i) run_node(K, g.pn[off + i], false);
-                for (uint32_t i = (h.left_off < m ? h.left_off : m - 1) + 1; i-- > 0 && !failed();) run_node(K, g.pn[off + i], false);
+                for (uint32_t i = h.right_off; i <= m && !failed() && h.n_multi; ++i) run_node(K, g.pn[off + i], false);
+                for (uint32_t i = (h.left_off < m ? h.left_off : m - 1) + 1; i-- > 0 && !failed() && h.n_multi;) run_node(K, g.pn[off + i], false);
                 // (what is left are nodes the walks cannot reach; the list starts over with them)
                 if (h.multi_n > h.cap_multi) h.multi_n = 0;
                 (void)team.bcast(0);

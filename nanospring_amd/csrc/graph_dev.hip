@@ -19,6 +19,7 @@ struct DevTeam {
     __device__ void add_to(uint32_t *p, uint32_t v) { atomicAdd(p, v); }
     __device__ void min_to(uint32_t *p, uint32_t v) { atomicMin(p, v); }
     __device__ uint32_t peek(const uint32_t *p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ bool cas(uint32_t *p, uint32_t expect, uint32_t v) { return atomicCAS(p, expect, v) == expect; }
     __device__ bool helper() const { return threadIdx.x >= 64u; }
     __device__ uint32_t crew_rank() const { return threadIdx.x == 0 ? 0u : threadIdx.x - 63u; }
     __device__ uint32_t crew_size() const { return blockDim.x > 64u ? blockDim.x - 63u : 1u; }
@@ -612,13 +613,14 @@ int DevGraph::finalize(bool wait)
         if (tot >= 200000) sh_->slow_phase[worst_i] += 1;                            // updates of 2 ms and more: by their longest phase
         static const bool slow_dbg = getenv("NSGPU_GRAPH_SLOW") != nullptr;
         if (slow_dbg && tot >= 800000)
-            fprintf(stderr, "[graph] slow update %.1f ms (phase %u: %.1f): path %u, read len %zu, splits %u ctx %u pops %u probes %u covering %u anc %u detours %u steps %u walked %u multi %u gap %u ended %u R %u Lf %u m %u la %u lenF %u touch_hi %u begin %lld end %lld\n", tot / 1e5, worst_i, worst / 1e5, hdr_.m, p_len_,
-                    hdr_.st_splits - dbg_seen_[0], hdr_.st_ctx - dbg_seen_[1], hdr_.st_pops - dbg_seen_[2], hdr_.st_probes - dbg_seen_[3], hdr_.st_probed - dbg_seen_[4], hdr_.st_anc - dbg_seen_[5], hdr_.st_detours - dbg_seen_[6], hdr_.st_steps - dbg_seen_[7], hdr_.st_walked - dbg_seen_[8], hdr_.n_multi, hdr_.st_gap - dbg_seen_[9], hdr_.st_ended - dbg_seen_[10], hdr_.st_last[0], hdr_.st_last[1], hdr_.st_last[2], hdr_.st_last[3], hdr_.st_last[4], hdr_.st_last[5], p_begin_, p_end_);
-        dbg_seen_[0] = hdr_.st_splits, dbg_seen_[1] = hdr_.st_ctx, dbg_seen_[2] = hdr_.st_pops, dbg_seen_[3] = hdr_.st_probes, dbg_seen_[4] = hdr_.st_probed, dbg_seen_[5] = hdr_.st_anc, dbg_seen_[6] = hdr_.st_detours, dbg_seen_[7] = hdr_.st_steps, dbg_seen_[8] = hdr_.st_walked, dbg_seen_[9] = hdr_.st_gap, dbg_seen_[10] = hdr_.st_ended;
+            fprintf(stderr, "[graph] slow update %.1f ms (phase %u: %.1f): path %u, read len %zu, splits %u (by routes %u: %u ctx) ctx %u pops %u probes %u covering %u anc %u detours %u steps %u walked %u multi %u gap %u ended %u R %u Lf %u m %u la %u lenF %u touch_hi %u begin %lld end %lld; removeCycles in parts: marking %.1f roots %.1f walks+splits %.1f (splitPath %.1f: looking %.1f, team %.1f); routes: walk %.1f compare %.1f copies %.1f rest %.1f\n", tot / 1e5, worst_i, worst / 1e5, hdr_.m, p_len_,
+                    hdr_.st_splits - dbg_seen_[0], hdr_.st_routes - dbg_seen_[11], hdr_.st_route_ctx - dbg_seen_[12], hdr_.st_ctx - dbg_seen_[1], hdr_.st_pops - dbg_seen_[2], hdr_.st_probes - dbg_seen_[3], hdr_.st_probed - dbg_seen_[4], hdr_.st_anc - dbg_seen_[5], hdr_.st_detours - dbg_seen_[6], hdr_.st_steps - dbg_seen_[7], hdr_.st_walked - dbg_seen_[8], hdr_.n_multi, hdr_.st_gap - dbg_seen_[9], hdr_.st_ended - dbg_seen_[10], hdr_.st_last[0], hdr_.st_last[1], hdr_.st_last[2], hdr_.st_last[3], hdr_.st_last[4], hdr_.st_last[5], p_begin_, p_end_, (hdr_.st_cyc[0] - cyc_seen_[0]) / 1e5, (hdr_.st_cyc[1] - cyc_seen_[1]) / 1e5, (hdr_.st_cyc[5] - cyc_seen_[5]) / 1e5, (hdr_.st_cyc[4] - cyc_seen_[4]) / 1e5, (hdr_.st_cyc[2] - cyc_seen_[2]) / 1e5, (hdr_.st_cyc[3] - cyc_seen_[3]) / 1e5, (hdr_.st_rt[0] - rt_seen_[0]) / 1e5, (hdr_.st_rt[1] - rt_seen_[1]) / 1e5, (hdr_.st_rt[2] - rt_seen_[2]) / 1e5, (hdr_.st_rt[3] - rt_seen_[3]) / 1e5);
+        dbg_seen_[0] = hdr_.st_splits, dbg_seen_[1] = hdr_.st_ctx, dbg_seen_[2] = hdr_.st_pops, dbg_seen_[3] = hdr_.st_probes, dbg_seen_[4] = hdr_.st_probed, dbg_seen_[5] = hdr_.st_anc, dbg_seen_[6] = hdr_.st_detours, dbg_seen_[7] = hdr_.st_steps, dbg_seen_[8] = hdr_.st_walked, dbg_seen_[9] = hdr_.st_gap, dbg_seen_[10] = hdr_.st_ended, dbg_seen_[11] = hdr_.st_routes, dbg_seen_[12] = hdr_.st_route_ctx;
+        for (int i = 0; i < 4; ++i) { sh_->rt[i] += (uint32_t)(hdr_.st_rt[i] - rt_seen_[i]); rt_seen_[i] = hdr_.st_rt[i]; }
     }
     for (int i = 0; i < 6; ++i) { sh_->cyc[i] += (uint32_t)(hdr_.st_cyc[i] - cyc_seen_[i]); cyc_seen_[i] = hdr_.st_cyc[i]; }
-    sh_->cnt[0] += hdr_.st_search - cnt_seen_[0], sh_->cnt[1] += hdr_.st_steps - cnt_seen_[1], sh_->cnt[2] += hdr_.st_idscan - cnt_seen_[2], sh_->cnt[3] += hdr_.st_ctx - cnt_seen_[3];
-    cnt_seen_[0] = hdr_.st_search, cnt_seen_[1] = hdr_.st_steps, cnt_seen_[2] = hdr_.st_idscan, cnt_seen_[3] = hdr_.st_ctx;
+    sh_->cnt[0] += hdr_.st_search - cnt_seen_[0], sh_->cnt[1] += hdr_.st_steps - cnt_seen_[1], sh_->cnt[2] += hdr_.st_idscan - cnt_seen_[2], sh_->cnt[3] += hdr_.st_ctx - cnt_seen_[3], sh_->cnt[4] += hdr_.st_routes - cnt_seen_[4], sh_->cnt[5] += hdr_.st_route_ctx - cnt_seen_[5];
+    cnt_seen_[0] = hdr_.st_search, cnt_seen_[1] = hdr_.st_steps, cnt_seen_[2] = hdr_.st_idscan, cnt_seen_[3] = hdr_.st_ctx, cnt_seen_[4] = hdr_.st_routes, cnt_seen_[5] = hdr_.st_route_ctx;
     sh_->n_seq_updates += hdr_.st_seq_exc - seen3_[0], sh_->n_full_walks += hdr_.st_full_walk - seen3_[1], sh_->n_splits += hdr_.st_splits - seen3_[2];
     seen3_[0] = hdr_.st_seq_exc, seen3_[1] = hdr_.st_full_walk, seen3_[2] = hdr_.st_splits;
     dbg[0] += 1, dbg[1] = dbg[0] - hdr_.st_cycles_run, dbg[2] = hdr_.st_detours, dbg[4] = hdr_.st_walked, dbg[5] = hdr_.st_cycles_run - hdr_.st_full_walk, dbg[6] = hdr_.st_splits, dbg[7] = hdr_.st_seq_exc;

@@ -96,7 +96,7 @@ struct DevGraphShared {
     std::atomic<uint64_t> n_updates{0}, n_grow{0}, n_mid_copies{0}, kernel_wait_ns{0}, bytes_back{0}, update_ns{0}, final_wait_ns{0};
     std::atomic<uint64_t> n_seq_updates{0}, n_full_walks{0}, n_splits{0};
     uint64_t edge_thr = ~0ull;                        // --edge-thr: num_edges() must be exact near it
-    std::atomic<uint64_t> phase_ticks[8], hist[8], slow_phase[8], cnt[4], cyc[6];             // the kernels' own clock (100 MHz) by phase, summed (debug report)
+    std::atomic<uint64_t> phase_ticks[8], hist[8], slow_phase[8], cnt[6], cyc[6], rt[4];             // the kernels' own clock (100 MHz) by phase, summed (debug report)
     ~DevGraphShared();
 };
 
@@ -145,7 +145,7 @@ private:
     int finalize(bool wait);
     int kernel_error();
     uint32_t ops_cap_ = 0;
-    uint32_t tm_seen_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt_seen_[4] = {0, 0, 0, 0}, cyc_seen_[6] = {0, 0, 0, 0, 0, 0}, dbg_seen_[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t tm_seen_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt_seen_[6] = {0, 0, 0, 0, 0, 0}, cyc_seen_[6] = {0, 0, 0, 0, 0, 0}, rt_seen_[4] = {0, 0, 0, 0}, dbg_seen_[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long p_begin_ = 0, p_end_ = 0;
     // pending update
     read_t p_id_ = 0; long p_pos_ = 0; size_t p_len_ = 0; bool p_rc_ = false; double p_t0_ = 0;
