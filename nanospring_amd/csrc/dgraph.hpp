@@ -1499,7 +1499,7 @@ template <class T> struct Ops {
     // walk's order (P7); old nodes left without edges go (P8).  order[]: 11 new_pre, 12 e, 13 own_off, 14 n; out: 16 done (0: a route does not fit,
     // nothing was changed), 17 the contexts.
     static constexpr uint32_t kRouteReads = 32, kRouteAfter = 48;
-    struct RouteWk { uint32_t *lc, *bf, *len, *lm, *pi, *lp, *cb, *nb, *kb, *d12, *d27, *ids, *rt; uint32_t cap_rt; };
+    struct RouteWk { uint32_t *lc, *bf, *len, *lm, *pi, *lp, *cb, *nb, *kb, *d12, *d27, *ids, *st, *rt; uint32_t cap_rt; };
     DG_HD RouteWk route_wk(const CycWk &K, uint32_t n0) const
     {
         RouteWk R;
@@ -1508,7 +1508,7 @@ template <class T> struct Ops {
         R.bf = p, p += kRouteReads * kRouteReads;
         R.len = p, p += kRouteReads; R.lm = p, p += kRouteReads; R.pi = p, p += kRouteReads; R.lp = p, p += kRouteReads;
         R.cb = p, p += kRouteReads; R.nb = p, p += kRouteReads; R.kb = p, p += kRouteReads; R.d12 = p, p += kRouteReads;
-        R.d27 = p, p += kRouteReads; R.ids = p, p += kRouteReads;
+        R.d27 = p, p += kRouteReads; R.ids = p, p += kRouteReads; R.st = p, p += 8 * kRouteReads;
         R.rt = p;
         const uint32_t fixed = (uint32_t)(p - K.route);
         R.cap_rt = K.cap_route > fixed && n0 ? (K.cap_route - fixed) / n0 : 0;
@@ -1549,23 +1549,64 @@ template <class T> struct Ops {
         // P1: the routes
         uint32_t tk = team.clock();
         auto lap = [&](uint32_t i) { if (tid == 0) { const uint32_t t = team.clock(); h.st_rt[i] += t - tk; tk = t; } };
+        // A route mostly runs along chains whose edges were made one after the other -- the by-passed stretch of the path (a read's own chain once), the
+        // read's own side branches -- so the lanes of a read's group try the edges ce + 1, ce + 2, ... at once: edge ce + j + 1 is the read's next one behind
+        // ce + j when it starts where that one ends and holds the read (a read is on one way out of a node).  Where the ids do not run on, the group's
+        // first lane looks the next edge up.  Rounds until every route has ended.
+        const uint32_t G = (h.dbg_flags & 8u) ? 16u : nc / n0 ? nc / n0 : 1u;      // lanes per read (a team of one: the routes step by step; tests: 16 lanes' work in turn)
+        // per read: ce, len, done, the round's first failing link -- two copies: a round reads one and writes the other (no lane of a group may see the
+        // group's next state before it has used the present one)
+        uint32_t par = 0;
         for (uint32_t b = cr; b < n0; b += nc) {
-            const uint32_t r = K.lists[own_off + b];
-            R.ids[b] = r;
-            uint32_t *rt = R.rt + (size_t)b * R.cap_rt;
-            uint32_t ce = e0, L = 0, lm = 0;
-            for (;;) {
-                if (L >= R.cap_rt) { L = NIL; break; }
-                rt[L++] = ce;
-                const Node &x = g.nodes[g.edges[ce].sink];
-                if (x.on_main) { lm = 1; break; }
-                uint32_t next = NIL;
-                for (uint32_t i = 0; i < x.n_out; ++i) { const uint32_t o = out_ref(x, i) & kRefMask; if (edge_has(g.edges[o], r)) { next = o; break; } }
-                if (next == NIL) break;                          // the read ends at this node
-                ce = next;
+            R.ids[b] = K.lists[own_off + b];
+            if (R.cap_rt) R.rt[(size_t)b * R.cap_rt] = e0;
+            uint32_t *st = R.st + 4 * b;
+            st[0] = e0, st[1] = 1, st[2] = 0, st[3] = G;
+            R.len[b] = 0, R.lm[b] = 0;
+        }
+        if (tid == 0) { ord[23] = 0; if (!R.cap_rt) ord[15] = 1; }
+        team.sync();
+        while (team.peek(&ord[23]) < n0 && !team.peek(&ord[15])) {
+            uint32_t *cur = R.st + par * 4 * kRouteReads, *nxt = R.st + (par ^ 1u) * 4 * kRouteReads;
+            for (uint32_t v = cr; v < n0 * G; v += nc) {
+                const uint32_t b = v / G, jx = v % G;
+                if (cur[4 * b + 2]) continue;
+                const uint64_t e1 = (uint64_t)cur[4 * b] + jx, e2 = e1 + 1;
+                bool ok = false;
+                if (e2 < h.n_edges) {
+                    const uint32_t mid = g.edges[e1].sink;
+                    const Edge &x2 = g.edges[e2];
+                    ok = mid != NIL && x2.src == mid && !g.nodes[mid].on_main && edge_has(x2, R.ids[b]);
+                }
+                if (!ok) team.min_to(&cur[4 * b + 3], jx);
             }
-            R.len[b] = L, R.lm[b] = lm;
-            if (L == NIL) team.add_to(&ord[15], 1);
+            team.sync();
+            for (uint32_t v = cr; v < n0 * G; v += nc) {
+                const uint32_t b = v / G, jx = v % G;
+                if (cur[4 * b + 2]) { if (jx == 0) nxt[4 * b + 2] = 1; continue; }
+                const uint32_t L = team.peek(&cur[4 * b + 3]), ce = cur[4 * b], len = cur[4 * b + 1];
+                uint32_t *rt = R.rt + (size_t)b * R.cap_rt;
+                if ((uint64_t)len + L + 1 > R.cap_rt) { if (jx == 0) { nxt[4 * b + 2] = 1; team.add_to(&ord[15], 1); team.add_to(&ord[23], 1); } continue; }
+                if (jx < L) rt[len + jx] = ce + jx + 1;
+                if (jx) continue;
+                // the group's first lane: where the ids stop running on, the next edge by looking it up
+                uint32_t c2 = ce + L, l2 = len + L, done = 0, lm = 0;
+                if (L < G) {
+                    const Node &x = g.nodes[g.edges[c2].sink];
+                    if (x.on_main) done = 1, lm = 1;
+                    else {
+                        uint32_t next = NIL;
+                        const uint32_t r = R.ids[b];
+                        for (uint32_t i = 0; i < x.n_out; ++i) { const uint32_t o = out_ref(x, i) & kRefMask; if (edge_has(g.edges[o], r)) { next = o; break; } }
+                        if (next == NIL) done = 1;               // the read ends at this node
+                        else rt[l2++] = next, c2 = next;
+                    }
+                }
+                nxt[4 * b] = c2, nxt[4 * b + 1] = l2, nxt[4 * b + 2] = done, nxt[4 * b + 3] = G;
+                if (done) { R.len[b] = l2, R.lm[b] = lm; team.add_to(&ord[23], 1); }
+            }
+            team.sync();
+            par ^= 1u;
         }
         team.sync();
         lap(0);

@@ -3,7 +3,8 @@ with a team of one) against the pointer graph (consensus.cpp) and the independen
   NSGPU_HARNESS_GRAPH=both  runs the two graphs side by side in the sequential -t 1 contig loop (tests/host_harness.cpp): after EVERY
   update + recompute the consensus, the contig's span and the graph's size must agree, and the emission of every contig must give the same bytes;
   NSGPU_SOA_DEBUG_FLAGS     takes the rare branches on every update: excursions one at a time (1), removeCycles by the reference's full walk (2),
-  the left part of the path moved instead of its tail (4), splitPath's chain runs and the probes with a team of one (8)."""
+  the left part of the path moved instead of its tail (4), splitPath's chain runs and the probes with a team of one (8), every splitPath call by the
+  reads' routes from its first edge (128; with 8: sixteen lanes' work per read in turn, the way a workgroup's groups try edge ids ahead)."""
 import os
 import subprocess
 import sys
@@ -31,6 +32,6 @@ def test_soa_graph_equals_pointer_graph_after_every_update_and_the_oracle(kind, 
     assert both == ptr and ptr[1] > 100
 
 
-@pytest.mark.parametrize("kind,seed,flags", [("repeats", 28, "3"), ("long", 1, "12"), ("repeats", 5, "15")])
+@pytest.mark.parametrize("kind,seed,flags", [("repeats", 28, "3"), ("long", 1, "12"), ("repeats", 5, "15"), ("long", 3, "128"), ("homopolymer", 7, "136"), ("long", 1, "136")])
 def test_soa_graph_rare_branches_change_nothing(kind, seed, flags):
     assert run(kind, seed, NSGPU_HARNESS_GRAPH="both", NSGPU_SOA_DEBUG_FLAGS=flags) == run(kind, seed)
