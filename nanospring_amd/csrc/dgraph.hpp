@@ -1339,17 +1339,19 @@ template <class T> struct Ops {
             lists_top = own_off + own_n;
             h.st_idscan += c[3] * g.edges[e].count; ++h.st_ctx;
             c[4] = own_off, c[5] = own_n, c[6] = 1;
-            // a split that has proven large: what hangs below this context is taken by the whole team, read by read (split_routes_run)
-            if (n_done >= ((h.dbg_flags & 128u) ? 0u : kRouteAfter) && own_n && own_n <= kRouteReads && !(h.dbg_flags & 64u)) {
-                const uint32_t r0 = team.clock();
-                K.order[11] = new_pre, K.order[12] = e, K.order[13] = own_off, K.order[14] = own_n, K.order[15] = 0, K.order[16] = 0, K.order[20] = 0, K.order[21] = 0, K.order[22] = 0;
-                (void)team.bcast(3);
-                split_routes_run(K);
-                h.st_cyc[3] += team.clock() - r0;
-                if (failed()) return;
-                if (K.order[16]) { n_done += K.order[17]; lists_top = own_off; continue; }
-            }
+            bool no_routes = (h.dbg_flags & 64u) != 0;
             while (own_n && !failed()) {
+                // a split that has proven large: what hangs below this edge is taken by the whole team, read by read (split_routes_run)
+                if (!no_routes && n_done >= ((h.dbg_flags & 128u) ? 0u : kRouteAfter) && own_n <= kRouteReads) {
+                    const uint32_t r0 = team.clock();
+                    K.order[11] = new_pre, K.order[12] = e, K.order[13] = own_off, K.order[14] = own_n, K.order[15] = 0, K.order[16] = 0, K.order[20] = 0, K.order[21] = 0, K.order[22] = 0;
+                    (void)team.bcast(3);
+                    split_routes_run(K);
+                    h.st_cyc[3] += team.clock() - r0;
+                    if (failed()) return;
+                    if (K.order[16]) { n_done += K.order[17]; own_n = 0, lists_top = own_off; c[5] = 0; break; }
+                    no_routes = true;                            // (a route longer than the work area: step by step)
+                }
                 // A stretch of nodes with one way out each (a by-passed piece of the old path, typically): not one step of this loop after the
                 // other -- the whole team takes the stretch at once (split_chain_run)
                 if (own_n <= kEdgeInl && ((team.crew_size() > 1 && !(h.dbg_flags & 32u)) || (h.dbg_flags & 8u))) {
@@ -1498,7 +1500,7 @@ template <class T> struct Ops {
     // what is appended to lists that exist (the first copy to the node in front, the forks of the tree, the edges back into the path) thread 0 does in the
     // walk's order (P7); old nodes left without edges go (P8).  order[]: 11 new_pre, 12 e, 13 own_off, 14 n; out: 16 done (0: a route does not fit,
     // nothing was changed), 17 the contexts.
-    static constexpr uint32_t kRouteReads = 32, kRouteAfter = 48;
+    static constexpr uint32_t kRouteReads = 32, kRouteAfter = 24;
     struct RouteWk { uint32_t *lc, *bf, *len, *lm, *pi, *lp, *cb, *nb, *kb, *d12, *d27, *ids, *st, *rt; uint32_t cap_rt; };
     DG_HD RouteWk route_wk(const CycWk &K, uint32_t n0) const
     {
@@ -1789,8 +1791,14 @@ template <class T> struct Ops {
             const uint32_t sink = g.edges[curr].sink, source = g.edges[curr].src;
             if (sink == NIL) continue;                           // (an edge a split before this one took away)
             if (g.nodes[sink].on_main) continue;
-            if (marked_only && g.mark[sink] != h.epoch) continue;     // nothing below an unmarked node can be split
+            // (nothing below an unmarked node can be split.  A node the walk has gone down from before -- it comes to a node once per edge in -- carries
+            // ~epoch: the edge it comes by now is split like any other, but below the node every edge has been looked at, and what the walk found there
+            // was either split away or led to a node with one way in, which it still is: the reference's second pass over the same branch changes nothing)
+            const uint32_t mk = g.mark[sink], seen = ~h.epoch;
+            if (marked_only && mk != h.epoch && mk != seen) continue;
             if (g.nodes[sink].n_in > 1) split_path(K, source, curr);
+            if (mk == seen) continue;
+            g.mark[sink] = seen;
             const Node &s = g.nodes[sink];
             if (s.n_out == 1 && s.n_in == 1 && probing()) {
                 if (++streak >= 3) {                          // down a branch without forks or ways in: nothing to split on a stretch of it
