@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--cpu-full", type=int, default=-1, help="also time the reference's -t <cores> (oracle) on the FULL input of the timed steps on this host, ~1-2 min (default: only with 1 GPU at full cfg2 size and a CPU sample; 0 = skip)")
     ap.add_argument("--legal-leg", type=int, default=-1, help="also time ONE step of the fastest reference-legal schedule within 5 %% of the reference's streams: 32 builders, one group, Consensus::getRead's seed rule (default: only with 1 GPU at full cfg2 size; 0 = skip)")
     ap.add_argument("--nonideal-leg", type=int, default=-1, help="also time ONE step on a genome with planted repeats (default: only with 1 GPU at full cfg2 size; 0 = skip)")
-    ap.add_argument("--graph", choices=["auto", "host", "device"], default="auto", help="where the contigs' consensus graphs live (nsgpu_set_graph): in HBM (one workgroup per accepted read), on the host (pointer graph), or by the host threads this process has (auto: in HBM with at most 3)")
+    ap.add_argument("--graph", choices=["auto", "host", "device"], default="auto", help="where the contigs' consensus graphs live (nsgpu_set_graph): in HBM (one workgroup per accepted read), on the host (pointer graph), or by the host threads this process has (auto: in HBM with at most 5)")
     ap.add_argument("--graph-leg", type=int, default=-1, help="also time ONE first step with the consensus graphs in the other placement (default: only with 1 GPU at full cfg2 size; 0 = skip)")
     ap.add_argument("--cfg3-leg", type=int, default=-1, help="also time ONE first step of BASELINE configs[2]'s shape (1.0 Gbase at 217x of a 4.6 Mb genome, automatic schedule) (default: only with 1 GPU at full cfg2 size; 0 = skip)")
     ap.add_argument("--no-exchange", action="store_true", help="multi-GPU: independent shards, no collective")
@@ -433,7 +433,7 @@ def main():
         want_ts = args.threads_sweep if args.threads_sweep >= 0 else int(full_size)
         if want_ts and world == 1:
             import subprocess
-            tsweep = {"note": "one first step per thread count, each in a child process (NSGPU_THREADS), consensus graphs where the library puts them by itself (in HBM with at most 3 host threads); the timed steps above ran with host_threads = %d.  The pointer graph on the host with 2 threads: profiles/r06_graph_placement_by_threads.txt" % a["host_threads"], "runs": []}
+            tsweep = {"note": "one first step per thread count, each in a child process (NSGPU_THREADS), consensus graphs where the library puts them by itself (in HBM with at most 5 host threads); the timed steps above ran with host_threads = %d.  The pointer graph on the host with 2 threads: profiles/r06_graph_placement_by_threads.txt" % a["host_threads"], "runs": []}
             for nthr in (4, 2):
                 cmd = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--throughput-leg", "0", "--cpu-sample", "0", "--cpu-full", "0", "--legal-leg", "0",
                        "--nonideal-leg", "0", "--threads-sweep", "0", "--reads", str(args.reads), "--mean-len", str(args.mean_len), "--depth", str(args.depth), "--genome", args.genome]

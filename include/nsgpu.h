@@ -299,7 +299,7 @@ int nsgpu_get_defer(const nsgpu_ctx *ctx, uint32_t *anchors, uint32_t *slots, ui
  *   NSGPU_GRAPH_HOST    the pointer graph on the host, updated by the pool's threads (one update = ~0.1 ms of one core);
  *   NSGPU_GRAPH_DEVICE  a structure of arrays with 32-bit ids in HBM, one workgroup per update (one launch per slot whose workgroups wait
  *                       for the accepted reads' scripts), the finished contig copied back once for the edit emission;
- *   NSGPU_GRAPH_AUTO    (default) in HBM when the process has at most 3 host threads (a rank of a shared node: NSGPU_THREADS / the CPU
+ *   NSGPU_GRAPH_AUTO    (default) in HBM when the process has at most 5 host threads (a rank of a shared node: NSGPU_THREADS / the CPU
  *                       quota divided by the local ranks), else on the host -- the measured cross-over, DESIGN.md section 6.
  * `| NSGPU_GRAPH_CHECK`: every update in HBM is also run on the host by the same code with a team of one and the arrays are compared entry
  * by entry (tests).  The environment's NSGPU_GRAPH = host | device | auto applies while this was never called.  Both placements give the

@@ -28,8 +28,8 @@ static int graph_shared_get(nsgpu_ctx *c, DevGraphShared **out)
     uint32_t mode = c->graph_mode & 0xffu;
     bool check = (c->graph_mode & NSGPU_GRAPH_CHECK) != 0 || getenv("NSGPU_GRAPH_CHECK") != nullptr;
     if (!c->graph_mode_set) { const char *e = getenv("NSGPU_GRAPH"); if (e) mode = !strcmp(e, "host") ? NSGPU_GRAPH_HOST : !strcmp(e, "device") ? NSGPU_GRAPH_DEVICE : NSGPU_GRAPH_AUTO; }
-    // (the measured cross-over: with 16 threads the pointer graph's updates ride on the DP phase for nothing, with 2 they ARE the step)
-    if (mode == NSGPU_GRAPH_AUTO) mode = host_threads() <= 3 ? NSGPU_GRAPH_DEVICE : NSGPU_GRAPH_HOST;
+    // (the measured cross-over, profiles/r06_graph_placement_by_threads.txt: with 16 threads the pointer graph's updates ride on the DP phase for nothing, with 2 they ARE the step; the two placements meet at 6)
+    if (mode == NSGPU_GRAPH_AUTO) mode = host_threads() <= 5 ? NSGPU_GRAPH_DEVICE : NSGPU_GRAPH_HOST;
     c->graph_used = mode;
     if (mode != NSGPU_GRAPH_DEVICE) return NSGPU_OK;
     if (!c->graph_shared) {

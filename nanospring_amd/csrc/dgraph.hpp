@@ -310,6 +310,33 @@ template <class T> struct Ops {
         for (uint32_t i = 0; i < x.n_out; ++i) { const uint32_t e = out_ref(x, i) & kRefMask, k = g.edges[e].count; if (k > c) c = k, best = e; }
         return best;
     }
+    // getBestEdgeOut of up to U nodes at once (NIL: none): the nodes' records, then all their edges' counts, loaded side by side
+    template <uint32_t U> DG_HD void best_out_many(const uint32_t *n, uint32_t *best) const
+    {
+        uint32_t refs[U][kOutInl], no[U], k[U][kOutInl];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (uint32_t q = 0; q < U; ++q) {
+            no[q] = 0;
+            if (n[q] != NIL) { const Node &x = g.nodes[n[q]]; no[q] = x.n_out; for (uint32_t i = 0; i < kOutInl; ++i) refs[q][i] = x.out[i]; }
+        }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (uint32_t q = 0; q < U; ++q)
+            for (uint32_t i = 0; i < kOutInl; ++i) k[q][i] = i < no[q] && no[q] <= kOutInl ? g.edges[refs[q][i] & kRefMask].count : 0u;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (uint32_t q = 0; q < U; ++q) {
+            if (n[q] == NIL) { best[q] = NIL; continue; }
+            if (no[q] > kOutInl) { best[q] = best_out(n[q]); continue; }
+            uint32_t b = NIL, c = 0;
+            for (uint32_t i = 0; i < kOutInl; ++i) if (i < no[q] && k[q][i] > c) c = k[q][i], b = refs[q][i] & kRefMask;
+            best[q] = b;
+        }
+    }
     DG_HD uint32_t best_in(uint32_t n) const
     {
         const Node &x = g.nodes[n];
@@ -627,20 +654,35 @@ template <class T> struct Ops {
             team.sync();
             ro = sh;
         }
-        for (uint32_t base = 0; base < n_run; base += nt) {
-            const uint32_t t = base + tid;
-            uint32_t e = NIL, need = 0;
-            if (t < n_run) {
+        // (four items per lane and round: the loads of four edges in flight at once -- a round is as long as its chain of dependent loads)
+        constexpr uint32_t U = 4;
+        for (uint32_t base = 0; base < n_run; base += nt * U) {
+            const uint32_t t0 = base + tid * U;
+            uint32_t e[U], need[U], nsum = 0, lo = 0;
+            if (t0 < n_run) {
                 // the op whose run holds item t: run_off[lo] <= t < run_off[hi]   (run_off[n_ops] = n_run)
-                uint32_t lo = 0, hi = n_ops;
-                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ro[mid] <= t) lo = mid; else hi = mid; }
-                e = g.pe[h.path_off + op_at[lo] + (t - ro[lo])];
-                need = append_needs_chunk(g.edges[e].count) ? 1u : 0u;
+                uint32_t hi = n_ops;
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ro[mid] <= t0) lo = mid; else hi = mid; }
             }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (uint32_t q = 0; q < U; ++q) {
+                const uint32_t t = t0 + q;
+                e[q] = NIL, need[q] = 0;
+                if (t < n_run) { while (lo + 1 < n_ops && ro[lo + 1] <= t) ++lo; e[q] = g.pe[h.path_off + op_at[lo] + (t - ro[lo])]; }
+            }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (uint32_t q = 0; q < U; ++q) if (e[q] != NIL) { need[q] = append_needs_chunk(g.edges[e[q]].count) ? 1u : 0u; nsum += need[q]; }
             uint32_t tot;
-            const uint32_t p = team.scan(need, tot);
+            uint32_t p = team.scan(nsum, tot);
             if ((uint64_t)chunks_base + tot > h.cap_chunks) { if (tid == 0) fail_at(__LINE__, ERR_CAP); team.sync(); return; }
-            if (t < n_run) append_id(e, id, need ? chunks_base + p : NIL);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (uint32_t q = 0; q < U; ++q) if (e[q] != NIL) { append_id(e[q], id, need[q] ? chunks_base + p : NIL); p += need[q]; }
             chunks_base += tot;
         }
         team.sync();
@@ -1128,13 +1170,29 @@ template <class T> struct Ops {
         for (int part = 0; part < 2; ++part) {
             const uint32_t lo_i = part ? m : R, hi_i = part ? m : hi_f;
             if (part && hi_f >= m) break;
-            for (uint32_t base = lo_i; base <= hi_i; base += nt) {
-                const uint32_t i = base + tid;
-                uint32_t d = 0, ch = NIL;
-                if (i <= hi_i) { ch = best_out(g.pn[off + i]); d = ch != (i < m ? g.pe[off + i] : NIL) ? 1u : 0u; }
+            constexpr uint32_t U = 4;                             // (four nodes per lane and round: their edges' counts are loaded side by side)
+            for (uint64_t base = lo_i; base <= hi_i; base += (uint64_t)nt * U) {
+                const uint64_t i0 = base + (uint64_t)tid * U;
+                uint32_t nn[U], ch[U], dsum = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                for (uint32_t q = 0; q < U; ++q) nn[q] = i0 + q <= hi_i ? g.pn[off + (uint32_t)(i0 + q)] : NIL;
+                best_out_many<U>(nn, ch);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                for (uint32_t q = 0; q < U; ++q) {
+                    const uint64_t i = i0 + q;
+                    const bool d = i <= hi_i && ch[q] != (i < m ? g.pe[off + (uint32_t)i] : NIL);
+                    if (!d) nn[q] = NIL; else ++dsum;              // (nn[q] != NIL from here on: a disagreement)
+                }
                 uint32_t tot;
-                const uint32_t p = team.scan(d, tot);
-                if (d && n_dis + p < cap_d) D[2 * (n_dis + p)] = i, D[2 * (n_dis + p) + 1] = ch;
+                uint32_t p = team.scan(dsum, tot);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                for (uint32_t q = 0; q < U; ++q) if (nn[q] != NIL) { if (n_dis + p < cap_d) D[2 * (n_dis + p)] = (uint32_t)(i0 + q), D[2 * (n_dis + p) + 1] = ch[q]; ++p; }
                 n_dis += tot;
             }
         }

@@ -104,7 +104,7 @@ def test_cfg2_full_default_schedule_in_hbm_equals_lockstep_oracle_hashes(monkeyp
 
 
 def test_automatic_placement_follows_the_host_threads():
-    """NSGPU_GRAPH unset: in HBM with at most 3 host threads (a rank of a shared node), on the host otherwise; same streams"""
+    """NSGPU_GRAPH unset: in HBM with at most 5 host threads (a rank of a shared node), on the host otherwise; same streams"""
     code = ("import sys, hashlib; sys.path.insert(0, %r); import nanospring_amd as ns; from nanospring_amd.filter import STREAMS\n"
             "bases, off = ns.synth_reads(5, 60000, 240, 2500.0)\n"
             "g = ns.NsGpu(); g.load_reads((bases, off)); g.sketch(ns.mt19937_64_salts(60), fetch=False); g.build_index()\n"
