@@ -436,14 +436,17 @@ def main():
             tsweep = {"note": "one first step per thread count, each in a child process (NSGPU_THREADS), consensus graphs where the library puts them by itself (in HBM with at most 5 host threads); the timed steps above ran with host_threads = %d.  The pointer graph on the host with 2 threads: profiles/r06_graph_placement_by_threads.txt" % a["host_threads"], "runs": []}
             for nthr in (4, 2):
                 cmd = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--throughput-leg", "0", "--cpu-sample", "0", "--cpu-full", "0", "--legal-leg", "0",
-                       "--nonideal-leg", "0", "--threads-sweep", "0", "--reads", str(args.reads), "--mean-len", str(args.mean_len), "--depth", str(args.depth), "--genome", args.genome]
+                       "--nonideal-leg", "0", "--threads-sweep", "0", "--graph-leg", "0", "--cfg3-leg", "0", "--reads", str(args.reads), "--mean-len", str(args.mean_len), "--depth", str(args.depth), "--genome", args.genome]
                 try:
                     rr = subprocess.run(cmd, env=dict(os.environ, NSGPU_THREADS=str(nthr)), capture_output=True, text=True, timeout=600)
-                    cj = json.loads([ln for ln in rr.stdout.splitlines() if ln.startswith("{")][-1])
+                    lines = [ln for ln in rr.stdout.splitlines() if ln.startswith("{")]
+                    if not lines: raise RuntimeError("the child printed no result (exit code %d): %s" % (rr.returncode, rr.stderr[-600:]))
+                    cj = json.loads(lines[-1])
                     tsweep["runs"].append({"host_threads": nthr, "value": cj["value"], "unit": "Mbases/s", "ms_per_step": cj["ms_per_step"], "consensus_graphs": cj["config"]["consensus_graph"]["placement"], "graph_host_wall_ms": cj["config"]["stage_ms_per_step"]["graph_host_wall"],
-                                           "lossless_roundtrip_bad_reads": cj["config"]["lossless_roundtrip_bad_reads"]})
+                                           "lossless_roundtrip_bad_reads": cj["config"]["lossless_roundtrip_bad_reads"], "streams_identical_to_the_fixture": (cj.get("parity") or {}).get("all_identical")})
+                    if cj["config"]["lossless_roundtrip_bad_reads"] or (cj.get("parity") or {}).get("all_identical") is False: tsweep["runs"][-1]["stderr_tail"] = rr.stderr[-3000:]
                 except Exception as ex:                 # (a leg, not the measurement: report and go on)
-                    tsweep["runs"].append({"host_threads": nthr, "error": str(ex)[:200]})
+                    tsweep["runs"].append({"host_threads": nthr, "error": str(ex)[:900]})
         gstats = ns.graph_stats(g)               # of the last timed step
         # ONE first step with the consensus graphs in the other placement (same schedule, same streams): what the choice costs / buys on this host
         gleg = None

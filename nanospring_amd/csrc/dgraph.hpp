@@ -1794,6 +1794,9 @@ template <class T> struct Ops {
         team.sync();
         // P7: what is appended to lists that were there before
         if (tid == 0) {
+            // (the copies' ids are taken first: the pushes below may hand out chunks of their own)
+            h.n_nodes += ord[18], h.live_nodes += ord[18], h.n_edges += ord[17], h.live_edges += ord[17] - team.peek(&ord[20]), h.n_chunks += ord[19];
+            h.n_multi -= team.peek(&ord[21]);
             out_push(new_pre, ebase | (code_of(g.nodes[g.edges[ebase].sink].base) << 29));
             for (uint32_t t = 1; t < n0; ++t) {
                 const uint32_t r = R.pi[t], d = R.lp[t];
@@ -1809,10 +1812,7 @@ template <class T> struct Ops {
                 const uint32_t ne = ebase + R.cb[t] + (R.len[r] - R.lp[t]) - 1;
                 in_push(g.edges[ne].sink, ne);
             }
-            const uint32_t C = ord[17], Nn = ord[18], Kc = ord[19];
-            h.n_nodes += Nn, h.live_nodes += Nn, h.n_edges += C, h.live_edges += C - team.peek(&ord[20]), h.n_chunks += Kc;
-            h.n_multi -= team.peek(&ord[21]);
-            h.st_ctx += C, ++h.st_routes, h.st_route_ctx += C;
+            h.st_ctx += ord[17], ++h.st_routes, h.st_route_ctx += ord[17];
         }
         team.sync();
         // P8: old nodes nothing leads to or from any more

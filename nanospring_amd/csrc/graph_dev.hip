@@ -218,6 +218,10 @@ void *SlabPool::alloc(size_t bytes, size_t *granted)
     void *s = nullptr;
     const hipError_t e = host_ ? hipHostMalloc(&s, sb, hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable) : hipMalloc(&s, sb);
     if (e != hipSuccess || !s) { set_error("graph memory pool: %s(%zu) failed: %s", host_ ? "hipHostMalloc" : "hipMalloc", sb, hipGetErrorString(e)); return nullptr; }
+    // (tests: fresh slabs full of a pattern -- HBM straight from the driver is often zero, and code that leans on that works until the process gets
+    // memory another one has used)
+    static const char *poison = getenv("NSGPU_POOL_POISON");         // the 32-bit word every fresh slab is filled with (decimal)
+    if (poison) { const uint32_t w = (uint32_t)strtoul(poison, nullptr, 0); if (host_) { uint32_t *q = static_cast<uint32_t *>(s); for (size_t i = 0; i < sb / 4; ++i) q[i] = w; } else (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(s), (int)w, sb / 4); }
     slabs_.push_back(s);
     mapped_ += sb;
     tails_.push_back(std::make_pair(static_cast<char *>(s) + ga, sb - ga));
