@@ -897,7 +897,8 @@ static int engine_early_updates(nsgpu_ctx *c, const int *gis, int n_gi)
     // whatever gets none -- an alignment that failed, a contested read -- is released when this function is left
     std::vector<DevGraph *> armed;
     struct Disarm { std::vector<DevGraph *> &v; ~Disarm() { for (DevGraph *g : v) if (g->armed()) g->cancel(); } } disarm{armed};
-    if (D.gsh) {
+    static const bool solo = getenv("NSGPU_GRAPH_SOLO") != nullptr;      // tests: no launch for a whole slot, every update a launch of its own
+    if (D.gsh && !solo) {
         for (int k = 0; k < n_act; ++k)
             for (uint32_t bi : E->awho[act[k]]) {
                 Builder &b = D.B[bi];

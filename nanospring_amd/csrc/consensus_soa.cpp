@@ -46,11 +46,22 @@ size_t SoaStore::bytes() const
 void SoaStore::reserve(uint32_t n_nodes, uint32_t n_edges, uint32_t n_chunks, uint32_t path_side, uint32_t wk_words)
 {
     auto grow = [](size_t have, size_t want) { size_t c = have ? have : 1024; while (c < want) c += c / 2 + 1024; return c; };
-    if (nodes.size() < n_nodes) { const size_t c = grow(nodes.size(), n_nodes); nodes.resize(c); mark.resize(c); pidx.resize(c); }
-    if (edges.size() < n_edges) edges.resize(grow(edges.size(), n_edges));
-    if (chunks.size() < n_chunks) chunks.resize(grow(chunks.size(), n_chunks));
-    if (wk.size() < wk_words) wk.resize(grow(wk.size(), wk_words));
-    if (multi.size() < 4096) multi.resize(4096);
+    // (tests: new entries full of a pattern instead of zeros -- NSGPU_SOA_POISON = the 32-bit word, a bit set per array in NSGPU_SOA_POISON_ARRAYS:
+    // 1 nodes, 2 edges, 4 chunks, 8 mark, 16 pidx, 32 the path arrays, 64 their staging, 128 the multi list, 256 the work area.  The arrays in
+    // HBM come out of a pool that does not clear them)
+    static const char *pz = getenv("NSGPU_SOA_POISON");
+    static const uint32_t pw = pz ? (uint32_t)strtoul(pz, nullptr, 0) : 0;
+    static const uint32_t pa = getenv("NSGPU_SOA_POISON_ARRAYS") ? (uint32_t)strtoul(getenv("NSGPU_SOA_POISON_ARRAYS"), nullptr, 0) : 0xffffffffu;
+    auto fill = [&](void *p, size_t from_bytes, size_t to_bytes, uint32_t bit) { if (!pz || !(pa & bit)) return; uint32_t *q = static_cast<uint32_t *>(p); for (size_t i = from_bytes / 4; i < to_bytes / 4; ++i) q[i] = pw; };
+    if (nodes.size() < n_nodes) {
+        const size_t c0 = nodes.size(), c = grow(nodes.size(), n_nodes);
+        nodes.resize(c); mark.resize(c); pidx.resize(c);
+        fill(nodes.data(), c0 * sizeof(dg::Node), c * sizeof(dg::Node), 1), fill(mark.data(), c0 * 4, c * 4, 8), fill(pidx.data(), c0 * 4, c * 4, 16);
+    }
+    if (edges.size() < n_edges) { const size_t c0 = edges.size(); edges.resize(grow(edges.size(), n_edges)); fill(edges.data(), c0 * sizeof(dg::Edge), edges.size() * sizeof(dg::Edge), 2); }
+    if (chunks.size() < n_chunks) { const size_t c0 = chunks.size(); chunks.resize(grow(chunks.size(), n_chunks)); fill(chunks.data(), c0 * sizeof(dg::Chunk), chunks.size() * sizeof(dg::Chunk), 4); }
+    if (wk.size() < wk_words) { const size_t c0 = wk.size(); wk.resize(grow(wk.size(), wk_words)); fill(wk.data(), c0 * 4, wk.size() * 4, 256); }
+    if (multi.size() < 4096) { multi.resize(4096); fill(multi.data(), 0, 4096 * 4, 128); }
     // the path: room of path_side entries on both sides of [path_off, path_off + m]
     const uint32_t len = hdr.cap_path ? hdr.m + 1 : 0;
     const bool short_left = hdr.path_off < path_side, short_right = (uint64_t)hdr.path_off + len + path_side > pe.size();
@@ -64,8 +75,12 @@ void SoaStore::reserve(uint32_t n_nodes, uint32_t n_edges, uint32_t n_chunks, ui
             memcpy(n2.data() + off2, pn.data() + hdr.path_off, (size_t)len * 4);
             memcpy(s2.data() + off2, ps.data() + hdr.path_off, len);
         }
+        if (pz && (pa & 32u)) {                             // (everything outside the copied path)
+            for (size_t i = 0; i < cap; ++i) if (i < off2 || i >= (size_t)off2 + len) { e2[i] = pw, n2[i] = pw, s2[i] = (uint8_t)pw; }
+            if (len) e2[off2 + len - 1] = pw;
+        }
         pe.swap(e2), pn.swap(n2), ps.swap(s2);
-        sv_e.assign(cap, 0), sv_n.assign(cap, 0), sv_s.assign(cap, 0);
+        sv_e.assign(cap, pz && (pa & 64u) ? pw : 0), sv_n.assign(cap, pz && (pa & 64u) ? pw : 0), sv_s.assign(cap, pz && (pa & 64u) ? (uint8_t)pw : 0);
         hdr.pos_bias += off2 - hdr.path_off;           // (what the nodes remember of their places moves with the arrays)
         hdr.path_off = off2;
     }
@@ -129,7 +144,7 @@ void SoaGraph::initialize(const std::string &seed, read_t id, long pos)
     // (reserve centres an empty path: initialize puts the seed in the middle of the arrays itself)
     dg::HostTeam t;
     HostOps ops(st_.view(), t);
-    { static const char *e = getenv("NSGPU_SOA_DEBUG_FLAGS"); st_.hdr.dbg_flags = e ? (uint32_t)atoi(e) : 0; }       // (tests: the rare branches on every update)
+    { static const char *e = getenv("NSGPU_SOA_DEBUG_FLAGS"); st_.hdr.dbg_flags = dbg_flags_override >= 0 ? (uint32_t)dbg_flags_override : e ? (uint32_t)atoi(e) : 0; }       // (tests: the rare branches on every update)
     ops.initialize(reinterpret_cast<const uint8_t *>(seed.data()), (uint32_t)seed.size(), id);
     die_on(st_.hdr, "initialize");
     reads.insert(std::make_pair(id, SoaRead{pos, 0u, seed.size(), false}));
@@ -171,6 +186,15 @@ void SoaGraph::calculate_main_path_greedy()
     }
     die_on(st_.hdr, "calculate_main_path_greedy");
     const dg::Hdr &h = st_.hdr;
+    {   // tests (NSGPU_SOA_POISON): every id handed out so far must have been written -- a record that still is the fill pattern was only counted
+        static const char *pz = getenv("NSGPU_SOA_POISON");
+        if (pz) {
+            const uint32_t pw = (uint32_t)strtoul(pz, nullptr, 0);
+            auto untouched = [&](const void *rec, size_t words) { const uint32_t *q = static_cast<const uint32_t *>(rec); for (size_t i = 0; i < words; ++i) if (q[i] != pw) return false; return true; };
+            for (uint32_t i = 0; i < h.n_nodes; ++i) if (untouched(&st_.nodes[i], 8)) { fprintf(stderr, "SOA POISON: node %u of %u was never written (edges %u)\n", i, h.n_nodes, h.n_edges); break; }
+            for (uint32_t i = 0; i < h.n_edges; ++i) if (untouched(&st_.edges[i], 16)) { fprintf(stderr, "SOA POISON: edge %u of %u was never written (nodes %u)\n", i, h.n_edges, h.n_nodes); break; }
+        }
+    }
     if (h.old_len != main_path.size()) { fprintf(stderr, "nsgpu: consensus length out of step with the graph (internal error)\n"); abort(); }
     soa_patch_path(main_path, h.P, h.S, h.new_len, st_.ps.data() + h.path_off + h.P);
     if (h.P < path_changed_from) path_changed_from = h.P;

@@ -67,6 +67,7 @@ public:
     read_t first_read = 0;
     std::map<read_t, SoaRead> reads;
     size_t path_changed_from = 0;
+    int dbg_flags_override = -1;                      // tests: this graph's dgraph.hpp debug flags (else NSGPU_SOA_DEBUG_FLAGS)
 
     void initialize(const std::string &seed, read_t id, long pos);
     void update_graph(const std::string &s, const std::vector<mm2::EditOp> &script, ssize_t begin_offset, ssize_t end_offset, read_t id, long pos, bool rc);

@@ -97,7 +97,14 @@ __device__ static void dg_apply_setup(const dg::G &g, const DgSetup &s)
 }
 
 // What a graph's workgroup is told (pinned host memory, written by the host while the kernel waits).  cmd is written last.
+// The order word carries the ticket of the prepare() it belongs to (code | ticket << 3): a workgroup is launched with its graph's ticket and takes
+// nothing else.  A launch whose workgroups START late -- its kernel queued behind others on a shared hardware queue: seen with a second process on
+// the GPU -- would otherwise find the slot record already re-armed for the graph's NEXT update and run that update beside the workgroup it was meant
+// for (the same script applied twice).  Tickets are unique over all graphs of the engine (a staging block may change hands).
 enum : uint32_t { DG_CMD_NONE = 0, DG_CMD_UPDATE = 1, DG_CMD_INIT_UPDATE = 2, DG_CMD_CANCEL = 3 };
+constexpr uint32_t kDgTicketShift = 3, kDgTicketMask = (1u << 29) - 1u;
+struct DgSlot;
+struct DgArm { DgSlot *slot; uint32_t ticket, pad; };
 struct DgSlot {
     uint32_t cmd, epoch, n_ops, id, seed_len, first_id;
     long long begin_offset, end_offset;
@@ -141,16 +148,21 @@ __device__ static void dg_report(const dg::G &g, DevTeam &t, DgResult *res, uint
 // reports into pinned memory.  ONE launch for the graphs of a whole slot: kernels launched one by one from eighty streams queue up behind each
 // other and behind the DP kernels on the runtime's eight hardware queues (measured: 3.3 ms from launch to report for 0.7 ms of kernel).
 // A workgroup that is never told anything leaves after `patience` ticks of the 100 MHz clock (the host always cancels what it does not use).
-__global__ __launch_bounds__(kDgThreads) void dg_serve_kernel(DgSlot *const *slots, unsigned long long patience)
+__global__ __launch_bounds__(kDgThreads) void dg_serve_kernel(const DgArm *arms, unsigned long long patience)
 {
     __shared__ uint32_t lds[16];
     __shared__ uint32_t shm[kDgSharedWords];
     __shared__ uint32_t slot_w[sizeof(DgSlot) / 4];
-    DgSlot *s = slots[blockIdx.x];
+    DgSlot *s = arms[blockIdx.x].slot;
+    const uint32_t ticket = arms[blockIdx.x].ticket;
     if (threadIdx.x == 0) {
         const unsigned long long t0 = wall_clock64();
         uint32_t cmd;
-        while ((cmd = __hip_atomic_load(&s->cmd, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) == DG_CMD_NONE) {
+        for (;;) {
+            const uint32_t w = __hip_atomic_load(&s->cmd, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((w >> kDgTicketShift) != ticket) { cmd = DG_CMD_CANCEL; break; }       // not this launch's order any more: the host has moved on
+            cmd = w & ((1u << kDgTicketShift) - 1u);
+            if (cmd != DG_CMD_NONE) break;
             if (wall_clock64() - t0 > patience) { cmd = DG_CMD_CANCEL; break; }
             __builtin_amdgcn_s_sleep(64);
         }
@@ -221,7 +233,7 @@ void *SlabPool::alloc(size_t bytes, size_t *granted)
     // (tests: fresh slabs full of a pattern -- HBM straight from the driver is often zero, and code that leans on that works until the process gets
     // memory another one has used)
     static const char *poison = getenv("NSGPU_POOL_POISON");         // the 32-bit word every fresh slab is filled with (decimal)
-    if (poison) { const uint32_t w = (uint32_t)strtoul(poison, nullptr, 0); if (host_) { uint32_t *q = static_cast<uint32_t *>(s); for (size_t i = 0; i < sb / 4; ++i) q[i] = w; } else (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(s), (int)w, sb / 4); }
+    if (poison) { const uint32_t w = (uint32_t)strtoul(poison, nullptr, 0); if (host_) { uint32_t *q = static_cast<uint32_t *>(s); for (size_t i = 0; i < sb / 4; ++i) q[i] = w; } else { (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(s), (int)w, sb / 4); (void)hipDeviceSynchronize(); } }     // (the fill is in place before anything is written there)
     slabs_.push_back(s);
     mapped_ += sb;
     tails_.push_back(std::make_pair(static_cast<char *>(s) + ga, sb - ga));
@@ -398,9 +410,9 @@ int DevGraph::prepare(size_t read_len)
     uint32_t *ops_pin = reinterpret_cast<uint32_t *>(res + 1);
     uint8_t *seed_pin = reinterpret_cast<uint8_t *>(ops_pin + max_ops + 16);
     ops_cap_ = max_ops;
-    ++epoch_;
-    if (epoch_ == 0) epoch_ = 1;
-    slot->cmd = DG_CMD_NONE, slot->epoch = epoch_, slot->n_ops = 0, slot->id = 0, slot->seed_len = seed_len, slot->first_id = (uint32_t)first_read;
+    epoch_ = (sh_->next_ticket.fetch_add(1) & kDgTicketMask);
+    if (epoch_ == 0) epoch_ = (sh_->next_ticket.fetch_add(1) & kDgTicketMask);
+    slot->cmd = DG_CMD_NONE | (epoch_ << kDgTicketShift), slot->epoch = epoch_, slot->n_ops = 0, slot->id = 0, slot->seed_len = seed_len, slot->first_id = (uint32_t)first_read;
     slot->begin_offset = slot->end_offset = 0;
     slot->g = view();
     slot->setup = DgSetup{cap_nodes_, cap_edges_, cap_chunks_, cap_path_, cap_wk_, cap_multi_, moved_path_ ? path_off_ : dg::NIL, sh_->dbg_flags};
@@ -424,15 +436,15 @@ int graph_serve_launch(DevGraphShared *sh, DevGraph *const *graphs, size_t n)
         else ++i;
     }
     DevGraphShared::Launch L;
-    L.ptrs = sh->pin.alloc(n * sizeof(void *), &L.granted);
+    L.ptrs = sh->pin.alloc(n * sizeof(DgArm), &L.granted);
     NS_CHECK(L.ptrs, NSGPU_ERR_NOMEM, "consensus graph: no pinned memory for a launch's slot list");
     if (!sh->free_events.empty()) { L.done = sh->free_events.back(); sh->free_events.pop_back(); }
     else NS_HIP(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
-    DgSlot **ptrs = static_cast<DgSlot **>(L.ptrs);
+    DgArm *ptrs = static_cast<DgArm *>(L.ptrs);
     for (size_t i = 0; i < n; ++i) {
         DevGraph *g = graphs[i];
         NS_CHECK(g->prepared_ && !g->armed_, NSGPU_ERR_ARG, "consensus graph: a serve launch over a graph that was not prepared (internal error)");
-        ptrs[i] = static_cast<DgSlot *>(g->pin_.p);
+        ptrs[i].slot = static_cast<DgSlot *>(g->pin_.p), ptrs[i].ticket = g->epoch_, ptrs[i].pad = 0;
         g->armed_ = true, g->prepared_ = false;
     }
     __atomic_thread_fence(__ATOMIC_RELEASE);
@@ -450,7 +462,7 @@ void DevGraph::cancel()
 {
     if (!armed_ || pending_) return;
     DgSlot *slot = static_cast<DgSlot *>(pin_.p);
-    __atomic_store_n(&slot->cmd, (uint32_t)DG_CMD_CANCEL, __ATOMIC_RELEASE);
+    __atomic_store_n(&slot->cmd, (uint32_t)DG_CMD_CANCEL | (epoch_ << kDgTicketShift), __ATOMIC_RELEASE);
     armed_ = false;
     // (the arrays prepare() replaced stay retired until the next update reports: nothing has read the new ones yet, but nothing is lost either)
 }
@@ -488,7 +500,7 @@ int DevGraph::submit(const std::string &query, const mm2::AlnOut &aln, read_t id
     }
     p_begin_ = (long long)aln.begin_offset, p_end_ = (long long)aln.end_offset;
     p_id_ = id, p_pos_ = (long)aln.rel_pos, p_len_ = query.size(), p_rc_ = rc, p_t0_ = now_ms_();
-    __atomic_store_n(&slot->cmd, (uint32_t)(first ? DG_CMD_INIT_UPDATE : DG_CMD_UPDATE), __ATOMIC_RELEASE);
+    __atomic_store_n(&slot->cmd, (uint32_t)(first ? DG_CMD_INIT_UPDATE : DG_CMD_UPDATE) | (epoch_ << kDgTicketShift), __ATOMIC_RELEASE);
     pending_ = true, armed_ = false;
     sh_->n_updates += 1;
     if (shadow_) {
@@ -649,8 +661,39 @@ int DevGraph::check_against_shadow(const char *where)
 {
     cons::SoaStore &S = shadow_->store();
     const dg::Hdr &a = hdr_, &b = S.hdr;
+    { static const bool solo = getenv("NSGPU_GRAPH_SOLO") != nullptr; if (solo) NS_HIP(hipStreamSynchronize(sh_->serve_stream)); }      // (tests: the update's kernel has ended, not only reported)
     auto bad = [&](const char *what, uint64_t x, uint64_t y) { set_error("consensus graph check (%s, read %u): %s differs: device %llu, host %llu", where, (unsigned)p_id_, what, (unsigned long long)x, (unsigned long long)y); return NSGPU_ERR_RANGE; };
-    if (path_ != shadow_->main_path) return bad("the consensus", path_.size(), shadow_->main_path.size());
+    if (path_ != shadow_->main_path) {
+        size_t d = 0;
+        while (d < path_.size() && d < shadow_->main_path.size() && path_[d] == shadow_->main_path[d]) ++d;
+        set_error("consensus graph check (%s, read %u): the consensus differs: device %zu bases, host %zu, first difference at %zu; device / host: P %u / %u, S %u / %u, old_len %u / %u, new_len %u / %u, m %u / %u, path_off %u / %u, R Lf m la lenF touch_hi %u %u %u %u %u %u / %u %u %u %u %u %u, detours %u / %u, walked %u / %u, disagreements %u / %u, ended %u / %u, gap %u / %u",
+                  where, (unsigned)p_id_, path_.size(), shadow_->main_path.size(), d, a.P, b.P, a.S, b.S, a.old_len, b.old_len, a.new_len, b.new_len, a.m, b.m, a.path_off, b.path_off,
+                  a.st_last[0], a.st_last[1], a.st_last[2], a.st_last[3], a.st_last[4], a.st_last[5], b.st_last[0], b.st_last[1], b.st_last[2], b.st_last[3], b.st_last[4], b.st_last[5],
+                  a.st_detours, b.st_detours, a.st_walked, b.st_walked, a.st_dis, b.st_dis, a.st_ended, b.st_ended, a.st_gap, b.st_gap);
+        {   // where the two paths part, and what the node in front of that offers on both sides
+            std::vector<dg::Node> nodes(a.n_nodes); std::vector<dg::Edge> edges(a.n_edges); std::vector<dg::Chunk> chunks(a.n_chunks); std::vector<uint32_t> pn(a.m + 1);
+            (void)hipMemcpy(nodes.data(), b_nodes_.p, nodes.size() * sizeof(dg::Node), hipMemcpyDeviceToHost);
+            if (!edges.empty()) (void)hipMemcpy(edges.data(), b_edges_.p, edges.size() * sizeof(dg::Edge), hipMemcpyDeviceToHost);
+            if (!chunks.empty()) (void)hipMemcpy(chunks.data(), b_chunks_.p, chunks.size() * sizeof(dg::Chunk), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(pn.data(), static_cast<uint32_t *>(b_pn_.p) + a.path_off, ((size_t)a.m + 1) * 4, hipMemcpyDeviceToHost);
+            uint32_t i = 0;
+            while (i <= a.m && i <= b.m && pn[i] == S.pn[b.path_off + i]) ++i;
+            std::string more = "; the paths part at node index " + std::to_string(i);
+            if (i > 0 && i <= a.m) {
+                const uint32_t n = pn[i - 1];
+                auto list_at = [](const std::vector<dg::Chunk> &ch, const uint32_t *inl, uint32_t n_inl, uint32_t ext, uint32_t k) { if (k < n_inl) return inl[k]; k -= n_inl; uint32_t c = ext; while (k >= dg::kChunkIds) c = ch[c].next, k -= dg::kChunkIds; return ch[c].v[k]; };
+                const dg::Node &x = nodes[n], &y = S.nodes[n];
+                more += " behind node " + std::to_string(n) + " (n_out " + std::to_string(x.n_out) + " / " + std::to_string(y.n_out) + ", out_ext " + std::to_string(x.out_ext) + " / " + std::to_string(y.out_ext) + "): device outs";
+                for (uint32_t k = 0; k < x.n_out && k < 8; ++k) { const uint32_t r = list_at(chunks, x.out, dg::kOutInl, x.out_ext, k) & dg::kRefMask; more += " " + std::to_string(r) + "(count " + std::to_string(r < edges.size() ? edges[r].count : 0u) + " sink " + std::to_string(r < edges.size() ? edges[r].sink : 0u) + ")"; }
+                more += "; host outs";
+                for (uint32_t k = 0; k < y.n_out && k < 8; ++k) { const uint32_t r = list_at(S.chunks, y.out, dg::kOutInl, y.out_ext, k) & dg::kRefMask; more += " " + std::to_string(r) + "(count " + std::to_string(S.edges[r].count) + " sink " + std::to_string(S.edges[r].sink) + ")"; }
+                more += "; next node device " + std::to_string(pn[i]) + " host " + std::to_string(i <= b.m ? S.pn[b.path_off + i] : 0u);
+            }
+            std::string msg = nsgpu_last_error();
+            set_error("%s%s", msg.c_str(), more.c_str());
+        }
+        return NSGPU_ERR_RANGE;
+    }
     if (a.n_nodes != b.n_nodes) return bad("n_nodes", a.n_nodes, b.n_nodes);
     if (a.n_edges != b.n_edges) return bad("n_edges", a.n_edges, b.n_edges);
     if (a.n_chunks != b.n_chunks) return bad("n_chunks", a.n_chunks, b.n_chunks);
@@ -673,9 +716,14 @@ int DevGraph::check_against_shadow(const char *where)
     auto list_at = [](const std::vector<dg::Chunk> &ch, const uint32_t *inl, uint32_t n_inl, uint32_t ext, uint32_t i) { if (i < n_inl) return inl[i]; i -= n_inl; uint32_t c = ext; while (i >= dg::kChunkIds) c = ch[c].next, i -= dg::kChunkIds; return ch[c].v[i]; };
     for (uint32_t n = 0; n < a.n_nodes; ++n) {
         const dg::Node &x = nodes[n], &y = S.nodes[n];
-        if (x.n_out != y.n_out || x.n_in != y.n_in || x.base != y.base || x.on_main != y.on_main) return bad("a node's header", n, ((uint64_t)x.n_out << 24) | ((uint64_t)x.n_in << 16) | ((uint64_t)x.on_main << 8) | y.on_main);
+        if (x.n_out != y.n_out || x.n_in != y.n_in || x.base != y.base || x.on_main != y.on_main) { set_error("consensus graph check (%s, read %u): the header of node %u differs: device n_out %u n_in %u base %u on_main %u, host n_out %u n_in %u base %u on_main %u (of %u nodes, %u before this update; splits by routes so far %u / %u, their contexts %u / %u, all contexts %u / %u)", where, (unsigned)p_id_, n, x.n_out, x.n_in, x.base, x.on_main, y.n_out, y.n_in, y.base, y.on_main, a.n_nodes, a.upd_nodes0, a.st_routes, b.st_routes, a.st_route_ctx, b.st_route_ctx, a.st_ctx, b.st_ctx); return NSGPU_ERR_RANGE; }
         for (uint32_t i = 0; i < x.n_out; ++i) if (list_at(chunks, x.out, dg::kOutInl, x.out_ext, i) != list_at(S.chunks, y.out, dg::kOutInl, y.out_ext, i)) return bad("an out reference of node", n, i);
-        for (uint32_t i = 0; i < x.n_in; ++i) if (list_at(chunks, x.in, dg::kInInl, x.in_ext, i) != list_at(S.chunks, y.in, dg::kInInl, y.in_ext, i)) return bad("an in reference of node", n, i);
+        for (uint32_t i = 0; i < x.n_in; ++i) if (list_at(chunks, x.in, dg::kInInl, x.in_ext, i) != list_at(S.chunks, y.in, dg::kInInl, y.in_ext, i)) {
+            std::string da, ho;
+            for (uint32_t q = 0; q < x.n_in; ++q) { da += " " + std::to_string(list_at(chunks, x.in, dg::kInInl, x.in_ext, q)); ho += " " + std::to_string(list_at(S.chunks, y.in, dg::kInInl, y.in_ext, q)); }
+            set_error("consensus graph check (%s, read %u): in reference %u of node %u differs (on_main %u, n_in %u, in_ext %u / %u, n_chunks %u, nodes %u, edges %u): device%s; host%s; splits by routes so far %u / %u, chain runs+routes ctx %u / %u", where, (unsigned)p_id_, i, n, x.on_main, x.n_in, x.in_ext, y.in_ext, a.n_chunks, a.n_nodes, a.n_edges, da.c_str(), ho.c_str(), a.st_routes, b.st_routes, a.st_ctx, b.st_ctx);
+            return NSGPU_ERR_RANGE;
+        }
     }
     for (uint32_t e = 0; e < a.n_edges; ++e) {
         const dg::Edge &x = edges[e], &y = S.edges[e];

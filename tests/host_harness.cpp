@@ -222,6 +222,32 @@ typedef struct { uint64_t n_contigs, n_lone, count_minhash, count_minhash_not_in
 struct ShadowGraph {
     ContigGraph a;
     SoaGraph b;
+    // NSGPU_HARNESS_SOA2_FLAGS: a second structure-of-arrays graph with these debug flags beside the first: whichever way a split is taken (step by
+    // step, stretches by the team, by routes; from which copy on) the nodes, the edges and every list must come out the same, id for id
+    SoaGraph c;
+    bool have_c = false;
+    void compare_soa(const char *where)
+    {
+        namespace dg = nsgpu::dg;
+        using dg::Hdr; using dg::Chunk; using dg::kChunkIds; using dg::kOutInl; using dg::kInInl; using dg::kEdgeInl;
+        nsgpu::cons::SoaStore &X = b.store(), &Y = c.store();
+        const Hdr &hx = X.hdr, &hy = Y.hdr;
+        auto list_at = [](const std::vector<Chunk> &ch, const uint32_t *inl, uint32_t n_inl, uint32_t ext, uint32_t k) { if (k < n_inl) return inl[k]; k -= n_inl; uint32_t cc = ext; while (k >= kChunkIds) cc = ch[cc].next, k -= kChunkIds; return ch[cc].v[k]; };
+        auto say = [&](const char *what, uint64_t i, uint64_t x, uint64_t y) { if (mismatches()++ < 5) fprintf(stderr, "SOA2 MISMATCH after %s (read count %zu): %s %llu: %llu / %llu (nodes %u / %u, edges %u / %u, routes %u / %u)\n", where, a.num_reads(), what, (unsigned long long)i, (unsigned long long)x, (unsigned long long)y, hx.n_nodes, hy.n_nodes, hx.n_edges, hy.n_edges, hx.st_routes, hy.st_routes); };
+        if (hx.n_nodes != hy.n_nodes || hx.n_edges != hy.n_edges || hx.live_nodes != hy.live_nodes || hx.live_edges != hy.live_edges || hx.m != hy.m || hx.n_multi != hy.n_multi) { say("counts", 0, hx.n_nodes, hy.n_nodes); return; }
+        for (uint32_t i = 0; i <= hx.m; ++i) if (X.pn[hx.path_off + i] != Y.pn[hy.path_off + i]) { say("path node", i, X.pn[hx.path_off + i], Y.pn[hy.path_off + i]); return; }
+        for (uint32_t n = 0; n < hx.n_nodes; ++n) {
+            const dg::Node &x = X.nodes[n], &y = Y.nodes[n];
+            if (x.n_out != y.n_out || x.n_in != y.n_in || x.base != y.base || x.on_main != y.on_main) { say("header of node", n, ((uint64_t)x.n_out << 24) | (x.n_in << 16) | (x.base << 8) | x.on_main, ((uint64_t)y.n_out << 24) | (y.n_in << 16) | (y.base << 8) | y.on_main); return; }
+            for (uint32_t k = 0; k < x.n_out; ++k) if (list_at(X.chunks, x.out, kOutInl, x.out_ext, k) != list_at(Y.chunks, y.out, kOutInl, y.out_ext, k)) { say("an out reference of node", n, list_at(X.chunks, x.out, kOutInl, x.out_ext, k), list_at(Y.chunks, y.out, kOutInl, y.out_ext, k)); return; }
+            for (uint32_t k = 0; k < x.n_in; ++k) if (list_at(X.chunks, x.in, kInInl, x.in_ext, k) != list_at(Y.chunks, y.in, kInInl, y.in_ext, k)) { say("an in reference of node", n, list_at(X.chunks, x.in, kInInl, x.in_ext, k), list_at(Y.chunks, y.in, kInInl, y.in_ext, k)); return; }
+        }
+        for (uint32_t e = 0; e < hx.n_edges; ++e) {
+            const dg::Edge &x = X.edges[e], &y = Y.edges[e];
+            if (x.src != y.src || x.sink != y.sink || x.count != y.count) { say("header of edge", e, ((uint64_t)x.src << 32) | x.sink, ((uint64_t)y.src << 32) | y.sink); return; }
+            for (uint32_t k = 0; k < x.count; ++k) if (list_at(X.chunks, x.ids, kEdgeInl, x.head, k) != list_at(Y.chunks, y.ids, kEdgeInl, y.head, k)) { say("a read id of edge", e, list_at(X.chunks, x.ids, kEdgeInl, x.head, k), list_at(Y.chunks, y.ids, kEdgeInl, y.head, k)); return; }
+        }
+    }
     ssize_t start_pos = 0, end_pos = 0;
     std::string main_path;
     read_t first_read = 0;
@@ -240,17 +266,25 @@ struct ShadowGraph {
         main_path = b.main_path, start_pos = b.start_pos, end_pos = b.end_pos;
         path_changed_from = std::min(a.path_changed_from, b.path_changed_from);
     }
-    void initialize(const std::string &seed, read_t id, long pos) { a.main_path.clear(); a.first_read = b.first_read = first_read; a.initialize(seed, id, pos); b.initialize(seed, id, pos); }
+    void initialize(const std::string &seed, read_t id, long pos)
+    {
+        a.main_path.clear(); a.first_read = b.first_read = first_read; a.initialize(seed, id, pos); b.initialize(seed, id, pos);
+        static const char *f2 = getenv("NSGPU_HARNESS_SOA2_FLAGS");
+        have_c = f2 != nullptr;
+        if (have_c) { c.dbg_flags_override = atoi(f2); c.first_read = first_read; c.initialize(seed, id, pos); }
+    }
     void update_graph(const std::string &s, const std::vector<nsgpu::mm2::EditOp> &script, ssize_t bo, ssize_t eo, read_t id, long pos, bool rc)
     {
         a.update_graph(s, script, bo, eo, id, pos, rc);
         b.update_graph(s, script, bo, eo, id, pos, rc);
+        if (have_c) c.update_graph(s, script, bo, eo, id, pos, rc);
     }
     void calculate_main_path_greedy()
     {
         a.path_changed_from = b.path_changed_from = path_changed_from;
         a.calculate_main_path_greedy();
         b.calculate_main_path_greedy();
+        if (have_c) { c.path_changed_from = path_changed_from; c.calculate_main_path_greedy(); compare_soa("calculate_main_path_greedy"); }
         sync_out("calculate_main_path_greedy");
     }
     size_t num_reads() const { return b.num_reads(); }
