@@ -33,6 +33,12 @@ Prints ONE JSON line on rank 0, including
                  (oracle/consensus_oracle.cpp, committed measurements under profiles/): the default schedule is chosen so that
                  the streams stay within 5 % of the reference's -t N (iso-compression); `throughput_schedule` times one step of the
                  1024-builder pipelined schedule, which is faster and is NOT iso-compression (its ratio is stated).
+  config.consensus_graph : where the contigs' consensus graphs lived in the timed steps (--graph: on the host as a pointer graph, or in HBM with
+                 one workgroup per accepted read; by default the library decides by the host threads of the process: in HBM with at most 5)
+                 and the graph kernels' counters (updates, launches, splitPath calls, sequential fall-backs: n_sequential_updates / n_full_walks).
+  consensus_graph_other_placement : ONE first step with the graphs in the other placement (same schedule; the streams must be the same bytes).
+  host_threads_sweep : ONE first step with 4 and with 2 host threads (what a rank of a shared node gets), each in a child process.
+  cfg3         : ONE first step of BASELINE configs[2]'s shape (1.0 Gbase at 217x of a 4.6 Mb genome), the automatic schedule.
 """
 import argparse
 import json

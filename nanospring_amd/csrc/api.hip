@@ -20,6 +20,8 @@ void set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+    static const bool loud = getenv("NSGPU_CONS_DEBUG") != nullptr;      // (an error raised on a worker thread reaches the caller as a code only)
+    if (loud) fprintf(stderr, "[nsgpu] error: %s\n", g_err);
 }
 
 // NSGPU_WAIT_TIMEOUT_S=n: a wait for the GPU that lasts longer than n seconds fails (hipErrorNotReady, with a message saying so)

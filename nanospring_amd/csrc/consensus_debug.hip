@@ -88,9 +88,9 @@ void debug_report_stage(nsgpu_ctx *c, Engine *E, const struct rusage &ru0, doubl
         DevGraphShared &G = *E->D.gsh;
         uint64_t splits = 0, seq = 0;
         for (const Builder &b : E->D.B) splits += b.dbg_g[0], seq += b.dbg_g[1];
-        fprintf(stderr, "[cons] consensus graphs in HBM: %llu updates in %llu launches%s, %llu array growths, %llu new stretches longer than a report (copied), host waited %.0f ms for first and %.0f ms for second reports in sum; "
+        fprintf(stderr, "[cons] consensus graphs in HBM: %llu updates in %llu launches%s (removeCycles run again behind a split that did not fit: %llu), %llu array growths, %llu new stretches longer than a report (copied), host waited %.0f ms for first and %.0f ms for second reports in sum; "
                         "%.2f GB of finished contigs copied back; splitPath calls %llu, excursions taken one at a time %llu; pool: HBM peak %.2f GB of %.2f GB mapped, pinned peak %.2f GB of %.2f GB\n",
-                (unsigned long long)G.n_updates.load(), (unsigned long long)G.n_launches.load(), G.check ? ", every one checked against the host's arrays" : "", (unsigned long long)G.n_grow.load(), (unsigned long long)G.n_mid_copies.load(),
+                (unsigned long long)G.n_updates.load(), (unsigned long long)G.n_launches.load(), G.check ? ", every one checked against the host's arrays" : "", (unsigned long long)G.n_regrow.load(), (unsigned long long)G.n_grow.load(), (unsigned long long)G.n_mid_copies.load(),
                 G.kernel_wait_ns.load() / 1e6, G.final_wait_ns.load() / 1e6, G.bytes_back.load() / 1e9, (unsigned long long)splits, (unsigned long long)seq, G.dev.peak() / 1e9, G.dev.mapped() / 1e9, G.pin.peak() / 1e9, G.pin.mapped() / 1e9);
         fprintf(stderr, "[cons] graph kernels, ms in sum by phase (their own clock): tables %.0f, runs %.0f, excursions %.0f, choices %.0f, stitching %.0f, writing %.0f, flags + kept ends %.0f, removeCycles %.0f; launch to report %.0f ms in sum\n",
                 G.phase_ticks[0].load() / 1e5, G.phase_ticks[1].load() / 1e5, G.phase_ticks[2].load() / 1e5, G.phase_ticks[3].load() / 1e5, G.phase_ticks[4].load() / 1e5, G.phase_ticks[5].load() / 1e5,

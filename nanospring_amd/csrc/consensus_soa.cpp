@@ -45,7 +45,8 @@ size_t SoaStore::bytes() const
 
 void SoaStore::reserve(uint32_t n_nodes, uint32_t n_edges, uint32_t n_chunks, uint32_t path_side, uint32_t wk_words)
 {
-    auto grow = [](size_t have, size_t want) { size_t c = have ? have : 1024; while (c < want) c += c / 2 + 1024; return c; };
+    static const bool exact = getenv("NSGPU_SOA_SLACK") != nullptr;      // (tests of ERR_ROOM: the arrays as large as asked, no more)
+    auto grow = [](size_t have, size_t want) { if (exact) return want > have ? want : have; size_t c = have ? have : 1024; while (c < want) c += c / 2 + 1024; return c; };
     // (tests: new entries full of a pattern instead of zeros -- NSGPU_SOA_POISON = the 32-bit word, a bit set per array in NSGPU_SOA_POISON_ARRAYS:
     // 1 nodes, 2 edges, 4 chunks, 8 mark, 16 pidx, 32 the path arrays, 64 their staging, 128 the multi list, 256 the work area.  The arrays in
     // HBM come out of a pool that does not clear them)
@@ -91,7 +92,8 @@ void SoaStore::reserve(uint32_t n_nodes, uint32_t n_edges, uint32_t n_chunks, ui
 void SoaStore::ensure(const SoaNeed &need)
 {
     // beyond the update's own worst case: room for the private copies a removeCycles behind it may make (a quarter more, at least 64 K entries)
-    const uint32_t slack_n = std::max<uint32_t>(1u << 16, hdr.n_nodes / 4), slack_e = std::max<uint32_t>(1u << 16, hdr.n_edges / 4), slack_c = std::max<uint32_t>(1u << 16, hdr.n_chunks / 4);
+    static const char *sl = getenv("NSGPU_SOA_SLACK");          // tests: next to no spare room (removeCycles' ERR_ROOM on every split of some size)
+    const uint32_t slack_n = sl ? (uint32_t)atoi(sl) : std::max<uint32_t>(1u << 16, hdr.n_nodes / 4), slack_e = sl ? (uint32_t)atoi(sl) : std::max<uint32_t>(1u << 16, hdr.n_edges / 4), slack_c = sl ? (uint32_t)atoi(sl) : std::max<uint32_t>(1u << 16, hdr.n_chunks / 4);
     reserve(hdr.n_nodes + need.nodes + slack_n, hdr.n_edges + need.edges + slack_e, hdr.n_chunks + need.chunks + slack_c, need.path_side, need.wk);
 }
 
@@ -172,14 +174,21 @@ void SoaGraph::calculate_main_path_greedy()
 {
     if (fresh_) { fresh_ = false; return; }          // initialize laid the whole seed out as the path
     dg::HostTeam t;
+    bool have_path = false;
     for (;;) {
         HostOps o(st_.view(), t);
-        o.main_path();
-        if (!st_.hdr.err) o.finish_path();
-        if (st_.hdr.err == dg::ERR_SCRATCH && st_.hdr.stage < 3) {      // the walks' lists did not fit and nothing was changed yet: a larger work area
+        if (!have_path) o.main_path();
+        if (!st_.hdr.err) { have_path = true; o.finish_path(); }
+        if (st_.hdr.err == dg::ERR_SCRATCH && st_.hdr.stage < 3 && !have_path) {      // the walks' lists did not fit and nothing was changed yet: a larger work area
             st_.hdr.err = 0;
             st_.wk.resize(st_.wk.size() * 2);
             st_.hdr.cap_wk = (uint32_t)st_.wk.size();
+            continue;
+        }
+        if (st_.hdr.err == dg::ERR_ROOM) {                    // removeCycles stopped in front of a split that does not fit: room for it, then again
+            st_.hdr.err = 0;
+            SoaNeed need{st_.hdr.need_nodes, st_.hdr.need_edges, st_.hdr.need_chunks, 0, (uint32_t)st_.wk.size()};
+            st_.ensure(need);
             continue;
         }
         break;

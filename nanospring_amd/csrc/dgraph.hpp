@@ -50,6 +50,8 @@ enum : uint32_t {
     ERR_DEGREE = 4u,     // more than 255 edges at one node
     ERR_WALK = 8u,       // a detour of the greedy walk that does not come back behind where it left (a cycle through the path)
     ERR_SCRATCH = 16u,   // the work area is too small
+    ERR_ROOM = 32u,      // removeCycles stopped in front of a split whose copies do not fit (Hdr::need_*): nothing of that split has been done, the
+                         // graph is whole -- the host makes room and runs removeCycles again (the one error that is an answer, not a failure)
 };
 
 // one op of the script: type (0 SAME, 1 INSERT, 2 DELETE) | base << 2 | num << 10
@@ -79,7 +81,7 @@ struct Hdr {
     uint32_t ending_id, starting_id;                  // the smallest read id on the path's last / first edge
     uint32_t st_splits, st_detours, st_walked, st_seq_exc, st_cycles_run, st_full_walk, st_dis;
     uint32_t stage;                                   // of the recompute: 2 = choosing (nothing changed yet), 3 = changing the graph
-    uint32_t dbg_flags;                               // tests: 1 = excursions one at a time, 2 = removeCycles by the reference's full walk, 4 = a longer path always moves its left part, 8 = chain runs of splitPath and probes with a team of one too, 16 = no probes, 32 = no chain runs, 64 = no splits by routes, 128 = every split by routes from its first edge
+    uint32_t dbg_flags;                               // tests: 1 = excursions one at a time, 2 = removeCycles by the reference's full walk, 4 = a longer path always moves its left part, 8 = chain runs of splitPath and probes with a team of one too, 16 = no probes, 32 = no chain runs, 64 = no splits by routes, 128 = a split goes over to routes only after 24 copies (step by step and by stretches before)
     uint32_t err_line;                                // where the first error was raised (dgraph.hpp line)
     uint32_t err_info[4];                             // what it was about (node / index ...)
     uint32_t st_search, st_steps, st_idscan, st_ctx;   // thread 0's loops: rejoin searches (entries looked at), detour steps, read ids compared in splitPath, its contexts
@@ -88,6 +90,7 @@ struct Hdr {
     uint32_t st_cyc[6];                               // removeCycles in parts (thread 0's clock): marking, finding the roots, splitPath: looking for stretches / stretches / the rest, the walks
     uint32_t st_tm[8];                                // ticks of the team's clock by phase: tables, runs, excursions, choices, stitching, writing, flags + P/S, removeCycles
     uint32_t st_routes, st_route_ctx;                 // splits by routes (split_routes_run) and the contexts they made
+    uint32_t need_nodes, need_edges, need_chunks, st_regrow;     // ERR_ROOM: what the split in front of which removeCycles stopped needs; how often that happened
     uint32_t st_rt[4];                                // ... in parts (thread 0's clock): walking the routes, comparing them, the copies, taking the reads off the old edges + the rest
 };
 static_assert(sizeof(Hdr) % 16 == 0, "header is whole 16-byte words");
@@ -1320,8 +1323,10 @@ template <class T> struct Ops {
         remove_cycles();
         if (tid == 0) {
             h.st_tm[7] += team.clock() - tk;
-            h.right_unch = g.pn[h.path_off + h.m], h.right_off = h.m;
-            h.left_unch = g.pn[h.path_off], h.left_off = 0;
+            if (!h.err) {                                    // (ERR_ROOM: the same call again when there is room)
+                h.right_unch = g.pn[h.path_off + h.m], h.right_off = h.m;
+                h.left_unch = g.pn[h.path_off], h.left_off = 0;
+            }
         }
         team.sync();
     }
@@ -1400,9 +1405,9 @@ template <class T> struct Ops {
             bool no_routes = (h.dbg_flags & 64u) != 0;
             while (own_n && !failed()) {
                 // a split that has proven large: what hangs below this edge is taken by the whole team, read by read (split_routes_run)
-                if (!no_routes && n_done >= ((h.dbg_flags & 128u) ? 0u : kRouteAfter) && own_n <= kRouteReads) {
+                if (!no_routes && n_done >= ((h.dbg_flags & 128u) ? 24u : kRouteAfter) && own_n <= kRouteReads) {
                     const uint32_t r0 = team.clock();
-                    K.order[11] = new_pre, K.order[12] = e, K.order[13] = own_off, K.order[14] = own_n, K.order[15] = 0, K.order[16] = 0, K.order[20] = 0, K.order[21] = 0, K.order[22] = 0;
+                    K.order[11] = new_pre, K.order[12] = e, K.order[13] = own_off, K.order[14] = own_n, K.order[15] = 0, K.order[16] = 0, K.order[20] = 0, K.order[21] = 0, K.order[22] = 0, K.order[24] = n_done == 0 && n_ctx == 1 ? 1u : 0u;
                     (void)team.bcast(3);
                     split_routes_run(K);
                     h.st_cyc[3] += team.clock() - r0;
@@ -1558,7 +1563,7 @@ template <class T> struct Ops {
     // what is appended to lists that exist (the first copy to the node in front, the forks of the tree, the edges back into the path) thread 0 does in the
     // walk's order (P7); old nodes left without edges go (P8).  order[]: 11 new_pre, 12 e, 13 own_off, 14 n; out: 16 done (0: a route does not fit,
     // nothing was changed), 17 the contexts.
-    static constexpr uint32_t kRouteReads = 32, kRouteAfter = 24;
+    static constexpr uint32_t kRouteReads = 32, kRouteAfter = 0;       // (from the first edge: the split's size is known before anything is changed)
     struct RouteWk { uint32_t *lc, *bf, *len, *lm, *pi, *lp, *cb, *nb, *kb, *d12, *d27, *ids, *st, *rt; uint32_t cap_rt; };
     DG_HD RouteWk route_wk(const CycWk &K, uint32_t n0) const
     {
@@ -1720,7 +1725,12 @@ template <class T> struct Ops {
                 Kc += 2 * (a - lp) + (b - a);
             }
             ord[17] = C, ord[18] = Nn, ord[19] = Kc;
-            if ((uint64_t)h.n_nodes + Nn > h.cap_nodes || (uint64_t)h.n_edges + C > h.cap_edges || (uint64_t)h.n_chunks + Kc + 2 * n0 + 8 > h.cap_chunks) { fail_at(__LINE__, ERR_CAP); ord[15] = 1; }
+            if ((uint64_t)h.n_nodes + Nn > h.cap_nodes || (uint64_t)h.n_edges + C > h.cap_edges || (uint64_t)h.n_chunks + Kc + 2 * n0 + 8 > h.cap_chunks) {
+                // a split taken by routes from its first edge has changed nothing yet: the caller can make room and come again
+                if (ord[24]) { h.need_nodes = Nn, h.need_edges = C, h.need_chunks = Kc + 2 * n0 + 8; ++h.st_regrow; fail_at(__LINE__, ERR_ROOM); }
+                else fail_at(__LINE__, ERR_CAP);
+                ord[15] = 1;
+            }
         }
         team.sync();
         if (team.peek(&ord[15])) { team.sync(); return; }

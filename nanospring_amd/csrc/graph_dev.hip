@@ -148,7 +148,7 @@ __device__ static void dg_report(const dg::G &g, DevTeam &t, DgResult *res, uint
 // reports into pinned memory.  ONE launch for the graphs of a whole slot: kernels launched one by one from eighty streams queue up behind each
 // other and behind the DP kernels on the runtime's eight hardware queues (measured: 3.3 ms from launch to report for 0.7 ms of kernel).
 // A workgroup that is never told anything leaves after `patience` ticks of the 100 MHz clock (the host always cancels what it does not use).
-__global__ __launch_bounds__(kDgThreads) void dg_serve_kernel(const DgArm *arms, unsigned long long patience)
+__global__ __launch_bounds__(kDgThreads) void dg_serve_kernel(const DgArm *arms, unsigned long long patience, unsigned long long late_start)
 {
     __shared__ uint32_t lds[16];
     __shared__ uint32_t shm[kDgSharedWords];
@@ -156,6 +156,8 @@ __global__ __launch_bounds__(kDgThreads) void dg_serve_kernel(const DgArm *arms,
     DgSlot *s = arms[blockIdx.x].slot;
     const uint32_t ticket = arms[blockIdx.x].ticket;
     if (threadIdx.x == 0) {
+        // (tests, NSGPU_GRAPH_LATE_START_US: the workgroups come to life this late -- what a launch queued behind other kernels looks like)
+        if (late_start) { const unsigned long long w0 = wall_clock64(); while (wall_clock64() - w0 < late_start) __builtin_amdgcn_s_sleep(64); }
         const unsigned long long t0 = wall_clock64();
         uint32_t cmd;
         for (;;) {
@@ -192,6 +194,28 @@ __global__ __launch_bounds__(kDgThreads) void dg_serve_kernel(const DgArm *arms,
     if (!o.failed()) o.main_path();
     __syncthreads();
     dg_report(g, t, L.res, L.epoch, false);           // the consensus is final: the builder goes on
+    if (!o.failed()) o.finish_path();
+    __syncthreads();
+    dg_report(g, t, L.res, L.epoch, true);
+}
+
+// removeCycles again for an update whose workgroup stopped in front of a split that did not fit (ERR_ROOM): the host has made room (the slot record
+// holds the arrays' new places and sizes; it is the update's own otherwise)
+__global__ __launch_bounds__(kDgThreads) void dg_finish_kernel(const DgSlot *s)
+{
+    __shared__ uint32_t lds[16];
+    __shared__ uint32_t shm[kDgSharedWords];
+    __shared__ uint32_t slot_w[sizeof(DgSlot) / 4];
+    for (uint32_t i = threadIdx.x; i < sizeof(DgSlot) / 4; i += blockDim.x) slot_w[i] = reinterpret_cast<const volatile uint32_t *>(s)[i];
+    __syncthreads();
+    const DgSlot &L = *reinterpret_cast<const DgSlot *>(slot_w);
+    const dg::G g = L.g;
+    uint32_t *lp = lds, *sp = shm;
+    asm volatile("" : "+s"(lp), "+s"(sp));
+    DevTeam t{lp, sp};
+    if (threadIdx.x == 0) { dg_apply_setup(g, L.setup); if (g.h->err == dg::ERR_ROOM) g.h->err = 0; }
+    __syncthreads();
+    dg::Ops<DevTeam> o(g, t);
     if (!o.failed()) o.finish_path();
     __syncthreads();
     dg_report(g, t, L.res, L.epoch, true);
@@ -324,12 +348,16 @@ dg::G DevGraph::view() const
 
 // room for the next update (worst case of its script + what a removeCycles behind it may copy); arrays that grow are copied on the
 // serve stream, in front of the kernel that will use them, and the old ones go back to the pool when that update has reported
-int DevGraph::grow(const cons::SoaNeed &need, uint32_t seed_len)
+int DevGraph::grow(const cons::SoaNeed &need, uint32_t seed_len, hipStream_t st)
 {
-    hipStream_t st = sh_->serve_stream;
-    auto bigger = [](size_t have, size_t want) { size_t c = have ? have : 4096; while (c < want) c += c / 2 + 4096; return c; };
+    if (!st) st = sh_->serve_stream;
+    std::function<size_t(size_t, size_t)> bigger = [](size_t have, size_t want) { size_t c = have ? have : 4096; while (c < want) c += c / 2 + 4096; return c; };
     const uint32_t n_nodes = inited_ ? hdr_.n_nodes : seed_len, n_edges = inited_ ? hdr_.n_edges : seed_len, n_chunks = inited_ ? hdr_.n_chunks : 0;
-    const uint32_t slack_n = std::max<uint32_t>(1u << 15, n_nodes / 4), slack_e = std::max<uint32_t>(1u << 15, n_edges / 4), slack_c = std::max<uint32_t>(1u << 15, n_chunks / 4);
+    // (spare room for the private copies a removeCycles behind the update may make; when a split needs more the kernel says so and is run again: ERR_ROOM.
+    // NSGPU_GRAPH_SLACK, tests: next to none, arrays as large as asked)
+    static const char *sl = getenv("NSGPU_GRAPH_SLACK");
+    const uint32_t slack_n = sl ? (uint32_t)atoi(sl) : std::max<uint32_t>(1u << 15, n_nodes / 4), slack_e = sl ? (uint32_t)atoi(sl) : std::max<uint32_t>(1u << 15, n_edges / 4), slack_c = sl ? (uint32_t)atoi(sl) : std::max<uint32_t>(1u << 15, n_chunks / 4);
+    if (sl) bigger = [](size_t have, size_t want) { return want > have ? want : have; };
     bool grew = false;
     if (!b_hdr_.p) { NS_TRY(take(b_hdr_, sizeof(dg::Hdr))); cap_multi_ = 16384; NS_TRY(take(b_multi_, (size_t)cap_multi_ * 4)); }
     const uint64_t want_n = (uint64_t)n_nodes + need.nodes + slack_n, want_e = (uint64_t)n_edges + need.edges + slack_e, want_c = (uint64_t)n_chunks + need.chunks + slack_c;
@@ -450,7 +478,8 @@ int graph_serve_launch(DevGraphShared *sh, DevGraph *const *graphs, size_t n)
     __atomic_thread_fence(__ATOMIC_RELEASE);
     static const unsigned long long patience = [] { const char *e = getenv("NSGPU_WAIT_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return (unsigned long long)((v > 0 ? v : 120.0) * 1e8); }();
     static const int n_thr = [] { const char *e = getenv("NSGPU_GRAPH_THREADS"); const int v = e ? atoi(e) : 0; return v == 512 || v == 256 || v == 128 ? v : 512; }();
-    hipLaunchKernelGGL(dg_serve_kernel, dim3((uint32_t)n), dim3(n_thr), 0, sh->serve_stream, ptrs, patience);
+    static const unsigned long long late = [] { const char *e = getenv("NSGPU_GRAPH_LATE_START_US"); return e ? (unsigned long long)(atof(e) * 100.0) : 0ull; }();
+    hipLaunchKernelGGL(dg_serve_kernel, dim3((uint32_t)n), dim3(n_thr), 0, sh->serve_stream, ptrs, patience, late);
     NS_HIP(hipGetLastError());
     NS_HIP(hipEventRecord(L.done, sh->serve_stream));
     sh->launches.push_back(L);
@@ -610,6 +639,30 @@ int DevGraph::finalize(bool wait)
             if (now_ms_() - w0 > give_up_ms) { set_error("consensus graph: an update's second report has not come after %.0f s", give_up_ms / 1e3); return fail_rc_ = NSGPU_ERR_HIP; }
         }
         sh_->final_wait_ns += (uint64_t)((now_ms_() - w0) * 1e6);
+    }
+    if (res->hdr2.err == dg::ERR_ROOM) {
+        // removeCycles stopped in front of a split whose copies do not fit (nothing of it done, the graph whole): room for it, and the same call again
+        // in a launch of its own behind the array copies.
+        // (On the stream of the copies back, not the serve stream: a slot's launch may be waiting there for its orders, and whoever waits for this
+        // graph -- a contig that has just ended -- must not wait for that slot's end.)
+        hdr_ = res->hdr2;
+        hdr_.err = 0;
+        cons::SoaNeed need{hdr_.need_nodes, hdr_.need_edges, hdr_.need_chunks, 0u, cap_wk_};
+        { const int rc = grow(need, 0, sh_->copy_stream); if (rc != NSGPU_OK) return fail_rc_ = rc; }
+        DgSlot *slot = static_cast<DgSlot *>(pin_.p);
+        slot->g = view();
+        slot->setup = DgSetup{cap_nodes_, cap_edges_, cap_chunks_, cap_path_, cap_wk_, cap_multi_, moved_path_ ? path_off_ : dg::NIL, sh_->dbg_flags};
+        DgResult *rw = reinterpret_cast<DgResult *>(slot + 1);
+        rw->status2 = 0;
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        static const int n_thr = [] { const char *e = getenv("NSGPU_GRAPH_THREADS"); const int v = e ? atoi(e) : 0; return v == 512 || v == 256 || v == 128 ? v : 512; }();
+        {
+            std::lock_guard<std::mutex> lk(sh_->serve_m);
+            hipLaunchKernelGGL(dg_finish_kernel, dim3(1), dim3(n_thr), 0, sh_->copy_stream, static_cast<const DgSlot *>(slot));
+            NS_HIP(hipGetLastError());
+        }
+        sh_->n_regrow += 1;
+        return finalize(wait);
     }
     const uint32_t edges1 = hdr_.live_edges;
     hdr_ = res->hdr2;

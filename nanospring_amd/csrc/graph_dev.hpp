@@ -95,7 +95,7 @@ struct DevGraphShared {
     bool check = false;                               // NSGPU_GRAPH_CHECK: every update also on the host, arrays compared
     uint32_t dbg_flags = 0;
     std::atomic<uint64_t> n_updates{0}, n_grow{0}, n_mid_copies{0}, kernel_wait_ns{0}, bytes_back{0}, update_ns{0}, final_wait_ns{0};
-    std::atomic<uint64_t> n_seq_updates{0}, n_full_walks{0}, n_splits{0};
+    std::atomic<uint64_t> n_seq_updates{0}, n_full_walks{0}, n_splits{0}, n_regrow{0};
     uint64_t edge_thr = ~0ull;                        // --edge-thr: num_edges() must be exact near it
     std::atomic<uint64_t> phase_ticks[8], hist[8], slow_phase[8], cnt[6], cyc[6], rt[4];             // the kernels' own clock (100 MHz) by phase, summed (debug report)
     ~DevGraphShared();
@@ -158,7 +158,7 @@ private:
     std::unique_ptr<cons::SoaGraph> shadow_;
     std::unique_ptr<cons::ContigGraph> ptr_shadow_;
     dg::G view() const;
-    int grow(const cons::SoaNeed &need, uint32_t seed_len);
+    int grow(const cons::SoaNeed &need, uint32_t seed_len, hipStream_t st = nullptr);
     int take(Block &b, size_t bytes, bool pinned = false);
     void give(Block &b, bool pinned = false);
     void retire(Block &b) { if (b.p) retired_.push_back(b); b = Block(); }

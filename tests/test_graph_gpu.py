@@ -40,6 +40,26 @@ def test_many_builders_in_hbm_equal_lockstep_oracle_every_update_checked(device_
     T.many_builders_equal_lockstep_oracle(bases, off, B, groups, depth, rings)
 
 
+def test_workgroups_that_start_late_take_no_other_update(monkeypatch):
+    """A launch whose workgroups come to life when the slot is over (NSGPU_GRAPH_LATE_START_US: its kernel queued behind others, as beside a
+    second process on the GPU) finds the slot records re-armed for the NEXT update: the order word carries the ticket of the prepare() it
+    belongs to, and a workgroup takes nothing else (without that: the same script applied twice -- reads that do not round-trip)."""
+    monkeypatch.setenv("NSGPU_GRAPH", "device")
+    monkeypatch.setenv("NSGPU_GRAPH_LATE_START_US", "2500")
+    bases, off = ns.synth_reads(31, 150000, 600, 4000.0)
+    T.many_builders_equal_lockstep_oracle(bases, off, 40, 1, 0, 1)
+
+
+def test_remove_cycles_that_runs_out_of_room_is_run_again(device_graphs_checked, monkeypatch):
+    """next to no spare room in the arrays (NSGPU_GRAPH_SLACK): removeCycles stops in front of every split whose copies do not fit -- nothing of it
+    done, the graph whole --, the host grows the arrays and runs it again (dg_finish_kernel); every update checked against the host's arrays"""
+    monkeypatch.setenv("NSGPU_GRAPH_SLACK", "48")
+    bases, off = _repeats_reads()
+    T.many_builders_equal_lockstep_oracle(bases, off, 20, 1, 2, 1)
+    bases, off = ns.synth_reads(7, 200000, 500, 8000.0)
+    T.one_builder_equals_oracle(bases, off)
+
+
 def _repeats_reads():
     from tests.align_cases import make_genome, mutate, revcomp
     rng = np.random.RandomState(12)
