@@ -663,17 +663,19 @@ def test_cfg2_full_default_schedule_equals_lockstep_oracle_hashes(fixture):
     g.close()
 
 
-def test_cfg4_per_gpu_share_on_one_gpu_lossless_deterministic_bounded_memory():
+@pytest.mark.parametrize("graphs", ["host", "device"])
+def test_cfg4_per_gpu_share_on_one_gpu_lossless_deterministic_bounded_memory(graphs):
     """BASELINE configs[3] (5 M reads of mean 10 kb over 8 GPUs) needs a node this round never had; its per-GPU share -- 625 000 reads, 6.25 Gbases:
     beyond 2^32 bases, so every offset on the path is exercised past 32 bits -- runs here on ONE GPU in the schedule the library derives itself
     (nsgpu_consensus_run with 0 builders: 625 builders, one group, buckets of depth 3, 5 rings, 3 in the tail): every read decodes, the streams
     are the ones recorded when the test was written (profiles/r05_cfg4_share_one_gpu.txt: two runs on another box gave this hash twice), and the
     process stays under 70 GB of host memory -- 10.2 B/base measured, 40 GB of it the graph slabs of 625 contigs in flight (the reference:
-    18-25 GB for 84-133 Gbases with 20 threads; 4 B/base is not met)."""
+    18-25 GB for 84-133 Gbases with 20 threads; 4 B/base is not met).  With the consensus graphs in HBM (round 6) the same streams and under
+    35 GB: 22.9 GB = 3.9 B/base measured, 101 GB of HBM at the peak (profiles/r06_cfg4_share_hbm_graphs.txt)."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     want = json.loads([l for l in open(os.path.join(root, "profiles", "r05_cfg4_share_one_gpu.txt")) if l.startswith("RUN 0")][0].split(" ", 2)[2])
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "cfg4_share.py"), "1"], capture_output=True, text=True, timeout=1700)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "cfg4_share.py"), "1"], capture_output=True, text=True, timeout=1700, env=dict(os.environ, NSGPU_GRAPH=graphs))
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
     inp = [l.split() for l in r.stdout.splitlines() if l.startswith("INPUT")][0]
     assert int(inp[1]) == 625000 and int(inp[2]) > (1 << 32)
@@ -682,5 +684,5 @@ def test_cfg4_per_gpu_share_on_one_gpu_lossless_deterministic_bounded_memory():
     assert got["schedule"] == [1, 3, 5, 3, 625]
     for f in ("contigs", "lone", "aligned", "slots", "sha256"):
         assert got[f] == want[f], (f, got[f], want[f])
-    assert got["peak_rss_gb"] < 70.0, got["peak_rss_gb"]
-    print("cfg4's per-GPU share on one GPU: %.1f s, %.1f Mbases/s, %.1f GB of host memory" % (got["s"], got["mbases_per_s"], got["peak_rss_gb"]))
+    assert got["peak_rss_gb"] < (70.0 if graphs == "host" else 35.0), got["peak_rss_gb"]
+    print("cfg4's per-GPU share on one GPU, consensus graphs on the %s: %.1f s, %.1f Mbases/s, %.1f GB of host memory" % (graphs, got["s"], got["mbases_per_s"], got["peak_rss_gb"]))
