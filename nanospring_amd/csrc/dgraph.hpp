@@ -90,6 +90,7 @@ struct Hdr {
     uint32_t st_cyc[6];                               // removeCycles in parts (thread 0's clock): marking, finding the roots, splitPath: looking for stretches / stretches / the rest, the walks
     uint32_t st_tm[8];                                // ticks of the team's clock by phase: tables, runs, excursions, choices, stitching, writing, flags + P/S, removeCycles
     uint32_t st_routes, st_route_ctx;                 // splits by routes (split_routes_run) and the contexts they made
+    uint32_t unreach_n, unreach_list_n, pad_[2];      // n_multi and multi_n as removeCycles left them when it found that NO side node with several ways in can be reached from the path (NIL: not known)
     uint32_t need_nodes, need_edges, need_chunks, st_regrow;     // ERR_ROOM: what the split in front of which removeCycles stopped needs; how often that happened
     uint32_t st_rt[4];                                // ... in parts (thread 0's clock): walking the routes, comparing them, the copies, taking the reads off the old edges + the rest
 };
@@ -588,7 +589,10 @@ template <class T> struct Ops {
         if (failed()) return;
         lap(1);
         // ---- pass C: the excursions ----
-        const bool parallel_exc = h.n_multi == 0 && !(h.dbg_flags & 1u);      // every side node then has one way in: no two excursions can meet
+        // every side node an excursion can come to has one way in then: no two excursions can meet.  (Side nodes with several ways in that cannot be
+        // reached from the path -- the heads of reads that start left of a contig whose front has moved on -- are out of every excursion's way: an
+        // excursion starts at a path node and follows edges, or creates what it needs.  removeCycles has said so if nothing has changed since.)
+        const bool parallel_exc = (h.n_multi == 0 || (h.n_multi == h.unreach_n && h.multi_n == h.unreach_list_n)) && !(h.dbg_flags & 1u);
         const uint32_t nodes_base = h.n_nodes, edges_base = h.n_edges;
         if (parallel_exc) {
             uint32_t tot_n = 0, tot_e = 0;
@@ -1898,13 +1902,14 @@ template <class T> struct Ops {
     {
         Hdr &h = *g.h;
         const uint32_t tid = team.tid(), nt = team.size();
-        if (h.n_multi == 0) { if (tid == 0) h.multi_n = 0; team.sync(); return; }
+        if (h.n_multi == 0) { if (tid == 0) h.multi_n = 0, h.unreach_n = NIL; team.sync(); return; }
         const CycWk K = cyc_wk();
         uint32_t mode = 0, n_roots = 0;                        // 0 nothing to do, 1 from the list, 2 the full walk
         const uint32_t c0 = team.clock();
         if (tid == 0) {
             ++h.st_cycles_run;
             ++h.epoch;
+            h.unreach_n = NIL;
             mode = 1;
             if (h.epoch == 0 || h.multi_n > h.cap_multi || (h.dbg_flags & 2u)) { mode = 2; if (h.epoch == 0) h.epoch = 1; }
             if (mode == 1) {
@@ -1937,7 +1942,7 @@ template <class T> struct Ops {
                         else { if (n_todo < K.cap_todo) K.todo[n_todo++] = s; else mode = 2; }
                     }
                 }
-                if (mode == 1 && n_roots == 0) mode = 0;        // not reachable from the path: the full walk would find nothing either
+                if (mode == 1 && n_roots == 0) { mode = 0; h.unreach_n = h.n_multi, h.unreach_list_n = h.multi_n; }        // not reachable from the path: the full walk would find nothing either (and no excursion of the next read can meet one of them: update())
             }
             if (mode == 2) ++h.st_full_walk;
             h.st_cyc[0] += team.clock() - c0;
