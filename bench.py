@@ -534,8 +534,8 @@ def main():
                        "stage_ms_per_step": {"sketch": round(sk_ms / steps, 2), "tables": round(idx_ms / steps, 2),
                                              "contig_stage_total": round(st["total_ms"], 1), "window_queries": round(st["filter_ms"], 1),
                                              "consensus_index": round(st["index_ms"], 1), "align_total": round(st["align_ms"], 1),
-                                             "align_dp_kernel_wall": round(a["dp_kernel_ms"] / steps, 1), "align_dp_kernel_sum": round(a["dp_kernel_sum_ms"] / steps, 1), "graph_host_wall": round(st["graph_ms"], 1),
-                                             "note": "with four groups the contig-stage parts overlap (host phase | batches part 1 | DP in flight | batches part 2) and do not add up to the total; with one group they run one after the other"},
+                                             "align_dp_kernel_wall": round(a["dp_kernel_ms"] / steps, 1), "align_dp_kernel_sum": round(a["dp_kernel_sum_ms"] / steps, 1), "graph_host_wall": round(st["graph_ms"], 1), "builder_steps_host_cpu": round(st["graph_cpu_ms"], 1),
+                                             "note": "graph_host_wall = wall of the phases in which the host applies alignments (it waits for the DP results there); builder_steps_host_cpu = CPU time of the builders' own steps in sum over the host threads, last step (the pointer graph's updates are in it; with the graphs in HBM what is left is the hand-over). With four groups the contig-stage parts overlap (host phase | batches part 1 | DP in flight | batches part 2) and do not add up to the total; with one group they run one after the other"},
                        "parallelism": (f"x{world}: reads sharded by id, replicated by all-gather at load; per step "
                                        + ("RCCL all-to-all of (slot, key, id) tuples to the bucket-table owners (table j on rank j % world) + all-gather of the sorted tables"
                                           if args.dist_mode == "alltoall" else "all-gather of sketch rows") +
