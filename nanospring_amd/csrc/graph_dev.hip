@@ -247,6 +247,14 @@ void *SlabPool::alloc(size_t bytes, size_t *granted)
     // a free block of this very size (the sizes are few: quarter-octave classes)
     for (size_t i = 0; i < free_sz_.size(); ++i)
         if (free_sz_[i].first == g && !free_sz_[i].second.empty()) { void *p = free_sz_[i].second.back(); free_sz_[i].second.pop_back(); in_use_ += g; if (in_use_ > peak_) peak_ = in_use_; return p; }
+    // no block of this size: the smallest free one of a larger class up to twice the size rather than new memory (graphs outgrow their blocks at
+    // different times: the sizes the pool holds free are rarely the very size asked for; the block keeps its own size when it comes back)
+    {
+        size_t best = 0, bi = 0;
+        for (size_t i = 0; i < free_sz_.size(); ++i)
+            if (free_sz_[i].first > g && free_sz_[i].first <= 2 * g && !free_sz_[i].second.empty() && (!best || free_sz_[i].first < best)) best = free_sz_[i].first, bi = i;
+        if (best) { void *p = free_sz_[bi].second.back(); free_sz_[bi].second.pop_back(); *granted = best; in_use_ += best; if (in_use_ > peak_) peak_ = in_use_; return p; }
+    }
     const size_t ga = (g + 255) & ~(size_t)255;
     for (auto &t : tails_)
         if (t.second >= ga) { void *p = t.first; t.first += ga, t.second -= ga; in_use_ += g; if (in_use_ > peak_) peak_ = in_use_; return p; }

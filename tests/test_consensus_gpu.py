@@ -675,6 +675,18 @@ def test_cfg4_per_gpu_share_on_one_gpu_lossless_deterministic_bounded_memory(gra
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     want = json.loads([l for l in open(os.path.join(root, "profiles", "r05_cfg4_share_one_gpu.txt")) if l.startswith("RUN 0")][0].split(" ", 2)[2])
+    import gc, ctypes
+    gc.collect()
+    if graphs == "device":                                       # the child's pool maps 190 GB of HBM at its peak (105 GB in use: blocks the growing graphs
+        free_gb = 0.0                                            # have left behind are kept for the next that needs that size)
+        for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
+            try:
+                fr, tot = ctypes.c_size_t(0), ctypes.c_size_t(0)
+                if ctypes.CDLL(name).hipMemGetInfo(ctypes.byref(fr), ctypes.byref(tot)) == 0: free_gb = fr.value / 1e9
+                break
+            except OSError:
+                continue
+        if 0 < free_gb < 225.0: pytest.skip("%.0f GB of HBM free in front of the child (this process holds the rest): the run needs 225" % free_gb)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "cfg4_share.py"), "1"], capture_output=True, text=True, timeout=1700, env=dict(os.environ, NSGPU_GRAPH=graphs))
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
     inp = [l.split() for l in r.stdout.splitlines() if l.startswith("INPUT")][0]
