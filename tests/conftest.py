@@ -20,6 +20,12 @@ def pytest_configure(config):
         config.option.timeout_method = "thread"
 
 
+def pytest_collection_modifyitems(config, items):
+    # the run that needs most of the GPU's memory (cfg4's per-GPU share with the consensus graphs in HBM: 190 GB mapped at its peak) goes first,
+    # while nothing else of the session holds HBM
+    items.sort(key=lambda it: 0 if "cfg4_per_gpu_share" in it.nodeid and "[device]" in it.nodeid else 1)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from tests import oracle_lib
