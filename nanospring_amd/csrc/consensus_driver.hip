@@ -45,6 +45,7 @@ static int graph_shared_get(nsgpu_ctx *c, DevGraphShared **out)
     sh->check = check;
     { const char *e = getenv("NSGPU_SOA_DEBUG_FLAGS"); sh->dbg_flags = e ? (uint32_t)atoi(e) : 0; }
     sh->n_updates = 0, sh->n_launches = 0, sh->n_grow = 0, sh->n_mid_copies = 0, sh->kernel_wait_ns = 0, sh->bytes_back = 0, sh->update_ns = 0, sh->final_wait_ns = 0, sh->n_seq_updates = 0, sh->n_full_walks = 0, sh->n_splits = 0, sh->n_regrow = 0;
+    sh->aborted = false;
     sh->edge_thr = c->prm.edge_threshold;
     for (auto &t : sh->phase_ticks) t = 0;
     for (auto &t : sh->hist) t = 0;

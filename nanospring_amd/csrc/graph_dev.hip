@@ -582,7 +582,10 @@ int DevGraph::complete()
         int spins = 0;
         while (!ready()) {
             if (++spins > 200) { timespec ts = {0, 5000}; nanosleep(&ts, nullptr); }
+            // (one wait that has run out ends the others too: the stage is lost, and a slot's worth of updates must not sit out the limit one after the other)
+            if (sh_->aborted.load()) { set_error("consensus graph: given up (another update of this stage was not reported in time)"); return NSGPU_ERR_HIP; }
             if (now_ms_() - w0 > give_up_ms) {
+                sh_->aborted.store(true);
                 const hipError_t e = hipStreamQuery(sh_->serve_stream);
                 set_error("consensus graph: an update has not been reported after %.0f s (stream: %s)", give_up_ms / 1e3, hipGetErrorString(e));
                 return NSGPU_ERR_HIP;
@@ -644,7 +647,8 @@ int DevGraph::finalize(bool wait)
         int spins = 0;
         while (!there()) {
             if (++spins > 200) { timespec ts = {0, 5000}; nanosleep(&ts, nullptr); }
-            if (now_ms_() - w0 > give_up_ms) { set_error("consensus graph: an update's second report has not come after %.0f s", give_up_ms / 1e3); return fail_rc_ = NSGPU_ERR_HIP; }
+            if (sh_->aborted.load()) { set_error("consensus graph: given up (another update of this stage was not reported in time)"); return fail_rc_ = NSGPU_ERR_HIP; }
+            if (now_ms_() - w0 > give_up_ms) { sh_->aborted.store(true); set_error("consensus graph: an update's second report has not come after %.0f s", give_up_ms / 1e3); return fail_rc_ = NSGPU_ERR_HIP; }
         }
         sh_->final_wait_ns += (uint64_t)((now_ms_() - w0) * 1e6);
     }

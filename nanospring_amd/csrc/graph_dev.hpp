@@ -90,6 +90,7 @@ struct DevGraphShared {
     std::vector<Launch> launches;                     // serve launches whose kernel may still be running (their slot lists stay until it is gone)
     std::vector<hipEvent_t> free_events;
     std::atomic<uint64_t> n_launches{0};
+    std::atomic<bool> aborted{false};                 // a wait for a report has run out: nobody waits any longer
     std::atomic<uint32_t> next_ticket{1};             // of prepare(): what binds a workgroup to the order it was launched for
     uint32_t max_ops = 0;                             // longest script the staging buffers take: 2 * longest read + slack
     bool check = false;                               // NSGPU_GRAPH_CHECK: every update also on the host, arrays compared
