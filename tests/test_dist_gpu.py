@@ -17,6 +17,11 @@ from tests.stream_decode import decode
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# Several ranks on ONE GPU (these tests; a deployment has one process per GPU): with the package's eight hardware queues per process the ranks' queues
+# outnumber what the GPU runs at once and take turns -- a rank's DP kernels can then sit unscheduled while its graph workgroups wait for the orders
+# those kernels' results lead to.  Two queues per process keep every queue on the GPU.
+SHARED_GPU = {"GPU_MAX_HW_QUEUES": "2"}
+
 N_READS, N_BUILDERS = 500, 24
 
 
@@ -42,7 +47,7 @@ def test_result_is_independent_of_rank_count(world, driver):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "o.pkl")
         port = str(29600 + world + 10 * ["py", "replicate", "alltoall"].index(driver))
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, NSGPU_THREADS="4")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, NSGPU_THREADS="4", **SHARED_GPU)
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                             "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(N_READS),
                             str(N_BUILDERS), out, driver], env=env, capture_output=True, text=True, timeout=1200)
@@ -164,7 +169,7 @@ def test_bench_two_ranks_on_one_gpu_default_schedule(mode):
     auto_count = mode.endswith("-auto")             # no --builders either: the count is the library's too (1 per 10 Mbases of the whole job, at least 32)
     mode = mode.split("-")[0]
     port = "29673" if auto_count else "29671" if mode == "alltoall" else "29672"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, NSGPU_BENCH_BACKEND="gloo", NSGPU_THREADS="4")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, NSGPU_BENCH_BACKEND="gloo", NSGPU_THREADS="4", **SHARED_GPU)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--reads", str(R), "--mean-len", str(L)] + ([] if auto_count else ["--builders", str(B)]) +
                        ["--cpu-sample", "0", "--dist-mode", mode], env=env, capture_output=True, text=True, timeout=1200)
@@ -203,7 +208,7 @@ def test_bench_four_ranks_on_one_gpu_two_host_threads_each_graphs_in_hbm():
     import json
     R, B, L = 400, 8, 3000.0
     port = "29677"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, NSGPU_BENCH_BACKEND="gloo", NSGPU_THREADS="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, NSGPU_BENCH_BACKEND="gloo", NSGPU_THREADS="2", **SHARED_GPU)
     env.pop("NSGPU_GRAPH", None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port", port,
                         os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0", "--reads", str(R), "--mean-len", str(L), "--builders", str(B),
