@@ -1,7 +1,7 @@
 // dgraph.hpp -- the consensus DAG (ConsensusGraph, src/ConsensusGraph.cpp:135-159 initialize, :400-557 updateGraph,
 // :559-615 calculateMainPathGreedy, :617-651 clearMainPath, :653-714 removeCycles / walkAndPrune, :716-807 splitPath, :809-897 the
 // node / edge bookkeeping; tie rules :33-91) as a structure of arrays with 32-bit ids, written ONCE for the host and for gfx950:
-// one workgroup of 256 threads per contig builder runs these functions on the graph where it lies in HBM (dgraph_dev.hip); the
+// one workgroup of 512 threads per accepted read runs these functions on the graph where it lies in HBM (graph_dev.hip); the
 // CPU test harness and the emission of a finished contig (consensus_soa.cpp) run the very same code with a team of one.
 //
 // Layout (all indices 32 bit, position independent: a graph moves between HBM and host memory by plain copies)
@@ -12,14 +12,16 @@
 //              The reference keeps the ids ordered (a sorted vector); nothing observable depends on the order (membership, the
 //              smallest id, intersections, differences), so they are kept in arrival order.
 //   path     : pe[] edge ids, pn[] node ids (m + 1), ps[] bases (m + 1), a deque inside arrays of cap_path entries (path_off).
-// Ids are handed out in a fixed order (prefix sums, never atomics), so a team of 256 and a team of one build byte-identical arrays:
+// Ids are handed out in a fixed order (prefix sums, never atomics), so a team of 512 and a team of one build byte-identical arrays:
 // the GPU tests compare the device arrays with the host run's after every update.
 //
 // What is parallel on the device: the appends of a read along the runs of the main path it follows (lanes over edges), the side
 // excursions of a read (lanes over excursions: each leaves the path at a node of its own and comes back at another), the creation
 // of new nodes and edges (lanes over nodes), the greedy choice at every node of the stretch the reference walks again (lanes over
 // nodes; only where the choice differs from the path the walk is followed step by step), the copies of path stretches, the
-// comparison of the old and the new consensus.  Sequential (thread 0): the stitching of detours, removeCycles / splitPath.
+// comparison of the old and the new consensus, the private copies of splitPath (by the reads' routes: split_routes_run; stretches of nodes
+// with one way out: split_chain_run), the probes along chains with consecutive ids.  Sequential (thread 0): the stitching of detours, the
+// walks of removeCycles, splits with more than 32 reads on their first edge.
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
