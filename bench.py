@@ -140,6 +140,29 @@ def cpu_baseline(n_reads, mean_len, k, n, thr, salts, t1_reads=1500):
                              f"reference re-indexes the whole consensus per candidate): 1.10 Mbases/s on the full cfg2 input (profiles/r01_parity_full.txt)"}}
 
 
+def threads_sweep(args):
+    """ONE first step with 4 and with 2 host threads (what a rank gets of a CPU quota it shares with the other ranks of its node), each in a child
+    process (the thread count is read once per process): this very script without its other legs.  Run BEFORE this process touches the GPU: a
+    child beside a process that holds the GPU shares the hardware queues with it and measures that, not the thread count."""
+    import subprocess
+    ts = {"note": "one first step per thread count, each in a child process (NSGPU_THREADS) before this process initialised the GPU, consensus graphs where the library puts them by itself (in HBM with at most 5 host threads); the timed steps above ran with host_threads = %d.  The pointer graph on the host with 2 threads: profiles/r06_graph_placement_by_threads.txt", "runs": []}
+    for nthr in (4, 2):
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--throughput-leg", "0", "--cpu-sample", "0", "--cpu-full", "0", "--legal-leg", "0",
+               "--nonideal-leg", "0", "--threads-sweep", "0", "--graph-leg", "0", "--cfg3-leg", "0", "--reads", str(args.reads), "--mean-len", str(args.mean_len), "--depth", str(args.depth), "--genome", args.genome]
+        try:
+            rr = subprocess.run(cmd, env=dict(os.environ, NSGPU_THREADS=str(nthr)), capture_output=True, text=True, timeout=600)
+            lines = [ln for ln in rr.stdout.splitlines() if ln.startswith("{")]
+            if not lines: raise RuntimeError("the child printed no result (exit code %d): %s" % (rr.returncode, rr.stderr[-600:]))
+            cj = json.loads(lines[-1])
+            ts["runs"].append({"host_threads": nthr, "value": cj["value"], "unit": "Mbases/s", "ms_per_step": cj["ms_per_step"], "consensus_graphs": cj["config"]["consensus_graph"]["placement"],
+                               "graph_host_wall_ms": cj["config"]["stage_ms_per_step"]["graph_host_wall"], "builder_steps_host_cpu_ms": cj["config"]["stage_ms_per_step"].get("builder_steps_host_cpu"),
+                               "lossless_roundtrip_bad_reads": cj["config"]["lossless_roundtrip_bad_reads"], "streams_identical_to_the_fixture": (cj.get("parity") or {}).get("all_identical")})
+            if cj["config"]["lossless_roundtrip_bad_reads"] or (cj.get("parity") or {}).get("all_identical") is False: ts["runs"][-1]["stderr_tail"] = rr.stderr[-3000:]
+        except Exception as ex:                 # (a leg, not the measurement: report and go on)
+            ts["runs"].append({"host_threads": nthr, "error": str(ex)[:900]})
+    return ts
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,6 +190,11 @@ def main():
     ap.add_argument("--dist-mode", choices=["alltoall", "replicate"], default="alltoall",
                     help="multi-GPU bucket tables: owners of an RCCL all-to-all of (slot, key, id) tuples, or all-gathered sketch rows")
     args = ap.parse_args()
+
+    pre_tsweep = None
+    _full = int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.reads == 100000 and args.depth == 20.0 and args.genome == "iid" and args.mean_len == 8000.0
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and (args.threads_sweep if args.threads_sweep >= 0 else int(_full)):
+        pre_tsweep = threads_sweep(args)
 
     import torch
     import nanospring_amd as ns
@@ -435,24 +463,9 @@ def main():
             del rb, ro
         # what a rank gets of a CPU quota it shares with the other ranks of its node: ONE step with 4 and with 2 host threads (the thread count is
         # read once per process: a child each, this very script without its other legs; the children's first step includes their allocations)
-        tsweep = None
-        want_ts = args.threads_sweep if args.threads_sweep >= 0 else int(full_size)
-        if want_ts and world == 1:
-            import subprocess
-            tsweep = {"note": "one first step per thread count, each in a child process (NSGPU_THREADS), consensus graphs where the library puts them by itself (in HBM with at most 5 host threads); the timed steps above ran with host_threads = %d.  The pointer graph on the host with 2 threads: profiles/r06_graph_placement_by_threads.txt" % a["host_threads"], "runs": []}
-            for nthr in (4, 2):
-                cmd = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--throughput-leg", "0", "--cpu-sample", "0", "--cpu-full", "0", "--legal-leg", "0",
-                       "--nonideal-leg", "0", "--threads-sweep", "0", "--graph-leg", "0", "--cfg3-leg", "0", "--reads", str(args.reads), "--mean-len", str(args.mean_len), "--depth", str(args.depth), "--genome", args.genome]
-                try:
-                    rr = subprocess.run(cmd, env=dict(os.environ, NSGPU_THREADS=str(nthr)), capture_output=True, text=True, timeout=600)
-                    lines = [ln for ln in rr.stdout.splitlines() if ln.startswith("{")]
-                    if not lines: raise RuntimeError("the child printed no result (exit code %d): %s" % (rr.returncode, rr.stderr[-600:]))
-                    cj = json.loads(lines[-1])
-                    tsweep["runs"].append({"host_threads": nthr, "value": cj["value"], "unit": "Mbases/s", "ms_per_step": cj["ms_per_step"], "consensus_graphs": cj["config"]["consensus_graph"]["placement"], "graph_host_wall_ms": cj["config"]["stage_ms_per_step"]["graph_host_wall"],
-                                           "lossless_roundtrip_bad_reads": cj["config"]["lossless_roundtrip_bad_reads"], "streams_identical_to_the_fixture": (cj.get("parity") or {}).get("all_identical")})
-                    if cj["config"]["lossless_roundtrip_bad_reads"] or (cj.get("parity") or {}).get("all_identical") is False: tsweep["runs"][-1]["stderr_tail"] = rr.stderr[-3000:]
-                except Exception as ex:                 # (a leg, not the measurement: report and go on)
-                    tsweep["runs"].append({"host_threads": nthr, "error": str(ex)[:900]})
+        tsweep = pre_tsweep
+        if tsweep is not None:
+            tsweep["note"] = tsweep["note"] % a["host_threads"]
         gstats = ns.graph_stats(g)               # of the last timed step
         # ONE first step with the consensus graphs in the other placement (same schedule, same streams): what the choice costs / buys on this host
         gleg = None
