@@ -170,7 +170,10 @@ int role_stream_create(hipStream_t *st, const char *role)
     std::string var = std::string("NSGPU_PRIO_") + role;
     for (char &ch : var) ch = (char)toupper((unsigned char)ch);
     const char *e = getenv(var.c_str());
-    std::string want = e ? e : (!strcmp(role, "sketch") ? "lo" : !strcmp(role, "seeds") ? "hi" : !strcmp(role, "dp_side") ? "hi" : "mid");
+    // (the runtime pools its hardware queues by priority: streams of different priorities never share one.  The graph streams are kept out of the
+    // pool of the streams the DP results come by: a serve launch holds its queue until the slot's last order, and whatever is enqueued behind it on
+    // the same hardware queue waits that long -- the kernels its orders depend on must never be there.)
+    std::string want = e ? e : (!strcmp(role, "sketch") ? "lo" : !strcmp(role, "seeds") ? "hi" : !strcmp(role, "dp_side") ? "hi" : !strcmp(role, "graph") || !strcmp(role, "graph_copy") ? "lo" : "mid");
     const int prio = want == "lo" ? least : want == "hi" ? greatest : (least + greatest) / 2;
     NS_HIP(hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio));
     return NSGPU_OK;
