@@ -92,7 +92,7 @@ struct Hdr {
     uint32_t st_cyc[6];                               // removeCycles in parts (thread 0's clock): marking, finding the roots, splitPath: looking for stretches / stretches / the rest, the walks
     uint32_t st_tm[8];                                // ticks of the team's clock by phase: tables, runs, excursions, choices, stitching, writing, flags + P/S, removeCycles
     uint32_t st_routes, st_route_ctx;                 // splits by routes (split_routes_run) and the contexts they made
-    uint32_t unreach_n, unreach_list_n, pad_[2];      // n_multi and multi_n as removeCycles left them when it found that NO side node with several ways in can be reached from the path (NIL: not known)
+    uint32_t unreach_n, unreach_list_n, st_unreach_par, pad_;      // n_multi and multi_n as removeCycles left them when it found that NO side node with several ways in can be reached from the path (NIL: not known)
     uint32_t need_nodes, need_edges, need_chunks, st_regrow;     // ERR_ROOM: what the split in front of which removeCycles stopped needs; how often that happened
     uint32_t st_rt[4];                                // ... in parts (thread 0's clock): walking the routes, comparing them, the copies, taking the reads off the old edges + the rest
 };
@@ -595,6 +595,7 @@ template <class T> struct Ops {
         // reached from the path -- the heads of reads that start left of a contig whose front has moved on -- are out of every excursion's way: an
         // excursion starts at a path node and follows edges, or creates what it needs.  removeCycles has said so if nothing has changed since.)
         const bool parallel_exc = (h.n_multi == 0 || (h.n_multi == h.unreach_n && h.multi_n == h.unreach_list_n)) && !(h.dbg_flags & 1u);
+        if (tid == 0 && parallel_exc && h.n_multi) ++h.st_unreach_par;
         const uint32_t nodes_base = h.n_nodes, edges_base = h.n_edges;
         if (parallel_exc) {
             uint32_t tot_n = 0, tot_e = 0;

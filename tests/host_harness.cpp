@@ -305,8 +305,8 @@ struct ShadowGraph {
 };
 template <class GT> struct GraphDbg { static void take(GT &) {} };
 uint64_t g_dbg_calls = 0, g_dbg_skipped = 0, g_dbg_spliced = 0, g_dbg_spliced_nodes = 0;
-uint64_t g_soa_stats[12];
-template <> struct GraphDbg<SoaGraph> { static void take(SoaGraph &g) { const nsgpu::dg::Hdr &h = g.store().hdr; g_soa_stats[0] += h.st_splits, g_soa_stats[1] += h.st_detours, g_soa_stats[2] += h.st_walked, g_soa_stats[3] += h.st_seq_exc, g_soa_stats[4] += h.st_cycles_run, g_soa_stats[5] += h.st_full_walk, g_soa_stats[6] += h.st_dis, g_soa_stats[7] += h.n_nodes - h.live_nodes, g_soa_stats[8] += h.st_routes, g_soa_stats[9] += h.st_route_ctx, g_soa_stats[10] += h.st_ctx, g_soa_stats[11] += h.st_regrow; } };
+uint64_t g_soa_stats[16];
+template <> struct GraphDbg<SoaGraph> { static void take(SoaGraph &g) { const nsgpu::dg::Hdr &h = g.store().hdr; g_soa_stats[0] += h.st_splits, g_soa_stats[1] += h.st_detours, g_soa_stats[2] += h.st_walked, g_soa_stats[3] += h.st_seq_exc, g_soa_stats[4] += h.st_cycles_run, g_soa_stats[5] += h.st_full_walk, g_soa_stats[6] += h.st_dis, g_soa_stats[7] += h.n_nodes - h.live_nodes, g_soa_stats[8] += h.st_routes, g_soa_stats[9] += h.st_route_ctx, g_soa_stats[10] += h.st_ctx, g_soa_stats[11] += h.st_regrow, g_soa_stats[12] += h.st_unreach_par; } };
 extern "C" uint64_t harness_soa_stat(int i) { return g_soa_stats[i]; }
 template <> struct GraphDbg<ShadowGraph> { static void take(ShadowGraph &g) { GraphDbg<SoaGraph>::take(g.b); } };
 template <> struct GraphDbg<ContigGraph> { static void take(ContigGraph &g) { g_dbg_calls += g.dbg_cycles_calls; g_dbg_skipped += g.dbg_cycles_skipped; g_dbg_spliced += g.dbg_spliced; g_dbg_spliced_nodes += g.dbg_spliced_nodes; } };

@@ -52,7 +52,7 @@ for k in sorted(out):
     h.update(out[k])
 print("HASH", h.hexdigest(), st["count_aligner"], st["n_contigs"])
 _hl = host_lib.lib(); _hl.harness_soa_stat.restype = __import__("ctypes").c_uint64
-print("SOASTAT", *[int(_hl.harness_soa_stat(i)) for i in range(12)])      # (the structure-of-arrays graph's counters, when it ran: tests/test_soa_graph.py)
+print("SOASTAT", *[int(_hl.harness_soa_stat(i)) for i in range(13)])      # (the structure-of-arrays graph's counters, when it ran: tests/test_soa_graph.py)
 if len(sys.argv) > 3 and oracle_lib.mm2ref() is not None:    # the independent oracle (oracle/consensus_oracle.cpp) on the same reads
     want, wst = oracle_lib.cons_oracle_run(bases, off, ns.mt19937_64_salts(60), checks=False)
     h = hashlib.sha256()
